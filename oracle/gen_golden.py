@@ -1,0 +1,186 @@
+"""Golden-vector generator: runs the UPSTREAM REFERENCE (imported from /root/reference through
+oracle/_refimport.py) on small seeded inputs and records inputs + reference outputs under
+tests/golden/*.npz.  Container-only script; the fixtures (data only) are what is committed and what
+travels to the GPU box.  Re-run with:  python oracle/gen_golden.py
+
+Fixture families:
+  terrain_T1_*   default_rng(42).normal((20,20)) f32/f64 with NaN/Inf holes x fits x curvature methods x res
+  terrain_T2_*   cumulative-sum "terrain-like" 64x64 f32 near 1000 m (precision stress), full attribute
+                 set incl. TPI/TRI (Riley + Wilson), degrees on/off, two hillshade settings
+  terrain_T3     reference's data-free known-answer DEMs (test_surfit.py:228-411, terrain.py doctests)
+  terrain_T4     int32 DEM -> float32 outputs
+  terrain_T5     window sizes 3/5/7 for TPI/TRI
+  nk_T5_*        Nuth-Kaab bin-fit cases (aspect binning, nanmedian per bin, curve_fit) + aux gradient (T8)
+  nk_T6          _iterate_method stop-rule trace
+  vario_T7       _choose_cdist_equidistant_sampling_parameters table + default bin edges
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+ref = _refimport.load()
+
+SURF = ["slope", "aspect", "hillshade", "curvature", "profile_curvature", "tangential_curvature",
+        "planform_curvature", "flowline_curvature", "max_curvature", "min_curvature"]
+SAH = ["slope", "aspect", "hillshade"]
+WIN = ["topographic_position_index", "terrain_ruggedness_index"]
+
+
+def _check_tables() -> None:
+    """The oracle's generated stencil tables must equal the reference's tabulated ones."""
+    import terrain_oracle as to
+
+    m = {"horn": {"zx": "h2", "zy": "h1"},
+         "zevenbergthorne": {"zx": "zt_h", "zy": "zt_g", "zxx": "zt_e", "zyy": "zt_d", "zxy": "zt_f"},
+         "florinsky": {"zx": "fl_p", "zy": "fl_q", "zxx": "fl_r", "zyy": "fl_t", "zxy": "fl_s"}}
+    for fit, names in m.items():
+        ks = to.conv_kernels(fit)
+        for n, refname in names.items():
+            tab, (const, power) = ks[n]
+            assert np.array_equal(tab, ref.surfit.all_coefs[refname]), (fit, n)
+            for r in (1.0, 2.0, 10.0, 0.3):
+                assert const * r**power == ref.surfit._divider_method_coef(r, refname), (fit, n, r)
+    print("stencil tables == reference tables")
+
+
+def run_ref(dem, attrs, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = ref.terrain.get_terrain_attribute(dem, attrs, **kw)
+    return out if isinstance(out, list) else [out]
+
+
+def terrain_T1() -> None:
+    rng = np.random.default_rng(42)
+    base = rng.normal(size=(20, 20))
+    for dt in (np.float32, np.float64):
+        for hole in ("nan", "inf"):
+            dem = base.astype(dt)
+            dem[4, 4:6] = np.nan
+            dem[17, 16] = np.nan if hole == "nan" else np.inf
+            if hole == "inf":
+                dem[10, 2] = -np.inf
+            rec = {"dem": dem}
+            for fit in ("Horn", "ZevenbergThorne", "Florinsky"):
+                for cm in ("geometric", "directional"):
+                    for res in (1.0, 2.0, 10.0):
+                        attrs = SAH if fit == "Horn" else SURF
+                        if fit == "Horn" and cm == "directional":
+                            continue
+                        outs = run_ref(dem, attrs, resolution=res, surface_fit=fit, curv_method=cm)
+                        for a, o in zip(attrs, outs):
+                            rec[f"{fit}|{cm}|{res}|{a}"] = o
+            np.savez_compressed(os.path.join(OUT, f"terrain_T1_{np.dtype(dt).name}_{hole}.npz"), **rec)
+
+
+def terrain_T2() -> None:
+    rng = np.random.default_rng(7)
+    dem = (1000.0 + np.cumsum(np.cumsum(rng.normal(scale=0.05, size=(64, 64)), axis=0), axis=1)).astype(np.float32)
+    dem[30:33, 40] = np.nan
+    rec = {"dem": dem}
+    full = [a for a in SURF if a != "curvature"] + WIN
+    for fit in ("ZevenbergThorne", "Florinsky"):
+        for cm in ("geometric", "directional"):
+            for deg in (True, False):
+                for (az, alt, zf) in ((315.0, 45.0, 1.0), (90.0, 10.0, 10.0)):
+                    for tri in ("Riley", "Wilson"):
+                        if tri == "Wilson" and not (deg and zf == 1.0):
+                            continue
+                        outs = run_ref(dem, full, resolution=10.0, surface_fit=fit, curv_method=cm, degrees=deg,
+                                       hillshade_azimuth=az, hillshade_altitude=alt, hillshade_z_factor=zf,
+                                       tri_method=tri)
+                        for a, o in zip(full, outs):
+                            rec[f"{fit}|{cm}|{int(deg)}|{az}|{alt}|{zf}|{tri}|{a}"] = o
+    outs = run_ref(dem, SAH, resolution=10.0, surface_fit="Horn")
+    for a, o in zip(SAH, outs):
+        rec[f"Horn|geometric|1|315.0|45.0|1.0|Riley|{a}"] = o
+    np.savez_compressed(os.path.join(OUT, "terrain_T2_f32.npz"), **rec)
+
+
+def terrain_T3() -> None:
+    """Known-answer DEMs of the reference's own data-free tests, with the reference outputs on them."""
+    rec = {}
+    dems = {}
+    dems["flat"] = np.ones((5, 5), dtype=np.float32)
+    dems["ramp_x"] = np.stack([np.ones(5) * i for i in range(5)], axis=1)
+    dems["ramp_y"] = np.stack([np.ones(5) * i for i in range(5)], axis=0)
+    dems["ramp_xy"] = np.stack([np.arange(0, 5) + i for i in range(5)], axis=1)
+    dems["ramp_yx"] = np.stack([np.flip(np.arange(0, 5)) + i for i in range(5)], axis=1)
+    dems["v_y_convex_t"] = np.stack([np.array([2, 1, 0, 1, 2]) + i for i in range(5)], axis=0)
+    dems["v_x_convex_t"] = np.stack([np.array([2, 1, 0, 1, 2]) + i for i in range(5)], axis=1)
+    dems["v_y_concave_t"] = np.stack([np.array([0, 1, 2, 1, 0]) + i for i in range(5)], axis=0)
+    dems["v_x_concave_t"] = np.stack([np.array([0, 1, 2, 1, 0]) + i for i in range(5)], axis=1)
+    dems["v_y_convex_s"] = np.stack([np.array([2, 1, 0, 1, 2]) + np.linspace(0, 1, 5) for i in range(5)], axis=0)
+    dems["v_x_convex_s"] = np.stack([np.array([2, 1, 0, 1, 2]) + np.linspace(0, 1, 5) for i in range(5)], axis=1)
+    dems["v_y_concave_s"] = np.stack([np.array([0, 1, 2, 1, 0]) + np.arange(0, 5) for i in range(5)], axis=0)
+    dems["v_x_concave_s"] = np.stack([np.array([0, 1, 2, 1, 0]) + np.arange(0, 5) for i in range(5)], axis=1)
+    x = np.linspace(-1, 1, 5)
+    X, Y = np.meshgrid(x, x)
+    dems["saddle"] = X**2 - Y**2
+    dems["ridge"] = 0.6 * X + 1.0 * np.exp(-(Y**2))
+    dems["trough"] = 0.6 * X - 1.0 * np.exp(-(Y**2))
+    dems["doc_south"] = np.repeat(np.arange(3), 3)[::-1].reshape(3, 3)  # terrain.py:269-278
+    dems["doc_north"] = np.repeat(np.arange(3), 3).reshape(3, 3)  # terrain.py:717-724
+    dems["doc_east"] = np.tile(np.arange(3), (3, 1))  # terrain.py:800-814 (values increasing eastward)
+    curvs = [a for a in SURF if a != "curvature"]
+    for name, dem in dems.items():
+        rec[f"dem|{name}"] = dem
+        for fit in ("ZevenbergThorne", "Florinsky"):
+            if dem.shape[0] < 5 and fit == "Florinsky":
+                continue
+            for res in (1.0, 5.0, 10.0):
+                outs = run_ref(dem, curvs, resolution=res, surface_fit=fit)
+                for a, o in zip(curvs, outs):
+                    rec[f"{name}|{fit}|{res}|{a}"] = o
+    np.savez_compressed(os.path.join(OUT, "terrain_T3_known_answers.npz"), **rec)
+
+
+def terrain_T4_T5() -> None:
+    rng = np.random.default_rng(3)
+    dem_i = rng.integers(0, 500, size=(24, 31)).astype(np.int32)
+    rec = {"dem": dem_i}
+    full = [a for a in SURF if a != "curvature"] + WIN
+    outs = run_ref(dem_i, full, resolution=5.0)
+    for a, o in zip(full, outs):
+        rec[a] = o
+    np.savez_compressed(os.path.join(OUT, "terrain_T4_int32.npz"), **rec)
+
+    dem = rng.normal(loc=50.0, scale=3.0, size=(33, 29)).astype(np.float32)
+    dem[12, 20] = np.nan
+    rec = {"dem": dem, "dem64": dem.astype(np.float64) + rng.normal(scale=1e-9, size=dem.shape)}
+    for w in (3, 5, 7):
+        for tri in ("Riley", "Wilson"):
+            for key in ("dem", "dem64"):
+                outs = run_ref(rec[key], WIN, window_size=w, tri_method=tri)
+                for a, o in zip(WIN, outs):
+                    rec[f"{key}|{w}|{tri}|{a}"] = o
+    np.savez_compressed(os.path.join(OUT, "terrain_T5_windows.npz"), **rec)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["terrain", "nk", "vario"]
+    if "terrain" in which:
+        _check_tables()
+        terrain_T1()
+        terrain_T2()
+        terrain_T3()
+        terrain_T4_T5()
+        print("terrain fixtures written")
+    if "nk" in which:
+        import gen_golden_nk
+
+        gen_golden_nk.main(ref, OUT)
+    if "vario" in which:
+        import gen_golden_vario
+
+        gen_golden_vario.main(ref, OUT)

@@ -1,0 +1,99 @@
+"""Pins the CPU oracle (oracle/terrain_oracle.py) against golden vectors recorded from the reference itself
+(oracle/gen_golden.py -> tests/golden/terrain_*.npz).  Bar: BIT-EXACT, NaN positions included."""
+import os
+
+import numpy as np
+import pytest
+
+import terrain_oracle as to
+
+from conftest import GOLDEN
+
+
+def _same(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.mark.parametrize("fname", ["terrain_T1_float32_nan.npz", "terrain_T1_float32_inf.npz",
+                                   "terrain_T1_float64_nan.npz", "terrain_T1_float64_inf.npz"])
+def test_T1_random_with_holes(fname):
+    z = _load(fname)
+    dem = z["dem"]
+    n = 0
+    for key in z.files:
+        if key == "dem":
+            continue
+        fit, cm, res, attr = key.split("|")
+        got = to.terrain_attributes(dem, [attr], resolution=float(res), surface_fit=fit, curv_method=cm)[0]
+        assert _same(got, z[key]), key
+        n += 1
+    assert n > 50
+
+
+def test_T2_terrain_like_full_set():
+    z = _load("terrain_T2_f32.npz")
+    dem = z["dem"]
+    groups = {}
+    for key in z.files:
+        if key == "dem":
+            continue
+        *cfg, attr = key.split("|")
+        groups.setdefault(tuple(cfg), []).append(attr)
+    assert len(groups) > 10
+    for cfg, attrs in groups.items():
+        fit, cm, deg, az, alt, zf, tri = cfg
+        got = to.terrain_attributes(dem, attrs, resolution=10.0, degrees=bool(int(deg)), hillshade_azimuth=float(az),
+                                    hillshade_altitude=float(alt), hillshade_z_factor=float(zf), surface_fit=fit,
+                                    curv_method=cm, tri_method=tri)
+        for a, g in zip(attrs, got):
+            assert _same(g, z["|".join(cfg) + "|" + a]), (cfg, a)
+
+
+def test_T3_known_answer_dems():
+    z = _load("terrain_T3_known_answers.npz")
+    n = 0
+    for key in z.files:
+        if key.startswith("dem|"):
+            continue
+        name, fit, res, attr = key.split("|")
+        got = to.terrain_attributes(z["dem|" + name], [attr], resolution=float(res), surface_fit=fit)[0]
+        assert _same(got, z[key]), key
+        n += 1
+    assert n > 100
+
+
+def test_T4_int32_input():
+    z = _load("terrain_T4_int32.npz")
+    attrs = [k for k in z.files if k != "dem"]
+    got = to.terrain_attributes(z["dem"], attrs, resolution=5.0)
+    for a, g in zip(attrs, got):
+        assert g.dtype == np.float32
+        assert _same(g, z[a]), a
+
+
+def test_T5_window_sizes():
+    z = _load("terrain_T5_windows.npz")
+    for key in z.files:
+        if "|" not in key:
+            continue
+        src, w, tri, attr = key.split("|")
+        got = to.terrain_attributes(z[src], [attr], window_size=int(w), tri_method=tri)[0]
+        assert _same(got, z[key]), key
+
+
+def test_oracle_convolution_equals_scipy():
+    """The restated convolution must reproduce scipy.ndimage.convolve (the reference's engine call) bit for bit."""
+    scipy_ndimage = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(0)
+    dem = (1000 + rng.normal(size=(40, 37)).cumsum(axis=0)).astype(np.float32)
+    dem[5, 5] = np.nan
+    for fit in ("horn", "zevenbergthorne", "florinsky"):
+        for name, (tab, (const, power)) in to.conv_kernels(fit).items():
+            k = tab.astype(np.float64) / (const * 3.0**power)
+            want = scipy_ndimage.convolve(dem, k, mode="constant", cval=np.nan)
+            got = to._convolve_nan_const(dem, k)
+            assert _same(got, want), (fit, name)
