@@ -1,0 +1,97 @@
+/* xdemhip.h -- C-ABI of libxdemhip.so: MI355X (gfx950) kernels for xDEM's three dense-array hot paths.
+ *
+ * The reference (GlacioHack/xdem) has no FFI: its operator boundary for these paths is a set of private
+ * Python engine functions that take plain ndarrays.  Every entry point below cites
+ * the reference function it stands in for; the ctypes binding a maintainer would add is in INTEGRATION.md
+ * and is what xdem_amd/_lib.py implements.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative XDEMHIP_E* code; nothing throws; the text of the
+ *    last error of a context is available through xdemhip_last_error();
+ *  - the caller owns every buffer; the library owns only the opaque context (one per GPU / per process);
+ *  - `memspace` says where the caller's buffers live: XDEMHIP_HOST (the library stages H2D/D2H itself) or
+ *    XDEMHIP_DEVICE (raw device pointers, e.g. torch tensors' data_ptr(); work is enqueued on the context
+ *    stream and the call returns without synchronising);
+ *  - rasters are row-major, element (row, col) at base[row * row_stride + col]; all sizes are 64-bit.
+ */
+#ifndef XDEMHIP_H
+#define XDEMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xdemhip_ctx xdemhip_ctx;
+
+enum { XDEMHIP_OK = 0, XDEMHIP_EINVAL = -1, XDEMHIP_ENODEV = -2, XDEMHIP_EHIP = -3, XDEMHIP_ENOMEM = -4,
+       XDEMHIP_EUNSUPPORTED = -5 };
+enum { XDEMHIP_F32 = 0, XDEMHIP_F64 = 1 };
+enum { XDEMHIP_HOST = 0, XDEMHIP_DEVICE = 1 };
+
+/* surface_fit ids: xdem/terrain/surfit.py:1240 ; curvature method ids: surfit.py:1244 ; TRI: window.py:964 */
+enum { XDEMHIP_FIT_HORN = 0, XDEMHIP_FIT_ZEVENBERGTHORNE = 1, XDEMHIP_FIT_FLORINSKY = 2 };
+enum { XDEMHIP_CURV_GEOMETRIC = 0, XDEMHIP_CURV_DIRECTIONAL = 1 };
+enum { XDEMHIP_TRI_RILEY = 0, XDEMHIP_TRI_WILSON = 1 };
+
+/* Attribute bits.  Bits 0-9 follow the reference's fixed attribute order (surfit.py:407-418), bits 10-11
+ * are the two windowed indexes of window.py:752-758 that are on the hot path. */
+enum {
+    XDEMHIP_ATTR_SLOPE = 1u << 0,
+    XDEMHIP_ATTR_ASPECT = 1u << 1,
+    XDEMHIP_ATTR_HILLSHADE = 1u << 2,
+    XDEMHIP_ATTR_CURVATURE = 1u << 3,
+    XDEMHIP_ATTR_PROFILE_CURVATURE = 1u << 4,
+    XDEMHIP_ATTR_TANGENTIAL_CURVATURE = 1u << 5,
+    XDEMHIP_ATTR_PLANFORM_CURVATURE = 1u << 6,
+    XDEMHIP_ATTR_FLOWLINE_CURVATURE = 1u << 7,
+    XDEMHIP_ATTR_MAX_CURVATURE = 1u << 8,
+    XDEMHIP_ATTR_MIN_CURVATURE = 1u << 9,
+    XDEMHIP_ATTR_TPI = 1u << 10,
+    XDEMHIP_ATTR_TRI = 1u << 11,
+    XDEMHIP_ATTR_COUNT = 12
+};
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int xdemhip_version(void);
+/* One context per process and GPU (the multi-GPU layer is one process per GPU, torch.distributed/RCCL). */
+int xdemhip_create(int device_id, xdemhip_ctx** out_ctx);
+void xdemhip_destroy(xdemhip_ctx* ctx);
+const char* xdemhip_last_error(const xdemhip_ctx* ctx);
+/* Use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream);
+int xdemhip_synchronize(xdemhip_ctx* ctx);
+/* Timing of the work enqueued by the last call on the context stream, measured with hipEvents recorded on
+ * that stream around the kernel launch(es); returns milliseconds in *ms (synchronises the stop event). */
+int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
+
+/* ---- path 1: terrain stencil engine --------------------------------------------------------------
+ * Replaces  _get_surface_attributes(dem, resolution, surface_attributes, out_dtype, surface_fit,
+ *           curv_method, engine, hillshade_*)                       xdem/terrain/surfit.py:1197-1305
+ *      and  _get_windowed_indexes(dem, window_size, windowed_indexes, resolution, out_dtype, tri_method,
+ *           engine) for TPI / TRI                                   xdem/terrain/window.py:926-1002
+ *      plus the unit conversion / clip of _get_terrain_attribute     xdem/terrain/terrain.py:586-596
+ * in ONE fused pass: one DEM read, one write per requested attribute.
+ *
+ *  dem          first row of the buffer.  Output row r (0 <= r < H) is buffer row (halo_top + r); the
+ *               buffer holds halo_top + H + halo_bottom rows.  Halo rows are neighbour data of a
+ *               row-block partition (multi-GPU); rows beyond them count as outside the raster (NaN), as
+ *               do columns outside [0, W).  Single raster: halo_top = halo_bottom = 0.
+ *  attr_mask    OR of XDEMHIP_ATTR_*; out_planes[k] receives the k-th SET bit in ascending bit order,
+ *               each an (H, W) plane with row stride W in out_dtype.
+ *  degrees      non-zero: slope / aspect in degrees (terrain.py:586-591), else radians.
+ *  window_size  odd window of TPI / TRI (reference default 3).
+ * NaN / +-Inf in the DEM are nodata: an output pixel is NaN iff its full window (3x3 Horn/ZT, 5x5
+ * Florinsky; window_size for TPI/TRI) holds a non-finite value or leaves the raster (surfit.py:1185-1192).
+ */
+int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H, int64_t W, int64_t row_stride,
+                    int64_t halo_top, int64_t halo_bottom, double resolution, int surface_fit, int curv_method,
+                    uint32_t attr_mask, int tri_method, int window_size, double hillshade_altitude_deg,
+                    double hillshade_azimuth_deg, double hillshade_z_factor, int degrees, int out_dtype,
+                    void* const* out_planes, int memspace);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XDEMHIP_H */

@@ -1,0 +1,72 @@
+// Host-compiled numerics harness for xdem_amd/csrc/terrain_math.h (TEST INFRASTRUCTURE ONLY).
+// Emulates what one workgroup of terrain.hip does -- stage a NaN-padded tile, march every column -- with
+// the very same march_column<> template the GPU kernel instantiates, so the stencil algebra, the window
+// rotation, the NaN rule and the division-free float64 formulas can be checked against the oracle on a
+// machine without a GPU.  Never linked into libxdemhip.so.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../xdem_amd/csrc/terrain_math.h"
+
+using namespace xd;
+
+template <int FIT, bool CURV, bool WIN, typename TIN, typename TOUT>
+static void run(const TIN* dem, int64_t H, int64_t W, int64_t halo_top, int64_t halo_bottom, int TH,
+                const TerrainParams& P, const Planes<TOUT>& out) {
+    constexpr int HALO = Halo<FIT>::v;
+    const int XPAD = 4, TW = 256, PITCH = TW + 2 * XPAD;
+    std::vector<TIN> tile((size_t)(TH + 2 * HALO) * PITCH);
+    for (int64_t y0 = 0; y0 < H; y0 += TH)
+        for (int64_t x0 = 0; x0 < W; x0 += TW) {
+            const int n_out = (int)std::min<int64_t>(TH, H - y0);
+            for (int r = 0; r < n_out + 2 * HALO; ++r)
+                for (int c = 0; c < PITCH; ++c) {
+                    const int64_t gy = y0 - HALO + r, gx = x0 - XPAD + c;
+                    const bool ok = gy >= -halo_top && gy < H + halo_bottom && gx >= 0 && gx < W;
+                    tile[(size_t)r * PITCH + c] = ok ? dem[(gy + halo_top) * W + gx] : (TIN)NAN;
+                }
+            for (int t = 0; t < TW && x0 + t < W; ++t)
+                march_column<FIT, CURV, WIN, TIN, TOUT>(tile.data() + XPAD + t, PITCH, n_out, P, out, y0 * W + x0 + t, W);
+        }
+}
+
+template <typename TIN, typename TOUT>
+static int go(const void* dem, int64_t H, int64_t W, int64_t ht, int64_t hb, int TH, int fit, const TerrainParams& P,
+              void* const* planes) {
+    Planes<TOUT> out;
+    for (int k = 0; k < N_ATTR; ++k) out.p[k] = static_cast<TOUT*>(planes[k]);
+    const TIN* d = static_cast<const TIN*>(dem);
+    const bool curv = (P.mask & A_ANY_CURV) != 0, win = (P.mask & A_ANY_WIN) != 0;
+#define GO(F, C, Wn) run<F, C, Wn, TIN, TOUT>(d, H, W, ht, hb, TH, P, out)
+    if (fit == 0) { if (win) GO(0, false, true); else GO(0, false, false); }
+    else if (fit == 1) { if (curv) { if (win) GO(1, true, true); else GO(1, true, false); } else { if (win) GO(1, false, true); else GO(1, false, false); } }
+    else { if (curv) { if (win) GO(2, true, true); else GO(2, true, false); } else { if (win) GO(2, false, true); else GO(2, false, false); } }
+#undef GO
+    return 0;
+}
+
+extern "C" int hostsim_terrain(const void* dem, int dem_dtype, int64_t H, int64_t W, int64_t halo_top,
+                               int64_t halo_bottom, int tile_rows, double resolution, int fit, int curv_dir,
+                               uint32_t mask, int tri_wilson, double hs_alt, double hs_az, double hs_z, int degrees,
+                               int out_dtype, void* const* planes12) {
+    TerrainParams P;
+    double c1 = 8, cxx = 1, cxy = 4;
+    if (fit == 1) { c1 = 2; }
+    if (fit == 2) { c1 = 420; cxx = 35; cxy = 100; }
+    P.s1 = 1.0 / (c1 * resolution);
+    P.sxx = 1.0 / (cxx * (resolution * resolution));
+    P.sxy = 1.0 / (cxy * (resolution * resolution));
+    const double deg = 0.017453292519943295;
+    const double az = (360.0 - hs_az) * deg, alt = hs_alt * deg;
+    P.hs_sin_alt = sin(alt);
+    P.hs_kx = -cos(alt) * hs_z * cos(az);
+    P.hs_ky = cos(alt) * hs_z * sin(az);
+    P.hs_zf2 = hs_z * hs_z;
+    P.mask = mask; P.curv_directional = curv_dir; P.tri_wilson = tri_wilson; P.degrees = degrees;
+    if (dem_dtype == 0 && out_dtype == 0) return go<float, float>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
+    if (dem_dtype == 1 && out_dtype == 1) return go<double, double>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
+    if (dem_dtype == 0 && out_dtype == 1) return go<float, double>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
+    return go<double, float>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
+}

@@ -1,0 +1,116 @@
+"""ctypes binding of libxdemhip.so (the C-ABI declared in include/xdemhip.h).
+
+There is deliberately NO fallback: if the HIP library has not been built, or no GPU context can be
+created, the package raises -- a silent CPU path would void every parity claim.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libxdemhip.so")
+
+OK = 0
+F32, F64 = 0, 1
+HOST, DEVICE = 0, 1
+
+_lib = None
+_lock = threading.Lock()
+
+
+class XdemHipError(RuntimeError):
+    """Raised for any non-zero status from libxdemhip.so."""
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the shared library with argtypes declared."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise XdemHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). xdem_amd has no CPU fallback."
+            )
+        # torch bundles its own libamdhip64: import it first so that both share one HIP runtime in-process
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for host-buffer use
+            pass
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        c_ctx = ctypes.c_void_p
+        L.xdemhip_version.restype = ctypes.c_int
+        L.xdemhip_create.argtypes = [ctypes.c_int, ctypes.POINTER(c_ctx)]
+        L.xdemhip_destroy.argtypes = [c_ctx]
+        L.xdemhip_destroy.restype = None
+        L.xdemhip_last_error.argtypes = [c_ctx]
+        L.xdemhip_last_error.restype = ctypes.c_char_p
+        L.xdemhip_set_stream.argtypes = [c_ctx, ctypes.c_void_p]
+        L.xdemhip_synchronize.argtypes = [c_ctx]
+        L.xdemhip_last_kernel_ms.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_float)]
+        L.xdemhip_terrain.argtypes = [
+            c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+        ]
+        _lib = L
+        return L
+
+
+class Context:
+    """One libxdemhip context = one GPU of this process."""
+
+    def __init__(self, device: int = 0) -> None:
+        self._L = lib()
+        h = ctypes.c_void_p()
+        rc = self._L.xdemhip_create(int(device), ctypes.byref(h))
+        if rc != OK or not h:
+            raise XdemHipError(
+                f"xdemhip_create(device={device}) failed with status {rc}: no usable MI355X/HIP device "
+                "(xdem_amd has no CPU fallback)"
+            )
+        self.handle = h
+        self.device = int(device)
+
+    def check(self, rc: int) -> None:
+        if rc != OK:
+            msg = self._L.xdemhip_last_error(self.handle)
+            raise XdemHipError(f"libxdemhip status {rc}: {msg.decode() if msg else ''}")
+
+    def set_stream(self, stream_ptr: int | None) -> None:
+        self.check(self._L.xdemhip_set_stream(self.handle, ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self) -> None:
+        self.check(self._L.xdemhip_synchronize(self.handle))
+
+    def last_kernel_ms(self) -> float:
+        ms = ctypes.c_float()
+        self.check(self._L.xdemhip_last_kernel_ms(self.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._L.xdemhip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    """Process-wide context for `device` (default: $XDEM_AMD_DEVICE, else LOCAL_RANK, else 0)."""
+    if device is None:
+        device = int(os.environ.get("XDEM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,159 @@
+// capi.hip -- extern "C" entry points of libxdemhip.so (declared in include/xdemhip.h): context
+// management, argument validation, host<->device staging.  Kernels live in terrain.hip / nuthkaab.hip /
+// variogram.hip.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+#define XDEMHIP_VERSION_NUM 100
+
+extern "C" {
+
+int xdemhip_version(void) { return XDEMHIP_VERSION_NUM; }
+
+int xdemhip_create(int device_id, xdemhip_ctx** out_ctx) {
+    if (!out_ctx) return XDEMHIP_EINVAL;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return XDEMHIP_ENODEV;
+    if (device_id < 0 || device_id >= n) return XDEMHIP_ENODEV;
+    xdemhip_ctx* c = new xdemhip_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; return XDEMHIP_EHIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XDEMHIP_EHIP; }
+    c->stream = c->own_stream;
+    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+        delete c;
+        return XDEMHIP_EHIP;
+    }
+    *out_ctx = c;
+    return XDEMHIP_OK;
+}
+
+void xdemhip_destroy(xdemhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* xdemhip_last_error(const xdemhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_synchronize(xdemhip_ctx* ctx) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
+int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return XDEMHIP_EINVAL;
+    if (!ctx->timed) return xd_fail(ctx, XDEMHIP_EINVAL, "no timed launch on this context yet");
+    XD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_stop));
+    XD_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return XDEMHIP_OK;
+}
+
+static int popcount32(uint32_t v) { return __builtin_popcount(v); }
+
+int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H, int64_t W, int64_t row_stride,
+                    int64_t halo_top, int64_t halo_bottom, double resolution, int surface_fit, int curv_method,
+                    uint32_t attr_mask, int tri_method, int window_size, double hs_alt, double hs_az, double hs_z,
+                    int degrees, int out_dtype, void* const* out_planes, int memspace) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (!dem || !out_planes) return xd_fail(ctx, XDEMHIP_EINVAL, "null buffer");
+    if (H <= 0 || W <= 0 || row_stride < W || halo_top < 0 || halo_bottom < 0)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "bad raster geometry");
+    if ((dem_dtype != XDEMHIP_F32 && dem_dtype != XDEMHIP_F64) || (out_dtype != XDEMHIP_F32 && out_dtype != XDEMHIP_F64))
+        return xd_fail(ctx, XDEMHIP_EINVAL, "dtype must be XDEMHIP_F32 or XDEMHIP_F64");
+    if (surface_fit < 0 || surface_fit > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "unknown surface_fit");
+    if (curv_method < 0 || curv_method > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "unknown curv_method");
+    if (tri_method < 0 || tri_method > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "unknown tri_method");
+    if (attr_mask == 0 || (attr_mask >> XDEMHIP_ATTR_COUNT)) return xd_fail(ctx, XDEMHIP_EINVAL, "bad attr_mask");
+    const uint32_t curv_bits = attr_mask & 0x3f8u;
+    if (surface_fit == XDEMHIP_FIT_HORN && curv_bits)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "'Horn' surface fit cannot be used to calculate curvatures");
+    if ((attr_mask & 0xc00u) && (window_size < 3 || (window_size & 1) == 0 || window_size > 1023))
+        return xd_fail(ctx, XDEMHIP_EINVAL, "window_size must be odd and >= 3");
+    if ((attr_mask & 0x3ffu) && !(resolution > 0.0) ) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
+    if (memspace != XDEMHIP_HOST && memspace != XDEMHIP_DEVICE) return xd_fail(ctx, XDEMHIP_EINVAL, "bad memspace");
+
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int n_planes = popcount32(attr_mask);
+    for (int i = 0; i < n_planes; ++i)
+        if (!out_planes[i]) return xd_fail(ctx, XDEMHIP_EINVAL, "null output plane");
+
+    xd::TerrainLaunch L;
+    memset(&L, 0, sizeof L);
+    L.dem_dtype = dem_dtype; L.out_dtype = out_dtype;
+    L.H = H; L.W = W; L.row_stride = row_stride; L.halo_top = halo_top; L.halo_bottom = halo_bottom;
+    L.resolution = (attr_mask & 0x3ffu) ? resolution : 1.0;
+    L.surface_fit = surface_fit; L.curv_method = curv_method; L.tri_method = tri_method;
+    L.window_size = window_size; L.degrees = degrees; L.attr_mask = attr_mask;
+    L.hs_alt = hs_alt; L.hs_az = hs_az; L.hs_z = hs_z;
+
+    const size_t in_es = dem_dtype == XDEMHIP_F32 ? 4 : 8, out_es = out_dtype == XDEMHIP_F32 ? 4 : 8;
+    const int64_t buf_rows = halo_top + H + halo_bottom;
+
+    if (memspace == XDEMHIP_DEVICE) {
+        L.dem = dem;
+        for (int bit = 0, i = 0; bit < XDEMHIP_ATTR_COUNT; ++bit)
+            if (attr_mask & (1u << bit)) L.planes[bit] = out_planes[i++];
+        XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        int rc = xd::launch_terrain(ctx, L);
+        XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+        ctx->timed = (rc == XDEMHIP_OK);
+        return rc;
+    }
+
+    // Host buffers: stage the whole raster (288 GB of HBM holds a 65536^2 float32 DEM with all planes).
+    void* d_dem = nullptr;
+    std::vector<void*> d_out(n_planes, nullptr);
+    int rc = XDEMHIP_OK;
+    auto cleanup = [&]() {
+        if (d_dem) (void)hipFree(d_dem);
+        for (void* p : d_out)
+            if (p) (void)hipFree(p);
+    };
+    const size_t in_bytes = (size_t)buf_rows * (size_t)W * in_es;
+    const size_t plane_bytes = (size_t)H * (size_t)W * out_es;
+    if (hipMalloc(&d_dem, in_bytes) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(dem) failed"); }
+    for (int i = 0; i < n_planes; ++i)
+        if (hipMalloc(&d_out[i], plane_bytes) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(plane) failed"); }
+    hipError_t e = hipMemcpy2DAsync(d_dem, (size_t)W * in_es, dem, (size_t)row_stride * in_es, (size_t)W * in_es,
+                                    (size_t)buf_rows, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, std::string("H2D copy failed: ") + hipGetErrorString(e)); }
+    L.dem = d_dem;
+    L.row_stride = W;
+    for (int bit = 0, i = 0; bit < XDEMHIP_ATTR_COUNT; ++bit)
+        if (attr_mask & (1u << bit)) L.planes[bit] = d_out[i++];
+    (void)hipEventRecord(ctx->ev_start, ctx->stream);
+    rc = xd::launch_terrain(ctx, L);
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+    ctx->timed = (rc == XDEMHIP_OK);
+    if (rc == XDEMHIP_OK) {
+        for (int i = 0; i < n_planes && rc == XDEMHIP_OK; ++i) {
+            e = hipMemcpyAsync(out_planes[i], d_out[i], plane_bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("D2H copy failed: ") + hipGetErrorString(e));
+        }
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess && rc == XDEMHIP_OK) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("kernel failed: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

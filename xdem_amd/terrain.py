@@ -1,0 +1,325 @@
+"""Terrain attributes on MI355X -- host-side mirror of ``xdem.terrain`` for the stencil hot path.
+
+Same call signatures, argument meaning, return-type rules and error messages as the reference
+(``xdem/terrain/terrain.py:176-485`` ``get_terrain_attribute`` and its thin wrappers 693-1571), but the
+engines behind it are the fused HIP kernel of ``csrc/terrain.hip`` reached through the C-ABI
+(``include/xdemhip.h``: ``xdemhip_terrain``).  There is no CPU engine in this package.
+
+Covered attributes (the hot path named in BASELINE.json): slope, aspect, hillshade, curvature
+(deprecated), profile / tangential / planform / flowline / max / min curvature, topographic position
+index, terrain ruggedness index.  ``roughness``, ``rugosity``, ``fractal_roughness`` and
+``texture_shading`` are outside that path and raise ``NotImplementedError`` here.
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+from collections.abc import Sized
+from typing import Any
+
+import numpy as np
+
+from . import _lib
+
+# Attribute families as in xdem/terrain/terrain.py:40-84
+available_attributes = [
+    "slope", "aspect", "hillshade", "profile_curvature", "tangential_curvature", "planform_curvature",
+    "flowline_curvature", "max_curvature", "min_curvature", "topographic_position_index",
+    "terrain_ruggedness_index", "roughness", "rugosity", "fractal_roughness", "texture_shading",
+]
+list_requiring_surface_fit = [
+    "slope", "aspect", "hillshade", "curvature", "profile_curvature", "tangential_curvature",
+    "planform_curvature", "flowline_curvature", "max_curvature", "min_curvature",
+]
+list_requiring_windowed_index = ["terrain_ruggedness_index", "topographic_position_index", "roughness", "rugosity"]
+list_requiring_windowed_fractal_index = ["fractal_roughness"]
+list_requiring_frequency_domain = ["texture_shading"]
+
+# attribute -> bit of the C-ABI mask (include/xdemhip.h)
+ATTR_BIT = {
+    "slope": 0, "aspect": 1, "hillshade": 2, "curvature": 3, "profile_curvature": 4, "tangential_curvature": 5,
+    "planform_curvature": 6, "flowline_curvature": 7, "max_curvature": 8, "min_curvature": 9,
+    "topographic_position_index": 10, "terrain_ruggedness_index": 11,
+}
+_NOT_ON_HOT_PATH = ("roughness", "rugosity", "fractal_roughness", "texture_shading")
+_FIT_ID = {"horn": 0, "zevenbergthorne": 1, "florinsky": 2}
+_CURV_ID = {"geometric": 0, "directional": 1}
+_TRI_ID = {"riley": 0, "wilson": 1}
+
+
+def _is_raster(obj: Any) -> bool:
+    """Duck-typed geoutils.Raster (the package is not a dependency): has .data, .res, .transform, .crs."""
+    return all(hasattr(obj, a) for a in ("data", "res", "transform", "crs")) and not isinstance(obj, np.ndarray)
+
+
+def _array_with_nan(dem: Any) -> np.ndarray:
+    """Equivalent of ``gu.raster.get_array_and_mask(dem)[0]`` (terrain.py:558): masked / nodata -> NaN."""
+    if _is_raster(dem):
+        dem = dem.data
+    if isinstance(dem, np.ma.MaskedArray):
+        arr = np.array(dem.data, copy=True)
+        mask = np.ma.getmaskarray(dem)
+        if np.issubdtype(arr.dtype, np.integer):
+            arr = arr.astype(np.float32)
+        if mask.any():
+            arr[mask] = np.nan
+        return arr
+    return np.asarray(dem)
+
+
+def _validate(dem, attribute, resolution, hillshade_altitude, hillshade_azimuth, hillshade_z_factor, surface_fit,
+              curv_method, tri_method, window_size_fractal):
+    """Input checks of xdem/terrain/terrain.py:293-409 with the reference's messages."""
+    if surface_fit == "Horn":
+        curvature_list = ["curvature", "profile_curvature", "tangential_curvature", "planform_curvature",
+                          "flowline_curvature", "max_curvature", "min_curvature"]
+        found = attribute in curvature_list if isinstance(attribute, str) else any(a in curvature_list for a in attribute)
+        if found:
+            raise ValueError(
+                "'Horn' surface fit method cannot be used for to calculate curvatures. "
+                "Use 'ZevenbergThorne' or 'Florinsky' instead."
+            )
+    if _is_raster(dem) and resolution is None:
+        resolution = dem.res
+    if isinstance(attribute, str):
+        attribute = [attribute]
+    attributes_requiring_surface_fit = [a for a in attribute if a in list_requiring_surface_fit]
+    if "fractal_roughness" in attribute:
+        if window_size_fractal < 5:
+            warnings.warn(category=UserWarning, stacklevel=3,
+                          message="Fractal roughness can only be computed on window sizes larger or equal to 5.")
+        elif window_size_fractal < 13:
+            warnings.warn(category=UserWarning, stacklevel=3,
+                          message="Fractal roughness results with window size of less than 13 can be inaccurate.")
+    attributes_requiring_resolution = attributes_requiring_surface_fit + (["rugosity"] if "rugosity" in attribute else [])
+    if len(attributes_requiring_resolution) > 0:
+        if resolution is None:
+            raise ValueError(
+                f"'resolution' must be provided as an argument for attributes: {attributes_requiring_resolution}"
+            )
+        if not isinstance(resolution, Sized):
+            resolution = (float(resolution), float(resolution))
+        if resolution[0] != resolution[1]:
+            raise ValueError(
+                f"Surface fit and rugosity require the same X and Y resolution ({resolution} was given). "
+                f"This was required by: {attributes_requiring_resolution}."
+            )
+    if resolution is None:
+        resolution = 1
+    elif isinstance(resolution, Sized):
+        resolution = resolution[0]
+    choices = (list_requiring_surface_fit + list_requiring_windowed_index + list_requiring_windowed_fractal_index
+               + list_requiring_frequency_domain)
+    for attr in attribute:
+        if attr not in choices:
+            raise ValueError(f"Attribute '{attr}' is not supported. Choices: {choices}")
+    list_surface_fit = ["Horn", "ZevenbergThorne", "Florinsky"]
+    if surface_fit.lower() not in [sm.lower() for sm in list_surface_fit]:
+        raise ValueError(f"Surface fit '{surface_fit}' is not supported. Must be one of: {list_surface_fit}")
+    list_curv_methods = ["geometric", "directional"]
+    if curv_method.lower() not in [cm.lower() for cm in list_curv_methods]:
+        raise ValueError(f"Curvature method '{curv_method}' is not supported. Must be one of: {list_curv_methods}")
+    list_tri_methods = ["Riley", "Wilson"]
+    if tri_method.lower() not in [tm.lower() for tm in list_tri_methods]:
+        raise ValueError(f"TRI method '{tri_method}' is not supported. Must be one of: {list_tri_methods}")
+    if (hillshade_azimuth < 0.0) or (hillshade_azimuth > 360.0):
+        raise ValueError(f"Azimuth must be a value between 0 and 360 degrees (given value: {hillshade_azimuth})")
+    if (hillshade_altitude < 0.0) or (hillshade_altitude > 90):
+        raise ValueError("Altitude must be a value between 0 and 90 degrees (given value: {altitude})")
+    if (hillshade_z_factor < 0.0) or not np.isfinite(hillshade_z_factor):
+        raise ValueError(f"z_factor must be a non-negative finite value (given value: {hillshade_z_factor})")
+    if _is_raster(dem) and len(attributes_requiring_surface_fit) > 0:
+        crs = getattr(dem, "crs", None)
+        if crs is not None and not getattr(crs, "is_projected", True):
+            warnings.warn(
+                category=UserWarning,
+                message=f"DEM is not in a projected CRS, the following surface fit attributes might be "
+                f"wrong: {list_requiring_surface_fit}."
+                f"Use DEM.reproject(crs=DEM.get_metric_crs()) to reproject in a projected CRS.",
+            )
+    for attr in attribute:
+        if attr in _NOT_ON_HOT_PATH:
+            raise NotImplementedError(
+                f"Attribute '{attr}' is not on the MI355X hot path of xdem_amd (slope, aspect, hillshade, curvatures, "
+                "TPI, TRI); see SURVEY.md section 8f."
+            )
+    return attribute, resolution
+
+
+def launch_terrain(ctx: _lib.Context, dem_ptr: int, dem_dtype, H: int, W: int, row_stride: int, halo_top: int,
+                   halo_bottom: int, resolution: float, surface_fit: str, curv_method: str, attribute: list[str],
+                   tri_method: str, window_size: int, hillshade_altitude: float, hillshade_azimuth: float,
+                   hillshade_z_factor: float, degrees: bool, out_dtype, plane_ptrs: dict[str, int], memspace: int) -> None:
+    """Thin marshalling of one ``xdemhip_terrain`` call (planes are passed in ascending attribute-bit order)."""
+    mask = 0
+    for a in attribute:
+        mask |= 1 << ATTR_BIT[a]
+    ordered = sorted(set(attribute), key=lambda a: ATTR_BIT[a])
+    planes = (ctypes.c_void_p * len(ordered))(*[plane_ptrs[a] for a in ordered])
+    ctx.check(ctx._L.xdemhip_terrain(
+        ctx.handle, ctypes.c_void_p(dem_ptr), _lib.F32 if np.dtype(dem_dtype) == np.float32 else _lib.F64, H, W,
+        row_stride, halo_top, halo_bottom, float(resolution), _FIT_ID[surface_fit.lower()],
+        _CURV_ID[curv_method.lower()], mask, _TRI_ID[tri_method.lower()], int(window_size), float(hillshade_altitude),
+        float(hillshade_azimuth), float(hillshade_z_factor), int(bool(degrees)),
+        _lib.F32 if np.dtype(out_dtype) == np.float32 else _lib.F64, planes, memspace))
+
+
+def get_terrain_attribute(
+    dem,
+    attribute,
+    resolution=None,
+    degrees: bool = True,
+    hillshade_altitude: float = 45.0,
+    hillshade_azimuth: float = 315.0,
+    hillshade_z_factor: float = 1.0,
+    slope_method=None,
+    surface_fit: str = "Florinsky",
+    curv_method: str = "geometric",
+    tri_method: str = "Riley",
+    window_size: int = 3,
+    window_size_fractal: int = 13,
+    engine: str = "hip",
+    texture_alpha: float = 0.8,
+    out_dtype=None,
+    mp_config=None,
+):
+    """Derive one or multiple terrain attributes from a DEM on the GPU.
+
+    Drop-in for ``xdem.terrain.get_terrain_attribute`` (xdem/terrain/terrain.py:176-485): ``str`` attribute
+    -> one array, ``list`` -> list of arrays (a one-element list also yields a single array, as upstream,
+    terrain.py:666); ndarray / masked-array in -> ndarray out; Raster-like in -> ``type(dem).from_array(...,
+    nodata=-99999)`` out.  ``engine`` must be ``"hip"``.
+    """
+    if slope_method is not None:
+        warnings.warn("'slope_method' is deprecated, use 'surface_fit' instead.", DeprecationWarning, stacklevel=2)
+        surface_fit = slope_method
+    if engine != "hip":
+        raise ValueError(f"xdem_amd only provides engine='hip' (got '{engine}'); it has no CPU engine.")
+    if mp_config is not None:
+        raise NotImplementedError("mp_config tiling is replaced by xdem_amd.dist (row blocks over GPUs); pass None.")
+
+    attribute, resolution = _validate(dem, attribute, resolution, hillshade_altitude, hillshade_azimuth,
+                                      hillshade_z_factor, surface_fit, curv_method, tri_method, window_size_fractal)
+    if out_dtype is None:
+        in_dt = np.asarray(dem.data if _is_raster(dem) else dem).dtype
+        out_dtype = np.float32 if np.issubdtype(in_dt, np.integer) else np.dtype(in_dt)
+    out_dtype = np.dtype(out_dtype)
+    if out_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError(f"out_dtype must be float32 or float64 on the HIP engine (got {out_dtype}).")
+
+    dem_arr = _array_with_nan(dem)
+    if dem_arr.ndim != 2:
+        raise ValueError("The DEM must be a 2D array.")
+    if np.issubdtype(dem_arr.dtype, np.integer):
+        dem_arr = dem_arr.astype(np.float32)
+    if dem_arr.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        dem_arr = dem_arr.astype(np.float64 if dem_arr.dtype.itemsize > 4 else np.float32)
+    dem_arr = np.ascontiguousarray(dem_arr)
+    H, W = dem_arr.shape
+
+    outs = {a: np.empty((H, W), dtype=out_dtype) for a in set(attribute)}
+    ctx = _lib.default_context()
+    launch_terrain(ctx, dem_arr.ctypes.data, dem_arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
+                   attribute, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
+                   degrees, out_dtype, {a: o.ctypes.data for a, o in outs.items()}, _lib.HOST)
+    output_attributes = [outs[a] for a in attribute]
+    if _is_raster(dem):
+        output_attributes = [
+            type(dem).from_array(attr, transform=dem.transform, crs=dem.crs, nodata=-99999) for attr in output_attributes
+        ]
+    return output_attributes if len(output_attributes) > 1 else output_attributes[0]
+
+
+def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0, degrees: bool = True,
+                              hillshade_altitude: float = 45.0, hillshade_azimuth: float = 315.0,
+                              hillshade_z_factor: float = 1.0, surface_fit: str = "Florinsky",
+                              curv_method: str = "geometric", tri_method: str = "Riley", window_size: int = 3,
+                              out=None, halo_top: int = 0, halo_bottom: int = 0, ctx: _lib.Context | None = None):
+    """Device-resident variant: ``dem`` is a CUDA(HIP) torch tensor (rows = halo_top + H + halo_bottom), result is
+    one (n_attr, H, W) tensor (or ``out``) filled on the current torch stream.  No host copies, no sync."""
+    import torch
+
+    assert dem.is_cuda and dem.dim() == 2 and dem.stride(1) == 1
+    Hbuf, W = dem.shape
+    H = Hbuf - halo_top - halo_bottom
+    dt = {torch.float32: np.float32, torch.float64: np.float64}[dem.dtype]
+    if out is None:
+        out = torch.empty((len(attribute), H, W), dtype=dem.dtype, device=dem.device)
+    ctx = ctx or _lib.default_context(dem.device.index)
+    ctx.set_stream(torch.cuda.current_stream(dem.device).cuda_stream)
+    assert out.shape == (len(attribute), H, W) and out.stride(2) == 1 and out.stride(1) == W and out.is_cuda
+    ptrs = {a: out[i].data_ptr() for i, a in enumerate(attribute)}  # planes may be row windows of a larger tensor
+    launch_terrain(ctx, dem.data_ptr(), dt, H, W, dem.stride(0), halo_top, halo_bottom, resolution, surface_fit,
+                   curv_method, list(attribute), tri_method, window_size, hillshade_altitude, hillshade_azimuth,
+                   hillshade_z_factor, degrees, {torch.float32: np.float32, torch.float64: np.float64}[out.dtype],
+                   ptrs, _lib.DEVICE)
+    return out
+
+
+def _deprecated_method(method, surface_fit):
+    if method is not None:
+        warnings.warn("'method' is deprecated, use 'surface_fit' instead.", DeprecationWarning, stacklevel=3)
+        return method
+    return surface_fit
+
+
+# ---- thin wrappers, same signatures as xdem/terrain/terrain.py:693-1571 --------------------------------
+def slope(dem, method=None, surface_fit="Florinsky", degrees=True, resolution=None, mp_config=None, engine="hip"):
+    """Slope map (terrain.py:694-747)."""
+    surface_fit = _deprecated_method(method, surface_fit)
+    return get_terrain_attribute(dem, attribute="slope", surface_fit=surface_fit, resolution=resolution,
+                                 degrees=degrees, mp_config=mp_config, engine=engine)
+
+
+def aspect(dem, method=None, surface_fit="Florinsky", degrees=True, mp_config=None, engine="hip"):
+    """Aspect map; always computed with resolution=1.0 like the reference (terrain.py:773-836)."""
+    surface_fit = _deprecated_method(method, surface_fit)
+    return get_terrain_attribute(dem, attribute="aspect", surface_fit=surface_fit, resolution=1.0, degrees=degrees,
+                                 mp_config=mp_config, engine=engine)
+
+
+def hillshade(dem, method=None, surface_fit="Florinsky", azimuth=315.0, altitude=45.0, z_factor=1.0, resolution=None,
+              mp_config=None, engine="hip"):
+    """Hillshade (terrain.py:867-919)."""
+    surface_fit = _deprecated_method(method, surface_fit)
+    return get_terrain_attribute(dem, attribute="hillshade", resolution=resolution, surface_fit=surface_fit,
+                                 hillshade_azimuth=azimuth, hillshade_altitude=altitude, hillshade_z_factor=z_factor,
+                                 mp_config=mp_config, engine=engine)
+
+
+def curvature(dem, resolution=None, surface_fit="Florinsky", mp_config=None, engine="hip"):
+    """Deprecated total curvature (terrain.py:944-991)."""
+    warnings.warn("The curvature attribute is deprecated, refer to docs for specific curvature functions.",
+                  DeprecationWarning, stacklevel=2)
+    return get_terrain_attribute(dem=dem, attribute="curvature", resolution=resolution, surface_fit=surface_fit,
+                                 mp_config=mp_config, engine=engine)
+
+
+def _curv_wrapper(name):
+    def f(dem, resolution=None, surface_fit="Florinsky", curv_method="geometric", mp_config=None, engine="hip"):
+        return get_terrain_attribute(dem=dem, attribute=name, resolution=resolution, surface_fit=surface_fit,
+                                     curv_method=curv_method, mp_config=mp_config, engine=engine)
+
+    f.__name__ = name
+    f.__doc__ = f"{name} (xdem/terrain/terrain.py:1016-1447), multiplied by 100."
+    return f
+
+
+profile_curvature = _curv_wrapper("profile_curvature")
+tangential_curvature = _curv_wrapper("tangential_curvature")
+planform_curvature = _curv_wrapper("planform_curvature")
+flowline_curvature = _curv_wrapper("flowline_curvature")
+max_curvature = _curv_wrapper("max_curvature")
+min_curvature = _curv_wrapper("min_curvature")
+
+
+def topographic_position_index(dem, window_size=3, mp_config=None, engine="hip"):
+    """TPI (terrain.py:1468-1508)."""
+    return get_terrain_attribute(dem=dem, attribute="topographic_position_index", window_size=window_size,
+                                 mp_config=mp_config, engine=engine)
+
+
+def terrain_ruggedness_index(dem, method="Riley", window_size=3, mp_config=None, engine="hip"):
+    """TRI, Riley (topography) or Wilson (bathymetry) (terrain.py:1531-1579)."""
+    return get_terrain_attribute(dem=dem, attribute="terrain_ruggedness_index", tri_method=method,
+                                 window_size=window_size, mp_config=mp_config, engine=engine)
