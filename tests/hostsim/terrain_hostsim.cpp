@@ -12,7 +12,7 @@
 
 using namespace xd;
 
-template <int FIT, bool CURV, bool WIN, typename TIN, typename TOUT>
+template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT>
 static void run(const TIN* dem, int64_t H, int64_t W, int64_t halo_top, int64_t halo_bottom, int TH,
                 const TerrainParams& P, const Planes<TOUT>& out) {
     constexpr int HALO = Halo<FIT>::v;
@@ -28,7 +28,12 @@ static void run(const TIN* dem, int64_t H, int64_t W, int64_t halo_top, int64_t 
                     tile[(size_t)r * PITCH + c] = ok ? dem[(gy + halo_top) * W + gx] : (TIN)NAN;
                 }
             for (int t = 0; t < TW && x0 + t < W; ++t)
-                march_column<FIT, CURV, WIN, TIN, TOUT>(tile.data() + XPAD + t, PITCH, n_out, P, out, y0 * W + x0 + t, W);
+                {
+                    Planes<TOUT> org;
+                    for (int k = 0; k < N_ATTR; ++k) org.p[k] = out.p[k] + (y0 * W + x0);
+                    march_column<FIT, CURV, WIN, SP, TIN, TOUT>(tile.data() + XPAD + t, PITCH, n_out, P, org,
+                                                                (uint32_t)(t * sizeof(TOUT)), (uint32_t)(W * sizeof(TOUT)));
+                }
         }
 }
 
@@ -39,7 +44,17 @@ static int go(const void* dem, int64_t H, int64_t W, int64_t ht, int64_t hb, int
     for (int k = 0; k < N_ATTR; ++k) out.p[k] = static_cast<TOUT*>(planes[k]);
     const TIN* d = static_cast<const TIN*>(dem);
     const bool curv = (P.mask & A_ANY_CURV) != 0, win = (P.mask & A_ANY_WIN) != 0;
-#define GO(F, C, Wn) run<F, C, Wn, TIN, TOUT>(d, H, W, ht, hb, TH, P, out)
+    // exercise the compile-time specialised instantiations exactly when the GPU launcher would pick them
+    if (P.mask == MASK_FULL11 && !P.curv_directional && P.degrees && !P.tri_wilson && fit != 0 && P.hs_zf2 == 1.0) {
+        if (fit == 2) run<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        else run<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        return 0;
+    }
+    if (P.mask == MASK_SAH_WIN && P.degrees && !P.tri_wilson && fit == 0 && P.hs_zf2 == 1.0) {
+        run<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        return 0;
+    }
+#define GO(F, C, Wn) run<F, C, Wn, SpecRuntime, TIN, TOUT>(d, H, W, ht, hb, TH, P, out)
     if (fit == 0) { if (win) GO(0, false, true); else GO(0, false, false); }
     else if (fit == 1) { if (curv) { if (win) GO(1, true, true); else GO(1, true, false); } else { if (win) GO(1, false, true); else GO(1, false, false); } }
     else { if (curv) { if (win) GO(2, true, true); else GO(2, true, false); } else { if (win) GO(2, false, true); else GO(2, false, false); } }

@@ -16,6 +16,8 @@
 //
 // Replaces xdem/terrain/surfit.py:1197-1305 (_get_surface_attributes), xdem/terrain/window.py:926-1002
 // (_get_windowed_indexes, TPI/TRI) and the post-steps of xdem/terrain/terrain.py:586-596.
+#include <stdlib.h>
+
 #include "common.h"
 #include "terrain_math.h"
 
@@ -36,8 +38,8 @@ template <typename TIN, typename TOUT> struct TileArgs {
 
 template <typename TIN> struct TileRows { static constexpr int v = (sizeof(TIN) == 4) ? 32 : 16; };
 
-template <int FIT, bool CURV, bool WIN, typename TIN, typename TOUT>
-__global__ __launch_bounds__(256) void terrain_tile_kernel(const TileArgs<TIN, TOUT> a) {
+template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<TIN, TOUT> a) {
     constexpr int HALO = Halo<FIT>::v;
     constexpr int TH = TileRows<TIN>::v;
     constexpr int VEC = 16 / sizeof(TIN);
@@ -76,8 +78,18 @@ __global__ __launch_bounds__(256) void terrain_tile_kernel(const TileArgs<TIN, T
     }
     __syncthreads();
 
-    if (x0 + tid < a.W)
-        march_column<FIT, CURV, WIN, TIN, TOUT>(tile + XPAD + tid, PITCH, n_out, a.P, a.out, y0 * a.W + x0 + tid, a.W);
+    if (x0 + tid < a.W) {
+        // wave-uniform plane pointers at the tile origin (SGPR pairs) + 32-bit per-thread byte offsets
+        // (readfirstlane pins the wave-uniform tile offset into SGPRs so the pointers below stay scalar)
+        const uint64_t org_u = (uint64_t)(y0 * a.W + x0);
+        const int64_t org_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(org_u >> 32)) << 32) |
+                                          __builtin_amdgcn_readfirstlane((uint32_t)org_u));
+        Planes<TOUT> org;
+#pragma unroll
+        for (int k = 0; k < N_ATTR; ++k) org.p[k] = a.out.p[k] + org_off;
+        march_column<FIT, CURV, WIN, SP, TIN, TOUT>(tile + XPAD + tid, PITCH, n_out, a.P, org,
+                                                    (uint32_t)(tid * sizeof(TOUT)), (uint32_t)(a.W * sizeof(TOUT)));
+    }
 }
 
 // TPI / TRI for an arbitrary odd window (reference default is 3, handled by the fused kernel above).
@@ -132,7 +144,7 @@ static void fill_params(const TerrainLaunch& L, TerrainParams& P) {
     P.degrees = L.degrees;
 }
 
-template <int FIT, bool CURV, bool WIN, typename TIN, typename TOUT>
+template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT, int MINW = 1>
 static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask) {
     TileArgs<TIN, TOUT> a;
     a.dem = static_cast<const TIN*>(L.dem);
@@ -147,7 +159,7 @@ static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask)
     fill_params(L, a.P);
     a.P.mask = mask;
     for (int k = 0; k < N_ATTR; ++k) a.out.p[k] = static_cast<TOUT*>(L.planes[k]);
-    hipLaunchKernelGGL((terrain_tile_kernel<FIT, CURV, WIN, TIN, TOUT>), dim3(a.grid8 * 8), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((terrain_tile_kernel<FIT, CURV, WIN, SP, TIN, TOUT, MINW>), dim3(a.grid8 * 8), dim3(256), 0, ctx->stream, a);
     XD_HIP_CHECK(ctx, hipGetLastError());
     return XDEMHIP_OK;
 }
@@ -162,7 +174,20 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
     int rc = XDEMHIP_OK;
     if (mask) {
         const int fit = surf ? L.surface_fit : XDEMHIP_FIT_ZEVENBERGTHORNE;  // window-only: cheapest 3x3 march
-#define XD_GO(F, C, Wn) rc = launch_tiles<F, C, Wn, TIN, TOUT>(ctx, L, mask)
+        // Compile-time specialised kernels for the headline configurations (reference defaults: geometric
+        // curvatures, degrees, Riley TRI, z_factor 1): all attribute branches fold away -> one schedulable basic block.
+        const bool defaults = L.curv_method == XDEMHIP_CURV_GEOMETRIC && L.degrees && L.tri_method == XDEMHIP_TRI_RILEY &&
+                              L.hs_z == 1.0;
+        if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY) {
+            static const int occ = getenv("XDEMHIP_TERRAIN_OCC") ? atoi(getenv("XDEMHIP_TERRAIN_OCC")) : 3;  // tuning knob
+            if (occ == 4) return launch_tiles<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT, 4>(ctx, L, mask);
+            return launch_tiles<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(ctx, L, mask);
+        }
+        if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_ZEVENBERGTHORNE)
+            return launch_tiles<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(ctx, L, mask);
+        if (defaults && mask == MASK_SAH_WIN && fit == XDEMHIP_FIT_HORN)
+            return launch_tiles<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>, TIN, TOUT>(ctx, L, mask);
+#define XD_GO(F, C, Wn) rc = launch_tiles<F, C, Wn, SpecRuntime, TIN, TOUT>(ctx, L, mask)
         if (fit == XDEMHIP_FIT_HORN) { if (fuse_win) XD_GO(0, false, true); else XD_GO(0, false, false); }
         else if (fit == XDEMHIP_FIT_ZEVENBERGTHORNE) {
             if (curv) { if (fuse_win) XD_GO(1, true, true); else XD_GO(1, true, false); }

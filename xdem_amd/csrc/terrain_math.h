@@ -91,23 +91,35 @@ XD_HD double sqrt_nr(double x) {
     return (x == 0.0 || x == INFINITY) ? x : g;
 }
 
+// p * s + c with the loop-invariant constant c kept in a scalar register pair: one v_fma_f64.  (Left to itself
+// hipcc parks such constants in VGPRs and emits v_mov_b64 + v_fmac_f64 per Horner step.)
+XD_HD double fma_c(double p, double s, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(s), "s"(c));
+    return r;
+#else
+    return fma(p, s, c);
+#endif
+}
+
 // asin(x) for 0 <= x <= 0.7075: x * P(x^2), degree-12 near-minimax fit of asin(sqrt(s))/sqrt(s) on
 // [0, 0.5005] (max relative error 1.4e-12, fitted with mpmath at Chebyshev nodes).
 XD_HD double asin_small(double x) {
     const double s = x * x;
     double p = 0.24356914533777926376;
-    p = fma(p, s, -0.52512032962871855258);
-    p = fma(p, s, 0.56591394039083322551);
-    p = fma(p, s, -0.33592284970511680326);
-    p = fma(p, s, 0.14996103080076613321);
-    p = fma(p, s, -0.023070071561117294953);
-    p = fma(p, s, 0.024014351127563767045);
-    p = fma(p, s, 0.021579572865057994895);
-    p = fma(p, s, 0.030441879262631139926);
-    p = fma(p, s, 0.044640181228123456917);
-    p = fma(p, s, 0.075000061658013184589);
-    p = fma(p, s, 0.16666666611178785838);
-    p = fma(p, s, 1.0000000000008227697);
+    p = fma_c(p, s, -0.52512032962871855258);
+    p = fma_c(p, s, 0.56591394039083322551);
+    p = fma_c(p, s, -0.33592284970511680326);
+    p = fma_c(p, s, 0.14996103080076613321);
+    p = fma_c(p, s, -0.023070071561117294953);
+    p = fma_c(p, s, 0.024014351127563767045);
+    p = fma_c(p, s, 0.021579572865057994895);
+    p = fma_c(p, s, 0.030441879262631139926);
+    p = fma_c(p, s, 0.044640181228123456917);
+    p = fma_c(p, s, 0.075000061658013184589);
+    p = fma_c(p, s, 0.16666666611178785838);
+    p = fma_c(p, s, 1.0000000000008227697);
     return x * p;
 }
 
@@ -115,23 +127,39 @@ template <typename T> struct DegScale;
 template <> struct DegScale<float> { static XD_HD float v() { return 57.295776f; } };  // 180.0f / float(pi) in float arithmetic, as np.rad2deg
 template <> struct DegScale<double> { static XD_HD double v() { return 57.29577951308232; } };
 
-template <typename T> XD_HD T round_to(double v) { return (T)v; }
-
-// Output sink: one pointer per attribute plane (null when not requested), element offset of the pixel.
+// Output sink: one pointer per attribute plane (null when not requested).  Pixels are addressed by a 32-bit BYTE
+// offset from the (wave-uniform) plane pointer, which maps to the scalar-base + VGPR-offset store form.
 template <typename TOUT> struct Planes { TOUT* p[N_ATTR]; };
+template <typename TOUT> XD_HD void put(TOUT* plane, uint32_t byte_off, TOUT v) {
+    *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(plane) + byte_off) = v;
+}
+
+// Compile-time specialisation knobs.  CMASK != 0 fixes the attribute mask: every `if (mask & ...)` folds away
+// and the independent attribute chains land in ONE basic block the scheduler can interleave; DIR / DEG /
+// WILSON / ZF1 = -1 mean "read the runtime flag".  Spec<0,-1,-1,-1,-1> is the fully general kernel.
+template <uint32_t CMASK_, int DIR_, int DEG_, int WILSON_, int ZF1_ = -1> struct Spec {
+    static constexpr uint32_t CMASK = CMASK_;
+    static constexpr int DIR = DIR_, DEG = DEG_, WILSON = WILSON_, ZF1 = ZF1_;  // ZF1: hillshade z_factor == 1
+};
+typedef Spec<0, -1, -1, -1, -1> SpecRuntime;
+constexpr uint32_t MASK_FULL11 = 0xFFFu & ~A_CURVATURE;  // the 11-attribute headline set (no deprecated 'curvature')
+constexpr uint32_t MASK_SAH_WIN = A_SLOPE | A_ASPECT | A_HILLSHADE | A_TPI | A_TRI;
 
 // ---- attributes from the five derivative estimates ----------------------------------------------------
-template <bool CURV, typename TOUT>
-XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zxy, bool valid,
-                         const TerrainParams& P, const Planes<TOUT>& out, int64_t o) {
-    const uint32_t m = P.mask;
-    const TOUT nanv = (TOUT)NAN;
+// Invalid windows arrive with zx (and zxx) already NaN ("poisoned" by the marcher), so NaN propagates through
+// every formula below without per-attribute selects; comparisons with NaN are false, which keeps each
+// special-case branch (flat, tiny, steep, quadrant) on its arithmetic path.
+template <bool CURV, class SP, typename TOUT>
+XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zxy, const TerrainParams& P,
+                         const Planes<TOUT>& out, uint32_t o) {
+    const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
+    const bool deg = SP::DEG < 0 ? (P.degrees != 0) : (SP::DEG != 0);
     const double zx2 = zx * zx, zy2 = zy * zy;
     const double g2 = zx2 + zy2;
     const double opg = (1.0 + zx2) + zy2;
     const bool flat = (g2 == 0.0);
     const double rw = rsqrt_pos(opg);                 // cos(slope)
-    const double rg = flat ? 0.0 : rsqrt_pos(g2);     // 1 / |grad|
+    const double rg = flat ? 0.0 : rsqrt_pos(g2);     // 1 / |grad|   (0 on flat ground: kills every x/g term)
     const double g = g2 * rg;                         // tan(slope)
 
     if (m & A_SLOPE) {
@@ -140,8 +168,8 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         double a = asin_small(steep ? rw : g * rw);
         a = steep ? (1.5707963267948966 - a) : a;
         TOUT v = (TOUT)a;
-        if (P.degrees) v = v * DegScale<TOUT>::v();
-        out.p[P_SLOPE][o] = valid ? v : nanv;
+        if (deg) v = v * DegScale<TOUT>::v();
+        put(out.p[P_SLOPE], o, (TOUT)(v));
     }
     if (m & A_ASPECT) {
         // aspect = atan2(zx, zy) mod 2pi, first-quadrant angle from the smaller normalised component
@@ -151,50 +179,42 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         a = xbig ? (1.5707963267948966 - a) : a;
         a = (zy < 0.0) ? (3.141592653589793 - a) : a;
         a = (zx < 0.0) ? -a : a;
-        a = (a < 0.0) ? (a + 6.283185307179586) : a;
-        a = flat ? 0.0 : a;
+        a = (a < 0.0) ? (a + 6.283185307179586) : a;   // flat ground: rg = 0 -> a = 0 already
         TOUT v = (TOUT)a;
-        if (P.degrees) v = v * DegScale<TOUT>::v();
-        out.p[P_ASPECT][o] = valid ? v : nanv;
+        if (deg) v = v * DegScale<TOUT>::v();
+        put(out.p[P_ASPECT], o, (TOUT)(v));
     }
     if (m & A_HILLSHADE) {
         // 1.5 + 254 (sin(alt) cos(s') + cos(alt) sin(s') sin(az' - aspect)), s' = atan(zf * g), all algebraic
-        const double rwz = (P.hs_zf2 == 1.0) ? rw : rsqrt_pos(fma(P.hs_zf2, g2, 1.0));
+        double rwz = rw;  // z_factor 1 (the default): cos(s') = cos(slope)
+        if (SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0)) rwz = rsqrt_pos(fma(P.hs_zf2, g2, 1.0));
         const double shade = rwz * (P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx));
         TOUT v = (TOUT)fma(254.0, shade, 1.5);
         v = v < (TOUT)0 ? (TOUT)0 : (v > (TOUT)255 ? (TOUT)255 : v);
-        out.p[P_HILLSHADE][o] = valid ? v : nanv;
+        put(out.p[P_HILLSHADE], o, (TOUT)(v));
     }
     if (!CURV) return;
-    if (m & A_CURVATURE) out.p[P_CURVATURE][o] = valid ? (TOUT)(-2.0 * (zxx + zyy) * 100.0) : nanv;
+    if (m & A_CURVATURE) put(out.p[P_CURVATURE], o, (TOUT)((TOUT)(-2.0 * (zxx + zyy) * 100.0)));
     if (m & (A_ANY_CURV & ~A_CURVATURE)) {
+        const bool dir = SP::DIR < 0 ? (P.curv_directional != 0) : (SP::DIR != 0);
         const double zxzy = zx * zy;
         const double cross = 2.0 * zxy * zxzy;
         const double n_prof = fma(zyy, zy2, fma(zxx, zx2, cross));       // zxx zx^2 + 2 zxy zx zy + zyy zy^2
         const double n_tan = fma(zyy, zx2, fma(zxx, zy2, -cross));        // zxx zy^2 - 2 zxy zx zy + zyy zx^2
         const double rg2 = rg * rg;
-        const bool tiny = (g2 < 10e-15);
-        const bool dir = P.curv_directional != 0;
+        const double rg_t = (g2 < 10e-15) ? 0.0 : rg;                     // planform / flowline zero below 1e-14
         if (m & A_PROFILE) {
             double v = -n_prof * rg2;
             if (!dir) v *= rw * rw * rw;
-            out.p[P_PROFILE][o] = valid ? (TOUT)((flat ? 0.0 : v) * 100.0) : nanv;
+            put(out.p[P_PROFILE], o, (TOUT)((TOUT)(v * 100.0)));
         }
         const double t_dir = -n_tan * rg2;
-        if (m & A_TANGENTIAL) {
-            const double v = dir ? t_dir : t_dir * rw;
-            out.p[P_TANGENTIAL][o] = valid ? (TOUT)((flat ? 0.0 : v) * 100.0) : nanv;
-        }
-        if (m & A_PLANFORM) {
-            const double v = t_dir * rg;
-            out.p[P_PLANFORM][o] = valid ? (TOUT)((tiny ? 0.0 : v) * 100.0) : nanv;
-        }
+        if (m & A_TANGENTIAL) put(out.p[P_TANGENTIAL], o, (TOUT)((TOUT)((dir ? t_dir : t_dir * rw) * 100.0)));
+        if (m & A_PLANFORM) put(out.p[P_PLANFORM], o, (TOUT)((TOUT)(t_dir * rg_t * 100.0)));
         if (m & A_FLOWLINE) {
             const double n_flow = fma(zxzy, zxx - zyy, -zxy * (zx2 - zy2));
-            double v = n_flow * rg2 * rg;
-            if (!dir) v *= rw;
-            const bool zero = dir ? flat : tiny;
-            out.p[P_FLOWLINE][o] = valid ? (TOUT)((zero ? 0.0 : v) * 100.0) : nanv;
+            const double v = dir ? n_flow * rg2 * rg : n_flow * rg2 * rg_t * rw;
+            put(out.p[P_FLOWLINE], o, (TOUT)((TOUT)(v * 100.0)));
         }
         if (m & (A_MAXC | A_MINC)) {
             double vmax, vmin;
@@ -214,32 +234,34 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
                 vmax = mean + uns;
                 vmin = mean - uns;
             }
-            if (m & A_MAXC) out.p[P_MAXC][o] = valid ? (TOUT)((flat ? 0.0 : vmax) * 100.0) : nanv;
-            if (m & A_MINC) out.p[P_MINC][o] = valid ? (TOUT)((flat ? 0.0 : vmin) * 100.0) : nanv;
+            if (m & A_MAXC) put(out.p[P_MAXC], o, (TOUT)((TOUT)((flat ? 0.0 : vmax) * 100.0)));
+            if (m & A_MINC) put(out.p[P_MINC], o, (TOUT)((TOUT)((flat ? 0.0 : vmin) * 100.0)));
         }
     }
 }
 
-// TPI / TRI of a 3x3 window given as raw values (row-major n0..n8, n4 = centre).
-template <typename TIN, typename TOUT>
-XD_HD void window3_pixel(const TIN (&n)[9], double sum9, const TerrainParams& P, const Planes<TOUT>& out, int64_t o) {
-    const double c = (double)n[4];
-    if (P.mask & A_TPI) out.p[P_TPI][o] = (TOUT)(c - (sum9 - c) * 0.125);
-    if (P.mask & A_TRI) {
+// TPI / TRI of a 3x3 window given as raw values (row-major n0..n8, n4 = centre).  Plain IEEE propagation.
+template <class SP, typename TOUT>
+XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams& P, const Planes<TOUT>& out, uint32_t o) {
+    const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
+    const bool wilson = SP::WILSON < 0 ? (P.tri_wilson != 0) : (SP::WILSON != 0);
+    const double c = n[4];
+    if (m & A_TPI) put(out.p[P_TPI], o, (TOUT)((TOUT)(c - (sum9 - c) * 0.125)));
+    if (m & A_TRI) {
         double acc = c - c;  // the centre's own term: 0, or NaN when the centre is +-Inf (IEEE, like the reference)
-        if (P.tri_wilson) {
+        if (wilson) {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                if (k != 4) acc += fabs((double)n[k] - c);
-            out.p[P_TRI][o] = (TOUT)(acc * 0.125);
+                if (k != 4) acc += fabs(n[k] - c);
+            put(out.p[P_TRI], o, (TOUT)((TOUT)(acc * 0.125)));
         } else {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
                 if (k != 4) {
-                    const double d = (double)n[k] - c;
+                    const double d = n[k] - c;
                     acc = fma(d, d, acc);
                 }
-            out.p[P_TRI][o] = (TOUT)sqrt_nr(acc);
+            put(out.p[P_TRI], o, (TOUT)((TOUT)sqrt_nr(acc)));
         }
     }
 }
@@ -249,23 +271,26 @@ template <typename TIN> XD_HD double round_in(double v) { return (double)(TIN)v;
 // ---- the column marcher -------------------------------------------------------------------------------
 // `col` points at the tile element of this thread's column in the first tile row; tile row t holds raster
 // row (first output row - HALO + t); element col[t * pitch + d] is the pixel d columns to the right.
-// Emits n_out output rows; out index of output row i is o0 + i * ostride.
+// Emits n_out output rows; the plane pointers in `out` are already offset to the tile's first output pixel
+// (wave-uniform, so stores use the scalar-base + 32-bit VGPR offset addressing form) and the BYTE offset of
+// output row i is o0 + i * ostride (32-bit: a tile spans far less than 4 GiB per plane).
 template <int FIT> struct Halo { static constexpr int v = (FIT == 2) ? 2 : 1; };
 
-template <int FIT, bool CURV, bool WIN, typename TIN, typename TOUT>
+template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT>
 XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParams& P, const Planes<TOUT>& out,
-                        int64_t o0, int64_t ostride) {
+                        uint32_t o0, uint32_t ostride) {
     constexpr int HALO = Halo<FIT>::v;
     constexpr int NS = 2 * HALO + 1;  // rotating window slots
     const int nrows = n_out + 2 * HALO;
+    const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
 
     // per-row partials (float64) -- Florinsky
     double A[NS], B[NS], R[NS], Wr[NS], Ua[NS], Ub[NS];
     // per-row partials -- 3x3 fits
     double Dr[NS], S[NS], Zc[NS];
-    // 3-wide row sums and raw values for TPI / TRI and the 3x3 validity detector
+    // 3-wide row sums and the float64 copies of the three centre columns for TPI / TRI (and the 3x3 detector)
     double R3[NS];
-    TIN rawl[NS], rawc[NS], rawr[NS];
+    double Nl[NS], Nc[NS], Nr[NS];
 
     for (int r0 = 0; r0 < nrows; r0 += NS) {
 #pragma unroll
@@ -281,45 +306,54 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
                     A[k] = zr - zl;
                     B[k] = z4 - z0;
                     R[k] = (p + q) + zc;
-                    Wr[k] = fma(2.0, p - zc, -q);
+                    if (CURV) Wr[k] = fma(2.0, p - zc, -q);
                     Ua[k] = fma(68.0, zc, fma(62.0, q, 44.0 * p));
                     Ub[k] = fma(17.0, zc, fma(5.0, q, -31.0 * p));
-                    R3[k] = q + zc;
+                    if (WIN) R3[k] = q + zc;
                 } else {
                     Dr[k] = zr - zl;
                     S[k] = zl + zr;
                     Zc[k] = zc;
                     R3[k] = (zl + zr) + zc;
                 }
-                if (WIN) { rawl[k] = tl; rawc[k] = tc; rawr[k] = tr; }
+                if (WIN) { Nl[k] = zl; Nc[k] = zc; Nr[k] = zr; }
 
                 const int i = r - 2 * HALO;  // output row whose window is now complete
                 if (i >= 0) {
-                    const int64_t o = o0 + (int64_t)i * ostride;
-                    // slot of window row (centre + d): newest row (k) is centre + HALO
+                    uint32_t o = o0 + (uint32_t)i * ostride;  // byte offset
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // keep `o` an opaque 32-bit VGPR: stops loop-strength-reduction from turning every plane
+                    // into its own 64-bit running pointer (11 VGPR pairs + one 64-bit add per store)
+                    asm volatile("" : "+v"(o));
+#endif
+                    // slot of window row (centre + d): the newest row (slot k) is centre + HALO
 #define XD_SLOT(d) ((k + NS - HALO + (d)) % NS)
                     double zx, zy, zxx = 0.0, zyy = 0.0, zxy = 0.0;
-                    bool valid;
                     if (FIT == 2) {
                         const int m2 = XD_SLOT(-2), m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1), p2 = XD_SLOT(2);
-                        const double det = ((R[m2] + R[m1]) + (R[c0] + R[p1])) + R[p2];
-                        valid = (det - det) == 0.0;  // finite <=> all 25 pixels finite and inside the raster
                         const double sx = fma(17.0, B[c0], fma(68.0, A[c0],
                                           fma(5.0, B[m1] + B[p1], fma(62.0, A[m1] + A[p1],
                                           fma(-31.0, B[m2] + B[p2], 44.0 * (A[m2] + A[p2]))))));
                         zx = round_in<TIN>(-sx * P.s1);
                         zy = round_in<TIN>(((Ua[p1] - Ua[m1]) + (Ub[p2] - Ub[m2])) * P.s1);
+                        double det;  // an all-25-pixel sum: non-finite <=> some pixel non-finite or outside the raster
                         if (CURV) {
-                            zxx = round_in<TIN>((((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2]) * P.sxx);
+                            det = ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2];
+                            zxx = round_in<TIN>(det * P.sxx);
                             zyy = round_in<TIN>(fma(2.0, (R[m2] + R[p2]) - R[c0], -(R[m1] + R[p1])) * P.sxx);
                             const double d_m2 = fma(2.0, B[m2], A[m2]), d_m1 = fma(2.0, B[m1], A[m1]);
                             const double d_p1 = fma(2.0, B[p1], A[p1]), d_p2 = fma(2.0, B[p2], A[p2]);
                             zxy = round_in<TIN>(fma(2.0, d_m2 - d_p2, d_m1 - d_p1) * P.sxy);
+                        } else {
+                            det = ((R[m2] + R[m1]) + (R[c0] + R[p1])) + R[p2];
                         }
+                        const double poison = det - det;  // 0, or NaN for an invalid window
+                        zx += poison;
+                        if (CURV) zxx += poison;
                     } else {
                         const int m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1);
                         const double det = (R3[m1] + R3[c0]) + R3[p1];
-                        valid = (det - det) == 0.0;
+                        const double poison = det - det;
                         if (FIT == 0) {  // Horn: [1 2 1] smoothing across the derivative direction
                             zx = round_in<TIN>(-(fma(2.0, Dr[c0], Dr[m1] + Dr[p1])) * P.s1);
                             zy = round_in<TIN>((fma(2.0, Zc[p1] - Zc[m1], S[p1] - S[m1])) * P.s1);
@@ -327,18 +361,18 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
                             zx = round_in<TIN>(-Dr[c0] * P.s1);
                             zy = round_in<TIN>((Zc[p1] - Zc[m1]) * P.s1);
                             if (CURV) {
-                                zxx = round_in<TIN>(fma(-2.0, Zc[c0], S[c0]) * P.sxx);
+                                zxx = round_in<TIN>(fma(-2.0, Zc[c0], S[c0]) * P.sxx) + poison;
                                 zyy = round_in<TIN>(fma(-2.0, Zc[c0], Zc[m1] + Zc[p1]) * P.sxx);
                                 zxy = round_in<TIN>((Dr[m1] - Dr[p1]) * P.sxy);
                             }
                         }
+                        zx += poison;
                     }
-                    if (P.mask & ~A_ANY_WIN) surface_pixel<CURV, TOUT>(zx, zy, zxx, zyy, zxy, valid, P, out, o);
+                    if (m & ~A_ANY_WIN) surface_pixel<CURV, SP, TOUT>(zx, zy, zxx, zyy, zxy, P, out, o);
                     if (WIN) {
                         const int w1 = XD_SLOT(-1), w0 = XD_SLOT(0), w2 = XD_SLOT(1);
-                        const TIN n[9] = {rawl[w1], rawc[w1], rawr[w1], rawl[w0], rawc[w0], rawr[w0],
-                                          rawl[w2], rawc[w2], rawr[w2]};
-                        window3_pixel<TIN, TOUT>(n, (R3[w1] + R3[w0]) + R3[w2], P, out, o);
+                        const double n[9] = {Nl[w1], Nc[w1], Nr[w1], Nl[w0], Nc[w0], Nr[w0], Nl[w2], Nc[w2], Nr[w2]};
+                        window3_pixel<SP, TOUT>(n, (R3[w1] + R3[w0]) + R3[w2], P, out, o);
                     }
 #undef XD_SLOT
                 }
