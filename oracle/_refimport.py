@@ -124,6 +124,9 @@ def install() -> None:
     geoutils.raster.Raster = _Raster
     geoutils.raster.RasterType = _Raster
     geoutils.raster.get_array_and_mask = _get_array_and_mask
+    import geopandas
+
+    geopandas.GeoDataFrame = type("GeoDataFrame", (), {})  # isinstance() sentinel, never instantiated
 
     pkg = types.ModuleType("xdem")
     pkg.__path__ = [os.path.join(REFERENCE_ROOT, "xdem")]

@@ -1,0 +1,147 @@
+"""Golden vectors for the Nuth-Kaab path, recorded from the REFERENCE's own functions (container-only script,
+called by oracle/gen_golden.py).  What can run here without geoutils: the aspect/slope auxiliary step, the
+72-bin nanmedian binning + curve_fit, the iteration driver.  The bilinear resampling of the shifted DEM lives
+in geoutils (absent): for the end-to-end fixture it is replaced by a stand-in implementing the build's STATED
+convention (oracle/nuthkaab_oracle.py header), so that fixture pins everything of the reference loop except
+that interpolation."""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _params():
+    import scipy.optimize
+
+    return {"fit_or_bin": "bin_and_fit", "fit_optimizer": scipy.optimize.curve_fit, "bin_sizes": 72,
+            "bin_statistic": np.nanmedian, "nd": 1, "bias_var_names": ["aspect"]}
+
+
+def main(ref, out_dir: str) -> None:
+    import nuthkaab_oracle as nko
+
+    aff, base, ss = ref.affine, ref.base, ref.spatialstats
+    rec = {}
+
+    # T8: auxiliary variables on float32 / float64 DEMs with NaNs and a flat patch
+    rng = np.random.default_rng(8)
+    for dt in (np.float32, np.float64):
+        dem = (500 + np.cumsum(np.cumsum(rng.normal(scale=0.3, size=(40, 53)), 0), 1)).astype(dt)
+        dem[10, 12] = np.nan
+        dem[30:34, 40:45] = 123.0  # flat patch -> zero slope
+        st, asp = aff._nuth_kaab_aux_vars(dem, dem)
+        st = st.copy()
+        st[np.isclose(st, 0)] = np.nan  # affine.py:578-579
+        n = np.dtype(dt).name
+        rec[f"T8|{n}|dem"], rec[f"T8|{n}|slope_tan"], rec[f"T8|{n}|aspect"] = dem, st, asp
+
+    # T5: bin + fit on synthetic (aspect, slope_tan, dh) with known (a, b, c)
+    for n_pts, seed in ((1000, 1), (200000, 2), (5001, 3)):
+        r = np.random.default_rng(seed)
+        aspect = r.uniform(0, 2 * np.pi, n_pts).astype(np.float32)
+        slope_tan = r.uniform(0.05, 1.2, n_pts).astype(np.float32)
+        a, b, c = 3.0, 0.7, 0.4
+        dh = ((a * np.cos(b - aspect) + c) * slope_tan + r.normal(scale=0.5, size=n_pts)).astype(np.float32)
+        if seed == 3:  # duplicates and a point exactly on the last edge
+            dh[:100] = dh[0]
+            aspect[:50] = aspect[0]
+        y = dh / slope_tan
+        df = ss.nd_binning(values=y, list_var=[aspect], list_var_names=["aspect"], list_var_bins=72,
+                           statistics=(np.nanmedian, "count"))
+        import pandas as pd
+
+        mids = pd.IntervalIndex(df["aspect"]).mid.values
+        e, n_, v = aff._nuth_kaab_bin_fit(dh.copy(), slope_tan, aspect, _params())
+        k = f"T5|{n_pts}"
+        rec[k + "|aspect"], rec[k + "|slope_tan"], rec[k + "|dh"] = aspect, slope_tan, dh
+        rec[k + "|nanmedian"] = df["nanmedian"].values.astype(np.float64)
+        rec[k + "|count"] = df["count"].values.astype(np.int64)
+        rec[k + "|mids"] = np.asarray(mids)
+        rec[k + "|left"] = np.array([iv.left for iv in df["aspect"]])
+        rec[k + "|right"] = np.array([iv.right for iv in df["aspect"]])
+        rec[k + "|enz"] = np.array([e, n_, v], dtype=np.float64)
+
+    # T6: stop rule of _iterate_method (i > 1 and stat < tol => at least 3 iterations)
+    calls = []
+
+    def fake(x, *const):
+        calls.append(x)
+        return x + 1, 10.0 ** (-len(calls))
+
+    final = aff._iterate_method(fake, 0, (), tolerance=1e-2, max_iterations=10)
+    rec["T6|final"], rec["T6|ncalls"] = np.int64(final), np.int64(len(calls))
+    calls.clear()
+    final = aff._iterate_method(fake, 0, (), tolerance=0.5, max_iterations=10)
+    rec["T6|final_loose"], rec["T6|ncalls_loose"] = np.int64(final), np.int64(len(calls))
+
+    # T9: reference nuth_kaab() end to end, geoutils pieces replaced by the stated-convention stand-ins
+    class _T:  # affine.Affine stand-in: north-up grid
+        def __init__(self, res):
+            self.a, self.e, self.c, self.f = res, -res, 0.0, 0.0
+
+    def _coords(transform, shape, area_or_point=None, grid=True):
+        H, W = shape
+        x = transform.c + (np.arange(W) + 0.5) * transform.a
+        y = transform.f + (np.arange(H) + 0.5) * transform.e
+        xx, yy = np.meshgrid(x, y)
+        return xx, yy
+
+    def _res(transform):
+        return (transform.a, -transform.e)
+
+    def _reproject(raster_arr, src_transform, dst_transform=None, return_interpolator=False, resampling="linear"):
+        assert return_interpolator
+        res = (src_transform.a, -src_transform.e)
+
+        def interp(yx):
+            yy, xx = yx
+            colf = (xx - src_transform.c) / res[0] - 0.5
+            rowf = (src_transform.f - yy) / res[1] - 0.5
+            return _bilinear_points(raster_arr, rowf, colf)
+
+        return interp
+
+    def _bilinear_points(arr, rowf, colf):
+        H, W = arr.shape
+        r0 = np.floor(rowf).astype(np.int64)
+        c0 = np.floor(colf).astype(np.int64)
+        fr, fc = rowf - r0, colf - c0
+        ok = (r0 >= 0) & (r0 + 1 < H) & (c0 >= 0) & (c0 + 1 < W)
+        r0c, c0c = np.clip(r0, 0, H - 2), np.clip(c0, 0, W - 2)
+        t = arr.astype(np.float64)
+        v00, v01, v10, v11 = t[r0c, c0c], t[r0c, c0c + 1], t[r0c + 1, c0c], t[r0c + 1, c0c + 1]
+        top = v00 + fc * (v01 - v00)
+        bot = v10 + fc * (v11 - v10)
+        val = top + fr * (bot - top)
+        fin = np.isfinite(v00) & np.isfinite(v01) & np.isfinite(v10) & np.isfinite(v11)
+        return np.where(ok & fin, val, np.nan).astype(arr.dtype)
+
+    aff._coords, aff._res, aff._reproject_horizontal_shift_samecrs = _coords, _res, _reproject
+    crs = types.SimpleNamespace(is_projected=True)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from xdem_amd.synth import fbm_numpy
+
+    refdem = fbm_numpy((160, 200), seed=42, std=150.0)
+    res = 10.0
+    true_shift = (1.7 * res, -0.6 * res)  # georeferenced units
+    tba = (refdem - nko.shifted_dh(refdem, refdem, true_shift[0], true_shift[1], (res, res)))  # tba(x) = ref(x + s)
+    tba = (tba + 2.0 + np.random.default_rng(43).normal(scale=0.05, size=tba.shape)).astype(np.float32)
+    hole = fbm_numpy((160, 200), seed=44, hurst=1.0, mean=0.0, std=1.0)
+    tba[hole < np.percentile(hole, 20)] = np.nan
+    inlier = np.ones(refdem.shape, dtype=bool)
+    inlier[:5, :] = False
+    for it, tol in ((10, 0.0), (10, 0.001)):
+        (e, n_, v), nsub = aff.nuth_kaab(refdem, tba, inlier, _T(res), crs, "Area", tol, it, _params(),
+                                          {"subsample": 1, "random_state": None}, "z")
+        rec[f"T9|{tol}|offsets"] = np.array([e, n_, v], dtype=np.float64)
+        rec[f"T9|{tol}|subsample_final"] = np.int64(nsub)
+    rec["T9|ref"], rec["T9|tba"], rec["T9|inlier"], rec["T9|res"] = refdem, tba, inlier, np.float64(res)
+
+    np.savez_compressed(os.path.join(out_dir, "nk_golden.npz"), **rec)
+    print("nk fixtures written:", len(rec), "arrays")

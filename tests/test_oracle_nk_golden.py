@@ -1,0 +1,74 @@
+"""Pins oracle/nuthkaab_oracle.py against vectors recorded from the reference's own Nuth-Kaab functions
+(oracle/gen_golden_nk.py -> tests/golden/nk_golden.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+import nuthkaab_oracle as nko
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def z():
+    return np.load(os.path.join(GOLDEN, "nk_golden.npz"))
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_T8_aux_vars(z, dt):
+    dem = z[f"T8|{dt}|dem"]
+    st, asp = nko.aux_vars(dem)
+    # gradient / slope tangent: same float ops as the reference -> bit-exact, NaN pattern included
+    assert np.array_equal(st, z[f"T8|{dt}|slope_tan"], equal_nan=True)
+    # aspect: the reference uses libm atan2 in the DEM dtype (float32: up to 1 ulp off the correctly rounded value)
+    ref = z[f"T8|{dt}|aspect"]
+    assert np.array_equal(np.isnan(asp), np.isnan(ref))
+    fin = np.isfinite(ref)
+    tol = 2 * np.spacing(np.abs(ref[fin]).max().astype(ref.dtype))
+    assert np.max(np.abs(asp[fin].astype(np.float64) - ref[fin])) <= tol
+    if dt == "float32":
+        assert np.mean(asp[fin] == ref[fin]) > 0.75  # NumPy float32 arctan2 (SVML / libm) is not correctly rounded
+
+
+@pytest.mark.parametrize("n", [1000, 200000, 5001])
+def test_T5_bin_and_fit(z, n):
+    k = f"T5|{n}"
+    aspect, slope_tan, dh = z[k + "|aspect"], z[k + "|slope_tan"], z[k + "|dh"]
+    (e, nn, c), det = nko.bin_fit(dh, slope_tan, aspect)
+    # integer work: bin membership counts bit-exact; edges bit-exact
+    assert np.array_equal(det["counts"], z[k + "|count"])
+    assert np.array_equal(det["edges"][:-1], z[k + "|left"]) and np.array_equal(det["edges"][1:], z[k + "|right"])
+    # medians are selections (or means of two float32): bit-exact
+    assert np.array_equal(det["medians"], z[k + "|nanmedian"], equal_nan=True)
+    assert np.allclose(det["mids"], z[k + "|mids"], rtol=0, atol=1e-6)
+    assert np.allclose([e, nn, c], z[k + "|enz"], rtol=1e-9, atol=1e-12)
+
+
+def test_T6_stop_rule(z):
+    def run(tol):
+        calls = []
+        x = 0
+        for i in range(10):
+            calls.append(x)
+            x, stat = x + 1, 10.0 ** (-len(calls))
+            if i > 1 and stat < tol:
+                break
+        return x, len(calls)
+
+    assert run(1e-2) == (int(z["T6|final"]), int(z["T6|ncalls"]))
+    assert run(0.5) == (int(z["T6|final_loose"]), int(z["T6|ncalls_loose"]))
+    assert int(z["T6|ncalls_loose"]) == 3  # never fewer than 3 iterations (affine.py:142)
+
+
+@pytest.mark.parametrize("tol", ["0.0", "0.001"])
+def test_T9_full_loop(z, tol):
+    ref, tba, inlier, res = z["T9|ref"], z["T9|tba"], z["T9|inlier"], float(z["T9|res"])
+    offsets, nvalid, trace = nko.nuth_kaab(ref, tba, inlier, (res, res), tolerance=float(tol), max_iterations=10)
+    want = z[f"T9|{tol}|offsets"]
+    assert nvalid == int(z[f"T9|{tol}|subsample_final"])
+    # aspect differs from the reference's libm atan2f by <= 1 ulp on a few pixels -> a handful of points change bin;
+    # the fitted shifts agree far below the 1e-3 px convergence threshold
+    assert np.allclose(offsets, want, rtol=1e-5, atol=1e-5 * res), (offsets, want)
+    # the synthetic pair was built as tba(x) = ref(x + (1.7, -0.6) px) + 2 m: the offsets that re-align it are the
+    # opposite (NuthKaab then reports shift_x = -east, shift_y = -north, affine.py:2526-2530)
+    assert abs(offsets[0] / res + 1.7) < 0.05 and abs(offsets[1] / res - 0.6) < 0.05 and abs(offsets[2] + 2.0) < 0.05
