@@ -91,6 +91,37 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
                     double hillshade_azimuth_deg, double hillshade_z_factor, int degrees, int out_dtype,
                     void* const* out_planes, int memspace);
 
+/* ---- path 2: Nuth & Kaab (2011) inner loop ------------------------------------------------------------
+ * Replaces the array work of  nuth_kaab(ref_elev, tba_elev, inlier_mask, transform, ...)   xdem/coreg/affine.py:539-609
+ * for two rasters on the same grid, i.e. what NuthKaab._fit_rst_rst reaches (affine.py:2458-2522):
+ *
+ *  xdemhip_nk_create   once per fit: slope tangent / aspect from np.gradient (affine.py:433-438), zero slopes -> NaN
+ *                      (affine.py:578-579), valid = inlier & finite(ref, tba, slope_tan, aspect) (base.py:650-661);
+ *                      *n_valid = number of valid pixels (the reference's `subsample_final` for subsample == 1).
+ *  xdemhip_nk_step     one _nuth_kaab_iteration_step (affine.py:477-536) up to, not including, the 72-point curve
+ *                      fit: for the current offsets (georeferenced units, east / north)
+ *                        dh      = ref - bilinear(tba)(row - shift_y/res_y, col + shift_x/res_x)     [convention: DESIGN.md]
+ *                        vshift  = np.nanmedian(dh)                          (exact, radix selection)
+ *                        y       = (dh - vshift) / slope_tan,  y_mean / y_std = np.nanmean / np.nanstd (for p0)
+ *                        edges[n_bins+1], counts[n_bins], medians[n_bins] = scipy.stats.binned_statistic(aspect, y,
+ *                                  np.nanmedian, bins=n_bins) with 'count'      (xdem/spatialstats.py:143-157)
+ *                      Empty bins give NaN medians.  Returns XDEMHIP_EINVAL ("The subsample contains no more valid
+ *                      values.") when no pixel survives, like affine.py:510-515.
+ *  xdemhip_binned_median  the binning alone on caller-supplied 1-D (x, y) host arrays (nd_binning, 1 variable).
+ * Host code fits a*cos(b - x) + c to (bin mids, medians) with scipy.optimize.curve_fit exactly as base.py:1038-1045.
+ */
+typedef struct xdemhip_nk_plan xdemhip_nk_plan;
+int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const uint8_t* inlier_mask_or_null, int dtype,
+                      int64_t H, int64_t W, int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid);
+int xdemhip_nk_step(xdemhip_nk_plan* plan, double shift_x, double shift_y, double res_x, double res_y, int n_bins,
+                    double* vshift, int64_t* n_valid, double* y_mean, double* y_std, double* edges, int64_t* counts,
+                    double* medians);
+/* Debug / test access: copy the auxiliary rasters back to host buffers (any pointer may be NULL). */
+int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uint8_t* valid);
+void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
+int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
+                          int64_t* counts, double* medians);
+
 #ifdef __cplusplus
 }
 #endif

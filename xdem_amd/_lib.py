@@ -57,6 +57,16 @@ def lib() -> ctypes.CDLL:
             ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
             ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
         ]
+        c_i64p, c_dp = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
+        L.xdemhip_nk_create.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p]
+        L.xdemhip_nk_step.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_int, c_dp, c_i64p, c_dp, c_dp, c_dp, c_i64p, c_dp]
+        L.xdemhip_nk_get_aux.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.xdemhip_nk_destroy.argtypes = [ctypes.c_void_p]
+        L.xdemhip_nk_destroy.restype = None
+        L.xdemhip_binned_median.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                            c_dp, c_i64p, c_dp]
         _lib = L
         return L
 

@@ -1,0 +1,232 @@
+"""Nuth & Kaab (2011) co-registration on MI355X -- host-side mirror of ``xdem.coreg.NuthKaab`` for the
+raster-raster hot path.
+
+Same constructor arguments, ``fit`` contract and ``meta`` outputs as the reference class
+(``xdem/coreg/affine.py:2386-2541``) and the same iteration driver (``affine.py:102-147, 477-609``); every pass
+over the grids (gradient, shifted elevation difference, exact ``nanmedian`` vertical shift, 72-bin aspect binning
+with exact per-bin ``nanmedian``) runs in ``csrc/nuthkaab.hip`` through ``xdemhip_nk_create`` / ``xdemhip_nk_step``.
+The 72-point ``scipy.optimize.curve_fit`` stays on the host exactly as upstream (``xdem/coreg/base.py:1038-1045``).
+
+Scope: two rasters on the same grid given as arrays (+ resolution), ``subsample=1`` (all valid pixels -- the
+BASELINE configuration); the default ``bin_before_fit=True`` with ``bin_statistic=np.nanmedian``.  Point-cloud
+inputs, random subsampling (geoutils' ``subsample_array``) and other statistics are outside the hot path and raise
+``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+from typing import Any, Callable
+
+import numpy as np
+
+from . import _lib
+
+
+def _nuth_kaab_fit_func(xx, *params):
+    """y(x) = a * cos(b - x) + c  (xdem/coreg/affine.py:340-355)."""
+    return params[0] * np.cos(params[1] - xx) + params[2]
+
+
+class NKPlan:
+    """Device-resident state of one fit (``xdemhip_nk_plan``)."""
+
+    def __init__(self, ref: np.ndarray, tba: np.ndarray, inlier_mask: np.ndarray | None, ctx: _lib.Context | None = None):
+        ref = np.ascontiguousarray(ref)
+        tba = np.ascontiguousarray(tba)
+        if ref.shape != tba.shape or ref.ndim != 2:
+            raise ValueError("ref and tba must be 2D arrays of the same shape")
+        if ref.dtype != tba.dtype or ref.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            dt = np.float64 if np.float64 in (ref.dtype, tba.dtype) else np.float32
+            ref, tba = ref.astype(dt), tba.astype(dt)
+        self.dtype = ref.dtype
+        self.shape = ref.shape
+        self.ctx = ctx or _lib.default_context()
+        inl = None
+        if inlier_mask is not None:
+            inl = np.ascontiguousarray(inlier_mask, dtype=np.uint8)
+        h = ctypes.c_void_p()
+        nv = ctypes.c_int64()
+        self.ctx.check(self.ctx._L.xdemhip_nk_create(
+            self.ctx.handle, ref.ctypes.data, tba.ctypes.data, inl.ctypes.data if inl is not None else None,
+            _lib.F32 if self.dtype == np.float32 else _lib.F64, ref.shape[0], ref.shape[1], _lib.HOST, ctypes.byref(h),
+            ctypes.byref(nv)))
+        self.handle = h
+        self.n_valid = int(nv.value)
+
+    def step(self, shift_x: float, shift_y: float, res: tuple[float, float], n_bins: int = 72) -> dict[str, Any]:
+        edges = np.empty(n_bins + 1, dtype=np.float64)
+        counts = np.empty(n_bins, dtype=np.int64)
+        med = np.empty(n_bins, dtype=np.float64)
+        vshift, ymean, ystd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        nv = ctypes.c_int64()
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+        rc = self.ctx._L.xdemhip_nk_step(self.handle, float(shift_x), float(shift_y), float(res[0]), float(res[1]), int(n_bins),
+                                         ctypes.byref(vshift), ctypes.byref(nv), ctypes.byref(ymean), ctypes.byref(ystd),
+                                         edges.ctypes.data_as(dp), counts.ctypes.data_as(ip), med.ctypes.data_as(dp))
+        if rc != _lib.OK:
+            msg = self.ctx._L.xdemhip_last_error(self.ctx.handle).decode()
+            if "no more valid values" in msg:
+                raise ValueError(
+                    "The subsample contains no more valid values. This can happen is the horizontal shift to "
+                    "correct is very large, or if the algorithm diverged. To ensure all possible points can "
+                    "be used at any iteration step, use subsample=1."
+                )
+            raise _lib.XdemHipError(f"libxdemhip status {rc}: {msg}")
+        return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
+                "edges": edges, "counts": counts, "medians": med}
+
+    def aux(self):
+        """(slope_tan, aspect, valid) copied back to the host (tests / debugging)."""
+        st = np.empty(self.shape, dtype=self.dtype)
+        asp = np.empty(self.shape, dtype=self.dtype)
+        valid = np.empty(self.shape, dtype=np.uint8)
+        self.ctx.check(self.ctx._L.xdemhip_nk_get_aux(self.handle, st.ctypes.data, asp.ctypes.data, valid.ctypes.data))
+        return st, asp, valid.astype(bool)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.ctx._L.xdemhip_nk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def binned_median(x: np.ndarray, y: np.ndarray, n_bins: int = 72, ctx: _lib.Context | None = None):
+    """``scipy.stats.binned_statistic(x, y, np.nanmedian, n_bins)`` + counts on the GPU (xdem/spatialstats.py:143-157).
+    Returns (edges float64[n+1], counts int64[n], medians float64[n])."""
+    x = np.ascontiguousarray(x).ravel()
+    y = np.ascontiguousarray(y).ravel()
+    dt = np.float64 if np.float64 in (x.dtype, y.dtype) else np.float32
+    x, y = x.astype(dt, copy=False), y.astype(dt, copy=False)
+    ctx = ctx or _lib.default_context()
+    edges = np.empty(n_bins + 1, dtype=np.float64)
+    counts = np.empty(n_bins, dtype=np.int64)
+    med = np.empty(n_bins, dtype=np.float64)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+    ctx.check(ctx._L.xdemhip_binned_median(ctx.handle, x.ctypes.data, y.ctypes.data, _lib.F32 if dt == np.float32 else _lib.F64,
+                                           x.size, int(n_bins), edges.ctypes.data_as(dp), counts.ctypes.data_as(ip),
+                                           med.ctypes.data_as(dp)))
+    return edges, counts, med
+
+
+def _bin_fit_from_step(det: dict[str, Any], fit_optimizer: Callable[..., Any], dtype) -> tuple[float, float, float]:
+    """The host half of ``_nuth_kaab_bin_fit`` (affine.py:381-409, base.py:1022-1045): p0, bin mids, curve_fit."""
+    p0 = (3 * det["y_std"] / (2**0.5), 0.0, det["y_mean"])
+    edges = det["edges"]  # sample-dtype values held in float64, like pd.IntervalIndex.from_breaks stores them
+    mids = 0.5 * (edges[:-1] + edges[1:])  # pd.IntervalIndex.mid (base.py:1027)
+    med = det["medians"]
+    ok = np.isfinite(med) & np.isfinite(mids)
+    if np.all(~ok):
+        raise ValueError("Only NaN values after binning, did you pass the right bin edges?")
+    results = fit_optimizer(f=_nuth_kaab_fit_func, xdata=mids[ok], ydata=med[ok], p0=p0, sigma=None, absolute_sigma=True)
+    a, b, c = results[0]
+    return a * np.sin(b), a * np.cos(b), c
+
+
+def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarray | None, res: tuple[float, float],
+              tolerance: float = 0.001, max_iterations: int = 10, bin_sizes: int = 72,
+              fit_optimizer: Callable[..., Any] | None = None, ctx: _lib.Context | None = None):
+    """Array-level entry mirroring ``nuth_kaab`` (xdem/coreg/affine.py:539-609) for two rasters, subsample == 1.
+
+    Returns ((easting, northing, vertical) offsets in georeferenced units, subsample_final)."""
+    import scipy.optimize
+
+    fit_optimizer = fit_optimizer or scipy.optimize.curve_fit
+    logging.info("Running Nuth and Kääb (2011) coregistration")
+    plan = NKPlan(ref_elev, tba_elev, inlier_mask, ctx)
+    try:
+        if plan.n_valid == 0:
+            raise ValueError(
+                "There is no valid points common to the input and auxiliary data (bias variables, or "
+                "derivatives required for this method, for example slope, aspect, etc)."
+            )
+        offsets = (0.0, 0.0, 0.0)
+        # _iterate_method (affine.py:102-147): stop when i > 1 and the horizontal step falls below the tolerance
+        for i in range(max_iterations):
+            det = plan.step(offsets[0], offsets[1], res, bin_sizes)
+            east, north, _ = _bin_fit_from_step(det, fit_optimizer, plan.dtype)
+            offsets = (offsets[0] + east * res[0], offsets[1] + north * res[1], float(det["vshift"]))
+            stat = float(np.sqrt(east**2 + north**2))
+            if logging.getLogger().getEffectiveLevel() <= logging.INFO:
+                logging.info("      Iteration #%d - Offset: %s; Magnitude: %s", i + 1, offsets, stat)
+            if i > 1 and stat < tolerance:
+                logging.info("   Last offset was below the residual offset threshold of %s -> stopping", tolerance)
+                break
+        return offsets, plan.n_valid
+    finally:
+        plan.close()
+
+
+class NuthKaab:
+    """Nuth and Kaab (2011) coregistration: horizontal and vertical translations by iterative slope/aspect alignment.
+
+    Constructor mirrors ``xdem.coreg.NuthKaab.__init__`` (xdem/coreg/affine.py:2397-2456).  ``fit`` takes the two DEMs
+    as arrays on the same grid plus ``resolution`` (the reference gets it from the raster transform); estimated shifts
+    land in ``self.meta["outputs"]["affine"]`` as ``shift_x = -easting``, ``shift_y = -northing``,
+    ``shift_z = vertical * vertical_shift`` (affine.py:2526-2530).
+    """
+
+    def __init__(self, max_iterations: int = 10, offset_threshold: float = 0.001, bin_before_fit: bool = True,
+                 fit_optimizer: Callable[..., Any] | None = None, bin_sizes: int = 72,
+                 bin_statistic: Callable[[np.ndarray], Any] = np.nanmedian, subsample: int | float = 5e5,
+                 vertical_shift: bool = True, initial_shift=None) -> None:
+        import scipy.optimize
+
+        if not bin_before_fit:
+            raise NotImplementedError("xdem_amd.NuthKaab implements the default bin_before_fit=True path only.")
+        if bin_statistic not in (np.nanmedian, np.median):
+            raise NotImplementedError("xdem_amd.NuthKaab bins with the exact median (the reference default np.nanmedian).")
+        if not isinstance(bin_sizes, (int, np.integer)):
+            raise NotImplementedError("bin_sizes must be an integer number of aspect bins (reference default 72).")
+        if initial_shift is not None:
+            raise NotImplementedError("initial_shift is applied by the reference outside the hot path; pre-shift the DEM instead.")
+        self.vertical_shift = vertical_shift
+        self.meta: dict[str, Any] = {
+            "inputs": {
+                "iterative": {"max_iterations": max_iterations, "tolerance": offset_threshold},
+                "fitorbin": {"fit_or_bin": "bin_and_fit", "fit_func": _nuth_kaab_fit_func,
+                             "fit_optimizer": fit_optimizer or scipy.optimize.curve_fit, "bin_sizes": int(bin_sizes),
+                             "bin_statistic": bin_statistic},
+                "random": {"subsample": subsample, "random_state": None},
+                "affine": {"apply_vshift": vertical_shift},
+            },
+            "outputs": {},
+        }
+
+    def fit(self, reference_elev: np.ndarray, to_be_aligned_elev: np.ndarray, inlier_mask: np.ndarray | None = None,
+            resolution: float | tuple[float, float] | None = None, subsample: int | float | None = None,
+            random_state=None, **kwargs: Any) -> "NuthKaab":
+        """Estimate the x/y/z offset between two DEMs given as arrays on the same grid (Coreg.fit, base.py:2250-2368)."""
+        if subsample is not None:
+            self.meta["inputs"]["random"]["subsample"] = subsample
+        if self.meta["inputs"]["random"]["subsample"] != 1:
+            raise NotImplementedError(
+                "xdem_amd.NuthKaab runs on all valid pixels: pass subsample=1 (the reference default of 5e5 random "
+                "points relies on geoutils' subsample_array, which is outside the hot path)."
+            )
+        if resolution is None:
+            raise ValueError("'resolution' must be provided when passing arrays.")
+        res = (float(resolution), float(resolution)) if np.isscalar(resolution) else (float(resolution[0]), float(resolution[1]))
+        ref = np.asarray(reference_elev.filled(np.nan) if isinstance(reference_elev, np.ma.MaskedArray) else reference_elev)
+        tba = np.asarray(to_be_aligned_elev.filled(np.nan) if isinstance(to_be_aligned_elev, np.ma.MaskedArray) else to_be_aligned_elev)
+        it = self.meta["inputs"]["iterative"]
+        fb = self.meta["inputs"]["fitorbin"]
+        (east, north, vert), n_final = nuth_kaab(ref, tba, inlier_mask, res, tolerance=it["tolerance"],
+                                                 max_iterations=it["max_iterations"], bin_sizes=fb["bin_sizes"],
+                                                 fit_optimizer=fb["fit_optimizer"])
+        self.meta["outputs"]["affine"] = {"shift_x": -east, "shift_y": -north, "shift_z": vert * self.vertical_shift}
+        self.meta["outputs"]["random"] = {"subsample_final": n_final}
+        return self
+
+    def to_matrix(self) -> np.ndarray:
+        """4x4 translation matrix (affine.py:2532-2541)."""
+        m = np.diag(np.ones(4, dtype=float))
+        m[0, 3] += self.meta["outputs"]["affine"]["shift_x"]
+        m[1, 3] += self.meta["outputs"]["affine"]["shift_y"]
+        m[2, 3] += self.meta["outputs"]["affine"]["shift_z"]
+        return m

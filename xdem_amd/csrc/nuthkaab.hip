@@ -1,0 +1,559 @@
+// nuthkaab.hip -- Nuth & Kaab (2011) inner loop on gfx950: everything of one iteration that touches the grids.
+//
+// Replaces, for raster-raster input (xdem/coreg/affine.py):
+//   _nuth_kaab_aux_vars 412-474 (+ zero-slope removal 578-579, valid mask base.py:650-661)   -> nk_aux_kernel (once)
+//   _nuth_kaab_iteration_step 477-536:  dh = ref - tba(shifted)                                  -> nk_dh_kernel
+//                                       vshift = nanmedian(dh)                                  -> radix select (select.h)
+//   _nuth_kaab_bin_fit 358-409:         y = dh / slope_tan, nanmean / nanstd                     -> nk_y_kernel
+//                                       binned_statistic(aspect, y, np.nanmedian, 72)            -> bin ids + radix select
+// The 72-point curve_fit stays on the host (scipy), exactly as in the reference.
+//
+// All kernels are streaming passes over row-major grids (coalesced 4-byte lanes, grid-stride), i.e. HBM-bound;
+// the per-bin histograms live in LDS (ds_add_u32) and are flushed once per workgroup.  Float arithmetic that the
+// reference does in the DEM dtype uses the non-contracting *_rn intrinsics so results are bit-identical to NumPy.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "select.h"
+
+namespace xd {
+
+// ---- dtype-exact arithmetic ---------------------------------------------------------------------------------
+// Plain operators under `fp contract(off)`: hipcc then emits IEEE-correctly-rounded add / mul / div / sqrt (its
+// default -fhip-fp32-correctly-rounded-divide-sqrt) and never fuses a*b+c.  (The __f*_rn intrinsics are NOT strict
+// in HIP: __fsqrt_rn is the 1-ulp native square root and __fmul_rn / __fadd_rn may be contracted.)
+#pragma clang fp contract(off)
+template <typename T> __device__ __forceinline__ T t_sub(T a, T b) { return a - b; }
+template <typename T> __device__ __forceinline__ T t_add(T a, T b) { return a + b; }
+template <typename T> __device__ __forceinline__ T t_mul(T a, T b) { return a * b; }
+template <typename T> __device__ __forceinline__ T t_div(T a, T b) { return a / b; }
+__device__ __forceinline__ float t_sqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ double t_sqrt(double a) { return sqrt(a); }
+template <typename T> __device__ __forceinline__ bool t_finite(T v) { return fabs((double)v) <= 1.79769313486231570e308 && v == v; }
+template <> __device__ __forceinline__ bool t_finite<float>(float v) { return fabsf(v) <= 3.402823466e38f; }
+
+// 64-bit keys are `unsigned long` on Linux; HIP's atomics / shuffles want `unsigned long long`
+__device__ __forceinline__ void k_atomic_min(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+__device__ __forceinline__ void k_atomic_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+__device__ __forceinline__ void k_atomic_min(uint64_t* p, uint64_t v) { atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+__device__ __forceinline__ void k_atomic_max(uint64_t* p, uint64_t v) { atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+__device__ __forceinline__ uint32_t k_shfl_down(uint32_t v, int off) { return __shfl_down(v, off); }
+__device__ __forceinline__ uint64_t k_shfl_down(uint64_t v, int off) { return (uint64_t)__shfl_down((unsigned long long)v, off); }
+
+// ---- aux: gradient -> slope tangent, aspect, valid mask --------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nk_aux_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
+                                                     const uint8_t* __restrict__ inlier, int64_t H, int64_t W,
+                                                     T* __restrict__ slope_tan, T* __restrict__ aspect,
+                                                     uint8_t* __restrict__ valid, unsigned long long* n_valid) {
+    const int64_t n = H * W;
+    unsigned long long local = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = p / W, j = p - i * W;
+        const T c = ref[p];
+        T gy, gx;
+        // np.gradient, unit spacing: central differences inside, one-sided on the borders
+        if (i == 0) gy = t_sub(ref[p + W], c);
+        else if (i == H - 1) gy = t_sub(c, ref[p - W]);
+        else gy = t_div(t_sub(ref[p + W], ref[p - W]), (T)2);
+        if (j == 0) gx = t_sub(ref[p + 1], c);
+        else if (j == W - 1) gx = t_sub(c, ref[p - 1]);
+        else gx = t_div(t_sub(ref[p + 1], ref[p - 1]), (T)2);
+        T st = t_sqrt(t_add(t_mul(gx, gx), t_mul(gy, gy)));
+        // aspect = arctan2(-gx, gy) + pi: correctly rounded to the DEM dtype from the float64 arctangent
+        T as = (T)atan2(-(double)gx, (double)gy);
+        as = t_add(as, (T)3.14159265358979323846);
+        if (fabs((double)st) <= 1e-8) st = (T)NAN;  // np.isclose(slope_tan, 0) -> NaN (affine.py:578-579)
+        const bool ok = (inlier ? inlier[p] != 0 : true) && t_finite(c) && t_finite(tba[p]) && t_finite(st) && t_finite(as);
+        slope_tan[p] = st;
+        aspect[p] = as;
+        valid[p] = ok ? 1 : 0;
+        local += ok ? 1 : 0;
+    }
+    // wave reduction then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_valid, local);
+}
+
+// ---- dh at a shifted position (stated bilinear convention) + first histogram digit of its global median -------
+template <typename T> struct DhStats {
+    typename KeyT<T>::type asp_min, asp_max;  // order-preserving keys of min / max aspect among finite dh
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
+                                                    const uint8_t* __restrict__ valid, const T* __restrict__ aspect,
+                                                    int64_t H, int64_t W, double dr, double dc, T* __restrict__ dh,
+                                                    DhStats<T>* stats) {
+    typedef typename KeyT<T>::type K;
+    const int64_t n = H * W;
+    K kmin = ~(K)0, kmax = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        T out = (T)NAN;
+        if (valid[p]) {
+            const int64_t i = p / W, j = p - i * W;
+            const double rr = t_add((double)i, dr), cc = t_add((double)j, dc);
+            const double r0f = floor(rr), c0f = floor(cc);
+            const double fr = t_sub(rr, r0f), fc = t_sub(cc, c0f);
+            const int64_t r0 = (int64_t)r0f, c0 = (int64_t)c0f;
+            if (r0 >= 0 && r0 + 1 < H && c0 >= 0 && c0 + 1 < W) {
+                const T* q = tba + r0 * W + c0;
+                const T a00 = q[0], a01 = q[1], a10 = q[W], a11 = q[W + 1];
+                if (t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11)) {
+                    const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
+                    const double top = t_add(v00, t_mul(fc, t_sub(v01, v00)));
+                    const double bot = t_add(v10, t_mul(fc, t_sub(v11, v10)));
+                    const double val = t_add(top, t_mul(fr, t_sub(bot, top)));
+                    out = t_sub(ref[p], (T)val);
+                    if (t_finite(out)) {
+                        const K ka = key_of(aspect[p]);
+                        kmin = ka < kmin ? ka : kmin;
+                        kmax = ka > kmax ? ka : kmax;
+                    } else {
+                        out = (T)NAN;
+                    }
+                }
+            }
+        }
+        dh[p] = out;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const K a = k_shfl_down(kmin, off), b = k_shfl_down(kmax, off);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (kmin != ~(K)0) k_atomic_min(&stats->asp_min, kmin);
+        if (kmax != 0) k_atomic_max(&stats->asp_max, kmax);
+    }
+}
+
+// ---- y = (dh - vshift) / slope_tan, aspect bin id, sums for nanmean / nanstd --------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, const T* __restrict__ slope_tan,
+                                                   const T* __restrict__ aspect, int64_t n, T vshift,
+                                                   const T* __restrict__ edges, int nb, T* __restrict__ y,
+                                                   uint16_t* __restrict__ bins, double* sums /* [sum, sumsq] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* e = reinterpret_cast<T*>(smem);
+    for (int k = threadIdx.x; k <= nb; k += blockDim.x) e[k] = edges[k];
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const T d = dh[p];
+        T yv = (T)NAN;
+        uint16_t b = 0xFFFF;
+        if (d == d) {  // dh is NaN wherever the pixel is unusable
+            yv = t_div(t_sub(d, vshift), slope_tan[p]);
+            const T x = aspect[p];
+            // np.digitize(x, edges): number of edges <= x; a sample equal to the last edge goes to the last bin
+            int lo = 0, hi = nb + 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (e[mid] <= x) lo = mid + 1; else hi = mid;
+            }
+            int idx = lo - 1;
+            if (idx == nb) idx = nb - 1;
+            b = (idx >= 0 && idx < nb) ? (uint16_t)idx : 0xFFFF;
+            s1 += (double)yv;
+            s2 += (double)yv * (double)yv;
+        }
+        y[p] = yv;
+        bins[p] = b;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s1); atomicAdd(&sums[1], s2); }
+}
+
+// ---- generic histogram / successor passes over (values, bin ids) ----------------------------------------------
+// bins == nullptr: single bin (global median).  LDS: nb * 256 uint32 counters.
+template <typename T>
+__global__ __launch_bounds__(512) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
+                                                        int64_t n, int nb, int bin0, const SelState<typename KeyT<T>::type>* st,
+                                                        int shift, int first, uint64_t* hist) {
+    typedef typename KeyT<T>::type K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* h = reinterpret_cast<uint32_t*>(smem);
+    for (int k = threadIdx.x; k < nb * SEL_RADIX; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    const K himask = first ? (K)0 : (K)(~(K)0 << (shift + 8));
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const T v = vals[p];
+        if (v != v) continue;
+        int b = bins ? (int)bins[p] - bin0 : 0;
+        if (b < 0 || b >= nb) continue;
+        const K key = key_of(v);
+        if (!first && (key & himask) != st[bin0 + b].prefix) continue;
+        atomicAdd(&h[b * SEL_RADIX + (int)((key >> shift) & 0xFF)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb * SEL_RADIX; k += blockDim.x)
+        if (h[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[(size_t)bin0 * SEL_RADIX + k]), (unsigned long long)h[k]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void succ_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
+                                                        int64_t n, int nb, SelState<typename KeyT<T>::type>* st) {
+    typedef typename KeyT<T>::type K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    K* m = reinterpret_cast<K*>(smem);
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) m[k] = ~(K)0;
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const T v = vals[p];
+        if (v != v) continue;
+        const int b = bins ? (int)bins[p] : 0;
+        if (b < 0 || b >= nb) continue;
+        const K key = key_of(v);
+        if (key > st[b].prefix && key < m[b]) k_atomic_min(&m[b], key);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += blockDim.x)
+        if (m[k] != ~(K)0) k_atomic_min(&st[k].succ, m[k]);
+}
+
+}  // namespace xd
+
+// ================================================================================================================
+using namespace xd;
+
+struct xdemhip_nk_plan {
+    xdemhip_ctx* ctx = nullptr;
+    int dtype = XDEMHIP_F32;
+    int64_t H = 0, W = 0;
+    void *ref = nullptr, *tba = nullptr;  // device (owned when own_inputs)
+    bool own_inputs = false;
+    void *slope_tan = nullptr, *aspect = nullptr, *dh = nullptr, *y = nullptr;
+    uint8_t* valid = nullptr;
+    uint16_t* bins = nullptr;
+    void* scratch = nullptr;  // states, histograms, stats, sums, edges
+    size_t scratch_bytes = 0;
+    int max_bins = 0;
+    long long n_valid0 = 0;
+};
+
+namespace {
+
+constexpr int MAX_BINS_PER_SWEEP = 128;  // 128 * 256 * 4 B = 128 KiB of LDS histograms per workgroup
+
+template <typename F> int set_big_lds(xdemhip_ctx* ctx, F func, size_t bytes) {
+    if (bytes > 48 * 1024) XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return XDEMHIP_OK;
+}
+
+int grid_for(const xdemhip_ctx* ctx, int64_t n, int block, int per_cu) {
+    int64_t g = (n + block - 1) / block;
+    const int64_t cap = (int64_t)ctx->num_cu * per_cu;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// scratch layout (bytes): [0, 16384) bin edges | +0 stats | +64 sums | +128 selection states | histograms
+constexpr size_t OFF_STATS = 16384, OFF_SUMS = OFF_STATS + 64, OFF_STATE = OFF_STATS + 128;
+size_t off_hist(int nb) { return OFF_STATE + (size_t)(nb > 1 ? nb : 1) * 64; }
+size_t scratch_size(int nb) { return off_hist(nb) + (size_t)(nb > 1 ? nb : 1) * SEL_RADIX * 8 + 256; }
+
+// Exact lower/upper medians of vals[] per bin (bins == nullptr: one bin).  Results: per-bin count, lo, hi values.
+template <typename T>
+int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, void* d_state, uint64_t* d_hist,
+               std::vector<SelState<typename KeyT<T>::type>>& host_state) {
+    typedef typename KeyT<T>::type K;
+    SelState<K>* st = static_cast<SelState<K>*>(d_state);
+    XD_HIP_CHECK(ctx, hipMemsetAsync(st, 0, sizeof(SelState<K>) * nb, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * (size_t)nb * SEL_RADIX, ctx->stream));
+    const int passes = KeyT<T>::passes;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * (passes - 1 - p);
+        for (int b0 = 0; b0 < nb; b0 += MAX_BINS_PER_SWEEP) {
+            const int nbs = (nb - b0) < MAX_BINS_PER_SWEEP ? (nb - b0) : MAX_BINS_PER_SWEEP;
+            const size_t lds = (size_t)nbs * SEL_RADIX * sizeof(uint32_t);
+            int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, lds > 64 * 1024 ? 1 : 2)), dim3(512), lds,
+                               ctx->stream, vals, bins, n, nbs, b0, st, shift, (int)(p == 0), d_hist);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL((select_advance_kernel<K>), dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
+                           (int)(p == 0), (int)(p == passes - 1));
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    const size_t lds = sizeof(K) * nb;
+    hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, 2)), dim3(512), lds, ctx->stream, vals, bins, n, nb, st);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    host_state.resize(nb);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(host_state.data(), st, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
+// np.nanmedian of a bin from its selection state: odd count -> the middle value; even -> mean of the two middle
+// values in the value dtype (np.mean of a 2-element array).
+template <typename T> double median_from(const SelState<typename KeyT<T>::type>& s) {
+    if (s.count == 0) return NAN;
+    const T lo = val_of(s.prefix);
+    if (s.count & 1) return (double)lo;
+    const uint64_t k2 = s.count / 2;  // 0-based rank of the upper median
+    const T hi = (s.n_le > k2) ? lo : val_of(s.succ);
+    return (double)(T)((T)(lo + hi) / (T)2);
+}
+
+// np.linspace(smin, smax, nb + 1) in double (k * step + start, end point forced), cast to T -- SciPy's _bin_edges
+template <typename T> void make_edges(double smin, double smax, int nb, std::vector<T>& e) {
+    if (smin == smax) { smin -= 0.5; smax += 0.5; }
+    e.resize(nb + 1);
+    const double step = (smax - smin) / nb;
+    for (int k = 0; k <= nb; ++k) e[k] = (T)((double)k * step + smin);
+    e[nb] = (T)smax;
+}
+
+template <typename T> int nk_create_typed(xdemhip_nk_plan* P, const uint8_t* d_inlier) {
+    xdemhip_ctx* ctx = P->ctx;
+    const int64_t n = P->H * P->W;
+    unsigned long long* d_cnt = static_cast<unsigned long long*>(P->scratch);
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    hipLaunchKernelGGL((nk_aux_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+                       static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), d_inlier, P->H, P->W,
+                       static_cast<T*>(P->slope_tan), static_cast<T*>(P->aspect), P->valid, d_cnt);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    unsigned long long c = 0;
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(&c, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    P->n_valid0 = (long long)c;
+    return XDEMHIP_OK;
+}
+
+template <typename T>
+int binned_median_device(xdemhip_ctx* ctx, const T* d_x, const T* d_y, int64_t n, int nb, T* d_ybuf, uint16_t* d_bins,
+                         void* scratch, const std::vector<T>& edges, double* out_edges, int64_t* counts, double* medians) {
+    typedef typename KeyT<T>::type K;
+    unsigned char* base = static_cast<unsigned char*>(scratch);
+    void* d_state = base + OFF_STATE;
+    uint64_t* d_hist = reinterpret_cast<uint64_t*>(base + off_hist(nb));
+    (void)d_x; (void)d_y;
+    std::vector<SelState<K>> hs;
+    int rc = run_select<T>(ctx, d_ybuf, d_bins, n, nb, d_state, d_hist, hs);
+    if (rc) return rc;
+    for (int k = 0; k < nb; ++k) {
+        counts[k] = (int64_t)hs[k].count;
+        medians[k] = median_from<T>(hs[k]);
+    }
+    for (int k = 0; k <= nb; ++k) out_edges[k] = (double)edges[k];
+    return XDEMHIP_OK;
+}
+
+template <typename T>
+int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int nb, double* vshift,
+                  int64_t* n_valid, double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians) {
+    typedef typename KeyT<T>::type K;
+    xdemhip_ctx* ctx = P->ctx;
+    const int64_t n = P->H * P->W;
+    unsigned char* base = static_cast<unsigned char*>(P->scratch);
+    DhStats<T>* d_stats = reinterpret_cast<DhStats<T>*>(base + OFF_STATS);
+    double* d_sums = reinterpret_cast<double*>(base + OFF_SUMS);
+    void* d_state = base + OFF_STATE;
+    uint64_t* d_hist = reinterpret_cast<uint64_t*>(base + off_hist(nb));
+
+    // 1. dh at the shifted position: tba sampled at (row - shift_y / res_y, col + shift_x / res_x)
+    DhStats<T> hs0;
+    hs0.asp_min = ~(K)0;
+    hs0.asp_max = 0;
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_stats, &hs0, sizeof hs0, hipMemcpyHostToDevice, ctx->stream));
+    const double dr = -shift_y / res_y, dc = shift_x / res_x;
+    hipLaunchKernelGGL((nk_dh_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+                       static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect),
+                       P->H, P->W, dr, dc, static_cast<T*>(P->dh), d_stats);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+
+    // 2. vertical shift = exact nanmedian(dh)
+    std::vector<SelState<K>> g;
+    int rc = run_select<T>(ctx, static_cast<const T*>(P->dh), nullptr, n, 1, d_state, d_hist, g);
+    if (rc) return rc;
+    *n_valid = (int64_t)g[0].count;
+    if (g[0].count == 0)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
+    const double vs = median_from<T>(g[0]);
+    *vshift = vs;
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(&hs0, d_stats, sizeof hs0, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+
+    // 3. y = (dh - vshift) / slope_tan, bin ids on SciPy's edges, sums
+    std::vector<T> edges;
+    make_edges<T>((double)val_of(hs0.asp_min), (double)val_of(hs0.asp_max), nb, edges);
+    T* d_edges = reinterpret_cast<T*>(base);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, edges.data(), sizeof(T) * (nb + 1), hipMemcpyHostToDevice, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
+    hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream,
+                       static_cast<const T*>(P->dh), static_cast<const T*>(P->slope_tan), static_cast<const T*>(P->aspect), n,
+                       (T)vs, d_edges, nb, static_cast<T*>(P->y), P->bins, d_sums);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+
+    // 4. per-bin exact medians
+    std::vector<SelState<K>> hs;
+    rc = run_select<T>(ctx, static_cast<const T*>(P->y), P->bins, n, nb, d_state, d_hist, hs);
+    if (rc) return rc;
+    double sums[2];
+    XD_HIP_CHECK(ctx, hipMemcpy(sums, d_sums, 16, hipMemcpyDeviceToHost));
+    const double cnt = (double)g[0].count;
+    const double mean = sums[0] / cnt;
+    double var = sums[1] / cnt - mean * mean;
+    *y_mean = mean;
+    *y_std = var > 0 ? sqrt(var) : 0.0;
+    for (int k = 0; k < nb; ++k) {
+        counts[k] = (int64_t)hs[k].count;
+        medians[k] = median_from<T>(hs[k]);
+    }
+    for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges[k];
+    return XDEMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
+    if (!P) return;
+    (void)hipSetDevice(P->ctx->device);
+    if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); }
+    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->scratch};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete P;
+}
+
+int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const uint8_t* inlier, int dtype, int64_t H, int64_t W,
+                      int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (!ref || !tba || !out_plan) return xd_fail(ctx, XDEMHIP_EINVAL, "null argument");
+    if (H < 2 || W < 2) return xd_fail(ctx, XDEMHIP_EINVAL, "Shape of array too small to calculate a numerical gradient, at least 2 elements are required.");
+    if (dtype != XDEMHIP_F32 && dtype != XDEMHIP_F64) return xd_fail(ctx, XDEMHIP_EINVAL, "dtype must be float32 or float64");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t es = dtype == XDEMHIP_F32 ? 4 : 8;
+    const size_t n = (size_t)H * (size_t)W;
+    xdemhip_nk_plan* P = new xdemhip_nk_plan();
+    P->ctx = ctx; P->dtype = dtype; P->H = H; P->W = W;
+    uint8_t* d_inlier = nullptr;
+    auto fail = [&](int code, const char* msg) { if (d_inlier && memspace == XDEMHIP_HOST) (void)hipFree(d_inlier); xdemhip_nk_destroy(P); return xd_fail(ctx, code, msg); };
+    if (memspace == XDEMHIP_HOST) {
+        P->own_inputs = true;
+        if (hipMalloc(&P->ref, n * es) != hipSuccess || hipMalloc(&P->tba, n * es) != hipSuccess) return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
+        if (hipMemcpyAsync(P->ref, ref, n * es, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(P->tba, tba, n * es, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "H2D copy failed");
+        if (inlier) {
+            if (hipMalloc(reinterpret_cast<void**>(&d_inlier), n) != hipSuccess) return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
+            if (hipMemcpyAsync(d_inlier, inlier, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "H2D copy failed");
+        }
+    } else {
+        P->ref = const_cast<void*>(ref);
+        P->tba = const_cast<void*>(tba);
+        d_inlier = const_cast<uint8_t*>(inlier);
+    }
+    P->max_bins = 1024;
+    P->scratch_bytes = scratch_size(P->max_bins);
+    if (hipMalloc(&P->slope_tan, n * es) != hipSuccess || hipMalloc(&P->aspect, n * es) != hipSuccess ||
+        hipMalloc(&P->dh, n * es) != hipSuccess || hipMalloc(&P->y, n * es) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&P->valid), n) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&P->bins), n * 2) != hipSuccess || hipMalloc(&P->scratch, P->scratch_bytes) != hipSuccess)
+        return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
+    int rc = dtype == XDEMHIP_F32 ? nk_create_typed<float>(P, d_inlier) : nk_create_typed<double>(P, d_inlier);
+    if (d_inlier && memspace == XDEMHIP_HOST) { (void)hipFree(d_inlier); d_inlier = nullptr; }
+    if (rc != XDEMHIP_OK) { xdemhip_nk_destroy(P); return rc; }
+    if (n_valid) *n_valid = P->n_valid0;
+    *out_plan = P;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_nk_get_aux(xdemhip_nk_plan* P, void* slope_tan, void* aspect, uint8_t* valid) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t es = P->dtype == XDEMHIP_F32 ? 4 : 8, n = (size_t)P->H * (size_t)P->W;
+    if (slope_tan) XD_HIP_CHECK(ctx, hipMemcpy(slope_tan, P->slope_tan, n * es, hipMemcpyDeviceToHost));
+    if (aspect) XD_HIP_CHECK(ctx, hipMemcpy(aspect, P->aspect, n * es, hipMemcpyDeviceToHost));
+    if (valid) XD_HIP_CHECK(ctx, hipMemcpy(valid, P->valid, n, hipMemcpyDeviceToHost));
+    return XDEMHIP_OK;
+}
+
+int xdemhip_nk_step(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int n_bins, double* vshift,
+                    int64_t* n_valid, double* y_mean, double* y_std, double* edges, int64_t* counts, double* medians) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (!vshift || !n_valid || !y_mean || !y_std || !edges || !counts || !medians) return xd_fail(ctx, XDEMHIP_EINVAL, "null output");
+    if (n_bins < 1 || n_bins > P->max_bins) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins out of range (1..1024)");
+    if (!(res_x > 0) || !(res_y > 0)) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    int rc = P->dtype == XDEMHIP_F32
+                 ? nk_step_typed<float>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, counts, medians)
+                 : nk_step_typed<double>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, counts, medians);
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+    ctx->timed = (rc == XDEMHIP_OK);
+    return rc;
+}
+
+// Stand-alone binned nanmedian: binned_statistic(x, y, np.nanmedian, n_bins) + counts on SciPy's edges.
+// (xdem/spatialstats.py:143-157 for one explanatory variable).  Non-finite (x, y) pairs are dropped like nd_binning does.
+int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
+                          int64_t* counts, double* medians) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (!x || !y || !edges || !counts || !medians || n <= 0) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    if (n_bins < 1 || n_bins > 1024) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins out of range (1..1024)");
+    if (dtype != XDEMHIP_F32 && dtype != XDEMHIP_F64) return xd_fail(ctx, XDEMHIP_EINVAL, "dtype must be float32 or float64");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // Host-side preparation mirrors nd_binning: keep finite pairs, edges from min / max of x, digitize on the device.
+    const size_t es = dtype == XDEMHIP_F32 ? 4 : 8;
+    void *d_x = nullptr, *d_y = nullptr, *d_one = nullptr, *d_dh = nullptr, *d_yb = nullptr, *scratch = nullptr;
+    uint16_t* d_bins = nullptr;
+    int rc = XDEMHIP_OK;
+    auto cleanup = [&]() { void* b[] = {d_x, d_y, d_one, d_dh, d_yb, scratch, d_bins}; for (void* p : b) if (p) (void)hipFree(p); };
+    // finite filter + min/max on the host (O(n), not the hot path of this helper)
+    double smin = INFINITY, smax = -INFINITY;
+    std::vector<unsigned char> xs((size_t)n * es), ys((size_t)n * es);
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double xv, yv;
+        if (dtype == XDEMHIP_F32) { xv = static_cast<const float*>(x)[i]; yv = static_cast<const float*>(y)[i]; }
+        else { xv = static_cast<const double*>(x)[i]; yv = static_cast<const double*>(y)[i]; }
+        if (!std::isfinite(xv) || !std::isfinite(yv)) continue;
+        memcpy(&xs[(size_t)m * es], static_cast<const unsigned char*>(x) + (size_t)i * es, es);
+        memcpy(&ys[(size_t)m * es], static_cast<const unsigned char*>(y) + (size_t)i * es, es);
+        smin = xv < smin ? xv : smin;
+        smax = xv > smax ? xv : smax;
+        ++m;
+    }
+    if (m == 0) { for (int k = 0; k < n_bins; ++k) { counts[k] = 0; medians[k] = NAN; } return XDEMHIP_OK; }
+    if (hipMalloc(&d_x, m * es) != hipSuccess || hipMalloc(&d_y, m * es) != hipSuccess || hipMalloc(&d_one, m * es) != hipSuccess ||
+        hipMalloc(&d_yb, m * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_bins), m * 2) != hipSuccess ||
+        hipMalloc(&scratch, scratch_size(n_bins)) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed"); }
+    (void)hipMemcpyAsync(d_x, xs.data(), m * es, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(d_y, ys.data(), m * es, hipMemcpyHostToDevice, ctx->stream);
+    unsigned char* base = static_cast<unsigned char*>(scratch);
+    double* d_sums = reinterpret_cast<double*>(base + OFF_SUMS);
+    (void)hipMemsetAsync(d_sums, 0, 16, ctx->stream);
+    if (dtype == XDEMHIP_F32) {
+        std::vector<float> e; make_edges<float>(smin, smax, n_bins, e);
+        std::vector<float> ones((size_t)m, 1.0f);
+        (void)hipMemcpyAsync(d_one, ones.data(), m * es, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(base, e.data(), sizeof(float) * (n_bins + 1), hipMemcpyHostToDevice, ctx->stream);
+        // reuse nk_y_kernel with vshift = 0 and slope_tan = 1: y passes through unchanged (y / 1 - 0 is exact)
+        hipLaunchKernelGGL((nk_y_kernel<float>), dim3(grid_for(ctx, m, 256, 16)), dim3(256), sizeof(float) * (n_bins + 1), ctx->stream,
+                           static_cast<const float*>(d_y), static_cast<const float*>(d_one), static_cast<const float*>(d_x), m, 0.0f,
+                           reinterpret_cast<const float*>(base), n_bins, static_cast<float*>(d_yb), d_bins, d_sums);
+        rc = binned_median_device<float>(ctx, nullptr, nullptr, m, n_bins, static_cast<float*>(d_yb), d_bins, scratch, e, edges, counts, medians);
+    } else {
+        std::vector<double> e; make_edges<double>(smin, smax, n_bins, e);
+        std::vector<double> ones((size_t)m, 1.0);
+        (void)hipMemcpyAsync(d_one, ones.data(), m * es, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(base, e.data(), sizeof(double) * (n_bins + 1), hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL((nk_y_kernel<double>), dim3(grid_for(ctx, m, 256, 16)), dim3(256), sizeof(double) * (n_bins + 1), ctx->stream,
+                           static_cast<const double*>(d_y), static_cast<const double*>(d_one), static_cast<const double*>(d_x), m, 0.0,
+                           reinterpret_cast<const double*>(base), n_bins, static_cast<double*>(d_yb), d_bins, d_sums);
+        rc = binned_median_device<double>(ctx, nullptr, nullptr, m, n_bins, static_cast<double*>(d_yb), d_bins, scratch, e, edges, counts, medians);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

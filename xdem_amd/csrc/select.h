@@ -1,0 +1,87 @@
+// select.h -- exact per-bin order statistics (medians) on the GPU by MSD radix selection.
+//
+// Medians are not sum-reducible, so the Nuth-Kaab aspect bins (np.nanmedian per bin,
+// xdem/coreg/affine.py:2404, xdem/spatialstats.py:143-157), the global vertical shift (np.nanmedian,
+// affine.py:504) and Dowd's variogram estimator (median of |differences| per lag) are all computed the same
+// way: the values are mapped to order-preserving unsigned keys and the k-th smallest key of every bin is
+// found digit by digit (8 bits per pass, most significant first).  One pass = every element whose key still
+// matches its bin's prefix increments an LDS histogram [bin][256] (ds_add_u32), the block flushes non-zero
+// counters to a global uint64 table, and a one-workgroup kernel advances each bin's (prefix, rank).  All
+// counting is integer, hence exact, order-independent and all-reducible across GPUs.  For an even count the
+// upper median is either the same value (duplicates) or the smallest key above it, found in one extra pass.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xd {
+
+constexpr int SEL_RADIX = 256;
+
+// order-preserving key of an IEEE float / double (NaN never gets here)
+__device__ __forceinline__ uint32_t key_of(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ uint64_t key_of(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return b ^ ((b >> 63) ? 0xFFFFFFFFFFFFFFFFull : 0x8000000000000000ull);
+}
+__host__ __device__ inline float val_of(uint32_t k) {
+    const uint32_t b = (k >> 31) ? (k ^ 0x80000000u) : ~k;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+__host__ __device__ inline double val_of(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+    double f;
+    __builtin_memcpy(&f, &b, 8);
+    return f;
+}
+template <typename T> struct KeyT;
+template <> struct KeyT<float> { typedef uint32_t type; static constexpr int passes = 4; };
+template <> struct KeyT<double> { typedef uint64_t type; static constexpr int passes = 8; };
+
+// Per-bin selection state kept on the device.
+template <typename K> struct SelState {
+    K prefix;          // key bits fixed so far (high digits)
+    K succ;            // smallest key > selected key (for even counts), all-ones if none
+    uint64_t rank;     // remaining 0-based rank inside the current prefix group
+    uint64_t count;    // elements in the bin
+    uint64_t n_le;     // elements <= selected key (valid after the last pass)
+};
+
+// Advance every bin by one digit: hist[bin][256] holds the counts of the current digit among the elements that
+// match the bin's prefix.  First pass (digit == top) also fixes count and the target rank (lower median).
+template <typename K>
+__global__ void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+        uint64_t* h = hist + (size_t)b * SEL_RADIX;
+        SelState<K> s = st[b];
+        if (first) {
+            uint64_t tot = 0;
+            for (int d = 0; d < SEL_RADIX; ++d) tot += h[d];
+            s.count = tot;
+            s.rank = tot ? (tot - 1) / 2 : 0;  // lower median
+            s.prefix = 0;
+            s.succ = ~(K)0;
+            s.n_le = 0;
+        }
+        if (s.count) {
+            uint64_t cum = 0;
+            int d = 0;
+            for (; d < SEL_RADIX - 1; ++d) {
+                if (cum + h[d] > s.rank) break;
+                cum += h[d];
+            }
+            s.prefix |= (K)d << shift;
+            s.n_le += cum;  // elements strictly below the chosen digit group
+            s.rank -= cum;
+            if (last) s.n_le += h[d];  // all digits fixed: group == the selected key's duplicates
+        }
+        st[b] = s;
+        for (int d = 0; d < SEL_RADIX; ++d) h[d] = 0;  // ready for the next pass
+    }
+}
+
+}  // namespace xd
