@@ -122,6 +122,34 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
                           int64_t* counts, double* medians);
 
+/* ---- path 3: empirical variogram, pairwise lag binning -----------------------------------------------
+ * Replaces the pairwise work sample_empirical_variogram delegates to scikit-gstat:
+ *   skg.Variogram(coordinates, values, bin_func=<right edges>, maxlag=, estimator=)      xdem/spatialstats.py:1091  (pdist)
+ *   skg.Variogram(RasterEquidistantMetricSpace / ProbabalisticMetricSpace, values, ...)  xdem/spatialstats.py:1247-1255 (cdist)
+ *   -> V.get_empirical(bin_center=False), V.bin_count
+ * A "pair set" is a list of blocks; block r pairs every point A_r[i] with every point B_r[j] (b_off != NULL), or
+ * all i < j inside A_r (b_off == NULL).  Points are SoA (x, y float64; value float32/float64), blocks concatenated,
+ * a_off / b_off hold n_blocks + 1 offsets.  Lag class k: right_edges[k-1] <= d < right_edges[k] (edges[-1] := 0);
+ * d >= right_edges[n_bins-1] is dropped.  Pairs with a NaN value difference are dropped.
+ *
+ *  xdemhip_pairs_sums   kind 0: sums[k] = sum |dv|^2 (Matheron), kind 1: sum sqrt|dv| (Cressie-Hawkins); counts[k]
+ *  xdemhip_pairs_hist   one radix-select pass for the exact per-class median of |dv| (Dowd): histogram (n_bins x 256,
+ *                       uint64) of key bits [shift, shift+8) among pairs whose higher key bits equal prefix[k]
+ *                       (first != 0: all pairs).  Keys are the order-preserving integer images of |dv|
+ *                       (32 bit for float32 values, 64 bit for float64).  The host advances the selection; integer
+ *                       histograms / counts can be summed over GPUs (all-reduce) before doing so.
+ *  xdemhip_pairs_succ   succ[k] = smallest key > key[k] in class k (all-ones if none): upper median of even classes.
+ */
+typedef struct xdemhip_pairs xdemhip_pairs;
+int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, const double* ax, const double* ay,
+                         const void* av, const int64_t* b_off, const double* bx, const double* by, const void* bv,
+                         int val_dtype, const double* right_edges, int n_bins, int memspace, xdemhip_pairs** out,
+                         int64_t* n_pairs);
+int xdemhip_pairs_sums(xdemhip_pairs* pairs, int kind, double* sums, int64_t* counts);
+int xdemhip_pairs_hist(xdemhip_pairs* pairs, int shift, int first, const uint64_t* prefix, uint64_t* hist);
+int xdemhip_pairs_succ(xdemhip_pairs* pairs, const uint64_t* key, uint64_t* succ);
+void xdemhip_pairs_destroy(xdemhip_pairs* pairs);
+
 #ifdef __cplusplus
 }
 #endif

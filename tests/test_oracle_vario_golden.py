@@ -1,0 +1,48 @@
+"""Pins the reference-owned host preparation of the variogram path (oracle/variogram_oracle.py) against vectors
+recorded from the reference; the scikit-gstat part is 'parity unpinned' (see the oracle header)."""
+import os
+
+import numpy as np
+
+import variogram_oracle as vo
+from conftest import GOLDEN
+
+
+def test_T7_sampling_parameter_table():
+    z = np.load(os.path.join(GOLDEN, "vario_golden.npz"))
+    n_ok = 0
+    for subsample, nx, ny, gsd, runs, samples, ratio in z["T7|params"]:
+        shape = (int(nx), int(ny))
+        extent = (0.0, (shape[0] - 1) * gsd, 0.0, (shape[1] - 1) * gsd)
+        if runs < 0:
+            try:
+                vo.choose_cdist_equidistant_sampling_parameters(int(subsample), extent, shape)
+                raise AssertionError("expected ValueError")
+            except ValueError:
+                continue
+        got = vo.choose_cdist_equidistant_sampling_parameters(int(subsample), extent, shape)
+        assert got[0] == int(runs) and got[1] == int(samples)  # integer work: exact
+        assert got[2] == ratio                                  # same float expression: bit-exact
+        n_ok += 1
+    assert n_ok >= 30
+    # the survey's probe: N0 = 1e7 -> runs = 100, samples = 223607
+    got = vo.choose_cdist_equidistant_sampling_parameters(10**7, (0, 19999, 0, 19999), (20000, 20000))
+    assert got[:2] == (100, 223607)
+
+
+def test_default_bin_edges_and_grid():
+    coords, extent, maxlag = vo.grid_coords_extent_maxlag((30, 40), 2.0)
+    assert coords.shape == (1200, 2) and extent == (0.0, 58.0, 0.0, 78.0)
+    e = vo.default_bin_edges(2.0, maxlag)
+    assert e[0] == np.sqrt(2) * 2.0 and e[-1] == maxlag and np.all(np.diff(e) > 0)
+    assert np.allclose(np.array(e[1:-1]) / np.array(e[:-2]), np.sqrt(2))
+
+
+def test_estimators_known_values():
+    d = np.array([1.0, 2.0, 3.0, 4.0])
+    assert vo._estimate(d, "matheron") == (1 + 4 + 9 + 16) / 8
+    assert vo._estimate(d, "dowd") == 2.198 * 2.5**2 / 2
+    assert np.isnan(vo._estimate(np.array([]), "matheron"))
+    # lag classes are [e_{k-1}, e_k): a distance equal to an edge opens the next class
+    g = vo.pair_groups(np.array([0.0]), np.array([0.0]), np.array([1.0, 2.0, 2.5, 5.0]), np.zeros(4), [1.0, 2.0, 5.0])
+    assert g.tolist() == [[1, 2, 2, -1]]

@@ -1,0 +1,141 @@
+"""GPU parity tests of the variogram path: pair kernels (through the C-ABI) vs the CPU oracle.
+Integer work (lag-class membership counts) bit-exact; Dowd (exact median) bit-exact; Matheron / Cressie sums within
+1e-12 relative (float64 accumulation order differs)."""
+import numpy as np
+import pytest
+
+import variogram_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ss():
+    from xdem_amd import spatialstats as s
+
+    return s
+
+
+def _pts(n, seed, dtype, extent=500.0, grid=True):
+    r = np.random.default_rng(seed)
+    if grid:
+        x = r.integers(0, int(extent), n).astype(np.float64)
+        y = r.integers(0, int(extent), n).astype(np.float64)
+    else:
+        x, y = r.uniform(0, extent, n), r.uniform(0, extent, n)
+    v = (np.sin(x / 40.0) + 0.3 * r.normal(size=n)).astype(dtype)
+    return x, y, v
+
+
+EDGES = [float(e) for e in vo.default_bin_edges(1.0, 700.0)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("estimator", ["matheron", "cressie", "dowd"])
+@pytest.mark.parametrize("mode", ["pdist", "cdist"])
+def test_pairs_vs_oracle(ss, dtype, estimator, mode):
+    if mode == "pdist":
+        blocks = [_pts(700, 1, dtype), _pts(301, 2, dtype, grid=False), _pts(2, 3, dtype), _pts(1, 4, dtype)]
+    else:
+        blocks = [_pts(300, 1, dtype) + _pts(1500, 2, dtype), _pts(257, 3, dtype, grid=False) + _pts(4097, 4, dtype, grid=False),
+                  _pts(1, 5, dtype) + _pts(3, 6, dtype)]
+    exp, count = ss.empirical_variogram_pairs(blocks, EDGES, estimator)
+    exp_o, count_o = vo.empirical_variogram_blocks(blocks, EDGES, estimator)
+    assert np.array_equal(count, count_o)  # class membership: bit-exact
+    assert np.array_equal(np.isnan(exp), np.isnan(exp_o))
+    ok = np.isfinite(exp_o)
+    if estimator == "dowd":
+        assert np.array_equal(exp[ok], exp_o[ok])  # exact medians
+    else:
+        assert np.allclose(exp[ok], exp_o[ok], rtol=1e-12, atol=0)
+
+
+def test_edge_inclusivity_and_nan(ss):
+    # distances exactly on an edge open the next class; NaN values never pair; beyond the last edge is dropped
+    ax, ay, av = np.array([0.0]), np.array([0.0]), np.array([1.0], np.float32)
+    bx = np.array([1.0, 2.0, 2.5, 5.0, 3.0, 4.0])
+    by = np.zeros(6)
+    bv = np.array([2.0, 4.0, 8.0, 16.0, np.nan, 3.0], np.float32)
+    edges = [1.0, 2.0, 5.0]
+    exp, count = ss.empirical_variogram_pairs([(ax, ay, av, bx, by, bv)], edges, "matheron")
+    assert count.tolist() == [0, 1, 3] and np.isnan(exp[0])
+    # the oracle has no NaN filter of its own (the reference drops NaN values before pairing): compare on the finite points
+    keep = np.isfinite(bv)
+    exp_o, count_o = vo.empirical_variogram_blocks([(ax, ay, av, bx[keep], by[keep], bv[keep])], edges, "matheron")
+    assert np.array_equal(count, count_o) and np.allclose(exp[1:], exp_o[1:], rtol=1e-14)
+    # 3-4-5 triangle: d == 5.0 exactly is outside [.., 5)
+    exp, count = ss.empirical_variogram_pairs([(np.array([0.0]), np.array([0.0]), av, np.array([3.0]), np.array([4.0]), av)], edges, "dowd")
+    assert count.sum() == 0 and np.isnan(exp).all()
+
+
+def test_dowd_even_odd_duplicates(ss):
+    x = np.arange(40, dtype=np.float64)
+    y = np.zeros(40)
+    v = np.repeat(np.arange(10), 4).astype(np.float32)  # many duplicate differences
+    for n in (5, 6, 39, 40):
+        blk = [(x[:n], y[:n], v[:n])]
+        exp, count = ss.empirical_variogram_pairs(blk, [2.0, 5.0, 100.0], "dowd")
+        exp_o, count_o = vo.empirical_variogram_blocks(blk, [2.0, 5.0, 100.0], "dowd")
+        assert np.array_equal(count, count_o) and np.array_equal(exp, exp_o, equal_nan=True)
+
+
+@pytest.mark.parametrize("method", ["cdist_equidistant", "cdist_point", "pdist_point"])
+@pytest.mark.parametrize("estimator", ["matheron", "dowd"])
+def test_sample_empirical_variogram_end_to_end(ss, method, estimator):
+    from xdem_amd.synth import fbm_numpy
+
+    vals = fbm_numpy((90, 120), hurst=0.3, seed=45, mean=0.0, std=2.0)
+    vals[10:14, 20:30] = np.nan
+    df = ss.sample_empirical_variogram(vals, gsd=5.0, subsample=120, subsample_method=method, random_state=42,
+                                       estimator=estimator)
+    # oracle composition with the same host preparation and RNG protocol
+    coords, extent, maxlag = vo.grid_coords_extent_maxlag(vals.shape, 5.0)
+    edges = vo.default_bin_edges(5.0, maxlag)
+    flat = vals.flatten()
+    valid = np.isfinite(flat)
+    seed = list(np.random.default_rng(42).choice(1, 1, replace=False))[0]
+    rng = np.random.default_rng(seed)
+    if method == "cdist_equidistant":
+        runs, samples, ratio = vo.choose_cdist_equidistant_sampling_parameters(120, extent, vals.shape)
+        blocks = vo.equidistant_blocks(coords, flat, valid, 5.0, runs, samples, ratio, rng)
+    elif method == "cdist_point":
+        idx = np.flatnonzero(valid)
+        a = rng.choice(idx, 120, replace=False)
+        b = rng.choice(idx, 120, replace=False)
+        blocks = [(coords[a, 0], coords[a, 1], flat[a], coords[b, 0], coords[b, 1], flat[b])]
+    else:
+        a = rng.choice(np.flatnonzero(valid), 120, replace=False)
+        blocks = [(coords[a, 0], coords[a, 1], flat[a])]
+    exp_o, count_o = vo.empirical_variogram_blocks(blocks, edges, estimator)
+    assert list(df.columns) == ["exp", "lags", "count", "err_exp"]
+    assert len(df) == len(edges) - 1 and df["count"].dtype == np.int64
+    assert np.array_equal(df["lags"].values, np.array(edges[:-1]))
+    assert np.array_equal(df["count"].values, count_o[:-1])
+    assert np.allclose(df["exp"].values, exp_o[:-1], rtol=1e-12, equal_nan=True)
+    assert df["err_exp"].isna().all()
+    assert df["count"].sum() > 1000
+
+
+def test_multiple_runs_aggregate(ss):
+    from xdem_amd.synth import fbm_numpy
+
+    vals = fbm_numpy((64, 64), hurst=0.3, seed=1, mean=0.0, std=1.0)
+    df = ss.sample_empirical_variogram(vals, gsd=1.0, subsample=60, n_variograms=3, random_state=7)
+    assert np.isfinite(df["err_exp"].values).any() and (df["count"] >= 0).all()
+    with pytest.raises(ValueError, match="2D when using"):
+        ss.sample_empirical_variogram(vals.ravel(), gsd=1.0)
+    with pytest.raises(TypeError, match="subsampling method"):
+        ss.sample_empirical_variogram(vals, gsd=1.0, subsample_method="nope")
+
+
+def test_large_pair_count_properties(ss):
+    """2e4-point pdist (2e8 pairs): counts sum to N(N-1)/2; a cdist block gives the same classes with A and B swapped."""
+    x, y, v = _pts(20000, 9, np.float32, extent=4000.0, grid=False)
+    edges = [float(e) for e in vo.default_bin_edges(1.0, 7000.0)]
+    exp, count = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron")
+    assert count.sum() == 20000 * 19999 // 2
+    h = 10000
+    e1, c1 = ss.empirical_variogram_pairs([(x[:h], y[:h], v[:h], x[h:], y[h:], v[h:])], edges, "dowd")
+    e2, c2 = ss.empirical_variogram_pairs([(x[h:], y[h:], v[h:], x[:h], y[:h], v[:h])], edges, "dowd")
+    assert np.array_equal(c1, c2) and np.array_equal(e1, e2, equal_nan=True)
+    assert c1.sum() == h * h

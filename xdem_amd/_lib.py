@@ -67,6 +67,15 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_nk_destroy.restype = None
         L.xdemhip_binned_median.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                             c_dp, c_i64p, c_dp]
+        c_u64p = ctypes.POINTER(ctypes.c_uint64)
+        L.xdemhip_pairs_create.argtypes = [c_ctx, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p]
+        L.xdemhip_pairs_sums.argtypes = [ctypes.c_void_p, ctypes.c_int, c_dp, c_i64p]
+        L.xdemhip_pairs_hist.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_u64p, c_u64p]
+        L.xdemhip_pairs_succ.argtypes = [ctypes.c_void_p, c_u64p, c_u64p]
+        L.xdemhip_pairs_destroy.argtypes = [ctypes.c_void_p]
+        L.xdemhip_pairs_destroy.restype = None
         _lib = L
         return L
 

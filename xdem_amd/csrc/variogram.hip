@@ -1,0 +1,385 @@
+// variogram.hip -- pairwise lag binning of the empirical variogram on gfx950.
+//
+// Replaces the pairwise work the reference hands to scikit-gstat from sample_empirical_variogram
+// (xdem/spatialstats.py:1091 pdist, 1247-1255 cdist): for every pair of a "pair block" (every point of set A with
+// every point of set B, or all i < j inside A) take the Euclidean distance d and the absolute value difference,
+// assign the lag class k with e_{k-1} <= d < e_k from explicit right edges, and reduce per class:
+//   sums   -> count and sum(diff^2) (Matheron) or sum(sqrt diff) (Cressie-Hawkins)
+//   hist   -> one 8-bit digit histogram of the diff keys per class (exact median for Dowd, select.h)
+//   succ   -> smallest key above the selected one (upper median of an even-sized class)
+// This is O(N^2) arithmetic over O(N) bytes: points are staged in LDS and re-used 256x, HBM traffic is negligible
+// and the bound is VALU + LDS-atomic throughput (no MFMA: there is no contraction, every pair ends in a scatter).
+//
+// One workgroup = 256 points of A (one per lane, in registers) x a chunk of B streamed through LDS in tiles of 256
+// (all lanes read the same B element: LDS broadcast, conflict-free).  Class lookup is a binary search over
+// thresholds on the SQUARED distance that are exact images of the edges under sqrt (computed on the host), so the
+// class is bit-identical to comparing the rounded float64 distance with the edges.  Accumulators live in LDS
+// (ds_add_u32 / ds_add_f64 / ds_min) and are flushed once per workgroup with global atomics; counts and histograms
+// are integers, hence exact and all-reducible across GPUs.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "select.h"
+
+namespace xd {
+
+#pragma clang fp contract(off)
+
+constexpr int PT = 256;      // points per tile
+constexpr int BCHUNK = 4096;  // B points per workgroup
+
+enum { OP_SUMS_SQ = 0, OP_SUMS_SQRT = 1, OP_HIST = 2, OP_SUCC = 3 };
+
+template <typename T> struct PairArgs {
+    const double *ax, *ay, *bx, *by;
+    const T *av, *bv;
+    const int64_t *a_off, *b_off;  // per block [nblk + 1]
+    const int64_t* wg_off;         // workgroups before each block [nblk + 1]
+    int nblk, nb, pdist;
+    const double* thr;  // nb thresholds on d^2
+    // outputs / state
+    double* sums;                  // [nb]
+    unsigned long long* counts;    // [nb]
+    unsigned long long* hist;      // [nb][256]
+    const typename KeyT<T>::type* prefix;  // [nb] selection prefix (hist) or selected key (succ)
+    unsigned long long* succ;              // [nb] 8-byte slots, all-ones = none
+    int shift, first, bin0, nbs;   // hist digit, first pass flag, LDS sweep window [bin0, bin0 + nbs)
+};
+
+template <typename K> __device__ __forceinline__ void lds_min(K* p, K v);
+template <> __device__ __forceinline__ void lds_min<uint32_t>(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+template <> __device__ __forceinline__ void lds_min<uint64_t>(uint64_t* p, uint64_t v) {
+    atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(PT) void pairs_kernel(const PairArgs<T> a) {
+    typedef typename KeyT<T>::type K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* s_bx = reinterpret_cast<double*>(smem);
+    double* s_by = s_bx + PT;
+    double* s_thr = s_by + PT;                       // nb
+    K* s_pref = reinterpret_cast<K*>(s_thr + a.nb);  // nb selection prefixes / selected keys (8-byte slots)
+    T* s_bv = reinterpret_cast<T*>(reinterpret_cast<uint64_t*>(s_pref) + a.nb);  // PT
+    unsigned char* acc = reinterpret_cast<unsigned char*>(s_bv + PT);            // PT * sizeof(T) is a multiple of 8
+    double* s_sum = reinterpret_cast<double*>(acc);                 // OP_SUMS: nb doubles
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_sum + a.nb);    //          nb counters
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(acc);            // OP_HIST: nbs * 256
+    K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
+
+    const int tid = threadIdx.x;
+    for (int k = tid; k < a.nb; k += PT) s_thr[k] = a.thr[k];
+    if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
+        for (int k = tid; k < a.nb; k += PT) { s_sum[k] = 0.0; s_cnt[k] = 0; }
+    if (OP == OP_HIST)
+        for (int k = tid; k < a.nbs * SEL_RADIX; k += PT) s_hist[k] = 0;
+    if (OP == OP_SUCC)
+        for (int k = tid; k < a.nb; k += PT) s_min[k] = ~(K)0;
+    if ((OP == OP_HIST && !a.first) || OP == OP_SUCC)
+        for (int k = tid; k < a.nb; k += PT) s_pref[k] = a.prefix[k];
+
+    // which block / A tile / B chunk is this workgroup?
+    const int64_t wg = blockIdx.x;
+    int lo = 0, hi = a.nblk;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.wg_off[mid] <= wg) lo = mid; else hi = mid;
+    }
+    const int r = lo;
+    const int64_t a0 = a.a_off[r], na = a.a_off[r + 1] - a0;
+    const int64_t b0 = a.pdist ? a0 : a.b_off[r], nbp = a.pdist ? na : a.b_off[r + 1] - b0;
+    const int64_t nchunk = (nbp + BCHUNK - 1) / BCHUNK;
+    const int64_t local = wg - a.wg_off[r];
+    const int64_t ta = local / nchunk, cb = local - ta * nchunk;
+    const int64_t ia = ta * PT + tid;  // index inside the block's A set
+    const int64_t jb0 = cb * BCHUNK, jb1 = (jb0 + BCHUNK < nbp) ? jb0 + BCHUNK : nbp;
+    const bool have_a = ia < na;
+    const bool skip_wg = a.pdist && (jb1 <= ta * PT + 1);  // whole chunk at or below the diagonal: no i < j pair
+    double px = 0.0, py = 0.0;
+    T pv = 0;
+    if (have_a) { px = a.ax[a0 + ia]; py = a.ay[a0 + ia]; pv = a.av[a0 + ia]; }
+    const double* gbx = a.pdist ? a.ax : a.bx;
+    const double* gby = a.pdist ? a.ay : a.by;
+    const T* gbv = a.pdist ? a.av : a.bv;
+    const int nb = a.nb;
+    const K himask = (OP == OP_HIST && !a.first) ? (K)(~(K)0 << (a.shift + 8)) : (K)0;
+
+    if (!skip_wg)
+        for (int64_t j0 = jb0; j0 < jb1; j0 += PT) {
+            __syncthreads();
+            const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
+            if (tid < cnt) {
+                s_bx[tid] = gbx[b0 + j0 + tid];
+                s_by[tid] = gby[b0 + j0 + tid];
+                s_bv[tid] = gbv[b0 + j0 + tid];
+            }
+            __syncthreads();
+            if (!have_a) continue;
+            for (int j = 0; j < cnt; ++j) {
+                if (a.pdist && (j0 + j) <= ia) continue;  // i < j only
+                const double dx = px - s_bx[j], dy = py - s_by[j];
+                const double s2 = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
+                // class = number of thresholds <= s2
+                int l = 0, h = nb;
+                while (l < h) {
+                    const int m = (l + h) >> 1;
+                    if (s_thr[m] <= s2) l = m + 1; else h = m;
+                }
+                if (l >= nb) continue;  // beyond the last edge (maxlag)
+                T d = pv - s_bv[j];
+                d = d < 0 ? -d : d;
+                if (d != d) continue;  // NaN values never form a pair
+                if (OP == OP_SUMS_SQ) {
+                    atomicAdd(&s_cnt[l], 1u);
+                    atomicAdd(&s_sum[l], (double)d * (double)d);
+                } else if (OP == OP_SUMS_SQRT) {
+                    atomicAdd(&s_cnt[l], 1u);
+                    atomicAdd(&s_sum[l], sqrt((double)d));
+                } else if (OP == OP_HIST) {
+                    const int lb = l - a.bin0;
+                    if (lb < 0 || lb >= a.nbs) continue;
+                    const K key = key_of(d);
+                    if (!a.first && (key & himask) != s_pref[l]) continue;
+                    atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
+                } else {
+                    const K key = key_of(d);
+                    if (key > s_pref[l] && key < s_min[l]) lds_min<K>(&s_min[l], key);
+                }
+            }
+        }
+    __syncthreads();
+    if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) {
+        for (int k = tid; k < nb; k += PT)
+            if (s_cnt[k]) { atomicAdd(&a.counts[k], (unsigned long long)s_cnt[k]); atomicAdd(&a.sums[k], s_sum[k]); }
+    } else if (OP == OP_HIST) {
+        for (int k = tid; k < a.nbs * SEL_RADIX; k += PT)
+            if (s_hist[k]) atomicAdd(&a.hist[(size_t)a.bin0 * SEL_RADIX + k], (unsigned long long)s_hist[k]);
+    } else {
+        for (int k = tid; k < nb; k += PT)
+            if (s_min[k] != ~(K)0) atomicMin(&a.succ[k], (unsigned long long)s_min[k]);
+    }
+}
+
+}  // namespace xd
+
+using namespace xd;
+
+struct xdemhip_pairs {
+    xdemhip_ctx* ctx = nullptr;
+    int val_dtype = XDEMHIP_F32, nblk = 0, nb = 0, pdist = 0;
+    bool own = false;
+    double *ax = nullptr, *ay = nullptr, *bx = nullptr, *by = nullptr;
+    void *av = nullptr, *bv = nullptr;
+    int64_t *a_off = nullptr, *b_off = nullptr, *wg_off = nullptr;
+    double *thr = nullptr, *sums = nullptr;
+    unsigned long long *counts = nullptr, *hist = nullptr;
+    void *prefix = nullptr, *succ = nullptr;
+    int64_t n_wg = 0, n_pairs = 0;
+};
+
+namespace {
+
+constexpr int HIST_BINS_PER_SWEEP = 128;
+
+template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
+    size_t base = sizeof(double) * (2 * PT + nb) + 8 * (size_t)nb + sizeof(T) * PT + 8;
+    if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
+    if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
+    return base + (size_t)nb * 12;
+}
+
+template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int first, int bin0, int nbs) {
+    xdemhip_ctx* ctx = P->ctx;
+    PairArgs<T> a;
+    a.ax = P->ax; a.ay = P->ay; a.bx = P->bx; a.by = P->by;
+    a.av = static_cast<const T*>(P->av); a.bv = static_cast<const T*>(P->bv);
+    a.a_off = P->a_off; a.b_off = P->b_off; a.wg_off = P->wg_off;
+    a.nblk = P->nblk; a.nb = P->nb; a.pdist = P->pdist; a.thr = P->thr;
+    a.sums = P->sums; a.counts = P->counts; a.hist = P->hist;
+    a.prefix = static_cast<const typename KeyT<T>::type*>(P->prefix);
+    a.succ = static_cast<unsigned long long*>(P->succ);
+    a.shift = shift; a.first = first; a.bin0 = bin0; a.nbs = nbs;
+    const size_t lds = lds_bytes<T>(P->nb, OP, nbs);
+    if (lds > 48 * 1024)
+        XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_kernel<T, OP>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (P->n_wg > 0x7fffffff) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many pair tiles for one launch");
+    hipLaunchKernelGGL((pairs_kernel<T, OP>), dim3((unsigned)P->n_wg), dim3(PT), lds, ctx->stream, a);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    return XDEMHIP_OK;
+}
+
+template <int OP> int launch_any(xdemhip_pairs* P, int shift = 0, int first = 0, int bin0 = 0, int nbs = 0) {
+    return P->val_dtype == XDEMHIP_F32 ? launch_pairs<float, OP>(P, shift, first, bin0, nbs)
+                                       : launch_pairs<double, OP>(P, shift, first, bin0, nbs);
+}
+
+// smallest double t with sqrt(t) >= e (round-to-nearest sqrt is monotone): d >= e  <=>  d^2-sum >= t
+double sq_threshold(double e) {
+    if (!(e > 0)) return 0.0;
+    double t = e * e;
+    while (sqrt(t) >= e) t = nextafter(t, 0.0);
+    while (sqrt(t) < e) t = nextafter(t, INFINITY);
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+void xdemhip_pairs_destroy(xdemhip_pairs* P) {
+    if (!P) return;
+    (void)hipSetDevice(P->ctx->device);
+    if (P->own) {
+        void* b[] = {P->ax, P->ay, P->bx, P->by, P->av, P->bv};
+        for (void* p : b) if (p) (void)hipFree(p);
+    }
+    void* b2[] = {P->a_off, P->b_off, P->wg_off, P->thr, P->sums, P->counts, P->hist, P->prefix, P->succ};
+    for (void* p : b2) if (p) (void)hipFree(p);
+    delete P;
+}
+
+int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, const double* ax, const double* ay, const void* av,
+                         const int64_t* b_off, const double* bx, const double* by, const void* bv, int val_dtype,
+                         const double* right_edges, int n_bins, int memspace, xdemhip_pairs** out, int64_t* n_pairs) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (!out || n_blocks <= 0 || !a_off || !ax || !ay || !av || !right_edges) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    if (n_bins < 1 || n_bins > 1024) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins out of range (1..1024)");
+    if (val_dtype != XDEMHIP_F32 && val_dtype != XDEMHIP_F64) return xd_fail(ctx, XDEMHIP_EINVAL, "values must be float32 or float64");
+    const bool pd = (b_off == nullptr);
+    if (!pd && (!bx || !by || !bv)) return xd_fail(ctx, XDEMHIP_EINVAL, "null B arrays");
+    for (int k = 1; k < n_bins; ++k)
+        if (!(right_edges[k] > right_edges[k - 1])) return xd_fail(ctx, XDEMHIP_EINVAL, "right_edges must be strictly increasing");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    xdemhip_pairs* P = new xdemhip_pairs();
+    P->ctx = ctx; P->val_dtype = val_dtype; P->nblk = n_blocks; P->nb = n_bins; P->pdist = pd;
+    const size_t es = val_dtype == XDEMHIP_F32 ? 4 : 8;
+    const int64_t na = a_off[n_blocks], nbt = pd ? 0 : b_off[n_blocks];
+    std::vector<int64_t> wg(n_blocks + 1, 0);
+    int64_t pairs = 0;
+    for (int r = 0; r < n_blocks; ++r) {
+        const int64_t a = a_off[r + 1] - a_off[r], b = pd ? a : b_off[r + 1] - b_off[r];
+        if (a < 0 || b < 0) { delete P; return xd_fail(ctx, XDEMHIP_EINVAL, "offsets must be non-decreasing"); }
+        wg[r + 1] = wg[r] + ((a + PT - 1) / PT) * ((b + BCHUNK - 1) / BCHUNK);
+        pairs += pd ? a * (a - 1) / 2 : a * b;
+    }
+    P->n_wg = wg[n_blocks];
+    P->n_pairs = pairs;
+    std::vector<double> thr(n_bins);
+    for (int k = 0; k < n_bins; ++k) thr[k] = sq_threshold(right_edges[k]);
+    auto fail = [&](int code, const char* m) { xdemhip_pairs_destroy(P); return xd_fail(ctx, code, m); };
+#define XD_ALLOC(ptr, bytes) if (hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes) ? (bytes) : 8) != hipSuccess) return fail(XDEMHIP_ENOMEM, "hipMalloc failed")
+    XD_ALLOC(P->a_off, sizeof(int64_t) * (n_blocks + 1));
+    XD_ALLOC(P->wg_off, sizeof(int64_t) * (n_blocks + 1));
+    XD_ALLOC(P->thr, sizeof(double) * n_bins);
+    XD_ALLOC(P->sums, sizeof(double) * n_bins);
+    XD_ALLOC(P->counts, 8 * n_bins);
+    XD_ALLOC(P->hist, 8 * (size_t)n_bins * SEL_RADIX);
+    XD_ALLOC(P->prefix, 8 * n_bins);
+    XD_ALLOC(P->succ, 8 * n_bins);
+    if (!pd) XD_ALLOC(P->b_off, sizeof(int64_t) * (n_blocks + 1));
+    (void)hipMemcpyAsync(P->a_off, a_off, sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(P->wg_off, wg.data(), sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(P->thr, thr.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream);
+    if (!pd) (void)hipMemcpyAsync(P->b_off, b_off, sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (memspace == XDEMHIP_HOST) {
+        P->own = true;
+        XD_ALLOC(P->ax, 8 * na); XD_ALLOC(P->ay, 8 * na); XD_ALLOC(P->av, es * na);
+        (void)hipMemcpyAsync(P->ax, ax, 8 * na, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(P->ay, ay, 8 * na, hipMemcpyHostToDevice, ctx->stream);
+        (void)hipMemcpyAsync(P->av, av, es * na, hipMemcpyHostToDevice, ctx->stream);
+        if (!pd) {
+            XD_ALLOC(P->bx, 8 * nbt); XD_ALLOC(P->by, 8 * nbt); XD_ALLOC(P->bv, es * nbt);
+            (void)hipMemcpyAsync(P->bx, bx, 8 * nbt, hipMemcpyHostToDevice, ctx->stream);
+            (void)hipMemcpyAsync(P->by, by, 8 * nbt, hipMemcpyHostToDevice, ctx->stream);
+            (void)hipMemcpyAsync(P->bv, bv, es * nbt, hipMemcpyHostToDevice, ctx->stream);
+        }
+    } else {
+        P->ax = const_cast<double*>(ax); P->ay = const_cast<double*>(ay); P->av = const_cast<void*>(av);
+        P->bx = const_cast<double*>(bx); P->by = const_cast<double*>(by); P->bv = const_cast<void*>(bv);
+    }
+#undef XD_ALLOC
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "upload failed");
+    if (n_pairs) *n_pairs = pairs;
+    *out = P;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_pairs_sums(xdemhip_pairs* P, int kind, double* sums, int64_t* counts) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (!sums || !counts || (kind != 0 && kind != 1)) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->sums, 0, 8 * P->nb, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->counts, 0, 8 * P->nb, ctx->stream));
+    int rc = XDEMHIP_OK;
+    if (P->n_wg > 0) {
+        XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        rc = kind == 0 ? launch_any<OP_SUMS_SQ>(P) : launch_any<OP_SUMS_SQRT>(P);
+        (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+        ctx->timed = rc == XDEMHIP_OK;
+        if (rc) return rc;
+    }
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, P->sums, 8 * P->nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(counts, P->counts, 8 * P->nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
+int xdemhip_pairs_hist(xdemhip_pairs* P, int shift, int first, const uint64_t* prefix, uint64_t* hist) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    const int key_bits = P->val_dtype == XDEMHIP_F32 ? 32 : 64;
+    if (!hist || shift < 0 || shift > key_bits - 8 || (shift & 7) || (!first && !prefix)) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->hist, 0, 8 * (size_t)P->nb * SEL_RADIX, ctx->stream));
+    if (!first) {
+        if (P->val_dtype == XDEMHIP_F32) {
+            std::vector<uint32_t> p32(P->nb);
+            for (int k = 0; k < P->nb; ++k) p32[k] = (uint32_t)prefix[k];
+            XD_HIP_CHECK(ctx, hipMemcpy(P->prefix, p32.data(), 4 * P->nb, hipMemcpyHostToDevice));
+        } else {
+            XD_HIP_CHECK(ctx, hipMemcpy(P->prefix, prefix, 8 * P->nb, hipMemcpyHostToDevice));
+        }
+    }
+    if (P->n_wg > 0) {
+        XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        for (int b0 = 0; b0 < P->nb; b0 += HIST_BINS_PER_SWEEP) {
+            const int nbs = (P->nb - b0) < HIST_BINS_PER_SWEEP ? (P->nb - b0) : HIST_BINS_PER_SWEEP;
+            int rc = launch_any<OP_HIST>(P, shift, first, b0, nbs);
+            if (rc) return rc;
+        }
+        (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+        ctx->timed = true;
+    }
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(hist, P->hist, 8 * (size_t)P->nb * SEL_RADIX, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
+int xdemhip_pairs_succ(xdemhip_pairs* P, const uint64_t* key, uint64_t* succ) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (!key || !succ) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->succ, 0xFF, 8 * P->nb, ctx->stream));
+    if (P->val_dtype == XDEMHIP_F32) {
+        std::vector<uint32_t> p32(P->nb);
+        for (int k = 0; k < P->nb; ++k) p32[k] = (uint32_t)key[k];
+        XD_HIP_CHECK(ctx, hipMemcpy(P->prefix, p32.data(), 4 * P->nb, hipMemcpyHostToDevice));
+    } else {
+        XD_HIP_CHECK(ctx, hipMemcpy(P->prefix, key, 8 * P->nb, hipMemcpyHostToDevice));
+    }
+    if (P->n_wg > 0) {
+        int rc = launch_any<OP_SUCC>(P);
+        if (rc) return rc;
+    }
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(succ, P->succ, 8 * P->nb, hipMemcpyDeviceToHost, ctx->stream));  // all-ones = none
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
+}  // extern "C"
