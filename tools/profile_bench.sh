@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py on the GPU box (run from the repo root through gpurun):
+#   1. --kernel-trace --stats   -> per-kernel durations (CSV)
+#   2. --pmc FETCH_SIZE         -> HBM read bytes  (own pass: TCC slots)
+#   3. --pmc WRITE_SIZE         -> HBM write bytes (own pass)
+#   4. --pmc SQ_* VALU counters -> issue mix
+# Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries worth keeping into profiles/.
+set -u
+TAG=${1:-r01}
+SIZE=${2:-40000}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --size $SIZE"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/sq -o bench -- $CMD > $OUT/sq.log 2>&1
+cd $GRAFT_REPO_ROOT
+find $OUT -type f | head -40
+for f in $(find $OUT -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
+tail -1 $OUT/stats.log
