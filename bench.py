@@ -48,6 +48,65 @@ def cpu_baseline(n: int = 2048) -> dict:
                       f"the reference SciPy engine), {dt:.1f} s, host has {os.cpu_count()} cores"}
 
 
+def measured_traffic_bytes(pixels_per_launch: int):
+    """HBM bytes per launch from the newest committed PMC profile of the same launch size (profiles/*_pmc.json:
+    2 x FETCH_SIZE (gfx950 wide-load correction) + WRITE_SIZE, KiB units), or None."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_terrain_pmc.json"))):
+        try:
+            d = json.load(open(f))
+            if int(d.get("_pixels_per_launch", 40000 * 40000)) == int(pixels_per_launch):
+                best = (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
+        except Exception:
+            pass
+    return best
+
+
+def secondary_metrics(ctx) -> dict:
+    """Small fixed-size runs of the other two hot paths (reported next to the headline metric, not part of `value`)."""
+    import numpy as np
+
+    from xdem_amd import coreg
+    from xdem_amd import spatialstats as ss
+    from xdem_amd.synth import fbm_numpy
+
+    out = {}
+    # variogram: 65536-point sample x 8192-point sample (5.4e8 pairs), 50 geometric lag classes, float32 values
+    rng = np.random.default_rng(45)
+    n = 65536
+    x, y = rng.uniform(0, 20000, n), rng.uniform(0, 20000, n)
+    v = (np.sin(x / 900) + 0.2 * rng.normal(size=n)).astype(np.float32)
+    edges = np.geomspace(np.sqrt(2), np.hypot(20000, 20000), 50)
+    ps = ss.PairSet([(x[: n // 8], y[: n // 8], v[: n // 8], x, y, v)], edges, ctx)
+    ps.sums(0)
+    ps.sums(0)
+    ms = ctx.last_kernel_ms()
+    t0 = time.perf_counter()
+    ss.class_medians(ps)
+    dt = time.perf_counter() - t0
+    out["variogram"] = {"pairs": ps.n_pairs, "lag_classes": 50, "matheron_pass_Gpairs_s": round(ps.n_pairs / ms / 1e6, 1),
+                        "dowd_exact_median_Gpairs_s": round(ps.n_pairs / dt / 1e9, 2),
+                        "note": "cdist 8192 x 65536 points, f32 values; Dowd = 4 histogram passes + successor pass"}
+    ps.close()
+    # Nuth-Kaab: 4096^2 pair, 20 % NaN, one iteration step (all grid passes of an iteration, exact medians)
+    m = 4096
+    ref = fbm_numpy((m, m), seed=42)
+    tba = (np.roll(ref, (1, -2), (0, 1)) + 2.0).astype(np.float32)
+    hole = fbm_numpy((m, m), seed=44, hurst=1.0, mean=0.0, std=1.0)
+    tba[hole < np.percentile(hole, 20)] = np.nan
+    plan = coreg.NKPlan(ref, tba, None, ctx)
+    plan.step(0.0, 0.0, (10.0, 10.0), 72)
+    t0 = time.perf_counter()
+    plan.step(3.0, -4.0, (10.0, 10.0), 72)
+    dt = time.perf_counter() - t0
+    out["nuthkaab"] = {"grid": f"{m}x{m}", "Mpixel_iterations_s": round(m * m / dt / 1e6, 1),
+                       "note": "one iteration step: shifted dh, exact nanmedian, 72-bin exact medians (float32)"}
+    plan.close()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,6 +114,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=40000, help="raster is size x size (40000 = the metric's DEM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the small variogram / Nuth-Kaab side measurements")
     ap.add_argument("--no-overlap", action="store_true", help="wait for the halo before launching anything")
     args = ap.parse_args()
 
@@ -139,12 +199,20 @@ def main() -> None:
                        "partition": f"{world} row block(s), halo depth {depth}" + (", RCCL send/recv" if world > 1 else ""),
                        "bytes_per_pixel": BYTES_PER_PIXEL},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": (lambda t: None if t is None else round(t / (kernel_ms * 1e-3) / 1e9, 1))(
+                             measured_traffic_bytes(px_launch) if world == 1 else None),
+                         "traffic_bytes_per_launch": measured_traffic_bytes(px_launch) if world == 1 else None,
                          "kernel": "terrain_tile_kernel<Florinsky,curv,win,f32,f32>",
                          "kernel_ms": round(kernel_ms, 4), "pixels_per_launch": px_launch},
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        if not args.no_secondary:
+            try:
+                res["secondary"] = secondary_metrics(ctx)
+            except Exception as e:  # the headline line must still be printed
+                res["secondary"] = {"error": repr(e)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
