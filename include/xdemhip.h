@@ -135,8 +135,9 @@ int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dt
  *  xdemhip_pairs_sums   kind 0: sums[k] = sum |dv|^2 (Matheron), kind 1: sum sqrt|dv| (Cressie-Hawkins); counts[k]
  *  xdemhip_pairs_hist   one radix-select pass for the exact per-class median of |dv| (Dowd): histogram (n_bins x 256,
  *                       uint64) of key bits [shift, shift+8) among pairs whose higher key bits equal prefix[k]
- *                       (first != 0: all pairs).  Keys are the order-preserving integer images of |dv|
- *                       (32 bit for float32 values, 64 bit for float64).  The host advances the selection; integer
+ *                       (first != 0: all pairs).  Keys are order-preserving integer images of |dv|: its IEEE bits
+ *                       shifted left by one (the sign bit of |dv| is always 0), 32 bit for float32 values, 64 bit for
+ *                       float64.  The host advances the selection; integer
  *                       histograms / counts can be summed over GPUs (all-reduce) before doing so.
  *  xdemhip_pairs_succ   succ[k] = smallest key > key[k] in class k (all-ones if none): upper median of even classes.
  */

@@ -101,8 +101,8 @@ def test_variogram_host_preparation():
     assert (runs, samples) == (100, 23) and abs(ratio - 0.0037559253144038175) < 1e-18   # SURVEY probe value
     with pytest.raises(ValueError, match="needs to be at least 10"):
         ss._choose_cdist_equidistant_sampling_parameters(extent=(0, 9, 0, 9), shape=(10, 10), subsample=5)
-    k = np.array([0x80000000 | 0x3F800000, (~np.uint32(0xBF800000)) & 0xFFFFFFFF], dtype=np.uint64)
-    assert ss._key_to_value(k, 32).tolist() == [1.0, -1.0]
+    k = np.array([0x3F800000 << 1, 0x40000000 << 1], dtype=np.uint64)
+    assert ss._key_to_value(k, 32).tolist() == [1.0, 2.0]
 
 
 def test_nuthkaab_class_contract():

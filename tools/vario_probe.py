@@ -26,6 +26,17 @@ for mode in ("pdist", "cdist"):
         wall = time.perf_counter() - t0
         ms = ctx.last_kernel_ms()
         print(f"{mode} {name}: pairs={ps.n_pairs:.3e} kernel={ms:.2f} ms -> {ps.n_pairs / ms / 1e6:.1f} Gpairs/s (wall {wall*1e3:.1f} ms)", flush=True)
+    # per-pass kernel times of the radix selection
+    prefix = np.zeros(ps.nb, dtype=np.uint64)
+    for pno, shift in enumerate((24, 16, 8, 0)):
+        h = ps.hist(shift, pno == 0, None if pno == 0 else prefix)
+        ms = ctx.last_kernel_ms()
+        if pno == 0:
+            count = h.sum(1); rank = np.where(count > 0, (count - 1) // 2, 0).astype(np.uint64)
+        cum = np.cumsum(h, 1); d = np.minimum((cum > rank[:, None]).argmax(1), 255)
+        before = cum[np.arange(ps.nb), d] - h[np.arange(ps.nb), d]
+        prefix |= d.astype(np.uint64) << np.uint64(shift); rank = rank - before
+        print(f"   pass {pno} shift {shift}: {ms:.2f} ms -> {ps.n_pairs / ms / 1e6:.1f} Gpairs/s", flush=True)
     t0 = time.perf_counter()
     med, cnt = ss.class_medians(ps)
     print(f"{mode} dowd full select: {time.perf_counter() - t0:.3f} s -> {ps.n_pairs / (time.perf_counter() - t0) / 1e9:.2f} Gpairs/s effective", flush=True)

@@ -28,8 +28,11 @@ namespace xd {
 
 #pragma clang fp contract(off)
 
-constexpr int PT = 256;      // points per tile
+constexpr int PT = 256;      // B points per LDS tile; A points per workgroup = NT (256 for sums / succ, 1024 for histograms)
 constexpr int BCHUNK = 4096;  // B points per workgroup
+constexpr int LUT_N = 256;    // half-binades of d^2 covered by the class lookup table
+constexpr int LUT_STEPS = 2;  // fixed scan steps after the table (host guarantees <= 2 thresholds per half-binade)
+constexpr int NCOPY = 32;     // privatised accumulator copies (copy = lane % 32 -> one LDS bank per copy)
 
 enum { OP_SUMS_SQ = 0, OP_SUMS_SQRT = 1, OP_HIST = 2, OP_SUCC = 3 };
 
@@ -37,9 +40,11 @@ template <typename T> struct PairArgs {
     const double *ax, *ay, *bx, *by;
     const T *av, *bv;
     const int64_t *a_off, *b_off;  // per block [nblk + 1]
-    const int64_t* wg_off;         // workgroups before each block [nblk + 1]
+    const int64_t* wg_off;         // workgroups before each block [nblk + 1] (for this kernel's NT)
     int nblk, nb, pdist;
     const double* thr;  // nb thresholds on d^2
+    const uint8_t* lut;  // [LUT_N] class lower bound per half-binade of d^2 (nullptr: plain binary search)
+    int lut_emin;        // (biased exponent << 1 | top mantissa bit) of LUT entry 0
     // outputs / state
     double* sums;                  // [nb]
     unsigned long long* counts;    // [nb]
@@ -55,31 +60,40 @@ template <> __device__ __forceinline__ void lds_min<uint64_t>(uint64_t* p, uint6
     atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
 }
 
-template <typename T, int OP>
-__global__ __launch_bounds__(PT) void pairs_kernel(const PairArgs<T> a) {
+// |dv| >= 0: its IEEE bits are already order-preserving; shifting the (always zero) sign bit out gives the first radix
+// digit the full 8 exponent bits instead of sign + 7 (twice the spread of the LDS counters it hits).
+__device__ __forceinline__ uint32_t key_abs(float v) { return __float_as_uint(v) << 1; }
+__device__ __forceinline__ uint64_t key_abs(double v) { return (uint64_t)__double_as_longlong(v) << 1; }
+
+template <typename T, int OP, bool FAST, int NT>
+__global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_bx = reinterpret_cast<double*>(smem);
     double* s_by = s_bx + PT;
-    double* s_thr = s_by + PT;                       // nb
-    K* s_pref = reinterpret_cast<K*>(s_thr + a.nb);  // nb selection prefixes / selected keys (8-byte slots)
+    double* s_thr = s_by + PT;                       // nb (+ LUT_STEPS + 1 entries of +inf padding)
+    K* s_pref = reinterpret_cast<K*>(s_thr + a.nb + LUT_STEPS + 1);  // nb selection prefixes / selected keys (8-byte slots)
     T* s_bv = reinterpret_cast<T*>(reinterpret_cast<uint64_t*>(s_pref) + a.nb);  // PT
     unsigned char* acc = reinterpret_cast<unsigned char*>(s_bv + PT);            // PT * sizeof(T) is a multiple of 8
-    double* s_sum = reinterpret_cast<double*>(acc);                 // OP_SUMS: nb doubles
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_sum + a.nb);    //          nb counters
+    // OP_SUMS: NCOPY privatised copies per class, copy = lane % 32: lanes of a wave that hit the same class land on
+    // different banks (at most 2 lanes per address) instead of serialising 64-way on one LDS word
+    double* s_sum = reinterpret_cast<double*>(acc);                        // [nb][NCOPY]
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_sum + a.nb * NCOPY);   // [nb][NCOPY]
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(acc);            // OP_HIST: nbs * 256
     K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
 
+    __shared__ uint8_t s_lut[LUT_N];
     const int tid = threadIdx.x;
-    for (int k = tid; k < a.nb; k += PT) s_thr[k] = a.thr[k];
+    if (FAST && tid < LUT_N) s_lut[tid] = a.lut[tid];
+    for (int k = tid; k < a.nb + LUT_STEPS + 1; k += NT) s_thr[k] = k < a.nb ? a.thr[k] : (double)INFINITY;
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
-        for (int k = tid; k < a.nb; k += PT) { s_sum[k] = 0.0; s_cnt[k] = 0; }
+        for (int k = tid; k < a.nb * NCOPY; k += NT) { s_sum[k] = 0.0; s_cnt[k] = 0; }
     if (OP == OP_HIST)
-        for (int k = tid; k < a.nbs * SEL_RADIX; k += PT) s_hist[k] = 0;
+        for (int k = tid; k < a.nbs * SEL_RADIX; k += NT) s_hist[k] = 0;
     if (OP == OP_SUCC)
-        for (int k = tid; k < a.nb; k += PT) s_min[k] = ~(K)0;
+        for (int k = tid; k < a.nb; k += NT) s_min[k] = ~(K)0;
     if ((OP == OP_HIST && !a.first) || OP == OP_SUCC)
-        for (int k = tid; k < a.nb; k += PT) s_pref[k] = a.prefix[k];
+        for (int k = tid; k < a.nb; k += NT) s_pref[k] = a.prefix[k];
 
     // which block / A tile / B chunk is this workgroup?
     const int64_t wg = blockIdx.x;
@@ -94,10 +108,10 @@ __global__ __launch_bounds__(PT) void pairs_kernel(const PairArgs<T> a) {
     const int64_t nchunk = (nbp + BCHUNK - 1) / BCHUNK;
     const int64_t local = wg - a.wg_off[r];
     const int64_t ta = local / nchunk, cb = local - ta * nchunk;
-    const int64_t ia = ta * PT + tid;  // index inside the block's A set
+    const int64_t ia = ta * NT + tid;  // index inside the block's A set
     const int64_t jb0 = cb * BCHUNK, jb1 = (jb0 + BCHUNK < nbp) ? jb0 + BCHUNK : nbp;
     const bool have_a = ia < na;
-    const bool skip_wg = a.pdist && (jb1 <= ta * PT + 1);  // whole chunk at or below the diagonal: no i < j pair
+    const bool skip_wg = a.pdist && (jb1 <= ta * NT + 1);  // whole chunk at or below the diagonal: no i < j pair
     double px = 0.0, py = 0.0;
     T pv = 0;
     if (have_a) { px = a.ax[a0 + ia]; py = a.ay[a0 + ia]; pv = a.av[a0 + ia]; }
@@ -118,47 +132,72 @@ __global__ __launch_bounds__(PT) void pairs_kernel(const PairArgs<T> a) {
             }
             __syncthreads();
             if (!have_a) continue;
-            for (int j = 0; j < cnt; ++j) {
-                if (a.pdist && (j0 + j) <= ia) continue;  // i < j only
+            // One pair: class lookup + accumulate.  `ok` folds every skip rule so the fast path stays branch-free
+            // up to the (exec-masked) LDS atomics.
+            auto pair = [&](int j, bool ok) {
                 const double dx = px - s_bx[j], dy = py - s_by[j];
                 const double s2 = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
-                // class = number of thresholds <= s2
-                int l = 0, h = nb;
-                while (l < h) {
-                    const int m = (l + h) >> 1;
-                    if (s_thr[m] <= s2) l = m + 1; else h = m;
+                int l;  // class = number of thresholds <= s2
+                if (FAST) {
+                    // half-binade of s2 -> first candidate class, then LUT_STEPS fixed compare-and-advance steps
+                    int e = (int)((unsigned long long)__double_as_longlong(s2) >> 51) - a.lut_emin;
+                    e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                    l = s_lut[e];
+#pragma unroll
+                    for (int q = 0; q < LUT_STEPS; ++q) l += (s_thr[l] <= s2) ? 1 : 0;
+                } else {
+                    l = 0;
+                    int h = nb;
+                    while (l < h) {
+                        const int m = (l + h) >> 1;
+                        if (s_thr[m] <= s2) l = m + 1; else h = m;
+                    }
                 }
-                if (l >= nb) continue;  // beyond the last edge (maxlag)
                 T d = pv - s_bv[j];
                 d = d < 0 ? -d : d;
-                if (d != d) continue;  // NaN values never form a pair
+                ok = ok && (l < nb) && (d == d);  // beyond the last edge (maxlag) / NaN values never form a pair
+                if (!ok) return;
                 if (OP == OP_SUMS_SQ) {
-                    atomicAdd(&s_cnt[l], 1u);
-                    atomicAdd(&s_sum[l], (double)d * (double)d);
+                    atomicAdd(&s_cnt[l * NCOPY + (tid & (NCOPY - 1))], 1u);
+                    atomicAdd(&s_sum[l * NCOPY + (tid & (NCOPY - 1))], (double)d * (double)d);
                 } else if (OP == OP_SUMS_SQRT) {
-                    atomicAdd(&s_cnt[l], 1u);
-                    atomicAdd(&s_sum[l], sqrt((double)d));
+                    atomicAdd(&s_cnt[l * NCOPY + (tid & (NCOPY - 1))], 1u);
+                    atomicAdd(&s_sum[l * NCOPY + (tid & (NCOPY - 1))], sqrt((double)d));
                 } else if (OP == OP_HIST) {
                     const int lb = l - a.bin0;
-                    if (lb < 0 || lb >= a.nbs) continue;
-                    const K key = key_of(d);
-                    if (!a.first && (key & himask) != s_pref[l]) continue;
+                    if (lb < 0 || lb >= a.nbs) return;
+                    const K key = key_abs(d);
+                    if (!a.first && (key & himask) != s_pref[l]) return;
                     atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
                 } else {
-                    const K key = key_of(d);
+                    const K key = key_abs(d);
                     if (key > s_pref[l] && key < s_min[l]) lds_min<K>(&s_min[l], key);
                 }
+            };
+            if (FAST) {
+                // 4 pairs per trip: the LDS reads of the table / thresholds of one pair overlap the arithmetic of the
+                // others (tile slots beyond cnt hold stale but finite-or-NaN data and are masked by `ok`)
+                for (int j = 0; j < cnt; j += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pair(j + u, (j + u) < cnt && (!a.pdist || (j0 + j + u) > ia));
+                }
+            } else {
+                for (int j = 0; j < cnt; ++j) pair(j, !a.pdist || (j0 + j) > ia);
             }
         }
     __syncthreads();
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) {
-        for (int k = tid; k < nb; k += PT)
-            if (s_cnt[k]) { atomicAdd(&a.counts[k], (unsigned long long)s_cnt[k]); atomicAdd(&a.sums[k], s_sum[k]); }
+        for (int k = tid; k < nb; k += NT) {
+            unsigned long long c = 0;
+            double sm = 0.0;
+            for (int q = 0; q < NCOPY; ++q) { c += s_cnt[k * NCOPY + q]; sm += s_sum[k * NCOPY + q]; }
+            if (c) { atomicAdd(&a.counts[k], c); atomicAdd(&a.sums[k], sm); }
+        }
     } else if (OP == OP_HIST) {
-        for (int k = tid; k < a.nbs * SEL_RADIX; k += PT)
+        for (int k = tid; k < a.nbs * SEL_RADIX; k += NT)
             if (s_hist[k]) atomicAdd(&a.hist[(size_t)a.bin0 * SEL_RADIX + k], (unsigned long long)s_hist[k]);
     } else {
-        for (int k = tid; k < nb; k += PT)
+        for (int k = tid; k < nb; k += NT)
             if (s_min[k] != ~(K)0) atomicMin(&a.succ[k], (unsigned long long)s_min[k]);
     }
 }
@@ -173,11 +212,13 @@ struct xdemhip_pairs {
     bool own = false;
     double *ax = nullptr, *ay = nullptr, *bx = nullptr, *by = nullptr;
     void *av = nullptr, *bv = nullptr;
-    int64_t *a_off = nullptr, *b_off = nullptr, *wg_off = nullptr;
+    int64_t *a_off = nullptr, *b_off = nullptr, *wg_off = nullptr, *wg_off_big = nullptr;
     double *thr = nullptr, *sums = nullptr;
+    uint8_t* lut = nullptr;  // null when the edges are too dense for the binade table
+    int lut_emin = 0;
     unsigned long long *counts = nullptr, *hist = nullptr;
     void *prefix = nullptr, *succ = nullptr;
-    int64_t n_wg = 0, n_pairs = 0;
+    int64_t n_wg = 0, n_wg_big = 0, n_pairs = 0;
 };
 
 namespace {
@@ -185,29 +226,38 @@ namespace {
 constexpr int HIST_BINS_PER_SWEEP = 128;
 
 template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
-    size_t base = sizeof(double) * (2 * PT + nb) + 8 * (size_t)nb + sizeof(T) * PT + 8;
+    size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 8 * (size_t)nb + sizeof(T) * PT + 8;
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
-    return base + (size_t)nb * 12;
+    return base + (size_t)nb * NCOPY * 12;
 }
 
 template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int first, int bin0, int nbs) {
     xdemhip_ctx* ctx = P->ctx;
+    constexpr int NT = (OP == OP_HIST) ? 1024 : 256;  // histograms: 16 waves share one 51 KB LDS table -> full occupancy
     PairArgs<T> a;
     a.ax = P->ax; a.ay = P->ay; a.bx = P->bx; a.by = P->by;
     a.av = static_cast<const T*>(P->av); a.bv = static_cast<const T*>(P->bv);
-    a.a_off = P->a_off; a.b_off = P->b_off; a.wg_off = P->wg_off;
-    a.nblk = P->nblk; a.nb = P->nb; a.pdist = P->pdist; a.thr = P->thr;
+    a.a_off = P->a_off; a.b_off = P->b_off; a.wg_off = (NT == 1024) ? P->wg_off_big : P->wg_off;
+    a.nblk = P->nblk; a.nb = P->nb; a.pdist = P->pdist; a.thr = P->thr; a.lut = P->lut; a.lut_emin = P->lut_emin;
     a.sums = P->sums; a.counts = P->counts; a.hist = P->hist;
     a.prefix = static_cast<const typename KeyT<T>::type*>(P->prefix);
     a.succ = static_cast<unsigned long long*>(P->succ);
     a.shift = shift; a.first = first; a.bin0 = bin0; a.nbs = nbs;
     const size_t lds = lds_bytes<T>(P->nb, OP, nbs);
-    if (lds > 48 * 1024)
-        XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_kernel<T, OP>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (P->n_wg > 0x7fffffff) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many pair tiles for one launch");
-    hipLaunchKernelGGL((pairs_kernel<T, OP>), dim3((unsigned)P->n_wg), dim3(PT), lds, ctx->stream, a);
+    const int64_t n_wg = (NT == 1024) ? P->n_wg_big : P->n_wg;
+    if (n_wg > 0x7fffffff) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many pair tiles for one launch");
+    if (P->lut) {
+        if (lds > 48 * 1024)
+            XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_kernel<T, OP, true, NT>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3((unsigned)n_wg), dim3(NT), lds, ctx->stream, a);
+    } else {
+        if (lds > 48 * 1024)
+            XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_kernel<T, OP, false, NT>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3((unsigned)n_wg), dim3(NT), lds, ctx->stream, a);
+    }
     XD_HIP_CHECK(ctx, hipGetLastError());
     return XDEMHIP_OK;
 }
@@ -237,7 +287,7 @@ void xdemhip_pairs_destroy(xdemhip_pairs* P) {
         void* b[] = {P->ax, P->ay, P->bx, P->by, P->av, P->bv};
         for (void* p : b) if (p) (void)hipFree(p);
     }
-    void* b2[] = {P->a_off, P->b_off, P->wg_off, P->thr, P->sums, P->counts, P->hist, P->prefix, P->succ};
+    void* b2[] = {P->a_off, P->b_off, P->wg_off, P->wg_off_big, P->thr, P->sums, P->counts, P->hist, P->prefix, P->succ, P->lut};
     for (void* p : b2) if (p) (void)hipFree(p);
     delete P;
 }
@@ -258,22 +308,48 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     P->ctx = ctx; P->val_dtype = val_dtype; P->nblk = n_blocks; P->nb = n_bins; P->pdist = pd;
     const size_t es = val_dtype == XDEMHIP_F32 ? 4 : 8;
     const int64_t na = a_off[n_blocks], nbt = pd ? 0 : b_off[n_blocks];
-    std::vector<int64_t> wg(n_blocks + 1, 0);
+    std::vector<int64_t> wg(n_blocks + 1, 0), wgb(n_blocks + 1, 0);
     int64_t pairs = 0;
     for (int r = 0; r < n_blocks; ++r) {
         const int64_t a = a_off[r + 1] - a_off[r], b = pd ? a : b_off[r + 1] - b_off[r];
         if (a < 0 || b < 0) { delete P; return xd_fail(ctx, XDEMHIP_EINVAL, "offsets must be non-decreasing"); }
-        wg[r + 1] = wg[r] + ((a + PT - 1) / PT) * ((b + BCHUNK - 1) / BCHUNK);
+        wg[r + 1] = wg[r] + ((a + 255) / 256) * ((b + BCHUNK - 1) / BCHUNK);
+        wgb[r + 1] = wgb[r] + ((a + 1023) / 1024) * ((b + BCHUNK - 1) / BCHUNK);
         pairs += pd ? a * (a - 1) / 2 : a * b;
     }
     P->n_wg = wg[n_blocks];
+    P->n_wg_big = wgb[n_blocks];
     P->n_pairs = pairs;
     std::vector<double> thr(n_bins);
     for (int k = 0; k < n_bins; ++k) thr[k] = sq_threshold(right_edges[k]);
+    // Half-binade lookup table over d^2: cell i covers [lo_i, lo_{i+1}) with lo_i the double whose top 12 bits
+    // (biased exponent, first mantissa bit) are emin + i; lut[i] = number of thresholds <= lo_i.  The kernel then does
+    // LUT_STEPS compare-and-advance steps, so the table is used only if no cell holds more than LUT_STEPS thresholds
+    // (true for the reference's sqrt(2)-geometric edges: one threshold per binade); otherwise binary search.
+    std::vector<uint8_t> lut(LUT_N, 0);
+    int emin = 0;
+    bool lut_ok = n_bins <= 255;
+    if (lut_ok) {
+        uint64_t bits;
+        memcpy(&bits, &thr[0], 8);
+        emin = (int)(bits >> 51) - 1;  // cell 0 lies strictly below every threshold: smaller d^2 clamp onto it
+        if (emin < 2) emin = 2;
+        auto cell_lo = [&](int i) { uint64_t b = (uint64_t)(emin + i) << 51; double v; memcpy(&v, &b, 8); return v; };
+        for (int i = 0; i < LUT_N; ++i) {
+            const double lo = cell_lo(i), hi2 = cell_lo(i + 1);
+            int below = 0, inside = 0;
+            for (int k = 0; k < n_bins; ++k) { below += thr[k] <= lo; inside += (thr[k] > lo && (i == LUT_N - 1 || thr[k] < hi2)); }
+            lut[i] = (uint8_t)below;
+            if (inside > LUT_STEPS) lut_ok = false;  // (the last cell also serves every larger d^2)
+        }
+        if (!(thr[0] > cell_lo(0))) lut_ok = false;
+    }
+    P->lut_emin = emin;
     auto fail = [&](int code, const char* m) { xdemhip_pairs_destroy(P); return xd_fail(ctx, code, m); };
 #define XD_ALLOC(ptr, bytes) if (hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes) ? (bytes) : 8) != hipSuccess) return fail(XDEMHIP_ENOMEM, "hipMalloc failed")
     XD_ALLOC(P->a_off, sizeof(int64_t) * (n_blocks + 1));
     XD_ALLOC(P->wg_off, sizeof(int64_t) * (n_blocks + 1));
+    XD_ALLOC(P->wg_off_big, sizeof(int64_t) * (n_blocks + 1));
     XD_ALLOC(P->thr, sizeof(double) * n_bins);
     XD_ALLOC(P->sums, sizeof(double) * n_bins);
     XD_ALLOC(P->counts, 8 * n_bins);
@@ -283,7 +359,12 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     if (!pd) XD_ALLOC(P->b_off, sizeof(int64_t) * (n_blocks + 1));
     (void)hipMemcpyAsync(P->a_off, a_off, sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(P->wg_off, wg.data(), sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(P->wg_off_big, wgb.data(), sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(P->thr, thr.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream);
+    if (lut_ok) {
+        XD_ALLOC(P->lut, LUT_N);
+        (void)hipMemcpyAsync(P->lut, lut.data(), LUT_N, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (!pd) (void)hipMemcpyAsync(P->b_off, b_off, sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
     if (memspace == XDEMHIP_HOST) {
         P->own = true;

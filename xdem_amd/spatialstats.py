@@ -90,14 +90,10 @@ class PairSet:
 
 
 def _key_to_value(key: np.ndarray, bits: int) -> np.ndarray:
-    """Inverse of the order-preserving key map of csrc/select.h."""
+    """Inverse of the variogram key map (csrc/variogram.hip key_abs): key = IEEE bits of |dv| shifted left by one."""
     if bits == 32:
-        k = key.astype(np.uint32)
-        b = np.where(k >> np.uint32(31), k ^ np.uint32(0x80000000), ~k)
-        return b.astype(np.uint32).view(np.float32)
-    k = key.astype(np.uint64)
-    b = np.where(k >> np.uint64(63), k ^ np.uint64(0x8000000000000000), ~k)
-    return b.astype(np.uint64).view(np.float64)
+        return (key.astype(np.uint64) >> np.uint64(1)).astype(np.uint32).view(np.float32)
+    return (key.astype(np.uint64) >> np.uint64(1)).view(np.float64)
 
 
 def _allreduce(arr: np.ndarray, group=None) -> np.ndarray:
