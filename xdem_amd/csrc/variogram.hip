@@ -30,8 +30,8 @@ namespace xd {
 
 constexpr int PT = 256;      // B points per LDS tile; A points per workgroup = NT (256 for sums / succ, 1024 for histograms)
 constexpr int BCHUNK = 4096;  // B points per workgroup
-constexpr int LUT_N = 256;    // half-binades of d^2 covered by the class lookup table
-constexpr int LUT_STEPS = 2;  // fixed scan steps after the table (host guarantees <= 2 thresholds per half-binade)
+constexpr int LUT_N = 512;    // cells (1/8 binade of d^2 each) of the class lookup table
+constexpr int LUT_STEPS = 1;  // a cell holds at most ONE threshold (host-checked), flagged in the entry's low bit
 constexpr int NCOPY = 32;     // privatised accumulator copies (copy = lane % 32 -> one LDS bank per copy)
 
 enum { OP_SUMS_SQ = 0, OP_SUMS_SQRT = 1, OP_HIST = 2, OP_SUCC = 3 };
@@ -43,8 +43,8 @@ template <typename T> struct PairArgs {
     const int64_t* wg_off;         // workgroups before each block [nblk + 1] (for this kernel's NT)
     int nblk, nb, pdist;
     const double* thr;  // nb thresholds on d^2
-    const uint8_t* lut;  // [LUT_N] class lower bound per half-binade of d^2 (nullptr: plain binary search)
-    int lut_emin;        // (biased exponent << 1 | top mantissa bit) of LUT entry 0
+    const uint8_t* lut;  // [LUT_N] (class lower bound << 1 | cell holds a threshold) per 1/8 binade of d^2; nullptr: binary search
+    int lut_emin;        // (biased exponent << 3 | top 3 mantissa bits) of LUT entry 0
     // outputs / state
     double* sums;                  // [nb]
     unsigned long long* counts;    // [nb]
@@ -139,12 +139,13 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 const double s2 = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
                 int l;  // class = number of thresholds <= s2
                 if (FAST) {
-                    // half-binade of s2 -> first candidate class, then LUT_STEPS fixed compare-and-advance steps
-                    int e = (int)((unsigned long long)__double_as_longlong(s2) >> 51) - a.lut_emin;
+                    // 1/8-binade cell of s2 -> class lower bound; only cells that contain a threshold (1 in 8 for the
+                    // reference's sqrt(2)-geometric edges) need the one exact compare against it
+                    int e = (int)((unsigned long long)__double_as_longlong(s2) >> 49) - a.lut_emin;
                     e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
-                    l = s_lut[e];
-#pragma unroll
-                    for (int q = 0; q < LUT_STEPS; ++q) l += (s_thr[l] <= s2) ? 1 : 0;
+                    const int c = s_lut[e];
+                    l = c >> 1;
+                    if (c & 1) l += (s_thr[l] <= s2) ? 1 : 0;
                 } else {
                     l = 0;
                     int h = nb;
@@ -175,11 +176,54 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 }
             };
             if (FAST) {
-                // 4 pairs per trip: the LDS reads of the table / thresholds of one pair overlap the arithmetic of the
-                // others (tile slots beyond cnt hold stale but finite-or-NaN data and are masked by `ok`)
+                // 4 pairs per trip, written stage by stage so that the 4 B-point reads, the 4 table reads and the 4
+                // threshold reads are each issued back to back (one LDS round trip per stage instead of per pair).
+                // Tile slots beyond cnt hold stale data and are masked by `ok`.
+                const int64_t rel = ia - j0;  // pdist: only B indices j > rel pair with this lane's A point
+                const int ia_rel = a.pdist ? (int)(rel < -1 ? -1 : (rel > PT ? PT : rel)) : -1;
                 for (int j = 0; j < cnt; j += 4) {
+                    double s2[4];
+                    T dv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) pair(j + u, (j + u) < cnt && (!a.pdist || (j0 + j + u) > ia));
+                    for (int u = 0; u < 4; ++u) {
+                        const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
+                        s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
+                        const T d = pv - s_bv[j + u];
+                        dv[u] = d < 0 ? -d : d;
+                    }
+                    int l[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
+                        e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                        l[u] = s_lut[e] >> 1;
+                    }
+                    double th[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];  // next threshold above the cell's lower bound
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int lu = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
+                        const T d = dv[u];
+                        const bool ok = (j + u) < cnt && (j + u) > ia_rel && lu < nb && d == d;
+                        if (ok) {
+                            if (OP == OP_SUMS_SQ) {
+                                atomicAdd(&s_cnt[lu * NCOPY + (tid & (NCOPY - 1))], 1u);
+                                atomicAdd(&s_sum[lu * NCOPY + (tid & (NCOPY - 1))], (double)d * (double)d);
+                            } else if (OP == OP_SUMS_SQRT) {
+                                atomicAdd(&s_cnt[lu * NCOPY + (tid & (NCOPY - 1))], 1u);
+                                atomicAdd(&s_sum[lu * NCOPY + (tid & (NCOPY - 1))], sqrt((double)d));
+                            } else if (OP == OP_HIST) {
+                                const int lb = lu - a.bin0;
+                                const K key = key_abs(d);
+                                if (lb >= 0 && lb < a.nbs && (a.first || (key & himask) == s_pref[lu]))
+                                    atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
+                            } else {
+                                const K key = key_abs(d);
+                                if (key > s_pref[lu] && key < s_min[lu]) lds_min<K>(&s_min[lu], key);
+                            }
+                        }
+                    }
                 }
             } else {
                 for (int j = 0; j < cnt; ++j) pair(j, !a.pdist || (j0 + j) > ia);
@@ -322,25 +366,25 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     P->n_pairs = pairs;
     std::vector<double> thr(n_bins);
     for (int k = 0; k < n_bins; ++k) thr[k] = sq_threshold(right_edges[k]);
-    // Half-binade lookup table over d^2: cell i covers [lo_i, lo_{i+1}) with lo_i the double whose top 12 bits
-    // (biased exponent, first mantissa bit) are emin + i; lut[i] = number of thresholds <= lo_i.  The kernel then does
-    // LUT_STEPS compare-and-advance steps, so the table is used only if no cell holds more than LUT_STEPS thresholds
-    // (true for the reference's sqrt(2)-geometric edges: one threshold per binade); otherwise binary search.
+    // Class lookup table over d^2: cell i covers [lo_i, lo_{i+1}) with lo_i the double whose top 15 bits (biased
+    // exponent, first 3 mantissa bits) are emin + i; entry = (number of thresholds <= lo_i) << 1 | (a threshold lies
+    // inside the cell).  Used only if no cell holds more than one threshold and there are < 128 classes (true for the
+    // reference's sqrt(2)-geometric edges: one threshold per binade = per 8 cells); otherwise binary search.
     std::vector<uint8_t> lut(LUT_N, 0);
     int emin = 0;
-    bool lut_ok = n_bins <= 255;
+    bool lut_ok = n_bins <= 127;
     if (lut_ok) {
         uint64_t bits;
         memcpy(&bits, &thr[0], 8);
-        emin = (int)(bits >> 51) - 1;  // cell 0 lies strictly below every threshold: smaller d^2 clamp onto it
-        if (emin < 2) emin = 2;
-        auto cell_lo = [&](int i) { uint64_t b = (uint64_t)(emin + i) << 51; double v; memcpy(&v, &b, 8); return v; };
+        emin = (int)(bits >> 49) - 1;  // cell 0 lies strictly below every threshold: smaller d^2 clamp onto it
+        if (emin < 8) emin = 8;
+        auto cell_lo = [&](int i) { uint64_t b = (uint64_t)(emin + i) << 49; double v; memcpy(&v, &b, 8); return v; };
         for (int i = 0; i < LUT_N; ++i) {
             const double lo = cell_lo(i), hi2 = cell_lo(i + 1);
             int below = 0, inside = 0;
             for (int k = 0; k < n_bins; ++k) { below += thr[k] <= lo; inside += (thr[k] > lo && (i == LUT_N - 1 || thr[k] < hi2)); }
-            lut[i] = (uint8_t)below;
-            if (inside > LUT_STEPS) lut_ok = false;  // (the last cell also serves every larger d^2)
+            lut[i] = (uint8_t)((below << 1) | (inside ? 1 : 0));
+            if (inside > 1) lut_ok = false;  // (the last cell also serves every larger d^2)
         }
         if (!(thr[0] > cell_lo(0))) lut_ok = false;
     }
