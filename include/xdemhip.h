@@ -66,6 +66,15 @@ int xdemhip_synchronize(xdemhip_ctx* ctx);
  * that stream around the kernel launch(es); returns milliseconds in *ms (synchronises the stop event). */
 int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
 
+/* Multi-GPU hook for the accumulator-style paths (Nuth-Kaab reductions): one process per GPU, every rank works on its
+ * share and calls the same entry points; wherever a global reduction is needed the library hands a small HOST array of
+ * `count` 8-byte elements to `fn`, which must combine it in place over all ranks (e.g. torch.distributed.all_reduce over
+ * RCCL) and return 0.  kind: 0 = sum of uint64, 1 = sum of float64, 2 = min of uint64, 3 = max of uint64.  Integer
+ * histograms / counts make the reductions exact and order-independent.  fn == NULL restores single-process behaviour. */
+enum { XDEMHIP_RED_SUM_U64 = 0, XDEMHIP_RED_SUM_F64 = 1, XDEMHIP_RED_MIN_U64 = 2, XDEMHIP_RED_MAX_U64 = 3 };
+typedef int (*xdemhip_allreduce_fn)(void* host_array, int64_t count, int kind, void* user);
+int xdemhip_set_allreduce(xdemhip_ctx* ctx, xdemhip_allreduce_fn fn, void* user);
+
 /* ---- path 1: terrain stencil engine --------------------------------------------------------------
  * Replaces  _get_surface_attributes(dem, resolution, surface_attributes, out_dtype, surface_fit,
  *           curv_method, engine, hillshade_*)                       xdem/terrain/surfit.py:1197-1305
@@ -116,6 +125,10 @@ int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const 
 int xdemhip_nk_step(xdemhip_nk_plan* plan, double shift_x, double shift_y, double res_x, double res_y, int n_bins,
                     double* vshift, int64_t* n_valid, double* y_mean, double* y_std, double* edges, int64_t* counts,
                     double* medians);
+/* Multi-GPU: restrict this rank's work to raster rows [row_begin, row_end) (every rank holds the full ref / tba, 3.2 GB
+ * for a 20000^2 pair; the streaming passes and their histograms are sharded by row block and combined through the
+ * all-reduce hook).  Call right after xdemhip_nk_create on every rank; n_valid then returns the global count. */
+int xdemhip_nk_set_rows(xdemhip_nk_plan* plan, int64_t row_begin, int64_t row_end, int64_t* n_valid);
 /* Debug / test access: copy the auxiliary rasters back to host buffers (any pointer may be NULL). */
 int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uint8_t* valid);
 void xdemhip_nk_destroy(xdemhip_nk_plan* plan);

@@ -67,6 +67,8 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_nk_destroy.restype = None
         L.xdemhip_binned_median.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                             c_dp, c_i64p, c_dp]
+        L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
+        L.xdemhip_nk_set_rows.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_i64p]
         c_u64p = ctypes.POINTER(ctypes.c_uint64)
         L.xdemhip_pairs_create.argtypes = [c_ctx, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -102,6 +104,56 @@ class Context:
 
     def set_stream(self, stream_ptr: int | None) -> None:
         self.check(self._L.xdemhip_set_stream(self.handle, ctypes.c_void_p(stream_ptr or 0)))
+
+    def set_allreduce(self, group="world") -> None:
+        """Install (group given) or remove (group=None) the multi-GPU reduction hook: small 8-byte-element host arrays
+        handed over by the library are combined in place over the ranks of `group` with torch.distributed
+        (backend nccl = RCCL over xGMI on GPUs, gloo on CPU)."""
+        if group is None:
+            self._hook = None
+            self.check(self._L.xdemhip_set_allreduce(self.handle, None, None))
+            return
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+
+        pg = None if group == "world" else group
+        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.SUM, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX}
+
+        def hook(ptr, count, kind, user):
+            try:
+                buf = (ctypes.c_uint64 * count).from_address(ptr)
+                a = np.frombuffer(buf, dtype=np.float64 if kind == 1 else np.uint64)
+                if kind == 1:
+                    t = torch.from_numpy(a.copy())
+                else:
+                    # unsigned keys / counters travel as int64: order-preserving because they stay below 2^63, except
+                    # the all-ones "none" marker of min reductions, which is mapped to int64 max and back
+                    v = a.copy()
+                    none = v == np.uint64(0xFFFFFFFFFFFFFFFF)
+                    v[none] = np.uint64(0x7FFFFFFFFFFFFFFF)
+                    t = torch.from_numpy(v.view(np.int64))
+                if dist.get_backend(pg) == "nccl":
+                    t = t.cuda(self.device)
+                dist.all_reduce(t, op=ops[kind], group=pg)
+                r = t.cpu().numpy()
+                if kind == 1:
+                    a[:] = r
+                else:
+                    r = r.view(np.uint64).copy()
+                    if kind == 2:
+                        r[r == np.uint64(0x7FFFFFFFFFFFFFFF)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+                    a[:] = r
+                return 0
+            except Exception:  # never propagate a Python exception through the C frame
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
+        self._hook = CB(hook)  # keep alive
+        self.check(self._L.xdemhip_set_allreduce(self.handle, ctypes.cast(self._hook, ctypes.c_void_p), None))
 
     def synchronize(self) -> None:
         self.check(self._L.xdemhip_synchronize(self.handle))

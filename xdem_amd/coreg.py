@@ -31,7 +31,10 @@ def _nuth_kaab_fit_func(xx, *params):
 class NKPlan:
     """Device-resident state of one fit (``xdemhip_nk_plan``)."""
 
-    def __init__(self, ref: np.ndarray, tba: np.ndarray, inlier_mask: np.ndarray | None, ctx: _lib.Context | None = None):
+    def __init__(self, ref: np.ndarray, tba: np.ndarray, inlier_mask: np.ndarray | None, ctx: _lib.Context | None = None,
+                 group=None):
+        """``group``: a torch.distributed process group (or "world") to shard the grid passes over its ranks by row
+        block -- every rank passes the same full rasters; histograms / counts are all-reduced (exact)."""
         ref = np.ascontiguousarray(ref)
         tba = np.ascontiguousarray(tba)
         if ref.shape != tba.shape or ref.ndim != 2:
@@ -53,6 +56,17 @@ class NKPlan:
             ctypes.byref(nv)))
         self.handle = h
         self.n_valid = int(nv.value)
+        self.group = group
+        if group is not None:
+            import torch.distributed as dist
+
+            from .dist import row_block
+
+            pg = None if group == "world" else group
+            r0, r1 = row_block(ref.shape[0], dist.get_world_size(pg), dist.get_rank(pg))
+            self.ctx.set_allreduce(group)
+            self.ctx.check(self.ctx._L.xdemhip_nk_set_rows(self.handle, r0, r1, ctypes.byref(nv)))
+            self.n_valid = int(nv.value)
 
     def step(self, shift_x: float, shift_y: float, res: tuple[float, float], n_bins: int = 72) -> dict[str, Any]:
         edges = np.empty(n_bins + 1, dtype=np.float64)
@@ -88,6 +102,8 @@ class NKPlan:
         if getattr(self, "handle", None):
             self.ctx._L.xdemhip_nk_destroy(self.handle)
             self.handle = None
+            if getattr(self, "group", None) is not None:
+                self.ctx.set_allreduce(None)
 
     def __del__(self):  # pragma: no cover
         try:
@@ -130,15 +146,16 @@ def _bin_fit_from_step(det: dict[str, Any], fit_optimizer: Callable[..., Any], d
 
 def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarray | None, res: tuple[float, float],
               tolerance: float = 0.001, max_iterations: int = 10, bin_sizes: int = 72,
-              fit_optimizer: Callable[..., Any] | None = None, ctx: _lib.Context | None = None):
+              fit_optimizer: Callable[..., Any] | None = None, ctx: _lib.Context | None = None, group=None):
     """Array-level entry mirroring ``nuth_kaab`` (xdem/coreg/affine.py:539-609) for two rasters, subsample == 1.
+    ``group`` (torch.distributed process group or "world") shards every grid pass over the ranks by row block.
 
     Returns ((easting, northing, vertical) offsets in georeferenced units, subsample_final)."""
     import scipy.optimize
 
     fit_optimizer = fit_optimizer or scipy.optimize.curve_fit
     logging.info("Running Nuth and Kääb (2011) coregistration")
-    plan = NKPlan(ref_elev, tba_elev, inlier_mask, ctx)
+    plan = NKPlan(ref_elev, tba_elev, inlier_mask, ctx, group)
     try:
         if plan.n_valid == 0:
             raise ValueError(

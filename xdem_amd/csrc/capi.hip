@@ -52,6 +52,13 @@ int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream) {
     return XDEMHIP_OK;
 }
 
+int xdemhip_set_allreduce(xdemhip_ctx* ctx, xdemhip_allreduce_fn fn, void* user) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    ctx->allreduce = fn;
+    ctx->allreduce_user = user;
+    return XDEMHIP_OK;
+}
+
 int xdemhip_synchronize(xdemhip_ctx* ctx) {
     if (!ctx) return XDEMHIP_EINVAL;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -14,6 +14,8 @@ struct xdemhip_ctx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     int num_cu = 256;
+    xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)
+    void* allreduce_user = nullptr;
     std::string err;
 };
 
@@ -31,6 +33,21 @@ struct xdemhip_ctx {
 inline int xd_fail(xdemhip_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
+}
+
+// All-reduce a small device array over the ranks through the caller's hook (no-op without a hook): the array is
+// staged to the host, combined by the hook (torch.distributed / RCCL or gloo on the Python side) and copied back.
+inline int xd_allreduce_device(xdemhip_ctx* ctx, void* dptr, int64_t count, int kind) {
+    if (!ctx->allreduce || count <= 0) return XDEMHIP_OK;
+    std::string buf((size_t)count * 8, '\0');
+    hipError_t e = hipMemcpyAsync(&buf[0], dptr, buf.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce staging (D2H) failed");
+    if (ctx->allreduce(&buf[0], count, kind, ctx->allreduce_user) != 0) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
+    e = hipMemcpyAsync(dptr, &buf[0], buf.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce staging (H2D) failed");
+    return XDEMHIP_OK;
 }
 
 // Launchers implemented in the kernel translation units.

@@ -48,10 +48,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void nk_aux_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
                                                      const uint8_t* __restrict__ inlier, int64_t H, int64_t W,
                                                      T* __restrict__ slope_tan, T* __restrict__ aspect,
-                                                     uint8_t* __restrict__ valid, unsigned long long* n_valid) {
-    const int64_t n = H * W;
+                                                     uint8_t* __restrict__ valid, unsigned long long* n_valid,
+                                                     int64_t p0, int64_t p1) {
     unsigned long long local = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = p / W, j = p - i * W;
         const T c = ref[p];
         T gy, gx;
@@ -79,19 +79,18 @@ __global__ __launch_bounds__(256) void nk_aux_kernel(const T* __restrict__ ref, 
 }
 
 // ---- dh at a shifted position (stated bilinear convention) + first histogram digit of its global median -------
-template <typename T> struct DhStats {
-    typename KeyT<T>::type asp_min, asp_max;  // order-preserving keys of min / max aspect among finite dh
+struct DhStats {
+    uint64_t asp_min, asp_max;  // order-preserving keys (widened to 64 bit) of min / max aspect among finite dh
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
                                                     const uint8_t* __restrict__ valid, const T* __restrict__ aspect,
                                                     int64_t H, int64_t W, double dr, double dc, T* __restrict__ dh,
-                                                    DhStats<T>* stats) {
+                                                    DhStats* stats, int64_t p0, int64_t p1) {
     typedef typename KeyT<T>::type K;
-    const int64_t n = H * W;
     K kmin = ~(K)0, kmax = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += (int64_t)gridDim.x * blockDim.x) {
         T out = (T)NAN;
         if (valid[p]) {
             const int64_t i = p / W, j = p - i * W;
@@ -126,8 +125,8 @@ __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, c
         kmax = b > kmax ? b : kmax;
     }
     if ((threadIdx.x & 63) == 0) {
-        if (kmin != ~(K)0) k_atomic_min(&stats->asp_min, kmin);
-        if (kmax != 0) k_atomic_max(&stats->asp_max, kmax);
+        if (kmin != ~(K)0) k_atomic_min(&stats->asp_min, (uint64_t)kmin);
+        if (kmax != 0) k_atomic_max(&stats->asp_max, (uint64_t)kmax);
     }
 }
 
@@ -196,7 +195,8 @@ __global__ __launch_bounds__(512) void hist_pass_kernel(const T* __restrict__ va
 
 template <typename T>
 __global__ __launch_bounds__(512) void succ_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
-                                                        int64_t n, int nb, SelState<typename KeyT<T>::type>* st) {
+                                                        int64_t n, int nb, const SelState<typename KeyT<T>::type>* st,
+                                                        uint64_t* succ /* [nb], all-ones = none */) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K* m = reinterpret_cast<K*>(smem);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void succ_pass_kernel(const T* __restrict__ va
     }
     __syncthreads();
     for (int k = threadIdx.x; k < nb; k += blockDim.x)
-        if (m[k] != ~(K)0) k_atomic_min(&st[k].succ, m[k]);
+        if (m[k] != ~(K)0) k_atomic_min(&succ[k], (uint64_t)m[k]);
 }
 
 }  // namespace xd
@@ -224,12 +224,14 @@ struct xdemhip_nk_plan {
     xdemhip_ctx* ctx = nullptr;
     int dtype = XDEMHIP_F32;
     int64_t H = 0, W = 0;
+    int64_t p0 = 0, p1 = 0;               // this rank's pixel range [p0, p1) (whole raster unless xdemhip_nk_set_rows)
     void *ref = nullptr, *tba = nullptr;  // device (owned when own_inputs)
+    uint8_t* inlier = nullptr;            // device copy kept for re-partitioning (owned when own_inputs)
     bool own_inputs = false;
     void *slope_tan = nullptr, *aspect = nullptr, *dh = nullptr, *y = nullptr;
     uint8_t* valid = nullptr;
     uint16_t* bins = nullptr;
-    void* scratch = nullptr;  // states, histograms, stats, sums, edges
+    void* scratch = nullptr;  // edges, stats, sums, selection states, successor keys, histograms
     size_t scratch_bytes = 0;
     int max_bins = 0;
     long long n_valid0 = 0;
@@ -250,52 +252,77 @@ int grid_for(const xdemhip_ctx* ctx, int64_t n, int block, int per_cu) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-// scratch layout (bytes): [0, 16384) bin edges | +0 stats | +64 sums | +128 selection states | histograms
+// scratch layout (bytes): [0, 16384) bin edges | stats | sums | selection states | successor keys | histograms
 constexpr size_t OFF_STATS = 16384, OFF_SUMS = OFF_STATS + 64, OFF_STATE = OFF_STATS + 128;
-size_t off_hist(int nb) { return OFF_STATE + (size_t)(nb > 1 ? nb : 1) * 64; }
-size_t scratch_size(int nb) { return off_hist(nb) + (size_t)(nb > 1 ? nb : 1) * SEL_RADIX * 8 + 256; }
+int nb1(int nb) { return nb > 1 ? nb : 1; }
+size_t off_succ(int nb) { return OFF_STATE + (size_t)nb1(nb) * 64; }
+size_t off_hist(int nb) { return off_succ(nb) + (size_t)nb1(nb) * 8; }
+size_t scratch_size(int nb) { return off_hist(nb) + (size_t)nb1(nb) * SEL_RADIX * 8 + 256; }
 
-// Exact lower/upper medians of vals[] per bin (bins == nullptr: one bin).  Results: per-bin count, lo, hi values.
+template <typename K> struct SelResult {
+    SelState<K> st;
+    uint64_t succ;  // smallest key above the selected one, all-ones if none
+};
+
+// Exact lower/upper medians of vals[0..n) per bin (bins == nullptr: one bin).  With an all-reduce hook installed the
+// integer histograms / successor keys are combined over the ranks after every pass, so every rank selects the same
+// global order statistics from its own share of the data.
 template <typename T>
-int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, void* d_state, uint64_t* d_hist,
-               std::vector<SelState<typename KeyT<T>::type>>& host_state) {
+int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
+               std::vector<SelResult<typename KeyT<T>::type>>& out) {
     typedef typename KeyT<T>::type K;
-    SelState<K>* st = static_cast<SelState<K>*>(d_state);
+    SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
+    uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
+    uint64_t* d_hist = reinterpret_cast<uint64_t*>(scratch + off_hist(nb));
     XD_HIP_CHECK(ctx, hipMemsetAsync(st, 0, sizeof(SelState<K>) * nb, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_succ, 0xFF, 8 * (size_t)nb, ctx->stream));
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * (size_t)nb * SEL_RADIX, ctx->stream));
     const int passes = KeyT<T>::passes;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * (passes - 1 - p);
-        for (int b0 = 0; b0 < nb; b0 += MAX_BINS_PER_SWEEP) {
-            const int nbs = (nb - b0) < MAX_BINS_PER_SWEEP ? (nb - b0) : MAX_BINS_PER_SWEEP;
-            const size_t lds = (size_t)nbs * SEL_RADIX * sizeof(uint32_t);
-            int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, lds > 64 * 1024 ? 1 : 2)), dim3(512), lds,
-                               ctx->stream, vals, bins, n, nbs, b0, st, shift, (int)(p == 0), d_hist);
-            XD_HIP_CHECK(ctx, hipGetLastError());
-        }
+        if (n > 0)
+            for (int b0 = 0; b0 < nb; b0 += MAX_BINS_PER_SWEEP) {
+                const int nbs = (nb - b0) < MAX_BINS_PER_SWEEP ? (nb - b0) : MAX_BINS_PER_SWEEP;
+                const size_t lds = (size_t)nbs * SEL_RADIX * sizeof(uint32_t);
+                int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, lds > 64 * 1024 ? 1 : 2)), dim3(512), lds,
+                                   ctx->stream, vals, bins, n, nbs, b0, st, shift, (int)(p == 0), d_hist);
+                XD_HIP_CHECK(ctx, hipGetLastError());
+            }
+        int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
+        if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
                            (int)(p == 0), (int)(p == passes - 1));
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
-    const size_t lds = sizeof(K) * nb;
-    hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, 2)), dim3(512), lds, ctx->stream, vals, bins, n, nb, st);
-    XD_HIP_CHECK(ctx, hipGetLastError());
-    host_state.resize(nb);
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(host_state.data(), st, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, 2)), dim3(512), sizeof(K) * nb, ctx->stream, vals,
+                           bins, n, nb, st, d_succ);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    int rc = xd_allreduce_device(ctx, d_succ, nb, XDEMHIP_RED_MIN_U64);
+    if (rc) return rc;
+    std::vector<SelState<K>> hs(nb);
+    std::vector<uint64_t> hsucc(nb);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), st, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(hsucc.data(), d_succ, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
     XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out.resize(nb);
+    for (int k = 0; k < nb; ++k) { out[k].st = hs[k]; out[k].succ = hsucc[k]; }
     return XDEMHIP_OK;
 }
 
 // np.nanmedian of a bin from its selection state: odd count -> the middle value; even -> mean of the two middle
 // values in the value dtype (np.mean of a 2-element array).
-template <typename T> double median_from(const SelState<typename KeyT<T>::type>& s) {
+template <typename T> double median_from(const SelResult<typename KeyT<T>::type>& r) {
+    typedef typename KeyT<T>::type K;
+    const SelState<K>& s = r.st;
     if (s.count == 0) return NAN;
     const T lo = val_of(s.prefix);
     if (s.count & 1) return (double)lo;
     const uint64_t k2 = s.count / 2;  // 0-based rank of the upper median
-    const T hi = (s.n_le > k2) ? lo : val_of(s.succ);
+    const T hi = (s.n_le > k2) ? lo : val_of((K)r.succ);
     return (double)(T)((T)(lo + hi) / (T)2);
 }
 
@@ -308,15 +335,20 @@ template <typename T> void make_edges(double smin, double smax, int nb, std::vec
     e[nb] = (T)smax;
 }
 
-template <typename T> int nk_create_typed(xdemhip_nk_plan* P, const uint8_t* d_inlier) {
+// aux variables + valid mask for this rank's pixel range; global valid count through the hook
+template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
     xdemhip_ctx* ctx = P->ctx;
-    const int64_t n = P->H * P->W;
-    unsigned long long* d_cnt = static_cast<unsigned long long*>(P->scratch);
+    const int64_t n = P->p1 - P->p0;
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(P->scratch) + OFF_STATS);
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-    hipLaunchKernelGGL((nk_aux_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
-                       static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), d_inlier, P->H, P->W,
-                       static_cast<T*>(P->slope_tan), static_cast<T*>(P->aspect), P->valid, d_cnt);
-    XD_HIP_CHECK(ctx, hipGetLastError());
+    if (n > 0) {
+        hipLaunchKernelGGL((nk_aux_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+                           static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->inlier, P->H, P->W,
+                           static_cast<T*>(P->slope_tan), static_cast<T*>(P->aspect), P->valid, d_cnt, P->p0, P->p1);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    int rc = xd_allreduce_device(ctx, d_cnt, 1, XDEMHIP_RED_SUM_U64);
+    if (rc) return rc;
     unsigned long long c = 0;
     XD_HIP_CHECK(ctx, hipMemcpyAsync(&c, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -325,54 +357,41 @@ template <typename T> int nk_create_typed(xdemhip_nk_plan* P, const uint8_t* d_i
 }
 
 template <typename T>
-int binned_median_device(xdemhip_ctx* ctx, const T* d_x, const T* d_y, int64_t n, int nb, T* d_ybuf, uint16_t* d_bins,
-                         void* scratch, const std::vector<T>& edges, double* out_edges, int64_t* counts, double* medians) {
-    typedef typename KeyT<T>::type K;
-    unsigned char* base = static_cast<unsigned char*>(scratch);
-    void* d_state = base + OFF_STATE;
-    uint64_t* d_hist = reinterpret_cast<uint64_t*>(base + off_hist(nb));
-    (void)d_x; (void)d_y;
-    std::vector<SelState<K>> hs;
-    int rc = run_select<T>(ctx, d_ybuf, d_bins, n, nb, d_state, d_hist, hs);
-    if (rc) return rc;
-    for (int k = 0; k < nb; ++k) {
-        counts[k] = (int64_t)hs[k].count;
-        medians[k] = median_from<T>(hs[k]);
-    }
-    for (int k = 0; k <= nb; ++k) out_edges[k] = (double)edges[k];
-    return XDEMHIP_OK;
-}
-
-template <typename T>
 int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int nb, double* vshift,
                   int64_t* n_valid, double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians) {
     typedef typename KeyT<T>::type K;
     xdemhip_ctx* ctx = P->ctx;
-    const int64_t n = P->H * P->W;
+    const int64_t n = P->p1 - P->p0;
     unsigned char* base = static_cast<unsigned char*>(P->scratch);
-    DhStats<T>* d_stats = reinterpret_cast<DhStats<T>*>(base + OFF_STATS);
+    DhStats* d_stats = reinterpret_cast<DhStats*>(base + OFF_STATS);
     double* d_sums = reinterpret_cast<double*>(base + OFF_SUMS);
-    void* d_state = base + OFF_STATE;
-    uint64_t* d_hist = reinterpret_cast<uint64_t*>(base + off_hist(nb));
+    const T* dh = static_cast<const T*>(P->dh) + P->p0;
+    T* y = static_cast<T*>(P->y) + P->p0;
+    uint16_t* bins = P->bins + P->p0;
 
     // 1. dh at the shifted position: tba sampled at (row - shift_y / res_y, col + shift_x / res_x)
-    DhStats<T> hs0;
-    hs0.asp_min = ~(K)0;
+    DhStats hs0;
+    hs0.asp_min = ~(uint64_t)0;
     hs0.asp_max = 0;
     XD_HIP_CHECK(ctx, hipMemcpyAsync(d_stats, &hs0, sizeof hs0, hipMemcpyHostToDevice, ctx->stream));
     const double dr = -shift_y / res_y, dc = shift_x / res_x;
-    hipLaunchKernelGGL((nk_dh_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
-                       static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect),
-                       P->H, P->W, dr, dc, static_cast<T*>(P->dh), d_stats);
-    XD_HIP_CHECK(ctx, hipGetLastError());
+    if (n > 0) {
+        hipLaunchKernelGGL((nk_dh_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+                           static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect),
+                           P->H, P->W, dr, dc, static_cast<T*>(P->dh), d_stats, P->p0, P->p1);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    int rc = xd_allreduce_device(ctx, &d_stats->asp_min, 1, XDEMHIP_RED_MIN_U64);
+    if (rc) return rc;
+    rc = xd_allreduce_device(ctx, &d_stats->asp_max, 1, XDEMHIP_RED_MAX_U64);
+    if (rc) return rc;
 
     // 2. vertical shift = exact nanmedian(dh)
-    std::vector<SelState<K>> g;
-    int rc = run_select<T>(ctx, static_cast<const T*>(P->dh), nullptr, n, 1, d_state, d_hist, g);
+    std::vector<SelResult<K>> g;
+    rc = run_select<T>(ctx, dh, nullptr, n, 1, base, g);
     if (rc) return rc;
-    *n_valid = (int64_t)g[0].count;
-    if (g[0].count == 0)
-        return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
+    *n_valid = (int64_t)g[0].st.count;
+    if (g[0].st.count == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
     const double vs = median_from<T>(g[0]);
     *vshift = vs;
     XD_HIP_CHECK(ctx, hipMemcpyAsync(&hs0, d_stats, sizeof hs0, hipMemcpyDeviceToHost, ctx->stream));
@@ -380,28 +399,32 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
 
     // 3. y = (dh - vshift) / slope_tan, bin ids on SciPy's edges, sums
     std::vector<T> edges;
-    make_edges<T>((double)val_of(hs0.asp_min), (double)val_of(hs0.asp_max), nb, edges);
+    make_edges<T>((double)val_of((K)hs0.asp_min), (double)val_of((K)hs0.asp_max), nb, edges);
     T* d_edges = reinterpret_cast<T*>(base);
     XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, edges.data(), sizeof(T) * (nb + 1), hipMemcpyHostToDevice, ctx->stream));
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
-    hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream,
-                       static_cast<const T*>(P->dh), static_cast<const T*>(P->slope_tan), static_cast<const T*>(P->aspect), n,
-                       (T)vs, d_edges, nb, static_cast<T*>(P->y), P->bins, d_sums);
-    XD_HIP_CHECK(ctx, hipGetLastError());
-
-    // 4. per-bin exact medians
-    std::vector<SelState<K>> hs;
-    rc = run_select<T>(ctx, static_cast<const T*>(P->y), P->bins, n, nb, d_state, d_hist, hs);
+    if (n > 0) {
+        hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream, dh,
+                           static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, n, (T)vs, d_edges,
+                           nb, y, bins, d_sums);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    rc = xd_allreduce_device(ctx, d_sums, 2, XDEMHIP_RED_SUM_F64);
     if (rc) return rc;
     double sums[2];
-    XD_HIP_CHECK(ctx, hipMemcpy(sums, d_sums, 16, hipMemcpyDeviceToHost));
-    const double cnt = (double)g[0].count;
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream));
+
+    // 4. per-bin exact medians
+    std::vector<SelResult<K>> hs;
+    rc = run_select<T>(ctx, y, bins, n, nb, base, hs);  // (synchronises the stream: `sums` has landed)
+    if (rc) return rc;
+    const double cnt = (double)g[0].st.count;
     const double mean = sums[0] / cnt;
-    double var = sums[1] / cnt - mean * mean;
+    const double var = sums[1] / cnt - mean * mean;
     *y_mean = mean;
     *y_std = var > 0 ? sqrt(var) : 0.0;
     for (int k = 0; k < nb; ++k) {
-        counts[k] = (int64_t)hs[k].count;
+        counts[k] = (int64_t)hs[k].st.count;
         medians[k] = median_from<T>(hs[k]);
     }
     for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges[k];
@@ -415,7 +438,7 @@ extern "C" {
 void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     if (!P) return;
     (void)hipSetDevice(P->ctx->device);
-    if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); }
+    if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
     void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->scratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -432,22 +455,21 @@ int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const 
     const size_t es = dtype == XDEMHIP_F32 ? 4 : 8;
     const size_t n = (size_t)H * (size_t)W;
     xdemhip_nk_plan* P = new xdemhip_nk_plan();
-    P->ctx = ctx; P->dtype = dtype; P->H = H; P->W = W;
-    uint8_t* d_inlier = nullptr;
-    auto fail = [&](int code, const char* msg) { if (d_inlier && memspace == XDEMHIP_HOST) (void)hipFree(d_inlier); xdemhip_nk_destroy(P); return xd_fail(ctx, code, msg); };
+    P->ctx = ctx; P->dtype = dtype; P->H = H; P->W = W; P->p0 = 0; P->p1 = (int64_t)n;
+    auto fail = [&](int code, const char* msg) { xdemhip_nk_destroy(P); return xd_fail(ctx, code, msg); };
     if (memspace == XDEMHIP_HOST) {
         P->own_inputs = true;
         if (hipMalloc(&P->ref, n * es) != hipSuccess || hipMalloc(&P->tba, n * es) != hipSuccess) return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
         if (hipMemcpyAsync(P->ref, ref, n * es, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(P->tba, tba, n * es, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "H2D copy failed");
         if (inlier) {
-            if (hipMalloc(reinterpret_cast<void**>(&d_inlier), n) != hipSuccess) return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
-            if (hipMemcpyAsync(d_inlier, inlier, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "H2D copy failed");
+            if (hipMalloc(reinterpret_cast<void**>(&P->inlier), n) != hipSuccess) return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
+            if (hipMemcpyAsync(P->inlier, inlier, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "H2D copy failed");
         }
     } else {
         P->ref = const_cast<void*>(ref);
         P->tba = const_cast<void*>(tba);
-        d_inlier = const_cast<uint8_t*>(inlier);
+        P->inlier = const_cast<uint8_t*>(inlier);
     }
     P->max_bins = 1024;
     P->scratch_bytes = scratch_size(P->max_bins);
@@ -456,11 +478,27 @@ int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const 
         hipMalloc(reinterpret_cast<void**>(&P->valid), n) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&P->bins), n * 2) != hipSuccess || hipMalloc(&P->scratch, P->scratch_bytes) != hipSuccess)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
-    int rc = dtype == XDEMHIP_F32 ? nk_create_typed<float>(P, d_inlier) : nk_create_typed<double>(P, d_inlier);
-    if (d_inlier && memspace == XDEMHIP_HOST) { (void)hipFree(d_inlier); d_inlier = nullptr; }
+    const xdemhip_allreduce_fn hook = ctx->allreduce;
+    ctx->allreduce = nullptr;  // the whole-raster pass at creation is local; xdemhip_nk_set_rows re-partitions with the hook
+    int rc = dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
+    ctx->allreduce = hook;
     if (rc != XDEMHIP_OK) { xdemhip_nk_destroy(P); return rc; }
     if (n_valid) *n_valid = P->n_valid0;
     *out_plan = P;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, int64_t* n_valid) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (row_begin < 0 || row_end < row_begin || row_end > P->H) return xd_fail(ctx, XDEMHIP_EINVAL, "bad row range");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    P->p0 = row_begin * P->W;
+    P->p1 = row_end * P->W;
+    // valid mask / aux rasters outside the range are never read by this rank; recount the global number of valid pixels
+    int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
+    if (rc) return rc;
+    if (n_valid) *n_valid = P->n_valid0;
     return XDEMHIP_OK;
 }
 
@@ -468,6 +506,7 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* P, void* slope_tan, void* aspect, uint8_
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const size_t es = P->dtype == XDEMHIP_F32 ? 4 : 8, n = (size_t)P->H * (size_t)P->W;
     if (slope_tan) XD_HIP_CHECK(ctx, hipMemcpy(slope_tan, P->slope_tan, n * es, hipMemcpyDeviceToHost));
     if (aspect) XD_HIP_CHECK(ctx, hipMemcpy(aspect, P->aspect, n * es, hipMemcpyDeviceToHost));
@@ -501,13 +540,8 @@ int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dt
     if (n_bins < 1 || n_bins > 1024) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins out of range (1..1024)");
     if (dtype != XDEMHIP_F32 && dtype != XDEMHIP_F64) return xd_fail(ctx, XDEMHIP_EINVAL, "dtype must be float32 or float64");
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    // Host-side preparation mirrors nd_binning: keep finite pairs, edges from min / max of x, digitize on the device.
     const size_t es = dtype == XDEMHIP_F32 ? 4 : 8;
-    void *d_x = nullptr, *d_y = nullptr, *d_one = nullptr, *d_dh = nullptr, *d_yb = nullptr, *scratch = nullptr;
-    uint16_t* d_bins = nullptr;
-    int rc = XDEMHIP_OK;
-    auto cleanup = [&]() { void* b[] = {d_x, d_y, d_one, d_dh, d_yb, scratch, d_bins}; for (void* p : b) if (p) (void)hipFree(p); };
-    // finite filter + min/max on the host (O(n), not the hot path of this helper)
+    // finite filter + min / max on the host, like nd_binning (O(n); this helper is not a hot path)
     double smin = INFINITY, smax = -INFINITY;
     std::vector<unsigned char> xs((size_t)n * es), ys((size_t)n * es);
     int64_t m = 0;
@@ -523,6 +557,9 @@ int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dt
         ++m;
     }
     if (m == 0) { for (int k = 0; k < n_bins; ++k) { counts[k] = 0; medians[k] = NAN; } return XDEMHIP_OK; }
+    void *d_x = nullptr, *d_y = nullptr, *d_one = nullptr, *d_yb = nullptr, *scratch = nullptr;
+    uint16_t* d_bins = nullptr;
+    auto cleanup = [&]() { void* b[] = {d_x, d_y, d_one, d_yb, scratch, d_bins}; for (void* p : b) if (p) (void)hipFree(p); };
     if (hipMalloc(&d_x, m * es) != hipSuccess || hipMalloc(&d_y, m * es) != hipSuccess || hipMalloc(&d_one, m * es) != hipSuccess ||
         hipMalloc(&d_yb, m * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_bins), m * 2) != hipSuccess ||
         hipMalloc(&scratch, scratch_size(n_bins)) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed"); }
@@ -531,16 +568,23 @@ int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dt
     unsigned char* base = static_cast<unsigned char*>(scratch);
     double* d_sums = reinterpret_cast<double*>(base + OFF_SUMS);
     (void)hipMemsetAsync(d_sums, 0, 16, ctx->stream);
+    int rc;
+    const xdemhip_allreduce_fn hook = ctx->allreduce;
+    ctx->allreduce = nullptr;  // a purely local helper
     if (dtype == XDEMHIP_F32) {
         std::vector<float> e; make_edges<float>(smin, smax, n_bins, e);
         std::vector<float> ones((size_t)m, 1.0f);
         (void)hipMemcpyAsync(d_one, ones.data(), m * es, hipMemcpyHostToDevice, ctx->stream);
         (void)hipMemcpyAsync(base, e.data(), sizeof(float) * (n_bins + 1), hipMemcpyHostToDevice, ctx->stream);
-        // reuse nk_y_kernel with vshift = 0 and slope_tan = 1: y passes through unchanged (y / 1 - 0 is exact)
+        // reuse nk_y_kernel with vshift = 0 and slope_tan = 1: y passes through unchanged ((y - 0) / 1 is exact)
         hipLaunchKernelGGL((nk_y_kernel<float>), dim3(grid_for(ctx, m, 256, 16)), dim3(256), sizeof(float) * (n_bins + 1), ctx->stream,
                            static_cast<const float*>(d_y), static_cast<const float*>(d_one), static_cast<const float*>(d_x), m, 0.0f,
                            reinterpret_cast<const float*>(base), n_bins, static_cast<float*>(d_yb), d_bins, d_sums);
-        rc = binned_median_device<float>(ctx, nullptr, nullptr, m, n_bins, static_cast<float*>(d_yb), d_bins, scratch, e, edges, counts, medians);
+        std::vector<SelResult<uint32_t>> hs;
+        rc = run_select<float>(ctx, static_cast<const float*>(d_yb), d_bins, m, n_bins, base, hs);
+        if (rc == XDEMHIP_OK)
+            for (int k = 0; k < n_bins; ++k) { counts[k] = (int64_t)hs[k].st.count; medians[k] = median_from<float>(hs[k]); }
+        for (int k = 0; k <= n_bins; ++k) edges[k] = (double)e[k];
     } else {
         std::vector<double> e; make_edges<double>(smin, smax, n_bins, e);
         std::vector<double> ones((size_t)m, 1.0);
@@ -549,8 +593,13 @@ int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dt
         hipLaunchKernelGGL((nk_y_kernel<double>), dim3(grid_for(ctx, m, 256, 16)), dim3(256), sizeof(double) * (n_bins + 1), ctx->stream,
                            static_cast<const double*>(d_y), static_cast<const double*>(d_one), static_cast<const double*>(d_x), m, 0.0,
                            reinterpret_cast<const double*>(base), n_bins, static_cast<double*>(d_yb), d_bins, d_sums);
-        rc = binned_median_device<double>(ctx, nullptr, nullptr, m, n_bins, static_cast<double*>(d_yb), d_bins, scratch, e, edges, counts, medians);
+        std::vector<SelResult<uint64_t>> hs;
+        rc = run_select<double>(ctx, static_cast<const double*>(d_yb), d_bins, m, n_bins, base, hs);
+        if (rc == XDEMHIP_OK)
+            for (int k = 0; k < n_bins; ++k) { counts[k] = (int64_t)hs[k].st.count; medians[k] = median_from<double>(hs[k]); }
+        for (int k = 0; k <= n_bins; ++k) edges[k] = (double)e[k];
     }
+    ctx->allreduce = hook;
     (void)hipStreamSynchronize(ctx->stream);
     cleanup();
     return rc;

@@ -45,7 +45,6 @@ template <> struct KeyT<double> { typedef uint64_t type; static constexpr int pa
 // Per-bin selection state kept on the device.
 template <typename K> struct SelState {
     K prefix;          // key bits fixed so far (high digits)
-    K succ;            // smallest key > selected key (for even counts), all-ones if none
     uint64_t rank;     // remaining 0-based rank inside the current prefix group
     uint64_t count;    // elements in the bin
     uint64_t n_le;     // elements <= selected key (valid after the last pass)
@@ -64,7 +63,6 @@ __global__ void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, i
             s.count = tot;
             s.rank = tot ? (tot - 1) / 2 : 0;  // lower median
             s.prefix = 0;
-            s.succ = ~(K)0;
             s.n_le = 0;
         }
         if (s.count) {
