@@ -135,6 +135,13 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
                           int64_t* counts, double* medians);
 
+/* "Next" row f1: the step right after a Nuth-Kaab fit -- resampling the translated DEM back onto
+ * its own grid, i.e. _reproject_horizontal_shift_samecrs(raster_arr, src_transform, dst_transform)
+ * (xdem/coreg/base.py:1615-1655) as used by Coreg.apply for pure translations:
+ *     out(r, c) = bilinear(src)(r + shift_row_px, c + shift_col_px) + dz      (same tap convention as xdemhip_nk_step) */
+int xdemhip_shift_bilinear(xdemhip_ctx* ctx, const void* src, int dtype, int64_t H, int64_t W, double shift_row_px,
+                           double shift_col_px, double dz, void* out, int memspace);
+
 /* ---- path 3: empirical variogram, pairwise lag binning -----------------------------------------------
  * Replaces the pairwise work sample_empirical_variogram delegates to scikit-gstat:
  *   skg.Variogram(coordinates, values, bin_func=<right edges>, maxlag=, estimator=)      xdem/spatialstats.py:1091  (pdist)

@@ -248,3 +248,21 @@ def test_row_sharding_is_exact(coreg):
         state["replay"] = [x.copy() for x in logs[1]]
     assert got["vshift"] == want["vshift"] and got["n_valid"] == want["n_valid"]
     assert np.array_equal(got["counts"], want["counts"]) and np.array_equal(got["medians"], want["medians"], equal_nan=True)
+
+
+def test_apply_translation_matches_oracle_and_realigns(coreg):
+    """f1: out(r,c) = elev(r + sy/res, c - sx/res) + sz; applying the fitted shift re-aligns the pair."""
+    ref, tba, inlier, res = _pair((160, 220))
+    for sx, sy, sz in ((17.0, -6.0, 2.0), (0.0, 0.0, -1.5), (-23.5, 4.25, 0.0)):
+        got = coreg.apply_translation(tba, sx, sy, sz, res)
+        # oracle: shifted_dh(ref=0, tba, E, N) = -tba(row - N/res, col + E/res)  with E = -sx, N = -sy
+        want = -nko.shifted_dh(np.zeros_like(tba), tba, -sx, -sy, (res, res)) + tba.dtype.type(sz)
+        assert np.array_equal(got, want.astype(tba.dtype), equal_nan=True)
+    nk = coreg.NuthKaab(subsample=1).fit(ref, tba, inlier, resolution=res)
+    aligned = nk.apply(tba, res)
+    ok = np.isfinite(aligned) & np.isfinite(ref)
+    before = np.isfinite(tba) & np.isfinite(ref)
+    assert np.nanstd((ref - aligned)[ok]) < np.nanstd((ref - tba)[before])  # (a rough fBm is not bilinear-invertible)
+    assert abs(np.nanmedian((ref - aligned)[ok])) < 0.05
+    with pytest.raises(ValueError, match="all nans"):
+        coreg.apply_translation(np.full((4, 4), np.nan, np.float32), 1, 1, 1, 1.0)

@@ -67,6 +67,8 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_nk_destroy.restype = None
         L.xdemhip_binned_median.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                             c_dp, c_i64p, c_dp]
+        L.xdemhip_shift_bilinear.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_nk_set_rows.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_i64p]
         c_u64p = ctypes.POINTER(ctypes.c_uint64)

@@ -179,6 +179,29 @@ def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarra
         plan.close()
 
 
+def apply_translation(elev: np.ndarray, shift_x: float, shift_y: float, shift_z: float, resolution, resample: bool = True,
+                      ctx: _lib.Context | None = None) -> np.ndarray:
+    """Apply a pure translation to a DEM array (``Coreg.apply`` for ``shift_x / shift_y / shift_z``): with
+    ``resample=True`` the shifted DEM is bilinearly resampled onto its original grid
+    (``_apply_matrix_rst`` case 2 + ``_reproject_horizontal_shift_samecrs``, xdem/coreg/base.py:1522-1570, 1615-1655):
+    ``out(r, c) = elev(r + shift_y / res_y, c - shift_x / res_x) + shift_z``.  Without resampling only ``shift_z`` is
+    added (the reference then just moves the geotransform)."""
+    arr = np.ascontiguousarray(elev.filled(np.nan) if isinstance(elev, np.ma.MaskedArray) else elev)
+    if arr.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        arr = arr.astype(np.float32)
+    if np.count_nonzero(np.isfinite(arr)) == 0:
+        raise ValueError("Input DEM has all nans.")
+    if not resample:
+        return arr + arr.dtype.type(shift_z)
+    res = (float(resolution), float(resolution)) if np.isscalar(resolution) else (float(resolution[0]), float(resolution[1]))
+    ctx = ctx or _lib.default_context()
+    out = np.empty_like(arr)
+    ctx.check(ctx._L.xdemhip_shift_bilinear(ctx.handle, arr.ctypes.data, _lib.F32 if arr.dtype == np.float32 else _lib.F64,
+                                            arr.shape[0], arr.shape[1], float(shift_y) / res[1], -float(shift_x) / res[0],
+                                            float(shift_z), out.ctypes.data, _lib.HOST))
+    return out
+
+
 class NuthKaab:
     """Nuth and Kaab (2011) coregistration: horizontal and vertical translations by iterative slope/aspect alignment.
 
@@ -239,6 +262,11 @@ class NuthKaab:
         self.meta["outputs"]["affine"] = {"shift_x": -east, "shift_y": -north, "shift_z": vert * self.vertical_shift}
         self.meta["outputs"]["random"] = {"subsample_final": n_final}
         return self
+
+    def apply(self, elev: np.ndarray, resolution: float | tuple[float, float], resample: bool = True) -> np.ndarray:
+        """Apply the estimated translation to a DEM array on the fit grid (Coreg.apply, translation case)."""
+        a = self.meta["outputs"]["affine"]
+        return apply_translation(elev, a["shift_x"], a["shift_y"], a["shift_z"], resolution, resample)
 
     def to_matrix(self) -> np.ndarray:
         """4x4 translation matrix (affine.py:2532-2541)."""

@@ -130,6 +130,33 @@ __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, c
     }
 }
 
+// ---- full-grid translation resample (Coreg.apply for a pure shift) --------------------------------
+// out(r, c) = bilinear(src)(r + dr, c + dc) + dz with the same stated tap convention as nk_dh_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void shift_bilinear_kernel(const T* __restrict__ src, int64_t H, int64_t W, double dr, double dc,
+                                                             T dz, T* __restrict__ out) {
+    const int64_t n = H * W;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = p / W, j = p - i * W;
+        const double rr = t_add((double)i, dr), cc = t_add((double)j, dc);
+        const double r0f = floor(rr), c0f = floor(cc);
+        const double fr = t_sub(rr, r0f), fc = t_sub(cc, c0f);
+        const int64_t r0 = (int64_t)r0f, c0 = (int64_t)c0f;
+        T o = (T)NAN;
+        if (r0 >= 0 && r0 + 1 < H && c0 >= 0 && c0 + 1 < W) {
+            const T* q = src + r0 * W + c0;
+            const T a00 = q[0], a01 = q[1], a10 = q[W], a11 = q[W + 1];
+            if (t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11)) {
+                const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
+                const double top = t_add(v00, t_mul(fc, t_sub(v01, v00)));
+                const double bot = t_add(v10, t_mul(fc, t_sub(v11, v10)));
+                o = t_add((T)t_add(top, t_mul(fr, t_sub(bot, top))), dz);
+            }
+        }
+        out[p] = o;
+    }
+}
+
 // ---- y = (dh - vshift) / slope_tan, aspect bin id, sums for nanmean / nanstd --------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, const T* __restrict__ slope_tan,
@@ -528,6 +555,46 @@ int xdemhip_nk_step(xdemhip_nk_plan* P, double shift_x, double shift_y, double r
                  : nk_step_typed<double>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, counts, medians);
     (void)hipEventRecord(ctx->ev_stop, ctx->stream);
     ctx->timed = (rc == XDEMHIP_OK);
+    return rc;
+}
+
+// resample a raster shifted by (shift_col, shift_row) pixels (+ dz) back onto its own grid -- the
+// translation case of Coreg.apply(resample=True): _reproject_horizontal_shift_samecrs, xdem/coreg/base.py:1615-1655.
+int xdemhip_shift_bilinear(xdemhip_ctx* ctx, const void* src, int dtype, int64_t H, int64_t W, double shift_row_px,
+                           double shift_col_px, double dz, void* out, int memspace) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (!src || !out || H < 1 || W < 1) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    if (dtype != XDEMHIP_F32 && dtype != XDEMHIP_F64) return xd_fail(ctx, XDEMHIP_EINVAL, "dtype must be float32 or float64");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t es = dtype == XDEMHIP_F32 ? 4 : 8, bytes = (size_t)H * (size_t)W * es;
+    void *d_src = const_cast<void*>(src), *d_out = out;
+    if (memspace == XDEMHIP_HOST) {
+        d_src = d_out = nullptr;
+        if (hipMalloc(&d_src, bytes) != hipSuccess || hipMalloc(&d_out, bytes) != hipSuccess) {
+            if (d_src) (void)hipFree(d_src);
+            return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+        }
+        (void)hipMemcpyAsync(d_src, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    }
+    const int64_t n = H * W;
+    XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    if (dtype == XDEMHIP_F32)
+        hipLaunchKernelGGL((shift_bilinear_kernel<float>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+                           static_cast<const float*>(d_src), H, W, shift_row_px, shift_col_px, (float)dz, static_cast<float*>(d_out));
+    else
+        hipLaunchKernelGGL((shift_bilinear_kernel<double>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+                           static_cast<const double*>(d_src), H, W, shift_row_px, shift_col_px, dz, static_cast<double*>(d_out));
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+    ctx->timed = true;
+    int rc = XDEMHIP_OK;
+    if (hipGetLastError() != hipSuccess) rc = xd_fail(ctx, XDEMHIP_EHIP, "shift kernel launch failed");
+    if (memspace == XDEMHIP_HOST) {
+        if (rc == XDEMHIP_OK && (hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                                 hipStreamSynchronize(ctx->stream) != hipSuccess))
+            rc = xd_fail(ctx, XDEMHIP_EHIP, "shift kernel / D2H failed");
+        (void)hipFree(d_src);
+        (void)hipFree(d_out);
+    }
     return rc;
 }
 
