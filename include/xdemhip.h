@@ -36,7 +36,7 @@ enum { XDEMHIP_CURV_GEOMETRIC = 0, XDEMHIP_CURV_DIRECTIONAL = 1 };
 enum { XDEMHIP_TRI_RILEY = 0, XDEMHIP_TRI_WILSON = 1 };
 
 /* Attribute bits.  Bits 0-9 follow the reference's fixed attribute order (surfit.py:407-418), bits 10-11
- * are the two windowed indexes of window.py:752-758 that are on the hot path. */
+ * are the two windowed indexes of window.py:752-758 that are on the hot path, bit 12 the first "next" one. */
 enum {
     XDEMHIP_ATTR_SLOPE = 1u << 0,
     XDEMHIP_ATTR_ASPECT = 1u << 1,
@@ -50,7 +50,8 @@ enum {
     XDEMHIP_ATTR_MIN_CURVATURE = 1u << 9,
     XDEMHIP_ATTR_TPI = 1u << 10,
     XDEMHIP_ATTR_TRI = 1u << 11,
-    XDEMHIP_ATTR_COUNT = 12
+    XDEMHIP_ATTR_ROUGHNESS = 1u << 12, /* max - min of the window (window.py:261-308) */
+    XDEMHIP_ATTR_COUNT = 13
 };
 
 /* ---- context ------------------------------------------------------------------------------------- */

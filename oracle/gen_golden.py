@@ -160,8 +160,8 @@ def terrain_T4_T5() -> None:
     for w in (3, 5, 7):
         for tri in ("Riley", "Wilson"):
             for key in ("dem", "dem64"):
-                outs = run_ref(rec[key], WIN, window_size=w, tri_method=tri)
-                for a, o in zip(WIN, outs):
+                outs = run_ref(rec[key], WIN + ["roughness"], window_size=w, tri_method=tri)
+                for a, o in zip(WIN + ["roughness"], outs):
                     rec[f"{key}|{w}|{tri}|{a}"] = o
     np.savez_compressed(os.path.join(OUT, "terrain_T5_windows.npz"), **rec)
 

@@ -40,7 +40,7 @@ SURFACE_ATTRIBUTES = (
     "max_curvature",
     "min_curvature",
 )
-WINDOW_ATTRIBUTES = ("topographic_position_index", "terrain_ruggedness_index")
+WINDOW_ATTRIBUTES = ("topographic_position_index", "terrain_ruggedness_index", "roughness")
 FITS = {"horn": 0, "zevenbergthorne": 1, "florinsky": 2}
 
 # ---------------------------------------------------------------------------------------------
@@ -287,6 +287,10 @@ def windowed_indexes(
                     out[i] = np.sqrt(_np_sum_axis0(diff**2))
                 else:
                     out[i] = _np_sum_axis0(diff) / (w**2 - 1)
+            elif name == "roughness":  # window.py:261-289: max - min, NaN if any NaN in the window
+                r = np.max(stack, axis=0) - np.min(stack, axis=0)
+                r[np.isnan(stack).any(axis=0)] = np.nan
+                out[i] = r
             else:
                 raise ValueError(f"oracle does not cover windowed index '{name}'")
     return out

@@ -13,7 +13,7 @@ SO = os.path.join(HERE, "hostsim", "_hostsim.so")
 ATTR_BITS = {
     "slope": 0, "aspect": 1, "hillshade": 2, "curvature": 3, "profile_curvature": 4, "tangential_curvature": 5,
     "planform_curvature": 6, "flowline_curvature": 7, "max_curvature": 8, "min_curvature": 9,
-    "topographic_position_index": 10, "terrain_ruggedness_index": 11,
+    "topographic_position_index": 10, "terrain_ruggedness_index": 11, "roughness": 12,
 }
 FITS = {"horn": 0, "zevenbergthorne": 1, "florinsky": 2}
 
@@ -34,7 +34,7 @@ def hostsim_terrain(dem, attrs, resolution=1.0, surface_fit="Florinsky", curv_me
     Hbuf, W = dem.shape
     H = Hbuf - halo_top - halo_bottom
     mask = 0
-    planes = (ctypes.c_void_p * 12)()
+    planes = (ctypes.c_void_p * 13)()
     outs = {}
     for a in attrs:
         b = ATTR_BITS[a]

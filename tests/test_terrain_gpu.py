@@ -177,3 +177,20 @@ def test_large_properties_16384(terrain):
     for i, r in enumerate(ref):
         g = out[i, 5002:5062, 3002:3398].cpu().numpy()
         assert_parity(g, r[2:-2, 2:-2], FULL[i])
+
+
+@pytest.mark.parametrize("w", [3, 5])
+def test_roughness_next_row_f2(terrain, w):
+    """SURVEY 8f-2 (first windowed index beyond TPI/TRI): max - min of the window, NaN if any NaN."""
+    dem = _dem((90, 300), seed=13)
+    dem[40, 100] = np.inf
+    attrs = ["roughness", "topographic_position_index", "slope"]
+    got = terrain.get_terrain_attribute(dem, attrs, window_size=w, resolution=2.0)
+    ref = to.terrain_attributes(dem, attrs, window_size=w, resolution=2.0)
+    assert np.array_equal(got[0], ref[0], equal_nan=True)  # pure selection: bit-exact
+    for g, r in zip(got[1:], ref[1:]):
+        assert_parity(g, r, f"w{w}")
+    assert np.array_equal(terrain.roughness(dem, window_size=w), ref[0], equal_nan=True)
+    z = np.load(os.path.join(GOLDEN, "terrain_T5_windows.npz"))
+    key = f"dem|{w}|Riley|roughness"
+    assert np.array_equal(terrain.roughness(z["dem"], window_size=w), z[key], equal_nan=True)  # reference's own output

@@ -93,7 +93,7 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     const uint32_t curv_bits = attr_mask & 0x3f8u;
     if (surface_fit == XDEMHIP_FIT_HORN && curv_bits)
         return xd_fail(ctx, XDEMHIP_EINVAL, "'Horn' surface fit cannot be used to calculate curvatures");
-    if ((attr_mask & 0xc00u) && (window_size < 3 || (window_size & 1) == 0 || window_size > 1023))
+    if ((attr_mask & 0x1c00u) && (window_size < 3 || (window_size & 1) == 0 || window_size > 1023))
         return xd_fail(ctx, XDEMHIP_EINVAL, "window_size must be odd and >= 3");
     if ((attr_mask & 0x3ffu) && !(resolution > 0.0) ) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
     if (memspace != XDEMHIP_HOST && memspace != XDEMHIP_DEVICE) return xd_fail(ctx, XDEMHIP_EINVAL, "bad memspace");

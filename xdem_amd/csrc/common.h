@@ -60,7 +60,7 @@ struct TerrainLaunch {
     int surface_fit, curv_method, tri_method, window_size, degrees;
     uint32_t attr_mask;
     double hs_alt, hs_az, hs_z;
-    void* planes[12];    // device pointers by attribute bit (null when not requested)
+    void* planes[13];    // device pointers by attribute bit (null when not requested)
 };
 int launch_terrain(xdemhip_ctx* ctx, const TerrainLaunch& L);
 }  // namespace xd

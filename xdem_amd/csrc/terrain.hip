@@ -98,13 +98,14 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(256) void window_generic_kernel(const TIN* dem, int64_t H, int64_t W, int64_t stride,
                                                               int64_t halo_top, int64_t halo_bottom, int w,
-                                                              int tri_wilson, TOUT* tpi, TOUT* tri) {
+                                                              int tri_wilson, TOUT* tpi, TOUT* tri, TOUT* rough) {
     const int64_t x = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int64_t y = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const int h = w / 2;
     const double c = (double)dem[(y + halo_top) * stride + x];
-    double sum = 0.0, acc = 0.0;
+    double sum = 0.0, acc = 0.0, mx = -INFINITY, mn = INFINITY;
+    bool has_nan = false;
     for (int dy = -h; dy <= h; ++dy) {
         const int64_t yy = y + dy;
         const bool rowok = (yy >= -halo_top) && (yy < H + halo_bottom);
@@ -112,6 +113,9 @@ __global__ __launch_bounds__(256) void window_generic_kernel(const TIN* dem, int
             const int64_t xx = x + dx;
             const double v = (rowok && xx >= 0 && xx < W) ? (double)dem[(yy + halo_top) * stride + xx] : (double)NAN;
             sum += v;
+            has_nan |= (v != v);
+            mx = v > mx ? v : mx;
+            mn = v < mn ? v : mn;
             const double d = fabs(v - c);
             acc = tri_wilson ? (acc + d) : fma(d, d, acc);
         }
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(256) void window_generic_kernel(const TIN* dem, int
     const int64_t o = y * W + x;
     if (tpi) tpi[o] = (TOUT)(c - (sum - c) / nn);
     if (tri) tri[o] = (TOUT)(tri_wilson ? acc / nn : sqrt(acc));
+    if (rough) rough[o] = has_nan ? (TOUT)NAN : (TOUT)(mx - mn);
 }
 
 static void fill_params(const TerrainLaunch& L, TerrainParams& P) {
@@ -205,7 +210,8 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
                            static_cast<const TIN*>(L.dem), L.H, L.W, L.row_stride, L.halo_top, L.halo_bottom,
                            L.window_size, (int)(L.tri_method == XDEMHIP_TRI_WILSON),
                            (win & A_TPI) ? static_cast<TOUT*>(L.planes[P_TPI]) : nullptr,
-                           (win & A_TRI) ? static_cast<TOUT*>(L.planes[P_TRI]) : nullptr);
+                           (win & A_TRI) ? static_cast<TOUT*>(L.planes[P_TRI]) : nullptr,
+                           (win & A_ROUGH) ? static_cast<TOUT*>(L.planes[P_ROUGH]) : nullptr);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     return XDEMHIP_OK;

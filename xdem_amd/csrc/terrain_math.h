@@ -36,13 +36,13 @@ namespace xd {
 enum : uint32_t {
     A_SLOPE = 1u << 0, A_ASPECT = 1u << 1, A_HILLSHADE = 1u << 2, A_CURVATURE = 1u << 3, A_PROFILE = 1u << 4,
     A_TANGENTIAL = 1u << 5, A_PLANFORM = 1u << 6, A_FLOWLINE = 1u << 7, A_MAXC = 1u << 8, A_MINC = 1u << 9,
-    A_TPI = 1u << 10, A_TRI = 1u << 11,
+    A_TPI = 1u << 10, A_TRI = 1u << 11, A_ROUGH = 1u << 12,
     A_ANY_CURV = A_CURVATURE | A_PROFILE | A_TANGENTIAL | A_PLANFORM | A_FLOWLINE | A_MAXC | A_MINC,
-    A_ANY_WIN = A_TPI | A_TRI
+    A_ANY_WIN = A_TPI | A_TRI | A_ROUGH
 };
-constexpr int N_ATTR = 12;
+constexpr int N_ATTR = 13;
 enum { P_SLOPE = 0, P_ASPECT, P_HILLSHADE, P_CURVATURE, P_PROFILE, P_TANGENTIAL, P_PLANFORM, P_FLOWLINE, P_MAXC,
-       P_MINC, P_TPI, P_TRI };
+       P_MINC, P_TPI, P_TRI, P_ROUGH };
 
 struct TerrainParams {
     double s1;       // 1 / (c * res)        first derivatives  (c = 8 Horn, 2 ZT, 420 Florinsky)
@@ -142,7 +142,7 @@ template <uint32_t CMASK_, int DIR_, int DEG_, int WILSON_, int ZF1_ = -1> struc
     static constexpr int DIR = DIR_, DEG = DEG_, WILSON = WILSON_, ZF1 = ZF1_;  // ZF1: hillshade z_factor == 1
 };
 typedef Spec<0, -1, -1, -1, -1> SpecRuntime;
-constexpr uint32_t MASK_FULL11 = 0xFFFu & ~A_CURVATURE;  // the 11-attribute headline set (no deprecated 'curvature')
+constexpr uint32_t MASK_FULL11 = 0xFFFu & ~A_CURVATURE;  // (bits 0-11)  // the 11-attribute headline set (no deprecated 'curvature')
 constexpr uint32_t MASK_SAH_WIN = A_SLOPE | A_ASPECT | A_HILLSHADE | A_TPI | A_TRI;
 
 // ---- attributes from the five derivative estimates ----------------------------------------------------
@@ -247,6 +247,18 @@ XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams&
     const bool wilson = SP::WILSON < 0 ? (P.tri_wilson != 0) : (SP::WILSON != 0);
     const double c = n[4];
     if (m & A_TPI) put(out.p[P_TPI], o, (TOUT)((TOUT)(c - (sum9 - c) * 0.125)));
+    if (m & A_ROUGH) {
+        // Dartnell roughness: max - min of the window, NaN if any NaN (window.py:261-289); +-Inf propagate like NumPy
+        double mx = n[0], mn = n[0];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            mx = (n[k] > mx) ? n[k] : mx;
+            mn = (n[k] < mn) ? n[k] : mn;
+        }
+        const bool has_nan = (n[0] != n[0]) | (n[1] != n[1]) | (n[2] != n[2]) | (n[3] != n[3]) | (n[4] != n[4]) |
+                             (n[5] != n[5]) | (n[6] != n[6]) | (n[7] != n[7]) | (n[8] != n[8]);
+        put(out.p[P_ROUGH], o, has_nan ? (TOUT)NAN : (TOUT)(mx - mn));
+    }
     if (m & A_TRI) {
         double acc = c - c;  // the centre's own term: 0, or NaN when the centre is +-Inf (IEEE, like the reference)
         if (wilson) {

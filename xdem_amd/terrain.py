@@ -7,8 +7,8 @@ engines behind it are the fused HIP kernel of ``csrc/terrain.hip`` reached throu
 
 Covered attributes (the hot path named in BASELINE.json): slope, aspect, hillshade, curvature
 (deprecated), profile / tangential / planform / flowline / max / min curvature, topographic position
-index, terrain ruggedness index.  ``roughness``, ``rugosity``, ``fractal_roughness`` and
-``texture_shading`` are outside that path and raise ``NotImplementedError`` here.
+index, terrain ruggedness index, plus ``roughness`` (first "next" row).  ``rugosity``,
+``fractal_roughness`` and ``texture_shading`` are outside the path and raise ``NotImplementedError`` here.
 """
 from __future__ import annotations
 
@@ -39,9 +39,9 @@ list_requiring_frequency_domain = ["texture_shading"]
 ATTR_BIT = {
     "slope": 0, "aspect": 1, "hillshade": 2, "curvature": 3, "profile_curvature": 4, "tangential_curvature": 5,
     "planform_curvature": 6, "flowline_curvature": 7, "max_curvature": 8, "min_curvature": 9,
-    "topographic_position_index": 10, "terrain_ruggedness_index": 11,
+    "topographic_position_index": 10, "terrain_ruggedness_index": 11, "roughness": 12,
 }
-_NOT_ON_HOT_PATH = ("roughness", "rugosity", "fractal_roughness", "texture_shading")
+_NOT_ON_HOT_PATH = ("rugosity", "fractal_roughness", "texture_shading")
 _FIT_ID = {"horn": 0, "zevenbergthorne": 1, "florinsky": 2}
 _CURV_ID = {"geometric": 0, "directional": 1}
 _TRI_ID = {"riley": 0, "wilson": 1}
@@ -317,6 +317,11 @@ def topographic_position_index(dem, window_size=3, mp_config=None, engine="hip")
     """TPI (terrain.py:1468-1508)."""
     return get_terrain_attribute(dem=dem, attribute="topographic_position_index", window_size=window_size,
                                  mp_config=mp_config, engine=engine)
+
+
+def roughness(dem, window_size=3, mp_config=None, engine="hip"):
+    """Roughness: largest elevation difference inside the window (terrain.py:1600-1640)."""
+    return get_terrain_attribute(dem=dem, attribute="roughness", window_size=window_size, mp_config=mp_config, engine=engine)
 
 
 def terrain_ruggedness_index(dem, method="Riley", window_size=3, mp_config=None, engine="hip"):
