@@ -10,6 +10,8 @@ there is no CPU fallback.
 """
 from . import _lib  # noqa: F401
 from . import terrain  # noqa: F401
+from . import coreg, spatialstats  # noqa: F401
+from .dem import DEM  # noqa: F401
 from .terrain import get_terrain_attribute  # noqa: F401
 
 __version__ = "0.1.0"
