@@ -140,7 +140,7 @@ def test_full_fit_vs_oracle_and_reference(coreg, z):
         # float32 by NumPy.  Agreement is therefore asserted at the method's own convergence threshold (1e-3 px).
         assert np.allclose(offsets, o_off, rtol=0, atol=1e-3 * res)
         assert np.allclose(offsets, z[f"T9|{tol}|offsets"], rtol=0, atol=1e-3 * res)  # the reference's own loop
-        assert offsets[2] == o_off[2]  # vertical shift = exact median: bit-identical
+        assert abs(offsets[2] - o_off[2]) < 1e-3  # (medians are exact per step; the offsets they are taken at differ as above)
 
 
 def test_class_api_recovers_shift(coreg):

@@ -50,9 +50,13 @@ __global__ __launch_bounds__(256) void nk_aux_kernel(const T* __restrict__ ref, 
                                                      T* __restrict__ slope_tan, T* __restrict__ aspect,
                                                      uint8_t* __restrict__ valid, unsigned long long* n_valid,
                                                      int64_t p0, int64_t p1) {
+    // rows [p0 / W, p1 / W) (row-aligned ranges): blockIdx.x tiles the columns, blockIdx.y strides over the rows
     unsigned long long local = 0;
-    for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = p / W, j = p - i * W;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row0 = p0 / W, row1 = p1 / W;
+    if (j < W)
+    for (int64_t i = row0 + blockIdx.y; i < row1; i += gridDim.y) {
+        const int64_t p = i * W + j;
         const T c = ref[p];
         T gy, gx;
         // np.gradient, unit spacing: central differences inside, one-sided on the borders
@@ -90,32 +94,40 @@ __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, c
                                                     DhStats* stats, int64_t p0, int64_t p1) {
     typedef typename KeyT<T>::type K;
     K kmin = ~(K)0, kmax = 0;
-    for (int64_t p = p0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p1; p += (int64_t)gridDim.x * blockDim.x) {
-        T out = (T)NAN;
-        if (valid[p]) {
-            const int64_t i = p / W, j = p - i * W;
-            const double rr = t_add((double)i, dr), cc = t_add((double)j, dc);
-            const double r0f = floor(rr), c0f = floor(cc);
-            const double fr = t_sub(rr, r0f), fc = t_sub(cc, c0f);
-            const int64_t r0 = (int64_t)r0f, c0 = (int64_t)c0f;
-            if (r0 >= 0 && r0 + 1 < H && c0 >= 0 && c0 + 1 < W) {
-                const T* q = tba + r0 * W + c0;
-                const T a00 = q[0], a01 = q[1], a10 = q[W], a11 = q[W + 1];
-                if (t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11)) {
-                    const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
-                    const double top = t_add(v00, t_mul(fc, t_sub(v01, v00)));
-                    const double bot = t_add(v10, t_mul(fc, t_sub(v11, v10)));
-                    const double val = t_add(top, t_mul(fr, t_sub(bot, top)));
-                    out = t_sub(ref[p], (T)val);
-                    if (t_finite(out)) {
-                        const K ka = key_of(aspect[p]);
-                        kmin = ka < kmin ? ka : kmin;
-                        kmax = ka > kmax ? ka : kmax;
-                    } else {
-                        out = (T)NAN;
-                    }
-                }
-            }
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row0 = p0 / W, row1 = p1 / W;
+    // column-invariant part of the bilinear tap position
+    const double cc = t_add((double)j, dc);
+    const double c0f = floor(cc);
+    const double fc = t_sub(cc, c0f);
+    const int64_t c0 = (int64_t)c0f;
+    const bool col_ok = j < W && c0 >= 0 && c0 + 1 < W;
+    const int64_t c0c = col_ok ? c0 : 0;
+    if (j < W)
+    for (int64_t i = row0 + blockIdx.y; i < row1; i += gridDim.y) {
+        const int64_t p = i * W + j;
+        const double rr = t_add((double)i, dr);
+        const double r0f = floor(rr);
+        const double fr = t_sub(rr, r0f);
+        const int64_t r0 = (int64_t)r0f;
+        const bool in = col_ok && r0 >= 0 && r0 + 1 < H;
+        // all loads issued unconditionally (clamped taps) so they overlap; validity is applied afterwards
+        const T* q = tba + (in ? r0 : 0) * W + c0c;
+        const T a00 = q[0], a01 = q[1], a10 = q[W], a11 = q[W + 1];
+        const T rv = ref[p];
+        const T av = aspect[p];
+        const bool ok = valid[p] && in && t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11);
+        const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
+        const double top = t_add(v00, t_mul(fc, t_sub(v01, v00)));
+        const double bot = t_add(v10, t_mul(fc, t_sub(v11, v10)));
+        const double val = t_add(top, t_mul(fr, t_sub(bot, top)));
+        T out = t_sub(rv, (T)val);
+        if (ok && t_finite(out)) {
+            const K ka = key_of(av);
+            kmin = ka < kmin ? ka : kmin;
+            kmax = ka > kmax ? ka : kmax;
+        } else {
+            out = (T)NAN;
         }
         dh[p] = out;
     }
@@ -167,21 +179,23 @@ __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, con
     T* e = reinterpret_cast<T*>(smem);
     for (int k = threadIdx.x; k <= nb; k += blockDim.x) e[k] = edges[k];
     __syncthreads();
+    const double inv_width = (double)nb / ((double)e[nb] - (double)e[0]);
     double s1 = 0.0, s2 = 0.0;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const T d = dh[p];
+        const T st = slope_tan[p];
+        const T x = aspect[p];
         T yv = (T)NAN;
         uint16_t b = 0xFFFF;
         if (d == d) {  // dh is NaN wherever the pixel is unusable
-            yv = t_div(t_sub(d, vshift), slope_tan[p]);
-            const T x = aspect[p];
-            // np.digitize(x, edges): number of edges <= x; a sample equal to the last edge goes to the last bin
-            int lo = 0, hi = nb + 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (e[mid] <= x) lo = mid + 1; else hi = mid;
-            }
-            int idx = lo - 1;
+            yv = t_div(t_sub(d, vshift), st);
+            // np.digitize(x, edges) - 1 = (number of edges <= x) - 1: arithmetic guess on the uniform grid, then an exact
+            // walk against the dtype-rounded edges (a step or two); a sample equal to the last edge goes to the last bin
+            int idx = (int)(((double)x - (double)e[0]) * inv_width);
+            idx = idx < 0 ? 0 : (idx > nb ? nb : idx);
+            while (idx > 0 && !(e[idx] <= x)) --idx;
+            while (idx < nb && e[idx + 1] <= x) ++idx;
+            if (!(e[0] <= x)) idx = -1;
             if (idx == nb) idx = nb - 1;
             b = (idx >= 0 && idx < nb) ? (uint16_t)idx : 0xFFFF;
             s1 += (double)yv;
@@ -195,16 +209,24 @@ __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, con
 }
 
 // ---- generic histogram / successor passes over (values, bin ids) ----------------------------------------------
-// bins == nullptr: single bin (global median).  LDS: nb * 256 uint32 counters.
+// bins == nullptr: single bin (global median).  LDS: `copies` privatised tables of nb * 256 uint32 counters
+// (copy = lane % copies): with few bins every lane of a wave would otherwise hit the same counter of the
+// low-entropy leading digit and serialise 64-way.  1024-thread workgroups so that even the 72 KB table of the
+// 72 aspect bins runs at full occupancy (2 workgroups = 32 waves per CU).
+constexpr int HIST_THREADS = 1024;
+
 template <typename T>
-__global__ __launch_bounds__(512) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
-                                                        int64_t n, int nb, int bin0, const SelState<typename KeyT<T>::type>* st,
-                                                        int shift, int first, uint64_t* hist) {
+__global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
+                                                                 int64_t n, int nb, int bin0, int copies,
+                                                                 const SelState<typename KeyT<T>::type>* st, int shift, int first,
+                                                                 uint64_t* hist) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* h = reinterpret_cast<uint32_t*>(smem);
-    for (int k = threadIdx.x; k < nb * SEL_RADIX; k += blockDim.x) h[k] = 0;
+    const int table = nb * SEL_RADIX;
+    for (int k = threadIdx.x; k < table * copies; k += blockDim.x) h[k] = 0;
     __syncthreads();
+    uint32_t* hc = h + (threadIdx.x % copies) * table;
     const K himask = first ? (K)0 : (K)(~(K)0 << (shift + 8));
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const T v = vals[p];
@@ -213,21 +235,25 @@ __global__ __launch_bounds__(512) void hist_pass_kernel(const T* __restrict__ va
         if (b < 0 || b >= nb) continue;
         const K key = key_of(v);
         if (!first && (key & himask) != st[bin0 + b].prefix) continue;
-        atomicAdd(&h[b * SEL_RADIX + (int)((key >> shift) & 0xFF)], 1u);
+        atomicAdd(&hc[b * SEL_RADIX + (int)((key >> shift) & 0xFF)], 1u);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < nb * SEL_RADIX; k += blockDim.x)
-        if (h[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[(size_t)bin0 * SEL_RADIX + k]), (unsigned long long)h[k]);
+    for (int k = threadIdx.x; k < table; k += blockDim.x) {
+        unsigned long long c = 0;
+        for (int q = 0; q < copies; ++q) c += h[q * table + k];
+        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[(size_t)bin0 * SEL_RADIX + k]), c);
+    }
 }
 
 template <typename T>
-__global__ __launch_bounds__(512) void succ_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
-                                                        int64_t n, int nb, const SelState<typename KeyT<T>::type>* st,
-                                                        uint64_t* succ /* [nb], all-ones = none */) {
+__global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
+                                                                 int64_t n, int nb, const SelState<typename KeyT<T>::type>* st,
+                                                                 uint64_t* succ /* [nb], all-ones = none */) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K* m = reinterpret_cast<K*>(smem);
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) m[k] = ~(K)0;
+    K* pref = m + nb;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { m[k] = ~(K)0; pref[k] = st[k].prefix; }
     __syncthreads();
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const T v = vals[p];
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(512) void succ_pass_kernel(const T* __restrict__ va
         const int b = bins ? (int)bins[p] : 0;
         if (b < 0 || b >= nb) continue;
         const K key = key_of(v);
-        if (key > st[b].prefix && key < m[b]) k_atomic_min(&m[b], key);
+        if (key > pref[b] && key < m[b]) k_atomic_min(&m[b], key);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < nb; k += blockDim.x)
@@ -279,6 +305,14 @@ int grid_for(const xdemhip_ctx* ctx, int64_t n, int block, int per_cu) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// column tiles of 256 x enough row-strided workgroups to fill the chip (~16 workgroups per CU)
+dim3 grid2d(const xdemhip_ctx* ctx, int64_t W, int64_t rows) {
+    const int64_t gx = (W + 255) / 256;
+    int64_t gy = ((int64_t)ctx->num_cu * 16 + gx - 1) / gx;
+    gy = gy < 1 ? 1 : (gy > rows ? (rows > 0 ? rows : 1) : gy);
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+
 // scratch layout (bytes): [0, 16384) bin edges | stats | sums | selection states | successor keys | histograms
 constexpr size_t OFF_STATS = 16384, OFF_SUMS = OFF_STATS + 64, OFF_STATE = OFF_STATS + 128;
 int nb1(int nb) { return nb > 1 ? nb : 1; }
@@ -310,22 +344,25 @@ int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n,
         if (n > 0)
             for (int b0 = 0; b0 < nb; b0 += MAX_BINS_PER_SWEEP) {
                 const int nbs = (nb - b0) < MAX_BINS_PER_SWEEP ? (nb - b0) : MAX_BINS_PER_SWEEP;
-                const size_t lds = (size_t)nbs * SEL_RADIX * sizeof(uint32_t);
+                // privatise the table as often as fits in ~64 KB (32 copies for the single-bin global median)
+                int copies = (64 * 1024) / (nbs * SEL_RADIX * (int)sizeof(uint32_t));
+                copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
+                const size_t lds = (size_t)nbs * SEL_RADIX * sizeof(uint32_t) * copies;
                 int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
                 if (rc) return rc;
-                hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, lds > 64 * 1024 ? 1 : 2)), dim3(512), lds,
-                                   ctx->stream, vals, bins, n, nbs, b0, st, shift, (int)(p == 0), d_hist);
+                hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * 4, 2)), dim3(HIST_THREADS), lds,
+                                   ctx->stream, vals, bins, n, nbs, b0, copies, st, shift, (int)(p == 0), d_hist);
                 XD_HIP_CHECK(ctx, hipGetLastError());
             }
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
-        hipLaunchKernelGGL((select_advance_kernel<K>), dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
+        hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
                            (int)(p == 0), (int)(p == passes - 1));
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     if (n > 0) {
-        hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid_for(ctx, n, 512 * 8, 2)), dim3(512), sizeof(K) * nb, ctx->stream, vals,
-                           bins, n, nb, st, d_succ);
+        hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * 4, 2)), dim3(HIST_THREADS), 2 * sizeof(K) * nb,
+                           ctx->stream, vals, bins, n, nb, st, d_succ);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     int rc = xd_allreduce_device(ctx, d_succ, nb, XDEMHIP_RED_MIN_U64);
@@ -369,7 +406,7 @@ template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(P->scratch) + OFF_STATS);
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (n > 0) {
-        hipLaunchKernelGGL((nk_aux_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((nk_aux_kernel<T>), grid2d(ctx, P->W, n / P->W), dim3(256), 0, ctx->stream,
                            static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->inlier, P->H, P->W,
                            static_cast<T*>(P->slope_tan), static_cast<T*>(P->aspect), P->valid, d_cnt, P->p0, P->p1);
         XD_HIP_CHECK(ctx, hipGetLastError());
@@ -403,7 +440,7 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
     XD_HIP_CHECK(ctx, hipMemcpyAsync(d_stats, &hs0, sizeof hs0, hipMemcpyHostToDevice, ctx->stream));
     const double dr = -shift_y / res_y, dc = shift_x / res_x;
     if (n > 0) {
-        hipLaunchKernelGGL((nk_dh_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((nk_dh_kernel<T>), grid2d(ctx, P->W, n / P->W), dim3(256), 0, ctx->stream,
                            static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect),
                            P->H, P->W, dr, dc, static_cast<T*>(P->dh), d_stats, P->p0, P->p1);
         XD_HIP_CHECK(ctx, hipGetLastError());

@@ -52,34 +52,52 @@ template <typename K> struct SelState {
 
 // Advance every bin by one digit: hist[bin][256] holds the counts of the current digit among the elements that
 // match the bin's prefix.  First pass (digit == top) also fixes count and the target rank (lower median).
+// One wave64 per bin: lane l owns buckets 4l .. 4l+3; wave prefix sums locate the bucket that holds the rank.
 template <typename K>
-__global__ void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last) {
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
-        uint64_t* h = hist + (size_t)b * SEL_RADIX;
-        SelState<K> s = st[b];
-        if (first) {
-            uint64_t tot = 0;
-            for (int d = 0; d < SEL_RADIX; ++d) tot += h[d];
-            s.count = tot;
-            s.rank = tot ? (tot - 1) / 2 : 0;  // lower median
-            s.prefix = 0;
-            s.n_le = 0;
-        }
-        if (s.count) {
-            uint64_t cum = 0;
-            int d = 0;
-            for (; d < SEL_RADIX - 1; ++d) {
-                if (cum + h[d] > s.rank) break;
-                cum += h[d];
-            }
-            s.prefix |= (K)d << shift;
-            s.n_le += cum;  // elements strictly below the chosen digit group
-            s.rank -= cum;
-            if (last) s.n_le += h[d];  // all digits fixed: group == the selected key's duplicates
-        }
-        st[b] = s;
-        for (int d = 0; d < SEL_RADIX; ++d) h[d] = 0;  // ready for the next pass
+__global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= nb) return;
+    uint64_t* h = hist + (size_t)b * SEL_RADIX;
+    unsigned long long c[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c[q] = h[4 * lane + q]; mine += c[q]; h[4 * lane + q] = 0; }  // (zeroed for the next pass)
+    // inclusive scan of the per-lane totals
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
     }
+    const unsigned long long total = __shfl(incl, 63);
+    SelState<K> s = st[b];
+    if (first) {
+        s.count = total;
+        s.rank = total ? (total - 1) / 2 : 0;  // lower median
+        s.prefix = 0;
+        s.n_le = 0;
+    }
+    if (s.count) {
+        // the lane whose bucket range contains the rank (the last non-empty lane if the rank lies beyond: cannot happen
+        // for a consistent histogram, kept for robustness)
+        const unsigned long long excl = incl - mine;
+        const bool here = (s.rank >= excl) && (s.rank < incl);
+        const unsigned long long vote = __ballot(here);
+        const int src = vote ? (int)__ffsll((long long)vote) - 1 : 63;
+        unsigned long long cum = excl;
+        int q = 0;
+        if (cum + c[0] <= s.rank) { cum += c[0]; q = 1;
+            if (cum + c[1] <= s.rank) { cum += c[1]; q = 2;
+                if (cum + c[2] <= s.rank) { cum += c[2]; q = 3; } } }
+        const unsigned long long hq = q == 0 ? c[0] : (q == 1 ? c[1] : (q == 2 ? c[2] : c[3]));
+        const int dsel = __shfl(4 * lane + q, src);
+        const unsigned long long cumsel = __shfl(cum, src);
+        const unsigned long long hsel = __shfl(hq, src);
+        s.prefix |= (K)dsel << shift;
+        s.n_le += cumsel;  // elements strictly below the chosen digit group
+        s.rank -= cumsel;
+        if (last) s.n_le += hsel;  // all digits fixed: group == the selected key's duplicates
+    }
+    if (lane == 0) st[b] = s;
 }
 
 }  // namespace xd
