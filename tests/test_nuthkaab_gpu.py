@@ -266,3 +266,37 @@ def test_apply_translation_matches_oracle_and_realigns(coreg):
     assert abs(np.nanmedian((ref - aligned)[ok])) < 0.05
     with pytest.raises(ValueError, match="all nans"):
         coreg.apply_translation(np.full((4, 4), np.nan, np.float32), 1, 1, 1, 1.0)
+
+
+def test_C3_full_size_properties(coreg):
+    """BASELINE config[2] size: 20000^2 float32 pair, 20 % NaN, exactly 10 iterations on every valid pixel.
+    The oracle cannot sort 3e8 points in test time, so size-independent properties are checked instead."""
+    from xdem_amd.synth import fbm_numpy
+
+    n, t, res = 20000, 2500, 10.0
+    tile = fbm_numpy((t, t), seed=42, std=150.0)
+    yy, xx = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), indexing="ij")
+    ref = np.tile(tile, (n // t, n // t)) + 40.0 * np.sin(xx * np.float32(2 * np.pi / n)) + 40.0 * np.cos(yy * np.float32(2 * np.pi / n))
+    del xx, yy
+    ref = ref.astype(np.float32)
+    # tba(x) = ref(x + (2, -1) px) + 2 m : an integer-pixel shift keeps the construction exact
+    tba = np.roll(ref, (1, -2), axis=(0, 1)) + np.float32(2.0)
+    hole = np.tile(fbm_numpy((t, t), seed=44, hurst=1.0, mean=0.0, std=1.0), (n // t, n // t))
+    tba[hole < np.percentile(hole[:t, :t], 20)] = np.nan
+    del hole
+    plan = coreg.NKPlan(ref, tba, None)
+    # (1) integer work: the valid count equals NumPy's (gradient-based aux variables are finite wherever ref is)
+    gy0 = np.isfinite(tba)
+    assert plan.n_valid <= int(gy0.sum()) and plan.n_valid > 0.75 * n * n
+    # (2) one step: counts partition the valid set, medians finite, edges monotone
+    d0 = plan.step(0.0, 0.0, (res, res), 72)
+    assert d0["counts"].sum() == d0["n_valid"] <= plan.n_valid
+    assert np.all(np.diff(d0["edges"]) > 0) and np.isfinite(d0["medians"]).all()
+    # (3) determinism: the same step twice is bit-identical (integer histograms, no floating reductions in the medians)
+    d1 = plan.step(0.0, 0.0, (res, res), 72)
+    assert d1["vshift"] == d0["vshift"] and np.array_equal(d1["medians"], d0["medians"]) and np.array_equal(d1["counts"], d0["counts"])
+    plan.close()
+    # (4) the full 10-iteration fit recovers the construction: offsets (-2 px, +1 px... in georeferenced units) and -2 m
+    offsets, n_final = coreg.nuth_kaab(ref, tba, None, (res, res), tolerance=0.0, max_iterations=10)
+    assert n_final > 0.75 * n * n
+    assert abs(offsets[0] / res + 2.0) < 0.02 and abs(offsets[1] / res + 1.0) < 0.02 and abs(offsets[2] + 2.0) < 0.02

@@ -139,3 +139,35 @@ def test_large_pair_count_properties(ss):
     e2, c2 = ss.empirical_variogram_pairs([(x[h:], y[h:], v[h:], x[:h], y[:h], v[:h])], edges, "dowd")
     assert np.array_equal(c1, c2) and np.array_equal(e1, e2, equal_nan=True)
     assert c1.sum() == h * h
+
+
+def test_C5_full_size_properties(ss):
+    """BASELINE config[4] scale (reading B of SURVEY 8d): 1e7 sampled points in 100 centre x ring blocks
+    (100 x 9091 x 90910 = 8.3e10 pairs), 50 lag classes, Matheron and exact Dowd."""
+    rng = np.random.default_rng(45)
+    runs, samples, rings = 100, 9091, 10
+    L = 20000.0
+    blocks = []
+    for _ in range(runs):
+        ax, ay = rng.uniform(0, L, samples), rng.uniform(0, L, samples)
+        bx, by = rng.uniform(0, L, samples * rings), rng.uniform(0, L, samples * rings)
+        av = (np.sin(ax / 900.0) + 0.2 * rng.normal(size=samples)).astype(np.float32)
+        bv = (np.sin(bx / 900.0) + 0.2 * rng.normal(size=samples * rings)).astype(np.float32)
+        blocks.append((ax, ay, av, bx, by, bv))
+    maxlag = float(np.hypot(L, L))
+    edges = np.geomspace(np.sqrt(2), maxlag, 50)
+    total = runs * samples * samples * rings
+    exp_m, cnt_m = ss.empirical_variogram_pairs(blocks, edges, "matheron")
+    exp_d, cnt_d = ss.empirical_variogram_pairs(blocks, edges, "dowd")
+    assert np.array_equal(cnt_m, cnt_d)                      # two independent kernels, same class membership
+    assert cnt_m.sum() == total                               # every pair is below the diagonal maxlag, none is lost
+    assert np.all(np.diff(cnt_m[10:40].astype(np.float64)) > 0)  # annulus areas grow geometrically below the domain scale
+    ok = cnt_m > 1000
+    assert np.all(exp_m[ok] > 0) and np.all(exp_d[ok] > 0)
+    # a 1 % subset of the blocks against the oracle (exact counts; Dowd exact)
+    import variogram_oracle as vo
+
+    sub = [tuple(a[:300] if i in (0, 1, 2) else a[:1200] for i, a in enumerate(b)) for b in blocks[:2]]
+    e_g, c_g = ss.empirical_variogram_pairs(sub, edges, "dowd")
+    e_o, c_o = vo.empirical_variogram_blocks(sub, edges, "dowd")
+    assert np.array_equal(c_g, c_o) and np.array_equal(e_g, e_o, equal_nan=True)
