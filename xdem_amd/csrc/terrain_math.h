@@ -81,14 +81,24 @@ XD_HD double rsqrt_pos(double x) {
     return fma(0.5 * y, e, y);
 }
 
-// sqrt(x) with IEEE special cases (0 -> 0, inf -> inf, negative / NaN -> NaN).
+// sqrt(x) for x >= 0 or NaN, IEEE results at the ends without selects: the seed is taken at x + 1e-300 (exact no-op for
+// x > 1e-284) so x = 0 gives 0 * 1e150 = 0, a negative x keeps a NaN seed, and x = +inf (seed 0 -> NaN) is restored by the
+// final maxNum with x * 1e-160 (<= sqrt(x) for every finite x, +inf for +inf, NaN for NaN).
 XD_HD double sqrt_nr(double x) {
-    double y = rsq_seed(x);
+    const double y = rsq_seed(x + 1e-300);
     double g = x * y;
-    double h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
-    return (x == 0.0 || x == INFINITY) ? x : g;
+    return fmax(g, x * 1e-160);
+}
+// same for a radicand that may be slightly negative (-> NaN like the reference's `** 0.5`) and is never +inf
+XD_HD double sqrt_nr_signed(double x) {
+    const double y = rsq_seed(x + 1e-300);
+    double g = x * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    return fma(g, r, g);
 }
 
 // p * s + c with the loop-invariant constant c kept in a scalar register pair: one v_fma_f64.  (Left to itself
@@ -175,7 +185,7 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         // aspect = atan2(zx, zy) mod 2pi, first-quadrant angle from the smaller normalised component
         const double ax = fabs(zx), ay = fabs(zy);
         const bool xbig = ax > ay;
-        double a = asin_small((xbig ? ay : ax) * rg);
+        double a = asin_small(fmin(ax, ay) * rg);
         a = xbig ? (1.5707963267948966 - a) : a;
         a = (zy < 0.0) ? (3.141592653589793 - a) : a;
         a = (zx < 0.0) ? -a : a;
@@ -201,41 +211,41 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         const double cross = 2.0 * zxy * zxzy;
         const double n_prof = fma(zyy, zy2, fma(zxx, zx2, cross));       // zxx zx^2 + 2 zxy zx zy + zyy zy^2
         const double n_tan = fma(zyy, zx2, fma(zxx, zy2, -cross));        // zxx zy^2 - 2 zxy zx zy + zyy zx^2
-        const double rg2 = rg * rg;
+        const double rg2 = rg * rg * 100.0;                               // (the x100 of every curvature folded in)
         const double rg_t = (g2 < 10e-15) ? 0.0 : rg;                     // planform / flowline zero below 1e-14
         if (m & A_PROFILE) {
             double v = -n_prof * rg2;
             if (!dir) v *= rw * rw * rw;
-            put(out.p[P_PROFILE], o, (TOUT)((TOUT)(v * 100.0)));
+            put(out.p[P_PROFILE], o, (TOUT)(v));
         }
         const double t_dir = -n_tan * rg2;
-        if (m & A_TANGENTIAL) put(out.p[P_TANGENTIAL], o, (TOUT)((TOUT)((dir ? t_dir : t_dir * rw) * 100.0)));
-        if (m & A_PLANFORM) put(out.p[P_PLANFORM], o, (TOUT)((TOUT)(t_dir * rg_t * 100.0)));
+        if (m & A_TANGENTIAL) put(out.p[P_TANGENTIAL], o, (TOUT)((dir ? t_dir : t_dir * rw)));
+        if (m & A_PLANFORM) put(out.p[P_PLANFORM], o, (TOUT)((TOUT)(t_dir * rg_t)));
         if (m & A_FLOWLINE) {
             const double n_flow = fma(zxzy, zxx - zyy, -zxy * (zx2 - zy2));
             const double v = dir ? n_flow * rg2 * rg : n_flow * rg2 * rg_t * rw;
-            put(out.p[P_FLOWLINE], o, (TOUT)((TOUT)(v * 100.0)));
+            put(out.p[P_FLOWLINE], o, (TOUT)(v));
         }
         if (m & (A_MAXC | A_MINC)) {
-            double vmax, vmin;
+            double vmax, vmin;  // already x100
             if (dir) {
-                const double half_tr = 0.5 * (zxx + zyy);
-                const double hd = 0.5 * (zxx - zyy);
-                const double rad = sqrt_nr(fma(hd, hd, zxy * zxy));
+                const double half_tr = 50.0 * (zxx + zyy);
+                const double hd = 50.0 * (zxx - zyy), sxy = 100.0 * zxy;
+                const double rad = sqrt_nr_signed(fma(hd, hd, sxy * sxy));
                 vmax = -(half_tr - rad);
                 vmin = -(half_tr + rad);
             } else {
                 // mean curvature H and unsphericity sqrt(H^2 - K); negative radicand -> NaN like the reference
                 const double q = (zxx + zyy) + n_tan;
-                const double rw2 = rw * rw;
+                const double rw2 = rw * rw * 100.0;
                 const double mean = -0.5 * q * rw2 * rw;
                 const double gauss = fma(zxx, zyy, -zxy * zxy) * rw2 * rw2;
-                const double uns = sqrt_nr(fma(mean, mean, -gauss));
+                const double uns = sqrt_nr_signed(fma(mean, mean, -gauss));
                 vmax = mean + uns;
                 vmin = mean - uns;
             }
-            if (m & A_MAXC) put(out.p[P_MAXC], o, (TOUT)((TOUT)((flat ? 0.0 : vmax) * 100.0)));
-            if (m & A_MINC) put(out.p[P_MINC], o, (TOUT)((TOUT)((flat ? 0.0 : vmin) * 100.0)));
+            if (m & A_MAXC) put(out.p[P_MAXC], o, (TOUT)(flat ? 0.0 : vmax));
+            if (m & A_MINC) put(out.p[P_MINC], o, (TOUT)(flat ? 0.0 : vmin));
         }
     }
 }
