@@ -51,7 +51,11 @@ enum {
     XDEMHIP_ATTR_TPI = 1u << 10,
     XDEMHIP_ATTR_TRI = 1u << 11,
     XDEMHIP_ATTR_ROUGHNESS = 1u << 12, /* max - min of the window (window.py:261-308) */
-    XDEMHIP_ATTR_COUNT = 13
+    XDEMHIP_ATTR_RUGOSITY = 1u << 13,  /* 8f-2: Jenness surface-area ratio, always 3x3, needs resolution (window.py:466-563) */
+    XDEMHIP_ATTR_FRACTAL_ROUGHNESS = 1u << 14, /* 8f-2: box-counting dimension over window_size (window.py:316-401);
+                                                   the reference runs it in a second engine call with its own
+                                                   window_size_fractal (terrain.py:619-630): do the same here */
+    XDEMHIP_ATTR_COUNT = 15
 };
 
 /* ---- context ------------------------------------------------------------------------------------- */
@@ -91,7 +95,8 @@ int xdemhip_set_allreduce(xdemhip_ctx* ctx, xdemhip_allreduce_fn fn, void* user)
  *  attr_mask    OR of XDEMHIP_ATTR_*; out_planes[k] receives the k-th SET bit in ascending bit order,
  *               each an (H, W) plane with row stride W in out_dtype.
  *  degrees      non-zero: slope / aspect in degrees (terrain.py:586-591), else radians.
- *  window_size  odd window of TPI / TRI (reference default 3).
+ *  window_size  odd window of TPI / TRI / roughness (reference default 3) and of fractal roughness (reference default
+ *               13 through its own window_size_fractal: request that attribute in a call of its own); rugosity is 3x3.
  * NaN / +-Inf in the DEM are nodata: an output pixel is NaN iff its full window (3x3 Horn/ZT, 5x5
  * Florinsky; window_size for TPI/TRI) holds a non-finite value or leaves the raster (surfit.py:1185-1192).
  */
@@ -100,6 +105,12 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
                     uint32_t attr_mask, int tri_method, int window_size, double hillshade_altitude_deg,
                     double hillshade_azimuth_deg, double hillshade_z_factor, int degrees, int out_dtype,
                     void* const* out_planes, int memspace);
+
+/* Host-only helper (no GPU needed): the regression abscissae of fractal roughness for a window size, with NumPy's
+ * float16 arithmetic reproduced (xdem/terrain/window.py:362-393: the divisors q of window_size//2 are a uint8 array, so
+ * np.log / np.mean / SS_xx are float16).  Fills q[], log_q[] (float16 values as double) and returns the number of
+ * divisors (<= max_q), or a negative status. */
+int xdemhip_fractal_constants(int window_size, int max_q, int* q, double* log_q, double* mean_log_q, double* ss_xx);
 
 /* ---- path 2: Nuth & Kaab (2011) inner loop ------------------------------------------------------------
  * Replaces the array work of  nuth_kaab(ref_elev, tba_elev, inlier_mask, transform, ...)   xdem/coreg/affine.py:539-609

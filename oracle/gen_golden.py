@@ -10,6 +10,7 @@ Fixture families:
   terrain_T3     reference's data-free known-answer DEMs (test_surfit.py:228-411, terrain.py doctests)
   terrain_T4     int32 DEM -> float32 outputs
   terrain_T5     window sizes 3/5/7 for TPI/TRI
+  terrain_T9     rugosity + fractal roughness (incl. the known answers of test_window.py:21-89)
   nk_T5_*        Nuth-Kaab bin-fit cases (aspect binning, nanmedian per bin, curve_fit) + aux gradient (T8)
   nk_T6          _iterate_method stop-rule trace
   vario_T7       _choose_cdist_equidistant_sampling_parameters table + default bin edges
@@ -166,6 +167,46 @@ def terrain_T4_T5() -> None:
     np.savez_compressed(os.path.join(OUT, "terrain_T5_windows.npz"), **rec)
 
 
+def terrain_T9() -> None:
+    """Rugosity (3x3, needs resolution) and fractal roughness (box counting) -- f2 of SURVEY 8f.  Includes the
+    reference's data-free known-answer DEMs (tests/test_terrain/test_window.py:21-89) with its outputs on them."""
+    rng = np.random.default_rng(11)
+    rec = {}
+    base = 1000.0 + np.cumsum(np.cumsum(rng.normal(scale=0.5, size=(40, 44)), axis=0), axis=1)
+    for dt in (np.float32, np.float64):
+        dem = base.astype(dt)
+        dem[5, 7] = np.nan
+        dem[20, 30] = np.inf
+        dem[30, 10] = -np.inf
+        n = np.dtype(dt).name
+        rec[f"dem|{n}"] = dem
+        for res in (1.0, 10.0, 0.3):
+            rec[f"{n}|rugosity|{res}"] = run_ref(dem, ["rugosity"], resolution=res)[0]
+        for wf in (5, 7, 9, 13):
+            rec[f"{n}|fractal_roughness|{wf}"] = run_ref(dem, ["fractal_roughness"], window_size_fractal=wf)[0]
+    # rough, voxel-scale relief (V not saturated at 0 / w)
+    dem = rng.uniform(0, 20, size=(30, 33)).astype(np.float32)
+    rec["dem|rough"] = dem
+    rec["rough|fractal_roughness|13"] = run_ref(dem, ["fractal_roughness"])[0]
+    rec["rough|rugosity|2.0"] = run_ref(dem, ["rugosity"], resolution=2.0)[0]
+    # known answers
+    jen = np.array([[190, 170, 155], [183, 165, 145], [175, 160, 122]], dtype="float32")
+    rec["dem|jenness"] = jen
+    rec["jenness|rugosity|100.0"] = run_ref(jen, ["rugosity"], resolution=100.0)[0]
+    for dh in np.linspace(0.01, 100, 3):
+        for res in np.linspace(0.01, 100, 3):
+            d = np.array([[1, 1, 1], [1, 1 + dh, 1], [1, 1, 1]], dtype="float64")
+            rec[f"dem|pyramid|{dh}"] = d
+            rec[f"pyramid|{dh}|rugosity|{res}"] = run_ref(d, ["rugosity"], resolution=float(res))[0]
+    line = np.zeros((13, 13)); line[1, 1] = 6.5
+    plane = np.zeros((13, 13)); plane[:, 1] = 13
+    cube = np.zeros((13, 13)); cube[:, :6] = 13
+    for name, d in (("line", line), ("plane", plane), ("cube", cube)):
+        rec[f"dem|{name}"] = d
+        rec[f"{name}|fractal_roughness|13"] = run_ref(d, ["fractal_roughness"])[0]
+    np.savez_compressed(os.path.join(OUT, "terrain_T9_rugosity_fractal.npz"), **rec)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["terrain", "nk", "vario"]
@@ -175,6 +216,7 @@ if __name__ == "__main__":
         terrain_T2()
         terrain_T3()
         terrain_T4_T5()
+        terrain_T9()
         print("terrain fixtures written")
     if "nk" in which:
         import gen_golden_nk

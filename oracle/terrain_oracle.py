@@ -40,7 +40,8 @@ SURFACE_ATTRIBUTES = (
     "max_curvature",
     "min_curvature",
 )
-WINDOW_ATTRIBUTES = ("topographic_position_index", "terrain_ruggedness_index", "roughness")
+WINDOW_ATTRIBUTES = ("topographic_position_index", "terrain_ruggedness_index", "roughness", "rugosity")
+FRACTAL_ATTRIBUTES = ("fractal_roughness",)
 FITS = {"horn": 0, "zevenbergthorne": 1, "florinsky": 2}
 
 # ---------------------------------------------------------------------------------------------
@@ -264,8 +265,71 @@ def _np_sum_axis0(stack: np.ndarray) -> np.ndarray:
     return acc
 
 
+def _rugosity(stack: np.ndarray, resolution: float, T) -> np.ndarray:
+    """Jenness rugosity of 3x3 windows (window.py:466-563, the per-window callback the SciPy generic_filter and
+    Numba engines run): 16 half segment lengths and 8 Heron triangle areas, every intermediate array held in
+    ``out_dtype`` (T) and Python ``sum`` (left to right) for the reductions."""
+    T = np.dtype(T).type
+    Z = stack
+    L = float(resolution)
+    dzs = [(Z[4] - Z[i]).astype(T) for i in range(9) if i != 4]
+    dls = [T(np.sqrt(j * j + k * k) * L) for j in (-1, 0, 1) for k in (-1, 0, 1) if not (j == 0 and k == 0)]
+    for a, b in ((0, 1), (1, 2), (6, 7), (7, 8), (0, 3), (3, 6), (2, 5), (5, 8)):
+        dzs.append((Z[a] - Z[b]).astype(T))
+        dls.append(T(L))
+    hsl = [np.sqrt(dz * dz + dl * dl) / T(2) for dz, dl in zip(dzs, dls)]
+    tri = ((3, 0, 12), (0, 1, 8), (1, 2, 9), (2, 4, 14), (4, 7, 15), (7, 6, 11), (6, 5, 10), (5, 3, 13))
+    total = None
+    for ia, ib, ic in tri:
+        a, b, c = hsl[ia], hsl[ib], hsl[ic]
+        hs = ((a + b) + c) / T(2)
+        area = np.sqrt(hs * (hs - a) * (hs - b) * (hs - c))
+        total = area if total is None else total + area
+    return total / T(L**2)
+
+
+def fractal_constants(window_size: int):
+    """Regression abscissae of the box-counting fit (window.py:362-393): the divisors q of hw are a uint8 array, so
+    ``np.log`` yields float16 and mean / SS_xx are float16 arithmetic.  Returns (qs, x[f16], m_x[f16], SS_xx[f16])."""
+    hw = window_size // 2
+    qs = np.array([q for q in range(1, hw + 1) if hw % q == 0], dtype=np.uint8)
+    x = np.log(qs)
+    n = len(x)
+    m_x = np.mean(x)
+    ss_xx = np.sum(x * x) - n * m_x * m_x
+    return qs, x, m_x, ss_xx
+
+
+def _fractal_roughness(stack: np.ndarray, w: int, T) -> np.ndarray:
+    """Taud & Parrot box-counting dimension (window.py:316-401, generic/Numba callback): voxel heights
+    V = clip(z - z_c, 0, w) in ``out_dtype``; for every divisor q of w//2 the (w-1)//q squared q x q block maxima
+    are summed left to right in ``out_dtype`` and divided by q; slope of log Ns over log q."""
+    T = np.dtype(T).type
+    c = stack[(w * w) // 2]
+    V = [[np.clip(stack[w * j + k] - c, 0, w).astype(T) for k in range(w)] for j in range(w)]
+    qs, x, m_x, ss_xx = fractal_constants(w)
+    n = len(qs)
+    ys = []
+    for q in qs:
+        q = int(q)
+        nq = int((w - 1) / q)
+        acc = None
+        for j in range(nq):
+            for k in range(nq):
+                blk = np.stack([V[a][b] for a in range(j * q, (j + 1) * q) for b in range(k * q, (k + 1) * q)], axis=0)
+                m = np.max(blk, axis=0)  # NaN-propagating
+                acc = m if acc is None else acc + m
+        ys.append(np.log(acc / T(q)))
+    sy = _np_sum_axis0(np.stack(ys, axis=0))  # np.mean / np.sum of an n-vector: left to right below 8 elements
+    sxy = _np_sum_axis0(np.stack([ys[i] * x[i] for i in range(n)], axis=0))
+    m_y = sy / T(n)
+    ss_xy = sxy - T(n) * m_y * m_x
+    return -(ss_xy / ss_xx)
+
+
 def windowed_indexes(
-    dem: np.ndarray, window_size: int, windowed_indexes: list[str], out_dtype=np.float32, tri_method: str = "Riley"
+    dem: np.ndarray, window_size: int, windowed_indexes: list[str], out_dtype=np.float32, tri_method: str = "Riley",
+    resolution: float = 1.0,
 ) -> np.ndarray:
     """Oracle of ``_get_windowed_indexes(..., engine="scipy")`` for TPI / TRI (window.py:67-252, 873-923)."""
     w = int(window_size)
@@ -291,6 +355,16 @@ def windowed_indexes(
                 r = np.max(stack, axis=0) - np.min(stack, axis=0)
                 r[np.isnan(stack).any(axis=0)] = np.nan
                 out[i] = r
+            elif name == "rugosity":  # always a 3x3 window (window.py:700-712)
+                if w == 3:
+                    s9 = stack
+                else:
+                    p3 = np.full((H + 2, W + 2), np.nan, dtype=np.float64)
+                    p3[1 : 1 + H, 1 : 1 + W] = dem
+                    s9 = np.stack([p3[a : a + H, b : b + W] for a in range(3) for b in range(3)], axis=0)
+                out[i] = _rugosity(s9, resolution, out_dtype)
+            elif name == "fractal_roughness":
+                out[i] = _fractal_roughness(stack, w, out_dtype)
             else:
                 raise ValueError(f"oracle does not cover windowed index '{name}'")
     return out
@@ -309,6 +383,7 @@ def terrain_attributes(
     tri_method: str = "Riley",
     window_size: int = 3,
     out_dtype=None,
+    window_size_fractal: int = 13,
 ) -> list[np.ndarray]:
     """Oracle of ``_get_terrain_attribute`` for ndarray input (terrain.py:528-666): engines + unit/clip post-steps."""
     dem = np.asarray(dem)
@@ -330,7 +405,12 @@ def terrain_attributes(
                 v = np.clip(v, 0, 255)
             results[name] = v
     if win:
-        wi = windowed_indexes(dem, window_size, win, out_dtype, tri_method)
+        wi = windowed_indexes(dem, window_size, win, out_dtype, tri_method, resolution)
         for i, name in enumerate(win):
+            results[name] = wi[i]
+    frac = [a for a in attribute if a in FRACTAL_ATTRIBUTES]
+    if frac:  # second windowed call with its own size (terrain.py:619-630)
+        wi = windowed_indexes(dem, window_size_fractal, frac, out_dtype, tri_method, resolution)
+        for i, name in enumerate(frac):
             results[name] = wi[i]
     return [results[a] for a in attribute]

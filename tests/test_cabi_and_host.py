@@ -30,6 +30,26 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.xdemhip_version() >= 100
 
 
+def test_fractal_constants_reproduce_numpy_float16(lib):
+    """Host-only helper of the C-ABI against the NumPy arithmetic the reference runs (window.py:362-393): np.log of a
+    uint8 divisor array is float16, and so are its mean and SS_xx."""
+    import terrain_oracle as to
+
+    for w in list(range(3, 131, 2)) + [241, 361, 481, 505, 511]:
+        q = (ctypes.c_int * 24)()
+        x = (ctypes.c_double * 24)()
+        mx, ss = ctypes.c_double(), ctypes.c_double()
+        with np.errstate(all="ignore"):
+            qs, xo, mxo, sso = to.fractal_constants(w)
+        n = lib.xdemhip_fractal_constants(w, 24, q, x, ctypes.byref(mx), ctypes.byref(ss))
+        assert n == len(qs), w
+        assert list(q[:n]) == [int(v) for v in qs]
+        assert np.array_equal(np.array(x[:n]), xo.astype(np.float64)), w
+        assert np.array_equal(np.float64(mx.value), np.float64(mxo), equal_nan=True), w
+        assert np.array_equal(np.float64(ss.value), np.float64(sso), equal_nan=True), w
+    assert lib.xdemhip_fractal_constants(4, 24, q, x, ctypes.byref(mx), ctypes.byref(ss)) < 0
+
+
 def test_no_gpu_means_loud_failure(lib):
     import torch
 
@@ -46,6 +66,7 @@ def test_no_gpu_means_loud_failure(lib):
 def test_terrain_argument_validation_messages():
     """Same checks and messages as xdem/terrain/terrain.py:293-409 (asserted by the reference's tests
     tests/test_terrain/test_terrain.py:428-490, test_surfit.py:123-134, 169-176) -- all raised before any GPU work."""
+    from xdem_amd import _lib
     from xdem_amd import terrain as t
 
     dem = np.ones((6, 6), np.float32)
@@ -74,7 +95,19 @@ def test_terrain_argument_validation_messages():
     with pytest.raises(ValueError, match="only provides engine='hip'"):
         t.slope(dem, resolution=1.0, engine="scipy")
     with pytest.raises(NotImplementedError, match="not on the MI355X hot path"):
-        t.get_terrain_attribute(dem, "rugosity", resolution=1.0)
+        t.get_terrain_attribute(dem, "texture_shading", resolution=1.0)
+    with pytest.raises(ValueError, match=re.escape("'resolution' must be provided as an argument for attributes: ['rugosity']")):
+        t.rugosity(dem)
+    with pytest.warns(UserWarning, match="window sizes larger or equal to 5"):
+        try:  # (without a GPU the launch itself fails loudly, after the warning)
+            t.fractal_roughness(dem, window_size_fractal=3)
+        except _lib.XdemHipError:
+            pass
+    with pytest.warns(UserWarning, match="less than 13 can be inaccurate"):
+        try:
+            t.fractal_roughness(dem, window_size_fractal=9)
+        except _lib.XdemHipError:
+            pass
     with pytest.warns(DeprecationWarning, match="'slope_method' is deprecated"):
         with pytest.raises(ValueError):
             t.get_terrain_attribute(dem, "slope", slope_method="bad", resolution=1.0)

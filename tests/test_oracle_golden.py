@@ -85,6 +85,37 @@ def test_T5_window_sizes():
         assert _same(got, z[key]), key
 
 
+def test_T9_rugosity_fractal_roughness():
+    """f2 of SURVEY 8f.  Rugosity: bit-exact.  Fractal roughness: bit-exact on this NumPy build; np.log on float32 is a
+    SIMD routine that is not correctly rounded, so 4 ulp are allowed for other CPU dispatch targets."""
+    z = _load("terrain_T9_rugosity_fractal.npz")
+    n = 0
+    for key in z.files:
+        if key.startswith("dem|"):
+            continue
+        parts = key.split("|")
+        if parts[0] == "pyramid":
+            dem, (attr, par) = z[f"dem|pyramid|{parts[1]}"], parts[2:]
+        else:
+            dem, (attr, par) = z[f"dem|{parts[0]}"], parts[1:]
+        if attr == "rugosity":
+            got = to.terrain_attributes(dem, [attr], resolution=float(par))[0]
+            assert _same(got, z[key]), key
+        else:
+            got = to.terrain_attributes(dem, [attr], window_size_fractal=int(par))[0]
+            ref = z[key]
+            assert got.dtype == ref.dtype and np.array_equal(np.isnan(got), np.isnan(ref)), key
+            ok = np.isfinite(ref)
+            assert np.array_equal(np.isinf(got), np.isinf(ref))
+            assert np.all(np.abs(got[ok] - ref[ok]) <= 4 * np.spacing(np.abs(ref[ok]))), key
+        n += 1
+    assert n >= 25
+    # the reference's own known answers (tests/test_terrain/test_window.py:21-89)
+    assert z["jenness|rugosity|100.0"][1, 1] == pytest.approx(10280.48 / 10000.0, rel=1e-4)
+    for name, d in (("line", 1.0), ("plane", 2.0), ("cube", 3.0)):
+        assert np.round(z[f"{name}|fractal_roughness|13"][6, 6], 3) == d
+
+
 def test_oracle_convolution_equals_scipy():
     """The restated convolution must reproduce scipy.ndimage.convolve (the reference's engine call) bit for bit."""
     scipy_ndimage = pytest.importorskip("scipy.ndimage")

@@ -217,3 +217,90 @@ def test_C1_dem_slope_plumbing_horn():
     assert np.array_equal(both[0].data, slope.data, equal_nan=True) and len(both) == 2
     aligned = dem.coregister_3d(xdem_amd.DEM.from_array(arr + 1.0, dem.transform, dem.crs, nodata=-9998.0))
     assert isinstance(aligned, xdem_amd.DEM) and abs(np.nanmedian(aligned.data - dem.data) - 1.0) < 0.05
+
+
+# ---- rugosity and fractal roughness (csrc/window_extra.hip) -------------------------------------------
+def _ulp_f(a, b):
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.abs(b)).astype(np.float64)
+
+
+def test_T9_golden_rugosity_fractal():
+    """Fixtures recorded from the reference (oracle/gen_golden.py: terrain_T9).  Rugosity bit-exact (same float32 /
+    float64 operations in the same order); fractal roughness within 1e-6 relative (float32 log, see window_extra.hip)."""
+    from xdem_amd import terrain as t
+
+    z = np.load(os.path.join(GOLDEN, "terrain_T9_rugosity_fractal.npz"))
+    n = 0
+    for key in z.files:
+        if key.startswith("dem|"):
+            continue
+        parts = key.split("|")
+        if parts[0] == "pyramid":
+            dem, (attr, par) = z[f"dem|pyramid|{parts[1]}"], parts[2:]
+        else:
+            dem, (attr, par) = z[f"dem|{parts[0]}"], parts[1:]
+        ref = z[key]
+        if attr == "rugosity":
+            got = t.rugosity(dem, resolution=float(par))
+            assert got.dtype == ref.dtype and np.array_equal(got, ref, equal_nan=True), key
+        else:
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = t.fractal_roughness(dem, window_size_fractal=int(par))
+            assert got.dtype == ref.dtype and np.array_equal(np.isnan(got), np.isnan(ref)), key
+            assert np.array_equal(np.isinf(got), np.isinf(ref)), key
+            ok = np.isfinite(ref)
+            assert np.all(np.abs(got[ok] - ref[ok]) <= 1e-6 * np.abs(ref[ok])), key
+        n += 1
+    assert n >= 25
+    # known answers of tests/test_terrain/test_window.py:21-89 through the product path
+    jen = np.array([[190, 170, 155], [183, 165, 145], [175, 160, 122]], dtype="float32")
+    assert t.rugosity(jen, resolution=100.0)[1, 1] == pytest.approx(10280.48 / 10000.0, rel=1e-4)
+    for dem, d in ((z["dem|line"], 1.0), (z["dem|plane"], 2.0), (z["dem|cube"], 3.0)):
+        assert np.round(t.fractal_roughness(dem)[6, 6], 3) == d
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_rugosity_fractal_vs_oracle_larger(dtype):
+    """300 x 517 terrain-like DEM with NaN / Inf holes, all windowed indexes in one call (two engine launches)."""
+    from xdem_amd import terrain as t
+
+    rng = np.random.default_rng(21)
+    dem = (500.0 + np.cumsum(np.cumsum(rng.normal(scale=0.4, size=(300, 517)), axis=0), axis=1)).astype(dtype)
+    dem[40, 100:104] = np.nan
+    dem[200, 300] = np.inf
+    dem[299, 0] = -np.inf
+    attrs = ["fractal_roughness", "rugosity", "roughness", "slope"]
+    got = t.get_terrain_attribute(dem, attrs, resolution=5.0)
+    ref = to.terrain_attributes(dem, attrs, resolution=5.0)
+    assert np.array_equal(got[1], ref[1], equal_nan=True)          # rugosity: bit-exact
+    assert np.array_equal(got[2], ref[2], equal_nan=True)
+    # fractal roughness: the shared 1e-6 scaled metric (NumPy's float32 log is not correctly rounded and the
+    # regression amplifies its last-bit differences ~5x); most pixels are still bit-identical
+    assert np.isfinite(ref[0]).sum() > 100000
+    assert_parity(got[0], ref[0], "fractal_roughness", min_exact=0.85 if dtype == np.float32 else 0.5)
+    for w in (5, 7, 21, 49):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g = t.fractal_roughness(dem[:120, :150], window_size_fractal=w)
+        r = to.terrain_attributes(dem[:120, :150], ["fractal_roughness"], window_size_fractal=w)[0]
+        assert_parity(g, r, f"fractal_roughness w={w}")
+
+
+def test_rugosity_fractal_device_row_blocks():
+    """Device-resident entry with halo rows: a split raster reproduces the single-launch result bit for bit."""
+    import torch
+    from xdem_amd.terrain import terrain_attributes_device
+
+    rng = np.random.default_rng(5)
+    dem = torch.from_numpy(rng.uniform(0, 30, size=(200, 333)).astype(np.float32)).cuda()
+    attrs = ["rugosity", "fractal_roughness"]
+    full = terrain_attributes_device(dem, attrs, resolution=2.0)
+    top = terrain_attributes_device(dem[:106], attrs, resolution=2.0, halo_bottom=6)
+    bot = terrain_attributes_device(dem[94:], attrs, resolution=2.0, halo_top=6)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([top, bot], dim=1).view(torch.int32), full.view(torch.int32))

@@ -25,6 +25,8 @@ cases = [
     ("FL curv6", FULL[3:9], "Florinsky"), ("FL win2", FULL[9:], "Florinsky"), ("FL tpi", FULL[9:10], "Florinsky"),
     ("ZT full11", FULL, "ZevenbergThorne"), ("ZT SAH", FULL[:3], "ZevenbergThorne"),
     ("Horn SAH+win", FULL[:3] + FULL[9:], "Horn"), ("Horn slope+aspect", FULL[:2], "Horn"),
+    ("rugosity", ["rugosity"], "Florinsky"), ("roughness", ["roughness"], "Florinsky"),
+    ("fractal w13", ["fractal_roughness"], "Florinsky"),
 ]
 res = []
 for name, attrs, fit in cases:

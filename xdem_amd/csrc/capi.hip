@@ -74,6 +74,17 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms) {
     return XDEMHIP_OK;
 }
 
+int xdemhip_fractal_constants(int window_size, int max_q, int* q, double* log_q, double* mean_log_q, double* ss_xx) {
+    if (window_size < 3 || (window_size & 1) == 0 || window_size > 1023 || !q || !log_q || !mean_log_q || !ss_xx)
+        return XDEMHIP_EINVAL;
+    int qs[24];
+    double x[24];
+    const int n = xd::fractal_constants(window_size, qs, x, mean_log_q, ss_xx);
+    if (n > max_q) return XDEMHIP_EINVAL;
+    for (int i = 0; i < n; ++i) { q[i] = qs[i]; log_q[i] = x[i]; }
+    return n;
+}
+
 static int popcount32(uint32_t v) { return __builtin_popcount(v); }
 
 int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H, int64_t W, int64_t row_stride,
@@ -93,9 +104,10 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     const uint32_t curv_bits = attr_mask & 0x3f8u;
     if (surface_fit == XDEMHIP_FIT_HORN && curv_bits)
         return xd_fail(ctx, XDEMHIP_EINVAL, "'Horn' surface fit cannot be used to calculate curvatures");
-    if ((attr_mask & 0x1c00u) && (window_size < 3 || (window_size & 1) == 0 || window_size > 1023))
+    if ((attr_mask & 0x5c00u) && (window_size < 3 || (window_size & 1) == 0 || window_size > 1023))
         return xd_fail(ctx, XDEMHIP_EINVAL, "window_size must be odd and >= 3");
-    if ((attr_mask & 0x3ffu) && !(resolution > 0.0) ) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
+    const uint32_t needs_res = 0x3ffu | XDEMHIP_ATTR_RUGOSITY;  // surface fit + rugosity (terrain.py:352-367)
+    if ((attr_mask & needs_res) && !(resolution > 0.0) ) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
     if (memspace != XDEMHIP_HOST && memspace != XDEMHIP_DEVICE) return xd_fail(ctx, XDEMHIP_EINVAL, "bad memspace");
 
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -107,7 +119,7 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     memset(&L, 0, sizeof L);
     L.dem_dtype = dem_dtype; L.out_dtype = out_dtype;
     L.H = H; L.W = W; L.row_stride = row_stride; L.halo_top = halo_top; L.halo_bottom = halo_bottom;
-    L.resolution = (attr_mask & 0x3ffu) ? resolution : 1.0;
+    L.resolution = (attr_mask & needs_res) ? resolution : 1.0;
     L.surface_fit = surface_fit; L.curv_method = curv_method; L.tri_method = tri_method;
     L.window_size = window_size; L.degrees = degrees; L.attr_mask = attr_mask;
     L.hs_alt = hs_alt; L.hs_az = hs_az; L.hs_z = hs_z;

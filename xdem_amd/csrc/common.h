@@ -60,7 +60,11 @@ struct TerrainLaunch {
     int surface_fit, curv_method, tri_method, window_size, degrees;
     uint32_t attr_mask;
     double hs_alt, hs_az, hs_z;
-    void* planes[13];    // device pointers by attribute bit (null when not requested)
+    void* planes[XDEMHIP_ATTR_COUNT];  // device pointers by attribute bit (null when not requested)
 };
 int launch_terrain(xdemhip_ctx* ctx, const TerrainLaunch& L);
+// rugosity / fractal roughness (window_extra.hip); plane indexes of the two attributes
+constexpr int P_RUGOSITY_IDX = 13, P_FRACTAL_IDX = 14;
+int launch_window_extra(xdemhip_ctx* ctx, const TerrainLaunch& L);
+int fractal_constants(int w, int* qs, double* x, double* m_x, double* ss_xx);
 }  // namespace xd

@@ -217,12 +217,24 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
     return XDEMHIP_OK;
 }
 
-int launch_terrain(xdemhip_ctx* ctx, const TerrainLaunch& L) {
+static int launch_core(xdemhip_ctx* ctx, const TerrainLaunch& L) {
     if (L.dem_dtype == XDEMHIP_F32 && L.out_dtype == XDEMHIP_F32) return launch_typed<float, float>(ctx, L);
     if (L.dem_dtype == XDEMHIP_F64 && L.out_dtype == XDEMHIP_F64) return launch_typed<double, double>(ctx, L);
     if (L.dem_dtype == XDEMHIP_F32 && L.out_dtype == XDEMHIP_F64) return launch_typed<float, double>(ctx, L);
     if (L.dem_dtype == XDEMHIP_F64 && L.out_dtype == XDEMHIP_F32) return launch_typed<double, float>(ctx, L);
     return xd_fail(ctx, XDEMHIP_EINVAL, "unsupported dtype combination");
+}
+
+int launch_terrain(xdemhip_ctx* ctx, const TerrainLaunch& L) {
+    const uint32_t core = L.attr_mask & ((1u << N_ATTR) - 1u);  // attributes of the fused tile / generic window kernels
+    if (core) {
+        TerrainLaunch C = L;
+        C.attr_mask = core;
+        const int rc = launch_core(ctx, C);
+        if (rc != XDEMHIP_OK) return rc;
+    }
+    if (L.attr_mask & ~((1u << N_ATTR) - 1u)) return launch_window_extra(ctx, L);  // rugosity, fractal roughness
+    return XDEMHIP_OK;
 }
 
 }  // namespace xd

@@ -103,6 +103,12 @@ class DEM:
     def roughness(self, window_size=3, mp_config=None) -> "DEM":
         return terrain.roughness(self, window_size=window_size, mp_config=mp_config)
 
+    def rugosity(self, mp_config=None) -> "DEM":
+        return terrain.rugosity(self, mp_config=mp_config)
+
+    def fractal_roughness(self, window_size_fractal=13, mp_config=None) -> "DEM":
+        return terrain.fractal_roughness(self, window_size_fractal=window_size_fractal, mp_config=mp_config)
+
     def get_terrain_attribute(self, attribute, **kwargs: Any):
         return terrain.get_terrain_attribute(self, attribute=attribute, **kwargs)
 

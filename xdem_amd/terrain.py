@@ -7,8 +7,9 @@ engines behind it are the fused HIP kernel of ``csrc/terrain.hip`` reached throu
 
 Covered attributes (the hot path named in BASELINE.json): slope, aspect, hillshade, curvature
 (deprecated), profile / tangential / planform / flowline / max / min curvature, topographic position
-index, terrain ruggedness index, plus ``roughness`` (first "next" row).  ``rugosity``,
-``fractal_roughness`` and ``texture_shading`` are outside the path and raise ``NotImplementedError`` here.
+index, terrain ruggedness index, plus the remaining windowed indexes: ``roughness``, ``rugosity``
+and ``fractal_roughness`` (``csrc/window_extra.hip``).  ``texture_shading`` (frequency domain) is outside the path
+and raises ``NotImplementedError`` here.
 """
 from __future__ import annotations
 
@@ -39,9 +40,10 @@ list_requiring_frequency_domain = ["texture_shading"]
 ATTR_BIT = {
     "slope": 0, "aspect": 1, "hillshade": 2, "curvature": 3, "profile_curvature": 4, "tangential_curvature": 5,
     "planform_curvature": 6, "flowline_curvature": 7, "max_curvature": 8, "min_curvature": 9,
-    "topographic_position_index": 10, "terrain_ruggedness_index": 11, "roughness": 12,
+    "topographic_position_index": 10, "terrain_ruggedness_index": 11, "roughness": 12, "rugosity": 13,
+    "fractal_roughness": 14,
 }
-_NOT_ON_HOT_PATH = ("rugosity", "fractal_roughness", "texture_shading")
+_NOT_ON_HOT_PATH = ("texture_shading",)
 _FIT_ID = {"horn": 0, "zevenbergthorne": 1, "florinsky": 2}
 _CURV_ID = {"geometric": 0, "directional": 1}
 _TRI_ID = {"riley": 0, "wilson": 1}
@@ -140,8 +142,8 @@ def _validate(dem, attribute, resolution, hillshade_altitude, hillshade_azimuth,
     for attr in attribute:
         if attr in _NOT_ON_HOT_PATH:
             raise NotImplementedError(
-                f"Attribute '{attr}' is not on the MI355X hot path of xdem_amd (slope, aspect, hillshade, curvatures, "
-                "TPI, TRI); see SURVEY.md section 8f."
+                f"Attribute '{attr}' is not on the MI355X hot path of xdem_amd (surface-fit attributes and windowed "
+                "indexes); see SURVEY.md section 8f."
             )
     return attribute, resolution
 
@@ -149,8 +151,19 @@ def _validate(dem, attribute, resolution, hillshade_altitude, hillshade_azimuth,
 def launch_terrain(ctx: _lib.Context, dem_ptr: int, dem_dtype, H: int, W: int, row_stride: int, halo_top: int,
                    halo_bottom: int, resolution: float, surface_fit: str, curv_method: str, attribute: list[str],
                    tri_method: str, window_size: int, hillshade_altitude: float, hillshade_azimuth: float,
-                   hillshade_z_factor: float, degrees: bool, out_dtype, plane_ptrs: dict[str, int], memspace: int) -> None:
-    """Thin marshalling of one ``xdemhip_terrain`` call (planes are passed in ascending attribute-bit order)."""
+                   hillshade_z_factor: float, degrees: bool, out_dtype, plane_ptrs: dict[str, int], memspace: int,
+                   window_size_fractal: int = 13) -> None:
+    """Thin marshalling of ``xdemhip_terrain`` (planes are passed in ascending attribute-bit order).  Fractal
+    roughness has its own window size and, like upstream (terrain.py:619-630), its own engine call."""
+    frac = [a for a in attribute if a in list_requiring_windowed_fractal_index]
+    if frac and len(frac) < len(set(attribute)):
+        rest = [a for a in attribute if a not in list_requiring_windowed_fractal_index]
+        launch_terrain(ctx, dem_ptr, dem_dtype, H, W, row_stride, halo_top, halo_bottom, resolution, surface_fit,
+                       curv_method, rest, tri_method, window_size, hillshade_altitude, hillshade_azimuth,
+                       hillshade_z_factor, degrees, out_dtype, plane_ptrs, memspace)
+        attribute = frac
+    if frac:
+        window_size = window_size_fractal
     mask = 0
     for a in attribute:
         mask |= 1 << ATTR_BIT[a]
@@ -221,7 +234,7 @@ def get_terrain_attribute(
     ctx = _lib.default_context()
     launch_terrain(ctx, dem_arr.ctypes.data, dem_arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
                    attribute, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
-                   degrees, out_dtype, {a: o.ctypes.data for a, o in outs.items()}, _lib.HOST)
+                   degrees, out_dtype, {a: o.ctypes.data for a, o in outs.items()}, _lib.HOST, window_size_fractal)
     output_attributes = [outs[a] for a in attribute]
     if _is_raster(dem):
         output_attributes = [
@@ -234,7 +247,8 @@ def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0
                               hillshade_altitude: float = 45.0, hillshade_azimuth: float = 315.0,
                               hillshade_z_factor: float = 1.0, surface_fit: str = "Florinsky",
                               curv_method: str = "geometric", tri_method: str = "Riley", window_size: int = 3,
-                              out=None, halo_top: int = 0, halo_bottom: int = 0, ctx: _lib.Context | None = None):
+                              out=None, halo_top: int = 0, halo_bottom: int = 0, ctx: _lib.Context | None = None,
+                              window_size_fractal: int = 13):
     """Device-resident variant: ``dem`` is a CUDA(HIP) torch tensor (rows = halo_top + H + halo_bottom), result is
     one (n_attr, H, W) tensor (or ``out``) filled on the current torch stream.  No host copies, no sync."""
     import torch
@@ -252,7 +266,7 @@ def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0
     launch_terrain(ctx, dem.data_ptr(), dt, H, W, dem.stride(0), halo_top, halo_bottom, resolution, surface_fit,
                    curv_method, list(attribute), tri_method, window_size, hillshade_altitude, hillshade_azimuth,
                    hillshade_z_factor, degrees, {torch.float32: np.float32, torch.float64: np.float64}[out.dtype],
-                   ptrs, _lib.DEVICE)
+                   ptrs, _lib.DEVICE, window_size_fractal)
     return out
 
 
@@ -322,6 +336,18 @@ def topographic_position_index(dem, window_size=3, mp_config=None, engine="hip")
 def roughness(dem, window_size=3, mp_config=None, engine="hip"):
     """Roughness: largest elevation difference inside the window (terrain.py:1600-1640)."""
     return get_terrain_attribute(dem=dem, attribute="roughness", window_size=window_size, mp_config=mp_config, engine=engine)
+
+
+def rugosity(dem, resolution=None, mp_config=None, engine="hip"):
+    """Rugosity: real over planimetric surface area on a 3x3 window, Jenness (2004) (terrain.py:1660-1700)."""
+    return get_terrain_attribute(dem=dem, attribute="rugosity", resolution=resolution, mp_config=mp_config, engine=engine)
+
+
+def fractal_roughness(dem, window_size_fractal=13, mp_config=None, engine="hip"):
+    """Fractal roughness: box-counting estimate of the local fractal dimension (1..3), Taud & Parrot (2005)
+    (terrain.py:1721-1765)."""
+    return get_terrain_attribute(dem=dem, attribute="fractal_roughness", window_size_fractal=window_size_fractal,
+                                 mp_config=mp_config, engine=engine)
 
 
 def terrain_ruggedness_index(dem, method="Riley", window_size=3, mp_config=None, engine="hip"):
