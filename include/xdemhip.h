@@ -183,6 +183,31 @@ int xdemhip_pairs_hist(xdemhip_pairs* pairs, int shift, int first, const uint64_
 int xdemhip_pairs_succ(xdemhip_pairs* pairs, const uint64_t* key, uint64_t* succ);
 void xdemhip_pairs_destroy(xdemhip_pairs* pairs);
 
+/* ---- next row 8f-3: N-dimensional binned statistics ---------------------------------------------------------------
+ * Replaces the array work of  nd_binning(values, list_var, list_var_names, list_var_bins, statistics, list_ranges)
+ * xdem/spatialstats.py:91-216, i.e. scipy.stats.binned_statistic / binned_statistic_2d / binned_statistic_dd with the
+ * statistics "count", np.nanmedian and nmad (1.4826 * nanmedian(|x - nanmedian(x)|), geoutils.stats.nmad) -- the binning
+ * behind the heteroscedasticity inference (spatialstats.py:576-631).
+ *
+ *  create / add_var   values and explanatory variables, all of length n (float32 or float64 each).
+ *  finalize           joint finiteness filter (spatialstats.py:140-143) -> n_valid, and every variable's min / max over
+ *                     the kept rows (what SciPy's _bin_edges takes its range from).
+ *  run                one binning over n_dims of the variables.  edges = the dimensions' bin edges concatenated
+ *                     (n_edges[d] each, float64 numbers already rounded to SciPy's edge dtype); decimals[d] = SciPy's
+ *                     `int(-log10(min edge spacing)) + 6` and sample_dtype = dtype of its sample matrix (both only matter
+ *                     for samples at or beyond the rightmost edge, _binned_statistic.py:_bin_numbers).  Outputs are in C
+ *                     order over the dimensions: counts (exact), medians (exact order statistics, mean of the two
+ *                     middle values in the value dtype for even counts, NaN for empty bins), nmads (want_nmad != 0).
+ */
+typedef struct xdemhip_binstats xdemhip_binstats;
+int xdemhip_binstats_create(xdemhip_ctx* ctx, const void* values, int dtype, int64_t n, int memspace, xdemhip_binstats** out);
+int xdemhip_binstats_add_var(xdemhip_binstats* plan, const void* var, int dtype, int memspace); /* returns the variable id */
+int xdemhip_binstats_finalize(xdemhip_binstats* plan, int64_t* n_valid, double* var_min, double* var_max);
+int xdemhip_binstats_run(xdemhip_binstats* plan, int n_dims, const int* var_ids, const double* edges, const int* n_edges,
+                         const int* decimals, int sample_dtype, int want_nmad, double nfact, int64_t* counts,
+                         double* medians, double* nmads);
+void xdemhip_binstats_destroy(xdemhip_binstats* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""CPU oracle of the N-D binned statistics -- TEST INFRASTRUCTURE ONLY.
+
+Restates what ``xdem.spatialstats.nd_binning`` (xdem/spatialstats.py:91-216) computes through
+``scipy.stats.binned_statistic / _2d / _dd`` for the statistics count, ``np.nanmedian`` and geoutils' ``nmad``:
+joint finite filter (140-143), SciPy's bin edges (``_binned_statistic.py:_bin_edges``: data range as float, +-0.5
+when degenerate, ``np.linspace`` in the sample dtype) and bin numbers (``_bin_numbers``: ``np.digitize`` + the
+rightmost-edge rounding rule), then the per-bin statistic on the value-dtype array of the bin.
+
+Pinned against outputs of the reference's own nd_binning recorded in tests/golden/binning_golden.npz
+(oracle/gen_golden_binning.py).  ``nmad`` lives in geoutils (absent here): its published definition
+``nfact * nanmedian(|x - nanmedian(x)|)`` is restated; parity of that one formula is unpinned.
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+
+def nmad(data, nfact: float = 1.4826):
+    arr = np.asarray(data)
+    return nfact * np.nanmedian(np.abs(arr - np.nanmedian(arr)))
+
+
+def bin_edges(sample: np.ndarray, bins: list) -> tuple[list[np.ndarray], list[int]]:
+    """(edges per dimension, SciPy's rounding decimals) for a (N, D) sample matrix, range=None."""
+    edges_dtype = sample.dtype if np.issubdtype(sample.dtype, np.floating) else np.dtype(float)
+    smin = np.atleast_1d(np.array(sample.min(axis=0), float))
+    smax = np.atleast_1d(np.array(sample.max(axis=0), float))
+    edges, decimals = [], []
+    for i in range(sample.shape[1]):
+        if smin[i] == smax[i]:
+            smin[i], smax[i] = smin[i] - 0.5, smax[i] + 0.5
+        if np.isscalar(bins[i]):
+            e = np.linspace(smin[i], smax[i], int(bins[i]) + 1, dtype=edges_dtype)
+        else:
+            e = np.asarray(np.asarray(bins[i], float), edges_dtype)
+        edges.append(e)
+        decimals.append(int(-np.log10(np.diff(e).min())) + 6)
+    return edges, decimals
+
+
+def bin_numbers(sample: np.ndarray, edges: list[np.ndarray], decimals: list[int]) -> np.ndarray:
+    """Flattened C-order bin id over the core bins, -1 for outliers."""
+    n, nd = sample.shape
+    flat = np.zeros(n, np.int64)
+    ok = np.ones(n, bool)
+    for i in range(nd):
+        idx = np.digitize(sample[:, i], edges[i])
+        on_edge = (sample[:, i] >= edges[i][-1]) & (np.around(sample[:, i], decimals[i]) == np.around(edges[i][-1], decimals[i]))
+        idx[on_edge] -= 1
+        nb = len(edges[i]) - 1
+        ok &= (idx >= 1) & (idx <= nb)
+        flat = flat * nb + (idx - 1)
+    flat[~ok] = -1
+    return flat
+
+
+def binned_stats(values: np.ndarray, cols: list[np.ndarray], bins: list):
+    """count / nanmedian / nmad per bin (float64 arrays shaped like the bin grid) + edges, inputs already filtered."""
+    sample = np.atleast_2d(cols).T
+    edges, decimals = bin_edges(sample, bins)
+    shape = tuple(len(e) - 1 for e in edges)
+    ids = bin_numbers(sample, edges, decimals)
+    nb = int(np.prod(shape))
+    count = np.zeros(nb)
+    med = np.full(nb, np.nan)
+    nm = np.full(nb, np.nan)
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    start = np.searchsorted(sid, np.arange(nb), side="left")
+    stop = np.searchsorted(sid, np.arange(nb), side="right")
+    for b in range(nb):
+        if stop[b] > start[b]:
+            v = values[order[start[b]:stop[b]]]
+            count[b] = v.size
+            med[b] = np.nanmedian(v)
+            nm[b] = nmad(v)
+    return count.reshape(shape), med.reshape(shape), nm.reshape(shape), edges
+
+
+def nd_binning_arrays(values, list_var, list_var_bins=None):
+    """All binnings nd_binning performs, as a list of (var_ids, count, median, nmad, edges) in its order: every 1-D,
+    every 2-D combination, then the N-D one when there are more than two variables."""
+    nv = len(list_var)
+    if list_var_bins is None:
+        list_var_bins = (10,) * nv
+    elif isinstance(list_var_bins, (int, np.integer)):
+        list_var_bins = (list_var_bins,) * nv
+    values = np.asarray(values).ravel()
+    list_var = [np.asarray(v).ravel() for v in list_var]
+    valid = np.logical_and.reduce([np.isfinite(values)] + [np.isfinite(v) for v in list_var])
+    values = values[valid]
+    list_var = [v[valid] for v in list_var]
+    out = []
+    for i in range(nv):
+        out.append(((i,),) + binned_stats(values, [list_var[i]], [list_var_bins[i]]))
+    if nv > 1:
+        for i1, i2 in itertools.combinations(range(nv), 2):
+            out.append(((i1, i2),) + binned_stats(values, [list_var[i1], list_var[i2]], [list_var_bins[i1], list_var_bins[i2]]))
+    if nv > 2:
+        out.append((tuple(range(nv)),) + binned_stats(values, list_var, list(list_var_bins)))
+    return out

@@ -209,7 +209,7 @@ def terrain_T9() -> None:
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["terrain", "nk", "vario"]
+    which = sys.argv[1:] or ["terrain", "nk", "vario", "binning"]
     if "terrain" in which:
         _check_tables()
         terrain_T1()
@@ -226,3 +226,7 @@ if __name__ == "__main__":
         import gen_golden_vario
 
         gen_golden_vario.main(ref, OUT)
+    if "binning" in which:
+        import gen_golden_binning
+
+        gen_golden_binning.main(ref, OUT)

@@ -81,6 +81,15 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_pairs_succ.argtypes = [ctypes.c_void_p, c_u64p, c_u64p]
         L.xdemhip_pairs_destroy.argtypes = [ctypes.c_void_p]
         L.xdemhip_pairs_destroy.restype = None
+        c_ip = ctypes.POINTER(ctypes.c_int)
+        L.xdemhip_binstats_create.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_void_p)]
+        L.xdemhip_binstats_add_var.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.xdemhip_binstats_finalize.argtypes = [ctypes.c_void_p, c_i64p, c_dp, c_dp]
+        L.xdemhip_binstats_run.argtypes = [ctypes.c_void_p, ctypes.c_int, c_ip, c_dp, c_ip, c_ip, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_double, c_i64p, c_dp, c_dp]
+        L.xdemhip_binstats_destroy.argtypes = [ctypes.c_void_p]
+        L.xdemhip_binstats_destroy.restype = None
         _lib = L
         return L
 

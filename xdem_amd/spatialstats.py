@@ -390,3 +390,179 @@ def equidistant_blocks_from_coords(coords: np.ndarray, values: np.ndarray, valid
         if a.size and b.size:
             blocks.append((cx[a], cy[a], values[a], cx[b], cy[b], values[b]))
     return blocks
+
+
+# ======================================================================================================================
+# N-D binned statistics: mirror of xdem/spatialstats.py:76-216 over csrc/binstats.hip
+# ======================================================================================================================
+def nmad(data, nfact: float = 1.4826):
+    """Normalized median absolute deviation, ``nfact * nanmedian(|x - nanmedian(x)|)`` (geoutils.stats.nmad, what
+    xdem/spatialstats.py:76-88 forwards to).  Host NumPy helper; as an ``nd_binning`` statistic it is evaluated per bin
+    on the GPU."""
+    arr = np.ma.filled(data, np.nan) if isinstance(data, np.ma.MaskedArray) else np.asarray(data)
+    return nfact * np.nanmedian(np.abs(arr - np.nanmedian(arr)))
+
+
+_GPU_STATS = {"count": "count", "nanmedian": "median", "median": "median", "nmad": "nmad"}
+
+
+def _scipy_edges(sample_cols: list[np.ndarray], mins: list[float], maxs: list[float], bins: list) -> tuple[list[np.ndarray], list[int], Any]:
+    """Bin edges, rounding decimals and sample dtype exactly as scipy.stats._binned_statistic._bin_edges /
+    _bin_numbers derive them (range=None): ``smin, smax`` of the kept rows as float, +-0.5 when equal, ``np.linspace`` in
+    the dtype of SciPy's sample matrix (the variables' common float dtype)."""
+    sdt = np.result_type(*[c.dtype for c in sample_cols])
+    edges_dtype = sdt if np.issubdtype(sdt, np.floating) else np.dtype(float)
+    edges, decimals = [], []
+    for i in range(len(sample_cols)):
+        if np.isscalar(bins[i]):
+            smin, smax = float(mins[i]), float(maxs[i])
+            if smin == smax:
+                smin, smax = smin - 0.5, smax + 0.5
+            e = np.linspace(smin, smax, int(bins[i]) + 1, dtype=edges_dtype)
+        else:
+            e = np.asarray(np.asarray(bins[i], float), edges_dtype)
+        d = np.diff(e)
+        dmin = d.min()
+        if dmin == 0:
+            raise ValueError("The smallest edge difference is numerically 0.")
+        decimals.append(int(-np.log10(dmin)) + 6)
+        edges.append(e)
+    return edges, decimals, edges_dtype
+
+
+class BinStatsPlan:
+    """Device-resident values + explanatory variables of one ``nd_binning`` call (``xdemhip_binstats``)."""
+
+    def __init__(self, values: np.ndarray, list_var: list[np.ndarray], ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        L = self.ctx._L
+
+        def prep(a):
+            a = np.asarray(a).ravel()
+            if a.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+                a = a.astype(np.float64)
+            return np.ascontiguousarray(a)
+
+        self.values = prep(values)
+        self.vars = [prep(v) for v in list_var]
+        n = self.values.size
+        if any(v.size != n for v in self.vars):
+            raise ValueError("values and explanatory variables must have the same number of elements")
+        h = ctypes.c_void_p()
+        code = lambda a: _lib.F32 if a.dtype == np.float32 else _lib.F64  # noqa: E731
+        self.ctx.check(L.xdemhip_binstats_create(self.ctx.handle, self.values.ctypes.data, code(self.values), n, _lib.HOST,
+                                                 ctypes.byref(h)))
+        self.handle = h
+        for v in self.vars:
+            rc = L.xdemhip_binstats_add_var(self.handle, v.ctypes.data, code(v), _lib.HOST)
+            if rc < 0:
+                self.ctx.check(rc)
+        nv = ctypes.c_int64()
+        k = max(len(self.vars), 1)
+        vmin, vmax = np.empty(k), np.empty(k)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self.ctx.check(L.xdemhip_binstats_finalize(self.handle, ctypes.byref(nv), vmin.ctypes.data_as(dp), vmax.ctypes.data_as(dp)))
+        self.n_valid = int(nv.value)
+        self.var_min, self.var_max = vmin, vmax
+
+    def run(self, var_ids: list[int], bins: list, want_nmad: bool = True, nfact: float = 1.4826):
+        """One binning over the given variables -> (count int64, median f64, nmad f64 | None, edges) in C order."""
+        cols = [self.vars[i] for i in var_ids]
+        edges, decimals, sdt = _scipy_edges(cols, [self.var_min[i] for i in var_ids], [self.var_max[i] for i in var_ids], bins)
+        shape = tuple(len(e) - 1 for e in edges)
+        nb = int(np.prod(shape))
+        flat = np.concatenate([np.asarray(e, np.float64) for e in edges])
+        counts = np.zeros(nb, np.int64)
+        med = np.full(nb, np.nan)
+        nm = np.full(nb, np.nan)
+        ip, dp, lp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+        ids = (ctypes.c_int * len(var_ids))(*var_ids)
+        ne = (ctypes.c_int * len(var_ids))(*[len(e) for e in edges])
+        dec = (ctypes.c_int * len(var_ids))(*decimals)
+        if self.n_valid > 0:
+            self.ctx.check(self.ctx._L.xdemhip_binstats_run(
+                self.handle, len(var_ids), ids, flat.ctypes.data_as(dp), ne, dec, _lib.F32 if sdt == np.float32 else _lib.F64,
+                int(want_nmad), float(nfact), counts.ctypes.data_as(lp), med.ctypes.data_as(dp), nm.ctypes.data_as(dp)))
+        return counts.reshape(shape), med.reshape(shape), (nm.reshape(shape) if want_nmad else None), edges
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.ctx._L.xdemhip_binstats_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=("count", np.nanmedian, nmad),
+               list_ranges=None, ctx: _lib.Context | None = None):
+    """N-dimensional binning of ``values`` by explanatory variables with per-bin statistics on the GPU.
+
+    Drop-in for ``xdem.spatialstats.nd_binning`` (xdem/spatialstats.py:91-216): same flattening, joint finite filter,
+    1-D binnings per variable, all 2-D combinations, one N-D binning when there are more than two variables, and the
+    same DataFrame layout (``nd``, statistic columns named after the callables, one ``pd.IntervalIndex`` column per
+    variable).  Statistics evaluated on the device: ``"count"``, ``np.nanmedian`` / ``"median"`` and ``nmad``; any other
+    callable raises ``NotImplementedError`` (this package has no CPU engine).  ``list_ranges`` must be None.
+    """
+    import itertools
+
+    import pandas as pd
+
+    if list_ranges is not None:
+        raise NotImplementedError("list_ranges is not supported by the HIP engine (bin ranges come from the data, as by default).")
+    if list_var_bins is None:
+        list_var_bins = (10,) * len(list_var_names)
+    elif isinstance(list_var_bins, (int, np.integer)):
+        list_var_bins = (list_var_bins,) * len(list_var_names)
+    statistics = list(statistics)
+    if "count" not in statistics:
+        statistics.insert(0, "count")
+    statistics_name = [f if isinstance(f, str) else f.__name__ for f in statistics]
+    kinds = []
+    for name in statistics_name:
+        if name not in _GPU_STATS:
+            raise NotImplementedError(f"Statistic '{name}' is not available on the HIP engine (count, nanmedian, nmad are).")
+        kinds.append(_GPU_STATS[name])
+    want_nmad = "nmad" in kinds
+
+    plan = BinStatsPlan(np.asarray(values), [np.asarray(v) for v in list_var], ctx)
+    try:
+        def stats_df(var_ids, bins):
+            c, m, s, edges = plan.run(var_ids, bins, want_nmad)
+            df = pd.DataFrame()
+            for name, kind in zip(statistics_name, kinds):
+                col = {"count": c.astype(float), "median": m, "nmad": s}[kind]
+                df[name] = col.flatten()
+            return df, edges
+
+        list_df_1d = []
+        for i in range(len(list_var)):
+            df, (e,) = stats_df([i], [list_var_bins[i]])
+            df[list_var_names[i]] = pd.IntervalIndex.from_breaks(e, closed="left")
+            df.insert(0, "nd", 1)
+            list_df_1d.append(df)
+        list_df_2d = []
+        if len(list_var) > 1:
+            for v1, v2 in itertools.combinations(list_var_names, 2):
+                i1, i2 = list_var_names.index(v1), list_var_names.index(v2)
+                df, (e1, e2) = stats_df([i1, i2], [list_var_bins[i1], list_var_bins[i2]])
+                ii1 = pd.IntervalIndex.from_breaks(e1, closed="left")
+                ii2 = pd.IntervalIndex.from_breaks(e2, closed="left")
+                df[v1] = [a for a in ii1 for b in ii2]
+                df[v2] = [b for a in ii1 for b in ii2]
+                df.insert(0, "nd", 2)
+                list_df_2d.append(df)
+        df_nd = pd.DataFrame()
+        if len(list_var) > 2:
+            df_nd, list_edges = stats_df(list(range(len(list_var))), list(list_var_bins))
+            list_ii = [pd.IntervalIndex.from_breaks(e, closed="left") for e in list_edges]
+            iind = np.meshgrid(*list_ii)  # (upstream's default 'xy' indexing, spatialstats.py:202)
+            for i, name in enumerate(list_var_names):
+                df_nd[name] = iind[i].flatten()
+            df_nd.insert(0, "nd", len(list_var_names))
+    finally:
+        plan.close()
+    return pd.concat(list_df_1d + list_df_2d + [df_nd])
