@@ -208,6 +208,20 @@ int xdemhip_binstats_run(xdemhip_binstats* plan, int n_dims, const int* var_ids,
                          double* medians, double* nmads);
 void xdemhip_binstats_destroy(xdemhip_binstats* plan);
 
+/* Global NMAD of an array, NaN-skipping: median = np.nanmedian(v), nmad = nfact * np.nanmedian(|v - median|) in the value
+ * dtype; values with |v| > abs_limit are dropped first (two_step_standardization's outlier filter, spatialstats.py:556-561;
+ * pass +inf to keep everything). */
+int xdemhip_nmad(xdemhip_ctx* ctx, const void* values, int dtype, int64_t n, double nfact, double abs_limit, int memspace,
+                 double* median, double* nmad, int64_t* count);
+
+/* out[p] = scale * f(vars[0][p], ..., vars[n_dims-1][p]) for the multilinear interpolant f on a regular grid: the evaluation
+ * scipy.interpolate.RegularGridInterpolator(axes, grid_values, method="linear", bounds_error=False, fill_value=None) performs
+ * for the error function returned by interp_nd_binning (xdem/spatialstats.py:417-421) and applied to whole rasters by
+ * infer_heteroscedasticity_from_stable (spatialstats.py:866-868).  axes = grid axes concatenated (n_axis[d] points each,
+ * ascending), grid_values in C order, NaN in any coordinate -> NaN, coordinates outside the grid extrapolate linearly. */
+int xdemhip_interp_grid_linear(xdemhip_ctx* ctx, int n_dims, const double* axes, const int* n_axis, const double* grid_values,
+                               const void* const* vars, const int* var_dtypes, int64_t n, double scale, double* out, int memspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,6 +127,10 @@ def install() -> None:
     import geopandas
 
     geopandas.GeoDataFrame = type("GeoDataFrame", (), {})  # isinstance() sentinel, never instantiated
+    import geoutils.vector.vector
+
+    geoutils.vector.vector.Vector = type("Vector", (), {})  # isinstance() sentinel (spatialstats.py:676-693)
+    geoutils.vector.vector.VectorType = geoutils.vector.vector.Vector
 
     pkg = types.ModuleType("xdem")
     pkg.__path__ = [os.path.join(REFERENCE_ROOT, "xdem")]

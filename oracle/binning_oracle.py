@@ -101,3 +101,43 @@ def nd_binning_arrays(values, list_var, list_var_bins=None):
     if nv > 2:
         out.append((tuple(range(nv)),) + binned_stats(values, list_var, list(list_var_bins)))
     return out
+
+
+# ---- heteroscedasticity inference (xdem/spatialstats.py:237-421, 530-631) ----------------------------------------------
+def interp_table(centres_per_bin: list[np.ndarray], stat: np.ndarray, count: np.ndarray, min_count):
+    """Regular-grid interpolant (scipy RegularGridInterpolator) of a binned statistic given per-bin centre coordinates:
+    bins under ``min_count`` dropped, linear griddata inside the hull, nearest-neighbour outside (on the grid, then on
+    the grid extended by one node per side), linear interpolation in between -- the documented stages of
+    interp_nd_binning."""
+    from scipy.interpolate import RegularGridInterpolator, griddata
+
+    stat = np.array(stat, float)
+    if min_count is not None:
+        stat[count < min_count] = np.nan
+    ok = np.isfinite(stat)
+    axes = [np.array(sorted(np.unique(c[ok]))) for c in centres_per_bin]
+    grid_pts = tuple(m.flatten() for m in np.meshgrid(*axes, indexing="ij"))
+    g = griddata(tuple(c[ok] for c in centres_per_bin), stat[ok], grid_pts, method="linear")
+    f = np.isfinite(g)
+    g = griddata(tuple(p[f] for p in grid_pts), g[f], grid_pts, method="nearest")
+    ext = [np.concatenate([[a[0] - 1], a, [a[-1] + 1]]) for a in axes]
+    ext_pts = tuple(m.flatten() for m in np.meshgrid(*ext, indexing="ij"))
+    ge = griddata(grid_pts, g, ext_pts, method="nearest").reshape([len(a) for a in ext])
+    return RegularGridInterpolator(tuple(ext), ge, method="linear", bounds_error=False, fill_value=None)
+
+
+def estimate_model_heteroscedasticity(dvalues, list_var, list_var_bins=None, min_count=100, fac_spread_outliers=7):
+    """(binning results, unscaled interpolant, scale factor): error = scale * interpolant(vars)."""
+    import pandas as pd
+
+    res = nd_binning_arrays(dvalues, list_var, list_var_bins)
+    nv = len(list_var)
+    ids, count, _, nm, edges = [r for r in res if len(r[0]) == nv][-1]
+    mids = [pd.IntervalIndex.from_breaks(e, closed="left").mid.values for e in edges]  # (float64 midpoints, base.py / pandas)
+    mesh = np.meshgrid(*mids, indexing="ij") if nv <= 2 else np.meshgrid(*mids)
+    fun = interp_table([m.flatten() for m in mesh], nm.flatten(), count.flatten(), min_count)
+    with np.errstate(all="ignore"):
+        z = np.asarray(dvalues).ravel() / fun(tuple(np.asarray(v).ravel() for v in list_var))
+    if fac_spread_outliers is not None:
+        z[np.abs(z) > fac_spread_outliers * nmad(z)] = np.nan
+    return res, fun, nmad(z)

@@ -51,5 +51,33 @@ def main(ref, out_dir: str) -> None:
             left = np.array([iv.left if hasattr(iv, "left") else np.nan for iv in df[nm].values], float)
             right = np.array([iv.right if hasattr(iv, "right") else np.nan for iv in df[nm].values], float)
             rec[f"{name}|{nm}|left"], rec[f"{name}|{nm}|right"] = left, right
+    # heteroscedasticity inference (spatialstats.py:576-631, 808-878): error map from the reference's own pipeline
+    rng = np.random.default_rng(123)
+    shape = (150, 160)
+    slope = rng.gamma(2.0, 8.0, shape).astype(np.float32)
+    maxc = np.abs(rng.normal(0, 1.5, shape)).astype(np.float32)
+    dh = (rng.normal(0, 1, shape) * (0.5 + 0.05 * slope + 0.3 * maxc)).astype(np.float32)
+    dh[::13, ::7] = np.nan
+    slope[5, 5] = np.nan
+    stable = rng.uniform(size=shape) < 0.7
+    # (infer_heteroscedasticity_from_stable itself needs a geoutils Raster to learn a ground sampling distance it never
+    # uses, spatialstats.py:707-719; its body after the masking is reproduced call by call: 856-868)
+    df, fun = ref.spatialstats._estimate_model_heteroscedasticity(
+        dvalues=dh[stable], list_var=[slope[stable], maxc[stable]], list_var_names=["slope", "maxc"], spread_statistic=nmad,
+        list_var_bins=(8, 6), min_count=30)
+    err = fun((slope, maxc))
+    rec["het|dh"], rec["het|slope"], rec["het|maxc"], rec["het|stable"] = dh, slope, maxc, stable
+    rec["het|error"] = np.asarray(err, np.float64)
+    rec["het|df_nd"] = df["nd"].values.astype(np.int64)
+    rec["het|df_count"] = df["count"].values.astype(np.float64)
+    rec["het|df_nmad"] = df["nmad"].values.astype(np.float64)
+    probe = (np.array([-5.0, 0.0, 3.3, 20.0, 55.5, 500.0, np.nan, 10.0]), np.array([0.1, -2.0, 1.7, 9.0, 0.5, 3.0, 1.0, np.nan]))
+    rec["het|probe_x"], rec["het|probe_y"] = probe
+    rec["het|probe_out"] = np.asarray(fun(probe), np.float64)
+    # the unscaled interpolant alone, 1-D and 2-D (interp_nd_binning, spatialstats.py:237-421)
+    f2 = ref.spatialstats.interp_nd_binning(df, ["slope", "maxc"], statistic="nmad", min_count=30)
+    rec["het|interp2_out"] = np.asarray(f2(probe), np.float64)
+    f1 = ref.spatialstats.interp_nd_binning(df, ["slope"], statistic="nmad", min_count=30)
+    rec["het|interp1_out"] = np.asarray(f1((probe[0],)), np.float64)
     np.savez_compressed(os.path.join(out_dir, "binning_golden.npz"), **rec)
     print("binning fixtures written")

@@ -76,3 +76,79 @@ def test_nd_binning_argument_rules():
     df = ss.nd_binning(v, [v], ["a"], list_var_bins=4, statistics=[np.nanmedian])  # count is added in front
     assert list(df.columns) == ["nd", "count", "nanmedian", "a"] and df["count"].tolist() == [25.0] * 4
     assert df["nanmedian"].tolist() == [12.0, 37.0, 62.0, 87.0]
+
+
+def test_heteroscedasticity_equals_reference_error_map():
+    """infer_heteroscedasticity_from_stable through the product path vs the error map the reference's own pipeline produced
+    (tests/golden/binning_golden.npz, het|*).  Binned table bit-exact; float64 error map within 1e-12 relative (the
+    multilinear evaluation order of the GPU kernel follows SciPy's generic path; its 2-D Cython fast path differs in the
+    last bits)."""
+    from xdem_amd import spatialstats as ss
+
+    z = np.load(os.path.join(GOLDEN, "binning_golden.npz"))
+    dh, slope, maxc, stable = z["het|dh"], z["het|slope"], z["het|maxc"], z["het|stable"]
+    err, df, fun = ss.infer_heteroscedasticity_from_stable(dh, [slope, maxc], stable_mask=stable, list_var_names=["slope", "maxc"],
+                                                           list_var_bins=(8, 6), min_count=30)
+    assert np.array_equal(df["nd"].values, z["het|df_nd"])
+    assert np.array_equal(df["count"].values, z["het|df_count"])
+    assert np.array_equal(df["nmad"].values, z["het|df_nmad"], equal_nan=True)
+    assert err.shape == dh.shape and err.dtype == np.float64
+    assert np.array_equal(np.isnan(err), np.isnan(z["het|error"]))
+    assert np.allclose(err, z["het|error"], rtol=1e-12, atol=0, equal_nan=True)
+    probe = (z["het|probe_x"], z["het|probe_y"])
+    assert np.allclose(fun(probe), z["het|probe_out"], rtol=1e-12, atol=0, equal_nan=True)
+    # the unscaled interpolants of interp_nd_binning, 2-D and 1-D
+    f2 = ss.interp_nd_binning(df, ["slope", "maxc"], statistic="nmad", min_count=30)
+    assert np.allclose(f2(probe), z["het|interp2_out"], rtol=1e-12, atol=0, equal_nan=True)
+    f1 = ss.interp_nd_binning(df, ["slope"], statistic="nmad", min_count=30)
+    assert np.allclose(f1((probe[0],)), z["het|interp1_out"], rtol=1e-12, atol=0, equal_nan=True)
+    # documented toy example of interp_nd_binning (spatialstats.py:266-290)
+    import pandas as pd
+
+    toy = pd.DataFrame({"var1": [1, 2, 3, 1, 2, 3, 1, 2, 3], "var2": [1, 1, 1, 2, 2, 2, 3, 3, 3], "statistic": [1, 2, 3, 4, 5, 6, 7, 8, 9]})
+    ft = ss.interp_nd_binning(toy, list_var_names=["var1", "var2"], statistic="statistic", min_count=None)
+    assert ft((2, 2)) == 5.0 and ft((1.5, 1.5)) == 3.0 and ft((-1, 1)) == 1.0
+
+
+def test_heteroscedasticity_large_vs_oracle():
+    """4e6-pixel grid, three explanatory variables (3-D binning + trilinear error function)."""
+    from xdem_amd import spatialstats as ss
+
+    rng = np.random.default_rng(8)
+    shape = (2000, 2000)
+    slope = rng.gamma(2.0, 8.0, shape).astype(np.float32)
+    maxc = np.abs(rng.normal(0, 1.5, shape)).astype(np.float32)
+    qual = rng.uniform(0, 100, shape).astype(np.float32)
+    dh = (rng.normal(0, 1, shape) * (0.5 + 0.05 * slope + 0.3 * maxc + 0.01 * qual)).astype(np.float32)
+    dh[::17, ::19] = np.nan
+    err, df, fun = ss.infer_heteroscedasticity_from_stable(dh, [slope, maxc, qual], list_var_bins=(6, 5, 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, ofun, scale = bo.estimate_model_heteroscedasticity(dh.ravel(), [slope.ravel(), maxc.ravel(), qual.ravel()], (6, 5, 4))
+        ref = (scale * ofun((slope, maxc, qual)))
+    got = df_to_cols_any(df, ["var1", "var2", "var3"])
+    flat = flatten_like_reference(res, 3)
+    assert np.array_equal(got["count"], flat["count"]) and np.array_equal(got["nmad"], flat["nmad"], equal_nan=True)
+    assert np.allclose(err, ref, rtol=1e-12, atol=0, equal_nan=True)
+    # heteroscedastic by construction: the error grows with slope
+    assert fun((40.0, 1.0, 50.0)) > fun((5.0, 1.0, 50.0))
+
+
+def df_to_cols_any(df, names):
+    return {c: df[c].values.astype(np.float64) for c in ("count", "nmad")}
+
+
+def test_nmad_device_matches_numpy():
+    from xdem_amd import spatialstats as ss
+
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64):
+        v = rng.standard_t(3, 1_000_001).astype(dt)
+        v[::1000] = np.nan
+        med, nm, cnt = ss.nmad_device(v)
+        assert cnt == np.isfinite(v).sum() and med == np.nanmedian(v) and nm == float(bo.nmad(v))
+        lim = 5.0
+        w = v.copy()
+        w[np.abs(w) > lim] = np.nan
+        med, nm, cnt = ss.nmad_device(v, abs_limit=lim)
+        assert cnt == np.isfinite(w).sum() and med == np.nanmedian(w) and nm == float(bo.nmad(w))

@@ -73,3 +73,21 @@ def test_oracle_equals_reference_nd_binning(name):
         ref = z[f"{name}|{key}"]
         assert arr.shape == ref.shape, (name, key)
         assert np.array_equal(np.asarray(arr, np.float64), np.asarray(ref, np.float64), equal_nan=True), (name, key)
+
+
+def test_oracle_heteroscedasticity_equals_reference():
+    """Error map of the reference's _estimate_model_heteroscedasticity + fun(full grid) (spatialstats.py:576-631, 866-868)."""
+    import warnings
+
+    z = np.load(os.path.join(GOLDEN, "binning_golden.npz"))
+    dh, slope, maxc, stable = z["het|dh"], z["het|slope"], z["het|maxc"], z["het|stable"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, fun, scale = bo.estimate_model_heteroscedasticity(dh[stable], [slope[stable], maxc[stable]], (8, 6), min_count=30)
+        err = scale * fun((slope, maxc))
+        probe = scale * fun((z["het|probe_x"], z["het|probe_y"]))
+    flat = flatten_like_reference(res, 2)
+    assert np.array_equal(flat["count"], z["het|df_count"]) and np.array_equal(flat["nmad"], z["het|df_nmad"], equal_nan=True)
+    assert np.array_equal(np.isnan(err), np.isnan(z["het|error"]))
+    assert np.allclose(err, z["het|error"], rtol=1e-13, atol=0, equal_nan=True)
+    assert np.allclose(probe, z["het|probe_out"], rtol=1e-13, atol=0, equal_nan=True)

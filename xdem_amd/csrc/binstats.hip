@@ -129,6 +129,79 @@ __global__ __launch_bounds__(256) void absdev_kernel(const T* __restrict__ v, co
     }
 }
 
+// ---- multilinear interpolation on a regular grid (scipy.interpolate.RegularGridInterpolator, method="linear",
+// bounds_error=False, fill_value=None: linear extrapolation from the edge intervals; NaN in any coordinate -> NaN) ----
+struct GridDims {
+    int nd;
+    int n[BS_MAXDIM], off[BS_MAXDIM], stride[BS_MAXDIM];
+    const void* var[BS_MAXDIM];
+    int var_f32[BS_MAXDIM];
+};
+
+__global__ __launch_bounds__(256) void interp_grid_kernel(GridDims G, const double* __restrict__ axes, int n_axes_total,
+                                                          const double* __restrict__ gv, int n_grid, int grid_in_lds, int64_t n,
+                                                          double scale, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ax = reinterpret_cast<double*>(smem);
+    double* vals = ax + n_axes_total;
+    for (int k = threadIdx.x; k < n_axes_total; k += blockDim.x) ax[k] = axes[k];
+    if (grid_in_lds)
+        for (int k = threadIdx.x; k < n_grid; k += blockDim.x) vals[k] = gv[k];
+    __syncthreads();
+    const double* V = grid_in_lds ? vals : gv;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        int base = 0;
+        double y[BS_MAXDIM];
+        bool isnan_any = false;
+#pragma unroll 1
+        for (int d = 0; d < G.nd; ++d) {
+            const double x = G.var_f32[d] ? (double)static_cast<const float*>(G.var[d])[p] : static_cast<const double*>(G.var[d])[p];
+            isnan_any |= (x != x);
+            const double* g = ax + G.off[d];
+            const int m = G.n[d];
+            // interval i with g[i] <= x < g[i+1], clipped to [0, m-2] (x == g[m-1] belongs to the last interval)
+            int lo = 0, hi = m - 1;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (g[mid] <= x) lo = mid; else hi = mid;
+            }
+            y[d] = (x - g[lo]) / (g[lo + 1] - g[lo]);
+            base += lo * G.stride[d];
+        }
+        // hypercube corners in itertools.product order (first dimension slowest), weights multiplied left to right
+        double value = 0.0;
+        const int corners = 1 << G.nd;
+        for (int c = 0; c < corners; ++c) {
+            double wgt = 1.0;
+            int idx = base;
+            for (int d = 0; d < G.nd; ++d) {
+                const int up = (c >> (G.nd - 1 - d)) & 1;
+                wgt = wgt * (up ? y[d] : (1.0 - y[d]));
+                idx += up * G.stride[d];
+            }
+            value = value + V[idx] * wgt;
+        }
+        out[p] = isnan_any ? (double)NAN : scale * value;
+    }
+}
+
+// |v| > limit -> NaN (two_step_standardization's outlier filter), else v; limit = +inf keeps everything
+template <typename T>
+__global__ __launch_bounds__(256) void clip_abs_kernel(const T* __restrict__ v, int64_t n, T limit, T* __restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const T x = v[p];
+        const T a = x < (T)0 ? -x : x;
+        out[p] = (a > limit) ? (T)NAN : x;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void absdev1_kernel(const T* __restrict__ v, int64_t n, T med, T* __restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const T d = t_sub(v[p], med);
+        out[p] = d < (T)0 ? -d : d;
+    }
+}
+
 }  // namespace xd
 
 using namespace xd;
@@ -345,6 +418,125 @@ int xdemhip_binstats_run(xdemhip_binstats* P, int n_dims, const int* var_ids, co
     }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_edges);
+    return rc;
+}
+
+}  // extern "C"
+
+template <typename T>
+static int nmad_typed(xdemhip_ctx* ctx, const void* values, int64_t n, double nfact, double abs_limit, int memspace, double* median,
+                      double* nmad_out, int64_t* count) {
+    typedef typename KeyT<T>::type K;
+    void *d_v = nullptr, *d_w = nullptr, *scratch = nullptr;
+    bool own = false;
+    auto cleanup = [&]() { if (own && d_v) (void)hipFree(d_v); if (d_w) (void)hipFree(d_w); if (scratch) (void)hipFree(scratch); };
+    int rc = upload(ctx, values, (size_t)n * sizeof(T), memspace, &d_v, &own);
+    if (rc == XDEMHIP_OK && (hipMalloc(&d_w, (size_t)n * sizeof(T)) != hipSuccess || hipMalloc(&scratch, scratch_size(1)) != hipSuccess))
+        rc = xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+    if (rc != XDEMHIP_OK) { cleanup(); return rc; }
+    const dim3 g(grid_for(ctx, n, 256, 16));
+    const T* src = static_cast<const T*>(d_v);
+    if (abs_limit == abs_limit && abs_limit < INFINITY) {
+        hipLaunchKernelGGL((clip_abs_kernel<T>), g, dim3(256), 0, ctx->stream, src, n, (T)abs_limit, static_cast<T*>(d_w));
+        // the filtered copy becomes the data; the deviations need a second buffer
+        void* d_f = d_w;
+        d_w = nullptr;
+        if (hipMalloc(&d_w, (size_t)n * sizeof(T)) != hipSuccess) { d_w = d_f; cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed"); }
+        if (own) (void)hipFree(d_v);
+        d_v = d_f; own = true;
+        src = static_cast<const T*>(d_v);
+    }
+    unsigned char* base = static_cast<unsigned char*>(scratch);
+    std::vector<SelResult<K>> r;
+    const xdemhip_allreduce_fn hook = ctx->allreduce;
+    ctx->allreduce = nullptr;
+    rc = run_select<T>(ctx, src, nullptr, n, 1, base, r);
+    if (rc == XDEMHIP_OK) {
+        *count = (int64_t)r[0].st.count;
+        const double med = median_from<T>(r[0]);
+        *median = med;
+        hipLaunchKernelGGL((absdev1_kernel<T>), g, dim3(256), 0, ctx->stream, src, n, (T)med, static_cast<T*>(d_w));
+        rc = run_select<T>(ctx, static_cast<const T*>(d_w), nullptr, n, 1, base, r);
+        if (rc == XDEMHIP_OK) *nmad_out = (double)(T)((T)nfact * (T)median_from<T>(r[0]));
+    }
+    ctx->allreduce = hook;
+    (void)hipStreamSynchronize(ctx->stream);
+    cleanup();
+    return rc;
+}
+
+extern "C" {
+
+int xdemhip_nmad(xdemhip_ctx* ctx, const void* values, int dtype, int64_t n, double nfact, double abs_limit, int memspace,
+                 double* median, double* nmad_out, int64_t* count) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (!values || n <= 0 || !median || !nmad_out || !count) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    if (memspace != XDEMHIP_HOST && memspace != XDEMHIP_DEVICE) return xd_fail(ctx, XDEMHIP_EINVAL, "bad memspace");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (dtype == XDEMHIP_F32) return nmad_typed<float>(ctx, values, n, nfact, abs_limit, memspace, median, nmad_out, count);
+    if (dtype == XDEMHIP_F64) return nmad_typed<double>(ctx, values, n, nfact, abs_limit, memspace, median, nmad_out, count);
+    return xd_fail(ctx, XDEMHIP_EINVAL, "dtype must be float32 or float64");
+}
+
+int xdemhip_interp_grid_linear(xdemhip_ctx* ctx, int n_dims, const double* axes, const int* n_axis, const double* grid_values,
+                               const void* const* vars, const int* var_dtypes, int64_t n, double scale, double* out, int memspace) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (n_dims < 1 || n_dims > BS_MAXDIM || !axes || !n_axis || !grid_values || !vars || !var_dtypes || !out || n <= 0)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    if (memspace != XDEMHIP_HOST && memspace != XDEMHIP_DEVICE) return xd_fail(ctx, XDEMHIP_EINVAL, "bad memspace");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    GridDims G;
+    memset(&G, 0, sizeof G);
+    G.nd = n_dims;
+    int tot = 0;
+    int64_t ngrid = 1;
+    for (int d = 0; d < n_dims; ++d) {
+        if (n_axis[d] < 2) return xd_fail(ctx, XDEMHIP_EINVAL, "every grid axis needs at least 2 points");
+        if (var_dtypes[d] != XDEMHIP_F32 && var_dtypes[d] != XDEMHIP_F64) return xd_fail(ctx, XDEMHIP_EINVAL, "bad variable dtype");
+        G.n[d] = n_axis[d]; G.off[d] = tot; tot += n_axis[d];
+        ngrid *= n_axis[d];
+        if (ngrid > (1 << 24)) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "interpolation grid too large");
+    }
+    for (int d = n_dims - 1, st = 1; d >= 0; --d) { G.stride[d] = st; st *= n_axis[d]; }
+    std::vector<void*> owned;
+    double *d_axes = nullptr, *d_grid = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : owned) (void)hipFree(p);
+        if (d_axes) (void)hipFree(d_axes);
+        if (d_grid) (void)hipFree(d_grid);
+        if (memspace == XDEMHIP_HOST && d_out) (void)hipFree(d_out);
+    };
+    int rc = XDEMHIP_OK;
+    for (int d = 0; d < n_dims && rc == XDEMHIP_OK; ++d) {
+        void* p = nullptr;
+        bool own = false;
+        rc = upload(ctx, vars[d], (size_t)n * (var_dtypes[d] == XDEMHIP_F32 ? 4 : 8), memspace, &p, &own);
+        if (own) owned.push_back(p);
+        G.var[d] = p; G.var_f32[d] = var_dtypes[d] == XDEMHIP_F32;
+    }
+    if (rc == XDEMHIP_OK && (hipMalloc(reinterpret_cast<void**>(&d_axes), (size_t)tot * 8) != hipSuccess ||
+                             hipMalloc(reinterpret_cast<void**>(&d_grid), (size_t)ngrid * 8) != hipSuccess))
+        rc = xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+    if (rc == XDEMHIP_OK) {
+        if (memspace == XDEMHIP_DEVICE) d_out = out;
+        else if (hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 8) != hipSuccess) rc = xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+    }
+    if (rc != XDEMHIP_OK) { cleanup(); return rc; }
+    hipError_t e = hipMemcpyAsync(d_axes, axes, (size_t)tot * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_grid, grid_values, (size_t)ngrid * 8, hipMemcpyHostToDevice, ctx->stream);
+    const int in_lds = ((size_t)(tot + ngrid) * 8 <= 40 * 1024);
+    const size_t lds = (size_t)(tot + (in_lds ? ngrid : 0)) * 8;
+    if (e == hipSuccess && lds > 48 * 1024) rc = xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many grid axis points");
+    if (e == hipSuccess && rc == XDEMHIP_OK) {
+        hipLaunchKernelGGL(interp_grid_kernel, dim3(grid_for(ctx, n, 256, 16)), dim3(256), lds, ctx->stream, G, d_axes, tot, d_grid,
+                           (int)ngrid, in_lds, n, scale, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && rc == XDEMHIP_OK && memspace == XDEMHIP_HOST)
+        e = hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess && rc == XDEMHIP_OK) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("grid interpolation failed: ") + hipGetErrorString(e));
+    cleanup();
     return rc;
 }
 

@@ -566,3 +566,199 @@ def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=
     finally:
         plan.close()
     return pd.concat(list_df_1d + list_df_2d + [df_nd])
+
+
+# ---- heteroscedasticity inference on top of nd_binning (xdem/spatialstats.py:237-421, 530-631, 808-878) ---------------
+class GridInterpolant:
+    """Multilinear interpolant on a regular N-D grid, evaluated on the GPU (``xdemhip_interp_grid_linear``).
+
+    Call signature of the object ``interp_nd_binning`` returns upstream (a ``scipy.interpolate.RegularGridInterpolator``
+    with ``method="linear", bounds_error=False, fill_value=None``): ``fun((x1, x2, ...))`` with arrays of one common
+    shape (or scalars) -> float64 array of that shape; NaN coordinates give NaN, outside points extrapolate linearly.
+    ``scale`` multiplies the result (the re-scaling factor of the two-step standardization)."""
+
+    def __init__(self, axes: list[np.ndarray], values: np.ndarray, scale: float = 1.0, ctx: _lib.Context | None = None):
+        self.grid = tuple(np.ascontiguousarray(a, dtype=np.float64) for a in axes)
+        self.values = np.ascontiguousarray(values, dtype=np.float64)
+        if self.values.shape != tuple(len(a) for a in self.grid):
+            raise ValueError("grid values do not match the axes")
+        self.scale = float(scale)
+        self.ctx = ctx
+
+    def scaled(self, factor: float) -> "GridInterpolant":
+        return GridInterpolant(list(self.grid), self.values, self.scale * float(factor), self.ctx)
+
+    def __call__(self, xi) -> np.ndarray:
+        if isinstance(xi, np.ndarray) and xi.ndim >= 1 and xi.shape[-1] == len(self.grid) and not isinstance(xi, tuple):
+            xi = tuple(xi[..., d] for d in range(len(self.grid)))
+        if len(xi) != len(self.grid):
+            raise ValueError(f"The requested sample points xi have dimension {len(xi)} but this interpolant has dimension {len(self.grid)}")
+        arrs = np.broadcast_arrays(*[np.asarray(x) for x in xi])
+        shape = arrs[0].shape
+        cols = []
+        for a in arrs:
+            a = np.ascontiguousarray(a).ravel()
+            if a.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+                a = a.astype(np.float64)
+            cols.append(a)
+        n = cols[0].size
+        out = np.empty(n, dtype=np.float64)
+        if n == 0:
+            return out.reshape(shape)
+        ctx = self.ctx or _lib.default_context()
+        nd = len(cols)
+        ptrs = (ctypes.c_void_p * nd)(*[c.ctypes.data for c in cols])
+        dts = (ctypes.c_int * nd)(*[_lib.F32 if c.dtype == np.float32 else _lib.F64 for c in cols])
+        na = (ctypes.c_int * nd)(*[len(a) for a in self.grid])
+        axes = np.concatenate(self.grid)
+        dp = ctypes.POINTER(ctypes.c_double)
+        ctx.check(ctx._L.xdemhip_interp_grid_linear(ctx.handle, nd, axes.ctypes.data_as(dp), na, self.values.ctypes.data_as(dp), ptrs,
+                                                    dts, n, self.scale, out.ctypes.data_as(dp), _lib.HOST))
+        return out.reshape(shape)
+
+
+def nmad_device(values: np.ndarray, nfact: float = 1.4826, abs_limit: float = np.inf, ctx: _lib.Context | None = None):
+    """(nanmedian, nmad, count) of an array on the GPU by exact selection; ``|v| > abs_limit`` is dropped first."""
+    v = np.ascontiguousarray(np.asarray(values).ravel())
+    if v.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        v = v.astype(np.float64)
+    ctx = ctx or _lib.default_context()
+    med, nm, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    ctx.check(ctx._L.xdemhip_nmad(ctx.handle, v.ctypes.data, _lib.F32 if v.dtype == np.float32 else _lib.F64, v.size, float(nfact),
+                                  float(abs_limit), _lib.HOST, ctypes.byref(med), ctypes.byref(nm), ctypes.byref(cnt)))
+    return med.value, nm.value, int(cnt.value)
+
+
+def interp_nd_binning(df, list_var_names, statistic="nmad", interpolate_method: str = "linear", min_count: int | None = 100,
+                      ctx: _lib.Context | None = None) -> GridInterpolant:
+    """Interpolant of a binned statistic over its explanatory variables (mirror of xdem/spatialstats.py:237-421).
+
+    Same three stages as upstream on the (small) table of bins, done with the same SciPy routines on the host: (1)
+    ``griddata`` of the valid bins onto the full grid of bin centres, (2) nearest-neighbour filling of what lies outside
+    the convex hull, on the grid and on the grid extended by one node per side, (3) a linear regular-grid interpolant
+    over the extended grid, so that extrapolation behaves as nearest neighbour.  Stage 3's evaluation is the dense
+    operation: it runs on the GPU (``GridInterpolant``)."""
+    import pandas as pd
+    from scipy.interpolate import griddata
+
+    if isinstance(list_var_names, str):
+        list_var_names = [list_var_names]
+    for var in list_var_names:
+        if var not in df.columns:
+            raise ValueError('Variable "' + var + '" does not exist in the provided dataframe.')
+    statistic_name = statistic if isinstance(statistic, str) else statistic.__name__
+    if statistic_name not in df.columns:
+        raise ValueError('Statistic "' + statistic_name + '" does not exist in the provided dataframe.')
+    if min_count is not None and "count" not in df.columns:
+        raise ValueError('Statistic "count" is not in the provided dataframe, necessary to use the min_count argument.')
+    if df.empty:
+        raise ValueError("Dataframe is empty.")
+    sub = df.copy()
+    if "nd" in sub.columns:
+        sub = sub[sub.nd == len(list_var_names)]
+    for var in list_var_names:
+        col = sub[var].values
+        if all(isinstance(x, (int, float, np.integer, np.floating)) for x in col):
+            continue
+        if any(isinstance(x, pd.Interval) for x in col):
+            sub[var] = pd.IntervalIndex(sub[var]).mid.values
+        else:
+            raise ValueError("The variable columns must be provided as numerical mid values, or pd.Interval values.")
+    sub = sub[np.logical_and.reduce([np.isfinite(sub[var].values) for var in list_var_names])]
+    if sub.empty:
+        raise ValueError("Dataframe does not contain a nd binning with the variables corresponding to the list of variables.")
+    if all(~np.isfinite(sub[statistic_name].values)):
+        raise ValueError("Dataframe does not contain any valid statistic values.")
+    if min_count is not None:
+        sub.loc[sub["count"] < min_count, statistic_name] = np.nan
+    stat = sub[statistic_name].values
+    good = np.isfinite(stat)
+    if all(~good):
+        raise ValueError("Dataframe does not contain any valid statistic values after filtering with min_count = "
+                         + str(min_count) + ".")
+    centres = [sorted(np.unique(sub[var][good])) for var in list_var_names]
+    shape = [len(c) for c in centres]
+    # (1) inside the convex hull of the valid bins
+    pts_good = tuple(sub[var].values[good] for var in list_var_names)
+    mesh = np.meshgrid(*centres, indexing="ij")
+    pts_grid = tuple(m.flatten() for m in mesh)
+    on_grid = griddata(pts_good, stat[good], pts_grid, method=interpolate_method)
+    # (2) nearest neighbour outside it, first on the grid itself, then on the grid grown by one node per side
+    filled = np.isfinite(on_grid)
+    on_grid = griddata(tuple(p[filled] for p in pts_grid), on_grid[filled], pts_grid, method="nearest")
+    grown = [np.append(np.insert(c, 0, c[0] - 1), c[-1] + 1) for c in centres]
+    mesh_g = np.meshgrid(*grown, indexing="ij")
+    on_grown = griddata(pts_grid, on_grid, tuple(m.flatten() for m in mesh_g), method="nearest").reshape(tuple(s + 2 for s in shape))
+    # (3)
+    return GridInterpolant(grown, on_grown, 1.0, ctx)
+
+
+def two_step_standardization(dvalues, list_var, unscaled_error_fun, spread_statistic=nmad, fac_spread_outliers: float | None = 7,
+                             ctx: _lib.Context | None = None):
+    """Standardize ``dvalues`` by the modelled spread, filter outliers, re-scale to unit spread
+    (mirror of xdem/spatialstats.py:530-573).  Returns (z-scores, final error function).  The spread statistic must be
+    ``nmad`` (evaluated by exact selection on the GPU)."""
+    name = spread_statistic if isinstance(spread_statistic, str) else spread_statistic.__name__
+    if name != "nmad":
+        raise NotImplementedError("two_step_standardization on the HIP engine supports spread_statistic=nmad only.")
+    with np.errstate(all="ignore"):
+        zscores = np.asarray(dvalues) / unscaled_error_fun(tuple(list_var))
+    limit = np.inf
+    if fac_spread_outliers is not None:
+        limit = fac_spread_outliers * nmad_device(zscores, ctx=ctx)[1]
+        zscores[np.abs(zscores) > limit] = np.nan
+    zscore_nmad = nmad_device(zscores, ctx=ctx)[1]
+    zscores /= zscore_nmad
+    if isinstance(unscaled_error_fun, GridInterpolant):
+        error_fun = unscaled_error_fun.scaled(zscore_nmad)
+    else:
+        def error_fun(*args):
+            return zscore_nmad * unscaled_error_fun(*args)
+    return zscores, error_fun
+
+
+def _estimate_model_heteroscedasticity(dvalues, list_var, list_var_names, spread_statistic=nmad, list_var_bins=None,
+                                       min_count: int | None = 100, fac_spread_outliers: float | None = 7,
+                                       ctx: _lib.Context | None = None):
+    """N-D binning of the spread -> interpolant -> two-step standardization (mirror of xdem/spatialstats.py:576-631)."""
+    df = nd_binning(values=dvalues, list_var=list_var, list_var_names=list_var_names, statistics=[spread_statistic],
+                    list_var_bins=list_var_bins, ctx=ctx)
+    fun = interp_nd_binning(df, list_var_names=list_var_names, statistic=spread_statistic.__name__, min_count=min_count, ctx=ctx)
+    final_fun = two_step_standardization(np.asarray(dvalues).ravel(), [np.asarray(v).ravel() for v in list_var], fun,
+                                         spread_statistic, fac_spread_outliers, ctx)[1]
+    return df, final_fun
+
+
+def infer_heteroscedasticity_from_stable(dvalues, list_var, stable_mask=None, unstable_mask=None, list_var_names=None,
+                                         spread_statistic=nmad, list_var_bins=None, min_count: int | None = 100,
+                                         fac_spread_outliers: float | None = 7, ctx: _lib.Context | None = None):
+    """Error map, binned-spread DataFrame and error function from differences on stable terrain
+    (mirror of xdem/spatialstats.py:808-878 for array inputs and boolean-array masks; Raster-likes are read through
+    ``.data`` and the error map is returned as ``dvalues.copy(new_array=...)`` when that method exists)."""
+    def arr_of(v):
+        if isinstance(v, np.ndarray):
+            return np.ma.filled(v, np.nan) if isinstance(v, np.ma.MaskedArray) else v
+        data = getattr(v, "data", None)
+        if data is None:
+            raise ValueError("The values must be a Raster or NumPy array, or a list of those.")
+        return np.ma.filled(data.astype(np.float32) if not np.issubdtype(data.dtype, np.floating) else data, np.nan)
+
+    if list_var_names is None:
+        list_var_names = ["var" + str(i + 1) for i in range(len(list_var))]
+    arrs = [arr_of(dvalues)] + [arr_of(v) for v in list_var]
+    for m in (stable_mask, unstable_mask):
+        if m is not None and not isinstance(m, np.ndarray):
+            raise ValueError("xdem_amd takes stable / unstable masks as boolean arrays (vector rasterisation is outside the hot path).")
+    include = np.ones(np.shape(arrs[0]), dtype=bool) if stable_mask is None else np.asarray(stable_mask, dtype=bool)
+    exclude = np.zeros(np.shape(arrs[0]), dtype=bool) if unstable_mask is None else np.asarray(unstable_mask, dtype=bool)
+    include = np.logical_and(include, ~exclude).squeeze()
+    stable = [a[include] for a in arrs]
+    df, fun = _estimate_model_heteroscedasticity(stable[0], stable[1:], list_var_names, spread_statistic, list_var_bins, min_count,
+                                                 fac_spread_outliers, ctx)
+    error = fun(tuple(arrs[1:]))
+    if not isinstance(dvalues, np.ndarray) and hasattr(dvalues, "copy"):
+        try:
+            return dvalues.copy(new_array=error), df, fun
+        except TypeError:
+            pass
+    return error, df, fun
