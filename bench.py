@@ -32,7 +32,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (about 6.3
 BYTES_PER_PIXEL = 4 + 4 * len(FULL)  # 4 B read + 4 B per attribute written = 48 B
 
 
-def cpu_baseline(n: int = 2048) -> dict:
+def cpu_baseline(n: int = 6144) -> dict:
     """Reference-recipe CPU port (oracle/terrain_oracle.py, single thread NumPy) on a bounded n x n sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import terrain_oracle
@@ -64,22 +64,29 @@ def measured_traffic_bytes(pixels_per_launch: int):
     return best
 
 
-def secondary_metrics(ctx) -> dict:
-    """Small fixed-size runs of the other two hot paths (reported next to the headline metric, not part of `value`)."""
+def secondary_metrics(ctx, dev) -> dict:
+    """The other two hot paths at BASELINE.json's configurations (reported next to the headline metric, not part of
+    `value`): C5 reading B of SURVEY.md 8d for the variogram, C3 for Nuth-Kaab."""
     import numpy as np
+    import torch
 
     from xdem_amd import coreg
     from xdem_amd import spatialstats as ss
-    from xdem_amd.synth import fbm_numpy
+    from xdem_amd.synth import fbm_torch
 
     out = {}
-    # variogram: 65536-point sample x 8192-point sample (5.4e8 pairs), 50 geometric lag classes, float32 values
+    # variogram C5-B: 1e7 sampled points = 100 runs x (9091 centre + 90910 ring points), 8.3e10 pairs, 50 lag classes
     rng = np.random.default_rng(45)
-    n = 65536
-    x, y = rng.uniform(0, 20000, n), rng.uniform(0, 20000, n)
-    v = (np.sin(x / 900) + 0.2 * rng.normal(size=n)).astype(np.float32)
-    edges = np.geomspace(np.sqrt(2), np.hypot(20000, 20000), 50)
-    ps = ss.PairSet([(x[: n // 8], y[: n // 8], v[: n // 8], x, y, v)], edges, ctx)
+    runs, samples, rings, L = 100, 9091, 10, 20000.0
+    blocks = []
+    for _ in range(runs):
+        ax, ay = rng.uniform(0, L, samples), rng.uniform(0, L, samples)
+        bx, by = rng.uniform(0, L, samples * rings), rng.uniform(0, L, samples * rings)
+        av = (np.sin(ax / 900.0) + 0.2 * rng.normal(size=samples)).astype(np.float32)
+        bv = (np.sin(bx / 900.0) + 0.2 * rng.normal(size=samples * rings)).astype(np.float32)
+        blocks.append((ax, ay, av, bx, by, bv))
+    edges = np.geomspace(np.sqrt(2), np.hypot(L, L), 50)
+    ps = ss.PairSet(blocks, edges, ctx)
     ps.sums(0)
     ps.sums(0)
     ms = ctx.last_kernel_ms()
@@ -88,21 +95,30 @@ def secondary_metrics(ctx) -> dict:
     dt = time.perf_counter() - t0
     out["variogram"] = {"pairs": ps.n_pairs, "lag_classes": 50, "matheron_pass_Gpairs_s": round(ps.n_pairs / ms / 1e6, 1),
                         "dowd_exact_median_Gpairs_s": round(ps.n_pairs / dt / 1e9, 2),
-                        "note": "cdist 8192 x 65536 points, f32 values; Dowd = 4 histogram passes + successor pass"}
+                        "note": "C5 (reading B): 100 blocks of 9091 x 90910 points, f32 values; Matheron = one pair pass; "
+                                "Dowd = exact per-class median of |dv| (4 histogram passes + successor pass, wall time)"}
     ps.close()
-    # Nuth-Kaab: 4096^2 pair, 20 % NaN, one iteration step (all grid passes of an iteration, exact medians)
-    m = 4096
-    ref = fbm_numpy((m, m), seed=42)
-    tba = (np.roll(ref, (1, -2), (0, 1)) + 2.0).astype(np.float32)
-    hole = fbm_numpy((m, m), seed=44, hurst=1.0, mean=0.0, std=1.0)
-    tba[hole < np.percentile(hole, 20)] = np.nan
-    plan = coreg.NKPlan(ref, tba, None, ctx)
+    del blocks
+    # Nuth-Kaab C3: 20000^2 pair, tba = ref shifted + 2 m, 20 % NaN in contiguous gaps; iteration steps on the full grid
+    m = 20000
+    ref = fbm_torch(m, m, dev, seed=42)
+    tba = torch.roll(ref, shifts=(1, -2), dims=(0, 1)) + 2.0
+    hole = fbm_torch(m, m, dev, seed=44)
+    thr = torch.quantile(hole[::16, ::16].flatten(), 0.2)
+    tba[hole < thr] = float("nan")
+    del hole
+    torch.cuda.synchronize(dev)
+    plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
     plan.step(0.0, 0.0, (10.0, 10.0), 72)
     t0 = time.perf_counter()
-    plan.step(3.0, -4.0, (10.0, 10.0), 72)
-    dt = time.perf_counter() - t0
-    out["nuthkaab"] = {"grid": f"{m}x{m}", "Mpixel_iterations_s": round(m * m / dt / 1e6, 1),
-                       "note": "one iteration step: shifted dh, exact nanmedian, 72-bin exact medians (float32)"}
+    k = 3
+    for i in range(k):
+        r = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
+    dt = (time.perf_counter() - t0) / k
+    out["nuthkaab"] = {"grid": f"{m}x{m}", "valid_fraction": round(r["n_valid"] / (m * m), 3),
+                       "Mpixel_iterations_s": round(m * m / dt / 1e6, 1), "ms_per_iteration": round(dt * 1e3, 2),
+                       "note": "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32), "
+                               "host 72-point fit excluded"}
     plan.close()
     return out
 
@@ -206,11 +222,13 @@ def main() -> None:
                          "kernel": "terrain_tile_kernel<Florinsky,curv,win,f32,f32>",
                          "kernel_ms": round(kernel_ms, 4), "pixels_per_launch": px_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
-        if not args.no_secondary:
+        if not args.no_secondary and world == 1:
             try:
-                res["secondary"] = secondary_metrics(ctx)
+                del out, block
+                torch.cuda.empty_cache()
+                res["secondary"] = secondary_metrics(ctx, dev)
             except Exception as e:  # the headline line must still be printed
                 res["secondary"] = {"error": repr(e)}
         print(json.dumps(res))

@@ -35,25 +35,45 @@ class NKPlan:
                  group=None):
         """``group``: a torch.distributed process group (or "world") to shard the grid passes over its ranks by row
         block -- every rank passes the same full rasters; histograms / counts are all-reduced (exact)."""
-        ref = np.ascontiguousarray(ref)
-        tba = np.ascontiguousarray(tba)
-        if ref.shape != tba.shape or ref.ndim != 2:
-            raise ValueError("ref and tba must be 2D arrays of the same shape")
-        if ref.dtype != tba.dtype or ref.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
-            dt = np.float64 if np.float64 in (ref.dtype, tba.dtype) else np.float32
-            ref, tba = ref.astype(dt), tba.astype(dt)
-        self.dtype = ref.dtype
-        self.shape = ref.shape
         self.ctx = ctx or _lib.default_context()
-        inl = None
-        if inlier_mask is not None:
-            inl = np.ascontiguousarray(inlier_mask, dtype=np.uint8)
         h = ctypes.c_void_p()
         nv = ctypes.c_int64()
-        self.ctx.check(self.ctx._L.xdemhip_nk_create(
-            self.ctx.handle, ref.ctypes.data, tba.ctypes.data, inl.ctypes.data if inl is not None else None,
-            _lib.F32 if self.dtype == np.float32 else _lib.F64, ref.shape[0], ref.shape[1], _lib.HOST, ctypes.byref(h),
-            ctypes.byref(nv)))
+        if hasattr(ref, "is_cuda"):
+            # device-resident rasters (torch CUDA/HIP tensors, same dtype, contiguous): no host copies; the caller keeps them alive
+            if not (ref.is_cuda and tba.is_cuda and ref.is_contiguous() and tba.is_contiguous() and ref.dtype == tba.dtype
+                    and ref.shape == tba.shape and ref.dim() == 2):
+                raise ValueError("device inputs must be contiguous 2D CUDA tensors of the same shape and dtype")
+            import torch
+
+            self.dtype = np.dtype({torch.float32: np.float32, torch.float64: np.float64}[ref.dtype])
+            self.shape = tuple(ref.shape)
+            self._keep = (ref, tba, inlier_mask)
+            inl_ptr = None
+            if inlier_mask is not None:
+                if not (inlier_mask.is_cuda and inlier_mask.dtype == torch.uint8 and inlier_mask.is_contiguous()):
+                    raise ValueError("device inlier mask must be a contiguous uint8 CUDA tensor")
+                inl_ptr = inlier_mask.data_ptr()
+            torch.cuda.current_stream(ref.device).synchronize()
+            self.ctx.check(self.ctx._L.xdemhip_nk_create(
+                self.ctx.handle, ref.data_ptr(), tba.data_ptr(), inl_ptr, _lib.F32 if self.dtype == np.float32 else _lib.F64,
+                self.shape[0], self.shape[1], _lib.DEVICE, ctypes.byref(h), ctypes.byref(nv)))
+        else:
+            ref = np.ascontiguousarray(ref)
+            tba = np.ascontiguousarray(tba)
+            if ref.shape != tba.shape or ref.ndim != 2:
+                raise ValueError("ref and tba must be 2D arrays of the same shape")
+            if ref.dtype != tba.dtype or ref.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+                dt = np.float64 if np.float64 in (ref.dtype, tba.dtype) else np.float32
+                ref, tba = ref.astype(dt), tba.astype(dt)
+            self.dtype = ref.dtype
+            self.shape = ref.shape
+            inl = None
+            if inlier_mask is not None:
+                inl = np.ascontiguousarray(inlier_mask, dtype=np.uint8)
+            self.ctx.check(self.ctx._L.xdemhip_nk_create(
+                self.ctx.handle, ref.ctypes.data, tba.ctypes.data, inl.ctypes.data if inl is not None else None,
+                _lib.F32 if self.dtype == np.float32 else _lib.F64, ref.shape[0], ref.shape[1], _lib.HOST, ctypes.byref(h),
+                ctypes.byref(nv)))
         self.handle = h
         self.n_valid = int(nv.value)
         self.group = group
@@ -63,7 +83,7 @@ class NKPlan:
             from .dist import row_block
 
             pg = None if group == "world" else group
-            r0, r1 = row_block(ref.shape[0], dist.get_world_size(pg), dist.get_rank(pg))
+            r0, r1 = row_block(self.shape[0], dist.get_world_size(pg), dist.get_rank(pg))
             self.ctx.set_allreduce(group)
             self.ctx.check(self.ctx._L.xdemhip_nk_set_rows(self.handle, r0, r1, ctypes.byref(nv)))
             self.n_valid = int(nv.value)
