@@ -112,6 +112,14 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
  * divisors (<= max_q), or a negative status. */
 int xdemhip_fractal_constants(int window_size, int max_q, int* q, double* log_q, double* mean_log_q, double* ss_xx);
 
+/* Texture shading, the frequency-domain attribute of get_terrain_attribute: replaces
+ *   _texture_shading_fft(dem, alpha)   xdem/terrain/freq.py:63-148   (called at xdem/terrain/terrain.py:637-644)
+ * non-finite pixels are filled with the NaN-ignoring mean, the raster is padded symmetrically to the next 2/3/5/7-smooth
+ * size, multiplied by |f|^alpha in the frequency domain (DC zeroed when alpha > 0) and cropped; invalid pixels -> NaN.
+ * 0 <= alpha <= 2.  The FFT itself is hipFFT's (loaded on first use), in the DEM's precision like scipy.fft. */
+int xdemhip_texture_shading(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H, int64_t W, double alpha, int out_dtype,
+                            void* out, int memspace);
+
 /* ---- path 2: Nuth & Kaab (2011) inner loop ------------------------------------------------------------
  * Replaces the array work of  nuth_kaab(ref_elev, tba_elev, inlier_mask, transform, ...)   xdem/coreg/affine.py:539-609
  * for two rasters on the same grid, i.e. what NuthKaab._fit_rst_rst reaches (affine.py:2458-2522):

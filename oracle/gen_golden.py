@@ -207,6 +207,32 @@ def terrain_T9() -> None:
     np.savez_compressed(os.path.join(OUT, "terrain_T9_rugosity_fractal.npz"), **rec)
 
 
+def terrain_T10() -> None:
+    """Texture shading (freq.py:63-148), SURVEY 8f-4: reference outputs for float32 / float64 DEMs with holes, several alpha,
+    FFT lengths below and above 1024 (power-of-two and 7-smooth padding), plus the data-free cases of test_freq.py."""
+    rng = np.random.default_rng(19)
+    rec = {}
+    base = 800.0 + np.cumsum(np.cumsum(rng.normal(scale=0.3, size=(70, 90)), axis=0), axis=1)
+    for dt in (np.float32, np.float64):
+        dem = base.astype(dt)
+        dem[10:13, 20] = np.nan
+        dem[50, 60] = np.nan
+        n = np.dtype(dt).name
+        rec[f"dem|{n}"] = dem
+        for alpha in (0.0, 0.5, 0.8, 1.5, 2.0):
+            rec[f"{n}|{alpha}"] = run_ref(dem, ["texture_shading"], texture_alpha=alpha)[0]
+    wide = (100.0 + np.cumsum(rng.normal(scale=0.5, size=(9, 1030)), axis=1)).astype(np.float32)  # FFT lengths 16 x 1050
+    rec["dem|wide"] = wide
+    rec["wide|0.8"] = run_ref(wide, ["texture_shading"])[0]
+    flat = np.full((16, 16), 5.0, dtype=np.float32)
+    rec["dem|flat"] = flat
+    rec["flat|0.8"] = run_ref(flat, ["texture_shading"])[0]
+    allnan = np.full((8, 8), np.nan, dtype=np.float32)
+    rec["dem|allnan"] = allnan
+    rec["allnan|0.8"] = run_ref(allnan, ["texture_shading"])[0]
+    np.savez_compressed(os.path.join(OUT, "terrain_T10_texture.npz"), **rec)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["terrain", "nk", "vario", "binning"]
@@ -217,6 +243,7 @@ if __name__ == "__main__":
         terrain_T3()
         terrain_T4_T5()
         terrain_T9()
+        terrain_T10()
         print("terrain fixtures written")
     if "nk" in which:
         import gen_golden_nk

@@ -370,6 +370,50 @@ def windowed_indexes(
     return out
 
 
+def _next_fft_len(n: int) -> int:
+    """freq.py:32-60: power of two up to 1024, otherwise the next integer whose only prime factors are 2, 3, 5, 7."""
+    if n <= 1:
+        return 1
+    if n <= 1024:
+        return int(2 ** np.ceil(np.log2(n)))
+    c = n
+    while True:
+        t = c
+        for f in (2, 3, 5, 7):
+            while t % f == 0:
+                t //= f
+        if t == 1:
+            return c
+        c += 1
+
+
+def texture_shading(dem: np.ndarray, alpha: float = 0.8) -> np.ndarray:
+    """Oracle of ``_texture_shading_fft`` (xdem/terrain/freq.py:63-148): mean-filled, symmetrically padded DEM times
+    ``hypot(fx, fy)**alpha`` in the frequency domain (scipy.fft keeps the DEM's precision), cropped, NaN restored."""
+    import scipy.fft as sfft
+
+    valid = np.isfinite(dem)
+    if not valid.any():
+        return np.full_like(dem, np.nan)
+    work = dem.copy()
+    if not valid.all():
+        work[~valid] = np.nanmean(dem)
+    H, W = work.shape
+    FH, FW = _next_fft_len(H), _next_fft_len(W)
+    pr, pc = (FH - H) // 2, (FW - W) // 2
+    work = np.pad(work, ((pr, FH - H - pr), (pc, FW - W - pc)), mode="symmetric")
+    mag = np.hypot(sfft.rfftfreq(FW)[None, :], sfft.fftfreq(FH)[:, None])
+    mag[0, 0] = 1.0
+    filt = mag**alpha
+    if alpha > 0:
+        filt[0, 0] = 0.0
+    spec = sfft.rfft2(work, s=(FH, FW))
+    spec *= filt
+    out = sfft.irfft2(spec, s=(FH, FW))[pr : pr + H, pc : pc + W]
+    out[~valid] = np.nan
+    return out
+
+
 def terrain_attributes(
     dem: np.ndarray,
     attribute: list[str],
@@ -384,6 +428,7 @@ def terrain_attributes(
     window_size: int = 3,
     out_dtype=None,
     window_size_fractal: int = 13,
+    texture_alpha: float = 0.8,
 ) -> list[np.ndarray]:
     """Oracle of ``_get_terrain_attribute`` for ndarray input (terrain.py:528-666): engines + unit/clip post-steps."""
     dem = np.asarray(dem)
@@ -413,4 +458,7 @@ def terrain_attributes(
         wi = windowed_indexes(dem, window_size_fractal, frac, out_dtype, tri_method, resolution)
         for i, name in enumerate(frac):
             results[name] = wi[i]
+    if "texture_shading" in attribute:
+        with np.errstate(all="ignore"):
+            results["texture_shading"] = texture_shading(dem, texture_alpha).astype(out_dtype)
     return [results[a] for a in attribute]

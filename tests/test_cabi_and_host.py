@@ -94,8 +94,9 @@ def test_terrain_argument_validation_messages():
         t.hillshade(dem, resolution=1.0, z_factor=np.inf)
     with pytest.raises(ValueError, match="only provides engine='hip'"):
         t.slope(dem, resolution=1.0, engine="scipy")
-    with pytest.raises(NotImplementedError, match="not on the MI355X hot path"):
-        t.get_terrain_attribute(dem, "texture_shading", resolution=1.0)
+    for bad in (-0.1, 2.1):  # tests/test_terrain/test_freq.py:47-51 (checked before any GPU work would matter)
+        with pytest.raises(ValueError, match="Alpha must be between 0 and 2"):
+            t.texture_shading(dem, alpha=bad)
     with pytest.raises(ValueError, match=re.escape("'resolution' must be provided as an argument for attributes: ['rugosity']")):
         t.rugosity(dem)
     with pytest.warns(UserWarning, match="window sizes larger or equal to 5"):

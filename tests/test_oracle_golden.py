@@ -116,6 +116,26 @@ def test_T9_rugosity_fractal_roughness():
         assert np.round(z[f"{name}|fractal_roughness|13"][6, 6], 3) == d
 
 
+def test_T10_texture_shading():
+    """f4 of SURVEY 8f: the oracle runs the same scipy.fft transforms as the reference -> bit-exact on this SciPy build
+    (a different pocketfft build may differ in the last bits: 1e-5 of the output scale allowed)."""
+    z = _load("terrain_T10_texture.npz")
+    n = 0
+    for key in z.files:
+        if key.startswith("dem|"):
+            continue
+        name, alpha = key.split("|")
+        got = to.terrain_attributes(z[f"dem|{name}"], ["texture_shading"], texture_alpha=float(alpha))[0]
+        ref = z[key]
+        assert got.dtype == ref.dtype and np.array_equal(np.isnan(got), np.isnan(ref)), key
+        ok = np.isfinite(ref)
+        if ok.any():
+            assert np.abs(got[ok] - ref[ok]).max() <= 1e-5 * max(np.abs(ref[ok]).max(), 1e-30), key
+        n += 1
+    assert n == 13
+    assert np.all(z["flat|0.8"] == 0) and np.isnan(z["allnan|0.8"]).all()  # tests/test_terrain/test_freq.py:53-57
+
+
 def test_oracle_convolution_equals_scipy():
     """The restated convolution must reproduce scipy.ndimage.convolve (the reference's engine call) bit for bit."""
     scipy_ndimage = pytest.importorskip("scipy.ndimage")

@@ -304,3 +304,59 @@ def test_rugosity_fractal_device_row_blocks():
     bot = terrain_attributes_device(dem[94:], attrs, resolution=2.0, halo_top=6)
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([top, bot], dim=1).view(torch.int32), full.view(torch.int32))
+
+
+# ---- texture shading (csrc/texture.hip: hipFFT + pad / filter / crop kernels) ----------------------------------
+def _tex_err(got, ref):
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and got.dtype == ref.dtype
+    if not ok.any():
+        return 0.0
+    return float(np.abs(got[ok].astype(np.float64) - ref[ok]).max() / max(np.abs(ref[ok]).max(), 1e-30))
+
+
+def test_T10_texture_shading_vs_reference():
+    """Reference outputs (tests/golden/terrain_T10_texture.npz).  Two different FFT libraries in the DEM's own precision:
+    float32 transforms carry the rounding noise of the ~1e3 m input, i.e. ~1e-6 of the output scale (the reference's own
+    result has that noise): tolerance 1e-5 of the output maximum for float32, 1e-12 for float64."""
+    from xdem_amd import terrain as t
+
+    z = np.load(os.path.join(GOLDEN, "terrain_T10_texture.npz"))
+    worst = {}
+    for key in z.files:
+        if key.startswith("dem|"):
+            continue
+        name, alpha = key.split("|")
+        got = t.texture_shading(z[f"dem|{name}"], alpha=float(alpha))
+        e = _tex_err(got, z[key])
+        worst[key] = e
+        tol = 1e-12 if z[key].dtype == np.float64 else 1e-5  # measured: 1e-14 / 2.5e-6 of the output maximum
+        assert e <= tol, (key, e)
+    assert np.all(t.texture_shading(z["dem|flat"]) == 0)
+    with pytest.raises(ValueError, match="Alpha must be between 0 and 2"):
+        t.texture_shading(z["dem|flat"], alpha=2.1)
+    print(worst)
+
+
+def test_texture_shading_properties_large():
+    """2000 x 3000 float32 DEM (FFT lengths 2000 x 3000 are 7-smooth): oracle comparison + the reference's invariants
+    (tests/test_terrain/test_freq.py:84-160): offset invariance for alpha > 0, linear scaling, all-attribute call."""
+    from xdem_amd import terrain as t
+    from xdem_amd.synth import fbm_numpy
+
+    dem = fbm_numpy((2000, 3000), seed=12)
+    dem[100:110, 200:260] = np.nan
+    got = t.texture_shading(dem, alpha=0.8)
+    ref = to.terrain_attributes(dem, ["texture_shading"])[0]
+    e32 = _tex_err(got, ref)
+    assert e32 <= 5e-5, e32
+    got64 = t.texture_shading(dem.astype(np.float64), alpha=0.8)
+    ref64 = to.terrain_attributes(dem.astype(np.float64), ["texture_shading"])[0]
+    assert _tex_err(got64, ref64) <= 1e-12
+    ok = np.isfinite(got64)
+    off = t.texture_shading(dem.astype(np.float64) + 1234.5, alpha=0.8)
+    assert np.abs(off[ok] - got64[ok]).max() <= 1e-8 * np.abs(got64[ok]).max()
+    sc = t.texture_shading(dem.astype(np.float64) * 3.0, alpha=0.8)
+    assert np.abs(sc[ok] - 3.0 * got64[ok]).max() <= 1e-9 * np.abs(got64[ok]).max()
+    both = t.get_terrain_attribute(dem, ["texture_shading", "slope", "fractal_roughness"], resolution=10.0)
+    assert np.array_equal(both[0], got, equal_nan=True) and both[1].shape == dem.shape

@@ -28,6 +28,20 @@ cases = [
     ("rugosity", ["rugosity"], "Florinsky"), ("roughness", ["roughness"], "Florinsky"),
     ("fractal w13", ["fractal_roughness"], "Florinsky"),
 ]
+# texture shading (hipFFT + 3 streaming kernels), host-timed around the device-resident C call
+import ctypes
+import time
+
+import numpy as np
+
+tex = torch.empty((n, n), device=dev, dtype=torch.float32)
+for i in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.check(ctx._L.xdemhip_texture_shading(ctx.handle, dem.data_ptr(), 0, n, n, 0.8, 0, tex.data_ptr(), 1))
+    torch.cuda.synchronize()
+    tt = (time.perf_counter() - t0) * 1e3
+print(json.dumps({"case": "texture_shading alpha=0.8 (incl. plan creation)", "n": n, "ms": round(tt, 3), "Mpix_s": round(n * n / tt / 1e3, 1)}), flush=True)
 res = []
 for name, attrs, fit in cases:
     o = out[: len(attrs)]

@@ -59,6 +59,8 @@ def lib() -> ctypes.CDLL:
         ]
         c_i64p, c_dp = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
         L.xdemhip_fractal_constants.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), c_dp, c_dp, c_dp]
+        L.xdemhip_texture_shading.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_nk_create.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p]
         L.xdemhip_nk_step.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,

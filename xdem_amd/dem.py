@@ -109,6 +109,9 @@ class DEM:
     def fractal_roughness(self, window_size_fractal=13, mp_config=None) -> "DEM":
         return terrain.fractal_roughness(self, window_size_fractal=window_size_fractal, mp_config=mp_config)
 
+    def texture_shading(self, alpha: float = 0.8, mp_config=None) -> "DEM":
+        return terrain.texture_shading(self, alpha=alpha, mp_config=mp_config)
+
     def get_terrain_attribute(self, attribute, **kwargs: Any):
         return terrain.get_terrain_attribute(self, attribute=attribute, **kwargs)
 

@@ -8,8 +8,8 @@ engines behind it are the fused HIP kernel of ``csrc/terrain.hip`` reached throu
 Covered attributes (the hot path named in BASELINE.json): slope, aspect, hillshade, curvature
 (deprecated), profile / tangential / planform / flowline / max / min curvature, topographic position
 index, terrain ruggedness index, plus the remaining windowed indexes: ``roughness``, ``rugosity``
-and ``fractal_roughness`` (``csrc/window_extra.hip``).  ``texture_shading`` (frequency domain) is outside the path
-and raises ``NotImplementedError`` here.
+and ``fractal_roughness`` (``csrc/window_extra.hip``) and the frequency-domain ``texture_shading`` (8f-4,
+``csrc/texture.hip``) -- i.e. every attribute ``xdem.terrain.get_terrain_attribute`` offers.
 """
 from __future__ import annotations
 
@@ -43,7 +43,7 @@ ATTR_BIT = {
     "topographic_position_index": 10, "terrain_ruggedness_index": 11, "roughness": 12, "rugosity": 13,
     "fractal_roughness": 14,
 }
-_NOT_ON_HOT_PATH = ("texture_shading",)
+_NOT_ON_HOT_PATH = ()
 _FIT_ID = {"horn": 0, "zevenbergthorne": 1, "florinsky": 2}
 _CURV_ID = {"geometric": 0, "directional": 1}
 _TRI_ID = {"riley": 0, "wilson": 1}
@@ -213,6 +213,10 @@ def get_terrain_attribute(
 
     attribute, resolution = _validate(dem, attribute, resolution, hillshade_altitude, hillshade_azimuth,
                                       hillshade_z_factor, surface_fit, curv_method, tri_method, window_size_fractal)
+    if "texture_shading" in attribute:
+        texture_alpha = 0.8 if texture_alpha is None else texture_alpha
+        if not 0 <= texture_alpha <= 2:
+            raise ValueError(f"Alpha must be between 0 and 2, got {texture_alpha}")  # freq.py:80-83
     if out_dtype is None:
         in_dt = np.asarray(dem.data if _is_raster(dem) else dem).dtype
         out_dtype = np.float32 if np.issubdtype(in_dt, np.integer) else np.dtype(in_dt)
@@ -232,9 +236,16 @@ def get_terrain_attribute(
 
     outs = {a: np.empty((H, W), dtype=out_dtype) for a in set(attribute)}
     ctx = _lib.default_context()
-    launch_terrain(ctx, dem_arr.ctypes.data, dem_arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
-                   attribute, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
-                   degrees, out_dtype, {a: o.ctypes.data for a, o in outs.items()}, _lib.HOST, window_size_fractal)
+    stencil = [a for a in attribute if a not in list_requiring_frequency_domain]
+    if stencil:
+        launch_terrain(ctx, dem_arr.ctypes.data, dem_arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
+                       stencil, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
+                       degrees, out_dtype, {a: outs[a].ctypes.data for a in set(stencil)}, _lib.HOST, window_size_fractal)
+    if "texture_shading" in attribute:  # frequency-domain attribute: its own engine (terrain.py:637-644)
+        alpha = texture_alpha
+        code = lambda dt: _lib.F32 if np.dtype(dt) == np.float32 else _lib.F64  # noqa: E731
+        ctx.check(ctx._L.xdemhip_texture_shading(ctx.handle, dem_arr.ctypes.data, code(dem_arr.dtype), H, W, float(alpha),
+                                                 code(out_dtype), outs["texture_shading"].ctypes.data, _lib.HOST))
     output_attributes = [outs[a] for a in attribute]
     if _is_raster(dem):
         output_attributes = [
@@ -348,6 +359,11 @@ def fractal_roughness(dem, window_size_fractal=13, mp_config=None, engine="hip")
     (terrain.py:1721-1765)."""
     return get_terrain_attribute(dem=dem, attribute="fractal_roughness", window_size_fractal=window_size_fractal,
                                  mp_config=mp_config, engine=engine)
+
+
+def texture_shading(dem, alpha: float = 0.8, mp_config=None, engine="hip"):
+    """Texture shading, the fractional Laplacian ``|f|^alpha`` of the DEM (Brown 2010) (terrain.py:1783-1840, freq.py:63-148)."""
+    return get_terrain_attribute(dem=dem, attribute="texture_shading", texture_alpha=alpha, mp_config=mp_config, engine=engine)
 
 
 def terrain_ruggedness_index(dem, method="Riley", window_size=3, mp_config=None, engine="hip"):
