@@ -70,6 +70,11 @@ int xdemhip_synchronize(xdemhip_ctx* ctx);
 /* Timing of the work enqueued by the last call on the context stream, measured with hipEvents recorded on
  * that stream around the kernel launch(es); returns milliseconds in *ms (synchronises the stop event). */
 int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
+/* Tuning / test switches.  "selection": how the exact medians (nanmedian of dh, aspect-bin and nd_binning medians, NMAD) are
+ * selected -- 0 (default) bracketed for large inputs: brackets from a ~1/64 line sample, one counting + compaction pass,
+ * exact selection among the candidates, plain radix passes if a bracket misses; 1 plain 8-bit radix passes only;
+ * 2 degenerate brackets (exercises the fall-back).  Results are identical in every mode. */
+int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value);
 
 /* Multi-GPU hook for the accumulator-style paths (Nuth-Kaab reductions): one process per GPU, every rank works on its
  * share and calls the same entry points; wherever a global reduction is needed the library hands a small HOST array of

@@ -152,3 +152,56 @@ def test_nmad_device_matches_numpy():
         w[np.abs(w) > lim] = np.nan
         med, nm, cnt = ss.nmad_device(v, abs_limit=lim)
         assert cnt == np.isfinite(w).sum() and med == np.nanmedian(w) and nm == float(bo.nmad(w))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_selection_modes_agree_on_large_inputs(mode):
+    """Bracketed selection (mode 0: sample -> brackets -> one counting/compaction pass -> candidates), plain radix passes
+    (1) and the bracket-miss fall-back (2) give the same exact order statistics: 6e6-sample binning with ties, global NMAD,
+    and a Nuth-Kaab step, all against NumPy / the oracle."""
+    from xdem_amd import _lib, coreg
+    from xdem_amd import spatialstats as ss
+    import nuthkaab_oracle as no
+
+    ctx = _lib.default_context()
+    ctx.set_option("selection", mode)
+    try:
+        rng = np.random.default_rng(17)
+        n = 6_000_000
+        x = rng.gamma(2.0, 8.0, n).astype(np.float32)
+        v = np.round(rng.normal(0, 1, n) * (0.5 + 0.05 * x), 2).astype(np.float32)   # many ties
+        v[::997] = np.nan
+        df = ss.nd_binning(v, [x], ["v0"], list_var_bins=16)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = flatten_like_reference(bo.nd_binning_arrays(v, [x], 16), 1)
+        for key in ("count", "nanmedian", "nmad"):
+            assert np.array_equal(df[key].values.astype(np.float64), ref[key], equal_nan=True), (mode, key)
+        for dt in (np.float32, np.float64):
+            w = rng.standard_t(3, 5_000_001).astype(dt)
+            med, nm, cnt = ss.nmad_device(w)
+            assert med == np.median(w) and nm == float(bo.nmad(w)) and cnt == w.size
+        # Nuth-Kaab step on a 2304^2 pair (5.3e6 pixels): global nanmedian + 72 bin medians vs the oracle
+        from xdem_amd.synth import fbm_numpy
+
+        m = 2304
+        refd = fbm_numpy((m, m), seed=3)
+        tba = (np.roll(refd, (1, -1), (0, 1)) + 1.5 + rng.normal(0, 0.3, (m, m))).astype(np.float32)
+        tba[rng.uniform(size=(m, m)) < 0.1] = np.nan
+        plan = coreg.NKPlan(refd, tba, None, ctx)
+        got = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+        plan.close()
+        st, asp = no.aux_vars(refd)
+        valid = np.isfinite(refd) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+        dh = no.shifted_dh(refd, tba, 2.0, -3.0, (10.0, 10.0))[valid]
+        vshift = np.nanmedian(dh)
+        assert got["vshift"] == float(vshift)
+        dh = dh - vshift
+        ok = np.isfinite(dh)
+        assert got["n_valid"] == int(ok.sum())
+        with np.errstate(all="ignore"):
+            y = dh[ok] / st[valid][ok]
+        edges, counts, med = no.bin_medians(asp[valid][ok], y, 72)
+        assert np.array_equal(got["counts"], counts) and np.array_equal(got["medians"], med, equal_nan=True)
+    finally:
+        ctx.set_option("selection", 0)

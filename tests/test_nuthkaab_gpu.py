@@ -156,9 +156,11 @@ def test_class_api_recovers_shift(coreg):
         coreg.NuthKaab(subsample=1).fit(ref, np.full_like(tba, np.nan), None, resolution=res)
 
 
-def test_sharded_reduction_path_single_rank(coreg):
+@pytest.mark.parametrize("shape", [(128, 200), (2304, 2304)])
+def test_sharded_reduction_path_single_rank(coreg, shape):
     """The multi-GPU path (row range + all-reduce hook through torch.distributed) on a 1-rank NCCL group: must give
-    exactly the single-process results.  (Multi-rank sums of the same integer histograms are exercised on CPU/gloo.)"""
+    exactly the single-process results.  (Multi-rank sums of the same integer histograms are exercised on CPU/gloo.)
+    The larger shape takes the bracketed-selection route (sample / counter / candidate reductions through the hook)."""
     import os
 
     import torch.distributed as dist
@@ -170,7 +172,7 @@ def test_sharded_reduction_path_single_rank(coreg):
         dist.init_process_group("nccl", rank=0, world_size=1)
         created = True
     try:
-        ref, tba, inlier, res = _pair((128, 200))
+        ref, tba, inlier, res = _pair(shape)
         base = coreg.NKPlan(ref, tba, inlier)
         want = base.step(7.0, -3.0, (res, res), 72)
         base.close()

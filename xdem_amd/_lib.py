@@ -50,6 +50,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_last_error.restype = ctypes.c_char_p
         L.xdemhip_set_stream.argtypes = [c_ctx, ctypes.c_void_p]
         L.xdemhip_synchronize.argtypes = [c_ctx]
+        L.xdemhip_set_option.argtypes = [c_ctx, ctypes.c_char_p, ctypes.c_int]
         L.xdemhip_last_kernel_ms.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_float)]
         L.xdemhip_terrain.argtypes = [
             c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -175,6 +176,10 @@ class Context:
 
     def synchronize(self) -> None:
         self.check(self._L.xdemhip_synchronize(self.handle))
+
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning / test switch of the library (``xdemhip_set_option``), e.g. ``("selection", 1)``."""
+        self.check(self._L.xdemhip_set_option(self.handle, name.encode(), int(value)))
 
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_float()

@@ -239,7 +239,12 @@ int run_typed(xdemhip_binstats* P, int nb, int want_nmad, double nfact, int64_t*
     if (hipMalloc(&scratch, scratch_size(nb)) != hipSuccess) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(scratch) failed");
     unsigned char* base = static_cast<unsigned char*>(scratch);
     std::vector<SelResult<K>> hs;
-    int rc = run_select<T>(ctx, static_cast<const T*>(P->values), P->bins, P->n, nb, base, hs);
+    SelWorkspace ws;
+    if (P->n >= SEL_BRACKET_MIN_N && nb <= MAX_BINS_PER_SWEEP && sel_ws_create(ctx, P->n, sizeof(T), nb, ws) != XDEMHIP_OK) {
+        (void)hipFree(scratch);
+        return XDEMHIP_ENOMEM;
+    }
+    int rc = run_select<T>(ctx, static_cast<const T*>(P->values), P->bins, P->n, nb, base, hs, &ws);
     std::vector<T> med(nb);
     if (rc == XDEMHIP_OK)
         for (int k = 0; k < nb; ++k) {
@@ -261,7 +266,7 @@ int run_typed(xdemhip_binstats* P, int nb, int want_nmad, double nfact, int64_t*
             e = hipGetLastError();
         }
         if (e != hipSuccess) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("absdev launch failed: ") + hipGetErrorString(e));
-        if (rc == XDEMHIP_OK) rc = run_select<T>(ctx, static_cast<const T*>(P->absdev), P->bins, P->n, nb, base, hs);
+        if (rc == XDEMHIP_OK) rc = run_select<T>(ctx, static_cast<const T*>(P->absdev), P->bins, P->n, nb, base, hs, &ws);
         if (rc == XDEMHIP_OK)
             for (int k = 0; k < nb; ++k) {
                 const double m = median_from<T>(hs[k]);
@@ -269,6 +274,7 @@ int run_typed(xdemhip_binstats* P, int nb, int want_nmad, double nfact, int64_t*
             }
         if (d_med_big) (void)hipFree(d_med_big);
     }
+    sel_ws_free(ws);
     (void)hipFree(scratch);
     return rc;
 }
@@ -450,17 +456,20 @@ static int nmad_typed(xdemhip_ctx* ctx, const void* values, int64_t n, double nf
     std::vector<SelResult<K>> r;
     const xdemhip_allreduce_fn hook = ctx->allreduce;
     ctx->allreduce = nullptr;
-    rc = run_select<T>(ctx, src, nullptr, n, 1, base, r);
+    SelWorkspace ws;
+    if (n >= SEL_BRACKET_MIN_N) (void)sel_ws_create(ctx, n, sizeof(T), 1, ws);  // (on failure: plain selection)
+    rc = run_select<T>(ctx, src, nullptr, n, 1, base, r, &ws);
     if (rc == XDEMHIP_OK) {
         *count = (int64_t)r[0].st.count;
         const double med = median_from<T>(r[0]);
         *median = med;
         hipLaunchKernelGGL((absdev1_kernel<T>), g, dim3(256), 0, ctx->stream, src, n, (T)med, static_cast<T*>(d_w));
-        rc = run_select<T>(ctx, static_cast<const T*>(d_w), nullptr, n, 1, base, r);
+        rc = run_select<T>(ctx, static_cast<const T*>(d_w), nullptr, n, 1, base, r, &ws);
         if (rc == XDEMHIP_OK) *nmad_out = (double)(T)((T)nfact * (T)median_from<T>(r[0]));
     }
     ctx->allreduce = hook;
     (void)hipStreamSynchronize(ctx->stream);
+    sel_ws_free(ws);
     cleanup();
     return rc;
 }

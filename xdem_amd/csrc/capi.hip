@@ -66,6 +66,16 @@ int xdemhip_synchronize(xdemhip_ctx* ctx) {
     return XDEMHIP_OK;
 }
 
+int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return XDEMHIP_EINVAL;
+    if (std::string(name) == "selection") {
+        if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets");
+        ctx->selection_mode = value;
+        return XDEMHIP_OK;
+    }
+    return xd_fail(ctx, XDEMHIP_EINVAL, std::string("unknown option: ") + name);
+}
+
 int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms) {
     if (!ctx || !ms) return XDEMHIP_EINVAL;
     if (!ctx->timed) return xd_fail(ctx, XDEMHIP_EINVAL, "no timed launch on this context yet");

@@ -207,6 +207,7 @@ struct xdemhip_nk_plan {
     size_t scratch_bytes = 0;
     int max_bins = 0;
     long long n_valid0 = 0;
+    xd::SelWorkspace ws;  // bracketed selection (select_run.h): sample + candidate buffers
 };
 
 namespace {
@@ -281,7 +282,7 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
 
     // 2. vertical shift = exact nanmedian(dh)
     std::vector<SelResult<K>> g;
-    rc = run_select<T>(ctx, dh, nullptr, n, 1, base, g);
+    rc = run_select<T>(ctx, dh, nullptr, n, 1, base, g, &P->ws);
     if (rc) return rc;
     *n_valid = (int64_t)g[0].st.count;
     if (g[0].st.count == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
@@ -309,7 +310,7 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
 
     // 4. per-bin exact medians
     std::vector<SelResult<K>> hs;
-    rc = run_select<T>(ctx, y, bins, n, nb, base, hs);  // (synchronises the stream: `sums` has landed)
+    rc = run_select<T>(ctx, y, bins, n, nb, base, hs, &P->ws);  // (synchronises the stream: `sums` has landed)
     if (rc) return rc;
     const double cnt = (double)g[0].st.count;
     const double mean = sums[0] / cnt;
@@ -335,6 +336,7 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->scratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    xd::sel_ws_free(P->ws);
     delete P;
 }
 
@@ -370,6 +372,8 @@ int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const 
         hipMalloc(&P->dh, n * es) != hipSuccess || hipMalloc(&P->y, n * es) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&P->valid), n) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&P->bins), n * 2) != hipSuccess || hipMalloc(&P->scratch, P->scratch_bytes) != hipSuccess)
+        return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
+    if ((int64_t)n >= SEL_BRACKET_MIN_N && sel_ws_create(ctx, (int64_t)n, es, MAX_BINS_PER_SWEEP, P->ws) != XDEMHIP_OK)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
     const xdemhip_allreduce_fn hook = ctx->allreduce;
     ctx->allreduce = nullptr;  // the whole-raster pass at creation is local; xdemhip_nk_set_rows re-partitions with the hook

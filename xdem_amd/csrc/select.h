@@ -11,6 +11,7 @@
 // upper median is either the same value (duplicates) or the smallest key above it, found in one extra pass.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 namespace xd {
@@ -53,8 +54,21 @@ template <typename K> struct SelState {
 // Advance every bin by one digit: hist[bin][256] holds the counts of the current digit among the elements that
 // match the bin's prefix.  First pass (digit == top) also fixes count and the target rank (lower median).
 // One wave64 per bin: lane l owns buckets 4l .. 4l+3; wave prefix sums locate the bucket that holds the rank.
+// Target rank fixed at the first pass: SEL_MEDIAN = lower median (count-1)/2; SEL_BRACKET_LO / _HI = the median rank of a
+// SAMPLE moved down / up by sel_bracket_halfwidth(count) (select_run.h: bracketed selection); SEL_GIVEN = given[bin]
+// (all-ones: skip the bin).
+enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3 };
+
+// Half width (in sample ranks) of the bracket around the sample median that holds the population median with
+// overwhelming probability: 6 standard deviations of the rank (0.5 sqrt(m_eff)) for an effective sample size of
+// m / 32 -- the sample is made of whole 32-element lines, fully correlated lines being the worst case -- plus slack.
+__host__ __device__ inline uint64_t sel_bracket_halfwidth(uint64_t m) {
+    return (uint64_t)(3.0 * sqrt(32.0 * (double)m)) + 32;
+}
+
 template <typename K>
-__global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last) {
+__global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
+                                                            int mode = SEL_MEDIAN, const uint64_t* given = nullptr) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
     uint64_t* h = hist + (size_t)b * SEL_RADIX;
@@ -72,7 +86,14 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
     SelState<K> s = st[b];
     if (first) {
         s.count = total;
-        s.rank = total ? (total - 1) / 2 : 0;  // lower median
+        uint64_t r = total ? (total - 1) / 2 : 0;  // lower median
+        if (mode == SEL_BRACKET_LO && total) { const uint64_t h = sel_bracket_halfwidth(total); r = r > h ? r - h : 0; }
+        if (mode == SEL_BRACKET_HI && total) { const uint64_t h = sel_bracket_halfwidth(total); r = (r + h < total) ? r + h : total - 1; }
+        if (mode == SEL_GIVEN) {
+            r = given[b];
+            if (r == ~(uint64_t)0 || r >= total) { s.count = 0; r = 0; }
+        }
+        s.rank = r;
         s.prefix = 0;
         s.n_le = 0;
     }

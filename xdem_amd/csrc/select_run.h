@@ -4,6 +4,7 @@
 // integer tables through the context hook when the data are sharded over GPUs).
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -126,8 +127,8 @@ template <typename K> struct SelResult {
 // integer histograms / successor keys are combined over the ranks after every pass, so every rank selects the same
 // global order statistics from its own share of the data.
 template <typename T>
-inline int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
-               std::vector<SelResult<typename KeyT<T>::type>>& out) {
+int run_select_core(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
+                    std::vector<SelResult<typename KeyT<T>::type>>& out, int mode, const uint64_t* d_given) {
     typedef typename KeyT<T>::type K;
     SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
@@ -154,7 +155,7 @@ inline int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
-                           (int)(p == 0), (int)(p == passes - 1));
+                           (int)(p == 0), (int)(p == passes - 1), mode, d_given);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     if (n > 0) {
@@ -171,6 +172,268 @@ inline int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int
     XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     out.resize(nb);
     for (int k = 0; k < nb; ++k) { out[k].st = hs[k]; out[k].succ = hsucc[k]; }
+    return XDEMHIP_OK;
+}
+
+// ---- bracketed selection ------------------------------------------------------------------------------------------
+// The plain selection above reads the data once per key digit (4 passes for float32, 8 for float64) plus once for the
+// successor.  For large inputs the medians are first bracketed from a ~1/64 sample made of whole 32-element lines
+// (pseudo-randomly chosen, so only those lines are fetched), then ONE pass over the data counts, per bin, the elements
+// below the bracket and compacts the few inside it; the exact order statistics are finally selected among those
+// candidates.  Everything stays integer and exact: the counts prove that the wanted ranks lie inside the brackets; if a
+// bracket misses (or the candidate buffer overflows) the plain selection runs instead.  Counts, sample and candidate
+// histograms go through the same all-reduce hook, so the result is identical on every rank.
+struct SelWorkspace {
+    void* s_vals = nullptr; uint16_t* s_bins = nullptr; int64_t s_cap = 0;   // sample
+    void* c_vals = nullptr; uint16_t* c_bins = nullptr; int64_t c_cap = 0;   // candidates
+    uint64_t* d_small = nullptr;  // [0] sample count, [1] candidate count, [2] overflow | klo | khi | given | counters[3 nb]
+    int nb_max = 0;
+    size_t es = 4;
+};
+constexpr int64_t SEL_BRACKET_MIN_N = (int64_t)1 << 22;
+
+inline void sel_ws_free(SelWorkspace& w) {
+    void* b[] = {w.s_vals, w.s_bins, w.c_vals, w.c_bins, w.d_small};
+    for (void* p : b)
+        if (p) (void)hipFree(p);
+    w = SelWorkspace();
+}
+inline int sel_ws_create(xdemhip_ctx* ctx, int64_t n, size_t es, int nb_max, SelWorkspace& w) {
+    w = SelWorkspace();
+    w.es = es; w.nb_max = nb_max;
+    w.s_cap = n / 24 + 4096;   // expected n / 64
+    w.c_cap = n / 2 + 4096;
+    if (hipMalloc(&w.s_vals, (size_t)w.s_cap * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&w.s_bins), (size_t)w.s_cap * 2) != hipSuccess ||
+        hipMalloc(&w.c_vals, (size_t)w.c_cap * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&w.c_bins), (size_t)w.c_cap * 2) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&w.d_small), (size_t)(8 + 6 * nb_max) * 8) != hipSuccess) {
+        sel_ws_free(w);
+        return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(selection workspace) failed");
+    }
+    return XDEMHIP_OK;
+}
+
+__device__ __forceinline__ bool sel_line_sampled(int64_t line) {
+    return ((uint64_t)line * 0x9E3779B97F4A7C15ull >> 58) == 0;  // top 6 bits of a multiplicative hash: 1 line in 64
+}
+
+// Block-level compaction: selected (value, bin) pairs collect in an LDS staging buffer (one LDS atomic per wave and step)
+// and leave in coalesced bursts, ONE global atomic per burst of thousands.  (A global atomic per wave would serialise
+// on a single address: ~1e8 updates/s, far below the data rate.)
+constexpr int SEL_TILE = 4;                        // elements per thread and step
+constexpr int SEL_STAGE_CAP = 8192;                // staging slots per workgroup
+template <typename T> struct BlockStage {
+    T* v;
+    uint16_t* b;
+    int* held;                   // LDS
+    unsigned long long* base;    // LDS
+    __device__ __forceinline__ void append(bool keep, T val, uint16_t bin) {
+        const unsigned long long mask = __ballot(keep);
+        if (!mask) return;
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        int pos0 = 0;
+        if (lane == leader) pos0 = atomicAdd(held, __popcll(mask));
+        pos0 = __shfl(pos0, leader);
+        if (keep) {
+            const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
+            v[pos] = val;
+            b[pos] = bin;
+        }
+    }
+    // called by every thread of the workgroup after each step (and with force at the end)
+    __device__ __forceinline__ void sync_and_flush(bool force, T* out_v, uint16_t* out_b, unsigned long long* counter, int64_t cap,
+                                                   unsigned long long* overflow) {
+        __syncthreads();
+        const int h = *held;
+        if (h > SEL_STAGE_CAP - SEL_TILE * (int)blockDim.x || (force && h > 0)) {
+            if (threadIdx.x == 0) *base = atomicAdd(counter, (unsigned long long)h);
+            __syncthreads();
+            const unsigned long long b0 = *base;
+            for (int i = threadIdx.x; i < h; i += blockDim.x) {
+                const unsigned long long pos = b0 + (unsigned long long)i;
+                if ((int64_t)pos < cap) { out_v[pos] = v[i]; out_b[pos] = b[i]; }
+                else *overflow = 1ull;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) *held = 0;
+            __syncthreads();
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins, int64_t n,
+                                                                    int nb, T* out_v, uint16_t* out_b, unsigned long long* ctr, int64_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    BlockStage<T> st;
+    st.v = reinterpret_cast<T*>(smem);
+    st.b = reinterpret_cast<uint16_t*>(st.v + SEL_STAGE_CAP);
+    st.base = reinterpret_cast<unsigned long long*>(st.b + SEL_STAGE_CAP);
+    st.held = reinterpret_cast<int*>(st.base + 1);
+    if (threadIdx.x == 0) *st.held = 0;
+    __syncthreads();
+    // a step covers 64 lines (2048 elements) per wave; only sampled lines are loaded
+    const int64_t step = (int64_t)blockDim.x * SEL_TILE;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+#pragma unroll
+        for (int q = 0; q < SEL_TILE; ++q) {
+            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+            bool keep = false;
+            T v = (T)0;
+            uint16_t b = 0;
+            if (p < n && sel_line_sampled(p >> 5)) {
+                v = vals[p];
+                b = bins ? bins[p] : (uint16_t)0;
+                keep = (v == v) && (int)b < nb;
+            }
+            st.append(keep, v, b);
+        }
+        st.sync_and_flush(false, out_v, out_b, &ctr[0], cap, &ctr[2]);
+    }
+    st.sync_and_flush(true, out_v, out_b, &ctr[0], cap, &ctr[2]);
+}
+
+// One pass over the data: per bin the number of (non-NaN) elements, of elements below the bracket and inside it; elements
+// inside [klo, khi] are compacted through the staging buffer.  LDS: staging | klo / khi per bin | `copies` privatised sets of
+// 3 counters per bin.
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins, int64_t n,
+                                                                    int nb, int copies, const typename KeyT<T>::type* __restrict__ klo,
+                                                                    const typename KeyT<T>::type* __restrict__ khi, uint64_t* counters /* [3][nb] */,
+                                                                    T* out_v, uint16_t* out_b, unsigned long long* ctr, int64_t cap) {
+    typedef typename KeyT<T>::type K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    BlockStage<T> st;
+    st.v = reinterpret_cast<T*>(smem);
+    st.b = reinterpret_cast<uint16_t*>(st.v + SEL_STAGE_CAP);
+    st.base = reinterpret_cast<unsigned long long*>(st.b + SEL_STAGE_CAP);
+    st.held = reinterpret_cast<int*>(st.base + 1);
+    K* lo = reinterpret_cast<K*>(st.base + 2);
+    K* hi = lo + nb;
+    uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { lo[k] = klo[k]; hi[k] = khi[k]; }
+    for (int k = threadIdx.x; k < 3 * nb * copies; k += blockDim.x) c[k] = 0;
+    if (threadIdx.x == 0) *st.held = 0;
+    __syncthreads();
+    uint32_t* cc = c + (threadIdx.x % copies) * 3 * nb;
+    const int64_t step = (int64_t)blockDim.x * SEL_TILE;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+        T v[SEL_TILE];
+        uint16_t b[SEL_TILE];
+#pragma unroll
+        for (int q = 0; q < SEL_TILE; ++q) {  // all loads of the step first
+            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+            v[q] = (p < n) ? vals[p] : (T)NAN;
+            b[q] = (p < n && bins) ? bins[p] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int q = 0; q < SEL_TILE; ++q) {
+            bool cand = false;
+            if (v[q] == v[q] && (int)b[q] < nb) {
+                const K key = key_of(v[q]);
+                atomicAdd(&cc[b[q]], 1u);
+                if (key < lo[b[q]]) atomicAdd(&cc[nb + b[q]], 1u);
+                else if (key <= hi[b[q]]) { atomicAdd(&cc[2 * nb + b[q]], 1u); cand = true; }
+            }
+            st.append(cand, v[q], b[q]);
+        }
+        st.sync_and_flush(false, out_v, out_b, &ctr[1], cap, &ctr[2]);
+    }
+    st.sync_and_flush(true, out_v, out_b, &ctr[1], cap, &ctr[2]);
+    for (int k = threadIdx.x; k < 3 * nb; k += blockDim.x) {
+        unsigned long long s = 0;
+        for (int q = 0; q < copies; ++q) s += c[q * 3 * nb + k];
+        if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[k]), s);
+    }
+}
+
+template <typename T>
+int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
+               std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws = nullptr) {
+    typedef typename KeyT<T>::type K;
+    static const bool disabled = getenv("XDEMHIP_NO_BRACKET") != nullptr;  // (A/B timing knob)
+    const bool plain = disabled || ctx->selection_mode == 1 || !ws || !ws->d_small || nb > ws->nb_max || ws->es != sizeof(T) || nb > MAX_BINS_PER_SWEEP ||
+                       n < SEL_BRACKET_MIN_N || (n / 24 + 4096) > ws->s_cap;
+    if (ctx->allreduce) {  // sharded data: every rank must take the same route (local sizes / allocations may differ)
+        uint64_t can = plain ? 0 : 1;
+        if (ctx->allreduce(&can, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
+        if (!can) return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
+    } else if (plain) {
+        return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
+    }
+    uint64_t* d_ctr = ws->d_small;
+    K* d_klo = reinterpret_cast<K*>(ws->d_small + 8);
+    K* d_khi = reinterpret_cast<K*>(ws->d_small + 8 + ws->nb_max);
+    uint64_t* d_given = ws->d_small + 8 + 2 * ws->nb_max;
+    uint64_t* d_cnt = ws->d_small + 8 + 3 * ws->nb_max;
+    XD_HIP_CHECK(ctx, hipMemsetAsync(ws->d_small, 0, (size_t)(8 + 6 * ws->nb_max) * 8, ctx->stream));
+    // 1. sample
+    const size_t lds_stage = (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
+    int rc = set_big_lds(ctx, sample_lines_kernel<T>, lds_stage);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sample_lines_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds_stage, ctx->stream,
+                       vals, bins, n, nb, static_cast<T*>(ws->s_vals), ws->s_bins, reinterpret_cast<unsigned long long*>(d_ctr), ws->s_cap);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    uint64_t h_ctr[3];
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 24, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t m = (int64_t)(h_ctr[0] < (uint64_t)ws->s_cap ? h_ctr[0] : (uint64_t)ws->s_cap);
+    // 2. brackets from the sample (global over the ranks through the hook)
+    std::vector<SelResult<K>> lo, hi;
+    rc = run_select_core<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, m, nb, scratch, lo, SEL_BRACKET_LO, nullptr);
+    if (rc) return rc;
+    rc = run_select_core<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, m, nb, scratch, hi, SEL_BRACKET_HI, nullptr);
+    if (rc) return rc;
+    std::vector<K> klo(nb), khi(nb);
+    for (int b = 0; b < nb; ++b) {
+        const bool have = lo[b].st.count > 0;
+        klo[b] = have ? lo[b].st.prefix : (K)0;
+        khi[b] = have ? hi[b].st.prefix : (K)~(K)0;
+        if (ctx->selection_mode == 2 && have) khi[b] = klo[b];  // test mode: brackets that (almost surely) miss
+    }
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_klo, klo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_khi, khi.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream));
+    // 3. the one pass over the data
+    int copies = (32 * 1024) / (nb * 12);
+    copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
+    const size_t lds = lds_stage + (size_t)nb * (2 * sizeof(K) + 12 * (size_t)copies);
+    rc = set_big_lds(ctx, bracket_pass_kernel<T>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((bracket_pass_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds, ctx->stream, vals,
+                       bins, n, nb, copies, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), ws->c_bins,
+                       reinterpret_cast<unsigned long long*>(d_ctr), ws->c_cap);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    rc = xd_allreduce_device(ctx, d_cnt, 3 * (int64_t)nb, XDEMHIP_RED_SUM_U64);
+    if (rc) return rc;
+    rc = xd_allreduce_device(ctx, d_ctr + 2, 1, XDEMHIP_RED_SUM_U64);  // overflow anywhere -> everybody falls back
+    if (rc) return rc;
+    std::vector<uint64_t> cnt(3 * nb);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(cnt.data(), d_cnt, 8 * 3 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 24, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    bool ok = h_ctr[2] == 0;
+    std::vector<uint64_t> given(nb);
+    for (int b = 0; b < nb && ok; ++b) {
+        const uint64_t total = cnt[b], lt = cnt[nb + b], in = cnt[2 * nb + b];
+        given[b] = ~(uint64_t)0;
+        if (total == 0) continue;
+        const uint64_t k = (total - 1) / 2;
+        const uint64_t need = (total & 1) ? k : k + 1;  // even counts also need the upper median inside the bracket
+        if (lt > k || need - lt >= in) ok = false;
+        else given[b] = k - lt;
+    }
+    if (!ok) return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    // 4. exact selection among the candidates
+    const int64_t nc = (int64_t)h_ctr[1];
+    rc = run_select_core<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, nc, nb, scratch, out, SEL_GIVEN, d_given);
+    if (rc) return rc;
+    for (int b = 0; b < nb; ++b) {
+        const uint64_t total = cnt[b], lt = cnt[nb + b];
+        if (total == 0) { out[b].st.count = 0; continue; }
+        out[b].st.count = total;
+        out[b].st.n_le += lt;
+    }
     return XDEMHIP_OK;
 }
 
