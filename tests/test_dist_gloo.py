@@ -41,6 +41,27 @@ def _worker(rank, world, port, q):
         m = ss._allreduce_min(np.array([10 + rank, 0xFFFFFFFFFFFFFFFF if rank == 0 else 7], dtype=np.uint64))
         ok_red = bool((s == sum(range(1, world + 1))).all()) and abs(c[0] - 1.5 * sum(range(1, world + 1))) < 1e-12 \
             and m.tolist() == [10, 7]
+        # the library's reduction hook (xdemhip_set_allreduce) on raw 8-byte host arrays, full unsigned 64-bit key range:
+        # keys of positive doubles have the top bit set, the all-ones marker means "none"
+        import ctypes
+
+        from xdem_amd import _lib
+
+        hook = _lib.make_reduce_hook("world", None)
+
+        def red(vals, kind, dtype=np.uint64):
+            a = (ctypes.c_uint64 * len(vals))()
+            np.frombuffer(a, dtype=dtype)[:] = np.array(vals, dtype=dtype)
+            assert hook(ctypes.addressof(a), len(vals), kind, None) == 0
+            return np.frombuffer(a, dtype=dtype).tolist()
+
+        big = 0x8000000000000000
+        ok_hook = red([5 + rank, big + 3], 0) == [sum(5 + r for r in range(world)), (world * (big + 3)) % 2**64]
+        ok_hook &= red([0.25 * (rank + 1)], 1, np.float64) == [0.25 * sum(range(1, world + 1))]
+        ok_hook &= red([big + 10 - rank, 7 + rank, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF if rank else big + 1], 2) == \
+            [big + 10 - (world - 1), 7, 0xFFFFFFFFFFFFFFFF, big + 1]
+        ok_hook &= red([big + rank, 3 + rank, (3 if rank else big + 2)], 3) == [big + world - 1, 3 + world - 1, big + 2]
+        ok_red = ok_red and ok_hook
         t = torch.tensor([float(rank)])
         xd.allreduce_sum_(t)
         q.put((rank, ok_halo, ok_halo2, ok_red, float(t.item())))

@@ -101,6 +101,50 @@ def lib() -> ctypes.CDLL:
         return L
 
 
+def make_reduce_hook(group="world", device: int | None = None):
+    """The Python side of ``xdemhip_set_allreduce``: a callable ``hook(ptr, count, kind, user) -> 0 | 1`` that combines an
+    8-byte-element host array in place over the ranks of `group` with torch.distributed.  kind 0 = uint64 sum, 1 = float64
+    sum, 2 / 3 = uint64 min / max (include/xdemhip.h XDEMHIP_RED_*)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    pg = None if group == "world" else group
+    ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.SUM, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX}
+
+    def hook(ptr, count, kind, user):
+        try:
+            buf = (ctypes.c_uint64 * count).from_address(ptr)
+            a = np.frombuffer(buf, dtype=np.float64 if kind == 1 else np.uint64)
+            top = np.uint64(1) << np.uint64(63)
+            if kind == 1:
+                t = torch.from_numpy(a.copy())
+            elif kind == 0:
+                t = torch.from_numpy(a.copy().view(np.int64))  # counters: two's-complement addition is exact
+            else:
+                # min / max of unsigned 64-bit keys travel as int64 with the top bit flipped: an order-preserving map
+                # (the all-ones "none" marker of min reductions becomes int64 max by itself)
+                t = torch.from_numpy((a ^ top).view(np.int64))
+            if dist.get_backend(pg) == "nccl":
+                t = t.cuda(device)
+            dist.all_reduce(t, op=ops[kind], group=pg)
+            r = t.cpu().numpy()
+            if kind == 1:
+                a[:] = r
+            elif kind == 0:
+                a[:] = r.view(np.uint64)
+            else:
+                a[:] = r.view(np.uint64) ^ top
+            return 0
+        except Exception:  # never propagate a Python exception through the C frame
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+    return hook
+
+
 class Context:
     """One libxdemhip context = one GPU of this process."""
 
@@ -132,44 +176,7 @@ class Context:
             self._hook = None
             self.check(self._L.xdemhip_set_allreduce(self.handle, None, None))
             return
-        import numpy as np
-        import torch
-        import torch.distributed as dist
-
-        pg = None if group == "world" else group
-        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.SUM, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX}
-
-        def hook(ptr, count, kind, user):
-            try:
-                buf = (ctypes.c_uint64 * count).from_address(ptr)
-                a = np.frombuffer(buf, dtype=np.float64 if kind == 1 else np.uint64)
-                if kind == 1:
-                    t = torch.from_numpy(a.copy())
-                else:
-                    # unsigned keys / counters travel as int64: order-preserving because they stay below 2^63, except
-                    # the all-ones "none" marker of min reductions, which is mapped to int64 max and back
-                    v = a.copy()
-                    none = v == np.uint64(0xFFFFFFFFFFFFFFFF)
-                    v[none] = np.uint64(0x7FFFFFFFFFFFFFFF)
-                    t = torch.from_numpy(v.view(np.int64))
-                if dist.get_backend(pg) == "nccl":
-                    t = t.cuda(self.device)
-                dist.all_reduce(t, op=ops[kind], group=pg)
-                r = t.cpu().numpy()
-                if kind == 1:
-                    a[:] = r
-                else:
-                    r = r.view(np.uint64).copy()
-                    if kind == 2:
-                        r[r == np.uint64(0x7FFFFFFFFFFFFFFF)] = np.uint64(0xFFFFFFFFFFFFFFFF)
-                    a[:] = r
-                return 0
-            except Exception:  # never propagate a Python exception through the C frame
-                import traceback
-
-                traceback.print_exc()
-                return 1
-
+        hook = make_reduce_hook(group, self.device)
         CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
         self._hook = CB(hook)  # keep alive
         self.check(self._L.xdemhip_set_allreduce(self.handle, ctypes.cast(self._hook, ctypes.c_void_p), None))
