@@ -96,7 +96,8 @@ def secondary_metrics(ctx, dev) -> dict:
     out["variogram"] = {"pairs": ps.n_pairs, "lag_classes": 50, "matheron_pass_Gpairs_s": round(ps.n_pairs / ms / 1e6, 1),
                         "dowd_exact_median_Gpairs_s": round(ps.n_pairs / dt / 1e9, 2),
                         "note": "C5 (reading B): 100 blocks of 9091 x 90910 points, f32 values; Matheron = one pair pass; "
-                                "Dowd = exact per-class median of |dv| (4 histogram passes + successor pass, wall time)"}
+                                "Dowd = exact per-class median of |dv| (bracketed selection: sampled digit passes, one "
+                                "counting + compaction pass over all pairs, exact selection among the candidates; wall time)"}
     ps.close()
     del blocks
     # Nuth-Kaab C3: 20000^2 pair, tba = ref shifted + 2 m, 20 % NaN in contiguous gaps; iteration steps on the full grid

@@ -194,6 +194,13 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
 int xdemhip_pairs_sums(xdemhip_pairs* pairs, int kind, double* sums, int64_t* counts);
 int xdemhip_pairs_hist(xdemhip_pairs* pairs, int shift, int first, const uint64_t* prefix, uint64_t* hist);
 int xdemhip_pairs_succ(xdemhip_pairs* pairs, const uint64_t* key, uint64_t* succ);
+/* Exact per-class median of |dv| (np.median semantics: mean of the two middle values in the value dtype for even classes,
+ * NaN for empty ones) and the class counts, selection state kept on the device: Dowd's estimator is
+ * 2.198 * median^2 / 2.  Large pair sets (>= 4e9 pairs) are bracketed first -- digit passes over a 1/64 sample of the
+ * (A tile x B tile) units, ONE pass over all pairs that counts and compacts the candidates, exact selection among them --
+ * with the plain 4 (float32) / 8 (float64) digit passes + successor pass as the fall-back and for small sets.  Histograms,
+ * counters and successor keys go through the xdemhip_set_allreduce hook when the pair blocks are sharded over GPUs. */
+int xdemhip_pairs_medians(xdemhip_pairs* pairs, int64_t* counts, double* medians);
 void xdemhip_pairs_destroy(xdemhip_pairs* pairs);
 
 /* ---- next row 8f-3: N-dimensional binned statistics ---------------------------------------------------------------

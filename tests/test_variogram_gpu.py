@@ -171,3 +171,36 @@ def test_C5_full_size_properties(ss):
     e_g, c_g = ss.empirical_variogram_pairs(sub, edges, "dowd")
     e_o, c_o = vo.empirical_variogram_blocks(sub, edges, "dowd")
     assert np.array_equal(c_g, c_o) and np.array_equal(e_g, e_o, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_class_medians_routes_agree(ss, dtype):
+    """xdemhip_pairs_medians (device-resident selection; bracketed for >= 4e9 pairs) vs the host-driven pass-by-pass
+    selection over the same C-ABI histograms, in every selection mode (0 auto, 1 plain passes, 2 bracket-miss fall-back):
+    identical medians and counts.  4.4e9 pairs (4 blocks of 16384 x 67000 points), values with many ties."""
+    from xdem_amd import _lib
+
+    rng = np.random.default_rng(31)
+    blocks = []
+    for _ in range(4):
+        na, nbp = 16384, 67000
+        ax, ay = rng.uniform(0, 20000, na), rng.uniform(0, 20000, na)
+        bx, by = rng.uniform(0, 20000, nbp), rng.uniform(0, 20000, nbp)
+        av = np.round(np.sin(ax / 900.0) + 0.2 * rng.normal(size=na), 3).astype(dtype)
+        bv = np.round(np.sin(bx / 900.0) + 0.2 * rng.normal(size=nbp), 3).astype(dtype)
+        blocks.append((ax, ay, av, bx, by, bv))
+    edges = np.geomspace(np.sqrt(2), np.hypot(20000, 20000), 50)
+    ctx = _lib.default_context()
+    ps = ss.PairSet(blocks, edges, ctx)
+    try:
+        assert ps.n_pairs >= 4_000_000_000
+        ref_med, ref_cnt = ss.class_medians_host_driven(ps)
+        assert ref_cnt.sum() == ps.n_pairs
+        for mode in (0, 1, 2):
+            ctx.set_option("selection", mode)
+            med, cnt = ss.class_medians(ps)
+            assert np.array_equal(cnt, ref_cnt), mode
+            assert np.array_equal(med, ref_med, equal_nan=True), mode
+    finally:
+        ctx.set_option("selection", 0)
+        ps.close()

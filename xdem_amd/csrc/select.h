@@ -57,13 +57,18 @@ template <typename K> struct SelState {
 // Target rank fixed at the first pass: SEL_MEDIAN = lower median (count-1)/2; SEL_BRACKET_LO / _HI = the median rank of a
 // SAMPLE moved down / up by sel_bracket_halfwidth(count) (select_run.h: bracketed selection); SEL_GIVEN = given[bin]
 // (all-ones: skip the bin).
-enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3 };
+enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3, SEL_BRACKET_LO_WIDE = 4, SEL_BRACKET_HI_WIDE = 5 };
 
 // Half width (in sample ranks) of the bracket around the sample median that holds the population median with
 // overwhelming probability: 6 standard deviations of the rank (0.5 sqrt(m_eff)) for an effective sample size of
 // m / 32 -- the sample is made of whole 32-element lines, fully correlated lines being the worst case -- plus slack.
 __host__ __device__ inline uint64_t sel_bracket_halfwidth(uint64_t m) {
     return (uint64_t)(3.0 * sqrt(32.0 * (double)m)) + 32;
+}
+// Same for samples of point PAIRS (variogram.hip): the sampled units are (1024 A points) x (256 B points) tiles whose pairs
+// share points, so the effective sample size is taken 64 times smaller than the pair count.
+__host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m) {
+    return (uint64_t)(3.0 * sqrt(64.0 * (double)m)) + 64;
 }
 
 template <typename K>
@@ -89,6 +94,8 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         uint64_t r = total ? (total - 1) / 2 : 0;  // lower median
         if (mode == SEL_BRACKET_LO && total) { const uint64_t h = sel_bracket_halfwidth(total); r = r > h ? r - h : 0; }
         if (mode == SEL_BRACKET_HI && total) { const uint64_t h = sel_bracket_halfwidth(total); r = (r + h < total) ? r + h : total - 1; }
+        if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total); r = r > h ? r - h : 0; }
+        if (mode == SEL_BRACKET_HI_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_GIVEN) {
             r = given[b];
             if (r == ~(uint64_t)0 || r >= total) { s.count = 0; r = 0; }

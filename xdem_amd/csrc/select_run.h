@@ -240,12 +240,33 @@ template <typename T> struct BlockStage {
             b[pos] = bin;
         }
     }
+    // same, for producers without a bound on the elements per step: a full buffer raises the overflow flag instead of writing
+    __device__ __forceinline__ void append_bounded(bool keep, T val, uint16_t bin, unsigned long long* overflow) {
+        const unsigned long long mask = __ballot(keep);
+        if (!mask) return;
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        int pos0 = 0;
+        if (lane == leader) pos0 = atomicAdd(held, __popcll(mask));
+        pos0 = __shfl(pos0, leader);
+        if (keep) {
+            const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < SEL_STAGE_CAP) { v[pos] = val; b[pos] = bin; }
+            else *overflow = 1ull;
+        }
+    }
     // called by every thread of the workgroup after each step (and with force at the end)
     __device__ __forceinline__ void sync_and_flush(bool force, T* out_v, uint16_t* out_b, unsigned long long* counter, int64_t cap,
                                                    unsigned long long* overflow) {
+        sync_and_flush_at(force ? 0 : SEL_STAGE_CAP - SEL_TILE * (int)blockDim.x, out_v, out_b, counter, cap, overflow);
+    }
+    // barrier, then flush if more than `threshold` elements are staged
+    __device__ __forceinline__ void sync_and_flush_at(int threshold, T* out_v, uint16_t* out_b, unsigned long long* counter, int64_t cap,
+                                                      unsigned long long* overflow) {
         __syncthreads();
-        const int h = *held;
-        if (h > SEL_STAGE_CAP - SEL_TILE * (int)blockDim.x || (force && h > 0)) {
+        int h = *held;
+        h = h > SEL_STAGE_CAP ? SEL_STAGE_CAP : h;  // (bounded appends may have counted past the end)
+        if (h > threshold) {
             if (threadIdx.x == 0) *base = atomicAdd(counter, (unsigned long long)h);
             __syncthreads();
             const unsigned long long b0 = *base;

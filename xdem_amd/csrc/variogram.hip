@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "select.h"
+#include "select_run.h"
 
 namespace xd {
 
@@ -34,7 +35,7 @@ constexpr int LUT_N = 512;    // cells (1/8 binade of d^2 each) of the class loo
 constexpr int LUT_STEPS = 1;  // a cell holds at most ONE threshold (host-checked), flagged in the entry's low bit
 constexpr int NCOPY = 32;     // privatised accumulator copies (copy = lane % 32 -> one LDS bank per copy)
 
-enum { OP_SUMS_SQ = 0, OP_SUMS_SQRT = 1, OP_HIST = 2, OP_SUCC = 3 };
+enum { OP_SUMS_SQ = 0, OP_SUMS_SQRT = 1, OP_HIST = 2, OP_SUCC = 3, OP_BRACKET = 4 };
 
 template <typename T> struct PairArgs {
     const double *ax, *ay, *bx, *by;
@@ -52,7 +53,19 @@ template <typename T> struct PairArgs {
     const typename KeyT<T>::type* prefix;  // [nb] selection prefix (hist) or selected key (succ)
     unsigned long long* succ;              // [nb] 8-byte slots, all-ones = none
     int shift, first, bin0, nbs;   // hist digit, first pass flag, LDS sweep window [bin0, bin0 + nbs)
+    int sample;                    // OP_HIST: only the pseudo-randomly chosen 1/64 of the (A tile x B tile) units
+    // OP_BRACKET (bracketed selection, select_run.h): keys in [prefix[k], khi[k]] are candidates
+    const typename KeyT<T>::type* khi;
+    unsigned long long* cnt3;      // [3][nb]: pairs per class, below the bracket, inside it
+    T* cand_v;                     // candidate |dv|
+    uint16_t* cand_b;              // and their class
+    unsigned long long* cand_ctr;  // [0] count, [1] overflow flag
+    long long cand_cap;
 };
+
+__device__ __forceinline__ bool unit_sampled(int64_t wg, int tile) {
+    return (((uint64_t)(wg * 16 + tile) * 0x9E3779B97F4A7C15ull) >> 58) == 0;
+}
 
 template <typename K> __device__ __forceinline__ void lds_min(K* p, K v);
 template <> __device__ __forceinline__ void lds_min<uint32_t>(uint32_t* p, uint32_t v) { atomicMin(p, v); }
@@ -72,8 +85,9 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     double* s_bx = reinterpret_cast<double*>(smem);
     double* s_by = s_bx + PT;
     double* s_thr = s_by + PT;                       // nb (+ LUT_STEPS + 1 entries of +inf padding)
-    K* s_pref = reinterpret_cast<K*>(s_thr + a.nb + LUT_STEPS + 1);  // nb selection prefixes / selected keys (8-byte slots)
-    T* s_bv = reinterpret_cast<T*>(reinterpret_cast<uint64_t*>(s_pref) + a.nb);  // PT
+    K* s_pref = reinterpret_cast<K*>(s_thr + a.nb + LUT_STEPS + 1);  // nb selection prefixes / selected keys / bracket lows (8-byte slots)
+    K* s_khi = reinterpret_cast<K*>(reinterpret_cast<uint64_t*>(s_pref) + a.nb);  // nb bracket highs (8-byte slots)
+    T* s_bv = reinterpret_cast<T*>(reinterpret_cast<uint64_t*>(s_khi) + a.nb);  // PT
     unsigned char* acc = reinterpret_cast<unsigned char*>(s_bv + PT);            // PT * sizeof(T) is a multiple of 8
     // OP_SUMS: NCOPY privatised copies per class, copy = lane % 32: lanes of a wave that hit the same class land on
     // different banks (at most 2 lanes per address) instead of serialising 64-way on one LDS word
@@ -81,6 +95,14 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_sum + a.nb * NCOPY);   // [nb][NCOPY]
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(acc);            // OP_HIST: nbs * 256
     K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
+    uint32_t* s_c3 = reinterpret_cast<uint32_t*>(acc);              // OP_BRACKET: [3][nb][NCOPY] counters, then the staging buffer
+    BlockStage<T> stage;
+    if (OP == OP_BRACKET) {
+        stage.v = reinterpret_cast<T*>(s_c3 + 3 * a.nb * NCOPY + ((3 * a.nb * NCOPY) & 1));  // 8-byte aligned
+        stage.b = reinterpret_cast<uint16_t*>(stage.v + SEL_STAGE_CAP);
+        stage.base = reinterpret_cast<unsigned long long*>(stage.b + SEL_STAGE_CAP);
+        stage.held = reinterpret_cast<int*>(stage.base + 1);
+    }
 
     __shared__ uint8_t s_lut[LUT_N];
     const int tid = threadIdx.x;
@@ -92,8 +114,13 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
         for (int k = tid; k < a.nbs * SEL_RADIX; k += NT) s_hist[k] = 0;
     if (OP == OP_SUCC)
         for (int k = tid; k < a.nb; k += NT) s_min[k] = ~(K)0;
-    if ((OP == OP_HIST && !a.first) || OP == OP_SUCC)
+    if ((OP == OP_HIST && !a.first) || OP == OP_SUCC || OP == OP_BRACKET)
         for (int k = tid; k < a.nb; k += NT) s_pref[k] = a.prefix[k];
+    if (OP == OP_BRACKET) {
+        for (int k = tid; k < a.nb; k += NT) s_khi[k] = a.khi[k];
+        for (int k = tid; k < 3 * a.nb * NCOPY; k += NT) s_c3[k] = 0;
+        if (tid == 0) *stage.held = 0;
+    }
 
     // which block / A tile / B chunk is this workgroup?
     const int64_t wg = blockIdx.x;
@@ -123,7 +150,11 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
 
     if (!skip_wg)
         for (int64_t j0 = jb0; j0 < jb1; j0 += PT) {
-            __syncthreads();
+            if (OP == OP_HIST && a.sample && !unit_sampled(wg, (int)((j0 - jb0) / PT))) continue;  // (uniform over the workgroup)
+            if (OP == OP_BRACKET)  // (starts with the barrier the tile reload needs); flush the staged candidates when half full
+                stage.sync_and_flush_at(SEL_STAGE_CAP / 2, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+            else
+                __syncthreads();
             const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
             if (tid < cnt) {
                 s_bx[tid] = gbx[b0 + j0 + tid];
@@ -132,6 +163,18 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
             }
             __syncthreads();
             if (!have_a) continue;
+            // OP_BRACKET, one pair: counters + staged candidate (every lane of the wave must reach the append)
+            auto bracket_pair = [&](bool ok, int l, T d) {
+                bool cand = false;
+                if (ok) {
+                    const K key = key_abs(d);
+                    const int cp = tid & (NCOPY - 1);
+                    atomicAdd(&s_c3[(0 * nb + l) * NCOPY + cp], 1u);
+                    if (key < s_pref[l]) atomicAdd(&s_c3[(1 * nb + l) * NCOPY + cp], 1u);
+                    else if (key <= s_khi[l]) { atomicAdd(&s_c3[(2 * nb + l) * NCOPY + cp], 1u); cand = true; }
+                }
+                stage.append_bounded(cand, d, (uint16_t)l, &a.cand_ctr[1]);
+            };
             // One pair: class lookup + accumulate.  `ok` folds every skip rule so the fast path stays branch-free
             // up to the (exec-masked) LDS atomics.
             auto pair = [&](int j, bool ok) {
@@ -157,6 +200,7 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 T d = pv - s_bv[j];
                 d = d < 0 ? -d : d;
                 ok = ok && (l < nb) && (d == d);  // beyond the last edge (maxlag) / NaN values never form a pair
+                if (OP == OP_BRACKET) { bracket_pair(ok, l, d); return; }
                 if (!ok) return;
                 if (OP == OP_SUMS_SQ) {
                     atomicAdd(&s_cnt[l * NCOPY + (tid & (NCOPY - 1))], 1u);
@@ -170,11 +214,12 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                     const K key = key_abs(d);
                     if (!a.first && (key & himask) != s_pref[l]) return;
                     atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
-                } else {
+                } else if (OP == OP_SUCC) {
                     const K key = key_abs(d);
                     if (key > s_pref[l] && key < s_min[l]) lds_min<K>(&s_min[l], key);
                 }
             };
+
             if (FAST) {
                 // 4 pairs per trip, written stage by stage so that the 4 B-point reads, the 4 table reads and the 4
                 // threshold reads are each issued back to back (one LDS round trip per stage instead of per pair).
@@ -206,7 +251,9 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                         const int lu = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
                         const T d = dv[u];
                         const bool ok = (j + u) < cnt && (j + u) > ia_rel && lu < nb && d == d;
-                        if (ok) {
+                        if (OP == OP_BRACKET) {
+                            bracket_pair(ok, lu, d);
+                        } else if (ok) {
                             if (OP == OP_SUMS_SQ) {
                                 atomicAdd(&s_cnt[lu * NCOPY + (tid & (NCOPY - 1))], 1u);
                                 atomicAdd(&s_sum[lu * NCOPY + (tid & (NCOPY - 1))], (double)d * (double)d);
@@ -218,7 +265,7 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                                 const K key = key_abs(d);
                                 if (lb >= 0 && lb < a.nbs && (a.first || (key & himask) == s_pref[lu]))
                                     atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
-                            } else {
+                            } else if (OP == OP_SUCC) {
                                 const K key = key_abs(d);
                                 if (key > s_pref[lu] && key < s_min[lu]) lds_min<K>(&s_min[lu], key);
                             }
@@ -240,6 +287,13 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     } else if (OP == OP_HIST) {
         for (int k = tid; k < a.nbs * SEL_RADIX; k += NT)
             if (s_hist[k]) atomicAdd(&a.hist[(size_t)a.bin0 * SEL_RADIX + k], (unsigned long long)s_hist[k]);
+    } else if (OP == OP_BRACKET) {
+        stage.sync_and_flush_at(0, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+        for (int k = tid; k < 3 * nb; k += NT) {
+            unsigned long long c = 0;
+            for (int q = 0; q < NCOPY; ++q) c += s_c3[k * NCOPY + q];
+            if (c) atomicAdd(&a.cnt3[k], c);
+        }
     } else {
         for (int k = tid; k < nb; k += NT)
             if (s_min[k] != ~(K)0) atomicMin(&a.succ[k], (unsigned long long)s_min[k]);
@@ -263,6 +317,13 @@ struct xdemhip_pairs {
     unsigned long long *counts = nullptr, *hist = nullptr;
     void *prefix = nullptr, *succ = nullptr;
     int64_t n_wg = 0, n_wg_big = 0, n_pairs = 0;
+    // bracketed selection state (xdemhip_pairs_medians)
+    int sample = 0;
+    void* khi = nullptr;
+    unsigned long long *cnt3 = nullptr, *cand_ctr = nullptr;
+    void* cand_v = nullptr;
+    uint16_t* cand_b = nullptr;
+    long long cand_cap = 0;
 };
 
 namespace {
@@ -270,15 +331,16 @@ namespace {
 constexpr int HIST_BINS_PER_SWEEP = 128;
 
 template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
-    size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 8 * (size_t)nb + sizeof(T) * PT + 8;
+    size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8;
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
+    if (op == OP_BRACKET) return base + (size_t)3 * nb * NCOPY * 4 + 8 + (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
     return base + (size_t)nb * NCOPY * 12;
 }
 
 template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int first, int bin0, int nbs) {
     xdemhip_ctx* ctx = P->ctx;
-    constexpr int NT = (OP == OP_HIST) ? 1024 : 256;  // histograms: 16 waves share one 51 KB LDS table -> full occupancy
+    constexpr int NT = (OP == OP_HIST || OP == OP_BRACKET) ? 1024 : 256;  // histograms: 16 waves share one 51 KB LDS table -> full occupancy
     PairArgs<T> a;
     a.ax = P->ax; a.ay = P->ay; a.bx = P->bx; a.by = P->by;
     a.av = static_cast<const T*>(P->av); a.bv = static_cast<const T*>(P->bv);
@@ -288,6 +350,9 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     a.prefix = static_cast<const typename KeyT<T>::type*>(P->prefix);
     a.succ = static_cast<unsigned long long*>(P->succ);
     a.shift = shift; a.first = first; a.bin0 = bin0; a.nbs = nbs;
+    a.sample = P->sample;
+    a.khi = static_cast<const typename KeyT<T>::type*>(P->khi);
+    a.cnt3 = P->cnt3; a.cand_v = static_cast<T*>(P->cand_v); a.cand_b = P->cand_b; a.cand_ctr = P->cand_ctr; a.cand_cap = P->cand_cap;
     const size_t lds = lds_bytes<T>(P->nb, OP, nbs);
     const int64_t n_wg = (NT == 1024) ? P->n_wg_big : P->n_wg;
     if (n_wg > 0x7fffffff) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many pair tiles for one launch");
@@ -505,6 +570,205 @@ int xdemhip_pairs_succ(xdemhip_pairs* P, const uint64_t* key, uint64_t* succ) {
     XD_HIP_CHECK(ctx, hipMemcpyAsync(succ, P->succ, 8 * P->nb, hipMemcpyDeviceToHost, ctx->stream));  // all-ones = none
     XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return XDEMHIP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <typename K> __global__ void extract_prefix_kernel(const SelState<K>* st, K* out, int nb) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nb) out[k] = st[k].prefix;
+}
+
+template <typename T> __host__ inline T abs_key_value(typename KeyT<T>::type key) {  // inverse of key_abs
+    typename KeyT<T>::type bits = key >> 1;
+    T v;
+    memcpy(&v, &bits, sizeof(T));
+    return v;
+}
+
+// 8-bit digit passes over the pairs (all of them, or the 1/64 unit sample) with the selection state kept on the device;
+// histograms go through the all-reduce hook, so sharded pair sets select the same global order statistics.
+template <typename T>
+int pairs_digit_passes(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st, int sample, int mode, const uint64_t* d_given,
+                       std::vector<SelState<typename KeyT<T>::type>>& out) {
+    typedef typename KeyT<T>::type K;
+    xdemhip_ctx* ctx = P->ctx;
+    const int nb = P->nb, passes = KeyT<T>::passes;
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_st, 0, sizeof(SelState<K>) * nb, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->hist, 0, 8 * (size_t)nb * SEL_RADIX, ctx->stream));
+    P->sample = sample;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * (passes - 1 - p);
+        if (P->n_wg_big > 0)
+            for (int b0 = 0; b0 < nb; b0 += HIST_BINS_PER_SWEEP) {
+                const int nbs = (nb - b0) < HIST_BINS_PER_SWEEP ? (nb - b0) : HIST_BINS_PER_SWEEP;
+                int rc = launch_pairs<T, OP_HIST>(P, shift, (int)(p == 0), b0, nbs);
+                if (rc) { P->sample = 0; return rc; }
+            }
+        int rc = xd_allreduce_device(ctx, P->hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
+        if (rc) { P->sample = 0; return rc; }
+        hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, d_st, reinterpret_cast<uint64_t*>(P->hist), nb,
+                           shift, (int)(p == 0), (int)(p == passes - 1), mode, d_given);
+        hipLaunchKernelGGL((extract_prefix_kernel<K>), dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, d_st, static_cast<K*>(P->prefix), nb);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    P->sample = 0;
+    out.resize(nb);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(out.data(), d_st, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
+template <typename T>
+int pairs_medians_plain(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st, int64_t* counts, double* medians) {
+    typedef typename KeyT<T>::type K;
+    xdemhip_ctx* ctx = P->ctx;
+    const int nb = P->nb;
+    std::vector<SelState<K>> st;
+    int rc = pairs_digit_passes<T>(P, d_st, 0, SEL_MEDIAN, nullptr, st);
+    if (rc) return rc;
+    // successor of the selected key per class (upper median of even classes); P->prefix holds the selected keys
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->succ, 0xFF, 8 * (size_t)nb, ctx->stream));
+    if (P->n_wg > 0) {
+        rc = launch_pairs<T, OP_SUCC>(P, 0, 0, 0, 0);
+        if (rc) return rc;
+    }
+    rc = xd_allreduce_device(ctx, P->succ, nb, XDEMHIP_RED_MIN_U64);
+    if (rc) return rc;
+    std::vector<uint64_t> succ(nb);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(succ.data(), P->succ, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < nb; ++k) {
+        counts[k] = (int64_t)st[k].count;
+        if (st[k].count == 0) { medians[k] = NAN; continue; }
+        const T lo = abs_key_value<T>(st[k].prefix);
+        if (st[k].count & 1) { medians[k] = (double)lo; continue; }
+        const uint64_t k2 = st[k].count / 2;
+        const T hi = (st[k].n_le > k2) ? lo : abs_key_value<T>((K)succ[k]);
+        medians[k] = (double)(T)((T)(lo + hi) / (T)2);
+    }
+    return XDEMHIP_OK;
+}
+
+constexpr int64_t PAIRS_BRACKET_MIN = (int64_t)4000000000ll;  // pairs; below this the sample units are too few
+
+template <typename T>
+int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
+    typedef typename KeyT<T>::type K;
+    xdemhip_ctx* ctx = P->ctx;
+    const int nb = P->nb;
+    // small device block: selection states | klo | khi | given | counters[3 nb] | candidate counter, overflow
+    unsigned char* d_small = nullptr;
+    const size_t off_klo = (size_t)nb * 32, off_khi = off_klo + 8 * (size_t)nb, off_given = off_khi + 8 * (size_t)nb,
+                 off_cnt = off_given + 8 * (size_t)nb, off_ctr = off_cnt + 24 * (size_t)nb, small_bytes = off_ctr + 16;
+    if (hipMalloc(reinterpret_cast<void**>(&d_small), small_bytes) != hipSuccess) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+    SelState<K>* d_st = reinterpret_cast<SelState<K>*>(d_small);
+    void* scratch = nullptr;
+    auto cleanup = [&]() {
+        if (P->cand_v) (void)hipFree(P->cand_v);
+        if (P->cand_b) (void)hipFree(P->cand_b);
+        P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0; P->khi = nullptr; P->cnt3 = nullptr; P->cand_ctr = nullptr;
+        if (scratch) (void)hipFree(scratch);
+        (void)hipFree(d_small);
+    };
+    bool bracket = ctx->selection_mode != 1 && nb <= HIST_BINS_PER_SWEEP && P->n_pairs >= PAIRS_BRACKET_MIN && P->n_wg_big >= 256;
+    if (bracket) {
+        P->cand_cap = (long long)(P->n_pairs / 64 + (1 << 20));
+        if (hipMalloc(&P->cand_v, (size_t)P->cand_cap * sizeof(T)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)P->cand_cap * 2) != hipSuccess ||
+            hipMalloc(&scratch, scratch_size(nb)) != hipSuccess)
+            bracket = false;  // not enough memory for the candidates: plain passes
+    }
+    if (ctx->allreduce) {  // sharded pair sets: every rank must take the same route
+        uint64_t can = bracket ? 1 : 0;
+        if (ctx->allreduce(&can, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed"); }
+        bracket = can != 0;
+    }
+    int rc = XDEMHIP_OK;
+    bool done = false;
+    if (bracket) {
+        std::vector<SelState<K>> lo, hi;
+        rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo);
+        if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi);
+        if (rc) { cleanup(); return rc; }
+        std::vector<K> klo(nb), khi(nb);
+        for (int k = 0; k < nb; ++k) {
+            const bool have = lo[k].count > 0;
+            klo[k] = have ? lo[k].prefix : (K)0;
+            khi[k] = have ? hi[k].prefix : (K)~(K)0;
+            if (ctx->selection_mode == 2 && have) khi[k] = klo[k];  // test mode: brackets that (almost surely) miss
+        }
+        K* d_klo = reinterpret_cast<K*>(d_small + off_klo);
+        K* d_khi = reinterpret_cast<K*>(d_small + off_khi);
+        uint64_t* d_given = reinterpret_cast<uint64_t*>(d_small + off_given);
+        P->cnt3 = reinterpret_cast<unsigned long long*>(d_small + off_cnt);
+        P->cand_ctr = reinterpret_cast<unsigned long long*>(d_small + off_ctr);
+        P->khi = d_khi;
+        hipError_t e = hipMemcpyAsync(P->prefix, klo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_khi, khi.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_small + off_cnt, 0, 24 * (size_t)nb + 16, ctx->stream);
+        (void)d_klo;
+        if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket setup failed"); }
+        if (P->n_wg_big > 0) {
+            XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+            rc = launch_pairs<T, OP_BRACKET>(P, 0, 0, 0, 0);
+            (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+            ctx->timed = rc == XDEMHIP_OK;
+        }
+        if (rc == XDEMHIP_OK) rc = xd_allreduce_device(ctx, P->cnt3, 3 * (int64_t)nb, XDEMHIP_RED_SUM_U64);
+        if (rc == XDEMHIP_OK) rc = xd_allreduce_device(ctx, P->cand_ctr + 1, 1, XDEMHIP_RED_SUM_U64);
+        if (rc) { cleanup(); return rc; }
+        std::vector<uint64_t> cnt(3 * nb);
+        uint64_t ctr[2];
+        e = hipMemcpyAsync(cnt.data(), P->cnt3, 24 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctr, P->cand_ctr, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, std::string("bracket pass failed: ") + hipGetErrorString(e)); }
+        bool ok = ctr[1] == 0;
+        std::vector<uint64_t> given(nb);
+        for (int k = 0; k < nb && ok; ++k) {
+            const uint64_t total = cnt[k], lt = cnt[nb + k], in = cnt[2 * nb + k];
+            given[k] = ~(uint64_t)0;
+            if (total == 0) continue;
+            const uint64_t r = (total - 1) / 2;
+            const uint64_t need = (total & 1) ? r : r + 1;
+            if (lt > r || need - lt >= in) ok = false;
+            else given[k] = r - lt;
+        }
+        if (ok) {
+            e = hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket ranks upload failed"); }
+            std::vector<SelResult<K>> res;
+            rc = run_select_core<T>(ctx, static_cast<const T*>(P->cand_v), P->cand_b, (int64_t)ctr[0], nb, static_cast<unsigned char*>(scratch),
+                                    res, SEL_GIVEN, d_given);
+            if (rc) { cleanup(); return rc; }
+            for (int k = 0; k < nb; ++k) {
+                counts[k] = (int64_t)cnt[k];
+                if (cnt[k] == 0) { medians[k] = NAN; continue; }
+                res[k].st.count = cnt[k];
+                res[k].st.n_le += cnt[nb + k];
+                medians[k] = median_from<T>(res[k]);
+            }
+            done = true;
+        }
+    }
+    if (!done) rc = pairs_medians_plain<T>(P, d_st, counts, medians);
+    cleanup();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xdemhip_pairs_medians(xdemhip_pairs* P, int64_t* counts, double* medians) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (!counts || !medians) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return P->val_dtype == XDEMHIP_F32 ? pairs_medians_typed<float>(P, counts, medians) : pairs_medians_typed<double>(P, counts, medians);
 }
 
 }  // extern "C"

@@ -113,8 +113,27 @@ def _allreduce(arr: np.ndarray, group=None) -> np.ndarray:
 
 
 def class_medians(pairs: PairSet, group=None):
-    """Exact per-class median of |dv| (np.median semantics) + counts, by MSD radix selection: 8 bits per pass,
-    integer histograms from the GPU (summed over ranks when distributed), selection advanced on the host."""
+    """Exact per-class median of |dv| (np.median semantics) + counts (``xdemhip_pairs_medians``): radix selection with the
+    state on the device, bracketed for large pair sets.  With an initialised process group every rank holds its share of the
+    blocks; the integer histograms / counters are combined through the library's reduction hook (exact)."""
+    ctx = pairs.ctx
+    hooked = group is not None or _dist_on()
+    if hooked:
+        ctx.set_allreduce("world" if group is None else group)
+    try:
+        counts = np.zeros(pairs.nb, dtype=np.int64)
+        med = np.full(pairs.nb, np.nan)
+        ctx.check(ctx._L.xdemhip_pairs_medians(pairs.handle, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                               med.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+    finally:
+        if hooked:
+            ctx.set_allreduce(None)
+    return med, counts
+
+
+def class_medians_host_driven(pairs: PairSet, group=None):
+    """The same selection advanced on the host from raw digit histograms (``xdemhip_pairs_hist`` / ``_succ``): the
+    pass-by-pass form of the C-ABI, kept as an independent cross-check of ``class_medians``."""
     nb, bits = pairs.nb, pairs.key_bits
     passes = bits // 8
     prefix = np.zeros(nb, dtype=np.uint64)
