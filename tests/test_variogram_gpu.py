@@ -204,3 +204,29 @@ def test_class_medians_routes_agree(ss, dtype):
     finally:
         ctx.set_option("selection", 0)
         ps.close()
+
+
+def test_class_medians_through_reduction_hook_single_rank(ss):
+    """The sharded route (integer histograms / counters / successor keys all-reduced through the library hook with
+    torch.distributed) on a 1-rank NCCL group equals the plain single-process result."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29613")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        blocks = [_pts(300, 1, np.float32) + _pts(1500, 2, np.float32), _pts(700, 3, np.float32)[:3] + _pts(901, 4, np.float32)]
+        want = ss.empirical_variogram_pairs(blocks, EDGES, "dowd")
+        got = ss.empirical_variogram_pairs(blocks, EDGES, "dowd", group=dist.group.WORLD)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0], equal_nan=True)
+        got_m = ss.empirical_variogram_pairs(blocks, EDGES, "matheron", group=dist.group.WORLD)
+        want_m = ss.empirical_variogram_pairs(blocks, EDGES, "matheron")
+        assert np.array_equal(got_m[1], want_m[1]) and np.allclose(got_m[0], want_m[0], rtol=1e-12, atol=0, equal_nan=True)  # (float64 atomics: order varies)
+    finally:
+        if created:
+            dist.destroy_process_group()
