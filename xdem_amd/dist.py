@@ -55,6 +55,8 @@ class RowBlock:
         under RCCL).  Returns the work handles; call ``wait_all`` before launching kernels that read the halo."""
         if self.world == 1:
             return []
+        if self.buf.is_cuda and dist.get_backend(group) == "gloo":
+            return self._exchange_staged(group)
         d, ops = self.depth, []
         up, down = self.rank - 1, self.rank + 1
         if up >= 0:
@@ -64,6 +66,34 @@ class RowBlock:
             ops.append(dist.P2POp(dist.isend, self.interior[-d:].contiguous(), down, group))
             ops.append(dist.P2POp(dist.irecv, self.buf[self.halo_top + self.rows :], down, group))
         return dist.batch_isend_irecv(ops)
+
+    def _exchange_staged(self, group=None) -> list:
+        """Same exchange for device buffers under the gloo backend (no device-side point-to-point there): halo rows are
+        staged through host tensors.  Lets several ranks share one GPU, which RCCL refuses -- used to test the multi-rank
+        path on a single-GPU box; production runs use RCCL."""
+        d = self.depth
+        up, down = self.rank - 1, self.rank + 1
+        ops, landings = [], []
+        if up >= 0:
+            ops.append(dist.P2POp(dist.isend, self.interior[:d].cpu(), up, group))
+            r = torch.empty((self.halo_top, self.buf.shape[1]), dtype=self.buf.dtype)
+            ops.append(dist.P2POp(dist.irecv, r, up, group))
+            landings.append((r, self.buf[: self.halo_top]))
+        if down < self.world:
+            ops.append(dist.P2POp(dist.isend, self.interior[-d:].cpu(), down, group))
+            r = torch.empty((self.halo_bottom, self.buf.shape[1]), dtype=self.buf.dtype)
+            ops.append(dist.P2POp(dist.irecv, r, down, group))
+            landings.append((r, self.buf[self.halo_top + self.rows :]))
+        works = dist.batch_isend_irecv(ops)
+
+        class _Landing:
+            def wait(self_inner):
+                for w in works:
+                    w.wait()
+                for src, dst in landings:
+                    dst.copy_(src)
+
+        return [_Landing()]
 
     @staticmethod
     def wait_all(works: list) -> None:
@@ -99,7 +129,7 @@ def terrain_row_block(block: RowBlock, attribute: list[str], out: torch.Tensor |
     # interior: output rows [top_n, rows - bot_n) only read this rank's own rows
     top_n = d if ht else 0
     bot_n = d if hb else 0
-    b0 = ht + top_n - d  # first buffer row the interior launch may read (its own halo = `d` own rows)
+    b0 = ht  # the interior launch starts at this rank's first own row: output row top_n reads own rows from top_n - d = 0 on
     inner_rows = rows - top_n - bot_n
     inner = block.buf[b0 : ht + rows - bot_n + (d if bot_n else 0)]
     terrain_attributes_device(inner, attribute, out=_rows(out, top_n, inner_rows), halo_top=(d if top_n else 0),
