@@ -64,7 +64,11 @@ int xdemhip_version(void);
 int xdemhip_create(int device_id, xdemhip_ctx** out_ctx);
 void xdemhip_destroy(xdemhip_ctx* ctx);
 const char* xdemhip_last_error(const xdemhip_ctx* ctx);
-/* Use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+/* Enqueue on the caller's hipStream_t, e.g. torch.cuda.current_stream().cuda_stream -- NULL (0) is HIP's default stream,
+ * which is what torch reports for its default stream: device-resident calls are then ordered with the caller's own kernels.
+ * XDEMHIP_OWN_STREAM returns to the context's private non-blocking stream (the initial setting; host-buffer calls synchronise
+ * it themselves). */
+#define XDEMHIP_OWN_STREAM ((void*)(intptr_t)-1)
 int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream);
 int xdemhip_synchronize(xdemhip_ctx* ctx);
 /* Timing of the work enqueued by the last call on the context stream, measured with hipEvents recorded on

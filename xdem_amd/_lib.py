@@ -167,7 +167,10 @@ class Context:
             raise XdemHipError(f"libxdemhip status {rc}: {msg.decode() if msg else ''}")
 
     def set_stream(self, stream_ptr: int | None) -> None:
-        self.check(self._L.xdemhip_set_stream(self.handle, ctypes.c_void_p(stream_ptr or 0)))
+        """Stream for device-resident calls: a hipStream_t value (0 = HIP's default stream, which is torch's default stream);
+        None = the context's private stream."""
+        v = ctypes.c_void_p(-1) if stream_ptr is None else ctypes.c_void_p(stream_ptr)
+        self.check(self._L.xdemhip_set_stream(self.handle, v))
 
     def set_allreduce(self, group="world") -> None:
         """Install (group given) or remove (group=None) the multi-GPU reduction hook: small 8-byte-element host arrays

@@ -48,7 +48,9 @@ const char* xdemhip_last_error(const xdemhip_ctx* ctx) { return ctx ? ctx->err.c
 
 int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream) {
     if (!ctx) return XDEMHIP_EINVAL;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    // NULL is a stream too: HIP's default stream, which is what torch.cuda.current_stream().cuda_stream reports (0) unless the
+    // caller switched streams -- work must be ordered with the caller's kernels on it, not parked on a private stream
+    ctx->stream = (hip_stream == XDEMHIP_OWN_STREAM) ? ctx->own_stream : static_cast<hipStream_t>(hip_stream);
     return XDEMHIP_OK;
 }
 
