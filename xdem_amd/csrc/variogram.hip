@@ -56,7 +56,7 @@ template <typename T> struct PairArgs {
     int sample;                    // OP_HIST: only the pseudo-randomly chosen 1/64 of the (A tile x B tile) units
     // OP_BRACKET (bracketed selection, select_run.h): keys in [prefix[k], khi[k]] are candidates
     const typename KeyT<T>::type* khi;
-    unsigned long long* cnt3;      // [3][nb]: pairs per class, below the bracket, inside it
+    unsigned long long* cnt3;      // [3][nb]: pairs per class at or above the bracket's low end, below it, inside the bracket
     T* cand_v;                     // candidate |dv|
     uint16_t* cand_b;              // and their class
     unsigned long long* cand_ctr;  // [0] count, [1] overflow flag
@@ -169,9 +169,10 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 if (ok) {
                     const K key = key_abs(d);
                     const int cp = tid & (NCOPY - 1);
-                    atomicAdd(&s_c3[(0 * nb + l) * NCOPY + cp], 1u);
-                    if (key < s_pref[l]) atomicAdd(&s_c3[(1 * nb + l) * NCOPY + cp], 1u);
-                    else if (key <= s_khi[l]) { atomicAdd(&s_c3[(2 * nb + l) * NCOPY + cp], 1u); cand = true; }
+                    // one counter update per pair: [0] keys at or above the bracket's low end, [1] below it, [2] inside it
+                    const bool below = key < s_pref[l];
+                    atomicAdd(&s_c3[((below ? 1 : 0) * nb + l) * NCOPY + cp], 1u);
+                    if (!below && key <= s_khi[l]) { atomicAdd(&s_c3[(2 * nb + l) * NCOPY + cp], 1u); cand = true; }
                 }
                 stage.append_bounded(cand, d, (uint16_t)l, &a.cand_ctr[1]);
             };
@@ -728,6 +729,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, std::string("bracket pass failed: ") + hipGetErrorString(e)); }
         bool ok = ctr[1] == 0;
         std::vector<uint64_t> given(nb);
+        for (int k = 0; k < nb; ++k) cnt[k] += cnt[nb + k];  // class total = (keys >= low end) + (keys below it)
         for (int k = 0; k < nb && ok; ++k) {
             const uint64_t total = cnt[k], lt = cnt[nb + k], in = cnt[2 * nb + k];
             given[k] = ~(uint64_t)0;
