@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -99,9 +101,27 @@ __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __rest
 
 constexpr int MAX_BINS_PER_SWEEP = 128;  // 128 * 256 * 4 B = 128 KiB of LDS histograms per workgroup
 
-template <typename F> int set_big_lds(xdemhip_ctx* ctx, F func, size_t bytes) {
-    if (bytes > 48 * 1024) XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+// Opt a kernel into more than 48 KiB of dynamic LDS.  hipFuncSetAttribute is a driver call (tens of microseconds, and the
+// selection launches this kernel dozens of times per step): repeated only when a launch needs more than was granted before.
+inline int set_big_lds_ptr(xdemhip_ctx* ctx, const void* func, size_t bytes) {
+    if (bytes <= 48 * 1024) return XDEMHIP_OK;
+    struct Entry { const void* f; int dev; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Entry> done;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& d : done)
+        if (d.f == func && d.dev == ctx->device) {
+            if (d.bytes >= bytes) return XDEMHIP_OK;
+            XD_HIP_CHECK(ctx, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            d.bytes = bytes;
+            return XDEMHIP_OK;
+        }
+    XD_HIP_CHECK(ctx, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.push_back({func, ctx->device, bytes});
     return XDEMHIP_OK;
+}
+template <typename F> int set_big_lds(xdemhip_ctx* ctx, F func, size_t bytes) {
+    return set_big_lds_ptr(ctx, reinterpret_cast<const void*>(func), bytes);
 }
 
 inline int grid_for(const xdemhip_ctx* ctx, int64_t n, int block, int per_cu) {

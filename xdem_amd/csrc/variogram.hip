@@ -358,14 +358,10 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     const int64_t n_wg = (NT == 1024) ? P->n_wg_big : P->n_wg;
     if (n_wg > 0x7fffffff) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many pair tiles for one launch");
     if (P->lut) {
-        if (lds > 48 * 1024)
-            XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_kernel<T, OP, true, NT>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT>, lds)) return rc;
         hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3((unsigned)n_wg), dim3(NT), lds, ctx->stream, a);
     } else {
-        if (lds > 48 * 1024)
-            XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pairs_kernel<T, OP, false, NT>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, false, NT>, lds)) return rc;
         hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3((unsigned)n_wg), dim3(NT), lds, ctx->stream, a);
     }
     XD_HIP_CHECK(ctx, hipGetLastError());
