@@ -70,3 +70,95 @@ def test_row_blocks_on_real_kernels_equal_full_raster(world, tmp_path):
     got = np.concatenate([np.load(os.path.join(str(tmp_path), f"rank{r}.npy")) for r in range(world)], axis=1)
     assert got.shape == full.shape
     assert np.array_equal(got.view(np.int32), full.view(np.int32))
+
+
+def _worker_reductions(rank, world, port, outdir):
+    """Nuth-Kaab step and Dowd variogram with the data sharded over `world` ranks (one GPU shared, gloo): every rank must
+    end up with the single-process results (integer histograms / counters all-reduced through the library hook)."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from xdem_amd import _lib, coreg
+        from xdem_amd import spatialstats as ss
+        from xdem_amd.synth import fbm_numpy
+
+        torch.cuda.set_device(0)
+        ctx = _lib.default_context(0)
+        res = {}
+        for m in (300, 3072):  # plain digit passes / bracketed selection (>= 4 M pixels per rank)
+            ref = fbm_numpy((m, m), seed=5)
+            rng = np.random.default_rng(6)
+            tba = (np.roll(ref, (1, -1), (0, 1)) + 1.5 + rng.normal(0, 0.3, (m, m))).astype(np.float32)
+            tba[rng.uniform(size=(m, m)) < 0.1] = np.nan
+            plan = coreg.NKPlan(ref, tba, None, ctx, group="world")
+            d = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+            plan.close()
+            res[f"nk{m}"] = np.concatenate([[d["vshift"], d["n_valid"], d["y_mean"]], d["counts"], d["medians"], d["edges"]])
+        rng = np.random.default_rng(9)
+        blocks = []
+        for _ in range(6):
+            ax, ay = rng.uniform(0, 5000, 700), rng.uniform(0, 5000, 700)
+            bx, by = rng.uniform(0, 5000, 3000), rng.uniform(0, 5000, 3000)
+            av = np.round(np.sin(ax / 500) + 0.2 * rng.normal(size=700), 2).astype(np.float32)
+            bv = np.round(np.sin(bx / 500) + 0.2 * rng.normal(size=3000), 2).astype(np.float32)
+            blocks.append((ax, ay, av, bx, by, bv))
+        edges = np.geomspace(np.sqrt(2), 7100.0, 30)
+        mine = blocks[rank::world]
+        e, c = ss.empirical_variogram_pairs(mine, edges, "dowd", ctx)
+        res["dowd"] = np.concatenate([e, c.astype(np.float64)])
+        e, c = ss.empirical_variogram_pairs(mine, edges, "matheron", ctx)
+        res["matheron_count"] = c.astype(np.float64)
+        res["matheron"] = e
+        np.savez(os.path.join(outdir, f"red{rank}.npz"), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_reductions_on_real_kernels(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = 29800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker_reductions, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    # single-process references
+    from xdem_amd import coreg
+    from xdem_amd import spatialstats as ss
+    from xdem_amd.synth import fbm_numpy
+
+    got = [np.load(os.path.join(str(tmp_path), f"red{r}.npz")) for r in range(world)]
+    for m in (300, 3072):
+        ref = fbm_numpy((m, m), seed=5)
+        rng = np.random.default_rng(6)
+        tba = (np.roll(ref, (1, -1), (0, 1)) + 1.5 + rng.normal(0, 0.3, (m, m))).astype(np.float32)
+        tba[rng.uniform(size=(m, m)) < 0.1] = np.nan
+        plan = coreg.NKPlan(ref, tba, None)
+        d = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+        plan.close()
+        want = np.concatenate([[d["vshift"], d["n_valid"], d["y_mean"]], d["counts"], d["medians"], d["edges"]])
+        for g in got:
+            a = g[f"nk{m}"]
+            assert np.array_equal(np.delete(a, 2), np.delete(want, 2), equal_nan=True), m   # exact: selections, counts, edges
+            assert np.isclose(a[2], want[2], rtol=1e-12)                                      # float64 sum of y: order differs
+    rng = np.random.default_rng(9)
+    blocks = []
+    for _ in range(6):
+        ax, ay = rng.uniform(0, 5000, 700), rng.uniform(0, 5000, 700)
+        bx, by = rng.uniform(0, 5000, 3000), rng.uniform(0, 5000, 3000)
+        av = np.round(np.sin(ax / 500) + 0.2 * rng.normal(size=700), 2).astype(np.float32)
+        bv = np.round(np.sin(bx / 500) + 0.2 * rng.normal(size=3000), 2).astype(np.float32)
+        blocks.append((ax, ay, av, bx, by, bv))
+    edges = np.geomspace(np.sqrt(2), 7100.0, 30)
+    e, c = ss.empirical_variogram_pairs(blocks, edges, "dowd")
+    em, cm = ss.empirical_variogram_pairs(blocks, edges, "matheron")
+    for g in got:
+        assert np.array_equal(g["dowd"], np.concatenate([e, c.astype(np.float64)]), equal_nan=True)
+        assert np.array_equal(g["matheron_count"], cm.astype(np.float64))
+        assert np.allclose(g["matheron"], em, rtol=1e-12, atol=0, equal_nan=True)
