@@ -64,6 +64,40 @@ def measured_traffic_bytes(pixels_per_launch: int):
     return best
 
 
+def secondary_cpu_baselines() -> dict:
+    """The CPU ports (oracles) of the two other paths on bounded samples (reported as rates, never extrapolated)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import nuthkaab_oracle as nko
+    import variogram_oracle as vo
+    from xdem_amd.synth import fbm_numpy
+
+    out = {}
+    m = 2000
+    rng = np.random.default_rng(1)
+    ref = fbm_numpy((m, m), seed=42)
+    tba = (np.roll(ref, (1, -2), (0, 1)) + 2.0).astype(np.float32)
+    tba[rng.uniform(size=(m, m)) < 0.2] = np.nan
+    st, asp = nko.aux_vars(ref)
+    valid = np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+    t0 = time.perf_counter()
+    nko.iteration_step((0.0, 0.0, 0.0), ref, tba, valid, st, asp, (10.0, 10.0), 72)
+    dt = time.perf_counter() - t0
+    out["nuthkaab"] = {"value": round(m * m / dt / 1e6, 3), "unit": "Mpixel_iterations_s", "cores": 1, "kind": "port",
+                       "sample": f"{m}x{m} pair, one iteration step, oracle/nuthkaab_oracle.py, {dt:.1f} s"}
+    n = 5000
+    x, y = rng.uniform(0, 20000, n), rng.uniform(0, 20000, n)
+    v = (np.sin(x / 900) + 0.2 * rng.normal(size=n)).astype(np.float32)
+    edges = np.geomspace(np.sqrt(2), np.hypot(20000, 20000), 50)
+    t0 = time.perf_counter()
+    _, c = vo.empirical_variogram_blocks([(x, y, v)], edges, "dowd")
+    dt = time.perf_counter() - t0
+    out["variogram"] = {"value": round(float(c.sum()) / dt / 1e9, 5), "unit": "Gpairs_s", "cores": 1, "kind": "port",
+                        "sample": f"pdist of {n} points ({int(c.sum())} pairs), 50 classes, Dowd, oracle/variogram_oracle.py, {dt:.1f} s"}
+    return out
+
+
 def secondary_metrics(ctx, dev) -> dict:
     """The other two hot paths at BASELINE.json's configurations (reported next to the headline metric, not part of
     `value`): C5 reading B of SURVEY.md 8d for the variogram, C3 for Nuth-Kaab."""
@@ -239,6 +273,8 @@ def main() -> None:
                 del out, block
                 torch.cuda.empty_cache()
                 res["secondary"] = secondary_metrics(ctx, dev)
+                if not args.no_cpu_baseline:
+                    res["secondary"]["cpu_baseline"] = secondary_cpu_baselines()
             except Exception as e:  # the headline line must still be printed
                 res["secondary"] = {"error": repr(e)}
         print(json.dumps(res))
