@@ -362,3 +362,73 @@ def test_texture_shading_properties_large():
     assert np.abs(sc[ok] - 3.0 * got64[ok]).max() <= 1e-9 * np.abs(got64[ok]).max()
     both = t.get_terrain_attribute(dem, ["texture_shading", "slope", "fractal_roughness"], resolution=10.0)
     assert np.array_equal(both[0], got, equal_nan=True) and both[1].shape == dem.shape
+
+
+def test_randomised_configurations_vs_oracle():
+    """Seeded sweep over what the fixed grids above do not enumerate: random attribute subsets in random order (runtime-mask
+    kernels, plane ordering), odd raster shapes down to 1 x N, both dtypes, all fits / curvature methods, random resolutions,
+    hillshade settings, TRI methods, window sizes, NaN / Inf holes -- every output against the oracle with the shared metric."""
+    from xdem_amd import terrain as t
+
+    rng = np.random.default_rng(20260926)
+    surf = ["slope", "aspect", "hillshade", "curvature", "profile_curvature", "tangential_curvature", "planform_curvature",
+            "flowline_curvature", "max_curvature", "min_curvature"]
+    win = ["topographic_position_index", "terrain_ruggedness_index", "roughness", "rugosity"]
+    n_checked = 0
+    for trial in range(160):
+        H, W = int(rng.integers(1, 90)), int(rng.integers(1, 300))
+        dtype = rng.choice([np.float32, np.float64])
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            dem = rng.normal(1500, 200, (H, W))
+        elif kind == 1:
+            dem = 300 + np.cumsum(np.cumsum(rng.normal(0, 0.3, (H, W)), 0), 1)
+        else:
+            dem = np.round(rng.uniform(0, 40, (H, W)))  # ties, flats
+        dem = dem.astype(dtype)
+        for _ in range(int(rng.integers(0, 4))):
+            dem[rng.integers(0, H), rng.integers(0, W)] = rng.choice([np.nan, np.inf, -np.inf])
+        fit = str(rng.choice(["Horn", "ZevenbergThorne", "Florinsky"]))
+        pool = (surf[:3] if fit == "Horn" else surf) + win
+        k = int(rng.integers(1, len(pool) + 1))
+        attrs = [str(a) for a in rng.choice(pool, size=k, replace=False)]
+        kw = dict(resolution=float(rng.choice([0.25, 1.0, 7.5, 30.0])), surface_fit=fit,
+                  curv_method=str(rng.choice(["geometric", "directional"])), degrees=bool(rng.integers(0, 2)),
+                  hillshade_altitude=float(rng.uniform(0, 90)), hillshade_azimuth=float(rng.uniform(0, 360)),
+                  hillshade_z_factor=float(rng.choice([1.0, 0.5, 3.0])), tri_method=str(rng.choice(["Riley", "Wilson"])),
+                  window_size=int(rng.choice([3, 3, 5, 7])))
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = t.get_terrain_attribute(dem, attrs, **kw)
+            ref = to.terrain_attributes(dem, attrs, **kw)
+        got = got if isinstance(got, list) else [got]
+        # Pixels whose two first derivatives cancel EXACTLY (integer-valued DEMs): the reference's non-cancelling w/divider
+        # weights leave |grad| ~ 1e-15 of rounding noise there, so its aspect and its gradient-normalised curvatures are that
+        # noise; the kernel's integer-weighted sums give the exact 0 (DESIGN.md, "Numerical recipe").  Not comparable.
+        degenerate = None
+        if fit in ("ZevenbergThorne", "Florinsky", "Horn") and any(a in attrs for a in surf):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sl = to.terrain_attributes(dem, ["slope"], **{**kw, "degrees": False})[0]
+            degenerate = np.isfinite(sl) & (sl < 1e-9)
+        for a, g, r in zip(attrs, got, ref):
+            if degenerate is not None and a in surf and a not in ("slope", "hillshade", "curvature"):
+                g, r = g.copy(), r.copy()
+                g[degenerate] = np.nan
+                r[degenerate] = np.nan
+            if a in ("rugosity", "roughness"):
+                assert np.array_equal(g, r, equal_nan=True), (trial, a, kw, dem.shape, dtype)
+            elif a == "aspect":
+                # an angle: where a derivative cancels exactly (integer-valued DEMs) the reference's rounding noise decides
+                # between 0 and 2 pi, the kernel returns 0 -- compare on the circle
+                period = 360.0 if kw["degrees"] else 2 * np.pi
+                assert np.array_equal(np.isnan(g), np.isnan(r))
+                ok = np.isfinite(r)
+                d = np.abs(g[ok].astype(np.float64) - r[ok])
+                assert np.all(np.minimum(d, period - d) <= 1e-6 * period), (trial, kw, dem.shape, dtype)
+            else:
+                assert_parity(g, r, f"trial {trial} {a} {fit} {dem.shape} {np.dtype(dtype).name} {kw}")
+            n_checked += 1
+    assert n_checked > 800
