@@ -44,6 +44,20 @@ def _worker(rank, world, port, n, outdir):
             res[overlap] = out.cpu().numpy()
         assert np.array_equal(res[True].view(np.int32), res[False].view(np.int32))
         np.save(os.path.join(outdir, f"rank{rank}.npy"), res[True])
+        # second configuration: 7 x 7 windowed indexes (generic window kernel, halo depth 3 > the 3 x 3 fit's 1) + ZT fit
+        attrs2 = ["slope", "max_curvature", "topographic_position_index", "terrain_ruggedness_index", "roughness"]
+        depth2 = xd.halo_depth(attrs2, "ZevenbergThorne", 7)
+        assert depth2 == 3
+        block2 = xd.RowBlock(n, n, depth2, rank, world, dev)
+        block2.buf.fill_(float("nan"))
+        block2.interior.copy_(block.interior)
+        for overlap in (True, False):
+            out2 = xd.terrain_row_block(block2, attrs2, overlap=overlap, resolution=10.0, surface_fit="ZevenbergThorne",
+                                        window_size=7, ctx=ctx)
+            torch.cuda.synchronize()
+            res[overlap] = out2.cpu().numpy()
+        assert np.array_equal(res[True].view(np.int32), res[False].view(np.int32))
+        np.save(os.path.join(outdir, f"rank{rank}_w7.npy"), res[True])
     finally:
         dist.destroy_process_group()
 
@@ -70,6 +84,12 @@ def test_row_blocks_on_real_kernels_equal_full_raster(world, tmp_path):
     got = np.concatenate([np.load(os.path.join(str(tmp_path), f"rank{r}.npy")) for r in range(world)], axis=1)
     assert got.shape == full.shape
     assert np.array_equal(got.view(np.int32), full.view(np.int32))
+    attrs2 = ["slope", "max_curvature", "topographic_position_index", "terrain_ruggedness_index", "roughness"]
+    full2 = terrain_attributes_device(fbm_torch(n, n, dev, seed=42), attrs2, resolution=10.0, surface_fit="ZevenbergThorne",
+                                      window_size=7)
+    torch.cuda.synchronize()
+    got2 = np.concatenate([np.load(os.path.join(str(tmp_path), f"rank{r}_w7.npy")) for r in range(world)], axis=1)
+    assert np.array_equal(got2.view(np.int32), full2.cpu().numpy().view(np.int32))
 
 
 def _worker_reductions(rank, world, port, outdir):

@@ -432,3 +432,21 @@ def test_randomised_configurations_vs_oracle():
                 assert_parity(g, r, f"trial {trial} {a} {fit} {dem.shape} {np.dtype(dtype).name} {kw}")
             n_checked += 1
     assert n_checked > 800
+
+
+def test_device_views_strided_and_misaligned():
+    """Device entry on tensor VIEWS: a column window of a wider tensor (row stride > width, base pointer not 16-byte aligned:
+    the scalar tile-load path instead of the float4 one) and a row window; results equal those of the contiguous copy."""
+    import torch
+    from xdem_amd.terrain import terrain_attributes_device
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big = (1000 + 50 * torch.randn((700, 1500), generator=g, device="cuda")).cumsum(0).cumsum(1) * 1e-3 + 500
+    big[100, 333] = float("nan")
+    for (r0, r1, c0, c1) in ((0, 700, 0, 1500), (5, 650, 3, 1290), (17, 400, 64, 1001), (1, 3, 1, 9)):
+        view = big[r0:r1, c0:c1]
+        assert view.stride(1) == 1 and (view.stride(0) != view.shape[1] or (r0, c0) == (0, 0))
+        a = terrain_attributes_device(view, FULL, resolution=10.0)
+        b = terrain_attributes_device(view.contiguous(), FULL, resolution=10.0)
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (r0, r1, c0, c1)
