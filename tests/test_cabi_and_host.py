@@ -151,3 +151,43 @@ def test_nuthkaab_class_contract():
         nk.fit(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
     x = np.linspace(0, 6, 50)
     assert np.allclose(coreg._nuth_kaab_fit_func(x, 2.0, 0.5, 1.0), 2.0 * np.cos(0.5 - x) + 1.0)
+
+
+def test_variogram_models_fit_and_correlation():
+    """Host-side callers of the variogram path (xdem/spatialstats.py:1583-1804): model table checks, sum-of-models fit with
+    the reference's bounds / first guesses, covariance and correlation functions.  (Model formulas restate scikit-gstat's
+    published definitions: parity unpinned, so these are self-consistency checks.)"""
+    import pandas as pd
+
+    from xdem_amd import spatialstats as ss
+    from xdem_amd import variogram_models as vm
+
+    h = np.linspace(0, 100, 51)
+    for name in vm.SUPPORTED:
+        extra = [1.5] if vm.n_params(name) == 3 else []
+        g = getattr(vm, name)(h, 30.0, 2.0, *extra)
+        assert g[0] == 0 and np.all(np.diff(g) >= -1e-12) and abs(g[-1] - 2.0) < 0.02 * 2.0   # monotone, reaches the sill
+        at_range = getattr(vm, name)(np.array([30.0]), 30.0, 2.0, *extra)[0]
+        assert at_range >= 0.94 * 2.0                                                             # effective range: ~95 % of the sill
+        assert vm.model_name(name[:3].upper()) == name and vm.model_name(getattr(vm, name)) == name
+    with pytest.raises(ValueError, match="not recognized"):
+        vm.model_name("nope")
+    true = vm.spherical(h, 30, 0.6) + vm.gaussian(h, 90, 0.4)
+    df = pd.DataFrame({"exp": true[1:], "lags": h[1:], "count": 1000, "err_exp": np.nan})
+    fun, par = ss.fit_sum_model_variogram(["Sph", "Gau"], df)
+    assert list(par["model"]) == ["spherical", "gaussian"]
+    assert np.allclose(par["range"].values, [30, 90], rtol=1e-5) and np.allclose(par["psill"].values, [0.6, 0.4], rtol=1e-5)
+    assert np.allclose(fun(h), true, atol=1e-7)
+    rho = ss.correlation_from_variogram(par)
+    cov = ss.covariance_from_variogram(par)
+    assert rho(np.array([0.0]))[0] == 1.0 and abs(rho(np.array([1e4]))[0]) < 1e-12 and np.isclose(cov(np.array([0.0]))[0], 1.0)
+    # weighted fit path + a 3-parameter model
+    df2 = pd.DataFrame({"exp": vm.stable(h[1:], 40, 1.0, 1.2), "lags": h[1:], "count": 10, "err_exp": 0.01 + 0.0 * h[1:]})
+    _, par2 = ss.fit_sum_model_variogram(["stable"], df2, bounds=[(1, 100), (0.1, 2), (0.5, 2)], p0=[30, 0.8, 1.0])
+    assert np.allclose([par2["range"].values[0], par2["psill"].values[0], par2["smooth"].values[0]], [40, 1.0, 1.2], rtol=1e-4)
+    with pytest.raises(ValueError, match='must contain the columns "model", "range" and "psill"'):
+        ss.get_variogram_model_func(pd.DataFrame({"model": ["spherical"], "range": [1.0]}))
+    with pytest.raises(ValueError, match="ranges must have non-zero, positive values"):
+        ss.get_variogram_model_func(pd.DataFrame({"model": ["spherical"], "range": [0.0], "psill": [1.0]}))
+    with pytest.raises(ValueError, match='must contain the column "smooth"'):
+        ss.get_variogram_model_func(pd.DataFrame({"model": ["matern"], "range": [1.0], "psill": [1.0]}))

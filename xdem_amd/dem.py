@@ -15,6 +15,7 @@ from typing import Any
 import numpy as np
 
 from . import coreg as _coreg
+from . import spatialstats as _ss
 from . import terrain
 
 
@@ -126,3 +127,40 @@ class DEM:
         mask = None if inlier_mask is None else np.asarray(getattr(inlier_mask, "data", inlier_mask), dtype=bool)
         method.fit(reference_elev.data, self.data, mask, resolution=self.res, **kwargs)
         return DEM(method.apply(self.data, self.res, resample=resample), self.transform, self.crs, self.nodata)
+
+    # ---- uncertainty forwarder (xdem/dem.py:667-780) ---------------------------------------------------------------
+    def estimate_uncertainty(self, other_elev: "DEM", stable_terrain=None, approach: str = "H2022", precision_of_other: str = "finer",
+                             spread_estimator=_ss.nmad, variogram_estimator: str = "dowd", list_vars=("slope", "max_curvature"),
+                             list_vario_models=("gaussian", "spherical"), z_name: str = "z", random_state=None):
+        """Per-pixel error map and spatial correlation function of the errors of this DEM, from its difference to
+        ``other_elev`` on stable terrain (Hugonnet et al., 2022) -- same steps as upstream: terrain attributes, N-D binning
+        of the spread and its interpolant (``infer_heteroscedasticity_from_stable``), standardized Dowd variogram and model
+        fit (``infer_spatial_correlation_from_stable``); all array work on the GPU.  ``other_elev`` must share this grid."""
+        approach_dict = {"H2022": {"heterosc": True, "multi_range": True}, "R2009": {"heterosc": False, "multi_range": True},
+                         "Basic": {"heterosc": False, "multi_range": False}}
+        if approach not in approach_dict:
+            raise ValueError(f"approach must be one of {list(approach_dict)}")
+        if not isinstance(other_elev, DEM):
+            raise TypeError("Other elevation should be a DEM or elevation point cloud object.")
+        if other_elev.shape != self.shape or other_elev.transform != self.transform:
+            raise NotImplementedError("both DEMs must share one grid (reprojection is geoutils' job).")
+        dh = other_elev.data - self.data
+        if precision_of_other == "same":
+            dh = dh / np.sqrt(2)
+        stable = None if stable_terrain is None else np.asarray(getattr(stable_terrain, "data", stable_terrain), dtype=bool)
+        if approach_dict[approach]["heterosc"]:
+            list_var_rast = [getattr(terrain, v)(self).data if isinstance(v, str) else np.asarray(getattr(v, "data", v)) for v in list_vars]
+            sig = _ss.infer_heteroscedasticity_from_stable(dvalues=dh, list_var=list_var_rast, spread_statistic=spread_estimator,
+                                                           stable_mask=stable)[0]
+        else:
+            sel = dh if stable is None else dh[stable]
+            sig = _ss.nmad_device(sel)[1] * np.ones(self.shape)
+        if not approach_dict[approach]["multi_range"] and not isinstance(list_vario_models, str) and len(list_vario_models) > 1:
+            warnings.warn("Several variogram models passed but this approach uses a single range,keeping only the first model.",
+                          category=UserWarning)
+            list_vario_models = list_vario_models[0]
+        models = [list_vario_models] if isinstance(list_vario_models, str) else list(list_vario_models)
+        corr_sig = _ss.infer_spatial_correlation_from_stable(dvalues=dh, list_models=models, stable_mask=stable, errors=sig,
+                                                             estimator=variogram_estimator, gsd=self.res[0],
+                                                             random_state=random_state)[2]
+        return DEM(sig, self.transform, self.crs, None), corr_sig

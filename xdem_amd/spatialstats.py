@@ -781,3 +781,171 @@ def infer_heteroscedasticity_from_stable(dvalues, list_var, stable_mask=None, un
         except TypeError:
             pass
     return error, df, fun
+
+
+# ======================================================================================================================
+# Spatial correlation of errors: variogram model fitting around the GPU variogram (callers of the hot path;
+# mirror of xdem/spatialstats.py:1583-1964).  Host-side SciPy, like upstream.
+# ======================================================================================================================
+def _check_validity_params_variogram(params_variogram_model) -> None:
+    from . import variogram_models as vm
+
+    if not all(c in params_variogram_model for c in ("model", "range", "psill")):
+        raise ValueError('The dataframe with variogram parameters must contain the columns "model", "range" and "psill".')
+    for model in params_variogram_model["model"].values:
+        vm.model_name(model)
+    num = (float, np.floating, int, np.integer)
+    for r in params_variogram_model["range"].values:
+        if not isinstance(r, num):
+            raise ValueError("The variogram ranges must be float or integer.")
+        if r <= 0:
+            raise ValueError("The variogram ranges must have non-zero, positive values.")
+    for p in params_variogram_model["psill"].values:
+        if not isinstance(p, num):
+            raise ValueError("The variogram partial sills must be float or integer.")
+        if p <= 0:
+            raise ValueError("The variogram partial sills must have non-zero, positive values.")
+    names = [vm.model_name(m) for m in params_variogram_model["model"].values]
+    if any(n in ("stable", "matern") for n in names):
+        if "smooth" not in params_variogram_model:
+            raise ValueError('The dataframe with variogram parameters must contain the column "smooth" for '
+                             "the smoothness factor when using Matern or Stable models.")
+        for n, s in zip(names, params_variogram_model["smooth"].values):
+            if n in ("stable", "matern"):
+                if not isinstance(s, num):
+                    raise ValueError("The variogram smoothness parameter must be float or integer.")
+                if s <= 0:
+                    raise ValueError("The variogram smoothness parameter must have non-zero, positive values.")
+
+
+def get_variogram_model_func(params_variogram_model):
+    """Sum of variogram models from a parameter table (columns model, range, psill[, smooth]) -> function of the lag."""
+    from . import variogram_models as vm
+
+    _check_validity_params_variogram(params_variogram_model)
+    rows = []
+    for i in range(len(params_variogram_model)):
+        name = vm.model_name(params_variogram_model["model"].values[i])
+        args = [params_variogram_model["range"].values[i], params_variogram_model["psill"].values[i]]
+        if vm.n_params(name) == 3:
+            args.append(params_variogram_model["smooth"].values[i])
+        rows.append((getattr(vm, name), args))
+
+    def sum_model(h):
+        fn = np.zeros(np.shape(h))
+        for f, args in rows:
+            fn = fn + f(h, *args)
+        return fn
+
+    return sum_model
+
+
+def covariance_from_variogram(params_variogram_model):
+    """C(h) = total sill - sum of variograms."""
+    _check_validity_params_variogram(params_variogram_model)
+    total_sill = np.sum(params_variogram_model["psill"])
+    sum_variogram = get_variogram_model_func(params_variogram_model)
+    return lambda h: total_sill - sum_variogram(h)
+
+
+def correlation_from_variogram(params_variogram_model):
+    """rho(h) = C(h) / total sill, between 0 and 1."""
+    _check_validity_params_variogram(params_variogram_model)
+    total_sill = np.sum(params_variogram_model["psill"].values)
+    cov = covariance_from_variogram(params_variogram_model)
+    return lambda h: cov(h) / total_sill
+
+
+def fit_sum_model_variogram(list_models, empirical_variogram, bounds=None, p0=None, maxfev=None):
+    """Weighted least-squares fit of a sum of variogram models to an empirical variogram (the DataFrame of
+    ``sample_empirical_variogram``): same bounds / first guesses / weighting rules as xdem/spatialstats.py:1680-1804.
+    Returns (fitted sum function, DataFrame of model, range, psill[, smooth])."""
+    import pandas as pd
+    from scipy.optimize import curve_fit
+
+    from . import variogram_models as vm
+
+    names = [vm.model_name(m) for m in list_models]
+
+    def variogram_sum(h, *args):
+        fn, i = 0.0, 0
+        for name in names:
+            k = vm.n_params(name)
+            fn = fn + getattr(vm, name)(h, *args[i:i + k])
+            i += k
+        return fn
+
+    ev = empirical_variogram[np.isfinite(empirical_variogram.exp.values)]
+    n_average = np.ceil(len(ev.exp.values) / 10)
+    max_var = np.max(np.convolve(ev.exp.values, np.ones(int(n_average)) / n_average, mode="valid"))
+    if bounds is None:
+        bounds = [(0, ev.lags.values[-1]), (0, max_var)] * len(names)
+    if p0 is None:
+        p0 = []
+        for i in range(len(names)):
+            p0.append(((i + 1) / len(names)) * ev.lags.values[-1])
+            p0.append(((i + 1) / len(names)) * max_var)
+    final_bounds = np.transpose(np.array(bounds))
+    err = ev.err_exp.values
+    if np.all(np.isnan(err)) or np.all(err == 0):
+        cof, _ = curve_fit(variogram_sum, ev.lags.values, ev.exp.values, method="trf", p0=p0, bounds=final_bounds, maxfev=maxfev)
+    else:
+        valid = np.isfinite(err)
+        cof, _ = curve_fit(variogram_sum, ev.lags.values[valid], ev.exp.values[valid], method="trf", p0=p0, bounds=final_bounds,
+                           sigma=err[valid], maxfev=maxfev)
+    list_df, i = [], 0
+    for name in names:
+        k = vm.n_params(name)
+        d = {"model": [name], "range": [cof[i]], "psill": [cof[i + 1]]}
+        if k == 3:
+            d["smooth"] = [cof[i + 2]]
+        list_df.append(pd.DataFrame(d))
+        i += k
+    df_params = pd.concat(list_df)
+    return get_variogram_model_func(df_params), df_params
+
+
+def _estimate_model_spatial_correlation(dvalues, list_models, estimator: str = "dowd", gsd: float = None, coords=None,
+                                        subsample: int = 1000, subsample_method: str = "cdist_equidistant", n_variograms: int = 1,
+                                        n_jobs: int = 1, random_state=None, bounds=None, p0=None, **kwargs):
+    """Empirical variogram on the GPU + model fit + correlation function (mirror of xdem/spatialstats.py:1807-1873)."""
+    empirical_variogram = sample_empirical_variogram(values=dvalues, estimator=estimator, gsd=gsd, coords=coords, subsample=subsample,
+                                                     subsample_method=subsample_method, n_variograms=n_variograms, n_jobs=n_jobs,
+                                                     random_state=random_state, **kwargs)
+    params = fit_sum_model_variogram(list_models=list_models, empirical_variogram=empirical_variogram, bounds=bounds, p0=p0)[1]
+    return empirical_variogram, params, correlation_from_variogram(params_variogram_model=params)
+
+
+def infer_spatial_correlation_from_stable(dvalues, list_models, stable_mask=None, unstable_mask=None, errors=None,
+                                          estimator: str = "dowd", gsd: float = None, coords=None, subsample: int = 1000,
+                                          subsample_method: str = "cdist_equidistant", n_variograms: int = 1, n_jobs: int = 1,
+                                          bounds=None, p0=None, random_state=None, **kwargs):
+    """Spatial correlation of errors from differences on stable terrain (mirror of xdem/spatialstats.py:1876-1964 for
+    array inputs with boolean-array masks, Raster-likes read through ``.data`` / ``.res``): non-stable pixels become NaN
+    (shape preserved), values are standardized by ``errors`` if given, then the variogram is sampled on the GPU and fitted."""
+    if isinstance(dvalues, np.ndarray):
+        arr = np.ma.filled(dvalues, np.nan) if isinstance(dvalues, np.ma.MaskedArray) else dvalues
+        if gsd is None:
+            raise ValueError("The ground sampling distance must be provided if no Raster object is passed.")
+    else:
+        data = getattr(dvalues, "data", None)
+        if data is None:
+            raise ValueError("The values must be a Raster or NumPy array, or a list of those.")
+        arr = np.ma.filled(data, np.nan)
+        if gsd is None:
+            gsd = dvalues.res[0]
+    for m in (stable_mask, unstable_mask):
+        if m is not None and not isinstance(m, np.ndarray):
+            raise ValueError("xdem_amd takes stable / unstable masks as boolean arrays (vector rasterisation is outside the hot path).")
+    include = np.ones(np.shape(arr), dtype=bool) if stable_mask is None else np.asarray(stable_mask, dtype=bool)
+    exclude = np.zeros(np.shape(arr), dtype=bool) if unstable_mask is None else np.asarray(unstable_mask, dtype=bool)
+    include = np.logical_and(include, ~exclude).squeeze()
+    stable = np.array(arr, dtype=arr.dtype if np.issubdtype(arr.dtype, np.floating) else np.float32, copy=True)
+    stable[~include] = np.nan
+    if errors is not None:
+        err = errors if isinstance(errors, np.ndarray) else np.ma.filled(getattr(errors, "data"), np.nan)
+        with np.errstate(all="ignore"):
+            stable = stable / err
+    return _estimate_model_spatial_correlation(dvalues=stable, list_models=list_models, estimator=estimator, gsd=gsd, coords=coords,
+                                               subsample=subsample, subsample_method=subsample_method, n_variograms=n_variograms,
+                                               n_jobs=n_jobs, random_state=random_state, bounds=bounds, p0=p0, **kwargs)
