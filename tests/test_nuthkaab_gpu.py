@@ -150,8 +150,19 @@ def test_class_api_recovers_shift(coreg):
     assert abs(out["shift_x"] / res - 1.7) < 0.1 and abs(out["shift_y"] / res + 0.6) < 0.1 and abs(out["shift_z"] + 2.0) < 0.1
     assert nk.meta["outputs"]["random"]["subsample_final"] > 0
     assert nk.to_matrix().shape == (4, 4)
-    with pytest.raises(NotImplementedError):
-        coreg.NuthKaab().fit(ref, tba, inlier, resolution=res)  # default 5e5 random subsample is outside the hot path
+    # random subsample (reference default: 5e5 points): a subset of the valid pixels drawn once; reproducible with a seed
+    full = nk.meta["outputs"]["affine"]
+    nks = coreg.NuthKaab(subsample=0.5).fit(ref, tba, inlier, resolution=res, random_state=42)
+    sub = nks.meta["outputs"]["affine"]
+    n_all = nk.meta["outputs"]["random"]["subsample_final"]
+    assert nks.meta["outputs"]["random"]["subsample_final"] == int(0.5 * n_all)
+    assert abs(sub["shift_x"] - full["shift_x"]) < 0.05 * res and abs(sub["shift_y"] - full["shift_y"]) < 0.05 * res
+    again = coreg.NuthKaab(subsample=0.5).fit(ref, tba, inlier, resolution=res, random_state=42).meta["outputs"]["affine"]
+    # (same pixels, same exact medians; the curve_fit start values come from float64 atomics whose order varies)
+    assert all(abs(again[k] - sub[k]) < 1e-6 for k in sub)
+    assert coreg.NuthKaab().fit(ref, tba, inlier, resolution=res).meta["outputs"]["random"]["subsample_final"] == n_all  # 5e5 > valid
+    m = coreg.subsample_valid_mask(np.array([[True, False, True], [True, True, False]]), 2, random_state=0)
+    assert m.sum() == 2 and not m[0, 1] and not m[1, 2]
     with pytest.raises(ValueError, match="no valid points"):
         coreg.NuthKaab(subsample=1).fit(ref, np.full_like(tba, np.nan), None, resolution=res)
 

@@ -7,10 +7,10 @@ over the grids (gradient, shifted elevation difference, exact ``nanmedian`` vert
 with exact per-bin ``nanmedian``) runs in ``csrc/nuthkaab.hip`` through ``xdemhip_nk_create`` / ``xdemhip_nk_step``.
 The 72-point ``scipy.optimize.curve_fit`` stays on the host exactly as upstream (``xdem/coreg/base.py:1038-1045``).
 
-Scope: two rasters on the same grid given as arrays (+ resolution), ``subsample=1`` (all valid pixels -- the
-BASELINE configuration); the default ``bin_before_fit=True`` with ``bin_statistic=np.nanmedian``.  Point-cloud
-inputs, random subsampling (geoutils' ``subsample_array``) and other statistics are outside the hot path and raise
-``NotImplementedError``.
+Scope: two rasters on the same grid given as arrays (+ resolution); the default ``bin_before_fit=True`` with
+``bin_statistic=np.nanmedian``.  ``subsample=1`` uses all valid pixels (the BASELINE configuration); any other value a
+random subset drawn once by the restated rule of geoutils' ``subsample_array`` (``subsample_valid_mask``).  Point-cloud
+inputs and other statistics are outside the hot path and raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -164,10 +164,36 @@ def _bin_fit_from_step(det: dict[str, Any], fit_optimizer: Callable[..., Any], d
     return a * np.sin(b), a * np.cos(b), c
 
 
+def subsample_valid_mask(valid_mask: np.ndarray, subsample: float | int, random_state=None) -> np.ndarray:
+    """Boolean mask of a random subsample of the valid pixels (``_get_subsample_on_valid_mask``, xdem/coreg/base.py:577-617).
+    The draw itself is geoutils' ``subsample_array`` (un-vendored, absent here); its published rule is restated --
+    ``rng = default_rng(random_state)``, ``n = int(subsample * n_valid)`` for 0 < subsample <= 1 else ``int(subsample)``,
+    capped at n_valid, ``rng.choice(flat valid indices, n, replace=False)`` -- **parity unpinned**."""
+    n_valid = int(np.count_nonzero(valid_mask))
+    if n_valid == 0:
+        raise ValueError(
+            "There is no valid points common to the input and auxiliary data (bias variables, or "
+            "derivatives required for this method, for example slope, aspect, etc)."
+        )
+    if subsample == 1:
+        return valid_mask
+    if subsample <= 0:
+        raise ValueError("`subsample` must be > 0")
+    npoints = int(subsample * n_valid) if subsample <= 1 else int(subsample)
+    npoints = min(npoints, n_valid)
+    rng = np.random.default_rng(random_state)
+    valids = np.flatnonzero(valid_mask.ravel())
+    out = np.zeros(valid_mask.size, dtype=bool)
+    out[rng.choice(valids, npoints, replace=False)] = True
+    return out.reshape(valid_mask.shape)
+
+
 def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarray | None, res: tuple[float, float],
               tolerance: float = 0.001, max_iterations: int = 10, bin_sizes: int = 72,
-              fit_optimizer: Callable[..., Any] | None = None, ctx: _lib.Context | None = None, group=None):
-    """Array-level entry mirroring ``nuth_kaab`` (xdem/coreg/affine.py:539-609) for two rasters, subsample == 1.
+              fit_optimizer: Callable[..., Any] | None = None, ctx: _lib.Context | None = None, group=None,
+              subsample: float | int = 1, random_state=None):
+    """Array-level entry mirroring ``nuth_kaab`` (xdem/coreg/affine.py:539-609) for two rasters.
+    ``subsample != 1`` restricts every iteration to a random subset of the valid pixels (drawn once, affine.py:581-593);
     ``group`` (torch.distributed process group or "world") shards every grid pass over the ranks by row block.
 
     Returns ((easting, northing, vertical) offsets in georeferenced units, subsample_final)."""
@@ -176,6 +202,11 @@ def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarra
     fit_optimizer = fit_optimizer or scipy.optimize.curve_fit
     logging.info("Running Nuth and Kääb (2011) coregistration")
     plan = NKPlan(ref_elev, tba_elev, inlier_mask, ctx, group)
+    if subsample != 1 and plan.n_valid > 0:
+        # valid = inlier & finite ref / tba / slope / aspect (base.py:650-661), as the aux pass just established it
+        valid = plan.aux()[2]
+        plan.close()
+        plan = NKPlan(ref_elev, tba_elev, subsample_valid_mask(valid, subsample, random_state), ctx, group)
     try:
         if plan.n_valid == 0:
             raise ValueError(
@@ -264,11 +295,8 @@ class NuthKaab:
         """Estimate the x/y/z offset between two DEMs given as arrays on the same grid (Coreg.fit, base.py:2250-2368)."""
         if subsample is not None:
             self.meta["inputs"]["random"]["subsample"] = subsample
-        if self.meta["inputs"]["random"]["subsample"] != 1:
-            raise NotImplementedError(
-                "xdem_amd.NuthKaab runs on all valid pixels: pass subsample=1 (the reference default of 5e5 random "
-                "points relies on geoutils' subsample_array, which is outside the hot path)."
-            )
+        if random_state is not None:
+            self.meta["inputs"]["random"]["random_state"] = random_state
         if resolution is None:
             raise ValueError("'resolution' must be provided when passing arrays.")
         res = (float(resolution), float(resolution)) if np.isscalar(resolution) else (float(resolution[0]), float(resolution[1]))
@@ -278,7 +306,9 @@ class NuthKaab:
         fb = self.meta["inputs"]["fitorbin"]
         (east, north, vert), n_final = nuth_kaab(ref, tba, inlier_mask, res, tolerance=it["tolerance"],
                                                  max_iterations=it["max_iterations"], bin_sizes=fb["bin_sizes"],
-                                                 fit_optimizer=fb["fit_optimizer"])
+                                                 fit_optimizer=fb["fit_optimizer"],
+                                                 subsample=self.meta["inputs"]["random"]["subsample"],
+                                                 random_state=self.meta["inputs"]["random"]["random_state"])
         self.meta["outputs"]["affine"] = {"shift_x": -east, "shift_y": -north, "shift_z": vert * self.vertical_shift}
         self.meta["outputs"]["random"] = {"subsample_final": n_final}
         return self
