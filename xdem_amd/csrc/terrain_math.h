@@ -113,6 +113,28 @@ XD_HD double fma_c(double p, double s, double c) {
 #endif
 }
 
+// a * b + c as ONE VOP3 v_fma_f64 with every operand in a VGPR pair.  (hipcc prefers the VOP2 v_fmac_f64 and, when `c` stays
+// live, pays a v_mov_b64 copy in front of it.)
+XD_HD double fma_v(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fma(a, b, c);
+#endif
+}
+// 2 * a + c (the 2.0 is an inline constant of the instruction)
+XD_HD double fma_2(double a, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, 2.0, %2" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+#else
+    return fma(2.0, a, c);
+#endif
+}
+
 // asin(x) for 0 <= x <= 0.7075: x * P(x^2), degree-12 near-minimax fit of asin(sqrt(s))/sqrt(s) on
 // [0, 0.5005] (max relative error 1.4e-12, fitted with mpmath at Chebyshev nodes).
 XD_HD double asin_small(double x) {
@@ -256,7 +278,7 @@ XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams&
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
     const bool wilson = SP::WILSON < 0 ? (P.tri_wilson != 0) : (SP::WILSON != 0);
     const double c = n[4];
-    if (m & A_TPI) put(out.p[P_TPI], o, (TOUT)((TOUT)(c - (sum9 - c) * 0.125)));
+    if (m & A_TPI) put(out.p[P_TPI], o, (TOUT)((TOUT)(c - (sum9 - c) * 0.125)));  // (exact either way: * 0.125 is a power of two)
     if (m & A_ROUGH) {
         // Dartnell roughness: max - min of the window, NaN if any NaN (window.py:261-289); +-Inf propagate like NumPy
         double mx = n[0], mn = n[0];
@@ -307,7 +329,7 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
 
     // per-row partials (float64) -- Florinsky
-    double A[NS], B[NS], R[NS], Wr[NS], Ua[NS], Ub[NS];
+    double A[NS], B[NS], R[NS], Wr[NS], Ua[NS], Ub[NS], D2[NS];  // D2 = A + 2 B (mixed derivative rows)
     // per-row partials -- 3x3 fits
     double Dr[NS], S[NS], Zc[NS];
     // 3-wide row sums and the float64 copies of the three centre columns for TPI / TRI (and the 3x3 detector)
@@ -327,6 +349,7 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
                     const double p = z0 + z4, q = zl + zr;
                     A[k] = zr - zl;
                     B[k] = z4 - z0;
+                    if (CURV) D2[k] = fma_2(B[k], A[k]);
                     R[k] = (p + q) + zc;
                     if (CURV) Wr[k] = fma(2.0, p - zc, -q);
                     Ua[k] = fma(68.0, zc, fma(62.0, q, 44.0 * p));
@@ -363,9 +386,7 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
                             det = ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2];
                             zxx = round_in<TIN>(det * P.sxx);
                             zyy = round_in<TIN>(fma(2.0, (R[m2] + R[p2]) - R[c0], -(R[m1] + R[p1])) * P.sxx);
-                            const double d_m2 = fma(2.0, B[m2], A[m2]), d_m1 = fma(2.0, B[m1], A[m1]);
-                            const double d_p1 = fma(2.0, B[p1], A[p1]), d_p2 = fma(2.0, B[p2], A[p2]);
-                            zxy = round_in<TIN>(fma(2.0, d_m2 - d_p2, d_m1 - d_p1) * P.sxy);
+                            zxy = round_in<TIN>(fma(2.0, D2[m2] - D2[p2], D2[m1] - D2[p1]) * P.sxy);
                         } else {
                             det = ((R[m2] + R[m1]) + (R[c0] + R[p1])) + R[p2];
                         }
