@@ -17,6 +17,7 @@
 // (ds_add_u32 / ds_add_f64 / ds_min) and are flushed once per workgroup with global atomics; counts and histograms
 // are integers, hence exact and all-reducible across GPUs.
 #include <math.h>
+#include <type_traits>
 #include <string.h>
 
 #include <vector>
@@ -54,6 +55,7 @@ template <typename T> struct PairArgs {
     unsigned long long* succ;              // [nb] 8-byte slots, all-ones = none
     int shift, first, bin0, nbs;   // hist digit, first pass flag, LDS sweep window [bin0, bin0 + nbs)
     int sample;                    // OP_HIST: only the pseudo-randomly chosen 1/64 of the (A tile x B tile) units
+    int has_nan;                   // some value is NaN (unknown for device-resident inputs: assumed): full tiles keep the NaN test
     // OP_BRACKET (bracketed selection, select_run.h): keys in [prefix[k], khi[k]] are candidates
     const typename KeyT<T>::type* khi;
     unsigned long long* cnt3;      // [3][nb]: pairs per class at or above the bracket's low end, below it, inside the bracket
@@ -91,8 +93,11 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     unsigned char* acc = reinterpret_cast<unsigned char*>(s_bv + PT);            // PT * sizeof(T) is a multiple of 8
     // OP_SUMS: NCOPY privatised copies per class, copy = lane % 32: lanes of a wave that hit the same class land on
     // different banks (at most 2 lanes per address) instead of serialising 64-way on one LDS word
-    double* s_sum = reinterpret_cast<double*>(acc);                        // [nb][NCOPY]
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_sum + a.nb * NCOPY);   // [nb][NCOPY]
+    // per class a 384-byte record: NCOPY float64 sums (256 B = all 64 LDS banks, one copy per lane % 32: conflict-free), then
+    // NCOPY uint32 counts.  Record nb collects the pairs beyond the last edge and is never read back, so full tiles need no
+    // class test.  Both atomics of a pair address the record with the same `l * 384` term.
+    constexpr int REC = NCOPY * 12;
+    unsigned char* s_rec = acc;
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(acc);            // OP_HIST: nbs * 256
     K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
     uint32_t* s_c3 = reinterpret_cast<uint32_t*>(acc);              // OP_BRACKET: [3][nb][NCOPY] counters, then the staging buffer
@@ -109,7 +114,14 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     if (FAST && tid < LUT_N) s_lut[tid] = a.lut[tid];
     for (int k = tid; k < a.nb + LUT_STEPS + 1; k += NT) s_thr[k] = k < a.nb ? a.thr[k] : (double)INFINITY;
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
-        for (int k = tid; k < a.nb * NCOPY; k += NT) { s_sum[k] = 0.0; s_cnt[k] = 0; }
+        for (int k = tid; k < (a.nb + 1) * REC / 4; k += NT) reinterpret_cast<uint32_t*>(s_rec)[k] = 0u;
+    unsigned char* const s_sum_cp = s_rec + (tid & (NCOPY - 1)) * 8;              // this lane's privatised copies
+    unsigned char* const s_cnt_cp = s_rec + NCOPY * 8 + (tid & (NCOPY - 1)) * 4;
+    auto rec_add = [&](int l, double term) {
+        const int off = l * REC;
+        atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), term);
+        atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), 1u);
+    };
     if (OP == OP_HIST)
         for (int k = tid; k < a.nbs * SEL_RADIX; k += NT) s_hist[k] = 0;
     if (OP == OP_SUCC)
@@ -204,11 +216,9 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 if (OP == OP_BRACKET) { bracket_pair(ok, l, d); return; }
                 if (!ok) return;
                 if (OP == OP_SUMS_SQ) {
-                    atomicAdd(&s_cnt[l * NCOPY + (tid & (NCOPY - 1))], 1u);
-                    atomicAdd(&s_sum[l * NCOPY + (tid & (NCOPY - 1))], (double)d * (double)d);
+                    rec_add(l, (double)d * (double)d);
                 } else if (OP == OP_SUMS_SQRT) {
-                    atomicAdd(&s_cnt[l * NCOPY + (tid & (NCOPY - 1))], 1u);
-                    atomicAdd(&s_sum[l * NCOPY + (tid & (NCOPY - 1))], sqrt((double)d));
+                    rec_add(l, sqrt((double)d));
                 } else if (OP == OP_HIST) {
                     const int lb = l - a.bin0;
                     if (lb < 0 || lb >= a.nbs) return;
@@ -227,52 +237,88 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 // Tile slots beyond cnt hold stale data and are masked by `ok`.
                 const int64_t rel = ia - j0;  // pdist: only B indices j > rel pair with this lane's A point
                 const int ia_rel = a.pdist ? (int)(rel < -1 ? -1 : (rel > PT ? PT : rel)) : -1;
-                for (int j = 0; j < cnt; j += 4) {
-                    double s2[4];
-                    T dv[4];
+                // Full tiles (the bulk of the pairs): every slot is a pair -- no index, diagonal, class or NaN test and no
+                // exec masking; the class beyond the last edge lands in the spare record.
+                const bool plain_tile = (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && cnt == PT && !a.has_nan &&
+                                        (!a.pdist || j0 >= (ta + 1) * (int64_t)NT);
+                if (plain_tile) {
+                    for (int j = 0; j < PT; j += 4) {
+                        double s2[4];
+                        T dv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
-                        s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
-                        const T d = pv - s_bv[j + u];
-                        dv[u] = d < 0 ? -d : d;
+                        for (int u = 0; u < 4; ++u) {
+                            const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
+                            s2[u] = dx * dx + dy * dy;
+                            dv[u] = pv - s_bv[j + u];
+                        }
+                        int l[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
+                            e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                            l[u] = s_lut[e] >> 1;
+                        }
+                        double th[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int lu = l[u] + ((th[u] <= s2[u]) ? 1 : 0);
+                            const double dd = (double)dv[u];
+                            rec_add(lu, OP == OP_SUMS_SQ ? dd * dd : sqrt(fabs(dd)));
+                        }
                     }
-                    int l[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
-                        e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
-                        l[u] = s_lut[e] >> 1;
-                    }
-                    double th[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];  // next threshold above the cell's lower bound
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int lu = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
-                        const T d = dv[u];
-                        const bool ok = (j + u) < cnt && (j + u) > ia_rel && lu < nb && d == d;
-                        if (OP == OP_BRACKET) {
-                            bracket_pair(ok, lu, d);
-                        } else if (ok) {
-                            if (OP == OP_SUMS_SQ) {
-                                atomicAdd(&s_cnt[lu * NCOPY + (tid & (NCOPY - 1))], 1u);
-                                atomicAdd(&s_sum[lu * NCOPY + (tid & (NCOPY - 1))], (double)d * (double)d);
-                            } else if (OP == OP_SUMS_SQRT) {
-                                atomicAdd(&s_cnt[lu * NCOPY + (tid & (NCOPY - 1))], 1u);
-                                atomicAdd(&s_sum[lu * NCOPY + (tid & (NCOPY - 1))], sqrt((double)d));
-                            } else if (OP == OP_HIST) {
-                                const int lb = lu - a.bin0;
-                                const K key = key_abs(d);
-                                if (lb >= 0 && lb < a.nbs && (a.first || (key & himask) == s_pref[lu]))
-                                    atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
-                            } else if (OP == OP_SUCC) {
-                                const K key = key_abs(d);
-                                if (key > s_pref[lu] && key < s_min[lu]) lds_min<K>(&s_min[lu], key);
+                    continue;
+                }
+                auto run4 = [&](auto plain_tag) {
+                    constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
+                    for (int j = 0; j < cnt; j += 4) {
+                        double s2[4];
+                        T dv[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
+                            s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
+                            const T d = pv - s_bv[j + u];
+                            dv[u] = d < 0 ? -d : d;
+                        }
+                        int l[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
+                            e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                            l[u] = s_lut[e] >> 1;
+                        }
+                        double th[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];  // next threshold above the cell's lower bound
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int lu = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
+                            const T d = dv[u];
+                            const bool ok = (PLAIN || ((j + u) < cnt && (j + u) > ia_rel && d == d)) && lu < nb;
+                            if (OP == OP_BRACKET) {
+                                bracket_pair(ok, lu, d);
+                            } else if (ok) {
+                                if (OP == OP_SUMS_SQ) {
+                                    rec_add(lu, (double)d * (double)d);
+                                } else if (OP == OP_SUMS_SQRT) {
+                                    rec_add(lu, sqrt((double)d));
+                                } else if (OP == OP_HIST) {
+                                    const int lb = lu - a.bin0;
+                                    const K key = key_abs(d);
+                                    if (lb >= 0 && lb < a.nbs && (a.first || (key & himask) == s_pref[lu]))
+                                        atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
+                                } else if (OP == OP_SUCC) {
+                                    const K key = key_abs(d);
+                                    if (key > s_pref[lu] && key < s_min[lu]) lds_min<K>(&s_min[lu], key);
+                                }
                             }
                         }
                     }
-                }
+                };
+                if (cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT)) run4(std::true_type());
+                else run4(std::false_type());
             } else {
                 for (int j = 0; j < cnt; ++j) pair(j, !a.pdist || (j0 + j) > ia);
             }
@@ -282,7 +328,11 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
         for (int k = tid; k < nb; k += NT) {
             unsigned long long c = 0;
             double sm = 0.0;
-            for (int q = 0; q < NCOPY; ++q) { c += s_cnt[k * NCOPY + q]; sm += s_sum[k * NCOPY + q]; }
+            for (int q = 0; q < NCOPY; ++q) {
+                const unsigned char* r = s_rec + k * (NCOPY * 12);
+                c += reinterpret_cast<const uint32_t*>(r + NCOPY * 8)[q];
+                sm += reinterpret_cast<const double*>(r)[q];
+            }
             if (c) { atomicAdd(&a.counts[k], c); atomicAdd(&a.sums[k], sm); }
         }
     } else if (OP == OP_HIST) {
@@ -319,7 +369,7 @@ struct xdemhip_pairs {
     void *prefix = nullptr, *succ = nullptr;
     int64_t n_wg = 0, n_wg_big = 0, n_pairs = 0;
     // bracketed selection state (xdemhip_pairs_medians)
-    int sample = 0;
+    int sample = 0, has_nan = 1;
     void* khi = nullptr;
     unsigned long long *cnt3 = nullptr, *cand_ctr = nullptr;
     void* cand_v = nullptr;
@@ -336,7 +386,7 @@ template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
     if (op == OP_BRACKET) return base + (size_t)3 * nb * NCOPY * 4 + 8 + (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
-    return base + (size_t)nb * NCOPY * 12;
+    return base + (size_t)(nb + 1) * NCOPY * 12;
 }
 
 template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int first, int bin0, int nbs) {
@@ -352,6 +402,7 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     a.succ = static_cast<unsigned long long*>(P->succ);
     a.shift = shift; a.first = first; a.bin0 = bin0; a.nbs = nbs;
     a.sample = P->sample;
+    a.has_nan = P->has_nan;
     a.khi = static_cast<const typename KeyT<T>::type*>(P->khi);
     a.cnt3 = P->cnt3; a.cand_v = static_cast<T*>(P->cand_v); a.cand_b = P->cand_b; a.cand_ctr = P->cand_ctr; a.cand_cap = P->cand_cap;
     const size_t lds = lds_bytes<T>(P->nb, OP, nbs);
@@ -473,6 +524,13 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     }
     if (!pd) (void)hipMemcpyAsync(P->b_off, b_off, sizeof(int64_t) * (n_blocks + 1), hipMemcpyHostToDevice, ctx->stream);
     if (memspace == XDEMHIP_HOST) {
+        // NaN values never pair (the kernel tests for them); knowing that there are none lets full tiles skip the test
+        auto any_nan = [&](const void* v, int64_t n) {
+            if (val_dtype == XDEMHIP_F32) { const float* f = static_cast<const float*>(v); for (int64_t i = 0; i < n; ++i) if (f[i] != f[i]) return true; }
+            else { const double* f = static_cast<const double*>(v); for (int64_t i = 0; i < n; ++i) if (f[i] != f[i]) return true; }
+            return false;
+        };
+        P->has_nan = (any_nan(av, na) || (!pd && any_nan(bv, nbt))) ? 1 : 0;
         P->own = true;
         XD_ALLOC(P->ax, 8 * na); XD_ALLOC(P->ay, 8 * na); XD_ALLOC(P->av, es * na);
         (void)hipMemcpyAsync(P->ax, ax, 8 * na, hipMemcpyHostToDevice, ctx->stream);
