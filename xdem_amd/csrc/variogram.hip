@@ -83,6 +83,13 @@ __device__ __forceinline__ uint64_t key_abs(double v) { return (uint64_t)__doubl
 template <typename T, int OP, bool FAST, int NT>
 __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     typedef typename KeyT<T>::type K;
+    // sampled digit passes: a workgroup none of whose (up to 16) B tiles is in the sample leaves before touching LDS (4 of 5 do;
+    // otherwise zeroing and flushing their 51 KB histograms would dominate the pass)
+    if (OP == OP_HIST && a.sample) {
+        bool any = false;
+        for (int t = 0; t < BCHUNK / PT; ++t) any |= unit_sampled(blockIdx.x, t);
+        if (!any) return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_bx = reinterpret_cast<double*>(smem);
     double* s_by = s_bx + PT;
