@@ -70,6 +70,11 @@ int xdemhip_synchronize(xdemhip_ctx* ctx) {
 
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return XDEMHIP_EINVAL;
+    if (std::string(name) == "host_chunk_mb") {  // device budget of one row chunk of host-buffer terrain calls (0 = default 8 GiB)
+        if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "host_chunk_mb must be >= 0");
+        ctx->host_chunk_mb = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "selection") {
         if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets");
         ctx->selection_mode = value;
@@ -150,7 +155,19 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
         return rc;
     }
 
-    // Host buffers: stage the whole raster (288 GB of HBM holds a 65536^2 float32 DEM with all planes).
+    // Host buffers: the raster streams through the device in ROW CHUNKS with the overlap the requested attributes need (the GPU
+    // analogue of the reference's map_overlap tiles, xdem/terrain/terrain.py:412-466): device memory stays bounded by the
+    // chunk budget however large the host raster is, and a chunk is computed exactly as the same rows of the whole raster
+    // (halo_top / halo_bottom of the kernels).
+    int depth = 0;  // overlap rows per side
+    if (attr_mask & 0x3ffu) depth = surface_fit == XDEMHIP_FIT_FLORINSKY ? 2 : 1;
+    if ((attr_mask & 0x5c00u) && window_size / 2 > depth) depth = window_size / 2;
+    if ((attr_mask & XDEMHIP_ATTR_RUGOSITY) && depth < 1) depth = 1;
+    const size_t budget = (size_t)(ctx->host_chunk_mb > 0 ? ctx->host_chunk_mb : 8192) << 20;
+    const size_t row_bytes = (size_t)W * (in_es + out_es * (size_t)n_planes);
+    int64_t chunk = (int64_t)(budget / (row_bytes ? row_bytes : 1)) - 2 * depth;
+    if (chunk < 64) chunk = 64;  // (a few rows of a very wide raster may exceed the budget; still correct)
+    if (chunk > H) chunk = H;
     void* d_dem = nullptr;
     std::vector<void*> d_out(n_planes, nullptr);
     int rc = XDEMHIP_OK;
@@ -159,30 +176,41 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
         for (void* p : d_out)
             if (p) (void)hipFree(p);
     };
-    const size_t in_bytes = (size_t)buf_rows * (size_t)W * in_es;
-    const size_t plane_bytes = (size_t)H * (size_t)W * out_es;
+    const size_t in_bytes = (size_t)(chunk + 2 * depth) * (size_t)W * in_es;
+    const size_t plane_bytes = (size_t)chunk * (size_t)W * out_es;
     if (hipMalloc(&d_dem, in_bytes) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(dem) failed"); }
     for (int i = 0; i < n_planes; ++i)
         if (hipMalloc(&d_out[i], plane_bytes) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(plane) failed"); }
-    hipError_t e = hipMemcpy2DAsync(d_dem, (size_t)W * in_es, dem, (size_t)row_stride * in_es, (size_t)W * in_es,
-                                    (size_t)buf_rows, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, std::string("H2D copy failed: ") + hipGetErrorString(e)); }
     L.dem = d_dem;
     L.row_stride = W;
     for (int bit = 0, i = 0; bit < XDEMHIP_ATTR_COUNT; ++bit)
         if (attr_mask & (1u << bit)) L.planes[bit] = d_out[i++];
-    (void)hipEventRecord(ctx->ev_start, ctx->stream);
-    rc = xd::launch_terrain(ctx, L);
-    (void)hipEventRecord(ctx->ev_stop, ctx->stream);
-    ctx->timed = (rc == XDEMHIP_OK);
-    if (rc == XDEMHIP_OK) {
-        for (int i = 0; i < n_planes && rc == XDEMHIP_OK; ++i) {
-            e = hipMemcpyAsync(out_planes[i], d_out[i], plane_bytes, hipMemcpyDeviceToHost, ctx->stream);
-            if (e != hipSuccess) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("D2H copy failed: ") + hipGetErrorString(e));
+    bool first = true;
+    for (int64_t r0 = 0; r0 < H && rc == XDEMHIP_OK; r0 += chunk) {
+        const int64_t r1 = (r0 + chunk < H) ? r0 + chunk : H;
+        // rows of the caller's buffer (which itself may carry halo rows) available above / below this chunk
+        const int64_t top = (r0 + halo_top < depth) ? r0 + halo_top : depth;
+        const int64_t bot = (H + halo_bottom - r1 < depth) ? H + halo_bottom - r1 : depth;
+        const char* src = static_cast<const char*>(dem) + (size_t)(r0 + halo_top - top) * (size_t)row_stride * in_es;
+        hipError_t e = hipMemcpy2DAsync(d_dem, (size_t)W * in_es, src, (size_t)row_stride * in_es, (size_t)W * in_es,
+                                        (size_t)(top + (r1 - r0) + bot), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("H2D copy failed: ") + hipGetErrorString(e)); break; }
+        L.H = r1 - r0; L.halo_top = top; L.halo_bottom = bot;
+        if (first) (void)hipEventRecord(ctx->ev_start, ctx->stream);
+        rc = xd::launch_terrain(ctx, L);
+        if (rc != XDEMHIP_OK) break;
+        if (r1 == H) (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+        first = false;
+        const size_t rows_bytes = (size_t)(r1 - r0) * (size_t)W * out_es;
+        for (int i = 0; i < n_planes; ++i) {
+            e = hipMemcpyAsync(static_cast<char*>(out_planes[i]) + (size_t)r0 * (size_t)W * out_es, d_out[i], rows_bytes,
+                               hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) { rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("D2H copy failed: ") + hipGetErrorString(e)); break; }
         }
-        e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess && rc == XDEMHIP_OK) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("kernel failed: ") + hipGetErrorString(e));
     }
+    ctx->timed = (rc == XDEMHIP_OK);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e2 != hipSuccess && rc == XDEMHIP_OK) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("kernel failed: ") + hipGetErrorString(e2));
     cleanup();
     return rc;
 }

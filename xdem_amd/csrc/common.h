@@ -16,6 +16,7 @@ struct xdemhip_ctx {
     int num_cu = 256;
     xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)
     void* allreduce_user = nullptr;
+    int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
     int selection_mode = 0;  // 0 auto (bracketed for large inputs), 1 plain digit passes only, 2 degenerate brackets (tests the fallback)
     std::string err;
 };
