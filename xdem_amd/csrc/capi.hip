@@ -4,6 +4,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -27,7 +28,10 @@ int xdemhip_create(int device_id, xdemhip_ctx** out_ctx) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XDEMHIP_EHIP; }
     c->stream = c->own_stream;
-    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+    for (int t = 0; t < 4; ++t)
+        if (hipStreamCreateWithFlags(&c->copy_streams[t], hipStreamNonBlocking) != hipSuccess) { delete c; return XDEMHIP_EHIP; }
+    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return XDEMHIP_EHIP;
     }
@@ -40,6 +44,9 @@ void xdemhip_destroy(xdemhip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+    for (int t = 0; t < 4; ++t)
+        if (ctx->copy_streams[t]) (void)hipStreamDestroy(ctx->copy_streams[t]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -202,11 +209,26 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
         if (r1 == H) (void)hipEventRecord(ctx->ev_stop, ctx->stream);
         first = false;
         const size_t rows_bytes = (size_t)(r1 - r0) * (size_t)W * out_es;
-        for (int i = 0; i < n_planes; ++i) {
-            e = hipMemcpyAsync(static_cast<char*>(out_planes[i]) + (size_t)r0 * (size_t)W * out_es, d_out[i], rows_bytes,
-                               hipMemcpyDeviceToHost, ctx->stream);
-            if (e != hipSuccess) { rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("D2H copy failed: ") + hipGetErrorString(e)); break; }
-        }
+        // Device -> pageable host memory is staged by the runtime on the calling thread; several threads, each with its own
+        // stream and its share of the planes, keep more of the PCIe link busy than one.
+        hipEvent_t done_ev = ctx->ev_copy;
+        (void)hipEventRecord(done_ev, ctx->stream);
+        const int nthreads = n_planes < 4 ? n_planes : 4;
+        std::vector<std::thread> workers;
+        std::vector<int> wrc(nthreads, 0);
+        for (int t = 0; t < nthreads; ++t)
+            workers.emplace_back([&, t]() {
+                if (hipSetDevice(ctx->device) != hipSuccess) { wrc[t] = 1; return; }
+                hipStream_t st = ctx->copy_streams[t];
+                if (hipStreamWaitEvent(st, done_ev, 0) != hipSuccess) { wrc[t] = 1; return; }
+                for (int i = t; i < n_planes; i += nthreads)
+                    if (hipMemcpyAsync(static_cast<char*>(out_planes[i]) + (size_t)r0 * (size_t)W * out_es, d_out[i], rows_bytes,
+                                       hipMemcpyDeviceToHost, st) != hipSuccess) { wrc[t] = 1; return; }
+                if (hipStreamSynchronize(st) != hipSuccess) wrc[t] = 1;
+            });
+        for (auto& w : workers) w.join();
+        for (int t = 0; t < nthreads; ++t)
+            if (wrc[t]) rc = xd_fail(ctx, XDEMHIP_EHIP, "D2H copy failed");
     }
     ctx->timed = (rc == XDEMHIP_OK);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);

@@ -11,7 +11,8 @@ struct xdemhip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream work is enqueued on (own_stream or the caller's)
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_copy = nullptr;
+    hipStream_t copy_streams[4] = {};  // device -> host copy threads of the host-buffer path
     bool timed = false;
     int num_cu = 256;
     xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)
