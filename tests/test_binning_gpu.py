@@ -240,3 +240,46 @@ def test_dem_estimate_uncertainty_end_to_end():
     # constant-error approaches run too
     sig_b, corr_b = d.estimate_uncertainty(other, stable_terrain=stable, approach="Basic", list_vario_models="spherical", random_state=1)
     assert np.ptp(sig_b.data) == 0 and 0 <= corr_b(np.array([50.0]))[0] <= 1
+
+
+def test_randomised_binnings_vs_oracle():
+    """Seeded sweep over nd_binning: 1-4 variables of mixed dtype, integer or explicit-edge bins, constant variables, NaN / Inf
+    rows, heavy ties, tiny and empty bins -- every column of every 1-D / 2-D / N-D block bit-exact against the oracle."""
+    from xdem_amd import spatialstats as ss
+
+    rng = np.random.default_rng(4242)
+    for trial in range(25):
+        n = int(rng.choice([50, 999, 20000, 150000]))
+        nv = int(rng.integers(1, 5))
+        vdt = rng.choice([np.float32, np.float64])
+        values = np.round(rng.normal(0, 2, n), int(rng.integers(0, 4))).astype(vdt)
+        values[rng.uniform(size=n) < 0.02] = np.nan
+        list_var, bins = [], []
+        for k in range(nv):
+            dt = rng.choice([np.float32, np.float64])
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                var = rng.gamma(2.0, 5.0, n)
+            elif kind == 1:
+                var = rng.integers(0, 7, n).astype(np.float64)      # few distinct values, many on bin edges
+            elif kind == 2:
+                var = np.full(n, 3.25)                               # constant: SciPy widens the range by +-0.5
+            else:
+                var = rng.normal(100, 30, n)
+            var = var.astype(dt)
+            if rng.uniform() < 0.5:
+                var[rng.integers(0, n)] = rng.choice([np.nan, np.inf])
+            list_var.append(var)
+            if rng.uniform() < 0.7 or kind == 2:
+                bins.append(int(rng.integers(1, 9)))
+            else:
+                lo, hi = np.nanmin(var[np.isfinite(var)]), np.nanmax(var[np.isfinite(var)])
+                bins.append(np.unique(np.round(np.linspace(lo - 1, hi + 0.5, int(rng.integers(2, 8))), 2)))
+        names = [f"v{i}" for i in range(nv)]
+        df = ss.nd_binning(values, list_var, names, list_var_bins=tuple(bins))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = flatten_like_reference(bo.nd_binning_arrays(values, list_var, tuple(bins)), nv)
+        got = df_to_cols(df, nv)
+        for key, arr in got.items():
+            assert np.array_equal(arr, np.asarray(ref[key], np.float64), equal_nan=True), (trial, key, n, nv, bins)

@@ -230,3 +230,60 @@ def test_class_medians_through_reduction_hook_single_rank(ss):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_randomised_pair_sets_vs_oracle(ss):
+    """Seeded sweep: random block structures (pdist / cdist, empty and 1-point blocks), both dtypes, all estimators, edge lists
+    that take the class-lookup table (geometric), the binary search (dense linear edges, > 127 classes) and few-class paths,
+    NaN values, duplicated points (zero distances) -- counts bit-exact, Dowd bit-exact, sums within 1e-12."""
+    rng = np.random.default_rng(777)
+    for trial in range(40):
+        dtype = rng.choice([np.float32, np.float64])
+        mode = rng.choice(["pdist", "cdist"])
+        nblk = int(rng.integers(1, 5))
+        extent = float(rng.choice([50.0, 500.0, 5000.0]))
+
+        def pts(n):
+            if rng.uniform() < 0.5:
+                x, y = rng.integers(0, int(extent), n).astype(np.float64), rng.integers(0, int(extent), n).astype(np.float64)
+            else:
+                x, y = rng.uniform(0, extent, n), rng.uniform(0, extent, n)
+            v = np.round(np.sin(x / (extent / 8)) + 0.3 * rng.normal(size=n), int(rng.integers(1, 6))).astype(dtype)
+            if n > 3 and rng.uniform() < 0.3:
+                v[rng.integers(0, n)] = np.nan
+            return x, y, v
+
+        blocks = []
+        for _ in range(nblk):
+            na = int(rng.choice([0, 1, 2, 37, 300, 1100]))
+            if mode == "pdist":
+                blocks.append(pts(na))
+            else:
+                blocks.append(pts(na) + pts(int(rng.choice([0, 1, 5, 260, 4100]))))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            edges = [float(e) for e in vo.default_bin_edges(1.0, 1.5 * extent)]
+        elif kind == 1:
+            edges = list(np.linspace(extent / 300, 1.2 * extent, 200))      # > 127 classes: binary search, 2 LDS sweeps
+        elif kind == 2:
+            edges = list(np.linspace(extent / 40, extent, 40))              # dense linear edges: several thresholds per binade cell
+        else:
+            edges = [extent / 10, extent / 3, extent]
+        est = str(rng.choice(["matheron", "cressie", "dowd"]))
+        # the oracle pairs every value; NaN values never pair in the reference (dropped beforehand): filter them for the oracle
+        def drop_nan(b):
+            if len(b) == 3:
+                k = np.isfinite(b[2])
+                return (b[0][k], b[1][k], b[2][k])
+            ka, kb = np.isfinite(b[2]), np.isfinite(b[5])
+            return (b[0][ka], b[1][ka], b[2][ka], b[3][kb], b[4][kb], b[5][kb])
+
+        got_e, got_c = ss.empirical_variogram_pairs(blocks, edges, est)
+        ref_e, ref_c = vo.empirical_variogram_blocks([drop_nan(b) for b in blocks], edges, est)
+        assert np.array_equal(got_c, ref_c), (trial, mode, kind, est)
+        assert np.array_equal(np.isnan(got_e), np.isnan(ref_e)), (trial, mode, kind, est)
+        ok = np.isfinite(ref_e)
+        if est == "dowd":
+            assert np.array_equal(got_e[ok], ref_e[ok]), (trial, mode, kind)
+        else:
+            assert np.allclose(got_e[ok], ref_e[ok], rtol=1e-12, atol=0), (trial, mode, kind, est)

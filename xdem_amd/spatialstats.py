@@ -205,7 +205,9 @@ def empirical_variogram_pairs(blocks: list[tuple], right_edges, estimator: str =
     try:
         if estimator == "dowd":
             med, count = class_medians(pairs, group)
-            exp = 2.198 * med**2 / 2
+            # per class as scalars: `median ** 2` on a float64 scalar goes through libm's pow (what scikit-gstat's scalar
+            # expression and the oracle evaluate), which can differ from an array square in the last bit
+            exp = np.array([2.198 * float(m) ** 2 / 2 for m in med], dtype=np.float64)
         else:
             s, count = pairs.sums(0 if estimator == "matheron" else 1)
             s, count = _allreduce(s, group), _allreduce(count, group)
