@@ -313,3 +313,50 @@ def test_C3_full_size_properties(coreg):
     offsets, n_final = coreg.nuth_kaab(ref, tba, None, (res, res), tolerance=0.0, max_iterations=10)
     assert n_final > 0.75 * n * n
     assert abs(offsets[0] / res + 2.0) < 0.02 and abs(offsets[1] / res + 1.0) < 0.02 and abs(offsets[2] + 2.0) < 0.02
+
+
+def test_randomised_steps_vs_oracle(coreg):
+    """Seeded sweep of one Nuth-Kaab iteration step: raster shapes, dtypes, NaN / inlier patterns, sub- and multi-pixel
+    shifts, resolutions, numbers of aspect bins (5, 72, 150 -- the last needs two LDS sweeps) -- vertical shift, valid count,
+    bin edges, per-bin counts and medians bit-exact against the oracle."""
+    rng = np.random.default_rng(99)
+    from xdem_amd.synth import fbm_numpy
+
+    for trial in range(24):
+        H, W = int(rng.integers(12, 220)), int(rng.integers(12, 257))
+        dtype = rng.choice([np.float32, np.float64])
+        res = float(rng.choice([1.0, 2.5, 30.0]))
+        base = fbm_numpy((256, 256), seed=int(rng.integers(0, 1000)), std=float(rng.choice([5.0, 200.0])))[:H, :W]
+        ref = base.astype(dtype)
+        tba = (np.roll(base, (int(rng.integers(-2, 3)), int(rng.integers(-2, 3))), (0, 1)) + rng.normal(0, 0.2, (H, W)) + 1.0).astype(dtype)
+        tba[rng.uniform(size=(H, W)) < float(rng.choice([0.0, 0.05, 0.4]))] = np.nan
+        if rng.uniform() < 0.3:
+            ref[rng.integers(0, H), :] = np.nan
+        inlier = None if rng.uniform() < 0.4 else (rng.uniform(size=(H, W)) < 0.8)
+        nb = int(rng.choice([5, 72, 150]))
+        sx, sy = float(rng.uniform(-3, 3) * res), float(rng.uniform(-3, 3) * res)
+        plan = coreg.NKPlan(ref, tba, inlier)
+        st, asp = nko.aux_vars(ref)
+        valid = (np.ones((H, W), bool) if inlier is None else inlier) & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+        dh = nko.shifted_dh(ref, tba, sx, sy, (res, res))[valid]
+        ok = np.isfinite(dh)
+        if not ok.any():
+            with pytest.raises(ValueError, match="no more valid values"):
+                plan.step(sx, sy, (res, res), nb)
+            plan.close()
+            continue
+        det = plan.step(sx, sy, (res, res), nb)
+        vshift = np.nanmedian(dh)
+        assert det["vshift"] == float(vshift), (trial, H, W, dtype)
+        dh = dh - vshift
+        assert det["n_valid"] == int(ok.sum())
+        with np.errstate(all="ignore"):
+            y = dh[ok] / st[valid][ok]
+        a = asp[valid][ok]
+        if dtype == np.float64:
+            a = plan.aux()[1][valid][ok]
+        edges, counts, med = nko.bin_medians(a, y, nb)
+        plan.close()
+        assert np.array_equal(det["counts"], counts), (trial, nb)
+        assert np.array_equal(det["edges"], edges.astype(np.float64)), (trial, nb)
+        assert np.array_equal(det["medians"], med, equal_nan=True), (trial, nb, H, W, dtype)
