@@ -248,6 +248,17 @@ int xdemhip_nmad(xdemhip_ctx* ctx, const void* values, int dtype, int64_t n, dou
 int xdemhip_interp_grid_linear(xdemhip_ctx* ctx, int n_dims, const double* axes, const int* n_axis, const double* grid_values,
                                const void* const* vars, const int* var_dtypes, int64_t n, double scale, double* out, int memspace);
 
+/* ---- caller of path 3: double sum of spatially correlated errors ------------------------------------------------------
+ * out = sum_i sum_j  ae[i] * be[j] * rho(|a_i - b_j|),  rho(h) = 1 - sum_m gamma_m(h) / sum_m psill_m: the O(N^2) part of
+ *   neff_exact(coords, errors, params_variogram_model)            xdem/spatialstats.py:2175-2236  (bx = NULL: B = A, every ordered
+ *                                                                  pair including i = j)
+ *   neff_hugonnet_approx(coords, errors, params, subsample, ...)  xdem/spatialstats.py:2239-2308  (B = the random subset)
+ * model_type: 0 spherical, 1 exponential, 2 gaussian, 3 cubic, 4 stable (smooth[m] used); scikit-gstat's effective-range forms.
+ * Coordinates and errors float64. */
+int xdemhip_cov_double_sum(xdemhip_ctx* ctx, const double* ax, const double* ay, const double* ae, int64_t na, const double* bx,
+                           const double* by, const double* be, int64_t nb, int n_models, const int* model_type, const double* range,
+                           const double* psill, const double* smooth, double* out_sum, int memspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -287,3 +287,40 @@ def test_randomised_pair_sets_vs_oracle(ss):
             assert np.array_equal(got_e[ok], ref_e[ok]), (trial, mode, kind)
         else:
             assert np.allclose(got_e[ok], ref_e[ok], rtol=1e-12, atol=0), (trial, mode, kind, est)
+
+
+def test_number_of_effective_samples(ss):
+    """Callers of the fitted variogram: neff_exact / neff_hugonnet_approx (double covariance sums on the GPU) against the
+    reference's vectorised NumPy expression restated here (xdem/spatialstats.py:2226-2231, 2297-2300), for every device
+    model; closed-form vs numerical disk integration (the reference's own consistency test)."""
+    import pandas as pd
+    from scipy.spatial.distance import cdist
+
+    rng = np.random.default_rng(12)
+    n = 1500
+    coords = rng.uniform(0, 2000, (n, 2))
+    errors = rng.uniform(0.5, 2.0, n)
+    for models in (pd.DataFrame({"model": ["spherical", "gaussian"], "range": [150.0, 900.0], "psill": [0.7, 0.3]}),
+                   pd.DataFrame({"model": ["exponential"], "range": [400.0], "psill": [1.2]}),
+                   pd.DataFrame({"model": ["cubic", "stable"], "range": [300.0, 1200.0], "psill": [0.5, 0.5], "smooth": [np.nan, 1.4]})):
+        rho = ss.correlation_from_variogram(models)
+        d = cdist(coords, coords)
+        var = np.sum(errors.reshape((-1, 1)) @ errors.reshape((1, -1)) * rho(d.flatten()).reshape(d.shape))
+        want = float(np.mean(errors)) ** 2 / (var / n**2)
+        got = ss.neff_exact(coords, errors, models)
+        assert got == pytest.approx(want, rel=1e-11)
+        sub = np.random.default_rng(5).choice(n, size=200, replace=False)
+        d2 = cdist(coords, coords[sub])
+        var2 = np.sum(errors.reshape((-1, 1)) @ errors[sub].reshape((1, -1)) * rho(d2.flatten()).reshape(d2.shape))
+        want2 = float(np.mean(errors)) ** 2 / (var2 / (n * 200))
+        assert ss.neff_hugonnet_approx(coords, errors, models, subsample=200, random_state=5) == pytest.approx(want2, rel=1e-11)
+    with pytest.raises(NotImplementedError, match="not available on the HIP engine"):
+        ss.neff_exact(coords, errors, pd.DataFrame({"model": ["matern"], "range": [100.0], "psill": [1.0], "smooth": [0.5]}))
+    m = pd.DataFrame({"model": ["spherical", "gaussian", "exponential", "cubic"], "range": [200.0, 500.0, 800.0, 1000.0],
+                      "psill": [0.2, 0.3, 0.1, 0.4]})
+    for area in (1e3, 1e5, 1e7):
+        assert ss.neff_circular_approx_numerical(area, m) == pytest.approx(ss.neff_circular_approx_theoretical(area, m), rel=1e-6)
+    # a regular grid of uncorrelated-scale points: about one effective sample per correlation patch
+    big = np.stack(np.meshgrid(np.arange(300.0), np.arange(300.0)), -1).reshape(-1, 2) * 10.0
+    ne = ss.neff_exact(big, np.ones(len(big)), m.iloc[:1])   # 90 000 points = 8.1e9 ordered pairs
+    assert 100 < ne < len(big)

@@ -94,6 +94,8 @@ def lib() -> ctypes.CDLL:
                                            ctypes.c_double, c_i64p, c_dp, c_dp]
         L.xdemhip_binstats_destroy.argtypes = [ctypes.c_void_p]
         L.xdemhip_binstats_destroy.restype = None
+        L.xdemhip_cov_double_sum.argtypes = [c_ctx, c_dp, c_dp, c_dp, ctypes.c_int64, c_dp, c_dp, c_dp, ctypes.c_int64, ctypes.c_int, c_ip,
+                                             c_dp, c_dp, c_dp, c_dp, ctypes.c_int]
         L.xdemhip_nmad.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_int, c_dp, c_dp, c_i64p]
         L.xdemhip_interp_grid_linear.argtypes = [c_ctx, ctypes.c_int, c_dp, c_ip, c_dp, ctypes.POINTER(ctypes.c_void_p), c_ip,

@@ -951,3 +951,107 @@ def infer_spatial_correlation_from_stable(dvalues, list_models, stable_mask=None
     return _estimate_model_spatial_correlation(dvalues=stable, list_models=list_models, estimator=estimator, gsd=gsd, coords=coords,
                                                subsample=subsample, subsample_method=subsample_method, n_variograms=n_variograms,
                                                n_jobs=n_jobs, random_state=random_state, bounds=bounds, p0=p0, **kwargs)
+
+
+# ======================================================================================================================
+# Number of effective samples (xdem/spatialstats.py:2011-2308): closed forms on the host, the O(N^2) double covariance sums
+# on the GPU (csrc/covsum.hip)
+# ======================================================================================================================
+_COV_MODEL_ID = {"spherical": 0, "exponential": 1, "gaussian": 2, "cubic": 3, "stable": 4}
+
+
+def _cov_double_sum(coords_a, errors_a, coords_b, errors_b, params_variogram_model, ctx: _lib.Context | None = None) -> float:
+    """sum_i sum_j e_i e_j rho(d_ij) on the device (``xdemhip_cov_double_sum``); coords_b None = the A set itself."""
+    from . import variogram_models as vm
+
+    _check_validity_params_variogram(params_variogram_model)
+    names = [vm.model_name(m) for m in params_variogram_model["model"].values]
+    for n in names:
+        if n not in _COV_MODEL_ID:
+            raise NotImplementedError(f"Variogram model '{n}' is not available on the HIP engine (no modified Bessel function there).")
+    ctx = ctx or _lib.default_context()
+    dp = ctypes.POINTER(ctypes.c_double)
+
+    def col(a, k=None):
+        return np.ascontiguousarray(np.asarray(a, dtype=np.float64) if k is None else np.asarray(a, dtype=np.float64)[:, k])
+
+    ax, ay, ae = col(coords_a, 0), col(coords_a, 1), col(errors_a)
+    if coords_b is None:
+        bx = by = be = None
+        nb = 0
+    else:
+        bx, by, be = col(coords_b, 0), col(coords_b, 1), col(errors_b)
+        nb = bx.size
+    k = len(names)
+    types = (ctypes.c_int * k)(*[_COV_MODEL_ID[n] for n in names])
+    rng_ = np.ascontiguousarray(params_variogram_model["range"].values, dtype=np.float64)
+    sil = np.ascontiguousarray(params_variogram_model["psill"].values, dtype=np.float64)
+    smooth = np.ones(k)
+    if "smooth" in params_variogram_model:
+        sm = np.asarray(params_variogram_model["smooth"].values, dtype=np.float64)
+        smooth = np.where(np.isfinite(sm), sm, 1.0)
+    out = ctypes.c_double()
+    ptr = lambda a: None if a is None else a.ctypes.data_as(dp)  # noqa: E731
+    ctx.check(ctx._L.xdemhip_cov_double_sum(ctx.handle, ptr(ax), ptr(ay), ptr(ae), ax.size, ptr(bx), ptr(by), ptr(be), nb, k, types,
+                                            ptr(rng_), ptr(sil), ptr(np.ascontiguousarray(smooth)), ctypes.byref(out), _lib.HOST))
+    return float(out.value)
+
+
+def neff_circular_approx_theoretical(area: float, params_variogram_model) -> float:
+    """Number of effective samples over a disk of the given area from the closed-form radial integrals of the spherical,
+    exponential, gaussian and cubic covariances (after Rolstad et al., 2009; mirror of xdem/spatialstats.py:2011-2114)."""
+    from . import variogram_models as vm
+
+    _check_validity_params_variogram(params_variogram_model)
+    L = np.sqrt(area / np.pi)
+    squared_se = 0.0
+    for i in range(len(params_variogram_model)):
+        name = vm.model_name(params_variogram_model["model"].values[i])
+        a1, c1 = params_variogram_model["range"].values[i], params_variogram_model["psill"].values[i]
+        if name == "spherical":
+            squared_se += c1 * (1 - L / a1 + 1 / 5 * (L / a1) ** 3) if L <= a1 else c1 / 5 * (a1 / L) ** 2
+        elif name == "exponential":
+            a = a1 / 3
+            squared_se += 2 * c1 * (a / L) ** 2 * (1 - np.exp(-L / a) * (1 + L / a))
+        elif name == "gaussian":
+            a = a1 / 2
+            squared_se += c1 * (a / L) ** 2 * (1 - np.exp(-(L**2) / a**2))
+        elif name == "cubic":
+            squared_se += (c1 * (6 * a1**7 - 21 * a1**5 * L**2 + 21 * a1**4 * L**3 - 6 * a1**2 * L**5 + L**7) / (6 * a1**7)
+                           if L <= a1 else 1 / 6 * c1 * a1**2 / L**2)
+    return np.nansum(params_variogram_model.psill) / squared_se
+
+
+def neff_circular_approx_numerical(area: float, params_variogram_model) -> float:
+    """Same by numerical integration of h * covariance(h) over the disk, for any sum of models (spatialstats.py:2129-2172)."""
+    from scipy import integrate
+
+    _check_validity_params_variogram(params_variogram_model)
+    total_sill = np.nansum(params_variogram_model.psill)
+    cov = covariance_from_variogram(params_variogram_model)
+    h_equiv = np.sqrt(area / np.pi)
+    full_int = integrate.quad(lambda h: h * cov(h), 0, h_equiv)[0]
+    return total_sill / (2 * np.pi * full_int / area)
+
+
+def neff_exact(coords, errors, params_variogram_model, vectorized: bool = True, ctx: _lib.Context | None = None) -> float:
+    """Exact number of effective samples from the double sum of covariances over all ordered point pairs (mirror of
+    xdem/spatialstats.py:2175-2236; the N x N work runs on the GPU, no N x N matrix is formed)."""
+    errors = np.asarray(errors, dtype=np.float64)
+    n = len(coords)
+    var = _cov_double_sum(coords, errors, None, None, params_variogram_model, ctx)
+    return float(np.mean(errors)) ** 2 / (var / n**2)
+
+
+def neff_hugonnet_approx(coords, errors, params_variogram_model, subsample: int = 1000, vectorized: bool = True, random_state=None,
+                         ctx: _lib.Context | None = None) -> float:
+    """Approximate number of effective samples: one of the two sums runs over a random subset (Hugonnet et al., 2022; mirror
+    of xdem/spatialstats.py:2239-2308, same random draw)."""
+    rng = np.random.default_rng(random_state)
+    coords = np.asarray(coords, dtype=np.float64)
+    errors = np.asarray(errors, dtype=np.float64)
+    n = len(coords)
+    subsample = min(subsample, n)
+    rand_points = rng.choice(n, size=subsample, replace=False)
+    var = _cov_double_sum(coords, errors, coords[rand_points, :], errors[rand_points], params_variogram_model, ctx)
+    return float(np.mean(errors)) ** 2 / (var / (n * subsample))
