@@ -213,6 +213,9 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if world > 1:  # communicator set-up (RCCL creates its point-to-point channels lazily) is not a step: do it up front
+        xdist.RowBlock.wait_all(block.exchange())
+        barrier()
     for _ in range(args.warmup):
         step()
     barrier()
