@@ -75,9 +75,9 @@ extern "C" int hostsim_terrain(const void* dem, int dem_dtype, int64_t H, int64_
     P.sxy = 1.0 / (cxy * (resolution * resolution));
     const double deg = 0.017453292519943295;
     const double az = (360.0 - hs_az) * deg, alt = hs_alt * deg;
-    P.hs_sin_alt = sin(alt);
-    P.hs_kx = -cos(alt) * hs_z * cos(az);
-    P.hs_ky = cos(alt) * hs_z * sin(az);
+    P.hs_sin_alt = 254.0 * sin(alt);  // (the factor 254 of the hillshade is folded into the sun coefficients, as in terrain.hip)
+    P.hs_kx = 254.0 * (-cos(alt) * hs_z * cos(az));
+    P.hs_ky = 254.0 * (cos(alt) * hs_z * sin(az));
     P.hs_zf2 = hs_z * hs_z;
     P.mask = mask; P.curv_directional = curv_dir; P.tri_wilson = tri_wilson; P.degrees = degrees;
     if (dem_dtype == 0 && out_dtype == 0) return go<float, float>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);

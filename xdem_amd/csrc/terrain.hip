@@ -139,9 +139,9 @@ static void fill_params(const TerrainLaunch& L, TerrainParams& P) {
     const double deg = 0.017453292519943295;
     const double az = (360.0 - L.hs_az) * deg;  // np.deg2rad(360 - azimuth), surfit.py:614
     const double alt = L.hs_alt * deg;
-    P.hs_sin_alt = sin(alt);
-    P.hs_kx = -cos(alt) * L.hs_z * cos(az);
-    P.hs_ky = cos(alt) * L.hs_z * sin(az);
+    P.hs_sin_alt = 254.0 * sin(alt);
+    P.hs_kx = 254.0 * (-cos(alt) * L.hs_z * cos(az));
+    P.hs_ky = 254.0 * (cos(alt) * L.hs_z * sin(az));
     P.hs_zf2 = L.hs_z * L.hs_z;
     P.mask = L.attr_mask;
     P.curv_directional = L.curv_method == XDEMHIP_CURV_DIRECTIONAL;

@@ -48,9 +48,9 @@ struct TerrainParams {
     double s1;       // 1 / (c * res)        first derivatives  (c = 8 Horn, 2 ZT, 420 Florinsky)
     double sxx;      // 1 / (c * res^2)      zxx, zyy           (c = 1 ZT, 35 Florinsky)
     double sxy;      // 1 / (c * res^2)      zxy                (c = 4 ZT, 100 Florinsky)
-    double hs_sin_alt;   // sin(altitude)
-    double hs_kx;        // -cos(altitude) * z_factor * cos(az'),   az' = deg2rad(360 - azimuth)
-    double hs_ky;        //  cos(altitude) * z_factor * sin(az')
+    double hs_sin_alt;   // 254 * sin(altitude)                        (the hillshade's scale factor 254 is folded in)
+    double hs_kx;        // 254 * -cos(altitude) * z_factor * cos(az'),   az' = deg2rad(360 - azimuth)
+    double hs_ky;        // 254 *  cos(altitude) * z_factor * sin(az')
     double hs_zf2;       // z_factor^2
     uint32_t mask;
     int curv_directional;
@@ -122,6 +122,16 @@ XD_HD double fma_v(double a, double b, double c) {
     return r;
 #else
     return fma(a, b, c);
+#endif
+}
+// a * k + c with the loop-invariant multiplier k in a scalar register pair
+XD_HD double fma_ks(double a, double k, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+#else
+    return fma(a, k, c);
 #endif
 }
 // 2 * a + c (the 2.0 is an inline constant of the instruction)
@@ -220,8 +230,8 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         // 1.5 + 254 (sin(alt) cos(s') + cos(alt) sin(s') sin(az' - aspect)), s' = atan(zf * g), all algebraic
         double rwz = rw;  // z_factor 1 (the default): cos(s') = cos(slope)
         if (SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0)) rwz = rsqrt_pos(fma(P.hs_zf2, g2, 1.0));
-        const double shade = rwz * (P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx));
-        TOUT v = (TOUT)fma(254.0, shade, 1.5);
+        // 1.5 + 254 * shade; the factor 254 is folded into the three sun coefficients on the host (fill_params)
+        TOUT v = (TOUT)fma_c(rwz, P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx), 1.5);
         v = v < (TOUT)0 ? (TOUT)0 : (v > (TOUT)255 ? (TOUT)255 : v);
         put(out.p[P_HILLSHADE], o, (TOUT)(v));
     }
@@ -278,7 +288,7 @@ XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams&
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
     const bool wilson = SP::WILSON < 0 ? (P.tri_wilson != 0) : (SP::WILSON != 0);
     const double c = n[4];
-    if (m & A_TPI) put(out.p[P_TPI], o, (TOUT)((TOUT)(c - (sum9 - c) * 0.125)));  // (exact either way: * 0.125 is a power of two)
+    if (m & A_TPI) put(out.p[P_TPI], o, (TOUT)((TOUT)fma_ks(sum9 - c, -0.125, c)));  // c - (sum9 - c) / 8, exact scaling
     if (m & A_ROUGH) {
         // Dartnell roughness: max - min of the window, NaN if any NaN (window.py:261-289); +-Inf propagate like NumPy
         double mx = n[0], mn = n[0];
