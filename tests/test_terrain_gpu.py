@@ -181,6 +181,28 @@ def test_large_properties_16384(terrain):
         assert_parity(g, r[2:-2, 2:-2], FULL[i])
 
 
+def test_raster_beyond_2g_pixels(terrain):
+    """46400^2 = 2.15e9 pixels: element offsets of the lower tiles exceed 2^31 (a sign-extended 32-bit half of the
+    tile origin once sent those stores out of bounds).  Crops from the bottom rows must match the whole-raster planes."""
+    import torch
+
+    from xdem_amd.synth import fbm_torch
+
+    n = 46400
+    attrs = ["slope", "max_curvature", "terrain_ruggedness_index"]
+    dem = fbm_torch(n, n, "cuda", seed=7)
+    out = terrain.terrain_attributes_device(dem, attrs, resolution=10.0)
+    torch.cuda.synchronize()
+    for (r, c) in ((n - 700, n - 1000), (n - 300, 5), (46341, 20000), (23170, 23000)):
+        r1, c1 = min(r + 300, n), min(c + 700, n)
+        oc = terrain.terrain_attributes_device(dem[r:r1, c:c1].contiguous(), attrs, resolution=10.0)
+        torch.cuda.synchronize()
+        a_ = oc[:, 2:-2, 2:-2].view(torch.int32)
+        b_ = out[:, r + 2:r1 - 2, c + 2:c1 - 2].view(torch.int32)
+        assert torch.equal(a_, b_), (r, c)
+    assert bool(torch.isfinite(out[0, 2:-2, 2:-2]).all())
+
+
 @pytest.mark.parametrize("w", [3, 5])
 def test_roughness_next_row_f2(terrain, w):
     """SURVEY 8f-2 (first windowed index beyond TPI/TRI): max - min of the window, NaN if any NaN."""

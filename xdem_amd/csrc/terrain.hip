@@ -82,8 +82,9 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
         // wave-uniform plane pointers at the tile origin (SGPR pairs) + 32-bit per-thread byte offsets
         // (readfirstlane pins the wave-uniform tile offset into SGPRs so the pointers below stay scalar)
         const uint64_t org_u = (uint64_t)(y0 * a.W + x0);
-        const int64_t org_off = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(org_u >> 32)) << 32) |
-                                          __builtin_amdgcn_readfirstlane((uint32_t)org_u));
+        // (the builtin returns a signed int: go through uint32_t, or a low half >= 2^31 sign-extends over the high half)
+        const int64_t org_off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(org_u >> 32)) << 32) |
+                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)org_u));
         Planes<TOUT> org;
 #pragma unroll
         for (int k = 0; k < N_ATTR; ++k) org.p[k] = a.out.p[k] + org_off;
