@@ -315,6 +315,37 @@ def test_C3_full_size_properties(coreg):
     assert abs(offsets[0] / res + 2.0) < 0.02 and abs(offsets[1] / res + 1.0) < 0.02 and abs(offsets[2] + 2.0) < 0.02
 
 
+def test_rows_beyond_2g_pixels_match_a_small_plan(coreg):
+    """46400^2 device-resident pair whose only valid rows are the LAST 3000 (pixel offsets > 2^31): every step output
+    equals that of a plan built on just those rows (tba NaN on the first two of them, as above them in the big raster)."""
+    import torch
+
+    from xdem_amd.synth import fbm_torch
+
+    n, k, res = 46400, 3000, 10.0
+    ref = fbm_torch(n, n, "cuda", seed=5)
+    tba = torch.full((n, n), float("nan"), device="cuda", dtype=torch.float32)
+    tba[n - k + 2:] = torch.roll(ref[n - k + 2:], shifts=-2, dims=1) + 1.5
+    tba[n - k + 2:, ::7] = float("nan")
+    big = coreg.NKPlan(ref, tba, None)
+    small = coreg.NKPlan(ref[n - k:].contiguous(), tba[n - k:].contiguous(), None)
+    assert big.n_valid == small.n_valid > 0.8 * (k - 3) * n
+    # whole-pixel shifts: the bilinear weights are exact whatever the absolute row index, so everything is bit-identical
+    # (a fractional shift rounds row + shift differently at row 46000 than at row 3000 -- last-ulp weights, as upstream)
+    for (sx, sy) in ((0.0, 0.0), (10.0, -20.0)):
+        a, b = big.step(sx, sy, (res, res), 72), small.step(sx, sy, (res, res), 72)
+        assert a["n_valid"] == b["n_valid"] and np.array_equal(a["counts"], b["counts"])
+        assert a["vshift"] == b["vshift"] and np.array_equal(a["edges"], b["edges"])
+        bad = np.flatnonzero(a["medians"] != b["medians"])
+        assert bad.size == 0, (bad, a["medians"][bad], b["medians"][bad], a["counts"][bad])
+        np.testing.assert_allclose([a["y_mean"], a["y_std"]], [b["y_mean"], b["y_std"]], rtol=1e-9)
+    a, b = big.step(1.25, -0.5, (res, res), 72), small.step(1.25, -0.5, (res, res), 72)
+    assert np.array_equal(a["counts"], b["counts"])
+    np.testing.assert_allclose(a["medians"], b["medians"], rtol=0, atol=1e-4)
+    big.close()
+    small.close()
+
+
 def test_randomised_steps_vs_oracle(coreg):
     """Seeded sweep of one Nuth-Kaab iteration step: raster shapes, dtypes, NaN / inlier patterns, sub- and multi-pixel
     shifts, resolutions, numbers of aspect bins (5, 72, 150 -- the last needs two LDS sweeps) -- vertical shift, valid count,
