@@ -201,6 +201,18 @@ def test_raster_beyond_2g_pixels(terrain):
         b_ = out[:, r + 2:r1 - 2, c + 2:c1 - 2].view(torch.int32)
         assert torch.equal(a_, b_), (r, c)
     assert bool(torch.isfinite(out[0, 2:-2, 2:-2]).all())
+    del out
+    # the other window kernels (rugosity, fractal roughness w=13, generic 5x5 roughness) address pixels the same way
+    for attrs, kw, m in ((["rugosity", "fractal_roughness"], {}, 6), (["roughness", "topographic_position_index"], {"window_size": 5}, 2)):
+        out = terrain.terrain_attributes_device(dem, attrs, resolution=10.0, **kw)
+        for (r, c) in ((n - 300, n - 700), (46341, 20000)):
+            r1, c1 = min(r + 300, n), min(c + 700, n)
+            oc = terrain.terrain_attributes_device(dem[r:r1, c:c1].contiguous(), attrs, resolution=10.0, **kw)
+            torch.cuda.synchronize()
+            a_ = oc[:, m:-m, m:-m].view(torch.int32)
+            b_ = out[:, r + m:r1 - m, c + m:c1 - m].view(torch.int32)
+            assert torch.equal(a_, b_), (attrs, r, c)
+        del out
 
 
 @pytest.mark.parametrize("w", [3, 5])
