@@ -92,8 +92,8 @@ def test_terrain_argument_validation_messages():
         t.hillshade(dem, resolution=1.0, altitude=91)
     with pytest.raises(ValueError, match="z_factor must be a non-negative finite value"):
         t.hillshade(dem, resolution=1.0, z_factor=np.inf)
-    with pytest.raises(ValueError, match="only provides engine='hip'"):
-        t.slope(dem, resolution=1.0, engine="scipy")
+    with pytest.raises(ValueError, match="engine must be 'hip', 'scipy' or 'numba'"):
+        t.slope(dem, resolution=1.0, engine="cpu")
     for bad in (-0.1, 2.1):  # tests/test_terrain/test_freq.py:47-51 (checked before any GPU work would matter)
         with pytest.raises(ValueError, match="Alpha must be between 0 and 2"):
             t.texture_shading(dem, alpha=bad)

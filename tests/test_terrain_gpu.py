@@ -76,6 +76,25 @@ def test_f64_in_out_and_mixed(terrain):
         assert_parity(g, r, f"f32->f64/{a}")
 
 
+def test_engine_names_select_the_precision_recipe(terrain):
+    """'scipy' = the default recipe (derivatives rounded to the DEM dtype); 'numba' = float64 derivatives
+    (surfit.py:1044), i.e. what the float64-input path computes on the widened DEM.  The Numba engine itself cannot run
+    here (numba absent): its variant is checked against the oracle's float64 path, which the reference fixtures pin."""
+    dem = _dem((150, 300), seed=13)
+    attrs = FULL + ["roughness"]
+    base = terrain.get_terrain_attribute(dem, attrs, resolution=10.0)
+    for g, b in zip(terrain.get_terrain_attribute(dem, attrs, resolution=10.0, engine="scipy"), base):
+        assert np.array_equal(g, b, equal_nan=True)
+    got = terrain.get_terrain_attribute(dem, attrs, resolution=10.0, engine="numba")
+    ref = to.terrain_attributes(dem.astype(np.float64), FULL, resolution=10.0, out_dtype=np.float32)
+    for a, g, r in zip(FULL, got, ref):
+        assert g.dtype == np.float32
+        assert_parity(g, r, f"numba-recipe/{a}")
+    for i in (9, 10, 11):  # windowed indexes: unchanged
+        assert np.array_equal(got[i], base[i], equal_nan=True)
+    assert not np.array_equal(got[0], base[0], equal_nan=True)  # and the recipes do differ in the last digits
+
+
 def test_inf_and_nan_propagation_bit_exact_mask(terrain):
     rng = np.random.default_rng(42)
     dem = rng.normal(size=(40, 300)).astype(np.float32)

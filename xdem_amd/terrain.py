@@ -201,13 +201,20 @@ def get_terrain_attribute(
     Drop-in for ``xdem.terrain.get_terrain_attribute`` (xdem/terrain/terrain.py:176-485): ``str`` attribute
     -> one array, ``list`` -> list of arrays (a one-element list also yields a single array, as upstream,
     terrain.py:666); ndarray / masked-array in -> ndarray out; Raster-like in -> ``type(dem).from_array(...,
-    nodata=-99999)`` out.  ``engine`` must be ``"hip"``.
+    nodata=-99999)`` out.
+
+    Every ``engine`` value runs the HIP kernels; the name only selects upstream's precision recipe for the surface
+    fit: ``"hip"`` / ``"scipy"`` (upstream's default engine, the one parity is pinned on) round the fitted derivatives
+    to the DEM dtype before the float64 attribute formulas (``scipy.ndimage.convolve`` returns the input dtype,
+    spatialstats.py:2512-2594); ``"numba"`` keeps them in float64 as upstream's Numba engine does (surfit.py:1044)
+    -- the two differ only for a float32 / integer DEM, at the 1e-7 relative level upstream itself tolerates
+    (tests/test_terrain/test_surfit.py:452).  Windowed indexes are the same in both.
     """
     if slope_method is not None:
         warnings.warn("'slope_method' is deprecated, use 'surface_fit' instead.", DeprecationWarning, stacklevel=2)
         surface_fit = slope_method
-    if engine != "hip":
-        raise ValueError(f"xdem_amd only provides engine='hip' (got '{engine}'); it has no CPU engine.")
+    if engine not in ("hip", "scipy", "numba"):
+        raise ValueError(f"engine must be 'hip', 'scipy' or 'numba' (got '{engine}'); all of them run on the GPU.")
     if mp_config is not None:
         raise NotImplementedError("mp_config tiling is replaced by xdem_amd.dist (row blocks over GPUs); pass None.")
 
@@ -237,10 +244,16 @@ def get_terrain_attribute(
     outs = {a: np.empty((H, W), dtype=out_dtype) for a in set(attribute)}
     ctx = _lib.default_context()
     stencil = [a for a in attribute if a not in list_requiring_frequency_domain]
-    if stencil:
-        launch_terrain(ctx, dem_arr.ctypes.data, dem_arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
-                       stencil, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
-                       degrees, out_dtype, {a: outs[a].ctypes.data for a in set(stencil)}, _lib.HOST, window_size_fractal)
+    groups = [(dem_arr, stencil)]
+    if engine == "numba" and dem_arr.dtype == np.float32 and any(a in list_requiring_surface_fit for a in stencil):
+        # unrounded derivatives: the float64-input kernel on the widened DEM (exact), windowed indexes on the DEM as is
+        groups = [(dem_arr.astype(np.float64), [a for a in stencil if a in list_requiring_surface_fit]),
+                  (dem_arr, [a for a in stencil if a not in list_requiring_surface_fit])]
+    for arr, names in groups:
+        if names:
+            launch_terrain(ctx, arr.ctypes.data, arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
+                           names, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
+                           degrees, out_dtype, {a: outs[a].ctypes.data for a in set(names)}, _lib.HOST, window_size_fractal)
     if "texture_shading" in attribute:  # frequency-domain attribute: its own engine (terrain.py:637-644)
         alpha = texture_alpha
         code = lambda dt: _lib.F32 if np.dtype(dt) == np.float32 else _lib.F64  # noqa: E731
