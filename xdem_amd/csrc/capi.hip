@@ -149,7 +149,6 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     L.hs_alt = hs_alt; L.hs_az = hs_az; L.hs_z = hs_z;
 
     const size_t in_es = dem_dtype == XDEMHIP_F32 ? 4 : 8, out_es = out_dtype == XDEMHIP_F32 ? 4 : 8;
-    const int64_t buf_rows = halo_top + H + halo_bottom;
 
     if (memspace == XDEMHIP_DEVICE) {
         L.dem = dem;

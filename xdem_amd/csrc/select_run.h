@@ -49,10 +49,14 @@ template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
                                                                  int64_t n, int nb, int bin0, int copies,
                                                                  const SelState<typename KeyT<T>::type>* st, int shift, int first,
-                                                                 uint64_t* hist) {
+                                                                 uint64_t* hist, const unsigned long long* n_dev = nullptr) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* h = reinterpret_cast<uint32_t*>(smem);
+    if (n_dev) {  // element count produced on the device (sample / candidate buffers): `n` is then the buffer capacity
+        const unsigned long long m = *n_dev;
+        n = m < (unsigned long long)n ? (int64_t)m : n;
+    }
     const int table = nb * SEL_RADIX;
     for (int k = threadIdx.x; k < table * copies; k += blockDim.x) h[k] = 0;
     __syncthreads();
@@ -78,10 +82,15 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
                                                                  int64_t n, int nb, const SelState<typename KeyT<T>::type>* st,
-                                                                 uint64_t* succ /* [nb], all-ones = none */) {
+                                                                 uint64_t* succ /* [nb], all-ones = none */,
+                                                                 const unsigned long long* n_dev = nullptr) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K* m = reinterpret_cast<K*>(smem);
+    if (n_dev) {
+        const unsigned long long c = *n_dev;
+        n = c < (unsigned long long)n ? (int64_t)c : n;
+    }
     K* pref = m + nb;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) { m[k] = ~(K)0; pref[k] = st[k].prefix; }
     __syncthreads();
@@ -146,9 +155,13 @@ template <typename K> struct SelResult {
 // Exact lower/upper medians of vals[0..n) per bin (bins == nullptr: one bin).  With an all-reduce hook installed the
 // integer histograms / successor keys are combined over the ranks after every pass, so every rank selects the same
 // global order statistics from its own share of the data.
+//
+// select_enqueue only queues the passes on the context's stream (no host synchronisation unless the hook is installed):
+// the states and successor keys stay in `scratch` until select_fetch copies them out.  `d_n` (optional) is a device-side
+// element count -- `n` is then the capacity of the buffer and `n_grid` the size the launch grids are dimensioned for.
 template <typename T>
-int run_select_core(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
-                    std::vector<SelResult<typename KeyT<T>::type>>& out, int mode, const uint64_t* d_given) {
+int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int64_t n_grid, const unsigned long long* d_n, int nb,
+                   unsigned char* scratch, int mode, const uint64_t* d_given) {
     typedef typename KeyT<T>::type K;
     SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
@@ -157,6 +170,7 @@ int run_select_core(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_succ, 0xFF, 8 * (size_t)nb, ctx->stream));
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * (size_t)nb * SEL_RADIX, ctx->stream));
     const int passes = KeyT<T>::passes;
+    const int grid = grid_for(ctx, n_grid, HIST_THREADS * 4, 2);
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * (passes - 1 - p);
         if (n > 0)
@@ -168,8 +182,8 @@ int run_select_core(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64
                 const size_t lds = (size_t)nbs * SEL_RADIX * sizeof(uint32_t) * copies;
                 int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
                 if (rc) return rc;
-                hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * 4, 2)), dim3(HIST_THREADS), lds,
-                                   ctx->stream, vals, bins, n, nbs, b0, copies, st, shift, (int)(p == 0), d_hist);
+                hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
+                                   st, shift, (int)(p == 0), d_hist, d_n);
                 XD_HIP_CHECK(ctx, hipGetLastError());
             }
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
@@ -179,20 +193,31 @@ int run_select_core(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     if (n > 0) {
-        hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * 4, 2)), dim3(HIST_THREADS), 2 * sizeof(K) * nb,
-                           ctx->stream, vals, bins, n, nb, st, d_succ);
+        hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), 2 * sizeof(K) * nb, ctx->stream, vals, bins, n, nb, st,
+                           d_succ, d_n);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
-    int rc = xd_allreduce_device(ctx, d_succ, nb, XDEMHIP_RED_MIN_U64);
-    if (rc) return rc;
+    return xd_allreduce_device(ctx, d_succ, nb, XDEMHIP_RED_MIN_U64);
+}
+
+template <typename T>
+int select_fetch(xdemhip_ctx* ctx, unsigned char* scratch, int nb, std::vector<SelResult<typename KeyT<T>::type>>& out) {
+    typedef typename KeyT<T>::type K;
     std::vector<SelState<K>> hs(nb);
     std::vector<uint64_t> hsucc(nb);
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), st, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(hsucc.data(), d_succ, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), scratch + OFF_STATE, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(hsucc.data(), scratch + off_succ(nb), 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
     XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     out.resize(nb);
     for (int k = 0; k < nb; ++k) { out[k].st = hs[k]; out[k].succ = hsucc[k]; }
     return XDEMHIP_OK;
+}
+
+template <typename T>
+int run_select_core(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
+                    std::vector<SelResult<typename KeyT<T>::type>>& out, int mode, const uint64_t* d_given) {
+    const int rc = select_enqueue<T>(ctx, vals, bins, n, n, nullptr, nb, scratch, mode, d_given);
+    return rc ? rc : select_fetch<T>(ctx, scratch, nb, out);
 }
 
 // ---- bracketed selection ------------------------------------------------------------------------------------------
@@ -232,8 +257,11 @@ inline int sel_ws_create(xdemhip_ctx* ctx, int64_t n, size_t es, int nb_max, Sel
     return XDEMHIP_OK;
 }
 
-__device__ __forceinline__ bool sel_line_sampled(int64_t line) {
-    return ((uint64_t)line * 0x9E3779B97F4A7C15ull >> 58) == 0;  // top 6 bits of a multiplicative hash: 1 line in 64
+// Stratified 1/64 sample of 32-element lines: group g covers lines [64 g, 64 g + 64) and contributes the one line picked by
+// the top 6 bits of a multiplicative hash of g (no aliasing with the raster's row period, and sampled lines can be
+// enumerated directly instead of testing every line).
+__device__ __forceinline__ int64_t sel_sampled_line(int64_t group) {
+    return group * 64 + (int64_t)((uint64_t)group * 0x9E3779B97F4A7C15ull >> 58);
 }
 
 // Block-level compaction: selected (value, bin) pairs collect in an LDS staging buffer (one LDS atomic per wave and step)
@@ -313,25 +341,55 @@ __global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(const T* __r
     st.held = reinterpret_cast<int*>(st.base + 1);
     if (threadIdx.x == 0) *st.held = 0;
     __syncthreads();
-    // a step covers 64 lines (2048 elements) per wave; only sampled lines are loaded
-    const int64_t step = (int64_t)blockDim.x * SEL_TILE;
-    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
-#pragma unroll
-        for (int q = 0; q < SEL_TILE; ++q) {
-            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
-            bool keep = false;
-            T v = (T)0;
-            uint16_t b = 0;
-            if (p < n && sel_line_sampled(p >> 5)) {
+    // a step covers one sampled line per half-wave (32 line groups = 65536 elements per 1024-thread workgroup)
+    const int64_t n_groups = (((n + 31) >> 5) + 63) >> 6;
+    const int halves = (int)blockDim.x >> 5;
+    const int half = (int)threadIdx.x >> 5, l32 = (int)threadIdx.x & 31;
+    for (int64_t g0 = (int64_t)blockIdx.x * halves; g0 < n_groups; g0 += (int64_t)gridDim.x * halves) {
+        const int64_t g = g0 + half;
+        bool keep = false;
+        T v = (T)0;
+        uint16_t b = 0;
+        if (g < n_groups) {
+            const int64_t p = (sel_sampled_line(g) << 5) + l32;
+            if (p < n) {
                 v = vals[p];
                 b = bins ? bins[p] : (uint16_t)0;
                 keep = (v == v) && (int)b < nb;
             }
-            st.append(keep, v, b);
         }
+        st.append(keep, v, b);
         st.sync_and_flush(false, out_v, out_b, &ctr[0], cap, &ctr[2]);
     }
     st.sync_and_flush(true, out_v, out_b, &ctr[0], cap, &ctr[2]);
+}
+
+// Brackets from the two sample selections: which = 0 stores the low keys after the SEL_BRACKET_LO selection, which = 1 the
+// high keys after SEL_BRACKET_HI (`degenerate`: high = low, a bracket that almost surely misses -- test mode of the fallback).
+template <typename K>
+__global__ void bracket_keys_kernel(const SelState<K>* st, int nb, int which, int degenerate, K* klo, K* khi) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const bool have = st[b].count > 0;
+    if (which == 0) klo[b] = have ? st[b].prefix : (K)0;
+    else khi[b] = have ? (degenerate ? klo[b] : st[b].prefix) : (K)~(K)0;
+}
+
+// Rank of the wanted order statistic among the candidates of every bin (all-ones: empty bin); raises flags[3] when a
+// bracket does not hold the lower (and, for an even count, the upper) median.
+static __global__ void bracket_given_kernel(const uint64_t* cnt /* [3][nb]: total, below, inside */, int nb, uint64_t* given,
+                                     unsigned long long* flags) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint64_t total = cnt[b], lt = cnt[nb + b], in = cnt[2 * nb + b];
+    uint64_t g = ~(uint64_t)0;
+    if (total) {
+        const uint64_t k = (total - 1) / 2;
+        const uint64_t need = (total & 1) ? k : k + 1;
+        if (lt > k || need - lt >= in) flags[3] = 1ull;
+        else g = k - lt;
+    }
+    given[b] = g;
 }
 
 // One pass over the data: per bin the number of (non-NaN) elements, of elements below the bracket and inside it; elements
@@ -402,38 +460,33 @@ int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n,
     } else if (plain) {
         return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
     }
-    uint64_t* d_ctr = ws->d_small;
+    uint64_t* d_ctr = ws->d_small;  // [0] sample count, [1] candidate count, [2] overflow, [3] bracket missed
+    unsigned long long* d_flags = reinterpret_cast<unsigned long long*>(d_ctr);
     K* d_klo = reinterpret_cast<K*>(ws->d_small + 8);
     K* d_khi = reinterpret_cast<K*>(ws->d_small + 8 + ws->nb_max);
     uint64_t* d_given = ws->d_small + 8 + 2 * ws->nb_max;
     uint64_t* d_cnt = ws->d_small + 8 + 3 * ws->nb_max;
+    const SelState<K>* d_st = reinterpret_cast<const SelState<K>*>(scratch + OFF_STATE);
     XD_HIP_CHECK(ctx, hipMemsetAsync(ws->d_small, 0, (size_t)(8 + 6 * ws->nb_max) * 8, ctx->stream));
+    // Everything below is queued back to back: sample and candidate counts, brackets and ranks stay on the device, and the
+    // host synchronises once at the end (with the all-reduce hook every reduction synchronises anyway).
     // 1. sample
     const size_t lds_stage = (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     int rc = set_big_lds(ctx, sample_lines_kernel<T>, lds_stage);
     if (rc) return rc;
-    hipLaunchKernelGGL((sample_lines_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds_stage, ctx->stream,
-                       vals, bins, n, nb, static_cast<T*>(ws->s_vals), ws->s_bins, reinterpret_cast<unsigned long long*>(d_ctr), ws->s_cap);
+    hipLaunchKernelGGL((sample_lines_kernel<T>), dim3(grid_for(ctx, n / 64 + 1, HIST_THREADS, 2)), dim3(HIST_THREADS), lds_stage, ctx->stream,
+                       vals, bins, n, nb, static_cast<T*>(ws->s_vals), ws->s_bins, d_flags, ws->s_cap);
     XD_HIP_CHECK(ctx, hipGetLastError());
-    uint64_t h_ctr[3];
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 24, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t m = (int64_t)(h_ctr[0] < (uint64_t)ws->s_cap ? h_ctr[0] : (uint64_t)ws->s_cap);
     // 2. brackets from the sample (global over the ranks through the hook)
-    std::vector<SelResult<K>> lo, hi;
-    rc = run_select_core<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, m, nb, scratch, lo, SEL_BRACKET_LO, nullptr);
+    const int nbb = (nb + 63) / 64;
+    const int64_t m_est = n / 48 + 1;  // (expected n / 64)
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_LO, nullptr);
     if (rc) return rc;
-    rc = run_select_core<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, m, nb, scratch, hi, SEL_BRACKET_HI, nullptr);
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, d_klo, d_khi);
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_HI, nullptr);
     if (rc) return rc;
-    std::vector<K> klo(nb), khi(nb);
-    for (int b = 0; b < nb; ++b) {
-        const bool have = lo[b].st.count > 0;
-        klo[b] = have ? lo[b].st.prefix : (K)0;
-        khi[b] = have ? hi[b].st.prefix : (K)~(K)0;
-        if (ctx->selection_mode == 2 && have) khi[b] = klo[b];  // test mode: brackets that (almost surely) miss
-    }
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_klo, klo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_khi, khi.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 1, (int)(ctx->selection_mode == 2), d_klo, d_khi);
+    XD_HIP_CHECK(ctx, hipGetLastError());
     // 3. the one pass over the data
     int copies = (32 * 1024) / (nb * 12);
     copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
@@ -441,34 +494,25 @@ int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n,
     rc = set_big_lds(ctx, bracket_pass_kernel<T>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((bracket_pass_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds, ctx->stream, vals,
-                       bins, n, nb, copies, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), ws->c_bins,
-                       reinterpret_cast<unsigned long long*>(d_ctr), ws->c_cap);
+                       bins, n, nb, copies, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), ws->c_bins, d_flags, ws->c_cap);
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = xd_allreduce_device(ctx, d_cnt, 3 * (int64_t)nb, XDEMHIP_RED_SUM_U64);
     if (rc) return rc;
     rc = xd_allreduce_device(ctx, d_ctr + 2, 1, XDEMHIP_RED_SUM_U64);  // overflow anywhere -> everybody falls back
     if (rc) return rc;
-    std::vector<uint64_t> cnt(3 * nb);
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(cnt.data(), d_cnt, 8 * 3 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 24, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    bool ok = h_ctr[2] == 0;
-    std::vector<uint64_t> given(nb);
-    for (int b = 0; b < nb && ok; ++b) {
-        const uint64_t total = cnt[b], lt = cnt[nb + b], in = cnt[2 * nb + b];
-        given[b] = ~(uint64_t)0;
-        if (total == 0) continue;
-        const uint64_t k = (total - 1) / 2;
-        const uint64_t need = (total & 1) ? k : k + 1;  // even counts also need the upper median inside the bracket
-        if (lt > k || need - lt >= in) ok = false;
-        else given[b] = k - lt;
-    }
-    if (!ok) return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
-    // 4. exact selection among the candidates
-    const int64_t nc = (int64_t)h_ctr[1];
-    rc = run_select_core<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, nc, nb, scratch, out, SEL_GIVEN, d_given);
+    hipLaunchKernelGGL(bracket_given_kernel, dim3(nbb), dim3(64), 0, ctx->stream, d_cnt, nb, d_given, d_flags);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    // 4. exact selection among the candidates (a few percent of the data)
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, ws->c_cap, n / 32 + 1, d_flags + 1, nb, scratch, SEL_GIVEN, d_given);
     if (rc) return rc;
+    std::vector<uint64_t> cnt(3 * nb);
+    uint64_t h_ctr[4];
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(cnt.data(), d_cnt, 8 * 3 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost, ctx->stream));
+    rc = select_fetch<T>(ctx, scratch, nb, out);  // (synchronises the stream)
+    if (rc) return rc;
+    if (h_ctr[2] != 0 || h_ctr[3] != 0)  // buffer overflow or a bracket missed: plain selection over all the data
+        return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
     for (int b = 0; b < nb; ++b) {
         const uint64_t total = cnt[b], lt = cnt[nb + b];
         if (total == 0) { out[b].st.count = 0; continue; }
