@@ -187,6 +187,53 @@ __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, con
     if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s1); atomicAdd(&sums[1], s2); }
 }
 
+// The same y / bin id computed on the fly for the bracketed selection (select_run.h): its sample and counting passes read
+// dh, slope_tan and aspect directly, so the y and bin-id arrays are neither written nor re-read (nk_y_kernel + plain
+// selection remain the fallback).  The counting pass, which sees every element once, also accumulates the two sums.
+template <typename T> struct NkYSource {
+    const T* dh;
+    const T* slope_tan;
+    const T* aspect;
+    T vshift;
+    const T* edges;  // [nb + 1], device
+    double* sums;    // [sum, sumsq], device
+    T* e;            // LDS copy of the edges (setup)
+    double inv_width;
+    struct Raw { T d, st, x; };
+    struct Acc { double s1 = 0.0, s2 = 0.0; };
+    static size_t lds_bytes(int nb) { return sizeof(T) * (size_t)(nb + 1) + 8; }
+    __device__ __forceinline__ void setup(unsigned char* lds, int nb) {
+        e = reinterpret_cast<T*>((reinterpret_cast<uintptr_t>(lds) + 7) & ~(uintptr_t)7);
+        for (int k = threadIdx.x; k <= nb; k += blockDim.x) e[k] = edges[k];
+        inv_width = (double)nb / ((double)edges[nb] - (double)edges[0]);
+    }
+    __device__ __forceinline__ void fetch(int64_t p, Raw& r) const { r.d = dh[p]; r.st = slope_tan[p]; r.x = aspect[p]; }
+    __device__ __forceinline__ void blank(Raw& r) const { r.d = (T)NAN; r.st = (T)1; r.x = (T)0; }
+    template <bool ACC> __device__ __forceinline__ bool eval(const Raw& r, int nb, T& v, uint16_t& b, Acc& acc) const {
+        v = (T)NAN;
+        b = 0xFFFF;
+        if (!(r.d == r.d)) return false;
+        const T yv = t_div(t_sub(r.d, vshift), r.st);
+        const T x = r.x;
+        int idx = (int)(((double)x - (double)e[0]) * inv_width);  // (same digitize as nk_y_kernel)
+        idx = idx < 0 ? 0 : (idx > nb ? nb : idx);
+        while (idx > 0 && !(e[idx] <= x)) --idx;
+        while (idx < nb && e[idx + 1] <= x) ++idx;
+        if (!(e[0] <= x)) idx = -1;
+        if (idx == nb) idx = nb - 1;
+        if (ACC) { acc.s1 += (double)yv; acc.s2 += (double)yv * (double)yv; }
+        v = yv;
+        if (idx < 0 || idx >= nb) return false;
+        b = (uint16_t)idx;
+        return yv == yv;
+    }
+    __device__ __forceinline__ void finish(Acc& acc) const {
+        double s1 = acc.s1, s2 = acc.s2;
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s1); atomicAdd(&sums[1], s2); }
+    }
+};
+
 }  // namespace xd
 
 // ================================================================================================================
@@ -296,22 +343,34 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
     make_edges<T>((double)val_of((K)hs0.asp_min), (double)val_of((K)hs0.asp_max), nb, edges);
     T* d_edges = reinterpret_cast<T*>(base);
     XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, edges.data(), sizeof(T) * (nb + 1), hipMemcpyHostToDevice, ctx->stream));
+    // 4. per-bin exact medians.  Bracketed route: y and the bin ids are computed on the fly by the sample / counting passes
+    // (NkYSource), the counting pass accumulates the sums.  Otherwise (small grids, plain mode, a missed bracket): y and
+    // bin-id arrays + plain digit passes.
+    std::vector<SelResult<K>> hs;
+    bool done = false;
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
-    if (n > 0) {
-        hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream, dh,
-                           static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, n, (T)vs, d_edges,
-                           nb, y, bins, d_sums);
-        XD_HIP_CHECK(ctx, hipGetLastError());
+    {
+        NkYSource<T> src{dh, static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, (T)vs, d_edges, d_sums,
+                         nullptr, 0.0};
+        rc = run_select_bracketed<T, NkYSource<T>>(ctx, src, n, nb, base, hs, &P->ws, &done);
+        if (rc) return rc;
+    }
+    if (!done) {
+        XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
+        if (n > 0) {
+            hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream, dh,
+                               static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, n, (T)vs, d_edges,
+                               nb, y, bins, d_sums);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+        }
+        rc = run_select_core<T>(ctx, y, bins, n, nb, base, hs, SEL_MEDIAN, nullptr);
+        if (rc) return rc;
     }
     rc = xd_allreduce_device(ctx, d_sums, 2, XDEMHIP_RED_SUM_F64);
     if (rc) return rc;
     double sums[2];
     XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream));
-
-    // 4. per-bin exact medians
-    std::vector<SelResult<K>> hs;
-    rc = run_select<T>(ctx, y, bins, n, nb, base, hs, &P->ws);  // (synchronises the stream: `sums` has landed)
-    if (rc) return rc;
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const double cnt = (double)g[0].st.count;
     const double mean = sums[0] / cnt;
     const double var = sums[1] / cnt - mean * mean;

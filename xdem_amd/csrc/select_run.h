@@ -44,12 +44,15 @@ __device__ __forceinline__ uint64_t k_shfl_down(uint64_t v, int off) { return (u
 // low-entropy leading digit and serialise 64-way.  1024-thread workgroups so that even the 72 KB table of the
 // 72 aspect bins runs at full occupancy (2 workgroups = 32 waves per CU).
 constexpr int HIST_THREADS = 1024;
+constexpr int SEL_UNROLL = 4;
 
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
                                                                  int64_t n, int nb, int bin0, int copies,
                                                                  const SelState<typename KeyT<T>::type>* st, int shift, int first,
-                                                                 uint64_t* hist, const unsigned long long* n_dev = nullptr) {
+                                                                 uint64_t* hist, const unsigned long long* n_dev = nullptr,
+                                                                 const typename KeyT<T>::type* rb_lo = nullptr,
+                                                                 const uint32_t* rb_shift = nullptr) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* h = reinterpret_cast<uint32_t*>(smem);
@@ -62,14 +65,31 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
     __syncthreads();
     uint32_t* hc = h + (threadIdx.x % copies) * table;
     const K himask = first ? (K)0 : (K)(~(K)0 << (shift + 8));
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const T v = vals[p];
-        if (v != v) continue;
-        int b = bins ? (int)bins[p] - bin0 : 0;
-        if (b < 0 || b >= nb) continue;
-        const K key = key_of(v);
-        if (!first && (key & himask) != st[bin0 + b].prefix) continue;
-        atomicAdd(&hc[b * SEL_RADIX + (int)((key >> shift) & 0xFF)], 1u);
+    // Rebased keys (candidates of a bracketed selection): every candidate of a bin lies in [lo, hi] and shares the leading
+    // digits of lo -- all lanes would hammer one LDS counter per bin.  (key - lo[bin]) << s, with s the same for all bins,
+    // keeps the order inside a bin and spreads the leading digit.
+    const int rbs = rb_shift ? (int)*rb_shift : 0;
+    // four elements per thread and step, all loads issued before the first use (memory-level parallelism)
+    const int64_t step = (int64_t)blockDim.x * SEL_UNROLL;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+        T v[SEL_UNROLL];
+        uint16_t bb[SEL_UNROLL];
+#pragma unroll
+        for (int q = 0; q < SEL_UNROLL; ++q) {
+            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+            v[q] = (p < n) ? vals[p] : (T)NAN;
+            bb[q] = (p < n && bins) ? bins[p] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int q = 0; q < SEL_UNROLL; ++q) {
+            if (v[q] != v[q]) continue;
+            const int b = bins ? (int)bb[q] - bin0 : 0;
+            if (b < 0 || b >= nb) continue;
+            K key = key_of(v[q]);
+            if (rb_lo) key = (K)((K)(key - rb_lo[bin0 + b]) << rbs);
+            if (!first && (key & himask) != st[bin0 + b].prefix) continue;
+            atomicAdd(&hc[b * SEL_RADIX + (int)((key >> shift) & 0xFF)], 1u);
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < table; k += blockDim.x) {
@@ -83,7 +103,9 @@ template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
                                                                  int64_t n, int nb, const SelState<typename KeyT<T>::type>* st,
                                                                  uint64_t* succ /* [nb], all-ones = none */,
-                                                                 const unsigned long long* n_dev = nullptr) {
+                                                                 const unsigned long long* n_dev = nullptr,
+                                                                 const typename KeyT<T>::type* rb_lo = nullptr,
+                                                                 const uint32_t* rb_shift = nullptr) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K* m = reinterpret_cast<K*>(smem);
@@ -93,14 +115,27 @@ __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __rest
     }
     K* pref = m + nb;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) { m[k] = ~(K)0; pref[k] = st[k].prefix; }
+    const int rbs = rb_shift ? (int)*rb_shift : 0;
     __syncthreads();
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const T v = vals[p];
-        if (v != v) continue;
-        const int b = bins ? (int)bins[p] : 0;
-        if (b < 0 || b >= nb) continue;
-        const K key = key_of(v);
-        if (key > pref[b] && key < m[b]) k_atomic_min(&m[b], key);
+    const int64_t step = (int64_t)blockDim.x * SEL_UNROLL;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+        T v[SEL_UNROLL];
+        uint16_t bb[SEL_UNROLL];
+#pragma unroll
+        for (int q = 0; q < SEL_UNROLL; ++q) {
+            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+            v[q] = (p < n) ? vals[p] : (T)NAN;
+            bb[q] = (p < n && bins) ? bins[p] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int q = 0; q < SEL_UNROLL; ++q) {
+            if (v[q] != v[q]) continue;
+            const int b = (int)bb[q];
+            if (b >= nb) continue;
+            K key = key_of(v[q]);
+            if (rb_lo) key = (K)((K)(key - rb_lo[b]) << rbs);
+            if (key > pref[b] && key < m[b]) k_atomic_min(&m[b], key);
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < nb; k += blockDim.x)
@@ -161,7 +196,8 @@ template <typename K> struct SelResult {
 // element count -- `n` is then the capacity of the buffer and `n_grid` the size the launch grids are dimensioned for.
 template <typename T>
 int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int64_t n_grid, const unsigned long long* d_n, int nb,
-                   unsigned char* scratch, int mode, const uint64_t* d_given) {
+                   unsigned char* scratch, int mode, const uint64_t* d_given, int n_passes = 0, bool want_succ = true,
+                   const typename KeyT<T>::type* rb_lo = nullptr, const uint32_t* rb_shift = nullptr) {
     typedef typename KeyT<T>::type K;
     SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
@@ -170,8 +206,9 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_succ, 0xFF, 8 * (size_t)nb, ctx->stream));
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * (size_t)nb * SEL_RADIX, ctx->stream));
     const int passes = KeyT<T>::passes;
+    const int run = (n_passes > 0 && n_passes < passes) ? n_passes : passes;  // leading digits only: bracket ends need no more
     const int grid = grid_for(ctx, n_grid, HIST_THREADS * 4, 2);
-    for (int p = 0; p < passes; ++p) {
+    for (int p = 0; p < run; ++p) {
         const int shift = 8 * (passes - 1 - p);
         if (n > 0)
             for (int b0 = 0; b0 < nb; b0 += MAX_BINS_PER_SWEEP) {
@@ -183,7 +220,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                 int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
                 if (rc) return rc;
                 hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
-                                   st, shift, (int)(p == 0), d_hist, d_n);
+                                   st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift);
                 XD_HIP_CHECK(ctx, hipGetLastError());
             }
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
@@ -192,9 +229,10 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                            (int)(p == 0), (int)(p == passes - 1), mode, d_given);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
+    if (!want_succ) return XDEMHIP_OK;
     if (n > 0) {
         hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), 2 * sizeof(K) * nb, ctx->stream, vals, bins, n, nb, st,
-                           d_succ, d_n);
+                           d_succ, d_n, rb_lo, rb_shift);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     return xd_allreduce_device(ctx, d_succ, nb, XDEMHIP_RED_MIN_U64);
@@ -330,17 +368,39 @@ template <typename T> struct BlockStage {
     }
 };
 
-template <typename T>
-__global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins, int64_t n,
-                                                                    int nb, T* out_v, uint16_t* out_b, unsigned long long* ctr, int64_t cap) {
+// Element sources of the sample / bracket passes.  A source hands out element p in two steps -- fetch (global loads only,
+// so that a step's loads can all be issued first) and eval (value, bin id, usable?) -- and may keep a table in LDS.
+// ArraySource: plain (values, bin ids) arrays.  Other sources compute the values on the fly from the arrays they derive
+// from (nuthkaab.hip: y = (dh - vshift) / slope_tan binned by aspect), which saves writing and re-reading them.
+template <typename T> struct ArraySource {
+    const T* vals;
+    const uint16_t* bins;  // nullptr: single bin
+    struct Raw { T v; uint16_t b; };
+    struct Acc {};
+    static size_t lds_bytes(int) { return 0; }
+    __device__ __forceinline__ void setup(unsigned char*, int) {}
+    __device__ __forceinline__ void fetch(int64_t p, Raw& r) const { r.v = vals[p]; r.b = bins ? bins[p] : (uint16_t)0; }
+    __device__ __forceinline__ void blank(Raw& r) const { r.v = (T)NAN; r.b = 0; }
+    template <bool ACC> __device__ __forceinline__ bool eval(const Raw& r, int nb, T& v, uint16_t& b, Acc&) const {
+        v = r.v; b = r.b;
+        return (v == v) && (int)b < nb;
+    }
+    __device__ __forceinline__ void finish(Acc&) const {}
+};
+
+template <typename T, typename Src>
+__global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(Src src, int64_t n, int nb, T* out_v, uint16_t* out_b,
+                                                                    unsigned long long* ctr, int64_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     BlockStage<T> st;
     st.v = reinterpret_cast<T*>(smem);
     st.b = reinterpret_cast<uint16_t*>(st.v + SEL_STAGE_CAP);
     st.base = reinterpret_cast<unsigned long long*>(st.b + SEL_STAGE_CAP);
     st.held = reinterpret_cast<int*>(st.base + 1);
+    src.setup(reinterpret_cast<unsigned char*>(st.base + 2), nb);
     if (threadIdx.x == 0) *st.held = 0;
     __syncthreads();
+    typename Src::Acc acc;
     // a step covers one sampled line per half-wave (32 line groups = 65536 elements per 1024-thread workgroup)
     const int64_t n_groups = (((n + 31) >> 5) + 63) >> 6;
     const int halves = (int)blockDim.x >> 5;
@@ -353,9 +413,9 @@ __global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(const T* __r
         if (g < n_groups) {
             const int64_t p = (sel_sampled_line(g) << 5) + l32;
             if (p < n) {
-                v = vals[p];
-                b = bins ? bins[p] : (uint16_t)0;
-                keep = (v == v) && (int)b < nb;
+                typename Src::Raw r;
+                src.fetch(p, r);
+                keep = src.template eval<false>(r, nb, v, b, acc);
             }
         }
         st.append(keep, v, b);
@@ -366,13 +426,31 @@ __global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(const T* __r
 
 // Brackets from the two sample selections: which = 0 stores the low keys after the SEL_BRACKET_LO selection, which = 1 the
 // high keys after SEL_BRACKET_HI (`degenerate`: high = low, a bracket that almost surely misses -- test mode of the fallback).
+// (The sample selections fix only the leading digits: `low_mask` = the digits left open, all ones at the high end.)
 template <typename K>
-__global__ void bracket_keys_kernel(const SelState<K>* st, int nb, int which, int degenerate, K* klo, K* khi) {
+__global__ void bracket_keys_kernel(const SelState<K>* st, int nb, int which, int degenerate, K low_mask, K* klo, K* khi) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const bool have = st[b].count > 0;
     if (which == 0) klo[b] = have ? st[b].prefix : (K)0;
-    else khi[b] = have ? (degenerate ? klo[b] : st[b].prefix) : (K)~(K)0;
+    else khi[b] = have ? (degenerate ? klo[b] : (K)(st[b].prefix | low_mask)) : (K)~(K)0;
+}
+
+// Left shift that brings the widest bracket's (hi - lo) up to the top key bit (rebased candidate keys, hist_pass_kernel).
+__host__ __device__ inline uint32_t rebase_shift_of(uint32_t range) { return range ? (uint32_t)__builtin_clz(range) : 0u; }
+__host__ __device__ inline uint32_t rebase_shift_of(uint64_t range) { return range ? (uint32_t)__builtin_clzll((unsigned long long)range) : 0u; }
+template <typename K>
+__global__ __launch_bounds__(64) void rebase_shift_kernel(const K* klo, const K* khi, int nb, uint32_t* shift) {
+    K r = 0;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        const K d = khi[b] >= klo[b] ? (K)(khi[b] - klo[b]) : (K)0;
+        r = d > r ? d : r;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const K o = k_shfl_down(r, off);
+        r = o > r ? o : r;
+    }
+    if (threadIdx.x == 0) *shift = rebase_shift_of(r);
 }
 
 // Rank of the wanted order statistic among the candidates of every bin (all-ones: empty bin); raises flags[3] when a
@@ -395,8 +473,8 @@ static __global__ void bracket_given_kernel(const uint64_t* cnt /* [3][nb]: tota
 // One pass over the data: per bin the number of (non-NaN) elements, of elements below the bracket and inside it; elements
 // inside [klo, khi] are compacted through the staging buffer.  LDS: staging | klo / khi per bin | `copies` privatised sets of
 // 3 counters per bin.
-template <typename T>
-__global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins, int64_t n,
+template <typename T, typename Src>
+__global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int64_t n,
                                                                     int nb, int copies, const typename KeyT<T>::type* __restrict__ klo,
                                                                     const typename KeyT<T>::type* __restrict__ khi, uint64_t* counters /* [3][nb] */,
                                                                     T* out_v, uint16_t* out_b, unsigned long long* ctr, int64_t cap) {
@@ -412,33 +490,37 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(const T* __r
     uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);
     for (int k = threadIdx.x; k < nb; k += blockDim.x) { lo[k] = klo[k]; hi[k] = khi[k]; }
     for (int k = threadIdx.x; k < 3 * nb * copies; k += blockDim.x) c[k] = 0;
+    src.setup(reinterpret_cast<unsigned char*>(c + 3 * nb * copies), nb);
     if (threadIdx.x == 0) *st.held = 0;
     __syncthreads();
     uint32_t* cc = c + (threadIdx.x % copies) * 3 * nb;
+    typename Src::Acc acc;
     const int64_t step = (int64_t)blockDim.x * SEL_TILE;
     for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
-        T v[SEL_TILE];
-        uint16_t b[SEL_TILE];
+        typename Src::Raw raw[SEL_TILE];
 #pragma unroll
         for (int q = 0; q < SEL_TILE; ++q) {  // all loads of the step first
             const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
-            v[q] = (p < n) ? vals[p] : (T)NAN;
-            b[q] = (p < n && bins) ? bins[p] : (uint16_t)0;
+            if (p < n) src.fetch(p, raw[q]);
+            else src.blank(raw[q]);
         }
 #pragma unroll
         for (int q = 0; q < SEL_TILE; ++q) {
             bool cand = false;
-            if (v[q] == v[q] && (int)b[q] < nb) {
-                const K key = key_of(v[q]);
-                atomicAdd(&cc[b[q]], 1u);
-                if (key < lo[b[q]]) atomicAdd(&cc[nb + b[q]], 1u);
-                else if (key <= hi[b[q]]) { atomicAdd(&cc[2 * nb + b[q]], 1u); cand = true; }
+            T v;
+            uint16_t b;
+            if (src.template eval<true>(raw[q], nb, v, b, acc)) {
+                const K key = key_of(v);
+                atomicAdd(&cc[b], 1u);
+                if (key < lo[b]) atomicAdd(&cc[nb + b], 1u);
+                else if (key <= hi[b]) { atomicAdd(&cc[2 * nb + b], 1u); cand = true; }
             }
-            st.append(cand, v[q], b[q]);
+            st.append(cand, v, b);
         }
         st.sync_and_flush(false, out_v, out_b, &ctr[1], cap, &ctr[2]);
     }
     st.sync_and_flush(true, out_v, out_b, &ctr[1], cap, &ctr[2]);
+    src.finish(acc);
     for (int k = threadIdx.x; k < 3 * nb; k += blockDim.x) {
         unsigned long long s = 0;
         for (int q = 0; q < copies; ++q) s += c[q * 3 * nb + k];
@@ -446,19 +528,23 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(const T* __r
     }
 }
 
-template <typename T>
-int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
-               std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws = nullptr) {
+// Bracketed selection over an element source.  *done = false (and `out` meaningless) when the route is not available --
+// small input, no workspace, plain mode, some rank cannot -- or when a bracket missed / a buffer overflowed: the caller
+// then runs the plain selection on materialised arrays.
+template <typename T, typename Src>
+int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, unsigned char* scratch,
+                         std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws, bool* done) {
     typedef typename KeyT<T>::type K;
+    *done = false;
     static const bool disabled = getenv("XDEMHIP_NO_BRACKET") != nullptr;  // (A/B timing knob)
     const bool plain = disabled || ctx->selection_mode == 1 || !ws || !ws->d_small || nb > ws->nb_max || ws->es != sizeof(T) || nb > MAX_BINS_PER_SWEEP ||
                        n < SEL_BRACKET_MIN_N || (n / 24 + 4096) > ws->s_cap;
     if (ctx->allreduce) {  // sharded data: every rank must take the same route (local sizes / allocations may differ)
         uint64_t can = plain ? 0 : 1;
         if (ctx->allreduce(&can, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
-        if (!can) return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
+        if (!can) return XDEMHIP_OK;
     } else if (plain) {
-        return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
+        return XDEMHIP_OK;
     }
     uint64_t* d_ctr = ws->d_small;  // [0] sample count, [1] candidate count, [2] overflow, [3] bracket missed
     unsigned long long* d_flags = reinterpret_cast<unsigned long long*>(d_ctr);
@@ -472,29 +558,37 @@ int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n,
     // host synchronises once at the end (with the all-reduce hook every reduction synchronises anyway).
     // 1. sample
     const size_t lds_stage = (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
-    int rc = set_big_lds(ctx, sample_lines_kernel<T>, lds_stage);
+    const size_t lds_src = Src::lds_bytes(nb);
+    int rc = set_big_lds(ctx, sample_lines_kernel<T, Src>, lds_stage + lds_src);
     if (rc) return rc;
-    hipLaunchKernelGGL((sample_lines_kernel<T>), dim3(grid_for(ctx, n / 64 + 1, HIST_THREADS, 2)), dim3(HIST_THREADS), lds_stage, ctx->stream,
-                       vals, bins, n, nb, static_cast<T*>(ws->s_vals), ws->s_bins, d_flags, ws->s_cap);
+    hipLaunchKernelGGL((sample_lines_kernel<T, Src>), dim3(grid_for(ctx, n / 64 + 1, HIST_THREADS, 2)), dim3(HIST_THREADS), lds_stage + lds_src,
+                       ctx->stream, src, n, nb, static_cast<T*>(ws->s_vals), ws->s_bins, d_flags, ws->s_cap);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 2. brackets from the sample (global over the ranks through the hook)
     const int nbb = (nb + 63) / 64;
     const int64_t m_est = n / 48 + 1;  // (expected n / 64)
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_LO, nullptr);
+    constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough (2^-15 / 2^-12 relative)
+    const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
+    uint32_t* d_rbs = reinterpret_cast<uint32_t*>(ws->d_small + 4);
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_LO, nullptr,
+                           BR_PASSES, false);
     if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, d_klo, d_khi);
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_HI, nullptr);
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, d_klo, d_khi);
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_HI, nullptr,
+                           BR_PASSES, false);
     if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 1, (int)(ctx->selection_mode == 2), d_klo, d_khi);
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 1, (int)(ctx->selection_mode == 2), low_mask, d_klo,
+                       d_khi);
+    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, nb, d_rbs);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 3. the one pass over the data
     int copies = (32 * 1024) / (nb * 12);
     copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
-    const size_t lds = lds_stage + (size_t)nb * (2 * sizeof(K) + 12 * (size_t)copies);
-    rc = set_big_lds(ctx, bracket_pass_kernel<T>, lds);
+    const size_t lds = lds_stage + (size_t)nb * (2 * sizeof(K) + 12 * (size_t)copies) + lds_src;
+    rc = set_big_lds(ctx, bracket_pass_kernel<T, Src>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((bracket_pass_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds, ctx->stream, vals,
-                       bins, n, nb, copies, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), ws->c_bins, d_flags, ws->c_cap);
+    hipLaunchKernelGGL((bracket_pass_kernel<T, Src>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds, ctx->stream, src,
+                       n, nb, copies, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), ws->c_bins, d_flags, ws->c_cap);
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = xd_allreduce_device(ctx, d_cnt, 3 * (int64_t)nb, XDEMHIP_RED_SUM_U64);
     if (rc) return rc;
@@ -503,23 +597,40 @@ int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n,
     hipLaunchKernelGGL(bracket_given_kernel, dim3(nbb), dim3(64), 0, ctx->stream, d_cnt, nb, d_given, d_flags);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 4. exact selection among the candidates (a few percent of the data)
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, ws->c_cap, n / 32 + 1, d_flags + 1, nb, scratch, SEL_GIVEN, d_given);
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, ws->c_cap, n / 32 + 1, d_flags + 1, nb, scratch, SEL_GIVEN, d_given,
+                           0, true, d_klo, d_rbs);
     if (rc) return rc;
     std::vector<uint64_t> cnt(3 * nb);
-    uint64_t h_ctr[4];
+    std::vector<K> klo(nb);
+    uint64_t h_ctr[5];
     XD_HIP_CHECK(ctx, hipMemcpyAsync(cnt.data(), d_cnt, 8 * 3 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(klo.data(), d_klo, sizeof(K) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 40, hipMemcpyDeviceToHost, ctx->stream));
     rc = select_fetch<T>(ctx, scratch, nb, out);  // (synchronises the stream)
     if (rc) return rc;
-    if (h_ctr[2] != 0 || h_ctr[3] != 0)  // buffer overflow or a bracket missed: plain selection over all the data
-        return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
+    if (h_ctr[2] != 0 || h_ctr[3] != 0) return XDEMHIP_OK;  // buffer overflow or a bracket missed (*done stays false)
+    const int rbs = (int)(uint32_t)h_ctr[4];
     for (int b = 0; b < nb; ++b) {
         const uint64_t total = cnt[b], lt = cnt[nb + b];
         if (total == 0) { out[b].st.count = 0; continue; }
         out[b].st.count = total;
         out[b].st.n_le += lt;
+        out[b].st.prefix = (K)((K)(out[b].st.prefix >> rbs) + klo[b]);  // back from the rebased candidate keys
+        if (out[b].succ != ~(uint64_t)0) out[b].succ = (uint64_t)(K)((K)((K)out[b].succ >> rbs) + klo[b]);
     }
+    *done = true;
     return XDEMHIP_OK;
+}
+
+// Exact medians of (values, bin ids) arrays: bracketed route when it applies, plain digit passes otherwise.
+template <typename T>
+int run_select(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int nb, unsigned char* scratch,
+               std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws = nullptr) {
+    bool done = false;
+    ArraySource<T> src{vals, bins};
+    const int rc = run_select_bracketed<T, ArraySource<T>>(ctx, src, n, nb, scratch, out, ws, &done);
+    if (rc || done) return rc;
+    return run_select_core<T>(ctx, vals, bins, n, nb, scratch, out, SEL_MEDIAN, nullptr);
 }
 
 // np.nanmedian of a bin from its selection state: odd count -> the middle value; even -> mean of the two middle

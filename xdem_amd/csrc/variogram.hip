@@ -724,7 +724,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     // small device block: selection states | klo | khi | given | counters[3 nb] | candidate counter, overflow
     unsigned char* d_small = nullptr;
     const size_t off_klo = (size_t)nb * 32, off_khi = off_klo + 8 * (size_t)nb, off_given = off_khi + 8 * (size_t)nb,
-                 off_cnt = off_given + 8 * (size_t)nb, off_ctr = off_cnt + 24 * (size_t)nb, small_bytes = off_ctr + 16;
+                 off_cnt = off_given + 8 * (size_t)nb, off_ctr = off_cnt + 24 * (size_t)nb, off_rbs = off_ctr + 16, small_bytes = off_rbs + 8;
     if (hipMalloc(reinterpret_cast<void**>(&d_small), small_bytes) != hipSuccess) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
     SelState<K>* d_st = reinterpret_cast<SelState<K>*>(d_small);
     void* scratch = nullptr;
@@ -771,7 +771,20 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         hipError_t e = hipMemcpyAsync(P->prefix, klo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_khi, khi.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_small + off_cnt, 0, 24 * (size_t)nb + 16, ctx->stream);
-        (void)d_klo;
+        // candidate keys are rebased for their selection (select_run.h, hist_pass_kernel): low ends and the common shift
+        // in key_of()'s key space (|dv| >= 0: key = bits | top bit; the pair passes use bits << 1)
+        const K top = (K)1 << (8 * sizeof(K) - 1);
+        std::vector<K> rb_lo(nb);
+        K widest = 0;
+        for (int k = 0; k < nb; ++k) {
+            rb_lo[k] = (K)((klo[k] >> 1) | top);
+            const K r = khi[k] >= klo[k] ? (K)((khi[k] >> 1) - (klo[k] >> 1)) : (K)0;
+            widest = r > widest ? r : widest;
+        }
+        const uint32_t rbs = rebase_shift_of(widest);
+        uint32_t* d_rbs = reinterpret_cast<uint32_t*>(d_small + off_rbs);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_klo, rb_lo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rbs, &rbs, 4, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket setup failed"); }
         if (P->n_wg_big > 0) {
             XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
@@ -804,14 +817,17 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
             e = hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket ranks upload failed"); }
             std::vector<SelResult<K>> res;
-            rc = run_select_core<T>(ctx, static_cast<const T*>(P->cand_v), P->cand_b, (int64_t)ctr[0], nb, static_cast<unsigned char*>(scratch),
-                                    res, SEL_GIVEN, d_given);
+            rc = select_enqueue<T>(ctx, static_cast<const T*>(P->cand_v), P->cand_b, (int64_t)ctr[0], (int64_t)ctr[0], nullptr, nb,
+                                   static_cast<unsigned char*>(scratch), SEL_GIVEN, d_given, 0, true, d_klo, d_rbs);
+            if (rc == XDEMHIP_OK) rc = select_fetch<T>(ctx, static_cast<unsigned char*>(scratch), nb, res);
             if (rc) { cleanup(); return rc; }
             for (int k = 0; k < nb; ++k) {
                 counts[k] = (int64_t)cnt[k];
                 if (cnt[k] == 0) { medians[k] = NAN; continue; }
                 res[k].st.count = cnt[k];
                 res[k].st.n_le += cnt[nb + k];
+                res[k].st.prefix = (K)((K)(res[k].st.prefix >> rbs) + rb_lo[k]);  // back from the rebased keys
+                if (res[k].succ != ~(uint64_t)0) res[k].succ = (uint64_t)(K)((K)((K)res[k].succ >> rbs) + rb_lo[k]);
                 medians[k] = median_from<T>(res[k]);
             }
             done = true;
