@@ -76,8 +76,9 @@ int xdemhip_synchronize(xdemhip_ctx* ctx);
 int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
 /* Tuning / test switches.  "selection": how the exact medians (nanmedian of dh, aspect-bin and nd_binning medians, NMAD) are
  * selected -- 0 (default) bracketed for large inputs: brackets from a ~1/64 line sample, one counting + compaction pass,
- * exact selection among the candidates, plain radix passes if a bracket misses; 1 plain 8-bit radix passes only;
- * 2 degenerate brackets (exercises the fall-back).  Results are identical in every mode.
+ * exact selection among the candidates, plain radix passes if a bracket misses or if the input is too small per bin for
+ * useful brackets; 1 plain 8-bit radix passes only; 2 degenerate brackets (exercises the fall-back); 3 bracketed even
+ * where the per-bin sample is small (test switch).  Results are identical in every mode.
  * "host_chunk_mb": device-memory budget (MiB) of one row chunk of host-buffer xdemhip_terrain calls (0 = default 8192): host
  * rasters of any size stream through the GPU in row chunks with the overlap the attributes need. */
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value);

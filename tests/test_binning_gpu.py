@@ -154,11 +154,12 @@ def test_nmad_device_matches_numpy():
         assert cnt == np.isfinite(w).sum() and med == np.nanmedian(w) and nm == float(bo.nmad(w))
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_selection_modes_agree_on_large_inputs(mode):
-    """Bracketed selection (mode 0: sample -> brackets -> one counting/compaction pass -> candidates), plain radix passes
-    (1) and the bracket-miss fall-back (2) give the same exact order statistics: 6e6-sample binning with ties, global NMAD,
-    and a Nuth-Kaab step, all against NumPy / the oracle."""
+    """Bracketed selection (sample -> brackets -> one counting/compaction pass -> candidates; mode 3 forces it for the
+    multi-bin cases too, which mode 0 leaves to the plain passes at these sizes), plain radix passes (1) and the
+    bracket-miss fall-back (2) give the same exact order statistics: 6e6-sample binning with ties, global NMAD, and a
+    Nuth-Kaab step (y and bin ids computed inside the passes on the bracketed route), all against NumPy / the oracle."""
     from xdem_amd import _lib, coreg
     from xdem_amd import spatialstats as ss
     import nuthkaab_oracle as no

@@ -114,9 +114,11 @@ def _worker_reductions(rank, world, port, outdir):
             rng = np.random.default_rng(6)
             tba = (np.roll(ref, (1, -1), (0, 1)) + 1.5 + rng.normal(0, 0.3, (m, m))).astype(np.float32)
             tba[rng.uniform(size=(m, m)) < 0.1] = np.nan
+            ctx.set_option("selection", 3 if m > 1000 else 0)  # (3: bracketed for the 72 aspect bins as well at this size)
             plan = coreg.NKPlan(ref, tba, None, ctx, group="world")
             d = plan.step(2.0, -3.0, (10.0, 10.0), 72)
             plan.close()
+            ctx.set_option("selection", 0)
             res[f"nk{m}"] = np.concatenate([[d["vshift"], d["n_valid"], d["y_mean"]], d["counts"], d["medians"], d["edges"]])
         rng = np.random.default_rng(9)
         blocks = []

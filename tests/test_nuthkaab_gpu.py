@@ -171,10 +171,13 @@ def test_class_api_recovers_shift(coreg):
 def test_sharded_reduction_path_single_rank(coreg, shape):
     """The multi-GPU path (row range + all-reduce hook through torch.distributed) on a 1-rank NCCL group: must give
     exactly the single-process results.  (Multi-rank sums of the same integer histograms are exercised on CPU/gloo.)
-    The larger shape takes the bracketed-selection route (sample / counter / candidate reductions through the hook)."""
+    The larger shape takes the bracketed-selection route (sample / counter / candidate reductions through the hook), forced
+    for the 72 aspect bins too (selection mode 3; mode 0 leaves them to the plain passes at this size)."""
     import os
 
     import torch.distributed as dist
+
+    from xdem_amd import _lib
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29611")
@@ -183,6 +186,7 @@ def test_sharded_reduction_path_single_rank(coreg, shape):
         dist.init_process_group("nccl", rank=0, world_size=1)
         created = True
     try:
+        _lib.default_context().set_option("selection", 3 if shape[0] > 1000 else 0)
         ref, tba, inlier, res = _pair(shape)
         base = coreg.NKPlan(ref, tba, inlier)
         want = base.step(7.0, -3.0, (res, res), 72)
@@ -196,6 +200,7 @@ def test_sharded_reduction_path_single_rank(coreg, shape):
         assert np.array_equal(got["counts"], want["counts"]) and np.array_equal(got["medians"], want["medians"], equal_nan=True)
         assert np.array_equal(got["edges"], want["edges"])
     finally:
+        _lib.default_context().set_option("selection", 0)
         if created:
             dist.destroy_process_group()
 

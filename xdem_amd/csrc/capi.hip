@@ -83,7 +83,7 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         return XDEMHIP_OK;
     }
     if (std::string(name) == "selection") {
-        if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets");
+        if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets, 3 bracketed");
         ctx->selection_mode = value;
         return XDEMHIP_OK;
     }

@@ -18,7 +18,8 @@ struct xdemhip_ctx {
     xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)
     void* allreduce_user = nullptr;
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
-    int selection_mode = 0;  // 0 auto (bracketed for large inputs), 1 plain digit passes only, 2 degenerate brackets (tests the fallback)
+    int selection_mode = 0;  // 0 auto (bracketed for large inputs), 1 plain digit passes only, 2 degenerate brackets (tests the
+                             // fallback), 3 bracketed whatever the per-bin sample size (2 and 3: test switches)
     std::string err;
 };
 

@@ -274,6 +274,9 @@ struct SelWorkspace {
     size_t es = 4;
 };
 constexpr int64_t SEL_BRACKET_MIN_N = (int64_t)1 << 22;
+// The bracket of a bin spans 6 sqrt(32 / m) of its elements (m = its share of the sample, n / (64 nb) on average): below
+// ~7000 sampled elements per bin more than 40 % of the data would be candidates and the plain passes are the better route.
+constexpr int64_t SEL_BRACKET_MIN_PER_BIN = 460000;
 
 inline void sel_ws_free(SelWorkspace& w) {
     void* b[] = {w.s_vals, w.s_bins, w.c_vals, w.c_bins, w.d_small};
@@ -538,7 +541,7 @@ int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, un
     *done = false;
     static const bool disabled = getenv("XDEMHIP_NO_BRACKET") != nullptr;  // (A/B timing knob)
     const bool plain = disabled || ctx->selection_mode == 1 || !ws || !ws->d_small || nb > ws->nb_max || ws->es != sizeof(T) || nb > MAX_BINS_PER_SWEEP ||
-                       n < SEL_BRACKET_MIN_N || (n / 24 + 4096) > ws->s_cap;
+                       n < SEL_BRACKET_MIN_N || (ctx->selection_mode == 0 && n < SEL_BRACKET_MIN_PER_BIN * nb) || (n / 24 + 4096) > ws->s_cap;
     if (ctx->allreduce) {  // sharded data: every rank must take the same route (local sizes / allocations may differ)
         uint64_t can = plain ? 0 : 1;
         if (ctx->allreduce(&can, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
