@@ -654,14 +654,15 @@ template <typename T> __host__ inline T abs_key_value(typename KeyT<T>::type key
 // histograms go through the all-reduce hook, so sharded pair sets select the same global order statistics.
 template <typename T>
 int pairs_digit_passes(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st, int sample, int mode, const uint64_t* d_given,
-                       std::vector<SelState<typename KeyT<T>::type>>& out) {
+                       std::vector<SelState<typename KeyT<T>::type>>& out, int n_passes = 0) {
     typedef typename KeyT<T>::type K;
     xdemhip_ctx* ctx = P->ctx;
     const int nb = P->nb, passes = KeyT<T>::passes;
+    const int run = (n_passes > 0 && n_passes < passes) ? n_passes : passes;  // (bracket ends: leading digits only)
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_st, 0, sizeof(SelState<K>) * nb, ctx->stream));
     XD_HIP_CHECK(ctx, hipMemsetAsync(P->hist, 0, 8 * (size_t)nb * SEL_RADIX, ctx->stream));
     P->sample = sample;
-    for (int p = 0; p < passes; ++p) {
+    for (int p = 0; p < run; ++p) {
         const int shift = 8 * (passes - 1 - p);
         if (P->n_wg_big > 0)
             for (int b0 = 0; b0 < nb; b0 += HIST_BINS_PER_SWEEP) {
@@ -752,14 +753,16 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     bool done = false;
     if (bracket) {
         std::vector<SelState<K>> lo, hi;
-        rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo);
-        if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi);
+        constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough
+        const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
+        rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo, BR_PASSES);
+        if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi, BR_PASSES);
         if (rc) { cleanup(); return rc; }
         std::vector<K> klo(nb), khi(nb);
         for (int k = 0; k < nb; ++k) {
             const bool have = lo[k].count > 0;
             klo[k] = have ? lo[k].prefix : (K)0;
-            khi[k] = have ? hi[k].prefix : (K)~(K)0;
+            khi[k] = have ? (K)(hi[k].prefix | low_mask) : (K)~(K)0;
             if (ctx->selection_mode == 2 && have) khi[k] = klo[k];  // test mode: brackets that (almost surely) miss
         }
         K* d_klo = reinterpret_cast<K*>(d_small + off_klo);
