@@ -162,6 +162,13 @@ int xdemhip_nk_step(xdemhip_nk_plan* plan, double shift_x, double shift_y, doubl
  * all-reduce hook).  Call right after xdemhip_nk_create on every rank; n_valid then returns the global count. */
 int xdemhip_nk_set_rows(xdemhip_nk_plan* plan, int64_t row_begin, int64_t row_end, int64_t* n_valid);
 /* Debug / test access: copy the auxiliary rasters back to host buffers (any pointer may be NULL). */
+/* Statistic of the aspect bins (NuthKaab(bin_statistic=...), xdem/coreg/affine.py:2404): XDEMHIP_BINSTAT_MEDIAN (default,
+ * np.nanmedian -- exact selection) or XDEMHIP_BINSTAT_MEAN (np.nanmean: per-bin float64 sums and counts in one pass, sum-
+ * reducible across GPUs; equals NumPy's float32 pairwise mean to rounding, not bit for bit).  xdemhip_nk_step then returns
+ * the bin means in `medians`. */
+#define XDEMHIP_BINSTAT_MEDIAN 0
+#define XDEMHIP_BINSTAT_MEAN 1
+int xdemhip_nk_set_statistic(xdemhip_nk_plan* plan, int bin_stat);
 int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uint8_t* valid);
 void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,

@@ -128,6 +128,19 @@ def bin_medians(x: np.ndarray, y: np.ndarray, n_bins: int = 72):
     return edges, counts, med
 
 
+def bin_means(x: np.ndarray, y: np.ndarray, n_bins: int = 72):
+    """(edges, counts, means) of binned_statistic(x, y, np.nanmean, n): SciPy calls the statistic on ``y[bin == k]`` for
+    every bin (callable path, _binned_statistic.py:648-657) -- NumPy's mean in the dtype of y; empty bins give NaN."""
+    edges = bin_edges(x, n_bins)
+    b = bin_index(x, edges)
+    counts = np.bincount(b[(b >= 0) & (b < n_bins)], minlength=n_bins).astype(np.int64)
+    means = np.full(n_bins, np.nan)
+    for k in range(n_bins):
+        if counts[k]:
+            means[k] = np.nanmean(y[b == k])
+    return edges, counts, means
+
+
 def fit_func(xx, a, b, c):
     """affine.py:340-355."""
     return a * np.cos(b - xx) + c

@@ -117,6 +117,10 @@ def _worker_reductions(rank, world, port, outdir):
             ctx.set_option("selection", 3 if m > 1000 else 0)  # (3: bracketed for the 72 aspect bins as well at this size)
             plan = coreg.NKPlan(ref, tba, None, ctx, group="world")
             d = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+            if m == 300:  # bin_statistic = mean: per-bin float64 sums / counts all-reduced through the hook
+                plan.set_statistic(np.nanmean)
+                dm = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+                res["nkmean"] = np.concatenate([dm["counts"], dm["medians"]])
             plan.close()
             ctx.set_option("selection", 0)
             res[f"nk{m}"] = np.concatenate([[d["vshift"], d["n_valid"], d["y_mean"]], d["counts"], d["medians"], d["edges"]])
@@ -163,6 +167,12 @@ def test_sharded_reductions_on_real_kernels(tmp_path):
         tba[rng.uniform(size=(m, m)) < 0.1] = np.nan
         plan = coreg.NKPlan(ref, tba, None)
         d = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+        if m == 300:
+            plan.set_statistic(np.nanmean)
+            dm = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+            for g in got:
+                assert np.array_equal(g["nkmean"][:72], dm["counts"])
+                assert np.allclose(g["nkmean"][72:], dm["medians"], rtol=1e-6, atol=0, equal_nan=True)  # (means are rounded to float32)
         plan.close()
         want = np.concatenate([[d["vshift"], d["n_valid"], d["y_mean"]], d["counts"], d["medians"], d["edges"]])
         for g in got:

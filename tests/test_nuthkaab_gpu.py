@@ -96,6 +96,54 @@ def test_step_matches_oracle(coreg, shift, dtype):
     plan.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_step_mean_statistic_matches_oracle(coreg, dtype):
+    """NuthKaab(bin_statistic=np.nanmean): counts and edges bit-exact; the bin means (float64 sums on the device, NumPy's
+    pairwise float32 / float64 mean upstream) within 1e-6 relative -- the float bar of the task, stated here."""
+    ref, tba, inlier, res = _pair(dtype=dtype)
+    plan = coreg.NKPlan(ref, tba, inlier)
+    plan.set_statistic(np.nanmean)
+    det = plan.step(17.3, -5.1, (res, res), 72)
+    aspect_dev = plan.aux()[1]
+    st, asp = nko.aux_vars(ref)
+    valid = inlier & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+    dh = nko.shifted_dh(ref, tba, 17.3, -5.1, (res, res))[valid]
+    vshift = np.nanmedian(dh)
+    assert det["vshift"] == float(vshift)
+    dh = dh - vshift
+    ok = np.isfinite(dh)
+    with np.errstate(all="ignore"):
+        y = dh[ok] / st[valid][ok]
+    a = asp[valid][ok] if dtype == np.float32 else aspect_dev[valid][ok]
+    edges, counts, means = nko.bin_means(a, y, 72)
+    assert np.array_equal(det["counts"], counts) and np.array_equal(det["edges"], edges.astype(np.float64))
+    assert np.array_equal(np.isnan(det["medians"]), np.isnan(means))
+    fin = np.isfinite(means)
+    np.testing.assert_allclose(det["medians"][fin], means[fin], rtol=1e-6, atol=1e-6 * float(np.nanstd(y)))
+    # back to the median: same plan, exact again
+    plan.set_statistic(np.nanmedian)
+    det2 = plan.step(17.3, -5.1, (res, res), 72)
+    assert np.array_equal(det2["medians"], nko.bin_medians(a, y, 72)[2], equal_nan=True)
+    plan.close()
+    with pytest.raises(NotImplementedError):
+        coreg.NuthKaab(bin_statistic=np.nanmax)
+
+
+def test_class_api_mean_statistic_recovers_shift(coreg):
+    from xdem_amd.synth import fbm_numpy
+
+    n, res = 600, 10.0
+    ref = fbm_numpy((n, n), seed=8, std=150.0)
+    tba = (np.roll(ref, (2, -1), (0, 1)) + 1.25).astype(np.float32)
+    nk = coreg.NuthKaab(bin_statistic=np.nanmean, subsample=1, offset_threshold=0.0, max_iterations=8)
+    nk.fit(ref, tba, None, resolution=res)
+    a = nk.meta["outputs"]["affine"]
+    # tba(x) = ref(x + (1, -2) px) + 1.25: shift_x = -easting etc. (same construction as test_class_api_recovers_shift)
+    med = coreg.NuthKaab(subsample=1, offset_threshold=0.0, max_iterations=8).fit(ref, tba, None, resolution=res).meta["outputs"]["affine"]
+    for k in ("shift_x", "shift_y", "shift_z"):
+        assert abs(a[k] - med[k]) < 0.05 * res, (k, a[k], med[k])
+
+
 @pytest.mark.parametrize("n", [1000, 200000, 5001])
 def test_binned_median_vs_reference_fixture(coreg, z, n):
     k = f"T5|{n}"

@@ -28,6 +28,16 @@ def _nuth_kaab_fit_func(xx, *params):
     return params[0] * np.cos(params[1] - xx) + params[2]
 
 
+def _bin_statistic_id(bin_statistic) -> int:
+    """0 = median, 1 = mean for the callables the GPU bins with (``NuthKaab(bin_statistic=...)``, affine.py:2404)."""
+    if bin_statistic in (np.nanmedian, np.median, "median", "nanmedian"):
+        return 0
+    if bin_statistic in (np.nanmean, np.mean, "mean", "nanmean"):
+        return 1
+    raise NotImplementedError("xdem_amd.NuthKaab bins with np.nanmedian (reference default, exact) or np.nanmean; other "
+                              "callables would need the binned values on the host.")
+
+
 class NKPlan:
     """Device-resident state of one fit (``xdemhip_nk_plan``)."""
 
@@ -110,6 +120,11 @@ class NKPlan:
         return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
                 "edges": edges, "counts": counts, "medians": med}
 
+    def set_statistic(self, bin_statistic) -> None:
+        """Statistic of the aspect bins: ``np.nanmedian`` / ``np.median`` (exact selection, the default) or ``np.nanmean`` /
+        ``np.mean`` (per-bin sums and counts); ``step`` then returns the bin means under ``"medians"``."""
+        self.ctx.check(self.ctx._L.xdemhip_nk_set_statistic(self.handle, _bin_statistic_id(bin_statistic)))
+
     def aux(self):
         """(slope_tan, aspect, valid) copied back to the host (tests / debugging)."""
         st = np.empty(self.shape, dtype=self.dtype)
@@ -191,7 +206,7 @@ def subsample_valid_mask(valid_mask: np.ndarray, subsample: float | int, random_
 def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarray | None, res: tuple[float, float],
               tolerance: float = 0.001, max_iterations: int = 10, bin_sizes: int = 72,
               fit_optimizer: Callable[..., Any] | None = None, ctx: _lib.Context | None = None, group=None,
-              subsample: float | int = 1, random_state=None):
+              subsample: float | int = 1, random_state=None, bin_statistic=np.nanmedian):
     """Array-level entry mirroring ``nuth_kaab`` (xdem/coreg/affine.py:539-609) for two rasters.
     ``subsample != 1`` restricts every iteration to a random subset of the valid pixels (drawn once, affine.py:581-593);
     ``group`` (torch.distributed process group or "world") shards every grid pass over the ranks by row block.
@@ -213,6 +228,7 @@ def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarra
                 "There is no valid points common to the input and auxiliary data (bias variables, or "
                 "derivatives required for this method, for example slope, aspect, etc)."
             )
+        plan.set_statistic(bin_statistic)
         offsets = (0.0, 0.0, 0.0)
         # _iterate_method (affine.py:102-147): stop when i > 1 and the horizontal step falls below the tolerance
         for i in range(max_iterations):
@@ -270,8 +286,7 @@ class NuthKaab:
 
         if not bin_before_fit:
             raise NotImplementedError("xdem_amd.NuthKaab implements the default bin_before_fit=True path only.")
-        if bin_statistic not in (np.nanmedian, np.median):
-            raise NotImplementedError("xdem_amd.NuthKaab bins with the exact median (the reference default np.nanmedian).")
+        _bin_statistic_id(bin_statistic)  # np.nanmedian (default) or np.nanmean; raises for anything else
         if not isinstance(bin_sizes, (int, np.integer)):
             raise NotImplementedError("bin_sizes must be an integer number of aspect bins (reference default 72).")
         if initial_shift is not None:
@@ -308,7 +323,8 @@ class NuthKaab:
                                                  max_iterations=it["max_iterations"], bin_sizes=fb["bin_sizes"],
                                                  fit_optimizer=fb["fit_optimizer"],
                                                  subsample=self.meta["inputs"]["random"]["subsample"],
-                                                 random_state=self.meta["inputs"]["random"]["random_state"])
+                                                 random_state=self.meta["inputs"]["random"]["random_state"],
+                                                 bin_statistic=fb["bin_statistic"])
         self.meta["outputs"]["affine"] = {"shift_x": -east, "shift_y": -north, "shift_z": vert * self.vertical_shift}
         self.meta["outputs"]["random"] = {"subsample_final": n_final}
         return self

@@ -255,6 +255,7 @@ struct xdemhip_nk_plan {
     int max_bins = 0;
     long long n_valid0 = 0;
     xd::SelWorkspace ws;  // bracketed selection (select_run.h): sample + candidate buffers
+    int bin_stat = XDEMHIP_BINSTAT_MEDIAN;
 };
 
 namespace {
@@ -343,6 +344,38 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
     make_edges<T>((double)val_of((K)hs0.asp_min), (double)val_of((K)hs0.asp_max), nb, edges);
     T* d_edges = reinterpret_cast<T*>(base);
     XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, edges.data(), sizeof(T) * (nb + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (P->bin_stat == XDEMHIP_BINSTAT_MEAN) {
+        // 4'. bin_statistic = np.nanmean: one pass, per-bin float64 sums and counts (and the two global sums)
+        if (nb > 3072) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins too large for the mean statistic");
+        double* d_bsum = reinterpret_cast<double*>(base + off_hist(nb));
+        unsigned long long* d_bcnt = reinterpret_cast<unsigned long long*>(d_bsum + nb);
+        XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
+        NkYSource<T> src{dh, static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, (T)vs, d_edges, d_sums,
+                         nullptr, 0.0};
+        rc = run_bin_sums<T, NkYSource<T>>(ctx, src, n, nb, d_bsum, d_bcnt);
+        if (rc) return rc;
+        rc = xd_allreduce_device(ctx, d_sums, 2, XDEMHIP_RED_SUM_F64);
+        if (rc) return rc;
+        std::vector<double> bs(nb);
+        std::vector<unsigned long long> bc(nb);
+        double sums[2];
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(bs.data(), d_bsum, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(bc.data(), d_bcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream));
+        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const double cnt = (double)g[0].st.count;
+        const double mean = sums[0] / cnt;
+        const double var = sums[1] / cnt - mean * mean;
+        *y_mean = mean;
+        *y_std = var > 0 ? sqrt(var) : 0.0;
+        for (int k = 0; k < nb; ++k) {
+            counts[k] = (int64_t)bc[k];
+            medians[k] = bc[k] ? (double)(T)(bs[k] / (double)bc[k]) : NAN;  // np.nanmean returns the sample dtype
+        }
+        for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges[k];
+        return XDEMHIP_OK;
+    }
+
     // 4. per-bin exact medians.  Bracketed route: y and the bin ids are computed on the fly by the sample / counting passes
     // (NkYSource), the counting pass accumulates the sums.  Otherwise (small grids, plain mode, a missed bracket): y and
     // bin-id arrays + plain digit passes.
@@ -455,6 +488,13 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, 
     int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
     if (rc) return rc;
     if (n_valid) *n_valid = P->n_valid0;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_nk_set_statistic(xdemhip_nk_plan* P, int bin_stat) {
+    if (!P) return XDEMHIP_EINVAL;
+    if (bin_stat != XDEMHIP_BINSTAT_MEDIAN && bin_stat != XDEMHIP_BINSTAT_MEAN) return xd_fail(P->ctx, XDEMHIP_EINVAL, "bin statistic: 0 median, 1 mean");
+    P->bin_stat = bin_stat;
     return XDEMHIP_OK;
 }
 

@@ -531,6 +531,69 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int
     }
 }
 
+// Per-bin sums and counts of a source's elements in one pass (mean-type bin statistics: sum-reducible, so the tables
+// all-reduce directly): LDS-privatised float64 sums (ds_add_f64) and uint32 counts, flushed with one global atomic per
+// non-empty (bin, workgroup).
+template <typename T, typename Src>
+__global__ __launch_bounds__(HIST_THREADS) void bin_sums_kernel(Src src, int64_t n, int nb, int copies, double* sums /* [nb] */,
+                                                                unsigned long long* counts /* [nb] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* s = reinterpret_cast<double*>(smem);
+    uint32_t* c = reinterpret_cast<uint32_t*>(s + (size_t)nb * copies);
+    for (int k = threadIdx.x; k < nb * copies; k += blockDim.x) { s[k] = 0.0; c[k] = 0; }
+    src.setup(reinterpret_cast<unsigned char*>(c + (size_t)nb * copies), nb);
+    __syncthreads();
+    double* sc = s + (threadIdx.x % copies) * nb;
+    uint32_t* cc = c + (threadIdx.x % copies) * nb;
+    typename Src::Acc acc;
+    const int64_t step = (int64_t)blockDim.x * SEL_TILE;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+        typename Src::Raw raw[SEL_TILE];
+#pragma unroll
+        for (int q = 0; q < SEL_TILE; ++q) {
+            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+            if (p < n) src.fetch(p, raw[q]);
+            else src.blank(raw[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < SEL_TILE; ++q) {
+            T v;
+            uint16_t b;
+            if (src.template eval<true>(raw[q], nb, v, b, acc)) {
+                unsafeAtomicAdd(&sc[b], (double)v);
+                atomicAdd(&cc[b], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    src.finish(acc);
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        double t = 0.0;
+        unsigned long long m = 0;
+        for (int q = 0; q < copies; ++q) { t += s[q * nb + k]; m += c[q * nb + k]; }
+        if (m) { unsafeAtomicAdd(&sums[k], t); atomicAdd(&counts[k], m); }
+    }
+}
+
+template <typename T, typename Src>
+int run_bin_sums(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, double* d_sums, unsigned long long* d_counts) {
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 8 * (size_t)nb, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, 8 * (size_t)nb, ctx->stream));
+    if (n > 0) {
+        int copies = (48 * 1024) / (nb * 12);
+        copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
+        const size_t lds = (size_t)nb * copies * 12 + Src::lds_bytes(nb);
+        int rc = set_big_lds(ctx, bin_sums_kernel<T, Src>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bin_sums_kernel<T, Src>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds, ctx->stream, src, n,
+                           nb, copies, d_sums, d_counts);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    int rc = xd_allreduce_device(ctx, d_sums, nb, XDEMHIP_RED_SUM_F64);
+    if (rc) return rc;
+    return xd_allreduce_device(ctx, d_counts, nb, XDEMHIP_RED_SUM_U64);
+}
+
 // Bracketed selection over an element source.  *done = false (and `out` meaningless) when the route is not available --
 // small input, no workspace, plain mode, some rank cannot -- or when a bracket missed / a buffer overflowed: the caller
 // then runs the plain selection on materialised arrays.
