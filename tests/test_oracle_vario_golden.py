@@ -46,3 +46,30 @@ def test_estimators_known_values():
     # lag classes are [e_{k-1}, e_k): a distance equal to an edge opens the next class
     g = vo.pair_groups(np.array([0.0]), np.array([0.0]), np.array([1.0, 2.0, 2.5, 5.0]), np.zeros(4), [1.0, 2.0, 5.0])
     assert g.tolist() == [[1, 2, 2, -1]]
+
+
+def test_T7_masks_and_multi_range_subsamples():
+    """The product's circular / ring masks (host logic of the "pdist_disk" / "pdist_ring" methods) against the masks recorded
+    from the reference; the multi-range subsampling on top of them: range list, ring disjointness, sizes, seeding."""
+    from xdem_amd import spatialstats as ss
+
+    z = np.load(os.path.join(GOLDEN, "vario_golden.npz"))
+    assert np.array_equal(ss._create_circular_mask((30, 41), center=(12, 20), radius=9.5), z["T7|circ"])
+    assert np.array_equal(ss._create_ring_mask((30, 41), center=(12, 20), in_radius=4.0, out_radius=11.0), z["T7|ring"])
+    shape, gsd = (200, 260), 2.0
+    maxlag = float(np.hypot(199 * gsd, 259 * gsd))
+    valid = np.ones(shape[0] * shape[1], dtype=bool)
+    valid[::7] = False
+    rings = ss._pdist_multi_range_subsamples(valid, shape, 500, "pdist_ring", gsd, maxlag, None, 11)
+    disks = ss._pdist_multi_range_subsamples(valid, shape, 500, "pdist_disk", gsd, maxlag, None, 11)
+    assert len(rings) == len(disks) == 6  # 20, 40, 80, 160, 320 (< maxlag / 2 = 326.6), maxlag
+    rng = np.random.default_rng(11)
+    cx, cy = rng.choice(shape[0], 1)[0], rng.choice(shape[1], 1)[0]  # one centre for all ranges of a seeded run
+    rr, cc = np.unravel_index(np.arange(valid.size), shape)
+    dist = np.sqrt((cc - cx) ** 2 + (rr - cy) ** 2)  # (the reference's axis convention)
+    bounds = [0.0, 10.0, 20.0, 40.0, 80.0, 160.0, maxlag / gsd]
+    for j, (r_, d_) in enumerate(zip(rings, disks)):
+        assert valid[r_].all() and valid[d_].all() and len(set(r_.tolist())) == r_.size <= 500
+        assert (dist[r_] >= bounds[j]).all() and (dist[r_] < bounds[j + 1]).all()
+        assert (dist[d_] < bounds[j + 1]).all()
+    assert ss._pdist_multi_range_subsamples(valid, shape, 500, "pdist_ring", gsd, maxlag, [30.0, 90.0], 11)[1].size == 500

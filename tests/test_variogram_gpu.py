@@ -116,6 +116,35 @@ def test_sample_empirical_variogram_end_to_end(ss, method, estimator):
     assert df["count"].sum() > 1000
 
 
+@pytest.mark.parametrize("method", ["pdist_disk", "pdist_ring"])
+def test_multi_range_pdist_methods(ss, method):
+    """"pdist_disk" / "pdist_ring": one pdist variogram per range, rows of all ranges kept, the last lag of each removed
+    (the reference drops by index label after the concat).  Every range against the oracle on the product's own subsample."""
+    from xdem_amd.synth import fbm_numpy
+
+    vals = fbm_numpy((90, 120), hurst=0.3, seed=45, mean=0.0, std=2.0)
+    vals[10:14, 20:30] = np.nan
+    gsd = 5.0
+    df = ss.sample_empirical_variogram(vals, gsd=gsd, subsample=150, subsample_method=method, random_state=3, estimator="dowd")
+    coords, extent, maxlag = vo.grid_coords_extent_maxlag(vals.shape, gsd)
+    edges = vo.default_bin_edges(gsd, maxlag)
+    flat = vals.flatten()
+    seed = list(np.random.default_rng(3).choice(1, 1, replace=False))[0]
+    sels = ss._pdist_multi_range_subsamples(np.isfinite(flat), vals.shape, 150, method, gsd, maxlag, None, seed)
+    ranges = [50.0, 100.0, 200.0, maxlag]  # 10 gsd doubling while below maxlag / 2 (= 372), then maxlag
+    assert len(sels) == len(ranges) and all(np.isfinite(flat[s_]).all() for s_ in sels)
+    nb = len(edges)
+    assert len(df) == len(sels) * (nb - 1)
+    for j, sel in enumerate(sels):
+        exp_o, count_o = vo.empirical_variogram_blocks([(coords[sel, 0], coords[sel, 1], flat[sel])], edges, "dowd")
+        part = df.iloc[j * (nb - 1):(j + 1) * (nb - 1)]
+        assert np.array_equal(part["lags"].values, np.array(edges[:-1]))
+        assert np.array_equal(part["count"].values, count_o[:-1])
+        assert np.allclose(part["exp"].values, exp_o[:-1], rtol=1e-12, equal_nan=True)
+    # smaller ranges only hold short lags
+    assert df.iloc[: nb - 1]["count"].values[np.array(edges[:-1]) > 2.1 * ranges[0]].sum() == 0
+
+
 def test_multiple_runs_aggregate(ss):
     from xdem_amd.synth import fbm_numpy
 

@@ -256,7 +256,10 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
 
     Returns a DataFrame with the empirical variance ``exp``, the upper bound of the lag ``lags``, the pair ``count``
     and ``err_exp`` (NaN for a single run), the last -- always under-sampled -- lag removed.
-    Supported ``subsample_method``: "cdist_equidistant" (default), "cdist_point", "pdist_point".
+    All five ``subsample_method`` values are supported: "cdist_equidistant" (default), "cdist_point", "pdist_point" and the
+    multi-range "pdist_disk" / "pdist_ring"; the random draws inside them belong to un-vendored dependencies (skgstat metric
+    spaces, ``geoutils.subsample_array``) and are restated with NumPy generators -- parity of the *draws* is unpinned, the
+    pair arithmetic is what the tests pin.
     """
     import pandas as pd
 
@@ -291,8 +294,6 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
             'The subsampling method must be one of "cdist_equidistant, "cdist_point", "pdist_point", '
             '"pdist_disk" or "pdist_ring".'
         )
-    if subsample_method in ("pdist_disk", "pdist_ring"):
-        raise NotImplementedError('"pdist_disk" / "pdist_ring" ("not used by default" upstream) are outside the GPU hot path.')
     if n_variograms > 1 and "bin_func" in kwargs and not isinstance(kwargs.get("bin_func"), Iterable):
         warnings.warn(
             "Using a named binning function of scikit-gstat might provide different binnings for each "
@@ -352,10 +353,16 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
             a = run_rng.choice(idx, n, replace=False)
             b = run_rng.choice(idx, n, replace=False)
             blocks = [(coords[a, 0], coords[a, 1], values[a], coords[b, 0], coords[b, 1], values[b])]
-        else:  # pdist_point
+        elif subsample_method == "pdist_point":
             idx = np.flatnonzero(valid)
             a = run_rng.choice(idx, min(int(subsample), idx.size), replace=False)
             blocks = [(coords[a, 0], coords[a, 1], values[a])]
+        else:  # pdist_disk / pdist_ring: one pdist variogram per range, all rows kept (1007-1060)
+            for sel in _pdist_multi_range_subsamples(valid, shape2d, int(subsample), subsample_method, gsd, kwargs["maxlag"],
+                                                     kwargs.get("pdist_multi_ranges"), list_random_state[i]):
+                exp, count = empirical_variogram_pairs([(coords[sel, 0], coords[sel, 1], values[sel])], edges, estimator)
+                list_df_run.append(pd.DataFrame().assign(exp=exp, bins=edges, count=count))
+            continue
         if blocks:
             exp, count = empirical_variogram_pairs(blocks, edges, estimator)
         else:
@@ -378,6 +385,64 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
     df.drop(df.tail(1).index, inplace=True)
     df = df.astype({"exp": "float64", "err_exp": "float64", "lags": "float64", "count": "int64"})
     return df
+
+
+def _create_circular_mask(shape: tuple[int, int], center=None, radius=None) -> np.ndarray:
+    """Mirror of ``_create_circular_mask`` (xdem/spatialstats.py:880-905), axis convention included (``center[0]`` is
+    compared with the second array axis)."""
+    w, h = shape
+    if center is None:
+        center = (int(w / 2), int(h / 2))
+    if radius is None:
+        radius = min(center[0], center[1], w - center[0], h - center[1])
+    Y, X = np.ogrid[:w, :h]
+    return np.sqrt((X - center[0]) ** 2 + (Y - center[1]) ** 2) < radius
+
+
+def _create_ring_mask(shape: tuple[int, int], center=None, in_radius: float = 0, out_radius=None) -> np.ndarray:
+    """Mirror of ``_create_ring_mask`` (xdem/spatialstats.py:908-937)."""
+    w, h = shape
+    if center is None:
+        center = (int(w / 2), int(h / 2))
+    if out_radius is None:
+        out_radius = min(center[0], center[1], w - center[0], h - center[1])
+    return np.logical_and(~_create_circular_mask((w, h), center=center, radius=in_radius),
+                          _create_circular_mask((w, h), center=center, radius=out_radius))
+
+
+def _pdist_multi_range_subsamples(valid: np.ndarray, shape: tuple[int, int], subsample: int, subsample_method: str, gsd: float,
+                                  maxlag: float, pdist_multi_ranges, random_state) -> list[np.ndarray]:
+    """Flat indices of the point subsample of every range of the "pdist_disk" / "pdist_ring" methods
+    (``_aggregate_pdist_empirical_variogram`` + ``_subsample_wrapper``, xdem/spatialstats.py:985-1060, 940-982): ranges
+    double from 10 gsd up to maxlag / 2, then maxlag; per range a random centre, the disk (or the ring between consecutive
+    ranges) around it, and ``subsample`` valid points of it (empty subsamples are skipped).  Every range re-seeds its
+    generator with the run's ``random_state``, as upstream does, so a seeded run keeps one centre for all its ranges."""
+    if pdist_multi_ranges is None:
+        pdist_multi_ranges = []
+        new_range = gsd * 10
+        while new_range < maxlag / 2:
+            pdist_multi_ranges.append(new_range)
+            new_range *= 2
+        pdist_multi_ranges.append(maxlag)
+    nx, ny = shape
+    binned = [0.0] + list(pdist_multi_ranges)
+    out = []
+    for j in range(len(pdist_multi_ranges)):
+        outside = binned[j + 1] / gsd
+        inside = binned[j] / gsd if subsample_method == "pdist_ring" else 0.0
+        rng = np.random.default_rng(random_state)
+        center = (rng.choice(nx, 1)[0], rng.choice(ny, 1)[0])
+        if subsample_method == "pdist_ring":
+            sub = _create_ring_mask((nx, ny), center=center, in_radius=inside, out_radius=outside)
+        else:
+            sub = _create_circular_mask((nx, ny), center=center, radius=outside)
+        idx = np.flatnonzero(sub.flatten() & valid)
+        if idx.size == 0:
+            continue
+        # geoutils.subsample_array(values_sp, subsample, return_indices=True, random_state): its own generator on the same seed
+        draw = np.random.default_rng(random_state)
+        out.append(draw.choice(idx, min(subsample, idx.size), replace=False))
+    return out
 
 
 def equidistant_blocks_from_coords(coords: np.ndarray, values: np.ndarray, valid: np.ndarray, gsd: float, runs: int,
