@@ -141,8 +141,9 @@ def test_multi_range_pdist_methods(ss, method):
         assert np.array_equal(part["lags"].values, np.array(edges[:-1]))
         assert np.array_equal(part["count"].values, count_o[:-1])
         assert np.allclose(part["exp"].values, exp_o[:-1], rtol=1e-12, equal_nan=True)
-    # smaller ranges only hold short lags
-    assert df.iloc[: nb - 1]["count"].values[np.array(edges[:-1]) > 2.1 * ranges[0]].sum() == 0
+    # (no geometric claim on the lags of a range: for a non-square grid upstream's meshgrid coordinates do not follow the
+    # C-order flattening of the values -- reproduced as is, see sample_empirical_variogram -- so a disk of pixels is not
+    # compact in coordinate space)
 
 
 def test_multiple_runs_aggregate(ss):
