@@ -13,7 +13,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 FULL = ["slope", "aspect", "hillshade", "profile_curvature", "tangential_curvature", "planform_curvature",
         "flowline_curvature", "max_curvature", "min_curvature", "topographic_position_index", "terrain_ruggedness_index"]
 dem = np.tile(fbm_numpy((2048, 2048), seed=1), (n // 2048, n // 2048))
-for attrs in (FULL, ["slope"]):
+from xdem_amd import _lib
+
+threads = [int(a) for a in sys.argv[2:]] or [8]
+for nt, attrs in [(t, a) for t in threads for a in (FULL, ["slope"])]:
+    _lib.default_context().set_option("host_copy_threads", nt)
+    print(f"[{nt} copy threads]", end=" ")
     terrain.get_terrain_attribute(dem[:1024, :1024], attrs, resolution=10.0)
     t0 = time.perf_counter()
     out = terrain.get_terrain_attribute(dem, attrs, resolution=10.0)

@@ -4,6 +4,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -28,7 +29,7 @@ int xdemhip_create(int device_id, xdemhip_ctx** out_ctx) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return XDEMHIP_EHIP; }
     c->stream = c->own_stream;
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < xdemhip_ctx::MAX_COPY_THREADS; ++t)
         if (hipStreamCreateWithFlags(&c->copy_streams[t], hipStreamNonBlocking) != hipSuccess) { delete c; return XDEMHIP_EHIP; }
     if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) {
@@ -45,7 +46,7 @@ void xdemhip_destroy(xdemhip_ctx* ctx) {
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < xdemhip_ctx::MAX_COPY_THREADS; ++t)
         if (ctx->copy_streams[t]) (void)hipStreamDestroy(ctx->copy_streams[t]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -80,6 +81,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
     if (std::string(name) == "host_chunk_mb") {  // device budget of one row chunk of host-buffer terrain calls (0 = default 8 GiB)
         if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "host_chunk_mb must be >= 0");
         ctx->host_chunk_mb = value;
+        return XDEMHIP_OK;
+    }
+    if (std::string(name) == "host_copy_threads") {  // threads (one stream each) moving host-buffer rasters over PCIe (0 = default 8)
+        if (value < 0 || value > xdemhip_ctx::MAX_COPY_THREADS) return xd_fail(ctx, XDEMHIP_EINVAL, "host_copy_threads must be 0..16");
+        ctx->host_copy_threads = value ? value : 8;
         return XDEMHIP_OK;
     }
     if (std::string(name) == "selection") {
@@ -198,36 +204,58 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
         const int64_t top = (r0 + halo_top < depth) ? r0 + halo_top : depth;
         const int64_t bot = (H + halo_bottom - r1 < depth) ? H + halo_bottom - r1 : depth;
         const char* src = static_cast<const char*>(dem) + (size_t)(r0 + halo_top - top) * (size_t)row_stride * in_es;
-        hipError_t e = hipMemcpy2DAsync(d_dem, (size_t)W * in_es, src, (size_t)row_stride * in_es, (size_t)W * in_es,
-                                        (size_t)(top + (r1 - r0) + bot), hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("H2D copy failed: ") + hipGetErrorString(e)); break; }
+        // Pageable host memory is staged by the runtime on the calling thread (and fresh output pages fault on first touch):
+        // `nthreads` threads, each with its own stream and its share of the rows, keep more of the PCIe link busy than one.
+        const int nthreads = ctx->host_copy_threads;
+        const int64_t in_rows = top + (r1 - r0) + bot;
+        auto run_threads = [&](const std::function<int(int, hipStream_t)>& body) -> bool {
+            std::vector<std::thread> workers;
+            std::vector<int> wrc(nthreads, 0);
+            for (int t = 0; t < nthreads; ++t)
+                workers.emplace_back([&, t]() {
+                    if (hipSetDevice(ctx->device) != hipSuccess) { wrc[t] = 1; return; }
+                    wrc[t] = body(t, ctx->copy_streams[t]);
+                });
+            for (auto& w : workers) w.join();
+            for (int t = 0; t < nthreads; ++t)
+                if (wrc[t]) return false;
+            return true;
+        };
+        // (the previous chunk's kernels and copies have completed: every thread synchronised its stream)
+        const bool up = run_threads([&](int t, hipStream_t st) -> int {
+            const int64_t a = in_rows * t / nthreads, b = in_rows * (t + 1) / nthreads;
+            if (b <= a) return 0;
+            if (hipMemcpy2DAsync(static_cast<char*>(d_dem) + (size_t)a * (size_t)W * in_es, (size_t)W * in_es,
+                                 src + (size_t)a * (size_t)row_stride * in_es, (size_t)row_stride * in_es, (size_t)W * in_es,
+                                 (size_t)(b - a), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+            return hipStreamSynchronize(st) != hipSuccess;
+        });
+        if (!up) { rc = xd_fail(ctx, XDEMHIP_EHIP, "H2D copy failed"); break; }
         L.H = r1 - r0; L.halo_top = top; L.halo_bottom = bot;
         if (first) (void)hipEventRecord(ctx->ev_start, ctx->stream);
         rc = xd::launch_terrain(ctx, L);
         if (rc != XDEMHIP_OK) break;
         if (r1 == H) (void)hipEventRecord(ctx->ev_stop, ctx->stream);
         first = false;
-        const size_t rows_bytes = (size_t)(r1 - r0) * (size_t)W * out_es;
-        // Device -> pageable host memory is staged by the runtime on the calling thread; several threads, each with its own
-        // stream and its share of the planes, keep more of the PCIe link busy than one.
         hipEvent_t done_ev = ctx->ev_copy;
         (void)hipEventRecord(done_ev, ctx->stream);
-        const int nthreads = n_planes < 4 ? n_planes : 4;
-        std::vector<std::thread> workers;
-        std::vector<int> wrc(nthreads, 0);
-        for (int t = 0; t < nthreads; ++t)
-            workers.emplace_back([&, t]() {
-                if (hipSetDevice(ctx->device) != hipSuccess) { wrc[t] = 1; return; }
-                hipStream_t st = ctx->copy_streams[t];
-                if (hipStreamWaitEvent(st, done_ev, 0) != hipSuccess) { wrc[t] = 1; return; }
-                for (int i = t; i < n_planes; i += nthreads)
-                    if (hipMemcpyAsync(static_cast<char*>(out_planes[i]) + (size_t)r0 * (size_t)W * out_es, d_out[i], rows_bytes,
-                                       hipMemcpyDeviceToHost, st) != hipSuccess) { wrc[t] = 1; return; }
-                if (hipStreamSynchronize(st) != hipSuccess) wrc[t] = 1;
-            });
-        for (auto& w : workers) w.join();
-        for (int t = 0; t < nthreads; ++t)
-            if (wrc[t]) rc = xd_fail(ctx, XDEMHIP_EHIP, "D2H copy failed");
+        // D2H: tasks = (plane, row slice); `slices` slices per plane so that every thread has work whatever the plane count
+        const int slices = (nthreads + n_planes - 1) / n_planes > 1 ? (nthreads + n_planes - 1) / n_planes : 2;
+        const int n_tasks = n_planes * slices;
+        const int64_t rows = r1 - r0;
+        const bool down = run_threads([&](int t, hipStream_t st) -> int {
+            if (hipStreamWaitEvent(st, done_ev, 0) != hipSuccess) return 1;
+            for (int k = t; k < n_tasks; k += nthreads) {
+                const int i = k / slices, sl = k % slices;
+                const int64_t a = rows * sl / slices, b = rows * (sl + 1) / slices;
+                if (b <= a) continue;
+                if (hipMemcpyAsync(static_cast<char*>(out_planes[i]) + (size_t)(r0 + a) * (size_t)W * out_es,
+                                   static_cast<char*>(d_out[i]) + (size_t)a * (size_t)W * out_es, (size_t)(b - a) * (size_t)W * out_es,
+                                   hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
+            }
+            return hipStreamSynchronize(st) != hipSuccess;
+        });
+        if (!down) rc = xd_fail(ctx, XDEMHIP_EHIP, "D2H copy failed");
     }
     ctx->timed = (rc == XDEMHIP_OK);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);

@@ -12,7 +12,9 @@ struct xdemhip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream work is enqueued on (own_stream or the caller's)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_copy = nullptr;
-    hipStream_t copy_streams[4] = {};  // device -> host copy threads of the host-buffer path
+    static constexpr int MAX_COPY_THREADS = 16;
+    hipStream_t copy_streams[MAX_COPY_THREADS] = {};  // one per copy thread of the host-buffer path
+    int host_copy_threads = 8;                        // option "host_copy_threads"
     bool timed = false;
     int num_cu = 256;
     xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)
