@@ -81,7 +81,9 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
  * where the per-bin sample is small (test switch).  Results are identical in every mode.
  * "host_chunk_mb": device-memory budget (MiB) of one row chunk of host-buffer xdemhip_terrain calls (0 = default 8192): host
  * rasters of any size stream through the GPU in row chunks with the overlap the attributes need.  "host_copy_threads":
- * threads (one HIP stream each) that move host-buffer rasters over PCIe, rows split among them (0 = default 8, at most 16). */
+ * threads (one HIP stream each) that move host-buffer rasters over PCIe, rows split among them (0 = default 8, at most 16).
+ * "pairs_launch_cap": workgroups per launch of the variogram pair passes (0 = default 2^31 / workgroup size, the most a HIP
+ * dispatch holds; a pass over more tiles goes out as several launches -- a small value is a test switch for that path). */
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value);
 
 /* Multi-GPU hook for the accumulator-style paths (Nuth-Kaab reductions): one process per GPU, every rank works on its

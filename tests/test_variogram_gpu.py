@@ -146,6 +146,37 @@ def test_multi_range_pdist_methods(ss, method):
     # compact in coordinate space)
 
 
+def test_pair_passes_split_over_several_launches(ss):
+    """A pass over more tiles than one HIP dispatch holds (total work-items are a 32-bit quantity: 5e13 pairs, SURVEY 8d's C5
+    reading A, need it) goes out as several launches.  Forced here with a small per-launch cap: every estimator must match
+    the single-launch result (integer work bit for bit)."""
+    from xdem_amd import _lib
+
+    rng = np.random.default_rng(21)
+    blocks = []
+    for _ in range(3):
+        ax, ay = rng.uniform(0, 4000, 1500), rng.uniform(0, 4000, 1500)
+        bx, by = rng.uniform(0, 4000, 20000), rng.uniform(0, 4000, 20000)
+        av = np.round(np.sin(ax / 300) + 0.3 * rng.normal(size=1500), 2).astype(np.float32)
+        bv = np.round(np.sin(bx / 300) + 0.3 * rng.normal(size=20000), 2).astype(np.float32)
+        blocks.append((ax, ay, av, bx, by, bv))
+    edges = np.geomspace(np.sqrt(2), 5700.0, 25)
+    ctx = _lib.default_context()
+    want = {est: ss.empirical_variogram_pairs(blocks, edges, est) for est in ("matheron", "cressie", "dowd")}
+    try:
+        for cap in (1, 7):
+            ctx.set_option("pairs_launch_cap", cap)
+            for est, (e0, c0) in want.items():
+                e1, c1 = ss.empirical_variogram_pairs(blocks, edges, est)
+                assert np.array_equal(c1, c0), (cap, est)
+                if est == "dowd":
+                    assert np.array_equal(e1, e0, equal_nan=True), cap
+                else:
+                    assert np.allclose(e1, e0, rtol=1e-12, equal_nan=True), (cap, est)
+    finally:
+        ctx.set_option("pairs_launch_cap", 0)
+
+
 def test_multiple_runs_aggregate(ss):
     from xdem_amd.synth import fbm_numpy
 

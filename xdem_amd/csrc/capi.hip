@@ -88,6 +88,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->host_copy_threads = value ? value : 8;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "pairs_launch_cap") {  // test switch: split the pair passes into launches of at most this many workgroups
+        if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "pairs_launch_cap must be >= 0");
+        ctx->pairs_launch_cap = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "selection") {
         if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets, 3 bracketed");
         ctx->selection_mode = value;

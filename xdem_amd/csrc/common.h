@@ -15,6 +15,7 @@ struct xdemhip_ctx {
     static constexpr int MAX_COPY_THREADS = 16;
     hipStream_t copy_streams[MAX_COPY_THREADS] = {};  // one per copy thread of the host-buffer path
     int host_copy_threads = 8;                        // option "host_copy_threads"
+    int pairs_launch_cap = 0;                         // option "pairs_launch_cap": workgroups per pair-kernel launch (0 = 2^31 / NT)
     bool timed = false;
     int num_cu = 256;
     xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)

@@ -137,7 +137,10 @@ extern "C" int xdemhip_cov_double_sum(xdemhip_ctx* ctx, const double* ax, const 
     owned.push_back(d_out);
     (void)hipMemsetAsync(d_out, 0, 8, ctx->stream);
     const int64_t n_wg = ((na + CV_NT - 1) / CV_NT) * ((nb + CV_CHUNK - 1) / CV_CHUNK);
-    if (n_wg > 0x7fffffff) { cleanup(); return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many point tiles for one launch"); }
+    if (n_wg * CV_NT >= ((int64_t)1 << 32)) {  // (total work-items of a HIP dispatch are a 32-bit quantity)
+        cleanup();
+        return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many point tiles for one launch");
+    }
     (void)hipEventRecord(ctx->ev_start, ctx->stream);
     hipLaunchKernelGGL(cov_sum_kernel, dim3((unsigned)n_wg), dim3(CV_NT), 0, ctx->stream, dax, day, dae, na, dbx, dby, dbe, nb, M, d_out);
     hipError_t e = hipGetLastError();

@@ -157,7 +157,9 @@ static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask)
     a.H = L.H; a.W = L.W; a.stride = L.row_stride; a.halo_top = L.halo_top; a.halo_bottom = L.halo_bottom;
     constexpr int TH = TileRows<TIN>::v;
     const int64_t tx = (L.W + TILE_W - 1) / TILE_W, ty = (L.H + TH - 1) / TH;
-    if (tx * ty > (int64_t)0x7ffffff0) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "raster too large for one launch");
+    // (a HIP dispatch carries the total work-item count in 32 bits: 2^24 tiles x 256 threads is the most one launch holds --
+    // 1.4e11 pixels, beyond any device memory)
+    if (tx * ty > (int64_t)0xfffff0) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "raster too large for one launch");
     a.tiles_x = (int)tx; a.tiles_y = (int)ty; a.ntiles = (int)(tx * ty);
     a.grid8 = (a.ntiles + 7) / 8;
     constexpr int VEC = 16 / sizeof(TIN);

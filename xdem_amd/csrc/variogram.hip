@@ -54,6 +54,7 @@ template <typename T> struct PairArgs {
     const typename KeyT<T>::type* prefix;  // [nb] selection prefix (hist) or selected key (succ)
     unsigned long long* succ;              // [nb] 8-byte slots, all-ones = none
     int shift, first, bin0, nbs;   // hist digit, first pass flag, LDS sweep window [bin0, bin0 + nbs)
+    int64_t wg_base;               // first workgroup of this launch (a pass over very many tiles takes several launches)
     int sample;                    // OP_HIST: only the pseudo-randomly chosen 1/64 of the (A tile x B tile) units
     int has_nan;                   // some value is NaN (unknown for device-resident inputs: assumed): full tiles keep the NaN test
     // OP_BRACKET (bracketed selection, select_run.h): keys in [prefix[k], khi[k]] are candidates
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     // otherwise zeroing and flushing their 51 KB histograms would dominate the pass)
     if (OP == OP_HIST && a.sample) {
         bool any = false;
-        for (int t = 0; t < BCHUNK / PT; ++t) any |= unit_sampled(blockIdx.x, t);
+        for (int t = 0; t < BCHUNK / PT; ++t) any |= unit_sampled(a.wg_base + blockIdx.x, t);
         if (!any) return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     }
 
     // which block / A tile / B chunk is this workgroup?
-    const int64_t wg = blockIdx.x;
+    const int64_t wg = a.wg_base + blockIdx.x;
     int lo = 0, hi = a.nblk;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -414,15 +415,18 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     a.cnt3 = P->cnt3; a.cand_v = static_cast<T*>(P->cand_v); a.cand_b = P->cand_b; a.cand_ctr = P->cand_ctr; a.cand_cap = P->cand_cap;
     const size_t lds = lds_bytes<T>(P->nb, OP, nbs);
     const int64_t n_wg = (NT == 1024) ? P->n_wg_big : P->n_wg;
-    if (n_wg > 0x7fffffff) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "too many pair tiles for one launch");
-    if (P->lut) {
-        if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT>, lds)) return rc;
-        hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3((unsigned)n_wg), dim3(NT), lds, ctx->stream, a);
-    } else {
-        if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, false, NT>, lds)) return rc;
-        hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3((unsigned)n_wg), dim3(NT), lds, ctx->stream, a);
+    // HIP dispatches carry the TOTAL work-item count of a dimension in 32 bits (a larger grid x block product is silently
+    // truncated): a pass over more workgroups than 2^31 / NT goes out as several launches, each told where it starts.
+    const int64_t per_launch = ctx->pairs_launch_cap > 0 ? (int64_t)ctx->pairs_launch_cap : ((int64_t)1 << 31) / NT;
+    if (P->lut) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT>, lds)) return rc; }
+    else { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, false, NT>, lds)) return rc; }
+    for (int64_t w0 = 0; w0 < n_wg; w0 += per_launch) {
+        const int64_t nw = (n_wg - w0) < per_launch ? (n_wg - w0) : per_launch;
+        a.wg_base = w0;
+        if (P->lut) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
+        XD_HIP_CHECK(ctx, hipGetLastError());
     }
-    XD_HIP_CHECK(ctx, hipGetLastError());
     return XDEMHIP_OK;
 }
 
@@ -737,13 +741,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         (void)hipFree(d_small);
     };
     bool bracket = ctx->selection_mode != 1 && nb <= HIST_BINS_PER_SWEEP && P->n_pairs >= PAIRS_BRACKET_MIN && P->n_wg_big >= 256;
-    if (bracket) {
-        P->cand_cap = (long long)(P->n_pairs / 64 + (1 << 20));
-        if (hipMalloc(&P->cand_v, (size_t)P->cand_cap * sizeof(T)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)P->cand_cap * 2) != hipSuccess ||
-            hipMalloc(&scratch, scratch_size(nb)) != hipSuccess)
-            bracket = false;  // not enough memory for the candidates: plain passes
-    }
+    if (bracket && hipMalloc(&scratch, scratch_size(nb)) != hipSuccess) bracket = false;
     if (ctx->allreduce) {  // sharded pair sets: every rank must take the same route
         uint64_t can = bracket ? 1 : 0;
         if (ctx->allreduce(&can, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed"); }
@@ -751,6 +749,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     }
     int rc = XDEMHIP_OK;
     bool done = false;
+    std::vector<K> klo(nb), khi(nb);
     if (bracket) {
         std::vector<SelState<K>> lo, hi;
         constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough
@@ -758,13 +757,40 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo, BR_PASSES);
         if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi, BR_PASSES);
         if (rc) { cleanup(); return rc; }
-        std::vector<K> klo(nb), khi(nb);
+        double expected = 0.0;  // candidates the brackets should hold: 64 x their width in sample ranks, at most the class
         for (int k = 0; k < nb; ++k) {
             const bool have = lo[k].count > 0;
             klo[k] = have ? lo[k].prefix : (K)0;
             khi[k] = have ? (K)(hi[k].prefix | low_mask) : (K)~(K)0;
             if (ctx->selection_mode == 2 && have) khi[k] = klo[k];  // test mode: brackets that (almost surely) miss
+            const double m = (double)lo[k].count, w = 2.0 * (double)sel_bracket_halfwidth_wide(lo[k].count) + 2.0;
+            expected += 64.0 * (w < m ? w : m);
         }
+        // candidate buffers sized from the brackets (x1.5 + slack), not from the pair count: 5e13 pairs (SURVEY 8d, C5 reading
+        // A) need ~2e10 slots, not n_pairs / 64.  Too little memory (on any rank): plain passes.
+        {
+            const double want = expected * 1.5 + (double)(1 << 20);
+            const double most = (double)P->n_pairs + 1024.0;
+            P->cand_cap = (long long)(want < most ? want : most);
+            uint64_t got = 1;
+            if (hipMalloc(&P->cand_v, (size_t)P->cand_cap * sizeof(T)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)P->cand_cap * 2) != hipSuccess) {
+                (void)hipGetLastError();
+                got = 0;
+            }
+            if (ctx->allreduce && ctx->allreduce(&got, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) {
+                cleanup();
+                return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
+            }
+            if (!got) {
+                if (P->cand_v) (void)hipFree(P->cand_v);
+                if (P->cand_b) (void)hipFree(P->cand_b);
+                P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0;
+                bracket = false;
+            }
+        }
+    }
+    if (bracket) {
         K* d_klo = reinterpret_cast<K*>(d_small + off_klo);
         K* d_khi = reinterpret_cast<K*>(d_small + off_khi);
         uint64_t* d_given = reinterpret_cast<uint64_t*>(d_small + off_given);
