@@ -191,6 +191,7 @@ def test_selection_modes_agree_on_large_inputs(mode):
         tba[rng.uniform(size=(m, m)) < 0.1] = np.nan
         plan = coreg.NKPlan(refd, tba, None, ctx)
         got = plan.step(2.0, -3.0, (10.0, 10.0), 72)
+        got6 = plan.step(2.0, -3.0, (10.0, 10.0), 6)  # few bins: per-bin samples large enough for real brackets at this size
         plan.close()
         st, asp = no.aux_vars(refd)
         valid = np.isfinite(refd) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
@@ -204,6 +205,9 @@ def test_selection_modes_agree_on_large_inputs(mode):
             y = dh[ok] / st[valid][ok]
         edges, counts, med = no.bin_medians(asp[valid][ok], y, 72)
         assert np.array_equal(got["counts"], counts) and np.array_equal(got["medians"], med, equal_nan=True)
+        edges, counts, med = no.bin_medians(asp[valid][ok], y, 6)
+        assert np.array_equal(got6["counts"], counts) and np.array_equal(got6["medians"], med, equal_nan=True)
+        assert np.array_equal(got6["edges"], edges.astype(np.float64))
     finally:
         ctx.set_option("selection", 0)
 

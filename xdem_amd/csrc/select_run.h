@@ -310,6 +310,7 @@ __device__ __forceinline__ int64_t sel_sampled_line(int64_t group) {
 // on a single address: ~1e8 updates/s, far below the data rate.)
 constexpr int SEL_TILE = 4;                        // elements per thread and step
 constexpr int SEL_STAGE_CAP = 8192;                // staging slots per workgroup
+constexpr int SEL_FLUSH_EVERY = 4;                 // bracket pass: steps (of SEL_TILE x 1024 elements) between two flushes
 template <typename T> struct BlockStage {
     T* v;
     uint16_t* b;
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int
     __syncthreads();
     uint32_t* cc = c + (threadIdx.x % copies) * 3 * nb;
     typename Src::Acc acc;
+    int it = 0;
     const int64_t step = (int64_t)blockDim.x * SEL_TILE;
     for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
         typename Src::Raw raw[SEL_TILE];
@@ -518,11 +520,14 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int
                 if (key < lo[b]) atomicAdd(&cc[nb + b], 1u);
                 else if (key <= hi[b]) { atomicAdd(&cc[2 * nb + b], 1u); cand = true; }
             }
-            st.append(cand, v, b);
+            st.append_bounded(cand, v, b, &ctr[2]);
         }
-        st.sync_and_flush(false, out_v, out_b, &ctr[1], cap, &ctr[2]);
+        // The staging buffer is emptied (one barrier pair + a coalesced burst) every SEL_FLUSH_EVERY steps only: it holds half
+        // of the elements of that many steps, and the bracketed route is not taken when more than ~40 % of a bin would be
+        // candidates.  A burst of candidates beyond that raises the overflow flag (-> plain selection), never a bad write.
+        if ((++it % SEL_FLUSH_EVERY) == 0) st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
     }
-    st.sync_and_flush(true, out_v, out_b, &ctr[1], cap, &ctr[2]);
+    st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
     src.finish(acc);
     for (int k = threadIdx.x; k < 3 * nb; k += blockDim.x) {
         unsigned long long s = 0;
