@@ -191,3 +191,36 @@ def test_variogram_models_fit_and_correlation():
         ss.get_variogram_model_func(pd.DataFrame({"model": ["spherical"], "range": [0.0], "psill": [1.0]}))
     with pytest.raises(ValueError, match='must contain the column "smooth"'):
         ss.get_variogram_model_func(pd.DataFrame({"model": ["matern"], "range": [1.0], "psill": [1.0]}))
+
+
+def test_dem_coregister_3d_argument_plumbing(monkeypatch):
+    """Host logic of DEM.coregister_3d (xdem/dem.py:621-665) without touching the GPU: random_state reaches fit(), `resample`
+    reaches apply(), bias_vars / foreign methods / mismatched grids raise."""
+    import xdem_amd
+    from xdem_amd import coreg
+
+    seen = {}
+
+    def fake_fit(self, ref, tba, inlier_mask=None, resolution=None, **kw):
+        seen["fit"] = dict(kw, resolution=resolution, mask=None if inlier_mask is None else inlier_mask.dtype)
+        return self
+
+    def fake_apply(self, elev, resolution, resample=True):
+        seen["apply"] = resample
+        return elev + 1.0
+
+    monkeypatch.setattr(coreg.NuthKaab, "fit", fake_fit)
+    monkeypatch.setattr(coreg.NuthKaab, "apply", fake_apply)
+    a = xdem_amd.DEM(np.zeros((5, 6), dtype=np.float32), transform=(2.0, 0.0, 0.0, 0.0, -2.0, 10.0))
+    b = xdem_amd.DEM(np.ones((5, 6), dtype=np.float32), transform=(2.0, 0.0, 0.0, 0.0, -2.0, 10.0))
+    out = a.coregister_3d(b, coreg.NuthKaab(), inlier_mask=np.ones((5, 6), dtype=np.uint8), random_state=7, resample=False)
+    assert isinstance(out, xdem_amd.DEM) and np.all(out.data == 1.0)
+    assert seen["fit"] == {"random_state": 7, "resolution": (2.0, 2.0), "mask": np.dtype(bool)} and seen["apply"] is False
+    a.coregister_3d(b)  # default method, default resample
+    assert seen["apply"] is True and "random_state" not in seen["fit"]
+    with pytest.raises(NotImplementedError, match="bias_vars"):
+        a.coregister_3d(b, bias_vars={"x": np.zeros((5, 6))})
+    with pytest.raises(ValueError, match="must be an xdem_amd.coreg instance"):
+        a.coregister_3d(b, coreg_method=object())
+    with pytest.raises(NotImplementedError, match="share one grid"):
+        a.coregister_3d(xdem_amd.DEM(np.ones((5, 7), dtype=np.float32)))

@@ -117,8 +117,17 @@ class DEM:
         return terrain.get_terrain_attribute(self, attribute=attribute, **kwargs)
 
     # ---- co-registration forwarder (xdem/dem.py:621-665) -----------------------------------------------------------
-    def coregister_3d(self, reference_elev: "DEM", coreg_method=None, inlier_mask=None, resample: bool = True, **kwargs) -> "DEM":
-        """Align this DEM to ``reference_elev`` (same grid) with ``coreg_method`` (default ``NuthKaab(subsample=1)``)."""
+    def coregister_3d(self, reference_elev: "DEM", coreg_method=None, inlier_mask=None, bias_vars=None, random_state=None,
+                      **kwargs) -> "DEM":
+        """Align this DEM to ``reference_elev`` (same grid) with ``coreg_method`` (upstream requires one and names Nuth and
+        Kaab as the default in its docstring: ``None`` means ``NuthKaab(subsample=1)`` here).  ``random_state`` seeds the
+        subsampling; ``resample`` (keyword, default True) as upstream; ``bias_vars`` belongs to bias-correction methods, which
+        are not part of this package."""
+        resample = kwargs.pop("resample", True)
+        if bias_vars is not None:
+            raise NotImplementedError("bias_vars is only used by bias-correction methods (not part of xdem_amd).")
+        if random_state is not None:
+            kwargs["random_state"] = random_state
         method = coreg_method if coreg_method is not None else _coreg.NuthKaab(subsample=1)
         if not isinstance(method, _coreg.NuthKaab):
             raise ValueError("Argument `coreg_method` must be an xdem_amd.coreg instance (e.g. xdem_amd.coreg.NuthKaab()).")
