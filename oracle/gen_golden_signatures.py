@@ -20,7 +20,8 @@ TERRAIN = ["get_terrain_attribute", "slope", "aspect", "hillshade", "curvature",
 SPATIALSTATS = ["nd_binning", "interp_nd_binning", "two_step_standardization", "infer_heteroscedasticity_from_stable",
                 "sample_empirical_variogram", "get_variogram_model_func", "covariance_from_variogram", "correlation_from_variogram",
                 "fit_sum_model_variogram", "infer_spatial_correlation_from_stable", "neff_circular_approx_theoretical",
-                "neff_circular_approx_numerical", "neff_exact", "neff_hugonnet_approx"]
+                "neff_circular_approx_numerical", "neff_exact", "neff_hugonnet_approx", "number_effective_samples",
+                "spatial_error_propagation"]
 
 
 def _literal(v):

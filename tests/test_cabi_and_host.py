@@ -224,3 +224,46 @@ def test_dem_coregister_3d_argument_plumbing(monkeypatch):
         a.coregister_3d(b, coreg_method=object())
     with pytest.raises(NotImplementedError, match="share one grid"):
         a.coregister_3d(xdem_amd.DEM(np.ones((5, 7), dtype=np.float32)))
+
+
+def test_number_effective_samples_host_logic(monkeypatch):
+    """number_effective_samples / spatial_error_propagation (xdem/spatialstats.py:2311-2458) without the GPU: the numeric-area
+    branch is host SciPy (checked against the closed form of a single model), the mask branch must hand the upstream pixel
+    coordinates and unit errors to neff_hugonnet_approx, bad inputs raise upstream's message."""
+    import pandas as pd
+
+    from xdem_amd import spatialstats as ss
+
+    one = pd.DataFrame({"model": ["spherical"], "range": [300.0], "psill": [1.0]})
+    for area in (1e3, 1e5, 2e6):
+        num, theo = ss.number_effective_samples(area, one), ss.neff_circular_approx_theoretical(area, one)
+        assert np.isclose(num, theo, rtol=1e-6), (area, num, theo)
+    two = pd.DataFrame({"model": ["spherical", "gaussian"], "range": [50.0, 500.0], "psill": [0.7, 0.3]})
+    assert ss.number_effective_samples(25000, two) == ss.neff_circular_approx_numerical(25000, two)  # ints are numeric areas
+    seen = {}
+
+    def fake(coords, errors, params_variogram_model, **kw):
+        seen.update(coords=coords, errors=errors, kw=kw)
+        return 7.0
+
+    monkeypatch.setattr(ss, "neff_hugonnet_approx", fake)
+    mask = np.zeros((4, 6), dtype=bool)
+    mask[1, 2] = mask[3, 5] = mask[0, 0] = True
+    assert ss.number_effective_samples(mask, two, rasterize_resolution=2.5, subsample=10, random_state=3) == 7.0
+    # upstream: x = res * arange(shape[0]), y = res * arange(shape[1]), coords = meshgrid(y, x)[:, mask].T
+    assert np.array_equal(seen["coords"], np.array([[0.0, 0.0], [5.0, 2.5], [12.5, 7.5]]))
+    assert np.array_equal(seen["errors"], np.ones(3)) and seen["kw"] == {"subsample": 10, "random_state": 3}
+    with pytest.warns(UserWarning, match="20% of the shortest"):
+        ss.number_effective_samples(mask, two)
+    assert np.array_equal(seen["coords"][1], [20.0, 10.0])  # default resolution = min(range) / 5 = 10
+    with pytest.raises(ValueError, match="Area must be a float, integer, Vector subclass or geopandas dataframe."):
+        ss.number_effective_samples("area", two)
+    with pytest.raises(ValueError, match="rasterize resolution must be"):
+        ss.number_effective_samples(mask, two, rasterize_resolution="1")
+    err = np.full((4, 6), 2.0)
+    err[0, 0] = np.nan
+    se = ss.spatial_error_propagation([25000.0, mask], err, two, rasterize_resolution=2.5)
+    assert np.isclose(se[0], 2.0 / np.sqrt(ss.neff_circular_approx_numerical(25000.0, two)))
+    assert np.isclose(se[1], 2.0 / np.sqrt(7.0))  # nanmean over the mask's pixels
+    with pytest.raises(ValueError, match="needs the grid spacing"):
+        ss.spatial_error_propagation([mask], err, two)

@@ -1120,3 +1120,62 @@ def neff_hugonnet_approx(coords, errors, params_variogram_model, subsample: int 
     rand_points = rng.choice(n, size=subsample, replace=False)
     var = _cov_double_sum(coords, errors, coords[rand_points, :], errors[rand_points], params_variogram_model, ctx)
     return float(np.mean(errors)) ** 2 / (var / (n * subsample))
+
+
+def number_effective_samples(area, params_variogram_model, rasterize_resolution=None, **kwargs: Any) -> float:
+    """Number of effective (uncorrelated) samples in an area for a sum of variogram models; mirror of
+    ``xdem.spatialstats.number_effective_samples`` (xdem/spatialstats.py:2311-2404).
+
+    A numeric ``area`` takes the continuous disk approximation (host SciPy integration, as upstream).  Where upstream takes a
+    vector and rasterises it with geoutils (vector I/O: out of scope here), pass the rasterised area itself: a 2-D boolean
+    ``area`` mask on a grid of ``rasterize_resolution`` -- the coordinates of its pixels are built exactly as upstream builds
+    them from its mask and the double sum of covariances runs on the GPU (``neff_hugonnet_approx``; ``kwargs`` go to it)."""
+    _check_validity_params_variogram(params_variogram_model)
+    if isinstance(area, (float, int)) and not isinstance(area, bool):
+        return neff_circular_approx_numerical(area=area, params_variogram_model=params_variogram_model)
+    if isinstance(area, np.ndarray) and area.dtype == bool and area.ndim == 2:
+        mask = area
+        if rasterize_resolution is None:
+            rasterize_resolution = np.min(params_variogram_model["range"].values) / 5.0
+            warnings.warn(
+                "Resolution for vector rasterization is not defined and thus set at 20% of the shortest "
+                "correlation range, which might result in large memory usage."
+            )
+        if not isinstance(rasterize_resolution, (float, int, np.floating, np.integer)):
+            raise ValueError("The rasterize resolution must be a float, integer or Raster subclass.")
+        x = rasterize_resolution * np.arange(0, mask.shape[0])
+        y = rasterize_resolution * np.arange(0, mask.shape[1])
+        coords = np.array(np.meshgrid(y, x))
+        coords_on_mask = coords[:, mask].T
+        errors_on_mask = np.ones(len(coords_on_mask))  # heteroscedasticity does not matter here: errors standardized to one
+        return neff_hugonnet_approx(coords=coords_on_mask, errors=errors_on_mask, params_variogram_model=params_variogram_model,
+                                    **kwargs)
+    raise ValueError("Area must be a float, integer, Vector subclass or geopandas dataframe.")
+
+
+def spatial_error_propagation(areas, errors, params_variogram_model, **kwargs: Any) -> list:
+    """Standard error (1-sigma) of the mean elevation error in each area: mean error / sqrt(number of effective samples); mirror
+    of ``xdem.spatialstats.spatial_error_propagation`` (xdem/spatialstats.py:2407-2458) for the array-level inputs of
+    ``number_effective_samples``: ``errors`` is the error map (array, masked array or Raster-like with ``.data`` / ``.res``),
+    an area is a float (disk of that surface, mean over the whole map) or a boolean mask on the map's grid."""
+    gsd = errors.res[0] if hasattr(errors, "res") and hasattr(errors, "data") else None
+    arr = errors.data if gsd is not None else errors
+    if isinstance(arr, np.ma.MaskedArray):
+        arr = np.where(np.ma.getmaskarray(arr), np.nan, arr.data.astype(np.float64, copy=False))
+    arr = np.asarray(arr)
+    standard_errors = []
+    for area in areas:
+        if isinstance(area, np.ndarray):
+            if gsd is None and "rasterize_resolution" not in kwargs:
+                raise ValueError("a mask area needs the grid spacing: pass a Raster-like `errors` or rasterize_resolution=")
+            kw = dict(kwargs)
+            res = kw.pop("rasterize_resolution", gsd)
+            neff = number_effective_samples(area, params_variogram_model, rasterize_resolution=res, **kw)
+            average_spread = np.nanmean(arr[area])
+        else:
+            kw = {k: v for k, v in kwargs.items() if k != "rasterize_resolution"}
+            neff = number_effective_samples(area, params_variogram_model, **kw)
+            # (upstream averages over the whole map for `float` areas only; an `int` area reaches its vector branch and fails)
+            average_spread = np.nanmean(arr)
+        standard_errors.append(average_spread / np.sqrt(neff))
+    return standard_errors
