@@ -93,6 +93,8 @@ def main() -> None:
     for n in SPATIALSTATS:
         rec["spatialstats"][n] = record(getattr(ref.spatialstats, n))
     rec["coreg"]["NuthKaab.__init__"] = record(ref.affine.NuthKaab.__init__)
+    rec["coreg"]["NuthKaab.fit"] = record(ref.affine.NuthKaab.fit)
+    rec["coreg"]["NuthKaab.fit_and_apply"] = record(ref.affine.NuthKaab.fit_and_apply)
     with open(OUT, "w") as f:
         json.dump(rec, f, indent=1, sort_keys=True)
     print("signatures written:", {k: len(v) for k, v in rec.items()})

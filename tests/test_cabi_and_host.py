@@ -147,7 +147,7 @@ def test_nuthkaab_class_contract():
     assert nk.meta["inputs"]["fitorbin"]["bin_sizes"] == 72
     with pytest.raises(NotImplementedError):
         coreg.NuthKaab(bin_before_fit=False)
-    with pytest.raises(ValueError, match="'resolution' must be provided"):
+    with pytest.raises(ValueError, match="'transform' must be given if both DEMs are array-like."):
         nk.fit(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
     x = np.linspace(0, 6, 50)
     assert np.allclose(coreg._nuth_kaab_fit_func(x, 2.0, 0.5, 1.0), 2.0 * np.cos(0.5 - x) + 1.0)
@@ -267,3 +267,51 @@ def test_number_effective_samples_host_logic(monkeypatch):
     assert np.isclose(se[1], 2.0 / np.sqrt(7.0))  # nanmean over the mask's pixels
     with pytest.raises(ValueError, match="needs the grid spacing"):
         ss.spatial_error_propagation([mask], err, two)
+
+
+def test_nuthkaab_fit_apply_interface(monkeypatch):
+    """Coreg.fit / apply / fit_and_apply call surface (xdem/coreg/base.py:2250-2590) without the GPU: grid spacing from an
+    affine transform, (array, transform) returned when a transform comes in, shift moved into the transform for
+    resample=False, copies are independent, foreign arguments raise."""
+    from xdem_amd import coreg
+
+    calls = {}
+
+    def fake_nk(ref, tba, inlier, res, **kw):
+        calls["fit"] = dict(res=res, **{k: kw[k] for k in ("subsample", "random_state", "bin_statistic")})
+        return (3.0, -4.0, 1.5), 42
+
+    def fake_apply(elev, sx, sy, sz, res, resample=True, ctx=None):
+        calls["apply"] = (sx, sy, sz, res, resample)
+        return elev + sz
+
+    monkeypatch.setattr(coreg, "nuth_kaab", fake_nk)
+    monkeypatch.setattr(coreg, "apply_translation", fake_apply)
+    a, b = np.zeros((4, 5), np.float32), np.ones((4, 5), np.float32)
+    tr = (2.0, 0.0, 100.0, 0.0, -2.0, 500.0)
+    nk = coreg.NuthKaab().fit(a, b, transform=tr, crs="EPSG:32633", subsample=0.5, random_state=9)
+    assert calls["fit"] == {"res": (2.0, 2.0), "subsample": 0.5, "random_state": 9, "bin_statistic": np.nanmedian}
+    assert nk.meta["outputs"]["affine"] == {"shift_x": -3.0, "shift_y": 4.0, "shift_z": 1.5}
+    assert nk.to_translations() == (-3.0, 4.0, 1.5) and nk.to_rotations() == (0.0, 0.0, 0.0) and nk.is_affine
+    out, tr2 = nk.apply(b, transform=tr, crs="EPSG:32633")
+    assert tr2 == tr and calls["apply"] == (-3.0, 4.0, 1.5, (2.0, 2.0), True) and np.all(out == 2.5)
+    out, tr3 = nk.apply(b, transform=tr, resample=False)
+    assert tr3 == (2.0, 0.0, 97.0, 0.0, -2.0, 504.0) and calls["apply"][4] is False
+    assert isinstance(nk.apply(b, 2.0), np.ndarray)          # resolution form: the array alone
+    aligned, _ = coreg.NuthKaab().fit_and_apply(a, b, transform=tr, random_state=1)
+    assert np.all(aligned == 2.5) and calls["fit"]["random_state"] == 1
+    assert isinstance(coreg.NuthKaab().fit_and_apply(a, b, fit_kwargs={"resolution": 2.0}), np.ndarray)
+    c = nk.copy()
+    c.meta["outputs"]["affine"]["shift_x"] = 0.0
+    assert nk.meta["outputs"]["affine"]["shift_x"] == -3.0
+
+    class Affine:  # rasterio-like transform object
+        def __init__(self, a, b, c, d, e, f):
+            self.a, self.b, self.c, self.d, self.e, self.f = a, b, c, d, e, f
+
+    out, t4 = nk.apply(b, transform=Affine(*tr), resample=False)
+    assert isinstance(t4, Affine) and (t4.c, t4.f) == (97.0, 504.0)
+    with pytest.raises(NotImplementedError):
+        nk.fit(a, b, transform=tr, weights=np.ones((4, 5)))
+    with pytest.raises(NotImplementedError):
+        nk.apply(b, transform=tr, resampling="cubic")

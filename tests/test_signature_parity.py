@@ -29,7 +29,7 @@ def _mirror(module: str, name: str):
     else:
         from xdem_amd import coreg as m
 
-        return m.NuthKaab.__init__
+        return getattr(m.NuthKaab, name.split(".")[1])
     return getattr(m, name)
 
 

@@ -304,17 +304,31 @@ class NuthKaab:
             "outputs": {},
         }
 
+    @staticmethod
+    def _resolution(resolution, transform) -> tuple[float, float]:
+        """(x, y) pixel size from ``resolution`` (scalar or pair) or from an affine ``transform`` (object with ``.a`` / ``.e`` or
+        a 6-tuple ``(a, b, c, d, e, f)``), which is how the reference's array interface carries it."""
+        if resolution is None and transform is not None:
+            a, e = (transform.a, transform.e) if hasattr(transform, "a") else (transform[0], transform[4])
+            return (abs(float(a)), abs(float(e)))
+        if resolution is None:
+            raise ValueError("'transform' must be given if both DEMs are array-like.")  # (base.py:204; or pass resolution=)
+        return (float(resolution), float(resolution)) if np.isscalar(resolution) else (float(resolution[0]), float(resolution[1]))
+
     def fit(self, reference_elev: np.ndarray, to_be_aligned_elev: np.ndarray, inlier_mask: np.ndarray | None = None,
-            resolution: float | tuple[float, float] | None = None, subsample: int | float | None = None,
-            random_state=None, **kwargs: Any) -> "NuthKaab":
-        """Estimate the x/y/z offset between two DEMs given as arrays on the same grid (Coreg.fit, base.py:2250-2368)."""
+            bias_vars=None, weights=None, subsample: int | float | None = None, transform=None, crs=None, area_or_point=None,
+            z_name: str | None = None, random_state=None, resolution: float | tuple[float, float] | None = None, **kwargs: Any) -> "NuthKaab":
+        """Estimate the x/y/z offset between two DEMs given as arrays on the same grid (``Coreg.fit``, base.py:2250-2368:
+        same parameters in the same order; the grid spacing comes from ``transform`` as upstream or from ``resolution``).
+        ``bias_vars`` / ``weights`` belong to other methods and must stay ``None``; ``crs`` / ``area_or_point`` / ``z_name``
+        are accepted for call compatibility (one shared grid is assumed, georeferencing stays with the caller)."""
+        if bias_vars is not None or weights is not None:
+            raise NotImplementedError("bias_vars / weights are not used by NuthKaab.")
         if subsample is not None:
             self.meta["inputs"]["random"]["subsample"] = subsample
         if random_state is not None:
             self.meta["inputs"]["random"]["random_state"] = random_state
-        if resolution is None:
-            raise ValueError("'resolution' must be provided when passing arrays.")
-        res = (float(resolution), float(resolution)) if np.isscalar(resolution) else (float(resolution[0]), float(resolution[1]))
+        res = self._resolution(resolution, transform)
         ref = np.asarray(reference_elev.filled(np.nan) if isinstance(reference_elev, np.ma.MaskedArray) else reference_elev)
         tba = np.asarray(to_be_aligned_elev.filled(np.nan) if isinstance(to_be_aligned_elev, np.ma.MaskedArray) else to_be_aligned_elev)
         it = self.meta["inputs"]["iterative"]
@@ -329,10 +343,59 @@ class NuthKaab:
         self.meta["outputs"]["random"] = {"subsample_final": n_final}
         return self
 
-    def apply(self, elev: np.ndarray, resolution: float | tuple[float, float], resample: bool = True) -> np.ndarray:
-        """Apply the estimated translation to a DEM array on the fit grid (Coreg.apply, translation case)."""
+    def apply(self, elev: np.ndarray, resolution: float | tuple[float, float] | None = None, resample: bool = True, *,
+              bias_vars=None, resampling: str = "bilinear", transform=None, crs=None, z_name: str = "z"):
+        """Apply the estimated translation to a DEM array on the fit grid (``Coreg.apply``, translation case; upstream's
+        keywords are keyword-only here).  With ``transform=`` the call returns ``(array, transform)`` like upstream's array
+        interface -- for ``resample=False`` the shift goes into the returned transform and only the vertical shift into the
+        array; with ``resolution=`` it returns the array alone."""
+        if bias_vars is not None:
+            raise NotImplementedError("bias_vars is not used by NuthKaab.")
+        if resampling != "bilinear":
+            raise NotImplementedError("the GPU resampler is bilinear (the reference default).")
         a = self.meta["outputs"]["affine"]
-        return apply_translation(elev, a["shift_x"], a["shift_y"], a["shift_z"], resolution, resample)
+        res = self._resolution(resolution, transform)
+        out = apply_translation(elev, a["shift_x"], a["shift_y"], a["shift_z"], res, resample)
+        if transform is None:
+            return out
+        if resample:
+            return out, transform
+        t = (transform.a, transform.b, transform.c, transform.d, transform.e, transform.f) if hasattr(transform, "a") else tuple(transform)
+        shifted = (t[0], t[1], t[2] + a["shift_x"], t[3], t[4], t[5] + a["shift_y"])
+        return out, (type(transform)(*shifted) if hasattr(transform, "a") else shifted)
+
+    def fit_and_apply(self, reference_elev, to_be_aligned_elev, inlier_mask=None, bias_vars=None, weights=None, subsample=None,
+                      transform=None, crs=None, area_or_point=None, z_name: str = "z", resample: bool = True,
+                      resampling: str = "bilinear", random_state=None, fit_kwargs=None, apply_kwargs=None):
+        """``Coreg.fit_and_apply`` (base.py:2482-2590): fit, then apply to the to-be-aligned elevations."""
+        fit_kwargs = dict(fit_kwargs or {})
+        apply_kwargs = dict(apply_kwargs or {})
+        self.fit(reference_elev, to_be_aligned_elev, inlier_mask=inlier_mask, bias_vars=bias_vars, weights=weights, subsample=subsample,
+                 transform=transform, crs=crs, area_or_point=area_or_point, z_name=z_name, random_state=random_state, **fit_kwargs)
+        resolution = apply_kwargs.pop("resolution", fit_kwargs.get("resolution"))
+        return self.apply(to_be_aligned_elev, resolution, resample, bias_vars=bias_vars, resampling=resampling, transform=transform,
+                          crs=crs, z_name=z_name, **apply_kwargs)
+
+    def copy(self) -> "NuthKaab":
+        """Identical, independent copy (base.py:1999-2006)."""
+        import copy as _copy
+
+        new = self.__new__(type(self))
+        new.__dict__ = {k: _copy.deepcopy(v) for k, v in self.__dict__.items()}
+        return new
+
+    @property
+    def is_affine(self) -> bool:
+        return True
+
+    def to_translations(self) -> tuple[float, float, float]:
+        """(x, y, z) translations of the estimated transform (base.py: ``to_translations`` of affine methods)."""
+        m = self.to_matrix()
+        return (float(m[0, 3]), float(m[1, 3]), float(m[2, 3]))
+
+    def to_rotations(self) -> tuple[float, float, float]:
+        """Rotations of the estimated transform: none, Nuth and Kaab is a pure translation."""
+        return (0.0, 0.0, 0.0)
 
     def to_matrix(self) -> np.ndarray:
         """4x4 translation matrix (affine.py:2532-2541)."""
