@@ -29,10 +29,11 @@ static void run(const TIN* dem, int64_t H, int64_t W, int64_t halo_top, int64_t 
                 }
             for (int t = 0; t < TW && x0 + t < W; ++t)
                 {
-                    Planes<TOUT> org;
-                    for (int k = 0; k < N_ATTR; ++k) org.p[k] = out.p[k] + (y0 * W + x0);
-                    march_column<FIT, CURV, WIN, SP, TIN, TOUT>(tile.data() + XPAD + t, PITCH, n_out, P, org,
-                                                                (uint32_t)(t * sizeof(TOUT)), (uint32_t)(W * sizeof(TOUT)));
+                    DirectSink<TOUT> sk;
+                    for (int k = 0; k < N_ATTR; ++k) sk.org.p[k] = out.p[k] + (y0 * W + x0);
+                    sk.o0 = (uint32_t)(t * sizeof(TOUT));
+                    sk.ostride = (uint32_t)(W * sizeof(TOUT));
+                    march_column<FIT, CURV, WIN, SP, TIN, DirectSink<TOUT>>(tile.data() + XPAD + t, PITCH, n_out, P, sk);
                 }
         }
 }
@@ -79,6 +80,7 @@ extern "C" int hostsim_terrain(const void* dem, int dem_dtype, int64_t H, int64_
     P.hs_kx = 254.0 * (-cos(alt) * hs_z * cos(az));
     P.hs_ky = 254.0 * (cos(alt) * hs_z * sin(az));
     P.hs_zf2 = hs_z * hs_z;
+    fill_ref_weights(fit, resolution, P.wref);
     P.mask = mask; P.curv_directional = curv_dir; P.tri_wilson = tri_wilson; P.degrees = degrees;
     if (dem_dtype == 0 && out_dtype == 0) return go<float, float>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
     if (dem_dtype == 1 && out_dtype == 1) return go<double, double>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);

@@ -37,3 +37,89 @@ def assert_parity(got, ref, name="", rtol: float = RTOL, min_exact: float = 0.0)
     assert c["max_scaled_err"] <= rtol, f"{name}: scaled error {c['max_scaled_err']:.3e} > {rtol:g}"
     assert c["bit_exact_frac"] >= min_exact, f"{name}: only {c['bit_exact_frac']:.6f} bit-exact"
     return c
+
+
+# ---- true relative error (round 2) ---------------------------------------------------------------------
+# The scaled metric above forgives errors on small values in a raster of large ones.  `compare_true` does not: every
+# finite pixel must satisfy |got - ref| <= rtol * |ref|, except where both numbers are float64 rounding noise of the
+# reference's own accumulation -- results whose exact value is 0 (curvature of a planar ramp, TPI of flat ground) come
+# out of the reference as ~1e-15 residues that depend on the order of its additions.  `noise_floor` bounds that noise
+# from the DEM: 64 * eps(float64) * attribute scale, with the scale of a curvature = 100 * 4 max|z| / res^2, of a
+# first-derivative attribute max|z| / res, of TPI / TRI / roughness max|z|.  It is ~1e-11 of real curvature values.
+_EPS64 = float(np.finfo(np.float64).eps)
+
+
+def noise_floor(attr: str, dem: np.ndarray, resolution: float = 1.0) -> float:
+    fin = np.isfinite(dem)
+    zmax = float(np.max(np.abs(dem[fin]))) if fin.any() else 0.0
+    if "curvature" in attr:
+        scale = 100.0 * 4.0 * zmax / (resolution * resolution)
+    elif attr in ("slope", "aspect", "hillshade"):
+        scale = 0.0  # first-derivative attributes are compared relatively everywhere (residues are reproduced exactly)
+    else:
+        scale = zmax
+    return 64.0 * _EPS64 * scale
+
+
+def ulp_distance(got: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    it = np.int32 if got.dtype == np.float32 else np.int64
+    a = got.view(it).astype(np.int64)
+    b = ref.view(it).astype(np.int64)
+    sign = np.int64(-(2**31)) if got.dtype == np.float32 else np.int64(-(2**63))
+    a = np.where(a < 0, sign - a, a)
+    b = np.where(b < 0, sign - b, b)
+    return np.abs(a - b)
+
+
+def compare_true(got: np.ndarray, ref: np.ndarray, floor: float = 0.0):
+    """NaN / Inf masks, worst TRUE relative error outside the noise floor, ulp histogram (0, 1, 2, 3-4, 5-8, >8)."""
+    assert got.shape == ref.shape and got.dtype == ref.dtype, (got.shape, ref.shape, got.dtype, ref.dtype)
+    nan_equal = np.array_equal(np.isnan(got), np.isnan(ref))
+    fin = np.isfinite(ref) & np.isfinite(got)
+    inf_equal = np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])
+    out = {"nan_equal": nan_equal, "inf_equal": inf_equal, "max_rel": 0.0, "exact": 1.0, "hist": [1.0, 0, 0, 0, 0, 0],
+           "max_ulp": 0, "n": int(fin.sum())}
+    if fin.any():
+        r = ref[fin].astype(np.float64)
+        g = got[fin].astype(np.float64)
+        err = np.abs(g - r)
+        judged = err > floor
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.where(judged, err / np.abs(r), 0.0)
+        out["max_rel"] = float(np.max(rel))
+        d = ulp_distance(got[fin], ref[fin])
+        d = np.where(judged, d, 0)
+        out["max_ulp"] = int(d.max())
+        out["exact"] = float(np.mean(d == 0))
+        out["hist"] = [float(np.mean(d == 0)), float(np.mean(d == 1)), float(np.mean(d == 2)),
+                       float(np.mean((d > 2) & (d <= 4))), float(np.mean((d > 4) & (d <= 8))), float(np.mean(d > 8))]
+    return out
+
+
+def assert_parity_true(got, ref, name="", floor: float = 0.0, rtol: float = RTOL, min_exact: float = 0.0):
+    c = compare_true(got, ref, floor)
+    assert c["nan_equal"], f"{name}: NaN mask differs"
+    assert c["inf_equal"], f"{name}: +-Inf positions/values differ"
+    assert c["max_rel"] <= rtol, f"{name}: true relative error {c['max_rel']:.3e} > {rtol:g} (max {c['max_ulp']} ulp)"
+    assert c["exact"] >= min_exact, f"{name}: only {c['exact']:.6f} bit-exact (< {min_exact})"
+    return c
+
+
+# Attributes whose float32 result is, by construction of the kernel, the reference's float64 evaluation rounded once
+# (>= 99.9 % of pixels bit-identical on terrain-like rasters); slope, aspect and TRI run their polynomial / sum-of-squares
+# part in float32 (a few float32 roundings: <= 8 ulp, far inside the 1e-6 bar).
+EXACT_ATTRS = {"hillshade", "curvature", "profile_curvature", "tangential_curvature", "planform_curvature",
+               "flowline_curvature", "max_curvature", "min_curvature", "topographic_position_index", "roughness"}
+
+
+def check_attribute(got, ref, attr, dem, resolution, name="", exact_frac=0.999, max_ulp_f32_math=8):
+    """The round-2 parity bar for one attribute plane: masks bit-exact, TRUE relative error <= 1e-6 outside the float64
+    noise floor, and for float32 planes either the bit-exact share (EXACT_ATTRS) or an ulp bound."""
+    floor = noise_floor(attr, dem, resolution)
+    c = assert_parity_true(got, ref, name or attr, floor=floor)
+    if got.dtype == np.float32 and c["n"] >= 1000:
+        if attr in EXACT_ATTRS:
+            assert c["exact"] >= exact_frac, f"{name or attr}: only {c['exact']:.5f} bit-exact (< {exact_frac})"
+        else:
+            assert c["max_ulp"] <= max_ulp_f32_math, f"{name or attr}: {c['max_ulp']} ulp (> {max_ulp_f32_math})"
+    return c

@@ -7,7 +7,7 @@ import pytest
 
 import terrain_oracle as to
 from conftest import GOLDEN
-from parity import assert_parity
+from parity import assert_parity, assert_parity_true, check_attribute, compare_true, noise_floor
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,7 @@ def test_fbm_f32_all_attributes(terrain, fit, cm, shape):
     got = terrain.get_terrain_attribute(dem, attrs, resolution=10.0, surface_fit=fit, curv_method=cm)
     ref = to.terrain_attributes(dem, attrs, resolution=10.0, surface_fit=fit, curv_method=cm)
     for a, g, r in zip(attrs, got, ref):
-        assert_parity(g, r, f"{fit}/{cm}/{shape}/{a}", min_exact=0.999 if min(shape) > 8 else 0.0)
+        check_attribute(g, r, a, dem, 10.0, f"{fit}/{cm}/{shape}/{a}")
 
 
 @pytest.mark.parametrize("kw", [
@@ -58,7 +58,7 @@ def test_options(terrain, kw):
     got = terrain.get_terrain_attribute(dem, FULL, **kw)
     ref = to.terrain_attributes(dem, FULL, **kw)
     for a, g, r in zip(FULL, got, ref):
-        assert_parity(g, r, f"{kw}/{a}")
+        check_attribute(g, r, a, dem, kw["resolution"], f"{kw}/{a}")
 
 
 def test_f64_in_out_and_mixed(terrain):
@@ -140,13 +140,78 @@ def test_golden_reference_vectors(terrain):
                                             tri_method=tri)
         got = got if isinstance(got, list) else [got]
         for a, g in zip(attrs, got):
-            assert_parity(g, z["|".join(cfg) + "|" + a], f"{cfg}/{a}")
+            check_attribute(g, z["|".join(cfg) + "|" + a], a, dem, 10.0, f"{cfg}/{a}")
     z = np.load(os.path.join(GOLDEN, "terrain_T4_int32.npz"))
     attrs = [k for k in z.files if k != "dem"]
     got = terrain.get_terrain_attribute(z["dem"], attrs, resolution=5.0)
     for a, g in zip(attrs, got):
         assert g.dtype == np.float32
-        assert_parity(g, z[a], f"int32/{a}")
+        check_attribute(g, z[a], a, z["dem"].astype(np.float32), 5.0, f"int32/{a}")
+
+
+def _ulp_line(c):
+    return "hist(0,1,2,3-4,5-8,>8)=" + "/".join(f"{h:.3f}" for h in c["hist"]) + f" max_ulp={c['max_ulp']} max_rel={c['max_rel']:.2e}"
+
+
+@pytest.mark.parametrize("fname", ["terrain_T1_float32_nan.npz", "terrain_T1_float32_inf.npz",
+                                   "terrain_T1_float64_nan.npz", "terrain_T1_float64_inf.npz"])
+def test_T1_reference_fixtures_on_the_hip_path(terrain, fname, record_property):
+    """Every T1 array recorded from the reference (normal noise with NaN / Inf holes x 3 fits x 2 curvature methods x 3
+    resolutions, float32 and float64, deprecated `curvature` included) through get_terrain_attribute on the HIP path:
+    masks bit-exact, TRUE relative error <= 1e-6.  (Zero-mean noise is the worst case for bit-identity: derivative sums of
+    full-width float32 values land on exact rounding ties, which the reference breaks by its float64 rounding noise.)"""
+    z = np.load(os.path.join(GOLDEN, fname))
+    dem = z["dem"]
+    n = 0
+    worst = {}
+    for key in z.files:
+        if key == "dem":
+            continue
+        fit, cm, res, attr = key.split("|")
+        got = terrain.get_terrain_attribute(dem, attr, resolution=float(res), surface_fit=fit, curv_method=cm)
+        c = assert_parity_true(got, z[key], f"{fname}:{key}", floor=noise_floor(attr, dem, float(res)))
+        w = worst.setdefault(attr, c)
+        if c["max_rel"] >= w["max_rel"]:
+            worst[attr] = c
+        n += 1
+    assert n > 100
+    for attr, c in worst.items():
+        record_property(f"T1/{fname}/{attr}", _ulp_line(c))
+
+
+def test_T3_reference_known_answers_on_the_hip_path(terrain, record_property):
+    """The reference's data-free known-answer DEMs (tests/test_terrain/test_surfit.py:228-411: flat, ramps, V shapes,
+    saddle, ridge, trough) with the outputs the reference itself produced, through the HIP path.  Includes the exactly
+    flat Florinsky window, where the reference returns its cancellation residue (slope 2.5e-15, aspect 198.43494 deg):
+    reproduced by the kernel's reference-order recomputation of exactly cancelling derivative sums."""
+    z = np.load(os.path.join(GOLDEN, "terrain_T3_known_answers.npz"))
+    n = 0
+    for key in z.files:
+        if key.startswith("dem|"):
+            continue
+        name, fit, res, attr = key.split("|")
+        dem = z["dem|" + name]
+        got = terrain.get_terrain_attribute(dem, attr, resolution=float(res), surface_fit=fit)
+        demf = dem.astype(np.float32) if dem.dtype.kind in "iu" else dem
+        assert_parity_true(got, z[key], key, floor=noise_floor(attr, demf, float(res)))
+        n += 1
+    assert n > 900
+    flat = terrain.get_terrain_attribute(z["dem|flat"], ["slope", "aspect"], resolution=1.0, surface_fit="Florinsky")
+    assert flat[1][2, 2] == z["flat|Florinsky|1.0|aspect"][2, 2] == np.float32(198.43494)
+    assert flat[0][2, 2] == z["flat|Florinsky|1.0|slope"][2, 2] and 0 < flat[0][2, 2] < 1e-12
+
+
+def test_ulp_histogram_per_attribute(terrain, record_property):
+    """Per-attribute ulp histogram of the float32 kernel against the oracle on a terrain-like raster (what
+    tools/ulp_report.py prints): the evidence behind the mixed-precision tail."""
+    dem = _dem((1500, 1531), seed=42)
+    for fit, attrs in (("Florinsky", FULL), ("ZevenbergThorne", FULL), ("Horn", SAH_WIN)):
+        got = terrain.get_terrain_attribute(dem, attrs, resolution=10.0, surface_fit=fit)
+        ref = to.terrain_attributes(dem, attrs, resolution=10.0, surface_fit=fit)
+        for a, g, r in zip(attrs, got, ref):
+            c = check_attribute(g, r, a, dem, 10.0, f"{fit}/{a}")
+            record_property(f"{fit}/{a}", _ulp_line(c))
+            print(f"{fit:16s} {a:28s} {_ulp_line(c)}")
 
 
 def test_halo_rows_equal_full_raster(terrain):
@@ -197,7 +262,7 @@ def test_large_properties_16384(terrain):
     ref = to.terrain_attributes(sub, FULL, resolution=10.0)
     for i, r in enumerate(ref):
         g = out[i, 5002:5062, 3002:3398].cpu().numpy()
-        assert_parity(g, r[2:-2, 2:-2], FULL[i])
+        check_attribute(g, r[2:-2, 2:-2], FULL[i], sub, 10.0, FULL[i])
 
 
 def test_raster_beyond_2g_pixels(terrain):
@@ -266,8 +331,8 @@ def test_C1_dem_slope_plumbing_horn():
     assert isinstance(slope, xdem_amd.DEM) and slope.transform == dem.transform and slope.crs == dem.crs and slope.nodata == -99999
     ref_s, = to.terrain_attributes(dem.data, ["slope"], resolution=20.0, surface_fit="Horn")
     ref_a, = to.terrain_attributes(dem.data, ["aspect"], resolution=1.0, surface_fit="Horn", degrees=False)
-    assert_parity(slope.data, ref_s, "DEM.slope", min_exact=0.999)
-    assert_parity(aspect.data, ref_a, "DEM.aspect", min_exact=0.999)
+    check_attribute(slope.data, ref_s, "slope", dem.data, 20.0, "DEM.slope")
+    check_attribute(aspect.data, ref_a, "aspect", dem.data, 1.0, "DEM.aspect")
     both = dem.get_terrain_attribute(["slope", "aspect"], surface_fit="Horn")
     assert np.array_equal(both[0].data, slope.data, equal_nan=True) and len(both) == 2
     aligned = dem.coregister_3d(xdem_amd.DEM.from_array(arr + 1.0, dem.transform, dem.crs, nodata=-9998.0))
@@ -457,32 +522,15 @@ def test_randomised_configurations_vs_oracle():
             got = t.get_terrain_attribute(dem, attrs, **kw)
             ref = to.terrain_attributes(dem, attrs, **kw)
         got = got if isinstance(got, list) else [got]
-        # Pixels whose two first derivatives cancel EXACTLY (integer-valued DEMs): the reference's non-cancelling w/divider
-        # weights leave |grad| ~ 1e-15 of rounding noise there, so its aspect and its gradient-normalised curvatures are that
-        # noise; the kernel's integer-weighted sums give the exact 0 ("Numerical recipe").  Not comparable.
-        degenerate = None
-        if fit in ("ZevenbergThorne", "Florinsky", "Horn") and any(a in attrs for a in surf):
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                sl = to.terrain_attributes(dem, ["slope"], **{**kw, "degrees": False})[0]
-            degenerate = np.isfinite(sl) & (sl < 1e-9)
+        # (Round 1 excluded pixels whose derivative sums cancel exactly -- integer-valued DEMs -- because the reference returns
+        # its ~1e-15 rounding residue there and hence an arbitrary aspect; the kernel now recomputes such sums in the
+        # reference's own order, so they are compared like everything else: TRUE relative error.)
         for a, g, r in zip(attrs, got, ref):
-            if degenerate is not None and a in surf and a not in ("slope", "hillshade", "curvature"):
-                g, r = g.copy(), r.copy()
-                g[degenerate] = np.nan
-                r[degenerate] = np.nan
             if a in ("rugosity", "roughness"):
                 assert np.array_equal(g, r, equal_nan=True), (trial, a, kw, dem.shape, dtype)
-            elif a == "aspect":
-                # an angle: where a derivative cancels exactly (integer-valued DEMs) the reference's rounding noise decides
-                # between 0 and 2 pi, the kernel returns 0 -- compare on the circle
-                period = 360.0 if kw["degrees"] else 2 * np.pi
-                assert np.array_equal(np.isnan(g), np.isnan(r))
-                ok = np.isfinite(r)
-                d = np.abs(g[ok].astype(np.float64) - r[ok])
-                assert np.all(np.minimum(d, period - d) <= 1e-6 * period), (trial, kw, dem.shape, dtype)
             else:
-                assert_parity(g, r, f"trial {trial} {a} {fit} {dem.shape} {np.dtype(dtype).name} {kw}")
+                assert_parity_true(g, r, f"trial {trial} {a} {fit} {dem.shape} {np.dtype(dtype).name} {kw}",
+                                   floor=noise_floor(a, dem, kw["resolution"]))
             n_checked += 1
     assert n_checked > 800
 

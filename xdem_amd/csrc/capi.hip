@@ -93,6 +93,21 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->pairs_launch_cap = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "terrain_store") {
+        if (value < -1 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_store: -1 automatic, 0 direct, 1 staged row stores");
+        ctx->terrain_store = value;
+        return XDEMHIP_OK;
+    }
+    if (std::string(name) == "terrain_rows") {
+        if (value != 0 && value != 16 && value != 24 && value != 32) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_rows: 0, 16, 24 or 32");
+        ctx->terrain_rows = value;
+        return XDEMHIP_OK;
+    }
+    if (std::string(name) == "terrain_math") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_math: 0 mixed precision, 1 float64");
+        ctx->terrain_math = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "selection") {
         if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets, 3 bracketed");
         ctx->selection_mode = value;

@@ -56,7 +56,64 @@ struct TerrainParams {
     int curv_directional;
     int tri_wilson;
     int degrees;
+    // The reference's own convolution weights (integer table / divider in double, flipped to correlation order, row-major
+    // over the window; |w| <= DBL_EPSILON -> 0 = skipped, as scipy.ndimage does) for zx, zy, zxx, zyy, zxy: used by the
+    // rare exact-cancellation path of march_column (see ref_order_sum).
+    double wref[5][25];
+    int slot[N_ATTR];  // attribute -> index among the requested planes (staged row stores of terrain.hip)
 };
+
+// ---- the reference's divided convolution kernels (host side) -------------------------------------------
+// xdem/terrain/surfit.py:65-304 (integer tables, generated here from their structure) divided in double by the resolution
+// dividers of surfit.py:281-302 exactly as surfit.py:373-377 does (`table.astype(float64) / (c * res**p)`), then flipped
+// on both axes because scipy.ndimage.convolve correlates with the flipped kernel (xdem/spatialstats.py:2521-2525).
+inline void fill_ref_weights(int fit, double res, double (&w)[5][25]) {
+    const int M = (fit == 2) ? 5 : 3;
+    double tab[5][25] = {};
+    double div[5] = {1, 1, 1, 1, 1};
+    if (fit == 0) {  // Horn
+        const int s3[3] = {1, 2, 1}, d3[3] = {-1, 0, 1};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                tab[0][a * 3 + b] = s3[a] * d3[b];
+                tab[1][a * 3 + b] = -d3[a] * s3[b];
+            }
+        div[0] = div[1] = 8 * res;
+    } else if (fit == 1) {  // Zevenbergen & Thorne
+        const int d3[3] = {-1, 0, 1}, c3[3] = {1, -2, 1};
+        for (int k = 0; k < 3; ++k) {
+            tab[0][1 * 3 + k] = d3[k];
+            tab[1][k * 3 + 1] = -d3[k];
+            tab[2][1 * 3 + k] = c3[k];
+            tab[3][k * 3 + 1] = c3[k];
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) tab[4][a * 3 + b] = -d3[a] * d3[b];
+        div[0] = div[1] = 2 * res;
+        div[2] = div[3] = pow(res, 2.0);
+        div[4] = 4 * pow(res, 2.0);
+    } else {  // Florinsky
+        const int u5[5] = {-2, -1, 0, 1, 2}, c5[5] = {2, -1, -2, -1, 2}, al[5] = {44, 62, 68, 62, 44},
+                  be[5] = {-31, 5, 17, 5, -31}, a5[5] = {0, -1, 0, 1, 0}, b5[5] = {-1, 0, 0, 0, 1};
+        for (int a = 0; a < 5; ++a)
+            for (int b = 0; b < 5; ++b) {
+                tab[0][a * 5 + b] = al[a] * a5[b] + be[a] * b5[b];
+                tab[1][a * 5 + b] = -(al[b] * a5[a] + be[b] * b5[a]);
+                tab[2][a * 5 + b] = c5[b];
+                tab[3][a * 5 + b] = c5[a];
+                tab[4][a * 5 + b] = -u5[a] * u5[b];
+            }
+        div[0] = div[1] = 420 * res;
+        div[2] = div[3] = 35 * pow(res, 2.0);
+        div[4] = 100 * pow(res, 2.0);
+    }
+    for (int d = 0; d < 5; ++d)
+        for (int a = 0; a < M; ++a)
+            for (int b = 0; b < M; ++b) {
+                const double v = tab[d][(M - 1 - a) * M + (M - 1 - b)] / div[d];
+                w[d][a * M + b] = (fabs(v) > 2.220446049250313e-16) ? v : 0.0;
+            }
+}
 
 // ---- small float64 primitives without divisions ------------------------------------------------------
 // Hardware seeds: v_rsq_f64 (device).  The host stand-in deliberately truncates the seed to ~26 bits so
@@ -165,25 +222,78 @@ XD_HD double asin_small(double x) {
     return x * p;
 }
 
+// ---- float32 primitives of the mixed-precision tail (float32 DEM -> float32 attributes) -----------------
+// Seeds: v_rsq_f32 / v_sqrt_f32 (1 ulp, device).  The host stand-ins are correctly rounded, i.e. at least as accurate.
+XD_HD float rsq32_seed(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return (float)(1.0 / sqrt((double)x));
+#endif
+}
+// 1/sqrt(x) for x in [1e-13, 1e16]: seed + one Newton step (~1 unit of 2^-24 relative)
+XD_HD float rsq32(float x) {
+    const float y = rsq32_seed(x);
+    const float e = fmaf(-x * y, y, 1.0f);
+    return fmaf(0.5f * y, e, y);
+}
+XD_HD float sqrt32_hw(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+// asin(x) for 0 <= x <= 0.7075 as x + x*s*Q(s), s = x^2: degree-7 Q fitted for the relative error of asin
+// (tools/fit_poly.py: 3.0e-9 with these float32 coefficients); the final fma keeps the evaluation error at one rounding.
+XD_HD float asin32(float x) {
+    const float s = x * x;
+    float p = 1.265096068e-01f;
+    p = fmaf(p, s, -1.407062411e-01f);
+    p = fmaf(p, s, 1.108867303e-01f);
+    p = fmaf(p, s, -8.274481632e-03f);
+    p = fmaf(p, s, 3.603736311e-02f);
+    p = fmaf(p, s, 4.407655075e-02f);
+    p = fmaf(p, s, 7.502710819e-02f);
+    p = fmaf(p, s, 1.666662246e-01f);
+    return fmaf(x * s, p, x);
+}
+
 template <typename T> struct DegScale;
 template <> struct DegScale<float> { static XD_HD float v() { return 57.295776f; } };  // 180.0f / float(pi) in float arithmetic, as np.rad2deg
 template <> struct DegScale<double> { static XD_HD double v() { return 57.29577951308232; } };
 
-// Output sink: one pointer per attribute plane (null when not requested).  Pixels are addressed by a 32-bit BYTE
-// offset from the (wave-uniform) plane pointer, which maps to the scalar-base + VGPR-offset store form.
+// Output sinks.  Planes = one pointer per attribute plane (null when not requested).  DirectSink stores every value
+// straight to its plane: pixels are addressed by a 32-bit BYTE offset from the (wave-uniform) plane pointer at the tile
+// origin, which maps to the scalar-base + VGPR-offset store form; the offset of output row i is o0 + i * ostride (a tile
+// spans far less than 4 GiB per plane).  (terrain.hip adds a sink that stages rows in LDS for 1 KiB row stores.)
 template <typename TOUT> struct Planes { TOUT* p[N_ATTR]; };
-template <typename TOUT> XD_HD void put(TOUT* plane, uint32_t byte_off, TOUT v) {
-    *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(plane) + byte_off) = v;
-}
+template <typename TOUT> struct DirectSink {
+    typedef TOUT out_t;
+    Planes<TOUT> org;
+    uint32_t o0, ostride, o;
+    XD_HD void begin_row(int i) {
+        o = o0 + (uint32_t)i * ostride;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keep `o` an opaque 32-bit VGPR: stops loop-strength-reduction from turning every plane into its own 64-bit
+        // running pointer (11 VGPR pairs + one 64-bit add per store)
+        asm volatile("" : "+v"(o));
+#endif
+    }
+    template <int K> XD_HD void put(TOUT v) { *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o) = v; }
+    XD_HD void end_row(int) {}
+};
 
 // Compile-time specialisation knobs.  CMASK != 0 fixes the attribute mask: every `if (mask & ...)` folds away
 // and the independent attribute chains land in ONE basic block the scheduler can interleave; DIR / DEG /
 // WILSON / ZF1 = -1 mean "read the runtime flag".  Spec<0,-1,-1,-1,-1> is the fully general kernel.
-template <uint32_t CMASK_, int DIR_, int DEG_, int WILSON_, int ZF1_ = -1> struct Spec {
+template <uint32_t CMASK_, int DIR_, int DEG_, int WILSON_, int ZF1_ = -1, int F64TAIL_ = 0> struct Spec {
     static constexpr uint32_t CMASK = CMASK_;
     static constexpr int DIR = DIR_, DEG = DEG_, WILSON = WILSON_, ZF1 = ZF1_;  // ZF1: hillshade z_factor == 1
+    static constexpr int F64TAIL = F64TAIL_;  // 1: float64 attribute math also for float32 in / float32 out
 };
 typedef Spec<0, -1, -1, -1, -1> SpecRuntime;
+typedef Spec<0, -1, -1, -1, -1, 1> SpecRuntimeF64;
 constexpr uint32_t MASK_FULL11 = 0xFFFu & ~A_CURVATURE;  // (bits 0-11)  // the 11-attribute headline set (no deprecated 'curvature')
 constexpr uint32_t MASK_SAH_WIN = A_SLOPE | A_ASPECT | A_HILLSHADE | A_TPI | A_TRI;
 
@@ -191,9 +301,9 @@ constexpr uint32_t MASK_SAH_WIN = A_SLOPE | A_ASPECT | A_HILLSHADE | A_TPI | A_T
 // Invalid windows arrive with zx (and zxx) already NaN ("poisoned" by the marcher), so NaN propagates through
 // every formula below without per-attribute selects; comparisons with NaN are false, which keeps each
 // special-case branch (flat, tiny, steep, quadrant) on its arithmetic path.
-template <bool CURV, class SP, typename TOUT>
-XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zxy, const TerrainParams& P,
-                         const Planes<TOUT>& out, uint32_t o) {
+template <bool CURV, class SP, class SINK>
+XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zxy, const TerrainParams& P, SINK& sk) {
+    typedef typename SINK::out_t TOUT;
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
     const bool deg = SP::DEG < 0 ? (P.degrees != 0) : (SP::DEG != 0);
     const double zx2 = zx * zx, zy2 = zy * zy;
@@ -211,7 +321,7 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         a = steep ? (1.5707963267948966 - a) : a;
         TOUT v = (TOUT)a;
         if (deg) v = v * DegScale<TOUT>::v();
-        put(out.p[P_SLOPE], o, (TOUT)(v));
+        sk.template put<P_SLOPE>((TOUT)(v));
     }
     if (m & A_ASPECT) {
         // aspect = atan2(zx, zy) mod 2pi, first-quadrant angle from the smaller normalised component
@@ -224,7 +334,7 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         a = (a < 0.0) ? (a + 6.283185307179586) : a;   // flat ground: rg = 0 -> a = 0 already
         TOUT v = (TOUT)a;
         if (deg) v = v * DegScale<TOUT>::v();
-        put(out.p[P_ASPECT], o, (TOUT)(v));
+        sk.template put<P_ASPECT>((TOUT)(v));
     }
     if (m & A_HILLSHADE) {
         // 1.5 + 254 (sin(alt) cos(s') + cos(alt) sin(s') sin(az' - aspect)), s' = atan(zf * g), all algebraic
@@ -233,10 +343,10 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         // 1.5 + 254 * shade; the factor 254 is folded into the three sun coefficients on the host (fill_params)
         TOUT v = (TOUT)fma_c(rwz, P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx), 1.5);
         v = v < (TOUT)0 ? (TOUT)0 : (v > (TOUT)255 ? (TOUT)255 : v);
-        put(out.p[P_HILLSHADE], o, (TOUT)(v));
+        sk.template put<P_HILLSHADE>((TOUT)(v));
     }
     if (!CURV) return;
-    if (m & A_CURVATURE) put(out.p[P_CURVATURE], o, (TOUT)((TOUT)(-2.0 * (zxx + zyy) * 100.0)));
+    if (m & A_CURVATURE) sk.template put<P_CURVATURE>((TOUT)((TOUT)(-2.0 * (zxx + zyy) * 100.0)));
     if (m & (A_ANY_CURV & ~A_CURVATURE)) {
         const bool dir = SP::DIR < 0 ? (P.curv_directional != 0) : (SP::DIR != 0);
         const double zxzy = zx * zy;
@@ -248,15 +358,15 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         if (m & A_PROFILE) {
             double v = -n_prof * rg2;
             if (!dir) v *= rw * rw * rw;
-            put(out.p[P_PROFILE], o, (TOUT)(v));
+            sk.template put<P_PROFILE>((TOUT)(v));
         }
         const double t_dir = -n_tan * rg2;
-        if (m & A_TANGENTIAL) put(out.p[P_TANGENTIAL], o, (TOUT)((dir ? t_dir : t_dir * rw)));
-        if (m & A_PLANFORM) put(out.p[P_PLANFORM], o, (TOUT)((TOUT)(t_dir * rg_t)));
+        if (m & A_TANGENTIAL) sk.template put<P_TANGENTIAL>((TOUT)((dir ? t_dir : t_dir * rw)));
+        if (m & A_PLANFORM) sk.template put<P_PLANFORM>((TOUT)((TOUT)(t_dir * rg_t)));
         if (m & A_FLOWLINE) {
             const double n_flow = fma(zxzy, zxx - zyy, -zxy * (zx2 - zy2));
             const double v = dir ? n_flow * rg2 * rg : n_flow * rg2 * rg_t * rw;
-            put(out.p[P_FLOWLINE], o, (TOUT)(v));
+            sk.template put<P_FLOWLINE>((TOUT)(v));
         }
         if (m & (A_MAXC | A_MINC)) {
             double vmax, vmin;  // already x100
@@ -276,19 +386,150 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
                 vmax = mean + uns;
                 vmin = mean - uns;
             }
-            if (m & A_MAXC) put(out.p[P_MAXC], o, (TOUT)(flat ? 0.0 : vmax));
-            if (m & A_MINC) put(out.p[P_MINC], o, (TOUT)(flat ? 0.0 : vmin));
+            if (m & A_MAXC) sk.template put<P_MAXC>((TOUT)(flat ? 0.0 : vmax));
+            if (m & A_MINC) sk.template put<P_MINC>((TOUT)(flat ? 0.0 : vmin));
+        }
+    }
+}
+
+// ---- mixed-precision tail: float32 DEM -> float32 attributes ---------------------------------------------
+// The derivative estimates arrive as the float32 values the reference rounds them to.  Everything that can cancel or that
+// is raised to a power stays in float64 -- squares, the 1/sqrt factors and their powers, the curvature numerators, the
+// discriminant of max/min curvature and its root, the hillshade -- so those outputs stay (almost always) bit-identical to
+// the reference's float64 evaluation.  What runs in float32 are the two arcsine polynomials of slope and aspect with the
+// octant assembly (float64 arguments rounded once, result within ~2 ulp) and the TRI sums of window3_pixel_mixed, i.e. the
+// parts whose float64 form costs the most cycles for digits the float32 output cannot hold.  Gradients outside
+// [1e-13, 1e16] (exactly flat ground, the reference's 1e-15 cancellation residues, absurd slopes) take the float64 tail,
+// so this one needs no flat-ground selects.
+// XD_TAIL_LEVEL 2 (default) is the above; level 1 also moves the 1/sqrt factors and the curvature scale products to
+// float32 (cheaper, a few more ulp on the curvatures: kept for measurements).
+#ifndef XD_TAIL_LEVEL
+#define XD_TAIL_LEVEL 2
+#endif
+template <bool CURV, class SP, class SINK>
+XD_HD void surface_pixel_mixed(float zxf, float zyf, float zxxf, float zyyf, float zxyf, const TerrainParams& P, SINK& sk) {
+    const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
+    const bool deg = SP::DEG < 0 ? (P.degrees != 0) : (SP::DEG != 0);
+    const bool zf_not_1 = SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0);
+    const double zx = (double)zxf, zy = (double)zyf;
+#if XD_TAIL_LEVEL == 1
+    const float g2f = fmaf(zyf, zyf, zxf * zxf);
+    if (__builtin_expect((g2f < 1e-13f) | (g2f > 1e16f), 0)) {
+        surface_pixel<CURV, SP, SINK>(zx, zy, (double)zxxf, (double)zyyf, (double)zxyf, P, sk);
+        return;
+    }
+    const float rw = rsq32(1.0f + g2f);   // cos(slope)
+    const float rg = rsq32(g2f);          // 1 / |grad|
+    const float rgf = rg;
+    const bool steep = g2f > 1.0f;
+    const float xs = steep ? rw : (g2f * rg) * rw;
+#else
+    const double zx2 = zx * zx, zy2 = zy * zy;
+    const double g2 = zx2 + zy2;
+    const double opg = (1.0 + zx2) + zy2;
+#if defined(XD_NO_COLD)
+    if (false) {
+#else
+    if (__builtin_expect((g2 < 1e-13) | (g2 > 1e16), 0)) {
+#endif
+        surface_pixel<CURV, SP, SINK>(zx, zy, (double)zxxf, (double)zyyf, (double)zxyf, P, sk);
+        return;
+    }
+    const double rw = rsqrt_pos(opg);     // cos(slope)
+    const double rg = rsqrt_pos(g2);      // 1 / |grad|
+    const float rgf = (float)rg;
+    const bool steep = g2 > 1.0;
+    const float xs = (float)(steep ? rw : (g2 * rg) * rw);
+#endif
+    if (m & A_SLOPE) {
+        // slope = atan(g): asin(g*rw) below 45 deg, pi/2 - asin(rw) above (pi/2 in two float32 pieces)
+        float a = asin32(xs);
+        a = steep ? ((1.57079637f - a) + -4.37113883e-08f) : a;
+        if (deg) a = a * DegScale<float>::v();
+        sk.template put<P_SLOPE>(a);
+    }
+    if (m & A_ASPECT) {
+        // aspect = atan2(zx, zy) mod 2pi = n * pi/2 +- a0 with the octant's quarter-turn count n and a0 in [0, pi/4]
+        const float ax = fabsf(zxf), ay = fabsf(zyf);
+        const bool xbig = ax > ay, sx = zxf < 0.0f, sy = zyf < 0.0f;
+        const float a0 = asin32(fminf(ax, ay) * rgf);
+        const float nf = xbig ? (sx ? 3.0f : 1.0f) : (sy ? 2.0f : (sx ? 4.0f : 0.0f));
+        const float t = fmaf(nf, -4.37113883e-08f, (xbig != (sx != sy)) ? -a0 : a0);
+        float a = fmaf(nf, 1.57079637f, t);
+        if (deg) a = a * DegScale<float>::v();
+        sk.template put<P_ASPECT>(a);
+    }
+    if (m & A_HILLSHADE) {
+        // 1.5 + 254 cos(s') (sin(alt) + cos(alt) zf (zy sin(az') - zx cos(az'))): the sun term can cancel -> float64
+#if XD_TAIL_LEVEL == 1
+        float rwz = rw;
+        if (zf_not_1) rwz = rsq32(fmaf((float)P.hs_zf2, g2f, 1.0f));
+        float v = (float)fma_c((double)rwz, P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx), 1.5);
+#else
+        double rwz = rw;
+        if (zf_not_1) rwz = rsqrt_pos(fma(P.hs_zf2, g2, 1.0));
+        float v = (float)fma_c(rwz, P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx), 1.5);
+#endif
+        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        sk.template put<P_HILLSHADE>(v);
+    }
+    if (!CURV) return;
+    const double zxx = (double)zxxf, zyy = (double)zyyf, zxy = (double)zxyf;
+    if (m & A_CURVATURE) sk.template put<P_CURVATURE>((float)(-2.0 * (zxx + zyy) * 100.0));
+    if (m & (A_ANY_CURV & ~A_CURVATURE)) {
+        const bool dir = SP::DIR < 0 ? (P.curv_directional != 0) : (SP::DIR != 0);
+#if XD_TAIL_LEVEL == 1
+        const double zx2 = zx * zx, zy2 = zy * zy;
+        typedef float scale_t;
+#else
+        typedef double scale_t;
+#endif
+        const double zxzy = zx * zy;
+        const double cross = 2.0 * zxy * zxzy;
+        const double n_prof = fma(zyy, zy2, fma(zxx, zx2, cross));     // zxx zx^2 + 2 zxy zx zy + zyy zy^2
+        const double n_tan = fma(zyy, zx2, fma(zxx, zy2, -cross));      // zxx zy^2 - 2 zxy zx zy + zyy zx^2
+        const scale_t rg2c = (rg * rg) * (scale_t)100;                  // 100 / g2
+        const scale_t rg3c = rg2c * rg;                                 // 100 / g2^1.5
+        const scale_t rw3 = (rw * rw) * rw;                             // 1 / (1 + g2)^1.5
+        if (m & A_PROFILE) sk.template put<P_PROFILE>((float)(-((scale_t)n_prof * (dir ? rg2c : rg2c * rw3))));
+        if (m & A_TANGENTIAL) sk.template put<P_TANGENTIAL>((float)(-((scale_t)n_tan * (dir ? rg2c : rg2c * rw))));
+        if (m & A_PLANFORM) sk.template put<P_PLANFORM>((float)(-((scale_t)n_tan * rg3c)));
+        if (m & A_FLOWLINE) {
+            const double n_flow = fma(zxzy, zxx - zyy, -zxy * (zx2 - zy2));
+            sk.template put<P_FLOWLINE>((float)((scale_t)n_flow * (dir ? rg3c : rg3c * rw)));
+        }
+        if (m & (A_MAXC | A_MINC)) {
+            if (dir) {
+                const double half_tr = 50.0 * (zxx + zyy);
+                const double hd = 50.0 * (zxx - zyy), sxy = 100.0 * zxy;
+                const double rad = sqrt_nr_signed(fma(hd, hd, sxy * sxy));
+                if (m & A_MAXC) sk.template put<P_MAXC>((float)(rad - half_tr));
+                if (m & A_MINC) sk.template put<P_MINC>((float)(-half_tr - rad));
+            } else {
+                // mean = -h / w^3, gauss = K / w^4 (w^2 = 1 + g2, h = half the mean-curvature numerator): the
+                // discriminant mean^2 - gauss = (h^2 - K w^2) / w^6 and the sums -h +- root stay in float64
+                const double h = 0.5 * ((zxx + zyy) + n_tan);
+#if XD_TAIL_LEVEL == 1
+                const double opg = (1.0 + zx2) + zy2;
+#endif
+                const double disc = fma(h, h, -(fma(zxx, zyy, -zxy * zxy) * opg));
+                const double root = sqrt_nr_signed(disc);   // negative radicand -> NaN like the reference's ** 0.5
+                const scale_t rw3c = rw3 * (scale_t)100;
+                if (m & A_MAXC) sk.template put<P_MAXC>((float)((scale_t)(root - h) * rw3c));
+                if (m & A_MINC) sk.template put<P_MINC>((float)((scale_t)(-h - root) * rw3c));
+            }
         }
     }
 }
 
 // TPI / TRI of a 3x3 window given as raw values (row-major n0..n8, n4 = centre).  Plain IEEE propagation.
-template <class SP, typename TOUT>
-XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams& P, const Planes<TOUT>& out, uint32_t o) {
+template <class SP, class SINK>
+XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams& P, SINK& sk) {
+    typedef typename SINK::out_t TOUT;
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
     const bool wilson = SP::WILSON < 0 ? (P.tri_wilson != 0) : (SP::WILSON != 0);
     const double c = n[4];
-    if (m & A_TPI) put(out.p[P_TPI], o, (TOUT)((TOUT)fma_ks(sum9 - c, -0.125, c)));  // c - (sum9 - c) / 8, exact scaling
+    if (m & A_TPI) sk.template put<P_TPI>((TOUT)((TOUT)fma_ks(sum9 - c, -0.125, c)));  // c - (sum9 - c) / 8, exact scaling
     if (m & A_ROUGH) {
         // Dartnell roughness: max - min of the window, NaN if any NaN (window.py:261-289); +-Inf propagate like NumPy
         double mx = n[0], mn = n[0];
@@ -299,7 +540,7 @@ XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams&
         }
         const bool has_nan = (n[0] != n[0]) | (n[1] != n[1]) | (n[2] != n[2]) | (n[3] != n[3]) | (n[4] != n[4]) |
                              (n[5] != n[5]) | (n[6] != n[6]) | (n[7] != n[7]) | (n[8] != n[8]);
-        put(out.p[P_ROUGH], o, has_nan ? (TOUT)NAN : (TOUT)(mx - mn));
+        sk.template put<P_ROUGH>(has_nan ? (TOUT)NAN : (TOUT)(mx - mn));
     }
     if (m & A_TRI) {
         double acc = c - c;  // the centre's own term: 0, or NaN when the centre is +-Inf (IEEE, like the reference)
@@ -307,7 +548,7 @@ XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams&
 #pragma unroll
             for (int k = 0; k < 9; ++k)
                 if (k != 4) acc += fabs(n[k] - c);
-            put(out.p[P_TRI], o, (TOUT)((TOUT)(acc * 0.125)));
+            sk.template put<P_TRI>((TOUT)((TOUT)(acc * 0.125)));
         } else {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
@@ -315,12 +556,91 @@ XD_HD void window3_pixel(const double (&n)[9], double sum9, const TerrainParams&
                     const double d = n[k] - c;
                     acc = fma(d, d, acc);
                 }
-            put(out.p[P_TRI], o, (TOUT)((TOUT)sqrt_nr(acc)));
+            sk.template put<P_TRI>((TOUT)((TOUT)sqrt_nr(acc)));
         }
     }
 }
 
-template <typename TIN> XD_HD double round_in(double v) { return (double)(TIN)v; }
+// Same for the mixed-precision tail: the window arrives as the raw float32 pixels.  Roughness (a float32 subtraction IS the
+// reference's float64 difference rounded once) is bit-exact, TPI keeps its exact float64 sum (c - mean cancels), the TRI
+// sums -- positive terms only, nothing cancels -- run in float32 (a few float32 roundings).
+template <class SP, class SINK>
+XD_HD void window3_pixel_mixed(const float (&n)[9], double sum9, const TerrainParams& P, SINK& sk) {
+    const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
+    const bool wilson = SP::WILSON < 0 ? (P.tri_wilson != 0) : (SP::WILSON != 0);
+    const float c = n[4];
+    if (m & A_TPI) {
+        const double cd = (double)c;
+        sk.template put<P_TPI>((float)fma_ks(sum9 - cd, -0.125, cd));
+    }
+    if (m & A_ROUGH) {
+        float mx = n[0], mn = n[0];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            mx = (n[k] > mx) ? n[k] : mx;
+            mn = (n[k] < mn) ? n[k] : mn;
+        }
+        const bool has_nan = (n[0] != n[0]) | (n[1] != n[1]) | (n[2] != n[2]) | (n[3] != n[3]) | (n[4] != n[4]) |
+                             (n[5] != n[5]) | (n[6] != n[6]) | (n[7] != n[7]) | (n[8] != n[8]);
+        sk.template put<P_ROUGH>(has_nan ? (float)NAN : (mx - mn));
+    }
+    if (m & A_TRI) {
+        float acc = c - c;  // 0, or NaN when the centre is +-Inf (IEEE, like the reference)
+        if (wilson) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k != 4) acc += fabsf(n[k] - c);
+            sk.template put<P_TRI>(acc * 0.125f);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k != 4) {
+                    const float d = n[k] - c;
+                    acc = fmaf(d, d, acc);
+                }
+            sk.template put<P_TRI>(sqrt32_hw(acc));
+        }
+    }
+}
+
+// The reference's own accumulation for one derivative estimate: scipy.ndimage.convolve adds w * value in double over the
+// non-zero weights in row-major order (xdem/spatialstats.py:2521-2525), the weights being table / divider in double, and
+// rounds the sum to the input dtype.  The marcher below sums with INTEGER weights (exact for float32 pixels) and scales
+// once; the two differ only where the terms cancel exactly -- flat or planar ground, where the reference returns its
+// rounding residue (|zx| ~ 1e-15, hence an "aspect" of 198.43 deg on a flat Florinsky window) instead of 0.  Such pixels
+// (an exact 0 from the fast sum) are recomputed here so that they carry the reference's value.  `win` = top-left pixel of
+// the M x M window in the LDS tile.  No fused multiply-add: SciPy's loop does not contract.
+template <int M, typename TIN>
+XD_HD TIN ref_order_sum(const TIN* win, int pitch, const double* w) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    double acc = 0.0;
+    // (deliberately not unrolled: a cold path, kept small so that the hot loop stays resident in the instruction cache)
+#if defined(__clang__)
+#pragma clang loop unroll(disable)
+#endif
+    for (int a = 0; a < M; ++a) {
+#if defined(__clang__)
+#pragma clang loop unroll(disable)
+#endif
+        for (int b = 0; b < M; ++b) {
+            const double wk = w[a * M + b];
+            if (wk != 0.0) {
+                const double t = wk * (double)win[a * pitch + b];
+                acc = acc + t;
+            }
+        }
+    }
+    return (TIN)acc;
+}
+
+template <typename T> XD_HD bool any_zero5(T a, T b, T c, T d, T e) {
+    return fmin(fmin(fabs((double)a), fabs((double)b)), fmin(fabs((double)c), fmin(fabs((double)d), fabs((double)e)))) == 0.0;
+}
+template <> XD_HD bool any_zero5<float>(float a, float b, float c, float d, float e) {
+    return fminf(fminf(fabsf(a), fabsf(b)), fminf(fabsf(c), fminf(fabsf(d), fabsf(e)))) == 0.0f;
+}
 
 // ---- the column marcher -------------------------------------------------------------------------------
 // `col` points at the tile element of this thread's column in the first tile row; tile row t holds raster
@@ -329,12 +649,38 @@ template <typename TIN> XD_HD double round_in(double v) { return (double)(TIN)v;
 // (wave-uniform, so stores use the scalar-base + 32-bit VGPR offset addressing form) and the BYTE offset of
 // output row i is o0 + i * ostride (32-bit: a tile spans far less than 4 GiB per plane).
 template <int FIT> struct Halo { static constexpr int v = (FIT == 2) ? 2 : 1; };
+template <typename A, typename B> struct SameT { static constexpr bool v = false; };
+template <typename A> struct SameT<A, A> { static constexpr bool v = true; };
 
-template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT>
-XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParams& P, const Planes<TOUT>& out,
-                        uint32_t o0, uint32_t ostride) {
+template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct SurfaceTail {
+    static XD_HD void go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk) {
+        surface_pixel<CURV, SP, SINK>((double)zx, (double)zy, (double)zxx, (double)zyy, (double)zxy, P, sk);
+    }
+};
+template <bool CURV, class SP, class SINK> struct SurfaceTail<true, CURV, SP, float, SINK> {
+    static XD_HD void go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
+        surface_pixel_mixed<CURV, SP, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
+    }
+};
+template <bool MIXED, class SP, typename TIN, class SINK> struct WindowTail {
+    static XD_HD void go(const TIN (&n)[9], double sum9, const TerrainParams& P, SINK& sk) {
+        const double nd[9] = {(double)n[0], (double)n[1], (double)n[2], (double)n[3], (double)n[4],
+                              (double)n[5], (double)n[6], (double)n[7], (double)n[8]};
+        window3_pixel<SP, SINK>(nd, sum9, P, sk);
+    }
+};
+template <class SP, class SINK> struct WindowTail<true, SP, float, SINK> {
+    static XD_HD void go(const float (&n)[9], double sum9, const TerrainParams& P, SINK& sk) {
+        window3_pixel_mixed<SP, SINK>(n, sum9, P, sk);
+    }
+};
+
+template <int FIT, bool CURV, bool WIN, class SP, typename TIN, class SINK>
+XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParams& P, SINK& sk) {
+    typedef typename SINK::out_t TOUT;
     constexpr int HALO = Halo<FIT>::v;
     constexpr int NS = 2 * HALO + 1;  // rotating window slots
+    constexpr bool MIXED = SameT<TIN, float>::v && SameT<TOUT, float>::v && (SP::F64TAIL == 0);
     const int nrows = n_out + 2 * HALO;
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
 
@@ -342,9 +688,9 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
     double A[NS], B[NS], R[NS], Wr[NS], Ua[NS], Ub[NS], D2[NS];  // D2 = A + 2 B (mixed derivative rows)
     // per-row partials -- 3x3 fits
     double Dr[NS], S[NS], Zc[NS];
-    // 3-wide row sums and the float64 copies of the three centre columns for TPI / TRI (and the 3x3 detector)
+    // 3-wide row sums and the raw pixels of the three centre columns for TPI / TRI (and the 3x3 detector)
     double R3[NS];
-    double Nl[NS], Nc[NS], Nr[NS];
+    TIN Nl[NS], Nc[NS], Nr[NS];
 
     for (int r0 = 0; r0 < nrows; r0 += NS) {
 #pragma unroll
@@ -371,62 +717,74 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
                     Zc[k] = zc;
                     R3[k] = (zl + zr) + zc;
                 }
-                if (WIN) { Nl[k] = zl; Nc[k] = zc; Nr[k] = zr; }
+                if (WIN) { Nl[k] = tl; Nc[k] = tc; Nr[k] = tr; }
 
                 const int i = r - 2 * HALO;  // output row whose window is now complete
                 if (i >= 0) {
-                    uint32_t o = o0 + (uint32_t)i * ostride;  // byte offset
-#if defined(__HIP_DEVICE_COMPILE__)
-                    // keep `o` an opaque 32-bit VGPR: stops loop-strength-reduction from turning every plane
-                    // into its own 64-bit running pointer (11 VGPR pairs + one 64-bit add per store)
-                    asm volatile("" : "+v"(o));
-#endif
+                    sk.begin_row(i);
                     // slot of window row (centre + d): the newest row (slot k) is centre + HALO
 #define XD_SLOT(d) ((k + NS - HALO + (d)) % NS)
-                    double zx, zy, zxx = 0.0, zyy = 0.0, zxy = 0.0;
+                    TIN zx, zy, zxx = (TIN)0, zyy = (TIN)0, zxy = (TIN)0;   // rounded to the input dtype like the reference
+                    double det;  // an all-window sum: non-finite <=> some pixel non-finite or outside the raster
                     if (FIT == 2) {
                         const int m2 = XD_SLOT(-2), m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1), p2 = XD_SLOT(2);
                         const double sx = fma(17.0, B[c0], fma(68.0, A[c0],
                                           fma(5.0, B[m1] + B[p1], fma(62.0, A[m1] + A[p1],
                                           fma(-31.0, B[m2] + B[p2], 44.0 * (A[m2] + A[p2]))))));
-                        zx = round_in<TIN>(-sx * P.s1);
-                        zy = round_in<TIN>(((Ua[p1] - Ua[m1]) + (Ub[p2] - Ub[m2])) * P.s1);
-                        double det;  // an all-25-pixel sum: non-finite <=> some pixel non-finite or outside the raster
+                        zx = (TIN)(-sx * P.s1);
+                        zy = (TIN)(((Ua[p1] - Ua[m1]) + (Ub[p2] - Ub[m2])) * P.s1);
                         if (CURV) {
                             det = ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2];
-                            zxx = round_in<TIN>(det * P.sxx);
-                            zyy = round_in<TIN>(fma(2.0, (R[m2] + R[p2]) - R[c0], -(R[m1] + R[p1])) * P.sxx);
-                            zxy = round_in<TIN>(fma(2.0, D2[m2] - D2[p2], D2[m1] - D2[p1]) * P.sxy);
+                            zxx = (TIN)(det * P.sxx);
+                            zyy = (TIN)(fma(2.0, (R[m2] + R[p2]) - R[c0], -(R[m1] + R[p1])) * P.sxx);
+                            zxy = (TIN)(fma(2.0, D2[m2] - D2[p2], D2[m1] - D2[p1]) * P.sxy);
                         } else {
                             det = ((R[m2] + R[m1]) + (R[c0] + R[p1])) + R[p2];
                         }
-                        const double poison = det - det;  // 0, or NaN for an invalid window
-                        zx += poison;
-                        if (CURV) zxx += poison;
                     } else {
                         const int m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1);
-                        const double det = (R3[m1] + R3[c0]) + R3[p1];
-                        const double poison = det - det;
+                        det = (R3[m1] + R3[c0]) + R3[p1];
                         if (FIT == 0) {  // Horn: [1 2 1] smoothing across the derivative direction
-                            zx = round_in<TIN>(-(fma(2.0, Dr[c0], Dr[m1] + Dr[p1])) * P.s1);
-                            zy = round_in<TIN>((fma(2.0, Zc[p1] - Zc[m1], S[p1] - S[m1])) * P.s1);
+                            zx = (TIN)(-(fma(2.0, Dr[c0], Dr[m1] + Dr[p1])) * P.s1);
+                            zy = (TIN)((fma(2.0, Zc[p1] - Zc[m1], S[p1] - S[m1])) * P.s1);
                         } else {         // Zevenbergen-Thorne: central differences
-                            zx = round_in<TIN>(-Dr[c0] * P.s1);
-                            zy = round_in<TIN>((Zc[p1] - Zc[m1]) * P.s1);
+                            zx = (TIN)(-Dr[c0] * P.s1);
+                            zy = (TIN)((Zc[p1] - Zc[m1]) * P.s1);
                             if (CURV) {
-                                zxx = round_in<TIN>(fma(-2.0, Zc[c0], S[c0]) * P.sxx) + poison;
-                                zyy = round_in<TIN>(fma(-2.0, Zc[c0], Zc[m1] + Zc[p1]) * P.sxx);
-                                zxy = round_in<TIN>((Dr[m1] - Dr[p1]) * P.sxy);
+                                zxx = (TIN)(fma(-2.0, Zc[c0], S[c0]) * P.sxx);
+                                zyy = (TIN)(fma(-2.0, Zc[c0], Zc[m1] + Zc[p1]) * P.sxx);
+                                zxy = (TIN)((Dr[m1] - Dr[p1]) * P.sxy);
                             }
                         }
-                        zx += poison;
                     }
-                    if (m & ~A_ANY_WIN) surface_pixel<CURV, SP, TOUT>(zx, zy, zxx, zyy, zxy, P, out, o);
+                    if (m & ~A_ANY_WIN) {
+                        // exact cancellation (flat / planar ground): hand the pixel the reference's own residue
+                        const bool z5 = CURV ? any_zero5<TIN>(zx, zy, zxx, zyy, zxy) : ((zx == (TIN)0) | (zy == (TIN)0));
+#if defined(XD_NO_COLD)  // (instruction-count analysis builds only: tools/isa_stats.py)
+                        if (false) {
+#else
+                        if (__builtin_expect(z5, 0)) {
+#endif
+                            const TIN* win = col + (int64_t)i * pitch - HALO;
+                            if (zx == (TIN)0) zx = ref_order_sum<NS, TIN>(win, pitch, P.wref[0]);
+                            if (zy == (TIN)0) zy = ref_order_sum<NS, TIN>(win, pitch, P.wref[1]);
+                            if (CURV) {
+                                if (zxx == (TIN)0) zxx = ref_order_sum<NS, TIN>(win, pitch, P.wref[2]);
+                                if (zyy == (TIN)0) zyy = ref_order_sum<NS, TIN>(win, pitch, P.wref[3]);
+                                if (zxy == (TIN)0) zxy = ref_order_sum<NS, TIN>(win, pitch, P.wref[4]);
+                            }
+                        }
+                        const TIN poison = (TIN)(det - det);  // 0, or NaN for an invalid window
+                        zx += poison;
+                        if (CURV) zxx += poison;
+                        SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk);
+                    }
                     if (WIN) {
                         const int w1 = XD_SLOT(-1), w0 = XD_SLOT(0), w2 = XD_SLOT(1);
-                        const double n[9] = {Nl[w1], Nc[w1], Nr[w1], Nl[w0], Nc[w0], Nr[w0], Nl[w2], Nc[w2], Nr[w2]};
-                        window3_pixel<SP, TOUT>(n, (R3[w1] + R3[w0]) + R3[w2], P, out, o);
+                        const TIN n[9] = {Nl[w1], Nc[w1], Nr[w1], Nl[w0], Nc[w0], Nr[w0], Nl[w2], Nc[w2], Nr[w2]};
+                        WindowTail<MIXED, SP, TIN, SINK>::go(n, (R3[w1] + R3[w0]) + R3[w2], P, sk);
                     }
+                    sk.end_row(i);
 #undef XD_SLOT
                 }
             }
