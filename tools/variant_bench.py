@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default="", help="comma-separated substrings: run only the variants whose name contains one")
     a = ap.parse_args()
     import torch
 
@@ -32,7 +33,7 @@ def main():
     out = torch.empty((11, n, n), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     csrc = os.path.join(ROOT, "xdem_amd", "csrc")
-    libs = {"L2": "libxdemhip_exp2.so", "L1": "libxdemhip_exp1.so"}
+    libs = {"R01": "libxdemhip_r01.so", "MIX": "libxdemhip_exp2.so", "NOSTORE": "libxdemhip_expnostore.so", "RAWRSQ": "libxdemhip_exprawrsq.so"}
     variants = []
     for tag, fn in libs.items():
         path = os.path.join(csrc, fn)
@@ -51,17 +52,25 @@ def main():
             ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
             ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
             ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
-        maths = [0, 1] if tag == "L2" else [0]
-        for math, store, rows in itertools.product(maths, [0, 1], [16, 24, 32]):
-            variants.append((f"{tag if math == 0 else 'F64'}/store{store}/rows{rows}", L, ctx, math, store, rows))
+        if tag == "R01":  # the round-1 library: in-session baseline (boxes of the pool clock differently)
+            if not a.only or any(o in "R01" for o in a.only.split(",")):
+                variants.append(("R01", L, ctx, None, None, None))
+            continue
+        combos = itertools.product([0, 1], [0, 1], [16, 24, 32]) if tag == "MIX" else [(0, 0, 32), (0, 0, 16)]
+        for math, store, rows in combos:
+            name = f"{tag if math == 0 else tag + '-F64'}/store{store}/rows{rows}"
+            if a.only and not any(o in name for o in a.only.split(",")):
+                continue
+            variants.append((name, L, ctx, math, store, rows))
     planes = (ctypes.c_void_p * 11)(*[out[i].data_ptr() for i in range(11)])
     mask = 0xFFF & ~(1 << 3)
     times = {v[0]: [] for v in variants}
 
     def run(L, ctx, math, store, rows):
-        L.xdemhip_set_option(ctx, b"terrain_math", math)
-        L.xdemhip_set_option(ctx, b"terrain_store", store)
-        L.xdemhip_set_option(ctx, b"terrain_rows", rows)
+        if math is not None:
+            L.xdemhip_set_option(ctx, b"terrain_math", math)
+            L.xdemhip_set_option(ctx, b"terrain_store", store)
+            L.xdemhip_set_option(ctx, b"terrain_rows", rows)
         rc = L.xdemhip_terrain(ctx, dem.data_ptr(), 0, n, n, n, 0, 0, 10.0, 2, 0, mask, 0, 3, 45.0, 315.0, 1.0, 1, 0, planes, 1)
         assert rc == 0, rc
         ms = ctypes.c_float()

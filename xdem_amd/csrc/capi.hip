@@ -94,7 +94,7 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         return XDEMHIP_OK;
     }
     if (std::string(name) == "terrain_store") {
-        if (value < -1 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_store: -1 automatic, 0 direct, 1 staged row stores");
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_store: 0 direct, 1 staged row stores");
         ctx->terrain_store = value;
         return XDEMHIP_OK;
     }

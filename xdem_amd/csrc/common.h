@@ -21,7 +21,7 @@ struct xdemhip_ctx {
     xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)
     void* allreduce_user = nullptr;
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
-    int terrain_store = -1;  // option "terrain_store": -1 automatic (staged 1 KiB row stores where possible), 0 direct, 1 staged
+    int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)
     int terrain_rows = 0;    // option "terrain_rows": tile height of the fused terrain kernel (0 automatic, 16, 24, 32)
     int terrain_math = 0;    // option "terrain_math": 0 mixed-precision tail for float32 rasters, 1 float64 tail everywhere
     int selection_mode = 0;  // 0 auto (bracketed for large inputs), 1 plain digit passes only, 2 degenerate brackets (tests the

@@ -244,18 +244,41 @@ XD_HD float sqrt32_hw(float x) {
     return sqrtf(x);
 #endif
 }
-// asin(x) for 0 <= x <= 0.7075 as x + x*s*Q(s), s = x^2: degree-7 Q fitted for the relative error of asin
-// (tools/fit_poly.py: 3.0e-9 with these float32 coefficients); the final fma keeps the evaluation error at one rounding.
+XD_HD uint32_t f32_bits(float x) { uint32_t b; __builtin_memcpy(&b, &x, 4); return b; }
+XD_HD float bits_f32(uint32_t b) { float x; __builtin_memcpy(&x, &b, 4); return x; }
+// c ? a : b on float32 values, decided by x > y in float64.  (Written out for the device: hipcc's VOP2 form of
+// v_cndmask_b32 -- the one that reads VCC -- issues at ~20 cycles on gfx950 (tools/ubench.hip), the VOP3 form with the
+// mask in a scalar register pair at 4.)
+XD_HD float select_gt(double x, double y, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    uint64_t mk;
+    asm("v_cmp_gt_f64_e64 %1, %2, %3\n\tv_cndmask_b32_e64 %0, %5, %4, %1" : "=v"(r), "=&s"(mk) : "v"(x), "v"(y), "v"(a), "v"(b));
+    return r;
+#else
+    return (x > y) ? a : b;
+#endif
+}
+// clamp to [lo, hi] that keeps NaN (v_med3_f32 alone would return the smaller bound for a NaN input)
+XD_HD float clamp_keep_nan(float v, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(v, lo, hi) + (v - v);
+#else
+    return (v < lo ? lo : (v > hi ? hi : v)) + (v - v);
+#endif
+}
+// asin(x) for 0 <= x <= 0.7075 as x + x*s*Q(s), s = x^2: degree-6 Q fitted for the relative error of asin
+// (tools/fit_poly.py: 1.7e-8 with these float32 coefficients, a quarter of a float32 rounding); the final fma keeps the
+// evaluation error at one rounding.
 XD_HD float asin32(float x) {
     const float s = x * x;
-    float p = 1.265096068e-01f;
-    p = fmaf(p, s, -1.407062411e-01f);
-    p = fmaf(p, s, 1.108867303e-01f);
-    p = fmaf(p, s, -8.274481632e-03f);
-    p = fmaf(p, s, 3.603736311e-02f);
-    p = fmaf(p, s, 4.407655075e-02f);
-    p = fmaf(p, s, 7.502710819e-02f);
-    p = fmaf(p, s, 1.666662246e-01f);
+    float p = 1.115436330e-01f;
+    p = fmaf(p, s, -9.298548102e-02f);
+    p = fmaf(p, s, 7.720199972e-02f);
+    p = fmaf(p, s, 1.631883346e-02f);
+    p = fmaf(p, s, 4.651309177e-02f);
+    p = fmaf(p, s, 7.488407940e-02f);
+    p = fmaf(p, s, 1.666690707e-01f);
     return fmaf(x * s, p, x);
 }
 
@@ -280,7 +303,12 @@ template <typename TOUT> struct DirectSink {
         asm volatile("" : "+v"(o));
 #endif
     }
-    template <int K> XD_HD void put(TOUT v) { *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o) = v; }
+    template <int K> XD_HD void put(TOUT v) {
+#if defined(XD_NOSTORE)  // (measurement builds: all the math, no output traffic)
+        if (v != (TOUT)12345.678)  return;
+#endif
+        *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o) = v;
+    }
     XD_HD void end_row(int) {}
 };
 
@@ -398,126 +426,101 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
 // discriminant of max/min curvature and its root, the hillshade -- so those outputs stay (almost always) bit-identical to
 // the reference's float64 evaluation.  What runs in float32 are the two arcsine polynomials of slope and aspect with the
 // octant assembly (float64 arguments rounded once, result within ~2 ulp) and the TRI sums of window3_pixel_mixed, i.e. the
-// parts whose float64 form costs the most cycles for digits the float32 output cannot hold.  Gradients outside
-// [1e-13, 1e16] (exactly flat ground, the reference's 1e-15 cancellation residues, absurd slopes) take the float64 tail,
-// so this one needs no flat-ground selects.
-// XD_TAIL_LEVEL 2 (default) is the above; level 1 also moves the 1/sqrt factors and the curvature scale products to
-// float32 (cheaper, a few more ulp on the curvatures: kept for measurements).
-#ifndef XD_TAIL_LEVEL
-#define XD_TAIL_LEVEL 2
-#endif
-template <bool CURV, class SP, class SINK>
+// parts whose float64 form costs the most cycles for digits the float32 output cannot hold.
+// FULLRANGE = false is the hot path: valid for squared gradients in [1e-13, 1e16] (no flat-ground selects, nothing can
+// under- or overflow).  FULLRANGE = true adds the reference's flat-ground rules (surfit.py:749-805, 825-937) and is what
+// march_column's cold path runs for the pixels outside that range (exactly flat ground, the reference's 1e-15
+// cancellation residues, absurd slopes: mixed_tail_out_of_range); it uses the very same constants as the hot path, so
+// hoisting them out of the row loop costs no extra scalar registers.
+template <bool CURV, class SP, bool FULLRANGE, class SINK>
 XD_HD void surface_pixel_mixed(float zxf, float zyf, float zxxf, float zyyf, float zxyf, const TerrainParams& P, SINK& sk) {
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
     const bool deg = SP::DEG < 0 ? (P.degrees != 0) : (SP::DEG != 0);
     const bool zf_not_1 = SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0);
     const double zx = (double)zxf, zy = (double)zyf;
-#if XD_TAIL_LEVEL == 1
-    const float g2f = fmaf(zyf, zyf, zxf * zxf);
-    if (__builtin_expect((g2f < 1e-13f) | (g2f > 1e16f), 0)) {
-        surface_pixel<CURV, SP, SINK>(zx, zy, (double)zxxf, (double)zyyf, (double)zxyf, P, sk);
-        return;
-    }
-    const float rw = rsq32(1.0f + g2f);   // cos(slope)
-    const float rg = rsq32(g2f);          // 1 / |grad|
-    const float rgf = rg;
-    const bool steep = g2f > 1.0f;
-    const float xs = steep ? rw : (g2f * rg) * rw;
-#else
     const double zx2 = zx * zx, zy2 = zy * zy;
     const double g2 = zx2 + zy2;
-    const double opg = (1.0 + zx2) + zy2;
-#if defined(XD_NO_COLD)
-    if (false) {
+    const double opg = 1.0 + g2;
+    const bool flat = FULLRANGE && (g2 == 0.0);
+#if defined(XD_RAW_RSQ)  // (measurement builds: hardware seeds without the Newton step, ~2^-26)
+    const double rw = rsq_seed(opg);
+    const double rg = flat ? 0.0 : rsq_seed(g2);
 #else
-    if (__builtin_expect((g2 < 1e-13) | (g2 > 1e16), 0)) {
+    const double rw = rsqrt_pos(opg);                              // cos(slope)
+    const double rg = flat ? 0.0 : rsqrt_pos(g2);                  // 1 / |grad|  (0 on flat ground: kills every x/g term)
 #endif
-        surface_pixel<CURV, SP, SINK>(zx, zy, (double)zxxf, (double)zyyf, (double)zxyf, P, sk);
-        return;
-    }
-    const double rw = rsqrt_pos(opg);     // cos(slope)
-    const double rg = rsqrt_pos(g2);      // 1 / |grad|
     const float rgf = (float)rg;
-    const bool steep = g2 > 1.0;
-    const float xs = (float)(steep ? rw : (g2 * rg) * rw);
-#endif
     if (m & A_SLOPE) {
-        // slope = atan(g): asin(g*rw) below 45 deg, pi/2 - asin(rw) above (pi/2 in two float32 pieces)
-        float a = asin32(xs);
-        a = steep ? ((1.57079637f - a) + -4.37113883e-08f) : a;
+        // slope = atan(g) = asin(g*rw) below 45 deg, pi/2 - asin(rw) above: the argument is min(sin, cos) of the slope
+        const float a0 = asin32((float)fmin((g2 * rg) * rw, rw));
+        float a = select_gt(g2, 1.0, (1.57079637f - a0) + -4.37113883e-08f, a0);   // pi/2 in two float32 pieces
         if (deg) a = a * DegScale<float>::v();
         sk.template put<P_SLOPE>(a);
     }
     if (m & A_ASPECT) {
-        // aspect = atan2(zx, zy) mod 2pi = n * pi/2 +- a0 with the octant's quarter-turn count n and a0 in [0, pi/4]
+        // aspect = atan2(zx, zy) mod 2pi = n * pi/2 +- a0 with the octant's quarter-turn count n and a0 in [0, pi/4]:
+        // octants in order (sx, sy, xbig) = 000 001 011 010 110 111 101 100 -> n = 0 1 1 2 2 3 3 4, a0 subtracted in the odd
+        // ones.  Sign bits and integer ops instead of compares + selects (x + 0 turns -0 into +0: "< 0" semantics).
         const float ax = fabsf(zxf), ay = fabsf(zyf);
-        const bool xbig = ax > ay, sx = zxf < 0.0f, sy = zyf < 0.0f;
         const float a0 = asin32(fminf(ax, ay) * rgf);
-        const float nf = xbig ? (sx ? 3.0f : 1.0f) : (sy ? 2.0f : (sx ? 4.0f : 0.0f));
-        const float t = fmaf(nf, -4.37113883e-08f, (xbig != (sx != sy)) ? -a0 : a0);
+        const uint32_t sx = f32_bits(zxf + 0.0f) >> 31, sy = f32_bits(zyf + 0.0f) >> 31;
+        const uint32_t xb = f32_bits(ay - ax) >> 31;   // |zx| > |zy|
+        const uint32_t q = sx ^ sy;
+        const uint32_t odd = q ^ xb;                    // octant index parity (Gray code -> binary, lowest bit)
+        const uint32_t oct = 4u * sx + 2u * q + odd;
+        const float nf = (float)(int)((oct + 1u) >> 1);
+        const float a0s = bits_f32(f32_bits(a0) ^ (odd << 31));
+        const float t = fmaf(nf, -4.37113883e-08f, a0s);
         float a = fmaf(nf, 1.57079637f, t);
         if (deg) a = a * DegScale<float>::v();
         sk.template put<P_ASPECT>(a);
     }
     if (m & A_HILLSHADE) {
         // 1.5 + 254 cos(s') (sin(alt) + cos(alt) zf (zy sin(az') - zx cos(az'))): the sun term can cancel -> float64
-#if XD_TAIL_LEVEL == 1
-        float rwz = rw;
-        if (zf_not_1) rwz = rsq32(fmaf((float)P.hs_zf2, g2f, 1.0f));
-        float v = (float)fma_c((double)rwz, P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx), 1.5);
-#else
         double rwz = rw;
         if (zf_not_1) rwz = rsqrt_pos(fma(P.hs_zf2, g2, 1.0));
-        float v = (float)fma_c(rwz, P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx), 1.5);
-#endif
-        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-        sk.template put<P_HILLSHADE>(v);
+        const float v = (float)fma_c(rwz, fma(P.hs_ky, zy, fma(P.hs_kx, zx, P.hs_sin_alt)), 1.5);
+        sk.template put<P_HILLSHADE>(clamp_keep_nan(v, 0.0f, 255.0f));
     }
     if (!CURV) return;
     const double zxx = (double)zxxf, zyy = (double)zyyf, zxy = (double)zxyf;
     if (m & A_CURVATURE) sk.template put<P_CURVATURE>((float)(-2.0 * (zxx + zyy) * 100.0));
     if (m & (A_ANY_CURV & ~A_CURVATURE)) {
         const bool dir = SP::DIR < 0 ? (P.curv_directional != 0) : (SP::DIR != 0);
-#if XD_TAIL_LEVEL == 1
-        const double zx2 = zx * zx, zy2 = zy * zy;
-        typedef float scale_t;
-#else
-        typedef double scale_t;
-#endif
         const double zxzy = zx * zy;
         const double cross = 2.0 * zxy * zxzy;
         const double n_prof = fma(zyy, zy2, fma(zxx, zx2, cross));     // zxx zx^2 + 2 zxy zx zy + zyy zy^2
         const double n_tan = fma(zyy, zx2, fma(zxx, zy2, -cross));      // zxx zy^2 - 2 zxy zx zy + zyy zx^2
-        const scale_t rg2c = (rg * rg) * (scale_t)100;                  // 100 / g2
-        const scale_t rg3c = rg2c * rg;                                 // 100 / g2^1.5
-        const scale_t rw3 = (rw * rw) * rw;                             // 1 / (1 + g2)^1.5
-        if (m & A_PROFILE) sk.template put<P_PROFILE>((float)(-((scale_t)n_prof * (dir ? rg2c : rg2c * rw3))));
-        if (m & A_TANGENTIAL) sk.template put<P_TANGENTIAL>((float)(-((scale_t)n_tan * (dir ? rg2c : rg2c * rw))));
-        if (m & A_PLANFORM) sk.template put<P_PLANFORM>((float)(-((scale_t)n_tan * rg3c)));
+        const double rg2c = (rg * rg) * 100.0;                          // 100 / g2
+        const double rg_t = (FULLRANGE && g2 < 10e-15) ? 0.0 : rg;      // planform / flowline: zero below 1e-14 (surfit.py:749-805)
+        const double rw3 = (rw * rw) * rw;                              // 1 / (1 + g2)^1.5
+        if (m & A_PROFILE) sk.template put<P_PROFILE>((float)(-(n_prof * (dir ? rg2c : rg2c * rw3))));
+        if (m & A_TANGENTIAL) sk.template put<P_TANGENTIAL>((float)(-(n_tan * (dir ? rg2c : rg2c * rw))));
+        if (m & A_PLANFORM) sk.template put<P_PLANFORM>((float)(-(n_tan * (rg2c * rg_t))));
         if (m & A_FLOWLINE) {
             const double n_flow = fma(zxzy, zxx - zyy, -zxy * (zx2 - zy2));
-            sk.template put<P_FLOWLINE>((float)((scale_t)n_flow * (dir ? rg3c : rg3c * rw)));
+            sk.template put<P_FLOWLINE>((float)(n_flow * (dir ? (rg2c * rg) : (rg2c * rg_t) * rw)));
         }
         if (m & (A_MAXC | A_MINC)) {
+            double vmax, vmin;
             if (dir) {
                 const double half_tr = 50.0 * (zxx + zyy);
                 const double hd = 50.0 * (zxx - zyy), sxy = 100.0 * zxy;
                 const double rad = sqrt_nr_signed(fma(hd, hd, sxy * sxy));
-                if (m & A_MAXC) sk.template put<P_MAXC>((float)(rad - half_tr));
-                if (m & A_MINC) sk.template put<P_MINC>((float)(-half_tr - rad));
+                vmax = rad - half_tr;
+                vmin = -half_tr - rad;
             } else {
                 // mean = -h / w^3, gauss = K / w^4 (w^2 = 1 + g2, h = half the mean-curvature numerator): the
                 // discriminant mean^2 - gauss = (h^2 - K w^2) / w^6 and the sums -h +- root stay in float64
                 const double h = 0.5 * ((zxx + zyy) + n_tan);
-#if XD_TAIL_LEVEL == 1
-                const double opg = (1.0 + zx2) + zy2;
-#endif
                 const double disc = fma(h, h, -(fma(zxx, zyy, -zxy * zxy) * opg));
                 const double root = sqrt_nr_signed(disc);   // negative radicand -> NaN like the reference's ** 0.5
-                const scale_t rw3c = rw3 * (scale_t)100;
-                if (m & A_MAXC) sk.template put<P_MAXC>((float)((scale_t)(root - h) * rw3c));
-                if (m & A_MINC) sk.template put<P_MINC>((float)((scale_t)(-h - root) * rw3c));
+                const double rw3c = rw3 * 100.0;
+                vmax = (root - h) * rw3c;
+                vmin = (-h - root) * rw3c;
             }
+            if (m & A_MAXC) sk.template put<P_MAXC>((float)(flat ? 0.0 : vmax));
+            if (m & A_MINC) sk.template put<P_MINC>((float)(flat ? 0.0 : vmin));
         }
     }
 }
@@ -635,6 +638,14 @@ XD_HD TIN ref_order_sum(const TIN* win, int pitch, const double* w) {
     return (TIN)acc;
 }
 
+// squared gradient outside the validity range of the mixed-precision tail (NaN: false -- NaN propagates by itself)
+XD_HD bool mixed_tail_out_of_range(float zxf, float zyf) {
+    const float g2f = fmaf(zyf, zyf, zxf * zxf);
+    return (g2f < 1e-13f) | (g2f > 1e16f);
+}
+// a first derivative that cancelled exactly (the product also underflows for two tiny derivatives: a few extra visits of
+// the cold path, which is correct for every pixel)
+template <typename T> XD_HD bool first_derivative_zero(T zx, T zy) { return (zx * zy) == (T)0; }
 template <typename T> XD_HD bool any_zero5(T a, T b, T c, T d, T e) {
     return fmin(fmin(fabs((double)a), fabs((double)b)), fmin(fabs((double)c), fmin(fabs((double)d), fabs((double)e)))) == 0.0;
 }
@@ -659,7 +670,17 @@ template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct Surf
 };
 template <bool CURV, class SP, class SINK> struct SurfaceTail<true, CURV, SP, float, SINK> {
     static XD_HD void go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
-        surface_pixel_mixed<CURV, SP, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
+        surface_pixel_mixed<CURV, SP, false, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
+    }
+};
+template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct ColdTail {
+    static XD_HD void go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk) {
+        surface_pixel<CURV, SP, SINK>((double)zx, (double)zy, (double)zxx, (double)zyy, (double)zxy, P, sk);
+    }
+};
+template <bool CURV, class SP, class SINK> struct ColdTail<true, CURV, SP, float, SINK> {
+    static XD_HD void go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
+        surface_pixel_mixed<CURV, SP, true, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
     }
 };
 template <bool MIXED, class SP, typename TIN, class SINK> struct WindowTail {
@@ -692,16 +713,23 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
     double R3[NS];
     TIN Nl[NS], Nc[NS], Nr[NS];
 
+    // the tile row of the NEXT step is fetched from LDS one step ahead, so its latency hides behind a whole row of math
+    TIN nx0 = (TIN)0, nx1 = col[-1], nx2 = col[0], nx3 = col[1], nx4 = (TIN)0;
+    if (FIT == 2) { nx0 = col[-2]; nx4 = col[2]; }
     for (int r0 = 0; r0 < nrows; r0 += NS) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int r = r0 + k;
             if (r < nrows) {
-                const TIN* row = col + (int64_t)r * pitch;
-                const TIN tl = row[-1], tc = row[0], tr = row[1];
+                const TIN t0 = nx0, tl = nx1, tc = nx2, tr = nx3, t4 = nx4;
+                {
+                    const TIN* row = col + (int64_t)((r + 1 < nrows) ? r + 1 : r) * pitch;
+                    nx1 = row[-1]; nx2 = row[0]; nx3 = row[1];
+                    if (FIT == 2) { nx0 = row[-2]; nx4 = row[2]; }
+                }
                 const double zl = (double)tl, zc = (double)tc, zr = (double)tr;
                 if (FIT == 2) {
-                    const double z0 = (double)row[-2], z4 = (double)row[2];
+                    const double z0 = (double)t0, z4 = (double)t4;
                     const double p = z0 + z4, q = zl + zr;
                     A[k] = zr - zl;
                     B[k] = z4 - z0;
@@ -725,64 +753,79 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
                     // slot of window row (centre + d): the newest row (slot k) is centre + HALO
 #define XD_SLOT(d) ((k + NS - HALO + (d)) % NS)
                     TIN zx, zy, zxx = (TIN)0, zyy = (TIN)0, zxy = (TIN)0;   // rounded to the input dtype like the reference
-                    double det;  // an all-window sum: non-finite <=> some pixel non-finite or outside the raster
+                    // `det` = a sum over every pixel of the window: non-finite <=> some pixel non-finite or outside the raster;
+                    // det - det (0 or NaN) rides on the scaling fma of zx (and zxx): invalid windows come out NaN at no cost
+                    double det, poison;
                     if (FIT == 2) {
                         const int m2 = XD_SLOT(-2), m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1), p2 = XD_SLOT(2);
                         const double sx = fma(17.0, B[c0], fma(68.0, A[c0],
                                           fma(5.0, B[m1] + B[p1], fma(62.0, A[m1] + A[p1],
                                           fma(-31.0, B[m2] + B[p2], 44.0 * (A[m2] + A[p2]))))));
-                        zx = (TIN)(-sx * P.s1);
+                        det = CURV ? ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2] : ((R[m2] + R[m1]) + (R[c0] + R[p1])) + R[p2];
+                        poison = det - det;
+                        zx = (TIN)fma(-sx, P.s1, poison);
                         zy = (TIN)(((Ua[p1] - Ua[m1]) + (Ub[p2] - Ub[m2])) * P.s1);
                         if (CURV) {
-                            det = ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2];
-                            zxx = (TIN)(det * P.sxx);
+                            zxx = (TIN)fma(det, P.sxx, poison);
                             zyy = (TIN)(fma(2.0, (R[m2] + R[p2]) - R[c0], -(R[m1] + R[p1])) * P.sxx);
                             zxy = (TIN)(fma(2.0, D2[m2] - D2[p2], D2[m1] - D2[p1]) * P.sxy);
-                        } else {
-                            det = ((R[m2] + R[m1]) + (R[c0] + R[p1])) + R[p2];
                         }
                     } else {
                         const int m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1);
                         det = (R3[m1] + R3[c0]) + R3[p1];
+                        poison = det - det;
                         if (FIT == 0) {  // Horn: [1 2 1] smoothing across the derivative direction
-                            zx = (TIN)(-(fma(2.0, Dr[c0], Dr[m1] + Dr[p1])) * P.s1);
+                            zx = (TIN)fma(-(fma(2.0, Dr[c0], Dr[m1] + Dr[p1])), P.s1, poison);
                             zy = (TIN)((fma(2.0, Zc[p1] - Zc[m1], S[p1] - S[m1])) * P.s1);
                         } else {         // Zevenbergen-Thorne: central differences
-                            zx = (TIN)(-Dr[c0] * P.s1);
+                            zx = (TIN)fma(-Dr[c0], P.s1, poison);
                             zy = (TIN)((Zc[p1] - Zc[m1]) * P.s1);
                             if (CURV) {
-                                zxx = (TIN)(fma(-2.0, Zc[c0], S[c0]) * P.sxx);
+                                zxx = (TIN)fma(fma(-2.0, Zc[c0], S[c0]), P.sxx, poison);
                                 zyy = (TIN)(fma(-2.0, Zc[c0], Zc[m1] + Zc[p1]) * P.sxx);
                                 zxy = (TIN)((Dr[m1] - Dr[p1]) * P.sxy);
                             }
                         }
                     }
                     if (m & ~A_ANY_WIN) {
-                        // exact cancellation (flat / planar ground): hand the pixel the reference's own residue
-                        const bool z5 = CURV ? any_zero5<TIN>(zx, zy, zxx, zyy, zxy) : ((zx == (TIN)0) | (zy == (TIN)0));
-#if defined(XD_NO_COLD)  // (instruction-count analysis builds only: tools/isa_stats.py)
-                        if (false) {
-#else
-                        if (__builtin_expect(z5, 0)) {
-#endif
-                            const TIN* win = col + (int64_t)i * pitch - HALO;
-                            if (zx == (TIN)0) zx = ref_order_sum<NS, TIN>(win, pitch, P.wref[0]);
-                            if (zy == (TIN)0) zy = ref_order_sum<NS, TIN>(win, pitch, P.wref[1]);
-                            if (CURV) {
-                                if (zxx == (TIN)0) zxx = ref_order_sum<NS, TIN>(win, pitch, P.wref[2]);
-                                if (zyy == (TIN)0) zyy = ref_order_sum<NS, TIN>(win, pitch, P.wref[3]);
-                                if (zxy == (TIN)0) zxy = ref_order_sum<NS, TIN>(win, pitch, P.wref[4]);
-                            }
-                        }
-                        const TIN poison = (TIN)(det - det);  // 0, or NaN for an invalid window
-                        zx += poison;
-                        if (CURV) zxx += poison;
+                        // hot path: every lane, straight-line (one basic block per output row)
                         SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk);
                     }
                     if (WIN) {
                         const int w1 = XD_SLOT(-1), w0 = XD_SLOT(0), w2 = XD_SLOT(1);
                         const TIN n[9] = {Nl[w1], Nc[w1], Nr[w1], Nl[w0], Nc[w0], Nr[w0], Nl[w2], Nc[w2], Nr[w2]};
                         WindowTail<MIXED, SP, TIN, SINK>::go(n, (R3[w1] + R3[w0]) + R3[w2], P, sk);
+                    }
+                    if (m & ~A_ANY_WIN) {
+                        // Cold path, entered by the whole wave only if some lane needs it (a scalar branch: the hot path above stays
+                        // free of exec-masked regions), executed by the lanes that need it, which overwrite what the hot path stored:
+                        //  * exact cancellation of a derivative sum (flat / planar ground): the pixel gets the reference's own
+                        //    residue (ref_order_sum) and the float64 tail;
+                        //  * mixed-precision tail outside its validity range: float64 tail.
+                        // (An exactly cancelling SECOND derivative alone does not send a pixel here: its residue only adds ~1e-15 of
+                        // the other curvature terms -- float64 rounding noise the reference's own result carries as well.)
+                        bool cold = first_derivative_zero<TIN>(zx, zy);
+                        if (MIXED) cold |= mixed_tail_out_of_range((float)zx, (float)zy);
+#if defined(XD_NO_COLD)  // (instruction-count analysis builds only: tools/isa_stats.py)
+                        cold = false;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(cold) != 0, 0))
+#endif
+                        {
+                            if (cold) {
+                                const TIN* win = col + (int64_t)i * pitch - HALO;
+                                if (zx == (TIN)0) zx = ref_order_sum<NS, TIN>(win, pitch, P.wref[0]);
+                                if (zy == (TIN)0) zy = ref_order_sum<NS, TIN>(win, pitch, P.wref[1]);
+                                if (CURV) {
+                                    if (zxx == (TIN)0) zxx = ref_order_sum<NS, TIN>(win, pitch, P.wref[2]);
+                                    if (zyy == (TIN)0) zyy = ref_order_sum<NS, TIN>(win, pitch, P.wref[3]);
+                                    if (zxy == (TIN)0) zxy = ref_order_sum<NS, TIN>(win, pitch, P.wref[4]);
+                                }
+                                const TIN pz = (TIN)poison;
+                                ColdTail<MIXED, CURV, SP, TIN, SINK>::go(zx + pz, zy, CURV ? zxx + pz : zxx, zyy, zxy, P, sk);
+                            }
+                        }
                     }
                     sk.end_row(i);
 #undef XD_SLOT

@@ -243,11 +243,11 @@ static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask)
     return XDEMHIP_OK;
 }
 
-// Tile height and store form.  float32 planes whose rows can leave as aligned float4 (W % 4 == 0, 16-byte aligned plane
-// pointers) use the staged 1 KiB row stores with 16-row tiles (tile + staging = 43 KB of LDS: three workgroups per CU);
-// everything else stores directly from 32-row (float32 DEM) / 16-row (float64 DEM) tiles.  Context options
-// "terrain_store" (0 direct, 1 staged, -1 automatic) and "terrain_rows" (0 automatic, 16, 24, 32) override the choice for
-// measurements.
+// Tile height and store form.  Default: direct stores (one 256-byte row segment per wave, plane and row) from 32-row
+// (float32 DEM) / 16-row (float64 DEM) tiles.  The staged form (StagedSink: rows leave as 1 KiB float4 stores after an
+// LDS transpose with one workgroup barrier per row; float32 planes, W % 4 == 0, 16-byte aligned planes) is kept behind
+// context option "terrain_store" = 1: measured 5-8 % SLOWER than the direct form on MI355X (profiles/README.md, r02 --
+// the per-row barrier costs more than the wider stores return); "terrain_rows" picks the tile height in measurement builds.
 template <typename TOUT> static bool staged_ok(const TerrainLaunch& L, uint32_t mask) {
     if (sizeof(TOUT) != 4 || (L.W & 3)) return false;
     for (int k = 0; k < N_ATTR; ++k)
@@ -259,7 +259,7 @@ template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT, b
 static int launch_shaped(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask) {
     constexpr int TH_DIRECT = (sizeof(TIN) == 4) ? 32 : 16;
     if constexpr (sizeof(TOUT) == 4) {
-        if ((ctx->terrain_store != 0) && staged_ok<TOUT>(L, mask)) {
+        if ((ctx->terrain_store == 1) && staged_ok<TOUT>(L, mask)) {
             if constexpr (ALLSHAPES) {  // measurement builds: option "terrain_rows"
                 if (ctx->terrain_rows == 32) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 32, 1>(ctx, L, mask);
                 if (ctx->terrain_rows == 24) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 24, 1>(ctx, L, mask);
