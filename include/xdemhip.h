@@ -82,6 +82,13 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
  * "host_chunk_mb": device-memory budget (MiB) of one row chunk of host-buffer xdemhip_terrain calls (0 = default 8192): host
  * rasters of any size stream through the GPU in row chunks with the overlap the attributes need.  "host_copy_threads":
  * threads (one HIP stream each) that move host-buffer rasters over PCIe, rows split among them (0 = default 8, at most 16).
+ * "nk_nan_rule": how nodata spreads through the bilinear taps of the Nuth-Kaab step / translation resample (the convention
+ * of geoutils' _interp_points is not pinned by anything readable offline): 0 "4tap" (default; NaN if any of the four taps is
+ * non-finite or outside, zero weights included), 1 "weighted" (zero-weight taps ignored: integer shifts keep the last row
+ * and column), 2 "dilate3x3" (NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite value).  Read when a
+ * plan is created / a resample is launched.
+ * "terrain_store" / "terrain_rows" / "terrain_math": measurement switches of the fused terrain kernel (0 = default each):
+ * staged 1 KiB row stores, tile height, float64 attribute math for float32 rasters.
  * "pairs_launch_cap": workgroups per launch of the variogram pair passes (0 = default 2^31 / workgroup size, the most a HIP
  * dispatch holds; a pass over more tiles goes out as several launches -- a small value is a test switch for that path). */
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value);
@@ -160,15 +167,38 @@ int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const 
 int xdemhip_nk_step(xdemhip_nk_plan* plan, double shift_x, double shift_y, double res_x, double res_y, int n_bins,
                     double* vshift, int64_t* n_valid, double* y_mean, double* y_std, double* edges, int64_t* counts,
                     double* medians);
-/* Multi-GPU: restrict this rank's work to raster rows [row_begin, row_end) (every rank holds the full ref / tba, 3.2 GB
- * for a 20000^2 pair; the streaming passes and their histograms are sharded by row block and combined through the
- * all-reduce hook).  Call right after xdemhip_nk_create on every rank; n_valid then returns the global count. */
+/* Multi-GPU, partitioned (the production layout; structural ancestor: xdem/coreg/blockwise.py:174): this rank holds only
+ * raster rows [row_begin - halo_top, row_end + halo_bottom) of ref / tba / inlier mask -- its own row block plus halo rows
+ * copied from the neighbours (xdem_amd.dist.RowBlock exchanges them over RCCL send / recv).  The gradient needs ONE halo
+ * row; the bilinear taps of a step need floor(|shift_y / res_y|) + 1 more, so the halo bounds the vertical shift a fit may
+ * reach: xdemhip_nk_step returns XDEMHIP_EINVAL ("halo too small ...") when a step would leave it, and the caller
+ * re-creates the plan with a deeper halo.  Install the all-reduce hook BEFORE this call: n_valid is the global count, and
+ * every reduction of a step (histograms, counters, min / max keys, successor keys) goes through the hook. */
+int xdemhip_nk_create_block(xdemhip_ctx* ctx, const void* ref_block, const void* tba_block, const uint8_t* inlier_block_or_null,
+                            int dtype, int64_t H, int64_t W, int64_t row_begin, int64_t row_end, int64_t halo_top,
+                            int64_t halo_bottom, int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid);
+/* Multi-GPU, replicated (every rank holds the full ref / tba): restrict this rank's work to raster rows
+ * [row_begin, row_end); the streaming passes and their histograms are sharded by row block and combined through the
+ * all-reduce hook.  Call right after xdemhip_nk_create on every rank; n_valid then returns the global count. */
 int xdemhip_nk_set_rows(xdemhip_nk_plan* plan, int64_t row_begin, int64_t row_end, int64_t* n_valid);
 /* Debug / test access: copy the auxiliary rasters back to host buffers (any pointer may be NULL). */
 /* Statistic of the aspect bins (NuthKaab(bin_statistic=...), xdem/coreg/affine.py:2404): XDEMHIP_BINSTAT_MEDIAN (default,
  * np.nanmedian -- exact selection) or XDEMHIP_BINSTAT_MEAN (np.nanmean: per-bin float64 sums and counts in one pass, sum-
  * reducible across GPUs; equals NumPy's float32 pairwise mean to rounding, not bit for bit).  xdemhip_nk_step then returns
  * the bin means in `medians`. */
+/* NuthKaab(bin_before_fit=False) (the mode of the reference's own synthetic tests, tests/test_coreg/test_affine.py:163-239):
+ * the step without binning.  curve_fit then runs on every valid point (xdem/coreg/base.py:975-989); the model
+ * a cos(b - x) + c is linear in (a cos b, a sin b, c), so its optimum follows from ten float64 sums over the points --
+ * sums = [n, S cos x, S sin x, S cos^2, S sin^2, S cos sin, S y, S y cos, S y sin, S y^2] with x = aspect, y = (dh - vshift) /
+ * slope_tan widened to float64 like curve_fit widens its inputs -- which is what this entry returns next to vshift,
+ * n_valid and the p0 ingredients (np.nanmean / np.nanstd of y). */
+int xdemhip_nk_step_fit(xdemhip_nk_plan* plan, double shift_x, double shift_y, double res_x, double res_y, double* vshift,
+                        int64_t* n_valid, double* y_mean, double* y_std, double* sums /* [10] */);
+/* Explicit aspect-bin edges (NuthKaab(bin_sizes={"aspect": edges}), the array form of scipy.stats.binned_statistic's `bins`):
+ * n_edges increasing values; xdemhip_nk_step then ignores n_bins and returns n_edges - 1 bins.  `decimal` = SciPy's
+ * `int(-log10(min edge spacing)) + 6` for these edges in the sample dtype (its rule for samples at or beyond the rightmost
+ * edge, _binned_statistic.py:_bin_numbers).  n_edges = 0 restores SciPy's automatic edges. */
+int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* plan, const double* edges, int n_edges, int decimal);
 #define XDEMHIP_BINSTAT_MEDIAN 0
 #define XDEMHIP_BINSTAT_MEAN 1
 int xdemhip_nk_set_statistic(xdemhip_nk_plan* plan, int bin_stat);

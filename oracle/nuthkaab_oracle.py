@@ -60,11 +60,12 @@ def aux_vars(ref: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     return slope_tan, aspect
 
 
-def shifted_dh(ref: np.ndarray, tba: np.ndarray, shift_x: float, shift_y: float, res: tuple[float, float]) -> np.ndarray:
-    """ref - bilinear(tba)(row - shift_y/res_y, col + shift_x/res_x) on the full grid (stated convention, see header)."""
-    H, W = ref.shape
-    dc = shift_x / res[0]
-    dr = -shift_y / res[1]
+def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int = 0) -> np.ndarray:
+    """bilinear(img)(row + dr, col + dc) on the full grid, float64 weights, result in img's dtype.  ``nan_rule`` = the
+    switchable nodata convention of the kernel (geoutils' own rule is unpinned, see header): 0 "4tap" -- NaN if any of the
+    four taps is non-finite or outside, zero weights included; 1 "weighted" -- taps with zero weight are ignored; 2
+    "dilate3x3" -- NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite pixel or leaves the raster."""
+    H, W = img.shape
     rr = np.arange(H, dtype=np.float64)[:, None] + dr
     cc = np.arange(W, dtype=np.float64)[None, :] + dc
     r0 = np.floor(rr)
@@ -73,22 +74,44 @@ def shifted_dh(ref: np.ndarray, tba: np.ndarray, shift_x: float, shift_y: float,
     fc = cc - c0
     r0 = r0.astype(np.int64)
     c0 = c0.astype(np.int64)
-    ok = (r0 >= 0) & (r0 + 1 < H) & (c0 >= 0) & (c0 + 1 < W)
-    ok = np.broadcast_to(ok, (H, W))
-    r0c = np.clip(r0, 0, H - 2) if H > 1 else np.zeros_like(r0)
-    c0c = np.clip(c0, 0, W - 2) if W > 1 else np.zeros_like(c0)
-    t = tba.astype(np.float64)
+    need_r1 = np.ones_like(fr, dtype=bool) if nan_rule != 1 else fr != 0
+    need_c1 = np.ones_like(fc, dtype=bool) if nan_rule != 1 else fc != 0
+    r1 = np.where(need_r1, r0 + 1, r0)
+    c1 = np.where(need_c1, c0 + 1, c0)
+    ok = np.broadcast_to((r0 >= 0) & (r1 < H), (H, W)) & np.broadcast_to((c0 >= 0) & (c1 < W), (H, W))
+    r0c, r1c = np.clip(r0, 0, H - 1), np.clip(r1, 0, H - 1)
+    c0c, c1c = np.clip(c0, 0, W - 1), np.clip(c1, 0, W - 1)
+    t = img.astype(np.float64)
     with np.errstate(invalid="ignore"):
         v00 = t[r0c, c0c]
-        v01 = t[r0c, c0c + 1]
-        v10 = t[r0c + 1, c0c]
-        v11 = t[r0c + 1, c0c + 1]
+        v01 = t[r0c, c1c]
+        v10 = t[r1c, c0c]
+        v11 = t[r1c, c1c]
         top = v00 + fc * (v01 - v00)
         bot = v10 + fc * (v11 - v10)
         val = top + fr * (bot - top)
         finite = np.isfinite(v00) & np.isfinite(v01) & np.isfinite(v10) & np.isfinite(v11)
-        val = np.where(ok & finite, val, np.nan).astype(ref.dtype)
-        return ref - val
+        good = ok & finite
+        if nan_rule == 2:
+            bad = ~np.isfinite(img)
+            pad = np.ones((H + 2, W + 2), dtype=bool)
+            pad[1:-1, 1:-1] = bad
+            dil = np.zeros((H, W), dtype=bool)
+            for a in range(3):
+                for b in range(3):
+                    dil |= pad[a : a + H, b : b + W]
+            rn = np.floor(rr + 0.5).astype(np.int64)
+            cn = np.floor(cc + 0.5).astype(np.int64)
+            inside = np.broadcast_to((rn >= 0) & (rn < H), (H, W)) & np.broadcast_to((cn >= 0) & (cn < W), (H, W))
+            near_bad = np.where(inside, dil[np.clip(rn, 0, H - 1), np.clip(cn, 0, W - 1)], True)
+            good = good & ~near_bad
+        return np.where(good, val, np.nan).astype(img.dtype)
+
+
+def shifted_dh(ref: np.ndarray, tba: np.ndarray, shift_x: float, shift_y: float, res: tuple[float, float],
+               nan_rule: int = 0) -> np.ndarray:
+    """ref - bilinear(tba)(row - shift_y/res_y, col + shift_x/res_x) on the full grid (stated convention, see header)."""
+    return ref - bilinear_shifted(tba, -shift_y / res[1], shift_x / res[0], nan_rule)
 
 
 def bin_edges(x: np.ndarray, n_bins: int) -> np.ndarray:

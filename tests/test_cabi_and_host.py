@@ -145,12 +145,39 @@ def test_nuthkaab_class_contract():
     nk = coreg.NuthKaab(max_iterations=7, offset_threshold=0.01, subsample=1)
     assert nk.meta["inputs"]["iterative"] == {"max_iterations": 7, "tolerance": 0.01}
     assert nk.meta["inputs"]["fitorbin"]["bin_sizes"] == 72
-    with pytest.raises(NotImplementedError):
-        coreg.NuthKaab(bin_before_fit=False)
+    # the options round 1 refused: un-binned fit, explicit bin edges (both upstream forms), initial shift (upstream's checks)
+    nf = coreg.NuthKaab(bin_before_fit=False, bin_sizes={"aspect": [0.0, 2.0, 4.0, 6.3]}, initial_shift=(3.0, -1.5))
+    assert nf.meta["inputs"]["fitorbin"]["fit_or_bin"] == "fit" and nf.meta["inputs"]["affine"]["initial_shift"] == (3.0, -1.5, 0)
+    assert np.array_equal(nf.meta["inputs"]["fitorbin"]["bin_sizes"], [0.0, 2.0, 4.0, 6.3])
+    with pytest.raises(ValueError, match="exactly two or three numerical values"):
+        coreg.NuthKaab(initial_shift=[1.0, 2.0])
+    with pytest.warns(UserWarning, match="work in progress"):
+        assert coreg.NuthKaab(initial_shift=(1.0, 2.0, 5.0)).meta["inputs"]["affine"]["initial_shift"] == (1.0, 2.0, 0)
+    with pytest.raises(ValueError, match="increasing bin edges"):
+        coreg.NuthKaab(bin_sizes=[3.0, 2.0, 1.0])
     with pytest.raises(ValueError, match="'transform' must be given if both DEMs are array-like."):
         nk.fit(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
     x = np.linspace(0, 6, 50)
     assert np.allclose(coreg._nuth_kaab_fit_func(x, 2.0, 0.5, 1.0), 2.0 * np.cos(0.5 - x) + 1.0)
+
+
+def test_unbinned_fit_from_sums_equals_curve_fit():
+    """bin_before_fit=False: the normal-equation solution from the ten sums xdemhip_nk_step_fit returns is the optimum that
+    the reference's curve_fit call (xdem/coreg/base.py:975-989) converges to from its p0 (affine.py:384)."""
+    import scipy.optimize
+
+    from xdem_amd import coreg
+
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 2 * np.pi, 5000)
+    y = 1.7 * np.cos(0.9 - x) + 0.4 + rng.normal(0, 0.3, x.size)
+    c, sn = np.cos(x), np.sin(x)
+    sums = np.array([x.size, c.sum(), sn.sum(), (c * c).sum(), (sn * sn).sum(), (c * sn).sum(), y.sum(), (y * c).sum(), (y * sn).sum(),
+                     (y * y).sum()])
+    east, north, vert = coreg._fit_from_sums({"sums": sums})
+    p0 = (3 * np.nanstd(y) / (2**0.5), 0.0, np.nanmean(y))
+    (a, b, cc), _ = scipy.optimize.curve_fit(coreg._nuth_kaab_fit_func, x, y, p0=p0, absolute_sigma=True)
+    assert np.allclose([east, north, vert], [a * np.sin(b), a * np.cos(b), cc], rtol=1e-6, atol=1e-9)
 
 
 def test_variogram_models_fit_and_correlation():

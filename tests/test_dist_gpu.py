@@ -194,3 +194,91 @@ def test_sharded_reductions_on_real_kernels(tmp_path):
         assert np.array_equal(g["dowd"], np.concatenate([e, c.astype(np.float64)]), equal_nan=True)
         assert np.array_equal(g["matheron_count"], cm.astype(np.float64))
         assert np.allclose(g["matheron"], em, rtol=1e-12, atol=0, equal_nan=True)
+
+
+def _worker_nk_blocks(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from xdem_amd import _lib, coreg
+        from xdem_amd import dist as xd
+
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        ctx = _lib.default_context(0)
+        ref, tba, inl = _nk_pair()
+        H = ref.shape[0]
+        r0, r1 = xd.row_block(H, world, rank)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a[r0:r1])).to(dev)
+        # (1) one step on a partitioned plan == the same step on the whole rasters
+        rb = xd.RowBlock(H, ref.shape[1], 4, rank, world, dev)
+        tb = xd.RowBlock(H, ref.shape[1], 4, rank, world, dev)
+        ib = xd.RowBlock(H, ref.shape[1], 4, rank, world, dev, dtype=torch.uint8)
+        for b, a in ((rb, ref), (tb, tba), (ib, inl.astype(np.uint8))):
+            b.interior.copy_(to(a))
+            xd.RowBlock.wait_all(b.exchange())
+        plan = coreg.NKPlan(rb.buf, tb.buf, ib.buf, ctx, "world", block=(H, r0, r1, rb.halo_top, rb.halo_bottom))
+        d = plan.step(12.0, -17.0, (10.0, 10.0), 72)   # 1.7 rows down: inside the 4-row halo
+        nv = plan.n_valid
+        try:
+            plan.step(0.0, 55.0, (10.0, 10.0), 72)      # 5.5 rows: outside
+            raised = False
+        except coreg.HaloTooSmall:
+            raised = True
+        plan.close()
+        # (2) the whole fit through the helper (halo 2 -> has to grow for this pair's 4-row shift)
+        off, n_final = xd.nuth_kaab_row_blocks(to(ref), to(tba), H, (10.0, 10.0), inlier_rows=to(inl.astype(np.uint8)), halo=2, ctx=ctx)
+        np.savez(os.path.join(outdir, f"nkb{rank}.npz"), step=np.concatenate([[d["vshift"], d["n_valid"], nv, float(raised)], d["counts"],
+                                                                              d["medians"], d["edges"]]),
+                 fit=np.array([*off, n_final], dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def _nk_pair():
+    from xdem_amd.synth import fbm_numpy
+
+    m = 2400
+    ref = fbm_numpy((m, m), seed=15, std=200.0)
+    rng = np.random.default_rng(16)
+    tba = (np.roll(ref, (4, -2), (0, 1)) + 1.5 + rng.normal(0, 0.2, (m, m))).astype(np.float32)
+    tba[rng.uniform(size=(m, m)) < 0.05] = np.nan
+    inl = np.ones((m, m), dtype=bool)
+    inl[1190:1210, 300:900] = False   # straddles the 2-rank block boundary
+    return ref, tba, inl
+
+
+def test_nuth_kaab_partitioned_row_blocks(tmp_path):
+    """the pair is PARTITIONED -- every rank holds only its row block + halo rows (RowBlock exchange) --
+    not replicated; steps and the whole fit are identical to the single-process results on the full rasters (exact
+    selections, integer histograms all-reduced through the hook)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker_nk_blocks, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    hung = [p for p in procs if p.exitcode is None]
+    for p in hung:
+        p.kill()
+    assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    from xdem_amd import coreg
+
+    ref, tba, inl = _nk_pair()
+    plan = coreg.NKPlan(ref, tba, inl)
+    d = plan.step(12.0, -17.0, (10.0, 10.0), 72)
+    nv = plan.n_valid
+    plan.close()
+    want_step = np.concatenate([[d["vshift"], d["n_valid"], nv, 1.0], d["counts"], d["medians"], d["edges"]])
+    off, n_final = coreg.nuth_kaab(ref, tba, inl, (10.0, 10.0))
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), f"nkb{r}.npz"))
+        assert np.array_equal(g["step"], want_step, equal_nan=True), r
+        assert np.allclose(g["fit"][:3], off, rtol=1e-9, atol=1e-9) and g["fit"][3] == n_final, (g["fit"], off)
+    assert abs(off[1] - (-40.0)) < 2.0 or abs(off[1] - 40.0) < 2.0   # the 4-row shift is found (|northing| ~ 40 m)

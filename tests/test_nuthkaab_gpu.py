@@ -444,3 +444,86 @@ def test_randomised_steps_vs_oracle(coreg):
         assert np.array_equal(det["counts"], counts), (trial, nb)
         assert np.array_equal(det["edges"], edges.astype(np.float64)), (trial, nb)
         assert np.array_equal(det["medians"], med, equal_nan=True), (trial, nb, H, W, dtype)
+
+
+def test_unbinned_fit_mode_vs_oracle(coreg):
+    """NuthKaab(bin_before_fit=False) -- the mode of the reference's synthetic tests (tests/test_coreg/test_affine.py:163-239):
+    the step returns the least-squares sums over every valid point; the fitted offsets equal curve_fit on all points (oracle:
+    scipy.optimize.curve_fit exactly as xdem/coreg/base.py:975-989 calls it) to 1e-6."""
+    import scipy.optimize
+
+    ref, tba, inlier, res = _pair((150, 210))
+    plan = coreg.NKPlan(ref, tba, inlier)
+    det = plan.step_fit(4.0, -6.0, (res, res))
+    plan.close()
+    st, asp = nko.aux_vars(ref)
+    valid = inlier & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+    dh = nko.shifted_dh(ref, tba, 4.0, -6.0, (res, res))
+    ok = valid & np.isfinite(dh)
+    vs = np.nanmedian(dh[ok])
+    assert det["vshift"] == float(vs) and det["n_valid"] == int(ok.sum())
+    y = ((dh[ok] - vs) / st[ok]).astype(np.float64)
+    x = asp[ok].astype(np.float64)
+    assert np.isclose(det["y_mean"], y.mean(), rtol=1e-9) and np.isclose(det["y_std"], y.std(), rtol=1e-6)
+    p0 = (3 * np.nanstd(y) / (2**0.5), 0.0, np.nanmean(y))
+    (a, b, c), _ = scipy.optimize.curve_fit(nko.fit_func, x, y, p0=p0, absolute_sigma=True)
+    east, north, vert = coreg._fit_from_sums(det)
+    assert np.allclose([east, north, vert], [a * np.sin(b), a * np.cos(b), c], rtol=1e-6, atol=1e-8)
+    # and the class recovers a synthetic shift in this mode, with an initial shift
+    nk = coreg.NuthKaab(bin_before_fit=False, subsample=1, initial_shift=(5.0, -5.0))
+    nk.fit(ref, tba, inlier, resolution=res)
+    nb = coreg.NuthKaab(subsample=1).fit(ref, tba, inlier, resolution=res)
+    for k in ("shift_x", "shift_y"):
+        assert abs(nk.meta["outputs"]["affine"][k] - nb.meta["outputs"]["affine"][k]) < 0.1 * res
+
+
+def test_explicit_bin_edges_vs_oracle(coreg):
+    """bin_sizes as an array of edges (scipy.stats.binned_statistic's `bins` sequence): counts / medians exact vs the oracle."""
+    import scipy.stats
+
+    ref, tba, inlier, res = _pair((140, 190))
+    edges = np.array([0.3, 1.0, 1.5, 2.9, 3.0, 4.4, 6.2])
+    plan = coreg.NKPlan(ref, tba, inlier)
+    plan.set_bin_edges(edges)
+    det = plan.step(2.0, 1.0, (res, res))
+    plan.set_bin_edges(None)
+    auto = plan.step(2.0, 1.0, (res, res), 72)
+    plan.close()
+    assert len(auto["counts"]) == 72 and len(det["counts"]) == 6
+    st, asp = nko.aux_vars(ref)
+    valid = inlier & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+    dh = nko.shifted_dh(ref, tba, 2.0, 1.0, (res, res))
+    ok = valid & np.isfinite(dh)
+    y = (dh[ok] - np.nanmedian(dh[ok])) / st[ok]
+    med = scipy.stats.binned_statistic(asp[ok], y, statistic=np.nanmedian, bins=edges.astype(np.float32))[0]
+    cnt = scipy.stats.binned_statistic(asp[ok], y, statistic="count", bins=edges.astype(np.float32))[0]
+    assert np.array_equal(det["counts"], cnt.astype(np.int64))
+    assert np.array_equal(det["medians"], med.astype(np.float64), equal_nan=True)
+
+
+@pytest.mark.parametrize("rule", [0, 1, 2])
+def test_nan_rules_of_the_bilinear_taps(coreg, rule):
+    """Context option "nk_nan_rule": the three nodata conventions of the bilinear taps (geoutils' own is unpinned), step and
+    translation resample, each bit-exact against the oracle's implementation of the same rule.  Rule 1 keeps the last row /
+    column at integer shifts (the ADVICE item of round 1)."""
+    ctx = coreg._lib.default_context()
+    ref, tba, inlier, res = _pair((110, 130))
+    try:
+        ctx.set_option("nk_nan_rule", rule)
+        for sx, sy in ((0.0, 0.0), (res * 2.0, -res * 1.0), (3.3, -7.1)):
+            plan = coreg.NKPlan(ref, tba, inlier)
+            det = plan.step(sx, sy, (res, res), 72)
+            plan.close()
+            st, asp = nko.aux_vars(ref)
+            valid = inlier & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+            dh = nko.shifted_dh(ref, tba, sx, sy, (res, res), nan_rule=rule)
+            ok = valid & np.isfinite(dh)
+            assert det["n_valid"] == int(ok.sum()) and det["vshift"] == float(np.nanmedian(dh[ok]))
+            out = coreg.apply_translation(tba, sx, sy, 0.5, (res, res))
+            want = nko.bilinear_shifted(tba, sy / res, -sx / res, nan_rule=rule) + np.float32(0.5)
+            assert np.array_equal(out, want, equal_nan=True)
+        if rule == 1:
+            out = coreg.apply_translation(tba, 0.0, 0.0, 0.0, (res, res))
+            assert np.array_equal(out, tba, equal_nan=True)   # zero shift = identity, last row and column included
+    finally:
+        ctx.set_option("nk_nan_rule", 0)

@@ -19,6 +19,8 @@ tba[hole < torch.quantile(hole[::16, ::16].flatten(), 0.2)] = float("nan")
 del hole
 torch.cuda.synchronize()
 ctx = _lib.default_context(0)
+if os.environ.get("NK_SELECTION"):
+    ctx.set_option("selection", int(os.environ["NK_SELECTION"]))
 plan = coreg.NKPlan(ref, tba, None, ctx)
 plan.step(0.0, 0.0, (10.0, 10.0), 72)
 for i in range(k):

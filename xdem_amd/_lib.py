@@ -64,8 +64,14 @@ def lib() -> ctypes.CDLL:
                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_nk_create.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p]
+        L.xdemhip_nk_create_block.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), c_i64p]
         L.xdemhip_nk_step.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_int, c_dp, c_i64p, c_dp, c_dp, c_dp, c_i64p, c_dp]
+        L.xdemhip_nk_step_fit.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                          c_dp, c_i64p, c_dp, c_dp, c_dp]
+        L.xdemhip_nk_set_bin_edges.argtypes = [ctypes.c_void_p, c_dp, ctypes.c_int, ctypes.c_int]
         L.xdemhip_nk_get_aux.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_nk_destroy.argtypes = [ctypes.c_void_p]
         L.xdemhip_nk_destroy.restype = None

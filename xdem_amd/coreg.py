@@ -38,16 +38,41 @@ def _bin_statistic_id(bin_statistic) -> int:
                               "callables would need the binned values on the host.")
 
 
+class HaloTooSmall(_lib.XdemHipError):
+    """A step of a partitioned (row-block) plan would sample tba outside the rank's halo rows: re-create the plan with a
+    deeper halo (``xdem_amd.dist.nuth_kaab_row_blocks`` does)."""
+
+
 class NKPlan:
     """Device-resident state of one fit (``xdemhip_nk_plan``)."""
 
     def __init__(self, ref: np.ndarray, tba: np.ndarray, inlier_mask: np.ndarray | None, ctx: _lib.Context | None = None,
-                 group=None):
+                 group=None, block: tuple[int, int, int, int, int] | None = None):
         """``group``: a torch.distributed process group (or "world") to shard the grid passes over its ranks by row
-        block -- every rank passes the same full rasters; histograms / counts are all-reduced (exact)."""
+        block; histograms / counts are all-reduced (exact).  Two layouts:
+
+        * replicated (``block=None``): every rank passes the same full rasters and works on its rows of them;
+        * partitioned (``block=(H, row_begin, row_end, halo_top, halo_bottom)``): ``ref`` / ``tba`` / ``inlier_mask`` hold only
+          raster rows ``[row_begin - halo_top, row_end + halo_bottom)`` of an ``H``-row raster -- the rank's row block plus
+          halo rows copied from its neighbours (``xdem_amd.dist.nuth_kaab_row_blocks`` builds and exchanges them).  One
+          halo row serves the gradient; the bilinear taps need ``floor(|shift_y| / res_y) + 1`` more."""
         self.ctx = ctx or _lib.default_context()
         h = ctypes.c_void_p()
         nv = ctypes.c_int64()
+        L = self.ctx._L
+        if block is not None:
+            if group is not None:
+                self.ctx.set_allreduce(group)  # (the creation pass already counts the valid pixels globally)
+            H, rb, re_, ht, hb = (int(v) for v in block)
+
+            def create(rp, tp, ip, dt, nrows, W, space):
+                if nrows != (re_ - rb) + ht + hb:
+                    raise ValueError(f"block arrays hold {nrows} rows, expected {(re_ - rb) + ht + hb}")
+                return L.xdemhip_nk_create_block(self.ctx.handle, rp, tp, ip, dt, H, W, rb, re_, ht, hb, space, ctypes.byref(h),
+                                                 ctypes.byref(nv))
+        else:
+            def create(rp, tp, ip, dt, nrows, W, space):
+                return L.xdemhip_nk_create(self.ctx.handle, rp, tp, ip, dt, nrows, W, space, ctypes.byref(h), ctypes.byref(nv))
         if hasattr(ref, "is_cuda"):
             # device-resident rasters (torch CUDA/HIP tensors, same dtype, contiguous): no host copies; the caller keeps them alive
             if not (ref.is_cuda and tba.is_cuda and ref.is_contiguous() and tba.is_contiguous() and ref.dtype == tba.dtype
@@ -57,6 +82,9 @@ class NKPlan:
 
             self.dtype = np.dtype({torch.float32: np.float32, torch.float64: np.float64}[ref.dtype])
             self.shape = tuple(ref.shape)
+            if inlier_mask is not None and not hasattr(inlier_mask, "is_cuda"):
+                # (a host mask next to device rasters, e.g. the random subsample drawn by nuth_kaab)
+                inlier_mask = torch.from_numpy(np.ascontiguousarray(inlier_mask, dtype=np.uint8)).to(ref.device)
             self._keep = (ref, tba, inlier_mask)
             inl_ptr = None
             if inlier_mask is not None:
@@ -64,9 +92,8 @@ class NKPlan:
                     raise ValueError("device inlier mask must be a contiguous uint8 CUDA tensor")
                 inl_ptr = inlier_mask.data_ptr()
             torch.cuda.current_stream(ref.device).synchronize()
-            self.ctx.check(self.ctx._L.xdemhip_nk_create(
-                self.ctx.handle, ref.data_ptr(), tba.data_ptr(), inl_ptr, _lib.F32 if self.dtype == np.float32 else _lib.F64,
-                self.shape[0], self.shape[1], _lib.DEVICE, ctypes.byref(h), ctypes.byref(nv)))
+            self.ctx.check(create(ref.data_ptr(), tba.data_ptr(), inl_ptr, _lib.F32 if self.dtype == np.float32 else _lib.F64,
+                                  self.shape[0], self.shape[1], _lib.DEVICE))
         else:
             ref = np.ascontiguousarray(ref)
             tba = np.ascontiguousarray(tba)
@@ -80,14 +107,12 @@ class NKPlan:
             inl = None
             if inlier_mask is not None:
                 inl = np.ascontiguousarray(inlier_mask, dtype=np.uint8)
-            self.ctx.check(self.ctx._L.xdemhip_nk_create(
-                self.ctx.handle, ref.ctypes.data, tba.ctypes.data, inl.ctypes.data if inl is not None else None,
-                _lib.F32 if self.dtype == np.float32 else _lib.F64, ref.shape[0], ref.shape[1], _lib.HOST, ctypes.byref(h),
-                ctypes.byref(nv)))
+            self.ctx.check(create(ref.ctypes.data, tba.ctypes.data, inl.ctypes.data if inl is not None else None,
+                                  _lib.F32 if self.dtype == np.float32 else _lib.F64, ref.shape[0], ref.shape[1], _lib.HOST))
         self.handle = h
         self.n_valid = int(nv.value)
         self.group = group
-        if group is not None:
+        if group is not None and block is None:
             import torch.distributed as dist
 
             from .dist import row_block
@@ -99,6 +124,7 @@ class NKPlan:
             self.n_valid = int(nv.value)
 
     def step(self, shift_x: float, shift_y: float, res: tuple[float, float], n_bins: int = 72) -> dict[str, Any]:
+        n_bins = getattr(self, "_n_custom_bins", None) or int(n_bins)
         edges = np.empty(n_bins + 1, dtype=np.float64)
         counts = np.empty(n_bins, dtype=np.int64)
         med = np.empty(n_bins, dtype=np.float64)
@@ -109,16 +135,48 @@ class NKPlan:
                                          ctypes.byref(vshift), ctypes.byref(nv), ctypes.byref(ymean), ctypes.byref(ystd),
                                          edges.ctypes.data_as(dp), counts.ctypes.data_as(ip), med.ctypes.data_as(dp))
         if rc != _lib.OK:
-            msg = self.ctx._L.xdemhip_last_error(self.ctx.handle).decode()
-            if "no more valid values" in msg:
-                raise ValueError(
-                    "The subsample contains no more valid values. This can happen is the horizontal shift to "
-                    "correct is very large, or if the algorithm diverged. To ensure all possible points can "
-                    "be used at any iteration step, use subsample=1."
-                )
-            raise _lib.XdemHipError(f"libxdemhip status {rc}: {msg}")
+            self._raise_step_error(rc)
         return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
                 "edges": edges, "counts": counts, "medians": med}
+
+    def _raise_step_error(self, rc: int) -> None:
+        msg = self.ctx._L.xdemhip_last_error(self.ctx.handle).decode()
+        if "no more valid values" in msg:
+            raise ValueError(
+                "The subsample contains no more valid values. This can happen is the horizontal shift to "
+                "correct is very large, or if the algorithm diverged. To ensure all possible points can "
+                "be used at any iteration step, use subsample=1."
+            )
+        if "halo too small" in msg:
+            raise HaloTooSmall(msg)
+        raise _lib.XdemHipError(f"libxdemhip status {rc}: {msg}")
+
+    def step_fit(self, shift_x: float, shift_y: float, res: tuple[float, float]) -> dict[str, Any]:
+        """One iteration without binning (``bin_before_fit=False``): vertical shift, valid count, the p0 ingredients and the
+        ten least-squares sums of ``y = A cos x + B sin x + c`` over every valid point (``xdemhip_nk_step_fit``)."""
+        sums = np.empty(10, dtype=np.float64)
+        vshift, ymean, ystd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        nv = ctypes.c_int64()
+        dp = ctypes.POINTER(ctypes.c_double)
+        rc = self.ctx._L.xdemhip_nk_step_fit(self.handle, float(shift_x), float(shift_y), float(res[0]), float(res[1]),
+                                             ctypes.byref(vshift), ctypes.byref(nv), ctypes.byref(ymean), ctypes.byref(ystd),
+                                             sums.ctypes.data_as(dp))
+        if rc != _lib.OK:
+            self._raise_step_error(rc)
+        return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value, "sums": sums}
+
+    def set_bin_edges(self, edges) -> None:
+        """Explicit aspect-bin edges (``bin_sizes={"aspect": edges}`` upstream); ``None`` restores SciPy's automatic edges."""
+        dp = ctypes.POINTER(ctypes.c_double)
+        if edges is None:
+            self.ctx.check(self.ctx._L.xdemhip_nk_set_bin_edges(self.handle, None, 0, 0))
+            self._n_custom_bins = None
+            return
+        e = np.ascontiguousarray(edges, dtype=np.float64).ravel()
+        # SciPy's rightmost-edge rule rounds to `decimal` digits, from the smallest spacing of the dtype-cast edges
+        decimal = int(-np.log10(np.diff(e.astype(self.dtype)).min())) + 6
+        self.ctx.check(self.ctx._L.xdemhip_nk_set_bin_edges(self.handle, e.ctypes.data_as(dp), int(e.size), decimal))
+        self._n_custom_bins = int(e.size) - 1
 
     def set_statistic(self, bin_statistic) -> None:
         """Statistic of the aspect bins: ``np.nanmedian`` / ``np.median`` (exact selection, the default) or ``np.nanmean`` /
@@ -179,6 +237,17 @@ def _bin_fit_from_step(det: dict[str, Any], fit_optimizer: Callable[..., Any], d
     return a * np.sin(b), a * np.cos(b), c
 
 
+def _fit_from_sums(det: dict[str, Any]) -> tuple[float, float, float]:
+    """``bin_before_fit=False``: the least-squares optimum of ``a cos(b - x) + c`` over all points, which is what upstream's
+    ``curve_fit`` converges to from its p0 (affine.py:381-409, base.py:975-989), from the normal equations of the linear
+    form ``y = A cos x + B sin x + c`` (A = a cos b = northing, B = a sin b = easting)."""
+    n, sc, ss, scc, sss, scs, sy, syc, sys_, _ = det["sums"]
+    m = np.array([[scc, scs, sc], [scs, sss, ss], [sc, ss, n]], dtype=np.float64)
+    rhs = np.array([syc, sys_, sy], dtype=np.float64)
+    a_, b_, c_ = np.linalg.solve(m, rhs)
+    return float(b_), float(a_), float(c_)
+
+
 def subsample_valid_mask(valid_mask: np.ndarray, subsample: float | int, random_state=None) -> np.ndarray:
     """Boolean mask of a random subsample of the valid pixels (``_get_subsample_on_valid_mask``, xdem/coreg/base.py:577-617).
     The draw itself is geoutils' ``subsample_array`` (un-vendored, absent here); its published rule is restated --
@@ -203,13 +272,46 @@ def subsample_valid_mask(valid_mask: np.ndarray, subsample: float | int, random_
     return out.reshape(valid_mask.shape)
 
 
+def _iterate(plan: "NKPlan", res, tolerance, max_iterations, bin_sizes, fit_optimizer, bin_before_fit: bool, initial_offsets=(0.0, 0.0)):
+    """``_iterate_method`` (affine.py:102-147) around one plan: stop when i > 1 and the horizontal step falls below the tolerance."""
+    offsets = (float(initial_offsets[0]), float(initial_offsets[1]), 0.0)
+    for i in range(max_iterations):
+        if bin_before_fit:
+            det = plan.step(offsets[0], offsets[1], res, bin_sizes if isinstance(bin_sizes, (int, np.integer)) else 72)
+            east, north, _ = _bin_fit_from_step(det, fit_optimizer, plan.dtype)
+        else:
+            det = plan.step_fit(offsets[0], offsets[1], res)
+            east, north, _ = _fit_from_sums(det)
+        offsets = (offsets[0] + east * res[0], offsets[1] + north * res[1], float(det["vshift"]))
+        stat = float(np.sqrt(east**2 + north**2))
+        if logging.getLogger().getEffectiveLevel() <= logging.INFO:
+            logging.info("      Iteration #%d - Offset: %s; Magnitude: %s", i + 1, offsets, stat)
+        if i > 1 and stat < tolerance:
+            logging.info("   Last offset was below the residual offset threshold of %s -> stopping", tolerance)
+            break
+    return offsets
+
+
+def _shared_seed(random_state, group):
+    """One seed for every rank of `group` (rank 0's choice), so that all ranks draw the same random subsample."""
+    import torch.distributed as dist
+
+    pg = None if group == "world" else group
+    box = [random_state if random_state is not None else int(np.random.SeedSequence().entropy % (2**63))]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+    return box[0]
+
+
 def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarray | None, res: tuple[float, float],
-              tolerance: float = 0.001, max_iterations: int = 10, bin_sizes: int = 72,
+              tolerance: float = 0.001, max_iterations: int = 10, bin_sizes=72,
               fit_optimizer: Callable[..., Any] | None = None, ctx: _lib.Context | None = None, group=None,
-              subsample: float | int = 1, random_state=None, bin_statistic=np.nanmedian):
+              subsample: float | int = 1, random_state=None, bin_statistic=np.nanmedian, bin_before_fit: bool = True,
+              initial_offsets: tuple[float, float] = (0.0, 0.0)):
     """Array-level entry mirroring ``nuth_kaab`` (xdem/coreg/affine.py:539-609) for two rasters.
-    ``subsample != 1`` restricts every iteration to a random subset of the valid pixels (drawn once, affine.py:581-593);
-    ``group`` (torch.distributed process group or "world") shards every grid pass over the ranks by row block.
+    ``subsample != 1`` restricts every iteration to a random subset of the valid pixels (drawn once, affine.py:581-593; with
+    ``group`` every rank draws with rank 0's seed); ``group`` (torch.distributed process group or "world") shards every grid
+    pass over the ranks by row block; ``bin_sizes``: number of aspect bins or an array of bin edges; ``bin_before_fit=False``
+    fits all points instead of the bin medians; ``initial_offsets`` = (easting, northing) the iteration starts from.
 
     Returns ((easting, northing, vertical) offsets in georeferenced units, subsample_final)."""
     import scipy.optimize
@@ -221,6 +323,8 @@ def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarra
         # valid = inlier & finite ref / tba / slope / aspect (base.py:650-661), as the aux pass just established it
         valid = plan.aux()[2]
         plan.close()
+        if group is not None:
+            random_state = _shared_seed(random_state, group)
         plan = NKPlan(ref_elev, tba_elev, subsample_valid_mask(valid, subsample, random_state), ctx, group)
     try:
         if plan.n_valid == 0:
@@ -229,18 +333,9 @@ def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarra
                 "derivatives required for this method, for example slope, aspect, etc)."
             )
         plan.set_statistic(bin_statistic)
-        offsets = (0.0, 0.0, 0.0)
-        # _iterate_method (affine.py:102-147): stop when i > 1 and the horizontal step falls below the tolerance
-        for i in range(max_iterations):
-            det = plan.step(offsets[0], offsets[1], res, bin_sizes)
-            east, north, _ = _bin_fit_from_step(det, fit_optimizer, plan.dtype)
-            offsets = (offsets[0] + east * res[0], offsets[1] + north * res[1], float(det["vshift"]))
-            stat = float(np.sqrt(east**2 + north**2))
-            if logging.getLogger().getEffectiveLevel() <= logging.INFO:
-                logging.info("      Iteration #%d - Offset: %s; Magnitude: %s", i + 1, offsets, stat)
-            if i > 1 and stat < tolerance:
-                logging.info("   Last offset was below the residual offset threshold of %s -> stopping", tolerance)
-                break
+        if not isinstance(bin_sizes, (int, np.integer)):
+            plan.set_bin_edges(bin_sizes)
+        offsets = _iterate(plan, res, tolerance, max_iterations, bin_sizes, fit_optimizer, bin_before_fit, initial_offsets)
         return offsets, plan.n_valid
     finally:
         plan.close()
@@ -284,22 +379,37 @@ class NuthKaab:
                  vertical_shift: bool = True, initial_shift=None) -> None:
         import scipy.optimize
 
-        if not bin_before_fit:
-            raise NotImplementedError("xdem_amd.NuthKaab implements the default bin_before_fit=True path only.")
         _bin_statistic_id(bin_statistic)  # np.nanmedian (default) or np.nanmean; raises for anything else
+        if isinstance(bin_sizes, dict):  # upstream's {"aspect": n | edges} form (base.py:957-966)
+            if list(bin_sizes) != ["aspect"]:
+                raise ValueError("The keys of `bin_sizes` must be ['aspect'] for NuthKaab.")
+            bin_sizes = bin_sizes["aspect"]
         if not isinstance(bin_sizes, (int, np.integer)):
-            raise NotImplementedError("bin_sizes must be an integer number of aspect bins (reference default 72).")
+            bin_sizes = np.asarray(bin_sizes, dtype=np.float64)
+            if bin_sizes.ndim != 1 or bin_sizes.size < 2 or np.any(np.diff(bin_sizes) <= 0):
+                raise ValueError("bin_sizes must be a number of bins or a 1-D array of increasing bin edges.")
         if initial_shift is not None:
-            raise NotImplementedError("initial_shift is applied by the reference outside the hot path; pre-shift the DEM instead.")
+            # same checks as AffineCoreg.__init__ (affine.py:1813-1829)
+            if not (isinstance(initial_shift, tuple) and len(initial_shift) in (2, 3)
+                    and all(isinstance(val, (float, int)) for val in initial_shift)):
+                raise ValueError("Argument `initial_shift` must be a tuple of exactly two or three numerical values.")
+            if len(initial_shift) == 2:
+                initial_shift += (0,)
+            elif initial_shift[2] != 0:
+                import warnings
+
+                initial_shift = (*initial_shift[:2], 0)
+                warnings.warn("Initial shift in altitude is currently work in progress.", category=UserWarning)
         self.vertical_shift = vertical_shift
         self.meta: dict[str, Any] = {
             "inputs": {
                 "iterative": {"max_iterations": max_iterations, "tolerance": offset_threshold},
-                "fitorbin": {"fit_or_bin": "bin_and_fit", "fit_func": _nuth_kaab_fit_func,
-                             "fit_optimizer": fit_optimizer or scipy.optimize.curve_fit, "bin_sizes": int(bin_sizes),
+                "fitorbin": {"fit_or_bin": "bin_and_fit" if bin_before_fit else "fit", "fit_func": _nuth_kaab_fit_func,
+                             "fit_optimizer": fit_optimizer or scipy.optimize.curve_fit,
+                             "bin_sizes": int(bin_sizes) if isinstance(bin_sizes, (int, np.integer)) else bin_sizes,
                              "bin_statistic": bin_statistic},
                 "random": {"subsample": subsample, "random_state": None},
-                "affine": {"apply_vshift": vertical_shift},
+                "affine": {"apply_vshift": vertical_shift, **({"initial_shift": initial_shift} if initial_shift is not None else {})},
             },
             "outputs": {},
         }
@@ -333,12 +443,18 @@ class NuthKaab:
         tba = np.asarray(to_be_aligned_elev.filled(np.nan) if isinstance(to_be_aligned_elev, np.ma.MaskedArray) else to_be_aligned_elev)
         it = self.meta["inputs"]["iterative"]
         fb = self.meta["inputs"]["fitorbin"]
+        # initial_shift (base.py:2307-2313, 2358-2366): upstream translates the reference by (-sx, -sy), fits, and adds (sx, sy)
+        # back to the estimated shift -- i.e. the search starts from shift_x = sx.  Here the iteration itself starts from
+        # the offsets (-sx, -sy), which samples the to-be-aligned DEM once at the shifted position instead of resampling
+        # it onto the translated grid first.
+        init = self.meta["inputs"]["affine"].get("initial_shift")
         (east, north, vert), n_final = nuth_kaab(ref, tba, inlier_mask, res, tolerance=it["tolerance"],
                                                  max_iterations=it["max_iterations"], bin_sizes=fb["bin_sizes"],
                                                  fit_optimizer=fb["fit_optimizer"],
                                                  subsample=self.meta["inputs"]["random"]["subsample"],
                                                  random_state=self.meta["inputs"]["random"]["random_state"],
-                                                 bin_statistic=fb["bin_statistic"])
+                                                 bin_statistic=fb["bin_statistic"], bin_before_fit=fb["fit_or_bin"] == "bin_and_fit",
+                                                 initial_offsets=(-init[0], -init[1]) if init is not None else (0.0, 0.0))
         self.meta["outputs"]["affine"] = {"shift_x": -east, "shift_y": -north, "shift_z": vert * self.vertical_shift}
         self.meta["outputs"]["random"] = {"subsample_final": n_final}
         return self

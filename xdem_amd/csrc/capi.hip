@@ -108,6 +108,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->terrain_math = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "nk_nan_rule") {
+        if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_nan_rule: 0 4tap, 1 weighted, 2 dilate3x3");
+        ctx->nk_nan_rule = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "selection") {
         if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets, 3 bracketed");
         ctx->selection_mode = value;

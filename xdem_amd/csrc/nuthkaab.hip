@@ -22,23 +22,108 @@
 
 namespace xd {
 
+// Geometry of a plan's buffers.  Every per-pixel array (ref, tba, valid, slope_tan, aspect, dh) covers raster rows
+// [roff, roff + nbuf) -- the whole raster, or a rank's row block plus its halo rows (multi-GPU) -- and is indexed by the
+// LOCAL linear index q = (row - roff) * W + col.
+struct NkGeom {
+    int64_t H, W;      // raster shape (global)
+    int64_t roff;      // raster row of buffer row 0
+    double dr, dc;     // tap position = (row + dr, col + dc)
+    int rule;          // NaN rule of the bilinear taps (context option "nk_nan_rule")
+};
+
+// ---- bilinear sample of tba at a shifted position ------------------------------------------------------------------
+// geoutils' _interp_points (un-vendored, absent here) is restated as: bilinear, float64 weights, result rounded to the DEM
+// dtype.  How nodata spreads is NOT pinned by anything in this image, so it is switchable (context option "nk_nan_rule"):
+//   0 "4tap"      NaN if any of the four taps is non-finite or outside the raster, zero weights included (what
+//                 scipy.ndimage.map_coordinates(order=1) does to NaN: 0 * NaN = NaN)                         [default]
+//   1 "weighted"  taps with zero weight are ignored: at integer shifts the last row / column keep their values
+//   2 "dilate3x3" NaN if any pixel of the 3 x 3 neighbourhood of the NEAREST pixel is non-finite or outside
+struct BiTap {
+    int64_t q00;       // local index of the top-left tap; the others are q00 + dc1, q00 + drw, q00 + drw + dc1
+    int64_t drw;       // W, or 0 where the lower row is ignored (rule 1, zero row weight)
+    int dc1;           // 1, or 0 where the right column is ignored
+    int64_t qn;        // nearest pixel (rule 2), -1 if its 3 x 3 neighbourhood leaves the raster
+    double fr, fc;
+    bool in;
+};
+// The tap position separates into a row part and a column part (kernels that walk down a column compute the latter once).
+struct BiAxis { int64_t k0; int d1; double f; double pos; bool in; };
+__device__ __forceinline__ BiAxis bi_axis(int64_t idx, double shift, int64_t extent, int rule) {
+    BiAxis a;
+    a.pos = t_add((double)idx, shift);
+    const double k0f = floor(a.pos);
+    a.f = t_sub(a.pos, k0f);
+    a.k0 = (int64_t)k0f;
+    a.d1 = (rule == 1 && a.f == 0.0) ? 0 : 1;
+    a.in = a.k0 >= 0 && a.k0 + a.d1 < extent;
+    return a;
+}
+__device__ __forceinline__ BiTap bi_combine(const NkGeom& g, const BiAxis& r, const BiAxis& c) {
+    BiTap t;
+    t.fr = r.f;
+    t.fc = c.f;
+    t.in = r.in && c.in;
+    t.q00 = t.in ? (r.k0 - g.roff) * g.W + c.k0 : 0;
+    t.drw = t.in ? (int64_t)r.d1 * g.W : 0;
+    t.dc1 = t.in ? c.d1 : 0;
+    t.qn = -1;
+    if (g.rule == 2) {
+        const int64_t rn = (int64_t)floor(r.pos + 0.5), cn = (int64_t)floor(c.pos + 0.5);
+        if (rn >= 1 && cn >= 1 && rn + 1 < g.H && cn + 1 < g.W) t.qn = (rn - g.roff) * g.W + cn;
+    }
+    return t;
+}
+__device__ __forceinline__ BiTap bi_locate(const NkGeom& g, int64_t i, int64_t j) {
+    return bi_combine(g, bi_axis(i, g.dr, g.H, g.rule), bi_axis(j, g.dc, g.W, g.rule));
+}
+template <typename T> struct BiVals { T a00, a01, a10, a11; };
+template <typename T> __device__ __forceinline__ BiVals<T> bi_load(const T* __restrict__ img, const BiTap& t) {
+    const T* q = img + t.q00;
+    BiVals<T> v;
+    v.a00 = q[0]; v.a01 = q[t.dc1]; v.a10 = q[t.drw]; v.a11 = q[t.drw + t.dc1];
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ bool bi_value(const NkGeom& g, const T* __restrict__ img, const BiTap& t, T a00, T a01, T a10, T a11, T& out) {
+    bool ok = t.in && t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11);
+    if (g.rule == 2) {
+        ok = ok && t.qn >= 0;
+        if (ok)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) ok = ok && t_finite(img[t.qn + dy * g.W + dx]);
+    }
+    const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
+    const double top = t_add(v00, t_mul(t.fc, t_sub(v01, v00)));
+    const double bot = t_add(v10, t_mul(t.fc, t_sub(v11, v10)));
+    out = (T)t_add(top, t_mul(t.fr, t_sub(bot, top)));
+    return ok;
+}
+// row / column of a local linear index (W <= 2^31, q < 2^52: one float64 multiply and a correction step)
+__device__ __forceinline__ void row_col(int64_t q, int64_t W, double invW, int64_t& li, int64_t& j) {
+    li = (int64_t)((double)q * invW);
+    j = q - li * W;
+    if (j < 0) { --li; j += W; }
+    else if (j >= W) { ++li; j -= W; }
+}
+
 // ---- aux: gradient -> slope tangent, aspect, valid mask --------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nk_aux_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
-                                                     const uint8_t* __restrict__ inlier, int64_t H, int64_t W,
+                                                     const uint8_t* __restrict__ inlier, NkGeom g,
                                                      T* __restrict__ slope_tan, T* __restrict__ aspect,
                                                      uint8_t* __restrict__ valid, unsigned long long* n_valid,
-                                                     int64_t p0, int64_t p1) {
-    // rows [p0 / W, p1 / W) (row-aligned ranges): blockIdx.x tiles the columns, blockIdx.y strides over the rows
+                                                     int64_t row0, int64_t row1) {
+    // raster rows [row0, row1): blockIdx.x tiles the columns, blockIdx.y strides over the rows
     unsigned long long local = 0;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row0 = p0 / W, row1 = p1 / W;
+    const int64_t H = g.H, W = g.W;
     if (j < W)
     for (int64_t i = row0 + blockIdx.y; i < row1; i += gridDim.y) {
-        const int64_t p = i * W + j;
+        const int64_t p = (i - g.roff) * W + j;
         const T c = ref[p];
         T gy, gx;
-        // np.gradient, unit spacing: central differences inside, one-sided on the borders
+        // np.gradient, unit spacing: central differences inside, one-sided on the borders of the RASTER
         if (i == 0) gy = t_sub(ref[p + W], c);
         else if (i == H - 1) gy = t_sub(c, ref[p - W]);
         else gy = t_div(t_sub(ref[p + W], ref[p - W]), (T)2);
@@ -61,7 +146,7 @@ __global__ __launch_bounds__(256) void nk_aux_kernel(const T* __restrict__ ref, 
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(n_valid, local);
 }
 
-// ---- dh at a shifted position (stated bilinear convention) + first histogram digit of its global median -------
+// ---- dh at a shifted position + min / max aspect over its finite pixels -------------------------------------------
 struct DhStats {
     uint64_t asp_min, asp_max;  // order-preserving keys (widened to 64 bit) of min / max aspect among finite dh
 };
@@ -69,38 +154,24 @@ struct DhStats {
 template <typename T>
 __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
                                                     const uint8_t* __restrict__ valid, const T* __restrict__ aspect,
-                                                    int64_t H, int64_t W, double dr, double dc, T* __restrict__ dh,
-                                                    DhStats* stats, int64_t p0, int64_t p1) {
+                                                    NkGeom g, T* __restrict__ dh, DhStats* stats, int64_t row0, int64_t row1) {
     typedef typename KeyT<T>::type K;
     K kmin = ~(K)0, kmax = 0;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row0 = p0 / W, row1 = p1 / W;
-    // column-invariant part of the bilinear tap position
-    const double cc = t_add((double)j, dc);
-    const double c0f = floor(cc);
-    const double fc = t_sub(cc, c0f);
-    const int64_t c0 = (int64_t)c0f;
-    const bool col_ok = j < W && c0 >= 0 && c0 + 1 < W;
-    const int64_t c0c = col_ok ? c0 : 0;
-    if (j < W)
+    const BiAxis col = bi_axis(j, g.dc, g.W, g.rule);
+    if (j < g.W)
     for (int64_t i = row0 + blockIdx.y; i < row1; i += gridDim.y) {
-        const int64_t p = i * W + j;
-        const double rr = t_add((double)i, dr);
-        const double r0f = floor(rr);
-        const double fr = t_sub(rr, r0f);
-        const int64_t r0 = (int64_t)r0f;
-        const bool in = col_ok && r0 >= 0 && r0 + 1 < H;
+        const int64_t p = (i - g.roff) * g.W + j;
+        const BiTap t = bi_combine(g, bi_axis(i, g.dr, g.H, g.rule), col);
         // all loads issued unconditionally (clamped taps) so they overlap; validity is applied afterwards
-        const T* q = tba + (in ? r0 : 0) * W + c0c;
-        const T a00 = q[0], a01 = q[1], a10 = q[W], a11 = q[W + 1];
+        const BiVals<T> tv = bi_load<T>(tba, t);
+            const T a00 = tv.a00, a01 = tv.a01, a10 = tv.a10, a11 = tv.a11;
         const T rv = ref[p];
         const T av = aspect[p];
-        const bool ok = valid[p] && in && t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11);
-        const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
-        const double top = t_add(v00, t_mul(fc, t_sub(v01, v00)));
-        const double bot = t_add(v10, t_mul(fc, t_sub(v11, v10)));
-        const double val = t_add(top, t_mul(fr, t_sub(bot, top)));
-        T out = t_sub(rv, (T)val);
+        const uint8_t vd = valid[p];  // (every load of the pixel is issued before the first use)
+        T val;
+        const bool ok = bi_value<T>(g, tba, t, a00, a01, a10, a11, val) & (vd != 0);
+        T out = t_sub(rv, val);
         if (ok && t_finite(out)) {
             const K ka = key_of(av);
             kmin = ka < kmin ? ka : kmin;
@@ -121,31 +192,180 @@ __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, c
     }
 }
 
-// ---- SURVEY 8f-1: full-grid translation resample (Coreg.apply for a pure shift) --------------------------------
-// out(r, c) = bilinear(src)(r + dr, c + dc) + dz with the same stated tap convention as nk_dh_kernel.
+// nk_dh_kernel + the counting / compaction pass of the global median's bracketed selection in one kernel: per pixel the
+// same arithmetic as nk_dh_kernel, then the order-preserving key of dh is compared with the bracket [klo, khi] of the
+// median (from the sample): counts of all / below / inside in registers, the few inside (~1-2 %) are compacted through a
+// small per-WAVE LDS staging buffer (no workgroup barrier anywhere in the row loop: the waves keep streaming independently)
+// that a wave empties with one global atomic once more than half of its 512 slots are taken (a row adds at most 64).
+constexpr int NKF_STAGE = 512;
 template <typename T>
-__global__ __launch_bounds__(256) void shift_bilinear_kernel(const T* __restrict__ src, int64_t H, int64_t W, double dr, double dc,
-                                                             T dz, T* __restrict__ out) {
-    const int64_t n = H * W;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = p / W, j = p - i * W;
-        const double rr = t_add((double)i, dr), cc = t_add((double)j, dc);
-        const double r0f = floor(rr), c0f = floor(cc);
-        const double fr = t_sub(rr, r0f), fc = t_sub(cc, c0f);
-        const int64_t r0 = (int64_t)r0f, c0 = (int64_t)c0f;
-        T o = (T)NAN;
-        if (r0 >= 0 && r0 + 1 < H && c0 >= 0 && c0 + 1 < W) {
-            const T* q = src + r0 * W + c0;
-            const T a00 = q[0], a01 = q[1], a10 = q[W], a11 = q[W + 1];
-            if (t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11)) {
-                const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
-                const double top = t_add(v00, t_mul(fc, t_sub(v01, v00)));
-                const double bot = t_add(v10, t_mul(fc, t_sub(v11, v10)));
-                o = t_add((T)t_add(top, t_mul(fr, t_sub(bot, top))), dz);
+__global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
+                                                          const uint8_t* __restrict__ valid, const T* __restrict__ aspect,
+                                                          NkGeom g, T* __restrict__ dh, DhStats* stats, int64_t row0, int64_t row1,
+                                                          const typename KeyT<T>::type* __restrict__ klo_p,
+                                                          const typename KeyT<T>::type* __restrict__ khi_p, uint64_t* counters /* [3] */,
+                                                          T* out_v, unsigned long long* ctr /* [1] candidates, [2] overflow */, int64_t cap) {
+    typedef typename KeyT<T>::type K;
+    __shared__ T stage_all[4][NKF_STAGE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T* stage = stage_all[wave];
+    int held = 0;  // wave-uniform
+    const K klo = *klo_p, khi = *khi_p;
+    K kmin = ~(K)0, kmax = 0;
+    uint32_t n_all = 0, n_below = 0, n_in = 0;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool jin = j < g.W;
+    const BiAxis col = bi_axis(j, g.dc, g.W, g.rule);
+    auto flush = [&]() {
+        unsigned long long b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&ctr[1], (unsigned long long)held);
+        b0 = __shfl(b0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = lane; k < held; k += 64) {
+            if ((int64_t)(b0 + k) < cap) out_v[b0 + k] = stage[k];
+            else ctr[2] = 1ull;
+        }
+        held = 0;
+    };
+    for (int64_t i = row0 + blockIdx.y; i < row1; i += gridDim.y) {
+        bool cand = false;
+        T out = (T)NAN;
+        if (jin) {
+            const int64_t p = (i - g.roff) * g.W + j;
+            const BiTap t = bi_combine(g, bi_axis(i, g.dr, g.H, g.rule), col);
+            const BiVals<T> tv = bi_load<T>(tba, t);
+            const T a00 = tv.a00, a01 = tv.a01, a10 = tv.a10, a11 = tv.a11;
+            const T rv = ref[p];
+            const T av = aspect[p];
+            const uint8_t vd = valid[p];  // (every load of the pixel is issued before the first use)
+            T val;
+            const bool ok = bi_value<T>(g, tba, t, a00, a01, a10, a11, val) & (vd != 0);
+            out = t_sub(rv, val);
+            if (ok && t_finite(out)) {
+                const K ka = key_of(av);
+                kmin = ka < kmin ? ka : kmin;
+                kmax = ka > kmax ? ka : kmax;
+                const K key = key_of(out);
+                ++n_all;
+                if (key < klo) ++n_below;
+                else if (key <= khi) { ++n_in; cand = true; }
+            } else {
+                out = (T)NAN;
+            }
+            dh[p] = out;
+        }
+        const unsigned long long mask = __ballot(cand);
+        if (mask) {
+            if (cand) stage[held + __popcll(mask & ((1ull << lane) - 1ull))] = out;
+            held += __popcll(mask);
+            if (held > NKF_STAGE / 2) flush();
+        }
+    }
+    if (held > 0) flush();
+    unsigned long long c0 = n_all, c1 = n_below, c2 = n_in;
+    for (int off = 32; off > 0; off >>= 1) {
+        const K a = k_shfl_down(kmin, off), b = k_shfl_down(kmax, off);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+        c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off);
+    }
+    if (lane == 0) {
+        if (kmin != ~(K)0) k_atomic_min(&stats->asp_min, (uint64_t)kmin);
+        if (kmax != 0) k_atomic_max(&stats->asp_max, (uint64_t)kmax);
+        if (c0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), c0);
+        if (c1) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[1]), c1);
+        if (c2) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2]), c2);
+    }
+}
+
+// The same dh as an element source of the bracketed selection's SAMPLE pass (select_run.h): evaluated on the sampled lines
+// only, before the dh raster exists, so that nk_dh_count_kernel can count against the bracket while it computes dh.
+template <typename T> struct NkDhSource {
+    typedef typename KeyT<T>::type K;
+    const T* ref; const T* tba; const uint8_t* valid; const T* aspect;
+    T* dh;
+    NkGeom g;
+    int64_t q0;       // local index of element 0 of the pass (this rank's first own pixel)
+    double invW;
+    DhStats* stats;
+    struct Raw { T a00, a01, a10, a11, rv, av; BiTap t; int64_t q; uint8_t vd; };
+    struct Acc { K kmin = ~(K)0, kmax = 0; };
+    static size_t lds_bytes(int) { return 0; }
+    __device__ __forceinline__ void setup(unsigned char*, int) {}
+    __device__ __forceinline__ void fetch(int64_t p, Raw& r) const {
+        r.q = q0 + p;
+        int64_t li, j;
+        row_col(r.q, g.W, invW, li, j);
+        r.t = bi_locate(g, li + g.roff, j);
+        const BiVals<T> tv = bi_load<T>(tba, r.t);
+        r.a00 = tv.a00; r.a01 = tv.a01; r.a10 = tv.a10; r.a11 = tv.a11;
+        r.rv = ref[r.q];
+        r.av = aspect[r.q];
+        r.vd = valid[r.q];
+    }
+    __device__ __forceinline__ void blank(Raw& r) const { r.q = -1; }
+    template <bool ACC> __device__ __forceinline__ bool eval(const Raw& r, int, T& v, uint16_t& b, Acc& acc) const {
+        b = 0;
+        v = (T)NAN;
+        if (r.q < 0) return false;
+        T val;
+        const bool ok = bi_value<T>(g, tba, r.t, r.a00, r.a01, r.a10, r.a11, val) && r.vd;
+        T out = t_sub(r.rv, val);
+        const bool keep = ok && t_finite(out);
+        if (!keep) out = (T)NAN;
+        if (ACC) {
+            dh[r.q] = out;
+            if (keep) {
+                const K ka = key_of(r.av);
+                acc.kmin = ka < acc.kmin ? ka : acc.kmin;
+                acc.kmax = ka > acc.kmax ? ka : acc.kmax;
             }
         }
-        out[p] = o;
+        v = out;
+        return keep;
     }
+    __device__ __forceinline__ void finish(Acc& acc) const {
+        K kmin = acc.kmin, kmax = acc.kmax;
+        for (int off = 32; off > 0; off >>= 1) {
+            const K a = k_shfl_down(kmin, off), c = k_shfl_down(kmax, off);
+            kmin = a < kmin ? a : kmin;
+            kmax = c > kmax ? c : kmax;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (kmin != ~(K)0) k_atomic_min(&stats->asp_min, (uint64_t)kmin);
+            if (kmax != 0) k_atomic_max(&stats->asp_max, (uint64_t)kmax);
+        }
+    }
+};
+
+// ---- SURVEY 8f-1: full-grid translation resample (Coreg.apply for a pure shift) --------------------------------
+// out(r, c) = bilinear(src)(r + dr, c + dc) + dz with the same tap convention / NaN rule as the Nuth-Kaab step.
+template <typename T>
+__global__ __launch_bounds__(256) void shift_bilinear_kernel(const T* __restrict__ src, NkGeom g, T dz, T* __restrict__ out) {
+    const int64_t n = g.H * g.W;
+    const double invW = 1.0 / (double)g.W;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i, j;
+        row_col(p, g.W, invW, i, j);
+        const BiTap t = bi_locate(g, i, j);
+        T val;
+        const BiVals<T> tv = bi_load<T>(src, t);
+        const bool ok = bi_value<T>(g, src, t, tv.a00, tv.a01, tv.a10, tv.a11, val);
+        out[p] = ok ? t_add(val, dz) : (T)NAN;
+    }
+}
+
+// SciPy's rule for samples at or beyond the rightmost edge (_binned_statistic.py:_bin_numbers): such a sample joins the last
+// bin iff np.around(x, decimal) == np.around(last_edge, decimal), decimal = int(-log10(min edge spacing)) + 6, evaluated in
+// the sample dtype.  With the automatic edges the largest sample IS the last edge (decimal = NK_AUTO_EDGES: always true);
+// explicit edges carry their decimal (computed by the caller exactly like SciPy).
+constexpr int NK_AUTO_EDGES = -100000;
+template <typename T> __device__ __forceinline__ bool on_last_edge(T x, T last, int decimal) {
+    if (decimal == NK_AUTO_EDGES) return true;
+    const T p10 = (T)pow(10.0, (double)(decimal < 0 ? -decimal : decimal));
+    const T rx = decimal >= 0 ? rint(x * p10) / p10 : rint(x / p10) * p10;
+    const T rl = decimal >= 0 ? rint(last * p10) / p10 : rint(last / p10) * p10;
+    return rx == rl;
 }
 
 // ---- y = (dh - vshift) / slope_tan, aspect bin id, sums for nanmean / nanstd --------------------------------
@@ -153,7 +373,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, const T* __restrict__ slope_tan,
                                                    const T* __restrict__ aspect, int64_t n, T vshift,
                                                    const T* __restrict__ edges, int nb, T* __restrict__ y,
-                                                   uint16_t* __restrict__ bins, double* sums /* [sum, sumsq] */) {
+                                                   uint16_t* __restrict__ bins, double* sums /* [sum, sumsq] */,
+                                                   int last_decimal = NK_AUTO_EDGES) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* e = reinterpret_cast<T*>(smem);
     for (int k = threadIdx.x; k <= nb; k += blockDim.x) e[k] = edges[k];
@@ -175,7 +396,7 @@ __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, con
             while (idx > 0 && !(e[idx] <= x)) --idx;
             while (idx < nb && e[idx + 1] <= x) ++idx;
             if (!(e[0] <= x)) idx = -1;
-            if (idx == nb) idx = nb - 1;
+            if (idx == nb && on_last_edge<T>(x, e[nb], last_decimal)) idx = nb - 1;
             b = (idx >= 0 && idx < nb) ? (uint16_t)idx : 0xFFFF;
             s1 += (double)yv;
             s2 += (double)yv * (double)yv;
@@ -194,11 +415,13 @@ template <typename T> struct NkYSource {
     const T* dh;
     const T* slope_tan;
     const T* aspect;
-    T vshift;
+    const T* vshift_p;  // device scalar (written by nk_vshift_edges_kernel, or uploaded by the host on the plain route)
     const T* edges;  // [nb + 1], device
     double* sums;    // [sum, sumsq], device
     T* e;            // LDS copy of the edges (setup)
     double inv_width;
+    T vshift;
+    int last_decimal;  // rounding precision of SciPy's rightmost-edge rule (NK_AUTO_EDGES for the automatic edges)
     struct Raw { T d, st, x; };
     struct Acc { double s1 = 0.0, s2 = 0.0; };
     static size_t lds_bytes(int nb) { return sizeof(T) * (size_t)(nb + 1) + 8; }
@@ -206,6 +429,7 @@ template <typename T> struct NkYSource {
         e = reinterpret_cast<T*>((reinterpret_cast<uintptr_t>(lds) + 7) & ~(uintptr_t)7);
         for (int k = threadIdx.x; k <= nb; k += blockDim.x) e[k] = edges[k];
         inv_width = (double)nb / ((double)edges[nb] - (double)edges[0]);
+        vshift = *vshift_p;
     }
     __device__ __forceinline__ void fetch(int64_t p, Raw& r) const { r.d = dh[p]; r.st = slope_tan[p]; r.x = aspect[p]; }
     __device__ __forceinline__ void blank(Raw& r) const { r.d = (T)NAN; r.st = (T)1; r.x = (T)0; }
@@ -220,7 +444,7 @@ template <typename T> struct NkYSource {
         while (idx > 0 && !(e[idx] <= x)) --idx;
         while (idx < nb && e[idx + 1] <= x) ++idx;
         if (!(e[0] <= x)) idx = -1;
-        if (idx == nb) idx = nb - 1;
+        if (idx == nb && on_last_edge<T>(x, e[nb], last_decimal)) idx = nb - 1;
         if (ACC) { acc.s1 += (double)yv; acc.s2 += (double)yv * (double)yv; }
         v = yv;
         if (idx < 0 || idx >= nb) return false;
@@ -242,8 +466,9 @@ using namespace xd;
 struct xdemhip_nk_plan {
     xdemhip_ctx* ctx = nullptr;
     int dtype = XDEMHIP_F32;
-    int64_t H = 0, W = 0;
-    int64_t p0 = 0, p1 = 0;               // this rank's pixel range [p0, p1) (whole raster unless xdemhip_nk_set_rows)
+    int64_t H = 0, W = 0;                 // raster shape (global)
+    int64_t roff = 0, nbuf = 0;           // the buffers hold raster rows [roff, roff + nbuf)
+    int64_t row0 = 0, row1 = 0;           // this rank's own rows [row0, row1) (whole raster unless sharded)
     void *ref = nullptr, *tba = nullptr;  // device (owned when own_inputs)
     uint8_t* inlier = nullptr;            // device copy kept for re-partitioning (owned when own_inputs)
     bool own_inputs = false;
@@ -256,9 +481,15 @@ struct xdemhip_nk_plan {
     long long n_valid0 = 0;
     xd::SelWorkspace ws;  // bracketed selection (select_run.h): sample + candidate buffers
     int bin_stat = XDEMHIP_BINSTAT_MEDIAN;
+    int nan_rule = 0;
+    int custom_decimal = 0;            // ... and the decimal of SciPy's rightmost-edge rule for them
+    std::vector<double> custom_edges;  // explicit bin edges (xdemhip_nk_set_bin_edges); empty: SciPy's linspace(min, max, n + 1)
 };
 
 namespace {
+
+// scratch (first 16 KiB): bin edges [0, 8208) | device-side step results at OFF_INFO
+constexpr size_t OFF_INFO = 12288;  // T vshift (8 B slot) | uint64 n_valid | uint64 flags | double vshift
 
 // column tiles of 256 x enough row-strided workgroups to fill the chip (~16 workgroups per CU)
 dim3 grid2d(const xdemhip_ctx* ctx, int64_t W, int64_t rows) {
@@ -269,24 +500,33 @@ dim3 grid2d(const xdemhip_ctx* ctx, int64_t W, int64_t rows) {
 }
 
 // np.linspace(smin, smax, nb + 1) in double (k * step + start, end point forced), cast to T -- SciPy's _bin_edges
-template <typename T> void make_edges(double smin, double smax, int nb, std::vector<T>& e) {
+template <typename T> __host__ __device__ inline void make_edges_into(double smin, double smax, int nb, T* e) {
     if (smin == smax) { smin -= 0.5; smax += 0.5; }
-    e.resize(nb + 1);
     const double step = (smax - smin) / nb;
     for (int k = 0; k <= nb; ++k) e[k] = (T)((double)k * step + smin);
     e[nb] = (T)smax;
 }
+template <typename T> void make_edges(double smin, double smax, int nb, std::vector<T>& e) {
+    e.resize(nb + 1);
+    make_edges_into<T>(smin, smax, nb, e.data());
+}
 
-// aux variables + valid mask for this rank's pixel range; global valid count through the hook
+NkGeom geom_of(const xdemhip_nk_plan* P, double dr, double dc) {
+    NkGeom g;
+    g.H = P->H; g.W = P->W; g.roff = P->roff; g.dr = dr; g.dc = dc; g.rule = P->nan_rule;
+    return g;
+}
+
+// aux variables + valid mask for this rank's rows; global valid count through the hook
 template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
     xdemhip_ctx* ctx = P->ctx;
-    const int64_t n = P->p1 - P->p0;
+    const int64_t rows = P->row1 - P->row0;
     unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(P->scratch) + OFF_STATS);
     XD_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-    if (n > 0) {
-        hipLaunchKernelGGL((nk_aux_kernel<T>), grid2d(ctx, P->W, n / P->W), dim3(256), 0, ctx->stream,
-                           static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->inlier, P->H, P->W,
-                           static_cast<T*>(P->slope_tan), static_cast<T*>(P->aspect), P->valid, d_cnt, P->p0, P->p1);
+    if (rows > 0) {
+        hipLaunchKernelGGL((nk_aux_kernel<T>), grid2d(ctx, P->W, rows), dim3(256), 0, ctx->stream,
+                           static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->inlier, geom_of(P, 0.0, 0.0),
+                           static_cast<T*>(P->slope_tan), static_cast<T*>(P->aspect), P->valid, d_cnt, P->row0, P->row1);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     int rc = xd_allreduce_device(ctx, d_cnt, 1, XDEMHIP_RED_SUM_U64);
@@ -298,151 +538,355 @@ template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
     return XDEMHIP_OK;
 }
 
+// Device-side epilogue of the fused global-median stage: vertical shift (np.nanmedian of dh, from the counters and the
+// candidate selection -- the arithmetic of run_select_bracketed's host epilogue and of median_from) and SciPy's bin edges
+// from the min / max aspect, so that the per-bin stage can be queued without a host round trip.
 template <typename T>
-int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int nb, double* vshift,
-                  int64_t* n_valid, double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians) {
+__global__ void nk_vshift_edges_kernel(const uint64_t* cnt /* total, below, inside */, const SelState<typename KeyT<T>::type>* st,
+                                       const uint64_t* succ, const typename KeyT<T>::type* klo, const uint32_t* rbs_p,
+                                       const unsigned long long* flags, const DhStats* stats, int nb, unsigned char* info, T* edges) {
+    typedef typename KeyT<T>::type K;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint64_t total = cnt[0], lt = cnt[1];
+    const int rbs = (int)*rbs_p;
+    T vs = (T)NAN;
+    if (total) {
+        const K prefix = (K)((K)(st[0].prefix >> rbs) + klo[0]);
+        const uint64_t n_le = st[0].n_le + lt;
+        const T lo = val_of(prefix);
+        if (total & 1) vs = lo;
+        else {
+            const uint64_t k2 = total / 2;
+            T hi = lo;
+            if (!(n_le > k2)) hi = val_of((K)((K)((K)succ[0] >> rbs) + klo[0]));
+            vs = (T)((T)(lo + hi) / (T)2);
+        }
+    }
+    *reinterpret_cast<T*>(info) = vs;
+    *reinterpret_cast<uint64_t*>(info + 8) = total;
+    *reinterpret_cast<uint64_t*>(info + 16) = (uint64_t)((flags[2] != 0) | ((flags[3] != 0) << 1));
+    *reinterpret_cast<double*>(info + 24) = (double)vs;
+    make_edges_into<T>((double)val_of((K)stats->asp_min), (double)val_of((K)stats->asp_max), nb, edges);
+}
+
+// Stage 1+2 of a step, fused: sample of dh on the sampled lines (computed on the fly) -> bracket of its median -> ONE pass
+// that computes dh for every own pixel, writes it, tracks min / max aspect and counts / compacts the bracket's candidates ->
+// exact selection among the candidates -> vshift and bin edges on the device.  Returns *queued = false when the bracketed
+// route does not apply (small grid, plain mode, no workspace): the caller then runs the separate passes.
+template <typename T>
+int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int nb, bool* queued) {
     typedef typename KeyT<T>::type K;
     xdemhip_ctx* ctx = P->ctx;
-    const int64_t n = P->p1 - P->p0;
+    SelWorkspace* ws = &P->ws;
+    unsigned char* scratch = static_cast<unsigned char*>(P->scratch);
+    *queued = false;
+    const bool plain = ctx->selection_mode == 1 || ctx->selection_mode == 2 || !ws->d_small || ws->es != sizeof(T) ||
+                       n < SEL_BRACKET_MIN_N || (n / 24 + 4096) > ws->s_cap;
+    if (ctx->allreduce) {  // sharded data: every rank must take the same route
+        uint64_t can = plain ? 0 : 1;
+        if (ctx->allreduce(&can, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
+        if (!can) return XDEMHIP_OK;
+    } else if (plain) {
+        return XDEMHIP_OK;
+    }
+    DhStats* d_stats = reinterpret_cast<DhStats*>(scratch + OFF_STATS);
+    NkDhSource<T> src{static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect),
+                      static_cast<T*>(P->dh), g, q0, 1.0 / (double)P->W, d_stats};
+    uint64_t* d_ctr = ws->d_small;
+    unsigned long long* d_flags = reinterpret_cast<unsigned long long*>(d_ctr);
+    K* d_klo = reinterpret_cast<K*>(ws->d_small + 8);
+    K* d_khi = reinterpret_cast<K*>(ws->d_small + 8 + ws->nb_max);
+    uint64_t* d_given = ws->d_small + 8 + 2 * ws->nb_max;
+    uint64_t* d_cnt = ws->d_small + 8 + 3 * ws->nb_max;
+    uint32_t* d_rbs = reinterpret_cast<uint32_t*>(ws->d_small + 4);
+    const SelState<K>* d_st = reinterpret_cast<const SelState<K>*>(scratch + OFF_STATE);
+    XD_HIP_CHECK(ctx, hipMemsetAsync(ws->d_small, 0, (size_t)(8 + 6 * ws->nb_max) * 8, ctx->stream));
+    const size_t lds_stage = (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
+    int rc = set_big_lds(ctx, sample_lines_kernel<T, NkDhSource<T>>, lds_stage);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sample_lines_kernel<T, NkDhSource<T>>), dim3(grid_for(ctx, n / 64 + 1, HIST_THREADS, 2)), dim3(HIST_THREADS), lds_stage,
+                       ctx->stream, src, n, 1, static_cast<T*>(ws->s_vals), ws->s_bins, d_flags, ws->s_cap);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    const int64_t m_est = n / 48 + 1;
+    constexpr int BR_PASSES = 3;
+    const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_LO, nullptr,
+                           BR_PASSES, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, d_klo, d_khi);
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_HI, nullptr,
+                           BR_PASSES, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 1, 0, low_mask, d_klo, d_khi);
+    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, 1, d_rbs);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    // the one pass: dh for every own pixel (written), min / max aspect, counters, candidates
+    if (P->row1 > P->row0) {
+        hipLaunchKernelGGL((nk_dh_count_kernel<T>), grid2d(ctx, P->W, P->row1 - P->row0), dim3(256), 0, ctx->stream,
+                           static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g,
+                           static_cast<T*>(P->dh), d_stats, P->row0, P->row1, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags,
+                           ws->c_cap);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    rc = xd_allreduce_device(ctx, d_cnt, 3, XDEMHIP_RED_SUM_U64);
+    if (rc) return rc;
+    rc = xd_allreduce_device(ctx, d_ctr + 2, 1, XDEMHIP_RED_SUM_U64);
+    if (rc) return rc;
+    rc = xd_allreduce_device(ctx, &d_stats->asp_min, 1, XDEMHIP_RED_MIN_U64);
+    if (rc) return rc;
+    rc = xd_allreduce_device(ctx, &d_stats->asp_max, 1, XDEMHIP_RED_MAX_U64);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bracket_given_kernel, dim3(1), dim3(64), 0, ctx->stream, d_cnt, 1, d_given, d_flags);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), nullptr, ws->c_cap, n / 32 + 1, d_flags + 1, 1, scratch, SEL_GIVEN, d_given,
+                           0, true, d_klo, d_rbs);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nk_vshift_edges_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_cnt, d_st,
+                       reinterpret_cast<const uint64_t*>(scratch + off_succ(1)), d_klo, d_rbs, d_flags, d_stats, nb, scratch + OFF_INFO,
+                       reinterpret_cast<T*>(scratch));
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    *queued = true;
+    return XDEMHIP_OK;
+}
+
+// Least-squares sums of the un-binned fit (NuthKaab(bin_before_fit=False): curve_fit of a cos(b - x) + c on every point,
+// xdem/coreg/base.py:975-989).  The model is linear in (A, B, c) = (a cos b, a sin b, c): y = A cos x + B sin x + c, so the
+// optimum curve_fit converges to follows from nine float64 sums; x = aspect and y = (dh - vshift) / slope_tan are widened
+// to float64 first, as curve_fit does with its inputs.  sums: n, Sc, Ss, Scc, Sss, Scs, Sy, Syc, Sys, Syy.
+template <typename T>
+__global__ __launch_bounds__(256) void nk_fit_sums_kernel(const T* __restrict__ dh, const T* __restrict__ slope_tan,
+                                                          const T* __restrict__ aspect, int64_t n, const T* __restrict__ vshift_p,
+                                                          double* sums /* [10] */) {
+    const T vshift = *vshift_p;
+    double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const T d = dh[p];
+        const T st = slope_tan[p];
+        const T x = aspect[p];
+        if (d == d) {
+            const double y = (double)t_div(t_sub(d, vshift), st);
+            const double c = cos((double)x), sn = sin((double)x);
+            a[0] += 1.0; a[1] += c; a[2] += sn; a[3] += c * c; a[4] += sn * sn; a[5] += c * sn;
+            a[6] += y; a[7] += y * c; a[8] += y * sn; a[9] += y * y;
+        }
+    }
+    __shared__ double blk[10];
+    if (threadIdx.x < 10) blk[threadIdx.x] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        double v = a[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&blk[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) atomicAdd(&sums[threadIdx.x], blk[threadIdx.x]);
+}
+
+// Stages 1 + 2 of a step: dh at the shifted position and its exact nanmedian.  On return the device holds dh, the vertical
+// shift (OFF_INFO), the bin edges (scratch start; the plan's custom edges if set) and, at OFF_INFO + 8 / + 16, the valid
+// count and the bracket flags.  *fused tells whether everything was only queued (fused route: flags must be checked after
+// the next synchronisation) or computed through the host (plain route: flags are 0).
+template <typename T>
+int nk_stage_a(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int nb, bool force_plain, bool* fused) {
+    typedef typename KeyT<T>::type K;
+    xdemhip_ctx* ctx = P->ctx;
     unsigned char* base = static_cast<unsigned char*>(P->scratch);
     DhStats* d_stats = reinterpret_cast<DhStats*>(base + OFF_STATS);
-    double* d_sums = reinterpret_cast<double*>(base + OFF_SUMS);
-    const T* dh = static_cast<const T*>(P->dh) + P->p0;
-    T* y = static_cast<T*>(P->y) + P->p0;
-    uint16_t* bins = P->bins + P->p0;
-
-    // 1. dh at the shifted position: tba sampled at (row - shift_y / res_y, col + shift_x / res_x)
+    T* d_edges = reinterpret_cast<T*>(base);
     DhStats hs0;
     hs0.asp_min = ~(uint64_t)0;
     hs0.asp_max = 0;
     XD_HIP_CHECK(ctx, hipMemcpyAsync(d_stats, &hs0, sizeof hs0, hipMemcpyHostToDevice, ctx->stream));
-    const double dr = -shift_y / res_y, dc = shift_x / res_x;
-    if (n > 0) {
-        hipLaunchKernelGGL((nk_dh_kernel<T>), grid2d(ctx, P->W, n / P->W), dim3(256), 0, ctx->stream,
-                           static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect),
-                           P->H, P->W, dr, dc, static_cast<T*>(P->dh), d_stats, P->p0, P->p1);
-        XD_HIP_CHECK(ctx, hipGetLastError());
+    *fused = false;
+    int rc = XDEMHIP_OK;
+    if (!force_plain) {
+        rc = nk_global_fused<T>(P, g, q0, n, nb, fused);
+        if (rc) return rc;
     }
-    int rc = xd_allreduce_device(ctx, &d_stats->asp_min, 1, XDEMHIP_RED_MIN_U64);
-    if (rc) return rc;
-    rc = xd_allreduce_device(ctx, &d_stats->asp_max, 1, XDEMHIP_RED_MAX_U64);
-    if (rc) return rc;
+    if (!*fused) {
+        if (n > 0) {
+            hipLaunchKernelGGL((nk_dh_kernel<T>), grid2d(ctx, P->W, P->row1 - P->row0), dim3(256), 0, ctx->stream,
+                               static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect),
+                               g, static_cast<T*>(P->dh), d_stats, P->row0, P->row1);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+        }
+        rc = xd_allreduce_device(ctx, &d_stats->asp_min, 1, XDEMHIP_RED_MIN_U64);
+        if (rc) return rc;
+        rc = xd_allreduce_device(ctx, &d_stats->asp_max, 1, XDEMHIP_RED_MAX_U64);
+        if (rc) return rc;
+        std::vector<SelResult<K>> g0;
+        rc = run_select<T>(ctx, static_cast<const T*>(P->dh) + q0, nullptr, n, 1, base, g0, &P->ws);
+        if (rc) return rc;
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(&hs0, d_stats, sizeof hs0, hipMemcpyDeviceToHost, ctx->stream));
+        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned char info[32] = {0};
+        const T vs_t = (T)median_from<T>(g0[0]);
+        const uint64_t total = g0[0].st.count, flags = 0;
+        const double vs = g0[0].st.count ? (double)vs_t : (double)NAN;
+        memcpy(info, &vs_t, sizeof(T));
+        memcpy(info + 8, &total, 8);
+        memcpy(info + 16, &flags, 8);
+        memcpy(info + 24, &vs, 8);
+        std::vector<T> edges;
+        make_edges<T>((double)val_of((K)hs0.asp_min), (double)val_of((K)hs0.asp_max), nb, edges);
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(base + OFF_INFO, info, 32, hipMemcpyHostToDevice, ctx->stream));
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, edges.data(), sizeof(T) * (nb + 1), hipMemcpyHostToDevice, ctx->stream));
+        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (info / edges are stack / local buffers)
+    }
+    if (!P->custom_edges.empty()) {  // explicit bin edges (NuthKaab(bin_sizes=<edges>)): SciPy casts them to the sample dtype
+        std::vector<T> e(P->custom_edges.size());
+        for (size_t k = 0; k < e.size(); ++k) e[k] = (T)P->custom_edges[k];
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, e.data(), sizeof(T) * e.size(), hipMemcpyHostToDevice, ctx->stream));
+        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return XDEMHIP_OK;
+}
 
-    // 2. vertical shift = exact nanmedian(dh)
-    std::vector<SelResult<K>> g;
-    rc = run_select<T>(ctx, dh, nullptr, n, 1, base, g, &P->ws);
-    if (rc) return rc;
-    *n_valid = (int64_t)g[0].st.count;
-    if (g[0].st.count == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
-    const double vs = median_from<T>(g[0]);
-    *vshift = vs;
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(&hs0, d_stats, sizeof hs0, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-
-    // 3. y = (dh - vshift) / slope_tan, bin ids on SciPy's edges, sums
-    std::vector<T> edges;
-    make_edges<T>((double)val_of((K)hs0.asp_min), (double)val_of((K)hs0.asp_max), nb, edges);
+template <typename T>
+int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int nb, double* vshift,
+                  int64_t* n_valid, double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians,
+                  double* fit_sums /* non-null: the un-binned least-squares sums instead of the binning */) {
+    typedef typename KeyT<T>::type K;
+    xdemhip_ctx* ctx = P->ctx;
+    const int64_t q0 = (P->row0 - P->roff) * P->W;
+    const int64_t n = (P->row1 - P->row0) * P->W;
+    unsigned char* base = static_cast<unsigned char*>(P->scratch);
+    double* d_sums = reinterpret_cast<double*>(base + OFF_SUMS);
+    const T* dh = static_cast<const T*>(P->dh) + q0;
+    const T* st = static_cast<const T*>(P->slope_tan) + q0;
+    const T* asp = static_cast<const T*>(P->aspect) + q0;
+    T* y = static_cast<T*>(P->y) + q0;
+    uint16_t* bins = P->bins + q0;
     T* d_edges = reinterpret_cast<T*>(base);
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, edges.data(), sizeof(T) * (nb + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (P->bin_stat == XDEMHIP_BINSTAT_MEAN) {
-        // 4'. bin_statistic = np.nanmean: one pass, per-bin float64 sums and counts (and the two global sums)
-        if (nb > 3072) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins too large for the mean statistic");
+    T* d_vshift = reinterpret_cast<T*>(base + OFF_INFO);
+    if (!P->custom_edges.empty()) nb = (int)P->custom_edges.size() - 1;
+
+    // tba is sampled at (row - shift_y / res_y, col + shift_x / res_x); the taps of this rank's rows must lie in its buffers
+    const double dr = -shift_y / res_y, dc = shift_x / res_x;
+    const NkGeom g = geom_of(P, dr, dc);
+    {
+        // Direction-agnostic on purpose: every rank of a partitioned fit must take the same decision (a rank that raised
+        // while its neighbours entered the next all-reduce would dead-lock the group), and all interior block borders
+        // carry the same halo depth.
+        const int64_t need = (int64_t)floor(fabs(dr)) + 1;
+        const bool top_ok = P->row0 == 0 || P->row0 - P->roff >= need;
+        const bool bottom_ok = P->row1 == P->H || P->roff + P->nbuf - P->row1 >= need;
+        if (!top_ok || !bottom_ok)
+            return xd_fail(ctx, XDEMHIP_EINVAL, "halo too small: the vertical shift moves the bilinear taps outside this rank's row block + halo");
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool fused = false;
+        int rc = nk_stage_a<T>(P, g, q0, n, nb, attempt == 1, &fused);
+        if (rc) return rc;
+        // stage 3 + 4, queued right behind stage 1 + 2 on the fused route (vshift and the edges are read from the device)
+        std::vector<SelResult<K>> hs;
+        bool bins_done = false;
         double* d_bsum = reinterpret_cast<double*>(base + off_hist(nb));
         unsigned long long* d_bcnt = reinterpret_cast<unsigned long long*>(d_bsum + nb);
+        double* d_fit = reinterpret_cast<double*>(base + off_hist(1));
+        NkYSource<T> src{dh, st, asp, d_vshift, d_edges, d_sums, nullptr, 0.0, (T)0,
+                         P->custom_edges.empty() ? NK_AUTO_EDGES : P->custom_decimal};
         XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
-        NkYSource<T> src{dh, static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, (T)vs, d_edges, d_sums,
-                         nullptr, 0.0};
-        rc = run_bin_sums<T, NkYSource<T>>(ctx, src, n, nb, d_bsum, d_bcnt);
-        if (rc) return rc;
+        if (fit_sums) {
+            XD_HIP_CHECK(ctx, hipMemsetAsync(d_fit, 0, 80, ctx->stream));
+            if (n > 0) {
+                hipLaunchKernelGGL((nk_fit_sums_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream, dh, st, asp, n, d_vshift,
+                                   d_fit);
+                XD_HIP_CHECK(ctx, hipGetLastError());
+            }
+            rc = xd_allreduce_device(ctx, d_fit, 10, XDEMHIP_RED_SUM_F64);
+            if (rc) return rc;
+        } else if (P->bin_stat == XDEMHIP_BINSTAT_MEAN) {
+            // bin_statistic = np.nanmean: one pass, per-bin float64 sums and counts (and the two global sums)
+            if (nb > 3072) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins too large for the mean statistic");
+            rc = run_bin_sums<T, NkYSource<T>>(ctx, src, n, nb, d_bsum, d_bcnt);
+            if (rc) return rc;
+        } else {
+            // per-bin exact medians, bracketed route: y and the bin ids are computed on the fly by the sample / counting
+            // passes (NkYSource), the counting pass accumulates the sums
+            rc = run_select_bracketed<T, NkYSource<T>>(ctx, src, n, nb, base, hs, &P->ws, &bins_done);
+            if (rc) return rc;
+        }
+        unsigned char info[32];
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(info, base + OFF_INFO, 32, hipMemcpyDeviceToHost, ctx->stream));
+        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t total, flags;
+        double vs;
+        memcpy(&total, info + 8, 8);
+        memcpy(&flags, info + 16, 8);
+        memcpy(&vs, info + 24, 8);
+        if (fused && flags != 0) continue;  // a bracket of the global median missed / overflowed: again on the plain route
+        *n_valid = (int64_t)total;
+        if (total == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
+        *vshift = vs;
+        if (!fit_sums && P->bin_stat == XDEMHIP_BINSTAT_MEDIAN && !bins_done) {
+            // small grids, plain mode, a missed bracket: y and bin-id arrays + plain digit passes
+            XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
+            if (n > 0) {
+                hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream, dh, st, asp, n,
+                                   (T)vs, d_edges, nb, y, bins, d_sums, P->custom_edges.empty() ? NK_AUTO_EDGES : P->custom_decimal);
+                XD_HIP_CHECK(ctx, hipGetLastError());
+            }
+            rc = run_select_core<T>(ctx, y, bins, n, nb, base, hs, SEL_MEDIAN, nullptr);
+            if (rc) return rc;
+        }
+        std::vector<T> edges(nb + 1);
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(edges.data(), d_edges, sizeof(T) * (nb + 1), hipMemcpyDeviceToHost, ctx->stream));
+        const double cnt = (double)total;
+        if (fit_sums) {
+            XD_HIP_CHECK(ctx, hipMemcpyAsync(fit_sums, d_fit, 80, hipMemcpyDeviceToHost, ctx->stream));
+            XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const double mean = fit_sums[6] / cnt;
+            const double var = fit_sums[9] / cnt - mean * mean;
+            *y_mean = mean;
+            *y_std = var > 0 ? sqrt(var) : 0.0;
+            return XDEMHIP_OK;
+        }
         rc = xd_allreduce_device(ctx, d_sums, 2, XDEMHIP_RED_SUM_F64);
         if (rc) return rc;
+        double sums[2];
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream));
         std::vector<double> bs(nb);
         std::vector<unsigned long long> bc(nb);
-        double sums[2];
-        XD_HIP_CHECK(ctx, hipMemcpyAsync(bs.data(), d_bsum, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-        XD_HIP_CHECK(ctx, hipMemcpyAsync(bc.data(), d_bcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-        XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (P->bin_stat == XDEMHIP_BINSTAT_MEAN) {
+            XD_HIP_CHECK(ctx, hipMemcpyAsync(bs.data(), d_bsum, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+            XD_HIP_CHECK(ctx, hipMemcpyAsync(bc.data(), d_bcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+        }
         XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        const double cnt = (double)g[0].st.count;
         const double mean = sums[0] / cnt;
         const double var = sums[1] / cnt - mean * mean;
         *y_mean = mean;
         *y_std = var > 0 ? sqrt(var) : 0.0;
         for (int k = 0; k < nb; ++k) {
-            counts[k] = (int64_t)bc[k];
-            medians[k] = bc[k] ? (double)(T)(bs[k] / (double)bc[k]) : NAN;  // np.nanmean returns the sample dtype
+            if (P->bin_stat == XDEMHIP_BINSTAT_MEAN) {
+                counts[k] = (int64_t)bc[k];
+                medians[k] = bc[k] ? (double)(T)(bs[k] / (double)bc[k]) : NAN;  // np.nanmean returns the sample dtype
+            } else {
+                counts[k] = (int64_t)hs[k].st.count;
+                medians[k] = median_from<T>(hs[k]);
+            }
         }
         for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges[k];
         return XDEMHIP_OK;
     }
-
-    // 4. per-bin exact medians.  Bracketed route: y and the bin ids are computed on the fly by the sample / counting passes
-    // (NkYSource), the counting pass accumulates the sums.  Otherwise (small grids, plain mode, a missed bracket): y and
-    // bin-id arrays + plain digit passes.
-    std::vector<SelResult<K>> hs;
-    bool done = false;
-    XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
-    {
-        NkYSource<T> src{dh, static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, (T)vs, d_edges, d_sums,
-                         nullptr, 0.0};
-        rc = run_select_bracketed<T, NkYSource<T>>(ctx, src, n, nb, base, hs, &P->ws, &done);
-        if (rc) return rc;
-    }
-    if (!done) {
-        XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
-        if (n > 0) {
-            hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream, dh,
-                               static_cast<const T*>(P->slope_tan) + P->p0, static_cast<const T*>(P->aspect) + P->p0, n, (T)vs, d_edges,
-                               nb, y, bins, d_sums);
-            XD_HIP_CHECK(ctx, hipGetLastError());
-        }
-        rc = run_select_core<T>(ctx, y, bins, n, nb, base, hs, SEL_MEDIAN, nullptr);
-        if (rc) return rc;
-    }
-    rc = xd_allreduce_device(ctx, d_sums, 2, XDEMHIP_RED_SUM_F64);
-    if (rc) return rc;
-    double sums[2];
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const double cnt = (double)g[0].st.count;
-    const double mean = sums[0] / cnt;
-    const double var = sums[1] / cnt - mean * mean;
-    *y_mean = mean;
-    *y_std = var > 0 ? sqrt(var) : 0.0;
-    for (int k = 0; k < nb; ++k) {
-        counts[k] = (int64_t)hs[k].st.count;
-        medians[k] = median_from<T>(hs[k]);
-    }
-    for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges[k];
-    return XDEMHIP_OK;
+    return xd_fail(ctx, XDEMHIP_EHIP, "Nuth-Kaab step: selection failed on both routes");
 }
 
-}  // namespace
-
-extern "C" {
-
-void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
-    if (!P) return;
-    (void)hipSetDevice(P->ctx->device);
-    if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
-    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->scratch};
-    for (void* b : bufs)
-        if (b) (void)hipFree(b);
-    xd::sel_ws_free(P->ws);
-    delete P;
-}
-
-int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const uint8_t* inlier, int dtype, int64_t H, int64_t W,
-                      int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid) {
+// Shared by the two creation entry points.  Buffers hold raster rows [roff, roff + nbuf); own rows [row0, row1).
+int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uint8_t* inlier, int dtype, int64_t H, int64_t W,
+                   int64_t roff, int64_t nbuf, int64_t row0, int64_t row1, int memspace, bool global_count,
+                   xdemhip_nk_plan** out_plan, int64_t* n_valid) {
     if (!ctx) return XDEMHIP_EINVAL;
     if (!ref || !tba || !out_plan) return xd_fail(ctx, XDEMHIP_EINVAL, "null argument");
     if (H < 2 || W < 2) return xd_fail(ctx, XDEMHIP_EINVAL, "Shape of array too small to calculate a numerical gradient, at least 2 elements are required.");
     if (dtype != XDEMHIP_F32 && dtype != XDEMHIP_F64) return xd_fail(ctx, XDEMHIP_EINVAL, "dtype must be float32 or float64");
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t es = dtype == XDEMHIP_F32 ? 4 : 8;
-    const size_t n = (size_t)H * (size_t)W;
+    const size_t n = (size_t)nbuf * (size_t)W;
     xdemhip_nk_plan* P = new xdemhip_nk_plan();
-    P->ctx = ctx; P->dtype = dtype; P->H = H; P->W = W; P->p0 = 0; P->p1 = (int64_t)n;
+    P->ctx = ctx; P->dtype = dtype; P->H = H; P->W = W; P->roff = roff; P->nbuf = nbuf; P->row0 = row0; P->row1 = row1;
+    P->nan_rule = ctx->nk_nan_rule;
     auto fail = [&](int code, const char* msg) { xdemhip_nk_destroy(P); return xd_fail(ctx, code, msg); };
     if (memspace == XDEMHIP_HOST) {
         P->own_inputs = true;
@@ -468,7 +912,7 @@ int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const 
     if ((int64_t)n >= SEL_BRACKET_MIN_N && sel_ws_create(ctx, (int64_t)n, es, MAX_BINS_PER_SWEEP, P->ws) != XDEMHIP_OK)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
     const xdemhip_allreduce_fn hook = ctx->allreduce;
-    ctx->allreduce = nullptr;  // the whole-raster pass at creation is local; xdemhip_nk_set_rows re-partitions with the hook
+    if (!global_count) ctx->allreduce = nullptr;  // whole-raster plan: local pass; xdemhip_nk_set_rows re-partitions with the hook
     int rc = dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
     ctx->allreduce = hook;
     if (rc != XDEMHIP_OK) { xdemhip_nk_destroy(P); return rc; }
@@ -477,13 +921,48 @@ int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const 
     return XDEMHIP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
+    if (!P) return;
+    (void)hipSetDevice(P->ctx->device);
+    if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
+    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->scratch};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    xd::sel_ws_free(P->ws);
+    delete P;
+}
+
+int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const uint8_t* inlier, int dtype, int64_t H, int64_t W,
+                      int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid) {
+    return nk_create_impl(ctx, ref, tba, inlier, dtype, H, W, 0, H, 0, H, memspace, false, out_plan, n_valid);
+}
+
+int xdemhip_nk_create_block(xdemhip_ctx* ctx, const void* ref_block, const void* tba_block, const uint8_t* inlier_block, int dtype,
+                            int64_t H, int64_t W, int64_t row_begin, int64_t row_end, int64_t halo_top, int64_t halo_bottom,
+                            int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (row_begin < 0 || row_end < row_begin || row_end > H || halo_top < 0 || halo_bottom < 0 || halo_top > row_begin ||
+        row_end + halo_bottom > H)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "bad row block");
+    // np.gradient reads one neighbour row on each side of an own row: a block that does not start / end at the raster's
+    // border needs at least one halo row there
+    if ((row_begin > 0 && halo_top < 1) || (row_end < H && halo_bottom < 1))
+        return xd_fail(ctx, XDEMHIP_EINVAL, "a row block inside the raster needs >= 1 halo row towards each neighbour");
+    return nk_create_impl(ctx, ref_block, tba_block, inlier_block, dtype, H, W, row_begin - halo_top, (row_end - row_begin) + halo_top + halo_bottom,
+                          row_begin, row_end, memspace, true, out_plan, n_valid);
+}
+
 int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, int64_t* n_valid) {
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
-    if (row_begin < 0 || row_end < row_begin || row_end > P->H) return xd_fail(ctx, XDEMHIP_EINVAL, "bad row range");
+    if (row_begin < P->roff || row_end < row_begin || row_end > P->roff + P->nbuf) return xd_fail(ctx, XDEMHIP_EINVAL, "bad row range");
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    P->p0 = row_begin * P->W;
-    P->p1 = row_end * P->W;
+    P->row0 = row_begin;
+    P->row1 = row_end;
     // valid mask / aux rasters outside the range are never read by this rank; recount the global number of valid pixels
     int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
     if (rc) return rc;
@@ -503,7 +982,7 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* P, void* slope_tan, void* aspect, uint8_
     xdemhip_ctx* ctx = P->ctx;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t es = P->dtype == XDEMHIP_F32 ? 4 : 8, n = (size_t)P->H * (size_t)P->W;
+    const size_t es = P->dtype == XDEMHIP_F32 ? 4 : 8, n = (size_t)P->nbuf * (size_t)P->W;  // (the plan's buffer rows)
     if (slope_tan) XD_HIP_CHECK(ctx, hipMemcpy(slope_tan, P->slope_tan, n * es, hipMemcpyDeviceToHost));
     if (aspect) XD_HIP_CHECK(ctx, hipMemcpy(aspect, P->aspect, n * es, hipMemcpyDeviceToHost));
     if (valid) XD_HIP_CHECK(ctx, hipMemcpy(valid, P->valid, n, hipMemcpyDeviceToHost));
@@ -520,11 +999,38 @@ int xdemhip_nk_step(xdemhip_nk_plan* P, double shift_x, double shift_y, double r
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     int rc = P->dtype == XDEMHIP_F32
-                 ? nk_step_typed<float>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, counts, medians)
-                 : nk_step_typed<double>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, counts, medians);
+                 ? nk_step_typed<float>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, counts, medians, nullptr)
+                 : nk_step_typed<double>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, counts, medians, nullptr);
     (void)hipEventRecord(ctx->ev_stop, ctx->stream);
     ctx->timed = (rc == XDEMHIP_OK);
     return rc;
+}
+
+int xdemhip_nk_step_fit(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, double* vshift, int64_t* n_valid,
+                        double* y_mean, double* y_std, double* sums) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (!vshift || !n_valid || !y_mean || !y_std || !sums) return xd_fail(ctx, XDEMHIP_EINVAL, "null output");
+    if (!(res_x > 0) || !(res_y > 0)) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    int rc = P->dtype == XDEMHIP_F32
+                 ? nk_step_typed<float>(P, shift_x, shift_y, res_x, res_y, 72, vshift, n_valid, y_mean, y_std, nullptr, nullptr, nullptr, sums)
+                 : nk_step_typed<double>(P, shift_x, shift_y, res_x, res_y, 72, vshift, n_valid, y_mean, y_std, nullptr, nullptr, nullptr, sums);
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+    ctx->timed = (rc == XDEMHIP_OK);
+    return rc;
+}
+
+int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* P, const double* edges, int n_edges, int decimal) {
+    if (!P) return XDEMHIP_EINVAL;
+    if (n_edges == 0) { P->custom_edges.clear(); return XDEMHIP_OK; }
+    if (!edges || n_edges < 2 || n_edges - 1 > MAX_BINS_PER_SWEEP) return xd_fail(P->ctx, XDEMHIP_EINVAL, "bin edges: 2 .. 129 increasing values");
+    for (int k = 1; k < n_edges; ++k)
+        if (!(edges[k] > edges[k - 1])) return xd_fail(P->ctx, XDEMHIP_EINVAL, "bin edges must increase strictly");
+    P->custom_edges.assign(edges, edges + n_edges);
+    P->custom_decimal = decimal;
+    return XDEMHIP_OK;
 }
 
 // resample a raster shifted by (shift_col, shift_row) pixels (+ dz) back onto its own grid -- the
@@ -547,12 +1053,14 @@ int xdemhip_shift_bilinear(xdemhip_ctx* ctx, const void* src, int dtype, int64_t
     }
     const int64_t n = H * W;
     XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    NkGeom g;
+    g.H = H; g.W = W; g.roff = 0; g.dr = shift_row_px; g.dc = shift_col_px; g.rule = ctx->nk_nan_rule;
     if (dtype == XDEMHIP_F32)
         hipLaunchKernelGGL((shift_bilinear_kernel<float>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
-                           static_cast<const float*>(d_src), H, W, shift_row_px, shift_col_px, (float)dz, static_cast<float*>(d_out));
+                           static_cast<const float*>(d_src), g, (float)dz, static_cast<float*>(d_out));
     else
         hipLaunchKernelGGL((shift_bilinear_kernel<double>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), 0, ctx->stream,
-                           static_cast<const double*>(d_src), H, W, shift_row_px, shift_col_px, dz, static_cast<double*>(d_out));
+                           static_cast<const double*>(d_src), g, dz, static_cast<double*>(d_out));
     (void)hipEventRecord(ctx->ev_stop, ctx->stream);
     ctx->timed = true;
     int rc = XDEMHIP_OK;

@@ -146,3 +146,66 @@ def terrain_row_block(block: RowBlock, attribute: list[str], out: torch.Tensor |
 
 def _rows(out: torch.Tensor, r0: int, n: int):
     return out[:, r0 : r0 + n, :]
+
+
+def nuth_kaab_row_blocks(ref_rows: torch.Tensor, tba_rows: torch.Tensor, total_rows: int, res: tuple[float, float],
+                         inlier_rows: torch.Tensor | None = None, group=None, halo: int = 8, ctx=None, tolerance: float = 0.001,
+                         max_iterations: int = 10, bin_sizes=72, fit_optimizer=None, bin_statistic=None, bin_before_fit: bool = True,
+                         initial_offsets: tuple[float, float] = (0.0, 0.0)):
+    """Nuth & Kaab fit of a raster pair PARTITIONED by row block over the ranks of ``group``: every rank passes only ITS
+    rows -- ``row_block(total_rows, world, rank)`` -- of the reference / to-be-aligned DEM (device tensors, same dtype) and
+    of the optional inlier mask (uint8).  Layout and halo exchange as for the terrain path (structural
+    ancestor: xdem/coreg/blockwise.py:174): each rank's buffers hold ``halo`` rows of both neighbours, copied once per fit
+    with one grouped send / recv pair per neighbour (``RowBlock.exchange``: ncclSend / ncclRecv under RCCL).  One halo row
+    serves ``np.gradient``, the rest bounds the vertical shift the iteration may reach (``floor(|shift_y| / res_y) + 2``
+    rows); if a step leaves it (``HaloTooSmall``, raised identically on every rank) the halo is doubled and the fit
+    restarts.  Every reduction of a step -- integer histograms, counters, min / max keys -- is all-reduced through the
+    library hook, so all ranks obtain the same, exact result as a single-GPU fit of the whole rasters.
+
+    Returns ((easting, northing, vertical) offsets, number of valid pixels of the whole pair)."""
+    import numpy as np
+    import scipy.optimize
+
+    from . import _lib, coreg
+
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    W = ref_rows.shape[1]
+    r0, r1 = row_block(total_rows, world, rank)
+    if tuple(ref_rows.shape) != (r1 - r0, W) or tba_rows.shape != ref_rows.shape:
+        raise ValueError(f"rank {rank} must pass rows [{r0}, {r1}) of both rasters")
+    ctx = ctx or _lib.default_context(ref_rows.device.index or 0)
+    fit_optimizer = fit_optimizer or scipy.optimize.curve_fit
+    bin_statistic = bin_statistic if bin_statistic is not None else np.nanmedian
+    while True:
+        depth = min(halo, (total_rows // world) if world > 1 else halo)
+        blocks = []
+        for t, dt in ((ref_rows, ref_rows.dtype), (tba_rows, tba_rows.dtype), (inlier_rows, torch.uint8)):
+            if t is None:
+                blocks.append(None)
+                continue
+            b = RowBlock(total_rows, W, depth, rank, world, ref_rows.device, dtype=dt)
+            b.interior.copy_(t)
+            RowBlock.wait_all(b.exchange(group))
+            blocks.append(b)
+        rb, tb, ib = blocks
+        plan = coreg.NKPlan(rb.buf, tb.buf, ib.buf if ib is not None else None, ctx,
+                            (group if group is not None else "world") if world > 1 else None,
+                            block=(total_rows, r0, r1, rb.halo_top, rb.halo_bottom))
+        try:
+            if plan.n_valid == 0:
+                raise ValueError(
+                    "There is no valid points common to the input and auxiliary data (bias variables, or "
+                    "derivatives required for this method, for example slope, aspect, etc)."
+                )
+            plan.set_statistic(bin_statistic)
+            if not isinstance(bin_sizes, (int, np.integer)):
+                plan.set_bin_edges(bin_sizes)
+            offsets = coreg._iterate(plan, res, tolerance, max_iterations, bin_sizes, fit_optimizer, bin_before_fit, initial_offsets)
+            return offsets, plan.n_valid
+        except coreg.HaloTooSmall:
+            if world == 1 or depth >= total_rows // world:
+                raise
+            halo = 2 * depth
+        finally:
+            plan.close()
