@@ -32,9 +32,28 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (about 6.3
 BYTES_PER_PIXEL = 4 + 4 * len(FULL)  # 4 B read + 4 B per attribute written = 48 B
 
 
-def cpu_baseline(n: int = 6144) -> dict:
-    """Reference-recipe CPU port (oracle/terrain_oracle.py, single thread NumPy) on a bounded n x n sample."""
+def _cpu_terrain_tile(args):
+    """Worker of the all-cores CPU leg: the oracle on one DEM tile (module level: multiprocessing 'spawn' imports it)."""
+    seed, rows, cols = args
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"  # one oracle thread per process: the processes are the parallelism
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import terrain_oracle
+
+    rng = np.random.default_rng(seed)
+    dem = (1000.0 + np.cumsum(np.cumsum(rng.normal(scale=0.2, size=(rows, cols)), 0), 1)).astype(np.float32)
+    t0 = time.perf_counter()
+    terrain_oracle.terrain_attributes(dem, FULL, resolution=10.0)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(n: int = 6144) -> dict:
+    """Reference-recipe CPU port (oracle/terrain_oracle.py = NumPy restatement of the reference's SciPy engine) on bounded
+    samples of the same workload, as SURVEY 8d asks: one thread, all host cores (one oracle process per core, one tile each),
+    and the reference engine's own primitive -- scipy.ndimage.convolve with the five Florinsky kernels -- where SciPy is there."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
     import terrain_oracle
 
     from xdem_amd.synth import fbm_numpy
@@ -43,9 +62,40 @@ def cpu_baseline(n: int = 6144) -> dict:
     t0 = time.perf_counter()
     terrain_oracle.terrain_attributes(dem, FULL, resolution=10.0)
     dt = time.perf_counter() - t0
-    return {"value": round(n * n / dt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"{n}x{n} fBm float32 DEM, full 11-attribute set, oracle/terrain_oracle.py (NumPy restatement of "
-                      f"the reference SciPy engine), {dt:.1f} s, host has {os.cpu_count()} cores"}
+    out = {"value": round(n * n / dt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+           "sample": f"{n}x{n} fBm float32 DEM, full 11-attribute set, oracle/terrain_oracle.py (NumPy restatement of "
+                     f"the reference SciPy engine), {dt:.1f} s, host has {os.cpu_count()} cores"}
+    # all cores: one process per core (capped), each times the oracle on its own 1024 x 2048 tile; rate = pixels / slowest
+    try:
+        import multiprocessing as mp
+
+        cores = min(os.cpu_count() or 1, 256)
+        rows, cols = 512, 2048
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_cpu_terrain_tile, [(i, 8, 64) for i in range(cores)])  # spin the workers up (imports) outside the clock
+            t0 = time.perf_counter()
+            pool.map(_cpu_terrain_tile, [(100 + i, rows, cols) for i in range(cores)], chunksize=1)
+            wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(cores * rows * cols / wall / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                            "sample": f"{cores} processes x one {rows}x{cols} float32 tile each, full 11-attribute set, {wall:.1f} s wall"}
+    except Exception as e:  # pragma: no cover - the single-thread figure stands on its own
+        out["all_cores"] = {"error": repr(e)}
+    try:
+        import scipy.ndimage
+
+        m = 4096
+        sub = dem[:m, :m]
+        ks = terrain_oracle.conv_kernels("florinsky")
+        t0 = time.perf_counter()
+        for name, (tab, (const, power)) in ks.items():
+            scipy.ndimage.convolve(sub, tab.astype(np.float64) / (const * 10.0**power), mode="constant", cval=np.nan)
+        dt2 = time.perf_counter() - t0
+        out["scipy_convolve"] = {"value": round(m * m / dt2 / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference primitive",
+                                 "sample": f"scipy.ndimage.convolve x 5 Florinsky kernels on {m}x{m} float32 (the surface-fit half of "
+                                           f"the reference engine, xdem/spatialstats.py:2521-2525), {dt2:.1f} s"}
+    except Exception as e:  # pragma: no cover
+        out["scipy_convolve"] = {"error": repr(e)}
+    return out
 
 
 def measured_traffic_bytes(pixels_per_launch: int):
@@ -58,7 +108,7 @@ def measured_traffic_bytes(pixels_per_launch: int):
         try:
             d = json.load(open(f))
             if int(d.get("_pixels_per_launch", 40000 * 40000)) == int(pixels_per_launch):
-                best = (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
+                best = ((2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0, os.path.basename(f))
         except Exception:
             pass
     return best
@@ -98,9 +148,13 @@ def secondary_cpu_baselines() -> dict:
     return out
 
 
+VALU_PEAK_TLANEOPS = 39.3   # MI355X: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = one wave64 VALU instruction per 4 cycles and SIMD
+PAIR_OPS_MODEL = 12         # ~12 VALU operations per pair (2 sub, 2 fma, |dv|, <= 6 compares, 1 accumulate)
+
+
 def secondary_metrics(ctx, dev) -> dict:
     """The other two hot paths at BASELINE.json's configurations (reported next to the headline metric, not part of
-    `value`): C5 reading B of SURVEY.md 8d for the variogram, C3 for Nuth-Kaab."""
+    `value`): C5 reading B of SURVEY.md 8d for the variogram, C3 for Nuth-Kaab, each with its roofline object."""
     import numpy as np
     import torch
 
@@ -109,13 +163,15 @@ def secondary_metrics(ctx, dev) -> dict:
     from xdem_amd.synth import fbm_torch
 
     out = {}
-    # variogram C5-B: 1e7 sampled points = 100 runs x (9091 centre + 90910 ring points), 8.3e10 pairs, 50 lag classes
+    # variogram C5-B: 1e7 sampled points = 100 runs x (9091 centre + 90910 ring points), 8.3e10 pairs, 50 lag classes.
+    # Points are PIXELS of a 20000^2 raster with gsd 1 (the reference's samplers draw raster pixels), i.e. integer
+    # lattice coordinates: the pair kernels run their integer-lattice form.
     rng = np.random.default_rng(45)
-    runs, samples, rings, L = 100, 9091, 10, 20000.0
+    runs, samples, rings, L = 100, 9091, 10, 20000
     blocks = []
     for _ in range(runs):
-        ax, ay = rng.uniform(0, L, samples), rng.uniform(0, L, samples)
-        bx, by = rng.uniform(0, L, samples * rings), rng.uniform(0, L, samples * rings)
+        ax, ay = rng.integers(0, L, samples).astype(np.float64), rng.integers(0, L, samples).astype(np.float64)
+        bx, by = rng.integers(0, L, samples * rings).astype(np.float64), rng.integers(0, L, samples * rings).astype(np.float64)
         av = (np.sin(ax / 900.0) + 0.2 * rng.normal(size=samples)).astype(np.float32)
         bv = (np.sin(bx / 900.0) + 0.2 * rng.normal(size=samples * rings)).astype(np.float32)
         blocks.append((ax, ay, av, bx, by, bv))
@@ -127,34 +183,71 @@ def secondary_metrics(ctx, dev) -> dict:
     t0 = time.perf_counter()
     ss.class_medians(ps)
     dt = time.perf_counter() - t0
-    out["variogram"] = {"pairs": ps.n_pairs, "lag_classes": 50, "matheron_pass_Gpairs_s": round(ps.n_pairs / ms / 1e6, 1),
-                        "dowd_exact_median_Gpairs_s": round(ps.n_pairs / dt / 1e9, 2),
-                        "note": "C5 (reading B): 100 blocks of 9091 x 90910 points, f32 values; Matheron = one pair pass; "
-                                "Dowd = exact per-class median of |dv| (bracketed selection: sampled digit passes, one "
-                                "counting + compaction pass over all pairs, exact selection among the candidates; wall time)"}
+    mat_rate = ps.n_pairs / ms / 1e6      # Gpairs/s
+    dowd_rate = ps.n_pairs / dt / 1e9
+    out["variogram"] = {"pairs": ps.n_pairs, "lag_classes": 50, "matheron_pass_Gpairs_s": round(mat_rate, 1),
+                        "dowd_exact_median_Gpairs_s": round(dowd_rate, 2),
+                        "roofline": {"bound": "valu", "model": f"{PAIR_OPS_MODEL} VALU lane-operations per pair (SURVEY 8d); bytes per pair ~ 0",
+                                     "achieved": round(PAIR_OPS_MODEL * mat_rate / 1e3, 2), "achieved_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3, 2),
+                                     "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                                     "frac": round(PAIR_OPS_MODEL * mat_rate / 1e3 / VALU_PEAK_TLANEOPS, 4),
+                                     "frac_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3 / VALU_PEAK_TLANEOPS, 4),
+                                     "instr_per_pair": "see profiles/README.md (SQ_INSTS_VALU of the pair kernels, rocprofv3 --pmc)"},
+                        "note": "C5 (reading B): 100 blocks of 9091 x 90910 raster pixels (integer-lattice pair kernels), f32 values; "
+                                "Matheron = one pair pass; Dowd = exact per-class median of |dv| (bracketed selection: sampled digit "
+                                "passes, one counting + compaction pass over all pairs, exact selection among the candidates; wall time)"}
     ps.close()
     del blocks
-    # Nuth-Kaab C3: 20000^2 pair, tba = ref shifted + 2 m, 20 % NaN in contiguous gaps; iteration steps on the full grid
+    # Nuth-Kaab C3: ref = fBm 20000^2 (seed 42); tba = ref bilinearly shifted by (+1.7, -0.6) px + 2.0 m + N(0, 0.5 m)
+    # (seed 43); 20 % NaN in contiguous gaps (threshold of an independent smooth field, seed 44) applied to tba;
+    # NuthKaab(max_iterations=10, offset_threshold=0, subsample=1): exactly 10 iterations on the full grid.
     m = 20000
     ref = fbm_torch(m, m, dev, seed=42)
-    tba = torch.roll(ref, shifts=(1, -2), dims=(0, 1)) + 2.0
+    fx, fy = 0.7, 0.6   # fractional parts of the (+1.7 col, -0.6 row) shift; integer parts by roll
+    a = torch.roll(ref, shifts=(0, -1), dims=(0, 1))
+    tba = ((1 - fy) * ((1 - fx) * a + fx * torch.roll(a, shifts=(0, -1), dims=(0, 1)))
+           + fy * torch.roll((1 - fx) * a + fx * torch.roll(a, shifts=(0, -1), dims=(0, 1)), shifts=(1, 0), dims=(0, 1)))
+    del a
+    g = torch.Generator(device=dev)
+    g.manual_seed(43)
+    tba += 2.0 + 0.5 * torch.randn((m, m), generator=g, device=dev, dtype=torch.float32)
     hole = fbm_torch(m, m, dev, seed=44)
     thr = torch.quantile(hole[::16, ::16].flatten(), 0.2)
     tba[hole < thr] = float("nan")
     del hole
     torch.cuda.synchronize(dev)
+    res = (10.0, 10.0)
     plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
-    plan.step(0.0, 0.0, (10.0, 10.0), 72)
+    plan.step(0.0, 0.0, res, 72)
     t0 = time.perf_counter()
     k = 3
     for i in range(k):
-        r = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
+        r = plan.step(3.0 + i, -4.0, res, 72)
     dt = (time.perf_counter() - t0) / k
-    out["nuthkaab"] = {"grid": f"{m}x{m}", "valid_fraction": round(r["n_valid"] / (m * m), 3),
-                       "Mpixel_iterations_s": round(m * m / dt / 1e6, 1), "ms_per_iteration": round(dt * 1e3, 2),
-                       "note": "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32), "
-                               "host 72-point fit excluded"}
+    import scipy.optimize
+
+    t0 = time.perf_counter()
+    offsets = coreg._iterate(plan, res, 0.0, 10, 72, scipy.optimize.curve_fit, True)
+    dt_fit = (time.perf_counter() - t0) / 10
     plan.close()
+    px = float(m) * m
+    passes = 2  # full passes over the pair per iteration: (dh + global-median counting) and (aspect-bin counting)
+    out["nuthkaab"] = {"grid": f"{m}x{m}", "valid_fraction": round(r["n_valid"] / (m * m), 3),
+                       "Mpixel_iterations_s": round(px / dt / 1e6, 1), "ms_per_iteration": round(dt * 1e3, 2),
+                       "ms_per_iteration_whole_fit": round(dt_fit * 1e3, 2),
+                       "fitted_shift_px": [round(-offsets[0] / res[0], 3), round(-offsets[1] / res[1], 3), round(offsets[2], 3)],
+                       "roofline": {"bound": "hbm", "model": "SURVEY 8d: 8 B/pixel (ref + tba) per data pass x P passes required by the exact "
+                                             "medians; P = 2 here (bracketed selections: one counting pass each for the global median and "
+                                             "the 72 aspect bins; plain radix passes would need 12)",
+                                    "passes": passes, "achieved": round(8 * passes * px / dt / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": round(8 * passes * px / dt / 1e9 / HBM_PEAK_GBPS, 4),
+                                    "touched_bytes_per_pixel": 31,
+                                    "touched_GBps": round(31 * px / dt / 1e9, 1),
+                                    "note": "the passes actually touch ~31 B/pixel (dh pass: ref 4 + tba taps ~6 + aspect 4 + mask 1 + dh out 4; "
+                                            "bin pass: dh 4 + slope_tan 4 + aspect 4): the aux rasters are stored, not recomputed"},
+                       "note": "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32); "
+                               "ms_per_iteration = grid work of a step (host 72-point fit excluded), ms_per_iteration_whole_fit = "
+                               "NuthKaab's 10-iteration loop incl. scipy curve_fit, per iteration"}
     return out
 
 
@@ -244,7 +337,8 @@ def main() -> None:
     if rank == 0:
         total_px = float(n) * n
         res = {
-            "metric": f"Mpixels/s full terrain-attribute set, {n}\u00b2 f32 DEM",
+            "metric": f"Mpixels/s full terrain-attribute set, {n}\u00b2 f32 DEM; variogram Gpairs/s"
+                      + ("" if (world == 1 and not args.no_secondary) else " (this line: terrain half only)"),
             "value": round(total_px * args.steps / elapsed / 1e6, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -263,9 +357,14 @@ def main() -> None:
                        "bytes_per_pixel": BYTES_PER_PIXEL},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": (lambda t: None if t is None else round(t / (kernel_ms * 1e-3) / 1e9, 1))(
+                         "traffic": (lambda t: None if t is None else round(t[0] / (kernel_ms * 1e-3) / 1e9, 1))(
                              measured_traffic_bytes(px_launch) if world == 1 else None),
-                         "traffic_bytes_per_launch": measured_traffic_bytes(px_launch) if world == 1 else None,
+                         "traffic_bytes_per_launch": (lambda t: None if t is None else t[0])(
+                             measured_traffic_bytes(px_launch) if world == 1 else None),
+                         "traffic_source": (lambda t: None if t is None else
+                                            f"profiles/{t[1]}: rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE), "
+                                            "a committed profile, not re-measured in this run")(
+                             measured_traffic_bytes(px_launch) if world == 1 else None),
                          "kernel": "terrain_tile_kernel<Florinsky,curv,win,f32,f32>",
                          "kernel_ms": round(kernel_ms, 4), "pixels_per_launch": px_launch},
         }

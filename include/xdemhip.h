@@ -87,6 +87,11 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
  * non-finite or outside, zero weights included), 1 "weighted" (zero-weight taps ignored: integer shifts keep the last row
  * and column), 2 "dilate3x3" (NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite value).  Read when a
  * plan is created / a resample is launched.
+ * "vario_edge": lag classes of the pair kernels, 0 = [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]; "vario_diff": |dv| formed
+ * 0 = in the value dtype (default), 1 = in float64 (float32 values widened at xdemhip_pairs_create) -- the two scikit-gstat
+ * conventions that nothing readable offline pins (oracle/pin_thirdparty.py regenerates fixtures for them where the package
+ * is importable).  "vario_grid": 1 (default) = raster-sampled points (coordinates on an integer lattice) run the
+ * integer-lattice pair kernels, 0 = always the float64-coordinate kernels; classes and results are identical.
  * "terrain_store" / "terrain_rows" / "terrain_math": measurement switches of the fused terrain kernel (0 = default each):
  * staged 1 KiB row stores, tile height, float64 attribute math for float32 rasters.
  * "pairs_launch_cap": workgroups per launch of the variogram pair passes (0 = default 2^31 / workgroup size, the most a HIP

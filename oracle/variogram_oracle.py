@@ -86,31 +86,36 @@ def _estimate(diffs: np.ndarray, estimator: str) -> float:
     raise ValueError(estimator)
 
 
-def pair_groups(ax, ay, bx, by, edges):
-    """Lag class of every pair (rows = a, cols = b): k with e_{k-1} <= d < e_k, or -1."""
+def pair_groups(ax, ay, bx, by, edges, right_closed: bool = False):
+    """Lag class of every pair (rows = a, cols = b): k with e_{k-1} <= d < e_k (``right_closed``: e_{k-1} < d <= e_k), or -1.
+    (Which of the two scikit-gstat uses is unpinned offline: the product switches with the option "vario_edge".)"""
     d = np.sqrt((ax[:, None] - bx[None, :]) ** 2 + (ay[:, None] - by[None, :]) ** 2)
-    g = np.searchsorted(np.asarray(edges, dtype=np.float64), d, side="right")
+    g = np.searchsorted(np.asarray(edges, dtype=np.float64), d, side="left" if right_closed else "right")
     g[g >= len(edges)] = -1
     return g
 
 
-def empirical_variogram_blocks(blocks, edges, estimator: str = "matheron"):
+def empirical_variogram_blocks(blocks, edges, estimator: str = "matheron", right_closed: bool = False, diff_f64: bool = False):
     """exp float64[n], count int64[n] over the union of pair blocks.
 
     ``blocks`` is a list of (ax, ay, av, bx, by, bv) -- every a paired with every b (cdist) -- or (ax, ay, av)
-    -- all pairs i < j inside the set (pdist).  Values keep their dtype: |v_i - v_j| is formed in it.
+    -- all pairs i < j inside the set (pdist).  Values keep their dtype: |v_i - v_j| is formed in it, or in float64 with
+    ``diff_f64`` (the product's option "vario_diff": SciPy's pdist / cdist widen first).
     """
     n = len(edges)
     per_bin: list[list[np.ndarray]] = [[] for _ in range(n)]
     for blk in blocks:
         if len(blk) == 3:
             ax, ay, av = blk
+            av = av.astype(np.float64) if diff_f64 else av
             iu = np.triu_indices(ax.size, k=1)
-            g = pair_groups(ax, ay, ax, ay, edges)[iu]
+            g = pair_groups(ax, ay, ax, ay, edges, right_closed)[iu]
             diff = np.abs(av[:, None] - av[None, :])[iu]
         else:
             ax, ay, av, bx, by, bv = blk
-            g = pair_groups(ax, ay, bx, by, edges).ravel()
+            if diff_f64:
+                av, bv = av.astype(np.float64), bv.astype(np.float64)
+            g = pair_groups(ax, ay, bx, by, edges, right_closed).ravel()
             diff = np.abs(av[:, None] - bv[None, :]).ravel()
         for k in range(n):
             sel = diff[g == k]

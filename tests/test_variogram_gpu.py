@@ -385,3 +385,106 @@ def test_number_of_effective_samples(ss):
     big = np.stack(np.meshgrid(np.arange(300.0), np.arange(300.0)), -1).reshape(-1, 2) * 10.0
     ne = ss.neff_exact(big, np.ones(len(big)), m.iloc[:1])   # 90 000 points = 8.1e9 ordered pairs
     assert 100 < ne < len(big)
+
+
+@pytest.mark.parametrize("gsd,x0", [(1.0, 0.0), (10.0, 502810.0), (0.5, -37.25), (2.5, 1e6), (30.0, 7.0)])
+@pytest.mark.parametrize("estimator", ["matheron", "dowd", "cressie"])
+def test_integer_lattice_kernels_equal_float64_kernels(ss, gsd, x0, estimator):
+    """Raster-sampled points (coordinates x0 + gsd * integer, as the reference's samplers draw them, xdem/spatialstats.py:
+    1413-1416) run the integer-lattice pair kernels: packed int16 indexes, one v_pk_sub_i16 + one v_dot2_i32_i16 per squared
+    distance, integer thresholds that are the exact pre-images of the float64 ones.  Classes, counts and estimates must be
+    IDENTICAL to the float64-coordinate kernels (option "vario_grid" = 0) and equal the oracle -- including pairs exactly on a
+    class edge (edges = gsd * integers and gsd * sqrt(2)-geometric)."""
+    from xdem_amd import _lib
+
+    ctx = _lib.default_context()
+    r = np.random.default_rng(17)
+
+    def pts(n, extent):
+        ix, iy = r.integers(0, extent, n), r.integers(0, extent, n)
+        v = np.round(np.sin(ix / 40.0) + 0.3 * r.normal(size=n), 3).astype(np.float32)
+        return x0 + gsd * ix, (x0 / 3) + gsd * iy, v
+
+    blocks_c = [pts(300, 900) + pts(2500, 900), pts(257, 30000) + pts(4097, 30000), pts(1, 5) + pts(3, 5)]
+    blocks_p = [pts(700, 600), pts(1025, 20000)]
+    edges = sorted(set([gsd * e for e in (1.0, 2.0, 3.0, 5.0, 13.0, 25.0, 100.0)] + [gsd * np.sqrt(2) ** k for k in range(1, 30)]))
+    for blocks in (blocks_c, blocks_p):
+        got = {}
+        for grid in (1, 0):
+            ctx.set_option("vario_grid", grid)
+            try:
+                got[grid] = ss.empirical_variogram_pairs(blocks, edges, estimator, ctx)
+            finally:
+                ctx.set_option("vario_grid", 1)
+        assert np.array_equal(got[1][1], got[0][1])
+        if estimator == "dowd":
+            assert np.array_equal(got[1][0], got[0][0], equal_nan=True)
+        else:
+            assert np.allclose(got[1][0], got[0][0], rtol=1e-13, atol=0, equal_nan=True)
+        small = [b for b in blocks if b[0].size * (b[3].size if len(b) == 6 else b[0].size) < 3e6]
+        e1, c1 = ss.empirical_variogram_pairs(small, edges, estimator, ctx)
+        eo, co = vo.empirical_variogram_blocks(small, edges, estimator)
+        assert np.array_equal(c1, co)
+        ok = np.isfinite(eo)
+        assert np.allclose(e1[ok], eo[ok], rtol=1e-12, atol=0)
+
+
+def test_lattice_path_refuses_what_it_cannot_represent(ss):
+    """Off-lattice points, lattices wider than 32767 cells and spacings whose squares are not exact fall back to the float64
+    kernels (same results as with the lattice kernels disabled)."""
+    from xdem_amd import _lib
+
+    ctx = _lib.default_context()
+    r = np.random.default_rng(5)
+    v = r.normal(size=900).astype(np.float32)
+    cases = [
+        (r.uniform(0, 500, 900), r.uniform(0, 500, 900)),                       # not a lattice
+        (r.integers(0, 40000, 900).astype(float), r.integers(0, 300, 900).astype(float)),  # too wide for int16
+        (r.integers(0, 500, 900) * 0.1, r.integers(0, 500, 900) * 0.1),          # 0.1 is not a dyadic multiple: rounded coordinates
+    ]
+    edges = [float(e) for e in vo.default_bin_edges(0.1, 60000.0)]
+    for x, y in cases:
+        res = {}
+        for grid in (1, 0):
+            ctx.set_option("vario_grid", grid)
+            try:
+                res[grid] = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron", ctx)
+            finally:
+                ctx.set_option("vario_grid", 1)
+        assert np.array_equal(res[1][1], res[0][1]) and np.allclose(res[1][0], res[0][0], rtol=1e-13, atol=0, equal_nan=True)
+        eo, co = vo.empirical_variogram_blocks([(x, y, v)], edges, "matheron")
+        assert np.array_equal(res[1][1], co)
+
+
+def test_switchable_scikit_gstat_conventions(ss):
+    """The two conventions of scikit-gstat that nothing readable offline pins are options, each checked against the oracle's
+    implementation of the same choice: "vario_edge" (a distance exactly on an edge: [e_{k-1}, e_k) vs (e_{k-1}, e_k]) and
+    "vario_diff" (|dv| in the value dtype vs float64)."""
+    from xdem_amd import _lib
+
+    ctx = _lib.default_context()
+    r = np.random.default_rng(8)
+    ix, iy = r.integers(0, 60, 500), r.integers(0, 60, 500)
+    x, y = 2.0 * ix, 2.0 * iy
+    v = (np.sin(ix / 9.0) * 1000 + r.normal(size=500)).astype(np.float32)
+    edges = [2.0, 4.0, 10.0, 20.0, 26.0, 100.0, 200.0]      # 3-4-5 multiples: many pairs exactly on an edge
+    for edge in (0, 1):
+        for diff in (0, 1):
+            ctx.set_option("vario_edge", edge)
+            ctx.set_option("vario_diff", diff)
+            try:
+                for est in ("matheron", "dowd"):
+                    e, c = ss.empirical_variogram_pairs([(x, y, v)], edges, est, ctx)
+                    eo, co = vo.empirical_variogram_blocks([(x, y, v)], edges, est, right_closed=bool(edge), diff_f64=bool(diff))
+                    assert np.array_equal(c, co), (edge, diff, est)
+                    assert np.allclose(e, eo, rtol=1e-12, atol=0, equal_nan=True)
+            finally:
+                ctx.set_option("vario_edge", 0)
+                ctx.set_option("vario_diff", 0)
+    e0, c0 = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron", ctx)
+    ctx.set_option("vario_edge", 1)
+    try:
+        e1, c1 = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron", ctx)
+    finally:
+        ctx.set_option("vario_edge", 0)
+    assert not np.array_equal(c0, c1) and c0.sum() != 0   # the two conventions do differ on lattice data

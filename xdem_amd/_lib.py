@@ -169,6 +169,7 @@ class Context:
             )
         self.handle = h
         self.device = int(device)
+        self.options: dict[str, int] = {}  # mirror of the xdemhip_set_option calls made through this object
 
     def check(self, rc: int) -> None:
         if rc != OK:
@@ -200,6 +201,7 @@ class Context:
     def set_option(self, name: str, value: int) -> None:
         """Tuning / test switch of the library (``xdemhip_set_option``), e.g. ``("selection", 1)``."""
         self.check(self._L.xdemhip_set_option(self.handle, name.encode(), int(value)))
+        self.options[name] = int(value)
 
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_float()

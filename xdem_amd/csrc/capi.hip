@@ -108,6 +108,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->terrain_math = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "vario_grid" || std::string(name) == "vario_edge" || std::string(name) == "vario_diff") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, std::string(name) + ": 0 or 1");
+        (std::string(name) == "vario_grid" ? ctx->vario_grid : std::string(name) == "vario_edge" ? ctx->vario_edge : ctx->vario_diff) = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "nk_nan_rule") {
         if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_nan_rule: 0 4tap, 1 weighted, 2 dilate3x3");
         ctx->nk_nan_rule = value;

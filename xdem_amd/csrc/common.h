@@ -24,6 +24,9 @@ struct xdemhip_ctx {
     int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)
     int terrain_rows = 0;    // option "terrain_rows": tile height of the fused terrain kernel (0 automatic, 16, 24, 32)
     int terrain_math = 0;    // option "terrain_math": 0 mixed-precision tail for float32 rasters, 1 float64 tail everywhere
+    int vario_grid = 1;      // option "vario_grid": 1 = integer-lattice pair kernels for raster-sampled points (default), 0 = always float64 coordinates
+    int vario_edge = 0;      // option "vario_edge": lag classes 0 = [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]
+    int vario_diff = 0;      // option "vario_diff": |dv| formed 0 = in the value dtype (default), 1 = in float64 (float32 values are widened)
     int nk_nan_rule = 0;     // option "nk_nan_rule": nodata spreading of the bilinear taps (nuthkaab.hip): 0 4tap, 1 weighted, 2 dilate3x3
     int selection_mode = 0;  // 0 auto (bracketed for large inputs), 1 plain digit passes only, 2 degenerate brackets (tests the
                              // fallback), 3 bracketed whatever the per-bin sample size (2 and 3: test switches)

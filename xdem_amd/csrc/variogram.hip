@@ -47,6 +47,12 @@ template <typename T> struct PairArgs {
     const double* thr;  // nb thresholds on d^2
     const uint8_t* lut;  // [LUT_N] (class lower bound << 1 | cell holds a threshold) per 1/8 binade of d^2; nullptr: binary search
     int lut_emin;        // (biased exponent << 3 | top 3 mantissa bits) of LUT entry 0
+    // integer-lattice path (GRID kernels): points as packed int16 lattice indexes (x | y << 16), thresholds on the integer
+    // squared lattice distance, class lower bound per 1/8 binade of float(d2)
+    const uint32_t *a_xy, *b_xy;
+    const uint32_t* thr_i;   // [nb]
+    const uint8_t* lut_i;    // [LUT_N]
+    int lut_i_emin;
     // outputs / state
     double* sums;                  // [nb]
     unsigned long long* counts;    // [nb]
@@ -81,7 +87,14 @@ template <> __device__ __forceinline__ void lds_min<uint64_t>(uint64_t* p, uint6
 __device__ __forceinline__ uint32_t key_abs(float v) { return __float_as_uint(v) << 1; }
 __device__ __forceinline__ uint64_t key_abs(double v) { return (uint64_t)__double_as_longlong(v) << 1; }
 
-template <typename T, int OP, bool FAST, int NT>
+typedef short v2s16 __attribute__((ext_vector_type(2)));
+
+// GRID (implies FAST): the points lie on an integer lattice (raster pixel centres -- the reference's cdist / pdist samplers
+// draw raster pixels, xdem/spatialstats.py:1413-1416): coordinates are packed int16 lattice indexes, the squared lattice
+// distance of a pair is ONE v_pk_sub_i16 + ONE v_dot2_i32_i16, exact in 32 bits, and the class follows from integer
+// thresholds that are the exact pre-images of the float64 thresholds (host: make_grid) -- identical classes, a third fewer
+// instructions per pair than the float64 coordinates (5 float64 operations + a 64-bit compare).
+template <typename T, int OP, bool FAST, int NT, bool GRID = false>
 __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     typedef typename KeyT<T>::type K;
     // sampled digit passes: a workgroup none of whose (up to 16) B tiles is in the sample leaves before touching LDS (4 of 5 do;
@@ -98,7 +111,9 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     K* s_pref = reinterpret_cast<K*>(s_thr + a.nb + LUT_STEPS + 1);  // nb selection prefixes / selected keys / bracket lows (8-byte slots)
     K* s_khi = reinterpret_cast<K*>(reinterpret_cast<uint64_t*>(s_pref) + a.nb);  // nb bracket highs (8-byte slots)
     T* s_bv = reinterpret_cast<T*>(reinterpret_cast<uint64_t*>(s_khi) + a.nb);  // PT
-    unsigned char* acc = reinterpret_cast<unsigned char*>(s_bv + PT);            // PT * sizeof(T) is a multiple of 8
+    uint32_t* s_bxy = reinterpret_cast<uint32_t*>(s_bv + PT);                    // PT packed lattice indexes (GRID)
+    uint32_t* s_thr_i = s_bxy + PT;                                              // nb + 2 integer thresholds (GRID), padded with all-ones
+    unsigned char* acc = reinterpret_cast<unsigned char*>(s_thr_i + ((a.nb + 2 + 1) & ~1));  // (8-byte aligned)
     // OP_SUMS: NCOPY privatised copies per class, copy = lane % 32: lanes of a wave that hit the same class land on
     // different banks (at most 2 lanes per address) instead of serialising 64-way on one LDS word
     // per class a 384-byte record: NCOPY float64 sums (256 B = all 64 LDS banks, one copy per lane % 32: conflict-free), then
@@ -119,8 +134,11 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
 
     __shared__ uint8_t s_lut[LUT_N];
     const int tid = threadIdx.x;
-    if (FAST && tid < LUT_N) s_lut[tid] = a.lut[tid];
+    if (FAST)  // (NT may be smaller than the table: round 1 loaded only its first NT entries -- wrong classes beyond 32 binades of d^2)
+        for (int k = tid; k < LUT_N; k += NT) s_lut[k] = GRID ? a.lut_i[k] : a.lut[k];
     for (int k = tid; k < a.nb + LUT_STEPS + 1; k += NT) s_thr[k] = k < a.nb ? a.thr[k] : (double)INFINITY;
+    if (GRID)
+        for (int k = tid; k < a.nb + 2; k += NT) s_thr_i[k] = k < a.nb ? a.thr_i[k] : 0xFFFFFFFFu;
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
         for (int k = tid; k < (a.nb + 1) * REC / 4; k += NT) reinterpret_cast<uint32_t*>(s_rec)[k] = 0u;
     unsigned char* const s_sum_cp = s_rec + (tid & (NCOPY - 1)) * 8;              // this lane's privatised copies
@@ -161,9 +179,15 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     const bool skip_wg = a.pdist && (jb1 <= ta * NT + 1);  // whole chunk at or below the diagonal: no i < j pair
     double px = 0.0, py = 0.0;
     T pv = 0;
-    if (have_a) { px = a.ax[a0 + ia]; py = a.ay[a0 + ia]; pv = a.av[a0 + ia]; }
+    uint32_t pxy = 0;
+    if (have_a) {
+        if (GRID) pxy = a.a_xy[a0 + ia];
+        else { px = a.ax[a0 + ia]; py = a.ay[a0 + ia]; }
+        pv = a.av[a0 + ia];
+    }
     const double* gbx = a.pdist ? a.ax : a.bx;
     const double* gby = a.pdist ? a.ay : a.by;
+    const uint32_t* gbxy = a.pdist ? a.a_xy : a.b_xy;
     const T* gbv = a.pdist ? a.av : a.bv;
     const int nb = a.nb;
     const K himask = (OP == OP_HIST && !a.first) ? (K)(~(K)0 << (a.shift + 8)) : (K)0;
@@ -177,8 +201,8 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 __syncthreads();
             const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
             if (tid < cnt) {
-                s_bx[tid] = gbx[b0 + j0 + tid];
-                s_by[tid] = gby[b0 + j0 + tid];
+                if (GRID) s_bxy[tid] = gbxy[b0 + j0 + tid];
+                else { s_bx[tid] = gbx[b0 + j0 + tid]; s_by[tid] = gby[b0 + j0 + tid]; }
                 s_bv[tid] = gbv[b0 + j0 + tid];
             }
             __syncthreads();
@@ -239,6 +263,51 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 }
             };
 
+            // classes of the 4 pairs (this lane's A point) x (tile slots j .. j + 3) and their raw value differences, written
+            // stage by stage so that the B-point reads, the table reads and the threshold reads are each issued back to back
+            auto classify4 = [&](int j, int (&lu)[4], T (&dv)[4]) {
+                if constexpr (GRID) {
+                    uint32_t d2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                        d2[u] = (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+                        dv[u] = pv - s_bv[j + u];
+                    }
+                    int l[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int e = (int)(__float_as_uint((float)d2[u]) >> 20) - a.lut_i_emin;  // 1/8-binade cell of float(d2) (monotone in d2)
+                        e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                        l[u] = s_lut[e];
+                    }
+                    uint32_t th[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) th[u] = s_thr_i[l[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) lu[u] = l[u] + ((th[u] <= d2[u]) ? 1 : 0);
+                } else {
+                    double s2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
+                        s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
+                        dv[u] = pv - s_bv[j + u];
+                    }
+                    int l[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
+                        e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                        l[u] = s_lut[e] >> 1;
+                    }
+                    double th[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];  // next threshold above the cell's lower bound
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) lu[u] = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
+                }
+            };
             if (FAST) {
                 // 4 pairs per trip, written stage by stage so that the 4 B-point reads, the 4 table reads and the 4
                 // threshold reads are each issued back to back (one LDS round trip per stage instead of per pair).
@@ -251,29 +320,13 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                                         (!a.pdist || j0 >= (ta + 1) * (int64_t)NT);
                 if (plain_tile) {
                     for (int j = 0; j < PT; j += 4) {
-                        double s2[4];
+                        int lu[4];
                         T dv[4];
+                        classify4(j, lu, dv);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
-                            s2[u] = dx * dx + dy * dy;
-                            dv[u] = pv - s_bv[j + u];
-                        }
-                        int l[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
-                            e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
-                            l[u] = s_lut[e] >> 1;
-                        }
-                        double th[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int lu = l[u] + ((th[u] <= s2[u]) ? 1 : 0);
                             const double dd = (double)dv[u];
-                            rec_add(lu, OP == OP_SUMS_SQ ? dd * dd : sqrt(fabs(dd)));
+                            rec_add(lu[u], OP == OP_SUMS_SQ ? dd * dd : sqrt(fabs(dd)));
                         }
                     }
                     continue;
@@ -281,28 +334,13 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 auto run4 = [&](auto plain_tag) {
                     constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
                     for (int j = 0; j < cnt; j += 4) {
-                        double s2[4];
+                        int lus[4];
                         T dv[4];
+                        classify4(j, lus, dv);
     #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
-                            s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
-                            const T d = pv - s_bv[j + u];
-                            dv[u] = d < 0 ? -d : d;
-                        }
-                        int l[4];
-    #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
-                            e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
-                            l[u] = s_lut[e] >> 1;
-                        }
-                        double th[4];
-    #pragma unroll
-                        for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];  // next threshold above the cell's lower bound
-    #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int lu = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
+                            const int lu = lus[u];
+                            dv[u] = dv[u] < 0 ? -dv[u] : dv[u];
                             const T d = dv[u];
                             const bool ok = (PLAIN || ((j + u) < cnt && (j + u) > ia_rel && d == d)) && lu < nb;
                             if (OP == OP_BRACKET) {
@@ -373,6 +411,11 @@ struct xdemhip_pairs {
     double *thr = nullptr, *sums = nullptr;
     uint8_t* lut = nullptr;  // null when the edges are too dense for the binade table
     int lut_emin = 0;
+    // integer-lattice path (make_grid): packed int16 lattice indexes, integer thresholds, class table over float(d2)
+    uint32_t *a_xy = nullptr, *b_xy = nullptr, *thr_i = nullptr;
+    uint8_t* lut_i = nullptr;
+    int lut_i_emin = 0;
+    bool grid = false;
     unsigned long long *counts = nullptr, *hist = nullptr;
     void *prefix = nullptr, *succ = nullptr;
     int64_t n_wg = 0, n_wg_big = 0, n_pairs = 0;
@@ -390,7 +433,7 @@ namespace {
 constexpr int HIST_BINS_PER_SWEEP = 128;
 
 template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
-    size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8;
+    size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8 + 4 * (size_t)(PT + nb + 4);
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
     if (op == OP_BRACKET) return base + (size_t)3 * nb * NCOPY * 4 + 8 + (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
@@ -405,6 +448,7 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     a.av = static_cast<const T*>(P->av); a.bv = static_cast<const T*>(P->bv);
     a.a_off = P->a_off; a.b_off = P->b_off; a.wg_off = (NT == 1024) ? P->wg_off_big : P->wg_off;
     a.nblk = P->nblk; a.nb = P->nb; a.pdist = P->pdist; a.thr = P->thr; a.lut = P->lut; a.lut_emin = P->lut_emin;
+    a.a_xy = P->a_xy; a.b_xy = P->b_xy; a.thr_i = P->thr_i; a.lut_i = P->lut_i; a.lut_i_emin = P->lut_i_emin;
     a.sums = P->sums; a.counts = P->counts; a.hist = P->hist;
     a.prefix = static_cast<const typename KeyT<T>::type*>(P->prefix);
     a.succ = static_cast<unsigned long long*>(P->succ);
@@ -418,12 +462,15 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     // HIP dispatches carry the TOTAL work-item count of a dimension in 32 bits (a larger grid x block product is silently
     // truncated): a pass over more workgroups than 2^31 / NT goes out as several launches, each told where it starts.
     const int64_t per_launch = ctx->pairs_launch_cap > 0 ? (int64_t)ctx->pairs_launch_cap : ((int64_t)1 << 31) / NT;
-    if (P->lut) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT>, lds)) return rc; }
+    const bool grid = P->grid && ctx->vario_grid != 0;
+    if (grid) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT, true>, lds)) return rc; }
+    else if (P->lut) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT>, lds)) return rc; }
     else { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, false, NT>, lds)) return rc; }
     for (int64_t w0 = 0; w0 < n_wg; w0 += per_launch) {
         const int64_t nw = (n_wg - w0) < per_launch ? (n_wg - w0) : per_launch;
         a.wg_base = w0;
-        if (P->lut) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
+        if (grid) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT, true>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
+        else if (P->lut) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
         else hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -444,6 +491,111 @@ double sq_threshold(double e) {
     return t;
 }
 
+// right-closed classes (context option "vario_edge" = 1): smallest double t with sqrt(t) > e
+double sq_threshold_strict(double e) {
+    if (!(e > 0)) return nextafter(0.0, INFINITY);
+    double t = e * e;
+    while (sqrt(t) > e) t = nextafter(t, 0.0);
+    while (!(sqrt(t) > e)) t = nextafter(t, INFINITY);
+    return t;
+}
+
+// 1/8-binade cell of float(d2) as the GRID kernels compute it (round-to-nearest conversion: monotone in d2)
+inline int cell_of_u32(uint32_t d2) {
+    const float f = (float)d2;
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    return (int)(b >> 20);
+}
+
+// Integer-lattice analysis of a pair set (host coordinates).  Succeeds when every coordinate is x0 + g * i (same g for x and
+// y, g = G * 2^-k with an integer G) with lattice indexes i < 32768, and when the float64 kernels' arithmetic is exact on
+// such points -- (g dx)^2 + (g dy)^2 < 2^53 -- so that their squared distance IS g^2 * d2 with d2 = dx^2 + dy^2 the integer
+// squared lattice distance.  Then class(d2) = #{k : T_k <= d2}, T_k = the smallest integer with g^2 T_k >= thr_k, is
+// identical to the float64 classification, pair by pair.
+struct GridInfo {
+    std::vector<uint32_t> a_xy, b_xy, thr_i;
+    std::vector<uint8_t> lut;
+    int emin = 0;
+};
+bool make_grid(const double* ax, const double* ay, int64_t na, const double* bx, const double* by, int64_t nbt, const std::vector<double>& thr,
+               GridInfo& out) {
+    auto scan = [&](auto&& f) {
+        for (int64_t i = 0; i < na; ++i) { if (!f(ax[i], 0) || !f(ay[i], 1)) return false; }
+        for (int64_t i = 0; i < nbt; ++i) { if (!f(bx[i], 0) || !f(by[i], 1)) return false; }
+        return true;
+    };
+    if (na + nbt == 0) return false;
+    // 1. a power-of-two scale that makes every coordinate an integer below 2^52
+    int k = -1;
+    for (int kk = 0; kk <= 20 && k < 0; ++kk) {
+        const double sc = ldexp(1.0, kk);
+        if (scan([&](double v, int) { const double w = v * sc; return std::isfinite(v) && fabs(w) < 4.5e15 && w == floor(w); })) k = kk;
+    }
+    if (k < 0) return false;
+    const double sc = ldexp(1.0, k);
+    double mn[2] = {INFINITY, INFINITY};
+    scan([&](double v, int ax_) { const double w = v * sc; mn[ax_] = w < mn[ax_] ? w : mn[ax_]; return true; });
+    // 2. lattice constant: gcd of all offsets from the minima
+    unsigned long long G = 0;
+    auto gcd = [](unsigned long long a_, unsigned long long b_) { while (b_) { const unsigned long long t = a_ % b_; a_ = b_; b_ = t; } return a_; };
+    scan([&](double v, int ax_) { G = gcd(G, (unsigned long long)(v * sc - mn[ax_])); return true; });
+    if (G == 0) G = 1;
+    // 3. index range and exactness of the float64 arithmetic on these points
+    unsigned long long imax = 0;
+    scan([&](double v, int ax_) { const unsigned long long i = (unsigned long long)(v * sc - mn[ax_]) / G; imax = i > imax ? i : imax; return true; });
+    if (imax > 32767ull) return false;
+    if ((long double)G * (long double)imax >= 67108864.0L) return false;  // (G dx)^2 + (G dy)^2 < 2^53
+    auto pack = [&](const double* x, const double* y, int64_t n, std::vector<uint32_t>& o) {
+        o.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            const uint32_t ix = (uint32_t)((unsigned long long)(x[i] * sc - mn[0]) / G), iy = (uint32_t)((unsigned long long)(y[i] * sc - mn[1]) / G);
+            o[(size_t)i] = ix | (iy << 16);
+        }
+    };
+    pack(ax, ay, na, out.a_xy);
+    if (bx) pack(bx, by, nbt, out.b_xy);
+    // 4. integer thresholds: smallest n with g2 * n >= thr, g2 = G^2 * 2^-2k (g2 * n is exact in float64 for n <= 2 imax^2)
+    const double g2 = ldexp((double)G * (double)G, -2 * k);
+    const unsigned long long nmax = 2ull * imax * imax;
+    out.thr_i.resize(thr.size());
+    for (size_t q = 0; q < thr.size(); ++q) {
+        const long double est = (long double)thr[q] / (long double)g2;
+        unsigned long long n = est >= 4.0e9L ? 0xFFFFFFFFull : (unsigned long long)ceill(est);
+        if (n <= nmax + 2) {  // refine with exact products (n inside the exactly representable range)
+            while (n > 0 && g2 * (double)(n - 1) >= thr[q]) --n;
+            while (g2 * (double)n < thr[q]) ++n;
+        } else if (n > 0xFFFFFFFFull) {
+            n = 0xFFFFFFFFull;
+        }
+        out.thr_i[q] = (uint32_t)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n);
+    }
+    // 5. class table over the cells of float(d2): entry = classes whose threshold lies at or below the cell's first d2; a cell
+    // may hold at most one more threshold (checked), which the kernel resolves with one integer compare
+    out.emin = cell_of_u32(1) - 1;
+    out.lut.assign(LUT_N, 0);
+    auto first_in_cell = [&](int c) -> unsigned long long {  // smallest d2 with cell(d2) >= c (2^32 if none)
+        unsigned long long lo = 0, hi = 0x100000000ull;
+        while (lo < hi) {
+            const unsigned long long mid = (lo + hi) >> 1;
+            if (cell_of_u32((uint32_t)mid) >= c) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    if (thr.size() > 255) return false;
+    for (int i = 0; i < LUT_N; ++i) {
+        const unsigned long long lo = i == 0 ? 0 : first_in_cell(out.emin + i), hi = i == LUT_N - 1 ? 0x100000000ull : first_in_cell(out.emin + i + 1);
+        int below = 0, inside = 0;
+        for (size_t q = 0; q < thr.size(); ++q) {
+            below += (unsigned long long)out.thr_i[q] <= lo;
+            inside += ((unsigned long long)out.thr_i[q] > lo && (unsigned long long)out.thr_i[q] < hi);
+        }
+        if (inside > 1) return false;
+        out.lut[i] = (uint8_t)below;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -455,7 +607,8 @@ void xdemhip_pairs_destroy(xdemhip_pairs* P) {
         void* b[] = {P->ax, P->ay, P->bx, P->by, P->av, P->bv};
         for (void* p : b) if (p) (void)hipFree(p);
     }
-    void* b2[] = {P->a_off, P->b_off, P->wg_off, P->wg_off_big, P->thr, P->sums, P->counts, P->hist, P->prefix, P->succ, P->lut};
+    void* b2[] = {P->a_off, P->b_off, P->wg_off, P->wg_off_big, P->thr, P->sums, P->counts, P->hist, P->prefix, P->succ, P->lut,
+                  P->a_xy, P->b_xy, P->thr_i, P->lut_i};
     for (void* p : b2) if (p) (void)hipFree(p);
     delete P;
 }
@@ -472,6 +625,21 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     for (int k = 1; k < n_bins; ++k)
         if (!(right_edges[k] > right_edges[k - 1])) return xd_fail(ctx, XDEMHIP_EINVAL, "right_edges must be strictly increasing");
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // context option "vario_diff" = 1: |dv| in float64 whatever the value dtype (SciPy's pdist / cdist, which scikit-gstat builds
+    // on, widen to float64 first): float32 values are widened here, every pass then runs the float64 instantiation
+    std::vector<double> wide_a, wide_b;
+    if (ctx->vario_diff && val_dtype == XDEMHIP_F32 && memspace == XDEMHIP_HOST) {
+        const int64_t na0 = a_off[n_blocks], nb0 = pd ? 0 : b_off[n_blocks];
+        wide_a.resize((size_t)na0);
+        for (int64_t i = 0; i < na0; ++i) wide_a[(size_t)i] = (double)static_cast<const float*>(av)[i];
+        av = wide_a.data();
+        if (!pd) {
+            wide_b.resize((size_t)nb0);
+            for (int64_t i = 0; i < nb0; ++i) wide_b[(size_t)i] = (double)static_cast<const float*>(bv)[i];
+            bv = wide_b.data();
+        }
+        val_dtype = XDEMHIP_F64;
+    }
     xdemhip_pairs* P = new xdemhip_pairs();
     P->ctx = ctx; P->val_dtype = val_dtype; P->nblk = n_blocks; P->nb = n_bins; P->pdist = pd;
     const size_t es = val_dtype == XDEMHIP_F32 ? 4 : 8;
@@ -489,7 +657,8 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     P->n_wg_big = wgb[n_blocks];
     P->n_pairs = pairs;
     std::vector<double> thr(n_bins);
-    for (int k = 0; k < n_bins; ++k) thr[k] = sq_threshold(right_edges[k]);
+    // context option "vario_edge": 0 = classes [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]
+    for (int k = 0; k < n_bins; ++k) thr[k] = ctx->vario_edge ? sq_threshold_strict(right_edges[k]) : sq_threshold(right_edges[k]);
     // Class lookup table over d^2: cell i covers [lo_i, lo_{i+1}) with lo_i the double whose top 15 bits (biased
     // exponent, first 3 mantissa bits) are emin + i; entry = (number of thresholds <= lo_i) << 1 | (a threshold lies
     // inside the cell).  Used only if no cell holds more than one threshold and there are < 128 classes (true for the
@@ -552,6 +721,22 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
             (void)hipMemcpyAsync(P->bx, bx, 8 * nbt, hipMemcpyHostToDevice, ctx->stream);
             (void)hipMemcpyAsync(P->by, by, 8 * nbt, hipMemcpyHostToDevice, ctx->stream);
             (void)hipMemcpyAsync(P->bv, bv, es * nbt, hipMemcpyHostToDevice, ctx->stream);
+        }
+        // raster-sampled points (the reference's samplers draw pixels): integer-lattice kernels
+        GridInfo gi;
+        if (lut_ok && ctx->vario_grid != 0 && make_grid(ax, ay, na, pd ? nullptr : bx, pd ? nullptr : by, nbt, thr, gi)) {
+            XD_ALLOC(P->a_xy, 4 * na);
+            XD_ALLOC(P->thr_i, 4 * n_bins);
+            XD_ALLOC(P->lut_i, LUT_N);
+            XD_HIP_CHECK(ctx, hipMemcpy(P->a_xy, gi.a_xy.data(), 4 * (size_t)na, hipMemcpyHostToDevice));
+            XD_HIP_CHECK(ctx, hipMemcpy(P->thr_i, gi.thr_i.data(), 4 * (size_t)n_bins, hipMemcpyHostToDevice));
+            XD_HIP_CHECK(ctx, hipMemcpy(P->lut_i, gi.lut.data(), LUT_N, hipMemcpyHostToDevice));
+            if (!pd) {
+                XD_ALLOC(P->b_xy, 4 * nbt);
+                XD_HIP_CHECK(ctx, hipMemcpy(P->b_xy, gi.b_xy.data(), 4 * (size_t)nbt, hipMemcpyHostToDevice));
+            }
+            P->lut_i_emin = gi.emin;
+            P->grid = true;
         }
     } else {
         P->ax = const_cast<double*>(ax); P->ay = const_cast<double*>(ay); P->av = const_cast<void*>(av);

@@ -37,7 +37,10 @@ class PairSet:
         pd = len(blocks[0]) == 3
         if any((len(b) == 3) != pd for b in blocks):
             raise ValueError("cannot mix pdist and cdist blocks")
+        self.ctx = ctx or _lib.default_context()
         vdt = np.float64 if any(np.asarray(b[2]).dtype == np.float64 for b in blocks) else np.float32
+        if self.ctx.options.get("vario_diff"):
+            vdt = np.float64  # option "vario_diff" = 1: |dv| in float64 whatever the value dtype (values are widened)
         cat = lambda i, dt: np.ascontiguousarray(np.concatenate([np.asarray(b[i], dtype=dt).ravel() for b in blocks]))
         off = lambda i: np.ascontiguousarray(np.concatenate([[0], np.cumsum([np.asarray(b[i]).size for b in blocks])]), dtype=np.int64)
         self._keep = [off(0), cat(0, np.float64), cat(1, np.float64), cat(2, vdt)]
@@ -47,7 +50,6 @@ class PairSet:
         self.nb = int(self.edges.size)
         self.vdtype = np.dtype(vdt)
         self.key_bits = 32 if vdt == np.float32 else 64
-        self.ctx = ctx or _lib.default_context()
         p = [a.ctypes.data for a in self._keep] + ([None] * 4 if pd else [])
         h, n_pairs = ctypes.c_void_p(), ctypes.c_int64()
         self.ctx.check(self.ctx._L.xdemhip_pairs_create(
