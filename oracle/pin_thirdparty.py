@@ -1,0 +1,97 @@
+"""Pins for the two third-party boundaries that nothing readable offline fixes -- run wherever geoutils and scikit-gstat
+are importable (they are un-vendored dependencies of the reference, absent from the build image):
+
+    python oracle/pin_thirdparty.py            # writes tests/golden/thirdparty_interp.npz / thirdparty_skgstat.npz
+
+TEST INFRASTRUCTURE (like everything under oracle/).  The script records INPUTS and the packages' OUTPUTS only:
+
+* geoutils ``_interp_points`` exactly as the reference calls it from the Nuth-Kaab loop (xdem/coreg/affine.py:172-184 via
+  xdem/coreg/base.py:1642-1649): a small DEM with NaN holes, sampled at the shifted pixel centres for integer, half-pixel
+  and generic shifts -> which of the product's ``nk_nan_rule`` conventions (0 "4tap", 1 "weighted", 2 "dilate3x3") is
+  geoutils' is then decided by tests/test_thirdparty_pins.py, which compares every rule of the ORACLE with the recording;
+* scikit-gstat ``Variogram`` exactly as xdem/spatialstats.py:1091, 1247-1255 construct it: lattice points whose pair
+  distances fall exactly on the bin edges (3-4-5 triangles) -> edge inclusivity ("vario_edge"), float32 values with large
+  offsets -> where |dv| is formed ("vario_diff"), estimator constants (matheron / cressie / dowd), and
+  ``RasterEquidistantMetricSpace`` on a small grid -> which pixel pairs a run contains (centre disk x rings, or also the
+  disk with itself: ADVICE.md round 1).
+
+Nothing here is imported by the product; the fixtures are data.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def pin_interp() -> str | None:
+    try:
+        import geoutils as gu
+        from geoutils.raster.georeferencing import _coords
+        from geoutils.raster.interpolate import _interp_points
+        import affine
+    except Exception as e:  # pragma: no cover - absent in the build image
+        print("geoutils not importable:", e)
+        return None
+    rng = np.random.default_rng(7)
+    dem = (100 + np.cumsum(np.cumsum(rng.normal(size=(24, 31)), 0), 1)).astype(np.float32)
+    dem[5, 6] = np.nan
+    dem[11:13, 20:23] = np.nan
+    dem[23, 30] = np.nan
+    res = 10.0
+    transform = affine.Affine(res, 0, 500000.0, 0, -res, 7000000.0)
+    # the coordinates and the interpolator the reference builds (affine.py:171-184)
+    xx, yy = _coords(transform=transform, shape=dem.shape, area_or_point=None, grid=True)
+    out = {"dem": dem, "res": np.float64(res), "geoutils_version": np.array(gu.__version__)}
+    for k, (sx, sy) in enumerate([(0.0, 0.0), (10.0, -20.0), (5.0, 5.0), (3.3, -7.1), (-17.0, 0.0), (0.0, 2.5)]):
+        vals = _interp_points(dem, transform=transform, points=(xx + sx, yy + sy), method="linear", area_or_point=None,
+                              shift_area_or_point=True)
+        out[f"shift{k}"] = np.array([sx, sy])
+        out[f"vals{k}"] = np.asarray(vals).reshape(dem.shape)
+    path = os.path.join(GOLDEN, "thirdparty_interp.npz")
+    np.savez_compressed(path, **out)
+    return path
+
+
+def pin_skgstat() -> str | None:
+    try:
+        import skgstat as skg
+    except Exception as e:  # pragma: no cover
+        print("scikit-gstat not importable:", e)
+        return None
+    out = {"skgstat_version": np.array(skg.__version__)}
+    # (1) edge inclusivity + estimator constants: lattice points, edges on exact pair distances
+    ix, iy = np.meshgrid(np.arange(12), np.arange(9))
+    coords = np.column_stack([ix.ravel(), iy.ravel()]).astype(np.float64) * 2.0
+    rng = np.random.default_rng(3)
+    values = (np.sin(coords[:, 0] / 5.0) * 1000.0 + rng.normal(size=coords.shape[0])).astype(np.float32)
+    edges = [2.0, 4.0, 10.0, 20.0, 26.0]
+    out["coords"], out["values"], out["edges"] = coords, values, np.array(edges)
+    for est in ("matheron", "cressie", "dowd"):
+        for vdt in (np.float32, np.float64):
+            V = skg.Variogram(coords, values.astype(vdt), normalize=False, fit_method=None, bin_func=edges, maxlag=edges[-1], estimator=est)
+            bins, exp = V.get_empirical(bin_center=False)
+            out[f"exp_{est}_{np.dtype(vdt).name}"] = np.asarray(exp, dtype=np.float64)
+            out[f"count_{est}_{np.dtype(vdt).name}"] = np.asarray(V.bin_count, dtype=np.int64)
+            out[f"bins_{est}_{np.dtype(vdt).name}"] = np.asarray(bins, dtype=np.float64)
+    # (2) RasterEquidistantMetricSpace: which pairs does one run hold?
+    shape, gsd = (40, 50), 1.0
+    x, y = np.meshgrid(np.arange(0, shape[0] * gsd, gsd), np.arange(0, shape[1] * gsd, gsd))
+    gc = np.dstack((x.flatten(), y.flatten())).squeeze()
+    extent = (gc[:, 0].min(), gc[:, 0].max(), gc[:, 1].min(), gc[:, 1].max())
+    M = skg.RasterEquidistantMetricSpace(gc, shape=shape, extent=extent, samples=12, ratio_subsample=0.05, runs=3, rnd=np.random.default_rng(11))
+    D = M.dists.tocoo()
+    out["rems_rows"], out["rems_cols"], out["rems_dists"] = D.row.astype(np.int64), D.col.astype(np.int64), D.data.astype(np.float64)
+    out["rems_shape"], out["rems_coords"] = np.array(shape), gc
+    path = os.path.join(GOLDEN, "thirdparty_skgstat.npz")
+    np.savez_compressed(path, **out)
+    return path
+
+
+if __name__ == "__main__":
+    made = [p for p in (pin_interp(), pin_skgstat()) if p]
+    print("written:", made if made else "nothing (packages absent)")
+    sys.exit(0)

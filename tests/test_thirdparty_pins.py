@@ -1,0 +1,53 @@
+"""Decides the switchable third-party conventions from fixtures recorded by oracle/pin_thirdparty.py -- wherever geoutils /
+scikit-gstat were importable.  The fixtures cannot be produced in the build image (both packages are absent), so these
+tests SKIP there and say so: until they run, the conventions stay "parity unpinned"  and the product keeps them
+switchable ("nk_nan_rule", "vario_edge", "vario_diff")."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def test_geoutils_interp_points_selects_the_nan_rule():
+    path = os.path.join(GOLDEN, "thirdparty_interp.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/thirdparty_interp.npz not recorded (geoutils absent here): run oracle/pin_thirdparty.py where it is importable")
+    import nuthkaab_oracle as nko
+
+    z = np.load(path)
+    dem, res = z["dem"], float(z["res"])
+    matches = {}
+    for rule in (0, 1, 2):
+        ok = True
+        for k in range(6):
+            sx, sy = z[f"shift{k}"]
+            want = z[f"vals{k}"]
+            got = nko.bilinear_shifted(dem, -sy / res, sx / res, nan_rule=rule)
+            ok &= np.array_equal(np.isnan(got), np.isnan(want)) and np.allclose(got, want, rtol=1e-6, atol=0, equal_nan=True)
+        matches[rule] = bool(ok)
+    assert sum(matches.values()) >= 1, f"no nk_nan_rule reproduces geoutils' _interp_points: {matches}"
+    assert matches[0], f"the default nk_nan_rule (0) is not geoutils' convention: {matches} -- change the default"
+
+
+def test_skgstat_selects_edge_and_diff_conventions():
+    path = os.path.join(GOLDEN, "thirdparty_skgstat.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/thirdparty_skgstat.npz not recorded (scikit-gstat absent here): run oracle/pin_thirdparty.py where it is importable")
+    import variogram_oracle as vo
+
+    z = np.load(path)
+    coords, values, edges = z["coords"], z["values"], [float(e) for e in z["edges"]]
+    found = {}
+    for est in ("matheron", "cressie", "dowd"):
+        for right_closed in (False, True):
+            for diff_f64 in (False, True):
+                e, c = vo.empirical_variogram_blocks([(coords[:, 0], coords[:, 1], values)], edges, est, right_closed=right_closed,
+                                                     diff_f64=diff_f64)
+                same = np.array_equal(c, z[f"count_{est}_float32"]) and np.allclose(e, z[f"exp_{est}_float32"], rtol=1e-9, equal_nan=True)
+                found[(est, right_closed, diff_f64)] = bool(same)
+    for est in ("matheron", "cressie", "dowd"):
+        assert any(v for (e_, _, _), v in found.items() if e_ == est), f"no convention reproduces scikit-gstat for {est}: {found}"
+    assert all(found[(est, False, False)] for est in ("matheron", "cressie", "dowd")), \
+        f"the defaults (vario_edge 0, vario_diff 0) are not scikit-gstat's conventions: {found} -- change the defaults"

@@ -11,11 +11,16 @@ from xdem_amd import _lib
 from xdem_amd import spatialstats as ss
 
 rng = np.random.default_rng(45)
-runs, samples, rings, L = 100, 9091, 10, 20000.0
+runs, samples, rings, L = int(os.environ.get("C5_RUNS", "100")), 9091, 10, 20000
+lattice = os.environ.get("C5_LATTICE", "1") == "1"   # raster pixels (integer-lattice kernels) or arbitrary coordinates (float64 kernels)
 blocks = []
 for _ in range(runs):
-    ax, ay = rng.uniform(0, L, samples), rng.uniform(0, L, samples)
-    bx, by = rng.uniform(0, L, samples * rings), rng.uniform(0, L, samples * rings)
+    if lattice:
+        ax, ay = rng.integers(0, L, samples).astype(np.float64), rng.integers(0, L, samples).astype(np.float64)
+        bx, by = rng.integers(0, L, samples * rings).astype(np.float64), rng.integers(0, L, samples * rings).astype(np.float64)
+    else:
+        ax, ay = rng.uniform(0, L, samples), rng.uniform(0, L, samples)
+        bx, by = rng.uniform(0, L, samples * rings), rng.uniform(0, L, samples * rings)
     av = (np.sin(ax / 900.0) + 0.2 * rng.normal(size=samples)).astype(np.float32)
     bv = (np.sin(bx / 900.0) + 0.2 * rng.normal(size=samples * rings)).astype(np.float32)
     blocks.append((ax, ay, av, bx, by, bv))

@@ -221,10 +221,33 @@ class Context:
 
 
 _default_ctx: dict[int, Context] = {}
+_tls = threading.local()
+
+
+class use_context:
+    """``with use_context(ctx): ...`` -- calls made by THIS thread inside the block that would take the process-wide default
+    context use `ctx` instead.  A context serialises its own work (one stream, one scratch state): threads that want to
+    overlap GPU work create one Context each (the library is re-entrant per context handle)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "ctx", None)
+        _tls.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _tls.ctx = self.prev
+        return False
 
 
 def default_context(device: int | None = None) -> Context:
-    """Process-wide context for `device` (default: $XDEM_AMD_DEVICE, else LOCAL_RANK, else 0)."""
+    """Process-wide context for `device` (default: $XDEM_AMD_DEVICE, else LOCAL_RANK, else 0), or the calling thread's
+    ``use_context`` override."""
+    cur = getattr(_tls, "ctx", None)
+    if cur is not None and (device is None or device == cur.device):
+        return cur
     if device is None:
         device = int(os.environ.get("XDEM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if device not in _default_ctx:

@@ -33,6 +33,8 @@ namespace xd {
 constexpr int PT = 256;      // B points per LDS tile; A points per workgroup = NT (256 for sums / succ, 1024 for histograms)
 constexpr int BCHUNK = 4096;  // B points per workgroup
 constexpr int LUT_N = 512;    // cells (1/8 binade of d^2 each) of the class lookup table
+constexpr int LUT_G = 256;    // GRID: cells of float(d2) from LUT_G0 on (d2 = 1 is cell 1016, d2 < 2^32 ends at 1272): 64 dwords = one per LDS bank
+constexpr int LUT_G0 = 1016;
 constexpr int LUT_STEPS = 1;  // a cell holds at most ONE threshold (host-checked), flagged in the entry's low bit
 constexpr int NCOPY = 32;     // privatised accumulator copies (copy = lane % 32 -> one LDS bank per copy)
 
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     // per class a 384-byte record: NCOPY float64 sums (256 B = all 64 LDS banks, one copy per lane % 32: conflict-free), then
     // NCOPY uint32 counts.  Record nb collects the pairs beyond the last edge and is never read back, so full tiles need no
     // class test.  Both atomics of a pair address the record with the same `l * 384` term.
+    // (An interleaved 16-byte (sum, count) slot per copy would save an address computation but puts four lanes of every
+    // 32-lane group on one bank pair: measured slower.)
     constexpr int REC = NCOPY * 12;
     unsigned char* s_rec = acc;
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(acc);            // OP_HIST: nbs * 256
@@ -132,10 +136,10 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
         stage.held = reinterpret_cast<int*>(stage.base + 1);
     }
 
-    __shared__ uint8_t s_lut[LUT_N];
+    __shared__ uint8_t s_lut[GRID ? LUT_G : LUT_N];
     const int tid = threadIdx.x;
     if (FAST)  // (NT may be smaller than the table: round 1 loaded only its first NT entries -- wrong classes beyond 32 binades of d^2)
-        for (int k = tid; k < LUT_N; k += NT) s_lut[k] = GRID ? a.lut_i[k] : a.lut[k];
+        for (int k = tid; k < (GRID ? LUT_G : LUT_N); k += NT) s_lut[k] = GRID ? a.lut_i[k] : a.lut[k];
     for (int k = tid; k < a.nb + LUT_STEPS + 1; k += NT) s_thr[k] = k < a.nb ? a.thr[k] : (double)INFINITY;
     if (GRID)
         for (int k = tid; k < a.nb + 2; k += NT) s_thr_i[k] = k < a.nb ? a.thr_i[k] : 0xFFFFFFFFu;
@@ -271,15 +275,16 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
-                        d2[u] = (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+                        // (the three-operand form with the inline constant 0: the builtin picks v_dot2c, which needs a zeroed accumulator)
+                        asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
                         dv[u] = pv - s_bv[j + u];
                     }
                     int l[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        int e = (int)(__float_as_uint((float)d2[u]) >> 20) - a.lut_i_emin;  // 1/8-binade cell of float(d2) (monotone in d2)
-                        e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
-                        l[u] = s_lut[e];
+                        // 1/8-binade cell of float(d2) (monotone in d2); d2 = 0 (coincident points) clamps onto the first cell
+                        const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
+                        l[u] = s_lut[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
                     }
                     uint32_t th[4];
 #pragma unroll
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
             unsigned long long c = 0;
             double sm = 0.0;
             for (int q = 0; q < NCOPY; ++q) {
-                const unsigned char* r = s_rec + k * (NCOPY * 12);
+                const unsigned char* r = s_rec + k * REC;
                 c += reinterpret_cast<const uint32_t*>(r + NCOPY * 8)[q];
                 sm += reinterpret_cast<const double*>(r)[q];
             }
@@ -570,10 +575,10 @@ bool make_grid(const double* ax, const double* ay, int64_t na, const double* bx,
         }
         out.thr_i[q] = (uint32_t)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n);
     }
-    // 5. class table over the cells of float(d2): entry = classes whose threshold lies at or below the cell's first d2; a cell
-    // may hold at most one more threshold (checked), which the kernel resolves with one integer compare
-    out.emin = cell_of_u32(1) - 1;
-    out.lut.assign(LUT_N, 0);
+    // 5. class table over the cells of float(d2), indexed directly by the cell: entry = classes whose threshold lies at or below
+    // the cell's first d2; a cell may hold at most one more threshold (checked), which the kernel resolves with one integer compare
+    out.emin = 0;
+    out.lut.assign(LUT_G, 0);
     auto first_in_cell = [&](int c) -> unsigned long long {  // smallest d2 with cell(d2) >= c (2^32 if none)
         unsigned long long lo = 0, hi = 0x100000000ull;
         while (lo < hi) {
@@ -582,9 +587,11 @@ bool make_grid(const double* ax, const double* ay, int64_t na, const double* bx,
         }
         return lo;
     };
-    if (thr.size() > 255) return false;
-    for (int i = 0; i < LUT_N; ++i) {
-        const unsigned long long lo = i == 0 ? 0 : first_in_cell(out.emin + i), hi = i == LUT_N - 1 ? 0x100000000ull : first_in_cell(out.emin + i + 1);
+    if (thr.size() > 255 || cell_of_u32(nmax > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nmax) >= LUT_G0 + LUT_G) return false;
+    for (int i = 0; i < LUT_G; ++i) {
+        // (entry 0 also serves d2 = 0: coincident points belong to the class of the smallest distances)
+        const unsigned long long lo = i == 0 ? 0 : first_in_cell(LUT_G0 + i), hi = first_in_cell(LUT_G0 + i + 1);
+        if (lo >= 0x100000000ull || lo == hi) { out.lut[i] = (uint8_t)(i ? out.lut[i - 1] : 0); continue; }  // no d2 maps here
         int below = 0, inside = 0;
         for (size_t q = 0; q < thr.size(); ++q) {
             below += (unsigned long long)out.thr_i[q] <= lo;
@@ -727,10 +734,10 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
         if (lut_ok && ctx->vario_grid != 0 && make_grid(ax, ay, na, pd ? nullptr : bx, pd ? nullptr : by, nbt, thr, gi)) {
             XD_ALLOC(P->a_xy, 4 * na);
             XD_ALLOC(P->thr_i, 4 * n_bins);
-            XD_ALLOC(P->lut_i, LUT_N);
+            XD_ALLOC(P->lut_i, LUT_G);
             XD_HIP_CHECK(ctx, hipMemcpy(P->a_xy, gi.a_xy.data(), 4 * (size_t)na, hipMemcpyHostToDevice));
             XD_HIP_CHECK(ctx, hipMemcpy(P->thr_i, gi.thr_i.data(), 4 * (size_t)n_bins, hipMemcpyHostToDevice));
-            XD_HIP_CHECK(ctx, hipMemcpy(P->lut_i, gi.lut.data(), LUT_N, hipMemcpyHostToDevice));
+            XD_HIP_CHECK(ctx, hipMemcpy(P->lut_i, gi.lut.data(), LUT_G, hipMemcpyHostToDevice));
             if (!pd) {
                 XD_ALLOC(P->b_xy, 4 * nbt);
                 XD_HIP_CHECK(ctx, hipMemcpy(P->b_xy, gi.b_xy.data(), 4 * (size_t)nbt, hipMemcpyHostToDevice));
