@@ -86,6 +86,11 @@ def pin_skgstat() -> str | None:
     D = M.dists.tocoo()
     out["rems_rows"], out["rems_cols"], out["rems_dists"] = D.row.astype(np.int64), D.col.astype(np.int64), D.data.astype(np.float64)
     out["rems_shape"], out["rems_coords"] = np.array(shape), gc
+    out["rems_samples"], out["rems_ratio"], out["rems_runs"] = np.int64(12), np.float64(0.05), np.int64(3)
+    for name, attr in (("rems_centers", "_centers"), ("rems_center_radius", "_center_radius"), ("rems_radii", "equidistant_radii"),
+                       ("rems_max_dist", "_max_dist")):
+        if getattr(M, attr, None) is not None:
+            out[name] = np.asarray(getattr(M, attr), dtype=np.float64)
     path = os.path.join(GOLDEN, "thirdparty_skgstat.npz")
     np.savez_compressed(path, **out)
     return path

@@ -134,30 +134,37 @@ def empirical_variogram_blocks(blocks, edges, estimator: str = "matheron", right
 def equidistant_blocks(coords: np.ndarray, values: np.ndarray, valid: np.ndarray, gsd: float, runs: int, samples: int,
                        ratio_subsample: float, rng: np.random.Generator, fac: float = np.sqrt(2)):
     """Pair blocks of the centre-disk / equidistant-ring scheme (Hugonnet et al. 2022, Suppl. Fig. 13; the design of
-    skgstat.RasterEquidistantMetricSpace restated): per run one random valid centre; up to `samples` valid points
-    from the disk of radius r0 = sqrt(samples / (ratio_subsample pi)) gsd, and up to `samples` from each ring
-    [r0 f^i, r0 f^(i+1)) until the extent diagonal is covered; pairs = disk sample x union of ring samples.
-    RNG protocol (shared with the product so that seeds reproduce): one ``choice`` for the centre, then one
-    ``choice(.., samples, replace=False)`` per over-full ring, inner to outer."""
+    skgstat.RasterEquidistantMetricSpace restated; PARITY UNPINNED against the package itself until
+    oracle/pin_thirdparty.py has run somewhere it is importable): per run one random valid centre; a centre sample of
+    up to `samples` valid points with d < r0 = sqrt(samples / (ratio_subsample pi)) gsd; an equidistant sample of up to
+    `samples` from each of the rings [0, r0), [r0, r0 f), [r0 f, r0 f^2) ... the last one ending at the extent diagonal
+    -- the first ring is the centre disk, sampled a second time; pairs = centre sample x union of ring samples.
+    RNG protocol (shared with the product so that seeds reproduce): one ``choice`` for the centre, one
+    ``choice(.., samples, replace=False)`` for the centre sample if over-full, then one per over-full ring, inner to outer."""
     x, y = coords[:, 0], coords[:, 1]
     r0 = np.sqrt(samples / (ratio_subsample * np.pi)) * gsd
     diag = np.hypot(x.max() - x.min(), y.max() - y.min())
-    bounds = [0.0, r0]
-    while bounds[-1] < diag:
-        bounds.append(bounds[-1] * fac)
+    bounds = [0.0]
+    nxt = r0
+    while nxt < diag:
+        bounds.append(nxt)
+        nxt = nxt * fac
+    bounds.append(diag)
     candidates = np.flatnonzero(valid)
     out = []
     for _ in range(runs):
         c = rng.choice(candidates)
         d = np.sqrt((x - x[c]) ** 2 + (y - y[c]) ** 2)
+        centre = np.flatnonzero(valid & (d < r0))
+        if centre.size > samples:
+            centre = rng.choice(centre, samples, replace=False)
         picked = []
         for lo, hi in zip(bounds[:-1], bounds[1:]):
             members = np.flatnonzero(valid & (d >= lo) & (d < hi))
             if members.size > samples:
                 members = rng.choice(members, samples, replace=False)
             picked.append(members)
-        a = picked[0]
-        b = np.concatenate(picked[1:]) if len(picked) > 1 else np.empty(0, dtype=np.int64)
-        if a.size and b.size:
-            out.append((x[a], y[a], values[a], x[b], y[b], values[b]))
+        b = np.concatenate(picked) if picked else np.empty(0, dtype=np.int64)
+        if centre.size and b.size:
+            out.append((x[centre], y[centre], values[centre], x[b], y[b], values[b]))
     return out

@@ -232,19 +232,28 @@ def test_dem_coregister_3d_argument_plumbing(monkeypatch):
         seen["fit"] = dict(kw, resolution=resolution, mask=None if inlier_mask is None else inlier_mask.dtype)
         return self
 
-    def fake_apply(self, elev, resolution, resample=True):
-        seen["apply"] = resample
-        return elev + 1.0
+    def fake_fit_with_shift(self, ref, tba, inlier_mask=None, resolution=None, **kw):
+        fake_fit(self, ref, tba, inlier_mask, resolution, **kw)
+        self.meta["outputs"]["affine"] = {"shift_x": 3.0, "shift_y": -5.0, "shift_z": 1.0}
+        return self
 
-    monkeypatch.setattr(coreg.NuthKaab, "fit", fake_fit)
-    monkeypatch.setattr(coreg.NuthKaab, "apply", fake_apply)
+    def fake_translation(elev, sx, sy, sz, res, resample=True):
+        seen["apply"] = resample
+        seen["apply_args"] = (sx, sy, sz, tuple(res))
+        return elev + sz
+
+    monkeypatch.setattr(coreg.NuthKaab, "fit", fake_fit_with_shift)
+    monkeypatch.setattr(coreg, "apply_translation", fake_translation)
     a = xdem_amd.DEM(np.zeros((5, 6), dtype=np.float32), transform=(2.0, 0.0, 0.0, 0.0, -2.0, 10.0))
     b = xdem_amd.DEM(np.ones((5, 6), dtype=np.float32), transform=(2.0, 0.0, 0.0, 0.0, -2.0, 10.0))
     out = a.coregister_3d(b, coreg.NuthKaab(), inlier_mask=np.ones((5, 6), dtype=np.uint8), random_state=7, resample=False)
     assert isinstance(out, xdem_amd.DEM) and np.all(out.data == 1.0)
     assert seen["fit"] == {"random_state": 7, "resolution": (2.0, 2.0), "mask": np.dtype(bool)} and seen["apply"] is False
-    a.coregister_3d(b)  # default method, default resample
-    assert seen["apply"] is True and "random_state" not in seen["fit"]
+    assert seen["apply_args"] == (3.0, -5.0, 1.0, (2.0, 2.0))
+    # resample=False: the horizontal shift moves the geotransform (xdem/coreg/base.py:1567-1570), the grid spacing stays
+    assert out.transform == (2.0, 0.0, 3.0, 0.0, -2.0, 5.0)
+    out = a.coregister_3d(b)  # default method, default resample: data resampled onto the unchanged grid
+    assert seen["apply"] is True and "random_state" not in seen["fit"] and out.transform == a.transform
     with pytest.raises(NotImplementedError, match="bias_vars"):
         a.coregister_3d(b, bias_vars={"x": np.zeros((5, 6))})
     with pytest.raises(ValueError, match="must be an xdem_amd.coreg instance"):
@@ -342,3 +351,15 @@ def test_nuthkaab_fit_apply_interface(monkeypatch):
         nk.fit(a, b, transform=tr, weights=np.ones((4, 5)))
     with pytest.raises(NotImplementedError):
         nk.apply(b, transform=tr, resampling="cubic")
+
+
+def test_dem_integer_nodata_becomes_nan():
+    """An integer raster with a nodata value must not hand nodata to the kernels as an elevation: geoutils gives upstream a
+    masked array whose get_nanarray() is float with NaN (xdem/terrain.py:1140-1160 takes it from there)."""
+    import xdem_amd
+
+    z = np.arange(30, dtype=np.int16).reshape(5, 6)
+    z[2, 3] = -9999
+    d = xdem_amd.DEM(z, nodata=-9999)
+    assert d.dtype == np.float32 and np.isnan(d.data[2, 3]) and np.count_nonzero(np.isnan(d.data)) == 1
+    assert xdem_amd.DEM(np.arange(30, dtype=np.int16).reshape(5, 6), nodata=-9999).dtype == np.int16  # nothing to mask: unchanged

@@ -51,3 +51,31 @@ def test_skgstat_selects_edge_and_diff_conventions():
         assert any(v for (e_, _, _), v in found.items() if e_ == est), f"no convention reproduces scikit-gstat for {est}: {found}"
     assert all(found[(est, False, False)] for est in ("matheron", "cressie", "dowd")), \
         f"the defaults (vario_edge 0, vario_diff 0) are not scikit-gstat's conventions: {found} -- change the defaults"
+
+
+def test_skgstat_equidistant_metric_space_structure():
+    """RasterEquidistantMetricSpace: radii list and whether centre-disk x centre-disk pairs exist."""
+    path = os.path.join(GOLDEN, "thirdparty_skgstat.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/thirdparty_skgstat.npz not recorded (scikit-gstat absent here): run oracle/pin_thirdparty.py where it is importable")
+    z = np.load(path)
+    if "rems_radii" not in z or "rems_centers" not in z:
+        pytest.skip("this scikit-gstat version does not expose the radii / centres")
+    gc, samples, ratio = z["rems_coords"], int(z["rems_samples"]), float(z["rems_ratio"])
+    r0 = np.sqrt(samples / (ratio * np.pi)) * 1.0
+    diag = np.hypot(np.ptp(gc[:, 0]), np.ptp(gc[:, 1]))
+    mine = [0.0]
+    r = r0
+    while r < diag:
+        mine.append(r)
+        r *= np.sqrt(2)
+    mine.append(diag)
+    assert np.allclose(z["rems_radii"], mine, rtol=1e-12), (z["rems_radii"], mine)
+    # disk x disk pairs: both endpoints inside the centre disk of one centre
+    rows, cols = z["rems_rows"], z["rems_cols"]
+    inside = np.zeros(rows.size, dtype=bool)
+    for c in z["rems_centers"]:
+        da = np.hypot(gc[rows, 0] - c[0], gc[rows, 1] - c[1])
+        db = np.hypot(gc[cols, 0] - c[0], gc[cols, 1] - c[1])
+        inside |= (da < r0) & (db < r0)
+    assert inside.any(), "scikit-gstat holds no disk x disk pairs: drop ring 0 from the equidistant sample again"

@@ -30,7 +30,12 @@ class DEM:
             arr = arr[0]
         if arr.ndim != 2:
             raise ValueError("DEM data must be 2D")
-        if nodata is not None and np.issubdtype(arr.dtype, np.floating):
+        if nodata is not None and not isinstance(data, np.ma.MaskedArray) and not np.issubdtype(arr.dtype, np.floating):
+            # integer rasters with a nodata value: geoutils hands them over masked, i.e. as float32 with NaN once filled
+            # (xdem/dem.py:429-619 all start from get_nanarray()); elevations equal to nodata must not reach the kernels
+            if np.any(arr == nodata):
+                arr = np.where(arr == nodata, np.float32(np.nan), arr.astype(np.float32))
+        elif nodata is not None and np.issubdtype(arr.dtype, np.floating):
             arr = np.where(arr == nodata, np.nan, arr)
         self.data = arr
         t = transform
@@ -135,7 +140,10 @@ class DEM:
             raise NotImplementedError("reference and to-be-aligned DEM must share one grid (reprojection is geoutils' job).")
         mask = None if inlier_mask is None else np.asarray(getattr(inlier_mask, "data", inlier_mask), dtype=bool)
         method.fit(reference_elev.data, self.data, mask, resolution=self.res, **kwargs)
-        return DEM(method.apply(self.data, self.res, resample=resample), self.transform, self.crs, self.nodata)
+        # array interface with transform=: for resample=False the horizontal shift moves the geotransform and only the
+        # vertical shift touches the data (xdem/coreg/base.py:1567-1570, _apply_matrix_rst case 2)
+        out, out_transform = method.apply(self.data, resample=resample, transform=self.transform)
+        return DEM(out, out_transform, self.crs, self.nodata)
 
     # ---- uncertainty forwarder (xdem/dem.py:667-780) ---------------------------------------------------------------
     def estimate_uncertainty(self, other_elev: "DEM", stable_terrain=None, approach: str = "H2022", precision_of_other: str = "finer",
@@ -163,7 +171,9 @@ class DEM:
                                                            stable_mask=stable)[0]
         else:
             sel = dh if stable is None else dh[stable]
-            sig = _ss.nmad_device(sel)[1] * np.ones(self.shape)
+            # xdem/dem.py:742-744: spread_estimator(dh[stable_terrain]); the default NMAD runs on the GPU (exact-median
+            # selection), any other callable is the caller's host function
+            sig = (_ss.nmad_device(sel)[1] if spread_estimator is _ss.nmad else float(spread_estimator(sel))) * np.ones(self.shape)
         if not approach_dict[approach]["multi_range"] and not isinstance(list_vario_models, str) and len(list_vario_models) > 1:
             warnings.warn("Several variogram models passed but this approach uses a single range,keeping only the first model.",
                           category=UserWarning)

@@ -341,9 +341,13 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
     for i in range(n_variograms):
         run_rng = np.random.default_rng(list_random_state[i])
         if subsample_method == "cdist_equidistant":
-            if "runs" in kwargs and "samples" in kwargs:
-                runs, samples = int(kwargs["runs"]), int(kwargs["samples"])
+            if "runs" in kwargs or "samples" in kwargs:
+                # user-defined: upstream only auto-chooses when NEITHER is given (spatialstats.py:1203) and otherwise leaves
+                # the missing one to RasterEquidistantMetricSpace's defaults (samples=100, ratio_subsample=0.01,
+                # runs = 1 % of the coordinates / samples)
+                samples = int(kwargs.get("samples", 100))
                 ratio = kwargs.get("ratio_subsample", 0.01)
+                runs = int(kwargs["runs"]) if kwargs.get("runs") is not None else int(np.count_nonzero(valid) * 0.01 / samples)
             else:
                 runs, samples, ratio = _choose_cdist_equidistant_sampling_parameters(
                     extent=extent, shape=shape2d, subsample=subsample, **({"nb_rings": kwargs["nb_rings"]} if "nb_rings" in kwargs else {}))
@@ -451,30 +455,41 @@ def equidistant_blocks_from_coords(coords: np.ndarray, values: np.ndarray, valid
                                    samples: int, ratio_subsample: float, rng: np.random.Generator,
                                    exp_increase_fac: float = np.sqrt(2)) -> list[tuple]:
     """Centre-disk x equidistant-ring pair blocks (Hugonnet et al. 2022, Suppl. Fig. 13; the scheme of skgstat's
-    RasterEquidistantMetricSpace restated): per run a random valid centre, `samples` valid points of the disk of
-    radius r0 = sqrt(samples / (ratio_subsample pi)) gsd and `samples` of every ring [r0 f^i, r0 f^(i+1)), f = sqrt 2,
-    out to the extent diagonal; pairs = disk sample x all ring samples."""
+    RasterEquidistantMetricSpace restated -- the package is absent offline, oracle/pin_thirdparty.py records its pair
+    structure where it is importable): per run a random valid centre and a "centre sample" of up to `samples` valid
+    points of the disk of radius r0 = sqrt(samples / (ratio_subsample pi)) gsd; the "equidistant sample" takes up to
+    `samples` valid points of every ring between the radii 0, r0, r0 f, r0 f^2, ... (f = sqrt 2) below the extent diagonal
+    and the diagonal itself as the last radius.  Its first ring is the centre disk again, drawn independently ("so that the
+    other half can be used by the equidistant sample for low distances"): the short lags come from disk x disk pairs.
+    Pairs = centre sample x the union of the ring samples."""
     cx, cy = coords[:, 0], coords[:, 1]
     r0 = np.sqrt(samples / (ratio_subsample * np.pi)) * gsd
     maxdist = np.sqrt((cx.max() - cx.min()) ** 2 + (cy.max() - cy.min()) ** 2)
-    radii = [0.0, r0]
-    while radii[-1] < maxdist:
-        radii.append(radii[-1] * exp_increase_fac)
+    radii = [0.0]
+    r = r0
+    while r < maxdist:
+        radii.append(r)
+        r *= exp_increase_fac
+    radii.append(maxdist)
     flat_valid = np.flatnonzero(valid)
     blocks = []
     for _ in range(runs):
         c = rng.choice(flat_valid)
         dist = np.sqrt((cx - cx[c]) ** 2 + (cy - cy[c]) ** 2)
+        # digitize: radii[i] <= d < radii[i+1] -> i; d >= maxdist (the far corner only) falls outside every ring;
+        # the centre disk is d < r0 whichever radius list the diagonal cuts short
         ring = np.digitize(dist, radii) - 1
-        ring[~valid] = -1
+        ring[(~valid) | (ring >= len(radii) - 1)] = -1
+        a = np.flatnonzero(valid & (dist < r0))
+        if a.size > samples:
+            a = rng.choice(a, samples, replace=False)
         sets = []
         for i in range(len(radii) - 1):
             idx = np.flatnonzero(ring == i)
             if idx.size > samples:
                 idx = rng.choice(idx, samples, replace=False)
             sets.append(idx)
-        a = sets[0]
-        b = np.concatenate(sets[1:]) if len(sets) > 1 else np.array([], dtype=np.int64)
+        b = np.concatenate(sets) if sets else np.array([], dtype=np.int64)
         if a.size and b.size:
             blocks.append((cx[a], cy[a], values[a], cx[b], cy[b], values[b]))
     return blocks
