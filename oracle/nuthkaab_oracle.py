@@ -63,7 +63,8 @@ def aux_vars(ref: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
 def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int = 0) -> np.ndarray:
     """bilinear(img)(row + dr, col + dc) on the full grid, float64 weights, result in img's dtype.  ``nan_rule`` = the
     switchable nodata convention of the kernel (geoutils' own rule is unpinned, see header): 0 "4tap" -- NaN if any of the
-    four taps is non-finite or outside, zero weights included; 1 "weighted" -- taps with zero weight are ignored; 2
+    four taps is non-finite or outside, zero weights included (except a zero-weight tap beyond the last row / column: nodes on
+    the upper edge keep their value); 1 "weighted" -- taps with zero weight are ignored; 2
     "dilate3x3" -- NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite pixel or leaves the raster."""
     H, W = img.shape
     rr = np.arange(H, dtype=np.float64)[:, None] + dr
@@ -74,8 +75,10 @@ def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int = 0) -
     fc = cc - c0
     r0 = r0.astype(np.int64)
     c0 = c0.astype(np.int64)
-    need_r1 = np.ones_like(fr, dtype=bool) if nan_rule != 1 else fr != 0
-    need_c1 = np.ones_like(fc, dtype=bool) if nan_rule != 1 else fc != 0
+    # zero-weight taps: ignored by rule 1 everywhere; by the other rules only where the tap would leave the raster (a node
+    # exactly on the upper edge is returned by every linear interpolator)
+    need_r1 = (fr != 0) if nan_rule == 1 else ((fr != 0) | (r0 + 1 < H))
+    need_c1 = (fc != 0) if nan_rule == 1 else ((fc != 0) | (c0 + 1 < W))
     r1 = np.where(need_r1, r0 + 1, r0)
     c1 = np.where(need_c1, c0 + 1, c0)
     ok = np.broadcast_to((r0 >= 0) & (r1 < H), (H, W)) & np.broadcast_to((c0 >= 0) & (c1 < W), (H, W))

@@ -55,7 +55,8 @@ __device__ __forceinline__ BiAxis bi_axis(int64_t idx, double shift, int64_t ext
     const double k0f = floor(a.pos);
     a.f = t_sub(a.pos, k0f);
     a.k0 = (int64_t)k0f;
-    a.d1 = (rule == 1 && a.f == 0.0) ? 0 : 1;
+    // a node exactly on the upper edge needs no tap beyond it (any linear interpolator returns the node value there)
+    a.d1 = (a.f == 0.0 && (rule == 1 || a.k0 + 1 >= extent)) ? 0 : 1;
     a.in = a.k0 >= 0 && a.k0 + a.d1 < extent;
     return a;
 }
