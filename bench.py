@@ -28,6 +28,7 @@ sys.path[:0] = [ROOT]
 FULL = ["slope", "aspect", "hillshade", "profile_curvature", "tangential_curvature", "planform_curvature",
         "flowline_curvature", "max_curvature", "min_curvature", "topographic_position_index",
         "terrain_ruggedness_index"]
+C4_SIZE = int(os.environ.get("XDEM_BENCH_C4_SIZE", "65536"))  # test knob: a smaller raster on shared-GPU boxes
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (about 6.3 TB/s achievable)
 BYTES_PER_PIXEL = 4 + 4 * len(FULL)  # 4 B read + 4 B per attribute written = 48 B
 
@@ -288,17 +289,9 @@ def main() -> None:
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n = args.size
     depth = xdist.halo_depth(FULL, "Florinsky", 3)
-    block = xdist.RowBlock(n, n, depth, rank, world, dev)
-    # each rank synthesises exactly its rows of the global raster (halo rows come from the neighbours)
-    block.interior.copy_(fbm_torch(block.rows, n, dev, seed=42, row0=block.r0, total_rows=n))
-    out = torch.empty((len(FULL), block.rows, n), device=dev, dtype=torch.float32)
     ctx = _lib.default_context(local_rank)
     kw = dict(resolution=10.0, surface_fit="Florinsky", curv_method="geometric", ctx=ctx)
-
-    def step():
-        xdist.terrain_row_block(block, FULL, out=out, overlap=not args.no_overlap, **kw)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -306,21 +299,33 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world > 1:  # communicator set-up (RCCL creates its point-to-point channels lazily) is not a step: do it up front
-        xdist.RowBlock.wait_all(block.exchange())
+    def partitioned_run(n, steps, warmup):
+        """`steps` timed passes of the 11-attribute set over the n x n raster held as `world` row blocks; max over ranks."""
+        block = xdist.RowBlock(n, n, depth, rank, world, dev)
+        # each rank synthesises exactly its rows of the global raster (halo rows come from the neighbours)
+        block.interior.copy_(fbm_torch(block.rows, n, dev, seed=42, row0=block.r0, total_rows=n))
+        out = torch.empty((len(FULL), block.rows, n), device=dev, dtype=torch.float32)
+
+        def step():
+            xdist.terrain_row_block(block, FULL, out=out, overlap=not args.no_overlap, **kw)
+
+        if world > 1:  # communicator set-up (RCCL creates its point-to-point channels lazily) is not a step: do it up front
+            xdist.RowBlock.wait_all(block.exchange())
+            barrier()
+        for _ in range(warmup):
+            step()
         barrier()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device="cpu" if share else dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), block, out
+
+    n = args.size
+    elapsed, block, out = partitioned_run(n, args.steps, args.warmup)
 
     # Kernel-only duration for the roofline: HIP events recorded by the library on the launch stream around the
     # kernel (xdemhip_last_kernel_ms), averaged over fresh launches of the dominant (interior / whole-block) kernel.
@@ -333,6 +338,19 @@ def main() -> None:
     kernel_ms = sum(kms) / len(kms)
     px_launch = block.rows * n
     achieved = BYTES_PER_PIXEL * px_launch / (kernel_ms * 1e-3) / 1e9
+
+    # C4 (BASELINE.json configs[3]): 65536^2 over the row blocks of all ranks with the halo exchange -- run by every rank whenever
+    # the job has more than one, reported under "secondary" (the headline stays the metric's 40000^2 raster)
+    c4 = None
+    if world > 1 and not args.no_secondary and n != C4_SIZE:
+        del out, block
+        torch.cuda.empty_cache()
+        c4_steps = max(2, min(args.steps, 5))
+        c4_elapsed, block, out = partitioned_run(C4_SIZE, c4_steps, max(1, min(args.warmup, 2)))
+        c4 = {"workload": f"C4: {C4_SIZE}x{C4_SIZE} float32 fBm DEM, 11 attributes, {world} row blocks, halo depth {depth}, "
+                          + ("shared-GPU gloo test mode" if share else "RCCL send/recv over xGMI"),
+              "value": round(float(C4_SIZE) ** 2 * c4_steps / c4_elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
+              "steps": c4_steps, "ms_per_step": round(c4_elapsed / c4_steps * 1e3, 4)}
 
     if rank == 0:
         total_px = float(n) * n
@@ -370,6 +388,8 @@ def main() -> None:
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
+        if c4 is not None:
+            res["secondary"] = {"c4_terrain_row_blocks": c4}
         if not args.no_secondary and world == 1:
             try:
                 del out, block

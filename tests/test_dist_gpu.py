@@ -282,3 +282,28 @@ def test_nuth_kaab_partitioned_row_blocks(tmp_path):
         assert np.array_equal(g["step"], want_step, equal_nan=True), r
         assert np.allclose(g["fit"][:3], off, rtol=1e-9, atol=1e-9) and g["fit"][3] == n_final, (g["fit"], off)
     assert abs(off[1] - (-40.0)) < 2.0 or abs(off[1] - 40.0) < 2.0   # the 4-row shift is found (|northing| ~ 40 m)
+
+
+def test_bench_two_ranks_reports_c4(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank) -- here with
+    both ranks on GPU 0 over gloo (XDEM_BENCH_SHARE_GPU) and small rasters: one JSON line, n_gpus 2, and the C4 row-block
+    measurement under "secondary" (65536^2 in production; XDEM_BENCH_C4_SIZE shrinks it for this test)."""
+    import json
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XDEM_BENCH_SHARE_GPU="1", XDEM_BENCH_C4_SIZE="4096", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "3000"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    c4 = res["secondary"]["c4_terrain_row_blocks"]
+    assert c4["n_gpus"] == 2 and c4["value"] > 0 and "4096x4096" in c4["workload"]

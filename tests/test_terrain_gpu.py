@@ -584,3 +584,42 @@ def test_host_path_row_chunks_equal_single_pass():
             ctx.set_option("host_chunk_mb", 0)
         for a, g, w in zip(attrs, got, want):
             assert np.array_equal(g.view(np.int32), w.view(np.int32)), (a, kw)
+
+
+def test_c4_size_on_one_gpu_crops_equal_full():
+    """BASELINE.json configs[3]'s raster size (65536^2: 4.3e9 pixels > 2^32, 17 GB in, 189 GB out) through the fused kernel on
+    ONE GPU, so that the size the 8-GPU configuration partitions is exercised by the suite: crops computed separately must
+    be bit-identical to the same windows of the whole-raster planes (translation equivariance of every attribute), including
+    windows beyond pixel offset 2^32 and at the raster's far corner."""
+    import torch
+
+    from xdem_amd.terrain import terrain_attributes_device
+
+    n = 65536
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 225 * 2**30:
+        pytest.skip(f"needs 225 GiB of free device memory, {free / 2**30:.0f} GiB free")
+    attrs = ["slope", "aspect", "hillshade", "profile_curvature", "tangential_curvature", "planform_curvature",
+             "flowline_curvature", "max_curvature", "min_curvature", "topographic_position_index", "terrain_ruggedness_index"]
+    r = torch.arange(n, device=dev, dtype=torch.float32)[:, None]
+    c = torch.arange(n, device=dev, dtype=torch.float32)[None, :]
+    dem = torch.empty((n, n), device=dev, dtype=torch.float32)
+    for i in range(0, n, 4096):
+        rr = r[i:i + 4096]
+        dem[i:i + 4096] = 1000.0 + 30.0 * torch.sin(rr * 0.013) * torch.cos(c * 0.011) + 0.002 * rr + 5.0 * torch.sin(c * 0.21 + rr * 0.17)
+    dem[50000:50003, 60000:60010] = float("nan")
+    out = terrain_attributes_device(dem, attrs, resolution=10.0)
+    torch.cuda.synchronize()
+    assert out.shape == (11, n, n)
+    for (r0, c0) in ((0, 0), (n - 600, n - 900), (n // 2 + 13, 7), (49800, 59500), (65536 - 601, 123)):
+        r1, c1 = min(r0 + 600, n), min(c0 + 900, n)
+        crop = terrain_attributes_device(dem[r0:r1, c0:c1].contiguous(), attrs, resolution=10.0)
+        torch.cuda.synchronize()
+        # the crop's own 2-pixel rim sees the raster edge rule instead of neighbours: compare interiors, NaN patterns included
+        a = crop[:, 2:-2, 2:-2].contiguous().view(torch.int32)
+        b = out[:, r0 + 2:r1 - 2, c0 + 2:c1 - 2].contiguous().view(torch.int32)
+        assert torch.equal(a, b), (r0, c0)
+    assert bool(torch.isnan(out[0, 50001, 60005])) and bool(torch.isfinite(out[0, 40000, 61000]))
+    del out, dem
+    torch.cuda.empty_cache()

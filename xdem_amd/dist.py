@@ -52,7 +52,17 @@ class RowBlock:
 
     def exchange(self, group=None) -> list:
         """Refresh the halo rows from the neighbours: one batched isend/irecv group (ncclSend/ncclRecv grouped
-        under RCCL).  Returns the work handles; call ``wait_all`` before launching kernels that read the halo."""
+        under RCCL).  Returns the work handles; call ``wait_all`` before launching kernels that read the halo.
+
+        Stream ordering under the nccl (= RCCL) backend, by torch's ProcessGroupNCCL rules: the grouped send / recv is
+        enqueued on the communicator's own stream after an event of the CURRENT torch stream (so it reads interior rows
+        that earlier work on the current stream -- the synthesis copy, the previous step's kernels -- has finished with,
+        and never overwrites halo rows a previous boundary launch still reads); ``work.wait()`` makes the current
+        stream wait for the exchange without blocking the host.  The library launches every device-resident call on the
+        current torch stream (``ctx.set_stream(torch.cuda.current_stream(...))`` in terrain_attributes_device), so the
+        interior launch issued between ``exchange`` and ``wait_all`` overlaps the transfer -- it reads only this rank's own
+        rows and writes only ``out`` -- and the boundary launches issued after ``wait_all`` are ordered behind it.  The send
+        slices are row ranges of the contiguous block buffer (``contiguous()`` returns views, nothing is staged)."""
         if self.world == 1:
             return []
         if self.buf.is_cuda and dist.get_backend(group) == "gloo":
