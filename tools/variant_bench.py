@@ -56,7 +56,7 @@ def main():
             if not a.only or any(o in "R01" for o in a.only.split(",")):
                 variants.append(("R01", L, ctx, None, None, None))
             continue
-        combos = itertools.product([0, 1], [0, 1], [16, 24, 32]) if tag == "MIX" else [(0, 0, 32), (0, 0, 16)]
+        combos = (list(itertools.product([0, 1], [0, 1], [16, 24, 32])) + [(0, 0, 132), (0, 0, 232), (0, 0, 332)]) if tag == "MIX" else [(0, 0, 32), (0, 0, 16)]
         for math, store, rows in combos:
             name = f"{tag if math == 0 else tag + '-F64'}/store{store}/rows{rows}"
             if a.only and not any(o in name for o in a.only.split(",")):

@@ -340,6 +340,7 @@ int xdemhip_binstats_add_var(xdemhip_binstats* P, const void* var, int dtype, in
 }
 
 int xdemhip_binstats_finalize(xdemhip_binstats* P, int64_t* n_valid, double* var_min, double* var_max) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     if (!n_valid || !var_min || !var_max) return xd_fail(ctx, XDEMHIP_EINVAL, "null output");
@@ -378,6 +379,7 @@ int xdemhip_binstats_finalize(xdemhip_binstats* P, int64_t* n_valid, double* var
 int xdemhip_binstats_run(xdemhip_binstats* P, int n_dims, const int* var_ids, const double* edges, const int* n_edges,
                          const int* decimals, int sample_dtype, int want_nmad, double nfact, int64_t* counts, double* medians,
                          double* nmads) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     if (!P->finalized) return xd_fail(ctx, XDEMHIP_EINVAL, "call xdemhip_binstats_finalize first");
@@ -478,6 +480,7 @@ extern "C" {
 
 int xdemhip_nmad(xdemhip_ctx* ctx, const void* values, int dtype, int64_t n, double nfact, double abs_limit, int memspace,
                  double* median, double* nmad_out, int64_t* count) {
+    XdFetchScope fetch_scope_(ctx);
     if (!ctx) return XDEMHIP_EINVAL;
     if (!values || n <= 0 || !median || !nmad_out || !count) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
     if (memspace != XDEMHIP_HOST && memspace != XDEMHIP_DEVICE) return xd_fail(ctx, XDEMHIP_EINVAL, "bad memspace");

@@ -49,6 +49,7 @@ void xdemhip_destroy(xdemhip_ctx* ctx) {
     for (int t = 0; t < xdemhip_ctx::MAX_COPY_THREADS; ++t)
         if (ctx->copy_streams[t]) (void)hipStreamDestroy(ctx->copy_streams[t]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     delete ctx;
 }
 
@@ -99,7 +100,8 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         return XDEMHIP_OK;
     }
     if (std::string(name) == "terrain_rows") {
-        if (value != 0 && value != 16 && value != 24 && value != 32) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_rows: 0, 16, 24 or 32");
+                // (values >= 100 select occupancy experiments of measurement builds and are ignored by the shipped library)
+        if (value != 0 && value != 16 && value != 24 && value != 32 && value < 100) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_rows: 0, 16, 24 or 32");
         ctx->terrain_rows = value;
         return XDEMHIP_OK;
     }

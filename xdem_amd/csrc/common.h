@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <string>
+#include <vector>
 
 #include "../../include/xdemhip.h"
 
@@ -30,6 +32,13 @@ struct xdemhip_ctx {
     int nk_nan_rule = 0;     // option "nk_nan_rule": nodata spreading of the bilinear taps (nuthkaab.hip): 0 4tap, 1 weighted, 2 dilate3x3
     int selection_mode = 0;  // 0 auto (bracketed for large inputs), 1 plain digit passes only, 2 degenerate brackets (tests the
                              // fallback), 3 bracketed whatever the per-bin sample size (2 and 3: test switches)
+    // Deferred device-to-host results (xd_d2h / xd_sync below): small result blocks land in one pinned staging buffer with
+    // truly asynchronous copies and are handed to their destinations at the next xd_sync -- a copy into pageable memory
+    // would stall the host once per block (tens of microseconds each, a dozen blocks per Nuth-Kaab step).
+    unsigned char* pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0;
+    struct Pending { void* dst; size_t off, bytes; };
+    std::vector<Pending> pending;
     std::string err;
 };
 
@@ -48,6 +57,44 @@ inline int xd_fail(xdemhip_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
 }
+
+// Queue a small device-to-host copy whose destination is filled by the next xd_sync(ctx) (falls back to a plain copy when
+// the staging buffer is full).  `dst` must stay alive until that xd_sync; xd_drop_pending forgets undelivered blocks (entry
+// points call it on their way in and out, so an error return never leaves a dangling destination behind).
+inline int xd_d2h(xdemhip_ctx* ctx, void* dst, const void* dsrc, size_t bytes) {
+    if (!ctx->pin) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin), 256 * 1024, hipHostMallocDefault) == hipSuccess) ctx->pin_cap = 256 * 1024;
+        else ctx->pin = nullptr;
+    }
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    if (!ctx->pin || ctx->pin_used + need > ctx->pin_cap) {
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return XDEMHIP_OK;
+    }
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pin + ctx->pin_used, dsrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending.push_back({dst, ctx->pin_used, bytes});
+    ctx->pin_used += need;
+    return XDEMHIP_OK;
+}
+inline void xd_drop_pending(xdemhip_ctx* ctx) {
+    ctx->pending.clear();
+    ctx->pin_used = 0;
+}
+inline int xd_sync(xdemhip_ctx* ctx) {
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        xd_drop_pending(ctx);
+        return xd_fail(ctx, XDEMHIP_EHIP, std::string("hipStreamSynchronize failed: ") + hipGetErrorString(e));
+    }
+    for (const auto& p : ctx->pending) memcpy(p.dst, ctx->pin + p.off, p.bytes);
+    xd_drop_pending(ctx);
+    return XDEMHIP_OK;
+}
+struct XdFetchScope {  // RAII for C entry points that queue deferred copies
+    xdemhip_ctx* c;
+    explicit XdFetchScope(xdemhip_ctx* ctx) : c(ctx) { if (c) xd_drop_pending(c); }
+    ~XdFetchScope() { if (c) xd_drop_pending(c); }
+};
 
 // All-reduce a small device array over the ranks through the caller's hook (no-op without a hook): the array is
 // staged to the host, combined by the hook (torch.distributed / RCCL or gloo on the Python side) and copied back.

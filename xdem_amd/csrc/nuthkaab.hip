@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void nk_aux_kernel(const T* __restrict__ ref, 
 struct DhStats {
     uint64_t asp_min, asp_max;  // order-preserving keys (widened to 64 bit) of min / max aspect among finite dh
 };
+static __global__ void nk_stats_init_kernel(DhStats* s) {
+    if (threadIdx.x == 0) { s->asp_min = ~(uint64_t)0; s->asp_max = 0; }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
@@ -228,19 +231,50 @@ __global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ 
         }
         held = 0;
     };
-    for (int64_t i = row0 + blockIdx.y; i < row1; i += gridDim.y) {
+    // This workgroup walks a contiguous chunk of rows down its 256 columns.  The taps of output row i + 1 sit one raster row
+    // below those of row i, so the lower tap pair of a row is carried over as the upper pair of the next one (two tap loads per
+    // pixel instead of four), and every load of row i + 1 is issued before row i is evaluated: one row of latency is always
+    // in flight.  (The carry is taken only when the tap rows really are consecutive: pos = i + dr is rounded per row.)
+    const int64_t chunk = (row1 - row0 + gridDim.y - 1) / gridDim.y;
+    int64_t i = row0 + (int64_t)blockIdx.y * chunk;
+    const int64_t iend = (i + chunk < row1) ? i + chunk : row1;
+    const int64_t jj = jin ? j : 0;  // lanes beyond the raster follow column 0 (loads stay in bounds) and discard everything
+    BiAxis rax = bi_axis(i < iend ? i : row0, g.dr, g.H, g.rule);
+    BiTap t = bi_combine(g, rax, col);
+    T a00 = (T)0, a01 = (T)0, a10 = (T)0, a11 = (T)0, rv = (T)0, av = (T)0;
+    uint8_t vd = 0;
+    int64_t p = (i - g.roff) * g.W + jj;
+    if (i < iend) {
+        const BiVals<T> tv = bi_load<T>(tba, t);
+        a00 = tv.a00; a01 = tv.a01; a10 = tv.a10; a11 = tv.a11;
+        rv = ref[p]; av = aspect[p]; vd = valid[p];
+    }
+    for (; i < iend; ++i) {
+        // ---- loads of the next row
+        BiAxis rn = rax;
+        BiTap tn = t;
+        T n00 = (T)0, n01 = (T)0, n10 = (T)0, n11 = (T)0, nrv = (T)0, nav = (T)0;
+        uint8_t nvd = 0;
+        const int64_t pn = p + g.W;
+        if (i + 1 < iend) {
+            rn = bi_axis(i + 1, g.dr, g.H, g.rule);
+            tn = bi_combine(g, rn, col);
+            nrv = ref[pn]; nav = aspect[pn]; nvd = valid[pn];
+            if (rax.in && rn.in && rax.d1 == 1 && rn.k0 == rax.k0 + 1) {  // (wave-uniform)
+                n00 = a10; n01 = a11;
+                if (rn.d1) { const T* q = tba + tn.q00 + tn.drw; n10 = q[0]; n11 = q[tn.dc1]; }
+                else { n10 = n00; n11 = n01; }
+            } else {
+                const BiVals<T> tv = bi_load<T>(tba, tn);
+                n00 = tv.a00; n01 = tv.a01; n10 = tv.a10; n11 = tv.a11;
+            }
+        }
+        // ---- this row
         bool cand = false;
         T out = (T)NAN;
-        if (jin) {
-            const int64_t p = (i - g.roff) * g.W + j;
-            const BiTap t = bi_combine(g, bi_axis(i, g.dr, g.H, g.rule), col);
-            const BiVals<T> tv = bi_load<T>(tba, t);
-            const T a00 = tv.a00, a01 = tv.a01, a10 = tv.a10, a11 = tv.a11;
-            const T rv = ref[p];
-            const T av = aspect[p];
-            const uint8_t vd = valid[p];  // (every load of the pixel is issued before the first use)
+        {
             T val;
-            const bool ok = bi_value<T>(g, tba, t, a00, a01, a10, a11, val) & (vd != 0);
+            const bool ok = bi_value<T>(g, tba, t, a00, a01, a10, a11, val) & (vd != 0) & jin;
             out = t_sub(rv, val);
             if (ok && t_finite(out)) {
                 const K ka = key_of(av);
@@ -253,7 +287,7 @@ __global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ 
             } else {
                 out = (T)NAN;
             }
-            dh[p] = out;
+            if (jin) dh[p] = out;
         }
         const unsigned long long mask = __ballot(cand);
         if (mask) {
@@ -261,6 +295,8 @@ __global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ 
             held += __popcll(mask);
             if (held > NKF_STAGE / 2) flush();
         }
+        rax = rn; t = tn; p = pn;
+        a00 = n00; a01 = n01; a10 = n10; a11 = n11; rv = nrv; av = nav; vd = nvd;
     }
     if (held > 0) flush();
     unsigned long long c0 = n_all, c1 = n_below, c2 = n_in;
@@ -276,6 +312,151 @@ __global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ 
         if (c0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), c0);
         if (c1) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[1]), c1);
         if (c2) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2]), c2);
+    }
+}
+
+// ---- the lean form of the pass above for NaN rules 0 and 1 (rule 2 reads a 3 x 3 neighbourhood per pixel and keeps the generic
+// kernel).  Measured on MI355X the generic kernel is VALU-bound (about 166 vector instructions per row of 64 pixels: per-row tap
+// geometry recomputed by every lane, four float64 lerps, 64-bit addressing), not HBM-bound.  Here
+//   * the row part of the tap geometry (fraction, upper tap row, flags) is computed once per workgroup into an LDS table;
+//   * the horizontal lerp of a tap row is carried in float64 from one output row to the next -- the lower tap row of row i is
+//     the upper tap row of row i + 1 and the column fraction never changes -- so a row costs two tap loads, one horizontal
+//     and one vertical lerp (same operations in the same order as bi_value: results are bit-identical);
+//   * addresses are a uniform row base plus constant 32-bit lane offsets; counters are wave-level popcounts of ballots;
+//   * the loads of row i + 1 are issued before row i is evaluated.
+struct NkRowTab { double fr; int k0l; int flags; };  // upper tap row (buffer-local, clamped), bit 0 = taps inside the raster, bit 1 = d1
+constexpr int NK_CHUNK_MAX = 512;
+constexpr int NK_PF = 3;
+template <typename T, int RULE>
+__global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
+                                                               const uint8_t* __restrict__ valid, const T* __restrict__ aspect,
+                                                               NkGeom g, T* __restrict__ dh, DhStats* stats, int64_t row0, int64_t row1,
+                                                               int64_t nbuf, const typename KeyT<T>::type* __restrict__ klo_p,
+                                                               const typename KeyT<T>::type* __restrict__ khi_p, uint64_t* counters /* [3] */,
+                                                               T* out_v, unsigned long long* ctr /* [1] candidates, [2] overflow */,
+                                                               int64_t cap) {
+    typedef typename KeyT<T>::type K;
+    __shared__ NkRowTab tab[NK_CHUNK_MAX + 1];
+    __shared__ T stage_all[4][NKF_STAGE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T* stage = stage_all[wave];
+    int held = 0;  // wave-uniform
+    const K klo = *klo_p, khi = *khi_p;
+    const int64_t chunk = (row1 - row0 + gridDim.y - 1) / gridDim.y;  // <= NK_CHUNK_MAX (launcher)
+    const int64_t i0 = row0 + (int64_t)blockIdx.y * chunk;
+    const int nrow = (int)((i0 + chunk < row1 ? i0 + chunk : row1) - i0);
+    for (int r = threadIdx.x; r <= nrow && r <= NK_CHUNK_MAX; r += blockDim.x) {
+        const BiAxis a = bi_axis(i0 + (r < nrow ? r : nrow - 1), g.dr, g.H, RULE);
+        int64_t kl = a.k0 - g.roff;
+        kl = (a.in && kl >= 0 && kl + a.d1 < nbuf) ? kl : 0;
+        NkRowTab e;
+        e.fr = a.f; e.k0l = (int)kl; e.flags = (a.in ? 1 : 0) | (a.d1 ? 2 : 0);
+        tab[r] = e;
+    }
+    __syncthreads();
+    if (nrow <= 0) return;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool jin = j < g.W;
+    const BiAxis col = bi_axis(j, g.dc, g.W, RULE);
+    const bool cin = col.in & jin;
+    const uint32_t c0 = cin ? (uint32_t)col.k0 : 0u, c1 = c0 + (cin ? (uint32_t)col.d1 : 0u);
+    const uint32_t jl = jin ? (uint32_t)j : 0u;
+    const double fc = col.f;
+    auto hlerp = [&](T a, T b) -> double {
+        const double v0 = a, v1 = b;
+        return t_add(v0, t_mul(fc, t_sub(v1, v0)));
+    };
+    T fmin_a = (T)INFINITY, fmax_a = -(T)INFINITY;
+    uint32_t n_all = 0, n_below = 0, n_in = 0;  // wave-uniform
+    auto flush = [&]() {
+        unsigned long long b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&ctr[1], (unsigned long long)held);
+        b0 = __shfl(b0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = lane; k < held; k += 64) {
+            if ((int64_t)(b0 + k) < cap) out_v[b0 + k] = stage[k];
+            else ctr[2] = 1ull;
+        }
+        held = 0;
+    };
+    // state carried down the column: the horizontal lerp `hl` of buffer tap row `have`
+    int have = -1;
+    double hl = 0.0;
+    // Software pipeline, NK_PF rows deep: the loads of row r + NK_PF are issued while row r is evaluated (one row in flight per
+    // wave leaves the kernel latency-bound at about half of the HBM rate: 32 waves x 1 KiB per CU in flight against ~2 us).
+    struct Pre { T b0, b1, rv, av; uint8_t vd; };
+    Pre pre[NK_PF];
+    const int64_t rb0 = (i0 - g.roff) * g.W;
+    auto issue = [&](int rr, Pre& q) {  // rr clamped: entry `nrow` of the table repeats the last row
+        const int rc = rr < nrow ? rr : nrow - 1;
+        const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
+        const T* rowp = tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W;
+        const int64_t rb = rb0 + (int64_t)rc * g.W;
+        q.b0 = rowp[c0]; q.b1 = rowp[c1];
+        q.rv = ref[rb + jl]; q.av = aspect[rb + jl]; q.vd = valid[rb + jl];
+    };
+#pragma unroll
+    for (int u = 0; u < NK_PF; ++u) issue(u, pre[u]);
+    for (int r0 = 0; r0 < nrow; r0 += NK_PF) {
+#pragma unroll
+        for (int u = 0; u < NK_PF; ++u) {
+            const int r = r0 + u;
+            if (r < nrow) {
+                const T b0v = pre[u].b0, b1v = pre[u].b1, rv = pre[u].rv, av = pre[u].av;
+                const uint8_t vd = pre[u].vd;
+                issue(r + NK_PF, pre[u]);
+                const int k0l = __builtin_amdgcn_readfirstlane(tab[r].k0l), fl = __builtin_amdgcn_readfirstlane(tab[r].flags);
+                const double fr = tab[r].fr;
+                const int64_t rb = rb0 + (int64_t)r * g.W;
+                double top;
+                if (have == k0l) {
+                    top = hl;
+                } else {  // chunk start, or a step of the tap row other than +1 (pos = i + dr is rounded per row): fetch the upper row
+                    const T* up = tba + (int64_t)k0l * g.W;
+                    top = hlerp(up[c0], up[c1]);
+                }
+                double bot = top;
+                if (fl & 2) bot = hlerp(b0v, b1v);
+                have = k0l + ((fl >> 1) & 1);
+                hl = bot;
+                const T val = (T)t_add(top, t_mul(fr, t_sub(bot, top)));
+                T out = t_sub(rv, val);
+                // (a non-finite tap makes val, hence out, non-finite by itself -- also through a zero weight: 0 * NaN = 0 * inf = NaN)
+                const bool ok = ((fl & 1) != 0) & cin & (vd != 0) & t_finite(out);
+                const K key = key_of(out);
+                const bool below = ok & (key < klo);
+                const bool cand = ok & (key >= klo) & (key <= khi);
+                out = ok ? out : (T)NAN;
+                if (jin) dh[rb + jl] = out;
+                fmin_a = fmin(fmin_a, ok ? av : (T)INFINITY);
+                fmax_a = fmax(fmax_a, ok ? av : -(T)INFINITY);
+                n_all += (uint32_t)__popcll(__ballot(ok));
+                n_below += (uint32_t)__popcll(__ballot(below));
+                const unsigned long long mask = __ballot(cand);
+                if (mask) {
+                    if (cand) stage[held + __popcll(mask & ((1ull << lane) - 1ull))] = out;
+                    const int c = __popcll(mask);
+                    held += c;
+                    n_in += (uint32_t)c;
+                    if (held > NKF_STAGE / 2) flush();
+                }
+            }
+        }
+    }
+    if (held > 0) flush();
+    K kmin = (fmin_a <= fmax_a) ? key_of(fmin_a) : ~(K)0;
+    K kmax = (fmin_a <= fmax_a) ? key_of(fmax_a) : (K)0;
+    for (int off = 32; off > 0; off >>= 1) {
+        const K a = k_shfl_down(kmin, off), b = k_shfl_down(kmax, off);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) {
+        if (kmin != ~(K)0) k_atomic_min(&stats->asp_min, (uint64_t)kmin);
+        if (kmax != 0) k_atomic_max(&stats->asp_max, (uint64_t)kmax);
+        if (n_all) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), (unsigned long long)n_all);
+        if (n_below) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[1]), (unsigned long long)n_below);
+        if (n_in) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2]), (unsigned long long)n_in);
     }
 }
 
@@ -533,8 +714,8 @@ template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
     int rc = xd_allreduce_device(ctx, d_cnt, 1, XDEMHIP_RED_SUM_U64);
     if (rc) return rc;
     unsigned long long c = 0;
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(&c, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rc_ = xd_d2h(ctx, &c, d_cnt, 8); if (rc_) return rc_; }
+    { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
     P->n_valid0 = (long long)c;
     return XDEMHIP_OK;
 }
@@ -623,10 +804,20 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     XD_HIP_CHECK(ctx, hipGetLastError());
     // the one pass: dh for every own pixel (written), min / max aspect, counters, candidates
     if (P->row1 > P->row0) {
-        hipLaunchKernelGGL((nk_dh_count_kernel<T>), grid2d(ctx, P->W, P->row1 - P->row0), dim3(256), 0, ctx->stream,
-                           static_cast<const T*>(P->ref), static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g,
-                           static_cast<T*>(P->dh), d_stats, P->row0, P->row1, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags,
-                           ws->c_cap);
+        dim3 grid = grid2d(ctx, P->W, P->row1 - P->row0);
+        const int64_t rows = P->row1 - P->row0;
+        if ((rows + grid.y - 1) / grid.y > NK_CHUNK_MAX) grid.y = (unsigned)((rows + NK_CHUNK_MAX - 1) / NK_CHUNK_MAX);
+#define XD_NK_LEAN(RULE)                                                                                                            \
+    hipLaunchKernelGGL((nk_dh_count_lean_kernel<T, RULE>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),          \
+                       static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh), d_stats, \
+                       P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap)
+        if (g.rule == 0) XD_NK_LEAN(0);
+        else if (g.rule == 1) XD_NK_LEAN(1);
+        else
+            hipLaunchKernelGGL((nk_dh_count_kernel<T>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),
+                               static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh),
+                               d_stats, P->row0, P->row1, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap);
+#undef XD_NK_LEAN
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     rc = xd_allreduce_device(ctx, d_cnt, 3, XDEMHIP_RED_SUM_U64);
@@ -696,9 +887,8 @@ int nk_stage_a(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int n
     DhStats* d_stats = reinterpret_cast<DhStats*>(base + OFF_STATS);
     T* d_edges = reinterpret_cast<T*>(base);
     DhStats hs0;
-    hs0.asp_min = ~(uint64_t)0;
-    hs0.asp_max = 0;
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(d_stats, &hs0, sizeof hs0, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(nk_stats_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats);
+    XD_HIP_CHECK(ctx, hipGetLastError());
     *fused = false;
     int rc = XDEMHIP_OK;
     if (!force_plain) {
@@ -719,8 +909,8 @@ int nk_stage_a(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int n
         std::vector<SelResult<K>> g0;
         rc = run_select<T>(ctx, static_cast<const T*>(P->dh) + q0, nullptr, n, 1, base, g0, &P->ws);
         if (rc) return rc;
-        XD_HIP_CHECK(ctx, hipMemcpyAsync(&hs0, d_stats, sizeof hs0, hipMemcpyDeviceToHost, ctx->stream));
-        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        { const int rc_ = xd_d2h(ctx, &hs0, d_stats, sizeof hs0); if (rc_) return rc_; }
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
         unsigned char info[32] = {0};
         const T vs_t = (T)median_from<T>(g0[0]);
         const uint64_t total = g0[0].st.count, flags = 0;
@@ -733,13 +923,13 @@ int nk_stage_a(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int n
         make_edges<T>((double)val_of((K)hs0.asp_min), (double)val_of((K)hs0.asp_max), nb, edges);
         XD_HIP_CHECK(ctx, hipMemcpyAsync(base + OFF_INFO, info, 32, hipMemcpyHostToDevice, ctx->stream));
         XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, edges.data(), sizeof(T) * (nb + 1), hipMemcpyHostToDevice, ctx->stream));
-        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (info / edges are stack / local buffers)
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }  // (info / edges are stack / local buffers)
     }
     if (!P->custom_edges.empty()) {  // explicit bin edges (NuthKaab(bin_sizes=<edges>)): SciPy casts them to the sample dtype
         std::vector<T> e(P->custom_edges.size());
         for (size_t k = 0; k < e.size(); ++k) e[k] = (T)P->custom_edges[k];
         XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, e.data(), sizeof(T) * e.size(), hipMemcpyHostToDevice, ctx->stream));
-        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
     }
     return XDEMHIP_OK;
 }
@@ -810,8 +1000,8 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
             if (rc) return rc;
         }
         unsigned char info[32];
-        XD_HIP_CHECK(ctx, hipMemcpyAsync(info, base + OFF_INFO, 32, hipMemcpyDeviceToHost, ctx->stream));
-        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        { const int rc_ = xd_d2h(ctx, info, base + OFF_INFO, 32); if (rc_) return rc_; }
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
         uint64_t total, flags;
         double vs;
         memcpy(&total, info + 8, 8);
@@ -833,11 +1023,11 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
             if (rc) return rc;
         }
         std::vector<T> edges(nb + 1);
-        XD_HIP_CHECK(ctx, hipMemcpyAsync(edges.data(), d_edges, sizeof(T) * (nb + 1), hipMemcpyDeviceToHost, ctx->stream));
+        { const int rc_ = xd_d2h(ctx, edges.data(), d_edges, sizeof(T) * (nb + 1)); if (rc_) return rc_; }
         const double cnt = (double)total;
         if (fit_sums) {
-            XD_HIP_CHECK(ctx, hipMemcpyAsync(fit_sums, d_fit, 80, hipMemcpyDeviceToHost, ctx->stream));
-            XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            { const int rc_ = xd_d2h(ctx, fit_sums, d_fit, 80); if (rc_) return rc_; }
+            { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
             const double mean = fit_sums[6] / cnt;
             const double var = fit_sums[9] / cnt - mean * mean;
             *y_mean = mean;
@@ -847,14 +1037,14 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         rc = xd_allreduce_device(ctx, d_sums, 2, XDEMHIP_RED_SUM_F64);
         if (rc) return rc;
         double sums[2];
-        XD_HIP_CHECK(ctx, hipMemcpyAsync(sums, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream));
+        { const int rc_ = xd_d2h(ctx, sums, d_sums, 16); if (rc_) return rc_; }
         std::vector<double> bs(nb);
         std::vector<unsigned long long> bc(nb);
         if (P->bin_stat == XDEMHIP_BINSTAT_MEAN) {
-            XD_HIP_CHECK(ctx, hipMemcpyAsync(bs.data(), d_bsum, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-            XD_HIP_CHECK(ctx, hipMemcpyAsync(bc.data(), d_bcnt, 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+            { const int rc_ = xd_d2h(ctx, bs.data(), d_bsum, 8 * (size_t)nb); if (rc_) return rc_; }
+            { const int rc_ = xd_d2h(ctx, bc.data(), d_bcnt, 8 * (size_t)nb); if (rc_) return rc_; }
         }
-        XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
         const double mean = sums[0] / cnt;
         const double var = sums[1] / cnt - mean * mean;
         *y_mean = mean;
@@ -939,12 +1129,14 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
 
 int xdemhip_nk_create(xdemhip_ctx* ctx, const void* ref, const void* tba, const uint8_t* inlier, int dtype, int64_t H, int64_t W,
                       int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid) {
+    XdFetchScope fetch_scope_(ctx);
     return nk_create_impl(ctx, ref, tba, inlier, dtype, H, W, 0, H, 0, H, memspace, false, out_plan, n_valid);
 }
 
 int xdemhip_nk_create_block(xdemhip_ctx* ctx, const void* ref_block, const void* tba_block, const uint8_t* inlier_block, int dtype,
                             int64_t H, int64_t W, int64_t row_begin, int64_t row_end, int64_t halo_top, int64_t halo_bottom,
                             int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid) {
+    XdFetchScope fetch_scope_(ctx);
     if (!ctx) return XDEMHIP_EINVAL;
     if (row_begin < 0 || row_end < row_begin || row_end > H || halo_top < 0 || halo_bottom < 0 || halo_top > row_begin ||
         row_end + halo_bottom > H)
@@ -958,6 +1150,7 @@ int xdemhip_nk_create_block(xdemhip_ctx* ctx, const void* ref_block, const void*
 }
 
 int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, int64_t* n_valid) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     if (row_begin < P->roff || row_end < row_begin || row_end > P->roff + P->nbuf) return xd_fail(ctx, XDEMHIP_EINVAL, "bad row range");
@@ -982,7 +1175,7 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* P, void* slope_tan, void* aspect, uint8_
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
     const size_t es = P->dtype == XDEMHIP_F32 ? 4 : 8, n = (size_t)P->nbuf * (size_t)P->W;  // (the plan's buffer rows)
     if (slope_tan) XD_HIP_CHECK(ctx, hipMemcpy(slope_tan, P->slope_tan, n * es, hipMemcpyDeviceToHost));
     if (aspect) XD_HIP_CHECK(ctx, hipMemcpy(aspect, P->aspect, n * es, hipMemcpyDeviceToHost));
@@ -992,6 +1185,7 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* P, void* slope_tan, void* aspect, uint8_
 
 int xdemhip_nk_step(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int n_bins, double* vshift,
                     int64_t* n_valid, double* y_mean, double* y_std, double* edges, int64_t* counts, double* medians) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     if (!vshift || !n_valid || !y_mean || !y_std || !edges || !counts || !medians) return xd_fail(ctx, XDEMHIP_EINVAL, "null output");
@@ -1009,6 +1203,7 @@ int xdemhip_nk_step(xdemhip_nk_plan* P, double shift_x, double shift_y, double r
 
 int xdemhip_nk_step_fit(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, double* vshift, int64_t* n_valid,
                         double* y_mean, double* y_std, double* sums) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     if (!vshift || !n_valid || !y_mean || !y_std || !sums) return xd_fail(ctx, XDEMHIP_EINVAL, "null output");
@@ -1080,6 +1275,7 @@ int xdemhip_shift_bilinear(xdemhip_ctx* ctx, const void* src, int dtype, int64_t
 // (xdem/spatialstats.py:143-157 for one explanatory variable).  Non-finite (x, y) pairs are dropped like nd_binning does.
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
                           int64_t* counts, double* medians) {
+    XdFetchScope fetch_scope_(ctx);
     if (!ctx) return XDEMHIP_EINVAL;
     if (!x || !y || !edges || !counts || !medians || n <= 0) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
     if (n_bins < 1 || n_bins > 1024) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins out of range (1..1024)");

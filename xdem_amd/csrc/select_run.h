@@ -182,6 +182,11 @@ inline size_t off_succ(int nb) { return OFF_STATE + (size_t)nb1(nb) * 64; }
 inline size_t off_hist(int nb) { return off_succ(nb) + (size_t)nb1(nb) * 8; }
 inline size_t scratch_size(int nb) { return off_hist(nb) + (size_t)nb1(nb) * SEL_RADIX * 8 + 256; }
 
+static __global__ void select_reset_kernel(uint64_t* base, int64_t w_state, int64_t w_succ, int64_t words) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x)
+        base[w] = (w >= w_state && w < w_state + w_succ) ? ~(uint64_t)0 : (uint64_t)0;
+}
+
 template <typename K> struct SelResult {
     SelState<K> st;
     uint64_t succ;  // smallest key above the selected one, all-ones if none
@@ -202,9 +207,15 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
     uint64_t* d_hist = reinterpret_cast<uint64_t*>(scratch + off_hist(nb));
-    XD_HIP_CHECK(ctx, hipMemsetAsync(st, 0, sizeof(SelState<K>) * nb, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemsetAsync(d_succ, 0xFF, 8 * (size_t)nb, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint64_t) * (size_t)nb * SEL_RADIX, ctx->stream));
+    {
+        // states | successor keys | histograms are contiguous in `scratch`: one launch resets all three (zeros, all-ones, zeros)
+        static_assert(sizeof(SelState<K>) <= 64, "state records live in 64-byte slots");
+        const int64_t w_state = (int64_t)nb1(nb) * 8, w_succ = (int64_t)nb1(nb), w_hist = (int64_t)nb * SEL_RADIX;
+        const int64_t words = w_state + w_succ + w_hist;
+        const int blocks = (int)((words + 1023) / 1024 < 256 ? (words + 1023) / 1024 : 256);
+        hipLaunchKernelGGL(select_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint64_t*>(st), w_state, w_succ, words);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
     const int passes = KeyT<T>::passes;
     const int run = (n_passes > 0 && n_passes < passes) ? n_passes : passes;  // leading digits only: bracket ends need no more
     const int grid = grid_for(ctx, n_grid, HIST_THREADS * 4, 2);
@@ -243,9 +254,9 @@ int select_fetch(xdemhip_ctx* ctx, unsigned char* scratch, int nb, std::vector<S
     typedef typename KeyT<T>::type K;
     std::vector<SelState<K>> hs(nb);
     std::vector<uint64_t> hsucc(nb);
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), scratch + OFF_STATE, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(hsucc.data(), scratch + off_succ(nb), 8 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    { const int rc_ = xd_d2h(ctx, hs.data(), scratch + OFF_STATE, sizeof(SelState<K>) * nb); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, hsucc.data(), scratch + off_succ(nb), 8 * (size_t)nb); if (rc_) return rc_; }
+    { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
     out.resize(nb);
     for (int k = 0; k < nb; ++k) { out[k].st = hs[k]; out[k].succ = hsucc[k]; }
     return XDEMHIP_OK;
@@ -515,10 +526,12 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int
             T v;
             uint16_t b;
             if (src.template eval<true>(raw[q], nb, v, b, acc)) {
+                // exactly one LDS atomic per element: class 0 above the bracket, 1 below, 2 inside (the totals are summed at the end)
                 const K key = key_of(v);
-                atomicAdd(&cc[b], 1u);
-                if (key < lo[b]) atomicAdd(&cc[nb + b], 1u);
-                else if (key <= hi[b]) { atomicAdd(&cc[2 * nb + b], 1u); cand = true; }
+                const K l = lo[b], h = hi[b];
+                cand = (key >= l) & (key <= h);
+                const int cls = key < l ? 1 : (cand ? 2 : 0);
+                atomicAdd(&cc[cls * nb + b], 1u);
             }
             st.append_bounded(cand, v, b, &ctr[2]);
         }
@@ -529,10 +542,14 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int
     }
     st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
     src.finish(acc);
-    for (int k = threadIdx.x; k < 3 * nb; k += blockDim.x) {
-        unsigned long long s = 0;
-        for (int q = 0; q < copies; ++q) s += c[q * 3 * nb + k];
-        if (s) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[k]), s);
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        unsigned long long above = 0, below = 0, inside = 0;
+        for (int q = 0; q < copies; ++q) {
+            above += c[q * 3 * nb + k]; below += c[q * 3 * nb + nb + k]; inside += c[q * 3 * nb + 2 * nb + k];
+        }
+        if (above + below + inside) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[k]), above + below + inside);
+        if (below) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[nb + k]), below);
+        if (inside) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2 * nb + k]), inside);
     }
 }
 
@@ -674,9 +691,9 @@ int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, un
     std::vector<uint64_t> cnt(3 * nb);
     std::vector<K> klo(nb);
     uint64_t h_ctr[5];
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(cnt.data(), d_cnt, 8 * 3 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(klo.data(), d_klo, sizeof(K) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(h_ctr, d_ctr, 40, hipMemcpyDeviceToHost, ctx->stream));
+    { const int rc_ = xd_d2h(ctx, cnt.data(), d_cnt, 8 * 3 * (size_t)nb); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, klo.data(), d_klo, sizeof(K) * nb); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, h_ctr, d_ctr, 40); if (rc_) return rc_; }
     rc = select_fetch<T>(ctx, scratch, nb, out);  // (synchronises the stream)
     if (rc) return rc;
     if (h_ctr[2] != 0 || h_ctr[3] != 0) return XDEMHIP_OK;  // buffer overflow or a bracket missed (*done stays false)

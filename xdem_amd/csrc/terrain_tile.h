@@ -212,7 +212,7 @@ static void fill_params(const TerrainLaunch& L, TerrainParams& P) {
 }
 
 template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT, int TH, int STORE, int MINW = 1>
-static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask) {
+static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask, unsigned dyn_lds = 0) {
     TileArgs<TIN, TOUT> a;
     a.dem = static_cast<const TIN*>(L.dem);
     a.H = L.H; a.W = L.W; a.stride = L.row_stride; a.halo_top = L.halo_top; a.halo_bottom = L.halo_bottom;
@@ -237,7 +237,7 @@ static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask)
             a.P.slot[k] = a.nplanes;
             a.compact[a.nplanes++] = static_cast<TOUT*>(L.planes[k]);
         }
-    hipLaunchKernelGGL((terrain_tile_kernel<FIT, CURV, WIN, SP, TIN, TOUT, TH, STORE, MINW>), dim3(a.grid8 * 8), dim3(256), 0,
+    hipLaunchKernelGGL((terrain_tile_kernel<FIT, CURV, WIN, SP, TIN, TOUT, TH, STORE, MINW>), dim3(a.grid8 * 8), dim3(256), dyn_lds,
                        ctx->stream, a);
     XD_HIP_CHECK(ctx, hipGetLastError());
     return XDEMHIP_OK;
@@ -270,6 +270,11 @@ static int launch_shaped(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
     if constexpr (ALLSHAPES && sizeof(TIN) == 4) {
         if (ctx->terrain_rows == 16) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 16, 0>(ctx, L, mask);
         if (ctx->terrain_rows == 24) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 24, 0>(ctx, L, mask);
+        // occupancy experiments: 132 = register cap of 4 waves / SIMD (128 VGPRs); 232 / 332 = the default kernel held to 2 / 1
+        // workgroups per CU by unused dynamic LDS
+        if (ctx->terrain_rows == 132) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 32, 0, 4>(ctx, L, mask);
+        if (ctx->terrain_rows == 232) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 32, 0>(ctx, L, mask, 40 * 1024);
+        if (ctx->terrain_rows == 332) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 32, 0>(ctx, L, mask, 90 * 1024);
     }
     return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, TH_DIRECT, 0>(ctx, L, mask);
 }
