@@ -327,6 +327,8 @@ __global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ 
 struct NkRowTab { double fr; int k0l; int flags; };  // upper tap row (buffer-local, clamped), bit 0 = taps inside the raster, bit 1 = d1
 constexpr int NK_CHUNK_MAX = 512;
 constexpr int NK_PF = 3;
+constexpr int NKL_ROWS = 4;      // rows between two looks at the staging buffer
+constexpr int NKL_CAP = 4096;    // staging slots per workgroup (flushed once fewer than 2 x NKL_ROWS rows would still fit)
 template <typename T, int RULE>
 __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
                                                                const uint8_t* __restrict__ valid, const T* __restrict__ aspect,
@@ -337,10 +339,14 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
                                                                int64_t cap) {
     typedef typename KeyT<T>::type K;
     __shared__ NkRowTab tab[NK_CHUNK_MAX + 1];
-    __shared__ T stage_all[4][NKF_STAGE];
+    // candidates collect in a workgroup staging buffer and leave in bursts of more than NKL_FLUSH values: one global atomic per
+    // burst (an atomic per wave and row group would serialise on the one counter, ~10 ns each)
+    __shared__ T stage[NKL_CAP];
+    __shared__ int s_held;
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_red[4][5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T* stage = stage_all[wave];
-    int held = 0;  // wave-uniform
+    if (threadIdx.x == 0) s_held = 0;
     const K klo = *klo_p, khi = *khi_p;
     const int64_t chunk = (row1 - row0 + gridDim.y - 1) / gridDim.y;  // <= NK_CHUNK_MAX (launcher)
     const int64_t i0 = row0 + (int64_t)blockIdx.y * chunk;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
         tab[r] = e;
     }
     __syncthreads();
-    if (nrow <= 0) return;
+    if (nrow <= 0) return;  // (uniform over the workgroup)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool jin = j < g.W;
     const BiAxis col = bi_axis(j, g.dc, g.W, RULE);
@@ -368,16 +374,21 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
     };
     T fmin_a = (T)INFINITY, fmax_a = -(T)INFINITY;
     uint32_t n_all = 0, n_below = 0, n_in = 0;  // wave-uniform
-    auto flush = [&]() {
-        unsigned long long b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&ctr[1], (unsigned long long)held);
-        b0 = __shfl(b0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int k = lane; k < held; k += 64) {
-            if ((int64_t)(b0 + k) < cap) out_v[b0 + k] = stage[k];
-            else ctr[2] = 1ull;
+    auto block_flush = [&](int threshold) {  // every thread of the workgroup
+        __syncthreads();
+        const int h = s_held;
+        if (h > threshold) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&ctr[1], (unsigned long long)h);
+            __syncthreads();
+            const unsigned long long b0 = s_base;
+            for (int k = threadIdx.x; k < h; k += blockDim.x) {
+                if ((int64_t)(b0 + k) < cap) out_v[b0 + k] = stage[k];
+                else ctr[2] = 1ull;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_held = 0;
+            __syncthreads();
         }
-        held = 0;
     };
     // state carried down the column: the horizontal lerp `hl` of buffer tap row `have`
     int have = -1;
@@ -434,16 +445,19 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
                 n_below += (uint32_t)__popcll(__ballot(below));
                 const unsigned long long mask = __ballot(cand);
                 if (mask) {
-                    if (cand) stage[held + __popcll(mask & ((1ull << lane) - 1ull))] = out;
                     const int c = __popcll(mask);
-                    held += c;
+                    int pos0 = 0;
+                    if (lane == 0) pos0 = atomicAdd(&s_held, c);
+                    pos0 = __builtin_amdgcn_readfirstlane(pos0);
+                    if (cand) stage[pos0 + __popcll(mask & ((1ull << lane) - 1ull))] = out;
                     n_in += (uint32_t)c;
-                    if (held > NKF_STAGE / 2) flush();
                 }
             }
+            // (r is uniform over the workgroup: every wave walks the same rows) room for NKL_ROWS more rows must remain
+            if (((r + 1) % NKL_ROWS) == 0 && r + 1 < nrow) block_flush(NKL_CAP - 2 * NKL_ROWS * 256);
         }
     }
-    if (held > 0) flush();
+    block_flush(0);
     K kmin = (fmin_a <= fmax_a) ? key_of(fmin_a) : ~(K)0;
     K kmax = (fmin_a <= fmax_a) ? key_of(fmax_a) : (K)0;
     for (int off = 32; off > 0; off >>= 1) {
@@ -451,12 +465,25 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
         kmin = a < kmin ? a : kmin;
         kmax = b > kmax ? b : kmax;
     }
+    // one set of global atomics per workgroup
     if (lane == 0) {
-        if (kmin != ~(K)0) k_atomic_min(&stats->asp_min, (uint64_t)kmin);
-        if (kmax != 0) k_atomic_max(&stats->asp_max, (uint64_t)kmax);
-        if (n_all) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), (unsigned long long)n_all);
-        if (n_below) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[1]), (unsigned long long)n_below);
-        if (n_in) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2]), (unsigned long long)n_in);
+        s_red[wave][0] = (uint64_t)kmin; s_red[wave][1] = (uint64_t)kmax;
+        s_red[wave][2] = n_all; s_red[wave][3] = n_below; s_red[wave][4] = n_in;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t mn = ~(uint64_t)0, mx = 0, c0 = 0, c1 = 0, c2 = 0;
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t a = (s_red[w][0] == (uint64_t)(~(K)0)) ? ~(uint64_t)0 : s_red[w][0];
+            mn = a < mn ? a : mn;
+            mx = s_red[w][1] > mx ? s_red[w][1] : mx;
+            c0 += s_red[w][2]; c1 += s_red[w][3]; c2 += s_red[w][4];
+        }
+        if (mn != ~(uint64_t)0) k_atomic_min(&stats->asp_min, mn);
+        if (mx != 0) k_atomic_max(&stats->asp_max, mx);
+        if (c0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), (unsigned long long)c0);
+        if (c1) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[1]), (unsigned long long)c1);
+        if (c2) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2]), (unsigned long long)c2);
     }
 }
 
@@ -473,6 +500,7 @@ template <typename T> struct NkDhSource {
     struct Raw { T a00, a01, a10, a11, rv, av; BiTap t; int64_t q; uint8_t vd; };
     struct Acc { K kmin = ~(K)0, kmax = 0; };
     static size_t lds_bytes(int) { return 0; }
+    static constexpr bool HAS_LEAN = false;
     __device__ __forceinline__ void setup(unsigned char*, int) {}
     __device__ __forceinline__ void fetch(int64_t p, Raw& r) const {
         r.q = q0 + p;
@@ -593,6 +621,26 @@ __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, con
 // The same y / bin id computed on the fly for the bracketed selection (select_run.h): its sample and counting passes read
 // dh, slope_tan and aspect directly, so the y and bin-id arrays are neither written nor re-read (nk_y_kernel + plain
 // selection remain the fallback).  The counting pass, which sees every element once, also accumulates the two sums.
+// Aspect-bin cache: the bin of a pixel depends only on its aspect and on the edges, and the edges (SciPy's linspace between the
+// min and max aspect of the valid pixels, or the caller's explicit edges) hardly ever change between the steps of a fit.  The
+// first pass under a given set of edges stores every pixel's bin id (uint16, 0xFFFF = outside) and later passes read 2 bytes
+// instead of digitizing a 4-byte aspect again; a one-thread kernel compares the edges with the record of what the cache holds.
+struct BinCacheRec { double e0, eN; int nb; int fresh; };
+template <typename T> __global__ void nk_bin_cache_check_kernel(const T* edges, int nb, BinCacheRec* rec, int force) {
+    if (threadIdx.x == 0) {
+        const double e0 = (double)edges[0], eN = (double)edges[nb];
+        rec->fresh = (!force && rec->nb == nb && rec->e0 == e0 && rec->eN == eN) ? 1 : 0;
+    }
+}
+// (launched once a pass over ALL own pixels has been queued under these edges; nb = 0 invalidates)
+template <typename T> __global__ void nk_bin_cache_commit_kernel(const T* edges, int nb, BinCacheRec* rec) {
+    if (threadIdx.x == 0) {
+        rec->e0 = nb > 0 ? (double)edges[0] : 0.0;
+        rec->eN = nb > 0 ? (double)edges[nb] : 0.0;
+        rec->nb = nb;
+    }
+}
+
 template <typename T> struct NkYSource {
     const T* dh;
     const T* slope_tan;
@@ -604,7 +652,10 @@ template <typename T> struct NkYSource {
     double inv_width;
     T vshift;
     int last_decimal;  // rounding precision of SciPy's rightmost-edge rule (NK_AUTO_EDGES for the automatic edges)
-    struct Raw { T d, st, x; };
+    uint16_t* bcache = nullptr;          // per-pixel bin ids (null: no cache)
+    const BinCacheRec* rec = nullptr;
+    int fresh = -1;                      // 1: read the cache, 0: digitize and fill it, -1: digitize only
+    struct Raw { T d, st, x; int64_t p; uint16_t b; };
     struct Acc { double s1 = 0.0, s2 = 0.0; };
     static size_t lds_bytes(int nb) { return sizeof(T) * (size_t)(nb + 1) + 8; }
     __device__ __forceinline__ void setup(unsigned char* lds, int nb) {
@@ -612,25 +663,40 @@ template <typename T> struct NkYSource {
         for (int k = threadIdx.x; k <= nb; k += blockDim.x) e[k] = edges[k];
         inv_width = (double)nb / ((double)edges[nb] - (double)edges[0]);
         vshift = *vshift_p;
+        fresh = bcache ? __builtin_amdgcn_readfirstlane(rec->fresh) : -1;
     }
-    __device__ __forceinline__ void fetch(int64_t p, Raw& r) const { r.d = dh[p]; r.st = slope_tan[p]; r.x = aspect[p]; }
-    __device__ __forceinline__ void blank(Raw& r) const { r.d = (T)NAN; r.st = (T)1; r.x = (T)0; }
-    template <bool ACC> __device__ __forceinline__ bool eval(const Raw& r, int nb, T& v, uint16_t& b, Acc& acc) const {
-        v = (T)NAN;
-        b = 0xFFFF;
-        if (!(r.d == r.d)) return false;
-        const T yv = t_div(t_sub(r.d, vshift), r.st);
-        const T x = r.x;
+    __device__ __forceinline__ void fetch(int64_t p, Raw& r) const {
+        r.d = dh[p]; r.st = slope_tan[p]; r.p = p;
+        if (fresh == 1) { r.b = bcache[p]; r.x = (T)0; }
+        else { r.x = aspect[p]; r.b = 0xFFFF; }
+    }
+    __device__ __forceinline__ void blank(Raw& r) const { r.d = (T)NAN; r.st = (T)1; r.x = (T)0; r.p = -1; r.b = 0xFFFF; }
+    __device__ __forceinline__ uint16_t digitize(T x, int nb) const {
         int idx = (int)(((double)x - (double)e[0]) * inv_width);  // (same digitize as nk_y_kernel)
         idx = idx < 0 ? 0 : (idx > nb ? nb : idx);
         while (idx > 0 && !(e[idx] <= x)) --idx;
         while (idx < nb && e[idx + 1] <= x) ++idx;
         if (!(e[0] <= x)) idx = -1;
         if (idx == nb && on_last_edge<T>(x, e[nb], last_decimal)) idx = nb - 1;
+        return (idx >= 0 && idx < nb) ? (uint16_t)idx : (uint16_t)0xFFFF;
+    }
+    template <bool ACC> __device__ __forceinline__ bool eval(const Raw& r, int nb, T& v, uint16_t& b, Acc& acc) const {
+        v = (T)NAN;
+        b = 0xFFFF;
+        uint16_t bin = r.b;
+        if (fresh != 1) {
+            if (fresh == 0) {  // filling pass: every pixel, whatever its dh is this step
+                if (r.p >= 0) { bin = digitize(r.x, nb); bcache[r.p] = bin; }
+            } else if (r.d == r.d) {
+                bin = digitize(r.x, nb);
+            }
+        }
+        if (!(r.d == r.d)) return false;
+        const T yv = t_div(t_sub(r.d, vshift), r.st);
         if (ACC) { acc.s1 += (double)yv; acc.s2 += (double)yv * (double)yv; }
         v = yv;
-        if (idx < 0 || idx >= nb) return false;
-        b = (uint16_t)idx;
+        if (bin == 0xFFFF) return false;
+        b = bin;
         return yv == yv;
     }
     __device__ __forceinline__ void finish(Acc& acc) const {
@@ -638,7 +704,116 @@ template <typename T> struct NkYSource {
         for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s1); atomicAdd(&sums[1], s2); }
     }
+    // the counting pass has a dedicated kernel for cached bins (nk_bins_lean_kernel below): the generic one steps aside then
+    static constexpr bool HAS_LEAN = true;
+    __device__ __forceinline__ bool skip_counting_pass() const { return fresh == 1; }
+    int launch_lean(xdemhip_ctx* ctx, int64_t n, int nb, const typename KeyT<T>::type* d_klo, const typename KeyT<T>::type* d_khi,
+                    uint64_t* d_cnt, T* c_vals, uint16_t* c_bins, unsigned long long* d_flags, int64_t c_cap) const;
 };
+
+// ---- lean form of the per-bin counting pass (select_run.h: bracket_pass_kernel over NkYSource) for steps whose aspect bins are
+// cached: 10 bytes per pixel (dh, slope tangent, bin id), one LDS read for the bin's bracket, one LDS atomic for its class,
+// candidates compacted through per-wave staging (no workgroup barrier in the loop).  The generic kernel -- measured VALU-bound at
+// about 145 vector instructions per element -- stays in charge of the steps that (re)fill the cache; both are queued, each
+// leaves at once when the device-side `fresh` flag says it is the other one's turn.
+constexpr int NKB_TILE = 4;
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __restrict__ dh, const T* __restrict__ slope_tan,
+                                                                    const uint16_t* __restrict__ bcache, const BinCacheRec* rec,
+                                                                    const T* vshift_p, int64_t n, int nb, int copies,
+                                                                    const typename KeyT<T>::type* __restrict__ klo,
+                                                                    const typename KeyT<T>::type* __restrict__ khi,
+                                                                    uint64_t* counters /* [3][nb] */, T* out_v, uint16_t* out_b,
+                                                                    unsigned long long* ctr, int64_t cap, double* sums) {
+    typedef typename KeyT<T>::type K;
+    if (rec->fresh != 1) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // workgroup staging exactly as in bracket_pass_kernel (one global atomic per burst of thousands of candidates)
+    BlockStage<T> st;
+    st.v = reinterpret_cast<T*>(smem);
+    st.b = reinterpret_cast<uint16_t*>(st.v + SEL_STAGE_CAP);
+    st.base = reinterpret_cast<unsigned long long*>(st.b + SEL_STAGE_CAP);
+    st.held = reinterpret_cast<int*>(st.base + 1);
+    K* lohi = reinterpret_cast<K*>(st.base + 2);               // [nb][2]
+    uint32_t* c = reinterpret_cast<uint32_t*>(lohi + 2 * nb);  // [copies][cs]: 3 counters per bin
+    const int cs = (3 * nb) | 1;  // odd copy stride: the copies of one counter fall into different LDS banks
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { lohi[2 * k] = klo[k]; lohi[2 * k + 1] = khi[k]; }
+    for (int k = threadIdx.x; k < cs * copies; k += blockDim.x) c[k] = 0;
+    if (threadIdx.x == 0) *st.held = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    uint32_t* cc = c + (threadIdx.x % copies) * cs;
+    const T vshift = *vshift_p;
+    double s1 = 0.0, s2 = 0.0;
+    int it = 0;
+    const int64_t step = (int64_t)blockDim.x * NKB_TILE;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+        T d[NKB_TILE], sl[NKB_TILE];
+        uint16_t b[NKB_TILE];
+        if (base + step <= n) {  // (uniform) whole tile inside: no per-element bounds logic
+#pragma unroll
+            for (int q = 0; q < NKB_TILE; ++q) {
+                const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+                d[q] = dh[p]; sl[q] = slope_tan[p]; b[q] = bcache[p];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NKB_TILE; ++q) {
+                const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+                const bool in = p < n;
+                const int64_t pc = in ? p : n - 1;
+                d[q] = dh[pc]; sl[q] = slope_tan[pc]; b[q] = bcache[pc];
+                if (!in) d[q] = (T)NAN;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NKB_TILE; ++q) {
+            const T yv = t_div(t_sub(d[q], vshift), sl[q]);
+            const bool has = d[q] == d[q];
+            if (has) { s1 += (double)yv; s2 += (double)yv * (double)yv; }
+            const bool ok = has & (b[q] != 0xFFFF) & (yv == yv);
+            bool cand = false;
+            if (ok) {
+                const K key = key_of(yv);
+                const K l = lohi[2 * b[q]], h = lohi[2 * b[q] + 1];
+                cand = (key >= l) & (key <= h);
+                const int cls = key < l ? 1 : (cand ? 2 : 0);
+                atomicAdd(&cc[cls * nb + b[q]], 1u);
+            }
+            st.append_bounded(cand, yv, b[q], &ctr[2]);
+        }
+        if ((++it % SEL_FLUSH_EVERY) == 0) st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
+    }
+    st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if (lane == 0) { atomicAdd(&sums[0], s1); atomicAdd(&sums[1], s2); }
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        unsigned long long above = 0, below = 0, inside = 0;
+        for (int q = 0; q < copies; ++q) {
+            above += c[q * cs + k]; below += c[q * cs + nb + k]; inside += c[q * cs + 2 * nb + k];
+        }
+        if (above + below + inside) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[k]), above + below + inside);
+        if (below) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[nb + k]), below);
+        if (inside) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2 * nb + k]), inside);
+    }
+}
+
+template <typename T>
+int NkYSource<T>::launch_lean(xdemhip_ctx* ctx, int64_t n, int nb, const typename KeyT<T>::type* d_klo, const typename KeyT<T>::type* d_khi,
+                              uint64_t* d_cnt, T* c_vals, uint16_t* c_bins, unsigned long long* d_flags, int64_t c_cap) const {
+    typedef typename KeyT<T>::type K;
+    if (!bcache || n <= 0) return XDEMHIP_OK;
+    int copies = (28 * 1024) / (nb * 12);
+    copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
+    const size_t lds = (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16 + (size_t)nb * 2 * sizeof(K) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies;
+    int rc = set_big_lds(ctx, nk_bins_lean_kernel<T>, lds);
+    if (rc) return rc;
+    // (grid-stride: two 1024-thread workgroups per CU are resident -- LDS -- and that is the grid)
+    hipLaunchKernelGGL((nk_bins_lean_kernel<T>), dim3(grid_for(ctx, n, HIST_THREADS * NKB_TILE, 2)), dim3(HIST_THREADS), lds, ctx->stream, dh,
+                       slope_tan, bcache, rec, vshift_p, n, nb, copies, d_klo, d_khi, d_cnt, c_vals, c_bins, d_flags, c_cap, sums);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    return XDEMHIP_OK;
+}
 
 }  // namespace xd
 
@@ -657,6 +832,8 @@ struct xdemhip_nk_plan {
     void *slope_tan = nullptr, *aspect = nullptr, *dh = nullptr, *y = nullptr;
     uint8_t* valid = nullptr;
     uint16_t* bins = nullptr;
+    uint16_t* bcache = nullptr;   // aspect-bin cache (NkYSource), one id per buffer pixel
+    bool bcache_force = true;     // the cache does not hold the bins of the current own rows / edges: refill at the next step
     void* scratch = nullptr;  // edges, stats, sums, selection states, successor keys, histograms
     size_t scratch_bytes = 0;
     int max_bins = 0;
@@ -972,12 +1149,19 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         if (rc) return rc;
         // stage 3 + 4, queued right behind stage 1 + 2 on the fused route (vshift and the edges are read from the device)
         std::vector<SelResult<K>> hs;
-        bool bins_done = false;
+        bool bins_done = false, bins_passed = false;
         double* d_bsum = reinterpret_cast<double*>(base + off_hist(nb));
         unsigned long long* d_bcnt = reinterpret_cast<unsigned long long*>(d_bsum + nb);
         double* d_fit = reinterpret_cast<double*>(base + off_hist(1));
         NkYSource<T> src{dh, st, asp, d_vshift, d_edges, d_sums, nullptr, 0.0, (T)0,
                          P->custom_edges.empty() ? NK_AUTO_EDGES : P->custom_decimal};
+        BinCacheRec* d_rec = reinterpret_cast<BinCacheRec*>(base + OFF_INFO + 64);
+        if (!fit_sums && P->bcache) {
+            src.bcache = P->bcache + q0;
+            src.rec = d_rec;
+            hipLaunchKernelGGL((nk_bin_cache_check_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec, (int)P->bcache_force);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+        }
         XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
         if (fit_sums) {
             XD_HIP_CHECK(ctx, hipMemsetAsync(d_fit, 0, 80, ctx->stream));
@@ -993,11 +1177,25 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
             if (nb > 3072) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins too large for the mean statistic");
             rc = run_bin_sums<T, NkYSource<T>>(ctx, src, n, nb, d_bsum, d_bcnt);
             if (rc) return rc;
+            if (src.bcache) {  // the pass visited every own pixel: the cache now holds the bins of these edges
+                hipLaunchKernelGGL((nk_bin_cache_commit_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec);
+                P->bcache_force = false;
+            }
         } else {
             // per-bin exact medians, bracketed route: y and the bin ids are computed on the fly by the sample / counting
             // passes (NkYSource), the counting pass accumulates the sums
-            rc = run_select_bracketed<T, NkYSource<T>>(ctx, src, n, nb, base, hs, &P->ws, &bins_done);
+            rc = run_select_bracketed<T, NkYSource<T>>(ctx, src, n, nb, base, hs, &P->ws, &bins_done, &bins_passed);
             if (rc) return rc;
+            if (src.bcache) {
+                // the counting pass ran over every own pixel (whether or not its brackets held): the cache is filled; a route
+                // that never launched it leaves the record untouched and the cache marked stale
+                if (bins_passed) {
+                    hipLaunchKernelGGL((nk_bin_cache_commit_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec);
+                    P->bcache_force = false;
+                } else {
+                    P->bcache_force = true;
+                }
+            }
         }
         unsigned char info[32];
         { const int rc_ = xd_d2h(ctx, info, base + OFF_INFO, 32); if (rc_) return rc_; }
@@ -1098,7 +1296,7 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
     if (hipMalloc(&P->slope_tan, n * es) != hipSuccess || hipMalloc(&P->aspect, n * es) != hipSuccess ||
         hipMalloc(&P->dh, n * es) != hipSuccess || hipMalloc(&P->y, n * es) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&P->valid), n) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&P->bins), n * 2) != hipSuccess || hipMalloc(&P->scratch, P->scratch_bytes) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&P->bins), n * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->bcache), n * 2) != hipSuccess || hipMalloc(&P->scratch, P->scratch_bytes) != hipSuccess)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
     if ((int64_t)n >= SEL_BRACKET_MIN_N && sel_ws_create(ctx, (int64_t)n, es, MAX_BINS_PER_SWEEP, P->ws) != XDEMHIP_OK)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
@@ -1120,7 +1318,7 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     if (!P) return;
     (void)hipSetDevice(P->ctx->device);
     if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
-    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->scratch};
+    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     xd::sel_ws_free(P->ws);
@@ -1157,6 +1355,7 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, 
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     P->row0 = row_begin;
     P->row1 = row_end;
+    P->bcache_force = true;  // other own rows: their bins were never cached
     // valid mask / aux rasters outside the range are never read by this rank; recount the global number of valid pixels
     int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
     if (rc) return rc;
@@ -1220,6 +1419,7 @@ int xdemhip_nk_step_fit(xdemhip_nk_plan* P, double shift_x, double shift_y, doub
 
 int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* P, const double* edges, int n_edges, int decimal) {
     if (!P) return XDEMHIP_EINVAL;
+    P->bcache_force = true;
     if (n_edges == 0) { P->custom_edges.clear(); return XDEMHIP_OK; }
     if (!edges || n_edges < 2 || n_edges - 1 > MAX_BINS_PER_SWEEP) return xd_fail(P->ctx, XDEMHIP_EINVAL, "bin edges: 2 .. 129 increasing values");
     for (int k = 1; k < n_edges; ++k)

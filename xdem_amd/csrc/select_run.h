@@ -61,9 +61,16 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
         n = m < (unsigned long long)n ? (int64_t)m : n;
     }
     const int table = nb * SEL_RADIX;
-    for (int k = threadIdx.x; k < table * copies; k += blockDim.x) h[k] = 0;
+    // privatised copies sit an ODD number of words apart: a stride that is a multiple of 32 would put the same counter of every
+    // copy into one LDS bank, and lanes that agree on (bin, digit) -- the common case -- would serialise on it
+    const int cstride = copies > 1 ? table + 1 : table;
+    for (int k = threadIdx.x; k < cstride * copies; k += blockDim.x) h[k] = 0;
+    // per-bin rebase offsets and prefixes: LDS copies (two dependent global loads per element otherwise)
+    K* s_lo = reinterpret_cast<K*>(h + (size_t)cstride * copies + (((size_t)cstride * copies) & 1));
+    K* s_pref = s_lo + nb;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { s_lo[k] = rb_lo ? rb_lo[bin0 + k] : (K)0; s_pref[k] = st[bin0 + k].prefix; }
     __syncthreads();
-    uint32_t* hc = h + (threadIdx.x % copies) * table;
+    uint32_t* hc = h + (threadIdx.x % copies) * cstride;
     const K himask = first ? (K)0 : (K)(~(K)0 << (shift + 8));
     // Rebased keys (candidates of a bracketed selection): every candidate of a bin lies in [lo, hi] and shares the leading
     // digits of lo -- all lanes would hammer one LDS counter per bin.  (key - lo[bin]) << s, with s the same for all bins,
@@ -86,15 +93,15 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
             const int b = bins ? (int)bb[q] - bin0 : 0;
             if (b < 0 || b >= nb) continue;
             K key = key_of(v[q]);
-            if (rb_lo) key = (K)((K)(key - rb_lo[bin0 + b]) << rbs);
-            if (!first && (key & himask) != st[bin0 + b].prefix) continue;
+            if (rb_lo) key = (K)((K)(key - s_lo[b]) << rbs);
+            if (!first && (key & himask) != s_pref[b]) continue;
             atomicAdd(&hc[b * SEL_RADIX + (int)((key >> shift) & 0xFF)], 1u);
         }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < table; k += blockDim.x) {
         unsigned long long c = 0;
-        for (int q = 0; q < copies; ++q) c += h[q * table + k];
+        for (int q = 0; q < copies; ++q) c += h[q * cstride + k];
         if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[(size_t)bin0 * SEL_RADIX + k]), c);
     }
 }
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __rest
         n = c < (unsigned long long)n ? (int64_t)c : n;
     }
     K* pref = m + nb;
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) { m[k] = ~(K)0; pref[k] = st[k].prefix; }
+    K* s_lo = pref + nb;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { m[k] = ~(K)0; pref[k] = st[k].prefix; s_lo[k] = rb_lo ? rb_lo[k] : (K)0; }
     const int rbs = rb_shift ? (int)*rb_shift : 0;
     __syncthreads();
     const int64_t step = (int64_t)blockDim.x * SEL_UNROLL;
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __rest
             const int b = (int)bb[q];
             if (b >= nb) continue;
             K key = key_of(v[q]);
-            if (rb_lo) key = (K)((K)(key - rb_lo[b]) << rbs);
+            if (rb_lo) key = (K)((K)(key - s_lo[b]) << rbs);
             if (key > pref[b] && key < m[b]) k_atomic_min(&m[b], key);
         }
     }
@@ -227,7 +235,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                 // privatise the table as often as fits in ~64 KB (32 copies for the single-bin global median)
                 int copies = (64 * 1024) / (nbs * SEL_RADIX * (int)sizeof(uint32_t));
                 copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
-                const size_t lds = (size_t)nbs * SEL_RADIX * sizeof(uint32_t) * copies;
+                const size_t lds = ((size_t)nbs * SEL_RADIX + 1) * sizeof(uint32_t) * copies + 8 + 2 * sizeof(K) * (size_t)nbs;
                 int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
                 if (rc) return rc;
                 hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
@@ -242,7 +250,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     }
     if (!want_succ) return XDEMHIP_OK;
     if (n > 0) {
-        hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), 2 * sizeof(K) * nb, ctx->stream, vals, bins, n, nb, st,
+        hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), 3 * sizeof(K) * nb, ctx->stream, vals, bins, n, nb, st,
                            d_succ, d_n, rb_lo, rb_shift);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -401,6 +409,7 @@ template <typename T> struct ArraySource {
         return (v == v) && (int)b < nb;
     }
     __device__ __forceinline__ void finish(Acc&) const {}
+    static constexpr bool HAS_LEAN = false;  // (sources with a dedicated counting kernel: see NkYSource)
 };
 
 template <typename T, typename Src>
@@ -504,11 +513,15 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int
     K* hi = lo + nb;
     uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);
     for (int k = threadIdx.x; k < nb; k += blockDim.x) { lo[k] = klo[k]; hi[k] = khi[k]; }
-    for (int k = threadIdx.x; k < 3 * nb * copies; k += blockDim.x) c[k] = 0;
-    src.setup(reinterpret_cast<unsigned char*>(c + 3 * nb * copies), nb);
+    const int cs = (3 * nb) | 1;  // odd copy stride: the copies of one counter fall into different LDS banks
+    for (int k = threadIdx.x; k < cs * copies; k += blockDim.x) c[k] = 0;
+    src.setup(reinterpret_cast<unsigned char*>(c + cs * copies), nb);
     if (threadIdx.x == 0) *st.held = 0;
     __syncthreads();
-    uint32_t* cc = c + (threadIdx.x % copies) * 3 * nb;
+    if constexpr (Src::HAS_LEAN) {
+        if (src.skip_counting_pass()) return;  // (uniform) the source's own kernel, queued right behind, does this step
+    }
+    uint32_t* cc = c + (threadIdx.x % copies) * cs;
     typename Src::Acc acc;
     int it = 0;
     const int64_t step = (int64_t)blockDim.x * SEL_TILE;
@@ -545,7 +558,7 @@ __global__ __launch_bounds__(HIST_THREADS) void bracket_pass_kernel(Src src, int
     for (int k = threadIdx.x; k < nb; k += blockDim.x) {
         unsigned long long above = 0, below = 0, inside = 0;
         for (int q = 0; q < copies; ++q) {
-            above += c[q * 3 * nb + k]; below += c[q * 3 * nb + nb + k]; inside += c[q * 3 * nb + 2 * nb + k];
+            above += c[q * cs + k]; below += c[q * cs + nb + k]; inside += c[q * cs + 2 * nb + k];
         }
         if (above + below + inside) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[k]), above + below + inside);
         if (below) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[nb + k]), below);
@@ -621,9 +634,10 @@ int run_bin_sums(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, double* d_
 // then runs the plain selection on materialised arrays.
 template <typename T, typename Src>
 int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, unsigned char* scratch,
-                         std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws, bool* done) {
+                         std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws, bool* done, bool* passed = nullptr) {
     typedef typename KeyT<T>::type K;
     *done = false;
+    if (passed) *passed = false;  // set once the pass over all elements has been queued (sources with side effects rely on it)
     static const bool disabled = getenv("XDEMHIP_NO_BRACKET") != nullptr;  // (A/B timing knob)
     const bool plain = disabled || ctx->selection_mode == 1 || !ws || !ws->d_small || nb > ws->nb_max || ws->es != sizeof(T) || nb > MAX_BINS_PER_SWEEP ||
                        n < SEL_BRACKET_MIN_N || (ctx->selection_mode == 0 && n < SEL_BRACKET_MIN_PER_BIN * nb) || (n / 24 + 4096) > ws->s_cap;
@@ -672,12 +686,17 @@ int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, un
     // 3. the one pass over the data
     int copies = (32 * 1024) / (nb * 12);
     copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
-    const size_t lds = lds_stage + (size_t)nb * (2 * sizeof(K) + 12 * (size_t)copies) + lds_src;
+    const size_t lds = lds_stage + (size_t)nb * 2 * sizeof(K) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies + 8 + lds_src;
     rc = set_big_lds(ctx, bracket_pass_kernel<T, Src>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((bracket_pass_kernel<T, Src>), dim3(grid_for(ctx, n, HIST_THREADS * SEL_TILE, 2)), dim3(HIST_THREADS), lds, ctx->stream, src,
                        n, nb, copies, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), ws->c_bins, d_flags, ws->c_cap);
     XD_HIP_CHECK(ctx, hipGetLastError());
+    if constexpr (Src::HAS_LEAN) {
+        rc = src.launch_lean(ctx, n, nb, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), ws->c_bins, d_flags, ws->c_cap);
+        if (rc) return rc;
+    }
+    if (passed) *passed = true;
     rc = xd_allreduce_device(ctx, d_cnt, 3 * (int64_t)nb, XDEMHIP_RED_SUM_U64);
     if (rc) return rc;
     rc = xd_allreduce_device(ctx, d_ctr + 2, 1, XDEMHIP_RED_SUM_U64);  // overflow anywhere -> everybody falls back
