@@ -49,6 +49,7 @@ template <typename K> struct SelState {
     uint64_t rank;     // remaining 0-based rank inside the current prefix group
     uint64_t count;    // elements in the bin
     uint64_t n_le;     // elements <= selected key (valid after the last pass)
+    uint64_t group;    // elements that share the digits fixed so far with the selected key
 };
 
 // Advance every bin by one digit: hist[bin][256] holds the counts of the current digit among the elements that
@@ -73,9 +74,16 @@ __host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m) {
 
 template <typename K>
 __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
-                                                            int mode = SEL_MEDIAN, const uint64_t* given = nullptr) {
+                                                            int mode = SEL_MEDIAN, const uint64_t* given = nullptr,
+                                                            const uint32_t* rb_shift = nullptr) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
+    // Rebased keys ((key - lo) << s, select_run.h) have s zero bits at the bottom: a digit that lies entirely inside them is 0
+    // for every element, its pass is skipped (hist_pass_kernel leaves at once) and the state moves on without a histogram.
+    if (!first && rb_shift && shift + 8 <= (int)*rb_shift) {
+        if (last && lane == 0 && st[b].count) st[b].n_le += st[b].group;
+        return;
+    }
     uint64_t* h = hist + (size_t)b * SEL_RADIX;
     unsigned long long c[4], mine = 0;
 #pragma unroll
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         s.rank = r;
         s.prefix = 0;
         s.n_le = 0;
+        s.group = total;
     }
     if (s.count) {
         // the lane whose bucket range contains the rank (the last non-empty lane if the rank lies beyond: cannot happen
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         s.prefix |= (K)dsel << shift;
         s.n_le += cumsel;  // elements strictly below the chosen digit group
         s.rank -= cumsel;
+        s.group = hsel;
         if (last) s.n_le += hsel;  // all digits fixed: group == the selected key's duplicates
     }
     if (lane == 0) st[b] = s;

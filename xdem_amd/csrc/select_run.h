@@ -60,6 +60,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
         const unsigned long long m = *n_dev;
         n = m < (unsigned long long)n ? (int64_t)m : n;
     }
+    if (!first && rb_shift && shift + 8 <= (int)*rb_shift) return;  // all-zero digit of rebased keys: see select_advance_kernel
     const int table = nb * SEL_RADIX;
     // privatised copies sit an ODD number of words apart: a stride that is a multiple of 32 would put the same counter of every
     // copy into one LDS bank, and lanes that agree on (bin, digit) -- the common case -- would serialise on it
@@ -245,7 +246,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
-                           (int)(p == 0), (int)(p == passes - 1), mode, d_given);
+                           (int)(p == 0), (int)(p == passes - 1), mode, d_given, rb_shift);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     if (!want_succ) return XDEMHIP_OK;

@@ -920,7 +920,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     const int nb = P->nb;
     // small device block: selection states | klo | khi | given | counters[3 nb] | candidate counter, overflow
     unsigned char* d_small = nullptr;
-    const size_t off_klo = (size_t)nb * 32, off_khi = off_klo + 8 * (size_t)nb, off_given = off_khi + 8 * (size_t)nb,
+    const size_t off_klo = (size_t)nb * sizeof(SelState<K>), off_khi = off_klo + 8 * (size_t)nb, off_given = off_khi + 8 * (size_t)nb,
                  off_cnt = off_given + 8 * (size_t)nb, off_ctr = off_cnt + 24 * (size_t)nb, off_rbs = off_ctr + 16, small_bytes = off_rbs + 8;
     if (hipMalloc(reinterpret_cast<void**>(&d_small), small_bytes) != hipSuccess) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
     SelState<K>* d_st = reinterpret_cast<SelState<K>*>(d_small);
