@@ -242,10 +242,12 @@ def secondary_metrics(ctx, dev) -> dict:
                                              "the 72 aspect bins; plain radix passes would need 12)",
                                     "passes": passes, "achieved": round(8 * passes * px / dt / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round(8 * passes * px / dt / 1e9 / HBM_PEAK_GBPS, 4),
-                                    "touched_bytes_per_pixel": 31,
-                                    "touched_GBps": round(31 * px / dt / 1e9, 1),
-                                    "note": "the passes actually touch ~31 B/pixel (dh pass: ref 4 + tba taps ~6 + aspect 4 + mask 1 + dh out 4; "
-                                            "bin pass: dh 4 + slope_tan 4 + aspect 4): the aux rasters are stored, not recomputed"},
+                                    "touched_bytes_per_pixel": 27,
+                                    "touched_GBps": round(27 * px / dt / 1e9, 1),
+                                    "note": "the two passes actually touch 27 B/pixel (dh pass: ref 4 + tba 4 + aspect 4 + mask 1 + dh out 4; "
+                                            "bin pass: dh 4 + slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not "
+                                            "recomputed; kernel times alone: dh pass ~1.35 ms (5.0 TB/s), bin pass ~0.97 ms (4.1 TB/s), "
+                                            "the rest of a step is ~45 small launches of the five exact selections"},
                        "note": "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32); "
                                "ms_per_iteration = grid work of a step (host 72-point fit excluded), ms_per_iteration_whole_fit = "
                                "NuthKaab's 10-iteration loop incl. scipy curve_fit, per iteration"}
