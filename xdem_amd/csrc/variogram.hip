@@ -91,13 +91,31 @@ __device__ __forceinline__ uint64_t key_abs(double v) { return (uint64_t)__doubl
 
 typedef short v2s16 __attribute__((ext_vector_type(2)));
 
+// r = (mask bit of this lane) ? b : a, the lane mask held in an SGPR pair (a divergent `bool` carried around a loop is
+// legalised into a 0/1 VGPR and costs a compare per use; an explicit 64-bit mask stays scalar)
+__device__ __forceinline__ uint32_t select_by_mask(uint32_t a, uint32_t b, unsigned long long mask) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ float select_by_mask(float a, float b, unsigned long long mask) {
+    return __uint_as_float(select_by_mask(__float_as_uint(a), __float_as_uint(b), mask));
+}
+__device__ __forceinline__ double select_by_mask(double a, double b, unsigned long long mask) {
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    const uint32_t lo = select_by_mask((uint32_t)ua, (uint32_t)ub, mask), hi = select_by_mask((uint32_t)(ua >> 32), (uint32_t)(ub >> 32), mask);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // GRID (implies FAST): the points lie on an integer lattice (raster pixel centres -- the reference's cdist / pdist samplers
 // draw raster pixels, xdem/spatialstats.py:1413-1416): coordinates are packed int16 lattice indexes, the squared lattice
 // distance of a pair is ONE v_pk_sub_i16 + ONE v_dot2_i32_i16, exact in 32 bits, and the class follows from integer
 // thresholds that are the exact pre-images of the float64 thresholds (host: make_grid) -- identical classes, a third fewer
 // instructions per pair than the float64 coordinates (5 float64 operations + a 64-bit compare).
 template <typename T, int OP, bool FAST, int NT, bool GRID = false>
-__global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
+// (1024-thread workgroups: two of them per CU -- 8 waves per SIMD -- need at most 64 VGPRs: second launch-bound = waves per SIMD; float32 values only, the float64
+// kernels do not fit that budget without spilling)
+__global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pairs_kernel(const PairArgs<T> a) {
     typedef typename KeyT<T>::type K;
     // sampled digit passes: a workgroup none of whose (up to 16) B tiles is in the sample leaves before touching LDS (4 of 5 do;
     // otherwise zeroing and flushing their 51 KB histograms would dominate the pass)
@@ -129,8 +147,12 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
     uint32_t* s_c3 = reinterpret_cast<uint32_t*>(acc);              // OP_BRACKET: [3][nb][NCOPY] counters, then the staging buffer
     BlockStage<T> stage;
+    // OP_BRACKET: counters [3][nb + 1][NCOPY] (class nb = spare: pairs that are no pairs -- beyond the last edge, diagonal, NaN --
+    // count there, so the hot loop needs no predicate), then the bracket ends interleaved {low, high} per class (one 8 / 16-byte
+    // read per pair; the spare class holds {all-ones, 0}: always "below", never a candidate), then the staging buffer
+    K* s_lh = reinterpret_cast<K*>(s_c3 + 3 * (a.nb + 1) * NCOPY);  // (3 * (nb + 1) * 32 words: 8-byte aligned)
     if (OP == OP_BRACKET) {
-        stage.v = reinterpret_cast<T*>(s_c3 + 3 * a.nb * NCOPY + ((3 * a.nb * NCOPY) & 1));  // 8-byte aligned
+        stage.v = reinterpret_cast<T*>(s_lh + 2 * (a.nb + 1));
         stage.b = reinterpret_cast<uint16_t*>(stage.v + SEL_STAGE_CAP);
         stage.base = reinterpret_cast<unsigned long long*>(stage.b + SEL_STAGE_CAP);
         stage.held = reinterpret_cast<int*>(stage.base + 1);
@@ -160,7 +182,11 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
         for (int k = tid; k < a.nb; k += NT) s_pref[k] = a.prefix[k];
     if (OP == OP_BRACKET) {
         for (int k = tid; k < a.nb; k += NT) s_khi[k] = a.khi[k];
-        for (int k = tid; k < 3 * a.nb * NCOPY; k += NT) s_c3[k] = 0;
+        for (int k = tid; k <= a.nb; k += NT) {
+            s_lh[2 * k] = k < a.nb ? a.prefix[k] : ~(K)0;
+            s_lh[2 * k + 1] = k < a.nb ? a.khi[k] : (K)0;
+        }
+        for (int k = tid; k < 3 * (a.nb + 1) * NCOPY; k += NT) s_c3[k] = 0;
         if (tid == 0) *stage.held = 0;
     }
 
@@ -196,6 +222,30 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
     const int nb = a.nb;
     const K himask = (OP == OP_HIST && !a.first) ? (K)(~(K)0 << (a.shift + 8)) : (K)0;
 
+    // OP_BRACKET, fast path: a lane keeps at most ONE candidate pending in registers; every 8 pairs the wave moves its pending
+    // candidates into the staging buffer with one LDS reservation (the per-pair form -- ballot, leader atomic with return and
+    // its round trip whenever any lane of the wave had a candidate, i.e. for half of all wave-pairs -- was most of the 22
+    // vector instructions per pair this pass spent beyond the class lookup).  A second candidate while one is pending (a few
+    // per thousand lane-octets) is appended directly.
+    T pend_v = (T)0;
+    uint32_t pend_l = 0;
+    unsigned long long pend_m = 0;  // lanes with a pending candidate (wave-uniform scalar)
+    auto flush_pending = [&]() {
+        const unsigned long long m = pend_m;
+        if (m) {  // (wave-uniform)
+            const int lane = tid & 63;
+            const int leader = __ffsll((long long)m) - 1;
+            int pos0 = 0;
+            if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(m));
+            pos0 = __builtin_amdgcn_readlane(pos0, leader);
+            if ((m >> lane) & 1ull) {
+                const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pos < SEL_STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
+                else a.cand_ctr[1] = 1ull;
+            }
+            pend_m = 0;
+        }
+    };
     if (!skip_wg)
         for (int64_t j0 = jb0; j0 < jb1; j0 += PT) {
             if (OP == OP_HIST && a.sample && !unit_sampled(wg, (int)((j0 - jb0) / PT))) continue;  // (uniform over the workgroup)
@@ -217,10 +267,10 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 if (ok) {
                     const K key = key_abs(d);
                     const int cp = tid & (NCOPY - 1);
-                    // one counter update per pair: [0] keys at or above the bracket's low end, [1] below it, [2] inside it
+                    // one counter update per pair: class 0 above the bracket, 1 below it, 2 inside it
                     const bool below = key < s_pref[l];
-                    atomicAdd(&s_c3[((below ? 1 : 0) * nb + l) * NCOPY + cp], 1u);
-                    if (!below && key <= s_khi[l]) { atomicAdd(&s_c3[(2 * nb + l) * NCOPY + cp], 1u); cand = true; }
+                    cand = !below && key <= s_khi[l];
+                    atomicAdd(&s_c3[((below ? 1 : (cand ? 2 : 0)) * (nb + 1) + l) * NCOPY + cp], 1u);
                 }
                 stage.append_bounded(cand, d, (uint16_t)l, &a.cand_ctr[1]);
             };
@@ -342,6 +392,47 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                         int lus[4];
                         T dv[4];
                         classify4(j, lus, dv);
+                        if constexpr (OP == OP_BRACKET) {
+                            const int cp = tid & (NCOPY - 1);
+                            static_assert(NCOPY * 4 == 128, "counter records are 128 bytes");
+                            const uint32_t c3_plane = (uint32_t)(nb + 1) * NCOPY * 4;
+                            int lc[4];
+                            K lo4[4], hi4[4];
+    #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                dv[u] = fabs(dv[u]);
+                                const bool ok = PLAIN || ((j + u) < cnt && (j + u) > ia_rel && dv[u] == dv[u]);
+                                lc[u] = (ok && lus[u] < nb) ? lus[u] : nb;  // everything that is no pair goes to the spare class
+                                lo4[u] = s_lh[2 * lc[u]];
+                                hi4[u] = s_lh[2 * lc[u] + 1];
+                            }
+    #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const K key = key_abs(dv[u]);
+                                const bool below = key < lo4[u];
+                                const bool inside = !below & (key <= hi4[u]);
+                                // counter address = this lane's copy + class * 128 B + {0, 1, 2} * (nb + 1) * 128 B: two selects of
+                                // uniform byte offsets and one shift-add (no 64-bit multiply-add for the index)
+                                uint32_t off = inside ? 2u * c3_plane : 0u;
+                                off = below ? c3_plane : off;
+                                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_c3 + cp) + ((uint32_t)lc[u] << 7) + off), 1u);
+                                const unsigned long long in_m = __ballot(inside);
+                                const unsigned long long clash = in_m & pend_m;
+                                if (__builtin_expect(clash != 0, 0)) {  // (wave-uniform, rare: a second candidate within 8 pairs)
+                                    if ((clash >> (tid & 63)) & 1ull) {
+                                        const int pos = atomicAdd(stage.held, 1);
+                                        if (pos < SEL_STAGE_CAP) { stage.v[pos] = dv[u]; stage.b[pos] = (uint16_t)lc[u]; }
+                                        else a.cand_ctr[1] = 1ull;
+                                    }
+                                }
+                                const unsigned long long take = in_m & ~pend_m;
+                                pend_v = select_by_mask(pend_v, dv[u], take);
+                                pend_l = select_by_mask(pend_l, (uint32_t)lc[u], take);
+                                pend_m |= take;
+                            }
+                            if ((j & 4) != 0) flush_pending();  // every second stage = 8 pairs
+                            continue;
+                        }
     #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int lu = lus[u];
@@ -370,6 +461,7 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
                 };
                 if (cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT)) run4(std::true_type());
                 else run4(std::false_type());
+                if (OP == OP_BRACKET) flush_pending();  // (a tile's pair count need not be a multiple of 8)
             } else {
                 for (int j = 0; j < cnt; ++j) pair(j, !a.pdist || (j0 + j) > ia);
             }
@@ -391,10 +483,16 @@ __global__ __launch_bounds__(NT) void pairs_kernel(const PairArgs<T> a) {
             if (s_hist[k]) atomicAdd(&a.hist[(size_t)a.bin0 * SEL_RADIX + k], (unsigned long long)s_hist[k]);
     } else if (OP == OP_BRACKET) {
         stage.sync_and_flush_at(0, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
-        for (int k = tid; k < 3 * nb; k += NT) {
-            unsigned long long c = 0;
-            for (int q = 0; q < NCOPY; ++q) c += s_c3[k * NCOPY + q];
-            if (c) atomicAdd(&a.cnt3[k], c);
+        for (int k = tid; k < nb; k += NT) {
+            unsigned long long above = 0, below = 0, inside = 0;
+            for (int q = 0; q < NCOPY; ++q) {
+                above += s_c3[k * NCOPY + q];
+                below += s_c3[((nb + 1) + k) * NCOPY + q];
+                inside += s_c3[(2 * (nb + 1) + k) * NCOPY + q];
+            }
+            if (above + inside) atomicAdd(&a.cnt3[k], above + inside);  // [0]: at or above the bracket's low end
+            if (below) atomicAdd(&a.cnt3[nb + k], below);
+            if (inside) atomicAdd(&a.cnt3[2 * nb + k], inside);
         }
     } else {
         for (int k = tid; k < nb; k += NT)
@@ -440,7 +538,9 @@ constexpr int HIST_BINS_PER_SWEEP = 128;
 template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
     size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8 + 4 * (size_t)(PT + nb + 4);
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
-    if (op == OP_BRACKET) return base + (size_t)3 * nb * NCOPY * 4 + 8 + (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
+    if (op == OP_BRACKET)
+        return base + (size_t)3 * (nb + 1) * NCOPY * 4 + 2 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 8 +
+               (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
     return base + (size_t)(nb + 1) * NCOPY * 12;
 }
