@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
     uint32_t* s_c3 = reinterpret_cast<uint32_t*>(acc);              // OP_BRACKET: [3][nb][NCOPY] counters, then the staging buffer
     BlockStage<T> stage;
-    // OP_BRACKET: counters [3][nb + 1][NCOPY] (class nb = spare: pairs that are no pairs -- beyond the last edge, diagonal, NaN --
+    // OP_BRACKET: counters [3 planes: below / inside / above the bracket][nb + 1][NCOPY] (class nb = spare: pairs that are no pairs -- beyond the last edge, diagonal, NaN --
     // count there, so the hot loop needs no predicate), then the bracket ends interleaved {low, high} per class (one 8 / 16-byte
     // read per pair; the spare class holds {all-ones, 0}: always "below", never a candidate), then the staging buffer
     K* s_lh = reinterpret_cast<K*>(s_c3 + 3 * (a.nb + 1) * NCOPY);  // (3 * (nb + 1) * 32 words: 8-byte aligned)
@@ -182,9 +182,12 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         for (int k = tid; k < a.nb; k += NT) s_pref[k] = a.prefix[k];
     if (OP == OP_BRACKET) {
         for (int k = tid; k < a.nb; k += NT) s_khi[k] = a.khi[k];
+        // (the fast loop compares the raw bits of |d| -- key_abs(d) >> 1 -- so the ends are stored halved: key >= lo <=> bits >=
+        // ceil(lo / 2), key <= hi <=> bits <= floor(hi / 2); the spare class gets an unreachable low end)
         for (int k = tid; k <= a.nb; k += NT) {
-            s_lh[2 * k] = k < a.nb ? a.prefix[k] : ~(K)0;
-            s_lh[2 * k + 1] = k < a.nb ? a.khi[k] : (K)0;
+            const K lo = k < a.nb ? a.prefix[k] : ~(K)0, hi = k < a.nb ? a.khi[k] : (K)0;
+            s_lh[2 * k] = (K)((lo >> 1) + (lo & 1));
+            s_lh[2 * k + 1] = (K)(hi >> 1);
         }
         for (int k = tid; k < 3 * (a.nb + 1) * NCOPY; k += NT) s_c3[k] = 0;
         if (tid == 0) *stage.held = 0;
@@ -267,10 +270,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 if (ok) {
                     const K key = key_abs(d);
                     const int cp = tid & (NCOPY - 1);
-                    // one counter update per pair: class 0 above the bracket, 1 below it, 2 inside it
+                    // one counter update per pair: plane 0 below the bracket, 1 inside it, 2 above it
                     const bool below = key < s_pref[l];
                     cand = !below && key <= s_khi[l];
-                    atomicAdd(&s_c3[((below ? 1 : (cand ? 2 : 0)) * (nb + 1) + l) * NCOPY + cp], 1u);
+                    atomicAdd(&s_c3[((below ? 0 : (cand ? 1 : 2)) * (nb + 1) + l) * NCOPY + cp], 1u);
                 }
                 stage.append_bounded(cand, d, (uint16_t)l, &a.cand_ctr[1]);
             };
@@ -408,15 +411,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             }
     #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const K key = key_abs(dv[u]);
-                                const bool below = key < lo4[u];
-                                const bool inside = !below & (key <= hi4[u]);
-                                // counter address = this lane's copy + class * 128 B + {0, 1, 2} * (nb + 1) * 128 B: two selects of
-                                // uniform byte offsets and one shift-add (no 64-bit multiply-add for the index)
-                                uint32_t off = inside ? 2u * c3_plane : 0u;
-                                off = below ? c3_plane : off;
-                                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_c3 + cp) + ((uint32_t)lc[u] << 7) + off), 1u);
-                                const unsigned long long in_m = __ballot(inside);
+                                const K bits = key_abs(dv[u]) >> 1;  // (|d| has no sign bit: its raw bits order like the keys)
+                                // counter plane = (bits >= lo) + (bits > hi): 0 below the bracket, 1 inside, 2 above -- two compares,
+                                // two carry adds, one multiply-add for the address (no selects)
+                                const bool ge_lo = bits >= lo4[u], gt_hi = bits > hi4[u];
+                                const uint32_t plane = (uint32_t)ge_lo + (uint32_t)(ge_lo & gt_hi);  // (an empty bracket, hi < lo: everything below or above)
+                                const bool inside = ge_lo & !gt_hi;
+                                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_c3 + cp) + ((uint32_t)lc[u] << 7) +
+                                                                      plane * c3_plane), 1u);
+                                const unsigned long long in_m = __builtin_amdgcn_ballot_w64(inside);
                                 const unsigned long long clash = in_m & pend_m;
                                 if (__builtin_expect(clash != 0, 0)) {  // (wave-uniform, rare: a second candidate within 8 pairs)
                                     if ((clash >> (tid & 63)) & 1ull) {
@@ -486,9 +489,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         for (int k = tid; k < nb; k += NT) {
             unsigned long long above = 0, below = 0, inside = 0;
             for (int q = 0; q < NCOPY; ++q) {
-                above += s_c3[k * NCOPY + q];
-                below += s_c3[((nb + 1) + k) * NCOPY + q];
-                inside += s_c3[(2 * (nb + 1) + k) * NCOPY + q];
+                below += s_c3[k * NCOPY + q];
+                inside += s_c3[((nb + 1) + k) * NCOPY + q];
+                above += s_c3[(2 * (nb + 1) + k) * NCOPY + q];
             }
             if (above + inside) atomicAdd(&a.cnt3[k], above + inside);  // [0]: at or above the bracket's low end
             if (below) atomicAdd(&a.cnt3[nb + k], below);
