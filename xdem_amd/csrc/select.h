@@ -62,9 +62,10 @@ enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3, SE
 
 // Half width (in sample ranks) of the bracket around the sample median that holds the population median with
 // overwhelming probability: 6 standard deviations of the rank (0.5 sqrt(m_eff)) for an effective sample size of
-// m / 32 -- the sample is made of whole 32-element lines, fully correlated lines being the worst case -- plus slack.
+// m / 8 -- the sample is made of whole 8-element lines (select_run.h: SEL_LINE), fully correlated lines being the worst
+// case -- plus slack.
 __host__ __device__ inline uint64_t sel_bracket_halfwidth(uint64_t m) {
-    return (uint64_t)(3.0 * sqrt(32.0 * (double)m)) + 32;
+    return (uint64_t)(3.0 * sqrt(8.0 * (double)m)) + 32;
 }
 // Same for samples of point PAIRS (variogram.hip): the sampled units are (1024 A points) x (256 B points) tiles whose pairs
 // share points, so the effective sample size is taken 64 times smaller than the pair count.

@@ -318,9 +318,13 @@ inline int sel_ws_create(xdemhip_ctx* ctx, int64_t n, size_t es, int nb_max, Sel
     return XDEMHIP_OK;
 }
 
-// Stratified 1/64 sample of 32-element lines: group g covers lines [64 g, 64 g + 64) and contributes the one line picked by
-// the top 6 bits of a multiplicative hash of g (no aliasing with the raster's row period, and sampled lines can be
-// enumerated directly instead of testing every line).
+// Stratified 1/64 sample of SEL_LINE-element lines: group g covers lines [64 g, 64 g + 64) and contributes the one line picked
+// by the top 6 bits of a multiplicative hash of g (no aliasing with the raster's row period, and sampled lines can be
+// enumerated directly instead of testing every line).  Lines are 8 elements (one 32-byte sector of a float32 array): the
+// bracket half width is sized for FULLY correlated lines (select.h: sel_bracket_halfwidth), so for the same sample volume
+// 8-element lines give brackets half as wide as the 32-element lines of round 1 -- half the candidates in the pass over all
+// elements and in the digit passes over the candidates -- for a sample pass that fetches 32-byte instead of 128-byte pieces.
+constexpr int SEL_LINE_LOG2 = 3, SEL_LINE = 1 << SEL_LINE_LOG2;
 __device__ __forceinline__ int64_t sel_sampled_line(int64_t group) {
     return group * 64 + (int64_t)((uint64_t)group * 0x9E3779B97F4A7C15ull >> 58);
 }
@@ -426,17 +430,17 @@ __global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(Src src, int
     if (threadIdx.x == 0) *st.held = 0;
     __syncthreads();
     typename Src::Acc acc;
-    // a step covers one sampled line per half-wave (32 line groups = 65536 elements per 1024-thread workgroup)
-    const int64_t n_groups = (((n + 31) >> 5) + 63) >> 6;
-    const int halves = (int)blockDim.x >> 5;
-    const int half = (int)threadIdx.x >> 5, l32 = (int)threadIdx.x & 31;
+    // a step covers one sampled line per SEL_LINE lanes (128 line groups = 65536 elements per 1024-thread workgroup)
+    const int64_t n_groups = (((n + SEL_LINE - 1) >> SEL_LINE_LOG2) + 63) >> 6;
+    const int halves = (int)blockDim.x >> SEL_LINE_LOG2;
+    const int half = (int)threadIdx.x >> SEL_LINE_LOG2, l32 = (int)threadIdx.x & (SEL_LINE - 1);
     for (int64_t g0 = (int64_t)blockIdx.x * halves; g0 < n_groups; g0 += (int64_t)gridDim.x * halves) {
         const int64_t g = g0 + half;
         bool keep = false;
         T v = (T)0;
         uint16_t b = 0;
         if (g < n_groups) {
-            const int64_t p = (sel_sampled_line(g) << 5) + l32;
+            const int64_t p = (sel_sampled_line(g) << SEL_LINE_LOG2) + l32;
             if (p < n) {
                 typename Src::Raw r;
                 src.fetch(p, r);
