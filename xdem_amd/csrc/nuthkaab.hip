@@ -969,14 +969,12 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const int64_t m_est = n / 48 + 1;
     constexpr int BR_PASSES = 3;
     const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_LO, nullptr,
+    // both ends of the bracket in ONE selection over the sample (two states, every element offered to both)
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), nullptr, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_DUAL, nullptr,
                            BR_PASSES, false);
     if (rc) return rc;
     hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, d_klo, d_khi);
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_HI, nullptr,
-                           BR_PASSES, false);
-    if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 1, 0, low_mask, d_klo, d_khi);
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st + 1, 1, 1, 0, low_mask, d_klo, d_khi);
     hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, 1, d_rbs);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // the one pass: dh for every own pixel (written), min / max aspect, counters, candidates
@@ -1149,7 +1147,10 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         if (rc) return rc;
         // stage 3 + 4, queued right behind stage 1 + 2 on the fused route (vshift and the edges are read from the device)
         std::vector<SelResult<K>> hs;
-        bool bins_done = false, bins_passed = false;
+        bool bins_done = false, bins_passed = false, tail_queued = false, committed = false;
+        unsigned char info[32];
+        std::vector<T> edges_early(nb + 1);
+        double sums_early[2] = {0.0, 0.0};
         double* d_bsum = reinterpret_cast<double*>(base + off_hist(nb));
         unsigned long long* d_bcnt = reinterpret_cast<unsigned long long*>(d_bsum + nb);
         double* d_fit = reinterpret_cast<double*>(base + off_hist(1));
@@ -1184,9 +1185,26 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         } else {
             // per-bin exact medians, bracketed route: y and the bin ids are computed on the fly by the sample / counting
             // passes (NkYSource), the counting pass accumulates the sums
-            rc = run_select_bracketed<T, NkYSource<T>>(ctx, src, n, nb, base, hs, &P->ws, &bins_done, &bins_passed);
+            // On a single GPU everything this step still has to hand back -- the cache commit, vshift / counts / flags, the edges
+            // and the two sums -- is queued behind the route BEFORE its one synchronisation (three host round trips of ~50 us
+            // otherwise).  With an all-reduce hook the sums need their reduction first: the separate copies below remain.
+            const std::function<int()> tail = [&]() -> int {
+                if (ctx->allreduce) return XDEMHIP_OK;
+                if (src.bcache) {
+                    hipLaunchKernelGGL((nk_bin_cache_commit_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec);
+                    XD_HIP_CHECK(ctx, hipGetLastError());
+                    P->bcache_force = false;
+                    committed = true;
+                }
+                { const int rc_ = xd_d2h(ctx, info, base + OFF_INFO, 32); if (rc_) return rc_; }
+                { const int rc_ = xd_d2h(ctx, edges_early.data(), d_edges, sizeof(T) * (nb + 1)); if (rc_) return rc_; }
+                { const int rc_ = xd_d2h(ctx, sums_early, d_sums, 16); if (rc_) return rc_; }
+                tail_queued = true;
+                return XDEMHIP_OK;
+            };
+            rc = run_select_bracketed<T, NkYSource<T>>(ctx, src, n, nb, base, hs, &P->ws, &bins_done, &bins_passed, &tail);
             if (rc) return rc;
-            if (src.bcache) {
+            if (src.bcache && !committed) {
                 // the counting pass ran over every own pixel (whether or not its brackets held): the cache is filled; a route
                 // that never launched it leaves the record untouched and the cache marked stale
                 if (bins_passed) {
@@ -1197,9 +1215,10 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
                 }
             }
         }
-        unsigned char info[32];
-        { const int rc_ = xd_d2h(ctx, info, base + OFF_INFO, 32); if (rc_) return rc_; }
-        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+        if (!tail_queued) {
+            { const int rc_ = xd_d2h(ctx, info, base + OFF_INFO, 32); if (rc_) return rc_; }
+            { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+        }
         uint64_t total, flags;
         double vs;
         memcpy(&total, info + 8, 8);
@@ -1220,9 +1239,22 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
             rc = run_select_core<T>(ctx, y, bins, n, nb, base, hs, SEL_MEDIAN, nullptr);
             if (rc) return rc;
         }
+        const double cnt = (double)total;
+        if (tail_queued && bins_done) {
+            // everything arrived with the route's own synchronisation
+            const double mean = sums_early[0] / cnt;
+            const double var = sums_early[1] / cnt - mean * mean;
+            *y_mean = mean;
+            *y_std = var > 0 ? sqrt(var) : 0.0;
+            for (int k = 0; k < nb; ++k) {
+                counts[k] = (int64_t)hs[k].st.count;
+                medians[k] = median_from<T>(hs[k]);
+            }
+            for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges_early[k];
+            return XDEMHIP_OK;
+        }
         std::vector<T> edges(nb + 1);
         { const int rc_ = xd_d2h(ctx, edges.data(), d_edges, sizeof(T) * (nb + 1)); if (rc_) return rc_; }
-        const double cnt = (double)total;
         if (fit_sums) {
             { const int rc_ = xd_d2h(ctx, fit_sums, d_fit, 80); if (rc_) return rc_; }
             { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }

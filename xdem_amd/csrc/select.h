@@ -58,7 +58,8 @@ template <typename K> struct SelState {
 // Target rank fixed at the first pass: SEL_MEDIAN = lower median (count-1)/2; SEL_BRACKET_LO / _HI = the median rank of a
 // SAMPLE moved down / up by sel_bracket_halfwidth(count) (select_run.h: bracketed selection); SEL_GIVEN = given[bin]
 // (all-ones: skip the bin).
-enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3, SEL_BRACKET_LO_WIDE = 4, SEL_BRACKET_HI_WIDE = 5 };
+enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3, SEL_BRACKET_LO_WIDE = 4, SEL_BRACKET_HI_WIDE = 5,
+       SEL_BRACKET_DUAL = 6 /* state 0 = low end, state 1 = high end of ONE bin's bracket, selected together */ };
 
 // Half width (in sample ranks) of the bracket around the sample median that holds the population median with
 // overwhelming probability: 6 standard deviations of the rank (0.5 sqrt(m_eff)) for an effective sample size of
@@ -101,8 +102,10 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
     if (first) {
         s.count = total;
         uint64_t r = total ? (total - 1) / 2 : 0;  // lower median
-        if (mode == SEL_BRACKET_LO && total) { const uint64_t h = sel_bracket_halfwidth(total); r = r > h ? r - h : 0; }
-        if (mode == SEL_BRACKET_HI && total) { const uint64_t h = sel_bracket_halfwidth(total); r = (r + h < total) ? r + h : total - 1; }
+        const bool lo_end = mode == SEL_BRACKET_LO || (mode == SEL_BRACKET_DUAL && b == 0);
+        const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && b == 1);
+        if (lo_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = r > h ? r - h : 0; }
+        if (hi_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total); r = r > h ? r - h : 0; }
         if (mode == SEL_BRACKET_HI_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_GIVEN) {

@@ -9,6 +9,7 @@
 
 #include <mutex>
 #include <utility>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -52,7 +53,9 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
                                                                  const SelState<typename KeyT<T>::type>* st, int shift, int first,
                                                                  uint64_t* hist, const unsigned long long* n_dev = nullptr,
                                                                  const typename KeyT<T>::type* rb_lo = nullptr,
-                                                                 const uint32_t* rb_shift = nullptr) {
+                                                                 const uint32_t* rb_shift = nullptr, int dual = 0) {
+    // dual: one data bin, TWO selection states (nb == 2, bins == nullptr) -- both ends of a bracket advance in the same passes
+    // over the sample; every element is offered to both states
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* h = reinterpret_cast<uint32_t*>(smem);
@@ -91,6 +94,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
 #pragma unroll
         for (int q = 0; q < SEL_UNROLL; ++q) {
             if (v[q] != v[q]) continue;
+            if (dual) {
+                const K key = key_of(v[q]);
+                const int digit = (int)((key >> shift) & 0xFF);
+                if (first || (key & himask) == s_pref[0]) atomicAdd(&hc[digit], 1u);
+                if (first || (key & himask) == s_pref[1]) atomicAdd(&hc[SEL_RADIX + digit], 1u);
+                continue;
+            }
             const int b = bins ? (int)bb[q] - bin0 : 0;
             if (b < 0 || b >= nb) continue;
             K key = key_of(v[q]);
@@ -213,6 +223,9 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                    unsigned char* scratch, int mode, const uint64_t* d_given, int n_passes = 0, bool want_succ = true,
                    const typename KeyT<T>::type* rb_lo = nullptr, const uint32_t* rb_shift = nullptr) {
     typedef typename KeyT<T>::type K;
+    // SEL_BRACKET_DUAL: one data bin (nb == 1 on entry, bins == nullptr), two selection states
+    const int dual = mode == SEL_BRACKET_DUAL ? 1 : 0;
+    if (dual) { if (nb != 1 || want_succ) return xd_fail(ctx, XDEMHIP_EINVAL, "dual bracket selection: one bin, no successor pass"); nb = 2; bins = nullptr; }
     SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
     uint64_t* d_hist = reinterpret_cast<uint64_t*>(scratch + off_hist(nb));
@@ -240,7 +253,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                 int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
                 if (rc) return rc;
                 hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
-                                   st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift);
+                                   st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift, dual);
                 XD_HIP_CHECK(ctx, hipGetLastError());
             }
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
@@ -639,7 +652,8 @@ int run_bin_sums(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, double* d_
 // then runs the plain selection on materialised arrays.
 template <typename T, typename Src>
 int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, unsigned char* scratch,
-                         std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws, bool* done, bool* passed = nullptr) {
+                         std::vector<SelResult<typename KeyT<T>::type>>& out, SelWorkspace* ws, bool* done, bool* passed = nullptr,
+                         const std::function<int()>* before_sync = nullptr /* queues the caller's own result copies behind the route */) {
     typedef typename KeyT<T>::type K;
     *done = false;
     if (passed) *passed = false;  // set once the pass over all elements has been queued (sources with side effects rely on it)
@@ -677,15 +691,25 @@ int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, un
     constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough (2^-15 / 2^-12 relative)
     const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
     uint32_t* d_rbs = reinterpret_cast<uint32_t*>(ws->d_small + 4);
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_LO, nullptr,
-                           BR_PASSES, false);
-    if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, d_klo, d_khi);
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_HI, nullptr,
-                           BR_PASSES, false);
-    if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 1, (int)(ctx->selection_mode == 2), low_mask, d_klo,
-                       d_khi);
+    if (nb == 1) {
+        // a single bin: both ends of its bracket in ONE selection over the sample (SEL_BRACKET_DUAL)
+        rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), nullptr, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_DUAL, nullptr,
+                               BR_PASSES, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, d_klo, d_khi);
+        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st + 1, 1, 1, (int)(ctx->selection_mode == 2), low_mask,
+                           d_klo, d_khi);
+    } else {
+        rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_LO,
+                               nullptr, BR_PASSES, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, d_klo, d_khi);
+        rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_HI,
+                               nullptr, BR_PASSES, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 1, (int)(ctx->selection_mode == 2), low_mask,
+                           d_klo, d_khi);
+    }
     hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, nb, d_rbs);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 3. the one pass over the data
@@ -718,6 +742,7 @@ int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, un
     { const int rc_ = xd_d2h(ctx, cnt.data(), d_cnt, 8 * 3 * (size_t)nb); if (rc_) return rc_; }
     { const int rc_ = xd_d2h(ctx, klo.data(), d_klo, sizeof(K) * nb); if (rc_) return rc_; }
     { const int rc_ = xd_d2h(ctx, h_ctr, d_ctr, 40); if (rc_) return rc_; }
+    if (before_sync) { rc = (*before_sync)(); if (rc) return rc; }
     rc = select_fetch<T>(ctx, scratch, nb, out);  // (synchronises the stream)
     if (rc) return rc;
     if (h_ctr[2] != 0 || h_ctr[3] != 0) return XDEMHIP_OK;  // buffer overflow or a bracket missed (*done stays false)
