@@ -33,7 +33,7 @@ def main():
     out = torch.empty((11, n, n), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     csrc = os.path.join(ROOT, "xdem_amd", "csrc")
-    libs = {"R01": "libxdemhip_r01.so", "MIX": "libxdemhip_exp2.so", "NOSTORE": "libxdemhip_expnostore.so", "RAWRSQ": "libxdemhip_exprawrsq.so"}
+    libs = {"R01": "libxdemhip_r01.so", "MIX": "libxdemhip_exp2.so", "NOSTORE": "libxdemhip_expnostore.so", "RAWRSQ": "libxdemhip_exprawrsq.so", "NOLOAD": "libxdemhip_expnoload.so"}
     variants = []
     for tag, fn in libs.items():
         path = os.path.join(csrc, fn)
@@ -54,19 +54,19 @@ def main():
             ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
         if tag == "R01":  # the round-1 library: in-session baseline (boxes of the pool clock differently)
             if not a.only or any(o in "R01" for o in a.only.split(",")):
-                variants.append(("R01", L, ctx, None, None, None))
+                variants.append(("R01", L, ctx, None, None, None, 0))
             continue
         combos = (list(itertools.product([0, 1], [0, 1], [16, 24, 32])) + [(0, 0, 132), (0, 0, 232), (0, 0, 332)]) if tag == "MIX" else [(0, 0, 32), (0, 0, 16)]
         for math, store, rows in combos:
             name = f"{tag if math == 0 else tag + '-F64'}/store{store}/rows{rows}"
             if a.only and not any(o in name for o in a.only.split(",")):
                 continue
-            variants.append((name, L, ctx, math, store, rows))
+            variants.append((name, L, ctx, math, store, rows, 0))
     planes = (ctypes.c_void_p * 11)(*[out[i].data_ptr() for i in range(11)])
     mask = 0xFFF & ~(1 << 3)
     times = {v[0]: [] for v in variants}
 
-    def run(L, ctx, math, store, rows):
+    def run(L, ctx, math, store, rows, pf=0):
         if math is not None:
             L.xdemhip_set_option(ctx, b"terrain_math", math)
             L.xdemhip_set_option(ctx, b"terrain_store", store)
@@ -78,15 +78,15 @@ def main():
         return ms.value
 
     sums = {}
-    for name, L, ctx, math, store, rows in variants:  # warm-up + checksum of every variant
-        run(L, ctx, math, store, rows)
+    for name, L, ctx, math, store, rows, pf in variants:  # warm-up + checksum of every variant
+        run(L, ctx, math, store, rows, pf)
         torch.cuda.synchronize()
         sums[name] = [float(torch.nan_to_num(out[i, ::37, ::41]).double().sum()) for i in range(11)]
     base = sums[variants[0][0]]
     for r in range(a.rounds):
-        for name, L, ctx, math, store, rows in variants:
+        for name, L, ctx, math, store, rows, pf in variants:
             for _ in range(a.reps):
-                times[name].append(run(L, ctx, math, store, rows))
+                times[name].append(run(L, ctx, math, store, rows, pf))
     gb = 48.0 * n * n / 1e9
     print(f"{'variant':24s} {'min ms':>8s} {'median':>8s} {'Gpx/s':>8s} {'TB/s':>6s} {'frac':>6s}  checksum-vs-first")
     res = {}

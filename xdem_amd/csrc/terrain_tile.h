@@ -107,6 +107,12 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
         const bool rowok = (gy >= -a.halo_top) && (gy < a.H + a.halo_bottom);
         const TIN* src = a.dem + (gy + a.halo_top) * a.stride + gx;
         vec_t val;
+#if defined(XD_NOLOAD)  // (measurement builds: what does the tile load phase cost?  synthetic pixels, no global loads)
+        if (true) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) val[e] = (TIN)(1000.0f + 0.37f * (float)((gx + e) & 1023) + 0.21f * (float)(gy & 1023) + 0.01f * (float)(((gx + e) * gy) & 255));
+        } else
+#endif
         if (rowok && a.vec_ok && gx >= 0 && gx + VEC <= a.W) {
             val = *reinterpret_cast<const vec_t*>(src);
         } else {
