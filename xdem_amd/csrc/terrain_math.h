@@ -307,7 +307,13 @@ template <typename TOUT> struct DirectSink {
 #if defined(XD_NOSTORE)  // (measurement builds: all the math, no output traffic)
         if (v != (TOUT)12345.678)  return;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XD_PLAINSTORE)
+        // streaming hint (`global_store_dword ... nt`): the planes are written once and not read back by this kernel; measured
+        // 2.8 % faster at 40000^2 (15.42 vs 15.87 ms on one box; XD_PLAINSTORE builds the old form)
+        __builtin_nontemporal_store(v, reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o));
+#else
         *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o) = v;
+#endif
     }
     XD_HD void end_row(int) {}
 };
