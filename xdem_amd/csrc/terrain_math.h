@@ -308,9 +308,19 @@ template <typename TOUT> struct DirectSink {
         if (v != (TOUT)12345.678)  return;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(XD_PLAINSTORE)
-        // streaming hint (`global_store_dword ... nt`): the planes are written once and not read back by this kernel; measured
-        // 2.8 % faster at 40000^2 (15.42 vs 15.87 ms on one box; XD_PLAINSTORE builds the old form)
-        __builtin_nontemporal_store(v, reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o));
+        // Streaming, write-through plane stores (`global_store_dword ... nt sc1`; XD_STORE_BITS overrides the bits in
+        // measurement builds): the planes are written once and never read back by this kernel.  Measured at 40000^2 in one
+        // session: plain 15.76 ms, `nt` 15.29, `nt sc1` 15.02, `nt sc0 sc1` 15.05, `sc0 sc1` 15.38.
+#ifndef XD_STORE_BITS
+#define XD_STORE_BITS "nt sc1"
+#endif
+        if constexpr (sizeof(TOUT) == 4) {
+            // (`s_nop 4`: a plane pointer restored from a spill by v_readlane right before the store needs 5 wait states
+            // before a VMEM instruction may read it -- the compiler inserts them for its own instructions, not for inline asm)
+            asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 " XD_STORE_BITS ::"v"(o), "v"(v), "s"(org.p[K]) : "memory");
+        } else {
+            __builtin_nontemporal_store(v, reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o));
+        }
 #else
         *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o) = v;
 #endif
