@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ 
 //   * the loads of row i + 1 are issued before row i is evaluated.
 struct NkRowTab { double fr; int k0l; int flags; };  // upper tap row (buffer-local, clamped), bit 0 = taps inside the raster, bit 1 = d1
 constexpr int NK_CHUNK_MAX = 512;
-constexpr int NK_PF = 3;
+constexpr int NK_PF = 4;
 constexpr int NKL_ROWS = 4;      // rows between two looks at the staging buffer
 constexpr int NKL_CAP = 4096;    // staging slots per workgroup (flushed once fewer than 2 x NKL_ROWS rows would still fit)
 template <typename T, int RULE>
