@@ -527,3 +527,41 @@ def test_nan_rules_of_the_bilinear_taps(coreg, rule):
             assert np.array_equal(out, tba, equal_nan=True)   # zero shift = identity, last row and column included
     finally:
         ctx.set_option("nk_nan_rule", 0)
+
+
+def test_lean_route_equals_plain_route_at_scale():
+    """At BASELINE's C3 scale the oracle is too slow, but the product has two independent implementations of a step: the queued
+    route (lean dh / bin kernels, bracketed selections on samples and candidates, aspect-bin cache) and the plain one (generic
+    kernels, y / bin-id arrays, full digit passes; option "selection" = 1).  Every output of every step must be identical, also
+    when a step is repeated after others (cache reuse) -- 12000^2 pair with noise and 20 % gaps."""
+    import torch
+
+    from xdem_amd import _lib, coreg
+    from xdem_amd.synth import fbm_torch
+
+    m = 12000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    ref = fbm_torch(m, m, dev, seed=42)
+    tba = torch.roll(ref, shifts=(1, -2), dims=(0, 1)) + 2.0 + 0.5 * torch.randn((m, m), device=dev, generator=g)
+    hole = fbm_torch(m, m, dev, seed=44)
+    tba[hole < torch.quantile(hole[::16, ::16].flatten(), 0.2)] = float("nan")
+    del hole
+    torch.cuda.synchronize()
+    ctx = _lib.Context(0)
+    try:
+        res = {}
+        for mode in (0, 1):
+            ctx.set_option("selection", mode)
+            plan = coreg.NKPlan(ref, tba, None, ctx)
+            res[mode] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
+            plan.close()
+        for a, b in zip(res[0], res[1]):
+            assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"]
+            assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True)
+            assert np.array_equal(a["edges"], b["edges"])
+            assert abs(a["y_mean"] - b["y_mean"]) <= 1e-12 * abs(b["y_mean"]) and abs(a["y_std"] - b["y_std"]) <= 1e-10 * b["y_std"]
+        assert res[0][1]["n_valid"] == res[0][3]["n_valid"] and np.array_equal(res[0][1]["medians"], res[0][3]["medians"], equal_nan=True)
+    finally:
+        ctx.close()
