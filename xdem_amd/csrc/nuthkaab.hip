@@ -716,7 +716,7 @@ template <typename T> struct NkYSource {
 // candidates compacted through per-wave staging (no workgroup barrier in the loop).  The generic kernel -- measured VALU-bound at
 // about 145 vector instructions per element -- stays in charge of the steps that (re)fill the cache; both are queued, each
 // leaves at once when the device-side `fresh` flag says it is the other one's turn.
-constexpr int NKB_TILE = 4;
+constexpr int NKB_TILE = 8;
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __restrict__ dh, const T* __restrict__ slope_tan,
                                                                     const uint16_t* __restrict__ bcache, const BinCacheRec* rec,
@@ -782,7 +782,8 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __r
             }
             st.append_bounded(cand, yv, b[q], &ctr[2]);
         }
-        if ((++it % SEL_FLUSH_EVERY) == 0) st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
+        // (same exposure to candidate bursts as the generic kernel: 16384 elements between two looks at the staging buffer)
+        if ((++it % (SEL_FLUSH_EVERY * SEL_TILE / NKB_TILE)) == 0) st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
     }
     st.sync_and_flush_at(0, out_v, out_b, &ctr[1], cap, &ctr[2]);
     for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
