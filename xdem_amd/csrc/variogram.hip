@@ -159,12 +159,20 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     }
 
     __shared__ uint8_t s_lut[GRID ? LUT_G : LUT_N];
+    // GRID: class of a cell's lower bound and the one threshold above it fused into one 8-byte entry (one LDS read per pair
+    // instead of a byte read and a dependent threshold read -- the Matheron pass is bound by the LDS array)
+    __shared__ uint2 s_lut2[GRID ? LUT_G : 1];
     const int tid = threadIdx.x;
     if (FAST)  // (NT may be smaller than the table: round 1 loaded only its first NT entries -- wrong classes beyond 32 binades of d^2)
         for (int k = tid; k < (GRID ? LUT_G : LUT_N); k += NT) s_lut[k] = GRID ? a.lut_i[k] : a.lut[k];
     for (int k = tid; k < a.nb + LUT_STEPS + 1; k += NT) s_thr[k] = k < a.nb ? a.thr[k] : (double)INFINITY;
-    if (GRID)
+    if (GRID) {
         for (int k = tid; k < a.nb + 2; k += NT) s_thr_i[k] = k < a.nb ? a.thr_i[k] : 0xFFFFFFFFu;
+        for (int k = tid; k < LUT_G; k += NT) {
+            const uint32_t c = a.lut_i[k];
+            s_lut2[k] = make_uint2(c, c < (uint32_t)a.nb ? a.thr_i[c] : 0xFFFFFFFFu);
+        }
+    }
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
         for (int k = tid; k < (a.nb + 1) * REC / 4; k += NT) reinterpret_cast<uint32_t*>(s_rec)[k] = 0u;
     unsigned char* const s_sum_cp = s_rec + (tid & (NCOPY - 1)) * 8;              // this lane's privatised copies
@@ -332,18 +340,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                         asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
                         dv[u] = pv - s_bv[j + u];
                     }
-                    int l[4];
+                    uint2 e[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         // 1/8-binade cell of float(d2) (monotone in d2); d2 = 0 (coincident points) clamps onto the first cell
                         const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
-                        l[u] = s_lut[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
+                        e[u] = s_lut2[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
                     }
-                    uint32_t th[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) th[u] = s_thr_i[l[u]];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) lu[u] = l[u] + ((th[u] <= d2[u]) ? 1 : 0);
+                    for (int u = 0; u < 4; ++u) lu[u] = (int)e[u].x + ((e[u].y <= d2[u]) ? 1 : 0);
                 } else {
                     double s2[4];
 #pragma unroll
