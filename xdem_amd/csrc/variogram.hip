@@ -409,8 +409,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 dv[u] = fabs(dv[u]);
-                                const bool ok = PLAIN || ((j + u) < cnt && (j + u) > ia_rel && dv[u] == dv[u]);
-                                lc[u] = (ok && lus[u] < nb) ? lus[u] : nb;  // everything that is no pair goes to the spare class
+                                // everything that is no pair goes to the spare class nb (the class lookup itself never exceeds nb:
+                                // "beyond the last edge" IS class nb, so full tiles need no test at all)
+                                if constexpr (PLAIN) lc[u] = lus[u];
+                                else lc[u] = ((j + u) < cnt && (j + u) > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
                                 lo4[u] = s_lh[2 * lc[u]];
                                 hi4[u] = s_lh[2 * lc[u] + 1];
                             }
@@ -420,11 +422,13 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 // counter plane = (bits >= lo) + (bits > hi): 0 below the bracket, 1 inside, 2 above -- two compares,
                                 // two carry adds, one multiply-add for the address (no selects)
                                 const bool ge_lo = bits >= lo4[u], gt_hi = bits > hi4[u];
-                                const uint32_t plane = (uint32_t)ge_lo + (uint32_t)(ge_lo & gt_hi);  // (an empty bracket, hi < lo: everything below or above)
-                                const bool inside = ge_lo & !gt_hi;
+                                // (lane masks handled as scalars: a `bool` combined in C++ comes back as a 0/1 VGPR and a compare)
+                                const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ge_lo), m_gt = __builtin_amdgcn_ballot_w64(gt_hi);
+                                const unsigned long long m_gt2 = m_ge & m_gt;  // (an empty bracket, hi < lo: everything below or above)
+                                const unsigned long long in_m = m_ge & ~m_gt;
+                                const uint32_t plane = select_by_mask(0u, 1u, m_ge) + select_by_mask(0u, 1u, m_gt2);
                                 atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_c3 + cp) + ((uint32_t)lc[u] << 7) +
-                                                                      plane * c3_plane), 1u);
-                                const unsigned long long in_m = __builtin_amdgcn_ballot_w64(inside);
+                                                                      __umul24(plane, c3_plane)), 1u);
                                 const unsigned long long clash = in_m & pend_m;
                                 if (__builtin_expect(clash != 0, 0)) {  // (wave-uniform, rare: a second candidate within 8 pairs)
                                     if ((clash >> (tid & 63)) & 1ull) {
