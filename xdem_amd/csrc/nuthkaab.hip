@@ -441,9 +441,9 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
                 if (jin) dh[rb + jl] = out;
                 fmin_a = fmin(fmin_a, ok ? av : (T)INFINITY);
                 fmax_a = fmax(fmax_a, ok ? av : -(T)INFINITY);
-                n_all += (uint32_t)__popcll(__ballot(ok));
-                n_below += (uint32_t)__popcll(__ballot(below));
-                const unsigned long long mask = __ballot(cand);
+                n_all += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
+                n_below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(below));
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
                 if (mask) {
                     const int c = __popcll(mask);
                     int pos0 = 0;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __r
                 const K l = lohi[2 * b[q]], h = lohi[2 * b[q] + 1];
                 cand = (key >= l) & (key <= h);
                 const int cls = key < l ? 1 : (cand ? 2 : 0);
-                atomicAdd(&cc[cls * nb + b[q]], 1u);
+                atomicAdd(&cc[__umul24((unsigned)cls, (unsigned)nb) + b[q]], 1u);
             }
             st.append_bounded(cand, yv, b[q], &ctr[2]);
         }

@@ -354,7 +354,7 @@ template <typename T> struct BlockStage {
     int* held;                   // LDS
     unsigned long long* base;    // LDS
     __device__ __forceinline__ void append(bool keep, T val, uint16_t bin) {
-        const unsigned long long mask = __ballot(keep);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
         if (!mask) return;
         const int lane = threadIdx.x & 63;
         const int leader = __ffsll((long long)mask) - 1;
@@ -369,7 +369,7 @@ template <typename T> struct BlockStage {
     }
     // same, for producers without a bound on the elements per step: a full buffer raises the overflow flag instead of writing
     __device__ __forceinline__ void append_bounded(bool keep, T val, uint16_t bin, unsigned long long* overflow) {
-        const unsigned long long mask = __ballot(keep);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
         if (!mask) return;
         const int lane = threadIdx.x & 63;
         const int leader = __ffsll((long long)mask) - 1;
