@@ -315,9 +315,17 @@ template <typename TOUT> struct DirectSink {
 #define XD_STORE_BITS "nt sc1"
 #endif
         if constexpr (sizeof(TOUT) == 4) {
-            // (`s_nop 4`: a plane pointer restored from a spill by v_readlane right before the store needs 5 wait states
-            // before a VMEM instruction may read it -- the compiler inserts them for its own instructions, not for inline asm)
+            // The plane pointer goes through a scalar copy inside the asm: a pointer the compiler has just restored from a spill
+            // with v_readlane (VALU write of an SGPR) may not be read by a VMEM instruction for 5 wait states -- the compiler
+            // inserts them for its own instructions, not for inline asm, and the runtime-mask kernels faulted without them.
+            // A SALU read of a VALU-written SGPR and a VMEM read of a SALU-written SGPR need none; `s_nop 4` instead of the
+            // copy (XD_STORE_NOP) measured 1.2 % slower (14.50 vs 14.33 ms).
+#if defined(XD_STORE_NOP)
             asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 " XD_STORE_BITS ::"v"(o), "v"(v), "s"(org.p[K]) : "memory");
+#else
+            uint64_t ptmp;
+            asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 " XD_STORE_BITS : "=&s"(ptmp) : "v"(o), "v"(v), "s"(org.p[K]) : "memory");
+#endif
         } else {
             __builtin_nontemporal_store(v, reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o));
         }
