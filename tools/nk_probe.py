@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from xdem_amd import _lib, coreg
+
+if os.environ.get("NK_LIB"):  # A/B runs inside one session: another build of the library
+    _lib.LIB_PATH = os.environ["NK_LIB"]
 from xdem_amd.synth import fbm_torch
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 20000

@@ -33,7 +33,7 @@ def main():
     out = torch.empty((11, n, n), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     csrc = os.path.join(ROOT, "xdem_amd", "csrc")
-    libs = {"R01": "libxdemhip_r01.so", "MIX": "libxdemhip_exp2.so", "NOSTORE": "libxdemhip_expnostore.so", "RAWRSQ": "libxdemhip_exprawrsq.so", "NOLOAD": "libxdemhip_expnoload.so", "PLAINSTORE": "libxdemhip_expplain.so", "SMOV": "libxdemhip_expsa.so", "NTSC0SC1": "libxdemhip_expsb.so", "SC0SC1": "libxdemhip_expsc.so"}
+    libs = {"R01": "libxdemhip_r01.so", "MIX": "libxdemhip_exp2.so", "NOSTORE": "libxdemhip_expnostore.so", "RAWRSQ": "libxdemhip_exprawrsq.so", "NOLOAD": "libxdemhip_expnoload.so", "PLAINSTORE": "libxdemhip_expplain.so", "PLAINLOAD": "libxdemhip_expsa.so", "NTSC0SC1": "libxdemhip_expsb.so", "SC0SC1": "libxdemhip_expsc.so"}
     variants = []
     for tag, fn in libs.items():
         path = os.path.join(csrc, fn)

@@ -403,8 +403,10 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
         const T* rowp = tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W;
         const int64_t rb = rb0 + (int64_t)rc * g.W;
-        q.b0 = rowp[c0]; q.b1 = rowp[c1];
-        q.rv = ref[rb + jl]; q.av = aspect[rb + jl]; q.vd = valid[rb + jl];
+        // (streaming hints: every input of this pass is read once per step)
+        q.b0 = __builtin_nontemporal_load(rowp + c0); q.b1 = __builtin_nontemporal_load(rowp + c1);
+        q.rv = __builtin_nontemporal_load(ref + rb + jl); q.av = __builtin_nontemporal_load(aspect + rb + jl);
+        q.vd = __builtin_nontemporal_load(valid + rb + jl);
     };
 #pragma unroll
     for (int u = 0; u < NK_PF; ++u) issue(u, pre[u]);
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
                 const bool below = ok & (key < klo);
                 const bool cand = ok & (key >= klo) & (key <= khi);
                 out = ok ? out : (T)NAN;
-                if (jin) dh[rb + jl] = out;
+                if (jin) __builtin_nontemporal_store(out, dh + rb + jl);
                 fmin_a = fmin(fmin_a, ok ? av : (T)INFINITY);
                 fmax_a = fmax(fmax_a, ok ? av : -(T)INFINITY);
                 n_all += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
@@ -754,7 +756,8 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __r
 #pragma unroll
             for (int q = 0; q < NKB_TILE; ++q) {
                 const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
-                d[q] = dh[p]; sl[q] = slope_tan[p]; b[q] = bcache[p];
+                d[q] = __builtin_nontemporal_load(dh + p); sl[q] = __builtin_nontemporal_load(slope_tan + p);
+                b[q] = __builtin_nontemporal_load(bcache + p);
             }
         } else {
 #pragma unroll

@@ -114,7 +114,13 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
         } else
 #endif
         if (rowok && a.vec_ok && gx >= 0 && gx + VEC <= a.W) {
+#if defined(XD_PLAINLOAD)  // (measurement builds)
             val = *reinterpret_cast<const vec_t*>(src);
+#else
+            // streaming hint: a tile's rows are used once (the rows shared with the tile row below come back from HBM anyway,
+            // FETCH_SIZE = 1.125 x the raster); 1.1 % faster (15.08 vs 15.25 ms in one session)
+            val = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(src));
+#endif
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
