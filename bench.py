@@ -214,7 +214,7 @@ def secondary_metrics(ctx, dev) -> dict:
                                      "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
                                      "frac": round(PAIR_OPS_MODEL * mat_rate / 1e3 / VALU_PEAK_TLANEOPS, 4),
                                      "frac_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3 / VALU_PEAK_TLANEOPS, 4),
-                                     "instr_per_pair": "see profiles/README.md (SQ_INSTS_VALU of the pair kernels, rocprofv3 --pmc)"},
+                                     "instr_per_pair": "measured (profiles/r02_nk_vario_pmc.json, rocprofv3 --pmc): Matheron pass 14.7 vector + 4.0 LDS instructions per pair, LDS array busy for the whole kernel (two accumulator atomics per pair); Dowd counting pass 29 vector + 4.5 LDS at the time of the profile, about 24 vector since"},
                         "note": "C5 (reading B): 100 blocks of 9091 x 90910 raster pixels (integer-lattice pair kernels), f32 values; "
                                 "Matheron = one pair pass; Dowd = exact per-class median of |dv| (bracketed selection: sampled digit "
                                 "passes, one counting + compaction pass over all pairs, exact selection among the candidates; wall time)"}
