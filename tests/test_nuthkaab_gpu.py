@@ -565,3 +565,48 @@ def test_lean_route_equals_plain_route_at_scale():
         assert res[0][1]["n_valid"] == res[0][3]["n_valid"] and np.array_equal(res[0][1]["medians"], res[0][3]["medians"], equal_nan=True)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("dtype,rule", [(np.float32, 0), (np.float32, 1), (np.float64, 0)])
+def test_lean_kernels_vs_oracle(coreg, dtype, rule):
+    """The queued route (lean dh / bin kernels, bracketed selections, aspect-bin cache) only runs from 2^22 pixels on: a
+    2100 x 2050 pair, selection mode 3 (bracketed route for the 72 bins whatever their sample size), against the oracle for
+    shifts that exercise the row-tap table and the carried lerps -- zero, integer, negative, beyond one pixel, a hair below an
+    integer (pos = i + dr rounds to the next tap row for large i) -- repeated so that the aspect-bin cache is both filled and
+    reused.  Vertical shift, valid count, edges, per-bin counts and medians bit-exact."""
+    from xdem_amd.synth import fbm_numpy
+
+    ctx = coreg._lib.default_context()
+    H, W, res = 2100, 2050, 10.0
+    rng = np.random.default_rng(17)
+    base = fbm_numpy((H, W), seed=7, std=150.0)
+    ref = base.astype(dtype)
+    tba = (np.roll(base, (1, -2), (0, 1)) + rng.normal(0, 0.3, (H, W)) + 1.5).astype(dtype)
+    tba[rng.uniform(size=(H, W)) < 0.03] = np.nan
+    tba[700:760, 900:1400] = np.nan
+    inlier = rng.uniform(size=(H, W)) < 0.9
+    st, asp = nko.aux_vars(ref)
+    valid = inlier & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+    try:
+        ctx.set_option("nk_nan_rule", rule)
+        ctx.set_option("selection", 3)
+        plan = coreg.NKPlan(ref, tba, inlier)
+        if dtype == np.float64:
+            asp = plan.aux()[1]
+        for sx, sy in ((0.0, 0.0), (res * 2.0, -res * 1.0), (3.3, -7.1), (-13.7, 21.3), (0.0, -res * 0.9999999999999999), (3.3, -7.1)):
+            det = plan.step(sx, sy, (res, res), 72)
+            dh = nko.shifted_dh(ref, tba, sx, sy, (res, res), nan_rule=rule)[valid]
+            ok = np.isfinite(dh)
+            vshift = np.nanmedian(dh)
+            assert det["n_valid"] == int(ok.sum()), (sx, sy)
+            assert det["vshift"] == float(vshift), (sx, sy)
+            with np.errstate(all="ignore"):
+                y = (dh - vshift)[ok] / st[valid][ok]
+            edges, counts, med = nko.bin_medians(asp[valid][ok], y, 72)
+            assert np.array_equal(det["counts"], counts), (sx, sy)
+            assert np.array_equal(det["edges"], edges.astype(np.float64)), (sx, sy)
+            assert np.array_equal(det["medians"], med, equal_nan=True), (sx, sy)
+        plan.close()
+    finally:
+        ctx.set_option("nk_nan_rule", 0)
+        ctx.set_option("selection", 0)
