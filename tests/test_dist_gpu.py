@@ -242,13 +242,13 @@ def _worker_nk_blocks(rank, world, port, outdir):
 def _nk_pair():
     from xdem_amd.synth import fbm_numpy
 
-    m = 2400
+    m = 3000  # 4.5e6 pixels per rank: from 2^22 on the queued route with the lean kernels runs (block geometry: roff > 0, halo rows)
     ref = fbm_numpy((m, m), seed=15, std=200.0)
     rng = np.random.default_rng(16)
     tba = (np.roll(ref, (4, -2), (0, 1)) + 1.5 + rng.normal(0, 0.2, (m, m))).astype(np.float32)
     tba[rng.uniform(size=(m, m)) < 0.05] = np.nan
     inl = np.ones((m, m), dtype=bool)
-    inl[1190:1210, 300:900] = False   # straddles the 2-rank block boundary
+    inl[1490:1510, 300:900] = False   # straddles the 2-rank block boundary
     return ref, tba, inl
 
 
