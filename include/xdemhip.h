@@ -86,7 +86,8 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
  * of geoutils' _interp_points is not pinned by anything readable offline): 0 "4tap" (default; NaN if any of the four taps is
  * non-finite or outside, zero weights included -- except a zero-weight tap beyond the last row / column, so a node exactly
  * on the upper edge keeps its value), 1 "weighted" (zero-weight taps ignored everywhere: a NaN neighbour with weight 0
- * does not spread), 2 "dilate3x3" (NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite value).  Read when a
+ * does not spread), 2 "dilate3x3" (NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite value), 3 "dilate_cross" (the same
+ * with the 4-connected cross: SciPy's default binary-dilation structure).  Read when a
  * plan is created / a resample is launched.
  * "vario_edge": lag classes of the pair kernels, 0 = [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]; "vario_diff": |dv| formed
  * 0 = in the value dtype (default), 1 = in float64 (float32 values widened at xdemhip_pairs_create) -- the two scikit-gstat

@@ -65,7 +65,8 @@ def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int = 0) -
     switchable nodata convention of the kernel (geoutils' own rule is unpinned, see header): 0 "4tap" -- NaN if any of the
     four taps is non-finite or outside, zero weights included (except a zero-weight tap beyond the last row / column: nodes on
     the upper edge keep their value); 1 "weighted" -- taps with zero weight are ignored; 2
-    "dilate3x3" -- NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite pixel or leaves the raster."""
+    "dilate3x3" -- NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite pixel or leaves the raster; 3
+    "dilate_cross" -- the same with the 4-connected cross."""
     H, W = img.shape
     rr = np.arange(H, dtype=np.float64)[:, None] + dr
     cc = np.arange(W, dtype=np.float64)[None, :] + dc
@@ -95,14 +96,15 @@ def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int = 0) -
         val = top + fr * (bot - top)
         finite = np.isfinite(v00) & np.isfinite(v01) & np.isfinite(v10) & np.isfinite(v11)
         good = ok & finite
-        if nan_rule == 2:
+        if nan_rule >= 2:
             bad = ~np.isfinite(img)
             pad = np.ones((H + 2, W + 2), dtype=bool)
             pad[1:-1, 1:-1] = bad
             dil = np.zeros((H, W), dtype=bool)
             for a in range(3):
                 for b in range(3):
-                    dil |= pad[a : a + H, b : b + W]
+                    if nan_rule == 2 or a == 1 or b == 1:  # rule 3: the 4-connected cross (SciPy's default dilation structure)
+                        dil |= pad[a : a + H, b : b + W]
             rn = np.floor(rr + 0.5).astype(np.int64)
             cn = np.floor(cc + 0.5).astype(np.int64)
             inside = np.broadcast_to((rn >= 0) & (rn < H), (H, W)) & np.broadcast_to((cn >= 0) & (cn < W), (H, W))

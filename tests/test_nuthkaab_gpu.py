@@ -501,7 +501,7 @@ def test_explicit_bin_edges_vs_oracle(coreg):
     assert np.array_equal(det["medians"], med.astype(np.float64), equal_nan=True)
 
 
-@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("rule", [0, 1, 2, 3])
 def test_nan_rules_of_the_bilinear_taps(coreg, rule):
     """Context option "nk_nan_rule": the three nodata conventions of the bilinear taps (geoutils' own is unpinned), step and
     translation resample, each bit-exact against the oracle's implementation of the same rule.  Rule 1 keeps the last row /

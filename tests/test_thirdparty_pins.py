@@ -19,7 +19,7 @@ def test_geoutils_interp_points_selects_the_nan_rule():
     z = np.load(path)
     dem, res = z["dem"], float(z["res"])
     matches = {}
-    for rule in (0, 1, 2):
+    for rule in (0, 1, 2, 3):
         ok = True
         for k in range(6):
             sx, sy = z[f"shift{k}"]

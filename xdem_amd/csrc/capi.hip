@@ -116,7 +116,7 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         return XDEMHIP_OK;
     }
     if (std::string(name) == "nk_nan_rule") {
-        if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_nan_rule: 0 4tap, 1 weighted, 2 dilate3x3");
+        if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_nan_rule: 0 4tap, 1 weighted, 2 dilate3x3, 3 dilate_cross");
         ctx->nk_nan_rule = value;
         return XDEMHIP_OK;
     }

@@ -29,7 +29,7 @@ struct xdemhip_ctx {
     int vario_grid = 1;      // option "vario_grid": 1 = integer-lattice pair kernels for raster-sampled points (default), 0 = always float64 coordinates
     int vario_edge = 0;      // option "vario_edge": lag classes 0 = [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]
     int vario_diff = 0;      // option "vario_diff": |dv| formed 0 = in the value dtype (default), 1 = in float64 (float32 values are widened)
-    int nk_nan_rule = 0;     // option "nk_nan_rule": nodata spreading of the bilinear taps (nuthkaab.hip): 0 4tap, 1 weighted, 2 dilate3x3
+    int nk_nan_rule = 0;     // option "nk_nan_rule": nodata spreading of the bilinear taps (nuthkaab.hip): 0 4tap, 1 weighted, 2 dilate3x3, 3 dilate_cross
     int selection_mode = 0;  // 0 auto (bracketed for large inputs), 1 plain digit passes only, 2 degenerate brackets (tests the
                              // fallback), 3 bracketed whatever the per-bin sample size (2 and 3: test switches)
     // Deferred device-to-host results (xd_d2h / xd_sync below): small result blocks land in one pinned staging buffer with

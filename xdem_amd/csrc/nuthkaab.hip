@@ -39,6 +39,7 @@ struct NkGeom {
 //                 scipy.ndimage.map_coordinates(order=1) does to NaN: 0 * NaN = NaN)                         [default]
 //   1 "weighted"  taps with zero weight are ignored: at integer shifts the last row / column keep their values
 //   2 "dilate3x3" NaN if any pixel of the 3 x 3 neighbourhood of the NEAREST pixel is non-finite or outside
+//   3 "dilate_cross" the same with the 4-connected cross instead of the square (SciPy's default binary-dilation structure)
 struct BiTap {
     int64_t q00;       // local index of the top-left tap; the others are q00 + dc1, q00 + drw, q00 + drw + dc1
     int64_t drw;       // W, or 0 where the lower row is ignored (rule 1, zero row weight)
@@ -69,7 +70,7 @@ __device__ __forceinline__ BiTap bi_combine(const NkGeom& g, const BiAxis& r, co
     t.drw = t.in ? (int64_t)r.d1 * g.W : 0;
     t.dc1 = t.in ? c.d1 : 0;
     t.qn = -1;
-    if (g.rule == 2) {
+    if (g.rule >= 2) {
         const int64_t rn = (int64_t)floor(r.pos + 0.5), cn = (int64_t)floor(c.pos + 0.5);
         if (rn >= 1 && cn >= 1 && rn + 1 < g.H && cn + 1 < g.W) t.qn = (rn - g.roff) * g.W + cn;
     }
@@ -88,11 +89,12 @@ template <typename T> __device__ __forceinline__ BiVals<T> bi_load(const T* __re
 template <typename T>
 __device__ __forceinline__ bool bi_value(const NkGeom& g, const T* __restrict__ img, const BiTap& t, T a00, T a01, T a10, T a11, T& out) {
     bool ok = t.in && t_finite(a00) && t_finite(a01) && t_finite(a10) && t_finite(a11);
-    if (g.rule == 2) {
+    if (g.rule >= 2) {
         ok = ok && t.qn >= 0;
         if (ok)
             for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) ok = ok && t_finite(img[t.qn + dy * g.W + dx]);
+                for (int dx = -1; dx <= 1; ++dx)
+                    if (g.rule == 2 || dy == 0 || dx == 0) ok = ok && t_finite(img[t.qn + dy * g.W + dx]);  // rule 3: the cross only
     }
     const double v00 = a00, v01 = a01, v10 = a10, v11 = a11;
     const double top = t_add(v00, t_mul(t.fc, t_sub(v01, v00)));
