@@ -294,9 +294,11 @@ template <typename TOUT> struct Planes { TOUT* p[N_ATTR]; };
 template <typename TOUT> struct DirectSink {
     typedef TOUT out_t;
     Planes<TOUT> org;
-    uint32_t o0, ostride, o;
+    uint32_t o0, ostride, o, o_row = 0;
     XD_HD void begin_row(int i) {
-        o = o0 + (uint32_t)i * ostride;
+        // rows arrive in order (march_column): a running offset instead of i * ostride (a quarter-rate v_mad_u64_u32 per row)
+        o = (i == 0) ? o0 : o_row + ostride;
+        o_row = o;
 #if defined(__HIP_DEVICE_COMPILE__)
         // keep `o` an opaque 32-bit VGPR: stops loop-strength-reduction from turning every plane into its own 64-bit
         // running pointer (11 VGPR pairs + one 64-bit add per store)
