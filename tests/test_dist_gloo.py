@@ -34,6 +34,13 @@ def _worker(rank, world, port, q):
         blk.interior.mul_(2.0)
         xd.RowBlock.wait_all(blk.exchange())
         ok_halo2 = bool(torch.equal(blk.buf, 2.0 * want))
+        # uint8 blocks with a deeper halo: the inlier-mask blocks of the partitioned Nuth-Kaab fit (dist.nuth_kaab_row_blocks)
+        full8 = (torch.arange(total * width) % 251).to(torch.uint8).reshape(total, width)
+        b8 = xd.RowBlock(total, width, 5, rank, world, "cpu", dtype=torch.uint8)
+        b8.buf.fill_(255)
+        b8.interior.copy_(full8[b8.r0:b8.r1])
+        xd.RowBlock.wait_all(b8.exchange())
+        ok_halo2 = ok_halo2 and b8.buf.dtype == torch.uint8 and bool(torch.equal(b8.buf, full8[b8.r0 - b8.halo_top: b8.r1 + b8.halo_bottom]))
         # accumulator all-reduces used by the variogram / selection passes
         h = np.full((3, 256), rank + 1, dtype=np.uint64)
         s = ss._allreduce(h)
