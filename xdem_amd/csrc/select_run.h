@@ -240,7 +240,11 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     }
     const int passes = KeyT<T>::passes;
     const int run = (n_passes > 0 && n_passes < passes) ? n_passes : passes;  // leading digits only: bracket ends need no more
-    const int grid = grid_for(ctx, n_grid, HIST_THREADS * 4, 2);
+    // (every workgroup zeroes and flushes a whole [bins][256] table: for small inputs -- the 1/64 samples -- one workgroup per CU
+    // halves that fixed cost, which dominates their passes)
+    // (measured on the Nuth-Kaab step, A/B in one session: 2 -> 1 workgroups per CU 3.00 / 3.13 -> 2.92 / 2.98 ms; half a
+    // workgroup per CU 3.10: too few)
+    const int grid = grid_for(ctx, n_grid, HIST_THREADS * 4, n_grid < ((int64_t)1 << 24) ? 1 : 2);
     for (int p = 0; p < run; ++p) {
         const int shift = 8 * (passes - 1 - p);
         if (n > 0)
