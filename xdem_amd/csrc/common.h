@@ -61,6 +61,10 @@ inline int xd_fail(xdemhip_ctx* ctx, int code, const std::string& msg) {
 // Queue a small device-to-host copy whose destination is filled by the next xd_sync(ctx) (falls back to a plain copy when
 // the staging buffer is full).  `dst` must stay alive until that xd_sync; xd_drop_pending forgets undelivered blocks (entry
 // points call it on their way in and out, so an error return never leaves a dangling destination behind).
+inline void xd_drop_pending(xdemhip_ctx* ctx) {
+    ctx->pending.clear();
+    ctx->pin_used = 0;
+}
 inline int xd_d2h(xdemhip_ctx* ctx, void* dst, const void* dsrc, size_t bytes) {
     if (!ctx->pin) {
         if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin), 256 * 1024, hipHostMallocDefault) == hipSuccess) ctx->pin_cap = 256 * 1024;
@@ -71,14 +75,13 @@ inline int xd_d2h(xdemhip_ctx* ctx, void* dst, const void* dsrc, size_t bytes) {
         XD_HIP_CHECK(ctx, hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
         return XDEMHIP_OK;
     }
-    XD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pin + ctx->pin_used, dsrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (hipMemcpyAsync(ctx->pin + ctx->pin_used, dsrc, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+        xd_drop_pending(ctx);  // the operation is abandoned: nothing queued before may be delivered into dead destinations later
+        return xd_fail(ctx, XDEMHIP_EHIP, "hipMemcpyAsync (deferred device-to-host copy) failed");
+    }
     ctx->pending.push_back({dst, ctx->pin_used, bytes});
     ctx->pin_used += need;
     return XDEMHIP_OK;
-}
-inline void xd_drop_pending(xdemhip_ctx* ctx) {
-    ctx->pending.clear();
-    ctx->pin_used = 0;
 }
 inline int xd_sync(xdemhip_ctx* ctx) {
     const hipError_t e = hipStreamSynchronize(ctx->stream);

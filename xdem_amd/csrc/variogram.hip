@@ -1176,6 +1176,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
 extern "C" {
 
 int xdemhip_pairs_medians(xdemhip_pairs* P, int64_t* counts, double* medians) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);  // (select_fetch queues deferred result copies)
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;
     if (!counts || !medians) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
