@@ -139,6 +139,57 @@ def test_variogram_host_preparation():
     assert ss._key_to_value(k, 32).tolist() == [1.0, 2.0]
 
 
+def test_raster_equidistant_sampler_matches_enumeration():
+    """The raster form of the equidistant ring sampler (closed-form column spans per row, no per-pixel distances) against the
+    oracle's enumeration of the same rings: identical pixel sets when a ring is taken in full, distinct valid ring members of
+    the requested number otherwise, uniform over the ring; block structure of the centre-disk x rings scheme."""
+    import variogram_oracle as vo
+    from xdem_amd import spatialstats as ss
+
+    rng = np.random.default_rng(1)
+    ny, nx, gsd = 300, 420, 2.0
+    v = rng.normal(size=(ny, nx)).astype(np.float32)
+    v[50:80, 100:200] = np.nan
+    valid = np.isfinite(v)
+    iy, ix = np.mgrid[0:ny, 0:nx]
+    for cx, cy, lo, hi, n in [(10, 10, 0.0, 30.0, 50), (200, 150, 100.0, 160.0, 20000), (419, 299, 37.5, 400.0, 300),
+                              (5, 290, 250.0, 1000.0, 10**6), (100, 100, 0.0, 3.0, 100), (0, 0, 2000.0, 3000.0, 10)]:
+        got = ss._draw_ring_pixels(valid, ny, nx, cx, cy, lo, hi, gsd, n, np.random.default_rng(3))
+        d = np.sqrt(((ix - cx) * gsd) ** 2 + ((iy - cy) * gsd) ** 2)
+        full = np.flatnonzero((valid & (d >= lo) & (d < hi)).ravel())
+        assert np.unique(got).size == got.size and np.isin(got, full).all() and got.size == min(n, full.size)
+        if n >= full.size:
+            assert np.array_equal(np.sort(got), full)
+    # uniformity: 400 draws of 200 from a ring of ~12000 pixels hit every octant of the ring about equally
+    cx, cy, lo, hi = 210, 150, 100.0, 160.0
+    hits = np.zeros(8)
+    for seed in range(400):
+        g = ss._draw_ring_pixels(None, ny, nx, cx, cy, lo, hi, gsd, 200, np.random.default_rng(seed))
+        ang = np.arctan2((g // nx) - cy, (g % nx) - cx)
+        hits += np.bincount(((ang + np.pi) / (2 * np.pi) * 8).astype(int) % 8, minlength=8)
+    assert hits.sum() == 400 * 200 and np.all(np.abs(hits / hits.mean() - 1) < 0.05)
+    # blocks: same ring bounds as the oracle's restatement (taken in full: samples >= every ring)
+    coords, extent, maxlag = vo.grid_coords_extent_maxlag((nx, ny), gsd)  # (upstream's meshgrid convention: shape[0] along x)
+    centres = []
+    blocks = ss.equidistant_blocks_from_raster(v, gsd, 3, 30, 0.002, np.random.default_rng(9), centres_out=centres)
+    assert len(blocks) == 3
+    r0, radii = ss._equidistant_radii(30, 0.002, gsd, maxlag)
+    flat, fvalid = v.reshape(-1), valid.reshape(-1)
+    for (ax, ay, av, bx, by, bv), (cxi, cyi) in zip(blocks, centres):
+        assert valid[cyi, cxi] and ax.size == 30 and np.isfinite(av).all() and np.isfinite(bv).all()
+        assert np.array_equal(av, v[(ay / gsd).astype(int), (ax / gsd).astype(int)])
+        assert np.all(np.hypot(ax - cxi * gsd, ay - cyi * gsd) < r0)
+        d = np.hypot(bx - cxi * gsd, by - cyi * gsd)
+        k = np.digitize(d, radii) - 1
+        assert np.all(np.diff(k) >= 0)  # inner to outer
+        # membership and sizes against the oracle's enumeration of the same rings around the same centre
+        dist = np.hypot(coords[:, 0] - cxi * gsd, coords[:, 1] - cyi * gsd)
+        for i, (lo, hi) in enumerate(zip(radii[:-1], radii[1:])):
+            members = np.flatnonzero(fvalid & (dist >= lo) & (dist < hi))
+            mine = ((by[k == i] / gsd).astype(np.int64) * nx + (bx[k == i] / gsd).astype(np.int64))
+            assert mine.size == min(30, members.size) and np.isin(mine, members).all()
+
+
 def test_nuthkaab_class_contract():
     from xdem_amd import coreg
 

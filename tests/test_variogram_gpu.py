@@ -96,8 +96,12 @@ def test_sample_empirical_variogram_end_to_end(ss, method, estimator):
     seed = list(np.random.default_rng(42).choice(1, 1, replace=False))[0]
     rng = np.random.default_rng(seed)
     if method == "cdist_equidistant":
+        # the draws of the ring sampler are the product's own (raster form: tests/test_cabi_and_host.py checks it against the
+        # enumeration of the rings); the pair arithmetic on those blocks is what the oracle checks here
         runs, samples, ratio = vo.choose_cdist_equidistant_sampling_parameters(120, extent, vals.shape)
-        blocks = vo.equidistant_blocks(coords, flat, valid, 5.0, runs, samples, ratio, rng)
+        img = flat.reshape(vals.shape[1], vals.shape[0])   # upstream's meshgrid convention: shape[0] along x
+        blocks = ss.equidistant_blocks_from_raster(img, 5.0, runs, samples, ratio, rng, valid2d=np.isfinite(img))
+        assert len(blocks) == runs
     elif method == "cdist_point":
         idx = np.flatnonzero(valid)
         a = rng.choice(idx, 120, replace=False)
@@ -232,6 +236,76 @@ def test_C5_full_size_properties(ss):
     e_g, c_g = ss.empirical_variogram_pairs(sub, edges, "dowd")
     e_o, c_o = vo.empirical_variogram_blocks(sub, edges, "dowd")
     assert np.array_equal(c_g, c_o) and np.array_equal(e_g, e_o, equal_nan=True)
+
+
+def test_C5_sampler_geometry_lattice_bracket_kernels(ss):
+    """BASELINE C5 (reading B) on the input SURVEY 8d names -- fBm(H = 0.3) values on a 20000^2 grid, points drawn by the
+    equidistant disk / ring sampler, i.e. INTEGER-LATTICE coordinates and >= 4e9 pairs: the configuration bench.py times, whose
+    exact-Dowd route runs `pairs_kernel<float, OP_BRACKET, GRID>` (lattice distances x bracketed counting pass).
+    (i) lattice kernels (option vario_grid = 1) == float64-coordinate kernels (0): class counts and exact Dowd medians
+        identical, in every selection mode (0 bracketed, 1 plain digit passes, 2 forced bracket miss) and with the pair
+        passes split into many launches (pairs_launch_cap);
+    (ii) a ~1 % subset of the blocks against the CPU oracle (counts and medians exact, Matheron to 1e-12);
+    (iii) Matheron and Dowd routes count the same pairs per class and together every pair below the last edge."""
+    import torch
+
+    from xdem_amd import _lib
+    from xdem_amd.synth import c5_variogram_blocks
+
+    blocks, edges = c5_variogram_blocks("cuda", runs=100, samples=9091)
+    assert len(blocks) == 100 and all(b[0].size == 9091 and 5 * 9091 <= b[3].size <= 11 * 9091 for b in blocks)
+    for b in blocks[:3]:
+        assert all(np.array_equal(c, np.round(c)) for c in (b[0], b[1], b[3], b[4]))  # raster pixels: lattice coordinates
+    ctx = _lib.default_context()
+    total = sum(b[0].size * b[3].size for b in blocks)
+    assert total >= 4_000_000_000
+    res = {}
+    try:
+        for grid in (1, 0):
+            ctx.set_option("vario_grid", grid)
+            ps = ss.PairSet(blocks, edges, ctx)
+            try:
+                assert ps.n_pairs == total
+                s_m, c_m = ps.sums(0)
+                for mode in (0, 1, 2):
+                    ctx.set_option("selection", mode)
+                    res[(grid, mode)] = ss.class_medians(ps)
+                    assert np.array_equal(res[(grid, mode)][1], c_m), (grid, mode)      # (iii) two routes, same membership
+                ctx.set_option("selection", 0)
+                if grid == 1:
+                    ctx.set_option("pairs_launch_cap", 3000)
+                    res["cap"] = ss.class_medians(ps)
+                    s_cap, c_cap = ps.sums(0)
+                    ctx.set_option("pairs_launch_cap", 0)
+                    assert np.array_equal(c_cap, c_m) and np.allclose(s_cap, s_m, rtol=1e-12, atol=0)
+                res[("sums", grid)] = (s_m, c_m)
+            finally:
+                ps.close()
+    finally:
+        ctx.set_option("vario_grid", 1)
+        ctx.set_option("selection", 0)
+        ctx.set_option("pairs_launch_cap", 0)
+    med0, cnt0 = res[(1, 0)]
+    for k, (med, cnt) in res.items():
+        if k[0] == "sums":
+            continue
+        assert np.array_equal(cnt, cnt0), k
+        assert np.array_equal(med, med0, equal_nan=True), k
+    assert np.array_equal(res[("sums", 1)][1], res[("sums", 0)][1])
+    assert np.allclose(res[("sums", 1)][0], res[("sums", 0)][0], rtol=1e-12, atol=0)
+    # every pair lies below the extent diagonal (= the last edge) except pairs AT it (none: corner to corner only)
+    assert cnt0.sum() == total
+    # (ii) a subset against the oracle: 3 blocks cut to 400 x 8000 points (9.6e6 pairs)
+    sub = [tuple(a[:400] if i < 3 else a[:: max(1, a.size // 8000)][:8000] for i, a in enumerate(b)) for b in blocks[:3]]
+    for est in ("dowd", "matheron"):
+        e_g, c_g = ss.empirical_variogram_pairs(sub, edges, est)
+        e_o, c_o = vo.empirical_variogram_blocks(sub, edges, est)
+        assert np.array_equal(c_g, c_o)
+        if est == "dowd":
+            assert np.array_equal(e_g, e_o, equal_nan=True)
+        else:
+            assert np.allclose(e_g, e_o, rtol=1e-12, atol=0, equal_nan=True)
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

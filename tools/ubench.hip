@@ -79,6 +79,17 @@ KERNEL_D(k_fmac_f64, "v_fmac_f64 %0, %1, %2")
 KERNEL_DF(k_cvt_f64_f32, "v_cvt_f64_f32 %0, %1")
 KERNEL_DF(k_cvt_f32_f64, "v_cvt_f32_f64 %1, %0")
 
+// packed float32: the operands are 64-bit VGPR pairs (two floats per lane); KERNEL_D's double registers serve as the pairs
+KERNEL_D(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %2")
+KERNEL_D(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+KERNEL_D(k_pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+KERNEL_F(k_sqrt_f32, "v_sqrt_f32 %0, %0")
+KERNEL_F(k_rcp_f32, "v_rcp_f32 %0, %0")
+KERNEL_F(k_mul_f32, "v_mul_f32 %0, %0, %1")
+KERNEL_F(k_add_f32, "v_add_f32 %0, %0, %1")
+KERNEL_F(k_fmaak_f32, "v_fmaak_f32 %0, %0, %1, 0x3f000000")
+KERNEL_F(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+
 typedef void (*kern_t)(double*, double);
 struct Case { const char* name; kern_t k; };
 
@@ -98,7 +109,10 @@ int main() {
                     {"v_bfi_b32", k_bfi_b32}, {"v_and_or_b32", k_and_or_b32}, {"v_xor_b32", k_xor_b32}, {"v_ashrrev_i32", k_ashr_i32},
                     {"v_max_f32", k_max_f32}, {"v_med3_f32", k_med3_f32}, {"v_cmp_gt_f32", k_cmp_f32}, {"v_min_f64", k_min_f64},
                     {"v_cmp_gt_f64_e64", k_cmp_e64_f64}, {"v_fmac_f64", k_fmac_f64},
-                    {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f32_f64", k_cvt_f32_f64}};
+                    {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f32_f64", k_cvt_f32_f64},
+                    {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32},
+                    {"v_sqrt_f32", k_sqrt_f32}, {"v_rcp_f32", k_rcp_f32}, {"v_mul_f32", k_mul_f32}, {"v_add_f32", k_add_f32},
+                    {"v_fmaak_f32", k_fmaak_f32}, {"v_mov_b32_dpp", k_mov_dpp}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);

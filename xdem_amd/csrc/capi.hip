@@ -105,6 +105,16 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->terrain_rows = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "terrain_sync") {
+        if (value < 0 || value > 32 || (value & (value - 1))) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_sync: 0 or a power of two <= 32");
+        ctx->terrain_sync = value;
+        return XDEMHIP_OK;
+    }
+    if (std::string(name) == "terrain_order") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_order: 0 XCD bands, 1 natural order");
+        ctx->terrain_order = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "terrain_math") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_math: 0 mixed precision, 1 float64");
         ctx->terrain_math = value;

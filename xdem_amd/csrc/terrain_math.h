@@ -295,6 +295,7 @@ template <typename TOUT> struct DirectSink {
     typedef TOUT out_t;
     Planes<TOUT> org;
     uint32_t o0, ostride, o, o_row = 0;
+    uint32_t sync_n = 0;  // workgroup barrier after every sync_n-th output row (a power of two; 0 = never): option "terrain_sync"
     XD_HD void begin_row(int i) {
         // rows arrive in order (march_column): a running offset instead of i * ostride (a quarter-rate v_mad_u64_u32 per row)
         o = (i == 0) ? o0 : o_row + ostride;
@@ -335,7 +336,15 @@ template <typename TOUT> struct DirectSink {
         *reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o) = v;
 #endif
     }
-    XD_HD void end_row(int) {}
+    XD_HD void end_row(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keeps the four waves of the workgroup on the same raster row: their four 256-byte segments of a plane's 1 KiB row
+        // piece then reach the memory controller together (every thread of the workgroup marches, see terrain_tile_kernel)
+        if (sync_n && ((uint32_t)(i + 1) & (sync_n - 1)) == 0) __builtin_amdgcn_s_barrier();
+#else
+        (void)i;
+#endif
+    }
 };
 
 // Compile-time specialisation knobs.  CMASK != 0 fixes the attribute mask: every `if (mask & ...)` folds away

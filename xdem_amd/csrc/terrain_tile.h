@@ -35,6 +35,7 @@ template <typename TIN, typename TOUT> struct TileArgs {
     int64_t H, W, stride, halo_top, halo_bottom;
     int tiles_x, tiles_y, ntiles, grid8;  // grid8 = padded grid / 8
     int vec_ok;
+    int sync_n, order;      // options "terrain_sync" / "terrain_order"
     int nplanes;            // requested planes of this launch (staged stores)
     TOUT* compact[N_ATTR];  // ... their pointers in ascending attribute order
     TerrainParams P;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
 
     // XCD-aware tile order (see file header)
     const int b = blockIdx.x;
-    const int logical = (b & 7) * a.grid8 + (b >> 3);
+    const int logical = a.order ? b : (b & 7) * a.grid8 + (b >> 3);
     if (logical >= a.ntiles) return;
     const int ty = logical / a.tiles_x, tx = logical - ty * a.tiles_x;
     const int64_t x0 = (int64_t)tx * TILE_W, y0 = (int64_t)ty * TH;
@@ -154,13 +155,19 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
         // every thread marches (the row barrier needs all four waves); columns beyond the raster only see NaN padding
         march_column<FIT, CURV, WIN, SP, TIN, sink_t>(tile + XPAD + tid, PITCH, n_out, a.P, sk);
     } else {
-        if (x0 + tid < a.W) {
+        {
+            // Every thread marches (the optional row barrier needs all four waves): a thread whose column lies beyond the raster
+            // takes the raster's last column instead and stores the same values to the same addresses as that column's own
+            // thread -- duplicate identical stores, only in the last tile of a tile row, and no predicate anywhere.
+            const int64_t last = a.W - 1 - x0;
+            const int ct = (int)((int64_t)tid < last ? (int64_t)tid : last);
             DirectSink<TOUT> sk;
 #pragma unroll
             for (int k = 0; k < N_ATTR; ++k) sk.org.p[k] = a.out.p[k] + org_off;
-            sk.o0 = (uint32_t)(tid * sizeof(TOUT));
+            sk.o0 = (uint32_t)(ct * sizeof(TOUT));
             sk.ostride = (uint32_t)(a.W * sizeof(TOUT));
-            march_column<FIT, CURV, WIN, SP, TIN, DirectSink<TOUT>>(tile + XPAD + tid, PITCH, n_out, a.P, sk);
+            sk.sync_n = (uint32_t)a.sync_n;
+            march_column<FIT, CURV, WIN, SP, TIN, DirectSink<TOUT>>(tile + XPAD + ct, PITCH, n_out, a.P, sk);
         }
     }
 }
@@ -236,6 +243,8 @@ static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask,
     a.grid8 = (a.ntiles + 7) / 8;
     constexpr int VEC = 16 / sizeof(TIN);
     a.vec_ok = ((reinterpret_cast<uintptr_t>(L.dem) & 15) == 0) && (L.row_stride % VEC == 0);
+    a.sync_n = ctx->terrain_sync;
+    a.order = ctx->terrain_order;
     fill_params(L, a.P);
     a.P.mask = mask;
     a.nplanes = 0;

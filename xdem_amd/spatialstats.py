@@ -310,13 +310,19 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
         if coords.shape[0] == 2 and coords.shape[1] != 2:
             coords = np.transpose(coords)
     else:
+        # Upstream builds meshgrid(arange(0, shape[0] gsd, gsd), arange(0, shape[1] gsd, gsd)) and pairs it with the C-order
+        # flattening of the values as is (spatialstats.py:1413-1416): flat element k sits at x = (k % shape[0]) gsd,
+        # y = (k // shape[0]) gsd.  The coordinates are formed on demand from k (a 20000^2 raster would need 6.4 GB of them).
         shape2d = values.shape
-        x, y = np.meshgrid(np.arange(0, values.shape[0] * gsd, gsd), np.arange(0, values.shape[1] * gsd, gsd))
-        coords = np.dstack((x.flatten(), y.flatten())).squeeze()
-        values = values.flatten()  # NB upstream pairs this C-order flattening with the meshgrid above as is
+        values = values.flatten()
     if gsd is None:
         gsd = np.mean([coords[0, 0] - coords[0, 1], coords[0, 0] - coords[1, 0]])
-    extent = (np.min(coords[:, 0]), np.max(coords[:, 0]), np.min(coords[:, 1]), np.max(coords[:, 1]))
+    if coords is not None:
+        extent = (np.min(coords[:, 0]), np.max(coords[:, 0]), np.min(coords[:, 1]), np.max(coords[:, 1]))
+        xy_of = lambda k: (coords[k, 0], coords[k, 1])
+    else:
+        extent = (0.0, float(np.arange(shape2d[0])[-1] * gsd), 0.0, float(np.arange(shape2d[1])[-1] * gsd))
+        xy_of = lambda k: ((np.asarray(k) % shape2d[0]) * gsd, (np.asarray(k) // shape2d[0]) * gsd)
     if "maxlag" not in kwargs:
         kwargs["maxlag"] = np.sqrt((extent[1] - extent[0]) ** 2 + (extent[3] - extent[2]) ** 2)
     if "bin_func" not in kwargs:
@@ -351,22 +357,25 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
             else:
                 runs, samples, ratio = _choose_cdist_equidistant_sampling_parameters(
                     extent=extent, shape=shape2d, subsample=subsample, **({"nb_rings": kwargs["nb_rings"]} if "nb_rings" in kwargs else {}))
-            # the coordinate arrays above index the grid as (values.shape[0] along x) like upstream's meshgrid call
-            blocks = equidistant_blocks_from_coords(coords, values, valid, gsd, runs, samples, ratio, run_rng)
+            if coords is not None:
+                blocks = equidistant_blocks_from_coords(coords, values, valid, gsd, runs, samples, ratio, run_rng)
+            else:  # full raster, indexed (values.shape[0] along x) like upstream's meshgrid call
+                blocks = equidistant_blocks_from_raster(values.reshape(shape2d[1], shape2d[0]), gsd, runs, samples, ratio, run_rng,
+                                                        valid2d=None if valid.all() else valid.reshape(shape2d[1], shape2d[0]))
         elif subsample_method == "cdist_point":
             idx = np.flatnonzero(valid)
             n = min(int(subsample), idx.size)
             a = run_rng.choice(idx, n, replace=False)
             b = run_rng.choice(idx, n, replace=False)
-            blocks = [(coords[a, 0], coords[a, 1], values[a], coords[b, 0], coords[b, 1], values[b])]
+            blocks = [xy_of(a) + (values[a],) + xy_of(b) + (values[b],)]
         elif subsample_method == "pdist_point":
             idx = np.flatnonzero(valid)
             a = run_rng.choice(idx, min(int(subsample), idx.size), replace=False)
-            blocks = [(coords[a, 0], coords[a, 1], values[a])]
+            blocks = [xy_of(a) + (values[a],)]
         else:  # pdist_disk / pdist_ring: one pdist variogram per range, all rows kept (1007-1060)
             for sel in _pdist_multi_range_subsamples(valid, shape2d, int(subsample), subsample_method, gsd, kwargs["maxlag"],
                                                      kwargs.get("pdist_multi_ranges"), list_random_state[i]):
-                exp, count = empirical_variogram_pairs([(coords[sel, 0], coords[sel, 1], values[sel])], edges, estimator)
+                exp, count = empirical_variogram_pairs([xy_of(sel) + (values[sel],)], edges, estimator)
                 list_df_run.append(pd.DataFrame().assign(exp=exp, bins=edges, count=count))
             continue
         if blocks:
@@ -492,6 +501,123 @@ def equidistant_blocks_from_coords(coords: np.ndarray, values: np.ndarray, valid
         b = np.concatenate(sets) if sets else np.array([], dtype=np.int64)
         if a.size and b.size:
             blocks.append((cx[a], cy[a], values[a], cx[b], cy[b], values[b]))
+    return blocks
+
+
+def _equidistant_radii(samples: int, ratio_subsample: float, gsd: float, maxdist: float, exp_increase_fac: float = np.sqrt(2)):
+    """Centre-disk radius r0 and the ring bounds 0, r0, r0 f, r0 f^2, ... (< maxdist), maxdist of the equidistant scheme."""
+    r0 = np.sqrt(samples / (ratio_subsample * np.pi)) * gsd
+    radii = [0.0]
+    r = r0
+    while r < maxdist:
+        radii.append(r)
+        r *= exp_increase_fac
+    radii.append(maxdist)
+    return r0, radii
+
+
+def _draw_ring_pixels(valid2d, ny: int, nx: int, cxi: int, cyi: int, lo: float, hi: float, gsd: float, samples: int,
+                      rng: np.random.Generator) -> np.ndarray:
+    """Up to `samples` distinct valid pixels (flat indexes iy * nx + ix) with lo <= distance to pixel (cxi, cyi) < hi, drawn
+    uniformly without replacement, without forming the distance of every raster pixel (4e8 of them at 20000^2).  Per raster row
+    the ring is two column spans known in closed form (taken one pixel generous); a uniform draw over the concatenated spans,
+    filtered by the exact distance test and the validity mask, is a uniform draw over the ring; the first occurrences of
+    independent draws are a uniform sample without replacement.  Small rings are enumerated instead."""
+    reach = int(np.floor(hi / gsd)) + 1
+    y0, y1 = max(0, cyi - reach), min(ny - 1, cyi + reach)
+    if y1 < y0:
+        return np.empty(0, dtype=np.int64)
+    rows = np.arange(y0, y1 + 1, dtype=np.int64)
+    dy2 = ((rows - cyi).astype(np.float64)) ** 2
+    wo = np.floor(np.sqrt(np.maximum((hi / gsd) ** 2 - dy2, 0.0))).astype(np.int64) + 1     # generous outer half width
+    wi = np.maximum(np.ceil(np.sqrt(np.maximum((lo / gsd) ** 2 - dy2, 0.0))).astype(np.int64) - 1, 0)  # shrunk inner one
+    # left span [cxi - wo, cxi - wi], right span [cxi + max(wi, 1), cxi + wo] (the centre column belongs to the left span)
+    la, lb = np.maximum(cxi - wo, 0), np.minimum(cxi - wi, nx - 1)
+    ra, rb = np.maximum(cxi + np.maximum(wi, 1), 0), np.minimum(cxi + wo, nx - 1)
+    nl, nr = np.maximum(lb - la + 1, 0), np.maximum(rb - ra + 1, 0)
+    cum = np.cumsum(nl + nr)
+    total = int(cum[-1])
+    if total == 0:
+        return np.empty(0, dtype=np.int64)
+    start = cum - (nl + nr)
+
+    def pixels(k):  # k-th candidate of the concatenated spans -> (ix, iy)
+        r = np.searchsorted(cum, k, side="right")
+        o = k - start[r]
+        left = o < nl[r]
+        return np.where(left, la[r] + o, ra[r] + (o - nl[r])), rows[r]
+
+    def exact(ix, iy):
+        d = np.sqrt(((ix - cxi) * gsd) ** 2 + ((iy - cyi) * gsd) ** 2)
+        ok = (d >= lo) & (d < hi)
+        if valid2d is not None:
+            ok &= valid2d[iy, ix]
+        return ok
+
+    def enumerate_all():
+        out = []
+        for k0 in range(0, total, 1 << 24):
+            ix, iy = pixels(np.arange(k0, min(total, k0 + (1 << 24)), dtype=np.int64))
+            ok = exact(ix, iy)
+            out.append(iy[ok] * nx + ix[ok])
+        idx = np.concatenate(out)
+        return rng.choice(idx, samples, replace=False) if idx.size > samples else idx
+
+    if total <= max(1 << 16, 4 * samples):
+        return enumerate_all()
+    kept = np.empty(0, dtype=np.int64)
+    batch = int(1.3 * samples) + 64
+    drawn = accepted = 0
+    for _ in range(16):
+        ix, iy = pixels(rng.integers(0, total, batch))
+        ok = exact(ix, iy)
+        drawn += batch
+        accepted += int(ok.sum())
+        cand = np.concatenate([kept, iy[ok] * nx + ix[ok]])
+        _, first = np.unique(cand, return_index=True)
+        kept = cand[np.sort(first)]
+        if kept.size >= samples:
+            return kept[:samples]
+        if accepted * (total / drawn) < 1.5 * samples:   # about as many (valid) ring pixels as wanted, or fewer: take them all
+            return enumerate_all()
+        batch = int(min(4e7, 1.5 * (samples - kept.size) * drawn / max(accepted, 1))) + 64
+    return enumerate_all()
+
+
+def equidistant_blocks_from_raster(values2d: np.ndarray, gsd: float, runs: int, samples: int, ratio_subsample: float,
+                                   rng: np.random.Generator, valid2d: np.ndarray | None = None,
+                                   exp_increase_fac: float = np.sqrt(2), values_of=None, shape=None,
+                                   centres_out: list | None = None) -> list[tuple]:
+    """The centre-disk x equidistant-ring scheme of `equidistant_blocks_from_coords` for a full raster (pixel (iy, ix) at
+    x = ix gsd, y = iy gsd), drawn ring by ring without forming the distance of every pixel to the centre: same disk and ring
+    definitions (centre sample = valid pixels with d < r0; rings [0, r0), [r0, r0 f), ... the last one ending at the extent
+    diagonal; up to `samples` pixels of each), uniform without replacement.  RNG protocol: centre by rejection among the
+    valid pixels, then `_draw_ring_pixels` for the centre sample and for each ring, inner to outer.  `values_of(flat_idx)`
+    may supply the values (e.g. a gather from a device-resident raster; then `values2d` may be None and `shape` = (ny, nx)
+    names the raster)."""
+    ny, nx = values2d.shape if values2d is not None else (valid2d.shape if valid2d is not None else shape)
+    maxdist = np.sqrt(((nx - 1) * gsd) ** 2 + ((ny - 1) * gsd) ** 2)
+    r0, radii = _equidistant_radii(samples, ratio_subsample, gsd, maxdist, exp_increase_fac)
+    if valid2d is None and values2d is not None:
+        valid2d = np.isfinite(values2d)
+        if valid2d.all():
+            valid2d = None
+    get = values_of if values_of is not None else (lambda idx: values2d.reshape(-1)[idx])
+    blocks = []
+    for _ in range(runs):
+        for _try in range(10000):
+            cyi, cxi = int(rng.integers(0, ny)), int(rng.integers(0, nx))
+            if valid2d is None or valid2d[cyi, cxi]:
+                break
+        else:
+            return blocks  # (practically) no valid pixel
+        a = _draw_ring_pixels(valid2d, ny, nx, cxi, cyi, 0.0, r0, gsd, samples, rng)
+        sets = [_draw_ring_pixels(valid2d, ny, nx, cxi, cyi, lo, hi, gsd, samples, rng) for lo, hi in zip(radii[:-1], radii[1:])]
+        b = np.concatenate(sets) if sets else np.empty(0, dtype=np.int64)
+        if a.size and b.size:
+            blocks.append(((a % nx) * float(gsd), (a // nx) * float(gsd), get(a), (b % nx) * float(gsd), (b // nx) * float(gsd), get(b)))
+            if centres_out is not None:
+                centres_out.append((cxi, cyi))
     return blocks
 
 

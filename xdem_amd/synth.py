@@ -56,3 +56,27 @@ def fbm_torch(H: int, W: int, device, hurst: float = 0.7, seed: int = 42, mean: 
             x1 = min(W, x0 + t)
             out[y0:y1, x0:x1] = mean + std * src_rows[:, : x1 - x0] + trend_x[None, x0:x1] + trend_y[:, None]
     return out
+
+
+def c5_variogram_blocks(device, runs: int = 100, samples: int = 9091, size: int = 20000, seed: int = 45, rings: int = 10):
+    """BASELINE C5 input as SURVEY.md 8d states it: a dh-like fBm(H = 0.3) field on a `size`^2 grid (gsd 1, no NaN, seed 45) and,
+    per run, the centre-disk x equidistant-ring blocks of the product's own raster sampler
+    (spatialstats.equidistant_blocks_from_raster; disk radius = extent diagonal / sqrt(2)^rings as
+    `_choose_cdist_equidistant_sampling_parameters` sets it for this grid).  samples = 9091 is reading B (1e7 points drawn in
+    total), samples = 223607 reading A (subsample = 1e7 in the reference's sense, 5e13 pairs).  Returns (blocks, right edges):
+    50 explicit edges geomspace(sqrt 2, maxlag, 50).  Rings that leave the raster hold fewer points -- that is the geometry."""
+    import torch
+
+    from . import spatialstats as ss
+
+    field = fbm_torch(size, size, device, hurst=0.3, seed=seed, mean=0.0, std=1.0).reshape(-1)
+    maxdist = math.sqrt(2.0) * (size - 1)
+    ratio = samples / (math.pi * maxdist**2 / math.sqrt(2.0) ** (2 * rings))   # res = 1: spatialstats.py:1176-1181
+
+    def values_of(idx):
+        return field[torch.from_numpy(np.ascontiguousarray(idx)).to(device)].cpu().numpy()
+
+    rng = np.random.default_rng(seed)
+    blocks = ss.equidistant_blocks_from_raster(None, 1.0, runs, samples, ratio, rng, values_of=values_of, shape=(size, size))
+    edges = np.geomspace(math.sqrt(2.0), maxdist, 50)
+    return blocks, edges
