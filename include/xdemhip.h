@@ -23,6 +23,9 @@
 extern "C" {
 #endif
 
+/* Threading contract: the library is re-entrant PER CONTEXT.  A context owns one stream, one scratch state and one queue of
+ * deferred result copies; calls on the same context (and on plans / pair sets created from it) must not overlap in time --
+ * drive a context from one thread at a time.  Different contexts may be used from different threads concurrently. */
 typedef struct xdemhip_ctx xdemhip_ctx;
 
 enum { XDEMHIP_OK = 0, XDEMHIP_EINVAL = -1, XDEMHIP_ENODEV = -2, XDEMHIP_EHIP = -3, XDEMHIP_ENOMEM = -4,
@@ -202,7 +205,8 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* plan, int64_t row_begin, int64_t row_en
 int xdemhip_nk_step_fit(xdemhip_nk_plan* plan, double shift_x, double shift_y, double res_x, double res_y, double* vshift,
                         int64_t* n_valid, double* y_mean, double* y_std, double* sums /* [10] */);
 /* Explicit aspect-bin edges (NuthKaab(bin_sizes={"aspect": edges}), the array form of scipy.stats.binned_statistic's `bins`):
- * n_edges increasing values; xdemhip_nk_step then ignores n_bins and returns n_edges - 1 bins.  `decimal` = SciPy's
+ * n_edges increasing values (2 .. 129: at most 128 bins, one histogram sweep); xdemhip_nk_step must then be called with
+ * n_bins = n_edges - 1 (its output arrays are sized by n_bins; any other value is XDEMHIP_EINVAL).  `decimal` = SciPy's
  * `int(-log10(min edge spacing)) + 6` for these edges in the sample dtype (its rule for samples at or beyond the rightmost
  * edge, _binned_statistic.py:_bin_numbers).  n_edges = 0 restores SciPy's automatic edges. */
 int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* plan, const double* edges, int n_edges, int decimal);

@@ -128,6 +128,32 @@ def test_halo_depth_and_row_blocks():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_default_context_does_not_deadlock():
+    """default_context() creates the process-wide context under its own lock; Context() -> lib() takes the loader's lock: they
+    must be two locks (one non-reentrant lock for both dead-locked every GPU run of round 3's first build).  Without a GPU the
+    call has to come back -- with the library's "no usable device" error -- instead of hanging."""
+    import threading
+
+    import torch
+
+    from xdem_amd import _lib
+
+    box = []
+
+    def run():
+        try:
+            box.append(_lib.default_context(0))
+        except _lib.XdemHipError as e:
+            box.append(e)
+
+    _lib._default_ctx.pop(0, None) if not torch.cuda.is_available() else None
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "default_context() hung"
+    assert box and (isinstance(box[0], _lib.Context) or "no usable" in str(box[0]))
+
+
 def test_variogram_host_preparation():
     from xdem_amd import spatialstats as ss
 

@@ -529,6 +529,101 @@ def test_nan_rules_of_the_bilinear_taps(coreg, rule):
         ctx.set_option("nk_nan_rule", 0)
 
 
+@pytest.mark.parametrize("rule", [0, 1, 2, 3])
+def test_block_plan_halo_depth_per_nan_rule(coreg, rule):
+    """A partitioned plan (row block + halo rows) reads exactly the rows the single-GPU step reads: with the dilation rules (2,
+    3) that is one row more than the four bilinear taps once the fractional row shift reaches one half.
+    Two blocks of one raster, each stepped alone: too thin a halo is refused (HaloTooSmall, not a silently different dh), a
+    sufficient one gives block counts of finite dh that add up to the unpartitioned step's."""
+    ctx = coreg._lib.default_context()
+    ref, tba, inlier, res = _pair((160, 130))
+    H, cut = ref.shape[0], 77
+    sy = -res * 2.6    # dr = +2.6 rows: taps in rows floor(r + 2.6) .. + 1 -> 3 halo rows; nearest row round(r + 2.6) +- 1 -> 4
+    need = 4 if rule >= 2 else 3
+
+    def blocks(halo):
+        out = []
+        for rb, re_ in ((0, cut), (cut, H)):
+            ht, hb = min(halo, rb), min(halo, H - re_)
+            sl = slice(rb - ht, re_ + hb)
+            out.append(coreg.NKPlan(ref[sl], tba[sl], inlier[sl], block=(H, rb, re_, ht, hb)))
+        return out
+
+    try:
+        ctx.set_option("nk_nan_rule", rule)
+        full = coreg.NKPlan(ref, tba, inlier)
+        want = full.step(3.3, sy, (res, res), 72)["n_valid"]
+        full.close()
+        for halo in (need - 1, need):
+            plans = blocks(halo)
+            try:
+                if halo < need:
+                    with pytest.raises(coreg.HaloTooSmall):
+                        plans[0].step(3.3, sy, (res, res), 72)
+                else:
+                    got = sum(p.step(3.3, sy, (res, res), 72)["n_valid"] for p in plans)
+                    assert got == want
+            finally:
+                for p in plans:
+                    p.close()
+    finally:
+        ctx.set_option("nk_nan_rule", 0)
+
+
+def test_advice_round2_contracts(coreg):
+    """(i) explicit bin edges: the C entry refuses an n_bins that does not match them (its outputs are sized by n_bins);
+    (ii) a partitioned plan whose creation fails leaves no reduction hook on the context; (iii) the un-binned fit refuses
+    optimisers it cannot honour and survives a degenerate system."""
+    import ctypes
+
+    import scipy.optimize
+
+    ref, tba, inlier, res = _pair((90, 100))
+    plan = coreg.NKPlan(ref, tba, inlier)
+    plan.set_bin_edges(np.array([0.5, 1.0, 2.0, 4.0]))
+    L, dp, ip = plan.ctx._L, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+    e, c, m = np.empty(73), np.empty(72, dtype=np.int64), np.empty(72)
+    v = [ctypes.c_double() for _ in range(3)]
+    nv = ctypes.c_int64()
+    rc = L.xdemhip_nk_step(plan.handle, 0.0, 0.0, res, res, 72, ctypes.byref(v[0]), ctypes.byref(nv), ctypes.byref(v[1]),
+                           ctypes.byref(v[2]), e.ctypes.data_as(dp), c.ctypes.data_as(ip), m.ctypes.data_as(dp))
+    assert rc == -1   # XDEMHIP_EINVAL
+    assert len(plan.step(0.0, 0.0, (res, res))["counts"]) == 3   # the wrapper passes n_edges - 1
+    plan.close()
+    with pytest.raises(NotImplementedError, match="128 bins"):
+        coreg.NuthKaab(bin_sizes=np.linspace(0, 6.3, 200))
+    # (ii) hook hygiene: creation fails (wrong row count) after set_allreduce
+    import torch.distributed as dist
+
+    created = False
+    if not dist.is_initialized():
+        import os
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29641")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        with pytest.raises(ValueError, match="block arrays hold"):
+            coreg.NKPlan(ref[:50], tba[:50], inlier[:50], group="world", block=(90, 0, 60, 0, 2))
+        assert getattr(coreg._lib.default_context(), "_hook", None) is None
+        ok = coreg.NKPlan(ref, tba, inlier)     # a plain single-process plan still steps (no collective entered)
+        assert ok.step(0.0, 0.0, (res, res), 72)["n_valid"] > 0
+        ok.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    # (iii)
+    with pytest.raises(NotImplementedError, match="bin_before_fit=False"):
+        coreg.NuthKaab(bin_before_fit=False, fit_optimizer=scipy.optimize.least_squares)
+    with pytest.raises(NotImplementedError, match="bin_before_fit=False"):
+        coreg.nuth_kaab(ref, tba, inlier, (res, res), bin_before_fit=False, fit_optimizer=lambda **k: None)
+    s = np.array([5.0, 5 * np.cos(1.0), 5 * np.sin(1.0), 5 * np.cos(1.0) ** 2, 5 * np.sin(1.0) ** 2, 5 * np.cos(1.0) * np.sin(1.0),
+                  10.0, 10 * np.cos(1.0), 10 * np.sin(1.0), 20.0])   # five points, all at aspect 1.0, y = 2: singular normal equations
+    east, north, c0 = coreg._fit_from_sums({"sums": s})
+    assert np.isfinite([east, north, c0]).all() and abs(north * np.cos(1.0) + east * np.sin(1.0) + c0 - 2.0) < 1e-9
+
+
 def test_lean_route_equals_plain_route_at_scale():
     """At BASELINE's C3 scale the oracle is too slow, but the product has two independent implementations of a step: the queued
     route (lean dh / bin kernels, bracketed selections on samples and candidates, aspect-bin cache) and the plain one (generic

@@ -229,6 +229,61 @@ def test_halo_rows_equal_full_raster(terrain):
         assert np.array_equal(out[i].cpu().numpy(), f[r0:r1], equal_nan=True)
 
 
+@pytest.mark.parametrize("fit,attrs", [("Florinsky", "FULL"), ("ZevenbergThorne", "FULL"), ("Horn", "SAH_WIN")])
+def test_streaming_strips_equal_tile_kernel_and_oracle(terrain, fit, attrs):
+    """The streaming route of the specialised kernels (raster interior by wave-autonomous 64-column strips fed by LDS-DMA,
+    frame of edge tiles by the tile kernel; context option "terrain_stream") runs the very same per-pixel code as the tile
+    kernel: planes must be BIT-IDENTICAL with the route switched off, for every band height, with NaN / Inf holes straddling
+    strip, band and ring-block boundaries, for row blocks with halo rows (the multi-GPU call) and for shapes whose last band
+    and frame are ragged; and equal to the oracle like every other configuration."""
+    import torch
+
+    from xdem_amd import _lib
+
+    attrs = FULL if attrs == "FULL" else SAH_WIN
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(7)
+    for shape in ((1400, 2600), (2309, 1801), (1153, 4100)):
+        dem = _dem(shape, seed=shape[0])
+        # holes: single pixels, a block across a 64-column strip border and a 128-row band border, +-Inf, a whole row piece
+        for _ in range(40):
+            dem[rng.integers(0, shape[0]), rng.integers(0, shape[1])] = np.nan
+        dem[30:36, 310:330] = np.nan
+        dem[158:163, 572:580] = np.nan
+        dem[287:290, 255:258] = np.inf
+        dem[600, 700:900] = np.nan
+        dem[shape[0] - 40, shape[1] - 300] = -np.inf
+        d = torch.from_numpy(dem).cuda()
+        ref_planes = None
+        try:
+            for stream in (0, 1, 128, 256, 512):
+                ctx.set_option("terrain_stream", stream)
+                out = terrain.terrain_attributes_device(d, attrs, resolution=10.0, surface_fit=fit)
+                torch.cuda.synchronize()
+                got = out.cpu().numpy()
+                if stream == 0:
+                    ref_planes = got
+                else:
+                    for i, a in enumerate(attrs):
+                        assert np.array_equal(got[i], ref_planes[i], equal_nan=True), (shape, stream, a)
+            # row block with halo rows: rows [r0, r1) of the raster from a buffer holding depth rows either side
+            ctx.set_option("terrain_stream", 1)
+            r0, r1, depth = 96, shape[0] - 70, 2
+            blk = terrain.terrain_attributes_device(d[r0 - depth:r1 + depth], attrs, resolution=10.0, surface_fit=fit,
+                                                    halo_top=depth, halo_bottom=depth)
+            top = terrain.terrain_attributes_device(d[:r1 + depth], attrs, resolution=10.0, surface_fit=fit, halo_bottom=depth)
+            torch.cuda.synchronize()
+            for i, a in enumerate(attrs):
+                assert np.array_equal(blk[i].cpu().numpy(), ref_planes[i][r0:r1], equal_nan=True), (shape, "block", a)
+                assert np.array_equal(top[i].cpu().numpy(), ref_planes[i][:r1], equal_nan=True), (shape, "top block", a)
+        finally:
+            ctx.set_option("terrain_stream", 1)
+        if shape == (1400, 2600):
+            ref = to.terrain_attributes(dem, attrs, resolution=10.0, surface_fit=fit)
+            for a, g, r in zip(attrs, ref_planes, ref):
+                check_attribute(g, r, a, dem, 10.0, f"{fit}/{a}")
+
+
 def test_large_properties_16384(terrain):
     """BASELINE config[1] size: size-independent properties instead of an oracle run."""
     import torch

@@ -125,6 +125,70 @@ __global__ __launch_bounds__(256) void pat_kernel(const float* in, Planes out, i
     }
 }
 
+// Streaming strips: every WAVE owns a 64-column strip and marches down BH rows on its own -- no workgroup barrier, no tile
+// load phase.  Rows arrive through LDS-DMA (global_load_lds_dwordx4: no staging registers) in blocks of 16 into a per-wave
+// ring of 32 rows x 72 columns (the 64 columns + 4 on either side); the block after the one being marched is in flight the
+// whole time.  vmcnt is counted: the plane stores issued after a block's loads stay in flight (vmcnt(63): gfx9 VMEM completes
+// in order, so "at most 63 outstanding" means the loads -- older than the last 63 stores -- have landed).
+template <int BH, int WORK, int PADKB>
+__global__ __launch_bounds__(256) void strip_kernel(const float* in, Planes out, int n, int strips, int bands) {
+    constexpr int RP = 72;            // ring pitch (floats)
+    constexpr int RING = 32;
+    __shared__ __attribute__((aligned(16))) float ring[4 * RING * RP];
+    __shared__ float pad[PADKB * 256 + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (PADKB && tid == 1000) pad[n & 255] = 1.0f;
+    const int task = blockIdx.x * 4 + wave;          // strip-major inside a band: neighbouring strips run together
+    if (task >= strips * bands) return;
+    const int band = task / strips, strip = task - band * strips;
+    const int64_t x0 = 64 + (int64_t)strip * 64, y0 = 32 + (int64_t)band * BH;   // (interior only: the model skips the frame)
+    float* my = ring + wave * (RING * RP);
+    // lane -> (row, 16-byte column quad) of a 16-row block: slot t = 64 i + lane, row = t / 18, quad = t % 18
+    auto issue = [&](int64_t row0, int half) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int t = 64 * i + lane;
+            const int r = t / 18, q = t - r * 18;
+            if (t < 288) {
+                const float* src = in + (row0 + r) * n + (x0 - 4) + 4 * q;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(my + half * 16 * RP + 64 * i * 4), 16, 0, 0);
+            }
+        }
+    };
+    issue(y0 - 2, 0);
+    issue(y0 + 14, 1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // first block landed, second in flight
+    float* base[K];
+    const int64_t org = y0 * n + x0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) base[k] = out.p[k] + org;
+    uint32_t off = lane * 4;
+    const uint32_t rowb = (uint32_t)n * 4;
+    double c0 = 1e-9, c1 = 2e-9, c2 = 3e-9, c3 = 4e-9;
+    for (int r = 0; r < BH; ++r) {
+        // ring row of raster row y0 + r (block b = (r + 2) / 16 sits in half b & 1)
+        const int rr = (r + 2) & (RING - 1);
+        if (((r + 2) & 15) == 0) {
+            // rows y0 + r .. + 15 are needed from here on: their block was issued 16 rows ago; refill the half just left
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            if (r + 14 < BH + 2) issue(y0 + r + 16 - 2 + 2, ((r + 2) >> 4) + 1 & 1);
+        }
+        const float* row = my + rr * RP + 4 + lane;
+        const float* up = my + ((rr + RING - 1) & (RING - 1)) * RP + 4 + lane;
+        double z0 = row[0], z1 = row[-1], z2 = row[1], z3 = up[0];
+#pragma unroll 4
+        for (int w = 0; w < WORK / 4; ++w) {
+            z0 = __builtin_fma(z0, 1.0000001, c0); z1 = __builtin_fma(z1, 1.0000001, c1);
+            z2 = __builtin_fma(z2, 1.0000001, c2); z3 = __builtin_fma(z3, 1.0000001, c3);
+        }
+        const float zf = (float)((z0 + z1) + (z2 + z3));
+#pragma unroll
+        for (int k = 0; k < K; ++k) st1(base[k], off, zf + k);
+        off += rowb;
+    }
+}
+
 // Ceilings of the memory system itself: linear float4 streams, grid-stride, nothing else.  MODE 0 write-only (11 planes),
 // 1 read-only (1 plane, 11 passes' worth of bytes is not needed: reports its own GB/s), 2 copy 1 -> 1, 3 the kernel's mix (1 read : 11 written)
 template <int MODE, bool NT>
@@ -171,13 +235,25 @@ template <int TH, int FORM, int SYNC, int PADKB, int WORK, int ORDER> void run(c
     fflush(stdout);
 }
 
+template <int BH, int WORK, int PADKB> void run_strip(const char* name) {
+    const int n = g_n;
+    const int strips = (n - 128) / 64, bands = (n - 64) / BH;
+    const int tasks = strips * bands, blocks = (tasks + 3) / 4;
+    float t = time_ms([&] { hipLaunchKernelGGL((strip_kernel<BH, WORK, PADKB>), dim3(blocks), dim3(256), 0, 0, g_in, g_out, n, strips, bands); });
+    const double gb = (double)strips * 64 * bands * BH * 4 * (1 + K) / 1e9;
+    printf("%-34s BH=%4d padKB=%2d work=%3d  %8.3f ms  %7.1f GB/s  (scaled to the full raster: %7.3f ms)\n", name, BH, PADKB, WORK, t, gb / t * 1e3,
+           t * ((double)n * n) / ((double)strips * 64 * bands * BH));
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     g_n = argc > 1 ? atoi(argv[1]) : 40000;
     const size_t px = (size_t)g_n * g_n;
     CHECK(hipMalloc(&g_in, px * 4));
     CHECK(hipMemset(g_in, 0, px * 4));
     for (int k = 0; k < K; ++k) CHECK(hipMalloc(&g_out.p[k], px * 4));
-    {
+    const bool only_strips = argc > 2 && argv[2][0] == 's';
+    if (!only_strips) {
         float* sink; CHECK(hipMalloc(&sink, 64));
         const size_t n4 = px / 4;
         const char* nm[4] = {"write-only 11 planes", "read-only 1 plane", "copy 1 -> 1", "read 1 : write 11"};
@@ -191,6 +267,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
     }
     // LDS per workgroup: tile 38 KB (TH 32) / 21 KB (TH 16); pads chosen for 3 workgroups per CU (~52 KB each)
+    if (only_strips) goto strips;
     // --- no math: what the store form alone streams
     run<32, 0, 0, 12, 0, 0>("direct");
     run<32, 0, 4, 12, 0, 0>("direct, sync 4");
@@ -222,5 +299,21 @@ int main(int argc, char** argv) {
     run<32, 1, 0, 1, 120, 0>("4 planes / dwordx4");
     run<32, 0, 0, 12, 200, 0>("direct");
     run<32, 1, 0, 1, 200, 0>("4 planes / dwordx4");
+strips:
+    run<32, 0, 0, 12, 200, 0>("direct (reference)");
+    run<32, 0, 0, 12, 160, 0>("direct (reference)");
+    run<32, 0, 0, 12, 120, 0>("direct (reference)");
+    // --- wave-autonomous streaming strips (LDS 36 KB per workgroup + pad: 3 workgroups per CU at pad 12)
+    run_strip<512, 0, 12>("strips, LDS-DMA ring");
+    run_strip<512, 120, 12>("strips, LDS-DMA ring");
+    run_strip<512, 160, 12>("strips, LDS-DMA ring");
+    run_strip<512, 200, 12>("strips, LDS-DMA ring");
+    run_strip<2048, 160, 12>("strips, LDS-DMA ring");
+    run_strip<2048, 200, 12>("strips, LDS-DMA ring");
+    run_strip<128, 200, 12>("strips, LDS-DMA ring");
+    run_strip<512, 200, 0>("strips, LDS-DMA ring, 4 WG/CU");
+    run_strip<512, 160, 0>("strips, LDS-DMA ring, 4 WG/CU");
+    run<32, 0, 0, 0, 200, 0>("direct, 4 WG/CU");
+    run<32, 0, 0, 0, 160, 0>("direct, 4 WG/CU");
     return 0;
 }

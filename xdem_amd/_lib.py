@@ -221,13 +221,16 @@ class Context:
 
 
 _default_ctx: dict[int, Context] = {}
+_ctx_lock = threading.Lock()
 _tls = threading.local()
 
 
 class use_context:
     """``with use_context(ctx): ...`` -- calls made by THIS thread inside the block that would take the process-wide default
-    context use `ctx` instead.  A context serialises its own work (one stream, one scratch state): threads that want to
-    overlap GPU work create one Context each (the library is re-entrant per context handle)."""
+    context use `ctx` instead.  A context serialises its own work (one stream, one scratch state, one queue of deferred
+    result copies) and MUST NOT be driven by two threads at once -- that includes the process-wide default context: threads
+    that want to overlap GPU work create one Context each and wrap their calls in ``use_context`` (the library is re-entrant
+    per context handle; include/xdemhip.h states the same contract)."""
 
     def __init__(self, ctx: Context):
         self.ctx = ctx
@@ -251,5 +254,7 @@ def default_context(device: int | None = None) -> Context:
     if device is None:
         device = int(os.environ.get("XDEM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
+        with _ctx_lock:  # (two threads asking for the first time must not create two contexts; not `_lock`: Context() -> lib() takes that one)
+            if device not in _default_ctx:
+                _default_ctx[device] = Context(device)
     return _default_ctx[device]

@@ -57,6 +57,21 @@ class NKPlan:
           halo rows copied from its neighbours (``xdem_amd.dist.nuth_kaab_row_blocks`` builds and exchanges them).  One
           halo row serves the gradient; the bilinear taps need ``floor(|shift_y| / res_y) + 1`` more."""
         self.ctx = ctx or _lib.default_context()
+        self.handle = None
+        self.group = None
+        try:
+            self._create(ref, tba, inlier_mask, group, block)
+        except BaseException:
+            # a creation that fails after the reduction hook went in must not leave it on the (usually process-wide) context:
+            # a later single-process call on it would enter a collective alone
+            if group is not None:
+                self.ctx.set_allreduce(None)
+            if self.handle:
+                self.ctx._L.xdemhip_nk_destroy(self.handle)
+                self.handle = None
+            raise
+
+    def _create(self, ref, tba, inlier_mask, group, block) -> None:
         h = ctypes.c_void_p()
         nv = ctypes.c_int64()
         L = self.ctx._L
@@ -244,8 +259,23 @@ def _fit_from_sums(det: dict[str, Any]) -> tuple[float, float, float]:
     n, sc, ss, scc, sss, scs, sy, syc, sys_, _ = det["sums"]
     m = np.array([[scc, scs, sc], [scs, sss, ss], [sc, ss, n]], dtype=np.float64)
     rhs = np.array([syc, sys_, sy], dtype=np.float64)
-    a_, b_, c_ = np.linalg.solve(m, rhs)
+    # (least squares, not `solve`: a degenerate system -- every point at one aspect -- has a minimum-norm answer, as an
+    # optimiser started from p0 would return some finite point instead of raising LinAlgError)
+    a_, b_, c_ = np.linalg.lstsq(m, rhs, rcond=None)[0]
     return float(b_), float(a_), float(c_)
+
+
+def _check_unbinned_optimizer(fit_optimizer, bin_before_fit: bool) -> None:
+    """``bin_before_fit=False`` is solved in closed form from ten sums over the grid (the optimum plain
+    ``scipy.optimize.curve_fit`` converges to); upstream would call ``fit_optimizer`` on every point (base.py:975-989), which
+    a robust or bounded optimiser answers differently -- refuse those instead of silently ignoring them."""
+    import scipy.optimize
+
+    if not bin_before_fit and fit_optimizer is not None and fit_optimizer is not scipy.optimize.curve_fit:
+        raise NotImplementedError(
+            "bin_before_fit=False is solved from least-squares sums on the GPU, which equals scipy.optimize.curve_fit only; "
+            "a custom fit_optimizer would need every point on the host. Use bin_before_fit=True with it."
+        )
 
 
 def subsample_valid_mask(valid_mask: np.ndarray, subsample: float | int, random_state=None) -> np.ndarray:
@@ -316,6 +346,7 @@ def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarra
     Returns ((easting, northing, vertical) offsets in georeferenced units, subsample_final)."""
     import scipy.optimize
 
+    _check_unbinned_optimizer(fit_optimizer, bin_before_fit)
     fit_optimizer = fit_optimizer or scipy.optimize.curve_fit
     logging.info("Running Nuth and Kääb (2011) coregistration")
     plan = NKPlan(ref_elev, tba_elev, inlier_mask, ctx, group)
@@ -380,6 +411,7 @@ class NuthKaab:
         import scipy.optimize
 
         _bin_statistic_id(bin_statistic)  # np.nanmedian (default) or np.nanmean; raises for anything else
+        _check_unbinned_optimizer(fit_optimizer, bin_before_fit)
         if isinstance(bin_sizes, dict):  # upstream's {"aspect": n | edges} form (base.py:957-966)
             if list(bin_sizes) != ["aspect"]:
                 raise ValueError("The keys of `bin_sizes` must be ['aspect'] for NuthKaab.")
@@ -388,6 +420,9 @@ class NuthKaab:
             bin_sizes = np.asarray(bin_sizes, dtype=np.float64)
             if bin_sizes.ndim != 1 or bin_sizes.size < 2 or np.any(np.diff(bin_sizes) <= 0):
                 raise ValueError("bin_sizes must be a number of bins or a 1-D array of increasing bin edges.")
+            if bin_sizes.size > 129:
+                raise NotImplementedError("explicit aspect-bin edges: at most 128 bins (one histogram sweep on the GPU); pass a "
+                                          "number of bins (up to 1024) for a finer uniform binning.")
         if initial_shift is not None:
             # same checks as AffineCoreg.__init__ (affine.py:1813-1829)
             if not (isinstance(initial_shift, tuple) and len(initial_shift) in (2, 3)

@@ -1141,7 +1141,9 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         // Direction-agnostic on purpose: every rank of a partitioned fit must take the same decision (a rank that raised
         // while its neighbours entered the next all-reduce would dead-lock the group), and all interior block borders
         // carry the same halo depth.
-        const int64_t need = (int64_t)floor(fabs(dr)) + 1;
+        // rules 0 / 1 read the four bilinear taps (rows floor(r + dr), + 1); rules 2 / 3 look one row around the NEAREST pixel,
+        // i.e. round(r + dr) +- 1: one more row once the fractional part of |dr| reaches one half
+        const int64_t need = (int64_t)floor(fabs(dr)) + (P->nan_rule >= 2 ? 2 : 1);
         const bool top_ok = P->row0 == 0 || P->row0 - P->roff >= need;
         const bool bottom_ok = P->row1 == P->H || P->roff + P->nbuf - P->row1 >= need;
         if (!top_ok || !bottom_ok)
@@ -1427,6 +1429,9 @@ int xdemhip_nk_step(xdemhip_nk_plan* P, double shift_x, double shift_y, double r
     xdemhip_ctx* ctx = P->ctx;
     if (!vshift || !n_valid || !y_mean || !y_std || !edges || !counts || !medians) return xd_fail(ctx, XDEMHIP_EINVAL, "null output");
     if (n_bins < 1 || n_bins > P->max_bins) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins out of range (1..1024)");
+    // explicit edges fix the number of bins: the caller's output arrays are sized by ITS n_bins, so the two must agree
+    if (!P->custom_edges.empty() && n_bins != (int)P->custom_edges.size() - 1)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins must equal the number of explicit bin edges - 1 (xdemhip_nk_set_bin_edges)");
     if (!(res_x > 0) || !(res_y > 0)) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));

@@ -647,9 +647,10 @@ XD_HD void window3_pixel_mixed(const float (&n)[9], double sum9, const TerrainPa
 // once; the two differ only where the terms cancel exactly -- flat or planar ground, where the reference returns its
 // rounding residue (|zx| ~ 1e-15, hence an "aspect" of 198.43 deg on a flat Florinsky window) instead of 0.  Such pixels
 // (an exact 0 from the fast sum) are recomputed here so that they carry the reference's value.  `win` = top-left pixel of
-// the M x M window in the LDS tile.  No fused multiply-add: SciPy's loop does not contract.
-template <int M, typename TIN>
-XD_HD TIN ref_order_sum(const TIN* win, int pitch, const double* w) {
+// the M x M window in the LDS tile (tile row `top`, `left` columns from the lane's own; rows through the row addresser of
+// march_column).  No fused multiply-add: SciPy's loop does not contract.
+template <int M, typename TIN, class ROWS>
+XD_HD TIN ref_order_sum(const ROWS& rows, int top, int left, const double* w) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -659,13 +660,14 @@ XD_HD TIN ref_order_sum(const TIN* win, int pitch, const double* w) {
 #pragma clang loop unroll(disable)
 #endif
     for (int a = 0; a < M; ++a) {
+        const TIN* win = rows.ptr(top + a) + left;
 #if defined(__clang__)
 #pragma clang loop unroll(disable)
 #endif
         for (int b = 0; b < M; ++b) {
             const double wk = w[a * M + b];
             if (wk != 0.0) {
-                const double t = wk * (double)win[a * pitch + b];
+                const double t = wk * (double)win[b];
                 acc = acc + t;
             }
         }
@@ -731,8 +733,27 @@ template <class SP, class SINK> struct WindowTail<true, SP, float, SINK> {
     }
 };
 
+// Row addressers: where tile row t of this lane's column lives.  RowsLinear: a row-major tile (`col` = the lane's column in
+// tile row 0).  The streaming kernel of terrain_tile.h supplies a per-wave ring refilled by LDS-DMA; `step(r)` is its hook
+// at the start of march step r (before the step's read of tile row r + 1).
+template <typename TIN> struct RowsLinear {
+    const TIN* col;
+    int pitch;
+    XD_HD const TIN* ptr(int t) const { return col + (int64_t)t * pitch; }
+    XD_HD void step(int) {}
+};
+
+template <int FIT, bool CURV, bool WIN, class SP, typename TIN, class SINK, class ROWS>
+XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk);
+
 template <int FIT, bool CURV, bool WIN, class SP, typename TIN, class SINK>
 XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParams& P, SINK& sk) {
+    RowsLinear<TIN> rows{col, pitch};
+    march_rows<FIT, CURV, WIN, SP, TIN, SINK, RowsLinear<TIN>>(rows, n_out, P, sk);
+}
+
+template <int FIT, bool CURV, bool WIN, class SP, typename TIN, class SINK, class ROWS>
+XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
     typedef typename SINK::out_t TOUT;
     constexpr int HALO = Halo<FIT>::v;
     constexpr int NS = 2 * HALO + 1;  // rotating window slots
@@ -749,16 +770,21 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
     TIN Nl[NS], Nc[NS], Nr[NS];
 
     // the tile row of the NEXT step is fetched from LDS one step ahead, so its latency hides behind a whole row of math
-    TIN nx0 = (TIN)0, nx1 = col[-1], nx2 = col[0], nx3 = col[1], nx4 = (TIN)0;
-    if (FIT == 2) { nx0 = col[-2]; nx4 = col[2]; }
+    TIN nx0 = (TIN)0, nx1, nx2, nx3, nx4 = (TIN)0;
+    {
+        const TIN* row0 = rows.ptr(0);
+        nx1 = row0[-1]; nx2 = row0[0]; nx3 = row0[1];
+        if (FIT == 2) { nx0 = row0[-2]; nx4 = row0[2]; }
+    }
     for (int r0 = 0; r0 < nrows; r0 += NS) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int r = r0 + k;
             if (r < nrows) {
                 const TIN t0 = nx0, tl = nx1, tc = nx2, tr = nx3, t4 = nx4;
+                rows.step(r);
                 {
-                    const TIN* row = col + (int64_t)((r + 1 < nrows) ? r + 1 : r) * pitch;
+                    const TIN* row = rows.ptr((r + 1 < nrows) ? r + 1 : r);
                     nx1 = row[-1]; nx2 = row[0]; nx3 = row[1];
                     if (FIT == 2) { nx0 = row[-2]; nx4 = row[2]; }
                 }
@@ -849,13 +875,13 @@ XD_HD void march_column(const TIN* col, int pitch, int n_out, const TerrainParam
 #endif
                         {
                             if (cold) {
-                                const TIN* win = col + (int64_t)i * pitch - HALO;
-                                if (zx == (TIN)0) zx = ref_order_sum<NS, TIN>(win, pitch, P.wref[0]);
-                                if (zy == (TIN)0) zy = ref_order_sum<NS, TIN>(win, pitch, P.wref[1]);
+                                // (window of output row i = tile rows i .. i + 2 HALO, columns -HALO .. +HALO around the lane's own)
+                                if (zx == (TIN)0) zx = ref_order_sum<NS, TIN, ROWS>(rows, i, -HALO, P.wref[0]);
+                                if (zy == (TIN)0) zy = ref_order_sum<NS, TIN, ROWS>(rows, i, -HALO, P.wref[1]);
                                 if (CURV) {
-                                    if (zxx == (TIN)0) zxx = ref_order_sum<NS, TIN>(win, pitch, P.wref[2]);
-                                    if (zyy == (TIN)0) zyy = ref_order_sum<NS, TIN>(win, pitch, P.wref[3]);
-                                    if (zxy == (TIN)0) zxy = ref_order_sum<NS, TIN>(win, pitch, P.wref[4]);
+                                    if (zxx == (TIN)0) zxx = ref_order_sum<NS, TIN, ROWS>(rows, i, -HALO, P.wref[2]);
+                                    if (zyy == (TIN)0) zyy = ref_order_sum<NS, TIN, ROWS>(rows, i, -HALO, P.wref[3]);
+                                    if (zxy == (TIN)0) zxy = ref_order_sum<NS, TIN, ROWS>(rows, i, -HALO, P.wref[4]);
                                 }
                                 const TIN pz = (TIN)poison;
                                 ColdTail<MIXED, CURV, SP, TIN, SINK>::go(zx + pz, zy, CURV ? zxx + pz : zxx, zyy, zxy, P, sk);

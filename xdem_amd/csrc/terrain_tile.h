@@ -36,6 +36,9 @@ template <typename TIN, typename TOUT> struct TileArgs {
     int tiles_x, tiles_y, ntiles, grid8;  // grid8 = padded grid / 8
     int vec_ok;
     int sync_n, order;      // options "terrain_sync" / "terrain_order"
+    // frame mode (frame != 0): only the tiles OUTSIDE the tile rectangle [fr_tx0, fr_tx1) x [fr_ty0, fr_ty1) -- the streaming
+    // kernel below covers that interior; ntiles then counts the frame tiles
+    int frame, fr_tx0, fr_tx1, fr_ty0, fr_ty1;
     int nplanes;            // requested planes of this launch (staged stores)
     TOUT* compact[N_ATTR];  // ... their pointers in ascending attribute order
     TerrainParams P;
@@ -91,9 +94,25 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
 
     // XCD-aware tile order (see file header)
     const int b = blockIdx.x;
-    const int logical = a.order ? b : (b & 7) * a.grid8 + (b >> 3);
+    const int logical = (a.order | a.frame) ? b : (b & 7) * a.grid8 + (b >> 3);
     if (logical >= a.ntiles) return;
-    const int ty = logical / a.tiles_x, tx = logical - ty * a.tiles_x;
+    int ty = logical / a.tiles_x, tx = logical - ty * a.tiles_x;
+    if (a.frame) {  // frame tiles in order: the tile rows above the interior, its left / right flanks, the tile rows below
+        int f = logical;
+        const int top = a.tiles_x * a.fr_ty0, midw = a.fr_tx0 + (a.tiles_x - a.fr_tx1), mid = midw * (a.fr_ty1 - a.fr_ty0);
+        if (f >= top) {
+            f -= top;
+            if (f < mid) {
+                ty = a.fr_ty0 + f / midw;
+                const int j = f - (f / midw) * midw;
+                tx = j < a.fr_tx0 ? j : a.fr_tx1 + (j - a.fr_tx0);
+            } else {
+                f -= mid;
+                ty = a.fr_ty1 + f / a.tiles_x;
+                tx = f - (f / a.tiles_x) * a.tiles_x;
+            }
+        }
+    }
     const int64_t x0 = (int64_t)tx * TILE_W, y0 = (int64_t)ty * TH;
     const int n_out = (int)((a.H - y0) < TH ? (a.H - y0) : TH);
     const int rows = n_out + 2 * HALO;
@@ -172,6 +191,102 @@ __global__ __launch_bounds__(256, MINW) void terrain_tile_kernel(const TileArgs<
     }
 }
 
+// ---- streaming strips (float32 rasters, the specialised attribute sets) ----------------------------------------------------
+// The tile kernel above pays, per 32-row tile, a load phase the whole workgroup waits for (global loads -> LDS -> barrier:
+// the three workgroups of a CU start together and stay in step, so those bubbles line up), 4 halo rows of partial sums and
+// 12 % re-read input.  Here every WAVE owns a 64-column strip and marches down a band of BH rows on its own: rows arrive by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) in blocks of 16 into a per-wave ring of 32 rows x
+// 72 columns (the strip + 4 columns either side: 16-byte quads), the block after the one being marched always in flight;
+// no workgroup barrier anywhere, halo rows only at the two ends of a band.  tools/membench3.hip (same structure, float64
+// FMAs standing in for the attribute math): 14.9 -> 13.5 ms at the kernel's amount of math, 12.2 ms without any.
+// The ring is filled from inside the raster only, so this kernel covers the raster's INTERIOR (whole 256-column x 32-row
+// tiles whose windows and 4-column pads stay inside); the frame of edge tiles goes to the tile kernel in frame mode.
+// VMEM bookkeeping: a block's loads are waited for with a COUNTED s_waitcnt -- the plane stores issued after them (inline asm,
+// invisible to the compiler) stay in flight: gfx9 VMEM operations of a wave retire in order, so "at most N outstanding" with
+// N <= the number of stores issued since the loads means the loads have landed.  N = min(63, 11 rows x planes per row).
+struct StripArgs {
+    const float* dem;
+    int64_t H, W, stride, halo_top;
+    int64_t xi0, yi0, yi1;      // interior: columns from xi0 (groups of 256), rows [yi0, yi1)
+    int groups_x, ngroups, grid8, order;
+    TerrainParams P;
+    Planes<float> out;
+};
+
+constexpr int RING_ROWS = 32, RING_PITCH = 72, RING_BLOCK = 16;
+constexpr int RING_QUADS = RING_BLOCK * RING_PITCH / 4;   // 288 float4 per block = 4.5 wave instructions
+
+template <int NPL> struct RowsRing {
+    const float* mine;      // LDS: this lane's column in ring row 0
+    const float* gsrc;      // global: first pixel (column x0 - 4) of tile row 0
+    float* ring;            // LDS: this wave's ring
+    int64_t stride;
+    int nrows, lane;
+    __device__ __forceinline__ const float* ptr(int t) const { return mine + (t & (RING_ROWS - 1)) * RING_PITCH; }
+    __device__ __forceinline__ void issue(int k) const {   // block k = tile rows [16 k, 16 k + 16) -> ring half k & 1
+        float* dst = ring + (k & 1) * (RING_BLOCK * RING_PITCH);
+#pragma unroll
+        for (int i = 0; i < (RING_QUADS + 63) / 64; ++i) {
+            const int t = 64 * i + lane;
+            const int r = t / (RING_PITCH / 4), q = t - r * (RING_PITCH / 4);
+            int row = RING_BLOCK * k + r;
+            row = row < nrows ? row : nrows - 1;   // (rows past the band's last: duplicates of it, never read)
+            if (t < RING_QUADS)
+                __builtin_amdgcn_global_load_lds(gsrc + (int64_t)row * stride + 4 * q,
+                                                 (__attribute__((address_space(3))) void*)(dst + 64 * i * 4), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void step(int r) const {
+        constexpr int N = 11 * NPL < 63 ? 11 * NPL : 63;
+        // about to read tile row r + 1, the first of its block: that block was issued at least 11 output rows ago
+        if (((r + 1) & (RING_BLOCK - 1)) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+        // tile rows below 16 (r >> 4) are dead from here on (the oldest row any path still reads is r - 4): refill their half
+        if ((r & (RING_BLOCK - 1)) == 4 && r >= RING_BLOCK + 4) {
+            const int k = (r >> 4) + 1;
+            if (RING_BLOCK * k < nrows) issue(k);
+        }
+    }
+};
+
+template <int FIT, bool CURV, bool WIN, class SP, int BH>
+__global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
+    constexpr int HALO = Halo<FIT>::v;
+    constexpr int NPL = __builtin_popcount(SP::CMASK);
+    static_assert(SP::CMASK != 0 && BH % 32 == 0, "specialised attribute sets only");
+    __shared__ __attribute__((aligned(16))) float ring[4 * RING_ROWS * RING_PITCH];
+    const int b = blockIdx.x;
+    const int logical = a.order ? b : (b & 7) * a.grid8 + (b >> 3);   // XCD-aware: neighbouring strip groups share an L2
+    if (logical >= a.ngroups) return;
+    const int band = logical / a.groups_x, gx = logical - band * a.groups_x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t x0 = a.xi0 + ((int64_t)gx * 4 + wave) * 64, y0 = a.yi0 + (int64_t)band * BH;
+    const int n_out = (int)((a.yi1 - y0) < BH ? (a.yi1 - y0) : BH);
+    RowsRing<NPL> rows;
+    rows.ring = ring + wave * (RING_ROWS * RING_PITCH);
+    rows.mine = rows.ring + 4 + lane;
+    rows.gsrc = a.dem + (y0 - HALO + a.halo_top) * a.stride + (x0 - 4);
+    rows.stride = a.stride;
+    rows.nrows = n_out + 2 * HALO;
+    rows.lane = lane;
+    rows.issue(0);
+    if (RING_BLOCK < rows.nrows) {
+        rows.issue(1);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // block 0 landed, the 5 loads of block 1 in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const uint64_t org_u = (uint64_t)(y0 * a.W + x0);
+    const int64_t org_off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(org_u >> 32)) << 32) |
+                                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)org_u));
+    DirectSink<float> sk;
+#pragma unroll
+    for (int k = 0; k < N_ATTR; ++k) sk.org.p[k] = a.out.p[k] + org_off;
+    sk.o0 = (uint32_t)(lane * sizeof(float));
+    sk.ostride = (uint32_t)(a.W * sizeof(float));
+    march_rows<FIT, CURV, WIN, SP, float, DirectSink<float>, RowsRing<NPL>>(rows, n_out, a.P, sk);
+}
+
 // TPI / TRI for an arbitrary odd window (reference default is 3, handled by the fused kernel above).
 // One thread per pixel, window read through L1/L2; float64 accumulation in row-major order like the
 // flattened footprint the reference's generic_filter callback sums (xdem/terrain/window.py:67-252).
@@ -230,8 +345,10 @@ static void fill_params(const TerrainLaunch& L, TerrainParams& P) {
     P.degrees = L.degrees;
 }
 
+struct FrameRect { int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0; };  // interior tile rectangle left out in frame mode (empty: all tiles)
+
 template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT, int TH, int STORE, int MINW = 1>
-static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask, unsigned dyn_lds = 0) {
+static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask, unsigned dyn_lds = 0, FrameRect fr = FrameRect()) {
     TileArgs<TIN, TOUT> a;
     a.dem = static_cast<const TIN*>(L.dem);
     a.H = L.H; a.W = L.W; a.stride = L.row_stride; a.halo_top = L.halo_top; a.halo_bottom = L.halo_bottom;
@@ -240,6 +357,10 @@ static int launch_tiles(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask,
     // 1.4e11 pixels, beyond any device memory)
     if (tx * ty > (int64_t)0xfffff0) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "raster too large for one launch");
     a.tiles_x = (int)tx; a.tiles_y = (int)ty; a.ntiles = (int)(tx * ty);
+    a.frame = (fr.tx1 > fr.tx0 && fr.ty1 > fr.ty0) ? 1 : 0;
+    a.fr_tx0 = fr.tx0; a.fr_tx1 = fr.tx1; a.fr_ty0 = fr.ty0; a.fr_ty1 = fr.ty1;
+    if (a.frame) a.ntiles -= (fr.tx1 - fr.tx0) * (fr.ty1 - fr.ty0);
+    if (a.ntiles == 0) return XDEMHIP_OK;
     a.grid8 = (a.ntiles + 7) / 8;
     constexpr int VEC = 16 / sizeof(TIN);
     a.vec_ok = ((reinterpret_cast<uintptr_t>(L.dem) & 15) == 0) && (L.row_stride % VEC == 0);
@@ -300,6 +421,50 @@ static int launch_shaped(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
     return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, TH_DIRECT, 0>(ctx, L, mask);
 }
 
+// Streaming route for float32 in / float32 out and the specialised attribute sets: the interior by terrain_strip_kernel, the
+// frame of edge tiles by the tile kernel.  Returns 1 if it took the launch, 0 if the raster does not qualify (caller falls
+// back to the tile kernel for everything), < 0 on error.  Option "terrain_stream": 0 off, 1 on (default), 128 / 256 / 512 =
+// band height (measurement).
+template <int FIT, bool CURV, bool WIN, class SP>
+static int launch_stream(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask) {
+    constexpr int HALO = Halo<FIT>::v;
+    constexpr int TH = 32;
+    if (ctx->terrain_stream == 0 || ctx->terrain_store == 1 || ctx->terrain_rows != 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(L.dem) & 15) || (L.row_stride & 3)) return 0;   // 16-byte quads of the LDS-DMA
+    FrameRect fr;
+    fr.tx0 = 1;
+    fr.tx1 = (int)((L.W - 4) / TILE_W);
+    fr.ty0 = L.halo_top >= HALO ? 0 : 1;
+    const int64_t ylim = (L.H + L.halo_bottom - HALO) < L.H ? (L.H + L.halo_bottom - HALO) : L.H;
+    fr.ty1 = (int)(ylim / TH);
+    if (fr.tx1 - fr.tx0 < 1 || fr.ty1 - fr.ty0 < 2) return 0;
+    if ((int64_t)(fr.tx1 - fr.tx0) * (fr.ty1 - fr.ty0) < 64) return 0;   // small rasters: one launch of the tile kernel
+    StripArgs a;
+    a.dem = static_cast<const float*>(L.dem);
+    a.H = L.H; a.W = L.W; a.stride = L.row_stride; a.halo_top = L.halo_top;
+    a.xi0 = (int64_t)fr.tx0 * TILE_W; a.yi0 = (int64_t)fr.ty0 * TH; a.yi1 = (int64_t)fr.ty1 * TH;
+    a.groups_x = fr.tx1 - fr.tx0;
+    a.order = ctx->terrain_order;
+    fill_params(L, a.P);
+    a.P.mask = mask;
+    for (int k = 0; k < N_ATTR; ++k) { a.out.p[k] = static_cast<float*>(L.planes[k]); a.P.slot[k] = 0; }
+    const int bh = ctx->terrain_stream >= 64 ? ctx->terrain_stream : 128;
+    const bool dbg_no_strips = ctx->terrain_stream == 3, dbg_no_frame = ctx->terrain_stream == 2;  // (debug: one of the two launches only)
+    const int64_t bands = (a.yi1 - a.yi0 + bh - 1) / bh;
+    if (bands * a.groups_x > (int64_t)0xfffff0) return 0;
+    a.ngroups = (int)(bands * a.groups_x);
+    a.grid8 = (a.ngroups + 7) / 8;
+    const dim3 grid(a.grid8 * 8), block(256);
+    if (dbg_no_strips) {}
+    else if (bh == 128) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 128>), grid, block, 0, ctx->stream, a);
+    else if (bh == 256) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 256>), grid, block, 0, ctx->stream, a);
+    else if (bh == 512) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 512>), grid, block, 0, ctx->stream, a);
+    else return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_stream: 0, 1, 128, 256 or 512");
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    const int rc = dbg_no_frame ? XDEMHIP_OK : launch_tiles<FIT, CURV, WIN, SP, float, float, TH, 0>(ctx, L, mask, 0, fr);
+    return rc == XDEMHIP_OK ? 1 : rc;
+}
+
 template <typename TIN, typename TOUT>
 static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
     const uint32_t surf = L.attr_mask & ~A_ANY_WIN;
@@ -323,6 +488,16 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
         constexpr bool ALLSHAPES = false;
 #endif
         if (!f64tail) {
+            if constexpr (FF) {  // streaming route (interior by wave-autonomous strips + frame by tiles) where the raster qualifies
+                int took = 0;
+                if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY)
+                    took = launch_stream<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>>(ctx, L, mask);
+                else if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_ZEVENBERGTHORNE)
+                    took = launch_stream<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>>(ctx, L, mask);
+                else if (defaults && mask == MASK_SAH_WIN && fit == XDEMHIP_FIT_HORN)
+                    took = launch_stream<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>>(ctx, L, mask);
+                if (took != 0) return took < 0 ? took : XDEMHIP_OK;
+            }
             if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY)
                 return launch_shaped<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT, ALLSHAPES>(ctx, L, mask);
             if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_ZEVENBERGTHORNE)
