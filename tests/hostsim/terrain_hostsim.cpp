@@ -38,6 +38,9 @@ static void run(const TIN* dem, int64_t H, int64_t W, int64_t halo_top, int64_t 
         }
 }
 
+static int g_tail = 2;  // tail of the specialised float32 kernels: 2 lean (the library's default), 0 mixed (option "terrain_math")
+extern "C" void hostsim_set_tail(int level) { g_tail = level; }
+
 template <typename TIN, typename TOUT>
 static int go(const void* dem, int64_t H, int64_t W, int64_t ht, int64_t hb, int TH, int fit, const TerrainParams& P,
               void* const* planes) {
@@ -47,12 +50,18 @@ static int go(const void* dem, int64_t H, int64_t W, int64_t ht, int64_t hb, int
     const bool curv = (P.mask & A_ANY_CURV) != 0, win = (P.mask & A_ANY_WIN) != 0;
     // exercise the compile-time specialised instantiations exactly when the GPU launcher would pick them
     if (P.mask == MASK_FULL11 && !P.curv_directional && P.degrees && !P.tri_wilson && fit != 0 && P.hs_zf2 == 1.0) {
-        if (fit == 2) run<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
-        else run<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        if (g_tail == 2) {
+            if (fit == 2) run<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+            else run<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        } else {
+            if (fit == 2) run<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+            else run<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        }
         return 0;
     }
     if (P.mask == MASK_SAH_WIN && P.degrees && !P.tri_wilson && fit == 0 && P.hs_zf2 == 1.0) {
-        run<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        if (g_tail == 2) run<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        else run<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
         return 0;
     }
 #define GO(F, C, Wn) run<F, C, Wn, SpecRuntime, TIN, TOUT>(d, H, W, ht, hb, TH, P, out)

@@ -26,8 +26,10 @@ def build():
 
 def hostsim_terrain(dem, attrs, resolution=1.0, surface_fit="Florinsky", curv_method="geometric", tri_method="Riley",
                     hillshade_altitude=45.0, hillshade_azimuth=315.0, hillshade_z_factor=1.0, degrees=True,
-                    out_dtype=None, halo_top=0, halo_bottom=0, tile_rows=32):
+                    out_dtype=None, halo_top=0, halo_bottom=0, tile_rows=32, tail=2):
+    """`tail`: attribute math of the specialised float32 kernels, 2 = lean (library default), 0 = mixed (round 2)."""
     lib = build()
+    lib.hostsim_set_tail(int(tail))
     dem = np.ascontiguousarray(dem)
     assert dem.dtype in (np.float32, np.float64)
     out_dtype = np.dtype(out_dtype or dem.dtype)

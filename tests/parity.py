@@ -106,19 +106,22 @@ def assert_parity_true(got, ref, name="", floor: float = 0.0, rtol: float = RTOL
 
 
 # Attributes whose float32 result is, by construction of the kernel, the reference's float64 evaluation rounded once
-# (>= 99.9 % of pixels bit-identical on terrain-like rasters); slope, aspect and TRI run their polynomial / sum-of-squares
-# part in float32 (a few float32 roundings: <= 8 ulp, far inside the 1e-6 bar).
-EXACT_ATTRS = {"hillshade", "curvature", "profile_curvature", "tangential_curvature", "planform_curvature",
-               "flowline_curvature", "max_curvature", "min_curvature", "topographic_position_index", "roughness"}
+# (>= 99.9 % of pixels bit-identical on terrain-like rasters).  Round 3: the lean tail of the specialised float32 kernels
+# spends the 1e-6 budget on float32 scale factors (curvatures, hillshade: a few float32 roundings, <= 16 ulp, measured maxima
+# 3e-7 .. 6e-7 true relative); what stays bit-exact are the planes that never leave float64 before their single rounding.
+EXACT_ATTRS = {"curvature", "topographic_position_index", "roughness"}
+# ... and with the mixed tail of round 2 (option "terrain_math" = 0, the runtime-mask kernels, tail=0 in the host simulator):
+EXACT_ATTRS_MIXED = EXACT_ATTRS | {"hillshade", "profile_curvature", "tangential_curvature", "planform_curvature",
+                                   "flowline_curvature", "max_curvature", "min_curvature"}
 
 
-def check_attribute(got, ref, attr, dem, resolution, name="", exact_frac=0.999, max_ulp_f32_math=8):
+def check_attribute(got, ref, attr, dem, resolution, name="", exact_frac=0.999, max_ulp_f32_math=16, exact_attrs=None):
     """The round-2 parity bar for one attribute plane: masks bit-exact, TRUE relative error <= 1e-6 outside the float64
     noise floor, and for float32 planes either the bit-exact share (EXACT_ATTRS) or an ulp bound."""
     floor = noise_floor(attr, dem, resolution)
     c = assert_parity_true(got, ref, name or attr, floor=floor)
     if got.dtype == np.float32 and c["n"] >= 1000:
-        if attr in EXACT_ATTRS:
+        if attr in (EXACT_ATTRS if exact_attrs is None else exact_attrs):
             assert c["exact"] >= exact_frac, f"{name or attr}: only {c['exact']:.5f} bit-exact (< {exact_frac})"
         else:
             assert c["max_ulp"] <= max_ulp_f32_math, f"{name or attr}: {c['max_ulp']} ulp (> {max_ulp_f32_math})"

@@ -202,16 +202,28 @@ def test_T3_reference_known_answers_on_the_hip_path(terrain, record_property):
 
 
 def test_ulp_histogram_per_attribute(terrain, record_property):
-    """Per-attribute ulp histogram of the float32 kernel against the oracle on a terrain-like raster (what
-    tools/ulp_report.py prints): the evidence behind the mixed-precision tail."""
-    dem = _dem((1500, 1531), seed=42)
-    for fit, attrs in (("Florinsky", FULL), ("ZevenbergThorne", FULL), ("Horn", SAH_WIN)):
-        got = terrain.get_terrain_attribute(dem, attrs, resolution=10.0, surface_fit=fit)
-        ref = to.terrain_attributes(dem, attrs, resolution=10.0, surface_fit=fit)
-        for a, g, r in zip(attrs, got, ref):
-            c = check_attribute(g, r, a, dem, 10.0, f"{fit}/{a}")
-            record_property(f"{fit}/{a}", _ulp_line(c))
-            print(f"{fit:16s} {a:28s} {_ulp_line(c)}")
+    """Per-attribute ulp histogram of the float32 kernels against the oracle on a terrain-like raster (what
+    tools/ulp_report.py prints), for both tails of the specialised kernels: the lean tail (option "terrain_math" = 2, default:
+    float32 scale factors, every plane within 1e-6 TRUE relative error) and the mixed tail of round 2 (0: eight planes
+    bit-identical).  The raster is large enough for the streaming-strip route (interior) and the tile kernel (frame)."""
+    from parity import EXACT_ATTRS_MIXED
+
+    from xdem_amd import _lib
+
+    ctx = _lib.default_context()
+    dem = _dem((1500, 1532), seed=42)
+    try:
+        for tail in (2, 0):
+            ctx.set_option("terrain_math", tail)
+            for fit, attrs in (("Florinsky", FULL), ("ZevenbergThorne", FULL), ("Horn", SAH_WIN)):
+                got = terrain.get_terrain_attribute(dem, attrs, resolution=10.0, surface_fit=fit)
+                ref = to.terrain_attributes(dem, attrs, resolution=10.0, surface_fit=fit)
+                for a, g, r in zip(attrs, got, ref):
+                    c = check_attribute(g, r, a, dem, 10.0, f"tail {tail} {fit}/{a}", exact_attrs=EXACT_ATTRS_MIXED if tail == 0 else None)
+                    record_property(f"tail{tail}/{fit}/{a}", _ulp_line(c))
+                    print(f"tail {tail} {fit:16s} {a:28s} {_ulp_line(c)}")
+    finally:
+        ctx.set_option("terrain_math", 2)
 
 
 def test_halo_rows_equal_full_raster(terrain):

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--opts", default="terrain_sync=0,2,4,8;terrain_order=0,1")
+    ap.add_argument("--combos", default="")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     import torch
@@ -36,14 +37,18 @@ def main():
     dem = fbm_torch(n, n, "cuda", seed=42)
     out = torch.empty((len(FULL), n, n), dtype=torch.float32, device="cuda")
     ctx = _lib.default_context(0)
-    settings = [("default", {})]
+    # --opts "a=0,1;b=2" times every listed value of a and of b alone (the other options at 0);
+    # --combos "a=1+b=2;a=0+b=2" times the named combinations.  Options not named in a setting are set to 0.
+    settings = []
     for spec in a.opts.split(";"):
         if not spec:
             continue
         name, vals = spec.split("=")
         for v in vals.split(","):
-            settings.append((f"{name}={v}", dict(kv.split(":") for kv in [f"{name}:{v}"])))
-    # combined settings: "a=1+b=2"
+            settings.append((f"{name}={v}", {name: v}))
+    for combo in a.combos.split(";"):
+        if combo:
+            settings.append((combo, dict(kv.split("=") for kv in combo.split("+"))))
     res = {k: [] for k, _ in settings}
     kw = dict(resolution=10.0, surface_fit="Florinsky", curv_method="geometric", ctx=ctx)
     names = sorted({k for _, d in settings for k in d})
@@ -55,7 +60,7 @@ def main():
                 terrain_attributes_device(dem, FULL, out=out, **kw)
                 res[label].append(ctx.last_kernel_ms())
     for k in names:
-        ctx.set_option(k, 0)
+        ctx.set_option(k, {"terrain_math": 2, "terrain_stream": 1}.get(k, 0))   # back to the library defaults
     summary = {}
     for label, _ in settings:
         t = sorted(res[label])

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--res", type=float, default=10.0)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--tail", type=int, default=2, help="2 lean tail (default), 0 mixed tail of round 2, 1 float64 (GPU only)")
     a = ap.parse_args()
     import terrain_oracle as to
     from xdem_amd.synth import fbm_numpy
@@ -60,11 +61,14 @@ def main():
     if a.gpu:
         from xdem_amd import terrain
 
+        from xdem_amd import _lib
+
+        _lib.default_context().set_option("terrain_math", a.tail)
         got = terrain.get_terrain_attribute(dem, attrs, resolution=a.res, surface_fit=a.fit)
     else:
         from hostsim_util import hostsim_terrain
 
-        got = hostsim_terrain(dem, attrs, resolution=a.res, surface_fit=a.fit)
+        got = hostsim_terrain(dem, attrs, resolution=a.res, surface_fit=a.fit, tail=a.tail)
     rep = {}
     print(f"{'attribute':32s} {'0ulp':>7s} {'1ulp':>7s} {'2ulp':>7s} {'3-4':>7s} {'5-8':>7s} {'>8':>7s} {'max':>5s} {'max rel (away from 0)':>22s}")
     for n, g, r in zip(attrs, got, ref):

@@ -121,7 +121,7 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         return XDEMHIP_OK;
     }
     if (std::string(name) == "terrain_math") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_math: 0 mixed precision, 1 float64");
+        if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_math: 0 mixed precision, 1 float64, 2 lean");
         ctx->terrain_math = value;
         return XDEMHIP_OK;
     }

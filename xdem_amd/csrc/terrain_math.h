@@ -282,6 +282,67 @@ XD_HD float asin32(float x) {
     return fmaf(x * s, p, x);
 }
 
+// ---- two float32 evaluations per instruction (v_pk_mul_f32 / v_pk_fma_f32) ---------------------------------------------------
+// The fused kernel is bound by instruction ISSUE (one wave instruction per ~4 cycles and SIMD whatever its type: profiles/
+// README.md, r03), so float32 work that comes in pairs -- the two arcsine polynomials, the two reciprocal square roots, the
+// eight squared differences of the TRI -- is packed: same IEEE operations per lane (the host versions below ARE the
+// definition), half the instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float xd_v2f __attribute__((ext_vector_type(2)));
+#endif
+// (asin32(x1), asin32(x2))
+XD_HD void asin32_pair(float x1, float x2, float& r1, float& r2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const xd_v2f x = {x1, x2};
+    const xd_v2f s = x * x;
+    xd_v2f p = {1.115436330e-01f, 1.115436330e-01f};
+    p = __builtin_elementwise_fma(p, s, (xd_v2f){-9.298548102e-02f, -9.298548102e-02f});
+    p = __builtin_elementwise_fma(p, s, (xd_v2f){7.720199972e-02f, 7.720199972e-02f});
+    p = __builtin_elementwise_fma(p, s, (xd_v2f){1.631883346e-02f, 1.631883346e-02f});
+    p = __builtin_elementwise_fma(p, s, (xd_v2f){4.651309177e-02f, 4.651309177e-02f});
+    p = __builtin_elementwise_fma(p, s, (xd_v2f){7.488407940e-02f, 7.488407940e-02f});
+    p = __builtin_elementwise_fma(p, s, (xd_v2f){1.666690707e-01f, 1.666690707e-01f});
+    const xd_v2f r = __builtin_elementwise_fma(x * s, p, x);
+    r1 = r.x; r2 = r.y;
+#else
+    r1 = asin32(x1); r2 = asin32(x2);
+#endif
+}
+// (rsq32(x1), rsq32(x2)): two hardware seeds, one packed Newton step
+XD_HD void rsq32_pair(float x1, float x2, float& r1, float& r2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const xd_v2f x = {x1, x2};
+    const xd_v2f y = {__builtin_amdgcn_rsqf(x1), __builtin_amdgcn_rsqf(x2)};
+    const xd_v2f e = __builtin_elementwise_fma(-x * y, y, (xd_v2f){1.0f, 1.0f});
+    const xd_v2f r = __builtin_elementwise_fma(y * (xd_v2f){0.5f, 0.5f}, e, y);
+    r1 = r.x; r2 = r.y;
+#else
+    r1 = rsq32(x1); r2 = rsq32(x2);
+#endif
+}
+// acc0 + sum over the eight neighbours k != 4 of (n[k] - c)^2, as two interleaved partial sums (even / odd neighbours in
+// row-major order 0 1 2 3 5 6 7 8), added at the end
+XD_HD float tri_sumsq8(const float (&n)[9], float c, float acc0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const xd_v2f cc = {c, c};
+    xd_v2f a = {acc0, 0.0f};
+    xd_v2f d = (xd_v2f){n[0], n[1]} - cc; a = __builtin_elementwise_fma(d, d, a);
+    d = (xd_v2f){n[2], n[3]} - cc; a = __builtin_elementwise_fma(d, d, a);
+    d = (xd_v2f){n[5], n[6]} - cc; a = __builtin_elementwise_fma(d, d, a);
+    d = (xd_v2f){n[7], n[8]} - cc; a = __builtin_elementwise_fma(d, d, a);
+    return a.x + a.y;
+#else
+    float ax = acc0, ay = 0.0f;
+    const int ev[4] = {0, 2, 5, 7}, od[4] = {1, 3, 6, 8};
+    for (int k = 0; k < 4; ++k) {
+        const float d0 = n[ev[k]] - c, d1 = n[od[k]] - c;
+        ax = fmaf(d0, d0, ax);
+        ay = fmaf(d1, d1, ay);
+    }
+    return ax + ay;
+#endif
+}
+
 template <typename T> struct DegScale;
 template <> struct DegScale<float> { static XD_HD float v() { return 57.295776f; } };  // 180.0f / float(pi) in float arithmetic, as np.rad2deg
 template <> struct DegScale<double> { static XD_HD double v() { return 57.29577951308232; } };
@@ -294,16 +355,20 @@ template <typename TOUT> struct Planes { TOUT* p[N_ATTR]; };
 template <typename TOUT> struct DirectSink {
     typedef TOUT out_t;
     Planes<TOUT> org;
-    uint32_t o0, ostride, o, o_row = 0;
+    uint32_t o0, ostride, o;
     uint32_t sync_n = 0;  // workgroup barrier after every sync_n-th output row (a power of two; 0 = never): option "terrain_sync"
     XD_HD void begin_row(int i) {
-        // rows arrive in order (march_column): a running offset instead of i * ostride (a quarter-rate v_mad_u64_u32 per row)
-        o = (i == 0) ? o0 : o_row + ostride;
-        o_row = o;
+        // byte offset of output row i: o0 + i * ostride with the product formed on the SCALAR unit (i and ostride are
+        // wave-uniform) -- one v_add_u32 per row.  (Left to itself hipcc forms a quarter-rate v_mad_u64_u32 per row, or, for the
+        // running-offset form `i == 0 ? o0 : o + ostride`, a VOP2 v_cndmask on VCC: ~20 cycles on gfx950, tools/ubench.hip.)
 #if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t rowoff = (uint32_t)__builtin_amdgcn_readfirstlane(i) * (uint32_t)__builtin_amdgcn_readfirstlane((int)ostride);
+        o = o0 + rowoff;
         // keep `o` an opaque 32-bit VGPR: stops loop-strength-reduction from turning every plane into its own 64-bit
         // running pointer (11 VGPR pairs + one 64-bit add per store)
         asm volatile("" : "+v"(o));
+#else
+        o = o0 + (uint32_t)i * ostride;
 #endif
     }
     template <int K> XD_HD void put(TOUT v) {
@@ -353,7 +418,7 @@ template <typename TOUT> struct DirectSink {
 template <uint32_t CMASK_, int DIR_, int DEG_, int WILSON_, int ZF1_ = -1, int F64TAIL_ = 0> struct Spec {
     static constexpr uint32_t CMASK = CMASK_;
     static constexpr int DIR = DIR_, DEG = DEG_, WILSON = WILSON_, ZF1 = ZF1_;  // ZF1: hillshade z_factor == 1
-    static constexpr int F64TAIL = F64TAIL_;  // 1: float64 attribute math also for float32 in / float32 out
+    static constexpr int F64TAIL = F64TAIL_;  // float32 in / float32 out: 0 mixed tail (round 2), 1 float64 attribute math, 2 lean tail (round 3)
 };
 typedef Spec<0, -1, -1, -1, -1> SpecRuntime;
 typedef Spec<0, -1, -1, -1, -1, 1> SpecRuntimeF64;
@@ -485,9 +550,18 @@ XD_HD void surface_pixel_mixed(float zxf, float zyf, float zxxf, float zyyf, flo
     const double rg = flat ? 0.0 : rsqrt_pos(g2);                  // 1 / |grad|  (0 on flat ground: kills every x/g term)
 #endif
     const float rgf = (float)rg;
+    // the two arcsine arguments: min(sin, cos) of the slope; the smaller normalised gradient component of the aspect's octant
+    const float ax = fabsf(zxf), ay = fabsf(zyf);
+    float as_slope = 0.0f, as_aspect = 0.0f;
+    {
+        const float xs = (float)fmin((g2 * rg) * rw, rw), xa = fminf(ax, ay) * rgf;
+        if ((m & A_SLOPE) && (m & A_ASPECT)) asin32_pair(xs, xa, as_slope, as_aspect);
+        else if (m & A_SLOPE) as_slope = asin32(xs);
+        else if (m & A_ASPECT) as_aspect = asin32(xa);
+    }
     if (m & A_SLOPE) {
-        // slope = atan(g) = asin(g*rw) below 45 deg, pi/2 - asin(rw) above: the argument is min(sin, cos) of the slope
-        const float a0 = asin32((float)fmin((g2 * rg) * rw, rw));
+        // slope = atan(g) = asin(g*rw) below 45 deg, pi/2 - asin(rw) above
+        const float a0 = as_slope;
         float a = select_gt(g2, 1.0, (1.57079637f - a0) + -4.37113883e-08f, a0);   // pi/2 in two float32 pieces
         if (deg) a = a * DegScale<float>::v();
         sk.template put<P_SLOPE>(a);
@@ -496,8 +570,7 @@ XD_HD void surface_pixel_mixed(float zxf, float zyf, float zxxf, float zyyf, flo
         // aspect = atan2(zx, zy) mod 2pi = n * pi/2 +- a0 with the octant's quarter-turn count n and a0 in [0, pi/4]:
         // octants in order (sx, sy, xbig) = 000 001 011 010 110 111 101 100 -> n = 0 1 1 2 2 3 3 4, a0 subtracted in the odd
         // ones.  Sign bits and integer ops instead of compares + selects (x + 0 turns -0 into +0: "< 0" semantics).
-        const float ax = fabsf(zxf), ay = fabsf(zyf);
-        const float a0 = asin32(fminf(ax, ay) * rgf);
+        const float a0 = as_aspect;
         const uint32_t sx = f32_bits(zxf + 0.0f) >> 31, sy = f32_bits(zyf + 0.0f) >> 31;
         const uint32_t xb = f32_bits(ay - ax) >> 31;   // |zx| > |zy|
         const uint32_t q = sx ^ sy;
@@ -558,6 +631,121 @@ XD_HD void surface_pixel_mixed(float zxf, float zyf, float zxxf, float zyyf, flo
             if (m & A_MINC) sk.template put<P_MINC>((float)(flat ? 0.0 : vmin));
         }
     }
+}
+
+// ---- lean tail (round 3): float32 DEM -> float32 attributes, float64 only where terms cancel --------------------------------
+// The bar is 1e-6 TRUE relative error against the reference's float64 evaluation; the mixed tail above spends none of it on
+// eight of the eleven planes.  Here float64 is kept for exactly the quantities whose terms cancel -- the squared gradient, the
+// three curvature numerators, the discriminant of max / min curvature with its root and the two sums (+-root - h), the sun term
+// of the hillshade -- and everything that only SCALES them runs in float32: both reciprocal square roots (v_rsq_f32 + one
+// Newton step on the float32-rounded argument, ~9e-8), their powers and products, the final multiplications.  Worst-case bound
+// of a curvature: 2 eps(rg) + 3 eps(rw) + 7 float32 roundings ~ 8.7e-7; measured maxima are about half (tools/ulp_report.py).
+// v_rsq_f64 and its four float64 Newton operations cost as much as 13 float32 operations (tools/ubench.hip), and a float64
+// multiply 1.8 float32 ones: this tail is ~25 float32-operation times (8 %) shorter per pixel than the mixed one.
+// Hillshade = 1.5 + cos(slope') * S: the product nearly cancels 1.5 for almost fully shadowed pixels, where float32 factors
+// would leave an ABSOLUTE error of 3e-7 on a value near 0 -- such pixels (value below 0.3 before clipping, and not safely
+// negative) are reported back (return value) and recomputed by the float64 cold path of march_rows, like flat ground.
+// Valid for squared gradients in [1e-13, 1e16] like the mixed hot path; everything else is the cold path's.
+template <bool CURV, class SP, class SINK>
+XD_HD bool surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, float zxyf, const TerrainParams& P, SINK& sk) {
+    const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
+    const bool deg = SP::DEG < 0 ? (P.degrees != 0) : (SP::DEG != 0);
+    const bool zf_not_1 = SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0);
+    const double zx = (double)zxf, zy = (double)zyf;
+    const double zx2 = zx * zx, zy2 = zy * zy;   // exact (24-bit factors)
+    const double g2 = zx2 + zy2;
+    const float g2f = (float)g2;
+    const float opgf = 1.0f + g2f;
+    float rwf, rgf;                              // cos(slope), 1 / |grad|
+    rsq32_pair(opgf, g2f, rwf, rgf);
+    bool want_f64 = false;
+    const float ax = fabsf(zxf), ay = fabsf(zyf);
+    float as_slope = 0.0f, as_aspect = 0.0f;
+    {
+        const float xs = fminf((g2f * rgf) * rwf, rwf), xa = fminf(ax, ay) * rgf;   // min(sin, cos) of the slope; aspect octant
+        if ((m & A_SLOPE) && (m & A_ASPECT)) asin32_pair(xs, xa, as_slope, as_aspect);
+        else if (m & A_SLOPE) as_slope = asin32(xs);
+        else if (m & A_ASPECT) as_aspect = asin32(xa);
+    }
+    if (m & A_SLOPE) {
+        const float a0 = as_slope;
+#if defined(__HIP_DEVICE_COMPILE__)
+        float a;
+        {
+            uint64_t mk;
+            asm("v_cmp_gt_f32_e64 %1, %2, 1.0\n\tv_cndmask_b32_e64 %0, %4, %3, %1" : "=v"(a), "=&s"(mk) : "v"(g2f), "v"((1.57079637f - a0) + -4.37113883e-08f), "v"(a0));
+        }
+#else
+        float a = (g2f > 1.0f) ? ((1.57079637f - a0) + -4.37113883e-08f) : a0;
+#endif
+        if (deg) a = a * DegScale<float>::v();
+        sk.template put<P_SLOPE>(a);
+    }
+    if (m & A_ASPECT) {
+        // (the octant assembly of surface_pixel_mixed)
+        const float a0 = as_aspect;
+        const uint32_t sx = f32_bits(zxf + 0.0f) >> 31, sy = f32_bits(zyf + 0.0f) >> 31;
+        const uint32_t xb = f32_bits(ay - ax) >> 31;
+        const uint32_t q = sx ^ sy;
+        const uint32_t odd = q ^ xb;
+        const uint32_t oct = 4u * sx + 2u * q + odd;
+        const float nf = (float)(int)((oct + 1u) >> 1);
+        const float a0s = bits_f32(f32_bits(a0) ^ (odd << 31));
+        const float t = fmaf(nf, -4.37113883e-08f, a0s);
+        float a = fmaf(nf, 1.57079637f, t);
+        if (deg) a = a * DegScale<float>::v();
+        sk.template put<P_ASPECT>(a);
+    }
+    if (m & A_HILLSHADE) {
+        float rwz = rwf;
+        if (zf_not_1) rwz = rsq32(fmaf((float)P.hs_zf2, g2f, 1.0f));
+        const float sun = (float)fma(P.hs_ky, zy, fma(P.hs_kx, zx, P.hs_sin_alt));   // can cancel: float64
+        const float v = fmaf(rwz, sun, 1.5f);
+        want_f64 = fabsf(v - 0.15f) < 0.15001f;   // -1e-5 < v < 0.30001: the float64 cold path decides (exact zero / tiny values)
+        sk.template put<P_HILLSHADE>(clamp_keep_nan(v, 0.0f, 255.0f));
+    }
+    if (!CURV) return want_f64;
+    const double zxx = (double)zxxf, zyy = (double)zyyf, zxy = (double)zxyf;
+    if (m & A_CURVATURE) sk.template put<P_CURVATURE>((float)(-2.0 * (zxx + zyy) * 100.0));
+    if (m & (A_ANY_CURV & ~A_CURVATURE)) {
+        const bool dir = SP::DIR < 0 ? (P.curv_directional != 0) : (SP::DIR != 0);
+        const double zxzy = zx * zy;
+        const double cross = 2.0 * zxy * zxzy;
+        const double n_prof = fma(zyy, zy2, fma(zxx, zx2, cross));
+        const double n_tan = fma(zyy, zx2, fma(zxx, zy2, -cross));
+        const float rg2c = (rgf * rgf) * 100.0f;     // 100 / g2
+        const float rw2 = rwf * rwf;
+        const float ntf = (float)n_tan;
+        if (m & A_PROFILE) sk.template put<P_PROFILE>(-((float)n_prof * (dir ? rg2c : (rg2c * rwf) * rw2)));
+        if (m & A_TANGENTIAL) sk.template put<P_TANGENTIAL>(-(ntf * (dir ? rg2c : rg2c * rwf)));
+        const float rg3c = rg2c * rgf;               // 100 / g2^1.5
+        if (m & A_PLANFORM) sk.template put<P_PLANFORM>(-(ntf * rg3c));
+        if (m & A_FLOWLINE) {
+            const double n_flow = fma(zxzy, zxx - zyy, -zxy * (zx2 - zy2));
+            sk.template put<P_FLOWLINE>((float)n_flow * (dir ? rg3c : rg3c * rwf));
+        }
+        if (m & (A_MAXC | A_MINC)) {
+            float vmax, vmin;
+            if (dir) {
+                const double half_tr = 50.0 * (zxx + zyy);
+                const double hd = 50.0 * (zxx - zyy), sxy = 100.0 * zxy;
+                const double rad = sqrt_nr_signed(fma(hd, hd, sxy * sxy));
+                vmax = (float)(rad - half_tr);
+                vmin = (float)(-half_tr - rad);
+            } else {
+                // (h, the discriminant and +-root - h in float64 as in the mixed tail; only the common factor 100 / w^3 is float32)
+                const double h = 0.5 * ((zxx + zyy) + n_tan);
+                const double disc = fma(h, h, -(fma(zxx, zyy, -zxy * zxy) * (1.0 + g2)));
+                const double root = sqrt_nr_signed(disc);
+                const float rw3c = (rw2 * rwf) * 100.0f;
+                vmax = (float)(root - h) * rw3c;
+                vmin = (float)(-h - root) * rw3c;
+            }
+            if (m & A_MAXC) sk.template put<P_MAXC>(vmax);
+            if (m & A_MINC) sk.template put<P_MINC>(vmin);
+        }
+    }
+    return want_f64;
 }
 
 // TPI / TRI of a 3x3 window given as raw values (row-major n0..n8, n4 = centre).  Plain IEEE propagation.
@@ -630,13 +818,7 @@ XD_HD void window3_pixel_mixed(const float (&n)[9], double sum9, const TerrainPa
                 if (k != 4) acc += fabsf(n[k] - c);
             sk.template put<P_TRI>(acc * 0.125f);
         } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (k != 4) {
-                    const float d = n[k] - c;
-                    acc = fmaf(d, d, acc);
-                }
-            sk.template put<P_TRI>(sqrt32_hw(acc));
+            sk.template put<P_TRI>(sqrt32_hw(tri_sumsq8(n, c, acc)));
         }
     }
 }
@@ -660,7 +842,7 @@ XD_HD TIN ref_order_sum(const ROWS& rows, int top, int left, const double* w) {
 #pragma clang loop unroll(disable)
 #endif
     for (int a = 0; a < M; ++a) {
-        const TIN* win = rows.ptr(top + a) + left;
+        const auto win = rows.ptr(top + a) + left;
 #if defined(__clang__)
 #pragma clang loop unroll(disable)
 #endif
@@ -700,14 +882,18 @@ template <int FIT> struct Halo { static constexpr int v = (FIT == 2) ? 2 : 1; };
 template <typename A, typename B> struct SameT { static constexpr bool v = false; };
 template <typename A> struct SameT<A, A> { static constexpr bool v = true; };
 
+// hot-path tail; returns true if the pixel additionally wants the float64 cold path (lean tail: nearly black hillshade)
 template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct SurfaceTail {
-    static XD_HD void go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk) {
+    static XD_HD bool go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk) {
         surface_pixel<CURV, SP, SINK>((double)zx, (double)zy, (double)zxx, (double)zyy, (double)zxy, P, sk);
+        return false;
     }
 };
 template <bool CURV, class SP, class SINK> struct SurfaceTail<true, CURV, SP, float, SINK> {
-    static XD_HD void go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
+    static XD_HD bool go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
+        if (SP::F64TAIL == 2) return surface_pixel_lean<CURV, SP, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
         surface_pixel_mixed<CURV, SP, false, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
+        return false;
     }
 };
 template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct ColdTail {
@@ -757,7 +943,7 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
     typedef typename SINK::out_t TOUT;
     constexpr int HALO = Halo<FIT>::v;
     constexpr int NS = 2 * HALO + 1;  // rotating window slots
-    constexpr bool MIXED = SameT<TIN, float>::v && SameT<TOUT, float>::v && (SP::F64TAIL == 0);
+    constexpr bool MIXED = SameT<TIN, float>::v && SameT<TOUT, float>::v && (SP::F64TAIL != 1);
     const int nrows = n_out + 2 * HALO;
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
 
@@ -772,7 +958,7 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
     // the tile row of the NEXT step is fetched from LDS one step ahead, so its latency hides behind a whole row of math
     TIN nx0 = (TIN)0, nx1, nx2, nx3, nx4 = (TIN)0;
     {
-        const TIN* row0 = rows.ptr(0);
+        const auto row0 = rows.ptr(0);
         nx1 = row0[-1]; nx2 = row0[0]; nx3 = row0[1];
         if (FIT == 2) { nx0 = row0[-2]; nx4 = row0[2]; }
     }
@@ -784,7 +970,7 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                 const TIN t0 = nx0, tl = nx1, tc = nx2, tr = nx3, t4 = nx4;
                 rows.step(r);
                 {
-                    const TIN* row = rows.ptr((r + 1 < nrows) ? r + 1 : r);
+                    const auto row = rows.ptr((r + 1 < nrows) ? r + 1 : r);
                     nx1 = row[-1]; nx2 = row[0]; nx3 = row[1];
                     if (FIT == 2) { nx0 = row[-2]; nx4 = row[2]; }
                 }
@@ -848,9 +1034,10 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                             }
                         }
                     }
+                    bool tail_cold = false;
                     if (m & ~A_ANY_WIN) {
                         // hot path: every lane, straight-line (one basic block per output row)
-                        SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk);
+                        tail_cold = SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk);
                     }
                     if (WIN) {
                         const int w1 = XD_SLOT(-1), w0 = XD_SLOT(0), w2 = XD_SLOT(1);
@@ -865,7 +1052,7 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                         //  * mixed-precision tail outside its validity range: float64 tail.
                         // (An exactly cancelling SECOND derivative alone does not send a pixel here: its residue only adds ~1e-15 of
                         // the other curvature terms -- float64 rounding noise the reference's own result carries as well.)
-                        bool cold = first_derivative_zero<TIN>(zx, zy);
+                        bool cold = first_derivative_zero<TIN>(zx, zy) | tail_cold;
                         if (MIXED) cold |= mixed_tail_out_of_range((float)zx, (float)zy);
 #if defined(XD_NO_COLD)  // (instruction-count analysis builds only: tools/isa_stats.py)
                         cold = false;

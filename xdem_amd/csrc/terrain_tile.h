@@ -216,13 +216,14 @@ struct StripArgs {
 constexpr int RING_ROWS = 32, RING_PITCH = 72, RING_BLOCK = 16;
 constexpr int RING_QUADS = RING_BLOCK * RING_PITCH / 4;   // 288 float4 per block = 4.5 wave instructions
 
+typedef const __attribute__((address_space(3))) float* lds_cfloat_ptr;   // 32-bit LDS address (a generic pointer costs 64-bit adds)
 template <int NPL> struct RowsRing {
-    const float* mine;      // LDS: this lane's column in ring row 0
+    lds_cfloat_ptr mine;    // LDS: this lane's column in ring row 0
     const float* gsrc;      // global: first pixel (column x0 - 4) of tile row 0
     float* ring;            // LDS: this wave's ring
     int64_t stride;
     int nrows, lane;
-    __device__ __forceinline__ const float* ptr(int t) const { return mine + (t & (RING_ROWS - 1)) * RING_PITCH; }
+    __device__ __forceinline__ lds_cfloat_ptr ptr(int t) const { return mine + (t & (RING_ROWS - 1)) * RING_PITCH; }
     __device__ __forceinline__ void issue(int k) const {   // block k = tile rows [16 k, 16 k + 16) -> ring half k & 1
         float* dst = ring + (k & 1) * (RING_BLOCK * RING_PITCH);
 #pragma unroll
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     const int n_out = (int)((a.yi1 - y0) < BH ? (a.yi1 - y0) : BH);
     RowsRing<NPL> rows;
     rows.ring = ring + wave * (RING_ROWS * RING_PITCH);
-    rows.mine = rows.ring + 4 + lane;
+    rows.mine = (lds_cfloat_ptr)(rows.ring + 4 + lane);
     rows.gsrc = a.dem + (y0 - HALO + a.halo_top) * a.stride + (x0 - 4);
     rows.stride = a.stride;
     rows.nrows = n_out + 2 * HALO;
@@ -479,7 +480,8 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
         // curvatures, degrees, Riley TRI, z_factor 1): all attribute branches fold away -> one schedulable basic block.
         const bool defaults = L.curv_method == XDEMHIP_CURV_GEOMETRIC && L.degrees && L.tri_method == XDEMHIP_TRI_RILEY &&
                               L.hs_z == 1.0;
-        // option "terrain_math" = 1: float64 attribute math for float32 rasters too (other dtype pairs always use it)
+        // option "terrain_math" = 1: float64 attribute math for float32 rasters too (other dtype pairs always use it);
+        // 2 (default) / 0: lean / mixed tail of the specialised float32 kernels (the runtime-mask kernels keep the mixed tail)
         constexpr bool FF = SameT<TIN, float>::v && SameT<TOUT, float>::v;
         const bool f64tail = FF && ctx->terrain_math == 1;
 #ifdef XD_EXPERIMENT
@@ -487,17 +489,27 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
 #else
         constexpr bool ALLSHAPES = false;
 #endif
-        if (!f64tail) {
-            if constexpr (FF) {  // streaming route (interior by wave-autonomous strips + frame by tiles) where the raster qualifies
-                int took = 0;
-                if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY)
-                    took = launch_stream<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>>(ctx, L, mask);
-                else if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_ZEVENBERGTHORNE)
-                    took = launch_stream<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>>(ctx, L, mask);
-                else if (defaults && mask == MASK_SAH_WIN && fit == XDEMHIP_FIT_HORN)
-                    took = launch_stream<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>>(ctx, L, mask);
-                if (took != 0) return took < 0 ? took : XDEMHIP_OK;
-            }
+        if constexpr (FF) {
+            // float32 in / float32 out, specialised sets: lean tail (option "terrain_math" = 2, the default) or the mixed tail of
+            // round 2 (0); the streaming route (interior by wave-autonomous strips + frame by tiles) where the raster qualifies
+            const bool fl = defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY;
+            const bool zt = defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_ZEVENBERGTHORNE;
+            const bool hn = defaults && mask == MASK_SAH_WIN && fit == XDEMHIP_FIT_HORN;
+#define XD_SPECIALISED(LV)                                                                                                   \
+    do {                                                                                                                     \
+        int took = 0;                                                                                                        \
+        if (fl) took = launch_stream<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>>(ctx, L, mask);                        \
+        else if (zt) took = launch_stream<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>>(ctx, L, mask);                   \
+        else if (hn) took = launch_stream<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1, LV>>(ctx, L, mask);                 \
+        if (took != 0) return took < 0 ? took : XDEMHIP_OK;                                                                  \
+        if (fl) return launch_shaped<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>, TIN, TOUT, ALLSHAPES>(ctx, L, mask);  \
+        if (zt) return launch_shaped<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>, TIN, TOUT>(ctx, L, mask);             \
+        if (hn) return launch_shaped<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1, LV>, TIN, TOUT>(ctx, L, mask);           \
+    } while (0)
+            if (ctx->terrain_math == 2) XD_SPECIALISED(2);
+            else if (ctx->terrain_math == 0) XD_SPECIALISED(0);
+#undef XD_SPECIALISED
+        } else if (!f64tail) {
             if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY)
                 return launch_shaped<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT, ALLSHAPES>(ctx, L, mask);
             if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_ZEVENBERGTHORNE)
