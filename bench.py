@@ -29,6 +29,8 @@ FULL = ["slope", "aspect", "hillshade", "profile_curvature", "tangential_curvatu
         "flowline_curvature", "max_curvature", "min_curvature", "topographic_position_index",
         "terrain_ruggedness_index"]
 C4_SIZE = int(os.environ.get("XDEM_BENCH_C4_SIZE", "65536"))  # test knob: a smaller raster on shared-GPU boxes
+C3_SIZE = int(os.environ.get("XDEM_BENCH_C3_SIZE", "20000"))  # test knobs of the secondary legs (BASELINE sizes by default)
+C5_RUNS = int(os.environ.get("XDEM_BENCH_C5_RUNS", "100"))
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (about 6.3 TB/s achievable)
 BYTES_PER_PIXEL = 4 + 4 * len(FULL)  # 4 B read + 4 B per attribute written = 48 B
 
@@ -170,60 +172,22 @@ def secondary_cpu_baselines() -> dict:
     return out
 
 
-VALU_PEAK_TLANEOPS = 39.3   # MI355X: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = one wave64 VALU instruction per 4 cycles and SIMD
+# MI355X float32 vector peak: 157.3 TFLOP/s (MI355X_MICROARCH.md) = 78.6e12 fused multiply-add lane-operations per second
+# (256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz): the unit of SURVEY 8d's "12 VALU operations per pair" model.  What a wave64 stream
+# of plain float32 instructions sustains when measured (tools/ubench.hip -> profiles/r03_ubench.txt: 2.9 cycles per wave
+# instruction and SIMD at the nominal clock) is 54 T lane-ops/s; it is reported next to the spec-derived peak.
+VALU_PEAK_TLANEOPS = 78.6
+VALU_MEASURED_TLANEOPS = 54.2
 PAIR_OPS_MODEL = 12         # ~12 VALU operations per pair (2 sub, 2 fma, |dv|, <= 6 compares, 1 accumulate)
 
 
-def secondary_metrics(ctx, dev) -> dict:
-    """The other two hot paths at BASELINE.json's configurations (reported next to the headline metric, not part of
-    `value`): C5 reading B of SURVEY.md 8d for the variogram, C3 for Nuth-Kaab, each with its roofline object."""
-    import numpy as np
+def _c3_pair(dev, m: int = 20000):
+    """BASELINE C3 input: ref = fBm m^2 (seed 42); tba = ref bilinearly shifted by (+1.7, -0.6) px + 2.0 m +
+    N(0, 0.5 m) (seed 43); 20 % NaN in contiguous gaps (threshold of an independent smooth field, seed 44) applied to tba."""
     import torch
 
-    from xdem_amd import coreg
-    from xdem_amd import spatialstats as ss
     from xdem_amd.synth import fbm_torch
 
-    out = {}
-    # variogram C5-B: 1e7 sampled points = 100 runs x (9091 centre + 90910 ring points), 8.3e10 pairs, 50 lag classes.
-    # Points are PIXELS of a 20000^2 raster with gsd 1 (the reference's samplers draw raster pixels, SURVEY 8d), i.e. integer
-    # lattice coordinates: the pair kernels run their integer-lattice form.
-    rng = np.random.default_rng(45)
-    runs, samples, rings, L = 100, 9091, 10, 20000
-    blocks = []
-    for _ in range(runs):
-        ax, ay = rng.integers(0, L, samples).astype(np.float64), rng.integers(0, L, samples).astype(np.float64)
-        bx, by = rng.integers(0, L, samples * rings).astype(np.float64), rng.integers(0, L, samples * rings).astype(np.float64)
-        av = (np.sin(ax / 900.0) + 0.2 * rng.normal(size=samples)).astype(np.float32)
-        bv = (np.sin(bx / 900.0) + 0.2 * rng.normal(size=samples * rings)).astype(np.float32)
-        blocks.append((ax, ay, av, bx, by, bv))
-    edges = np.geomspace(np.sqrt(2), np.hypot(L, L), 50)
-    ps = ss.PairSet(blocks, edges, ctx)
-    ps.sums(0)
-    ps.sums(0)
-    ms = ctx.last_kernel_ms()
-    t0 = time.perf_counter()
-    ss.class_medians(ps)
-    dt = time.perf_counter() - t0
-    mat_rate = ps.n_pairs / ms / 1e6      # Gpairs/s
-    dowd_rate = ps.n_pairs / dt / 1e9
-    out["variogram"] = {"pairs": ps.n_pairs, "lag_classes": 50, "matheron_pass_Gpairs_s": round(mat_rate, 1),
-                        "dowd_exact_median_Gpairs_s": round(dowd_rate, 2),
-                        "roofline": {"bound": "valu", "model": f"{PAIR_OPS_MODEL} VALU lane-operations per pair (SURVEY 8d); bytes per pair ~ 0",
-                                     "achieved": round(PAIR_OPS_MODEL * mat_rate / 1e3, 2), "achieved_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3, 2),
-                                     "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
-                                     "frac": round(PAIR_OPS_MODEL * mat_rate / 1e3 / VALU_PEAK_TLANEOPS, 4),
-                                     "frac_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3 / VALU_PEAK_TLANEOPS, 4),
-                                     "instr_per_pair": "measured (profiles/r02_nk_vario_pmc.json, rocprofv3 --pmc): Matheron pass 14.7 vector + 4.0 LDS instructions per pair, LDS array busy for the whole kernel (two accumulator atomics per pair); Dowd counting pass 29 vector + 4.5 LDS at the time of the profile, about 24 vector since"},
-                        "note": "C5 (reading B): 100 blocks of 9091 x 90910 raster pixels (integer-lattice pair kernels), f32 values; "
-                                "Matheron = one pair pass; Dowd = exact per-class median of |dv| (bracketed selection: sampled digit "
-                                "passes, one counting + compaction pass over all pairs, exact selection among the candidates; wall time)"}
-    ps.close()
-    del blocks
-    # Nuth-Kaab C3 (SURVEY 8d): ref = fBm 20000^2 (seed 42); tba = ref bilinearly shifted by (+1.7, -0.6) px + 2.0 m + N(0, 0.5 m)
-    # (seed 43); 20 % NaN in contiguous gaps (threshold of an independent smooth field, seed 44) applied to tba;
-    # NuthKaab(max_iterations=10, offset_threshold=0, subsample=1): exactly 10 iterations on the full grid.
-    m = 20000
     ref = fbm_torch(m, m, dev, seed=42)
     fx, fy = 0.7, 0.6   # fractional parts of the (+1.7 col, -0.6 row) shift; integer parts by roll
     a = torch.roll(ref, shifts=(0, -1), dims=(0, 1))
@@ -238,41 +202,167 @@ def secondary_metrics(ctx, dev) -> dict:
     tba[hole < thr] = float("nan")
     del hole
     torch.cuda.synchronize(dev)
-    res = (10.0, 10.0)
-    plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
-    plan.step(0.0, 0.0, res, 72)
-    t0 = time.perf_counter()
-    k = 3
-    for i in range(k):
-        r = plan.step(3.0 + i, -4.0, res, 72)
-    dt = (time.perf_counter() - t0) / k
-    import scipy.optimize
+    return ref, tba
 
-    t0 = time.perf_counter()
-    offsets = coreg._iterate(plan, res, 0.0, 10, 72, scipy.optimize.curve_fit, True)
-    dt_fit = (time.perf_counter() - t0) / 10
-    plan.close()
+
+def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a: bool = False) -> dict:
+    """The other two hot paths at BASELINE.json's configurations (reported next to the headline metric, not part of
+    `value`): C5 (reading B; reading A on request) for the variogram, C3 for Nuth-Kaab, each with its roofline
+    object.  With more than one rank the pair blocks are dealt round-robin to the ranks (integer histograms / counters
+    all-reduced through the library hook, sums on the host) and the C3 pair is PARTITIONED by row block (halo rows + the
+    step's reductions over the process group); every rank runs this function, rank 0's dictionary is printed."""
+    import numpy as np
+    import torch
+
+    from xdem_amd import coreg
+    from xdem_amd import dist as xdist
+    from xdem_amd import spatialstats as ss
+    from xdem_amd.synth import c5_variogram_blocks
+
+    barrier = barrier or (lambda: torch.cuda.synchronize(dev))
+    group = "world" if world > 1 else None
+    out = {}
+
+    def variogram_leg(samples: int, label: str) -> dict:
+        # the SAME seeded blocks on every rank (fBm(H = 0.3) values on a 20000^2 grid, the product's equidistant disk / ring
+        # sampler: raster pixels = integer-lattice coordinates -> the integer-lattice pair kernels); rank r keeps blocks r::world
+        blocks, edges = c5_variogram_blocks(dev, runs=C5_RUNS, samples=samples)
+        total = sum(int(b[0].size) * int(b[3].size) for b in blocks)
+        mine = blocks[rank::world]
+        ps = ss.PairSet(mine, edges, ctx)
+        del blocks
+        try:
+            ps.sums(0)                       # warm-up (kernel load, clocks)
+            barrier()
+            t0 = time.perf_counter()
+            s_m, c_m = ps.sums(0)
+            s_m, c_m = ss._allreduce(s_m), ss._allreduce(c_m)   # (no-ops on one rank)
+            barrier()
+            dt_m = time.perf_counter() - t0
+            ms_kernel = ctx.last_kernel_ms() if world == 1 else None
+            barrier()
+            t0 = time.perf_counter()
+            med, c_d = ss.class_medians(ps, group)
+            barrier()
+            dt_d = time.perf_counter() - t0
+        finally:
+            ps.close()
+        # validation inside the run: the two routes (sum kernel / bracketed exact selection) must agree on the class membership
+        # of every pair, and no pair may be lost (every sampled pair lies below the extent diagonal = the last edge)
+        if not np.array_equal(c_m, c_d):
+            raise RuntimeError("variogram: Matheron and Dowd routes count different pairs per lag class")
+        if int(c_m.sum()) != total:
+            raise RuntimeError(f"variogram: {int(c_m.sum())} pairs inside the lags, {total} formed")
+        if not (np.all(np.isfinite(med[c_d > 0])) and np.all(s_m[c_m > 0] >= 0)):
+            raise RuntimeError("variogram: non-finite class estimate")
+        mat_rate = total / (ms_kernel * 1e-3 if ms_kernel else dt_m) / 1e9     # Gpairs/s (kernel time on one GPU, wall over ranks)
+        dowd_rate = total / dt_d / 1e9
+        return {"pairs": total, "lag_classes": int(len(edges)), "n_gpus": world,
+                "matheron_pass_Gpairs_s": round(mat_rate, 1), "dowd_exact_median_Gpairs_s": round(dowd_rate, 2),
+                "validated": "class counts of the Matheron and exact-Dowd routes identical, their sum = pairs formed",
+                "roofline": {"bound": "valu", "model": f"{PAIR_OPS_MODEL} VALU lane-operations per pair (SURVEY 8d); bytes per pair ~ 0",
+                             "achieved": round(PAIR_OPS_MODEL * mat_rate / 1e3, 2), "achieved_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3, 2),
+                             "peak": VALU_PEAK_TLANEOPS * world, "unit": "T lane-ops/s",
+                             "frac": round(PAIR_OPS_MODEL * mat_rate / 1e3 / (VALU_PEAK_TLANEOPS * world), 4),
+                             "frac_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3 / (VALU_PEAK_TLANEOPS * world), 4),
+                             "peak_source": "157.3 TFLOP/s float32 vector (MI355X_MICROARCH.md) / 2 flop per lane-op",
+                             "measured_issue_peak": VALU_MEASURED_TLANEOPS * world,
+                             "measured_issue_peak_source": "tools/ubench.hip (profiles/r03_ubench.txt): v_fma_f32 2.9 cycles per wave "
+                                                           "instruction and SIMD at the nominal 2.4 GHz",
+                             "limiter": VARIO_LIMITER_NOTE},
+                "note": label}
+
+    out["variogram"] = variogram_leg(9091, "C5 reading B (SURVEY 8d): fBm(H=0.3) values on a 20000^2 grid, 100 runs of the equidistant "
+                                            "sampler (centre disk x rings, 9091 points each; rings that leave the raster hold fewer), 50 "
+                                            "edges geomspace(sqrt 2, maxlag); Matheron = one pair pass (kernel time), Dowd = exact per-class "
+                                            "median of |dv| by bracketed selection (wall time)")
+    if c5a:
+        out["variogram_c5a"] = variogram_leg(223607, "C5 reading A (SURVEY 8d): subsample = 1e7 in the reference's sense -> 100 runs x "
+                                                     "223607-point samples, ~5e13 pairs")
+    # Nuth-Kaab C3
+    m = C3_SIZE
+    res = (10.0, 10.0)
+    ref, tba = _c3_pair(dev, m)
     px = float(m) * m
     passes = 2  # full passes over the pair per iteration: (dh + global-median counting) and (aspect-bin counting)
-    out["nuthkaab"] = {"grid": f"{m}x{m}", "valid_fraction": round(r["n_valid"] / (m * m), 3),
+    import scipy.optimize
+
+    if world == 1:
+        plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
+        plan.step(0.0, 0.0, res, 72)
+        t0 = time.perf_counter()
+        k = 3
+        for i in range(k):
+            r = plan.step(3.0 + i, -4.0, res, 72)
+        dt = (time.perf_counter() - t0) / k
+        t0 = time.perf_counter()
+        offsets = coreg._iterate(plan, res, 0.0, 10, 72, scipy.optimize.curve_fit, True)
+        dt_fit = (time.perf_counter() - t0) / 10
+        n_valid = r["n_valid"]
+        plan.close()
+        how = "one GPU"
+    else:
+        r0, r1 = xdist.row_block(m, world, rank)
+        ref_rows, tba_rows = ref[r0:r1].contiguous(), tba[r0:r1].contiguous()
+        del ref, tba
+        torch.cuda.empty_cache()
+        xdist.nuth_kaab_row_blocks(ref_rows, tba_rows, m, res, halo=8, ctx=ctx, tolerance=0.0, max_iterations=2)   # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        offsets, n_valid = xdist.nuth_kaab_row_blocks(ref_rows, tba_rows, m, res, halo=8, ctx=ctx, tolerance=0.0, max_iterations=10)
+        barrier()
+        dt_fit = (time.perf_counter() - t0) / 10
+        dt = dt_fit
+        how = f"row blocks of {world} ranks + halo rows, every reduction of a step through the process group"
+    # validation inside the run: the fit must find the shift the pair was built with
+    sx, sy, sz = -offsets[0] / res[0], -offsets[1] / res[1], offsets[2]
+    if not (abs(sx - 1.7) < 0.05 and abs(sy - 0.6) < 0.05 and abs(sz + 2.0) < 0.05):
+        raise RuntimeError(f"Nuth-Kaab: fitted shift ({sx:.3f}, {sy:.3f}, {sz:.3f}) px / m is not the (1.7, 0.6, -2.0) the pair was built with")
+    out["nuthkaab"] = {"grid": f"{m}x{m}", "n_gpus": world, "partition": how, "valid_fraction": round(n_valid / (m * m), 3),
                        "Mpixel_iterations_s": round(px / dt / 1e6, 1), "ms_per_iteration": round(dt * 1e3, 2),
                        "ms_per_iteration_whole_fit": round(dt_fit * 1e3, 2),
-                       "fitted_shift_px": [round(-offsets[0] / res[0], 3), round(-offsets[1] / res[1], 3), round(offsets[2], 3)],
+                       "fitted_shift_px": [round(sx, 3), round(sy, 3), round(sz, 3)],
+                       "validated": "the 10-iteration fit recovers the (+1.7, +0.6) px, -2.0 m shift the pair was built with",
                        "roofline": {"bound": "hbm", "model": "SURVEY 8d: 8 B/pixel (ref + tba) per data pass x P passes required by the exact "
                                              "medians; P = 2 here (bracketed selections: one counting pass each for the global median and "
                                              "the 72 aspect bins; plain radix passes would need 12)",
-                                    "passes": passes, "achieved": round(8 * passes * px / dt / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                    "frac": round(8 * passes * px / dt / 1e9 / HBM_PEAK_GBPS, 4),
-                                    "touched_bytes_per_pixel": 27,
-                                    "touched_GBps": round(27 * px / dt / 1e9, 1),
-                                    "note": "the two passes actually touch 27 B/pixel (dh pass: ref 4 + tba 4 + aspect 4 + mask 1 + dh out 4; "
-                                            "bin pass: dh 4 + slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not "
-                                            "recomputed; kernel times alone: dh pass ~1.35 ms (5.0 TB/s), bin pass ~0.97 ms (4.1 TB/s), "
-                                            "the rest of a step is ~45 small launches of the five exact selections"},
+                                    "passes": passes, "achieved": round(8 * passes * px / dt / 1e9, 1), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                                    "frac": round(8 * passes * px / dt / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                                    "touched_bytes_per_pixel": NK_TOUCHED_BYTES,
+                                    "touched_GBps": round(NK_TOUCHED_BYTES * px / dt / 1e9, 1),
+                                    "note": NK_TOUCHED_NOTE},
                        "note": "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32); "
-                               "ms_per_iteration = grid work of a step (host 72-point fit excluded), ms_per_iteration_whole_fit = "
-                               "NuthKaab's 10-iteration loop incl. scipy curve_fit, per iteration"}
+                               "ms_per_iteration = grid work of a step (host 72-point fit excluded; with more than one rank: the whole fit "
+                               "per iteration), ms_per_iteration_whole_fit = NuthKaab's 10-iteration loop incl. scipy curve_fit, per iteration"}
     return out
+
+
+VARIO_LIMITER_NOTE = ("measured (profiles/r02_nk_vario_pmc.json, rocprofv3 --pmc): Matheron pass 14.7 vector + 4.0 LDS instructions per pair, "
+                      "LDS array busy for the whole kernel (two accumulator atomics per pair): the LDS array, not the VALU, is the limiter")
+NK_TOUCHED_BYTES = 27
+NK_TOUCHED_NOTE = ("the two passes actually touch 27 B/pixel (dh pass: ref 4 + tba 4 + aspect 4 + mask 1 + dh out 4; bin pass: dh 4 + "
+                   "slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not recomputed")
+
+
+def end_to_end_host_path(ctx, n: int = 16384) -> dict:
+    """SURVEY 8d "separate end-to-end number including H2D/D2H": BASELINE C2 (16384^2 float32, 11 attributes) through the call
+    users make -- get_terrain_attribute(ndarray) -> list of ndarrays -- host buffers in and out, PCIe both ways."""
+    import numpy as np
+
+    from xdem_amd import terrain
+    from xdem_amd.synth import fbm_numpy
+
+    tile = fbm_numpy((4096, 4096), seed=42)
+    dem = np.tile(tile, (n // 4096, n // 4096)) + np.linspace(0, 50, n, dtype=np.float32)[None, :]
+    terrain.get_terrain_attribute(dem[:1024], FULL, resolution=10.0)   # warm-up: library load, pinned staging buffers
+    t0 = time.perf_counter()
+    out = terrain.get_terrain_attribute(dem, FULL, resolution=10.0)
+    dt = time.perf_counter() - t0
+    ok = all(o.shape == dem.shape for o in out)
+    gb = (4 + 4 * len(FULL)) * float(n) * n / 1e9
+    return {"workload": f"C2: {n}x{n} float32 DEM, 11 attributes, NumPy arrays in and out (H2D + kernel + D2H)", "seconds": round(dt, 3),
+            "Mpixels_s": round(float(n) * n / dt / 1e6, 1), "effective_GBps_over_PCIe": round(gb / dt, 1), "shapes_ok": bool(ok),
+            "note": "never the reported `value` (that is device-resident); PCIe Gen5 x16 = 63 GB/s per direction"}
 
 
 def main() -> None:
@@ -284,6 +374,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the small variogram / Nuth-Kaab side measurements")
     ap.add_argument("--no-overlap", action="store_true", help="wait for the halo before launching anything")
+    ap.add_argument("--c5a", action="store_true", help="also run the variogram at C5 reading A (5e13 pairs: about two minutes)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (PCIe-inclusive) C2 figure")
     args = ap.parse_args()
 
     import torch
@@ -338,27 +430,27 @@ def main() -> None:
         for _ in range(warmup):
             step()
         barrier()
+        # HIP events around every step ON THE LAUNCH STREAM (the library launches on torch's current stream here), recorded
+        # inside the timed region and read after it: the same launches under both clocks
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for a_, b_ in ev:
+            a_.record()
             step()
+            b_.record()
         barrier()
         t = torch.tensor([time.perf_counter() - t0], device="cpu" if share else dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), block, out
+        step_ms = [a_.elapsed_time(b_) for a_, b_ in ev]
+        return float(t.item()), block, out, sum(step_ms) / len(step_ms)
 
     n = args.size
-    elapsed, block, out = partitioned_run(n, args.steps, args.warmup)
+    elapsed, block, out, kernel_ms = partitioned_run(n, args.steps, args.warmup)
 
-    # Kernel-only duration for the roofline: HIP events recorded by the library on the launch stream around the
-    # kernel (xdemhip_last_kernel_ms), averaged over fresh launches of the dominant (interior / whole-block) kernel.
-    from xdem_amd.terrain import terrain_attributes_device
-
-    kms = []
-    for _ in range(max(3, min(args.steps, 10))):
-        terrain_attributes_device(block.buf, FULL, out=out, halo_top=block.halo_top, halo_bottom=block.halo_bottom, **kw)
-        kms.append(ctx.last_kernel_ms())
-    kernel_ms = sum(kms) / len(kms)
+    # Kernel duration for the roofline: the mean of the HIP-event times of the K timed steps themselves (events recorded on the
+    # launch stream around each step; one step = the streaming kernel over the raster interior + the tile kernel over its frame
+    # of edge tiles, plus the halo exchange when the raster is partitioned).  By construction kernel_ms <= ms_per_step.
     px_launch = block.rows * n
     achieved = BYTES_PER_PIXEL * px_launch / (kernel_ms * 1e-3) / 1e9
 
@@ -369,7 +461,7 @@ def main() -> None:
         del out, block
         torch.cuda.empty_cache()
         c4_steps = max(2, min(args.steps, 5))
-        c4_elapsed, block, out = partitioned_run(C4_SIZE, c4_steps, max(1, min(args.warmup, 2)))
+        c4_elapsed, block, out, _ = partitioned_run(C4_SIZE, c4_steps, max(1, min(args.warmup, 2)))
         c4 = {"workload": f"C4: {C4_SIZE}x{C4_SIZE} float32 fBm DEM, 11 attributes, {world} row blocks, halo depth {depth}, "
                           + ("shared-GPU gloo test mode" if share else "RCCL send/recv over xGMI"),
               "value": round(float(C4_SIZE) ** 2 * c4_steps / c4_elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
@@ -379,7 +471,7 @@ def main() -> None:
         total_px = float(n) * n
         res = {
             "metric": f"Mpixels/s full terrain-attribute set, {n}\u00b2 f32 DEM; variogram Gpairs/s"
-                      + ("" if (world == 1 and not args.no_secondary) else " (this line: terrain half only)"),
+                      + ("" if not args.no_secondary else " (this line: terrain half only)"),
             "value": round(total_px * args.steps / elapsed / 1e6, 1),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -389,7 +481,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32 in/out, mixed f64/f32 arithmetic (f64 where cancellation demands: stencil sums, curvature numerators, discriminants)",
             "data": "synthetic",
             "config": {"workload": f"{n}x{n} float32 fBm DEM (H=0.7, 1000+-300 m, res 10 m), Florinsky fit, geometric "
                                    f"curvatures, 11 attributes, device-resident in/out",
@@ -406,22 +498,33 @@ def main() -> None:
                                             f"profiles/{t[1]}: rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE), "
                                             "a committed profile, not re-measured in this run")(
                              measured_traffic_bytes(px_launch) if world == 1 else None),
-                         "kernel": "terrain_tile_kernel<Florinsky,curv,win,f32,f32>",
+                         "kernel": "terrain_strip_kernel<Florinsky,curv,win,lean tail> (raster interior, 98.6 % of the pixels) + "
+                                   "terrain_tile_kernel (frame of edge tiles)",
+                         "kernel_ms_source": "mean HIP-event time of the timed steps themselves (events on the launch stream)",
                          "kernel_ms": round(kernel_ms, 4), "pixels_per_launch": px_launch},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
         if c4 is not None:
             res["secondary"] = {"c4_terrain_row_blocks": c4}
-        if not args.no_secondary and world == 1:
+    sec = None
+    if not args.no_secondary:   # every rank runs the secondary legs (they shard over the ranks); rank 0 reports
+        try:
+            del out, block
+            torch.cuda.empty_cache()
+            sec = secondary_metrics(ctx, dev, rank, world, barrier, c5a=args.c5a)
+        except Exception as e:  # the headline line must still be printed
+            sec = {"error": repr(e)}
+    if rank == 0:
+        if sec is not None:
+            res.setdefault("secondary", {}).update(sec)
+            if not args.no_cpu_baseline and world == 1 and "error" not in sec:
+                res["secondary"]["cpu_baseline"] = secondary_cpu_baselines()
+        if world == 1 and not args.no_end_to_end and not args.no_secondary:
             try:
-                del out, block
-                torch.cuda.empty_cache()
-                res["secondary"] = secondary_metrics(ctx, dev)
-                if not args.no_cpu_baseline:
-                    res["secondary"]["cpu_baseline"] = secondary_cpu_baselines()
-            except Exception as e:  # the headline line must still be printed
-                res["secondary"] = {"error": repr(e)}
+                res["end_to_end"] = end_to_end_host_path(ctx)
+            except Exception as e:
+                res["end_to_end"] = {"error": repr(e)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

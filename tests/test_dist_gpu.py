@@ -296,7 +296,8 @@ def test_bench_two_ranks_reports_c4(tmp_path):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, XDEM_BENCH_SHARE_GPU="1", XDEM_BENCH_C4_SIZE="4096", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, XDEM_BENCH_SHARE_GPU="1", XDEM_BENCH_C4_SIZE="4096", XDEM_BENCH_C3_SIZE="3000", XDEM_BENCH_C5_RUNS="6",
+               MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "3000"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
@@ -307,3 +308,9 @@ def test_bench_two_ranks_reports_c4(tmp_path):
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "strong" and res["value"] > 0
     c4 = res["secondary"]["c4_terrain_row_blocks"]
     assert c4["n_gpus"] == 2 and c4["value"] > 0 and "4096x4096" in c4["workload"]
+    # the other two paths report with more than one rank too: pair blocks dealt to the ranks (histograms / counters all-reduced),
+    # the Nuth-Kaab pair partitioned by row block -- both validated inside bench.py (equal class counts; recovered shift)
+    assert "error" not in res["secondary"], res["secondary"]
+    v, nk = res["secondary"]["variogram"], res["secondary"]["nuthkaab"]
+    assert v["n_gpus"] == 2 and v["matheron_pass_Gpairs_s"] > 0 and v["dowd_exact_median_Gpairs_s"] > 0 and "validated" in v
+    assert nk["n_gpus"] == 2 and "row blocks of 2 ranks" in nk["partition"] and abs(nk["fitted_shift_px"][0] - 1.7) < 0.05

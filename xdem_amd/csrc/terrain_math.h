@@ -919,6 +919,21 @@ template <class SP, class SINK> struct WindowTail<true, SP, float, SINK> {
     }
 };
 
+// hillshade of one pixel in float64 (the formula of surface_pixel_mixed): the lean tail's fix-up for nearly black pixels
+template <class SP, typename TIN, class SINK> struct HillshadeF64 {
+    static XD_HD void go(TIN, TIN, const TerrainParams&, SINK&) {}
+};
+template <class SP, class SINK> struct HillshadeF64<SP, float, SINK> {
+    static XD_HD void go(float zxf, float zyf, const TerrainParams& P, SINK& sk) {
+        const bool zf_not_1 = SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0);
+        const double zx = (double)zxf, zy = (double)zyf;
+        const double g2 = zx * zx + zy * zy;
+        const double rwz = rsqrt_pos(zf_not_1 ? fma(P.hs_zf2, g2, 1.0) : 1.0 + g2);
+        const float v = (float)fma_c(rwz, fma(P.hs_ky, zy, fma(P.hs_kx, zx, P.hs_sin_alt)), 1.5);
+        sk.template put<P_HILLSHADE>(clamp_keep_nan(v, 0.0f, 255.0f));
+    }
+};
+
 // Row addressers: where tile row t of this lane's column lives.  RowsLinear: a row-major tile (`col` = the lane's column in
 // tile row 0).  The streaming kernel of terrain_tile.h supplies a per-wave ring refilled by LDS-DMA; `step(r)` is its hook
 // at the start of march step r (before the step's read of tile row r + 1).
@@ -1052,8 +1067,19 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                         //  * mixed-precision tail outside its validity range: float64 tail.
                         // (An exactly cancelling SECOND derivative alone does not send a pixel here: its residue only adds ~1e-15 of
                         // the other curvature terms -- float64 rounding noise the reference's own result carries as well.)
-                        bool cold = first_derivative_zero<TIN>(zx, zy) | tail_cold;
+                        bool cold = first_derivative_zero<TIN>(zx, zy);
                         if (MIXED) cold |= mixed_tail_out_of_range((float)zx, (float)zy);
+                        // lean tail: a nearly black hillshade is the only plane its float32 factors cannot carry -- that one plane is
+                        // recomputed in float64 (its own wave-uniform branch: ~3 % of the wave rows of steep terrain come here,
+                        // the full cold tail below would cost them ten times as much)
+                        if (MIXED && SP::F64TAIL == 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                            if (__builtin_expect(__builtin_amdgcn_ballot_w64(tail_cold) != 0, 0))
+#endif
+                            {
+                                if (tail_cold && !cold) HillshadeF64<SP, TIN, SINK>::go(zx, zy, P, sk);
+                            }
+                        }
 #if defined(XD_NO_COLD)  // (instruction-count analysis builds only: tools/isa_stats.py)
                         cold = false;
 #endif

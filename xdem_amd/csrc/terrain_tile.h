@@ -226,14 +226,17 @@ template <int NPL> struct RowsRing {
     __device__ __forceinline__ lds_cfloat_ptr ptr(int t) const { return mine + (t & (RING_ROWS - 1)) * RING_PITCH; }
     __device__ __forceinline__ void issue(int k) const {   // block k = tile rows [16 k, 16 k + 16) -> ring half k & 1
         float* dst = ring + (k & 1) * (RING_BLOCK * RING_PITCH);
+        // block base on the scalar unit, per-lane element offsets in 24-bit multiplies (stride < 2^24: launch_stream checks)
+        const float* base = gsrc + (int64_t)(RING_BLOCK * k) * stride;
+        const int last = nrows - 1 - RING_BLOCK * k;   // (rows past the band's last: duplicates of it, never read)
 #pragma unroll
         for (int i = 0; i < (RING_QUADS + 63) / 64; ++i) {
             const int t = 64 * i + lane;
-            const int r = t / (RING_PITCH / 4), q = t - r * (RING_PITCH / 4);
-            int row = RING_BLOCK * k + r;
-            row = row < nrows ? row : nrows - 1;   // (rows past the band's last: duplicates of it, never read)
+            int r = t / (RING_PITCH / 4);
+            const int q = t - r * (RING_PITCH / 4);
+            r = r < last ? r : last;
             if (t < RING_QUADS)
-                __builtin_amdgcn_global_load_lds(gsrc + (int64_t)row * stride + 4 * q,
+                __builtin_amdgcn_global_load_lds(base + (__umul24((uint32_t)r, (uint32_t)stride) + 4u * (uint32_t)q),
                                                  (__attribute__((address_space(3))) void*)(dst + 64 * i * 4), 16, 0, 0);
         }
     }
@@ -432,6 +435,7 @@ static int launch_stream(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
     constexpr int TH = 32;
     if (ctx->terrain_stream == 0 || ctx->terrain_store == 1 || ctx->terrain_rows != 0) return 0;
     if ((reinterpret_cast<uintptr_t>(L.dem) & 15) || (L.row_stride & 3)) return 0;   // 16-byte quads of the LDS-DMA
+    if (L.row_stride >= ((int64_t)1 << 24) - 64) return 0;                               // 24-bit row offsets inside a block
     FrameRect fr;
     fr.tx0 = 1;
     fr.tx1 = (int)((L.W - 4) / TILE_W);
