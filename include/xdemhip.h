@@ -218,6 +218,16 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
                           int64_t* counts, double* medians);
 
+/* "Next" row f4: the dense step of the patches method -- mean_filter_nan(img, kernel_size, kernel_shape)
+ * (xdem/spatialstats.py:2597-2655: two scipy.ndimage.convolve calls with a ones / circular uint8 kernel, mode="constant",
+ * cval=nan).  kernel_shape 0 = square, 1 = circular (_create_circular_mask, spatialstats.py:880-904).  Outputs are float64
+ * (H, W) like the reference's: mean of the finite pixels under the kernel and their number; a window with a kernel pixel
+ * outside the raster gives (NaN, 0) as SciPy's NaN border value does.  *n_kernel_px = np.count_nonzero(kernel).  Kernels of
+ * more than 127 pixels (kernel_size > 11 square, > 13 circular) return XDEMHIP_EUNSUPPORTED: the reference counts in int8,
+ * which wraps there. */
+int xdemhip_mean_filter_nan(xdemhip_ctx* ctx, const void* img, int dtype, int64_t H, int64_t W, int kernel_size, int kernel_shape,
+                            double* mean_out, double* nvalid_out, int* n_kernel_px, int memspace);
+
 /* "Next" row f1: the step right after a Nuth-Kaab fit -- resampling the translated DEM back onto
  * its own grid, i.e. _reproject_horizontal_shift_samecrs(raster_arr, src_transform, dst_transform)
  * (xdem/coreg/base.py:1615-1655) as used by Coreg.apply for pure translations:

@@ -235,7 +235,7 @@ def terrain_T10() -> None:
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["terrain", "nk", "vario", "binning"]
+    which = sys.argv[1:] or ["terrain", "nk", "vario", "binning", "patches"]
     if "terrain" in which:
         _check_tables()
         terrain_T1()
@@ -257,3 +257,7 @@ if __name__ == "__main__":
         import gen_golden_binning
 
         gen_golden_binning.main(ref, OUT)
+    if "patches" in which:
+        import gen_golden_patches
+
+        gen_golden_patches.main(ref, OUT)

@@ -77,6 +77,8 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_nk_destroy.restype = None
         L.xdemhip_binned_median.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                             c_dp, c_i64p, c_dp]
+        L.xdemhip_mean_filter_nan.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
         L.xdemhip_shift_bilinear.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                              ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]

@@ -18,7 +18,7 @@ import ctypes
 import logging
 import warnings
 from collections.abc import Iterable
-from typing import Any
+from typing import Any, Callable
 
 import numpy as np
 
@@ -1322,3 +1322,196 @@ def spatial_error_propagation(areas, errors, params_variogram_model, **kwargs: A
             average_spread = np.nanmean(arr)
         standard_errors.append(average_spread / np.sqrt(neff))
     return standard_errors
+
+
+# ======================================================================================================================
+# Patches method: mirror of xdem/spatialstats.py:2597-3048 over csrc/meanfilter.hip
+# ======================================================================================================================
+def mean_filter_nan(img: np.ndarray, kernel_size: int, kernel_shape: str = "circular", method: str = "scipy",
+                    ctx: _lib.Context | None = None) -> tuple[np.ndarray, np.ndarray, int]:
+    """Mean filter with a square or circular kernel that ignores NaNs; drop-in for ``xdem.spatialstats.mean_filter_nan``
+    (2597-2655).  Returns (mean image, number of valid pixels per window, number of pixels in the kernel), the two images
+    float64 like upstream's.  Runs the HIP kernel (``xdemhip_mean_filter_nan``), which reproduces the two
+    ``scipy.ndimage.convolve(..., mode="constant", cval=nan)`` calls bit for bit: windows that leave the raster give
+    (NaN, 0).  ``method`` ("scipy" / "numba" upstream) only names upstream's CPU engines and is accepted for signature
+    compatibility.  Kernels of more than 127 pixels (``kernel_size`` > 11 square, > 13 circular) raise
+    ``NotImplementedError``: upstream counts the valid pixels in an int8 image, which wraps beyond 127 (a 12 x 12 square
+    reports -112 valid pixels) -- there is no meaningful result to reproduce."""
+    if kernel_shape.lower() not in ("square", "circular"):
+        raise ValueError('Kernel shape should be "square" or "circular".')
+    if method.lower() != "scipy" and "numba" not in method.lower():
+        raise ValueError('Method must be "scipy" or "numba".')
+    arr = np.ascontiguousarray(img)
+    if arr.ndim != 2:
+        raise ValueError("img must be a 2D array")
+    if arr.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        arr = arr.astype(np.float64 if arr.dtype.itemsize > 4 else np.float32)
+    ctx = ctx or _lib.default_context()
+    mean = np.empty(arr.shape, dtype=np.float64)
+    nvalid = np.empty(arr.shape, dtype=np.float64)
+    npx = ctypes.c_int()
+    rc = ctx._L.xdemhip_mean_filter_nan(ctx.handle, arr.ctypes.data, _lib.F32 if arr.dtype == np.float32 else _lib.F64, arr.shape[0],
+                                        arr.shape[1], int(kernel_size), 0 if kernel_shape.lower() == "square" else 1,
+                                        mean.ctypes.data, nvalid.ctypes.data, ctypes.byref(npx), _lib.HOST)
+    if rc == -5:   # XDEMHIP_EUNSUPPORTED
+        raise NotImplementedError(
+            f"mean_filter_nan: a {kernel_shape} kernel of size {kernel_size} holds {npx.value if npx.value <= 127 else 'more than 127'} "
+            "pixels; the reference counts valid pixels in an int8 image, which wraps beyond 127 pixels "
+            "(xdem/spatialstats.py:2637-2646) -- such kernels are refused instead of reproducing the wrap-around."
+        )
+    ctx.check(rc)
+    return mean, nvalid, int(npx.value)
+
+
+def _patches_convolution(values: np.ndarray, gsd: float, area: float, perc_min_valid: float = 80.0, patch_shape: str = "circular",
+                         method: str = "scipy", statistic_between_patches: Callable[[np.ndarray], Any] = nmad,
+                         return_in_patch_statistics: bool = False):
+    """Vectorized patches method: every pixel is the centre of a patch (``mean_filter_nan``), the statistic between patches is
+    averaged over the kernel_size^2 sets of non-overlapping patches (xdem/spatialstats.py:2658-2741)."""
+    import pandas as pd
+
+    if patch_shape.lower() == "circular":
+        kernel_size = int(np.round(2 * np.sqrt(area / np.pi) / gsd, decimals=0))   # the diameter
+    elif patch_shape.lower() == "square":
+        kernel_size = int(np.round(np.sqrt(area) / gsd, decimals=0))               # the side
+    else:
+        raise ValueError('Kernel shape should be "square" or "circular".')
+    logging.info("Computing the convolution on the entire array...")
+    mean_img, nb_valid_img, nb_pixel_per_kernel = mean_filter_nan(img=values, kernel_size=kernel_size, kernel_shape=patch_shape, method=method)
+    mean_img[nb_valid_img < nb_pixel_per_kernel * perc_min_valid / 100.0] = np.nan
+    logging.info("Computing statistic between patches for all independent combinations...")
+    stats, nbs = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)   # all-NaN subsets (upstream lets NumPy warn)
+        for i in range(kernel_size):
+            for j in range(kernel_size):
+                sub = mean_img[i::kernel_size, j::kernel_size]
+                stats.append(statistic_between_patches(sub.ravel()))
+                nbs.append(np.count_nonzero(np.isfinite(sub)))
+        average_statistic = float(np.nanmean(np.asarray(stats)))
+        nb_independent_patches = float(np.nanmean(np.asarray(nbs)))
+    exact_area = nb_pixel_per_kernel * gsd**2
+    if return_in_patch_statistics:
+        df = pd.DataFrame(data={"nanmean": mean_img[::kernel_size, ::kernel_size].ravel(),
+                                "count": nb_valid_img[::kernel_size, ::kernel_size].ravel()})
+        return average_statistic, nb_independent_patches, exact_area, df
+    return average_statistic, nb_independent_patches, exact_area
+
+
+def _patches_loop_quadrants(values: np.ndarray, gsd: float, area: float, patch_shape: str = "circular", n_patches: int = 1000,
+                            perc_min_valid: float = 80.0, statistics_in_patch=(np.nanmean,),
+                            statistic_between_patches: Callable[[np.ndarray], Any] = nmad, random_state=None,
+                            return_in_patch_statistics: bool = False):
+    """Patches method by random quadrants (xdem/spatialstats.py:2744-2879): host-side sampling of at most `n_patches` patches, any
+    in-patch statistics (a few thousand small patches: not a dense array step, no kernel involved).  Upstream's bookkeeping is
+    kept as it is -- for square patches "the exact number of pixels" is the number of quadrants, so square patches only ever
+    qualify when kernel_size^2 happens to equal it."""
+    import pandas as pd
+
+    stats_in = list(statistics_in_patch) + ["count"]
+    names = [f if isinstance(f, str) else f.__name__ for f in stats_in]
+    rng = np.random.default_rng(random_state)
+    nx, ny = np.shape(values)
+    kernel_size = int(np.round(np.sqrt(area) / gsd, decimals=0))
+    nx_sub, ny_sub = int(np.floor((nx - 1) / kernel_size)), int(np.floor((ny - 1) / kernel_size))
+    rad = int(np.round(np.sqrt(area / np.pi) / gsd, decimals=0))
+    if patch_shape.lower() == "square":
+        nb_pixel_exact = nx_sub * ny_sub
+    elif patch_shape.lower() == "circular":
+        nb_pixel_exact = np.count_nonzero(_create_circular_mask(shape=(nx, ny), radius=rad))
+    else:
+        raise ValueError("Patch method must be square or circular.")
+    exact_area = nb_pixel_exact * gsd**2
+    quadrants = [[i, j] for i in range(nx_sub) for j in range(ny_sub)]
+    u, remaining = 0, n_patches
+    rows = []
+    while len(quadrants) > 0 and u < n_patches:
+        drawn = rng.choice(len(quadrants), size=min(len(quadrants), 10 * remaining))
+        for iq in drawn:
+            i, j = quadrants[iq]
+            if patch_shape.lower() == "square":
+                patch = values[kernel_size * i : kernel_size * (i + 1), kernel_size * j : kernel_size * (j + 1)].flatten()
+            else:
+                center = (np.floor(kernel_size * (i + 1 / 2)), np.floor(kernel_size * (j + 1 / 2)))
+                patch = values[_create_circular_mask((nx, ny), center=center, radius=rad)]
+            nb_total = len(patch)
+            valid = patch[np.isfinite(patch)]
+            if len(valid) >= np.ceil(perc_min_valid / 100.0 * nb_total) and nb_total == nb_pixel_exact:
+                u += 1
+                if u > n_patches:
+                    break
+                row = {"tile": f"{i}_{j}"}
+                for name, stat in zip(names, stats_in):
+                    if isinstance(stat, str):
+                        if stat != "count":
+                            raise ValueError('No other string than "count" are supported for named statistics.')
+                        row[stat] = len(valid)
+                    else:
+                        row[name] = stat(valid.astype("float64"))
+                rows.append(row)
+        remaining = n_patches - u
+        taken = {int(q) for q in drawn}
+        quadrants = [c for q, c in enumerate(quadrants) if q not in taken]
+    if rows:
+        df_all = pd.DataFrame(rows)
+        average_statistic = float(statistic_between_patches(df_all[names[0]].values))
+        nb_independent_patches = np.count_nonzero(np.isfinite(df_all[names[0]].values))
+    else:
+        df_all = pd.DataFrame({name: [np.nan] for name in names})
+        average_statistic, nb_independent_patches = np.nan, 0
+        warnings.warn("No valid patch found covering this area size, returning NaN for statistic.")
+    if return_in_patch_statistics:
+        return average_statistic, nb_independent_patches, exact_area, df_all
+    return average_statistic, nb_independent_patches, exact_area
+
+
+def patches_method(values, areas: list[float], gsd: float = None, stable_mask=None, unstable_mask=None,
+                   statistics_in_patch=(np.nanmean,), statistic_between_patches: Callable[[np.ndarray], Any] = nmad,
+                   perc_min_valid: float = 80.0, patch_shape: str = "circular", vectorized: bool = True,
+                   convolution_method: str = "scipy", n_patches: int = 1000, return_in_patch_statistics: bool = False,
+                   random_state=None):
+    """Monte-Carlo patches method: empirical standard error of the mean over patches of given areas; drop-in for
+    ``xdem.spatialstats.patches_method`` (2928-3048) for arrays (or Raster-like objects with ``.data`` / ``.res``) and boolean
+    array masks (vector masks need the I/O stack, which is out of scope).  ``vectorized=True`` runs the mean filter on the GPU
+    for every pixel at once; ``False`` samples quadrants on the host."""
+    import pandas as pd
+
+    if hasattr(values, "res") and hasattr(values, "data"):
+        gsd = values.res[0] if gsd is None else gsd
+        values = values.data
+    if not isinstance(values, np.ndarray):
+        raise ValueError("The values must be a Raster or NumPy array, or a list of those.")
+    for m_ in (stable_mask, unstable_mask):
+        if m_ is not None and not isinstance(m_, np.ndarray):
+            raise NotImplementedError("stable / unstable masks must be boolean arrays here (vector masks need rasterisation: out of scope)")
+    if gsd is None:
+        raise ValueError("The ground sampling distance must be provided if no Raster object is passed.")
+    if isinstance(values, np.ma.MaskedArray):
+        arr = np.array(values.data, dtype=values.dtype if np.issubdtype(values.dtype, np.floating) else np.float32, copy=True)
+        arr[np.ma.getmaskarray(values)] = np.nan
+    else:
+        arr = np.array(values, dtype=values.dtype if np.issubdtype(values.dtype, np.floating) else np.float32, copy=True)
+    include = np.ones(arr.shape, dtype=bool) if stable_mask is None else np.asarray(stable_mask, dtype=bool).reshape(arr.shape)
+    exclude = np.zeros(arr.shape, dtype=bool) if unstable_mask is None else np.asarray(unstable_mask, dtype=bool).reshape(arr.shape)
+    arr[~(include & ~exclude)] = np.nan      # masked terrain -> NaN, shape preserved (spatialstats.py:737-760)
+    list_stats, list_nb, list_exact, list_df = [], [], [], []
+    for area in areas:
+        if vectorized:
+            outputs = _patches_convolution(arr, gsd, area, perc_min_valid, patch_shape, convolution_method, statistic_between_patches,
+                                           return_in_patch_statistics)
+        else:
+            outputs = _patches_loop_quadrants(arr, gsd, area, patch_shape, n_patches, perc_min_valid, statistics_in_patch,
+                                              statistic_between_patches, random_state, return_in_patch_statistics)
+        list_stats.append(outputs[0])
+        list_nb.append(outputs[1])
+        list_exact.append(outputs[2])
+        if return_in_patch_statistics:
+            df = outputs[3]
+            df["areas"] = area
+            df["exact_areas"] = outputs[2]
+            list_df.append(df)
+    df_statistic = pd.DataFrame(data={statistic_between_patches.__name__: list_stats, "nb_indep_patches": list_nb,
+                                      "exact_areas": list_exact, "areas": areas})
+    if return_in_patch_statistics:
+        return df_statistic, pd.concat(list_df)
+    return df_statistic
