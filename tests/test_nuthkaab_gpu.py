@@ -578,7 +578,7 @@ def test_advice_round2_contracts(coreg):
 
     import scipy.optimize
 
-    ref, tba, inlier, res = _pair((90, 100))
+    ref, tba, inlier, res = _pair((140, 150))
     plan = coreg.NKPlan(ref, tba, inlier)
     plan.set_bin_edges(np.array([0.5, 1.0, 2.0, 4.0]))
     L, dp, ip = plan.ctx._L, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
@@ -605,7 +605,7 @@ def test_advice_round2_contracts(coreg):
         created = True
     try:
         with pytest.raises(ValueError, match="block arrays hold"):
-            coreg.NKPlan(ref[:50], tba[:50], inlier[:50], group="world", block=(90, 0, 60, 0, 2))
+            coreg.NKPlan(ref[:50], tba[:50], inlier[:50], group="world", block=(140, 0, 60, 0, 2))
         assert getattr(coreg._lib.default_context(), "_hook", None) is None
         ok = coreg.NKPlan(ref, tba, inlier)     # a plain single-process plan still steps (no collective entered)
         assert ok.step(0.0, 0.0, (res, res), 72)["n_valid"] > 0

@@ -85,17 +85,21 @@ def test_patches_method_public_entry(ss):
     vals = rng.normal(0, 2, (300, 360)).astype(np.float32)
     unstable = np.zeros(vals.shape, dtype=bool)
     unstable[100:180, 50:200] = True
-    df = ss.patches_method(vals, gsd=10.0, areas=[10000, 20000], unstable_mask=unstable, vectorized=True, convolution_method="scipy")
+    gsd = 20.0   # (the reference's test runs on a 20 m DEM: areas of 10000 / 20000 m^2 = circular kernels of 6 / 8 pixels across)
+    df = ss.patches_method(vals, gsd=gsd, areas=[10000, 20000], unstable_mask=unstable, vectorized=True, convolution_method="scipy")
     assert df.shape == (2, 4) and list(df.columns) == ["nmad", "nb_indep_patches", "exact_areas", "areas"]
     assert df["exact_areas"][0] == pytest.approx(df["areas"][0], rel=0.2)
     assert df["nmad"][0] > df["nmad"][1] > 0            # the standard error of the mean falls with the patch area
-    assert abs(df["nmad"][0] - 2.0 / np.sqrt(81)) < 0.1  # white noise: sigma / sqrt(pixels per patch) (circular 11: 81 px)
-    df2, full = ss.patches_method(vals, gsd=10.0, areas=[10000], unstable_mask=unstable, vectorized=False, n_patches=7, random_state=42,
+    npx = int(po.kernel_of(6, "circular").sum())
+    assert df["exact_areas"][0] == npx * gsd**2 and abs(df["nmad"][0] - 2.0 / np.sqrt(npx)) < 0.1   # white noise: sigma / sqrt(pixels)
+    df2, full = ss.patches_method(vals, gsd=gsd, areas=[10000], unstable_mask=unstable, vectorized=False, n_patches=7, random_state=42,
                                   return_in_patch_statistics=True)
     assert df2.shape == (1, 4) and df2["nb_indep_patches"][0] == 7 and full.shape == (7, 5)
     assert all(full["count"].values > 0.8 * np.max(full["count"].values))
+    with pytest.raises(NotImplementedError, match="int8"):
+        ss.patches_method(vals, gsd=10.0, areas=[20000])   # a 16-pixel circle: 197 pixels, beyond the reference's int8 count
     # masked terrain never enters a patch mean: filling it with garbage changes nothing
     vals2 = vals.copy()
     vals2[unstable] = 1e6
-    dfb = ss.patches_method(vals2, gsd=10.0, areas=[10000, 20000], unstable_mask=unstable)
+    dfb = ss.patches_method(vals2, gsd=gsd, areas=[10000, 20000], unstable_mask=unstable)
     assert np.array_equal(dfb.values, df.values)

@@ -68,10 +68,13 @@ enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3, SE
 __host__ __device__ inline uint64_t sel_bracket_halfwidth(uint64_t m) {
     return (uint64_t)(3.0 * sqrt(8.0 * (double)m)) + 32;
 }
-// Same for samples of point PAIRS (variogram.hip): the sampled units are (1024 A points) x (256 B points) tiles whose pairs
-// share points, so the effective sample size is taken 64 times smaller than the pair count.
+// Same for samples of point PAIRS (variogram.hip).  The sample is a 1/64 subsample of the B points against ALL A points of a block
+// (variogram.hip: unit_sample_slot): pairs that share a point are strongly dependent (values of a spatially correlated field:
+// |v_a - v_b| moves with v_b for all ~9000 A points at once), so the effective sample size is about the number of distinct
+// sampled B points in the class, not the number of pairs -- taken as m / 4096 (measured on SURVEY 8d's C5 input: a class of
+// 8.5e7 sampled pairs behaves like ~2e4 independent draws).
 __host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m) {
-    return (uint64_t)(3.0 * sqrt(64.0 * (double)m)) + 64;
+    return (uint64_t)(3.0 * sqrt(4096.0 * (double)m)) + 64;
 }
 
 template <typename K>

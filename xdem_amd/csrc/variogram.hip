@@ -22,6 +22,10 @@
 
 #include <vector>
 
+#include <stdio.h>
+#include <time.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "select.h"
 #include "select_run.h"
@@ -74,8 +78,13 @@ template <typename T> struct PairArgs {
     long long cand_cap;
 };
 
-__device__ __forceinline__ bool unit_sampled(int64_t wg, int tile) {
-    return (((uint64_t)(wg * 16 + tile) * 0x9E3779B97F4A7C15ull) >> 58) == 0;
+// Sampled digit passes (bracketed selection): EVERY (A tile x B tile) unit contributes the pairs of 4 of its 256 B slots -- slots
+// [4 h, 4 h + 4), h hashed from the unit -- i.e. exactly 1/64 of its pairs.  (Round 2 sampled whole units with probability
+// 1/64: for values of a spatially correlated field the class distributions differ from block to block, the number of sampled
+// units per block was binomial (3 +- 1.7), and the mixture weights -- hence the sample medians -- were too noisy for any
+// affordable bracket.  With every unit represented the sample is a 1/64 subsample of the B POINTS against all A points.)
+__device__ __forceinline__ int unit_sample_slot(int64_t wg, int tile) {
+    return (int)(((uint64_t)(wg * 16 + tile) * 0x9E3779B97F4A7C15ull) >> 58);   // 0 .. 63
 }
 
 template <typename K> __device__ __forceinline__ void lds_min(K* p, K v);
@@ -117,13 +126,6 @@ template <typename T, int OP, bool FAST, int NT, bool GRID = false>
 // kernels do not fit that budget without spilling)
 __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pairs_kernel(const PairArgs<T> a) {
     typedef typename KeyT<T>::type K;
-    // sampled digit passes: a workgroup none of whose (up to 16) B tiles is in the sample leaves before touching LDS (4 of 5 do;
-    // otherwise zeroing and flushing their 51 KB histograms would dominate the pass)
-    if (OP == OP_HIST && a.sample) {
-        bool any = false;
-        for (int t = 0; t < BCHUNK / PT; ++t) any |= unit_sampled(a.wg_base + blockIdx.x, t);
-        if (!any) return;
-    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_bx = reinterpret_cast<double*>(smem);
     double* s_by = s_bx + PT;
@@ -241,6 +243,25 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     T pend_v = (T)0;
     uint32_t pend_l = 0;
     unsigned long long pend_m = 0;  // lanes with a pending candidate (wave-uniform scalar)
+    // Candidates that find the staging buffer full go straight to the global candidate buffer, one global atomic per wave and
+    // call.  (Values of a spatially correlated field cluster: all 262144 pairs of a tile -- 1024 neighbouring A points x 256 B
+    // points -- can fall into a class's bracket at once, far more than the 8192 staging slots a tile may fill; round 2's "flag
+    // an overflow and redo everything with plain passes" made the C5 input of SURVEY 8d five times slower than uniform noise.)
+    auto spill = [&](bool mine, T v, uint32_t l) {   // every lane of the wave calls this
+        const unsigned long long ov = __builtin_amdgcn_ballot_w64(mine);
+        if (!ov) return;
+        const int lane = tid & 63;
+        const int leader = __ffsll((long long)ov) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&a.cand_ctr[0], (unsigned long long)__popcll(ov));
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+               (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (mine) {
+            const unsigned long long pos = base + (unsigned long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(ov >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ov, 0u));
+            if ((long long)pos < a.cand_cap) { a.cand_v[pos] = v; a.cand_b[pos] = (uint16_t)l; }
+            else a.cand_ctr[1] = 1ull;
+        }
+    };
     auto flush_pending = [&]() {
         const unsigned long long m = pend_m;
         if (m) {  // (wave-uniform)
@@ -249,17 +270,18 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
             int pos0 = 0;
             if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(m));
             pos0 = __builtin_amdgcn_readlane(pos0, leader);
-            if ((m >> lane) & 1ull) {
-                const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (pos < SEL_STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
-                else a.cand_ctr[1] = 1ull;
-            }
+            const bool has = (m >> lane) & 1ull;
+            const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (has && pos < SEL_STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
+            if (__builtin_expect(pos0 + __popcll(m) > SEL_STAGE_CAP, 0)) spill(has && pos >= SEL_STAGE_CAP, pend_v, pend_l);   // (wave-uniform test)
             pend_m = 0;
         }
     };
     if (!skip_wg)
         for (int64_t j0 = jb0; j0 < jb1; j0 += PT) {
-            if (OP == OP_HIST && a.sample && !unit_sampled(wg, (int)((j0 - jb0) / PT))) continue;  // (uniform over the workgroup)
+            // sampled pass: only slots [jbeg, jend) of this tile (uniform over the workgroup)
+            const bool sampled = OP == OP_HIST && a.sample;
+            const int jslot = sampled ? 4 * unit_sample_slot(wg, (int)((j0 - jb0) / PT)) : 0;
             if (OP == OP_BRACKET)  // (starts with the barrier the tile reload needs); flush the staged candidates when half full
                 stage.sync_and_flush_at(SEL_STAGE_CAP / 2, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
             else
@@ -271,7 +293,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 s_bv[tid] = gbv[b0 + j0 + tid];
             }
             __syncthreads();
-            if (!have_a) continue;
+            if (!have_a && OP != OP_BRACKET) continue;   // (OP_BRACKET: every thread stays for the mid-tile flush barriers)
             // OP_BRACKET, one pair: counters + staged candidate (every lane of the wave must reach the append)
             auto bracket_pair = [&](bool ok, int l, T d) {
                 bool cand = false;
@@ -283,7 +305,18 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     cand = !below && key <= s_khi[l];
                     atomicAdd(&s_c3[((below ? 0 : (cand ? 1 : 2)) * (nb + 1) + l) * NCOPY + cp], 1u);
                 }
-                stage.append_bounded(cand, d, (uint16_t)l, &a.cand_ctr[1]);
+                {   // staged append (one LDS reservation per wave); what does not fit the staging buffer spills to global memory
+                    const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
+                    if (cm) {
+                        const int lane = tid & 63, leader = __ffsll((long long)cm) - 1;
+                        int pos0 = 0;
+                        if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(cm));
+                        pos0 = __builtin_amdgcn_readlane(pos0, leader);
+                        const int pos = pos0 + __popcll(cm & ((1ull << lane) - 1ull));
+                        if (cand && pos < SEL_STAGE_CAP) { stage.v[pos] = d; stage.b[pos] = (uint16_t)l; }
+                        if (pos0 + __popcll(cm) > SEL_STAGE_CAP) spill(cand && pos >= SEL_STAGE_CAP, d, (uint32_t)l);
+                    }
+                }
             };
             // One pair: class lookup + accumulate.  `ok` folds every skip rule so the fast path stays branch-free
             // up to the (exec-masked) LDS atomics.
@@ -376,7 +409,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 // threshold reads are each issued back to back (one LDS round trip per stage instead of per pair).
                 // Tile slots beyond cnt hold stale data and are masked by `ok`.
                 const int64_t rel = ia - j0;  // pdist: only B indices j > rel pair with this lane's A point
-                const int ia_rel = a.pdist ? (int)(rel < -1 ? -1 : (rel > PT ? PT : rel)) : -1;
+                // (a thread without an A point -- last A tile of a block -- pairs with nothing: every slot masked)
+                const int ia_rel = !have_a ? PT : (a.pdist ? (int)(rel < -1 ? -1 : (rel > PT ? PT : rel)) : -1);
                 // Full tiles (the bulk of the pairs): every slot is a pair -- no index, diagonal, class or NaN test and no
                 // exec masking; the class beyond the last edge lands in the spare record.
                 const bool plain_tile = (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && cnt == PT && !a.has_nan &&
@@ -396,7 +430,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 }
                 auto run4 = [&](auto plain_tag) {
                     constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
-                    for (int j = 0; j < cnt; j += 4) {
+                    const int jend = sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt;
+                    for (int j = jslot; j < jend; j += 4) {
                         int lus[4];
                         T dv[4];
                         classify4(j, lus, dv);
@@ -431,11 +466,13 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                                                       __umul24(plane, c3_plane)), 1u);
                                 const unsigned long long clash = in_m & pend_m;
                                 if (__builtin_expect(clash != 0, 0)) {  // (wave-uniform, rare: a second candidate within 8 pairs)
-                                    if ((clash >> (tid & 63)) & 1ull) {
-                                        const int pos = atomicAdd(stage.held, 1);
+                                    const bool mine = (clash >> (tid & 63)) & 1ull;
+                                    int pos = 0;
+                                    if (mine) {
+                                        pos = atomicAdd(stage.held, 1);
                                         if (pos < SEL_STAGE_CAP) { stage.v[pos] = dv[u]; stage.b[pos] = (uint16_t)lc[u]; }
-                                        else a.cand_ctr[1] = 1ull;
                                     }
+                                    spill(mine && pos >= SEL_STAGE_CAP, dv[u], (uint32_t)lc[u]);
                                 }
                                 const unsigned long long take = in_m & ~pend_m;
                                 pend_v = select_by_mask(pend_v, dv[u], take);
@@ -443,6 +480,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 pend_m |= take;
                             }
                             if ((j & 4) != 0) flush_pending();  // every second stage = 8 pairs
+                            // every 64 B slots (65536 pairs of the workgroup) the staged candidates leave if the buffer is a quarter full:
+                            // the brackets of spatially correlated values hold a few per cent of the pairs, a whole tile's worth
+                            // would not fit (j and cnt are uniform over the workgroup: every thread meets this barrier)
+                            if ((j & 63) == 60 && j + 4 < jend)
+                                stage.sync_and_flush_at(SEL_STAGE_CAP / 4, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
                             continue;
                         }
     #pragma unroll
@@ -471,11 +513,13 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                         }
                     }
                 };
-                if (cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT)) run4(std::true_type());
+                // (PLAIN needs every thread of the workgroup to hold an A point: uniform, the mid-tile barriers sit inside run4)
+                if (cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT) && (ta + 1) * (int64_t)NT <= na) run4(std::true_type());
                 else run4(std::false_type());
                 if (OP == OP_BRACKET) flush_pending();  // (a tile's pair count need not be a multiple of 8)
             } else {
-                for (int j = 0; j < cnt; ++j) pair(j, !a.pdist || (j0 + j) > ia);
+                const int jend = sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt;
+                for (int j = jslot; j < jend; ++j) pair(j, have_a && (!a.pdist || (j0 + j) > ia));
             }
         }
     __syncthreads();
@@ -1044,6 +1088,10 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         if (scratch) (void)hipFree(scratch);
         (void)hipFree(d_small);
     };
+    const bool dbg = getenv("XDEMHIP_DEBUG") != nullptr;
+    auto now_ms = [&]() { (void)hipStreamSynchronize(ctx->stream); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t_phase = dbg ? now_ms() : 0.0;
+    auto phase = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "[xdemhip] pair medians: %-28s %8.2f ms\n", what, t - t_phase); t_phase = t; } };
     bool bracket = ctx->selection_mode != 1 && nb <= HIST_BINS_PER_SWEEP && P->n_pairs >= PAIRS_BRACKET_MIN && P->n_wg_big >= 256;
     if (bracket && hipMalloc(&scratch, scratch_size(nb)) != hipSuccess) bracket = false;
     if (ctx->allreduce) {  // sharded pair sets: every rank must take the same route
@@ -1054,6 +1102,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     int rc = XDEMHIP_OK;
     bool done = false;
     std::vector<K> klo(nb), khi(nb);
+    std::vector<uint64_t> lo_count(nb, 0);
     if (bracket) {
         std::vector<SelState<K>> lo, hi;
         constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough
@@ -1061,9 +1110,11 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo, BR_PASSES);
         if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi, BR_PASSES);
         if (rc) { cleanup(); return rc; }
+        phase("sampled digit passes");
         double expected = 0.0;  // candidates the brackets should hold: 64 x their width in sample ranks, at most the class
         for (int k = 0; k < nb; ++k) {
             const bool have = lo[k].count > 0;
+            lo_count[k] = lo[k].count;
             klo[k] = have ? lo[k].prefix : (K)0;
             khi[k] = have ? (K)(hi[k].prefix | low_mask) : (K)~(K)0;
             if (ctx->selection_mode == 2 && have) khi[k] = klo[k];  // test mode: brackets that (almost surely) miss
@@ -1094,6 +1145,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
             }
         }
     }
+    phase("candidate buffers");
     if (bracket) {
         K* d_klo = reinterpret_cast<K*>(d_small + off_klo);
         K* d_khi = reinterpret_cast<K*>(d_small + off_khi);
@@ -1134,6 +1186,8 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         if (e == hipSuccess) e = hipMemcpyAsync(ctr, P->cand_ctr, 16, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, std::string("bracket pass failed: ") + hipGetErrorString(e)); }
+        phase("counting + compaction pass");
+        if (dbg) fprintf(stderr, "[xdemhip] pair medians: %llu candidates (%.2f %% of the pairs)\n", (unsigned long long)ctr[0], 100.0 * (double)ctr[0] / (double)P->n_pairs);
         bool ok = ctr[1] == 0;
         std::vector<uint64_t> given(nb);
         for (int k = 0; k < nb; ++k) cnt[k] += cnt[nb + k];  // class total = (keys >= low end) + (keys below it)
@@ -1143,9 +1197,16 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
             if (total == 0) continue;
             const uint64_t r = (total - 1) / 2;
             const uint64_t need = (total & 1) ? r : r + 1;
-            if (lt > r || need - lt >= in) ok = false;
-            else given[k] = r - lt;
+            if (lt > r || need - lt >= in) {
+                ok = false;
+                if (getenv("XDEMHIP_DEBUG"))
+                    fprintf(stderr, "[xdemhip] pair medians: bracket of class %d missed (total %llu, below %llu, inside %llu, rank %llu, sample %llu)\n",
+                            k, (unsigned long long)total, (unsigned long long)lt, (unsigned long long)in, (unsigned long long)r,
+                            (unsigned long long)lo_count[k]);
+            } else given[k] = r - lt;
         }
+        if (!ok && getenv("XDEMHIP_DEBUG")) fprintf(stderr, "[xdemhip] pair medians: candidate overflow flag %llu, candidates %llu of %lld\n",
+                                                   (unsigned long long)ctr[1], (unsigned long long)ctr[0], (long long)P->cand_cap);
         if (ok) {
             e = hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket ranks upload failed"); }
@@ -1154,6 +1215,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
                                    static_cast<unsigned char*>(scratch), SEL_GIVEN, d_given, 0, true, d_klo, d_rbs);
             if (rc == XDEMHIP_OK) rc = select_fetch<T>(ctx, static_cast<unsigned char*>(scratch), nb, res);
             if (rc) { cleanup(); return rc; }
+            phase("selection among candidates");
             for (int k = 0; k < nb; ++k) {
                 counts[k] = (int64_t)cnt[k];
                 if (cnt[k] == 0) { medians[k] = NAN; continue; }
@@ -1166,8 +1228,9 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
             done = true;
         }
     }
-    if (!done) rc = pairs_medians_plain<T>(P, d_st, counts, medians);
+    if (!done) { rc = pairs_medians_plain<T>(P, d_st, counts, medians); phase("plain digit passes"); }
     cleanup();
+    phase("cleanup");
     return rc;
 }
 
