@@ -705,3 +705,46 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule):
     finally:
         ctx.set_option("nk_nan_rule", 0)
         ctx.set_option("selection", 0)
+
+
+def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
+    """Round 3: the dh pass of large single-GPU plans takes min / max aspect from lists of extreme-aspect pixels and reads a
+    masked copy of the reference DEM instead of mask + aspect (option "nk_ext", default on).  (i) Steps of both routes are
+    identical field by field; (ii) when every listed pixel loses its dh -- here: the only rows whose aspects reach the ends of
+    [0, 2 pi) have no tba -- the step notices, repeats on the route that reads the aspect, and stays identical."""
+    from xdem_amd.synth import fbm_numpy
+
+    ctx = coreg._lib.default_context()
+    H, W, res = 2200, 2048, 10.0
+    rng = np.random.default_rng(23)
+    base = fbm_numpy((H, W), seed=9, std=120.0)
+    # bottom half tilted steeply towards one side: its aspects stay away from 0 / 2 pi, the extremes all come from the top half
+    tilt = np.zeros((H, W), dtype=np.float32)
+    tilt[H // 2:] = (np.arange(W, dtype=np.float32) * 80.0)[None, :]
+    ref = (base + tilt).astype(np.float32)
+    tba_full = (np.roll(ref, (1, -1), (0, 1)) + rng.normal(0, 0.2, (H, W)).astype(np.float32) + 0.7).astype(np.float32)
+    tba_full[rng.uniform(size=(H, W)) < 0.02] = np.nan
+    tba_bottom = tba_full.copy()
+    tba_bottom[: H // 2 + 8] = np.nan      # no dh in the top half: every listed extreme-aspect pixel dies
+    keys = ("vshift", "n_valid", "y_mean", "y_std")
+    for name, tba in (("full", tba_full), ("bottom only", tba_bottom)):
+        got = {}
+        for ext in (1, 0):
+            ctx.set_option("nk_ext", ext)
+            try:
+                plan = coreg.NKPlan(ref, tba, None)
+                got[ext] = [plan.step(sx, sy, (res, res), 72) for sx, sy in ((0.0, 0.0), (7.3, -12.1), (7.3, -12.1))]
+                plan.close()
+            finally:
+                ctx.set_option("nk_ext", 1)
+        for a, b in zip(got[1], got[0]):
+            assert all(a[k] == b[k] for k in keys), name
+            assert np.array_equal(a["edges"], b["edges"]) and np.array_equal(a["counts"], b["counts"]), name
+            assert np.array_equal(a["medians"], b["medians"], equal_nan=True), name
+        if name == "bottom only":
+            asp = coreg.NKPlan(ref, tba, None)
+            a_ = asp.aux()[1]
+            asp.close()
+            # the premise of (ii): the surviving half does not reach the aspect extremes the full raster has
+            assert np.nanmin(a_[H // 2 + 10:]) > np.nanmin(a_[: H // 2]) and np.nanmax(a_[H // 2 + 10:]) < np.nanmax(a_[: H // 2])
+            assert got[1][0]["edges"][0] > float(np.nanmin(a_[: H // 2]))

@@ -105,6 +105,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->terrain_rows = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "nk_ext") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_ext: 0 or 1");
+        ctx->nk_ext = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "terrain_stream") {
         if (value != 0 && value != 1 && value != 2 && value != 3 && value != 128 && value != 256 && value != 512) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_stream: 0, 1, 128, 256 or 512");
         ctx->terrain_stream = value;

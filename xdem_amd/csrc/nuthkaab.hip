@@ -317,6 +317,85 @@ __global__ __launch_bounds__(256) void nk_dh_count_kernel(const T* __restrict__ 
     }
 }
 
+// ---- min / max aspect without reading the aspect raster every step (round 3) -----------------------------------------------
+// The dh pass needs min / max of the aspect over the pixels whose dh is finite (SciPy's bin edges) -- two numbers, each set by
+// ONE pixel -- and used to read the 4-byte aspect of every pixel for them.  At plan creation the valid pixels whose aspect lies
+// in the lowest / highest ~16 K of the raster are listed (EXT lists); a step evaluates dh at those few pixels only: the minimum
+// over the listed pixels with a finite dh IS the minimum over all of them as long as one listed pixel survives (every unlisted
+// pixel has a larger aspect); if none survives, or a list came out empty / overfull, the step falls back to the kernel that
+// reads the aspect (flag bit 2 -> the step's second attempt).  The same kernel folds the valid mask into a plan-owned copy of
+// the reference DEM (NaN where a pixel is not valid): dh = ref - bilinear(tba) is then non-finite by itself and the dh pass
+// reads neither the mask nor the aspect: 12 instead of 17 B/pixel.
+constexpr int EXT_TARGET = 16384, EXT_CAP = 4 * EXT_TARGET;
+template <typename T>
+__global__ __launch_bounds__(256) void nk_ext_build_kernel(const T* __restrict__ ref, const uint8_t* __restrict__ valid,
+                                                           const T* __restrict__ aspect, int64_t q0, int64_t n, T thr_lo, T thr_hi,
+                                                           T* __restrict__ ref_m, int64_t* __restrict__ ext_idx,
+                                                           unsigned long long* __restrict__ ext_cnt /* [2] */) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = base + threadIdx.x;
+        bool lo = false, hi = false;
+        if (p < n) {
+            const int64_t q = q0 + p;
+            const bool v = valid[q] != 0;
+            ref_m[q] = v ? ref[q] : (T)NAN;
+            const T a = aspect[q];
+            lo = v && a < thr_lo;
+            hi = v && a > thr_hi;
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const bool mine = w ? hi : lo;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned long long b = 0;
+                if (lane == leader) b = atomicAdd(&ext_cnt[w], (unsigned long long)__popcll(m));
+                b = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), leader) << 32) |
+                    (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+                const unsigned long long pos = b + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                if (mine && pos < (unsigned long long)EXT_CAP) ext_idx[(int64_t)w * EXT_CAP + (int64_t)pos] = q0 + p;
+            }
+        }
+    }
+}
+// one thread per listed pixel: is its dh finite at this step's shift?  -> min / max aspect keys, survivors per list
+template <typename T>
+__global__ __launch_bounds__(256) void nk_ext_eval_kernel(const T* __restrict__ ref_m, const T* __restrict__ tba, const T* __restrict__ aspect,
+                                                          NkGeom g, const int64_t* __restrict__ ext_idx, const unsigned long long* __restrict__ ext_cnt,
+                                                          DhStats* stats, unsigned long long* survivors /* [2] */) {
+    typedef typename KeyT<T>::type K;
+    const int w = blockIdx.y;
+    const unsigned long long cnt = ext_cnt[w] < (unsigned long long)EXT_CAP ? ext_cnt[w] : (unsigned long long)EXT_CAP;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    K key = 0;
+    if ((unsigned long long)k < cnt) {
+        const int64_t q = ext_idx[(int64_t)w * EXT_CAP + k];
+        const int64_t li = q / g.W, j = q - li * g.W;
+        const BiTap t = bi_locate(g, li + g.roff, j);
+        const BiVals<T> tv = bi_load<T>(tba, t);
+        T val;
+        const bool in = bi_value<T>(g, tba, t, tv.a00, tv.a01, tv.a10, tv.a11, val);
+        const T out = t_sub(ref_m[q], val);
+        ok = in && t_finite(out);
+        key = key_of(aspect[q]);
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+    if (!m) return;
+    K best = ok ? key : (w ? (K)0 : ~(K)0);
+    for (int off = 32; off > 0; off >>= 1) {
+        const K o = k_shfl_down(best, off);
+        best = w ? (o > best ? o : best) : (o < best ? o : best);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (w) k_atomic_max(&stats->asp_max, (uint64_t)best);
+        else k_atomic_min(&stats->asp_min, (uint64_t)best);
+        atomicAdd(&survivors[w], (unsigned long long)__popcll(m));
+    }
+}
+
 // ---- the lean form of the pass above for NaN rules 0 and 1 (rule 2 reads a 3 x 3 neighbourhood per pixel and keeps the generic
 // kernel).  Measured on MI355X the generic kernel is VALU-bound (about 166 vector instructions per row of 64 pixels: per-row tap
 // geometry recomputed by every lane, four float64 lerps, 64-bit addressing), not HBM-bound.  Here
@@ -331,7 +410,7 @@ constexpr int NK_CHUNK_MAX = 512;
 constexpr int NK_PF = 4;
 constexpr int NKL_ROWS = 4;      // rows between two looks at the staging buffer
 constexpr int NKL_CAP = 4096;    // staging slots per workgroup (flushed once fewer than 2 x NKL_ROWS rows would still fit)
-template <typename T, int RULE>
+template <typename T, int RULE, bool EXT = false>   // EXT: `ref` is the masked copy (NaN where not valid), no mask / aspect reads
 __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
                                                                const uint8_t* __restrict__ valid, const T* __restrict__ aspect,
                                                                NkGeom g, T* __restrict__ dh, DhStats* stats, int64_t row0, int64_t row1,
@@ -407,8 +486,9 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
         const int64_t rb = rb0 + (int64_t)rc * g.W;
         // (streaming hints: every input of this pass is read once per step)
         q.b0 = __builtin_nontemporal_load(rowp + c0); q.b1 = __builtin_nontemporal_load(rowp + c1);
-        q.rv = __builtin_nontemporal_load(ref + rb + jl); q.av = __builtin_nontemporal_load(aspect + rb + jl);
-        q.vd = __builtin_nontemporal_load(valid + rb + jl);
+        q.rv = __builtin_nontemporal_load(ref + rb + jl);
+        if (!EXT) { q.av = __builtin_nontemporal_load(aspect + rb + jl); q.vd = __builtin_nontemporal_load(valid + rb + jl); }
+        else { q.av = (T)0; q.vd = 1; }
     };
 #pragma unroll
     for (int u = 0; u < NK_PF; ++u) issue(u, pre[u]);
@@ -443,8 +523,10 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
                 const bool cand = ok & (key >= klo) & (key <= khi);
                 out = ok ? out : (T)NAN;
                 if (jin) __builtin_nontemporal_store(out, dh + rb + jl);
-                fmin_a = fmin(fmin_a, ok ? av : (T)INFINITY);
-                fmax_a = fmax(fmax_a, ok ? av : -(T)INFINITY);
+                if (!EXT) {
+                    fmin_a = fmin(fmin_a, ok ? av : (T)INFINITY);
+                    fmax_a = fmax(fmax_a, ok ? av : -(T)INFINITY);
+                }
                 n_all += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
                 n_below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(below));
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
@@ -483,8 +565,8 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
             mx = s_red[w][1] > mx ? s_red[w][1] : mx;
             c0 += s_red[w][2]; c1 += s_red[w][3]; c2 += s_red[w][4];
         }
-        if (mn != ~(uint64_t)0) k_atomic_min(&stats->asp_min, mn);
-        if (mx != 0) k_atomic_max(&stats->asp_max, mx);
+        if (!EXT && mn != ~(uint64_t)0) k_atomic_min(&stats->asp_min, mn);
+        if (!EXT && mx != 0) k_atomic_max(&stats->asp_max, mx);
         if (c0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), (unsigned long long)c0);
         if (c1) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[1]), (unsigned long long)c1);
         if (c2) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[2]), (unsigned long long)c2);
@@ -840,6 +922,10 @@ struct xdemhip_nk_plan {
     uint16_t* bins = nullptr;
     uint16_t* bcache = nullptr;   // aspect-bin cache (NkYSource), one id per buffer pixel
     bool bcache_force = true;     // the cache does not hold the bins of the current own rows / edges: refill at the next step
+    void* ref_m = nullptr;        // reference DEM with NaN where a pixel is not valid (EXT route of the dh pass)
+    int64_t* ext_idx = nullptr;   // [2][EXT_CAP] pixels with the lowest / highest aspects
+    unsigned long long* ext_cnt = nullptr;  // [0..1] list lengths, [2..3] survivors of the current step
+    bool ext_ok = false;
     void* scratch = nullptr;  // edges, stats, sums, selection states, successor keys, histograms
     size_t scratch_bytes = 0;
     int max_bins = 0;
@@ -900,6 +986,23 @@ template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
     { const int rc_ = xd_d2h(ctx, &c, d_cnt, 8); if (rc_) return rc_; }
     { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
     P->n_valid0 = (long long)c;
+    // EXT route (see nk_ext_build_kernel): single-GPU plans only -- with a reduction hook every rank would have to agree on
+    // the route at every step; the sharded plans keep reading mask and aspect
+    P->ext_ok = false;
+    if (P->ref_m && !ctx->allreduce && rows > 0 && P->n_valid0 >= 8 * (long long)EXT_TARGET) {
+        const double frac = (double)EXT_TARGET / (double)P->n_valid0;
+        const T thr_lo = (T)(6.283185307179586 * frac), thr_hi = (T)(6.283185307179586 * (1.0 - frac));
+        const int64_t q0 = (P->row0 - P->roff) * P->W, nown = rows * P->W;
+        XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt, 0, 32, ctx->stream));
+        hipLaunchKernelGGL((nk_ext_build_kernel<T>), dim3(grid_for(ctx, nown, 256, 16)), dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),
+                           P->valid, static_cast<const T*>(P->aspect), q0, nown, thr_lo, thr_hi, static_cast<T*>(P->ref_m), P->ext_idx, P->ext_cnt);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+        unsigned long long ec[2] = {0, 0};
+        { const int rc_ = xd_d2h(ctx, ec, P->ext_cnt, 16); if (rc_) return rc_; }
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+        // (aspects far from uniform -- a tilted plane, a raster of one slope direction -- leave a list empty or overfull)
+        P->ext_ok = ec[0] >= 1 && ec[0] <= (unsigned long long)EXT_CAP && ec[1] >= 1 && ec[1] <= (unsigned long long)EXT_CAP;
+    }
     return XDEMHIP_OK;
 }
 
@@ -909,7 +1012,8 @@ template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
 template <typename T>
 __global__ void nk_vshift_edges_kernel(const uint64_t* cnt /* total, below, inside */, const SelState<typename KeyT<T>::type>* st,
                                        const uint64_t* succ, const typename KeyT<T>::type* klo, const uint32_t* rbs_p,
-                                       const unsigned long long* flags, const DhStats* stats, int nb, unsigned char* info, T* edges) {
+                                       const unsigned long long* flags, const DhStats* stats, int nb, unsigned char* info, T* edges,
+                                       const unsigned long long* ext_survivors = nullptr) {
     typedef typename KeyT<T>::type K;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint64_t total = cnt[0], lt = cnt[1];
@@ -929,7 +1033,9 @@ __global__ void nk_vshift_edges_kernel(const uint64_t* cnt /* total, below, insi
     }
     *reinterpret_cast<T*>(info) = vs;
     *reinterpret_cast<uint64_t*>(info + 8) = total;
-    *reinterpret_cast<uint64_t*>(info + 16) = (uint64_t)((flags[2] != 0) | ((flags[3] != 0) << 1));
+    // bit 2: EXT route and no listed pixel of a list kept a finite dh (with finite dh at all): min / max aspect unknown
+    const bool ext_miss = ext_survivors && total && (ext_survivors[0] == 0 || ext_survivors[1] == 0);
+    *reinterpret_cast<uint64_t*>(info + 16) = (uint64_t)((flags[2] != 0) | ((flags[3] != 0) << 1) | ((ext_miss ? 1 : 0) << 2));
     *reinterpret_cast<double*>(info + 24) = (double)vs;
     make_edges_into<T>((double)val_of((K)stats->asp_min), (double)val_of((K)stats->asp_max), nb, edges);
 }
@@ -984,14 +1090,30 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, 1, d_rbs);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // the one pass: dh for every own pixel (written), min / max aspect, counters, candidates
+    bool ext_used = false;
     if (P->row1 > P->row0) {
         dim3 grid = grid2d(ctx, P->W, P->row1 - P->row0);
         const int64_t rows = P->row1 - P->row0;
         if ((rows + grid.y - 1) / grid.y > NK_CHUNK_MAX) grid.y = (unsigned)((rows + NK_CHUNK_MAX - 1) / NK_CHUNK_MAX);
+        const bool ext = P->ext_ok && !ctx->allreduce && g.rule <= 1;
+        if (ext) {   // min / max aspect from the listed extreme-aspect pixels; the dh pass then reads neither mask nor aspect
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt + 2, 0, 16, ctx->stream));
+            hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref_m),
+                               static_cast<const T*>(P->tba), static_cast<const T*>(P->aspect), g, P->ext_idx, P->ext_cnt, d_stats, P->ext_cnt + 2);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+        }
+        ext_used = ext;
 #define XD_NK_LEAN(RULE)                                                                                                            \
-    hipLaunchKernelGGL((nk_dh_count_lean_kernel<T, RULE>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),          \
-                       static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh), d_stats, \
-                       P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap)
+    do {                                                                                                                            \
+        if (ext)                                                                                                                    \
+            hipLaunchKernelGGL((nk_dh_count_lean_kernel<T, RULE, true>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref_m), \
+                               static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh), d_stats, \
+                               P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap);   \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((nk_dh_count_lean_kernel<T, RULE>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),  \
+                               static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh), d_stats, \
+                               P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap);   \
+    } while (0)
         if (g.rule == 0) XD_NK_LEAN(0);
         else if (g.rule == 1) XD_NK_LEAN(1);
         else
@@ -1016,7 +1138,7 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if (rc) return rc;
     hipLaunchKernelGGL((nk_vshift_edges_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_cnt, d_st,
                        reinterpret_cast<const uint64_t*>(scratch + off_succ(1)), d_klo, d_rbs, d_flags, d_stats, nb, scratch + OFF_INFO,
-                       reinterpret_cast<T*>(scratch));
+                       reinterpret_cast<T*>(scratch), ext_used ? P->ext_cnt + 2 : nullptr);
     XD_HIP_CHECK(ctx, hipGetLastError());
     *queued = true;
     return XDEMHIP_OK;
@@ -1232,6 +1354,7 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         memcpy(&total, info + 8, 8);
         memcpy(&flags, info + 16, 8);
         memcpy(&vs, info + 24, 8);
+        if (fused && (flags & 4)) P->ext_ok = false;  // no listed extreme-aspect pixel kept a finite dh: this plan reads the aspect again
         if (fused && flags != 0) continue;  // a bracket of the global median missed / overflowed: again on the plain route
         *n_valid = (int64_t)total;
         if (total == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
@@ -1340,6 +1463,18 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
     if ((int64_t)n >= SEL_BRACKET_MIN_N && sel_ws_create(ctx, (int64_t)n, es, MAX_BINS_PER_SWEEP, P->ws) != XDEMHIP_OK)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
+    // EXT route of the dh pass (large single-GPU plans): masked copy of the reference DEM + the lists of extreme-aspect pixels;
+    // without the memory for it the plan simply keeps the route that reads mask and aspect
+    if ((int64_t)n >= SEL_BRACKET_MIN_N && ctx->nk_ext != 0) {
+        if (hipMalloc(&P->ref_m, n * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->ext_idx), (size_t)2 * EXT_CAP * 8) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&P->ext_cnt), 32) != hipSuccess) {
+            (void)hipGetLastError();
+            if (P->ref_m) (void)hipFree(P->ref_m);
+            if (P->ext_idx) (void)hipFree(P->ext_idx);
+            if (P->ext_cnt) (void)hipFree(P->ext_cnt);
+            P->ref_m = nullptr; P->ext_idx = nullptr; P->ext_cnt = nullptr;
+        }
+    }
     const xdemhip_allreduce_fn hook = ctx->allreduce;
     if (!global_count) ctx->allreduce = nullptr;  // whole-raster plan: local pass; xdemhip_nk_set_rows re-partitions with the hook
     int rc = dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
@@ -1358,7 +1493,7 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     if (!P) return;
     (void)hipSetDevice(P->ctx->device);
     if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
-    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch};
+    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     xd::sel_ws_free(P->ws);
