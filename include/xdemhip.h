@@ -111,6 +111,17 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value);
 enum { XDEMHIP_RED_SUM_U64 = 0, XDEMHIP_RED_SUM_F64 = 1, XDEMHIP_RED_MIN_U64 = 2, XDEMHIP_RED_MAX_U64 = 3 };
 typedef int (*xdemhip_allreduce_fn)(void* host_array, int64_t count, int kind, void* user);
 int xdemhip_set_allreduce(xdemhip_ctx* ctx, xdemhip_allreduce_fn fn, void* user);
+/* Device-side form of the same hook (round 3): the library's per-pass reductions (integer histograms, counters, min / max
+ * keys) live in DEVICE memory; with this hook installed next to the host one they are handed over as they are -- `fn` gets
+ * the device pointer and the hipStream_t (as void*) the library's work is queued on, must ENQUEUE the in-place all-reduce so
+ * that it is ordered after the work already on that stream and before whatever is queued next (RCCL: ncclAllReduce on that
+ * stream, or on another one bracketed by events), and returns without waiting: no D2H / H2D staging, no host
+ * synchronisation per reduction.  The host hook stays in use for the few host-side scalars (route agreements).  NULL
+ * removes it (every reduction is then staged through the host hook).  xdemhip_reduction_calls reports how many reductions
+ * went through each hook since the context was created. */
+typedef int (*xdemhip_allreduce_device_fn)(void* device_array, int64_t count, int kind, void* hip_stream, void* user);
+int xdemhip_set_allreduce_device(xdemhip_ctx* ctx, xdemhip_allreduce_device_fn fn, void* user);
+int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* device_calls);
 
 /* ---- path 1: terrain stencil engine --------------------------------------------------------------
  * Replaces  _get_surface_attributes(dem, resolution, surface_attributes, out_dtype, surface_fit,

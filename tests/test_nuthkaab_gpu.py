@@ -239,10 +239,32 @@ def test_sharded_reduction_path_single_rank(coreg, shape):
         base = coreg.NKPlan(ref, tba, inlier)
         want = base.step(7.0, -3.0, (res, res), 72)
         base.close()
+        ctx = _lib.default_context()
+        h0, d0 = ctx.reduction_calls()
         plan = coreg.NKPlan(ref, tba, inlier, group="world")
         got = plan.step(7.0, -3.0, (res, res), 72)
         assert plan.n_valid == int((inlier & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(nko.aux_vars(ref)[0])).sum())
         plan.close()
+        # round 3: with an RCCL group the library's device arrays are all-reduced in place through the device-side hook -- no
+        # staging through the host, no host synchronisation per reduction
+        h1, d1 = ctx.reduction_calls()
+        assert d1 - d0 >= 5 and h1 == h0, (h0, h1, d0, d1)
+        # ... and the host-staged form (what gloo groups use) gives the same
+        plan = coreg.NKPlan(ref, tba, inlier)
+        ctx.set_allreduce("world", device_side=False)
+        try:
+            r0, r1 = 0, ref.shape[0]
+            import ctypes
+
+            nv = ctypes.c_int64()
+            ctx.check(ctx._L.xdemhip_nk_set_rows(plan.handle, r0, r1, ctypes.byref(nv)))
+            got_host = plan.step(7.0, -3.0, (res, res), 72)
+        finally:
+            ctx.set_allreduce(None)
+            plan.close()
+        h2, d2 = ctx.reduction_calls()
+        assert h2 > h1 and d2 == d1
+        assert got_host["vshift"] == got["vshift"] and np.array_equal(got_host["medians"], got["medians"], equal_nan=True)
         for k in ("vshift", "n_valid"):
             assert got[k] == want[k]
         assert np.array_equal(got["counts"], want["counts"]) and np.array_equal(got["medians"], want["medians"], equal_nan=True)
@@ -748,3 +770,52 @@ def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
             # the premise of (ii): the surviving half does not reach the aspect extremes the full raster has
             assert np.nanmin(a_[H // 2 + 10:]) > np.nanmin(a_[: H // 2]) and np.nanmax(a_[H // 2 + 10:]) < np.nanmax(a_[: H // 2])
             assert got[1][0]["edges"][0] > float(np.nanmin(a_[: H // 2]))
+
+
+def test_device_side_reductions_cost_little():
+    """SURVEY 8e / round-2 review: the sharded step used to make ~25 host round trips (D2H + sync + hook + H2D + sync per digit
+    pass).  With the device-side hook on a 1-rank RCCL group a 12000^2 step must stay within 25 % of the hook-less step
+    (the reductions are enqueued on the library's stream; what remains on the host are the two route agreements)."""
+    import os
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from xdem_amd import _lib, coreg
+    from xdem_amd.synth import fbm_torch
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        m = 12000
+        ref = fbm_torch(m, m, "cuda", seed=42)
+        tba = torch.roll(ref, shifts=(1, -2), dims=(0, 1)) + 1.0 + 0.3 * torch.randn((m, m), device="cuda")
+        tba[torch.rand((m, m), device="cuda") < 0.1] = float("nan")
+        torch.cuda.synchronize()
+        ctx = _lib.default_context()
+        times = {}
+        res = {}
+        for mode in ("plain", "hooked"):
+            plan = coreg.NKPlan(ref, tba, None, ctx, group="world" if mode == "hooked" else None)
+            plan.step(0.0, 0.0, (10.0, 10.0), 72)
+            h0, d0 = ctx.reduction_calls()
+            t0 = time.perf_counter()
+            for i in range(3):
+                res[mode] = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
+            times[mode] = (time.perf_counter() - t0) / 3
+            h1, d1 = ctx.reduction_calls()
+            plan.close()
+            if mode == "hooked":
+                assert h1 == h0 and d1 > d0
+        assert res["plain"]["vshift"] == res["hooked"]["vshift"]
+        assert np.array_equal(res["plain"]["medians"], res["hooked"]["medians"], equal_nan=True)
+        print(f"step plain {times['plain'] * 1e3:.2f} ms, through the device-side hook {times['hooked'] * 1e3:.2f} ms")
+        assert times["hooked"] < 1.25 * times["plain"] + 0.5e-3
+    finally:
+        if created:
+            dist.destroy_process_group()

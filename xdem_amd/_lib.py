@@ -51,6 +51,9 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_set_stream.argtypes = [c_ctx, ctypes.c_void_p]
         L.xdemhip_synchronize.argtypes = [c_ctx]
         L.xdemhip_set_option.argtypes = [c_ctx, ctypes.c_char_p, ctypes.c_int]
+        L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
+        L.xdemhip_set_allreduce_device.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
+        L.xdemhip_reduction_calls.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.xdemhip_last_kernel_ms.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_float)]
         L.xdemhip_terrain.argtypes = [
             c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -157,6 +160,47 @@ def make_reduce_hook(group="world", device: int | None = None):
     return hook
 
 
+class _DeviceArray:
+    """A device pointer dressed up for ``torch.as_tensor`` (CUDA array interface, zero copy)."""
+
+    def __init__(self, ptr: int, count: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def make_device_reduce_hook(group="world", device: int | None = None):
+    """The Python side of ``xdemhip_set_allreduce_device``: ``hook(device_ptr, count, kind, hip_stream, user) -> 0 | 1`` wraps the
+    library's device array as a torch tensor (no copy) and ENQUEUES ``torch.distributed.all_reduce`` (RCCL) with the
+    library's stream as the current stream: the collective waits for the work already queued there and the stream waits for
+    the collective -- no host synchronisation, no staging.  min / max of unsigned 64-bit keys travel as int64 with the top
+    bit flipped (an order-preserving map), flipped on the device before and after."""
+    import torch
+    import torch.distributed as dist
+
+    pg = None if group == "world" else group
+    ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.SUM, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX}
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    top = -(2**63)
+
+    def hook(ptr, count, kind, stream, user):
+        try:
+            t = torch.as_tensor(_DeviceArray(ptr, count, "<f8" if kind == 1 else "<i8"), device=dev)
+            s = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.stream(s):
+                if kind in (2, 3):
+                    t.bitwise_xor_(top)
+                dist.all_reduce(t, op=ops[kind], group=pg)
+                if kind in (2, 3):
+                    t.bitwise_xor_(top)
+            return 0
+        except Exception:  # never propagate a Python exception through the C frame
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+    return hook
+
+
 class Context:
     """One libxdemhip context = one GPU of this process."""
 
@@ -184,18 +228,39 @@ class Context:
         v = ctypes.c_void_p(-1) if stream_ptr is None else ctypes.c_void_p(stream_ptr)
         self.check(self._L.xdemhip_set_stream(self.handle, v))
 
-    def set_allreduce(self, group="world") -> None:
-        """Install (group given) or remove (group=None) the multi-GPU reduction hook: small 8-byte-element host arrays
-        handed over by the library are combined in place over the ranks of `group` with torch.distributed
-        (backend nccl = RCCL over xGMI on GPUs, gloo on CPU)."""
+    def set_allreduce(self, group="world", device_side: bool | None = None) -> None:
+        """Install (group given) or remove (group=None) the multi-GPU reduction hooks.  The host hook combines small
+        8-byte-element host arrays over the ranks of `group` with torch.distributed; with an RCCL ("nccl") group the
+        device-side hook is installed next to it (``device_side`` forces it on / off): the library's per-pass reductions --
+        histograms, counters, keys, all in device memory -- are then all-reduced in place on the library's stream with no
+        staging and no host synchronisation; gloo groups (CPU tests) stage everything through the host hook."""
         if group is None:
             self._hook = None
+            self._dev_hook = None
+            self.check(self._L.xdemhip_set_allreduce_device(self.handle, None, None))
             self.check(self._L.xdemhip_set_allreduce(self.handle, None, None))
             return
         hook = make_reduce_hook(group, self.device)
         CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
         self._hook = CB(hook)  # keep alive
         self.check(self._L.xdemhip_set_allreduce(self.handle, ctypes.cast(self._hook, ctypes.c_void_p), None))
+        if device_side is None:
+            import torch.distributed as dist
+
+            device_side = dist.get_backend(None if group == "world" else group) == "nccl"
+        if device_side:
+            CBD = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+            self._dev_hook = CBD(make_device_reduce_hook(group, self.device))
+            self.check(self._L.xdemhip_set_allreduce_device(self.handle, ctypes.cast(self._dev_hook, ctypes.c_void_p), None))
+        else:
+            self._dev_hook = None
+            self.check(self._L.xdemhip_set_allreduce_device(self.handle, None, None))
+
+    def reduction_calls(self) -> tuple[int, int]:
+        """(reductions staged through the host hook, reductions enqueued through the device hook) since the context was created."""
+        h, d = ctypes.c_int64(), ctypes.c_int64()
+        self.check(self._L.xdemhip_reduction_calls(self.handle, ctypes.byref(h), ctypes.byref(d)))
+        return int(h.value), int(d.value)
 
     def synchronize(self) -> None:
         self.check(self._L.xdemhip_synchronize(self.handle))

@@ -70,6 +70,20 @@ int xdemhip_set_allreduce(xdemhip_ctx* ctx, xdemhip_allreduce_fn fn, void* user)
     return XDEMHIP_OK;
 }
 
+int xdemhip_set_allreduce_device(xdemhip_ctx* ctx, xdemhip_allreduce_device_fn fn, void* user) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    ctx->allreduce_dev = fn;
+    ctx->allreduce_dev_user = user;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* device_calls) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (host_calls) *host_calls = ctx->n_red_host;
+    if (device_calls) *device_calls = ctx->n_red_dev;
+    return XDEMHIP_OK;
+}
+
 int xdemhip_synchronize(xdemhip_ctx* ctx) {
     if (!ctx) return XDEMHIP_EINVAL;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));

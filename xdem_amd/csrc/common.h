@@ -22,6 +22,9 @@ struct xdemhip_ctx {
     int num_cu = 256;
     xdemhip_allreduce_fn allreduce = nullptr;  // multi-GPU hook (null: single process)
     void* allreduce_user = nullptr;
+    xdemhip_allreduce_device_fn allreduce_dev = nullptr;  // device-side form of the hook (device arrays stay on the device)
+    void* allreduce_dev_user = nullptr;
+    int64_t n_red_host = 0, n_red_dev = 0;     // reductions that went through the host / the device hook
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
     int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)
     int terrain_rows = 0;    // option "terrain_rows": tile height of the fused terrain kernel (0 automatic, 16, 24, 32)
@@ -107,6 +110,13 @@ struct XdFetchScope {  // RAII for C entry points that queue deferred copies
 // staged to the host, combined by the hook (torch.distributed / RCCL or gloo on the Python side) and copied back.
 inline int xd_allreduce_device(xdemhip_ctx* ctx, void* dptr, int64_t count, int kind) {
     if (!ctx->allreduce || count <= 0) return XDEMHIP_OK;
+    if (ctx->allreduce_dev) {  // enqueued on the context's stream by the caller's hook: no staging, no host synchronisation
+        ++ctx->n_red_dev;
+        if (ctx->allreduce_dev(dptr, count, kind, static_cast<void*>(ctx->stream), ctx->allreduce_dev_user) != 0)
+            return xd_fail(ctx, XDEMHIP_EHIP, "device all-reduce hook failed");
+        return XDEMHIP_OK;
+    }
+    ++ctx->n_red_host;
     std::string buf((size_t)count * 8, '\0');
     hipError_t e = hipMemcpyAsync(&buf[0], dptr, buf.size(), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
