@@ -748,7 +748,7 @@ def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
     tba_full[rng.uniform(size=(H, W)) < 0.02] = np.nan
     tba_bottom = tba_full.copy()
     tba_bottom[: H // 2 + 8] = np.nan      # no dh in the top half: every listed extreme-aspect pixel dies
-    keys = ("vshift", "n_valid", "y_mean", "y_std")
+    keys = ("vshift", "n_valid")
     for name, tba in (("full", tba_full), ("bottom only", tba_bottom)):
         got = {}
         for ext in (1, 0):
@@ -761,6 +761,8 @@ def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
                 ctx.set_option("nk_ext", 1)
         for a, b in zip(got[1], got[0]):
             assert all(a[k] == b[k] for k in keys), name
+            # (the two moments are float64 atomics: their last bits depend on the order of the additions even within one route)
+            assert abs(a["y_mean"] - b["y_mean"]) <= 1e-11 * (abs(b["y_mean"]) + 1e-9) + 1e-13 and abs(a["y_std"] - b["y_std"]) <= 1e-11 * abs(b["y_std"])
             assert np.array_equal(a["edges"], b["edges"]) and np.array_equal(a["counts"], b["counts"]), name
             assert np.array_equal(a["medians"], b["medians"], equal_nan=True), name
         if name == "bottom only":

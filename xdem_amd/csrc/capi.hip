@@ -50,6 +50,10 @@ void xdemhip_destroy(xdemhip_ctx* ctx) {
         if (ctx->copy_streams[t]) (void)hipStreamDestroy(ctx->copy_streams[t]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (int q = 0; q < 2; ++q) {
+        if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
+        if (ctx->stage_out[q]) (void)hipHostFree(ctx->stage_out[q]);
+    }
     delete ctx;
 }
 
@@ -93,7 +97,7 @@ int xdemhip_synchronize(xdemhip_ctx* ctx) {
 
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return XDEMHIP_EINVAL;
-    if (std::string(name) == "host_chunk_mb") {  // device budget of one row chunk of host-buffer terrain calls (0 = default 8 GiB)
+    if (std::string(name) == "host_chunk_mb") {  // device / pinned budget of one row chunk of host-buffer terrain calls (0 = default 288 MiB)
         if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "host_chunk_mb must be >= 0");
         ctx->host_chunk_mb = value;
         return XDEMHIP_OK;
@@ -234,95 +238,155 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     }
 
     // Host buffers: the raster streams through the device in ROW CHUNKS with the overlap the requested attributes need (the GPU
-    // analogue of the reference's map_overlap tiles, xdem/terrain/terrain.py:412-466): device memory stays bounded by the
-    // chunk budget however large the host raster is, and a chunk is computed exactly as the same rows of the whole raster
-    // (halo_top / halo_bottom of the kernels).
+    // analogue of the reference's map_overlap tiles, xdem/terrain/terrain.py:412-466): device memory stays bounded however
+    // large the host raster is, and a chunk is computed exactly as the same rows of the whole raster (halo_top / halo_bottom
+    // of the kernels).  Round 3: a double-buffered pipeline over PINNED staging buffers owned by the context --
+    //   copy threads: caller's rows -> pinned in[k & 1]      |  H2D (copy stream 0)  |  kernels (context stream)
+    //   D2H (copy stream 1) -> pinned out[k & 1]             |  copy threads: pinned out -> caller's planes
+    // with chunk k's transfers and kernels running while the threads move chunk k - 1's planes into the caller's (pageable,
+    // often never-touched) arrays: the PCIe link stays busy in both directions instead of idling behind a pageable copy.
     int depth = 0;  // overlap rows per side
     if (attr_mask & 0x3ffu) depth = surface_fit == XDEMHIP_FIT_FLORINSKY ? 2 : 1;
     if ((attr_mask & 0x5c00u) && window_size / 2 > depth) depth = window_size / 2;
     if ((attr_mask & XDEMHIP_ATTR_RUGOSITY) && depth < 1) depth = 1;
-    const size_t budget = (size_t)(ctx->host_chunk_mb > 0 ? ctx->host_chunk_mb : 8192) << 20;
+    // chunk size: ~256 MiB of output planes per chunk by default (deep enough to hide latencies, small enough to pipeline),
+    // capped by option "host_chunk_mb" (the device / pinned budget of one chunk, input + planes)
     const size_t row_bytes = (size_t)W * (in_es + out_es * (size_t)n_planes);
+    const size_t budget = (size_t)(ctx->host_chunk_mb > 0 ? ctx->host_chunk_mb : 288) << 20;
     int64_t chunk = (int64_t)(budget / (row_bytes ? row_bytes : 1)) - 2 * depth;
     if (chunk < 64) chunk = 64;  // (a few rows of a very wide raster may exceed the budget; still correct)
     if (chunk > H) chunk = H;
-    void* d_dem = nullptr;
-    std::vector<void*> d_out(n_planes, nullptr);
-    int rc = XDEMHIP_OK;
-    auto cleanup = [&]() {
-        if (d_dem) (void)hipFree(d_dem);
-        for (void* p : d_out)
-            if (p) (void)hipFree(p);
-    };
     const size_t in_bytes = (size_t)(chunk + 2 * depth) * (size_t)W * in_es;
     const size_t plane_bytes = (size_t)chunk * (size_t)W * out_es;
-    if (hipMalloc(&d_dem, in_bytes) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(dem) failed"); }
-    for (int i = 0; i < n_planes; ++i)
-        if (hipMalloc(&d_out[i], plane_bytes) != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(plane) failed"); }
-    L.dem = d_dem;
+    const size_t out_bytes = plane_bytes * (size_t)n_planes;
+    void* d_in[2] = {nullptr, nullptr};
+    void* d_out[2] = {nullptr, nullptr};
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    int rc = XDEMHIP_OK;
+    auto cleanup = [&]() {
+        for (int q = 0; q < 2; ++q) {
+            if (d_in[q]) (void)hipFree(d_in[q]);
+            if (d_out[q]) (void)hipFree(d_out[q]);
+            if (ev_in[q]) (void)hipEventDestroy(ev_in[q]);
+            if (ev_comp[q]) (void)hipEventDestroy(ev_comp[q]);
+            if (ev_out[q]) (void)hipEventDestroy(ev_out[q]);
+        }
+    };
+    // pinned staging, kept by the context between calls (pinning hundreds of MiB costs more than moving them)
+    if (ctx->stage_in_bytes < in_bytes || ctx->stage_out_bytes < out_bytes) {
+        for (int q = 0; q < 2; ++q) {
+            if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
+            if (ctx->stage_out[q]) (void)hipHostFree(ctx->stage_out[q]);
+            ctx->stage_in[q] = ctx->stage_out[q] = nullptr;
+        }
+        ctx->stage_in_bytes = ctx->stage_out_bytes = 0;
+        for (int q = 0; q < 2; ++q)
+            if (hipHostMalloc(&ctx->stage_in[q], in_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc(&ctx->stage_out[q], out_bytes, hipHostMallocDefault) != hipSuccess)
+                return xd_fail(ctx, XDEMHIP_ENOMEM, "hipHostMalloc(staging) failed");
+        ctx->stage_in_bytes = in_bytes;
+        ctx->stage_out_bytes = out_bytes;
+    }
+    for (int q = 0; q < 2; ++q) {
+        if (hipMalloc(&d_in[q], in_bytes) != hipSuccess || hipMalloc(&d_out[q], out_bytes) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_in[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_comp[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_out[q], hipEventDisableTiming) != hipSuccess) {
+            cleanup();
+            return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc / hipEventCreate (host path) failed");
+        }
+    }
     L.row_stride = W;
-    for (int bit = 0, i = 0; bit < XDEMHIP_ATTR_COUNT; ++bit)
-        if (attr_mask & (1u << bit)) L.planes[bit] = d_out[i++];
-    bool first = true;
-    for (int64_t r0 = 0; r0 < H && rc == XDEMHIP_OK; r0 += chunk) {
-        const int64_t r1 = (r0 + chunk < H) ? r0 + chunk : H;
+    const int nthreads = ctx->host_copy_threads;
+    hipStream_t s_h2d = ctx->copy_streams[0], s_d2h = ctx->copy_streams[1];
+    // `nthreads` threads, each copying its share of the byte ranges handed to it (caller's memory is pageable; fresh output
+    // pages fault on first touch: both want many threads)
+    struct Span { char* dst; const char* src; size_t bytes; };
+    auto parallel_copy = [&](const std::vector<Span>& spans) {
+        size_t total = 0;
+        for (const Span& sp : spans) total += sp.bytes;
+        if (total < ((size_t)4 << 20) || nthreads <= 1) {
+            for (const Span& sp : spans) memcpy(sp.dst, sp.src, sp.bytes);
+            return;
+        }
+        std::vector<std::thread> workers;
+        const size_t per = (total + (size_t)nthreads - 1) / (size_t)nthreads;
+        for (int t = 0; t < nthreads; ++t)
+            workers.emplace_back([&, t]() {
+                size_t lo = per * (size_t)t, hi = lo + per < total ? lo + per : total, pos = 0;
+                for (const Span& sp : spans) {
+                    const size_t a = pos > lo ? pos : lo, b = pos + sp.bytes < hi ? pos + sp.bytes : hi;
+                    if (b > a) memcpy(sp.dst + (a - pos), sp.src + (a - pos), b - a);
+                    pos += sp.bytes;
+                    if (pos >= hi) break;
+                }
+            });
+        for (auto& w : workers) w.join();
+    };
+    struct ChunkGeom { int64_t r0, r1, top, bot; };
+    std::vector<ChunkGeom> chunks;
+    for (int64_t r0 = 0; r0 < H; r0 += chunk) {
+        ChunkGeom g;
+        g.r0 = r0; g.r1 = (r0 + chunk < H) ? r0 + chunk : H;
         // rows of the caller's buffer (which itself may carry halo rows) available above / below this chunk
-        const int64_t top = (r0 + halo_top < depth) ? r0 + halo_top : depth;
-        const int64_t bot = (H + halo_bottom - r1 < depth) ? H + halo_bottom - r1 : depth;
-        const char* src = static_cast<const char*>(dem) + (size_t)(r0 + halo_top - top) * (size_t)row_stride * in_es;
-        // Pageable host memory is staged by the runtime on the calling thread (and fresh output pages fault on first touch):
-        // `nthreads` threads, each with its own stream and its share of the rows, keep more of the PCIe link busy than one.
-        const int nthreads = ctx->host_copy_threads;
-        const int64_t in_rows = top + (r1 - r0) + bot;
-        auto run_threads = [&](const std::function<int(int, hipStream_t)>& body) -> bool {
-            std::vector<std::thread> workers;
-            std::vector<int> wrc(nthreads, 0);
-            for (int t = 0; t < nthreads; ++t)
-                workers.emplace_back([&, t]() {
-                    if (hipSetDevice(ctx->device) != hipSuccess) { wrc[t] = 1; return; }
-                    wrc[t] = body(t, ctx->copy_streams[t]);
-                });
-            for (auto& w : workers) w.join();
-            for (int t = 0; t < nthreads; ++t)
-                if (wrc[t]) return false;
-            return true;
-        };
-        // (the previous chunk's kernels and copies have completed: every thread synchronised its stream)
-        const bool up = run_threads([&](int t, hipStream_t st) -> int {
-            const int64_t a = in_rows * t / nthreads, b = in_rows * (t + 1) / nthreads;
-            if (b <= a) return 0;
-            if (hipMemcpy2DAsync(static_cast<char*>(d_dem) + (size_t)a * (size_t)W * in_es, (size_t)W * in_es,
-                                 src + (size_t)a * (size_t)row_stride * in_es, (size_t)row_stride * in_es, (size_t)W * in_es,
-                                 (size_t)(b - a), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
-            return hipStreamSynchronize(st) != hipSuccess;
-        });
-        if (!up) { rc = xd_fail(ctx, XDEMHIP_EHIP, "H2D copy failed"); break; }
-        L.H = r1 - r0; L.halo_top = top; L.halo_bottom = bot;
-        if (first) (void)hipEventRecord(ctx->ev_start, ctx->stream);
+        g.top = (r0 + halo_top < depth) ? r0 + halo_top : depth;
+        g.bot = (H + halo_bottom - g.r1 < depth) ? H + halo_bottom - g.r1 : depth;
+        chunks.push_back(g);
+    }
+    const int nchunks = (int)chunks.size();
+    auto drain = [&](int k) -> int {   // chunk k's planes: pinned staging -> caller's arrays (after its D2H has landed)
+        const ChunkGeom& g = chunks[k];
+        const int q = k & 1;
+        if (hipEventSynchronize(ev_out[q]) != hipSuccess) return xd_fail(ctx, XDEMHIP_EHIP, "D2H copy failed");
+        std::vector<Span> spans;
+        const size_t nb = (size_t)(g.r1 - g.r0) * (size_t)W * out_es;
+        for (int i = 0; i < n_planes; ++i)
+            spans.push_back({static_cast<char*>(out_planes[i]) + (size_t)g.r0 * (size_t)W * out_es,
+                             static_cast<const char*>(ctx->stage_out[q]) + (size_t)i * plane_bytes, nb});
+        parallel_copy(spans);
+        return XDEMHIP_OK;
+    };
+    for (int k = 0; k < nchunks && rc == XDEMHIP_OK; ++k) {
+        const ChunkGeom& g = chunks[k];
+        const int q = k & 1;
+        const int64_t in_rows = g.top + (g.r1 - g.r0) + g.bot;
+        // (buffers q are free: chunk k - 2 was drained two iterations ago, which followed its kernels and copies)
+        {   // caller's rows -> pinned in[q] (row stride squeezed out), then H2D
+            const char* src = static_cast<const char*>(dem) + (size_t)(g.r0 + halo_top - g.top) * (size_t)row_stride * in_es;
+            std::vector<Span> spans;
+            if (row_stride == W) spans.push_back({static_cast<char*>(ctx->stage_in[q]), src, (size_t)in_rows * (size_t)W * in_es});
+            else
+                for (int64_t r = 0; r < in_rows; ++r)
+                    spans.push_back({static_cast<char*>(ctx->stage_in[q]) + (size_t)r * (size_t)W * in_es,
+                                     src + (size_t)r * (size_t)row_stride * in_es, (size_t)W * in_es});
+            parallel_copy(spans);
+        }
+        if (hipMemcpyAsync(d_in[q], ctx->stage_in[q], (size_t)in_rows * (size_t)W * in_es, hipMemcpyHostToDevice, s_h2d) != hipSuccess ||
+            hipEventRecord(ev_in[q], s_h2d) != hipSuccess || hipStreamWaitEvent(ctx->stream, ev_in[q], 0) != hipSuccess) {
+            rc = xd_fail(ctx, XDEMHIP_EHIP, "H2D copy failed");
+            break;
+        }
+        L.dem = d_in[q];
+        for (int bit = 0, i = 0; bit < XDEMHIP_ATTR_COUNT; ++bit)
+            if (attr_mask & (1u << bit)) L.planes[bit] = static_cast<char*>(d_out[q]) + (size_t)(i++) * plane_bytes;
+        L.H = g.r1 - g.r0; L.halo_top = g.top; L.halo_bottom = g.bot;
+        if (k == 0) (void)hipEventRecord(ctx->ev_start, ctx->stream);
         rc = xd::launch_terrain(ctx, L);
         if (rc != XDEMHIP_OK) break;
-        if (r1 == H) (void)hipEventRecord(ctx->ev_stop, ctx->stream);
-        first = false;
-        hipEvent_t done_ev = ctx->ev_copy;
-        (void)hipEventRecord(done_ev, ctx->stream);
-        // D2H: tasks = (plane, row slice); `slices` slices per plane so that every thread has work whatever the plane count
-        const int slices = (nthreads + n_planes - 1) / n_planes > 1 ? (nthreads + n_planes - 1) / n_planes : 2;
-        const int n_tasks = n_planes * slices;
-        const int64_t rows = r1 - r0;
-        const bool down = run_threads([&](int t, hipStream_t st) -> int {
-            if (hipStreamWaitEvent(st, done_ev, 0) != hipSuccess) return 1;
-            for (int k = t; k < n_tasks; k += nthreads) {
-                const int i = k / slices, sl = k % slices;
-                const int64_t a = rows * sl / slices, b = rows * (sl + 1) / slices;
-                if (b <= a) continue;
-                if (hipMemcpyAsync(static_cast<char*>(out_planes[i]) + (size_t)(r0 + a) * (size_t)W * out_es,
-                                   static_cast<char*>(d_out[i]) + (size_t)a * (size_t)W * out_es, (size_t)(b - a) * (size_t)W * out_es,
-                                   hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
-            }
-            return hipStreamSynchronize(st) != hipSuccess;
-        });
-        if (!down) rc = xd_fail(ctx, XDEMHIP_EHIP, "D2H copy failed");
+        if (k == nchunks - 1) (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+        const size_t nb = (size_t)(g.r1 - g.r0) * (size_t)W * out_es;
+        hipError_t e = hipEventRecord(ev_comp[q], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_d2h, ev_comp[q], 0);
+        for (int i = 0; i < n_planes && e == hipSuccess; ++i)   // (a short last chunk leaves gaps between its planes: one copy per plane)
+            e = hipMemcpyAsync(static_cast<char*>(ctx->stage_out[q]) + (size_t)i * plane_bytes,
+                               static_cast<const char*>(d_out[q]) + (size_t)i * plane_bytes, nb, hipMemcpyDeviceToHost, s_d2h);
+        if (e == hipSuccess) e = hipEventRecord(ev_out[q], s_d2h);
+        if (e != hipSuccess) { rc = xd_fail(ctx, XDEMHIP_EHIP, "D2H copy failed"); break; }
+        // while the device works on chunk k, move chunk k - 1's planes into the caller's arrays
+        if (k > 0) rc = drain(k - 1);
     }
+    if (rc == XDEMHIP_OK) rc = drain(nchunks - 1);
+    if (rc != XDEMHIP_OK) { (void)hipStreamSynchronize(s_h2d); (void)hipStreamSynchronize(s_d2h); }
     ctx->timed = (rc == XDEMHIP_OK);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
     if (e2 != hipSuccess && rc == XDEMHIP_OK) rc = xd_fail(ctx, XDEMHIP_EHIP, std::string("kernel failed: ") + hipGetErrorString(e2));

@@ -17,6 +17,9 @@ struct xdemhip_ctx {
     static constexpr int MAX_COPY_THREADS = 16;
     hipStream_t copy_streams[MAX_COPY_THREADS] = {};  // one per copy thread of the host-buffer path
     int host_copy_threads = 8;                        // option "host_copy_threads"
+    void* stage_in[2] = {nullptr, nullptr};            // pinned staging of the host-buffer terrain path (double-buffered), kept between calls
+    void* stage_out[2] = {nullptr, nullptr};
+    size_t stage_in_bytes = 0, stage_out_bytes = 0;
     int pairs_launch_cap = 0;                         // option "pairs_launch_cap": workgroups per pair-kernel launch (0 = 2^31 / NT)
     bool timed = false;
     int num_cu = 256;
