@@ -15,6 +15,12 @@ TEST INFRASTRUCTURE (like everything under oracle/).  The script records INPUTS 
   ``RasterEquidistantMetricSpace`` on a small grid -> which pixel pairs a run contains (centre disk x rings, or also the
   disk with itself: ADVICE.md round 1).
 
+* geoutils ``subsample_array`` -- the draw behind NuthKaab's default 5e5-point subsample (xdem/coreg/base.py:600-605) and
+  behind the variogram samplers (xdem/spatialstats.py:978): which indexes does it return for a given ``random_state``,
+  array (with NaNs / a mask) and ``subsample`` (fraction and count)?  The product restates its published rule
+  (``coreg.subsample_valid_mask``: ``default_rng(random_state).choice(valid flat indexes, n, replace=False)``); the recording
+  settles the RNG protocol (generator type, order of the draws, sorted or not).
+
 Nothing here is imported by the product; the fixtures are data.
 """
 from __future__ import annotations
@@ -96,7 +102,42 @@ def pin_skgstat() -> str | None:
     return path
 
 
+def pin_subsample() -> str | None:
+    try:
+        import geoutils as gu
+        from geoutils.raster import subsample_array
+    except Exception as e:  # pragma: no cover - absent in the build image
+        print("geoutils.raster.subsample_array not importable:", e)
+        return None
+    rng = np.random.default_rng(21)
+    arr = rng.normal(size=(37, 53)).astype(np.float32)
+    arr[3:6, 10:20] = np.nan
+    arr[30, 5] = np.nan
+    marr = np.ma.masked_array(arr.copy(), mask=rng.uniform(size=arr.shape) < 0.1)
+    out = {"arr": arr, "mask": np.ma.getmaskarray(marr), "geoutils_version": np.array(gu.__version__)}
+    k = 0
+    for name, a in (("nan", arr), ("masked", marr)):
+        for subsample in (0.25, 1, 200, 10**6):
+            for seed in (42, 7):
+                idx = subsample_array(a, subsample=subsample, return_indices=True, random_state=seed)
+                out[f"case{k}"] = np.array([name, str(subsample), str(seed)])
+                out[f"rows{k}"], out[f"cols{k}"] = (np.asarray(i, dtype=np.int64) for i in idx)
+                vals = subsample_array(a, subsample=subsample, return_indices=False, random_state=seed)
+                out[f"vals{k}"] = np.asarray(vals, dtype=np.float32)
+                k += 1
+    # a Generator passed in (the variogram samplers hand one over): state consumed?
+    g = np.random.default_rng(5)
+    i1 = subsample_array(arr, subsample=50, return_indices=True, random_state=g)
+    i2 = subsample_array(arr, subsample=50, return_indices=True, random_state=g)
+    out["gen_rows1"], out["gen_cols1"] = (np.asarray(i, dtype=np.int64) for i in i1)
+    out["gen_rows2"], out["gen_cols2"] = (np.asarray(i, dtype=np.int64) for i in i2)
+    out["n_cases"] = np.int64(k)
+    path = os.path.join(GOLDEN, "thirdparty_subsample.npz")
+    np.savez_compressed(path, **out)
+    return path
+
+
 if __name__ == "__main__":
-    made = [p for p in (pin_interp(), pin_skgstat()) if p]
+    made = [p for p in (pin_interp(), pin_skgstat(), pin_subsample()) if p]
     print("written:", made if made else "nothing (packages absent)")
     sys.exit(0)

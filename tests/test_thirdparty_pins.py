@@ -79,3 +79,24 @@ def test_skgstat_equidistant_metric_space_structure():
         db = np.hypot(gc[cols, 0] - c[0], gc[cols, 1] - c[1])
         inside |= (da < r0) & (db < r0)
     assert inside.any(), "scikit-gstat holds no disk x disk pairs: drop ring 0 from the equidistant sample again"
+
+
+def test_geoutils_subsample_array_draw():
+    """The restated draw behind NuthKaab's default subsample and the variogram samplers (coreg.subsample_valid_mask:
+    default_rng(random_state).choice(valid flat indexes, n, replace=False)) against geoutils' own subsample_array."""
+    path = os.path.join(GOLDEN, "thirdparty_subsample.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/thirdparty_subsample.npz not recorded (geoutils absent here): run oracle/pin_thirdparty.py where it is importable")
+    from xdem_amd import coreg
+
+    z = np.load(path)
+    arr, mask = z["arr"], z["mask"]
+    for k in range(int(z["n_cases"])):
+        name, subsample, seed = (str(v) for v in z[f"case{k}"])
+        valid = np.isfinite(arr) & (~mask if name == "masked" else True)
+        sub = float(subsample)
+        sub = int(sub) if sub > 1 else sub
+        got = coreg.subsample_valid_mask(valid, sub, random_state=int(seed))
+        want = np.zeros(arr.shape, dtype=bool)
+        want[z[f"rows{k}"], z[f"cols{k}"]] = True
+        assert np.array_equal(got, want), (name, subsample, seed)
