@@ -154,6 +154,32 @@ def test_default_context_does_not_deadlock():
     assert box and (isinstance(box[0], _lib.Context) or "no usable" in str(box[0]))
 
 
+def test_streaming_kernels_keep_plane_pointers_in_scalar_registers(tmp_path):
+    """The streaming terrain kernels store through `global_store_dword v, v, s[base]` inline asm WITHOUT the scalar copy of the
+    plane pointer the tile kernels carry (DirectSink<float, false>): that is only safe while no plane pointer is ever restored
+    from a VGPR lane (v_readlane writes an SGPR on the vector unit; a VMEM instruction may not read it for 5 wait states and
+    inline asm gets no hazard handling).  Checked on the compiled code: no v_readlane / v_writelane in any streaming kernel."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "terrain_ff.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                           os.path.join(root, "xdem_amd", "csrc", "terrain_ff.hip"), "-o", out], stderr=subprocess.DEVNULL)
+    src = open(out).read()
+    n = 0
+    for m in re.finditer(r"\n(_Z\w*terrain_strip_kernel\w+):[^\n]*\n(.*?)\n\t\.amdhsa_kernel \1\n", src, re.S):
+        body = m.group(2)
+        assert "v_readlane_b32" not in body and "v_writelane_b32" not in body, m.group(1)
+        assert "global_load_lds_dwordx4" in body and "global_store_dword" in body
+        n += 1
+    assert n >= 6   # 3 attribute sets x 2 tails (x band heights)
+
+
 def test_variogram_host_preparation():
     from xdem_amd import spatialstats as ss
 

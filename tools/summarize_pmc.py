@@ -12,22 +12,31 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-pat = sys.argv[3] if len(sys.argv) > 3 else "terrain_tile_kernel"
+# several comma-separated patterns = the kernels that together make one step (round 3: streaming strips + frame tiles): the
+# per-dispatch means of each are ADDED ("mean" = bytes / instructions per step); "per_kernel" keeps them apart
+pats = (sys.argv[3] if len(sys.argv) > 3 else "terrain_tile_kernel").split(",")
+pat = pats[0]
 pixels = int(sys.argv[4]) if len(sys.argv) > 4 else 40000 * 40000
 out = {}
 for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
     per = {}
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if pat not in row.get("Kernel_Name", ""):
+            hit = [p_ for p_ in pats if p_ in row.get("Kernel_Name", "")]
+            if not hit:
                 continue
-            key = (row["Counter_Name"], row["Dispatch_Id"])
+            key = (row["Counter_Name"], hit[0], row["Dispatch_Id"])
             per[key] = per.get(key, 0.0) + float(row["Counter_Value"])  # (summed over XCDs / dimensions of one dispatch)
-    names = sorted({k[0] for k in per})
-    for n in names:
-        vals = [v for (c, _), v in per.items() if c == n]
-        out[n] = {"dispatches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
-out["_kernel_pattern"] = pat
+    for n in sorted({k[0] for k in per}):
+        entry = {"mean": 0.0, "per_kernel": {}}
+        for p_ in pats:
+            vals = [v for (c, kp, _), v in per.items() if c == n and kp == p_]
+            if vals:
+                entry["per_kernel"][p_] = {"dispatches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
+                entry["mean"] += sum(vals) / len(vals)
+        entry["dispatches"] = max(v["dispatches"] for v in entry["per_kernel"].values())
+        out[n] = entry
+out["_kernel_pattern"] = ",".join(pats)
 out["_pixels_per_launch"] = pixels
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)

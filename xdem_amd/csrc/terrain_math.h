@@ -352,7 +352,10 @@ template <> struct DegScale<double> { static XD_HD double v() { return 57.295779
 // origin, which maps to the scalar-base + VGPR-offset store form; the offset of output row i is o0 + i * ostride (a tile
 // spans far less than 4 GiB per plane).  (terrain.hip adds a sink that stages rows in LDS for 1 KiB row stores.)
 template <typename TOUT> struct Planes { TOUT* p[N_ATTR]; };
-template <typename TOUT> struct DirectSink {
+// PTR_COPY: copy the plane pointer through a scalar register inside the store's asm text (see put<>); kernels whose plane
+// pointers are never spilled to VGPR lanes (no v_readlane in their code: tests/test_cabi_and_host.py checks the ISA of the
+// streaming kernels) can do without: 11 scalar instructions less per output row of an issue-bound kernel.
+template <typename TOUT, bool PTR_COPY = true> struct DirectSink {
     typedef TOUT out_t;
     Planes<TOUT> org;
     uint32_t o0, ostride, o;
@@ -391,8 +394,12 @@ template <typename TOUT> struct DirectSink {
 #if defined(XD_STORE_NOP)
             asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 " XD_STORE_BITS ::"v"(o), "v"(v), "s"(org.p[K]) : "memory");
 #else
-            uint64_t ptmp;
-            asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 " XD_STORE_BITS : "=&s"(ptmp) : "v"(o), "v"(v), "s"(org.p[K]) : "memory");
+            if constexpr (PTR_COPY) {
+                uint64_t ptmp;
+                asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 " XD_STORE_BITS : "=&s"(ptmp) : "v"(o), "v"(v), "s"(org.p[K]) : "memory");
+            } else {
+                asm volatile("global_store_dword %0, %1, %2 " XD_STORE_BITS ::"v"(o), "v"(v), "s"(org.p[K]) : "memory");
+            }
 #endif
         } else {
             __builtin_nontemporal_store(v, reinterpret_cast<TOUT*>(reinterpret_cast<char*>(org.p[K]) + o));

@@ -283,12 +283,14 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     const uint64_t org_u = (uint64_t)(y0 * a.W + x0);
     const int64_t org_off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(org_u >> 32)) << 32) |
                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)org_u));
-    DirectSink<float> sk;
+    // (plane pointers stay in scalar registers for the whole kernel -- none is spilled to VGPR lanes, which the CPU test suite
+    // checks on the compiled code -- so the stores read them directly: DirectSink<float, false>)
+    DirectSink<float, false> sk;
 #pragma unroll
     for (int k = 0; k < N_ATTR; ++k) sk.org.p[k] = a.out.p[k] + org_off;
     sk.o0 = (uint32_t)(lane * sizeof(float));
     sk.ostride = (uint32_t)(a.W * sizeof(float));
-    march_rows<FIT, CURV, WIN, SP, float, DirectSink<float>, RowsRing<NPL>>(rows, n_out, a.P, sk);
+    march_rows<FIT, CURV, WIN, SP, float, DirectSink<float, false>, RowsRing<NPL>>(rows, n_out, a.P, sk);
 }
 
 // TPI / TRI for an arbitrary odd window (reference default is 3, handled by the fused kernel above).
