@@ -123,6 +123,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->terrain_rows = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "vario_sort") {  // host side (PairSet): Morton order of the uploaded points; recorded here so that the option travels with the context
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "vario_sort: 0 or 1");
+        ctx->vario_sort = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "nk_ext") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_ext: 0 or 1");
         ctx->nk_ext = value;

@@ -240,6 +240,13 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     // its round trip whenever any lane of the wave had a candidate, i.e. for half of all wave-pairs -- was most of the 22
     // vector instructions per pair this pass spent beyond the class lookup).  A second candidate while one is pending (a few
     // per thousand lane-octets) is appended directly.
+    // OP_SUMS, full tiles: RUN-LENGTH accumulation.  The point sets are uploaded in Morton order (PairSet: neighbouring slots are
+    // neighbouring points), so consecutive B points of a tile mostly fall into the same lag class of a lane's A point: the lane
+    // keeps the running sum and count of its current class in registers and touches the LDS record -- two atomics -- only when
+    // the class changes.  (Round 2 paid both atomics for every pair and the LDS array was busy for the whole kernel.)
+    int run_l = a.nb;          // spare class: flushing the empty initial run adds (0, 0) to the record nobody reads
+    double run_s = 0.0;
+    uint32_t run_c = 0;
     T pend_v = (T)0;
     uint32_t pend_l = 0;
     unsigned long long pend_m = 0;  // lanes with a pending candidate (wave-uniform scalar)
@@ -287,7 +294,21 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
             else
                 __syncthreads();
             const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
-            if (tid < cnt) {
+            // sampled pass over every-a-with-every-b blocks: the 4 sampled B points of the tile are taken 64 slots apart (h, h + 64,
+            // h + 128, h + 192 -- the sets arrive in Morton order, adjacent slots are neighbouring points and would count as one)
+            // and parked in slots jslot .. jslot + 3; i < j blocks keep 4 adjacent slots (their diagonal test needs the slot index)
+            const bool spread = sampled && !a.pdist;
+            int n_sampled = 4;
+            if (spread) {
+                const int h = jslot >> 2;
+                n_sampled = h < cnt ? (cnt - 1 - h) / 64 + 1 : 0;
+                if (tid < n_sampled) {
+                    const int64_t src = b0 + j0 + h + 64 * tid;
+                    if (GRID) s_bxy[jslot + tid] = gbxy[src];
+                    else { s_bx[jslot + tid] = gbx[src]; s_by[jslot + tid] = gby[src]; }
+                    s_bv[jslot + tid] = gbv[src];
+                }
+            } else if (tid < cnt) {
                 if (GRID) s_bxy[tid] = gbxy[b0 + j0 + tid];
                 else { s_bx[tid] = gbx[b0 + j0 + tid]; s_by[tid] = gby[b0 + j0 + tid]; }
                 s_bv[tid] = gbv[b0 + j0 + tid];
@@ -423,14 +444,24 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const double dd = (double)dv[u];
-                            rec_add(lu[u], OP == OP_SUMS_SQ ? dd * dd : sqrt(fabs(dd)));
+                            if (lu[u] != run_l) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
+                                const int off = run_l * REC;
+                                atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
+                                atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_c);
+                                run_l = lu[u];
+                                run_s = 0.0;
+                                run_c = 0;
+                            }
+                            run_s = OP == OP_SUMS_SQ ? __builtin_fma(dd, dd, run_s) : run_s + sqrt(fabs(dd));
+                            run_c += 1;
                         }
                     }
                     continue;
                 }
                 auto run4 = [&](auto plain_tag) {
                     constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
-                    const int jend = sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt;
+                    const int jend = spread ? jslot + n_sampled : (sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt);
+                    const int cnt_m = spread ? jend : cnt;   // slots at or beyond this hold no point of the tile
                     for (int j = jslot; j < jend; j += 4) {
                         int lus[4];
                         T dv[4];
@@ -447,7 +478,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 // everything that is no pair goes to the spare class nb (the class lookup itself never exceeds nb:
                                 // "beyond the last edge" IS class nb, so full tiles need no test at all)
                                 if constexpr (PLAIN) lc[u] = lus[u];
-                                else lc[u] = ((j + u) < cnt && (j + u) > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
+                                else lc[u] = ((j + u) < cnt_m && (j + u) > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
                                 lo4[u] = s_lh[2 * lc[u]];
                                 hi4[u] = s_lh[2 * lc[u] + 1];
                             }
@@ -492,7 +523,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             const int lu = lus[u];
                             dv[u] = dv[u] < 0 ? -dv[u] : dv[u];
                             const T d = dv[u];
-                            const bool ok = (PLAIN || ((j + u) < cnt && (j + u) > ia_rel && d == d)) && lu < nb;
+                            const bool ok = (PLAIN || ((j + u) < cnt_m && (j + u) > ia_rel && d == d)) && lu < nb;
                             if (OP == OP_BRACKET) {
                                 bracket_pair(ok, lu, d);
                             } else if (ok) {
@@ -518,10 +549,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 else run4(std::false_type());
                 if (OP == OP_BRACKET) flush_pending();  // (a tile's pair count need not be a multiple of 8)
             } else {
-                const int jend = sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt;
+                const int jend = spread ? jslot + n_sampled : (sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt);
                 for (int j = jslot; j < jend; ++j) pair(j, have_a && (!a.pdist || (j0 + j) > ia));
             }
         }
+    if ((OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && run_c) {   // the open run of every lane
+        const int off = run_l * REC;
+        atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
+        atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_c);
+    }
     __syncthreads();
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) {
         for (int k = tid; k < nb; k += NT) {
@@ -773,6 +809,8 @@ void xdemhip_pairs_destroy(xdemhip_pairs* P) {
     void* b2[] = {P->a_off, P->b_off, P->wg_off, P->wg_off_big, P->thr, P->sums, P->counts, P->hist, P->prefix, P->succ, P->lut,
                   P->a_xy, P->b_xy, P->thr_i, P->lut_i};
     for (void* p : b2) if (p) (void)hipFree(p);
+    if (P->cand_v) (void)hipFree(P->cand_v);   // candidate buffers of the bracketed selection (kept between calls)
+    if (P->cand_b) (void)hipFree(P->cand_b);
     delete P;
 }
 
@@ -1082,9 +1120,9 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     SelState<K>* d_st = reinterpret_cast<SelState<K>*>(d_small);
     void* scratch = nullptr;
     auto cleanup = [&]() {
-        if (P->cand_v) (void)hipFree(P->cand_v);
-        if (P->cand_b) (void)hipFree(P->cand_b);
-        P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0; P->khi = nullptr; P->cnt3 = nullptr; P->cand_ctr = nullptr;
+        // (the candidate buffers stay with the pair set -- tens of GB whose hipMalloc and first touch cost a second: a second
+        // selection on the same set, e.g. after a warm-up call, reuses them; xdemhip_pairs_destroy frees them)
+        P->khi = nullptr; P->cnt3 = nullptr; P->cand_ctr = nullptr;
         if (scratch) (void)hipFree(scratch);
         (void)hipFree(d_small);
     };
@@ -1126,12 +1164,19 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         {
             const double want = expected * 1.5 + (double)(1 << 20);
             const double most = (double)P->n_pairs + 1024.0;
-            P->cand_cap = (long long)(want < most ? want : most);
+            const long long need = (long long)(want < most ? want : most);
             uint64_t got = 1;
-            if (hipMalloc(&P->cand_v, (size_t)P->cand_cap * sizeof(T)) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)P->cand_cap * 2) != hipSuccess) {
-                (void)hipGetLastError();
-                got = 0;
+            if (P->cand_cap < need) {
+                if (P->cand_v) (void)hipFree(P->cand_v);
+                if (P->cand_b) (void)hipFree(P->cand_b);
+                P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0;
+                if (hipMalloc(&P->cand_v, (size_t)need * sizeof(T)) != hipSuccess ||
+                    hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)need * 2) != hipSuccess) {
+                    (void)hipGetLastError();
+                    got = 0;
+                } else {
+                    P->cand_cap = need;
+                }
             }
             if (ctx->allreduce && ctx->allreduce(&got, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) {
                 cleanup();

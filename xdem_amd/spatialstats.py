@@ -27,6 +27,37 @@ from . import _lib
 _ESTIMATORS = ("matheron", "cressie", "dowd")
 
 
+def _morton_order(x: np.ndarray, y: np.ndarray) -> np.ndarray | None:
+    """Permutation that sorts the points along a Z-order curve over their bounding box (16 bits per axis)."""
+    if x.size < 3:
+        return None
+    with np.errstate(invalid="ignore"):
+        fin = np.isfinite(x) & np.isfinite(y)
+    if not fin.all():
+        return None
+    spanx, spany = float(x.max() - x.min()), float(y.max() - y.min())
+    qx = ((x - x.min()) * (65535.0 / spanx if spanx > 0 else 0.0)).astype(np.uint64)
+    qy = ((y - y.min()) * (65535.0 / spany if spany > 0 else 0.0)).astype(np.uint64)
+
+    def spread(v):
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x33333333)
+        v = (v | (v << np.uint64(1))) & np.uint64(0x55555555)
+        return v
+
+    return np.argsort(spread(qx) | (spread(qy) << np.uint64(1)), kind="stable")
+
+
+def _morton_sorted_block(b: tuple) -> tuple:
+    out = list(np.asarray(c) for c in b)
+    for k in range(0, len(out), 3):
+        o = _morton_order(np.asarray(out[k], dtype=np.float64).ravel(), np.asarray(out[k + 1], dtype=np.float64).ravel())
+        if o is not None:
+            out[k], out[k + 1], out[k + 2] = (np.asarray(out[k]).ravel()[o], np.asarray(out[k + 1]).ravel()[o], np.asarray(out[k + 2]).ravel()[o])
+    return tuple(out)
+
+
 class PairSet:
     """Device-resident pair blocks + lag edges (``xdemhip_pairs``).  ``blocks`` is a list of (ax, ay, av, bx, by, bv)
     (every a with every b) or (ax, ay, av) (all i < j)."""
@@ -41,6 +72,13 @@ class PairSet:
         vdt = np.float64 if any(np.asarray(b[2]).dtype == np.float64 for b in blocks) else np.float32
         if self.ctx.options.get("vario_diff"):
             vdt = np.float64  # option "vario_diff" = 1: |dv| in float64 whatever the value dtype (values are widened)
+        # Points go to the device in MORTON ORDER within each block (neighbouring slots = neighbouring points): the pair kernels
+        # accumulate run-length -- a lane keeps the sum of its current lag class in registers and touches the LDS accumulators
+        # only when the class changes -- and consecutive B points of one neighbourhood mostly share the class.  The pair SET,
+        # hence every count and median, does not depend on the order (float64 sums: to rounding).  Option "vario_sort" = 0
+        # keeps the caller's order.
+        if self.ctx.options.get("vario_sort", 1):
+            blocks = [_morton_sorted_block(b) for b in blocks]
         cat = lambda i, dt: np.ascontiguousarray(np.concatenate([np.asarray(b[i], dtype=dt).ravel() for b in blocks]))
         off = lambda i: np.ascontiguousarray(np.concatenate([[0], np.cumsum([np.asarray(b[i]).size for b in blocks])]), dtype=np.int64)
         self._keep = [off(0), cat(0, np.float64), cat(1, np.float64), cat(2, vdt)]
