@@ -72,29 +72,45 @@ class PairSet:
         vdt = np.float64 if any(np.asarray(b[2]).dtype == np.float64 for b in blocks) else np.float32
         if self.ctx.options.get("vario_diff"):
             vdt = np.float64  # option "vario_diff" = 1: |dv| in float64 whatever the value dtype (values are widened)
-        # Points go to the device in MORTON ORDER within each block (neighbouring slots = neighbouring points): the pair kernels
-        # accumulate run-length -- a lane keeps the sum of its current lag class in registers and touches the LDS accumulators
-        # only when the class changes -- and consecutive B points of one neighbourhood mostly share the class.  The pair SET,
-        # hence every count and median, does not depend on the order (float64 sums: to rounding).  Option "vario_sort" = 0
-        # keeps the caller's order.
-        if self.ctx.options.get("vario_sort", 1):
-            blocks = [_morton_sorted_block(b) for b in blocks]
-        cat = lambda i, dt: np.ascontiguousarray(np.concatenate([np.asarray(b[i], dtype=dt).ravel() for b in blocks]))
+        # TWO device copies of the pair set (same pairs, different slot order):
+        #  * `handle` -- points in MORTON ORDER within each block (neighbouring slots = neighbouring points) for the sum passes
+        #    (Matheron / Cressie): the pair kernels accumulate run-length, a lane keeps the sum of its current lag class in
+        #    registers and touches the LDS accumulators only when the class changes, and consecutive B points of one
+        #    neighbourhood mostly share the class (2.1 -> 2.7 Tpairs/s on SURVEY 8d's C5 input);
+        #  * `handle_sel` -- the caller's order for the exact-median selection (Dowd): its counting pass compacts the pairs
+        #    inside the brackets through a small staging buffer, and spatially sorted tiles of a correlated field fall into a
+        #    bracket wholesale (measured: 88 -> 590 ms).
+        # Counts and medians do not depend on the order; float64 sums agree to rounding.  Option "vario_sort" = 0: one copy.
+        cat = lambda bl, i, dt: np.ascontiguousarray(np.concatenate([np.asarray(b[i], dtype=dt).ravel() for b in bl]))
         off = lambda i: np.ascontiguousarray(np.concatenate([[0], np.cumsum([np.asarray(b[i]).size for b in blocks])]), dtype=np.int64)
-        self._keep = [off(0), cat(0, np.float64), cat(1, np.float64), cat(2, vdt)]
-        if not pd:
-            self._keep += [off(3), cat(3, np.float64), cat(4, np.float64), cat(5, vdt)]
         self.edges = np.ascontiguousarray(right_edges, dtype=np.float64)
         self.nb = int(self.edges.size)
         self.vdtype = np.dtype(vdt)
         self.key_bits = 32 if vdt == np.float32 else 64
-        p = [a.ctypes.data for a in self._keep] + ([None] * 4 if pd else [])
-        h, n_pairs = ctypes.c_void_p(), ctypes.c_int64()
-        self.ctx.check(self.ctx._L.xdemhip_pairs_create(
-            self.ctx.handle, len(blocks), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
-            _lib.F32 if vdt == np.float32 else _lib.F64, self.edges.ctypes.data, self.nb, _lib.HOST, ctypes.byref(h),
-            ctypes.byref(n_pairs)))
-        self.handle, self.n_pairs = h, int(n_pairs.value)
+
+        def create(bl):
+            keep = [off(0), cat(bl, 0, np.float64), cat(bl, 1, np.float64), cat(bl, 2, vdt)]
+            if not pd:
+                keep += [off(3), cat(bl, 3, np.float64), cat(bl, 4, np.float64), cat(bl, 5, vdt)]
+            p = [a.ctypes.data for a in keep] + ([None] * 4 if pd else [])
+            h, n_pairs = ctypes.c_void_p(), ctypes.c_int64()
+            self.ctx.check(self.ctx._L.xdemhip_pairs_create(
+                self.ctx.handle, len(bl), p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
+                _lib.F32 if vdt == np.float32 else _lib.F64, self.edges.ctypes.data, self.nb, _lib.HOST, ctypes.byref(h),
+                ctypes.byref(n_pairs)))
+            return h, int(n_pairs.value)
+
+        self.handle = self.handle_sel = None
+        self.handle_sel, self.n_pairs = create(blocks)
+        if self.ctx.options.get("vario_sort", 1):
+            try:
+                self.handle, n2 = create([_morton_sorted_block(b) for b in blocks])
+            except Exception:
+                self.close()
+                raise
+            assert n2 == self.n_pairs
+        else:
+            self.handle = self.handle_sel
 
     def sums(self, kind: int):
         s = np.zeros(self.nb, dtype=np.float64)
@@ -107,20 +123,23 @@ class PairSet:
         h = np.zeros((self.nb, 256), dtype=np.uint64)
         u64p = ctypes.POINTER(ctypes.c_uint64)
         pp = np.ascontiguousarray(prefix, dtype=np.uint64).ctypes.data_as(u64p) if prefix is not None else None
-        self.ctx.check(self.ctx._L.xdemhip_pairs_hist(self.handle, shift, int(first), pp, h.ctypes.data_as(u64p)))
+        self.ctx.check(self.ctx._L.xdemhip_pairs_hist(self.handle_sel, shift, int(first), pp, h.ctypes.data_as(u64p)))
         return h
 
     def succ(self, key: np.ndarray) -> np.ndarray:
         out = np.zeros(self.nb, dtype=np.uint64)
         u64p = ctypes.POINTER(ctypes.c_uint64)
-        self.ctx.check(self.ctx._L.xdemhip_pairs_succ(self.handle, np.ascontiguousarray(key, dtype=np.uint64).ctypes.data_as(u64p),
+        self.ctx.check(self.ctx._L.xdemhip_pairs_succ(self.handle_sel, np.ascontiguousarray(key, dtype=np.uint64).ctypes.data_as(u64p),
                                                      out.ctypes.data_as(u64p)))
         return out
 
     def close(self) -> None:
-        if getattr(self, "handle", None):
-            self.ctx._L.xdemhip_pairs_destroy(self.handle)
-            self.handle = None
+        h, hs = getattr(self, "handle", None), getattr(self, "handle_sel", None)
+        if h:
+            self.ctx._L.xdemhip_pairs_destroy(h)
+        if hs and (not h or hs.value != h.value):
+            self.ctx._L.xdemhip_pairs_destroy(hs)
+        self.handle = self.handle_sel = None
 
     def __del__(self):  # pragma: no cover
         try:
@@ -163,7 +182,7 @@ def class_medians(pairs: PairSet, group=None):
     try:
         counts = np.zeros(pairs.nb, dtype=np.int64)
         med = np.full(pairs.nb, np.nan)
-        ctx.check(ctx._L.xdemhip_pairs_medians(pairs.handle, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+        ctx.check(ctx._L.xdemhip_pairs_medians(pairs.handle_sel, counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
                                                med.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
     finally:
         if hooked:
