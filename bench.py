@@ -451,10 +451,11 @@ def main() -> None:
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         step_ms = [a_.elapsed_time(b_) for a_, b_ in ev]
-        return float(t.item()), block, out, sum(step_ms) / len(step_ms)
+        return float(t.item()), block, out, step_ms
 
     n = args.size
-    elapsed, block, out, kernel_ms = partitioned_run(n, args.steps, args.warmup)
+    elapsed, block, out, step_ms = partitioned_run(n, args.steps, args.warmup)
+    kernel_ms = sum(step_ms) / len(step_ms)
 
     # Kernel duration for the roofline: the mean of the HIP-event times of the K timed steps themselves (events recorded on the
     # launch stream around each step; one step = the streaming kernel over the raster interior + the tile kernel over its frame
@@ -509,7 +510,8 @@ def main() -> None:
                          "kernel": "terrain_strip_kernel<Florinsky,curv,win,lean tail> (raster interior, 98.6 % of the pixels) + "
                                    "terrain_tile_kernel (frame of edge tiles)",
                          "kernel_ms_source": "mean HIP-event time of the timed steps themselves (events on the launch stream)",
-                         "kernel_ms": round(kernel_ms, 4), "pixels_per_launch": px_launch},
+                         "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(min(step_ms), 4),
+                         "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
