@@ -347,9 +347,10 @@ VARIO_LIMITER_NOTE = ("round 2 (profiles/r02_nk_vario_pmc.json): 14.7 vector + 4
                       "(LDS atomics only when a lane's lag class changes): the pass is bound by vector-instruction issue (~17 per pair); "
                       "the exact Dowd route is bound by its counting + compaction pass and the candidate selection (5 % of the pairs are "
                       "candidates: brackets sized for samples of point-sharing pairs of a spatially correlated field)")
-NK_TOUCHED_BYTES = 27
-NK_TOUCHED_NOTE = ("the two passes actually touch 27 B/pixel (dh pass: ref 4 + tba 4 + aspect 4 + mask 1 + dh out 4; bin pass: dh 4 + "
-                   "slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not recomputed")
+NK_TOUCHED_BYTES = 22
+NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference copy 4 + tba 4 + dh out 4 -- min / max aspect come from the "
+                   "plan's lists of extreme-aspect pixels, the inlier mask is folded into the reference copy as NaN; bin pass: dh 4 + "
+                   "slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not recomputed; 27 B/pixel in round 2")
 
 
 def end_to_end_host_path(ctx, n: int = 16384) -> dict:

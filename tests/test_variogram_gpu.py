@@ -503,6 +503,46 @@ def test_integer_lattice_kernels_equal_float64_kernels(ss, gsd, x0, estimator):
         assert np.allclose(e1[ok], eo[ok], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("estimator", ["matheron", "cressie", "dowd"])
+def test_morton_ordered_copy_equals_callers_order(ss, estimator):
+    """Round 3: the sum passes run over a second device copy of the pair set whose points are in Morton order (run-length
+    accumulation in registers).  Order must not matter: counts and Dowd medians identical, float64 sums to rounding, against
+    the one-copy route (option "vario_sort" = 0) and the oracle -- on a spatially correlated field with NaN values, points that
+    coincide, a block of a single point and pdist blocks, i.e. where runs of one lag class are long and where they are not."""
+    from xdem_amd import _lib
+
+    ctx = _lib.default_context()
+    r = np.random.default_rng(29)
+
+    def pts(n, extent, x0=0.0):
+        ix, iy = r.integers(0, extent, n), r.integers(0, extent, n)
+        v = (np.sin(ix / 25.0) * np.cos(iy / 31.0) + 0.05 * r.normal(size=n)).astype(np.float32)
+        v[r.random(n) < 0.03] = np.nan
+        return x0 + 5.0 * ix, 5.0 * iy, v
+
+    dense = pts(3000, 40)                       # ~2 points per lattice cell: coincident points, zero distances
+    blocks_c = [pts(700, 300) + pts(5000, 300), dense + dense, pts(1, 9) + pts(300, 9)]
+    blocks_p = [pts(1500, 200), pts(513, 4000, x0=1e5)]
+    edges = [float(e) for e in vo.default_bin_edges(5.0, 30000.0)]
+    for blocks in (blocks_c, blocks_p):
+        got = {}
+        for srt in (1, 0):
+            ctx.set_option("vario_sort", srt)
+            try:
+                got[srt] = ss.empirical_variogram_pairs(blocks, edges, estimator, ctx)
+            finally:
+                ctx.set_option("vario_sort", 1)
+        assert np.array_equal(got[1][1], got[0][1])
+        if estimator == "dowd":
+            assert np.array_equal(got[1][0], got[0][0], equal_nan=True)
+        else:
+            assert np.allclose(got[1][0], got[0][0], rtol=1e-12, atol=0, equal_nan=True)
+        eo, co = vo.empirical_variogram_blocks(blocks, edges, estimator)
+        assert np.array_equal(got[1][1], co)
+        ok = np.isfinite(eo)
+        assert np.allclose(got[1][0][ok], eo[ok], rtol=1e-12, atol=0)
+
+
 def test_lattice_path_refuses_what_it_cannot_represent(ss):
     """Off-lattice points, lattices wider than 32767 cells and spacings whose squares are not exact fall back to the float64
     kernels (same results as with the lattice kernels disabled)."""
