@@ -1,0 +1,85 @@
+"""A/B timing of the headline terrain launch between builds of the library, in one process (measurement tool).
+
+  python tools/ab_libs.py [--size 40000] [--reps 6] [--rounds 3] name=path/to/lib.so [name=path ...]
+
+Every library gets its own context; launches are interleaved over `rounds` so that the box's clock drift hits all builds
+alike.  Times are the libraries' own HIP events (xdemhip_last_kernel_ms).  Also checks that the builds agree bit for bit
+on a crop (or reports the largest ulp distance per plane)."""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+FULL_MASK = 4087  # slope .. TRI: the 11-attribute set of the headline
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=40000)
+    ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("libs", nargs="+")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+
+    from xdem_amd.synth import fbm_torch
+
+    n = a.size
+    dem = fbm_torch(n, n, "cuda", seed=42)
+    out = torch.empty((11, n, n), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    built = []
+    for spec in a.libs:
+        name, path = spec.split("=", 1)
+        L = ctypes.CDLL(os.path.join(ROOT, path))
+        ctx = ctypes.c_void_p()
+        L.xdemhip_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        assert L.xdemhip_create(0, ctypes.byref(ctx)) == 0
+        L.xdemhip_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.xdemhip_synchronize.argtypes = [ctypes.c_void_p]
+        L.xdemhip_terrain.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+            ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+        built.append((name, L, ctx))
+    planes = (ctypes.c_void_p * 11)(*[out[i].data_ptr() for i in range(11)])
+
+    def launch(L, ctx):
+        rc = L.xdemhip_terrain(ctx, ctypes.c_void_p(dem.data_ptr()), 0, n, n, n, 0, 0, 10.0, 2, 0, FULL_MASK, 0, 3, 45.0, 315.0,
+                               1.0, 1, 0, planes, 1)
+        assert rc == 0, rc
+        L.xdemhip_synchronize(ctx)
+        ms = ctypes.c_float()
+        L.xdemhip_last_kernel_ms(ctx, ctypes.byref(ms))
+        return float(ms.value)
+
+    times = {name: [] for name, _, _ in built}
+    for name, L, ctx in built:
+        launch(L, ctx)
+    for _ in range(a.rounds):
+        for name, L, ctx in built:
+            for _ in range(a.reps):
+                times[name].append(launch(L, ctx))
+    for name, t in times.items():
+        t = sorted(t)
+        print(f"{name:12s} min {t[0]:7.3f}  median {t[len(t) // 2]:7.3f}  max {t[-1]:7.3f} ms", flush=True)
+    # agreement on a crop (bit patterns; NaN == NaN)
+    crop = slice(0, min(n, 4096))
+    ref = None
+    for name, L, ctx in built:
+        launch(L, ctx)
+        got = out[:, crop, crop].cpu().numpy().view(np.int32).astype(np.int64)
+        got = np.where(got < 0, -(got & 0x7FFFFFFF), got)
+        if ref is None:
+            ref = got
+            continue
+        d = np.abs(got - ref)
+        print(f"{name} vs {built[0][0]}: max ulp distance per plane {d.reshape(11, -1).max(axis=1).tolist()}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,11 @@
 #define XD_HD inline
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define XD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define XD_SCHED_FENCE() ((void)0)
+#endif
 namespace xd {
 
 enum : uint32_t {
@@ -323,24 +328,17 @@ XD_HD void rsq32_pair(float x1, float x2, float& r1, float& r2) {
 // acc0 + sum over the eight neighbours k != 4 of (n[k] - c)^2, as two interleaved partial sums (even / odd neighbours in
 // row-major order 0 1 2 3 5 6 7 8), added at the end
 XD_HD float tri_sumsq8(const float (&n)[9], float c, float acc0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const xd_v2f cc = {c, c};
-    xd_v2f a = {acc0, 0.0f};
-    xd_v2f d = (xd_v2f){n[0], n[1]} - cc; a = __builtin_elementwise_fma(d, d, a);
-    d = (xd_v2f){n[2], n[3]} - cc; a = __builtin_elementwise_fma(d, d, a);
-    d = (xd_v2f){n[5], n[6]} - cc; a = __builtin_elementwise_fma(d, d, a);
-    d = (xd_v2f){n[7], n[8]} - cc; a = __builtin_elementwise_fma(d, d, a);
-    return a.x + a.y;
-#else
+    // (round 3: a packed form of these eight terms needed eight v_mov to pair the window registers and packed float32 FMAs
+    // cost two plain ones on gfx950 -- tools/ubench.hip -- so the plain form is the cheaper one; same two partial sums)
     float ax = acc0, ay = 0.0f;
     const int ev[4] = {0, 2, 5, 7}, od[4] = {1, 3, 6, 8};
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float d0 = n[ev[k]] - c, d1 = n[od[k]] - c;
         ax = fmaf(d0, d0, ax);
         ay = fmaf(d1, d1, ay);
     }
     return ax + ay;
-#endif
 }
 
 template <typename T> struct DegScale;
@@ -653,8 +651,12 @@ XD_HD void surface_pixel_mixed(float zxf, float zyf, float zxxf, float zyyf, flo
 // would leave an ABSOLUTE error of 3e-7 on a value near 0 -- such pixels (value below 0.3 before clipping, and not safely
 // negative) are reported back (return value) and recomputed by the float64 cold path of march_rows, like flat ground.
 // Valid for squared gradients in [1e-13, 1e16] like the mixed hot path; everything else is the cold path's.
+// Returns flag bits: TAIL_WANT_F64 (hillshade plane wants float64), TAIL_COLD (the pixel belongs to the cold path: a first
+// derivative cancelled exactly or the squared gradient is outside the range above -- decided here from values the tail has
+// anyway: min(|zx|, |zy|) and the rounded g2), TAIL_COLD_KNOWN (always set: the caller need not test again).
+enum : unsigned { TAIL_WANT_F64 = 1u, TAIL_COLD = 2u, TAIL_COLD_KNOWN = 4u };
 template <bool CURV, class SP, class SINK>
-XD_HD bool surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, float zxyf, const TerrainParams& P, SINK& sk) {
+XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, float zxyf, const TerrainParams& P, SINK& sk) {
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
     const bool deg = SP::DEG < 0 ? (P.degrees != 0) : (SP::DEG != 0);
     const bool zf_not_1 = SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0);
@@ -667,9 +669,13 @@ XD_HD bool surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, floa
     rsq32_pair(opgf, g2f, rwf, rgf);
     bool want_f64 = false;
     const float ax = fabsf(zxf), ay = fabsf(zyf);
+    const float amin = fminf(ax, ay);
+    // (NaN: the range tests are false and NaN propagates by itself; fminf(0, NaN) = 0 sends a zero derivative next to a
+    // NaN one to the cold path, which returns NaN for it as well)
+    const unsigned cold_bits = TAIL_COLD_KNOWN | (((amin == 0.0f) | (g2f < 1e-13f) | (g2f > 1e16f)) ? TAIL_COLD : 0u);
     float as_slope = 0.0f, as_aspect = 0.0f;
     {
-        const float xs = fminf((g2f * rgf) * rwf, rwf), xa = fminf(ax, ay) * rgf;   // min(sin, cos) of the slope; aspect octant
+        const float xs = fminf((g2f * rgf) * rwf, rwf), xa = amin * rgf;   // min(sin, cos) of the slope; aspect octant
         if ((m & A_SLOPE) && (m & A_ASPECT)) asin32_pair(xs, xa, as_slope, as_aspect);
         else if (m & A_SLOPE) as_slope = asin32(xs);
         else if (m & A_ASPECT) as_aspect = asin32(xa);
@@ -711,7 +717,7 @@ XD_HD bool surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, floa
         want_f64 = fabsf(v - 0.15f) < 0.15001f;   // -1e-5 < v < 0.30001: the float64 cold path decides (exact zero / tiny values)
         sk.template put<P_HILLSHADE>(clamp_keep_nan(v, 0.0f, 255.0f));
     }
-    if (!CURV) return want_f64;
+    if (!CURV) return cold_bits | (want_f64 ? TAIL_WANT_F64 : 0u);
     const double zxx = (double)zxxf, zyy = (double)zyyf, zxy = (double)zxyf;
     if (m & A_CURVATURE) sk.template put<P_CURVATURE>((float)(-2.0 * (zxx + zyy) * 100.0));
     if (m & (A_ANY_CURV & ~A_CURVATURE)) {
@@ -752,7 +758,7 @@ XD_HD bool surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, floa
             if (m & A_MINC) sk.template put<P_MINC>(vmin);
         }
     }
-    return want_f64;
+    return cold_bits | (want_f64 ? TAIL_WANT_F64 : 0u);
 }
 
 // TPI / TRI of a 3x3 window given as raw values (row-major n0..n8, n4 = centre).  Plain IEEE propagation.
@@ -889,18 +895,18 @@ template <int FIT> struct Halo { static constexpr int v = (FIT == 2) ? 2 : 1; };
 template <typename A, typename B> struct SameT { static constexpr bool v = false; };
 template <typename A> struct SameT<A, A> { static constexpr bool v = true; };
 
-// hot-path tail; returns true if the pixel additionally wants the float64 cold path (lean tail: nearly black hillshade)
+// hot-path tail; returns the TAIL_* flag bits (lean tail only: nearly black hillshade wants float64; cold-path decision)
 template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct SurfaceTail {
-    static XD_HD bool go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk) {
+    static XD_HD unsigned go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk) {
         surface_pixel<CURV, SP, SINK>((double)zx, (double)zy, (double)zxx, (double)zyy, (double)zxy, P, sk);
-        return false;
+        return 0u;
     }
 };
 template <bool CURV, class SP, class SINK> struct SurfaceTail<true, CURV, SP, float, SINK> {
-    static XD_HD bool go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
+    static XD_HD unsigned go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
         if (SP::F64TAIL == 2) return surface_pixel_lean<CURV, SP, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
         surface_pixel_mixed<CURV, SP, false, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
-        return false;
+        return 0u;
     }
 };
 template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct ColdTail {
@@ -990,15 +996,21 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
             const int r = r0 + k;
             if (r < nrows) {
                 const TIN t0 = nx0, tl = nx1, tc = nx2, tr = nx3, t4 = nx4;
+                // the prefetched row is CONSUMED (widened) before the next row's LDS reads are issued: the compiler otherwise
+                // hoists those reads above the conversions and has to wait for them on the spot (s_waitcnt lgkmcnt(0) right
+                // after the reads: a full LDS round trip per row); in this order the wait at the top of a row is for reads
+                // issued a whole row of arithmetic earlier
+                const double zl = (double)tl, zc = (double)tc, zr = (double)tr;
+                const double z0 = FIT == 2 ? (double)t0 : 0.0, z4 = FIT == 2 ? (double)t4 : 0.0;
+                XD_SCHED_FENCE();
                 rows.step(r);
                 {
                     const auto row = rows.ptr((r + 1 < nrows) ? r + 1 : r);
                     nx1 = row[-1]; nx2 = row[0]; nx3 = row[1];
                     if (FIT == 2) { nx0 = row[-2]; nx4 = row[2]; }
                 }
-                const double zl = (double)tl, zc = (double)tc, zr = (double)tr;
+                XD_SCHED_FENCE();
                 if (FIT == 2) {
-                    const double z0 = (double)t0, z4 = (double)t4;
                     const double p = z0 + z4, q = zl + zr;
                     A[k] = zr - zl;
                     B[k] = z4 - z0;
@@ -1056,11 +1068,12 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                             }
                         }
                     }
-                    bool tail_cold = false;
+                    unsigned tail_bits = 0u;
                     if (m & ~A_ANY_WIN) {
                         // hot path: every lane, straight-line (one basic block per output row)
-                        tail_cold = SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk);
+                        tail_bits = SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk);
                     }
+                    const bool tail_cold = (tail_bits & TAIL_WANT_F64) != 0u;
                     if (WIN) {
                         const int w1 = XD_SLOT(-1), w0 = XD_SLOT(0), w2 = XD_SLOT(1);
                         const TIN n[9] = {Nl[w1], Nc[w1], Nr[w1], Nl[w0], Nc[w0], Nr[w0], Nl[w2], Nc[w2], Nr[w2]};
@@ -1074,8 +1087,13 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                         //  * mixed-precision tail outside its validity range: float64 tail.
                         // (An exactly cancelling SECOND derivative alone does not send a pixel here: its residue only adds ~1e-15 of
                         // the other curvature terms -- float64 rounding noise the reference's own result carries as well.)
-                        bool cold = first_derivative_zero<TIN>(zx, zy);
-                        if (MIXED) cold |= mixed_tail_out_of_range((float)zx, (float)zy);
+                        bool cold;
+                        if (tail_bits & TAIL_COLD_KNOWN) {
+                            cold = (tail_bits & TAIL_COLD) != 0u;
+                        } else {
+                            cold = first_derivative_zero<TIN>(zx, zy);
+                            if (MIXED) cold |= mixed_tail_out_of_range((float)zx, (float)zy);
+                        }
                         // lean tail: a nearly black hillshade is the only plane its float32 factors cannot carry -- that one plane is
                         // recomputed in float64 (its own wave-uniform branch: ~3 % of the wave rows of steep terrain come here,
                         // the full cold tail below would cost them ten times as much)
