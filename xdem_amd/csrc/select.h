@@ -73,14 +73,21 @@ __host__ __device__ inline uint64_t sel_bracket_halfwidth(uint64_t m) {
 // |v_a - v_b| moves with v_b for all ~9000 A points at once), so the effective sample size is about the number of distinct
 // sampled B points in the class, not the number of pairs -- taken as m / 4096 (measured on SURVEY 8d's C5 input: a class of
 // 8.5e7 sampled pairs behaves like ~2e4 independent draws).
-__host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m) {
-    return (uint64_t)(3.0 * sqrt(4096.0 * (double)m)) + 64;
+// `deff` = the design effect assumed for the sample (pairs per independent draw): 4096 for the samples that pair a few B points
+// with ALL A points of a tile (i < j blocks), PAIR_DEFF_SPREAD for the samples in which every point of a unit takes part in a
+// few pairs only (variogram.hip: unit_sample_slot).
+// PAIR_DEFF_SPREAD measured on SURVEY 8d's C5 input (tools/vario_c5_probe.py): the wanted rank lies 0.04 half widths off the
+// bracket centre at worst (rms 0.012) with 64 -- the spread sample behaves like independent draws (design effect < 1: every unit
+// is represented), 64 leaves a factor ~25 for fields and geometries that correlate more strongly.
+constexpr uint32_t PAIR_DEFF_WIDE = 4096, PAIR_DEFF_SPREAD = 64;
+__host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m, uint32_t deff = PAIR_DEFF_WIDE) {
+    return (uint64_t)(3.0 * sqrt((double)deff * (double)m)) + 64;
 }
 
 template <typename K>
 __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
                                                             int mode = SEL_MEDIAN, const uint64_t* given = nullptr,
-                                                            const uint32_t* rb_shift = nullptr) {
+                                                            const uint32_t* rb_shift = nullptr, uint32_t wide_deff = PAIR_DEFF_WIDE) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
     // Rebased keys ((key - lo) << s, select_run.h) have s zero bits at the bottom: a digit that lies entirely inside them is 0
@@ -109,8 +116,8 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && b == 1);
         if (lo_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = r > h ? r - h : 0; }
         if (hi_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = (r + h < total) ? r + h : total - 1; }
-        if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total); r = r > h ? r - h : 0; }
-        if (mode == SEL_BRACKET_HI_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total); r = (r + h < total) ? r + h : total - 1; }
+        if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = r > h ? r - h : 0; }
+        if (mode == SEL_BRACKET_HI_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_GIVEN) {
             r = given[b];
             if (r == ~(uint64_t)0 || r >= total) { s.count = 0; r = 0; }

@@ -78,11 +78,17 @@ template <typename T> struct PairArgs {
     long long cand_cap;
 };
 
-// Sampled digit passes (bracketed selection): EVERY (A tile x B tile) unit contributes the pairs of 4 of its 256 B slots -- slots
-// [4 h, 4 h + 4), h hashed from the unit -- i.e. exactly 1/64 of its pairs.  (Round 2 sampled whole units with probability
-// 1/64: for values of a spatially correlated field the class distributions differ from block to block, the number of sampled
-// units per block was binomial (3 +- 1.7), and the mixture weights -- hence the sample medians -- were too noisy for any
-// affordable bracket.  With every unit represented the sample is a 1/64 subsample of the B POINTS against all A points.)
+// Sampled digit passes (bracketed selection): EVERY (A tile x B tile) unit contributes exactly 1/64 of its pairs.  (Round 2
+// sampled whole units with probability 1/64: for values of a spatially correlated field the class distributions differ from
+// block to block, the number of sampled units per block was binomial (3 +- 1.7), and the mixture weights -- hence the sample
+// medians -- were too noisy for any affordable bracket.)
+//  * every-a-with-every-b blocks: thread t (A point t of the tile) takes the four B slots (h + lane + 64 u) mod 256, u = 0..3, h
+//    hashed from the unit: the 4096 sampled pairs of a unit use each of its 1024 A points 4 times and each of its 256 B points 16
+//    times.  (The first form of this round took 4 B slots for ALL A points: 1024 pairs per sampled B point, and since |v_a - v_b|
+//    of a correlated field moves with v_b for all of them at once, a class of 8.5e7 sampled pairs behaved like 2e4 independent
+//    draws -- brackets 8 x wider, 5 % of all pairs candidates.)
+//  * i < j blocks keep 4 adjacent slots [4 h, 4 h + 4) against all A points (the diagonal test needs the uniform slot index) and
+//    the wide brackets that go with them.
 __device__ __forceinline__ int unit_sample_slot(int64_t wg, int tile) {
     return (int)(((uint64_t)(wg * 16 + tile) * 0x9E3779B97F4A7C15ull) >> 58);   // 0 .. 63
 }
@@ -294,21 +300,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
             else
                 __syncthreads();
             const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
-            // sampled pass over every-a-with-every-b blocks: the 4 sampled B points of the tile are taken 64 slots apart (h, h + 64,
-            // h + 128, h + 192 -- the sets arrive in Morton order, adjacent slots are neighbouring points and would count as one)
-            // and parked in slots jslot .. jslot + 3; i < j blocks keep 4 adjacent slots (their diagonal test needs the slot index)
+            // sampled pass over every-a-with-every-b blocks: per-lane slots (see unit_sample_slot), the whole tile is loaded
             const bool spread = sampled && !a.pdist;
-            int n_sampled = 4;
-            if (spread) {
-                const int h = jslot >> 2;
-                n_sampled = h < cnt ? (cnt - 1 - h) / 64 + 1 : 0;
-                if (tid < n_sampled) {
-                    const int64_t src = b0 + j0 + h + 64 * tid;
-                    if (GRID) s_bxy[jslot + tid] = gbxy[src];
-                    else { s_bx[jslot + tid] = gbx[src]; s_by[jslot + tid] = gby[src]; }
-                    s_bv[jslot + tid] = gbv[src];
-                }
-            } else if (tid < cnt) {
+            const int hslot = jslot >> 2;
+            if (tid < cnt) {
                 if (GRID) s_bxy[tid] = gbxy[b0 + j0 + tid];
                 else { s_bx[tid] = gbx[b0 + j0 + tid]; s_by[tid] = gby[b0 + j0 + tid]; }
                 s_bv[tid] = gbv[b0 + j0 + tid];
@@ -384,15 +379,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
 
             // classes of the 4 pairs (this lane's A point) x (tile slots j .. j + 3) and their raw value differences, written
             // stage by stage so that the B-point reads, the table reads and the threshold reads are each issued back to back
-            auto classify4 = [&](int j, int (&lu)[4], T (&dv)[4]) {
+            auto classify4 = [&](const int (&js)[4], int (&lu)[4], T (&dv)[4]) {
                 if constexpr (GRID) {
                     uint32_t d2[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                        const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[js[u]]);
                         // (the three-operand form with the inline constant 0: the builtin picks v_dot2c, which needs a zeroed accumulator)
                         asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
-                        dv[u] = pv - s_bv[j + u];
+                        dv[u] = pv - s_bv[js[u]];
                     }
                     uint2 e[4];
 #pragma unroll
@@ -407,9 +402,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     double s2[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const double dx = px - s_bx[j + u], dy = py - s_by[j + u];
+                        const double dx = px - s_bx[js[u]], dy = py - s_by[js[u]];
                         s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
-                        dv[u] = pv - s_bv[j + u];
+                        dv[u] = pv - s_bv[js[u]];
                     }
                     int l[4];
 #pragma unroll
@@ -440,7 +435,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     for (int j = 0; j < PT; j += 4) {
                         int lu[4];
                         T dv[4];
-                        classify4(j, lu, dv);
+                        const int js[4] = {j, j + 1, j + 2, j + 3};
+                        classify4(js, lu, dv);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const double dd = (double)dv[u];
@@ -460,12 +456,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 }
                 auto run4 = [&](auto plain_tag) {
                     constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
-                    const int jend = spread ? jslot + n_sampled : (sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt);
-                    const int cnt_m = spread ? jend : cnt;   // slots at or beyond this hold no point of the tile
+                    const int jend = spread ? jslot + 4 : (sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt);
+                    const int cnt_m = cnt;   // slots at or beyond this hold no point of the tile
                     for (int j = jslot; j < jend; j += 4) {
                         int lus[4];
                         T dv[4];
-                        classify4(j, lus, dv);
+                        int js[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) js[u] = spread ? ((hslot + (tid & 63) + 64 * u) & (PT - 1)) : j + u;
+                        classify4(js, lus, dv);
                         if constexpr (OP == OP_BRACKET) {
                             const int cp = tid & (NCOPY - 1);
                             static_assert(NCOPY * 4 == 128, "counter records are 128 bytes");
@@ -478,7 +477,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 // everything that is no pair goes to the spare class nb (the class lookup itself never exceeds nb:
                                 // "beyond the last edge" IS class nb, so full tiles need no test at all)
                                 if constexpr (PLAIN) lc[u] = lus[u];
-                                else lc[u] = ((j + u) < cnt_m && (j + u) > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
+                                else lc[u] = (js[u] < cnt_m && js[u] > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
                                 lo4[u] = s_lh[2 * lc[u]];
                                 hi4[u] = s_lh[2 * lc[u] + 1];
                             }
@@ -523,7 +522,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             const int lu = lus[u];
                             dv[u] = dv[u] < 0 ? -dv[u] : dv[u];
                             const T d = dv[u];
-                            const bool ok = (PLAIN || ((j + u) < cnt_m && (j + u) > ia_rel && d == d)) && lu < nb;
+                            const bool ok = (PLAIN || (js[u] < cnt_m && js[u] > ia_rel && d == d)) && lu < nb;
                             if (OP == OP_BRACKET) {
                                 bracket_pair(ok, lu, d);
                             } else if (ok) {
@@ -549,8 +548,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 else run4(std::false_type());
                 if (OP == OP_BRACKET) flush_pending();  // (a tile's pair count need not be a multiple of 8)
             } else {
-                const int jend = spread ? jslot + n_sampled : (sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt);
-                for (int j = jslot; j < jend; ++j) pair(j, have_a && (!a.pdist || (j0 + j) > ia));
+                if (spread) {
+                    for (int u = 0; u < 4; ++u) {
+                        const int sj = (hslot + (tid & 63) + 64 * u) & (PT - 1);
+                        pair(sj, have_a && sj < cnt);
+                    }
+                } else {
+                    const int jend = sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt;
+                    for (int j = jslot; j < jend; ++j) pair(j, have_a && (!a.pdist || (j0 + j) > ia));
+                }
             }
         }
     if ((OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && run_c) {   // the open run of every lane
@@ -1044,7 +1050,7 @@ template <typename T> __host__ inline T abs_key_value(typename KeyT<T>::type key
 // histograms go through the all-reduce hook, so sharded pair sets select the same global order statistics.
 template <typename T>
 int pairs_digit_passes(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st, int sample, int mode, const uint64_t* d_given,
-                       std::vector<SelState<typename KeyT<T>::type>>& out, int n_passes = 0) {
+                       std::vector<SelState<typename KeyT<T>::type>>& out, int n_passes = 0, uint32_t wide_deff = PAIR_DEFF_WIDE) {
     typedef typename KeyT<T>::type K;
     xdemhip_ctx* ctx = P->ctx;
     const int nb = P->nb, passes = KeyT<T>::passes;
@@ -1063,7 +1069,7 @@ int pairs_digit_passes(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st,
         int rc = xd_allreduce_device(ctx, P->hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
         if (rc) { P->sample = 0; return rc; }
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, d_st, reinterpret_cast<uint64_t*>(P->hist), nb,
-                           shift, (int)(p == 0), (int)(p == passes - 1), mode, d_given);
+                           shift, (int)(p == 0), (int)(p == passes - 1), mode, d_given, (const uint32_t*)nullptr, wide_deff);
         hipLaunchKernelGGL((extract_prefix_kernel<K>), dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, d_st, static_cast<K*>(P->prefix), nb);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -1141,136 +1147,162 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     bool done = false;
     std::vector<K> klo(nb), khi(nb);
     std::vector<uint64_t> lo_count(nb, 0);
-    if (bracket) {
-        std::vector<SelState<K>> lo, hi;
-        constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough
-        const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
-        rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo, BR_PASSES);
-        if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi, BR_PASSES);
-        if (rc) { cleanup(); return rc; }
-        phase("sampled digit passes");
-        double expected = 0.0;  // candidates the brackets should hold: 64 x their width in sample ranks, at most the class
-        for (int k = 0; k < nb; ++k) {
-            const bool have = lo[k].count > 0;
-            lo_count[k] = lo[k].count;
-            klo[k] = have ? lo[k].prefix : (K)0;
-            khi[k] = have ? (K)(hi[k].prefix | low_mask) : (K)~(K)0;
-            if (ctx->selection_mode == 2 && have) khi[k] = klo[k];  // test mode: brackets that (almost surely) miss
-            const double m = (double)lo[k].count, w = 2.0 * (double)sel_bracket_halfwidth_wide(lo[k].count) + 2.0;
-            expected += 64.0 * (w < m ? w : m);
+    // Design effect assumed for the sample (select.h): every-a-with-every-b blocks are sampled with per-lane B slots (few pairs
+    // per point), i < j blocks with 4 B slots against all A points; option "vario_deff" overrides (tests, measurements).  A
+    // bracket that misses its rank (the integer counts tell) costs one more attempt with the wide brackets before the plain
+    // digit passes take over; with a reduction hook the counts are global, so every rank retries alike.
+    uint32_t deff = ctx->vario_deff > 0 ? (uint32_t)ctx->vario_deff : (P->pdist ? PAIR_DEFF_WIDE : PAIR_DEFF_SPREAD);
+    for (int attempt = 0; attempt < 2 && bracket && !done; ++attempt) {
+        if (attempt == 1) {
+            if (deff >= PAIR_DEFF_WIDE) break;
+            deff = PAIR_DEFF_WIDE;
+            if (dbg) fprintf(stderr, "[xdemhip] pair medians: second attempt with the wide brackets\n");
         }
-        // candidate buffers sized from the brackets (x1.5 + slack), not from the pair count: 5e13 pairs (SURVEY 8d, C5 reading
-        // A) need ~2e10 slots, not n_pairs / 64.  Too little memory (on any rank): plain passes.
-        {
-            const double want = expected * 1.5 + (double)(1 << 20);
-            const double most = (double)P->n_pairs + 1024.0;
-            const long long need = (long long)(want < most ? want : most);
-            uint64_t got = 1;
-            if (P->cand_cap < need) {
-                if (P->cand_v) (void)hipFree(P->cand_v);
-                if (P->cand_b) (void)hipFree(P->cand_b);
-                P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0;
-                if (hipMalloc(&P->cand_v, (size_t)need * sizeof(T)) != hipSuccess ||
-                    hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)need * 2) != hipSuccess) {
-                    (void)hipGetLastError();
-                    got = 0;
-                } else {
-                    P->cand_cap = need;
+        if (bracket) {
+            std::vector<SelState<K>> lo, hi;
+            constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough
+            const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
+            rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo, BR_PASSES, deff);
+            if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi, BR_PASSES, deff);
+            if (rc) { cleanup(); return rc; }
+            phase("sampled digit passes");
+            double expected = 0.0;  // candidates the brackets should hold: 64 x their width in sample ranks, at most the class
+            for (int k = 0; k < nb; ++k) {
+                const bool have = lo[k].count > 0;
+                lo_count[k] = lo[k].count;
+                klo[k] = have ? lo[k].prefix : (K)0;
+                khi[k] = have ? (K)(hi[k].prefix | low_mask) : (K)~(K)0;
+                if (ctx->selection_mode == 2 && have) khi[k] = klo[k];  // test mode: brackets that (almost surely) miss
+                const double m = (double)lo[k].count, w = 2.0 * (double)sel_bracket_halfwidth_wide(lo[k].count, deff) + 2.0;
+                expected += 64.0 * (w < m ? w : m);
+            }
+            // candidate buffers sized from the brackets (x1.5 + slack), not from the pair count: 5e13 pairs (SURVEY 8d, C5 reading
+            // A) need ~2e10 slots, not n_pairs / 64.  Too little memory (on any rank): plain passes.
+            {
+                const double want = expected * 1.5 + (double)(1 << 20);
+                const double most = (double)P->n_pairs + 1024.0;
+                const long long need = (long long)(want < most ? want : most);
+                uint64_t got = 1;
+                if (P->cand_cap < need) {
+                    if (P->cand_v) (void)hipFree(P->cand_v);
+                    if (P->cand_b) (void)hipFree(P->cand_b);
+                    P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0;
+                    if (hipMalloc(&P->cand_v, (size_t)need * sizeof(T)) != hipSuccess ||
+                        hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)need * 2) != hipSuccess) {
+                        (void)hipGetLastError();
+                        got = 0;
+                    } else {
+                        P->cand_cap = need;
+                    }
+                }
+                if (ctx->allreduce && ctx->allreduce(&got, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) {
+                    cleanup();
+                    return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
+                }
+                if (!got) {
+                    if (P->cand_v) (void)hipFree(P->cand_v);
+                    if (P->cand_b) (void)hipFree(P->cand_b);
+                    P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0;
+                    bracket = false;
                 }
             }
-            if (ctx->allreduce && ctx->allreduce(&got, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) {
-                cleanup();
-                return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
-            }
-            if (!got) {
-                if (P->cand_v) (void)hipFree(P->cand_v);
-                if (P->cand_b) (void)hipFree(P->cand_b);
-                P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0;
-                bracket = false;
-            }
         }
-    }
-    phase("candidate buffers");
-    if (bracket) {
-        K* d_klo = reinterpret_cast<K*>(d_small + off_klo);
-        K* d_khi = reinterpret_cast<K*>(d_small + off_khi);
-        uint64_t* d_given = reinterpret_cast<uint64_t*>(d_small + off_given);
-        P->cnt3 = reinterpret_cast<unsigned long long*>(d_small + off_cnt);
-        P->cand_ctr = reinterpret_cast<unsigned long long*>(d_small + off_ctr);
-        P->khi = d_khi;
-        hipError_t e = hipMemcpyAsync(P->prefix, klo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_khi, khi.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_small + off_cnt, 0, 24 * (size_t)nb + 16, ctx->stream);
-        // candidate keys are rebased for their selection (select_run.h, hist_pass_kernel): low ends and the common shift
-        // in key_of()'s key space (|dv| >= 0: key = bits | top bit; the pair passes use bits << 1)
-        const K top = (K)1 << (8 * sizeof(K) - 1);
-        std::vector<K> rb_lo(nb);
-        K widest = 0;
-        for (int k = 0; k < nb; ++k) {
-            rb_lo[k] = (K)((klo[k] >> 1) | top);
-            const K r = khi[k] >= klo[k] ? (K)((khi[k] >> 1) - (klo[k] >> 1)) : (K)0;
-            widest = r > widest ? r : widest;
-        }
-        const uint32_t rbs = rebase_shift_of(widest);
-        uint32_t* d_rbs = reinterpret_cast<uint32_t*>(d_small + off_rbs);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_klo, rb_lo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_rbs, &rbs, 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket setup failed"); }
-        if (P->n_wg_big > 0) {
-            XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-            rc = launch_pairs<T, OP_BRACKET>(P, 0, 0, 0, 0);
-            (void)hipEventRecord(ctx->ev_stop, ctx->stream);
-            ctx->timed = rc == XDEMHIP_OK;
-        }
-        if (rc == XDEMHIP_OK) rc = xd_allreduce_device(ctx, P->cnt3, 3 * (int64_t)nb, XDEMHIP_RED_SUM_U64);
-        if (rc == XDEMHIP_OK) rc = xd_allreduce_device(ctx, P->cand_ctr + 1, 1, XDEMHIP_RED_SUM_U64);
-        if (rc) { cleanup(); return rc; }
-        std::vector<uint64_t> cnt(3 * nb);
-        uint64_t ctr[2];
-        e = hipMemcpyAsync(cnt.data(), P->cnt3, 24 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ctr, P->cand_ctr, 16, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, std::string("bracket pass failed: ") + hipGetErrorString(e)); }
-        phase("counting + compaction pass");
-        if (dbg) fprintf(stderr, "[xdemhip] pair medians: %llu candidates (%.2f %% of the pairs)\n", (unsigned long long)ctr[0], 100.0 * (double)ctr[0] / (double)P->n_pairs);
-        bool ok = ctr[1] == 0;
-        std::vector<uint64_t> given(nb);
-        for (int k = 0; k < nb; ++k) cnt[k] += cnt[nb + k];  // class total = (keys >= low end) + (keys below it)
-        for (int k = 0; k < nb && ok; ++k) {
-            const uint64_t total = cnt[k], lt = cnt[nb + k], in = cnt[2 * nb + k];
-            given[k] = ~(uint64_t)0;
-            if (total == 0) continue;
-            const uint64_t r = (total - 1) / 2;
-            const uint64_t need = (total & 1) ? r : r + 1;
-            if (lt > r || need - lt >= in) {
-                ok = false;
-                if (getenv("XDEMHIP_DEBUG"))
-                    fprintf(stderr, "[xdemhip] pair medians: bracket of class %d missed (total %llu, below %llu, inside %llu, rank %llu, sample %llu)\n",
-                            k, (unsigned long long)total, (unsigned long long)lt, (unsigned long long)in, (unsigned long long)r,
-                            (unsigned long long)lo_count[k]);
-            } else given[k] = r - lt;
-        }
-        if (!ok && getenv("XDEMHIP_DEBUG")) fprintf(stderr, "[xdemhip] pair medians: candidate overflow flag %llu, candidates %llu of %lld\n",
-                                                   (unsigned long long)ctr[1], (unsigned long long)ctr[0], (long long)P->cand_cap);
-        if (ok) {
-            e = hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket ranks upload failed"); }
-            std::vector<SelResult<K>> res;
-            rc = select_enqueue<T>(ctx, static_cast<const T*>(P->cand_v), P->cand_b, (int64_t)ctr[0], (int64_t)ctr[0], nullptr, nb,
-                                   static_cast<unsigned char*>(scratch), SEL_GIVEN, d_given, 0, true, d_klo, d_rbs);
-            if (rc == XDEMHIP_OK) rc = select_fetch<T>(ctx, static_cast<unsigned char*>(scratch), nb, res);
-            if (rc) { cleanup(); return rc; }
-            phase("selection among candidates");
+        phase("candidate buffers");
+        if (bracket) {
+            K* d_klo = reinterpret_cast<K*>(d_small + off_klo);
+            K* d_khi = reinterpret_cast<K*>(d_small + off_khi);
+            uint64_t* d_given = reinterpret_cast<uint64_t*>(d_small + off_given);
+            P->cnt3 = reinterpret_cast<unsigned long long*>(d_small + off_cnt);
+            P->cand_ctr = reinterpret_cast<unsigned long long*>(d_small + off_ctr);
+            P->khi = d_khi;
+            hipError_t e = hipMemcpyAsync(P->prefix, klo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_khi, khi.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_small + off_cnt, 0, 24 * (size_t)nb + 16, ctx->stream);
+            // candidate keys are rebased for their selection (select_run.h, hist_pass_kernel): low ends and the common shift
+            // in key_of()'s key space (|dv| >= 0: key = bits | top bit; the pair passes use bits << 1)
+            const K top = (K)1 << (8 * sizeof(K) - 1);
+            std::vector<K> rb_lo(nb);
+            K widest = 0;
             for (int k = 0; k < nb; ++k) {
-                counts[k] = (int64_t)cnt[k];
-                if (cnt[k] == 0) { medians[k] = NAN; continue; }
-                res[k].st.count = cnt[k];
-                res[k].st.n_le += cnt[nb + k];
-                res[k].st.prefix = (K)((K)(res[k].st.prefix >> rbs) + rb_lo[k]);  // back from the rebased keys
-                if (res[k].succ != ~(uint64_t)0) res[k].succ = (uint64_t)(K)((K)((K)res[k].succ >> rbs) + rb_lo[k]);
-                medians[k] = median_from<T>(res[k]);
+                rb_lo[k] = (K)((klo[k] >> 1) | top);
+                const K r = khi[k] >= klo[k] ? (K)((khi[k] >> 1) - (klo[k] >> 1)) : (K)0;
+                widest = r > widest ? r : widest;
             }
-            done = true;
+            const uint32_t rbs = rebase_shift_of(widest);
+            uint32_t* d_rbs = reinterpret_cast<uint32_t*>(d_small + off_rbs);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_klo, rb_lo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_rbs, &rbs, 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket setup failed"); }
+            if (P->n_wg_big > 0) {
+                XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+                rc = launch_pairs<T, OP_BRACKET>(P, 0, 0, 0, 0);
+                (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+                ctx->timed = rc == XDEMHIP_OK;
+            }
+            if (rc == XDEMHIP_OK) rc = xd_allreduce_device(ctx, P->cnt3, 3 * (int64_t)nb, XDEMHIP_RED_SUM_U64);
+            if (rc == XDEMHIP_OK) rc = xd_allreduce_device(ctx, P->cand_ctr + 1, 1, XDEMHIP_RED_SUM_U64);
+            if (rc) { cleanup(); return rc; }
+            std::vector<uint64_t> cnt(3 * nb);
+            uint64_t ctr[2];
+            e = hipMemcpyAsync(cnt.data(), P->cnt3, 24 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctr, P->cand_ctr, 16, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, std::string("bracket pass failed: ") + hipGetErrorString(e)); }
+            phase("counting + compaction pass");
+            if (dbg) fprintf(stderr, "[xdemhip] pair medians: %llu candidates (%.2f %% of the pairs)\n", (unsigned long long)ctr[0], 100.0 * (double)ctr[0] / (double)P->n_pairs);
+            bool ok = ctr[1] == 0;
+            std::vector<uint64_t> given(nb);
+            for (int k = 0; k < nb; ++k) cnt[k] += cnt[nb + k];  // class total = (keys >= low end) + (keys below it)
+            if (dbg) {  // how far from the bracket's centre the wanted rank lies, in half widths (1 = the bracket just missed)
+                double worst = 0.0, sum2 = 0.0;
+                int nn = 0, kw = -1;
+                for (int k = 0; k < nb; ++k) {
+                    const double total = (double)cnt[k], lt = (double)cnt[nb + k], in = (double)cnt[2 * nb + k];
+                    if (total < 1.0 || in < 1.0 || lo_count[k] == 0) continue;
+                    if (in >= total) continue;  // the bracket holds the whole class
+                    const double off = fabs(((total - 1.0) * 0.5 - lt) - 0.5 * in) / (0.5 * in);
+                    sum2 += off * off; ++nn;
+                    if (off > worst) { worst = off; kw = k; }
+                }
+                fprintf(stderr, "[xdemhip] pair medians: wanted rank off the bracket centre by %.3f half widths at worst (class %d), rms %.3f over %d classes\n",
+                        worst, kw, nn ? sqrt(sum2 / nn) : 0.0, nn);
+            }
+            for (int k = 0; k < nb && ok; ++k) {
+                const uint64_t total = cnt[k], lt = cnt[nb + k], in = cnt[2 * nb + k];
+                given[k] = ~(uint64_t)0;
+                if (total == 0) continue;
+                const uint64_t r = (total - 1) / 2;
+                const uint64_t need = (total & 1) ? r : r + 1;
+                if (lt > r || need - lt >= in) {
+                    ok = false;
+                    if (getenv("XDEMHIP_DEBUG"))
+                        fprintf(stderr, "[xdemhip] pair medians: bracket of class %d missed (total %llu, below %llu, inside %llu, rank %llu, sample %llu)\n",
+                                k, (unsigned long long)total, (unsigned long long)lt, (unsigned long long)in, (unsigned long long)r,
+                                (unsigned long long)lo_count[k]);
+                } else given[k] = r - lt;
+            }
+            if (!ok && getenv("XDEMHIP_DEBUG")) fprintf(stderr, "[xdemhip] pair medians: candidate overflow flag %llu, candidates %llu of %lld\n",
+                                                       (unsigned long long)ctr[1], (unsigned long long)ctr[0], (long long)P->cand_cap);
+            if (ok) {
+                e = hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream);
+                if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket ranks upload failed"); }
+                std::vector<SelResult<K>> res;
+                rc = select_enqueue<T>(ctx, static_cast<const T*>(P->cand_v), P->cand_b, (int64_t)ctr[0], (int64_t)ctr[0], nullptr, nb,
+                                       static_cast<unsigned char*>(scratch), SEL_GIVEN, d_given, 0, true, d_klo, d_rbs);
+                if (rc == XDEMHIP_OK) rc = select_fetch<T>(ctx, static_cast<unsigned char*>(scratch), nb, res);
+                if (rc) { cleanup(); return rc; }
+                phase("selection among candidates");
+                for (int k = 0; k < nb; ++k) {
+                    counts[k] = (int64_t)cnt[k];
+                    if (cnt[k] == 0) { medians[k] = NAN; continue; }
+                    res[k].st.count = cnt[k];
+                    res[k].st.n_le += cnt[nb + k];
+                    res[k].st.prefix = (K)((K)(res[k].st.prefix >> rbs) + rb_lo[k]);  // back from the rebased keys
+                    if (res[k].succ != ~(uint64_t)0) res[k].succ = (uint64_t)(K)((K)((K)res[k].succ >> rbs) + rb_lo[k]);
+                    medians[k] = median_from<T>(res[k]);
+                }
+                done = true;
+            }
         }
     }
     if (!done) { rc = pairs_medians_plain<T>(P, d_st, counts, medians); phase("plain digit passes"); }
