@@ -66,8 +66,13 @@ template <typename T> struct PairArgs {
     const typename KeyT<T>::type* prefix;  // [nb] selection prefix (hist) or selected key (succ)
     unsigned long long* succ;              // [nb] 8-byte slots, all-ones = none
     int shift, first, bin0, nbs;   // hist digit, first pass flag, LDS sweep window [bin0, bin0 + nbs)
-    int64_t wg_base;               // first workgroup of this launch (a pass over very many tiles takes several launches)
+    int64_t wg_base, wg_end;       // units [wg_base, wg_end) belong to this launch (a pass over very many tiles takes several launches)
     int sample;                    // OP_HIST: only the pseudo-randomly chosen 1/64 of the (A tile x B tile) units
+    // OP_HIST, dual: TWO selection states per class advance in the same pass (both ends of a bracket): a second prefix array and
+    // a second histogram; an element is counted under each prefix it matches
+    int dual;
+    const typename KeyT<T>::type* prefix2;
+    unsigned long long* hist2;
     int has_nan;                   // some value is NaN (unknown for device-resident inputs: assumed): full tiles keep the NaN test
     // OP_BRACKET (bracketed selection, select_run.h): keys in [prefix[k], khi[k]] are candidates
     const typename KeyT<T>::type* khi;
@@ -84,7 +89,9 @@ template <typename T> struct PairArgs {
 // medians -- were too noisy for any affordable bracket.)
 //  * every-a-with-every-b blocks: thread t (A point t of the tile) takes the four B slots (h + lane + 64 u) mod 256, u = 0..3, h
 //    hashed from the unit: the 4096 sampled pairs of a unit use each of its 1024 A points 4 times and each of its 256 B points 16
-//    times.  (The first form of this round took 4 B slots for ALL A points: 1024 pairs per sampled B point, and since |v_a - v_b|
+//    times.  EVERY tile takes part: sampling every 4th tile with 16 slots per lane (a quarter of the tile loads and barriers
+//    for the same pairs) was measured -- the wanted ranks then sat 0.63 half widths off the bracket centres instead of 0.04: B
+//    points arrive ring by ring, a tile is one distance class of one block, and the class mixtures over the blocks get noisy.  (The first form of this round took 4 B slots for ALL A points: 1024 pairs per sampled B point, and since |v_a - v_b|
 //    of a correlated field moves with v_b for all of them at once, a class of 8.5e7 sampled pairs behaved like 2e4 independent
 //    draws -- brackets 8 x wider, 5 % of all pairs candidates.)
 //  * i < j blocks keep 4 adjacent slots [4 h, 4 h + 4) against all A points (the diagonal test needs the uniform slot index) and
@@ -190,8 +197,12 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), term);
         atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), 1u);
     };
+    // (the first digit's histogram is the same for both states: only table A is filled, the host copies it)
+    const bool dual = OP == OP_HIST && a.dual && !a.first;
     if (OP == OP_HIST)
-        for (int k = tid; k < a.nbs * SEL_RADIX; k += NT) s_hist[k] = 0;
+        for (int k = tid; k < a.nbs * SEL_RADIX * (dual ? 2 : 1); k += NT) s_hist[k] = 0;
+    if (dual)
+        for (int k = tid; k < a.nb; k += NT) s_khi[k] = a.prefix2[k];
     if (OP == OP_SUCC)
         for (int k = tid; k < a.nb; k += NT) s_min[k] = ~(K)0;
     if ((OP == OP_HIST && !a.first) || OP == OP_SUCC || OP == OP_BRACKET)
@@ -209,356 +220,415 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         if (tid == 0) *stage.held = 0;
     }
 
-    // which block / A tile / B chunk is this workgroup?
-    const int64_t wg = a.wg_base + blockIdx.x;
-    int lo = 0, hi = a.nblk;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.wg_off[mid] <= wg) lo = mid; else hi = mid;
-    }
-    const int r = lo;
-    const int64_t a0 = a.a_off[r], na = a.a_off[r + 1] - a0;
-    const int64_t b0 = a.pdist ? a0 : a.b_off[r], nbp = a.pdist ? na : a.b_off[r + 1] - b0;
-    const int64_t nchunk = (nbp + BCHUNK - 1) / BCHUNK;
-    const int64_t local = wg - a.wg_off[r];
-    const int64_t ta = local / nchunk, cb = local - ta * nchunk;
-    const int64_t ia = ta * NT + tid;  // index inside the block's A set
-    const int64_t jb0 = cb * BCHUNK, jb1 = (jb0 + BCHUNK < nbp) ? jb0 + BCHUNK : nbp;
-    const bool have_a = ia < na;
-    const bool skip_wg = a.pdist && (jb1 <= ta * NT + 1);  // whole chunk at or below the diagonal: no i < j pair
-    double px = 0.0, py = 0.0;
-    T pv = 0;
-    uint32_t pxy = 0;
-    if (have_a) {
-        if (GRID) pxy = a.a_xy[a0 + ia];
-        else { px = a.ax[a0 + ia]; py = a.ay[a0 + ia]; }
-        pv = a.av[a0 + ia];
-    }
-    const double* gbx = a.pdist ? a.ax : a.bx;
-    const double* gby = a.pdist ? a.ay : a.by;
-    const uint32_t* gbxy = a.pdist ? a.a_xy : a.b_xy;
-    const T* gbv = a.pdist ? a.av : a.bv;
     const int nb = a.nb;
     const K himask = (OP == OP_HIST && !a.first) ? (K)(~(K)0 << (a.shift + 8)) : (K)0;
-
-    // OP_BRACKET, fast path: a lane keeps at most ONE candidate pending in registers; every 8 pairs the wave moves its pending
-    // candidates into the staging buffer with one LDS reservation (the per-pair form -- ballot, leader atomic with return and
-    // its round trip whenever any lane of the wave had a candidate, i.e. for half of all wave-pairs -- was most of the 22
-    // vector instructions per pair this pass spent beyond the class lookup).  A second candidate while one is pending (a few
-    // per thousand lane-octets) is appended directly.
-    // OP_SUMS, full tiles: RUN-LENGTH accumulation.  The point sets are uploaded in Morton order (PairSet: neighbouring slots are
-    // neighbouring points), so consecutive B points of a tile mostly fall into the same lag class of a lane's A point: the lane
-    // keeps the running sum and count of its current class in registers and touches the LDS record -- two atomics -- only when
-    // the class changes.  (Round 2 paid both atomics for every pair and the LDS array was busy for the whole kernel.)
     int run_l = a.nb;          // spare class: flushing the empty initial run adds (0, 0) to the record nobody reads
     double run_s = 0.0;
     uint32_t run_c = 0;
-    T pend_v = (T)0;
-    uint32_t pend_l = 0;
-    unsigned long long pend_m = 0;  // lanes with a pending candidate (wave-uniform scalar)
-    // Candidates that find the staging buffer full go straight to the global candidate buffer, one global atomic per wave and
-    // call.  (Values of a spatially correlated field cluster: all 262144 pairs of a tile -- 1024 neighbouring A points x 256 B
-    // points -- can fall into a class's bracket at once, far more than the 8192 staging slots a tile may fill; round 2's "flag
-    // an overflow and redo everything with plain passes" made the C5 input of SURVEY 8d five times slower than uniform noise.)
-    auto spill = [&](bool mine, T v, uint32_t l) {   // every lane of the wave calls this
-        const unsigned long long ov = __builtin_amdgcn_ballot_w64(mine);
-        if (!ov) return;
-        const int lane = tid & 63;
-        const int leader = __ffsll((long long)ov) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&a.cand_ctr[0], (unsigned long long)__popcll(ov));
-        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
-               (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (mine) {
-            const unsigned long long pos = base + (unsigned long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(ov >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ov, 0u));
-            if ((long long)pos < a.cand_cap) { a.cand_v[pos] = v; a.cand_b[pos] = (uint16_t)l; }
-            else a.cand_ctr[1] = 1ull;
+    // One workgroup = one (A tile x B chunk) unit, except in the SAMPLED digit passes: there a unit is 16 tile loads and 16 k pairs,
+    // while zeroing and flushing the [classes][256] LDS tables costs ~25 k LDS writes and thousands of global atomics -- a
+    // resident set of workgroups therefore walks over all units (grid-stride) and flushes once.
+    __syncthreads();   // the tables above are complete (the barrier-free sampled path below reads them at once)
+    for (int64_t wg = a.wg_base + blockIdx.x; wg < a.wg_end; wg += gridDim.x) {
+        // which block / A tile / B chunk is this unit?
+        int lo = 0, hi = a.nblk;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.wg_off[mid] <= wg) lo = mid; else hi = mid;
         }
-    };
-    auto flush_pending = [&]() {
-        const unsigned long long m = pend_m;
-        if (m) {  // (wave-uniform)
-            const int lane = tid & 63;
-            const int leader = __ffsll((long long)m) - 1;
-            int pos0 = 0;
-            if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(m));
-            pos0 = __builtin_amdgcn_readlane(pos0, leader);
-            const bool has = (m >> lane) & 1ull;
-            const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (has && pos < SEL_STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
-            if (__builtin_expect(pos0 + __popcll(m) > SEL_STAGE_CAP, 0)) spill(has && pos >= SEL_STAGE_CAP, pend_v, pend_l);   // (wave-uniform test)
-            pend_m = 0;
+        const int r = lo;
+        const int64_t a0 = a.a_off[r], na = a.a_off[r + 1] - a0;
+        const int64_t b0 = a.pdist ? a0 : a.b_off[r], nbp = a.pdist ? na : a.b_off[r + 1] - b0;
+        const int64_t nchunk = (nbp + BCHUNK - 1) / BCHUNK;
+        const int64_t local = wg - a.wg_off[r];
+        const int64_t ta = local / nchunk, cb = local - ta * nchunk;
+        const int64_t ia = ta * NT + tid;  // index inside the block's A set
+        const int64_t jb0 = cb * BCHUNK, jb1 = (jb0 + BCHUNK < nbp) ? jb0 + BCHUNK : nbp;
+        const bool have_a = ia < na;
+        const bool skip_wg = a.pdist && (jb1 <= ta * NT + 1);  // whole chunk at or below the diagonal: no i < j pair
+        double px = 0.0, py = 0.0;
+        T pv = 0;
+        uint32_t pxy = 0;
+        if (have_a) {
+            if (GRID) pxy = a.a_xy[a0 + ia];
+            else { px = a.ax[a0 + ia]; py = a.ay[a0 + ia]; }
+            pv = a.av[a0 + ia];
         }
-    };
-    if (!skip_wg)
-        for (int64_t j0 = jb0; j0 < jb1; j0 += PT) {
-            // sampled pass: only slots [jbeg, jend) of this tile (uniform over the workgroup)
-            const bool sampled = OP == OP_HIST && a.sample;
-            const int jslot = sampled ? 4 * unit_sample_slot(wg, (int)((j0 - jb0) / PT)) : 0;
-            if (OP == OP_BRACKET)  // (starts with the barrier the tile reload needs); flush the staged candidates when half full
-                stage.sync_and_flush_at(SEL_STAGE_CAP / 2, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
-            else
-                __syncthreads();
-            const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
-            // sampled pass over every-a-with-every-b blocks: per-lane slots (see unit_sample_slot), the whole tile is loaded
-            const bool spread = sampled && !a.pdist;
-            const int hslot = jslot >> 2;
-            if (tid < cnt) {
-                if (GRID) s_bxy[tid] = gbxy[b0 + j0 + tid];
-                else { s_bx[tid] = gbx[b0 + j0 + tid]; s_by[tid] = gby[b0 + j0 + tid]; }
-                s_bv[tid] = gbv[b0 + j0 + tid];
-            }
-            __syncthreads();
-            if (!have_a && OP != OP_BRACKET) continue;   // (OP_BRACKET: every thread stays for the mid-tile flush barriers)
-            // OP_BRACKET, one pair: counters + staged candidate (every lane of the wave must reach the append)
-            auto bracket_pair = [&](bool ok, int l, T d) {
-                bool cand = false;
-                if (ok) {
-                    const K key = key_abs(d);
-                    const int cp = tid & (NCOPY - 1);
-                    // one counter update per pair: plane 0 below the bracket, 1 inside it, 2 above it
-                    const bool below = key < s_pref[l];
-                    cand = !below && key <= s_khi[l];
-                    atomicAdd(&s_c3[((below ? 0 : (cand ? 1 : 2)) * (nb + 1) + l) * NCOPY + cp], 1u);
-                }
-                {   // staged append (one LDS reservation per wave); what does not fit the staging buffer spills to global memory
-                    const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
-                    if (cm) {
-                        const int lane = tid & 63, leader = __ffsll((long long)cm) - 1;
-                        int pos0 = 0;
-                        if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(cm));
-                        pos0 = __builtin_amdgcn_readlane(pos0, leader);
-                        const int pos = pos0 + __popcll(cm & ((1ull << lane) - 1ull));
-                        if (cand && pos < SEL_STAGE_CAP) { stage.v[pos] = d; stage.b[pos] = (uint16_t)l; }
-                        if (pos0 + __popcll(cm) > SEL_STAGE_CAP) spill(cand && pos >= SEL_STAGE_CAP, d, (uint32_t)l);
-                    }
-                }
-            };
-            // One pair: class lookup + accumulate.  `ok` folds every skip rule so the fast path stays branch-free
-            // up to the (exec-masked) LDS atomics.
-            auto pair = [&](int j, bool ok) {
-                const double dx = px - s_bx[j], dy = py - s_by[j];
-                const double s2 = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
-                int l;  // class = number of thresholds <= s2
-                if (FAST) {
-                    // 1/8-binade cell of s2 -> class lower bound; only cells that contain a threshold (1 in 8 for the
-                    // reference's sqrt(2)-geometric edges) need the one exact compare against it
-                    int e = (int)((unsigned long long)__double_as_longlong(s2) >> 49) - a.lut_emin;
-                    e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
-                    const int c = s_lut[e];
-                    l = c >> 1;
-                    if (c & 1) l += (s_thr[l] <= s2) ? 1 : 0;
-                } else {
-                    l = 0;
-                    int h = nb;
-                    while (l < h) {
-                        const int m = (l + h) >> 1;
-                        if (s_thr[m] <= s2) l = m + 1; else h = m;
-                    }
-                }
-                T d = pv - s_bv[j];
-                d = d < 0 ? -d : d;
-                ok = ok && (l < nb) && (d == d);  // beyond the last edge (maxlag) / NaN values never form a pair
-                if (OP == OP_BRACKET) { bracket_pair(ok, l, d); return; }
-                if (!ok) return;
-                if (OP == OP_SUMS_SQ) {
-                    rec_add(l, (double)d * (double)d);
-                } else if (OP == OP_SUMS_SQRT) {
-                    rec_add(l, sqrt((double)d));
-                } else if (OP == OP_HIST) {
-                    const int lb = l - a.bin0;
-                    if (lb < 0 || lb >= a.nbs) return;
-                    const K key = key_abs(d);
-                    if (!a.first && (key & himask) != s_pref[l]) return;
-                    atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
-                } else if (OP == OP_SUCC) {
-                    const K key = key_abs(d);
-                    if (key > s_pref[l] && key < s_min[l]) lds_min<K>(&s_min[l], key);
-                }
-            };
+        const double* gbx = a.pdist ? a.ax : a.bx;
+        const double* gby = a.pdist ? a.ay : a.by;
+        const uint32_t* gbxy = a.pdist ? a.a_xy : a.b_xy;
+        const T* gbv = a.pdist ? a.av : a.bv;
 
-            // classes of the 4 pairs (this lane's A point) x (tile slots j .. j + 3) and their raw value differences, written
-            // stage by stage so that the B-point reads, the table reads and the threshold reads are each issued back to back
-            auto classify4 = [&](const int (&js)[4], int (&lu)[4], T (&dv)[4]) {
-                if constexpr (GRID) {
-                    uint32_t d2[4];
+        // OP_BRACKET, fast path: a lane keeps at most ONE candidate pending in registers; every 8 pairs the wave moves its pending
+        // candidates into the staging buffer with one LDS reservation (the per-pair form -- ballot, leader atomic with return and
+        // its round trip whenever any lane of the wave had a candidate, i.e. for half of all wave-pairs -- was most of the 22
+        // vector instructions per pair this pass spent beyond the class lookup).  A second candidate while one is pending (a few
+        // per thousand lane-octets) is appended directly.
+        // OP_SUMS, full tiles: RUN-LENGTH accumulation.  The point sets are uploaded in Morton order (PairSet: neighbouring slots are
+        // neighbouring points), so consecutive B points of a tile mostly fall into the same lag class of a lane's A point: the lane
+        // keeps the running sum and count of its current class in registers and touches the LDS record -- two atomics -- only when
+        // the class changes.  (Round 2 paid both atomics for every pair and the LDS array was busy for the whole kernel.)
+        T pend_v = (T)0;
+        uint32_t pend_l = 0;
+        unsigned long long pend_m = 0;  // lanes with a pending candidate (wave-uniform scalar)
+        // Candidates that find the staging buffer full go straight to the global candidate buffer, one global atomic per wave and
+        // call.  (Values of a spatially correlated field cluster: all 262144 pairs of a tile -- 1024 neighbouring A points x 256 B
+        // points -- can fall into a class's bracket at once, far more than the 8192 staging slots a tile may fill; round 2's "flag
+        // an overflow and redo everything with plain passes" made the C5 input of SURVEY 8d five times slower than uniform noise.)
+        auto spill = [&](bool mine, T v, uint32_t l) {   // every lane of the wave calls this
+            const unsigned long long ov = __builtin_amdgcn_ballot_w64(mine);
+            if (!ov) return;
+            const int lane = tid & 63;
+            const int leader = __ffsll((long long)ov) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&a.cand_ctr[0], (unsigned long long)__popcll(ov));
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+                   (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (mine) {
+                const unsigned long long pos = base + (unsigned long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(ov >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ov, 0u));
+                if ((long long)pos < a.cand_cap) { a.cand_v[pos] = v; a.cand_b[pos] = (uint16_t)l; }
+                else a.cand_ctr[1] = 1ull;
+            }
+        };
+        auto flush_pending = [&]() {
+            const unsigned long long m = pend_m;
+            if (m) {  // (wave-uniform)
+                const int lane = tid & 63;
+                const int leader = __ffsll((long long)m) - 1;
+                int pos0 = 0;
+                if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(m));
+                pos0 = __builtin_amdgcn_readlane(pos0, leader);
+                const bool has = (m >> lane) & 1ull;
+                const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (has && pos < SEL_STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
+                if (__builtin_expect(pos0 + __popcll(m) > SEL_STAGE_CAP, 0)) spill(has && pos >= SEL_STAGE_CAP, pend_v, pend_l);   // (wave-uniform test)
+                pend_m = 0;
+            }
+        };
+        // Sampled pass over every-a-with-every-b blocks on the integer lattice, straight from global memory: a lane needs 4 B points
+        // of each tile (slots h + lane + 64 u: consecutive over the lanes, so the loads coalesce), which is not worth a 256-point
+        // LDS tile and two barriers -- that form left a workgroup waiting for one tile load at a time, 2.6 us per tile and 3.4 ms
+        // per pass.  Four tiles per trip: 16 independent pairs (32 loads) per lane in flight, no barrier, waves run on their own.
+        if constexpr (GRID && OP == OP_HIST) {
+            if (a.sample && !a.pdist) {   // (uniform over the launch)
+                const int lane = tid & 63;
+                for (int64_t j0 = jb0; j0 < jb1; j0 += 4 * PT) {
+                    uint32_t bxy[16];
+                    T bvv[16];
+                    bool okk[16];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[js[u]]);
-                        // (the three-operand form with the inline constant 0: the builtin picks v_dot2c, which needs a zeroed accumulator)
-                        asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
-                        dv[u] = pv - s_bv[js[u]];
-                    }
-                    uint2 e[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        // 1/8-binade cell of float(d2) (monotone in d2); d2 = 0 (coincident points) clamps onto the first cell
-                        const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
-                        e[u] = s_lut2[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) lu[u] = (int)e[u].x + ((e[u].y <= d2[u]) ? 1 : 0);
-                } else {
-                    double s2[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double dx = px - s_bx[js[u]], dy = py - s_by[js[u]];
-                        s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
-                        dv[u] = pv - s_bv[js[u]];
-                    }
-                    int l[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
-                        e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
-                        l[u] = s_lut[e] >> 1;
-                    }
-                    double th[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];  // next threshold above the cell's lower bound
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) lu[u] = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
-                }
-            };
-            if (FAST) {
-                // 4 pairs per trip, written stage by stage so that the 4 B-point reads, the 4 table reads and the 4
-                // threshold reads are each issued back to back (one LDS round trip per stage instead of per pair).
-                // Tile slots beyond cnt hold stale data and are masked by `ok`.
-                const int64_t rel = ia - j0;  // pdist: only B indices j > rel pair with this lane's A point
-                // (a thread without an A point -- last A tile of a block -- pairs with nothing: every slot masked)
-                const int ia_rel = !have_a ? PT : (a.pdist ? (int)(rel < -1 ? -1 : (rel > PT ? PT : rel)) : -1);
-                // Full tiles (the bulk of the pairs): every slot is a pair -- no index, diagonal, class or NaN test and no
-                // exec masking; the class beyond the last edge lands in the spare record.
-                const bool plain_tile = (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && cnt == PT && !a.has_nan &&
-                                        (!a.pdist || j0 >= (ta + 1) * (int64_t)NT);
-                if (plain_tile) {
-                    for (int j = 0; j < PT; j += 4) {
-                        int lu[4];
-                        T dv[4];
-                        const int js[4] = {j, j + 1, j + 2, j + 3};
-                        classify4(js, lu, dv);
+                    for (int t = 0; t < 4; ++t) {
+                        const int64_t jt = j0 + (int64_t)t * PT;
+                        const int h = unit_sample_slot(wg, (int)((jt - jb0) / PT));
+                        const int64_t cnt_t = jb1 - jt;   // (<= 0: no such tile)
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const double dd = (double)dv[u];
-                            if (lu[u] != run_l) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
-                                const int off = run_l * REC;
-                                atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
-                                atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_c);
-                                run_l = lu[u];
-                                run_s = 0.0;
-                                run_c = 0;
-                            }
-                            run_s = OP == OP_SUMS_SQ ? __builtin_fma(dd, dd, run_s) : run_s + sqrt(fabs(dd));
-                            run_c += 1;
+                            const int sj = (h + lane + 64 * u) & (PT - 1);
+                            const bool ok = have_a && sj < cnt_t;
+                            const int64_t src = b0 + (ok ? jt + sj : jb0);
+                            okk[4 * t + u] = ok;
+                            bxy[4 * t + u] = gbxy[src];
+                            bvv[4 * t + u] = gbv[src];
                         }
                     }
-                    continue;
-                }
-                auto run4 = [&](auto plain_tag) {
-                    constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
-                    const int jend = spread ? jslot + 4 : (sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt);
-                    const int cnt_m = cnt;   // slots at or beyond this hold no point of the tile
-                    for (int j = jslot; j < jend; j += 4) {
-                        int lus[4];
-                        T dv[4];
-                        int js[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) js[u] = spread ? ((hslot + (tid & 63) + 64 * u) & (PT - 1)) : j + u;
-                        classify4(js, lus, dv);
-                        if constexpr (OP == OP_BRACKET) {
-                            const int cp = tid & (NCOPY - 1);
-                            static_assert(NCOPY * 4 == 128, "counter records are 128 bytes");
-                            const uint32_t c3_plane = (uint32_t)(nb + 1) * NCOPY * 4;
-                            int lc[4];
-                            K lo4[4], hi4[4];
-    #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                dv[u] = fabs(dv[u]);
-                                // everything that is no pair goes to the spare class nb (the class lookup itself never exceeds nb:
-                                // "beyond the last edge" IS class nb, so full tiles need no test at all)
-                                if constexpr (PLAIN) lc[u] = lus[u];
-                                else lc[u] = (js[u] < cnt_m && js[u] > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
-                                lo4[u] = s_lh[2 * lc[u]];
-                                hi4[u] = s_lh[2 * lc[u] + 1];
-                            }
-    #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const K bits = key_abs(dv[u]) >> 1;  // (|d| has no sign bit: its raw bits order like the keys)
-                                // counter plane = (bits >= lo) + (bits > hi): 0 below the bracket, 1 inside, 2 above -- two compares,
-                                // two carry adds, one multiply-add for the address (no selects)
-                                const bool ge_lo = bits >= lo4[u], gt_hi = bits > hi4[u];
-                                // (lane masks handled as scalars: a `bool` combined in C++ comes back as a 0/1 VGPR and a compare)
-                                const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ge_lo), m_gt = __builtin_amdgcn_ballot_w64(gt_hi);
-                                const unsigned long long m_gt2 = m_ge & m_gt;  // (an empty bracket, hi < lo: everything below or above)
-                                const unsigned long long in_m = m_ge & ~m_gt;
-                                const uint32_t plane = select_by_mask(0u, 1u, m_ge) + select_by_mask(0u, 1u, m_gt2);
-                                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_c3 + cp) + ((uint32_t)lc[u] << 7) +
-                                                                      __umul24(plane, c3_plane)), 1u);
-                                const unsigned long long clash = in_m & pend_m;
-                                if (__builtin_expect(clash != 0, 0)) {  // (wave-uniform, rare: a second candidate within 8 pairs)
-                                    const bool mine = (clash >> (tid & 63)) & 1ull;
-                                    int pos = 0;
-                                    if (mine) {
-                                        pos = atomicAdd(stage.held, 1);
-                                        if (pos < SEL_STAGE_CAP) { stage.v[pos] = dv[u]; stage.b[pos] = (uint16_t)lc[u]; }
-                                    }
-                                    spill(mine && pos >= SEL_STAGE_CAP, dv[u], (uint32_t)lc[u]);
-                                }
-                                const unsigned long long take = in_m & ~pend_m;
-                                pend_v = select_by_mask(pend_v, dv[u], take);
-                                pend_l = select_by_mask(pend_l, (uint32_t)lc[u], take);
-                                pend_m |= take;
-                            }
-                            if ((j & 4) != 0) flush_pending();  // every second stage = 8 pairs
-                            // every 64 B slots (65536 pairs of the workgroup) the staged candidates leave if the buffer is a quarter full:
-                            // the brackets of spatially correlated values hold a few per cent of the pairs, a whole tile's worth
-                            // would not fit (j and cnt are uniform over the workgroup: every thread meets this barrier)
-                            if ((j & 63) == 60 && j + 4 < jend)
-                                stage.sync_and_flush_at(SEL_STAGE_CAP / 4, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
-                            continue;
+                    for (int q = 0; q < 16; ++q) {
+                        const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, bxy[q]);
+                        uint32_t d2;
+                        asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2) : "v"(d));
+                        const uint32_t cell = __float_as_uint((float)d2) >> 20;
+                        const uint2 e = s_lut2[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
+                        const int lu = (int)e.x + ((e.y <= d2) ? 1 : 0);
+                        T dd = pv - bvv[q];
+                        dd = dd < 0 ? -dd : dd;
+                        const int lb = lu - a.bin0;
+                        if (okk[q] && lu < nb && dd == dd && lb >= 0 && lb < a.nbs) {
+                            const K key = key_abs(dd);
+                            const int digit = (int)((key >> a.shift) & 0xFF);
+                            if (a.first || (key & himask) == s_pref[lu]) atomicAdd(&s_hist[lb * SEL_RADIX + digit], 1u);
+                            if (dual && (key & himask) == s_khi[lu]) atomicAdd(&s_hist[(a.nbs + lb) * SEL_RADIX + digit], 1u);
                         }
-    #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int lu = lus[u];
-                            dv[u] = dv[u] < 0 ? -dv[u] : dv[u];
-                            const T d = dv[u];
-                            const bool ok = (PLAIN || (js[u] < cnt_m && js[u] > ia_rel && d == d)) && lu < nb;
-                            if (OP == OP_BRACKET) {
-                                bracket_pair(ok, lu, d);
-                            } else if (ok) {
-                                if (OP == OP_SUMS_SQ) {
-                                    rec_add(lu, (double)d * (double)d);
-                                } else if (OP == OP_SUMS_SQRT) {
-                                    rec_add(lu, sqrt((double)d));
-                                } else if (OP == OP_HIST) {
-                                    const int lb = lu - a.bin0;
-                                    const K key = key_abs(d);
-                                    if (lb >= 0 && lb < a.nbs && (a.first || (key & himask) == s_pref[lu]))
-                                        atomicAdd(&s_hist[lb * SEL_RADIX + (int)((key >> a.shift) & 0xFF)], 1u);
-                                } else if (OP == OP_SUCC) {
-                                    const K key = key_abs(d);
-                                    if (key > s_pref[lu] && key < s_min[lu]) lds_min<K>(&s_min[lu], key);
-                                }
-                            }
+                    }
+                }
+                continue;   // next unit
+            }
+        }
+        if (!skip_wg)
+            for (int64_t j0 = jb0; j0 < jb1; j0 += PT) {
+                // sampled pass: only slots [jbeg, jend) of this tile (uniform over the workgroup)
+                const bool sampled = OP == OP_HIST && a.sample;
+                const int jslot = sampled ? 4 * unit_sample_slot(wg, (int)((j0 - jb0) / PT)) : 0;
+                if (OP == OP_BRACKET)  // (starts with the barrier the tile reload needs); flush the staged candidates when half full
+                    stage.sync_and_flush_at(SEL_STAGE_CAP / 2, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+                else
+                    __syncthreads();
+                const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
+                // sampled pass over every-a-with-every-b blocks: per-lane slots (see unit_sample_slot), the whole tile is loaded
+                const bool spread = sampled && !a.pdist;
+                const int hslot = jslot >> 2;
+                if (tid < cnt) {
+                    if (GRID) s_bxy[tid] = gbxy[b0 + j0 + tid];
+                    else { s_bx[tid] = gbx[b0 + j0 + tid]; s_by[tid] = gby[b0 + j0 + tid]; }
+                    s_bv[tid] = gbv[b0 + j0 + tid];
+                }
+                __syncthreads();
+                if (!have_a && OP != OP_BRACKET) continue;   // (OP_BRACKET: every thread stays for the mid-tile flush barriers)
+                // OP_BRACKET, one pair: counters + staged candidate (every lane of the wave must reach the append)
+                auto bracket_pair = [&](bool ok, int l, T d) {
+                    bool cand = false;
+                    if (ok) {
+                        const K key = key_abs(d);
+                        const int cp = tid & (NCOPY - 1);
+                        // one counter update per pair: plane 0 below the bracket, 1 inside it, 2 above it
+                        const bool below = key < s_pref[l];
+                        cand = !below && key <= s_khi[l];
+                        atomicAdd(&s_c3[((below ? 0 : (cand ? 1 : 2)) * (nb + 1) + l) * NCOPY + cp], 1u);
+                    }
+                    {   // staged append (one LDS reservation per wave); what does not fit the staging buffer spills to global memory
+                        const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
+                        if (cm) {
+                            const int lane = tid & 63, leader = __ffsll((long long)cm) - 1;
+                            int pos0 = 0;
+                            if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(cm));
+                            pos0 = __builtin_amdgcn_readlane(pos0, leader);
+                            const int pos = pos0 + __popcll(cm & ((1ull << lane) - 1ull));
+                            if (cand && pos < SEL_STAGE_CAP) { stage.v[pos] = d; stage.b[pos] = (uint16_t)l; }
+                            if (pos0 + __popcll(cm) > SEL_STAGE_CAP) spill(cand && pos >= SEL_STAGE_CAP, d, (uint32_t)l);
                         }
                     }
                 };
-                // (PLAIN needs every thread of the workgroup to hold an A point: uniform, the mid-tile barriers sit inside run4)
-                if (cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT) && (ta + 1) * (int64_t)NT <= na) run4(std::true_type());
-                else run4(std::false_type());
-                if (OP == OP_BRACKET) flush_pending();  // (a tile's pair count need not be a multiple of 8)
-            } else {
-                if (spread) {
-                    for (int u = 0; u < 4; ++u) {
-                        const int sj = (hslot + (tid & 63) + 64 * u) & (PT - 1);
-                        pair(sj, have_a && sj < cnt);
+                // One pair: class lookup + accumulate.  `ok` folds every skip rule so the fast path stays branch-free
+                // up to the (exec-masked) LDS atomics.
+                auto pair = [&](int j, bool ok) {
+                    const double dx = px - s_bx[j], dy = py - s_by[j];
+                    const double s2 = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
+                    int l;  // class = number of thresholds <= s2
+                    if (FAST) {
+                        // 1/8-binade cell of s2 -> class lower bound; only cells that contain a threshold (1 in 8 for the
+                        // reference's sqrt(2)-geometric edges) need the one exact compare against it
+                        int e = (int)((unsigned long long)__double_as_longlong(s2) >> 49) - a.lut_emin;
+                        e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                        const int c = s_lut[e];
+                        l = c >> 1;
+                        if (c & 1) l += (s_thr[l] <= s2) ? 1 : 0;
+                    } else {
+                        l = 0;
+                        int h = nb;
+                        while (l < h) {
+                            const int m = (l + h) >> 1;
+                            if (s_thr[m] <= s2) l = m + 1; else h = m;
+                        }
                     }
+                    T d = pv - s_bv[j];
+                    d = d < 0 ? -d : d;
+                    ok = ok && (l < nb) && (d == d);  // beyond the last edge (maxlag) / NaN values never form a pair
+                    if (OP == OP_BRACKET) { bracket_pair(ok, l, d); return; }
+                    if (!ok) return;
+                    if (OP == OP_SUMS_SQ) {
+                        rec_add(l, (double)d * (double)d);
+                    } else if (OP == OP_SUMS_SQRT) {
+                        rec_add(l, sqrt((double)d));
+                    } else if (OP == OP_HIST) {
+                        const int lb = l - a.bin0;
+                        if (lb < 0 || lb >= a.nbs) return;
+                        const K key = key_abs(d);
+                        const int digit = (int)((key >> a.shift) & 0xFF);
+                        if (a.first || (key & himask) == s_pref[l]) atomicAdd(&s_hist[lb * SEL_RADIX + digit], 1u);
+                        if (dual && (key & himask) == s_khi[l]) atomicAdd(&s_hist[(a.nbs + lb) * SEL_RADIX + digit], 1u);
+                    } else if (OP == OP_SUCC) {
+                        const K key = key_abs(d);
+                        if (key > s_pref[l] && key < s_min[l]) lds_min<K>(&s_min[l], key);
+                    }
+                };
+
+                // classes of the 4 pairs (this lane's A point) x (tile slots j .. j + 3) and their raw value differences, written
+                // stage by stage so that the B-point reads, the table reads and the threshold reads are each issued back to back
+                auto classify4 = [&](const int (&js)[4], int (&lu)[4], T (&dv)[4]) {
+                    if constexpr (GRID) {
+                        uint32_t d2[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[js[u]]);
+                            // (the three-operand form with the inline constant 0: the builtin picks v_dot2c, which needs a zeroed accumulator)
+                            asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
+                            dv[u] = pv - s_bv[js[u]];
+                        }
+                        uint2 e[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            // 1/8-binade cell of float(d2) (monotone in d2); d2 = 0 (coincident points) clamps onto the first cell
+                            const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
+                            e[u] = s_lut2[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
+                        }
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) lu[u] = (int)e[u].x + ((e[u].y <= d2[u]) ? 1 : 0);
+                    } else {
+                        double s2[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double dx = px - s_bx[js[u]], dy = py - s_by[js[u]];
+                            s2[u] = dx * dx + dy * dy;  // not contracted: same rounding as NumPy's dx**2 + dy**2
+                            dv[u] = pv - s_bv[js[u]];
+                        }
+                        int l[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            int e = (int)((unsigned long long)__double_as_longlong(s2[u]) >> 49) - a.lut_emin;
+                            e = e < 0 ? 0 : (e > LUT_N - 1 ? LUT_N - 1 : e);
+                            l[u] = s_lut[e] >> 1;
+                        }
+                        double th[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) th[u] = s_thr[l[u]];  // next threshold above the cell's lower bound
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) lu[u] = l[u] + ((th[u] <= s2[u]) ? 1 : 0);  // class = number of thresholds <= s2
+                    }
+                };
+                if (FAST) {
+                    // 4 pairs per trip, written stage by stage so that the 4 B-point reads, the 4 table reads and the 4
+                    // threshold reads are each issued back to back (one LDS round trip per stage instead of per pair).
+                    // Tile slots beyond cnt hold stale data and are masked by `ok`.
+                    const int64_t rel = ia - j0;  // pdist: only B indices j > rel pair with this lane's A point
+                    // (a thread without an A point -- last A tile of a block -- pairs with nothing: every slot masked)
+                    const int ia_rel = !have_a ? PT : (a.pdist ? (int)(rel < -1 ? -1 : (rel > PT ? PT : rel)) : -1);
+                    // Full tiles (the bulk of the pairs): every slot is a pair -- no index, diagonal, class or NaN test and no
+                    // exec masking; the class beyond the last edge lands in the spare record.
+                    const bool plain_tile = (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && cnt == PT && !a.has_nan &&
+                                            (!a.pdist || j0 >= (ta + 1) * (int64_t)NT);
+                    if (plain_tile) {
+                        for (int j = 0; j < PT; j += 4) {
+                            int lu[4];
+                            T dv[4];
+                            const int js[4] = {j, j + 1, j + 2, j + 3};
+                            classify4(js, lu, dv);
+    #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const double dd = (double)dv[u];
+                                if (lu[u] != run_l) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
+                                    const int off = run_l * REC;
+                                    atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
+                                    atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_c);
+                                    run_l = lu[u];
+                                    run_s = 0.0;
+                                    run_c = 0;
+                                }
+                                run_s = OP == OP_SUMS_SQ ? __builtin_fma(dd, dd, run_s) : run_s + sqrt(fabs(dd));
+                                run_c += 1;
+                            }
+                        }
+                        continue;
+                    }
+                    auto run4 = [&](auto plain_tag) {
+                        constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
+                        const int jbeg = spread ? 0 : jslot;
+                        const int jend = spread ? 4 : (sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt);
+                        const int cnt_m = cnt;   // slots at or beyond this hold no point of the tile
+                        for (int j = jbeg; j < jend; j += 4) {
+                            int lus[4];
+                            T dv[4];
+                            int js[4];
+    #pragma unroll
+                            for (int u = 0; u < 4; ++u) js[u] = spread ? ((hslot + (tid & 63) + 64 * (j + u)) & (PT - 1)) : j + u;
+                            classify4(js, lus, dv);
+                            if constexpr (OP == OP_BRACKET) {
+                                const int cp = tid & (NCOPY - 1);
+                                static_assert(NCOPY * 4 == 128, "counter records are 128 bytes");
+                                const uint32_t c3_plane = (uint32_t)(nb + 1) * NCOPY * 4;
+                                int lc[4];
+                                K lo4[4], hi4[4];
+        #pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    dv[u] = fabs(dv[u]);
+                                    // everything that is no pair goes to the spare class nb (the class lookup itself never exceeds nb:
+                                    // "beyond the last edge" IS class nb, so full tiles need no test at all)
+                                    if constexpr (PLAIN) lc[u] = lus[u];
+                                    else lc[u] = (js[u] < cnt_m && js[u] > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
+                                    lo4[u] = s_lh[2 * lc[u]];
+                                    hi4[u] = s_lh[2 * lc[u] + 1];
+                                }
+        #pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const K bits = key_abs(dv[u]) >> 1;  // (|d| has no sign bit: its raw bits order like the keys)
+                                    // counter plane = (bits >= lo) + (bits > hi): 0 below the bracket, 1 inside, 2 above -- two compares,
+                                    // two carry adds, one multiply-add for the address (no selects)
+                                    const bool ge_lo = bits >= lo4[u], gt_hi = bits > hi4[u];
+                                    // (lane masks handled as scalars: a `bool` combined in C++ comes back as a 0/1 VGPR and a compare)
+                                    const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ge_lo), m_gt = __builtin_amdgcn_ballot_w64(gt_hi);
+                                    const unsigned long long m_gt2 = m_ge & m_gt;  // (an empty bracket, hi < lo: everything below or above)
+                                    const unsigned long long in_m = m_ge & ~m_gt;
+                                    const uint32_t plane = select_by_mask(0u, 1u, m_ge) + select_by_mask(0u, 1u, m_gt2);
+                                    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_c3 + cp) + ((uint32_t)lc[u] << 7) +
+                                                                          __umul24(plane, c3_plane)), 1u);
+                                    const unsigned long long clash = in_m & pend_m;
+                                    if (__builtin_expect(clash != 0, 0)) {  // (wave-uniform, rare: a second candidate within 8 pairs)
+                                        const bool mine = (clash >> (tid & 63)) & 1ull;
+                                        int pos = 0;
+                                        if (mine) {
+                                            pos = atomicAdd(stage.held, 1);
+                                            if (pos < SEL_STAGE_CAP) { stage.v[pos] = dv[u]; stage.b[pos] = (uint16_t)lc[u]; }
+                                        }
+                                        spill(mine && pos >= SEL_STAGE_CAP, dv[u], (uint32_t)lc[u]);
+                                    }
+                                    const unsigned long long take = in_m & ~pend_m;
+                                    pend_v = select_by_mask(pend_v, dv[u], take);
+                                    pend_l = select_by_mask(pend_l, (uint32_t)lc[u], take);
+                                    pend_m |= take;
+                                }
+                                if ((j & 4) != 0) flush_pending();  // every second stage = 8 pairs
+                                // every 64 B slots (65536 pairs of the workgroup) the staged candidates leave if the buffer is a quarter full:
+                                // the brackets of spatially correlated values hold a few per cent of the pairs, a whole tile's worth
+                                // would not fit (j and cnt are uniform over the workgroup: every thread meets this barrier)
+                                if ((j & 63) == 60 && j + 4 < jend)
+                                    stage.sync_and_flush_at(SEL_STAGE_CAP / 4, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+                                continue;
+                            }
+        #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int lu = lus[u];
+                                dv[u] = dv[u] < 0 ? -dv[u] : dv[u];
+                                const T d = dv[u];
+                                const bool ok = (PLAIN || (js[u] < cnt_m && js[u] > ia_rel && d == d)) && lu < nb;
+                                if (OP == OP_BRACKET) {
+                                    bracket_pair(ok, lu, d);
+                                } else if (ok) {
+                                    if (OP == OP_SUMS_SQ) {
+                                        rec_add(lu, (double)d * (double)d);
+                                    } else if (OP == OP_SUMS_SQRT) {
+                                        rec_add(lu, sqrt((double)d));
+                                    } else if (OP == OP_HIST) {
+                                        const int lb = lu - a.bin0;
+                                        const K key = key_abs(d);
+                                        if (lb >= 0 && lb < a.nbs) {
+                                            const int digit = (int)((key >> a.shift) & 0xFF);
+                                            if (a.first || (key & himask) == s_pref[lu]) atomicAdd(&s_hist[lb * SEL_RADIX + digit], 1u);
+                                            if (dual && (key & himask) == s_khi[lu])
+                                                atomicAdd(&s_hist[(a.nbs + lb) * SEL_RADIX + digit], 1u);
+                                        }
+                                    } else if (OP == OP_SUCC) {
+                                        const K key = key_abs(d);
+                                        if (key > s_pref[lu] && key < s_min[lu]) lds_min<K>(&s_min[lu], key);
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    // (PLAIN needs every thread of the workgroup to hold an A point: uniform, the mid-tile barriers sit inside run4)
+                    if (cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT) && (ta + 1) * (int64_t)NT <= na) run4(std::true_type());
+                    else run4(std::false_type());
+                    if (OP == OP_BRACKET) flush_pending();  // (a tile's pair count need not be a multiple of 8)
                 } else {
-                    const int jend = sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt;
-                    for (int j = jslot; j < jend; ++j) pair(j, have_a && (!a.pdist || (j0 + j) > ia));
+                    if (spread) {
+                        for (int u = 0; u < 4; ++u) {
+                            const int sj = (hslot + (tid & 63) + 64 * u) & (PT - 1);
+                            pair(sj, have_a && sj < cnt);
+                        }
+                    } else {
+                        const int jend = sampled ? (jslot + 4 < cnt ? jslot + 4 : cnt) : cnt;
+                        for (int j = jslot; j < jend; ++j) pair(j, have_a && (!a.pdist || (j0 + j) > ia));
+                    }
                 }
             }
-        }
+    }
     if ((OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && run_c) {   // the open run of every lane
         const int off = run_l * REC;
         atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
@@ -579,6 +649,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     } else if (OP == OP_HIST) {
         for (int k = tid; k < a.nbs * SEL_RADIX; k += NT)
             if (s_hist[k]) atomicAdd(&a.hist[(size_t)a.bin0 * SEL_RADIX + k], (unsigned long long)s_hist[k]);
+        if (dual)
+            for (int k = tid; k < a.nbs * SEL_RADIX; k += NT) {
+                const uint32_t c = s_hist[a.nbs * SEL_RADIX + k];
+                if (c) atomicAdd(&a.hist2[(size_t)a.bin0 * SEL_RADIX + k], (unsigned long long)c);
+            }
     } else if (OP == OP_BRACKET) {
         stage.sync_and_flush_at(0, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
         for (int k = tid; k < nb; k += NT) {
@@ -621,7 +696,9 @@ struct xdemhip_pairs {
     void *prefix = nullptr, *succ = nullptr;
     int64_t n_wg = 0, n_wg_big = 0, n_pairs = 0;
     // bracketed selection state (xdemhip_pairs_medians)
-    int sample = 0, has_nan = 1;
+    int sample = 0, has_nan = 1, dual = 0;
+    void* prefix2 = nullptr;             // (points into the caller's scratch while a dual pass runs)
+    unsigned long long* hist2 = nullptr;
     void* khi = nullptr;
     unsigned long long *cnt3 = nullptr, *cand_ctr = nullptr;
     void* cand_v = nullptr;
@@ -657,10 +734,13 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     a.succ = static_cast<unsigned long long*>(P->succ);
     a.shift = shift; a.first = first; a.bin0 = bin0; a.nbs = nbs;
     a.sample = P->sample;
+    a.dual = (OP == OP_HIST) ? P->dual : 0;
+    a.prefix2 = static_cast<const typename KeyT<T>::type*>(P->prefix2);
+    a.hist2 = P->hist2;
     a.has_nan = P->has_nan;
     a.khi = static_cast<const typename KeyT<T>::type*>(P->khi);
     a.cnt3 = P->cnt3; a.cand_v = static_cast<T*>(P->cand_v); a.cand_b = P->cand_b; a.cand_ctr = P->cand_ctr; a.cand_cap = P->cand_cap;
-    const size_t lds = lds_bytes<T>(P->nb, OP, nbs);
+    const size_t lds = lds_bytes<T>(P->nb, OP, (OP == OP_HIST && P->dual) ? 2 * nbs : nbs);
     const int64_t n_wg = (NT == 1024) ? P->n_wg_big : P->n_wg;
     // HIP dispatches carry the TOTAL work-item count of a dimension in 32 bits (a larger grid x block product is silently
     // truncated): a pass over more workgroups than 2^31 / NT goes out as several launches, each told where it starts.
@@ -672,9 +752,13 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     for (int64_t w0 = 0; w0 < n_wg; w0 += per_launch) {
         const int64_t nw = (n_wg - w0) < per_launch ? (n_wg - w0) : per_launch;
         a.wg_base = w0;
-        if (grid) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT, true>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
-        else if (P->lut) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3((unsigned)nw), dim3(NT), lds, ctx->stream, a);
+        a.wg_end = w0 + nw;
+        // sampled digit passes: resident workgroups walking over the units (see the kernel); everything else one unit each
+        const int64_t resident = (int64_t)ctx->num_cu * (lds > 80 * 1024 ? 1 : 2);
+        const unsigned nlaunch = (unsigned)((OP == OP_HIST && P->sample && nw > resident) ? resident : nw);
+        if (grid) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT, true>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
+        else if (P->lut) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     return XDEMHIP_OK;
@@ -812,7 +896,7 @@ void xdemhip_pairs_destroy(xdemhip_pairs* P) {
         void* b[] = {P->ax, P->ay, P->bx, P->by, P->av, P->bv};
         for (void* p : b) if (p) (void)hipFree(p);
     }
-    void* b2[] = {P->a_off, P->b_off, P->wg_off, P->wg_off_big, P->thr, P->sums, P->counts, P->hist, P->prefix, P->succ, P->lut,
+    void* b2[] = {P->a_off, P->b_off, P->wg_off, P->wg_off_big, P->thr, P->sums, P->counts, P->hist, P->hist2, P->prefix, P->succ, P->lut,
                   P->a_xy, P->b_xy, P->thr_i, P->lut_i};
     for (void* p : b2) if (p) (void)hipFree(p);
     if (P->cand_v) (void)hipFree(P->cand_v);   // candidate buffers of the bracketed selection (kept between calls)
@@ -898,6 +982,7 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     XD_ALLOC(P->sums, sizeof(double) * n_bins);
     XD_ALLOC(P->counts, 8 * n_bins);
     XD_ALLOC(P->hist, 8 * (size_t)n_bins * SEL_RADIX);
+    XD_ALLOC(P->hist2, 8 * (size_t)n_bins * SEL_RADIX);
     XD_ALLOC(P->prefix, 8 * n_bins);
     XD_ALLOC(P->succ, 8 * n_bins);
     if (!pd) XD_ALLOC(P->b_off, sizeof(int64_t) * (n_blocks + 1));
@@ -1080,6 +1165,52 @@ int pairs_digit_passes(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st,
     return XDEMHIP_OK;
 }
 
+// Both ends of every class's bracket from ONE set of sampled digit passes: states [0, nb) select the low ends (d_st), states
+// [nb, 2 nb) the high ends; the pair kernel counts every sampled pair under each of the two prefixes of its class it matches
+// (PairArgs::dual).  `d_pref2` = nb key slots for the second prefix array.
+template <typename T>
+int pairs_digit_passes_dual(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st, typename KeyT<T>::type* d_pref2, uint32_t wide_deff,
+                            std::vector<SelState<typename KeyT<T>::type>>& lo, std::vector<SelState<typename KeyT<T>::type>>& hi, int n_passes) {
+    typedef typename KeyT<T>::type K;
+    xdemhip_ctx* ctx = P->ctx;
+    const int nb = P->nb, passes = KeyT<T>::passes;
+    const int run = (n_passes > 0 && n_passes < passes) ? n_passes : passes;
+    constexpr int SWEEP = HIST_BINS_PER_SWEEP / 2;   // two [classes][256] tables per sweep in LDS
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_st, 0, sizeof(SelState<K>) * 2 * nb, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->hist, 0, 8 * (size_t)nb * SEL_RADIX, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->hist2, 0, 8 * (size_t)nb * SEL_RADIX, ctx->stream));
+    P->sample = 1; P->dual = 1; P->prefix2 = d_pref2;
+    auto leave = [&](int rc) { P->sample = 0; P->dual = 0; P->prefix2 = nullptr; return rc; };
+    for (int p = 0; p < run; ++p) {
+        const int shift = 8 * (passes - 1 - p);
+        if (P->n_wg_big > 0)
+            for (int b0 = 0; b0 < nb; b0 += SWEEP) {
+                const int nbs = (nb - b0) < SWEEP ? (nb - b0) : SWEEP;
+                int rc = launch_pairs<T, OP_HIST>(P, shift, (int)(p == 0), b0, nbs);
+                if (rc) return leave(rc);
+            }
+        int rc = xd_allreduce_device(ctx, P->hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
+        if (rc == XDEMHIP_OK && p > 0) rc = xd_allreduce_device(ctx, P->hist2, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
+        if (rc) return leave(rc);
+        if (p == 0)   // the first digit's histogram serves both states
+            if (hipMemcpyAsync(P->hist2, P->hist, 8 * (size_t)nb * SEL_RADIX, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                return leave(xd_fail(ctx, XDEMHIP_EHIP, "histogram copy failed"));
+        hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, d_st, reinterpret_cast<uint64_t*>(P->hist), nb,
+                           shift, (int)(p == 0), (int)(p == passes - 1), (int)SEL_BRACKET_LO_WIDE, (const uint64_t*)nullptr, (const uint32_t*)nullptr, wide_deff);
+        hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, d_st + nb, reinterpret_cast<uint64_t*>(P->hist2), nb,
+                           shift, (int)(p == 0), (int)(p == passes - 1), (int)SEL_BRACKET_HI_WIDE, (const uint64_t*)nullptr, (const uint32_t*)nullptr, wide_deff);
+        hipLaunchKernelGGL((extract_prefix_kernel<K>), dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, d_st, static_cast<K*>(P->prefix), nb);
+        hipLaunchKernelGGL((extract_prefix_kernel<K>), dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, d_st + nb, d_pref2, nb);
+        if (hipGetLastError() != hipSuccess) return leave(xd_fail(ctx, XDEMHIP_EHIP, "sampled digit pass failed"));
+    }
+    leave(0);
+    lo.resize(nb); hi.resize(nb);
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(lo.data(), d_st, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(hi.data(), d_st + nb, sizeof(SelState<K>) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
 template <typename T>
 int pairs_medians_plain(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st, int64_t* counts, double* medians) {
     typedef typename KeyT<T>::type K;
@@ -1120,8 +1251,9 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     const int nb = P->nb;
     // small device block: selection states | klo | khi | given | counters[3 nb] | candidate counter, overflow
     unsigned char* d_small = nullptr;
-    const size_t off_klo = (size_t)nb * sizeof(SelState<K>), off_khi = off_klo + 8 * (size_t)nb, off_given = off_khi + 8 * (size_t)nb,
-                 off_cnt = off_given + 8 * (size_t)nb, off_ctr = off_cnt + 24 * (size_t)nb, off_rbs = off_ctr + 16, small_bytes = off_rbs + 8;
+    const size_t off_klo = 2 * (size_t)nb * sizeof(SelState<K>), off_khi = off_klo + 8 * (size_t)nb, off_given = off_khi + 8 * (size_t)nb,
+                 off_cnt = off_given + 8 * (size_t)nb, off_ctr = off_cnt + 24 * (size_t)nb, off_rbs = off_ctr + 16, off_pref2 = off_rbs + 8,
+                 small_bytes = off_pref2 + 8 * (size_t)nb;
     if (hipMalloc(reinterpret_cast<void**>(&d_small), small_bytes) != hipSuccess) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
     SelState<K>* d_st = reinterpret_cast<SelState<K>*>(d_small);
     void* scratch = nullptr;
@@ -1162,8 +1294,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
             std::vector<SelState<K>> lo, hi;
             constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough
             const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
-            rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_LO_WIDE, nullptr, lo, BR_PASSES, deff);
-            if (rc == XDEMHIP_OK) rc = pairs_digit_passes<T>(P, d_st, 1, SEL_BRACKET_HI_WIDE, nullptr, hi, BR_PASSES, deff);
+            rc = pairs_digit_passes_dual<T>(P, d_st, reinterpret_cast<K*>(d_small + off_pref2), deff, lo, hi, BR_PASSES);
             if (rc) { cleanup(); return rc; }
             phase("sampled digit passes");
             double expected = 0.0;  // candidates the brackets should hold: 64 x their width in sample ranks, at most the class
