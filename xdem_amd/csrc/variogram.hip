@@ -160,12 +160,16 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     unsigned char* s_rec = acc;
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(acc);            // OP_HIST: nbs * 256
     K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
-    uint32_t* s_c3 = reinterpret_cast<uint32_t*>(acc);              // OP_BRACKET: [3][nb][NCOPY] counters, then the staging buffer
+    unsigned long long* s_c3 = reinterpret_cast<unsigned long long*>(acc);   // OP_BRACKET: [nb + 1][NCOPY] packed counters, then the staging buffer
     BlockStage<T> stage;
-    // OP_BRACKET: counters [3 planes: below / inside / above the bracket][nb + 1][NCOPY] (class nb = spare: pairs that are no pairs -- beyond the last edge, diagonal, NaN --
-    // count there, so the hot loop needs no predicate), then the bracket ends interleaved {low, high} per class (one 8 / 16-byte
-    // read per pair; the spare class holds {all-ones, 0}: always "below", never a candidate), then the staging buffer
-    K* s_lh = reinterpret_cast<K*>(s_c3 + 3 * (a.nb + 1) * NCOPY);  // (3 * (nb + 1) * 32 words: 8-byte aligned)
+    // OP_BRACKET: one PACKED 64-bit counter per class and copy -- bits 0..20 pairs of the class, 21..41 those at or above the
+    // bracket's low end, 42..62 those above its high end (a workgroup gives a copy at most 1024 x 4096 / 32 = 2^17 pairs): ONE
+    // ds_add_u64 of (1 | ge << 21 | gt << 42) per pair, its value two selects on the compare masks, its address one shift-add
+    // (three separate planes needed a plane index, a multiply-add and two more adds).  Class nb = spare: pairs that are no pairs
+    // -- beyond the last edge, diagonal, NaN -- count there, so the hot loop needs no predicate.  Then the bracket ends
+    // interleaved {low, high} per class (one 8 / 16-byte read per pair; the spare class holds {all-ones, 0}: always "below",
+    // never a candidate), then the staging buffer
+    K* s_lh = reinterpret_cast<K*>(s_c3 + (a.nb + 1) * NCOPY);
     if (OP == OP_BRACKET) {
         stage.v = reinterpret_cast<T*>(s_lh + 2 * (a.nb + 1));
         stage.b = reinterpret_cast<uint16_t*>(stage.v + SEL_STAGE_CAP);
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
             s_lh[2 * k] = (K)((lo >> 1) + (lo & 1));
             s_lh[2 * k + 1] = (K)(hi >> 1);
         }
-        for (int k = tid; k < 3 * (a.nb + 1) * NCOPY; k += NT) s_c3[k] = 0;
+        for (int k = tid; k < (a.nb + 1) * NCOPY; k += NT) s_c3[k] = 0ull;
         if (tid == 0) *stage.held = 0;
     }
 
@@ -379,10 +383,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     if (ok) {
                         const K key = key_abs(d);
                         const int cp = tid & (NCOPY - 1);
-                        // one counter update per pair: plane 0 below the bracket, 1 inside it, 2 above it
+                        // one packed counter update per pair (see s_c3)
                         const bool below = key < s_pref[l];
                         cand = !below && key <= s_khi[l];
-                        atomicAdd(&s_c3[((below ? 0 : (cand ? 1 : 2)) * (nb + 1) + l) * NCOPY + cp], 1u);
+                        atomicAdd(&s_c3[l * NCOPY + cp], 1ull | (below ? 0ull : (1ull << 21)) | ((below || cand) ? 0ull : (1ull << 42)));
                     }
                     {   // staged append (one LDS reservation per wave); what does not fit the staging buffer spills to global memory
                         const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
@@ -531,9 +535,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             for (int u = 0; u < 4; ++u) js[u] = spread ? ((hslot + (tid & 63) + 64 * (j + u)) & (PT - 1)) : j + u;
                             classify4(js, lus, dv);
                             if constexpr (OP == OP_BRACKET) {
-                                const int cp = tid & (NCOPY - 1);
-                                static_assert(NCOPY * 4 == 128, "counter records are 128 bytes");
-                                const uint32_t c3_plane = (uint32_t)(nb + 1) * NCOPY * 4;
+                                static_assert(NCOPY * 8 == 256, "counter records are 256 bytes");
+                                unsigned char* const c3_mine = reinterpret_cast<unsigned char*>(s_c3 + (tid & (NCOPY - 1)));
                                 int lc[4];
                                 K lo4[4], hi4[4];
         #pragma unroll
@@ -556,25 +559,18 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                     const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ge_lo), m_gt = __builtin_amdgcn_ballot_w64(gt_hi);
                                     const unsigned long long m_gt2 = m_ge & m_gt;  // (an empty bracket, hi < lo: everything below or above)
                                     const unsigned long long in_m = m_ge & ~m_gt;
-                                    const uint32_t plane = select_by_mask(0u, 1u, m_ge) + select_by_mask(0u, 1u, m_gt2);
-                                    atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_c3 + cp) + ((uint32_t)lc[u] << 7) +
-                                                                          __umul24(plane, c3_plane)), 1u);
-                                    const unsigned long long clash = in_m & pend_m;
-                                    if (__builtin_expect(clash != 0, 0)) {  // (wave-uniform, rare: a second candidate within 8 pairs)
-                                        const bool mine = (clash >> (tid & 63)) & 1ull;
-                                        int pos = 0;
-                                        if (mine) {
-                                            pos = atomicAdd(stage.held, 1);
-                                            if (pos < SEL_STAGE_CAP) { stage.v[pos] = dv[u]; stage.b[pos] = (uint16_t)lc[u]; }
-                                        }
-                                        spill(mine && pos >= SEL_STAGE_CAP, dv[u], (uint32_t)lc[u]);
-                                    }
+                                    const unsigned long long inc = (unsigned long long)select_by_mask(1u, 1u | (1u << 21), m_ge) |
+                                                                   ((unsigned long long)select_by_mask(0u, 1u << 10, m_gt2) << 32);
+                                    atomicAdd(reinterpret_cast<unsigned long long*>(c3_mine + ((uint32_t)lc[u] << 8)), inc);
+                                    // (wave-uniform, rare: a second candidate of some lane before the next flush -- the pending ones leave
+                                    // first, one LDS reservation for the wave, and the lane keeps the new one)
+                                    if (__builtin_expect((in_m & pend_m) != 0, 0)) flush_pending();
                                     const unsigned long long take = in_m & ~pend_m;
                                     pend_v = select_by_mask(pend_v, dv[u], take);
                                     pend_l = select_by_mask(pend_l, (uint32_t)lc[u], take);
                                     pend_m |= take;
                                 }
-                                if ((j & 4) != 0) flush_pending();  // every second stage = 8 pairs
+                                if ((j & 12) == 12) flush_pending();  // every fourth stage = 16 pairs (brackets hold < 1 % of the pairs)
                                 // every 64 B slots (65536 pairs of the workgroup) the staged candidates leave if the buffer is a quarter full:
                                 // the brackets of spatially correlated values hold a few per cent of the pairs, a whole tile's worth
                                 // would not fit (j and cnt are uniform over the workgroup: every thread meets this barrier)
@@ -659,9 +655,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         for (int k = tid; k < nb; k += NT) {
             unsigned long long above = 0, below = 0, inside = 0;
             for (int q = 0; q < NCOPY; ++q) {
-                below += s_c3[k * NCOPY + q];
-                inside += s_c3[((nb + 1) + k) * NCOPY + q];
-                above += s_c3[(2 * (nb + 1) + k) * NCOPY + q];
+                const unsigned long long c = s_c3[k * NCOPY + q];
+                const unsigned long long total = c & 0x1FFFFFull, ge = (c >> 21) & 0x1FFFFFull, gt = (c >> 42) & 0x1FFFFFull;
+                below += total - ge;
+                inside += ge - gt;
+                above += gt;
             }
             if (above + inside) atomicAdd(&a.cnt3[k], above + inside);  // [0]: at or above the bracket's low end
             if (below) atomicAdd(&a.cnt3[nb + k], below);
@@ -714,7 +712,7 @@ template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
     size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8 + 4 * (size_t)(PT + nb + 4);
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
     if (op == OP_BRACKET)
-        return base + (size_t)3 * (nb + 1) * NCOPY * 4 + 2 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 8 +
+        return base + (size_t)(nb + 1) * NCOPY * 8 + 2 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 8 +
                (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
     return base + (size_t)(nb + 1) * NCOPY * 12;
