@@ -59,7 +59,7 @@ template <typename K> struct SelState {
 // SAMPLE moved down / up by sel_bracket_halfwidth(count) (select_run.h: bracketed selection); SEL_GIVEN = given[bin]
 // (all-ones: skip the bin).
 enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3, SEL_BRACKET_LO_WIDE = 4, SEL_BRACKET_HI_WIDE = 5,
-       SEL_BRACKET_DUAL = 6 /* state 0 = low end, state 1 = high end of ONE bin's bracket, selected together */ };
+       SEL_BRACKET_DUAL = 6 /* states [0, nb) = low ends, [nb, 2 nb) = high ends of the bins' brackets, selected together */ };
 
 // Half width (in sample ranks) of the bracket around the sample median that holds the population median with
 // overwhelming probability: 6 standard deviations of the rank (0.5 sqrt(m_eff)) for an effective sample size of
@@ -88,7 +88,8 @@ __host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m, uint3
 template <typename K>
 __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
                                                             int mode = SEL_MEDIAN, const uint64_t* given = nullptr,
-                                                            const uint32_t* rb_shift = nullptr, uint32_t wide_deff = PAIR_DEFF_WIDE) {
+                                                            const uint32_t* rb_shift = nullptr, uint32_t wide_deff = PAIR_DEFF_WIDE,
+                                                            int dual_nb = 1 /* SEL_BRACKET_DUAL: states below this are low ends */) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
     // Rebased keys ((key - lo) << s, select_run.h) have s zero bits at the bottom: a digit that lies entirely inside them is 0
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
     if (first) {
         s.count = total;
         uint64_t r = total ? (total - 1) / 2 : 0;  // lower median
-        const bool lo_end = mode == SEL_BRACKET_LO || (mode == SEL_BRACKET_DUAL && b == 0);
-        const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && b == 1);
+        const bool lo_end = mode == SEL_BRACKET_LO || (mode == SEL_BRACKET_DUAL && b < dual_nb);
+        const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && b >= dual_nb);
         if (lo_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = r > h ? r - h : 0; }
         if (hi_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = r > h ? r - h : 0; }

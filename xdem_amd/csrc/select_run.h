@@ -53,9 +53,11 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
                                                                  const SelState<typename KeyT<T>::type>* st, int shift, int first,
                                                                  uint64_t* hist, const unsigned long long* n_dev = nullptr,
                                                                  const typename KeyT<T>::type* rb_lo = nullptr,
-                                                                 const uint32_t* rb_shift = nullptr, int dual = 0) {
-    // dual: one data bin, TWO selection states (nb == 2, bins == nullptr) -- both ends of a bracket advance in the same passes
-    // over the sample; every element is offered to both states
+                                                                 const uint32_t* rb_shift = nullptr, int dual_total = 0) {
+    // dual (dual_total = number of data bins of the whole selection, 0 = off): TWO selection states per data bin -- states
+    // [0, dual_total) the low ends, [dual_total, 2 dual_total) the high ends of the brackets -- advance in the same passes over
+    // the sample; every element is offered to both states of its bin.  `nb` stays the number of DATA bins of this sweep, the
+    // LDS table holds 2 nb rows (low-end rows first)
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* h = reinterpret_cast<uint32_t*>(smem);
@@ -64,15 +66,20 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
         n = m < (unsigned long long)n ? (int64_t)m : n;
     }
     if (!first && rb_shift && shift + 8 <= (int)*rb_shift) return;  // all-zero digit of rebased keys: see select_advance_kernel
-    const int table = nb * SEL_RADIX;
+    const int rows = dual_total ? 2 * nb : nb;
+    const int table = rows * SEL_RADIX;
     // privatised copies sit an ODD number of words apart: a stride that is a multiple of 32 would put the same counter of every
     // copy into one LDS bank, and lanes that agree on (bin, digit) -- the common case -- would serialise on it
     const int cstride = copies > 1 ? table + 1 : table;
     for (int k = threadIdx.x; k < cstride * copies; k += blockDim.x) h[k] = 0;
     // per-bin rebase offsets and prefixes: LDS copies (two dependent global loads per element otherwise)
     K* s_lo = reinterpret_cast<K*>(h + (size_t)cstride * copies + (((size_t)cstride * copies) & 1));
-    K* s_pref = s_lo + nb;
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) { s_lo[k] = rb_lo ? rb_lo[bin0 + k] : (K)0; s_pref[k] = st[bin0 + k].prefix; }
+    K* s_pref = s_lo + nb;   // [rows]
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        s_lo[k] = rb_lo ? rb_lo[bin0 + k] : (K)0;
+        s_pref[k] = st[bin0 + k].prefix;
+        if (dual_total) s_pref[nb + k] = st[dual_total + bin0 + k].prefix;
+    }
     __syncthreads();
     uint32_t* hc = h + (threadIdx.x % copies) * cstride;
     const K himask = first ? (K)0 : (K)(~(K)0 << (shift + 8));
@@ -94,15 +101,15 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
 #pragma unroll
         for (int q = 0; q < SEL_UNROLL; ++q) {
             if (v[q] != v[q]) continue;
-            if (dual) {
-                const K key = key_of(v[q]);
-                const int digit = (int)((key >> shift) & 0xFF);
-                if (first || (key & himask) == s_pref[0]) atomicAdd(&hc[digit], 1u);
-                if (first || (key & himask) == s_pref[1]) atomicAdd(&hc[SEL_RADIX + digit], 1u);
-                continue;
-            }
             const int b = bins ? (int)bb[q] - bin0 : 0;
             if (b < 0 || b >= nb) continue;
+            if (dual_total) {
+                const K key = key_of(v[q]);
+                const int digit = (int)((key >> shift) & 0xFF);
+                if (first || (key & himask) == s_pref[b]) atomicAdd(&hc[b * SEL_RADIX + digit], 1u);
+                if (first || (key & himask) == s_pref[nb + b]) atomicAdd(&hc[(nb + b) * SEL_RADIX + digit], 1u);
+                continue;
+            }
             K key = key_of(v[q]);
             if (rb_lo) key = (K)((K)(key - s_lo[b]) << rbs);
             if (!first && (key & himask) != s_pref[b]) continue;
@@ -113,7 +120,9 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
     for (int k = threadIdx.x; k < table; k += blockDim.x) {
         unsigned long long c = 0;
         for (int q = 0; q < copies; ++q) c += h[q * cstride + k];
-        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[(size_t)bin0 * SEL_RADIX + k]), c);
+        // (dual: the high-end rows of this sweep belong to the states behind all the low-end ones)
+        const size_t row0 = (dual_total && k >= nb * SEL_RADIX) ? (size_t)(dual_total - nb) + (size_t)bin0 : (size_t)bin0;
+        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[row0 * SEL_RADIX + k]), c);
     }
 }
 
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __rest
 
 
 constexpr int MAX_BINS_PER_SWEEP = 128;  // 128 * 256 * 4 B = 128 KiB of LDS histograms per workgroup
+constexpr int MAX_ROWS_PER_SWEEP_DUAL = 152;  // dual selections: two rows per data bin; 152 KiB + prefixes < 160 KiB (the 72 aspect bins in one sweep)
 
 // Opt a kernel into more than 48 KiB of dynamic LDS.  hipFuncSetAttribute is a driver call (tens of microseconds, and the
 // selection launches this kernel dozens of times per step): repeated only when a launch needs more than was granted before.
@@ -199,7 +209,8 @@ constexpr size_t OFF_STATS = 16384, OFF_SUMS = OFF_STATS + 64, OFF_STATE = OFF_S
 inline int nb1(int nb) { return nb > 1 ? nb : 1; }
 inline size_t off_succ(int nb) { return OFF_STATE + (size_t)nb1(nb) * 64; }
 inline size_t off_hist(int nb) { return off_succ(nb) + (size_t)nb1(nb) * 8; }
-inline size_t scratch_size(int nb) { return off_hist(nb) + (size_t)nb1(nb) * SEL_RADIX * 8 + 256; }
+// (sized for 2 nb states: the dual bracket selection keeps a low-end and a high-end state per bin)
+inline size_t scratch_size(int nb) { return off_hist(2 * nb1(nb)) + (size_t)2 * nb1(nb) * SEL_RADIX * 8 + 256; }
 
 static __global__ void select_reset_kernel(uint64_t* base, int64_t w_state, int64_t w_succ, int64_t words) {
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x)
@@ -223,9 +234,12 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                    unsigned char* scratch, int mode, const uint64_t* d_given, int n_passes = 0, bool want_succ = true,
                    const typename KeyT<T>::type* rb_lo = nullptr, const uint32_t* rb_shift = nullptr) {
     typedef typename KeyT<T>::type K;
-    // SEL_BRACKET_DUAL: one data bin (nb == 1 on entry, bins == nullptr), two selection states
+    // SEL_BRACKET_DUAL: two selection states per data bin (low ends in states [0, nb), high ends in [nb, 2 nb)); `scratch` holds
+    // 2 nb states (scratch_size provides for that)
     const int dual = mode == SEL_BRACKET_DUAL ? 1 : 0;
-    if (dual) { if (nb != 1 || want_succ) return xd_fail(ctx, XDEMHIP_EINVAL, "dual bracket selection: one bin, no successor pass"); nb = 2; bins = nullptr; }
+    if (dual && want_succ) return xd_fail(ctx, XDEMHIP_EINVAL, "dual bracket selection: no successor pass");
+    const int nb_data = nb;
+    if (dual) { nb = 2 * nb_data; if (nb_data == 1) bins = nullptr; }
     SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
     uint64_t* d_hist = reinterpret_cast<uint64_t*>(scratch + off_hist(nb));
@@ -247,23 +261,26 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     const int grid = grid_for(ctx, n_grid, HIST_THREADS * 4, n_grid < ((int64_t)1 << 24) ? 1 : 2);
     for (int p = 0; p < run; ++p) {
         const int shift = 8 * (passes - 1 - p);
-        if (n > 0)
-            for (int b0 = 0; b0 < nb; b0 += MAX_BINS_PER_SWEEP) {
-                const int nbs = (nb - b0) < MAX_BINS_PER_SWEEP ? (nb - b0) : MAX_BINS_PER_SWEEP;
+        if (n > 0) {
+            const int per_sweep = dual ? MAX_ROWS_PER_SWEEP_DUAL / 2 : MAX_BINS_PER_SWEEP;
+            for (int b0 = 0; b0 < nb_data; b0 += per_sweep) {
+                const int nbs = (nb_data - b0) < per_sweep ? (nb_data - b0) : per_sweep;
+                const int rows = dual ? 2 * nbs : nbs;
                 // privatise the table as often as fits in ~64 KB (32 copies for the single-bin global median)
-                int copies = (64 * 1024) / (nbs * SEL_RADIX * (int)sizeof(uint32_t));
+                int copies = (64 * 1024) / (rows * SEL_RADIX * (int)sizeof(uint32_t));
                 copies = copies < 1 ? 1 : (copies > 32 ? 32 : copies);
-                const size_t lds = ((size_t)nbs * SEL_RADIX + 1) * sizeof(uint32_t) * copies + 8 + 2 * sizeof(K) * (size_t)nbs;
+                const size_t lds = ((size_t)rows * SEL_RADIX + 1) * sizeof(uint32_t) * copies + 8 + 2 * sizeof(K) * (size_t)rows;
                 int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
                 if (rc) return rc;
                 hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
-                                   st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift, dual);
+                                   st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift, dual ? nb_data : 0);
                 XD_HIP_CHECK(ctx, hipGetLastError());
             }
+        }
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
-                           (int)(p == 0), (int)(p == passes - 1), mode, d_given, rb_shift);
+                           (int)(p == 0), (int)(p == passes - 1), mode, d_given, rb_shift, PAIR_DEFF_WIDE, nb_data);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     if (!want_succ) return XDEMHIP_OK;
@@ -451,20 +468,28 @@ __global__ __launch_bounds__(HIST_THREADS) void sample_lines_kernel(Src src, int
     const int64_t n_groups = (((n + SEL_LINE - 1) >> SEL_LINE_LOG2) + 63) >> 6;
     const int halves = (int)blockDim.x >> SEL_LINE_LOG2;
     const int half = (int)threadIdx.x >> SEL_LINE_LOG2, l32 = (int)threadIdx.x & (SEL_LINE - 1);
-    for (int64_t g0 = (int64_t)blockIdx.x * halves; g0 < n_groups; g0 += (int64_t)gridDim.x * halves) {
-        const int64_t g = g0 + half;
-        bool keep = false;
-        T v = (T)0;
-        uint16_t b = 0;
-        if (g < n_groups) {
+    // SEL_TILE line groups per thread and step: all of a step's (scattered, 32-byte) fetches are issued before the first is used,
+    // and the workgroup synchronises once per step -- with one group per step the kernel was a chain of a dozen dependent memory
+    // round trips per workgroup (81 us for the 1/64 sample of a 20000^2 raster, as long as a pass over 8 % of the data)
+    for (int64_t g0 = (int64_t)blockIdx.x * halves * SEL_TILE; g0 < n_groups; g0 += (int64_t)gridDim.x * halves * SEL_TILE) {
+        typename Src::Raw r[SEL_TILE];
+        bool have[SEL_TILE];
+#pragma unroll
+        for (int q = 0; q < SEL_TILE; ++q) {
+            const int64_t g = g0 + (int64_t)q * halves + half;
             const int64_t p = (sel_sampled_line(g) << SEL_LINE_LOG2) + l32;
-            if (p < n) {
-                typename Src::Raw r;
-                src.fetch(p, r);
-                keep = src.template eval<false>(r, nb, v, b, acc);
-            }
+            have[q] = g < n_groups && p < n;
+            if (have[q]) src.fetch(p, r[q]);
+            else src.blank(r[q]);
         }
-        st.append(keep, v, b);
+#pragma unroll
+        for (int q = 0; q < SEL_TILE; ++q) {
+            T v = (T)0;
+            uint16_t b = 0;
+            bool keep = false;
+            if (have[q]) keep = src.template eval<false>(r[q], nb, v, b, acc);
+            st.append(keep, v, b);
+        }
         st.sync_and_flush(false, out_v, out_b, &ctr[0], cap, &ctr[2]);
     }
     st.sync_and_flush(true, out_v, out_b, &ctr[0], cap, &ctr[2]);
@@ -695,25 +720,13 @@ int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, un
     constexpr int BR_PASSES = 3;  // 24 leading key bits place the bracket ends finely enough (2^-15 / 2^-12 relative)
     const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
     uint32_t* d_rbs = reinterpret_cast<uint32_t*>(ws->d_small + 4);
-    if (nb == 1) {
-        // a single bin: both ends of its bracket in ONE selection over the sample (SEL_BRACKET_DUAL)
-        rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), nullptr, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_DUAL, nullptr,
-                               BR_PASSES, false);
-        if (rc) return rc;
-        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, d_klo, d_khi);
-        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st + 1, 1, 1, (int)(ctx->selection_mode == 2), low_mask,
-                           d_klo, d_khi);
-    } else {
-        rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_LO,
-                               nullptr, BR_PASSES, false);
-        if (rc) return rc;
-        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, d_klo, d_khi);
-        rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch, SEL_BRACKET_HI,
-                               nullptr, BR_PASSES, false);
-        if (rc) return rc;
-        hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 1, (int)(ctx->selection_mode == 2), low_mask,
-                           d_klo, d_khi);
-    }
+    // both ends of every bin's bracket in ONE selection over the sample (SEL_BRACKET_DUAL: states [0, nb) low, [nb, 2 nb) high)
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), nb == 1 ? nullptr : ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch,
+                           SEL_BRACKET_DUAL, nullptr, BR_PASSES, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, d_klo, d_khi);
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st + nb, nb, 1, (int)(ctx->selection_mode == 2), low_mask,
+                       d_klo, d_khi);
     hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, nb, d_rbs);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 3. the one pass over the data
