@@ -684,6 +684,42 @@ def test_lean_route_equals_plain_route_at_scale():
         ctx.close()
 
 
+def test_bench_C3_pair_at_full_size_routes_agree():
+    """The very input bench.py times (SURVEY 8d's C3: 20000^2 pair, tba = ref shifted bilinearly by (+1.7, -0.6) px + 2 m + noise,
+    20 % gaps) at full size: the queued route the bench runs (EXT dh pass, lean kernels, dual bracket selections, aspect-bin cache)
+    against the plain one (option "selection" = 1: generic kernels, full digit passes) -- every integer output identical for
+    fractional steps, repeated steps included; and the fit the bench reports recovers the construction."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from xdem_amd import _lib, coreg
+
+    dev = torch.device("cuda", 0)
+    ref, tba = bench._c3_pair(dev, 20000)
+    ctx = _lib.Context(0)
+    try:
+        steps = ((0.0, 0.0), (1.7, 0.6), (1.2, 0.9), (1.7, 0.6))
+        res = {}
+        for mode in (0, 1):
+            ctx.set_option("selection", mode)
+            plan = coreg.NKPlan(ref, tba, None, ctx)
+            res[mode] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in steps]
+            plan.close()
+        ctx.set_option("selection", 0)
+        for a, b in zip(res[0], res[1]):
+            assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"]
+            assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True)
+            assert np.array_equal(a["edges"], b["edges"])
+        assert np.array_equal(res[0][1]["medians"], res[0][3]["medians"], equal_nan=True)
+        assert 0.75 * 4e8 < res[0][0]["n_valid"] < 0.85 * 4e8
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("dtype,rule", [(np.float32, 0), (np.float32, 1), (np.float64, 0)])
 def test_lean_kernels_vs_oracle(coreg, dtype, rule):
     """The queued route (lean dh / bin kernels, bracketed selections, aspect-bin cache) only runs from 2^22 pixels on: a

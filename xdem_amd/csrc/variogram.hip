@@ -546,8 +546,14 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                     // "beyond the last edge" IS class nb, so full tiles need no test at all)
                                     if constexpr (PLAIN) lc[u] = lus[u];
                                     else lc[u] = (js[u] < cnt_m && js[u] > ia_rel && dv[u] == dv[u]) ? lus[u] : nb;
-                                    lo4[u] = s_lh[2 * lc[u]];
-                                    hi4[u] = s_lh[2 * lc[u] + 1];
+                                    if constexpr (sizeof(K) == 4) {   // one 8-byte read (its constant offset folds into the instruction)
+                                        const uint2 lh = *reinterpret_cast<const uint2*>(s_lh + 2 * lc[u]);
+                                        lo4[u] = lh.x;
+                                        hi4[u] = lh.y;
+                                    } else {
+                                        lo4[u] = s_lh[2 * lc[u]];
+                                        hi4[u] = s_lh[2 * lc[u] + 1];
+                                    }
                                 }
         #pragma unroll
                                 for (int u = 0; u < 4; ++u) {

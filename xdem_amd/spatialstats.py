@@ -15,7 +15,6 @@ dowd = 2.198 median(d)^2 / 2.  Random subsampling uses NumPy generators (geoutil
 from __future__ import annotations
 
 import ctypes
-import os
 import logging
 import warnings
 from collections.abc import Iterable
@@ -102,10 +101,6 @@ class PairSet:
             return h, int(n_pairs.value)
 
         self.handle = self.handle_sel = None
-        if os.environ.get("XDEM_VARIO_SEL_SORTED") == "1" and self.ctx.options.get("vario_sort", 1):   # (measurement switch)
-            self.handle, self.n_pairs = create([_morton_sorted_block(b) for b in blocks])
-            self.handle_sel = self.handle
-            return
         self.handle_sel, self.n_pairs = create(blocks)
         if self.ctx.options.get("vario_sort", 1):
             try:
