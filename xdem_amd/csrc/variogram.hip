@@ -539,6 +539,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 unsigned char* const c3_mine = reinterpret_cast<unsigned char*>(s_c3 + (tid & (NCOPY - 1)));
                                 int lc[4];
                                 K lo4[4], hi4[4];
+                                unsigned long long in4[4];
         #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
                                     dv[u] = fabs(dv[u]);
@@ -564,17 +565,24 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                     // (lane masks handled as scalars: a `bool` combined in C++ comes back as a 0/1 VGPR and a compare)
                                     const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ge_lo), m_gt = __builtin_amdgcn_ballot_w64(gt_hi);
                                     const unsigned long long m_gt2 = m_ge & m_gt;  // (an empty bracket, hi < lo: everything below or above)
-                                    const unsigned long long in_m = m_ge & ~m_gt;
+                                    in4[u] = m_ge & ~m_gt;
                                     const unsigned long long inc = (unsigned long long)select_by_mask(1u, 1u | (1u << 21), m_ge) |
                                                                    ((unsigned long long)select_by_mask(0u, 1u << 10, m_gt2) << 32);
                                     atomicAdd(reinterpret_cast<unsigned long long*>(c3_mine + ((uint32_t)lc[u] << 8)), inc);
-                                    // (wave-uniform, rare: a second candidate of some lane before the next flush -- the pending ones leave
-                                    // first, one LDS reservation for the wave, and the lane keeps the new one)
-                                    if (__builtin_expect((in_m & pend_m) != 0, 0)) flush_pending();
-                                    const unsigned long long take = in_m & ~pend_m;
-                                    pend_v = select_by_mask(pend_v, dv[u], take);
-                                    pend_l = select_by_mask(pend_l, (uint32_t)lc[u], take);
-                                    pend_m |= take;
+                                }
+                                // Candidates (0.3 % of the pairs): nearly half of the wave-trips hold none in their 256 lane-pairs and
+                                // skip this altogether (one scalar test per trip instead of two selects per pair)
+                                if ((in4[0] | in4[1] | in4[2] | in4[3]) != 0) {
+        #pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        // (wave-uniform, rare: a second candidate of some lane before the next flush -- the pending ones
+                                        // leave first, one LDS reservation for the wave, and the lane keeps the new one)
+                                        if (__builtin_expect((in4[u] & pend_m) != 0, 0)) flush_pending();
+                                        const unsigned long long take = in4[u] & ~pend_m;
+                                        pend_v = select_by_mask(pend_v, dv[u], take);
+                                        pend_l = select_by_mask(pend_l, (uint32_t)lc[u], take);
+                                        pend_m |= take;
+                                    }
                                 }
                                 if ((j & 12) == 12) flush_pending();  // every fourth stage = 16 pairs (brackets hold < 1 % of the pairs)
                                 // every 64 B slots (65536 pairs of the workgroup) the staged candidates leave if the buffer is a quarter full:
