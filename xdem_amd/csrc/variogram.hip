@@ -34,7 +34,16 @@ namespace xd {
 
 #pragma clang fp contract(off)
 
+// spread pair sample (every-a-with-every-b blocks): B slots per lane and tile -> SPREAD_SLOTS / 256 of the pairs of every unit.
+// (4 = 1/64 was the first setting; the brackets scale with 1 / sqrt(sample), the three sampled passes with the sample: 2 slots
+// cost 0.1 % more candidates and save a third of the sampled passes' time on SURVEY 8d's C5)
+constexpr int SPREAD_SLOTS = 2;
 constexpr int PT = 256;      // B points per LDS tile; A points per workgroup = NT (256 for sums / succ, 1024 for histograms)
+// (a lane's SPREAD_SLOTS slots lie PT / SPREAD_SLOTS apart, so one wave covers SPREAD_SLOTS of the tile's four 64-slot groups:
+// consecutive waves start in different groups and the waves of a workgroup together cover every B point of the tile -- with one
+// common start the 2-slot sample used half of the B points of a unit and its ranks scattered three times as far)
+static_assert(SPREAD_SLOTS == 1 || SPREAD_SLOTS == 2 || SPREAD_SLOTS == 4, "64-slot groups");
+__device__ __forceinline__ int spread_wave_offset(int tid) { return 64 * ((tid >> 6) % (4 / SPREAD_SLOTS)); }
 constexpr int BCHUNK = 4096;  // B points per workgroup
 constexpr int LUT_N = 512;    // cells (1/8 binade of d^2 each) of the class lookup table
 constexpr int LUT_G = 256;    // GRID: cells of float(d2) from LUT_G0 on (d2 = 1 is cell 1016, d2 < 2^32 ends at 1272): 64 dwords = one per LDS bank
@@ -87,9 +96,9 @@ template <typename T> struct PairArgs {
 // sampled whole units with probability 1/64: for values of a spatially correlated field the class distributions differ from
 // block to block, the number of sampled units per block was binomial (3 +- 1.7), and the mixture weights -- hence the sample
 // medians -- were too noisy for any affordable bracket.)
-//  * every-a-with-every-b blocks: thread t (A point t of the tile) takes the four B slots (h + lane + 64 u) mod 256, u = 0..3, h
-//    hashed from the unit: the 4096 sampled pairs of a unit use each of its 1024 A points 4 times and each of its 256 B points 16
-//    times.  EVERY tile takes part: sampling every 4th tile with 16 slots per lane (a quarter of the tile loads and barriers
+//  * every-a-with-every-b blocks: thread t (A point t of the tile) takes SPREAD_SLOTS B slots (h + lane + u 256 / SPREAD_SLOTS) mod
+//    256, h hashed from the unit: the sampled pairs of a unit use each of its 1024 A points SPREAD_SLOTS times and each of its
+//    256 B points 4 SPREAD_SLOTS times.  EVERY tile takes part: sampling every 4th tile with 16 slots per lane (a quarter of the tile loads and barriers
 //    for the same pairs) was measured -- the wanted ranks then sat 0.63 half widths off the bracket centres instead of 0.04: B
 //    points arrive ring by ring, a tile is one distance class of one block, and the class mixtures over the blocks get noisy.  (The first form of this round took 4 B slots for ALL A points: 1024 pairs per sampled B point, and since |v_a - v_b|
 //    of a correlated field moves with v_b for all of them at once, a class of 8.5e7 sampled pairs behaved like 2e4 independent
@@ -317,26 +326,26 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
             if (a.sample && !a.pdist) {   // (uniform over the launch)
                 const int lane = tid & 63;
                 for (int64_t j0 = jb0; j0 < jb1; j0 += 4 * PT) {
-                    uint32_t bxy[16];
-                    T bvv[16];
-                    bool okk[16];
+                    uint32_t bxy[4 * SPREAD_SLOTS];
+                    T bvv[4 * SPREAD_SLOTS];
+                    bool okk[4 * SPREAD_SLOTS];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int64_t jt = j0 + (int64_t)t * PT;
                         const int h = unit_sample_slot(wg, (int)((jt - jb0) / PT));
                         const int64_t cnt_t = jb1 - jt;   // (<= 0: no such tile)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int sj = (h + lane + 64 * u) & (PT - 1);
+                        for (int u = 0; u < SPREAD_SLOTS; ++u) {
+                            const int sj = (h + lane + spread_wave_offset(tid) + (PT / SPREAD_SLOTS) * u) & (PT - 1);
                             const bool ok = have_a && sj < cnt_t;
                             const int64_t src = b0 + (ok ? jt + sj : jb0);
-                            okk[4 * t + u] = ok;
-                            bxy[4 * t + u] = gbxy[src];
-                            bvv[4 * t + u] = gbv[src];
+                            okk[SPREAD_SLOTS * t + u] = ok;
+                            bxy[SPREAD_SLOTS * t + u] = gbxy[src];
+                            bvv[SPREAD_SLOTS * t + u] = gbv[src];
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
+                    for (int q = 0; q < 4 * SPREAD_SLOTS; ++q) {
                         const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, bxy[q]);
                         uint32_t d2;
                         asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2) : "v"(d));
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             T dv[4];
                             int js[4];
     #pragma unroll
-                            for (int u = 0; u < 4; ++u) js[u] = spread ? ((hslot + (tid & 63) + 64 * (j + u)) & (PT - 1)) : j + u;
+                            for (int u = 0; u < 4; ++u) js[u] = spread ? ((hslot + (tid & 63) + spread_wave_offset(tid) + (PT / SPREAD_SLOTS) * (j + u)) & (PT - 1)) : j + u;
                             classify4(js, lus, dv);
                             if constexpr (OP == OP_BRACKET) {
                                 static_assert(NCOPY * 8 == 256, "counter records are 256 bytes");
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 const int lu = lus[u];
                                 dv[u] = dv[u] < 0 ? -dv[u] : dv[u];
                                 const T d = dv[u];
-                                const bool ok = (PLAIN || (js[u] < cnt_m && js[u] > ia_rel && d == d)) && lu < nb;
+                                const bool ok = (PLAIN || (js[u] < cnt_m && js[u] > ia_rel && d == d)) && lu < nb && (!spread || u < SPREAD_SLOTS);   // (a trip = 4 pairs: the first SPREAD_SLOTS are the sampled ones)
                                 if (OP == OP_BRACKET) {
                                     bracket_pair(ok, lu, d);
                                 } else if (ok) {
@@ -628,8 +637,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     if (OP == OP_BRACKET) flush_pending();  // (a tile's pair count need not be a multiple of 8)
                 } else {
                     if (spread) {
-                        for (int u = 0; u < 4; ++u) {
-                            const int sj = (hslot + (tid & 63) + 64 * u) & (PT - 1);
+                        for (int u = 0; u < SPREAD_SLOTS; ++u) {
+                            const int sj = (hslot + (tid & 63) + spread_wave_offset(tid) + (PT / SPREAD_SLOTS) * u) & (PT - 1);
                             pair(sj, have_a && sj < cnt);
                         }
                     } else {
@@ -1317,7 +1326,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
                 khi[k] = have ? (K)(hi[k].prefix | low_mask) : (K)~(K)0;
                 if (ctx->selection_mode == 2 && have) khi[k] = klo[k];  // test mode: brackets that (almost surely) miss
                 const double m = (double)lo[k].count, w = 2.0 * (double)sel_bracket_halfwidth_wide(lo[k].count, deff) + 2.0;
-                expected += 64.0 * (w < m ? w : m);
+                expected += (P->pdist ? 64.0 : (double)(PT / SPREAD_SLOTS)) * (w < m ? w : m);
             }
             // candidate buffers sized from the brackets (x1.5 + slack), not from the pair count: 5e13 pairs (SURVEY 8d, C5 reading
             // A) need ~2e10 slots, not n_pairs / 64.  Too little memory (on any rank): plain passes.
