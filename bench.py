@@ -345,9 +345,9 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
 VARIO_LIMITER_NOTE = ("round 2 (profiles/r02_nk_vario_pmc.json): 14.7 vector + 4.0 LDS instructions per pair, the LDS array busy for the whole kernel "
                       "with two accumulator atomics per pair.  Round 3: points uploaded in Morton order + run-length accumulation in registers "
                       "(LDS atomics only when a lane's lag class changes): the pass is bound by vector-instruction issue (~17 per pair); "
-                      "the exact Dowd route = three sampled digit passes for both bracket ends (7 ms) + ONE counting / compaction pass over all pairs "
-                      "(48 ms, ~20 vector instructions per pair, one packed LDS counter update each) + the selection among the 0.3 % of the "
-                      "pairs inside the brackets (2 ms)")
+                      "the exact Dowd route = three sampled digit passes for both bracket ends (4 ms) + ONE counting / compaction pass over all pairs "
+                      "(46 ms, ~19 vector instructions per pair, one packed LDS counter update each) + the selection among the 0.4 % of the "
+                      "pairs inside the brackets (3 ms)")
 NK_TOUCHED_BYTES = 22
 NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference copy 4 + tba 4 + dh out 4 -- min / max aspect come from the "
                    "plan's lists of extreme-aspect pixels, the inlier mask is folded into the reference copy as NaN; bin pass: dh 4 + "
