@@ -241,6 +241,45 @@ def test_halo_rows_equal_full_raster(terrain):
         assert np.array_equal(out[i].cpu().numpy(), f[r0:r1], equal_nan=True)
 
 
+def test_library_allocated_planes(terrain):
+    """xdemhip_device_alloc / terrain.alloc_planes: resident planes as one physically contiguous allocation (the layout the
+    streaming kernel is fastest on).  Same results as on torch's own memory, the memory goes back when the tensor dies, small
+    sets stay with torch's allocator, and a size nobody can provide fails loudly."""
+    import gc
+
+    import torch
+
+    from xdem_amd import _lib
+    from xdem_amd.synth import fbm_torch
+
+    ctx = _lib.default_context()
+    attrs = ["slope", "aspect", "hillshade", "profile_curvature", "topographic_position_index", "terrain_ruggedness_index"]
+    n = 4608   # 6 planes x 85 MB: above the 256 MiB threshold of alloc_planes
+    dem = fbm_torch(n, n, "cuda", seed=3)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    planes = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx)
+    assert planes.shape == (len(attrs), n, n) and planes.is_cuda and hasattr(planes, "xdem_contiguous")
+    assert torch.cuda.mem_get_info()[0] <= free0 - planes.numel() * 4 + (64 << 20)
+    got = terrain.terrain_attributes_device(dem, attrs, resolution=10.0, out=planes, ctx=ctx)
+    ref = terrain.terrain_attributes_device(dem, attrs, resolution=10.0, out=torch.empty_like(planes), ctx=ctx)
+    torch.cuda.synchronize()
+    assert got.data_ptr() == planes.data_ptr()
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    view = planes[2, 100:200]          # a view keeps the allocation alive
+    del planes, got
+    gc.collect()
+    assert torch.equal(view.view(torch.int32), ref[2, 100:200].view(torch.int32))
+    del view, ref
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    small = terrain.alloc_planes(2, 64, 64, torch.float32, ctx)
+    assert not hasattr(small, "xdem_contiguous")
+    with pytest.raises(_lib.XdemHipError):
+        ctx.device_tensor((1 << 40,), "float32")   # 4 TiB
+
+
 @pytest.mark.parametrize("fit,attrs", [("Florinsky", "FULL"), ("ZevenbergThorne", "FULL"), ("Horn", "SAH_WIN")])
 def test_streaming_strips_equal_tile_kernel_and_oracle(terrain, fit, attrs):
     """The streaming route of the specialised kernels (raster interior by wave-autonomous 64-column strips fed by LDS-DMA,

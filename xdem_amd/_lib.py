@@ -50,6 +50,8 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_last_error.restype = ctypes.c_char_p
         L.xdemhip_set_stream.argtypes = [c_ctx, ctypes.c_void_p]
         L.xdemhip_synchronize.argtypes = [c_ctx]
+        L.xdemhip_device_alloc.argtypes = [c_ctx, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]
+        L.xdemhip_device_free.argtypes = [c_ctx, ctypes.c_void_p]
         L.xdemhip_set_option.argtypes = [c_ctx, ctypes.c_char_p, ctypes.c_int]
         L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_set_allreduce_device.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
@@ -167,6 +169,22 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+class _OwnedDeviceArray(_DeviceArray):
+    """The same, owning its memory (``xdemhip_device_alloc``): torch keeps the object alive as long as a tensor built on it."""
+
+    def __init__(self, ctx, ptr: int, count: int, typestr: str):
+        super().__init__(ptr, count, typestr)
+        self._ctx, self._ptr = ctx, ptr
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._ptr and getattr(self._ctx, "handle", None):
+                self._ctx._L.xdemhip_device_free(self._ctx.handle, ctypes.c_void_p(self._ptr))
+        except Exception:
+            pass
+        self._ptr = 0
+
+
 def make_device_reduce_hook(group="world", device: int | None = None):
     """The Python side of ``xdemhip_set_allreduce_device``: ``hook(device_ptr, count, kind, hip_stream, user) -> 0 | 1`` wraps the
     library's device array as a torch tensor (no copy) and ENQUEUES ``torch.distributed.all_reduce`` (RCCL) with the
@@ -264,6 +282,22 @@ class Context:
 
     def synchronize(self) -> None:
         self.check(self._L.xdemhip_synchronize(self.handle))
+
+    def device_tensor(self, shape, dtype="float32", contiguous: bool = True):
+        """A torch tensor over device memory from ``xdemhip_device_alloc`` -- physically contiguous when the driver can provide it
+        (``tensor.xdem_contiguous`` tells): the layout the streaming terrain kernel wants for its output planes (include/xdemhip.h).
+        The memory is released when the tensor (and every view of it) is gone."""
+        import numpy as np
+        import torch
+
+        np_dt = np.dtype(dtype)
+        count = int(np.prod(shape))
+        ptr, got = ctypes.c_void_p(), ctypes.c_int()
+        self.check(self._L.xdemhip_device_alloc(self.handle, count * np_dt.itemsize, int(bool(contiguous)), ctypes.byref(ptr), ctypes.byref(got)))
+        owner = _OwnedDeviceArray(self, int(ptr.value), count, np_dt.str)
+        t = torch.as_tensor(owner, device=torch.device("cuda", self.device)).view(*shape)
+        t.xdem_contiguous = bool(got.value)
+        return t
 
     def set_option(self, name: str, value: int) -> None:
         """Tuning / test switch of the library (``xdemhip_set_option``), e.g. ``("selection", 1)``."""

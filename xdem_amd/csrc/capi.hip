@@ -88,6 +88,35 @@ int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* devi
     return XDEMHIP_OK;
 }
 
+int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int contiguous, void** ptr, int* got_contiguous) {
+    if (!ctx || !ptr || bytes == 0) return ctx ? xd_fail(ctx, XDEMHIP_EINVAL, "bad argument") : XDEMHIP_EINVAL;
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    *ptr = nullptr;
+    if (got_contiguous) *got_contiguous = 0;
+    if (contiguous) {
+        if (hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocContiguous) == hipSuccess && *ptr) {
+            if (got_contiguous) *got_contiguous = 1;
+            return XDEMHIP_OK;
+        }
+        (void)hipGetLastError();   // no single piece of that size: an ordinary allocation will do
+        *ptr = nullptr;
+    }
+    if (hipMalloc(ptr, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+    }
+    return XDEMHIP_OK;
+}
+
+int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (!ptr) return XDEMHIP_OK;
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipFree(ptr));
+    return XDEMHIP_OK;
+}
+
 int xdemhip_synchronize(xdemhip_ctx* ctx) {
     if (!ctx) return XDEMHIP_EINVAL;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));

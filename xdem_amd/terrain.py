@@ -267,6 +267,22 @@ def get_terrain_attribute(
     return output_attributes if len(output_attributes) > 1 else output_attributes[0]
 
 
+def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None):
+    """(n_attr, H, W) device tensor for resident attribute planes.  Large sets come from ``xdemhip_device_alloc`` as ONE physically
+    contiguous piece where the driver can provide it: the streaming kernel writes 256-byte row segments of every plane a raster
+    row apart, so planes assembled from small physical pieces make the launch translation-bound -- measured on the 40000^2
+    set: 12.9-13.1 ms on contiguous planes in every trial, 13.0 or 14.6-14.9 ms on ``torch.empty`` planes depending on the
+    allocation (profiles/r03_box_variance.txt).  Small sets stay with torch's caching allocator."""
+    import torch
+
+    dtype = dtype or torch.float32
+    ctx = ctx or _lib.default_context(None if device is None else torch.device(device).index)
+    dev = torch.device("cuda", ctx.device)
+    if n_attr * H * W * torch.empty((), dtype=dtype).element_size() < (1 << 28):
+        return torch.empty((n_attr, H, W), dtype=dtype, device=dev)
+    return ctx.device_tensor((n_attr, H, W), {torch.float32: "float32", torch.float64: "float64"}[dtype], contiguous=True)
+
+
 def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0, degrees: bool = True,
                               hillshade_altitude: float = 45.0, hillshade_azimuth: float = 315.0,
                               hillshade_z_factor: float = 1.0, surface_fit: str = "Florinsky",
@@ -281,9 +297,9 @@ def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0
     Hbuf, W = dem.shape
     H = Hbuf - halo_top - halo_bottom
     dt = {torch.float32: np.float32, torch.float64: np.float64}[dem.dtype]
-    if out is None:
-        out = torch.empty((len(attribute), H, W), dtype=dem.dtype, device=dem.device)
     ctx = ctx or _lib.default_context(dem.device.index)
+    if out is None:
+        out = alloc_planes(len(attribute), H, W, dem.dtype, ctx, dem.device)
     ctx.set_stream(torch.cuda.current_stream(dem.device).cuda_stream)
     assert out.shape == (len(attribute), H, W) and out.stride(2) == 1 and out.stride(1) == W and out.is_cuda
     ptrs = {a: out[i].data_ptr() for i, a in enumerate(attribute)}  # planes may be row windows of a larger tensor
