@@ -354,6 +354,21 @@ NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference c
                    "slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not recomputed; 27 B/pixel in round 2")
 
 
+def device_state() -> list:
+    """What rocm-smi says about the GPU the line was measured on (partition modes, power cap, memory / fabric clock levels): the
+    same binary runs the headline launch in 12.7-13.3 ms on most boxes of the pool and 14.5-15.0 ms on others (DESIGN.md section 1,
+    profiles/r03_box_variance.txt) -- recorded so that a line can be read against the box it came from.  Best effort."""
+    import subprocess
+
+    try:
+        txt = subprocess.run(["rocm-smi", "--showmemorypartition", "--showcomputepartition", "--showmaxpower", "--showclocks", "--showtemp"],
+                             capture_output=True, text=True, timeout=15).stdout
+        keep = ("Partition", "Max Graphics", "mclk", "fclk", "sclk", "junction")
+        return [" ".join(l.split()) for l in txt.splitlines() if l.startswith("GPU[0]") and any(k in l for k in keep)]
+    except Exception:
+        return []
+
+
 def end_to_end_host_path(ctx, n: int = 16384) -> dict:
     """SURVEY 8d "separate end-to-end number including H2D/D2H": BASELINE C2 (16384^2 float32, 11 attributes) through the call
     users make -- get_terrain_attribute(ndarray) -> list of ndarrays -- host buffers in and out, PCIe both ways."""
@@ -517,6 +532,7 @@ def main() -> None:
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(min(step_ms), 4),
                          "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch},
         }
+        res["device_state"] = device_state()
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
         if c4 is not None:

@@ -74,13 +74,15 @@ const char* xdemhip_last_error(const xdemhip_ctx* ctx);
 #define XDEMHIP_OWN_STREAM ((void*)(intptr_t)-1)
 int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream);
 int xdemhip_synchronize(xdemhip_ctx* ctx);
-/* Device memory for callers that keep rasters resident (the planes of xdemhip_terrain, 70 GB for the 40000^2 set).
- * `contiguous` != 0 asks the driver for PHYSICALLY contiguous memory (hipExtMallocWithFlags / hipDeviceMallocContiguous), i.e.
- * maximal page-table fragments: the streaming terrain kernel writes 256-byte row segments 160 KB apart into eleven planes, so
- * every store of a wave lands in a different 4 KiB page, and a plane assembled from small physical pieces makes the run
- * translation-bound (measured: the same launch 12.9 or 14.8 ms depending on the allocation).  Falls back
- * to an ordinary allocation when the driver cannot provide one piece; *got_contiguous (optional) reports which it was. */
-int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int contiguous, void** ptr, int* got_contiguous);
+/* Device memory for callers that keep rasters resident (the planes of xdemhip_terrain, 70 GB for the 40000^2 set).  `flags`:
+ * XDEMHIP_ALLOC_CONTIGUOUS asks the driver for PHYSICALLY contiguous memory (hipExtMallocWithFlags / hipDeviceMallocContiguous),
+ * i.e. maximal page-table fragments: the streaming terrain kernel writes 256-byte row segments 160 KB apart into eleven planes,
+ * so every store of a wave lands in a different 4 KiB page (falls back to an ordinary allocation when the driver has no single
+ * piece; *got_contiguous, optional, reports which it was).  XDEMHIP_ALLOC_RECYCLED serves the request twice -- allocate, touch,
+ * free, allocate again: on part of the MI355X boxes the same launch runs 12.9 ms on planes in a virtual range the process has
+ * used before and 14.6-14.9 ms on planes in a fresh one (eight of eight trials), whatever the alignment. */
+enum { XDEMHIP_ALLOC_CONTIGUOUS = 1, XDEMHIP_ALLOC_RECYCLED = 2 };
+int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, int* got_contiguous);
 int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr);
 /* Timing of the work enqueued by the last call on the context stream, measured with hipEvents recorded on
  * that stream around the kernel launch(es); returns milliseconds in *ms (synchronises the stop event). */

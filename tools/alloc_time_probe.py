@@ -19,14 +19,19 @@ ctx = _lib.default_context(0)
 dem = fbm_torch(n, n, "cuda", seed=42)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-if len(sys.argv) > 1 and sys.argv[1] == "contig":
-    out = terrain.alloc_planes(11, n, n, torch.float32, ctx)
+mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
+if mode == "contig":
+    out = terrain.alloc_planes(11, n, n, torch.float32, ctx, recycled=False)
+elif mode == "recycled":
+    out = terrain.alloc_planes(11, n, n, torch.float32, ctx, recycled=True)
+elif mode == "recycled_plain":
+    out = ctx.device_tensor((11, n, n), "float32", contiguous=False, recycled=True)
 else:
     out = torch.empty((11, n, n), dtype=torch.float32, device="cuda")
 line = []
-for i in range(400):
+for i in range(int(os.environ.get("PROBE_LAUNCHES", "60"))):
     terrain.terrain_attributes_device(dem, FULL, out=out, resolution=10.0, surface_fit="Florinsky", curv_method="geometric", ctx=ctx)
     ms = ctx.last_kernel_ms()
     if i % 10 == 0:
         line.append(f"{time.perf_counter() - t0:5.2f}s:{ms:6.2f}")
-print(" ".join(line), flush=True)
+print(f"{mode:15s}", " ".join(line), flush=True)

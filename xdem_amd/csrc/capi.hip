@@ -88,9 +88,8 @@ int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* devi
     return XDEMHIP_OK;
 }
 
-int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int contiguous, void** ptr, int* got_contiguous) {
-    if (!ctx || !ptr || bytes == 0) return ctx ? xd_fail(ctx, XDEMHIP_EINVAL, "bad argument") : XDEMHIP_EINVAL;
-    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+namespace {
+int device_alloc_once(xdemhip_ctx* ctx, size_t bytes, bool contiguous, void** ptr, int* got_contiguous) {
     *ptr = nullptr;
     if (got_contiguous) *got_contiguous = 0;
     if (contiguous) {
@@ -107,6 +106,26 @@ int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int contiguous, void** 
         return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
     }
     return XDEMHIP_OK;
+}
+}  // namespace
+
+int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, int* got_contiguous) {
+    if (!ctx || !ptr || bytes == 0) return ctx ? xd_fail(ctx, XDEMHIP_EINVAL, "bad argument") : XDEMHIP_EINVAL;
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const bool contiguous = (flags & XDEMHIP_ALLOC_CONTIGUOUS) != 0;
+    if (flags & XDEMHIP_ALLOC_RECYCLED) {
+        // a first allocation of this size is mapped, touched and released, and the request is served again: the second allocation
+        // reuses the virtual range whose page tables now exist (see include/xdemhip.h)
+        void* first = nullptr;
+        int rc = device_alloc_once(ctx, bytes, contiguous, &first, nullptr);
+        if (rc) return rc;
+        const size_t touch = bytes < ((size_t)64 << 20) ? bytes : ((size_t)64 << 20);
+        (void)hipMemsetAsync(first, 0, touch, ctx->stream);
+        (void)hipMemsetAsync(static_cast<char*>(first) + (bytes - touch), 0, touch, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        XD_HIP_CHECK(ctx, hipFree(first));
+    }
+    return device_alloc_once(ctx, bytes, contiguous, ptr, got_contiguous);
 }
 
 int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr) {

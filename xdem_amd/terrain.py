@@ -267,7 +267,7 @@ def get_terrain_attribute(
     return output_attributes if len(output_attributes) > 1 else output_attributes[0]
 
 
-def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None):
+def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None, recycled: bool = True):
     """(n_attr, H, W) device tensor for resident attribute planes.  Large sets come from ``xdemhip_device_alloc`` as ONE physically
     contiguous piece where the driver can provide it: the streaming kernel writes 256-byte row segments of every plane a raster
     row apart, so planes assembled from small physical pieces make the launch translation-bound -- measured on the 40000^2
@@ -280,7 +280,8 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
     dev = torch.device("cuda", ctx.device)
     if n_attr * H * W * torch.empty((), dtype=dtype).element_size() < (1 << 28):
         return torch.empty((n_attr, H, W), dtype=dtype, device=dev)
-    return ctx.device_tensor((n_attr, H, W), {torch.float32: "float32", torch.float64: "float64"}[dtype], contiguous=True)
+    return ctx.device_tensor((n_attr, H, W), {torch.float32: "float32", torch.float64: "float64"}[dtype], contiguous=True,
+                             recycled=recycled)
 
 
 def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0, degrees: bool = True,
