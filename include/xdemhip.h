@@ -79,8 +79,8 @@ int xdemhip_synchronize(xdemhip_ctx* ctx);
  * i.e. maximal page-table fragments: the streaming terrain kernel writes 256-byte row segments 160 KB apart into eleven planes,
  * so every store of a wave lands in a different 4 KiB page (falls back to an ordinary allocation when the driver has no single
  * piece; *got_contiguous, optional, reports which it was).  XDEMHIP_ALLOC_RECYCLED serves the request twice -- allocate, touch,
- * free, allocate again: on part of the MI355X boxes the same launch runs 12.9 ms on planes in a virtual range the process has
- * used before and 14.6-14.9 ms on planes in a fresh one (eight of eight trials), whatever the alignment. */
+ * free, allocate again (a measurement switch: in one probe the same launch ran 12.9 ms on planes in a virtual range the process
+ * had used before and 14.6-14.9 ms in a fresh one, eight of eight trials; later sessions did not confirm it). */
 enum { XDEMHIP_ALLOC_CONTIGUOUS = 1, XDEMHIP_ALLOC_RECYCLED = 2 };
 int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, int* got_contiguous);
 int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr);

@@ -267,12 +267,14 @@ def get_terrain_attribute(
     return output_attributes if len(output_attributes) > 1 else output_attributes[0]
 
 
-def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None, recycled: bool = True):
+def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None, recycled: bool = False):
     """(n_attr, H, W) device tensor for resident attribute planes.  Large sets come from ``xdemhip_device_alloc`` as ONE physically
     contiguous piece where the driver can provide it: the streaming kernel writes 256-byte row segments of every plane a raster
     row apart, so planes assembled from small physical pieces make the launch translation-bound -- measured on the 40000^2
     set: 12.9-13.1 ms on contiguous planes in every trial, 13.0 or 14.6-14.9 ms on ``torch.empty`` planes depending on the
-    allocation (profiles/r03_box_variance.txt).  Small sets stay with torch's caching allocator."""
+    allocation (profiles/r03_box_variance.txt; later sessions showed that contiguity alone does not decide the mode -- DESIGN.md
+    section 1 -- the allocator stays because it never hurt).  ``recycled`` = XDEMHIP_ALLOC_RECYCLED (a measurement switch).
+    Small sets stay with torch's caching allocator."""
     import torch
 
     dtype = dtype or torch.float32
