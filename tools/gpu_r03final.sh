@@ -17,3 +17,9 @@ for f in ("bench_first","bench_last"):
             v=s.get("variogram",{}); n=s.get("nuthkaab",{})
             print("   vario", v.get("matheron_pass_Gpairs_s"), v.get("dowd_exact_median_Gpairs_s"), v.get("dowd_first_call_Gpairs_s"), "nk", n.get("ms_per_iteration"), n.get("ms_per_iteration_whole_fit"), "e2e", d.get("end_to_end",{}).get("Mpixels_s"), s.get("error"))
 P
+# closing kernel summary of the final build (one rocprofv3 --kernel-trace --stats pass of bench.py)
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03final/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end > $GRAFT_REPO_ROOT/gpurun_out/r03final/stats.log 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/r03final/stats -name '*.csv' -size +3M -delete
+head -9 $(find gpurun_out/r03final/stats -name '*kernel_stats.csv' | head -1) | cut -c1-110,250-330
