@@ -74,14 +74,13 @@ const char* xdemhip_last_error(const xdemhip_ctx* ctx);
 #define XDEMHIP_OWN_STREAM ((void*)(intptr_t)-1)
 int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream);
 int xdemhip_synchronize(xdemhip_ctx* ctx);
-/* Device memory for callers that keep rasters resident (the planes of xdemhip_terrain, 70 GB for the 40000^2 set).  `flags`:
- * XDEMHIP_ALLOC_CONTIGUOUS asks the driver for PHYSICALLY contiguous memory (hipExtMallocWithFlags / hipDeviceMallocContiguous),
- * i.e. maximal page-table fragments: the streaming terrain kernel writes 256-byte row segments 160 KB apart into eleven planes,
- * so every store of a wave lands in a different 4 KiB page (falls back to an ordinary allocation when the driver has no single
- * piece; *got_contiguous, optional, reports which it was).  XDEMHIP_ALLOC_RECYCLED serves the request twice -- allocate, touch,
- * free, allocate again (a measurement switch: in one probe the same launch ran 12.9 ms on planes in a virtual range the process
- * had used before and 14.6-14.9 ms in a fresh one, eight of eight trials; later sessions did not confirm it). */
-enum { XDEMHIP_ALLOC_CONTIGUOUS = 1, XDEMHIP_ALLOC_RECYCLED = 2 };
+/* Device memory with a chosen PHYSICAL backing -- measurement switches for resident planes (the streaming
+ * terrain kernel runs the 40000^2 set in 12.7-13.4 ms on ordinary allocations of most boxes and in 14.3-14.7 ms on physically
+ * contiguous planes).  `flags` = 0: hipMalloc.  XDEMHIP_ALLOC_CONTIGUOUS: one physically contiguous piece (hipExtMallocWithFlags /
+ * hipDeviceMallocContiguous; an ordinary allocation when the driver has no such piece, *got_contiguous -- optional -- tells).
+ * XDEMHIP_ALLOC_RECYCLED (with or without CONTIGUOUS): allocate, touch, free, allocate again.  XDEMHIP_ALLOC_CHUNKED: one
+ * virtual range over separately created 64 MiB pieces (HIP virtual memory management).  xdemhip_device_free takes all of them. */
+enum { XDEMHIP_ALLOC_CONTIGUOUS = 1, XDEMHIP_ALLOC_RECYCLED = 2, XDEMHIP_ALLOC_CHUNKED = 4 };
 int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, int* got_contiguous);
 int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr);
 /* Timing of the work enqueued by the last call on the context stream, measured with hipEvents recorded on

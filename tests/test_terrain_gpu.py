@@ -241,10 +241,11 @@ def test_halo_rows_equal_full_raster(terrain):
         assert np.array_equal(out[i].cpu().numpy(), f[r0:r1], equal_nan=True)
 
 
-def test_library_allocated_planes(terrain):
-    """xdemhip_device_alloc / terrain.alloc_planes: resident planes as one physically contiguous allocation (the layout the
-    streaming kernel is fastest on).  Same results as on torch's own memory, the memory goes back when the tensor dies, small
-    sets stay with torch's allocator, and a size nobody can provide fails loudly."""
+@pytest.mark.parametrize("backing", ["contiguous", "chunked", "recycled"])
+def test_library_allocated_planes(terrain, backing):
+    """xdemhip_device_alloc / terrain.alloc_planes(backing=...): resident planes on the library's own allocations (physically
+    contiguous, chunked virtual range, recycled).  Same results as on torch's own memory, the memory goes back when the tensor
+    dies, and a size nobody can provide fails loudly."""
     import gc
 
     import torch
@@ -254,11 +255,11 @@ def test_library_allocated_planes(terrain):
 
     ctx = _lib.default_context()
     attrs = ["slope", "aspect", "hillshade", "profile_curvature", "topographic_position_index", "terrain_ruggedness_index"]
-    n = 4608   # 6 planes x 85 MB: above the 256 MiB threshold of alloc_planes
+    n = 4608
     dem = fbm_torch(n, n, "cuda", seed=3)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
-    planes = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx)
+    planes = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx, backing=backing)
     assert planes.shape == (len(attrs), n, n) and planes.is_cuda and hasattr(planes, "xdem_contiguous")
     assert torch.cuda.mem_get_info()[0] <= free0 - planes.numel() * 4 + (64 << 20)
     got = terrain.terrain_attributes_device(dem, attrs, resolution=10.0, out=planes, ctx=ctx)
@@ -274,8 +275,7 @@ def test_library_allocated_planes(terrain):
     gc.collect()
     torch.cuda.empty_cache()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
-    small = terrain.alloc_planes(2, 64, 64, torch.float32, ctx)
-    assert not hasattr(small, "xdem_contiguous")
+    assert not hasattr(terrain.alloc_planes(2, 64, 64, torch.float32, ctx), "xdem_contiguous")   # default: torch's allocator
     with pytest.raises(_lib.XdemHipError):
         ctx.device_tensor((1 << 40,), "float32")   # 4 TiB
 

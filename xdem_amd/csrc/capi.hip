@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -109,9 +110,94 @@ int device_alloc_once(xdemhip_ctx* ctx, size_t bytes, bool contiguous, void** pt
 }
 }  // namespace
 
+namespace {
+// XDEMHIP_ALLOC_CHUNKED: one virtual range backed by separately created physical pieces (HIP virtual memory management)
+struct ChunkedAlloc { void* base; size_t size; std::vector<hipMemGenericAllocationHandle_t> pieces; std::vector<size_t> piece_bytes; };
+std::mutex g_chunk_mu;
+std::vector<ChunkedAlloc> g_chunked;
+
+void chunked_release(ChunkedAlloc& c, size_t mapped_pieces) {
+    size_t off = 0;
+    for (size_t i = 0; i < c.pieces.size(); ++i) {
+        if (i < mapped_pieces) (void)hipMemUnmap(static_cast<char*>(c.base) + off, c.piece_bytes[i]);
+        (void)hipMemRelease(c.pieces[i]);
+        off += c.piece_bytes[i];
+    }
+    if (c.base) (void)hipMemAddressFree(c.base, c.size);
+}
+
+int device_alloc_chunked(xdemhip_ctx* ctx, size_t bytes, size_t piece, void** ptr) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+        (void)hipGetLastError();
+        return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "virtual memory management is not available");
+    }
+    piece = ((piece + gran - 1) / gran) * gran;
+    ChunkedAlloc c;
+    c.base = nullptr;
+    c.size = ((bytes + gran - 1) / gran) * gran;
+    if (hipMemAddressReserve(&c.base, c.size, 0, nullptr, 0) != hipSuccess || !c.base) {
+        (void)hipGetLastError();
+        return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMemAddressReserve failed");
+    }
+    size_t off = 0, mapped = 0;
+    bool ok = true;
+    while (off < c.size && ok) {
+        const size_t nbytes = (c.size - off) < piece ? (c.size - off) : piece;
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, nbytes, &prop, 0) != hipSuccess) { ok = false; break; }
+        c.pieces.push_back(h);
+        c.piece_bytes.push_back(nbytes);
+        if (hipMemMap(static_cast<char*>(c.base) + off, nbytes, 0, h, 0) != hipSuccess) { ok = false; break; }
+        ++mapped;
+        off += nbytes;
+    }
+    if (ok) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(c.base, c.size, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        chunked_release(c, mapped);
+        return xd_fail(ctx, XDEMHIP_ENOMEM, "chunked device allocation failed");
+    }
+    *ptr = c.base;
+    std::lock_guard<std::mutex> lock(g_chunk_mu);
+    g_chunked.push_back(std::move(c));
+    return XDEMHIP_OK;
+}
+
+bool device_free_chunked(void* p) {   // true: `p` was a chunked allocation (now released)
+    ChunkedAlloc c;
+    {
+        std::lock_guard<std::mutex> lock(g_chunk_mu);
+        size_t i = 0;
+        for (; i < g_chunked.size(); ++i)
+            if (g_chunked[i].base == p) break;
+        if (i == g_chunked.size()) return false;
+        c = std::move(g_chunked[i]);
+        g_chunked.erase(g_chunked.begin() + (long)i);
+    }
+    (void)hipDeviceSynchronize();
+    chunked_release(c, c.pieces.size());
+    return true;
+}
+}  // namespace
+
 int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, int* got_contiguous) {
     if (!ctx || !ptr || bytes == 0) return ctx ? xd_fail(ctx, XDEMHIP_EINVAL, "bad argument") : XDEMHIP_EINVAL;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (flags & XDEMHIP_ALLOC_CHUNKED) {
+        *ptr = nullptr;
+        if (got_contiguous) *got_contiguous = 0;
+        return device_alloc_chunked(ctx, bytes, (size_t)64 << 20, ptr);
+    }
     const bool contiguous = (flags & XDEMHIP_ALLOC_CONTIGUOUS) != 0;
     if (flags & XDEMHIP_ALLOC_RECYCLED) {
         // a first allocation of this size is mapped, touched and released, and the request is served again: the second allocation
@@ -132,6 +218,7 @@ int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr) {
     if (!ctx) return XDEMHIP_EINVAL;
     if (!ptr) return XDEMHIP_OK;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (device_free_chunked(ptr)) return XDEMHIP_OK;
     XD_HIP_CHECK(ctx, hipFree(ptr));
     return XDEMHIP_OK;
 }

@@ -267,23 +267,23 @@ def get_terrain_attribute(
     return output_attributes if len(output_attributes) > 1 else output_attributes[0]
 
 
-def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None, recycled: bool = False):
-    """(n_attr, H, W) device tensor for resident attribute planes.  Large sets come from ``xdemhip_device_alloc`` as ONE physically
-    contiguous piece where the driver can provide it: the streaming kernel writes 256-byte row segments of every plane a raster
-    row apart, so planes assembled from small physical pieces make the launch translation-bound -- measured on the 40000^2
-    set: 12.9-13.1 ms on contiguous planes in every trial, 13.0 or 14.6-14.9 ms on ``torch.empty`` planes depending on the
-    allocation (profiles/r03_box_variance.txt; later sessions showed that contiguity alone does not decide the mode -- DESIGN.md
-    section 1 -- the allocator stays because it never hurt).  ``recycled`` = XDEMHIP_ALLOC_RECYCLED (a measurement switch).
-    Small sets stay with torch's caching allocator."""
+def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None, backing: str = "default"):
+    """(n_attr, H, W) device tensor for resident attribute planes.  ``backing`` = "default" (torch's allocator, i.e. an ordinary
+    hipMalloc) or one of the ``xdemhip_device_alloc`` forms -- "contiguous" (one physically contiguous piece), "chunked" (one
+    virtual range over separately created 64 MiB pieces), "recycled" (allocate, touch, free, allocate again).  These exist to
+    MEASURE how the physical backing of the planes decides the speed of the streaming kernel: physically
+    contiguous planes ran the 40000^2 launch at 14.3-14.7 ms in 12 of 13 trials, ordinary allocations at 12.7-13.4 ms on most
+    boxes -- so the default stays with the ordinary allocation."""
     import torch
 
     dtype = dtype or torch.float32
     ctx = ctx or _lib.default_context(None if device is None else torch.device(device).index)
-    dev = torch.device("cuda", ctx.device)
-    if n_attr * H * W * torch.empty((), dtype=dtype).element_size() < (1 << 28):
-        return torch.empty((n_attr, H, W), dtype=dtype, device=dev)
-    return ctx.device_tensor((n_attr, H, W), {torch.float32: "float32", torch.float64: "float64"}[dtype], contiguous=True,
-                             recycled=recycled)
+    if backing == "default":
+        return torch.empty((n_attr, H, W), dtype=dtype, device=torch.device("cuda", ctx.device))
+    if backing not in ("contiguous", "chunked", "recycled"):
+        raise ValueError("backing must be 'default', 'contiguous', 'chunked' or 'recycled'")
+    return ctx.device_tensor((n_attr, H, W), {torch.float32: "float32", torch.float64: "float64"}[dtype],
+                             contiguous=backing in ("contiguous", "recycled"), recycled=backing == "recycled", chunked=backing == "chunked")
 
 
 def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0, degrees: bool = True,
@@ -302,7 +302,7 @@ def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0
     dt = {torch.float32: np.float32, torch.float64: np.float64}[dem.dtype]
     ctx = ctx or _lib.default_context(dem.device.index)
     if out is None:
-        out = alloc_planes(len(attribute), H, W, dem.dtype, ctx, dem.device)
+        out = torch.empty((len(attribute), H, W), dtype=dem.dtype, device=dem.device)
     ctx.set_stream(torch.cuda.current_stream(dem.device).cuda_stream)
     assert out.shape == (len(attribute), H, W) and out.stride(2) == 1 and out.stride(1) == W and out.is_cuda
     ptrs = {a: out[i].data_ptr() for i, a in enumerate(attribute)}  # planes may be row windows of a larger tensor
