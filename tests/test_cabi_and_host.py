@@ -30,6 +30,38 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.xdemhip_version() >= 100
 
 
+def test_header_constants_match_the_binding():
+    """The numeric constants the ctypes side hard-codes are the header's: memory spaces, dtypes, allocation flags, reduction kinds."""
+    import re
+
+    from xdem_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "xdemhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+    enums = {}
+    for body in re.findall(r"enum\s*\{([^}]*)\}", hdr):
+        nxt = 0
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            m = re.match(r"(\w+)\s*(?:=\s*(-?\w+))?", item)
+            name, val = m.group(1), m.group(2)
+            if val is not None:
+                try:
+                    nxt = int(val.rstrip("uUlL"), 0)
+                except ValueError:   # an expression (attribute bits: 1u << k): not one of the constants checked here
+                    nxt = None
+            enums[name] = nxt
+            nxt = None if nxt is None else nxt + 1
+    assert (enums["XDEMHIP_HOST"], enums["XDEMHIP_DEVICE"]) == (_lib.HOST, _lib.DEVICE)
+    assert (enums["XDEMHIP_F32"], enums["XDEMHIP_F64"]) == (_lib.F32, _lib.F64)
+    assert (enums["XDEMHIP_ALLOC_CONTIGUOUS"], enums["XDEMHIP_ALLOC_RECYCLED"], enums["XDEMHIP_ALLOC_CHUNKED"]) == (1, 2, 4)
+    src = open(os.path.join(ROOT, "xdem_amd", "_lib.py")).read()
+    assert "flags = (4 if chunked else ((1 if contiguous else 0) | (2 if recycled else 0)))" in src
+
+
 def test_fractal_constants_reproduce_numpy_float16(lib):
     """Host-only helper of the C-ABI against the NumPy arithmetic the reference runs (window.py:362-393): np.log of a
     uint8 divisor array is float16, and so are its mean and SS_xx."""
