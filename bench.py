@@ -442,9 +442,10 @@ def main() -> None:
     def partitioned_run(n, steps, warmup):
         """`steps` timed passes of the 11-attribute set over the n x n raster held as `world` row blocks; max over ranks."""
         block = xdist.RowBlock(n, n, depth, rank, world, dev)
-        # resident planes: an ordinary allocation (XDEM_BENCH_PLANES = contiguous | chunked | recycled selects one of the measurement
-        # forms of xdemhip_device_alloc: physically contiguous planes run this launch 10 % slower, DESIGN.md section 1)
-        out = terrain.alloc_planes(len(FULL), block.rows, n, torch.float32, ctx, dev, backing=os.environ.get("XDEM_BENCH_PLANES", "default"))
+        # resident planes from the library's allocator: one virtual range over 8 MiB physical pieces in pseudo-random order, so that
+        # the ~55 row streams of the kernel spread over the memory channels whatever the driver's free list looks like (DESIGN.md
+        # section 1; XDEM_BENCH_PLANES = torch | contiguous | chunked selects another backing for measurements)
+        out = terrain.alloc_planes(len(FULL), block.rows, n, torch.float32, ctx, dev, backing=os.environ.get("XDEM_BENCH_PLANES", "auto"))
         # each rank synthesises exactly its rows of the global raster (halo rows come from the neighbours)
         block.interior.copy_(fbm_torch(block.rows, n, dev, seed=42, row0=block.r0, total_rows=n))
 
@@ -512,7 +513,7 @@ def main() -> None:
             "dtype": "f32 in/out, mixed f64/f32 arithmetic (f64 where cancellation demands: stencil sums, curvature numerators, discriminants)",
             "data": "synthetic",
             "config": {"workload": f"{n}x{n} float32 fBm DEM (H=0.7, 1000+-300 m, res 10 m), Florinsky fit, geometric "
-                                   f"curvatures, 11 attributes, device-resident in/out",
+                                   f"curvatures, 11 attributes, device-resident in/out (planes: the library's scattered 8 MiB-piece backing)",
                        "partition": f"{world} row block(s), halo depth {depth}" +
                                     (", shared-GPU gloo test mode" if share else (", RCCL send/recv" if world > 1 else "")),
                        "bytes_per_pixel": BYTES_PER_PIXEL},

@@ -74,13 +74,15 @@ const char* xdemhip_last_error(const xdemhip_ctx* ctx);
 #define XDEMHIP_OWN_STREAM ((void*)(intptr_t)-1)
 int xdemhip_set_stream(xdemhip_ctx* ctx, void* hip_stream);
 int xdemhip_synchronize(xdemhip_ctx* ctx);
-/* Device memory with a chosen PHYSICAL backing -- measurement switches for resident planes (the streaming
- * terrain kernel runs the 40000^2 set in 12.7-13.4 ms on ordinary allocations of most boxes and in 14.3-14.7 ms on physically
- * contiguous planes).  `flags` = 0: hipMalloc.  XDEMHIP_ALLOC_CONTIGUOUS: one physically contiguous piece (hipExtMallocWithFlags /
- * hipDeviceMallocContiguous; an ordinary allocation when the driver has no such piece, *got_contiguous -- optional -- tells).
- * XDEMHIP_ALLOC_RECYCLED (with or without CONTIGUOUS): allocate, touch, free, allocate again.  XDEMHIP_ALLOC_CHUNKED: one
- * virtual range over separately created 64 MiB pieces (HIP virtual memory management).  xdemhip_device_free takes all of them. */
-enum { XDEMHIP_ALLOC_CONTIGUOUS = 1, XDEMHIP_ALLOC_RECYCLED = 2, XDEMHIP_ALLOC_CHUNKED = 4 };
+/* Device memory with a chosen PHYSICAL backing, for resident planes.  The streaming terrain kernel keeps
+ * ~55 row streams going at once; in physically contiguous memory -- XDEMHIP_ALLOC_CONTIGUOUS, or an ordinary allocation on a box
+ * whose free memory is one block -- they collide in the memory channels (14.4-15.6 ms for the 40000^2 set), in memory whose
+ * pieces are scattered they do not (12.7-13.3 ms).  XDEMHIP_ALLOC_SCATTERED is the form to use: one virtual range over 8 MiB
+ * physical pieces mapped in a fixed pseudo-random order (HIP virtual memory management).  `flags` = 0: hipMalloc.
+ * XDEMHIP_ALLOC_CONTIGUOUS (hipExtMallocWithFlags / hipDeviceMallocContiguous; *got_contiguous -- optional -- tells whether the
+ * driver had one piece), XDEMHIP_ALLOC_RECYCLED (allocate, touch, free, allocate again), XDEMHIP_ALLOC_CHUNKED (64 MiB pieces in
+ * order) exist for measurements.  xdemhip_device_free takes all of them. */
+enum { XDEMHIP_ALLOC_CONTIGUOUS = 1, XDEMHIP_ALLOC_RECYCLED = 2, XDEMHIP_ALLOC_CHUNKED = 4, XDEMHIP_ALLOC_SCATTERED = 8 };
 int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, int* got_contiguous);
 int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr);
 /* Timing of the work enqueued by the last call on the context stream, measured with hipEvents recorded on

@@ -57,9 +57,10 @@ def test_header_constants_match_the_binding():
             nxt = None if nxt is None else nxt + 1
     assert (enums["XDEMHIP_HOST"], enums["XDEMHIP_DEVICE"]) == (_lib.HOST, _lib.DEVICE)
     assert (enums["XDEMHIP_F32"], enums["XDEMHIP_F64"]) == (_lib.F32, _lib.F64)
-    assert (enums["XDEMHIP_ALLOC_CONTIGUOUS"], enums["XDEMHIP_ALLOC_RECYCLED"], enums["XDEMHIP_ALLOC_CHUNKED"]) == (1, 2, 4)
+    assert (enums["XDEMHIP_ALLOC_CONTIGUOUS"], enums["XDEMHIP_ALLOC_RECYCLED"], enums["XDEMHIP_ALLOC_CHUNKED"],
+            enums["XDEMHIP_ALLOC_SCATTERED"]) == (1, 2, 4, 8)
     src = open(os.path.join(ROOT, "xdem_amd", "_lib.py")).read()
-    assert "flags = (4 if chunked else ((1 if contiguous else 0) | (2 if recycled else 0)))" in src
+    assert "flags = 8 if scattered else (4 if chunked else ((1 if contiguous else 0) | (2 if recycled else 0)))" in src
 
 
 def test_fractal_constants_reproduce_numpy_float16(lib):

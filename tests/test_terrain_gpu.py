@@ -241,7 +241,7 @@ def test_halo_rows_equal_full_raster(terrain):
         assert np.array_equal(out[i].cpu().numpy(), f[r0:r1], equal_nan=True)
 
 
-@pytest.mark.parametrize("backing", ["contiguous", "chunked", "recycled"])
+@pytest.mark.parametrize("backing", ["contiguous", "chunked", "scattered", "recycled"])
 def test_library_allocated_planes(terrain, backing):
     """xdemhip_device_alloc / terrain.alloc_planes(backing=...): resident planes on the library's own allocations (physically
     contiguous, chunked virtual range, recycled).  Same results as on torch's own memory, the memory goes back when the tensor
@@ -275,7 +275,8 @@ def test_library_allocated_planes(terrain, backing):
     gc.collect()
     torch.cuda.empty_cache()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
-    assert not hasattr(terrain.alloc_planes(2, 64, 64, torch.float32, ctx), "xdem_contiguous")   # default: torch's allocator
+    assert not hasattr(terrain.alloc_planes(2, 64, 64, torch.float32, ctx), "xdem_contiguous")   # small sets: torch's allocator
+    assert hasattr(terrain.alloc_planes(4, n, n, torch.float32, ctx), "xdem_contiguous")          # 340 MB: the library's scattered backing
     with pytest.raises(_lib.XdemHipError):
         ctx.device_tensor((1 << 40,), "float32")   # 4 TiB
 

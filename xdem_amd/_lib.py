@@ -283,7 +283,8 @@ class Context:
     def synchronize(self) -> None:
         self.check(self._L.xdemhip_synchronize(self.handle))
 
-    def device_tensor(self, shape, dtype="float32", contiguous: bool = True, recycled: bool = False, chunked: bool = False):
+    def device_tensor(self, shape, dtype="float32", contiguous: bool = True, recycled: bool = False, chunked: bool = False,
+                      scattered: bool = False):
         """A torch tensor over device memory from ``xdemhip_device_alloc`` -- physically contiguous when the driver can provide it
         (``tensor.xdem_contiguous`` tells): the layout the streaming terrain kernel wants for its output planes (include/xdemhip.h).
         The memory is released when the tensor (and every view of it) is gone."""
@@ -293,7 +294,8 @@ class Context:
         np_dt = np.dtype(dtype)
         count = int(np.prod(shape))
         ptr, got = ctypes.c_void_p(), ctypes.c_int()
-        flags = (4 if chunked else ((1 if contiguous else 0) | (2 if recycled else 0)))   # XDEMHIP_ALLOC_CHUNKED / _CONTIGUOUS | _RECYCLED
+        # XDEMHIP_ALLOC_SCATTERED / _CHUNKED / _CONTIGUOUS | _RECYCLED
+        flags = 8 if scattered else (4 if chunked else ((1 if contiguous else 0) | (2 if recycled else 0)))
         self.check(self._L.xdemhip_device_alloc(self.handle, count * np_dt.itemsize, flags, ctypes.byref(ptr), ctypes.byref(got)))
         owner = _OwnedDeviceArray(self, int(ptr.value), count, np_dt.str)
         t = torch.as_tensor(owner, device=torch.device("cuda", self.device)).view(*shape)

@@ -111,22 +111,22 @@ int device_alloc_once(xdemhip_ctx* ctx, size_t bytes, bool contiguous, void** pt
 }  // namespace
 
 namespace {
-// XDEMHIP_ALLOC_CHUNKED: one virtual range backed by separately created physical pieces (HIP virtual memory management)
-struct ChunkedAlloc { void* base; size_t size; std::vector<hipMemGenericAllocationHandle_t> pieces; std::vector<size_t> piece_bytes; };
+// XDEMHIP_ALLOC_CHUNKED / _SCATTERED: one virtual range backed by separately created physical pieces (HIP virtual memory
+// management); SCATTERED maps the pieces into the range in a pseudo-random order, so that neighbouring pieces of the range are not
+// neighbours in device memory even when the driver hands the pieces out of one contiguous block
+struct ChunkedAlloc { void* base = nullptr; size_t size = 0, piece = 0; std::vector<hipMemGenericAllocationHandle_t> pieces; std::vector<size_t> slot; };
 std::mutex g_chunk_mu;
 std::vector<ChunkedAlloc> g_chunked;
 
 void chunked_release(ChunkedAlloc& c, size_t mapped_pieces) {
-    size_t off = 0;
     for (size_t i = 0; i < c.pieces.size(); ++i) {
-        if (i < mapped_pieces) (void)hipMemUnmap(static_cast<char*>(c.base) + off, c.piece_bytes[i]);
+        if (i < mapped_pieces) (void)hipMemUnmap(static_cast<char*>(c.base) + c.slot[i] * c.piece, c.piece);
         (void)hipMemRelease(c.pieces[i]);
-        off += c.piece_bytes[i];
     }
     if (c.base) (void)hipMemAddressFree(c.base, c.size);
 }
 
-int device_alloc_chunked(xdemhip_ctx* ctx, size_t bytes, size_t piece, void** ptr) {
+int device_alloc_chunked(xdemhip_ctx* ctx, size_t bytes, size_t piece, bool shuffle, void** ptr) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -136,25 +136,32 @@ int device_alloc_chunked(xdemhip_ctx* ctx, size_t bytes, size_t piece, void** pt
         (void)hipGetLastError();
         return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "virtual memory management is not available");
     }
-    piece = ((piece + gran - 1) / gran) * gran;
     ChunkedAlloc c;
-    c.base = nullptr;
-    c.size = ((bytes + gran - 1) / gran) * gran;
+    c.piece = ((piece + gran - 1) / gran) * gran;
+    const size_t n = (bytes + c.piece - 1) / c.piece;
+    c.size = n * c.piece;
     if (hipMemAddressReserve(&c.base, c.size, 0, nullptr, 0) != hipSuccess || !c.base) {
         (void)hipGetLastError();
         return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMemAddressReserve failed");
     }
-    size_t off = 0, mapped = 0;
+    c.slot.resize(n);
+    for (size_t i = 0; i < n; ++i) c.slot[i] = i;
+    if (shuffle) {   // Fisher-Yates with a fixed linear congruential generator: the same layout every time
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        for (size_t i = n; i > 1; --i) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            const size_t k = (size_t)((st >> 33) % i);
+            std::swap(c.slot[i - 1], c.slot[k]);
+        }
+    }
+    size_t mapped = 0;
     bool ok = true;
-    while (off < c.size && ok) {
-        const size_t nbytes = (c.size - off) < piece ? (c.size - off) : piece;
+    for (size_t i = 0; i < n && ok; ++i) {
         hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, nbytes, &prop, 0) != hipSuccess) { ok = false; break; }
+        if (hipMemCreate(&h, c.piece, &prop, 0) != hipSuccess) { ok = false; break; }
         c.pieces.push_back(h);
-        c.piece_bytes.push_back(nbytes);
-        if (hipMemMap(static_cast<char*>(c.base) + off, nbytes, 0, h, 0) != hipSuccess) { ok = false; break; }
+        if (hipMemMap(static_cast<char*>(c.base) + c.slot[i] * c.piece, c.piece, 0, h, 0) != hipSuccess) { ok = false; break; }
         ++mapped;
-        off += nbytes;
     }
     if (ok) {
         hipMemAccessDesc acc = {};
@@ -193,10 +200,11 @@ bool device_free_chunked(void* p) {   // true: `p` was a chunked allocation (now
 int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, int* got_contiguous) {
     if (!ctx || !ptr || bytes == 0) return ctx ? xd_fail(ctx, XDEMHIP_EINVAL, "bad argument") : XDEMHIP_EINVAL;
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (flags & XDEMHIP_ALLOC_CHUNKED) {
+    if (flags & (XDEMHIP_ALLOC_CHUNKED | XDEMHIP_ALLOC_SCATTERED)) {
         *ptr = nullptr;
         if (got_contiguous) *got_contiguous = 0;
-        return device_alloc_chunked(ctx, bytes, (size_t)64 << 20, ptr);
+        const bool scattered = (flags & XDEMHIP_ALLOC_SCATTERED) != 0;
+        return device_alloc_chunked(ctx, bytes, scattered ? (size_t)8 << 20 : (size_t)64 << 20, scattered, ptr);
     }
     const bool contiguous = (flags & XDEMHIP_ALLOC_CONTIGUOUS) != 0;
     if (flags & XDEMHIP_ALLOC_RECYCLED) {

@@ -267,23 +267,31 @@ def get_terrain_attribute(
     return output_attributes if len(output_attributes) > 1 else output_attributes[0]
 
 
-def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None, backing: str = "default"):
-    """(n_attr, H, W) device tensor for resident attribute planes.  ``backing`` = "default" (torch's allocator, i.e. an ordinary
-    hipMalloc) or one of the ``xdemhip_device_alloc`` forms -- "contiguous" (one physically contiguous piece), "chunked" (one
-    virtual range over separately created 64 MiB pieces), "recycled" (allocate, touch, free, allocate again).  These exist to
-    MEASURE how the physical backing of the planes decides the speed of the streaming kernel: physically
-    contiguous planes ran the 40000^2 launch at 14.3-14.7 ms in 12 of 13 trials, ordinary allocations at 12.7-13.4 ms on most
-    boxes -- so the default stays with the ordinary allocation."""
+def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | None = None, device=None, backing: str = "auto"):
+    """(n_attr, H, W) device tensor for resident attribute planes.
+
+    How the planes are backed PHYSICALLY decides the speed of the streaming kernel: it writes ~55 row
+    streams at once (11 planes x the row bands in flight), and when the planes sit in one physically contiguous block -- what an
+    ordinary hipMalloc returns on a box whose free device memory is still one piece -- those streams collide in the memory
+    channels: 14.4-15.6 ms for the 40000^2 set instead of 12.7-13.3 ms.  ``backing``:
+    "auto" (default) = "scattered" for sets of 256 MiB and more, torch's allocator below; "scattered" = one virtual range over
+    8 MiB physical pieces mapped in a fixed pseudo-random order (``xdemhip_device_alloc``, HIP virtual memory management): 13.3 ms
+    on a box where ordinary and contiguous planes ran at 15.0-15.6 / 14.8 ms in the same process; "torch" = torch's allocator
+    (ordinary hipMalloc); "contiguous", "chunked" (64 MiB pieces in order), "recycled" = the other forms, kept for measurements.
+    The memory of the library's forms is released when the tensor (and every view of it) is gone."""
     import torch
 
     dtype = dtype or torch.float32
     ctx = ctx or _lib.default_context(None if device is None else torch.device(device).index)
-    if backing == "default":
+    if backing == "auto":
+        backing = "scattered" if n_attr * H * W * torch.empty((), dtype=dtype).element_size() >= (1 << 28) else "torch"
+    if backing == "torch":
         return torch.empty((n_attr, H, W), dtype=dtype, device=torch.device("cuda", ctx.device))
-    if backing not in ("contiguous", "chunked", "recycled"):
-        raise ValueError("backing must be 'default', 'contiguous', 'chunked' or 'recycled'")
+    if backing not in ("contiguous", "chunked", "recycled", "scattered"):
+        raise ValueError("backing must be 'auto', 'torch', 'scattered', 'contiguous', 'chunked' or 'recycled'")
     return ctx.device_tensor((n_attr, H, W), {torch.float32: "float32", torch.float64: "float64"}[dtype],
-                             contiguous=backing in ("contiguous", "recycled"), recycled=backing == "recycled", chunked=backing == "chunked")
+                             contiguous=backing in ("contiguous", "recycled"), recycled=backing == "recycled", chunked=backing == "chunked",
+                             scattered=backing == "scattered")
 
 
 def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0, degrees: bool = True,
@@ -302,7 +310,7 @@ def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0
     dt = {torch.float32: np.float32, torch.float64: np.float64}[dem.dtype]
     ctx = ctx or _lib.default_context(dem.device.index)
     if out is None:
-        out = torch.empty((len(attribute), H, W), dtype=dem.dtype, device=dem.device)
+        out = alloc_planes(len(attribute), H, W, dem.dtype, ctx, dem.device)
     ctx.set_stream(torch.cuda.current_stream(dem.device).cuda_stream)
     assert out.shape == (len(attribute), H, W) and out.stride(2) == 1 and out.stride(1) == W and out.is_cuda
     ptrs = {a: out[i].data_ptr() for i, a in enumerate(attribute)}  # planes may be row windows of a larger tensor
