@@ -274,7 +274,8 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
     streams at once (11 planes x the row bands in flight), and when the planes sit in one physically contiguous block -- what an
     ordinary hipMalloc returns on a box whose free device memory is still one piece -- those streams collide in the memory
     channels: 14.4-15.6 ms for the 40000^2 set instead of 12.7-13.3 ms.  ``backing``:
-    "auto" (default) = "scattered" for sets of 256 MiB and more, torch's allocator below; "scattered" = one virtual range over
+    "auto" (default) = "scattered" for sets of 256 MiB and more (an ordinary allocation if the driver cannot provide the pieces),
+    torch's allocator below; "scattered" = one virtual range over
     8 MiB physical pieces mapped in a fixed pseudo-random order (``xdemhip_device_alloc``, HIP virtual memory management): 13.3 ms
     on a box where ordinary and contiguous planes ran at 15.0-15.6 / 14.8 ms in the same process; "torch" = torch's allocator
     (ordinary hipMalloc); "contiguous", "chunked" (64 MiB pieces in order), "recycled" = the other forms, kept for measurements.
@@ -283,15 +284,28 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
 
     dtype = dtype or torch.float32
     ctx = ctx or _lib.default_context(None if device is None else torch.device(device).index)
-    if backing == "auto":
+    auto = backing == "auto"
+    if auto:
         backing = "scattered" if n_attr * H * W * torch.empty((), dtype=dtype).element_size() >= (1 << 28) else "torch"
     if backing == "torch":
         return torch.empty((n_attr, H, W), dtype=dtype, device=torch.device("cuda", ctx.device))
     if backing not in ("contiguous", "chunked", "recycled", "scattered"):
         raise ValueError("backing must be 'auto', 'torch', 'scattered', 'contiguous', 'chunked' or 'recycled'")
-    return ctx.device_tensor((n_attr, H, W), {torch.float32: "float32", torch.float64: "float64"}[dtype],
-                             contiguous=backing in ("contiguous", "recycled"), recycled=backing == "recycled", chunked=backing == "chunked",
-                             scattered=backing == "scattered")
+    kw = dict(contiguous=backing in ("contiguous", "recycled"), recycled=backing == "recycled", chunked=backing == "chunked",
+              scattered=backing == "scattered")
+    np_dt = {torch.float32: "float32", torch.float64: "float64"}[dtype]
+    try:
+        return ctx.device_tensor((n_attr, H, W), np_dt, **kw)
+    except _lib.XdemHipError:
+        if not auto:
+            raise
+    # "auto": the library's pieces do not come out of torch's cache -- hand the cached blocks back to the driver and try again,
+    # and rather take an ordinary allocation than fail
+    torch.cuda.empty_cache()
+    try:
+        return ctx.device_tensor((n_attr, H, W), np_dt, **kw)
+    except _lib.XdemHipError:
+        return torch.empty((n_attr, H, W), dtype=dtype, device=torch.device("cuda", ctx.device))
 
 
 def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0, degrees: bool = True,
@@ -309,8 +323,8 @@ def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0
     H = Hbuf - halo_top - halo_bottom
     dt = {torch.float32: np.float32, torch.float64: np.float64}[dem.dtype]
     ctx = ctx or _lib.default_context(dem.device.index)
-    if out is None:
-        out = alloc_planes(len(attribute), H, W, dem.dtype, ctx, dem.device)
+    if out is None:   # (callers who keep large plane sets resident: see alloc_planes for the backing that is fastest to write)
+        out = torch.empty((len(attribute), H, W), dtype=dem.dtype, device=dem.device)
     ctx.set_stream(torch.cuda.current_stream(dem.device).cuda_stream)
     assert out.shape == (len(attribute), H, W) and out.stride(2) == 1 and out.stride(1) == W and out.is_cuda
     ptrs = {a: out[i].data_ptr() for i, a in enumerate(attribute)}  # planes may be row windows of a larger tensor
