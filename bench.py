@@ -223,16 +223,17 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
     group = "world" if world > 1 else None
     out = {}
 
-    def variogram_leg(samples: int, label: str) -> dict:
+    def variogram_leg(samples: int, label: str, runs: int = C5_RUNS, warm: bool = True) -> dict:
         # the SAME seeded blocks on every rank (fBm(H = 0.3) values on a 20000^2 grid, the product's equidistant disk / ring
         # sampler: raster pixels = integer-lattice coordinates -> the integer-lattice pair kernels); rank r keeps blocks r::world
-        blocks, edges = c5_variogram_blocks(dev, runs=C5_RUNS, samples=samples)
+        blocks, edges = c5_variogram_blocks(dev, runs=runs, samples=samples)
         total = sum(int(b[0].size) * int(b[3].size) for b in blocks)
         mine = blocks[rank::world]
         ps = ss.PairSet(mine, edges, ctx)
         del blocks
         try:
-            ps.sums(0)                       # warm-up (kernel load, clocks)
+            if warm:
+                ps.sums(0)                   # warm-up (kernel load, clocks)
             barrier()
             t0 = time.perf_counter()
             s_m, c_m = ps.sums(0)
@@ -245,10 +246,12 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
             med, c_d = ss.class_medians(ps, group)    # first call: also allocates (and first-touches) the candidate buffers
             barrier()
             dt_d_cold = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            med, c_d = ss.class_medians(ps, group)    # timed like every other leg: after a warm-up call
-            barrier()
-            dt_d = time.perf_counter() - t0
+            dt_d = dt_d_cold
+            if warm:
+                t0 = time.perf_counter()
+                med, c_d = ss.class_medians(ps, group)    # timed like every other leg: after a warm-up call
+                barrier()
+                dt_d = time.perf_counter() - t0
         finally:
             ps.close()
         # validation inside the run: the two routes (sum kernel / bracketed exact selection) must agree on the class membership
@@ -263,7 +266,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         dowd_rate = total / dt_d / 1e9
         return {"pairs": total, "lag_classes": int(len(edges)), "n_gpus": world,
                 "matheron_pass_Gpairs_s": round(mat_rate, 1), "dowd_exact_median_Gpairs_s": round(dowd_rate, 2),
-                "dowd_first_call_Gpairs_s": round(total / dt_d_cold / 1e9, 2),
+                "dowd_first_call_Gpairs_s": round(total / dt_d_cold / 1e9, 2), "runs": runs, "points_per_sample": samples,
                 "validated": "class counts of the Matheron and exact-Dowd routes identical, their sum = pairs formed",
                 "roofline": {"bound": "valu", "model": f"{PAIR_OPS_MODEL} VALU lane-operations per pair (SURVEY 8d); bytes per pair ~ 0",
                              "achieved": round(PAIR_OPS_MODEL * mat_rate / 1e3, 2), "achieved_dowd": round(PAIR_OPS_MODEL * dowd_rate / 1e3, 2),
@@ -281,9 +284,13 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
                                             "sampler (centre disk x rings, 9091 points each; rings that leave the raster hold fewer), 50 "
                                             "edges geomspace(sqrt 2, maxlag); Matheron = one pair pass (kernel time), Dowd = exact per-class "
                                             "median of |dv| by bracketed selection (wall time)")
-    if c5a:
-        out["variogram_c5a"] = variogram_leg(223607, "C5 reading A (SURVEY 8d): subsample = 1e7 in the reference's sense -> 100 runs x "
-                                                     "223607-point samples, ~5e13 pairs")
+    # C5 in SURVEY 8d's PRIMARY reading A (subsample = 1e7 in the reference's sense -> runs x (centre disk x 10 rings of 223607
+    # points), xdem/spatialstats.py:1104-1183): every default run carries 20 of its 100 runs (1e13 pairs, ~25 s, same in-run
+    # validation; rates per pair do not depend on the number of runs), --c5a the full 100 runs / 5e13 pairs (minutes)
+    a_runs = max(1, min(C5_RUNS, 100 if c5a else 20))
+    out["variogram_c5a"] = variogram_leg(223607, f"C5 reading A (SURVEY 8d): subsample = 1e7 in the reference's sense -> {a_runs} of the 100 "
+                                                 "runs x 223607-point samples (5e13 pairs for the 100; --c5a runs them all); each "
+                                                 "route timed once, after reading B has warmed the kernels", runs=a_runs, warm=False)
     # Nuth-Kaab C3
     m = C3_SIZE
     res = (10.0, 10.0)
@@ -352,6 +359,46 @@ NK_TOUCHED_BYTES = 22
 NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference copy 4 + tba 4 + dh out 4 -- min / max aspect come from the "
                    "plan's lists of extreme-aspect pixels, the inlier mask is folded into the reference copy as NaN; bin pass: dh 4 + "
                    "slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not recomputed; 27 B/pixel in round 2")
+
+
+def terrain_sets(ctx, dev, dem, kw, steps: int) -> dict:
+    """The SMALL attribute sets users ask for far more often than all eleven planes -- DEM.slope(), slope + aspect, a hillshade
+    -- and the full set with directional curvatures, on the headline raster: rate, bytes per pixel (4 read + 4 per plane
+    written) and fraction of the HBM roofline per launch (HIP events on the launch stream, planes from terrain.alloc_planes)."""
+    import torch
+
+    from xdem_amd import terrain
+
+    H, W = dem.shape
+    cases = [("slope", ["slope"], dict(surface_fit="Florinsky")),
+             ("slope+aspect Horn (DEM.slope() / aspect() defaults of the reference's examples)", ["slope", "aspect"], dict(surface_fit="Horn")),
+             ("slope+aspect Florinsky", ["slope", "aspect"], dict(surface_fit="Florinsky")),
+             ("hillshade", ["hillshade"], dict(surface_fit="Florinsky")),
+             ("slope+aspect+hillshade Florinsky", ["slope", "aspect", "hillshade"], dict(surface_fit="Florinsky")),
+             ("full 11, directional curvatures", FULL, dict(surface_fit="Florinsky", curv_method="directional"))]
+    out = {}
+    for name, attrs, extra in cases:
+        planes = terrain.alloc_planes(len(attrs), H, W, torch.float32, ctx, dev)
+        k = dict(kw)
+        k.update(extra)
+        for _ in range(2):
+            terrain.terrain_attributes_device(dem, attrs, out=planes, **k)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a_, b_ in ev:
+            a_.record()
+            terrain.terrain_attributes_device(dem, attrs, out=planes, **k)
+            b_.record()
+        torch.cuda.synchronize(dev)
+        ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
+        med = ms[len(ms) // 2]
+        bpp = 4 + 4 * len(attrs)
+        gbps = bpp * float(H) * W / (med * 1e-3) / 1e9
+        out[name] = {"planes": len(attrs), "bytes_per_pixel": bpp, "kernel_ms_median": round(med, 4), "kernel_ms_min": round(ms[0], 4),
+                     "Mpixels_s": round(float(H) * W / (med * 1e-3) / 1e6, 1), "achieved_GBps": round(gbps, 1),
+                     "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
+        del planes
+    return {"raster": f"{H}x{W} float32 (the headline DEM)", "steps": steps, "sets": out,
+            "note": "one launch per step, device-resident; fractions against the 8 TB/s HBM peak at 4 + 4 K bytes per pixel"}
 
 
 def device_state() -> list:
@@ -429,6 +476,10 @@ def main() -> None:
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    if not share and torch.cuda.device_count() < min(args.gpus, 8):
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible: one rank per GPU is the measured configuration")
     depth = xdist.halo_depth(FULL, "Florinsky", 3)
     ctx = _lib.default_context(local_rank)
     kw = dict(resolution=10.0, surface_fit="Florinsky", curv_method="geometric", ctx=ctx)
@@ -439,15 +490,19 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def partitioned_run(n, steps, warmup):
+    def partitioned_run(n, steps, warmup, backing=None, block=None):
         """`steps` timed passes of the 11-attribute set over the n x n raster held as `world` row blocks; max over ranks."""
-        block = xdist.RowBlock(n, n, depth, rank, world, dev)
+        fresh = block is None
+        if fresh:
+            block = xdist.RowBlock(n, n, depth, rank, world, dev)
         # resident planes from the library's allocator: one virtual range over 8 MiB physical pieces in pseudo-random order, so that
         # the ~55 row streams of the kernel spread over the memory channels whatever the driver's free list looks like (DESIGN.md
         # section 1; XDEM_BENCH_PLANES = torch | contiguous | chunked selects another backing for measurements)
-        out = terrain.alloc_planes(len(FULL), block.rows, n, torch.float32, ctx, dev, backing=os.environ.get("XDEM_BENCH_PLANES", "auto"))
+        out = terrain.alloc_planes(len(FULL), block.rows, n, torch.float32, ctx, dev,
+                                   backing=backing or os.environ.get("XDEM_BENCH_PLANES", "auto"))
         # each rank synthesises exactly its rows of the global raster (halo rows come from the neighbours)
-        block.interior.copy_(fbm_torch(block.rows, n, dev, seed=42, row0=block.r0, total_rows=n))
+        if fresh:
+            block.interior.copy_(fbm_torch(block.rows, n, dev, seed=42, row0=block.r0, total_rows=n))
 
         def step():
             xdist.terrain_row_block(block, FULL, out=out, overlap=not args.no_overlap, **kw)
@@ -476,6 +531,22 @@ def main() -> None:
     n = args.size
     elapsed, block, out, step_ms = partitioned_run(n, args.steps, args.warmup)
     kernel_ms = sum(step_ms) / len(step_ms)
+    # A/B of the plane backing inside the same process (one GPU): the same launches on planes a CALLER would bring -- an ordinary
+    # allocation (torch.empty = hipMalloc), which on some boxes is one physically contiguous block -- after the library's
+    # scattered backing above.  Every driver run is thereby a data point of "is >= 0.70 the kernel's or the allocator's"
+    # (XDEM_BENCH_AB=0 skips it).
+    ab = None
+    if world == 1 and os.environ.get("XDEM_BENCH_AB", "1") == "1" and os.environ.get("XDEM_BENCH_PLANES", "auto") == "auto":
+        del out
+        import gc
+
+        gc.collect()
+        _, _, out, ms2 = partitioned_run(n, args.steps, args.warmup, backing="torch", block=block)
+        k2 = sum(ms2) / len(ms2)
+        ab = {"planes": "torch.empty (ordinary hipMalloc: what a caller of the C-ABI brings)", "kernel_ms": round(k2, 4),
+              "kernel_ms_min": round(min(ms2), 4), "kernel_ms_max": round(max(ms2), 4),
+              "achieved": round(BYTES_PER_PIXEL * block.rows * n / (k2 * 1e-3) / 1e9, 1),
+              "frac": round(BYTES_PER_PIXEL * block.rows * n / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
     # Kernel duration for the roofline: the mean of the HIP-event times of the K timed steps themselves (events recorded on the
     # launch stream around each step; one step = the streaming kernel over the raster interior + the tile kernel over its frame
@@ -533,19 +604,46 @@ def main() -> None:
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(min(step_ms), 4),
                          "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch},
         }
+        if ab is not None:
+            res["roofline"]["frac_caller_planes"] = ab["frac"]
+            res["roofline"]["kernel_ms_caller_planes"] = ab["kernel_ms"]
+            res["roofline"]["caller_planes"] = ab
+        res["config"]["rccl_ranks"] = world if world == 1 else dist.get_world_size()
+        res["config"]["visible_gpus"] = torch.cuda.device_count()
         res["device_state"] = device_state()
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
         if c4 is not None:
             res["secondary"] = {"c4_terrain_row_blocks": c4}
     sec = None
+    failed = []
     if not args.no_secondary:   # every rank runs the secondary legs (they shard over the ranks); rank 0 reports
+        sets = None
+        if world == 1:
+            try:
+                del out
+                sets = terrain_sets(ctx, dev, block.interior, kw, max(3, min(args.steps, 5)))
+            except Exception as e:
+                import traceback
+
+                traceback.print_exc()
+                sets = {"error": repr(e)}
+                failed.append("terrain_sets")
         try:
-            del out, block
+            out = block = None
+            import gc
+
+            gc.collect()
             torch.cuda.empty_cache()
             sec = secondary_metrics(ctx, dev, rank, world, barrier, c5a=args.c5a)
-        except Exception as e:  # the headline line must still be printed
+        except Exception as e:  # the headline line must still be printed -- and the process must not look healthy afterwards
+            import traceback
+
+            traceback.print_exc()
             sec = {"error": repr(e)}
+            failed.append("secondary")
+        if sets is not None:
+            sec["terrain_sets"] = sets
     if rank == 0:
         if sec is not None:
             res.setdefault("secondary", {}).update(sec)
@@ -556,9 +654,12 @@ def main() -> None:
                 res["end_to_end"] = end_to_end_host_path(ctx)
             except Exception as e:
                 res["end_to_end"] = {"error": repr(e)}
-        print(json.dumps(res))
+                failed.append("end_to_end")
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if failed:   # a broken secondary path may not produce a green-looking record: the line is out, the exit code says so
+        raise SystemExit(f"bench.py: failed legs: {failed}")
 
 
 if __name__ == "__main__":

@@ -314,3 +314,85 @@ def test_bench_two_ranks_reports_c4(tmp_path):
     v, nk = res["secondary"]["variogram"], res["secondary"]["nuthkaab"]
     assert v["n_gpus"] == 2 and v["matheron_pass_Gpairs_s"] > 0 and v["dowd_exact_median_Gpairs_s"] > 0 and "validated" in v
     assert nk["n_gpus"] == 2 and "row blocks of 2 ranks" in nk["partition"] and abs(nk["fitted_shift_px"][0] - 1.7) < 0.05
+
+
+def test_rccl_branch_of_the_halo_exchange_on_a_one_rank_group():
+    """The branch of ``RowBlock.exchange`` the 8-GPU run takes -- ``batch_isend_irecv`` of DEVICE row slices under the nccl (=
+    RCCL) backend, grouped ncclSend / ncclRecv on the communicator's stream -- driven on the one GPU of the test box: a block
+    with the geometry of a MIDDLE rank (halo rows on both sides) whose two neighbours are this very process in a 1-rank RCCL
+    group.  Self-addressed send / recv pairs of one group call match in issue order, so the halo above must receive the
+    block's own first rows and the halo below its last ones.  Checked: the halo contents, the stream ordering of the overlapped
+    form (interior launch, exchange, boundary launches behind it -- on a side stream, with the interior rewritten just before),
+    and the planes against the raster the exchange is equivalent to."""
+    import torch.distributed as dist
+
+    from xdem_amd import _lib
+    from xdem_amd import dist as xd
+    from xdem_amd.synth import fbm_torch
+    from xdem_amd.terrain import terrain_attributes_device
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        assert dist.get_backend() == "nccl"
+        dev = torch.device("cuda", 0)
+        ctx = _lib.default_context(0)
+        n, W, depth = 1537, 2100, xd.halo_depth(ATTRS, "Florinsky", 3)
+        block = xd.RowBlock(n, W, depth, 1, 3, dev)            # rows [512, 1024) of a 3-rank partition
+        assert block.halo_top == depth and block.halo_bottom == depth
+        block.peer_up = block.peer_down = 0                     # both neighbours: this process
+        block.buf.fill_(float("nan"))
+        rows = fbm_torch(block.rows, W, dev, seed=42, row0=block.r0, total_rows=n)
+        block.interior.copy_(rows)
+        works = block.exchange()
+        assert len(works) > 0   # (the gloo branch stages through the host and returns a landing object: not this one)
+        xd.RowBlock.wait_all(works)
+        torch.cuda.synchronize()
+        assert torch.equal(block.buf[:depth].view(torch.int32), rows[:depth].view(torch.int32))
+        assert torch.equal(block.buf[-depth:].view(torch.int32), rows[-depth:].view(torch.int32))
+        # overlapped form on a side stream: the interior is rewritten right before, so a boundary launch that ran ahead of the
+        # exchange (or an exchange that ran ahead of the copy) would read stale / NaN halo rows
+        want_buf = torch.cat([rows[:depth] + 1.0, rows + 1.0, rows[-depth:] + 1.0])
+        want = terrain_attributes_device(want_buf, ATTRS, resolution=10.0, halo_top=depth, halo_bottom=depth, ctx=ctx)
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream(dev)
+        for overlap in (True, False):
+            block.buf.fill_(float("nan"))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s):
+                block.interior.copy_(rows + 1.0)
+                out = xd.terrain_row_block(block, ATTRS, overlap=overlap, resolution=10.0, surface_fit="Florinsky",
+                                           curv_method="geometric", ctx=ctx)
+            s.synchronize()
+            assert torch.equal(out.view(torch.int32), want.view(torch.int32)), overlap
+        # the partitioned Nuth-Kaab plan (xdemhip_nk_create_block: row block + halo rows) with the DEVICE-side reduction hook on
+        # the same 1-rank RCCL group: every reduction of the fit enqueued through RCCL on the library's stream, nothing staged
+        from xdem_amd import coreg
+        import scipy.optimize
+
+        m = 2304
+        ref = fbm_torch(m, m, dev, seed=21)
+        tba = torch.roll(ref, shifts=(1, -2), dims=(0, 1)) + 1.0 + 0.3 * torch.randn((m, m), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+        tba[torch.rand((m, m), device=dev, generator=torch.Generator(device=dev).manual_seed(6)) < 0.1] = float("nan")
+        torch.cuda.synchronize()
+        ctx.set_option("selection", 3)
+        try:
+            base = coreg.NKPlan(ref, tba, None, ctx)
+            want_off = coreg._iterate(base, (10.0, 10.0), 0.0, 3, 72, scipy.optimize.curve_fit, True)
+            base.close()
+            h0, d0 = ctx.reduction_calls()
+            plan = coreg.NKPlan(ref, tba, None, ctx, "world", block=(m, 0, m, 0, 0))
+            got_off = coreg._iterate(plan, (10.0, 10.0), 0.0, 3, 72, scipy.optimize.curve_fit, True)
+            plan.close()
+            h1, d1 = ctx.reduction_calls()
+        finally:
+            ctx.set_option("selection", 0)
+        assert d1 - d0 >= 15 and h1 == h0, (h0, h1, d0, d1)
+        assert np.allclose(got_off, want_off, rtol=1e-9, atol=1e-9), (got_off, want_off)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -150,7 +150,8 @@ def test_golden_reference_vectors(terrain):
 
 
 def _ulp_line(c):
-    return "hist(0,1,2,3-4,5-8,>8)=" + "/".join(f"{h:.3f}" for h in c["hist"]) + f" max_ulp={c['max_ulp']} max_rel={c['max_rel']:.2e}"
+    return ("hist(0,1,2,3-4,5-8,>8)=" + "/".join(f"{h:.3f}" for h in c["hist"]) + f" max_ulp={c['max_ulp']} max_rel={c['max_rel']:.2e}"
+            + f" excused_by_noise_floor={c['excused']:.5f}")
 
 
 @pytest.mark.parametrize("fname", ["terrain_T1_float32_nan.npz", "terrain_T1_float32_inf.npz",
@@ -163,20 +164,23 @@ def test_T1_reference_fixtures_on_the_hip_path(terrain, fname, record_property):
     z = np.load(os.path.join(GOLDEN, fname))
     dem = z["dem"]
     n = 0
-    worst = {}
+    worst, excused = {}, {}
     for key in z.files:
         if key == "dem":
             continue
         fit, cm, res, attr = key.split("|")
         got = terrain.get_terrain_attribute(dem, attr, resolution=float(res), surface_fit=fit, curv_method=cm)
-        c = assert_parity_true(got, z[key], f"{fname}:{key}", floor=noise_floor(attr, dem, float(res)))
+        # (T1 is noise with relief everywhere: the float64 noise floor may excuse 5 % of the differing pixels at most)
+        c = assert_parity_true(got, z[key], f"{fname}:{key}", floor=noise_floor(attr, dem, float(res)), max_excused=0.05)
         w = worst.setdefault(attr, c)
         if c["max_rel"] >= w["max_rel"]:
             worst[attr] = c
+        excused[attr] = max(excused.get(attr, 0.0), c["excused"])
         n += 1
     assert n > 100
     for attr, c in worst.items():
-        record_property(f"T1/{fname}/{attr}", _ulp_line(c))
+        record_property(f"T1/{fname}/{attr}", _ulp_line(c) + f" worst_excused_share_over_configs={excused[attr]:.5f}")
+        print(f"T1 {fname} {attr:28s} {_ulp_line(c)} worst excused share {excused[attr]:.5f}")
 
 
 def test_T3_reference_known_answers_on_the_hip_path(terrain, record_property):
@@ -186,6 +190,7 @@ def test_T3_reference_known_answers_on_the_hip_path(terrain, record_property):
     reproduced by the kernel's reference-order recomputation of exactly cancelling derivative sums."""
     z = np.load(os.path.join(GOLDEN, "terrain_T3_known_answers.npz"))
     n = 0
+    exc = {}
     for key in z.files:
         if key.startswith("dem|"):
             continue
@@ -193,9 +198,15 @@ def test_T3_reference_known_answers_on_the_hip_path(terrain, record_property):
         dem = z["dem|" + name]
         got = terrain.get_terrain_attribute(dem, attr, resolution=float(res), surface_fit=fit)
         demf = dem.astype(np.float32) if dem.dtype.kind in "iu" else dem
-        assert_parity_true(got, z[key], key, floor=noise_floor(attr, demf, float(res)))
+        # (known-answer DEMs are planar / flat by construction: their curvatures and TPI are exact zeros, so the reference's
+        # float64 residues -- the noise floor's whole purpose -- can be every pixel of a fixture; the share is recorded)
+        c = assert_parity_true(got, z[key], key, floor=noise_floor(attr, demf, float(res)))
+        exc[attr] = max(exc.get(attr, 0.0), c["excused"])
         n += 1
     assert n > 900
+    for attr, e in exc.items():
+        record_property(f"T3/{attr}/max_share_excused_by_noise_floor", f"{e:.5f}")
+        print(f"T3 {attr:28s} max share excused by the noise floor {e:.5f}")
     flat = terrain.get_terrain_attribute(z["dem|flat"], ["slope", "aspect"], resolution=1.0, surface_fit="Florinsky")
     assert flat[1][2, 2] == z["flat|Florinsky|1.0|aspect"][2, 2] == np.float32(198.43494)
     assert flat[0][2, 2] == z["flat|Florinsky|1.0|slope"][2, 2] and 0 < flat[0][2, 2] < 1e-12
@@ -274,9 +285,20 @@ def test_library_allocated_planes(terrain, backing):
     del view, ref
     gc.collect()
     torch.cuda.empty_cache()
+    if backing == "scattered":
+        # a released scattered range waits in the context's pool for the next request of its size ...
+        assert torch.cuda.mem_get_info()[0] < free0 - (400 << 20)
+        again = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx, backing=backing)
+        assert torch.cuda.mem_get_info()[0] <= free0 - again.numel() * 4 + (64 << 20)   # ... which takes it instead of a new one
+        del again
+        gc.collect()
+        ctx.release_pool()   # ... and goes back to the driver on request
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
     assert not hasattr(terrain.alloc_planes(2, 64, 64, torch.float32, ctx), "xdem_contiguous")   # small sets: torch's allocator
     assert hasattr(terrain.alloc_planes(4, n, n, torch.float32, ctx), "xdem_contiguous")          # 340 MB: the library's scattered backing
+    assert hasattr(terrain.terrain_attributes_device(dem, attrs[:4], resolution=10.0, ctx=ctx), "xdem_contiguous")   # out=None: the same
+    gc.collect()
+    ctx.release_pool()
     with pytest.raises(_lib.XdemHipError):
         ctx.device_tensor((1 << 40,), "float32")   # 4 TiB
 
@@ -318,8 +340,22 @@ def test_streaming_strips_equal_tile_kernel_and_oracle(terrain, fit, attrs):
                 else:
                     for i, a in enumerate(attrs):
                         assert np.array_equal(got[i], ref_planes[i], equal_nan=True), (shape, stream, a)
-            # row block with halo rows: rows [r0, r1) of the raster from a buffer holding depth rows either side
+            # strip-to-workgroup orders (0 XCD bands, 1 natural, 2 permuted, 3 column-major) and the conservative form of the
+            # ring wait (vmcnt(0) instead of the counted wait: the counted form may never read a stale ring row)
             ctx.set_option("terrain_stream", 1)
+            for order, wait in ((1, 0), (2, 0), (3, 0), (0, 1)):
+                try:
+                    ctx.set_option("terrain_order", order)
+                    ctx.set_option("terrain_ring_wait", wait)
+                    got = terrain.terrain_attributes_device(d, attrs, resolution=10.0, surface_fit=fit)
+                    torch.cuda.synchronize()
+                    got = got.cpu().numpy()
+                finally:
+                    ctx.set_option("terrain_order", 0)
+                    ctx.set_option("terrain_ring_wait", 0)
+                for i, a in enumerate(attrs):
+                    assert np.array_equal(got[i], ref_planes[i], equal_nan=True), (shape, "order", order, "wait", wait, a)
+            # row block with halo rows: rows [r0, r1) of the raster from a buffer holding depth rows either side
             r0, r1, depth = 96, shape[0] - 70, 2
             blk = terrain.terrain_attributes_device(d[r0 - depth:r1 + depth], attrs, resolution=10.0, surface_fit=fit,
                                                     halo_top=depth, halo_bottom=depth)

@@ -1,0 +1,30 @@
+"""Two Nuth-Kaab steps on bench.py's C3 pair (the command rocprofv3 --kernel-trace wraps; tools/trace_sequence.py prints the
+dispatch sequence of the last step): python tools/nk_trace.py [size] [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import faulthandler
+
+faulthandler.dump_traceback_later(200, exit=True)
+import torch
+
+import bench
+from xdem_amd import _lib, coreg
+
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+dev = torch.device("cuda", 0)
+ref, tba = bench._c3_pair(dev, m)
+ctx = _lib.default_context(0)
+plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
+plan.step(0.0, 0.0, (10.0, 10.0), 72)
+for i in range(k):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
+    dt = time.perf_counter() - t0
+    print(f"step {m}x{m}: {dt * 1e3:.3f} ms (n_valid {d['n_valid']}, vshift {d['vshift']:.6f})", flush=True)
+plan.close()

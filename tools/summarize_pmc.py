@@ -32,7 +32,9 @@ for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recu
         for p_ in pats:
             vals = [v for (c, kp, _), v in per.items() if c == n and kp == p_]
             if vals:
-                entry["per_kernel"][p_] = {"dispatches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
+                sv = sorted(vals)
+                entry["per_kernel"][p_] = {"dispatches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals),
+                                           "median": sv[len(sv) // 2] if len(sv) % 2 else 0.5 * (sv[len(sv) // 2 - 1] + sv[len(sv) // 2])}
                 entry["mean"] += sum(vals) / len(vals)
         entry["dispatches"] = max(v["dispatches"] for v in entry["per_kernel"].values())
         out[n] = entry
@@ -42,4 +44,27 @@ json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], dst + "_kernel_stats.csv")
+# rocprofv3's --stats averages every dispatch of a kernel, the cold first one included (the first launch of a 70 GB write set
+# runs 10-15 % long), so its mean can exceed the bench's ms_per_step of the timed steps.  From the kernel trace of the same run:
+# per-kernel MEDIAN and the mean WITHOUT each kernel's first dispatch -- the numbers to hold against bench.py's kernel_ms.
+traces = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
+if traces:
+    durs = {}
+    with open(traces[0]) as fh:
+        for row in csv.DictReader(fh):
+            try:
+                durs.setdefault(row["Kernel_Name"], []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+            except (KeyError, ValueError):
+                pass
+    med = {}
+    for name, v in durs.items():
+        v.sort()
+        d = [x[1] for x in v]
+        warm = d[1:] if len(d) > 1 else d
+        sw = sorted(warm)
+        med[name[:160]] = {"calls": len(d), "first_us": d[0] / 1e3, "median_us": (sw[len(sw) // 2] if len(sw) % 2 else 0.5 * (sw[len(sw) // 2 - 1] + sw[len(sw) // 2])) / 1e3,
+                           "mean_without_first_us": sum(warm) / len(warm) / 1e3, "min_us": min(d) / 1e3, "max_us": max(d) / 1e3,
+                           "total_ms": sum(d) / 1e6}
+    top = dict(sorted(med.items(), key=lambda kv: -kv[1]["total_ms"])[:60])
+    json.dump(top, open(dst + "_kernel_medians.json", "w"), indent=1)
 print(json.dumps({k: (v["mean"] if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))

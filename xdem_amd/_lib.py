@@ -172,14 +172,14 @@ class _DeviceArray:
 class _OwnedDeviceArray(_DeviceArray):
     """The same, owning its memory (``xdemhip_device_alloc``): torch keeps the object alive as long as a tensor built on it."""
 
-    def __init__(self, ctx, ptr: int, count: int, typestr: str):
+    def __init__(self, ctx, ptr: int, count: int, typestr: str, nbytes: int = 0, flags: int = 0):
         super().__init__(ptr, count, typestr)
-        self._ctx, self._ptr = ctx, ptr
+        self._ctx, self._ptr, self._nbytes, self._flags = ctx, ptr, nbytes, flags
 
     def __del__(self):  # pragma: no cover
         try:
             if self._ptr and getattr(self._ctx, "handle", None):
-                self._ctx._L.xdemhip_device_free(self._ctx.handle, ctypes.c_void_p(self._ptr))
+                self._ctx._give_back(self._ptr, self._nbytes, self._flags)
         except Exception:
             pass
         self._ptr = 0
@@ -233,6 +233,13 @@ class Context:
             )
         self.handle = h
         self.device = int(device)
+        self._group = None   # process group of the installed reduction hooks (set_allreduce)
+        # Released scattered plane ranges are kept for the next request of the same size (building a range is ~30 us per 8 MiB
+        # piece: 0.4 s for the 11 planes of a 16384^2 raster, every call, if nothing were kept) -- at most this many bytes in
+        # all, least recently released first out; larger ranges (the 70 GB of the 40000^2 set) go back to the driver at once.
+        self._pool: list[tuple[int, int, int]] = []   # (nbytes, flags, ptr)
+        self._pool_cap = int(float(os.environ.get("XDEM_PLANE_POOL_GB", "16")) * (1 << 30))
+        self._pool_lock = threading.Lock()
         self.options: dict[str, int] = {}  # mirror of the xdemhip_set_option calls made through this object
 
     def check(self, rc: int) -> None:
@@ -252,6 +259,7 @@ class Context:
         device-side hook is installed next to it (``device_side`` forces it on / off): the library's per-pass reductions --
         histograms, counters, keys, all in device memory -- are then all-reduced in place on the library's stream with no
         staging and no host synchronisation; gloo groups (CPU tests) stage everything through the host hook."""
+        self._group = group   # (remembered so that a caller which installs hooks temporarily can put these back)
         if group is None:
             self._hook = None
             self._dev_hook = None
@@ -296,11 +304,48 @@ class Context:
         ptr, got = ctypes.c_void_p(), ctypes.c_int()
         # XDEMHIP_ALLOC_SCATTERED / _CHUNKED / _CONTIGUOUS | _RECYCLED
         flags = 8 if scattered else (4 if chunked else ((1 if contiguous else 0) | (2 if recycled else 0)))
-        self.check(self._L.xdemhip_device_alloc(self.handle, count * np_dt.itemsize, flags, ctypes.byref(ptr), ctypes.byref(got)))
-        owner = _OwnedDeviceArray(self, int(ptr.value), count, np_dt.str)
+        nbytes = count * np_dt.itemsize
+        pooled = self._take_pooled(nbytes, flags)
+        if pooled:
+            ptr.value, got.value = pooled, 0
+        else:
+            rc = self._L.xdemhip_device_alloc(self.handle, nbytes, flags, ctypes.byref(ptr), ctypes.byref(got))
+            if rc != OK and self._pool:   # the pool may hold what this request needs: empty it and try once more
+                self.release_pool()
+                rc = self._L.xdemhip_device_alloc(self.handle, nbytes, flags, ctypes.byref(ptr), ctypes.byref(got))
+            self.check(rc)
+        owner = _OwnedDeviceArray(self, int(ptr.value), count, np_dt.str, nbytes, flags)
         t = torch.as_tensor(owner, device=torch.device("cuda", self.device)).view(*shape)
         t.xdem_contiguous = bool(got.value)
         return t
+
+    def _take_pooled(self, nbytes: int, flags: int) -> int:
+        with self._pool_lock:
+            for i, (b, f, p) in enumerate(self._pool):
+                if b == nbytes and f == flags:
+                    del self._pool[i]
+                    return p
+        return 0
+
+    def _give_back(self, ptr: int, nbytes: int, flags: int) -> None:
+        """A device range nobody references any more: scattered ranges of moderate size wait in the pool, the rest is freed."""
+        if flags == 8 and 0 < nbytes <= self._pool_cap:
+            evict = []
+            with self._pool_lock:
+                self._pool.append((nbytes, flags, ptr))
+                while sum(b for b, _, _ in self._pool) > self._pool_cap:
+                    evict.append(self._pool.pop(0))
+            for _, _, p in evict:
+                self._L.xdemhip_device_free(self.handle, ctypes.c_void_p(p))
+            return
+        self._L.xdemhip_device_free(self.handle, ctypes.c_void_p(ptr))
+
+    def release_pool(self) -> None:
+        """Hand the pooled plane ranges back to the driver (the analogue of ``torch.cuda.empty_cache()``)."""
+        with self._pool_lock:
+            items, self._pool = self._pool, []
+        for _, _, p in items:
+            self._L.xdemhip_device_free(self.handle, ctypes.c_void_p(p))
 
     def set_option(self, name: str, value: int) -> None:
         """Tuning / test switch of the library (``xdemhip_set_option``), e.g. ``("selection", 1)``."""
@@ -314,6 +359,7 @@ class Context:
 
     def close(self) -> None:
         if getattr(self, "handle", None):
+            self.release_pool()
             self._L.xdemhip_destroy(self.handle)
             self.handle = None
 

@@ -59,13 +59,15 @@ class NKPlan:
         self.ctx = ctx or _lib.default_context()
         self.handle = None
         self.group = None
+        prev_group = getattr(self.ctx, "_group", None)   # hooks the caller had on the context before this plan
         try:
             self._create(ref, tba, inlier_mask, group, block)
         except BaseException:
-            # a creation that fails after the reduction hook went in must not leave it on the (usually process-wide) context:
-            # a later single-process call on it would enter a collective alone
+            # a creation that fails after the reduction hook went in must not leave it on the (usually process-wide) context
+            # -- a later single-process call on it would enter a collective alone -- and must not take away hooks the caller
+            # had installed before either: the previous state comes back
             if group is not None:
-                self.ctx.set_allreduce(None)
+                self.ctx.set_allreduce(prev_group)
             if self.handle:
                 self.ctx._L.xdemhip_nk_destroy(self.handle)
                 self.handle = None

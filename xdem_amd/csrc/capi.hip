@@ -245,6 +245,15 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->host_chunk_mb = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "host_release") {  // free the pinned staging buffers of the host-buffer terrain path (they come back with the next call)
+        for (int q = 0; q < 2; ++q) {
+            if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
+            if (ctx->stage_out[q]) (void)hipHostFree(ctx->stage_out[q]);
+            ctx->stage_in[q] = ctx->stage_out[q] = nullptr;
+        }
+        ctx->stage_in_bytes = ctx->stage_out_bytes = 0;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "host_copy_threads") {  // threads (one stream each) moving host-buffer rasters over PCIe (0 = default 8)
         if (value < 0 || value > xdemhip_ctx::MAX_COPY_THREADS) return xd_fail(ctx, XDEMHIP_EINVAL, "host_copy_threads must be 0..16");
         ctx->host_copy_threads = value ? value : 8;
@@ -292,8 +301,13 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         return XDEMHIP_OK;
     }
     if (std::string(name) == "terrain_order") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_order: 0 XCD bands, 1 natural order");
+        if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_order: 0 XCD bands, 1 natural order, 2 permuted strips, 3 column-major strips");
         ctx->terrain_order = value;
+        return XDEMHIP_OK;
+    }
+    if (std::string(name) == "terrain_ring_wait") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_ring_wait: 0 counted wait, 1 vmcnt(0)");
+        ctx->terrain_ring_wait = value;
         return XDEMHIP_OK;
     }
     if (std::string(name) == "terrain_math") {
@@ -409,9 +423,13 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     int64_t chunk = (int64_t)(budget / (row_bytes ? row_bytes : 1)) - 2 * depth;
     if (chunk < 64) chunk = 64;  // (a few rows of a very wide raster may exceed the budget; still correct)
     if (chunk > H) chunk = H;
-    const size_t in_bytes = (size_t)(chunk + 2 * depth) * (size_t)W * in_es;
-    const size_t plane_bytes = (size_t)chunk * (size_t)W * out_es;
-    const size_t out_bytes = plane_bytes * (size_t)n_planes;
+    size_t in_bytes = 0, plane_bytes = 0, out_bytes = 0;
+    auto size_chunk = [&]() {
+        in_bytes = (size_t)(chunk + 2 * depth) * (size_t)W * in_es;
+        plane_bytes = (size_t)chunk * (size_t)W * out_es;
+        out_bytes = plane_bytes * (size_t)n_planes;
+    };
+    size_chunk();
     void* d_in[2] = {nullptr, nullptr};
     void* d_out[2] = {nullptr, nullptr};
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
@@ -425,18 +443,31 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
             if (ev_out[q]) (void)hipEventDestroy(ev_out[q]);
         }
     };
-    // pinned staging, kept by the context between calls (pinning hundreds of MiB costs more than moving them)
+    // pinned staging, kept by the context between calls (pinning hundreds of MiB costs more than moving them).  The budget sizes
+    // 2 x (input + planes) of pinned host memory AND the same of device memory; where the host cannot pin that much the chunk is
+    // halved until it can (down to 64 rows) instead of failing the call.  Option "host_release" frees the staging buffers.
     if (ctx->stage_in_bytes < in_bytes || ctx->stage_out_bytes < out_bytes) {
-        for (int q = 0; q < 2; ++q) {
-            if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
-            if (ctx->stage_out[q]) (void)hipHostFree(ctx->stage_out[q]);
-            ctx->stage_in[q] = ctx->stage_out[q] = nullptr;
+        auto drop_staging = [&]() {
+            for (int q = 0; q < 2; ++q) {
+                if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
+                if (ctx->stage_out[q]) (void)hipHostFree(ctx->stage_out[q]);
+                ctx->stage_in[q] = ctx->stage_out[q] = nullptr;
+            }
+            ctx->stage_in_bytes = ctx->stage_out_bytes = 0;
+        };
+        for (;;) {
+            drop_staging();
+            bool ok = true;
+            for (int q = 0; q < 2 && ok; ++q)
+                ok = hipHostMalloc(&ctx->stage_in[q], in_bytes, hipHostMallocDefault) == hipSuccess &&
+                     hipHostMalloc(&ctx->stage_out[q], out_bytes, hipHostMallocDefault) == hipSuccess;
+            if (ok) break;
+            (void)hipGetLastError();
+            drop_staging();
+            if (chunk <= 64) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipHostMalloc(staging) failed even for 64-row chunks");
+            chunk = chunk / 2 < 64 ? 64 : chunk / 2;
+            size_chunk();
         }
-        ctx->stage_in_bytes = ctx->stage_out_bytes = 0;
-        for (int q = 0; q < 2; ++q)
-            if (hipHostMalloc(&ctx->stage_in[q], in_bytes, hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc(&ctx->stage_out[q], out_bytes, hipHostMallocDefault) != hipSuccess)
-                return xd_fail(ctx, XDEMHIP_ENOMEM, "hipHostMalloc(staging) failed");
         ctx->stage_in_bytes = in_bytes;
         ctx->stage_out_bytes = out_bytes;
     }

@@ -209,6 +209,9 @@ struct StripArgs {
     int64_t H, W, stride, halo_top;
     int64_t xi0, yi0, yi1;      // interior: columns from xi0 (groups of 256), rows [yi0, yi1)
     int groups_x, ngroups, grid8, order;
+    int nbands;             // bands of BH rows (order 3 deals the strip groups of one column band to consecutive workgroups)
+    uint32_t perm_mul;      // order 2: workgroup b takes strip group (b * perm_mul) mod (grid8 * 8), perm_mul coprime to that
+    int safe_wait;          // option "terrain_ring_wait" = 1: s_waitcnt vmcnt(0) instead of the counted wait (test switch)
     TerrainParams P;
     Planes<float> out;
 };
@@ -223,6 +226,7 @@ template <int NPL> struct RowsRing {
     float* ring;            // LDS: this wave's ring
     int64_t stride;
     int nrows, lane;
+    int safe_wait;          // (wave-uniform) drain every VMEM operation instead of counting: the check of the counted form
     __device__ __forceinline__ lds_cfloat_ptr ptr(int t) const { return mine + (t & (RING_ROWS - 1)) * RING_PITCH; }
     __device__ __forceinline__ void issue(int k) const {   // block k = tile rows [16 k, 16 k + 16) -> ring half k & 1
         float* dst = ring + (k & 1) * (RING_BLOCK * RING_PITCH);
@@ -240,12 +244,28 @@ template <int NPL> struct RowsRing {
                                                  (__attribute__((address_space(3))) void*)(dst + 64 * i * 4), 16, 0, 0);
         }
     }
+    // The counted wait below is only as good as the schedule it counts on.  A block is issued at march step r with
+    // (r mod RING_BLOCK) == REFILL_AT and first read at the step with (r + 1) mod RING_BLOCK == 0, i.e. ROWS_BETWEEN steps later;
+    // every one of those steps emits one output row (r >= RING_BLOCK + REFILL_AT > 2 HALO: past the band's lead-in) and an
+    // output row is NPL unpredicated plane stores -- the cold paths only ADD stores -- so at least ROWS_BETWEEN * NPL VMEM
+    // operations are younger than the block's loads, and gfx9 retires a wave's VMEM operations in order: "at most N
+    // outstanding" with N <= ROWS_BETWEEN * NPL means the loads have landed.  The constants are tied together here so that an
+    // edit of the schedule fails to compile instead of reading stale ring rows; option "terrain_ring_wait" = 1 replaces the
+    // counted wait by vmcnt(0) (GPU test: identical planes).
+    static constexpr int REFILL_AT = 4;                                  // oldest row still read at step r is r - 4 (Florinsky window)
+    static constexpr int ROWS_BETWEEN = RING_BLOCK - 1 - REFILL_AT;      // 11 output rows between a block's issue and its first read
+    static constexpr int N_WAIT = ROWS_BETWEEN * NPL < 63 ? ROWS_BETWEEN * NPL : 63;
+    static_assert(RING_ROWS == 2 * RING_BLOCK, "two ring halves: the block being marched and the one in flight");
+    static_assert(REFILL_AT >= 4 && REFILL_AT < RING_BLOCK - 1, "a half is refilled only once no path reads its rows any more");
+    static_assert(N_WAIT >= 1 && N_WAIT <= ROWS_BETWEEN * NPL, "the counted wait may not exceed the stores issued since the refill");
     __device__ __forceinline__ void step(int r) const {
-        constexpr int N = 11 * NPL < 63 ? 11 * NPL : 63;
-        // about to read tile row r + 1, the first of its block: that block was issued at least 11 output rows ago
-        if (((r + 1) & (RING_BLOCK - 1)) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+        // about to read tile row r + 1, the first of its block: that block was issued ROWS_BETWEEN output rows ago
+        if (((r + 1) & (RING_BLOCK - 1)) == 0) {
+            if (safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_WAIT) : "memory");
+        }
         // tile rows below 16 (r >> 4) are dead from here on (the oldest row any path still reads is r - 4): refill their half
-        if ((r & (RING_BLOCK - 1)) == 4 && r >= RING_BLOCK + 4) {
+        if ((r & (RING_BLOCK - 1)) == REFILL_AT && r >= RING_BLOCK + REFILL_AT) {
             const int k = (r >> 4) + 1;
             if (RING_BLOCK * k < nrows) issue(k);
         }
@@ -259,9 +279,14 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     static_assert(SP::CMASK != 0 && BH % 32 == 0, "specialised attribute sets only");
     __shared__ __attribute__((aligned(16))) float ring[4 * RING_ROWS * RING_PITCH];
     const int b = blockIdx.x;
-    const int logical = a.order ? b : (b & 7) * a.grid8 + (b >> 3);   // XCD-aware: neighbouring strip groups share an L2
+    // order 0 (default): one band of strip groups per XCD, neighbouring groups share an L2; 1: natural order; 2 / 3: measurement
+    // forms that spread the groups in flight over the raster -- 2 a multiplicative permutation of the group index, 3 column-major
+    // (consecutive workgroups of an XCD walk DOWN a 256-column band: their row streams lie a band height apart instead of 1 KiB)
+    int logical = (a.order == 1 || a.order == 2) ? b : (b & 7) * a.grid8 + (b >> 3);
+    if (a.order == 2) logical = (int)(((uint64_t)(uint32_t)b * a.perm_mul) % (uint32_t)(a.grid8 * 8));
     if (logical >= a.ngroups) return;
-    const int band = logical / a.groups_x, gx = logical - band * a.groups_x;
+    int band = logical / a.groups_x, gx = logical - band * a.groups_x;
+    if (a.order == 3) { gx = logical / a.nbands; band = logical - gx * a.nbands; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t x0 = a.xi0 + ((int64_t)gx * 4 + wave) * 64, y0 = a.yi0 + (int64_t)band * BH;
@@ -273,6 +298,7 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     rows.stride = a.stride;
     rows.nrows = n_out + 2 * HALO;
     rows.lane = lane;
+    rows.safe_wait = a.safe_wait;
     rows.issue(0);
     if (RING_BLOCK < rows.nrows) {
         rows.issue(1);
@@ -461,6 +487,15 @@ static int launch_stream(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
     if (bands * a.groups_x > (int64_t)0xfffff0) return 0;
     a.ngroups = (int)(bands * a.groups_x);
     a.grid8 = (a.ngroups + 7) / 8;
+    a.nbands = (int)bands;
+    a.safe_wait = ctx->terrain_ring_wait;
+    {   // multiplier of order 2: near the golden section of the grid, coprime to it
+        const uint32_t n = (uint32_t)a.grid8 * 8u;
+        uint32_t m = (uint32_t)(0.6180339887 * (double)n) | 1u;
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+        while (m > 1 && gcd(m, n) != 1) m += 2;
+        a.perm_mul = m;
+    }
     const dim3 grid(a.grid8 * 8), block(256);
     if (dbg_no_strips) {}
     else if (bh == 128) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 128>), grid, block, 0, ctx->stream, a);

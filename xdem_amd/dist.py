@@ -44,6 +44,9 @@ class RowBlock:
             raise ValueError(f"row block of {self.rows} rows is thinner than the halo depth {depth}")
         self.halo_top = depth if rank > 0 else 0
         self.halo_bottom = depth if rank < world - 1 else 0
+        # ranks (of the exchange's group) that hold the rows above / below; a test may point both at this very process to drive
+        # the RCCL branch of `exchange` on a one-GPU box (self-addressed ncclSend / ncclRecv pairs match in issue order)
+        self.peer_up, self.peer_down = rank - 1, rank + 1
         self.buf = torch.empty((self.halo_top + self.rows + self.halo_bottom, width), device=device, dtype=dtype)
 
     @property
@@ -68,13 +71,12 @@ class RowBlock:
         if self.buf.is_cuda and dist.get_backend(group) == "gloo":
             return self._exchange_staged(group)
         d, ops = self.depth, []
-        up, down = self.rank - 1, self.rank + 1
-        if up >= 0:
-            ops.append(dist.P2POp(dist.isend, self.interior[:d].contiguous(), up, group))
-            ops.append(dist.P2POp(dist.irecv, self.buf[: self.halo_top], up, group))
-        if down < self.world:
-            ops.append(dist.P2POp(dist.isend, self.interior[-d:].contiguous(), down, group))
-            ops.append(dist.P2POp(dist.irecv, self.buf[self.halo_top + self.rows :], down, group))
+        if self.halo_top:
+            ops.append(dist.P2POp(dist.isend, self.interior[:d].contiguous(), self.peer_up, group))
+            ops.append(dist.P2POp(dist.irecv, self.buf[: self.halo_top], self.peer_up, group))
+        if self.halo_bottom:
+            ops.append(dist.P2POp(dist.isend, self.interior[-d:].contiguous(), self.peer_down, group))
+            ops.append(dist.P2POp(dist.irecv, self.buf[self.halo_top + self.rows :], self.peer_down, group))
         return dist.batch_isend_irecv(ops)
 
     def _exchange_staged(self, group=None) -> list:
@@ -82,14 +84,14 @@ class RowBlock:
         staged through host tensors.  Lets several ranks share one GPU, which RCCL refuses -- used to test the multi-rank
         path on a single-GPU box; production runs use RCCL."""
         d = self.depth
-        up, down = self.rank - 1, self.rank + 1
+        up, down = self.peer_up, self.peer_down
         ops, landings = [], []
-        if up >= 0:
+        if self.halo_top:
             ops.append(dist.P2POp(dist.isend, self.interior[:d].cpu(), up, group))
             r = torch.empty((self.halo_top, self.buf.shape[1]), dtype=self.buf.dtype)
             ops.append(dist.P2POp(dist.irecv, r, up, group))
             landings.append((r, self.buf[: self.halo_top]))
-        if down < self.world:
+        if self.halo_bottom:
             ops.append(dist.P2POp(dist.isend, self.interior[-d:].cpu(), down, group))
             r = torch.empty((self.halo_bottom, self.buf.shape[1]), dtype=self.buf.dtype)
             ops.append(dist.P2POp(dist.irecv, r, down, group))

@@ -279,7 +279,9 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
     8 MiB physical pieces mapped in a fixed pseudo-random order (``xdemhip_device_alloc``, HIP virtual memory management): 13.3 ms
     on a box where ordinary and contiguous planes ran at 15.0-15.6 / 14.8 ms in the same process; "torch" = torch's allocator
     (ordinary hipMalloc); "contiguous", "chunked" (64 MiB pieces in order), "recycled" = the other forms, kept for measurements.
-    The memory of the library's forms is released when the tensor (and every view of it) is gone."""
+    The memory of the library's forms is released when the tensor (and every view of it) is gone.  The scattered pieces are mapped
+    for THIS device only (``hipMemSetAccess`` of the owning device): planes another GPU reads directly (peer access, IPC handles)
+    must come from ``backing="torch"``; RCCL send / recv of their rows is fine (the local GPU reads them)."""
     import torch
 
     dtype = dtype or torch.float32
@@ -296,7 +298,7 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
     np_dt = {torch.float32: "float32", torch.float64: "float64"}[dtype]
     try:
         return ctx.device_tensor((n_attr, H, W), np_dt, **kw)
-    except _lib.XdemHipError:
+    except Exception:   # (XdemHipError from the allocator, or whatever torch raises when it cannot wrap the range)
         if not auto:
             raise
     # "auto": the library's pieces do not come out of torch's cache -- hand the cached blocks back to the driver and try again,
@@ -304,7 +306,7 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
     torch.cuda.empty_cache()
     try:
         return ctx.device_tensor((n_attr, H, W), np_dt, **kw)
-    except _lib.XdemHipError:
+    except Exception:
         return torch.empty((n_attr, H, W), dtype=dtype, device=torch.device("cuda", ctx.device))
 
 
@@ -323,8 +325,10 @@ def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0
     H = Hbuf - halo_top - halo_bottom
     dt = {torch.float32: np.float32, torch.float64: np.float64}[dem.dtype]
     ctx = ctx or _lib.default_context(dem.device.index)
-    if out is None:   # (callers who keep large plane sets resident: see alloc_planes for the backing that is fastest to write)
-        out = torch.empty((len(attribute), H, W), dtype=dem.dtype, device=dem.device)
+    if out is None:
+        # the callee allocates the outputs, as upstream's engines do (terrain.py:528-666): plane sets of 256 MiB and more come
+        # from the library's scattered backing, the form the streaming kernel writes fastest on every box (alloc_planes)
+        out = alloc_planes(len(attribute), H, W, dem.dtype, ctx, dem.device)
     ctx.set_stream(torch.cuda.current_stream(dem.device).cuda_stream)
     assert out.shape == (len(attribute), H, W) and out.stride(2) == 1 and out.stride(1) == W and out.is_cuda
     ptrs = {a: out[i].data_ptr() for i, a in enumerate(attribute)}  # planes may be row windows of a larger tensor
