@@ -107,7 +107,10 @@ def assert_parity_true(got, ref, name="", floor: float = 0.0, rtol: float = RTOL
     assert c["inf_equal"], f"{name}: +-Inf positions/values differ"
     assert c["max_rel"] <= rtol, f"{name}: true relative error {c['max_rel']:.3e} > {rtol:g} (max {c['max_ulp']} ulp)"
     assert c["exact"] >= min_exact, f"{name}: only {c['exact']:.6f} bit-exact (< {min_exact})"
-    assert c["excused"] <= max_excused, f"{name}: the noise floor excuses {c['excused']:.4f} of the pixels (> {max_excused})"
+    # (float64 planes: a difference in the last bits of a double IS float64 rounding noise -- of the order of the floor by
+    # construction -- so the share is recorded but bounded only for float32 planes, whose ulp lies far above the floor)
+    if got.dtype == np.float32:
+        assert c["excused"] <= max_excused, f"{name}: the noise floor excuses {c['excused']:.4f} of the pixels (> {max_excused})"
     return c
 
 

@@ -123,6 +123,47 @@ def test_generic_window_sizes(terrain, w):
             assert_parity(g, r, f"w{w}/{tri}")
 
 
+def test_window_lds_kernel_equals_per_pixel_kernel(terrain):
+    """Round 4: windows other than 3 x 3 run the LDS-tiled kernel (window_lds_kernel: the patch of a 64 x 16 output tile staged
+    once, taps from LDS, same row-major float64 accumulation).  Every plane must be BIT-IDENTICAL to the per-pixel kernel of
+    rounds 1-3 (option "terrain_window_lds" = 0): all seven subsets of {TPI, TRI, roughness}, Riley and Wilson, float32 and
+    float64, NaN / Inf holes, ragged shapes, row blocks with halo rows, windows up to the LDS limit and beyond it."""
+    import torch
+
+    from xdem_amd import _lib
+
+    ctx = _lib.default_context()
+    names = ["topographic_position_index", "terrain_ruggedness_index", "roughness"]
+    rng = np.random.default_rng(11)
+    for dtype in (np.float32, np.float64):
+        dem = _dem((203, 517), seed=5).astype(dtype)
+        for _ in range(25):
+            dem[rng.integers(0, dem.shape[0]), rng.integers(0, dem.shape[1])] = np.nan
+        dem[40:44, 100:103] = np.inf
+        dem[150, 300] = -np.inf
+        d = torch.from_numpy(dem).cuda()
+        for w in (5, 7, 13, 31, 89, 95):          # 89: the largest window whose patch fits the LDS budget; 95: the fall-back
+            for tri in ("Riley", "Wilson"):
+                for sub in range(1, 8):
+                    if (w > 13 or dtype == np.float64) and sub not in (1, 7):
+                        continue
+                    attrs = [n_ for i, n_ in enumerate(names) if sub >> i & 1]
+                    res = {}
+                    for lds in (1, 0):
+                        try:
+                            ctx.set_option("terrain_window_lds", lds)
+                            full = terrain.terrain_attributes_device(d, attrs, window_size=w, tri_method=tri)
+                            blk = terrain.terrain_attributes_device(d[20:190], attrs, window_size=w, tri_method=tri,
+                                                                    halo_top=min(w // 2, 10), halo_bottom=min(w // 2, 3))
+                            torch.cuda.synchronize()
+                        finally:
+                            ctx.set_option("terrain_window_lds", 1)
+                        res[lds] = (full.cpu().numpy(), blk.cpu().numpy())
+                    it = np.int32 if dtype == np.float32 else np.int64
+                    for k in (0, 1):
+                        assert np.array_equal(res[1][k].view(it), res[0][k].view(it)), (dtype, w, tri, attrs, k)
+
+
 def test_golden_reference_vectors(terrain):
     """Directly against outputs recorded from the reference itself (not via the oracle)."""
     z = np.load(os.path.join(GOLDEN, "terrain_T2_f32.npz"))

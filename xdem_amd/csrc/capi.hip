@@ -305,6 +305,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->terrain_order = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "terrain_window_lds") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_window_lds: 0 or 1");
+        ctx->terrain_window_lds = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "terrain_ring_wait") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_ring_wait: 0 counted wait, 1 vmcnt(0)");
         ctx->terrain_ring_wait = value;

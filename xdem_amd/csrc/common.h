@@ -37,6 +37,7 @@ struct xdemhip_ctx {
     int terrain_stream = 1;  // option "terrain_stream": 1 streaming strips for the raster interior where they apply (default), 0 tiles only; 128 / 256 / 512 = band height
     int terrain_sync = 0;    // option "terrain_sync": workgroup barrier every N output rows of the direct-store march (0 none; N a power of two)
     int terrain_order = 0;   // option "terrain_order": 0 one band of tiles per XCD (default), 1 natural order (XCDs interleave along a tile row); strips only: 2 permuted, 3 column-major (measurement)
+    int terrain_window_lds = 1;  // option "terrain_window_lds": 1 LDS-tiled window kernel for window sizes != 3 (default), 0 the per-pixel form (its check)
     int terrain_ring_wait = 0;  // option "terrain_ring_wait": 1 = the streaming strips drain every VMEM operation before reading a refilled ring block (test switch for the counted wait)
     int terrain_math = 2;    // option "terrain_math": float32 rasters: 2 lean tail for the specialised attribute sets (default), 0 mixed-precision tail of round 2, 1 float64 tail everywhere
     int vario_grid = 1;      // option "vario_grid": 1 = integer-lattice pair kernels for raster-sampled points (default), 0 = always float64 coordinates

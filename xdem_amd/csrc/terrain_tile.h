@@ -209,6 +209,8 @@ struct StripArgs {
     int64_t H, W, stride, halo_top;
     int64_t xi0, yi0, yi1;      // interior: columns from xi0 (groups of 256), rows [yi0, yi1)
     int groups_x, ngroups, grid8, order;
+    int sync_n;             // option "terrain_sync": workgroup barrier every sync_n output rows (the four strips of a group then write
+                            // the same plane rows at about the same time: 1 KiB row pieces instead of four 256-byte ones far apart in time)
     int nbands;             // bands of BH rows (order 3 deals the strip groups of one column band to consecutive workgroups)
     uint32_t perm_mul;      // order 2: workgroup b takes strip group (b * perm_mul) mod (grid8 * 8), perm_mul coprime to that
     int safe_wait;          // option "terrain_ring_wait" = 1: s_waitcnt vmcnt(0) instead of the counted wait (test switch)
@@ -316,12 +318,82 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     for (int k = 0; k < N_ATTR; ++k) sk.org.p[k] = a.out.p[k] + org_off;
     sk.o0 = (uint32_t)(lane * sizeof(float));
     sk.ostride = (uint32_t)(a.W * sizeof(float));
+    sk.sync_n = (uint32_t)a.sync_n;   // (legal: the four waves of a group march the same number of rows)
     march_rows<FIT, CURV, WIN, SP, float, DirectSink<float, false>, RowsRing<NPL>>(rows, n_out, a.P, sk);
 }
 
-// TPI / TRI for an arbitrary odd window (reference default is 3, handled by the fused kernel above).
-// One thread per pixel, window read through L1/L2; float64 accumulation in row-major order like the
-// flattened footprint the reference's generic_filter callback sums (xdem/terrain/window.py:67-252).
+// TPI / TRI / roughness for an arbitrary odd window (the reference default 3 is handled by the fused kernels above).
+// Per pixel the window is summed in float64 in row-major order -- the order of the flattened footprint the reference's
+// generic_filter callbacks receive (xdem/terrain/window.py:67-308) -- whatever the route:
+//  * window_lds_kernel (round 4): a workgroup of 256 threads owns WIN_TW x WIN_TH output pixels and stages the
+//    (WIN_TH + w - 1) x (WIN_TW + w - 1) patch of the DEM in LDS once (coalesced row loads, NaN outside the raster and its
+//    halo rows); every tap is then a conflict-free LDS read (lanes = consecutive columns) instead of a global load through
+//    L1 / L2 -- w^2 of them per pixel -- and only the requested indexes are computed (compile-time flags: TPI alone skips the
+//    difference / fused-multiply-add / min / max chains).  Windows whose patch exceeds WIN_LDS_BYTES (w > ~90) and
+//    option "terrain_window_lds" = 0 take
+//  * window_generic_kernel: one thread per pixel, taps through L1 / L2 (the form of rounds 1-3; the check of the other).
+constexpr int WIN_TW = 64, WIN_TH = 16;
+constexpr size_t WIN_LDS_BYTES = 64 * 1024;
+
+template <typename TIN, typename TOUT, bool DO_TPI, bool DO_TRI, bool DO_ROUGH>
+__device__ __forceinline__ void window_accumulate(const TIN* win /* top-left tap */, int pitch, int w, double c, int tri_wilson,
+                                                  double& sum, double& acc, TIN& mx, TIN& mn, bool& has_nan) {
+    for (int dy = 0; dy < w; ++dy) {
+        const TIN* row = win + dy * pitch;
+        for (int dx = 0; dx < w; ++dx) {
+            const TIN t = row[dx];
+            const double v = (double)t;
+            if (DO_TPI) sum += v;
+            if (DO_ROUGH) {
+                has_nan |= (t != t);
+                mx = t > mx ? t : mx;
+                mn = t < mn ? t : mn;
+            }
+            if (DO_TRI) {
+                const double d = fabs(v - c);
+                acc = tri_wilson ? (acc + d) : fma(d, d, acc);
+            }
+        }
+    }
+}
+
+template <typename TIN, typename TOUT, bool DO_TPI, bool DO_TRI, bool DO_ROUGH>
+__global__ __launch_bounds__(256) void window_lds_kernel(const TIN* __restrict__ dem, int64_t H, int64_t W, int64_t stride,
+                                                          int64_t halo_top, int64_t halo_bottom, int w, int tri_wilson,
+                                                          TOUT* __restrict__ tpi, TOUT* __restrict__ tri, TOUT* __restrict__ rough) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char win_smem[];
+    TIN* tile = reinterpret_cast<TIN*>(win_smem);
+    const int h = w / 2;
+    const int pitch = WIN_TW + w - 1, prow = WIN_TH + w - 1;
+    const int64_t x0 = (int64_t)blockIdx.x * WIN_TW, y0 = (int64_t)blockIdx.y * WIN_TH;
+    const TIN nan_in = (TIN)NAN;
+    for (int idx = threadIdx.x; idx < prow * pitch; idx += 256) {
+        const int r = idx / pitch, cidx = idx - r * pitch;
+        const int64_t gy = y0 - h + r, gx = x0 - h + cidx;
+        const bool ok = (gy >= -halo_top) && (gy < H + halo_bottom) && gx >= 0 && gx < W;
+        tile[idx] = ok ? dem[(gy + halo_top) * stride + gx] : nan_in;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+    const int64_t x = x0 + lx;
+    if (x >= W) return;
+    const double nn = (double)(w * w - 1);
+#pragma unroll 1
+    for (int ly = ly0; ly < WIN_TH; ly += 4) {
+        const int64_t y = y0 + ly;
+        if (y >= H) break;
+        const double c = (double)tile[(ly + h) * pitch + lx + h];
+        double sum = 0.0, acc = 0.0;
+        TIN mx = -(TIN)INFINITY, mn = (TIN)INFINITY;
+        bool has_nan = false;
+        window_accumulate<TIN, TOUT, DO_TPI, DO_TRI, DO_ROUGH>(tile + ly * pitch + lx, pitch, w, c, tri_wilson, sum, acc, mx, mn, has_nan);
+        const int64_t o = y * W + x;
+        if (DO_TPI) tpi[o] = (TOUT)(c - (sum - c) / nn);
+        if (DO_TRI) tri[o] = (TOUT)(tri_wilson ? acc / nn : sqrt(acc));
+        if (DO_ROUGH) rough[o] = has_nan ? (TOUT)NAN : (TOUT)((double)mx - (double)mn);
+    }
+}
+
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(256) void window_generic_kernel(const TIN* dem, int64_t H, int64_t W, int64_t stride,
                                                               int64_t halo_top, int64_t halo_bottom, int w,
@@ -352,6 +424,47 @@ __global__ __launch_bounds__(256) void window_generic_kernel(const TIN* dem, int
     if (tpi) tpi[o] = (TOUT)(c - (sum - c) / nn);
     if (tri) tri[o] = (TOUT)(tri_wilson ? acc / nn : sqrt(acc));
     if (rough) rough[o] = has_nan ? (TOUT)NAN : (TOUT)(mx - mn);
+}
+
+// Launcher of the two forms above; returns XDEMHIP_OK or an error code
+template <typename TIN, typename TOUT>
+static int launch_window(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t win) {
+    const TIN* dem = static_cast<const TIN*>(L.dem);
+    TOUT* tpi = (win & A_TPI) ? static_cast<TOUT*>(L.planes[P_TPI]) : nullptr;
+    TOUT* tri = (win & A_TRI) ? static_cast<TOUT*>(L.planes[P_TRI]) : nullptr;
+    TOUT* rough = (win & A_ROUGH) ? static_cast<TOUT*>(L.planes[P_ROUGH]) : nullptr;
+    const int w = L.window_size, wilson = (int)(L.tri_method == XDEMHIP_TRI_WILSON);
+    const size_t lds = (size_t)(WIN_TH + w - 1) * (size_t)(WIN_TW + w - 1) * sizeof(TIN);
+    const int64_t gy_lds = (L.H + WIN_TH - 1) / WIN_TH, gy_gen = (L.H + 3) / 4;
+    if (ctx->terrain_window_lds != 0 && lds <= WIN_LDS_BYTES && gy_lds <= 65535) {
+        const dim3 grid((unsigned)((L.W + WIN_TW - 1) / WIN_TW), (unsigned)gy_lds);
+        const int which = (tpi ? 1 : 0) | (tri ? 2 : 0) | (rough ? 4 : 0);
+#define XD_WIN(T, R, O)                                                                                                       \
+    do {                                                                                                                      \
+        if (lds > 48 * 1024) XD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lds_kernel<TIN, TOUT, T, R, O>), \
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES)); \
+        hipLaunchKernelGGL((window_lds_kernel<TIN, TOUT, T, R, O>), grid, dim3(256), lds, ctx->stream, dem, L.H, L.W, L.row_stride, \
+                           L.halo_top, L.halo_bottom, w, wilson, tpi, tri, rough);                                            \
+    } while (0)
+        switch (which) {
+            case 1: XD_WIN(true, false, false); break;
+            case 2: XD_WIN(false, true, false); break;
+            case 3: XD_WIN(true, true, false); break;
+            case 4: XD_WIN(false, false, true); break;
+            case 5: XD_WIN(true, false, true); break;
+            case 6: XD_WIN(false, true, true); break;
+            default: XD_WIN(true, true, true); break;
+        }
+#undef XD_WIN
+        XD_HIP_CHECK(ctx, hipGetLastError());
+        return XDEMHIP_OK;
+    }
+    if (gy_gen > 65535) return xd_fail(ctx, XDEMHIP_EUNSUPPORTED, "raster too tall for one launch of the window kernel");
+    dim3 grid((unsigned)((L.W + 63) / 64), (unsigned)gy_gen);
+    hipLaunchKernelGGL((window_generic_kernel<TIN, TOUT>), grid, dim3(256), 0, ctx->stream, dem, L.H, L.W, L.row_stride, L.halo_top,
+                       L.halo_bottom, w, wilson, tpi, tri, rough);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    return XDEMHIP_OK;
 }
 
 static void fill_params(const TerrainLaunch& L, TerrainParams& P) {
@@ -488,6 +601,7 @@ static int launch_stream(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
     a.ngroups = (int)(bands * a.groups_x);
     a.grid8 = (a.ngroups + 7) / 8;
     a.nbands = (int)bands;
+    a.sync_n = ctx->terrain_sync;
     a.safe_wait = ctx->terrain_ring_wait;
     {   // multiplier of order 2: near the golden section of the grid, coprime to it
         const uint32_t n = (uint32_t)a.grid8 * 8u;
@@ -550,6 +664,30 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
             if (ctx->terrain_math == 2) XD_SPECIALISED(2);
             else if (ctx->terrain_math == 0) XD_SPECIALISED(0);
 #undef XD_SPECIALISED
+            // Round 4: the SMALL surface sets -- DEM.slope(), slope + aspect, a hillshade, the three together -- for every fit, with
+            // reference defaults (degrees, z_factor 1): compile-time masks + lean tail + the streaming route, like the full set.
+            // With 8-16 bytes per pixel instead of 48 these launches are bound by instruction issue, so the folded attribute
+            // branches and the float32 scale factors matter more here than for the eleven planes.
+            if (ctx->terrain_math == 2 && L.degrees && L.hs_z == 1.0 && (mask & ~(A_SLOPE | A_ASPECT | A_HILLSHADE)) == 0) {
+#define XD_SMALL(F, M)                                                                                                       \
+    do {                                                                                                                     \
+        const int took = launch_stream<F, false, false, Spec<M, 0, 1, 0, 1, 2>>(ctx, L, mask);                              \
+        if (took != 0) return took < 0 ? took : XDEMHIP_OK;                                                                  \
+        return launch_shaped<F, false, false, Spec<M, 0, 1, 0, 1, 2>, TIN, TOUT>(ctx, L, mask);                             \
+    } while (0)
+#define XD_SMALL_FITS(M)                                                                                                     \
+    do {                                                                                                                     \
+        if (fit == XDEMHIP_FIT_HORN) XD_SMALL(0, M);                                                                         \
+        else if (fit == XDEMHIP_FIT_ZEVENBERGTHORNE) XD_SMALL(1, M);                                                         \
+        else XD_SMALL(2, M);                                                                                                 \
+    } while (0)
+                if (mask == A_SLOPE) XD_SMALL_FITS(A_SLOPE);
+                else if (mask == (A_SLOPE | A_ASPECT)) XD_SMALL_FITS(A_SLOPE | A_ASPECT);
+                else if (mask == A_HILLSHADE) XD_SMALL_FITS(A_HILLSHADE);
+                else if (mask == (A_SLOPE | A_ASPECT | A_HILLSHADE)) XD_SMALL_FITS(A_SLOPE | A_ASPECT | A_HILLSHADE);
+#undef XD_SMALL_FITS
+#undef XD_SMALL
+            }
         } else if (!f64tail) {
             if (defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY)
                 return launch_shaped<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1>, TIN, TOUT, ALLSHAPES>(ctx, L, mask);
@@ -583,14 +721,8 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
         if (rc != XDEMHIP_OK) return rc;
     }
     if (win && !fuse_win) {
-        dim3 grid((unsigned)((L.W + 63) / 64), (unsigned)((L.H + 3) / 4));
-        hipLaunchKernelGGL((window_generic_kernel<TIN, TOUT>), grid, dim3(256), 0, ctx->stream,
-                           static_cast<const TIN*>(L.dem), L.H, L.W, L.row_stride, L.halo_top, L.halo_bottom,
-                           L.window_size, (int)(L.tri_method == XDEMHIP_TRI_WILSON),
-                           (win & A_TPI) ? static_cast<TOUT*>(L.planes[P_TPI]) : nullptr,
-                           (win & A_TRI) ? static_cast<TOUT*>(L.planes[P_TRI]) : nullptr,
-                           (win & A_ROUGH) ? static_cast<TOUT*>(L.planes[P_ROUGH]) : nullptr);
-        XD_HIP_CHECK(ctx, hipGetLastError());
+        rc = launch_window<TIN, TOUT>(ctx, L, win);
+        if (rc != XDEMHIP_OK) return rc;
     }
     return XDEMHIP_OK;
 }
