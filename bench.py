@@ -296,7 +296,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
     res = (10.0, 10.0)
     ref, tba = _c3_pair(dev, m)
     px = float(m) * m
-    passes = 2  # full passes over the pair per iteration: (dh + global-median counting) and (aspect-bin counting)
+    routes = None
     import scipy.optimize
 
     if world == 1:
@@ -311,6 +311,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         offsets = coreg._iterate(plan, res, 0.0, 10, 72, scipy.optimize.curve_fit, True)
         dt_fit = (time.perf_counter() - t0) / 10
         n_valid = r["n_valid"]
+        routes = plan.route_counts()
         plan.close()
         how = "one GPU"
     else:
@@ -326,6 +327,12 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         dt_fit = (time.perf_counter() - t0) / 10
         dt = dt_fit
         how = f"row blocks of {world} ranks + halo rows, every reduction of a step through the process group"
+    # full data passes per iteration: ONE on the one-pass step of round 4 (dh, the counting for its median and the aspect-bin
+    # counting against sample brackets in the same pass), two on the queued route of rounds 2-3 (row-partitioned fits)
+    onepass = bool(routes and routes["onepass"] > 0 and routes["twopass"] == 0 and routes["plain"] == 0)
+    passes = 1 if onepass else 2
+    alg_bpp = 16 if onepass else 8 * passes   # 8 B/pixel/pass recomputing the aux rasters, 16 B/pixel/pass with stored aux arrays
+    touched = 14 if onepass else NK_TOUCHED_BYTES
     # validation inside the run: the fit must find the shift the pair was built with
     sx, sy, sz = -offsets[0] / res[0], -offsets[1] / res[1], offsets[2]
     if not (abs(sx - 1.7) < 0.05 and abs(sy - 0.6) < 0.05 and abs(sz + 2.0) < 0.05):
@@ -335,14 +342,20 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
                        "ms_per_iteration_whole_fit": round(dt_fit * 1e3, 2),
                        "fitted_shift_px": [round(sx, 3), round(sy, 3), round(sz, 3)],
                        "validated": "the 10-iteration fit recovers the (+1.7, +0.6) px, -2.0 m shift the pair was built with",
-                       "roofline": {"bound": "hbm", "model": "SURVEY 8d: 8 B/pixel (ref + tba) per data pass x P passes required by the exact "
-                                             "medians; P = 2 here (bracketed selections: one counting pass each for the global median and "
-                                             "the 72 aspect bins; plain radix passes would need 12)",
-                                    "passes": passes, "achieved": round(8 * passes * px / dt / 1e9, 1), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
-                                    "frac": round(8 * passes * px / dt / 1e9 / (HBM_PEAK_GBPS * world), 4),
-                                    "touched_bytes_per_pixel": NK_TOUCHED_BYTES,
-                                    "touched_GBps": round(NK_TOUCHED_BYTES * px / dt / 1e9, 1),
-                                    "note": NK_TOUCHED_NOTE},
+                       "routes": routes,
+                       "roofline": {"bound": "hbm", "model": ("SURVEY 8d: 16 B/pixel per data pass with stored aux arrays (ref 4 + tba 4 + slope tangent + aspect bin) "
+                                                              "x P passes; P = 1: the one-pass step counts for the median of dh and for the 72 bin medians in the "
+                                                              "same pass, against brackets from a 1/64 sample (8 B/pixel/pass x 2 passes in rounds 2-3: the same 16)"
+                                                              if onepass else
+                                                              "SURVEY 8d: 8 B/pixel (ref + tba) per data pass x P passes required by the exact "
+                                                              "medians; P = 2 here (bracketed selections: one counting pass each for the global median and "
+                                                              "the 72 aspect bins; plain radix passes would need 12)"),
+                                    "passes": passes, "algorithmic_bytes_per_pixel": alg_bpp,
+                                    "achieved": round(alg_bpp * px / dt / 1e9, 1), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                                    "frac": round(alg_bpp * px / dt / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                                    "touched_bytes_per_pixel": touched,
+                                    "touched_GBps": round(touched * px / dt / 1e9, 1),
+                                    "note": NK_ONEPASS_NOTE if onepass else NK_TOUCHED_NOTE},
                        "note": "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32); "
                                "ms_per_iteration = grid work of a step (host 72-point fit excluded; with more than one rank: the whole fit "
                                "per iteration), ms_per_iteration_whole_fit = NuthKaab's 10-iteration loop incl. scipy curve_fit, per iteration"}
@@ -355,6 +368,9 @@ VARIO_LIMITER_NOTE = ("round 2 (profiles/r02_nk_vario_pmc.json): 14.7 vector + 4
                       "the exact Dowd route = three sampled digit passes for both bracket ends (4 ms) + ONE counting / compaction pass over all pairs "
                       "(46 ms, ~19 vector instructions per pair, one packed LDS counter update each) + the selection among the 0.4 % of the "
                       "pairs inside the brackets (3 ms)")
+NK_ONEPASS_NOTE = ("the one pass touches 14 B/pixel: masked reference copy 4 + tba 4 + slope tangent 4 + cached aspect-bin id 2; no dh raster is "
+                   "written or re-read (22 B/pixel in two passes in round 3); candidates of the medians (a few percent) leave as (dh, slope "
+                   "tangent, bin) triples")
 NK_TOUCHED_BYTES = 22
 NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference copy 4 + tba 4 + dh out 4 -- min / max aspect come from the "
                    "plan's lists of extreme-aspect pixels, the inlier mask is folded into the reference copy as NaN; bin pass: dh 4 + "

@@ -236,6 +236,14 @@ int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* plan, const double* edges, int n_e
 #define XDEMHIP_BINSTAT_MEAN 1
 int xdemhip_nk_set_statistic(xdemhip_nk_plan* plan, int bin_stat);
 int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uint8_t* valid);
+/* How the steps of this plan were answered so far (any pointer may be NULL): by the ONE-PASS step of round 4 (one data pass of
+ * 14 B/pixel: the shifted elevation difference, the counting for its exact median and the aspect-bin counting against sample
+ * brackets with per-pixel margins; large single-GPU plans, median statistic, context option "nk_fused" = 1, the default), by
+ * the two queued passes of rounds 2-3, or by the plain digit passes (small rasters; the fall-back of both).  Results are
+ * identical on every route (integer counts, exact selections); nanmean / nanstd of y -- the p0 of the curve fit -- agree to
+ * 2e-6 of the spread on the one-pass route (float32 partial sums, the accuracy class of the reference's own float32
+ * np.nanmean). */
+int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* twopass, int64_t* plain);
 void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
                           int64_t* counts, double* medians);

@@ -392,7 +392,9 @@ def test_rccl_branch_of_the_halo_exchange_on_a_one_rank_group():
         finally:
             ctx.set_option("selection", 0)
         assert d1 - d0 >= 15 and h1 == h0, (h0, h1, d0, d1)
-        assert np.allclose(got_off, want_off, rtol=1e-9, atol=1e-9), (got_off, want_off)
+        # (the single-rank reference runs the one-pass step, whose nanmean / nanstd -- the p0 of the curve fit -- carry float32
+        # partial sums: the fitted offsets agree to the optimiser's tolerance, not to the last bits)
+        assert np.allclose(got_off, want_off, rtol=1e-6, atol=1e-6), (got_off, want_off)
     finally:
         if created:
             dist.destroy_process_group()

@@ -13,6 +13,17 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+
+def _moments_close(a, b, onepass=True):
+    """nanmean / nanstd of y.  They only seed the 72-point curve fit (p0, xdem/coreg/affine.py:386) and the reference itself
+    forms them in float32 (np.nanmean / np.nanstd of a float32 array: pairwise float32 sums, ~1e-7 of the spread).  The two-pass
+    routes accumulate float64 atomics (last bits depend on the order of the additions); the one-pass step of round 4 (option
+    "nk_fused") sums y^ = (dh - v^) / slope_tan in float32 pieces with a first-order correction in (v^ - vshift): 2e-6 of
+    the spread, the reference's own accuracy class."""
+    tol = 2e-6 * abs(b["y_std"]) if onepass else 1e-10 * abs(b["y_std"]) + 1e-11 * abs(b["y_mean"]) + 1e-13
+    return abs(a["y_mean"] - b["y_mean"]) <= tol and abs(a["y_std"] - b["y_std"]) <= tol
+
+
 def coreg():
     from xdem_amd import coreg as c
 
@@ -413,7 +424,7 @@ def test_rows_beyond_2g_pixels_match_a_small_plan(coreg):
         assert a["vshift"] == b["vshift"] and np.array_equal(a["edges"], b["edges"])
         bad = np.flatnonzero(a["medians"] != b["medians"])
         assert bad.size == 0, (bad, a["medians"][bad], b["medians"][bad], a["counts"][bad])
-        np.testing.assert_allclose([a["y_mean"], a["y_std"]], [b["y_mean"], b["y_std"]], rtol=1e-9)
+        assert _moments_close(a, b)
     a, b = big.step(1.25, -0.5, (res, res), 72), small.step(1.25, -0.5, (res, res), 72)
     assert np.array_equal(a["counts"], b["counts"])
     np.testing.assert_allclose(a["medians"], b["medians"], rtol=0, atol=1e-4)
@@ -669,17 +680,21 @@ def test_lean_route_equals_plain_route_at_scale():
     ctx = _lib.Context(0)
     try:
         res = {}
-        for mode in (0, 1):
+        # round 4: three implementations -- the one-pass step (default), the two-pass queued route (option "nk_fused" = 0) and plain
+        for name, mode, fused in (("onepass", 0, 1), ("twopass", 0, 0), ("plain", 1, 0)):
             ctx.set_option("selection", mode)
+            ctx.set_option("nk_fused", fused)
             plan = coreg.NKPlan(ref, tba, None, ctx)
-            res[mode] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
+            res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
+            assert plan.route_counts()[name] == 4, (name, plan.route_counts())   # every step answered by the route under test
             plan.close()
-        for a, b in zip(res[0], res[1]):
-            assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"]
-            assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True)
-            assert np.array_equal(a["edges"], b["edges"])
-            assert abs(a["y_mean"] - b["y_mean"]) <= 1e-12 * abs(b["y_mean"]) and abs(a["y_std"] - b["y_std"]) <= 1e-10 * b["y_std"]
-        assert res[0][1]["n_valid"] == res[0][3]["n_valid"] and np.array_equal(res[0][1]["medians"], res[0][3]["medians"], equal_nan=True)
+        for name in ("onepass", "twopass"):
+            for a, b in zip(res[name], res["plain"]):
+                assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], name
+                assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), name
+                assert np.array_equal(a["edges"], b["edges"]), name
+                assert _moments_close(a, b, onepass=name == "onepass"), (name, a["y_mean"], b["y_mean"], a["y_std"], b["y_std"])
+            assert res[name][1]["n_valid"] == res[name][3]["n_valid"] and np.array_equal(res[name][1]["medians"], res[name][3]["medians"], equal_nan=True)
     finally:
         ctx.close()
 
@@ -704,24 +719,29 @@ def test_bench_C3_pair_at_full_size_routes_agree():
     try:
         steps = ((0.0, 0.0), (1.7, 0.6), (1.2, 0.9), (1.7, 0.6))
         res = {}
-        for mode in (0, 1):
+        for name, mode, fused in (("onepass", 0, 1), ("twopass", 0, 0), ("plain", 1, 0)):
             ctx.set_option("selection", mode)
+            ctx.set_option("nk_fused", fused)
             plan = coreg.NKPlan(ref, tba, None, ctx)
-            res[mode] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in steps]
+            res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in steps]
+            assert plan.route_counts()[name] == len(steps), (name, plan.route_counts())
             plan.close()
         ctx.set_option("selection", 0)
-        for a, b in zip(res[0], res[1]):
-            assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"]
-            assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True)
-            assert np.array_equal(a["edges"], b["edges"])
-        assert np.array_equal(res[0][1]["medians"], res[0][3]["medians"], equal_nan=True)
-        assert 0.75 * 4e8 < res[0][0]["n_valid"] < 0.85 * 4e8
+        for name in ("onepass", "twopass"):
+            for a, b in zip(res[name], res["plain"]):
+                assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], name
+                assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), name
+                assert np.array_equal(a["edges"], b["edges"]), name
+                assert _moments_close(a, b, onepass=name == "onepass"), name
+            assert np.array_equal(res[name][1]["medians"], res[name][3]["medians"], equal_nan=True)
+        assert 0.75 * 4e8 < res["onepass"][0]["n_valid"] < 0.85 * 4e8
     finally:
         ctx.close()
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("dtype,rule", [(np.float32, 0), (np.float32, 1), (np.float64, 0)])
-def test_lean_kernels_vs_oracle(coreg, dtype, rule):
+def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused):
     """The queued route (lean dh / bin kernels, bracketed selections, aspect-bin cache) only runs from 2^22 pixels on: a
     2100 x 2050 pair, selection mode 3 (bracketed route for the 72 bins whatever their sample size), against the oracle for
     shifts that exercise the row-tap table and the carried lerps -- zero, integer, negative, beyond one pixel, a hair below an
@@ -743,6 +763,7 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule):
     try:
         ctx.set_option("nk_nan_rule", rule)
         ctx.set_option("selection", 3)
+        ctx.set_option("nk_fused", fused)   # round 4: the one-pass step (1, default) / the two passes of round 3 (0)
         plan = coreg.NKPlan(ref, tba, inlier)
         if dtype == np.float64:
             asp = plan.aux()[1]
@@ -759,10 +780,15 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule):
             assert np.array_equal(det["counts"], counts), (sx, sy)
             assert np.array_equal(det["edges"], edges.astype(np.float64)), (sx, sy)
             assert np.array_equal(det["medians"], med, equal_nan=True), (sx, sy)
+            y64 = y.astype(np.float64)
+            assert _moments_close(det, {"y_mean": float(y64.mean()), "y_std": float(y64.std())}, onepass=bool(fused)), (sx, sy)
+        rc_ = plan.route_counts()
+        assert rc_["onepass" if fused else "twopass"] == 6 and rc_["plain"] == 0, rc_
         plan.close()
     finally:
         ctx.set_option("nk_nan_rule", 0)
         ctx.set_option("selection", 0)
+        ctx.set_option("nk_fused", 1)
 
 
 def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
@@ -787,20 +813,26 @@ def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
     keys = ("vshift", "n_valid")
     for name, tba in (("full", tba_full), ("bottom only", tba_bottom)):
         got = {}
-        for ext in (1, 0):
+        # (ext, fused): the one-pass step of round 4 builds on the EXT buffers and, like the EXT dh pass, must notice when no
+        # listed extreme-aspect pixel keeps a dh and hand the step to the route that reads the aspect
+        for ext, fused in ((1, 1), (1, 0), (0, 0)):
             ctx.set_option("nk_ext", ext)
+            ctx.set_option("nk_fused", fused)
             try:
                 plan = coreg.NKPlan(ref, tba, None)
-                got[ext] = [plan.step(sx, sy, (res, res), 72) for sx, sy in ((0.0, 0.0), (7.3, -12.1), (7.3, -12.1))]
+                got[(ext, fused)] = [plan.step(sx, sy, (res, res), 72) for sx, sy in ((0.0, 0.0), (7.3, -12.1), (7.3, -12.1))]
                 plan.close()
             finally:
                 ctx.set_option("nk_ext", 1)
-        for a, b in zip(got[1], got[0]):
-            assert all(a[k] == b[k] for k in keys), name
-            # (the two moments are float64 atomics: their last bits depend on the order of the additions even within one route)
-            assert abs(a["y_mean"] - b["y_mean"]) <= 1e-11 * (abs(b["y_mean"]) + 1e-9) + 1e-13 and abs(a["y_std"] - b["y_std"]) <= 1e-11 * abs(b["y_std"])
-            assert np.array_equal(a["edges"], b["edges"]) and np.array_equal(a["counts"], b["counts"]), name
-            assert np.array_equal(a["medians"], b["medians"], equal_nan=True), name
+                ctx.set_option("nk_fused", 1)
+        for cfg in ((1, 1), (1, 0)):
+            for a, b in zip(got[cfg], got[(0, 0)]):
+                assert all(a[k] == b[k] for k in keys), (name, cfg)
+                # (the two moments are float64 atomics: their last bits depend on the order of the additions even within one route)
+                assert _moments_close(a, b, onepass=cfg == (1, 1) and name == "full"), (name, cfg)
+                assert np.array_equal(a["edges"], b["edges"]) and np.array_equal(a["counts"], b["counts"]), (name, cfg)
+                assert np.array_equal(a["medians"], b["medians"], equal_nan=True), (name, cfg)
+        got[1], got[0] = got[(1, 0)], got[(0, 0)]
         if name == "bottom only":
             asp = coreg.NKPlan(ref, tba, None)
             a_ = asp.aux()[1]

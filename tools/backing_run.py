@@ -12,6 +12,9 @@ import numpy as np
 import torch
 
 from xdem_amd import _lib, terrain
+
+if os.environ.get("XD_LIB"):   # A/B of library builds across processes (measurement variants: xdem_amd/csrc/Makefile)
+    _lib.LIB_PATH = os.environ["XD_LIB"]
 from xdem_amd.synth import fbm_torch
 
 FULL = ["slope", "aspect", "hillshade", "profile_curvature", "tangential_curvature", "planform_curvature",
@@ -28,4 +31,4 @@ t = []
 for i in range(launches):
     terrain.terrain_attributes_device(dem, FULL, out=out, resolution=10.0, surface_fit="Florinsky", curv_method="geometric", ctx=ctx)
     t.append(ctx.last_kernel_ms())
-print(f"backing {backing} order {order}: launches {['%.2f' % x for x in t]} median {np.median(t[1:]):.3f} ms", flush=True)
+print(f"lib {os.path.basename(_lib.LIB_PATH)} backing {backing} order {order}: launches {['%.2f' % x for x in t]} median {np.median(t[1:]):.3f} ms", flush=True)

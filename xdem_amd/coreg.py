@@ -182,6 +182,12 @@ class NKPlan:
             self._raise_step_error(rc)
         return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value, "sums": sums}
 
+    def route_counts(self) -> dict[str, int]:
+        """Steps answered so far by the one-pass step, by the two queued passes, by the plain digit passes (``xdemhip_nk_route_counts``)."""
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self.ctx.check(self.ctx._L.xdemhip_nk_route_counts(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"onepass": int(a.value), "twopass": int(b.value), "plain": int(c.value)}
+
     def set_bin_edges(self, edges) -> None:
         """Explicit aspect-bin edges (``bin_sizes={"aspect": edges}`` upstream); ``None`` restores SciPy's automatic edges."""
         dp = ctypes.POINTER(ctypes.c_double)

@@ -903,6 +903,417 @@ int NkYSource<T>::launch_lean(xdemhip_ctx* ctx, int64_t n, int nb, const typenam
     return XDEMHIP_OK;
 }
 
+
+// ================================================================================================================
+// Round 4: the ONE-PASS step (option "nk_fused", default on; single GPU, median statistic, NaN rules 0 / 1, EXT route).
+// The two data passes of rounds 2-3 -- dh (written) with the counting for its median, then y = (dh - vshift) / slope_tan
+// binned by aspect with the counting for the bin medians (dh re-read) -- become one: 4 (masked reference) + 4 (tba) + 4
+// (slope tangent) + 2 (cached aspect bin) = 14 B/pixel, no dh raster.  The obstacle is that y needs vshift = the exact
+// median of dh, which exists only after the pass.  But the 1/64 sample brackets it BEFORE the pass: v_lo <= vshift <= v_hi
+// (proved afterwards by the integer counts, as before).  With v^ the bracket's midpoint and delta >= max(v^ - v_lo, v_hi -
+// v^), every pixel's y lies within m = delta / slope_tan (+ rounding slack) of y^ = (dh - v^) / slope_tan, so against the
+// bracket [lo_b, hi_b] of its aspect bin (from the same sample, evaluated with v^) a pixel is
+//     certainly below   if y^ + m < lo_b,        certainly above   if y^ - m > hi_b,        a candidate otherwise;
+// the certain ones are counted, the candidates (a few percent) staged as (dh, slope_tan, bin) triples.  Once vshift is
+// known exactly (selection among the dh candidates, as before), nk_resolve_kernel evaluates the candidates' y in the
+// reference's arithmetic, counts those below / inside [lo_b, hi_b] and hands the inside ones to the same exact selection as
+// before: rank (k - certainly below - candidates below) among them.  All counting is integer; every rank claim is checked by
+// the counts (bracket_given_kernel); a miss or an overflow anywhere sends the step to the two-pass route of round 3.
+// Monotonicity makes the classification safe, not a tolerance: y(v) = fl(fl(dh - v) / st) is non-increasing in v for st > 0,
+// and m bounds |y(v) - y^| for every v in [v_lo, v_hi] including the roundings of both evaluations (slack terms below).
+// nanmean / nanstd of y (the p0 of the 72-point curve fit only) come from sums of y^ and the first-order correction in
+// (v^ - vshift): sum y = sum y^ + (v^ - v) sum r, sum y^2 = sum y^^2 + 2 (v^ - v) sum y^ r + (v^ - v)^2 sum r^2, r = 1 / st.
+// np.linspace(smin, smax, nb + 1) in double (k * step + start, end point forced), cast to T -- SciPy's _bin_edges
+template <typename T> __host__ __device__ inline void make_edges_into(double smin, double smax, int nb, T* e) {
+    if (smin == smax) { smin -= 0.5; smax += 0.5; }
+    const double step = (smax - smin) / nb;
+    for (int k = 0; k <= nb; ++k) e[k] = (T)((double)k * step + smin);
+    e[nb] = (T)smax;
+}
+template <typename T> struct FzEps;   // relative slack that covers the roundings of y^ (fast reciprocal) and of y itself
+template <> struct FzEps<float> { static constexpr float rel = 4e-6f, grow = 1.00002f, tiny = 1e-37f; };
+template <> struct FzEps<double> { static constexpr double rel = 1e-14, grow = 1.0000000001, tiny = 1e-300; };
+__device__ __forceinline__ float fz_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fz_rcp(double x) { return 1.0 / x; }
+
+// edges from the min / max aspect of this step (EXT lists), freshness of the aspect-bin cache, EXT miss -> flag
+template <typename T>
+__global__ void nk_fz_prep_kernel(const DhStats* stats, const unsigned long long* ext_survivors, int nb, int custom_edges, T* edges,
+                                  BinCacheRec* rec, int force, unsigned long long* ctr) {
+    typedef typename KeyT<T>::type K;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (ext_survivors[0] == 0 || ext_survivors[1] == 0) ctr[3] = 1ull;   // min / max aspect unknown on this route
+    if (!custom_edges) make_edges_into<T>((double)val_of((K)stats->asp_min), (double)val_of((K)stats->asp_max), nb, edges);
+    const double e0 = (double)edges[0], eN = (double)edges[nb];
+    rec->fresh = (!force && rec->nb == nb && rec->e0 == e0 && rec->eN == eN) ? 1 : 0;
+}
+
+template <typename T> __device__ __forceinline__ uint16_t fz_digitize(const T* e, double inv_width, int nb, T x, int last_decimal) {
+    int idx = (int)(((double)x - (double)e[0]) * inv_width);  // (the digitize of nk_y_kernel / NkYSource)
+    idx = idx < 0 ? 0 : (idx > nb ? nb : idx);
+    while (idx > 0 && !(e[idx] <= x)) --idx;
+    while (idx < nb && e[idx + 1] <= x) ++idx;
+    if (!(e[0] <= x)) idx = -1;
+    if (idx == nb && on_last_edge<T>(x, e[nb], last_decimal)) idx = nb - 1;
+    return (idx >= 0 && idx < nb) ? (uint16_t)idx : (uint16_t)0xFFFF;
+}
+// (re)fill of the aspect-bin cache; leaves at once while the cache is fresh
+template <typename T>
+__global__ __launch_bounds__(256) void nk_bin_fill_kernel(const T* __restrict__ aspect, int64_t n, const T* __restrict__ edges, int nb,
+                                                          int last_decimal, const BinCacheRec* rec, uint16_t* __restrict__ bcache) {
+    if (rec->fresh == 1) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
+    T* e = reinterpret_cast<T*>(fz_smem);
+    for (int k = threadIdx.x; k <= nb; k += blockDim.x) e[k] = edges[k];
+    __syncthreads();
+    const double inv_width = (double)nb / ((double)e[nb] - (double)e[0]);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+        bcache[p] = fz_digitize<T>(e, inv_width, nb, aspect[p], last_decimal);
+}
+
+// positional 1/64 line sample of dh at this step's shift: slot i <-> element (i mod 8) of sampled line (i / 8); NaN where the
+// pixel has no dh (the digit passes skip NaN), so no compaction and no counter
+template <typename T>
+__global__ __launch_bounds__(256) void nk_sample_dh_kernel(const T* __restrict__ ref_m, const T* __restrict__ tba, NkGeom g, int64_t q0, int64_t n,
+                                                           double invW, int64_t n_slots, T* __restrict__ s_d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = (sel_sampled_line(i >> SEL_LINE_LOG2) << SEL_LINE_LOG2) + (i & (SEL_LINE - 1));
+        T out = (T)NAN;
+        if (p < n) {
+            const int64_t q = q0 + p;
+            int64_t li, j;
+            row_col(q, g.W, invW, li, j);
+            const BiTap t = bi_locate(g, li + g.roff, j);
+            const BiVals<T> tv = bi_load<T>(tba, t);
+            T val;
+            const bool in = bi_value<T>(g, tba, t, tv.a00, tv.a01, tv.a10, tv.a11, val);
+            const T d = t_sub(ref_m[q], val);
+            if (in && t_finite(d)) out = d;
+        }
+        s_d[i] = out;
+    }
+}
+
+// v^ and delta from the bracket keys of the dh sample (two selection states: low end, high end)
+template <typename T>
+__global__ void nk_vhat_kernel(const SelState<typename KeyT<T>::type>* st, const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
+                               T* vhat, T* delta, unsigned long long* ctr) {
+    typedef typename KeyT<T>::type K;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st[0].count == 0) { ctr[3] = 1ull; *vhat = (T)0; *delta = (T)0; return; }
+    const K lo = klo[0], hi = khi[0];
+    const K mid = (K)(lo + (K)((K)(hi - lo) >> 1));
+    const double vl = (double)val_of(lo), vh = (double)val_of(hi), vm = (double)val_of(mid);
+    const double d = fmax(vm - vl, vh - vm);
+    *vhat = val_of(mid);
+    // rounded up, with room for the roundings of (dh - v) in the value dtype
+    T df = (T)(d * 1.000001 + 1e-300);
+    if ((double)df < d * 1.0000005) df = (T)((double)df * 1.000001);
+    *delta = df;
+    if (!(vl <= vm && vm <= vh) || !t_finite((T)vl) || !t_finite((T)vh)) ctr[3] = 1ull;   // a bracket that reaches +-Inf: not this route
+}
+
+// sample of y^ = (dh - v^) / slope_tan with its aspect bin, in place over the dh sample
+template <typename T>
+__global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, uint16_t* __restrict__ s_b, const T* __restrict__ slope_tan,
+                                                          const uint16_t* __restrict__ bcache, int64_t n, int64_t n_slots, const T* vhat_p) {
+    const T vhat = *vhat_p;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = (sel_sampled_line(i >> SEL_LINE_LOG2) << SEL_LINE_LOG2) + (i & (SEL_LINE - 1));
+        const T d = s_v[i];
+        T y = (T)NAN;
+        uint16_t b = 0xFFFF;
+        if (p < n && d == d) {
+            b = bcache[p];
+            y = t_div(t_sub(d, vhat), slope_tan[p]);
+            if (b == 0xFFFF || !(y == y)) y = (T)NAN;
+        }
+        s_v[i] = y;
+        s_b[i] = b;
+    }
+}
+
+constexpr int NKZ_ROWS = 2;      // rows between two looks at the staging buffers
+// staging slots per workgroup and kind (flushed once fewer than 2 x NKZ_ROWS rows would still fit; float64: static LDS stays < 48 KiB)
+template <typename T> struct NkzCap { static constexpr int v = sizeof(T) == 4 ? 2048 : 1024; };
+template <typename T> struct FzPair { T lo, hi; };
+
+template <typename T, int RULE>
+__global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
+                                                       const uint16_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
+                                                       int nb, int copies, const typename KeyT<T>::type* __restrict__ klo_p,
+                                                       const typename KeyT<T>::type* __restrict__ khi_p, const T* vhat_p, const T* delta_p,
+                                                       const typename KeyT<T>::type* __restrict__ klo_y,
+                                                       const typename KeyT<T>::type* __restrict__ khi_y, uint64_t* cnt_d /* [3] */,
+                                                       uint64_t* cls_y /* [3][nb]: above, below, candidates */, T* cd_vals, int64_t cd_cap,
+                                                       T* cy_d, T* cy_st, uint16_t* cy_b, int64_t cy_cap,
+                                                       unsigned long long* ctr /* [1] dh candidates, [5] y candidates, [2] overflow */,
+                                                       double* sums /* [5] */) {
+    typedef typename KeyT<T>::type K;
+    constexpr int NKZ_CAP = NkzCap<T>::v;
+    static_assert(NKZ_CAP >= 2 * NKZ_ROWS * 256, "a flush check must leave room for NKZ_ROWS rows of candidates");
+    __shared__ NkRowTab tab[NK_CHUNK_MAX + 1];
+    __shared__ T stage_d[NKZ_CAP];
+    __shared__ T sy_d[NKZ_CAP];
+    __shared__ T sy_st[NKZ_CAP];
+    __shared__ uint16_t sy_b[NKZ_CAP];
+    __shared__ int s_held[2];
+    __shared__ unsigned long long s_base[2];
+    __shared__ unsigned long long s_red[4][3];
+    __shared__ double s_sum[4][5];
+    extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
+    FzPair<T>* lohi = reinterpret_cast<FzPair<T>*>(fz_smem);                       // [nb] bin brackets as values
+    uint32_t* c = reinterpret_cast<uint32_t*>(lohi + nb);                          // [copies][cs]: 3 counters per bin
+    const int cs = (3 * nb) | 1;  // odd copy stride: the copies of one counter fall into different LDS banks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2) s_held[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { lohi[k].lo = val_of(klo_y[k]); lohi[k].hi = val_of(khi_y[k]); }
+    for (int k = threadIdx.x; k < cs * copies; k += blockDim.x) c[k] = 0;
+    const K klo = *klo_p, khi = *khi_p;
+    const T vhat = *vhat_p;
+    const T dgrow = (T)(*delta_p * FzEps<T>::grow);
+    const int64_t chunk = (row1 - row0 + gridDim.y - 1) / gridDim.y;  // <= NK_CHUNK_MAX (launcher)
+    const int64_t i0 = row0 + (int64_t)blockIdx.y * chunk;
+    const int nrow = (int)((i0 + chunk < row1 ? i0 + chunk : row1) - i0);
+    for (int r = threadIdx.x; r <= nrow && r <= NK_CHUNK_MAX; r += blockDim.x) {
+        const BiAxis a = bi_axis(i0 + (r < nrow ? r : nrow - 1), g.dr, g.H, RULE);
+        int64_t kl = a.k0 - g.roff;
+        kl = (a.in && kl >= 0 && kl + a.d1 < nbuf) ? kl : 0;
+        NkRowTab e;
+        e.fr = a.f; e.k0l = (int)kl; e.flags = (a.in ? 1 : 0) | (a.d1 ? 2 : 0);
+        tab[r] = e;
+    }
+    __syncthreads();
+    if (nrow <= 0) return;  // (uniform over the workgroup)
+    uint32_t* cc = c + (threadIdx.x % copies) * cs;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool jin = j < g.W;
+    const BiAxis col = bi_axis(j, g.dc, g.W, RULE);
+    const bool cin = col.in & jin;
+    const uint32_t c0 = cin ? (uint32_t)col.k0 : 0u, c1 = c0 + (cin ? (uint32_t)col.d1 : 0u);
+    const uint32_t jl = jin ? (uint32_t)j : 0u;
+    const double fc = col.f;
+    auto hlerp = [&](T a, T b) -> double {
+        const double v0 = a, v1 = b;
+        return t_add(v0, t_mul(fc, t_sub(v1, v0)));
+    };
+    uint32_t n_all = 0, n_below = 0, n_in = 0;  // wave-uniform
+    // staging: [0] candidates of the median of dh (values), [1] candidates of the bin medians (dh, slope_tan, bin)
+    auto block_flush = [&](int threshold) {  // every thread of the workgroup
+        __syncthreads();
+        const int h0 = s_held[0], h1 = s_held[1];
+        const bool f0 = h0 > threshold, f1 = h1 > threshold;
+        if (f0 || f1) {   // (uniform)
+            if (threadIdx.x == 0 && f0) s_base[0] = atomicAdd(&ctr[1], (unsigned long long)h0);
+            if (threadIdx.x == 64 && f1) s_base[1] = atomicAdd(&ctr[5], (unsigned long long)h1);
+            __syncthreads();
+            if (f0) {
+                const unsigned long long b0 = s_base[0];
+                for (int k = threadIdx.x; k < h0; k += blockDim.x) {
+                    if ((int64_t)(b0 + k) < cd_cap) cd_vals[b0 + k] = stage_d[k];
+                    else ctr[2] = 1ull;
+                }
+            }
+            if (f1) {
+                const unsigned long long b1 = s_base[1];
+                for (int k = threadIdx.x; k < h1; k += blockDim.x) {
+                    if ((int64_t)(b1 + k) < cy_cap) { cy_d[b1 + k] = sy_d[k]; cy_st[b1 + k] = sy_st[k]; cy_b[b1 + k] = sy_b[k]; }
+                    else ctr[2] = 1ull;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0 && f0) s_held[0] = 0;
+            if (threadIdx.x == 64 && f1) s_held[1] = 0;
+            __syncthreads();
+        }
+    };
+    int have = -1;
+    double hl = 0.0;
+    struct Pre { T b0, b1, rv, st; uint16_t bin; };
+    Pre pre[NK_PF];
+    const int64_t rb0 = (i0 - g.roff) * g.W;
+    auto issue = [&](int rr, Pre& q) {  // rr clamped: entry `nrow` of the table repeats the last row
+        const int rc = rr < nrow ? rr : nrow - 1;
+        const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
+        const T* rowp = tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W;
+        const int64_t rb = rb0 + (int64_t)rc * g.W;
+        q.b0 = __builtin_nontemporal_load(rowp + c0); q.b1 = __builtin_nontemporal_load(rowp + c1);
+        q.rv = __builtin_nontemporal_load(ref + rb + jl);
+        q.st = __builtin_nontemporal_load(slope_tan + rb + jl);
+        q.bin = __builtin_nontemporal_load(bcache + rb + jl);
+    };
+    // sums of y^ and of the correction terms: float32 partial sums (y^, y^ y^ folded into float64 every NK_PF rows; the three
+    // correction sums scale a term ~1e-3 of the total and stay float32 over the chunk)
+    float p_y = 0.0f, p_yy = 0.0f, p_r = 0.0f, p_yr = 0.0f, p_rr = 0.0f;
+    double a_y = 0.0, a_yy = 0.0;
+#pragma unroll
+    for (int u = 0; u < NK_PF; ++u) issue(u, pre[u]);
+    for (int r0 = 0; r0 < nrow; r0 += NK_PF) {
+#pragma unroll
+        for (int u = 0; u < NK_PF; ++u) {
+            const int r = r0 + u;
+            if (r < nrow) {
+                const T b0v = pre[u].b0, b1v = pre[u].b1, rv = pre[u].rv, stv = pre[u].st;
+                const uint16_t bin = pre[u].bin;
+                issue(r + NK_PF, pre[u]);
+                const int k0l = __builtin_amdgcn_readfirstlane(tab[r].k0l), fl = __builtin_amdgcn_readfirstlane(tab[r].flags);
+                const double fr = tab[r].fr;
+                double top;
+                if (have == k0l) {
+                    top = hl;
+                } else {  // chunk start, or a step of the tap row other than +1: fetch the upper row
+                    const T* up = tba + (int64_t)k0l * g.W;
+                    top = hlerp(up[c0], up[c1]);
+                }
+                double bot = top;
+                if (fl & 2) bot = hlerp(b0v, b1v);
+                have = k0l + ((fl >> 1) & 1);
+                hl = bot;
+                const T val = (T)t_add(top, t_mul(fr, t_sub(bot, top)));
+                const T out = t_sub(rv, val);
+                const bool ok = ((fl & 1) != 0) & cin & t_finite(out);
+                const K key = key_of(out);
+                const bool below = ok & (key < klo);
+                const bool cand = ok & (key >= klo) & (key <= khi);
+                n_all += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
+                n_below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(below));
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
+                if (mask) {
+                    const int cn = __popcll(mask);
+                    int pos0 = 0;
+                    if (lane == 0) pos0 = atomicAdd(&s_held[0], cn);
+                    pos0 = __builtin_amdgcn_readfirstlane(pos0);
+                    if (cand) stage_d[pos0 + __popcll(mask & ((1ull << lane) - 1ull))] = out;
+                    n_in += (uint32_t)cn;
+                }
+                // ---- the bin side: y^ with its margin against the bracket of the pixel's aspect bin
+                const T rr = fz_rcp(stv);
+                const T yh = (T)(out - vhat) * rr;
+                const T m = (T)(dgrow * rr) + (T)(fabs(yh) * FzEps<T>::rel) + FzEps<T>::tiny;
+                const bool yb = ok & (bin != (uint16_t)0xFFFF) & (yh == yh);
+                const FzPair<T> lh = lohi[yb ? bin : 0];
+                const bool isb = yb & ((T)(yh + m) < lh.lo);
+                const bool isa = yb & ((T)(yh - m) > lh.hi);
+                const bool cy = yb & !isb & !isa;
+                if (yb) atomicAdd(&cc[__umul24((unsigned)(isb ? 1 : (cy ? 2 : 0)), (unsigned)nb) + bin], 1u);
+                const unsigned long long my = __builtin_amdgcn_ballot_w64(cy);
+                if (my) {
+                    const int cn = __popcll(my);
+                    int pos0 = 0;
+                    if (lane == 0) pos0 = atomicAdd(&s_held[1], cn);
+                    pos0 = __builtin_amdgcn_readfirstlane(pos0);
+                    if (cy) {
+                        const int pos = pos0 + __popcll(my & ((1ull << lane) - 1ull));
+                        sy_d[pos] = out; sy_st[pos] = stv; sy_b[pos] = bin;
+                    }
+                }
+                const float yf = ok ? (float)yh : 0.0f, rf = ok ? (float)rr : 0.0f;
+                p_y += yf; p_yy = fmaf(yf, yf, p_yy);
+                p_r += rf; p_yr = fmaf(yf, rf, p_yr); p_rr = fmaf(rf, rf, p_rr);
+            }
+            // (r is uniform over the workgroup: every wave walks the same rows) room for NKZ_ROWS more rows must remain
+            if (((r + 1) % NKZ_ROWS) == 0 && r + 1 < nrow) block_flush(NKZ_CAP - 2 * NKZ_ROWS * 256);
+        }
+        a_y += (double)p_y; a_yy += (double)p_yy;
+        p_y = 0.0f; p_yy = 0.0f;
+    }
+    block_flush(0);
+    double sv[5] = {a_y, a_yy, (double)p_r, (double)p_yr, (double)p_rr};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        for (int off = 32; off > 0; off >>= 1) sv[k] += __shfl_down(sv[k], off);
+    if (lane == 0) {
+        s_red[wave][0] = n_all; s_red[wave][1] = n_below; s_red[wave][2] = n_in;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_sum[wave][k] = sv[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long q0 = 0, q1 = 0, q2 = 0;
+        for (int w = 0; w < 4; ++w) { q0 += s_red[w][0]; q1 += s_red[w][1]; q2 += s_red[w][2]; }
+        if (q0) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt_d[0]), q0);
+        if (q1) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt_d[1]), q1);
+        if (q2) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt_d[2]), q2);
+    }
+    if (threadIdx.x < 5) atomicAdd(&sums[threadIdx.x], s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
+    for (int k = threadIdx.x; k < 3 * nb; k += blockDim.x) {
+        unsigned long long t = 0;
+        for (int q = 0; q < copies; ++q) t += c[q * cs + k];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long*>(&cls_y[k]), t);
+    }
+}
+
+// vertical shift from the counters and the selection among the dh candidates (the arithmetic of nk_vshift_edges_kernel)
+template <typename T>
+__global__ void nk_fz_vshift_kernel(const uint64_t* cnt /* total, below, inside */, const SelState<typename KeyT<T>::type>* st, const uint64_t* succ,
+                                    const typename KeyT<T>::type* klo, const uint32_t* rbs_p, const unsigned long long* ctr, unsigned char* info) {
+    typedef typename KeyT<T>::type K;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint64_t total = cnt[0], lt = cnt[1];
+    const int rbs = (int)*rbs_p;
+    T vs = (T)NAN;
+    if (total) {
+        const K prefix = (K)((K)(st[0].prefix >> rbs) + klo[0]);
+        const uint64_t n_le = st[0].n_le + lt;
+        const T lo = val_of(prefix);
+        if (total & 1) vs = lo;
+        else {
+            const uint64_t k2 = total / 2;
+            T hi = lo;
+            if (!(n_le > k2)) hi = val_of((K)((K)((K)succ[0] >> rbs) + klo[0]));
+            vs = (T)((T)(lo + hi) / (T)2);
+        }
+    }
+    *reinterpret_cast<T*>(info) = vs;
+    *reinterpret_cast<uint64_t*>(info + 8) = total;
+    *reinterpret_cast<uint64_t*>(info + 16) = (uint64_t)((ctr[2] != 0) | ((ctr[3] != 0) << 1));
+    *reinterpret_cast<double*>(info + 24) = (double)vs;
+}
+
+// candidates of the bin medians, now that vshift is known: y in the reference's arithmetic; below / inside the bin's bracket are
+// counted, the inside ones keep their y (NaN for the others: the digit passes skip NaN)
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_resolve_kernel(T* __restrict__ c_v /* dh in, y out */, const T* __restrict__ c_st,
+                                                                  const uint16_t* __restrict__ c_b, int64_t cap, const unsigned long long* n_dev,
+                                                                  const T* vshift_p, int nb, const typename KeyT<T>::type* __restrict__ klo,
+                                                                  const typename KeyT<T>::type* __restrict__ khi, uint64_t* res /* [2][nb] */) {
+    typedef typename KeyT<T>::type K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
+    K* lo = reinterpret_cast<K*>(fz_smem);
+    K* hi = lo + nb;
+    uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);   // [2][nb]
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { lo[k] = klo[k]; hi[k] = khi[k]; }
+    for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x) c[k] = 0;
+    __syncthreads();
+    const unsigned long long m = *n_dev;
+    const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
+    const T vshift = *vshift_p;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)c_b[p];
+        const T y = t_div(t_sub(c_v[p], vshift), c_st[p]);
+        T keep = (T)NAN;
+        if (y == y && b < nb) {
+            const K key = key_of(y);
+            if (key < lo[b]) atomicAdd(&c[b], 1u);
+            else if (key <= hi[b]) { atomicAdd(&c[nb + b], 1u); keep = y; }
+        }
+        c_v[p] = keep;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x)
+        if (c[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&res[k]), (unsigned long long)c[k]);
+}
+
+// per bin: total / below / inside in the layout bracket_given_kernel reads, from the classes of the pass and of the candidates
+static __global__ void nk_fz_counts_kernel(const uint64_t* cls /* [3][nb]: above, below, candidates */, const uint64_t* res /* [2][nb] */, int nb,
+                                           uint64_t* cnt /* [3][nb] */) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    cnt[b] = cls[b] + cls[nb + b] + cls[2 * nb + b];
+    cnt[nb + b] = cls[nb + b] + res[b];
+    cnt[2 * nb + b] = res[nb + b];
+}
+
 }  // namespace xd
 
 // ================================================================================================================
@@ -926,6 +1337,12 @@ struct xdemhip_nk_plan {
     int64_t* ext_idx = nullptr;   // [2][EXT_CAP] pixels with the lowest / highest aspects
     unsigned long long* ext_cnt = nullptr;  // [0..1] list lengths, [2..3] survivors of the current step
     bool ext_ok = false;
+    uint64_t* fz = nullptr;       // device block of the one-pass step (nk_step_onepass): counters, bracket keys, v^, sums
+    size_t fz_bytes = 0;
+    void* cd_vals = nullptr;      // ... candidates of the median of dh
+    int64_t cd_cap = 0;
+    void* c_st = nullptr;         // ... slope tangents of the bin candidates (next to ws.c_vals / ws.c_bins)
+    int64_t n_onepass = 0, n_twopass = 0, n_plain = 0;   // steps answered by each route (xdemhip_nk_route_counts)
     void* scratch = nullptr;  // edges, stats, sums, selection states, successor keys, histograms
     size_t scratch_bytes = 0;
     int max_bins = 0;
@@ -950,13 +1367,6 @@ dim3 grid2d(const xdemhip_ctx* ctx, int64_t W, int64_t rows) {
     return dim3((unsigned)gx, (unsigned)gy);
 }
 
-// np.linspace(smin, smax, nb + 1) in double (k * step + start, end point forced), cast to T -- SciPy's _bin_edges
-template <typename T> __host__ __device__ inline void make_edges_into(double smin, double smax, int nb, T* e) {
-    if (smin == smax) { smin -= 0.5; smax += 0.5; }
-    const double step = (smax - smin) / nb;
-    for (int k = 0; k <= nb; ++k) e[k] = (T)((double)k * step + smin);
-    e[nb] = (T)smax;
-}
 template <typename T> void make_edges(double smin, double smax, int nb, std::vector<T>& e) {
     e.resize(nb + 1);
     make_edges_into<T>(smin, smax, nb, e.data());
@@ -1237,6 +1647,185 @@ int nk_stage_a(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int n
     return XDEMHIP_OK;
 }
 
+
+// ---- host side of the one-pass step (device code: "Round 4: the ONE-PASS step" above) ------------------------------------------
+// *done = false (nothing returned) when the route does not apply or when a bracket missed / a buffer overflowed: the caller
+// then runs the two-pass route of round 3, which needs nothing from here.
+template <typename T>
+int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int nb, bool* done, double* vshift, int64_t* n_valid,
+                    double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians) {
+    typedef typename KeyT<T>::type K;
+    *done = false;
+    xdemhip_ctx* ctx = P->ctx;
+    SelWorkspace* ws = &P->ws;
+    const int64_t rows = P->row1 - P->row0;
+    const int64_t n_slots = ((((n + SEL_LINE - 1) >> SEL_LINE_LOG2) + 63) >> 6) << SEL_LINE_LOG2;
+    if (!ctx->nk_fused || ctx->allreduce || !P->fz || !P->cd_vals || !P->c_st || !P->bcache || !P->ext_ok || g.rule > 1 || rows <= 0 ||
+        P->bin_stat != XDEMHIP_BINSTAT_MEDIAN || !(ctx->selection_mode == 0 || ctx->selection_mode == 3) || !ws->d_small ||
+        ws->es != sizeof(T) || nb > ws->nb_max || nb > MAX_BINS_PER_SWEEP || n < SEL_BRACKET_MIN_N ||
+        (ctx->selection_mode == 0 && n < SEL_BRACKET_MIN_PER_BIN * nb) || n_slots > ws->s_cap)
+        return XDEMHIP_OK;
+    unsigned char* scratch = static_cast<unsigned char*>(P->scratch);
+    T* d_edges = reinterpret_cast<T*>(scratch);
+    DhStats* d_stats = reinterpret_cast<DhStats*>(scratch + OFF_STATS);
+    BinCacheRec* d_rec = reinterpret_cast<BinCacheRec*>(scratch + OFF_INFO + 64);
+    const SelState<K>* d_st = reinterpret_cast<const SelState<K>*>(scratch + OFF_STATE);
+    const int nbm = ws->nb_max;
+    uint64_t* fz = P->fz;
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(fz);   // [1] dh candidates, [2] overflow, [3] miss, [5] y candidates
+    uint32_t* rbs_d = reinterpret_cast<uint32_t*>(fz + 8);
+    uint32_t* rbs_y = reinterpret_cast<uint32_t*>(fz + 9);
+    uint64_t* cnt_d = fz + 10;
+    uint64_t* given_d = fz + 13;
+    K* klo_d = reinterpret_cast<K*>(fz + 14);
+    K* khi_d = reinterpret_cast<K*>(fz + 15);
+    T* d_vhat = reinterpret_cast<T*>(fz + 16);
+    T* d_delta = reinterpret_cast<T*>(fz + 17);
+    double* d_sums = reinterpret_cast<double*>(fz + 18);
+    K* klo_y = reinterpret_cast<K*>(fz + 24);
+    K* khi_y = reinterpret_cast<K*>(fz + 24 + nbm);
+    uint64_t* given_y = fz + 24 + 2 * nbm;
+    uint64_t* cls_y = fz + 24 + 3 * nbm;
+    uint64_t* res_y = fz + 24 + 6 * nbm;
+    uint64_t* cnt_y = fz + 24 + 8 * nbm;
+    XD_HIP_CHECK(ctx, hipMemsetAsync(fz, 0, P->fz_bytes, ctx->stream));
+    const bool custom = !P->custom_edges.empty();
+    const int last_decimal = custom ? P->custom_decimal : NK_AUTO_EDGES;
+    if (custom) {  // explicit bin edges: SciPy casts them to the sample dtype (rare path: a blocking copy)
+        std::vector<T> e(P->custom_edges.size());
+        for (size_t k = 0; k < e.size(); ++k) e[k] = (T)P->custom_edges[k];
+        XD_HIP_CHECK(ctx, hipMemcpyAsync(d_edges, e.data(), sizeof(T) * e.size(), hipMemcpyHostToDevice, ctx->stream));
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+    }
+    const T* ref_m = static_cast<const T*>(P->ref_m);
+    const T* tba = static_cast<const T*>(P->tba);
+    const T* st_all = static_cast<const T*>(P->slope_tan);
+    // 1. min / max aspect of this step from the EXT lists -> edges, freshness of the bin cache; (re)fill of the cache
+    hipLaunchKernelGGL(nk_stats_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats);
+    XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt + 2, 0, 16, ctx->stream));
+    hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, ref_m, tba, static_cast<const T*>(P->aspect), g,
+                       P->ext_idx, P->ext_cnt, d_stats, P->ext_cnt + 2);
+    hipLaunchKernelGGL((nk_fz_prep_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, nb, (int)custom, d_edges, d_rec,
+                       (int)P->bcache_force, ctr);
+    hipLaunchKernelGGL((nk_bin_fill_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream,
+                       static_cast<const T*>(P->aspect) + q0, n, d_edges, nb, last_decimal, d_rec, P->bcache + q0);
+    hipLaunchKernelGGL((nk_bin_cache_commit_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    P->bcache_force = false;
+    // 2. sample of dh -> bracket of its median, v^, delta
+    T* s_v = static_cast<T*>(ws->s_vals);
+    hipLaunchKernelGGL((nk_sample_dh_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
+                       1.0 / (double)P->W, n_slots, s_v);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    constexpr int BR_PASSES = 3;
+    const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
+    int rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, klo_d, khi_d);
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st + 1, 1, 1, 0, low_mask, klo_d, khi_d);
+    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, klo_d, khi_d, 1, rbs_d);
+    hipLaunchKernelGGL((nk_vhat_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_st, klo_d, khi_d, d_vhat, d_delta, ctr);
+    // 3. sample of y^ per aspect bin -> brackets of the bin medians
+    hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
+                       P->bcache + q0, n, n_slots, d_vhat);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    rc = select_enqueue<T>(ctx, s_v, nb == 1 ? nullptr : ws->s_bins, n_slots, n_slots, nullptr, nb, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES,
+                           false);
+    if (rc) return rc;
+    const int nbb = (nb + 63) / 64;
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, klo_y, khi_y);
+    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st + nb, nb, 1, 0, low_mask, klo_y, khi_y);
+    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, klo_y, khi_y, nb, rbs_y);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    // 4. the one pass
+    {
+        dim3 grid = grid2d(ctx, P->W, rows);
+        if ((rows + grid.y - 1) / grid.y > NK_CHUNK_MAX) grid.y = (unsigned)((rows + NK_CHUNK_MAX - 1) / NK_CHUNK_MAX);
+        int copies = (8 * 1024) / (nb * 12);
+        copies = copies < 1 ? 1 : (copies > 16 ? 16 : copies);
+        const size_t lds = (size_t)nb * sizeof(FzPair<T>) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies;
+        T* cy_d = static_cast<T*>(ws->c_vals);
+#define XD_NK_FZ(RULE)                                                                                                               \
+    hipLaunchKernelGGL((nk_fused_kernel<T, RULE>), grid, dim3(256), lds, ctx->stream, ref_m, tba, st_all, P->bcache, g, P->row0, P->row1,  \
+                       P->nbuf, nb, copies, klo_d, khi_d, d_vhat, d_delta, klo_y, khi_y, cnt_d, cls_y, static_cast<T*>(P->cd_vals),   \
+                       P->cd_cap, cy_d, static_cast<T*>(P->c_st), ws->c_bins, ws->c_cap, ctr, d_sums)
+        if (g.rule == 0) XD_NK_FZ(0);
+        else XD_NK_FZ(1);
+#undef XD_NK_FZ
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
+    // 5. exact median of dh among its candidates -> vshift
+    hipLaunchKernelGGL(bracket_given_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt_d, 1, given_d, ctr);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(P->cd_vals), nullptr, P->cd_cap, n / 32 + 1, ctr + 1, 1, scratch, SEL_GIVEN, given_d, 0, true,
+                           klo_d, rbs_d);
+    if (rc) return rc;
+    hipLaunchKernelGGL((nk_fz_vshift_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, cnt_d, d_st, reinterpret_cast<const uint64_t*>(scratch + off_succ(1)),
+                       klo_d, rbs_d, ctr, scratch + OFF_INFO);
+    // 6. the bin candidates with the exact vshift -> counts, exact medians among those inside the brackets
+    {
+        const size_t lds = (size_t)nb * 2 * sizeof(K) + (size_t)nb * 2 * 4;
+        hipLaunchKernelGGL((nk_resolve_kernel<T>), dim3(grid_for(ctx, n / 16 + 1, HIST_THREADS, 2)), dim3(HIST_THREADS), lds, ctx->stream,
+                           static_cast<T*>(ws->c_vals), static_cast<const T*>(P->c_st), ws->c_bins, ws->c_cap, ctr + 5,
+                           reinterpret_cast<const T*>(scratch + OFF_INFO), nb, klo_y, khi_y, res_y);
+    }
+    hipLaunchKernelGGL(nk_fz_counts_kernel, dim3(nbb), dim3(64), 0, ctx->stream, cls_y, res_y, nb, cnt_y);
+    hipLaunchKernelGGL(bracket_given_kernel, dim3(nbb), dim3(64), 0, ctx->stream, cnt_y, nb, given_y, ctr);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, ws->c_cap, n / 16 + 1, ctr + 5, nb, scratch, SEL_GIVEN, given_y, 0, true,
+                           klo_y, rbs_y);
+    if (rc) return rc;
+    // 7. everything the step hands back, behind one synchronisation
+    std::vector<uint64_t> cnt(3 * (size_t)nb);
+    std::vector<K> klo(nb);
+    std::vector<T> edges(nb + 1);
+    unsigned long long h_ctr[8];
+    uint64_t h_rbs = 0;
+    unsigned char info[32];
+    double sums[5];
+    T h_vhat = (T)0;
+    { const int rc_ = xd_d2h(ctx, cnt.data(), cnt_y, 8 * 3 * (size_t)nb); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, klo.data(), klo_y, sizeof(K) * nb); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, h_ctr, ctr, 64); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, &h_rbs, rbs_y, 8); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, info, scratch + OFF_INFO, 32); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, sums, d_sums, 40); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, &h_vhat, d_vhat, sizeof(T)); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, edges.data(), d_edges, sizeof(T) * (nb + 1)); if (rc_) return rc_; }
+    std::vector<SelResult<K>> hs;
+    rc = select_fetch<T>(ctx, scratch, nb, hs);  // (synchronises the stream)
+    if (rc) return rc;
+    if (h_ctr[2] != 0 || h_ctr[3] != 0) return XDEMHIP_OK;  // overflow / a bracket missed / no extreme-aspect survivor: the two-pass route
+    uint64_t total;
+    double vs;
+    memcpy(&total, info + 8, 8);
+    memcpy(&vs, info + 24, 8);
+    *n_valid = (int64_t)total;
+    if (total == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
+    *vshift = vs;
+    const int rbs = (int)(uint32_t)h_rbs;
+    for (int b = 0; b < nb; ++b) {
+        const uint64_t tot = cnt[b], lt = cnt[nb + b];
+        if (tot == 0) { hs[b].st.count = 0; counts[b] = 0; medians[b] = NAN; continue; }
+        hs[b].st.count = tot;
+        hs[b].st.n_le += lt;
+        hs[b].st.prefix = (K)((K)(hs[b].st.prefix >> rbs) + klo[b]);  // back from the rebased candidate keys
+        if (hs[b].succ != ~(uint64_t)0) hs[b].succ = (uint64_t)(K)((K)((K)hs[b].succ >> rbs) + klo[b]);
+        counts[b] = (int64_t)tot;
+        medians[b] = median_from<T>(hs[b]);
+    }
+    for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges[k];
+    // nanmean / nanstd of y from the sums of y^ and the first-order correction in (v^ - vshift)
+    const double dlt = (double)h_vhat - vs, cntd = (double)total;
+    const double s1 = sums[0] + dlt * sums[2];
+    const double s2 = sums[1] + 2.0 * dlt * sums[3] + dlt * dlt * sums[4];
+    const double mean = s1 / cntd, var = s2 / cntd - mean * mean;
+    *y_mean = mean;
+    *y_std = var > 0 ? sqrt(var) : 0.0;
+    *done = true;
+    return XDEMHIP_OK;
+}
+
 template <typename T>
 int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int nb, double* vshift,
                   int64_t* n_valid, double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians,
@@ -1270,6 +1859,12 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         const bool bottom_ok = P->row1 == P->H || P->roff + P->nbuf - P->row1 >= need;
         if (!top_ok || !bottom_ok)
             return xd_fail(ctx, XDEMHIP_EINVAL, "halo too small: the vertical shift moves the bilinear taps outside this rank's row block + halo");
+    }
+    if (!fit_sums) {   // round 4: one data pass (14 B/pixel) where the plan and the step qualify; anything it cannot prove falls through
+        bool done = false;
+        const int rc1 = nk_step_onepass<T>(P, g, q0, n, nb, &done, vshift, n_valid, y_mean, y_std, edges_out, counts, medians);
+        if (rc1) return rc1;
+        if (done) { ++P->n_onepass; return XDEMHIP_OK; }
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool fused = false;
@@ -1356,6 +1951,7 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         memcpy(&vs, info + 24, 8);
         if (fused && (flags & 4)) P->ext_ok = false;  // no listed extreme-aspect pixel kept a finite dh: this plan reads the aspect again
         if (fused && flags != 0) continue;  // a bracket of the global median missed / overflowed: again on the plain route
+        if (fused) ++P->n_twopass; else ++P->n_plain;
         *n_valid = (int64_t)total;
         if (total == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
         *vshift = vs;
@@ -1475,6 +2071,20 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
             P->ref_m = nullptr; P->ext_idx = nullptr; P->ext_cnt = nullptr;
         }
     }
+    // one-pass step (large single-GPU plans with the EXT buffers): its device block and candidate buffers; without the memory the
+    // plan keeps the two-pass route
+    if (P->ref_m && P->ws.d_small && ctx->nk_fused != 0) {
+        P->fz_bytes = (size_t)(24 + 11 * P->ws.nb_max) * 8;
+        P->cd_cap = (int64_t)n / 8 + 4096;
+        if (hipMalloc(reinterpret_cast<void**>(&P->fz), P->fz_bytes) != hipSuccess || hipMalloc(&P->cd_vals, (size_t)P->cd_cap * es) != hipSuccess ||
+            hipMalloc(&P->c_st, (size_t)P->ws.c_cap * es) != hipSuccess) {
+            (void)hipGetLastError();
+            if (P->fz) (void)hipFree(P->fz);
+            if (P->cd_vals) (void)hipFree(P->cd_vals);
+            if (P->c_st) (void)hipFree(P->c_st);
+            P->fz = nullptr; P->cd_vals = nullptr; P->c_st = nullptr;
+        }
+    }
     const xdemhip_allreduce_fn hook = ctx->allreduce;
     if (!global_count) ctx->allreduce = nullptr;  // whole-raster plan: local pass; xdemhip_nk_set_rows re-partitions with the hook
     int rc = dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
@@ -1493,7 +2103,8 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     if (!P) return;
     (void)hipSetDevice(P->ctx->device);
     if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
-    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt};
+    void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt,
+                    P->fz, P->cd_vals, P->c_st};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     xd::sel_ws_free(P->ws);
@@ -1535,6 +2146,14 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, 
     int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
     if (rc) return rc;
     if (n_valid) *n_valid = P->n_valid0;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_nk_route_counts(xdemhip_nk_plan* P, int64_t* onepass, int64_t* twopass, int64_t* plain) {
+    if (!P) return XDEMHIP_EINVAL;
+    if (onepass) *onepass = P->n_onepass;
+    if (twopass) *twopass = P->n_twopass;
+    if (plain) *plain = P->n_plain;
     return XDEMHIP_OK;
 }
 

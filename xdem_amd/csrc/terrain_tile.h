@@ -209,8 +209,6 @@ struct StripArgs {
     int64_t H, W, stride, halo_top;
     int64_t xi0, yi0, yi1;      // interior: columns from xi0 (groups of 256), rows [yi0, yi1)
     int groups_x, ngroups, grid8, order;
-    int sync_n;             // option "terrain_sync": workgroup barrier every sync_n output rows (the four strips of a group then write
-                            // the same plane rows at about the same time: 1 KiB row pieces instead of four 256-byte ones far apart in time)
     int nbands;             // bands of BH rows (order 3 deals the strip groups of one column band to consecutive workgroups)
     uint32_t perm_mul;      // order 2: workgroup b takes strip group (b * perm_mul) mod (grid8 * 8), perm_mul coprime to that
     int safe_wait;          // option "terrain_ring_wait" = 1: s_waitcnt vmcnt(0) instead of the counted wait (test switch)
@@ -227,14 +225,17 @@ template <int NPL> struct RowsRing {
     const float* gsrc;      // global: first pixel (column x0 - 4) of tile row 0
     float* ring;            // LDS: this wave's ring
     int64_t stride;
-    int nrows, lane;
-    int safe_wait;          // (wave-uniform) drain every VMEM operation instead of counting: the check of the counted form
+    int nrows, lane;        // nrows: bit 30 = option "terrain_ring_wait" (drain every VMEM operation instead of counting: the check of the
+                            // counted form) -- packed into a value that is live anyway: the headline kernel has no scalar register to spare
+                            // (a spilled plane pointer would come back through v_readlane, which the inline-asm stores must not follow)
+    static constexpr int SAFE_BIT = 1 << 30;
+    __device__ __forceinline__ int n_rows() const { return nrows & (SAFE_BIT - 1); }
     __device__ __forceinline__ lds_cfloat_ptr ptr(int t) const { return mine + (t & (RING_ROWS - 1)) * RING_PITCH; }
     __device__ __forceinline__ void issue(int k) const {   // block k = tile rows [16 k, 16 k + 16) -> ring half k & 1
         float* dst = ring + (k & 1) * (RING_BLOCK * RING_PITCH);
         // block base on the scalar unit, per-lane element offsets in 24-bit multiplies (stride < 2^24: launch_stream checks)
         const float* base = gsrc + (int64_t)(RING_BLOCK * k) * stride;
-        const int last = nrows - 1 - RING_BLOCK * k;   // (rows past the band's last: duplicates of it, never read)
+        const int last = n_rows() - 1 - RING_BLOCK * k;   // (rows past the band's last: duplicates of it, never read)
 #pragma unroll
         for (int i = 0; i < (RING_QUADS + 63) / 64; ++i) {
             const int t = 64 * i + lane;
@@ -263,13 +264,13 @@ template <int NPL> struct RowsRing {
     __device__ __forceinline__ void step(int r) const {
         // about to read tile row r + 1, the first of its block: that block was issued ROWS_BETWEEN output rows ago
         if (((r + 1) & (RING_BLOCK - 1)) == 0) {
-            if (safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (nrows & SAFE_BIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_WAIT) : "memory");
         }
         // tile rows below 16 (r >> 4) are dead from here on (the oldest row any path still reads is r - 4): refill their half
         if ((r & (RING_BLOCK - 1)) == REFILL_AT && r >= RING_BLOCK + REFILL_AT) {
             const int k = (r >> 4) + 1;
-            if (RING_BLOCK * k < nrows) issue(k);
+            if (RING_BLOCK * k < n_rows()) issue(k);
         }
     }
 };
@@ -298,11 +299,10 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     rows.mine = (lds_cfloat_ptr)(rows.ring + 4 + lane);
     rows.gsrc = a.dem + (y0 - HALO + a.halo_top) * a.stride + (x0 - 4);
     rows.stride = a.stride;
-    rows.nrows = n_out + 2 * HALO;
+    rows.nrows = (n_out + 2 * HALO) | (a.safe_wait ? RowsRing<NPL>::SAFE_BIT : 0);
     rows.lane = lane;
-    rows.safe_wait = a.safe_wait;
     rows.issue(0);
-    if (RING_BLOCK < rows.nrows) {
+    if (RING_BLOCK < rows.n_rows()) {
         rows.issue(1);
         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // block 0 landed, the 5 loads of block 1 in flight
     } else {
@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     for (int k = 0; k < N_ATTR; ++k) sk.org.p[k] = a.out.p[k] + org_off;
     sk.o0 = (uint32_t)(lane * sizeof(float));
     sk.ostride = (uint32_t)(a.W * sizeof(float));
-    sk.sync_n = (uint32_t)a.sync_n;   // (legal: the four waves of a group march the same number of rows)
+#if defined(XD_STRIP_SYNC)   // (measurement builds: workgroup barrier every XD_STRIP_SYNC output rows -- the four strips of a group then write
+    sk.sync_n = XD_STRIP_SYNC;   // the same plane rows at about the same time; legal: the four waves march the same number of rows)
+#endif
     march_rows<FIT, CURV, WIN, SP, float, DirectSink<float, false>, RowsRing<NPL>>(rows, n_out, a.P, sk);
 }
 
@@ -601,7 +603,6 @@ static int launch_stream(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
     a.ngroups = (int)(bands * a.groups_x);
     a.grid8 = (a.ngroups + 7) / 8;
     a.nbands = (int)bands;
-    a.sync_n = ctx->terrain_sync;
     a.safe_wait = ctx->terrain_ring_wait;
     {   // multiplier of order 2: near the golden section of the grid, coprime to it
         const uint32_t n = (uint32_t)a.grid8 * 8u;
