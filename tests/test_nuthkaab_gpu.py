@@ -12,8 +12,6 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-
 def _moments_close(a, b, onepass=True):
     """nanmean / nanstd of y.  They only seed the 72-point curve fit (p0, xdem/coreg/affine.py:386) and the reference itself
     forms them in float32 (np.nanmean / np.nanstd of a float32 array: pairwise float32 sums, ~1e-7 of the spread).  The two-pass
@@ -24,6 +22,8 @@ def _moments_close(a, b, onepass=True):
     return abs(a["y_mean"] - b["y_mean"]) <= tol and abs(a["y_std"] - b["y_std"]) <= tol
 
 
+
+@pytest.fixture(scope="module")
 def coreg():
     from xdem_amd import coreg as c
 

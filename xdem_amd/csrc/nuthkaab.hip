@@ -1038,6 +1038,7 @@ constexpr int NKZ_ROWS = 2;      // rows between two looks at the staging buffer
 template <typename T> struct NkzCap { static constexpr int v = sizeof(T) == 4 ? 2048 : 1024; };
 template <typename T> struct FzPair { T lo, hi; };
 
+constexpr int NKZ_CHUNK_MAX = 256;   // rows of a workgroup's chunk (row-tap table in LDS)
 template <typename T, int RULE>
 __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
                                                        const uint16_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
@@ -1051,13 +1052,16 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                                                        double* sums /* [5] */) {
     typedef typename KeyT<T>::type K;
     constexpr int NKZ_CAP = NkzCap<T>::v;
-    static_assert(NKZ_CAP >= 2 * NKZ_ROWS * 256, "a flush check must leave room for NKZ_ROWS rows of candidates");
-    __shared__ NkRowTab tab[NK_CHUNK_MAX + 1];
+    constexpr int SEG = NKZ_CAP / 4;      // staging slots of ONE wave: waves reserve in their own segment with a scalar counter --
+                                          // no LDS atomic with return and its round trip on the path of every row (bin candidates are
+                                          // ~7 % of the pixels: practically every row of every wave holds some)
+    static_assert(SEG >= 2 * NKZ_ROWS * 64, "a flush check must leave room for NKZ_ROWS rows of candidates");
+    __shared__ NkRowTab tab[NKZ_CHUNK_MAX + 1];
     __shared__ T stage_d[NKZ_CAP];
     __shared__ T sy_d[NKZ_CAP];
     __shared__ T sy_st[NKZ_CAP];
     __shared__ uint16_t sy_b[NKZ_CAP];
-    __shared__ int s_held[2];
+    __shared__ int s_cnt[2][4];
     __shared__ unsigned long long s_base[2];
     __shared__ unsigned long long s_red[4][3];
     __shared__ double s_sum[4][5];
@@ -1065,17 +1069,17 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
     FzPair<T>* lohi = reinterpret_cast<FzPair<T>*>(fz_smem);                       // [nb] bin brackets as values
     uint32_t* c = reinterpret_cast<uint32_t*>(lohi + nb);                          // [copies][cs]: 3 counters per bin
     const int cs = (3 * nb) | 1;  // odd copy stride: the copies of one counter fall into different LDS banks
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 2) s_held[threadIdx.x] = 0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (int k = threadIdx.x; k < nb; k += blockDim.x) { lohi[k].lo = val_of(klo_y[k]); lohi[k].hi = val_of(khi_y[k]); }
     for (int k = threadIdx.x; k < cs * copies; k += blockDim.x) c[k] = 0;
     const K klo = *klo_p, khi = *khi_p;
     const T vhat = *vhat_p;
     const T dgrow = (T)(*delta_p * FzEps<T>::grow);
-    const int64_t chunk = (row1 - row0 + gridDim.y - 1) / gridDim.y;  // <= NK_CHUNK_MAX (launcher)
+    const int64_t chunk = (row1 - row0 + gridDim.y - 1) / gridDim.y;  // <= NKZ_CHUNK_MAX (launcher)
     const int64_t i0 = row0 + (int64_t)blockIdx.y * chunk;
     const int nrow = (int)((i0 + chunk < row1 ? i0 + chunk : row1) - i0);
-    for (int r = threadIdx.x; r <= nrow && r <= NK_CHUNK_MAX; r += blockDim.x) {
+    for (int r = threadIdx.x; r <= nrow && r <= NKZ_CHUNK_MAX; r += blockDim.x) {
         const BiAxis a = bi_axis(i0 + (r < nrow ? r : nrow - 1), g.dr, g.H, RULE);
         int64_t kl = a.k0 - g.roff;
         kl = (a.in && kl >= 0 && kl + a.d1 < nbuf) ? kl : 0;
@@ -1085,7 +1089,7 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
     }
     __syncthreads();
     if (nrow <= 0) return;  // (uniform over the workgroup)
-    uint32_t* cc = c + (threadIdx.x % copies) * cs;
+    uint32_t* cc = c + ((threadIdx.x * 7u) % (unsigned)copies) * cs;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool jin = j < g.W;
     const BiAxis col = bi_axis(j, g.dc, g.W, RULE);
@@ -1098,33 +1102,51 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
         return t_add(v0, t_mul(fc, t_sub(v1, v0)));
     };
     uint32_t n_all = 0, n_below = 0, n_in = 0;  // wave-uniform
-    // staging: [0] candidates of the median of dh (values), [1] candidates of the bin medians (dh, slope_tan, bin)
+    int held_d = 0, held_y = 0;                  // wave-uniform: candidates staged in this wave's segments
+    T* const seg_d = stage_d + wave * SEG;
+    T* const seg_yd = sy_d + wave * SEG;
+    T* const seg_ys = sy_st + wave * SEG;
+    uint16_t* const seg_yb = sy_b + wave * SEG;
+    // staging: [0] candidates of the median of dh (values), [1] candidates of the bin medians (dh, slope_tan, bin); a look at the
+    // buffers every NKZ_ROWS rows (one barrier), a flush -- one global atomic per kind and workgroup -- when some wave's segment
+    // could not take NKZ_ROWS more rows
     auto block_flush = [&](int threshold) {  // every thread of the workgroup
+        if (lane == 0) { s_cnt[0][wave] = held_d; s_cnt[1][wave] = held_y; }
         __syncthreads();
-        const int h0 = s_held[0], h1 = s_held[1];
-        const bool f0 = h0 > threshold, f1 = h1 > threshold;
+        int n0[4], n1[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { n0[w] = s_cnt[0][w]; n1[w] = s_cnt[1][w]; }
+        const int m0 = max(max(n0[0], n0[1]), max(n0[2], n0[3])), m1 = max(max(n1[0], n1[1]), max(n1[2], n1[3]));
+        const bool f0 = m0 > threshold, f1 = m1 > threshold;
         if (f0 || f1) {   // (uniform)
-            if (threadIdx.x == 0 && f0) s_base[0] = atomicAdd(&ctr[1], (unsigned long long)h0);
-            if (threadIdx.x == 64 && f1) s_base[1] = atomicAdd(&ctr[5], (unsigned long long)h1);
+            if (threadIdx.x == 0 && f0) s_base[0] = atomicAdd(&ctr[1], (unsigned long long)(n0[0] + n0[1] + n0[2] + n0[3]));
+            if (threadIdx.x == 64 && f1) s_base[1] = atomicAdd(&ctr[5], (unsigned long long)(n1[0] + n1[1] + n1[2] + n1[3]));
             __syncthreads();
             if (f0) {
-                const unsigned long long b0 = s_base[0];
-                for (int k = threadIdx.x; k < h0; k += blockDim.x) {
-                    if ((int64_t)(b0 + k) < cd_cap) cd_vals[b0 + k] = stage_d[k];
-                    else ctr[2] = 1ull;
+                unsigned long long b0 = s_base[0];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    for (int k = threadIdx.x; k < n0[w]; k += blockDim.x) {
+                        if ((int64_t)(b0 + k) < cd_cap) cd_vals[b0 + k] = stage_d[w * SEG + k];
+                        else ctr[2] = 1ull;
+                    }
+                    b0 += (unsigned long long)n0[w];
                 }
+                held_d = 0;
             }
             if (f1) {
-                const unsigned long long b1 = s_base[1];
-                for (int k = threadIdx.x; k < h1; k += blockDim.x) {
-                    if ((int64_t)(b1 + k) < cy_cap) { cy_d[b1 + k] = sy_d[k]; cy_st[b1 + k] = sy_st[k]; cy_b[b1 + k] = sy_b[k]; }
-                    else ctr[2] = 1ull;
+                unsigned long long b1 = s_base[1];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    for (int k = threadIdx.x; k < n1[w]; k += blockDim.x) {
+                        if ((int64_t)(b1 + k) < cy_cap) { cy_d[b1 + k] = sy_d[w * SEG + k]; cy_st[b1 + k] = sy_st[w * SEG + k]; cy_b[b1 + k] = sy_b[w * SEG + k]; }
+                        else ctr[2] = 1ull;
+                    }
+                    b1 += (unsigned long long)n1[w];
                 }
+                held_y = 0;
             }
-            __syncthreads();
-            if (threadIdx.x == 0 && f0) s_held[0] = 0;
-            if (threadIdx.x == 64 && f1) s_held[1] = 0;
-            __syncthreads();
+            __syncthreads();   // (the segments are free again; s_cnt is rewritten only after every thread has read it)
         }
     };
     int have = -1;
@@ -1132,15 +1154,22 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
     struct Pre { T b0, b1, rv, st; uint16_t bin; };
     Pre pre[NK_PF];
     const int64_t rb0 = (i0 - g.roff) * g.W;
-    auto issue = [&](int rr, Pre& q) {  // rr clamped: entry `nrow` of the table repeats the last row
+    // per-lane row pointers of the three rasters indexed by the output pixel, advanced by one raster row per issue (the row-tap
+    // table gives the tba row of every output row; the others walk down the chunk)
+    const T* p_ref = ref + rb0 + jl;
+    const T* p_st = slope_tan + rb0 + jl;
+    const uint16_t* p_bin = bcache + rb0 + jl;
+    int issued = 0;   // rows issued so far (uniform)
+    auto issue = [&](int rr, Pre& q) {  // called with rr = 0, 1, 2, ... in order; rows past the chunk repeat its last row
         const int rc = rr < nrow ? rr : nrow - 1;
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
         const T* rowp = tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W;
-        const int64_t rb = rb0 + (int64_t)rc * g.W;
         q.b0 = __builtin_nontemporal_load(rowp + c0); q.b1 = __builtin_nontemporal_load(rowp + c1);
-        q.rv = __builtin_nontemporal_load(ref + rb + jl);
-        q.st = __builtin_nontemporal_load(slope_tan + rb + jl);
-        q.bin = __builtin_nontemporal_load(bcache + rb + jl);
+        q.rv = __builtin_nontemporal_load(p_ref);
+        q.st = __builtin_nontemporal_load(p_st);
+        q.bin = __builtin_nontemporal_load(p_bin);
+        if (issued + 1 < nrow) { p_ref += g.W; p_st += g.W; p_bin += g.W; }
+        ++issued;
     };
     // sums of y^ and of the correction terms: float32 partial sums (y^, y^ y^ folded into float64 every NK_PF rows; the three
     // correction sums scale a term ~1e-3 of the total and stay float32 over the chunk)
@@ -1173,17 +1202,16 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                 const T out = t_sub(rv, val);
                 const bool ok = ((fl & 1) != 0) & cin & t_finite(out);
                 const K key = key_of(out);
-                const bool below = ok & (key < klo);
-                const bool cand = ok & (key >= klo) & (key <= khi);
-                n_all += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
-                n_below += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(below));
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
-                if (mask) {
+                const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok);
+                const unsigned long long m_below = __builtin_amdgcn_ballot_w64(ok & (key < klo));
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok & (key >= klo) & (key <= khi));
+                n_all += (uint32_t)__popcll(m_ok);
+                n_below += (uint32_t)__popcll(m_below);
+                if (mask) {   // (uniform)
+                    if ((mask >> lane) & 1ull)
+                        seg_d[held_d + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = out;
                     const int cn = __popcll(mask);
-                    int pos0 = 0;
-                    if (lane == 0) pos0 = atomicAdd(&s_held[0], cn);
-                    pos0 = __builtin_amdgcn_readfirstlane(pos0);
-                    if (cand) stage_d[pos0 + __popcll(mask & ((1ull << lane) - 1ull))] = out;
+                    held_d += cn;
                     n_in += (uint32_t)cn;
                 }
                 // ---- the bin side: y^ with its margin against the bracket of the pixel's aspect bin
@@ -1192,27 +1220,22 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                 const T m = (T)(dgrow * rr) + (T)(fabs(yh) * FzEps<T>::rel) + FzEps<T>::tiny;
                 const bool yb = ok & (bin != (uint16_t)0xFFFF) & (yh == yh);
                 const FzPair<T> lh = lohi[yb ? bin : 0];
-                const bool isb = yb & ((T)(yh + m) < lh.lo);
-                const bool isa = yb & ((T)(yh - m) > lh.hi);
-                const bool cy = yb & !isb & !isa;
-                if (yb) atomicAdd(&cc[__umul24((unsigned)(isb ? 1 : (cy ? 2 : 0)), (unsigned)nb) + bin], 1u);
-                const unsigned long long my = __builtin_amdgcn_ballot_w64(cy);
-                if (my) {
-                    const int cn = __popcll(my);
-                    int pos0 = 0;
-                    if (lane == 0) pos0 = atomicAdd(&s_held[1], cn);
-                    pos0 = __builtin_amdgcn_readfirstlane(pos0);
-                    if (cy) {
-                        const int pos = pos0 + __popcll(my & ((1ull << lane) - 1ull));
-                        sy_d[pos] = out; sy_st[pos] = stv; sy_b[pos] = bin;
+                const bool nb_ = !((T)(yh + m) < lh.lo), na_ = !((T)(yh - m) > lh.hi);   // not certainly below / not certainly above
+                if (yb) atomicAdd(&cc[__umul24((unsigned)(nb_ ? (na_ ? 2 : 0) : 1), (unsigned)nb) + bin], 1u);
+                const unsigned long long my = __builtin_amdgcn_ballot_w64(yb & nb_ & na_);
+                if (my) {   // (uniform)
+                    if ((my >> lane) & 1ull) {
+                        const int pos = held_y + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(my >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)my, 0u));
+                        seg_yd[pos] = out; seg_ys[pos] = stv; seg_yb[pos] = bin;
                     }
+                    held_y += __popcll(my);
                 }
                 const float yf = ok ? (float)yh : 0.0f, rf = ok ? (float)rr : 0.0f;
                 p_y += yf; p_yy = fmaf(yf, yf, p_yy);
                 p_r += rf; p_yr = fmaf(yf, rf, p_yr); p_rr = fmaf(rf, rf, p_rr);
             }
             // (r is uniform over the workgroup: every wave walks the same rows) room for NKZ_ROWS more rows must remain
-            if (((r + 1) % NKZ_ROWS) == 0 && r + 1 < nrow) block_flush(NKZ_CAP - 2 * NKZ_ROWS * 256);
+            if (((r + 1) % NKZ_ROWS) == 0 && r + 1 < nrow) block_flush(SEG - 2 * NKZ_ROWS * 64);
         }
         a_y += (double)p_y; a_yy += (double)p_yy;
         p_y = 0.0f; p_yy = 0.0f;
@@ -1740,8 +1763,8 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     // 4. the one pass
     {
         dim3 grid = grid2d(ctx, P->W, rows);
-        if ((rows + grid.y - 1) / grid.y > NK_CHUNK_MAX) grid.y = (unsigned)((rows + NK_CHUNK_MAX - 1) / NK_CHUNK_MAX);
-        int copies = (8 * 1024) / (nb * 12);
+        if ((rows + grid.y - 1) / grid.y > NKZ_CHUNK_MAX) grid.y = (unsigned)((rows + NKZ_CHUNK_MAX - 1) / NKZ_CHUNK_MAX);
+        int copies = (6 * 1024) / (nb * 12);
         copies = copies < 1 ? 1 : (copies > 16 ? 16 : copies);
         const size_t lds = (size_t)nb * sizeof(FzPair<T>) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies;
         T* cy_d = static_cast<T*>(ws->c_vals);

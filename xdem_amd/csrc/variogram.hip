@@ -190,6 +190,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     // GRID: class of a cell's lower bound and the one threshold above it fused into one 8-byte entry (one LDS read per pair
     // instead of a byte read and a dependent threshold read -- the Matheron pass is bound by the LDS array)
     __shared__ uint2 s_lut2[GRID ? LUT_G : 1];
+    // sums on the lattice (round 4): {class of the cell's lower bound c, threshold c, threshold c - 1 (0 for c = 0), threshold c + 1}: the
+    // class of a d^2 AND the d^2 interval of that class from one 16-byte read (see the run-length loop)
+    __shared__ uint4 s_lut4[(GRID && (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)) ? LUT_G : 1];
     const int tid = threadIdx.x;
     if (FAST)  // (NT may be smaller than the table: round 1 loaded only its first NT entries -- wrong classes beyond 32 binades of d^2)
         for (int k = tid; k < (GRID ? LUT_G : LUT_N); k += NT) s_lut[k] = GRID ? a.lut_i[k] : a.lut[k];
@@ -199,6 +202,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         for (int k = tid; k < LUT_G; k += NT) {
             const uint32_t c = a.lut_i[k];
             s_lut2[k] = make_uint2(c, c < (uint32_t)a.nb ? a.thr_i[c] : 0xFFFFFFFFu);
+            if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
+                s_lut4[k] = make_uint4(c, c < (uint32_t)a.nb ? a.thr_i[c] : 0xFFFFFFFFu, (c > 0 && c - 1 < (uint32_t)a.nb) ? a.thr_i[c - 1] : (c > 0 ? 0xFFFFFFFFu : 0u),
+                                       c + 1 < (uint32_t)a.nb ? a.thr_i[c + 1] : 0xFFFFFFFFu);
         }
     }
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
@@ -237,7 +243,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     const K himask = (OP == OP_HIST && !a.first) ? (K)(~(K)0 << (a.shift + 8)) : (K)0;
     int run_l = a.nb;          // spare class: flushing the empty initial run adds (0, 0) to the record nobody reads
     double run_s = 0.0;
-    uint32_t run_c = 0;
+    uint32_t run_start = 0;    // position (count of plain-tile pairs so far, the same for every lane) at which the lane's run began
+    uint32_t run_pos = 0;      // ... and the current position: a run's length is their difference, no per-pair counter
+    uint32_t run_lo = 1u, run_w = 0u;   // GRID: d^2 interval of the run's class (empty: the first pair looks its class up)
     // One workgroup = one (A tile x B chunk) unit, except in the SAMPLED digit passes: there a unit is 16 tile loads and 16 k pairs,
     // while zeroing and flushing the [classes][256] LDS tables costs ~25 k LDS writes and thousands of global atomics -- a
     // resident set of workgroups therefore walks over all units (grid-stride) and flushes once.
@@ -509,6 +517,45 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     const bool plain_tile = (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && cnt == PT && !a.has_nan &&
                                             (!a.pdist || j0 >= (ta + 1) * (int64_t)NT);
                     if (plain_tile) {
+                        if constexpr (GRID) {
+                            // Round 4: no class lookup per pair.  A lane keeps the d^2 interval [run_lo, run_lo + run_w) of the lag class
+                            // its run is in (integer thresholds: exact pre-images of the float64 edges) -- a pair that stays in the
+                            // class costs one subtract and one unsigned compare instead of the table lookup (convert, cell, table
+                            // read, threshold compare, class compare: 9 vector instructions); only a pair that LEAVES the class
+                            // -- 5 % of the pairs of a lane, a third of the wave-pairs on SURVEY 8d's C5 geometry -- looks its
+                            // class up, flushes the run (the run's length is the distance of its positions: no counter per pair)
+                            // and loads the new bounds.
+                            for (int j = 0; j < PT; j += 4) {
+                                uint32_t d2[4];
+                                T dv[4];
+    #pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                                    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
+                                    dv[u] = pv - s_bv[j + u];
+                                }
+    #pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    if (!((uint32_t)(d2[u] - run_lo) < run_w)) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
+                                        const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
+                                        const uint4 e = s_lut4[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
+                                        const bool up = e.y <= d2[u];   // the cell's one threshold lies at or below d^2: the class above it
+                                        const int off = (int)__umul24((unsigned)run_l, (unsigned)REC);
+                                        atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
+                                        atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_pos - run_start);
+                                        run_l = (int)e.x + (up ? 1 : 0);
+                                        run_s = 0.0;
+                                        run_start = run_pos;
+                                        run_lo = up ? e.y : e.z;
+                                        run_w = (up ? e.w : e.y) - run_lo;   // (beyond the last edge: thresholds padded with all ones)
+                                    }
+                                    const double dd = (double)dv[u];
+                                    run_s = OP == OP_SUMS_SQ ? __builtin_fma(dd, dd, run_s) : run_s + sqrt(fabs(dd));
+                                    run_pos += 1;   // (uniform: a scalar counter)
+                                }
+                            }
+                            continue;
+                        }
                         for (int j = 0; j < PT; j += 4) {
                             int lu[4];
                             T dv[4];
@@ -520,13 +567,13 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 if (lu[u] != run_l) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
                                     const int off = run_l * REC;
                                     atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
-                                    atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_c);
+                                    atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_pos - run_start);
                                     run_l = lu[u];
                                     run_s = 0.0;
-                                    run_c = 0;
+                                    run_start = run_pos;
                                 }
                                 run_s = OP == OP_SUMS_SQ ? __builtin_fma(dd, dd, run_s) : run_s + sqrt(fabs(dd));
-                                run_c += 1;
+                                run_pos += 1;
                             }
                         }
                         continue;
@@ -648,10 +695,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 }
             }
     }
-    if ((OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && run_c) {   // the open run of every lane
+    if ((OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) && run_pos != run_start) {   // the open run of every lane
         const int off = run_l * REC;
         atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
-        atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_c);
+        atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_pos - run_start);
     }
     __syncthreads();
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) {
