@@ -739,14 +739,17 @@ def test_bench_C3_pair_at_full_size_routes_agree():
         ctx.close()
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused,n_bins", [(1, 8), (0, 72)])
 @pytest.mark.parametrize("dtype,rule", [(np.float32, 0), (np.float32, 1), (np.float64, 0)])
-def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused):
+def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused, n_bins):
     """The queued route (lean dh / bin kernels, bracketed selections, aspect-bin cache) only runs from 2^22 pixels on: a
     2100 x 2050 pair, selection mode 3 (bracketed route for the 72 bins whatever their sample size), against the oracle for
     shifts that exercise the row-tap table and the carried lerps -- zero, integer, negative, beyond one pixel, a hair below an
     integer (pos = i + dr rounds to the next tap row for large i) -- repeated so that the aspect-bin cache is both filled and
-    reused.  Vertical shift, valid count, edges, per-bin counts and medians bit-exact."""
+    reused.  Vertical shift, valid count, edges, per-bin counts and medians bit-exact.
+    Round 4: the one-pass step (option "nk_fused" = 1) on the same pair with 8 aspect bins -- at 4.3 M pixels a 1/64 sample gives
+    72 bins ~900 values each, brackets that hold most of a bin, more candidates than the buffers take (the step then falls
+    through to the two passes, which is what the 72-bin case runs); 8 bins bracket tightly enough for the route to answer."""
     from xdem_amd.synth import fbm_numpy
 
     ctx = coreg._lib.default_context()
@@ -768,7 +771,7 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused):
         if dtype == np.float64:
             asp = plan.aux()[1]
         for sx, sy in ((0.0, 0.0), (res * 2.0, -res * 1.0), (3.3, -7.1), (-13.7, 21.3), (0.0, -res * 0.9999999999999999), (3.3, -7.1)):
-            det = plan.step(sx, sy, (res, res), 72)
+            det = plan.step(sx, sy, (res, res), n_bins)
             dh = nko.shifted_dh(ref, tba, sx, sy, (res, res), nan_rule=rule)[valid]
             ok = np.isfinite(dh)
             vshift = np.nanmedian(dh)
@@ -776,7 +779,7 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused):
             assert det["vshift"] == float(vshift), (sx, sy)
             with np.errstate(all="ignore"):
                 y = (dh - vshift)[ok] / st[valid][ok]
-            edges, counts, med = nko.bin_medians(asp[valid][ok], y, 72)
+            edges, counts, med = nko.bin_medians(asp[valid][ok], y, n_bins)
             assert np.array_equal(det["counts"], counts), (sx, sy)
             assert np.array_equal(det["edges"], edges.astype(np.float64)), (sx, sy)
             assert np.array_equal(det["medians"], med, equal_nan=True), (sx, sy)

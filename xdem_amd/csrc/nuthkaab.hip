@@ -930,6 +930,25 @@ template <typename T> __host__ __device__ inline void make_edges_into(double smi
     for (int k = 0; k <= nb; ++k) e[k] = (T)((double)k * step + smin);
     e[nb] = (T)smax;
 }
+// Lane masks as 64-bit scalars: compares that deliver the mask itself (a C++ `bool` that also feeds a ballot is legalised into a
+// 0/1 register and compared again), and selects that take such a mask as their condition
+__device__ __forceinline__ unsigned long long cm_nlt(float a, float b) { unsigned long long m; asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ unsigned long long cm_ngt(float a, float b) { unsigned long long m; asm("v_cmp_ngt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ unsigned long long cm_nlt(double a, double b) { unsigned long long m; asm("v_cmp_nlt_f64_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ unsigned long long cm_ngt(double a, double b) { unsigned long long m; asm("v_cmp_ngt_f64_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ uint32_t sel_mask(uint32_t a, uint32_t b, unsigned long long mask) {   // lane's mask bit ? b : a
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ float sel_mask(float a, float b, unsigned long long mask) { return __uint_as_float(sel_mask(__float_as_uint(a), __float_as_uint(b), mask)); }
+__device__ __forceinline__ int sel_mask(int a, int b, unsigned long long mask) { return (int)sel_mask((uint32_t)a, (uint32_t)b, mask); }
+__device__ __forceinline__ uint32_t* sel_mask_ptr(uint32_t* a, uint32_t* b, unsigned long long mask) {   // LDS pointers: 32-bit addresses
+    typedef __attribute__((address_space(3))) uint32_t* lp;
+    const uint32_t r = sel_mask((uint32_t)(uintptr_t)(lp)a, (uint32_t)(uintptr_t)(lp)b, mask);
+    return (uint32_t*)(lp)(uintptr_t)r;
+}
+
 template <typename T> struct FzEps;   // relative slack that covers the roundings of y^ (fast reciprocal) and of y itself
 template <> struct FzEps<float> { static constexpr float rel = 4e-6f, grow = 1.00002f, tiny = 1e-37f; };
 template <> struct FzEps<double> { static constexpr double rel = 1e-14, grow = 1.0000000001, tiny = 1e-300; };
@@ -1057,10 +1076,10 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                                           // ~7 % of the pixels: practically every row of every wave holds some)
     static_assert(SEG >= 2 * NKZ_ROWS * 64, "a flush check must leave room for NKZ_ROWS rows of candidates");
     __shared__ NkRowTab tab[NKZ_CHUNK_MAX + 1];
-    __shared__ T stage_d[NKZ_CAP];
-    __shared__ T sy_d[NKZ_CAP];
-    __shared__ T sy_st[NKZ_CAP];
-    __shared__ uint16_t sy_b[NKZ_CAP];
+    __shared__ T stage_d[NKZ_CAP + 4];       // (+ one slot per wave that nobody reads: lanes without a candidate write there, so the
+    __shared__ T sy_d[NKZ_CAP + 4];          //  staging stores need no exec mask)
+    __shared__ T sy_st[NKZ_CAP + 4];
+    __shared__ uint16_t sy_b[NKZ_CAP + 4];
     __shared__ int s_cnt[2][4];
     __shared__ unsigned long long s_base[2];
     __shared__ unsigned long long s_red[4][3];
@@ -1078,7 +1097,9 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
     const T dgrow = (T)(*delta_p * FzEps<T>::grow);
     const int64_t chunk = (row1 - row0 + gridDim.y - 1) / gridDim.y;  // <= NKZ_CHUNK_MAX (launcher)
     const int64_t i0 = row0 + (int64_t)blockIdx.y * chunk;
-    const int nrow = (int)((i0 + chunk < row1 ? i0 + chunk : row1) - i0);
+    // (readfirstlane: the row count and everything derived from it -- loop counters, candidate counters, flush decisions -- are
+    // wave-uniform and belong on the scalar unit; the compiler does not see that through the 64-bit arithmetic above)
+    const int nrow = __builtin_amdgcn_readfirstlane((int)((i0 + chunk < row1 ? i0 + chunk : row1) - i0));
     for (int r = threadIdx.x; r <= nrow && r <= NKZ_CHUNK_MAX; r += blockDim.x) {
         const BiAxis a = bi_axis(i0 + (r < nrow ? r : nrow - 1), g.dr, g.H, RULE);
         int64_t kl = a.k0 - g.roff;
@@ -1089,24 +1110,32 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
     }
     __syncthreads();
     if (nrow <= 0) return;  // (uniform over the workgroup)
-    uint32_t* cc = c + ((threadIdx.x * 7u) % (unsigned)copies) * cs;
+    uint32_t* cc = c + (threadIdx.x % (unsigned)copies) * cs;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool jin = j < g.W;
     const BiAxis col = bi_axis(j, g.dc, g.W, RULE);
     const bool cin = col.in & jin;
-    const uint32_t c0 = cin ? (uint32_t)col.k0 : 0u, c1 = c0 + (cin ? (uint32_t)col.d1 : 0u);
+    const unsigned long long m_cin = __builtin_amdgcn_ballot_w64(cin);
+    // byte offsets of this lane's columns: 32-bit, added to uniform row pointers by the load instruction itself (a chunk spans
+    // at most NKZ_CHUNK_MAX rows: (NKZ_CHUNK_MAX + 1) * W * 4 < 2^32 is the launcher's condition for this route)
+    const uint32_t c0b = (cin ? (uint32_t)col.k0 : 0u) * (uint32_t)sizeof(T);
+    const uint32_t c1b = c0b + (cin ? (uint32_t)col.d1 : 0u) * (uint32_t)sizeof(T);
     const uint32_t jl = jin ? (uint32_t)j : 0u;
+    const uint32_t wb = (uint32_t)g.W;
     const double fc = col.f;
     auto hlerp = [&](T a, T b) -> double {
         const double v0 = a, v1 = b;
         return t_add(v0, t_mul(fc, t_sub(v1, v0)));
     };
+    auto at = [](const void* base, uint32_t byte_off) { return reinterpret_cast<const char*>(base) + byte_off; };
     uint32_t n_all = 0, n_below = 0, n_in = 0;  // wave-uniform
     int held_d = 0, held_y = 0;                  // wave-uniform: candidates staged in this wave's segments
     T* const seg_d = stage_d + wave * SEG;
     T* const seg_yd = sy_d + wave * SEG;
     T* const seg_ys = sy_st + wave * SEG;
     uint16_t* const seg_yb = sy_b + wave * SEG;
+    const int trash = NKZ_CAP + wave - wave * SEG;       // index of this wave's unread slot, relative to its segment
+    uint32_t* const dummy = c + cs * copies + lane;      // 64 words behind the counters: where "add 0" goes
     // staging: [0] candidates of the median of dh (values), [1] candidates of the bin medians (dh, slope_tan, bin); a look at the
     // buffers every NKZ_ROWS rows (one barrier), a flush -- one global atomic per kind and workgroup -- when some wave's segment
     // could not take NKZ_ROWS more rows
@@ -1115,7 +1144,7 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
         __syncthreads();
         int n0[4], n1[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { n0[w] = s_cnt[0][w]; n1[w] = s_cnt[1][w]; }
+        for (int w = 0; w < 4; ++w) { n0[w] = __builtin_amdgcn_readfirstlane(s_cnt[0][w]); n1[w] = __builtin_amdgcn_readfirstlane(s_cnt[1][w]); }
         const int m0 = max(max(n0[0], n0[1]), max(n0[2], n0[3])), m1 = max(max(n1[0], n1[1]), max(n1[2], n1[3]));
         const bool f0 = m0 > threshold, f1 = m1 > threshold;
         if (f0 || f1) {   // (uniform)
@@ -1124,25 +1153,27 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
             __syncthreads();
             if (f0) {
                 unsigned long long b0 = s_base[0];
-#pragma unroll
+#pragma unroll 1
                 for (int w = 0; w < 4; ++w) {
-                    for (int k = threadIdx.x; k < n0[w]; k += blockDim.x) {
+                    const int nw = __builtin_amdgcn_readfirstlane(s_cnt[0][w]);
+                    for (int k = threadIdx.x; k < nw; k += blockDim.x) {
                         if ((int64_t)(b0 + k) < cd_cap) cd_vals[b0 + k] = stage_d[w * SEG + k];
                         else ctr[2] = 1ull;
                     }
-                    b0 += (unsigned long long)n0[w];
+                    b0 += (unsigned long long)nw;
                 }
                 held_d = 0;
             }
             if (f1) {
                 unsigned long long b1 = s_base[1];
-#pragma unroll
+#pragma unroll 1
                 for (int w = 0; w < 4; ++w) {
-                    for (int k = threadIdx.x; k < n1[w]; k += blockDim.x) {
+                    const int nw = __builtin_amdgcn_readfirstlane(s_cnt[1][w]);
+                    for (int k = threadIdx.x; k < nw; k += blockDim.x) {
                         if ((int64_t)(b1 + k) < cy_cap) { cy_d[b1 + k] = sy_d[w * SEG + k]; cy_st[b1 + k] = sy_st[w * SEG + k]; cy_b[b1 + k] = sy_b[w * SEG + k]; }
                         else ctr[2] = 1ull;
                     }
-                    b1 += (unsigned long long)n1[w];
+                    b1 += (unsigned long long)nw;
                 }
                 held_y = 0;
             }
@@ -1154,21 +1185,22 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
     struct Pre { T b0, b1, rv, st; uint16_t bin; };
     Pre pre[NK_PF];
     const int64_t rb0 = (i0 - g.roff) * g.W;
-    // per-lane row pointers of the three rasters indexed by the output pixel, advanced by one raster row per issue (the row-tap
-    // table gives the tba row of every output row; the others walk down the chunk)
-    const T* p_ref = ref + rb0 + jl;
-    const T* p_st = slope_tan + rb0 + jl;
-    const uint16_t* p_bin = bcache + rb0 + jl;
-    int issued = 0;   // rows issued so far (uniform)
+    // uniform chunk bases of the three rasters indexed by the output pixel + one 32-bit per-lane element offset walking down the chunk
+    const T* const ref_c = ref + rb0;
+    const T* const st_c = slope_tan + rb0;
+    const uint16_t* const bin_c = bcache + rb0;
+    uint32_t o_el = jl;   // element offset of this lane's pixel in the row being issued
+    int issued = 0;       // rows issued so far (uniform)
     auto issue = [&](int rr, Pre& q) {  // called with rr = 0, 1, 2, ... in order; rows past the chunk repeat its last row
         const int rc = rr < nrow ? rr : nrow - 1;
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
         const T* rowp = tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W;
-        q.b0 = __builtin_nontemporal_load(rowp + c0); q.b1 = __builtin_nontemporal_load(rowp + c1);
-        q.rv = __builtin_nontemporal_load(p_ref);
-        q.st = __builtin_nontemporal_load(p_st);
-        q.bin = __builtin_nontemporal_load(p_bin);
-        if (issued + 1 < nrow) { p_ref += g.W; p_st += g.W; p_bin += g.W; }
+        q.b0 = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(rowp, c0b)));
+        q.b1 = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(rowp, c1b)));
+        q.rv = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(ref_c, o_el * (uint32_t)sizeof(T))));
+        q.st = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(st_c, o_el * (uint32_t)sizeof(T))));
+        q.bin = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(at(bin_c, o_el * 2u)));
+        if (issued + 1 < nrow) o_el += wb;   // (uniform condition)
         ++issued;
     };
     // sums of y^ and of the correction terms: float32 partial sums (y^, y^ y^ folded into float64 every NK_PF rows; the three
@@ -1181,7 +1213,7 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
 #pragma unroll
         for (int u = 0; u < NK_PF; ++u) {
             const int r = r0 + u;
-            if (r < nrow) {
+            if (r < nrow) {   // (uniform)
                 const T b0v = pre[u].b0, b1v = pre[u].b1, rv = pre[u].rv, stv = pre[u].st;
                 const uint16_t bin = pre[u].bin;
                 issue(r + NK_PF, pre[u]);
@@ -1192,7 +1224,7 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                     top = hl;
                 } else {  // chunk start, or a step of the tap row other than +1: fetch the upper row
                     const T* up = tba + (int64_t)k0l * g.W;
-                    top = hlerp(up[c0], up[c1]);
+                    top = hlerp(*reinterpret_cast<const T*>(at(up, c0b)), *reinterpret_cast<const T*>(at(up, c1b)));
                 }
                 double bot = top;
                 if (fl & 2) bot = hlerp(b0v, b1v);
@@ -1200,16 +1232,18 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                 hl = bot;
                 const T val = (T)t_add(top, t_mul(fr, t_sub(bot, top)));
                 const T out = t_sub(rv, val);
-                const bool ok = ((fl & 1) != 0) & cin & t_finite(out);
+                // lane masks as 64-bit scalars; per-lane choices are selects on those masks, stores and the counter update run
+                // unmasked (lanes that have nothing to say write to a slot / add 0 to a word nobody reads): one basic block per row
+                const unsigned long long m_row = (fl & 1) ? m_cin : 0ull;
+                const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(t_finite(out)) & m_row;
                 const K key = key_of(out);
-                const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(ok);
-                const unsigned long long m_below = __builtin_amdgcn_ballot_w64(ok & (key < klo));
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok & (key >= klo) & (key <= khi));
+                const unsigned long long m_lt = __builtin_amdgcn_ballot_w64(key < klo), m_le = __builtin_amdgcn_ballot_w64(key <= khi);
+                const unsigned long long mask = m_ok & ~m_lt & m_le;
                 n_all += (uint32_t)__popcll(m_ok);
-                n_below += (uint32_t)__popcll(m_below);
+                n_below += (uint32_t)__popcll(m_ok & m_lt);
                 if (mask) {   // (uniform)
-                    if ((mask >> lane) & 1ull)
-                        seg_d[held_d + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = out;
+                    const int pos = held_d + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    seg_d[sel_mask(trash, pos, mask)] = out;
                     const int cn = __popcll(mask);
                     held_d += cn;
                     n_in += (uint32_t)cn;
@@ -1218,19 +1252,20 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                 const T rr = fz_rcp(stv);
                 const T yh = (T)(out - vhat) * rr;
                 const T m = (T)(dgrow * rr) + (T)(fabs(yh) * FzEps<T>::rel) + FzEps<T>::tiny;
-                const bool yb = ok & (bin != (uint16_t)0xFFFF) & (yh == yh);
-                const FzPair<T> lh = lohi[yb ? bin : 0];
-                const bool nb_ = !((T)(yh + m) < lh.lo), na_ = !((T)(yh - m) > lh.hi);   // not certainly below / not certainly above
-                if (yb) atomicAdd(&cc[__umul24((unsigned)(nb_ ? (na_ ? 2 : 0) : 1), (unsigned)nb) + bin], 1u);
-                const unsigned long long my = __builtin_amdgcn_ballot_w64(yb & nb_ & na_);
+                const unsigned long long m_yb = m_ok & __builtin_amdgcn_ballot_w64(bin != (uint16_t)0xFFFF) & __builtin_amdgcn_ballot_w64(yh == yh);
+                const uint32_t binx = sel_mask(0u, (uint32_t)bin, m_yb);
+                const FzPair<T> lh = lohi[binx];
+                const unsigned long long m_nb = cm_nlt((T)(yh + m), lh.lo), m_na = cm_ngt((T)(yh - m), lh.hi);   // not certainly below / above
+                const uint32_t cls = sel_mask(1u, sel_mask(0u, 2u, m_na), m_nb);
+                // (lanes without a bin add 0 to a word of their own: no exec mask, no same-address pile-up)
+                atomicAdd(sel_mask_ptr(dummy, &cc[__umul24(cls, (unsigned)nb) + binx], m_yb), sel_mask(0u, 1u, m_yb));
+                const unsigned long long my = m_yb & m_nb & m_na;
                 if (my) {   // (uniform)
-                    if ((my >> lane) & 1ull) {
-                        const int pos = held_y + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(my >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)my, 0u));
-                        seg_yd[pos] = out; seg_ys[pos] = stv; seg_yb[pos] = bin;
-                    }
+                    const int pos = sel_mask(trash, held_y + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(my >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)my, 0u)), my);
+                    seg_yd[pos] = out; seg_ys[pos] = stv; seg_yb[pos] = bin;
                     held_y += __popcll(my);
                 }
-                const float yf = ok ? (float)yh : 0.0f, rf = ok ? (float)rr : 0.0f;
+                const float yf = sel_mask(0.0f, (float)yh, m_ok), rf = sel_mask(0.0f, (float)rr, m_ok);
                 p_y += yf; p_yy = fmaf(yf, yf, p_yy);
                 p_r += rf; p_yr = fmaf(yf, rf, p_yr); p_rr = fmaf(rf, rf, p_rr);
             }
@@ -1686,7 +1721,8 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if (!ctx->nk_fused || ctx->allreduce || !P->fz || !P->cd_vals || !P->c_st || !P->bcache || !P->ext_ok || g.rule > 1 || rows <= 0 ||
         P->bin_stat != XDEMHIP_BINSTAT_MEDIAN || !(ctx->selection_mode == 0 || ctx->selection_mode == 3) || !ws->d_small ||
         ws->es != sizeof(T) || nb > ws->nb_max || nb > MAX_BINS_PER_SWEEP || n < SEL_BRACKET_MIN_N ||
-        (ctx->selection_mode == 0 && n < SEL_BRACKET_MIN_PER_BIN * nb) || n_slots > ws->s_cap)
+        (ctx->selection_mode == 0 && n < SEL_BRACKET_MIN_PER_BIN * nb) || n_slots > ws->s_cap ||
+        (int64_t)(NKZ_CHUNK_MAX + 2) * P->W * (int64_t)sizeof(T) >= ((int64_t)1 << 32))   // (32-bit byte offsets inside a chunk of rows)
         return XDEMHIP_OK;
     unsigned char* scratch = static_cast<unsigned char*>(P->scratch);
     T* d_edges = reinterpret_cast<T*>(scratch);
@@ -1766,7 +1802,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         if ((rows + grid.y - 1) / grid.y > NKZ_CHUNK_MAX) grid.y = (unsigned)((rows + NKZ_CHUNK_MAX - 1) / NKZ_CHUNK_MAX);
         int copies = (6 * 1024) / (nb * 12);
         copies = copies < 1 ? 1 : (copies > 16 ? 16 : copies);
-        const size_t lds = (size_t)nb * sizeof(FzPair<T>) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies;
+        const size_t lds = (size_t)nb * sizeof(FzPair<T>) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies + 64 * 4;
         T* cy_d = static_cast<T*>(ws->c_vals);
 #define XD_NK_FZ(RULE)                                                                                                               \
     hipLaunchKernelGGL((nk_fused_kernel<T, RULE>), grid, dim3(256), lds, ctx->stream, ref_m, tba, st_all, P->bcache, g, P->row0, P->row1,  \

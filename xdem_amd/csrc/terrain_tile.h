@@ -669,7 +669,8 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
             // reference defaults (degrees, z_factor 1): compile-time masks + lean tail + the streaming route, like the full set.
             // With 8-16 bytes per pixel instead of 48 these launches are bound by instruction issue, so the folded attribute
             // branches and the float32 scale factors matter more here than for the eleven planes.
-            if (ctx->terrain_math == 2 && L.degrees && L.hs_z == 1.0 && (mask & ~(A_SLOPE | A_ASPECT | A_HILLSHADE)) == 0) {
+            // (win == 0: a windowed index of another window size still has its own launch below -- these macros return)
+            if (win == 0 && ctx->terrain_math == 2 && L.degrees && L.hs_z == 1.0 && (mask & ~(A_SLOPE | A_ASPECT | A_HILLSHADE)) == 0) {
 #define XD_SMALL(F, M)                                                                                                       \
     do {                                                                                                                     \
         const int took = launch_stream<F, false, false, Spec<M, 0, 1, 0, 1, 2>>(ctx, L, mask);                              \
