@@ -1059,7 +1059,7 @@ template <typename T> struct FzPair { T lo, hi; };
 
 constexpr int NKZ_CHUNK_MAX = 256;   // rows of a workgroup's chunk (row-tap table in LDS)
 template <typename T, int RULE>
-__global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
+__global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
                                                        const uint16_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
                                                        int nb, int copies, const typename KeyT<T>::type* __restrict__ klo_p,
                                                        const typename KeyT<T>::type* __restrict__ khi_p, const T* vhat_p, const T* delta_p,
@@ -1075,8 +1075,12 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                                           // no LDS atomic with return and its round trip on the path of every row (bin candidates are
                                           // ~7 % of the pixels: practically every row of every wave holds some)
     static_assert(SEG >= 2 * NKZ_ROWS * 64, "a flush check must leave room for NKZ_ROWS rows of candidates");
+    // candidates of the median of dh are ~0.7 % of the pixels (half a pixel per wave and row): their segments are small and a wave
+    // that would overrun its segment between two looks -- more than half of its pixels inside the bracket of the median: a raster
+    // of (nearly) one dh value -- raises the overflow flag, i.e. hands the step to the two-pass route, which is built for that
+    constexpr int SEG_D = 128;
     __shared__ NkRowTab tab[NKZ_CHUNK_MAX + 1];
-    __shared__ T stage_d[NKZ_CAP + 4];       // (+ one slot per wave that nobody reads: lanes without a candidate write there, so the
+    __shared__ T stage_d[4 * SEG_D + 4];     // (+ one slot per wave that nobody reads: lanes without a candidate write there, so the
     __shared__ T sy_d[NKZ_CAP + 4];          //  staging stores need no exec mask)
     __shared__ T sy_st[NKZ_CAP + 4];
     __shared__ uint16_t sy_b[NKZ_CAP + 4];
@@ -1130,7 +1134,8 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
     auto at = [](const void* base, uint32_t byte_off) { return reinterpret_cast<const char*>(base) + byte_off; };
     uint32_t n_all = 0, n_below = 0, n_in = 0;  // wave-uniform
     int held_d = 0, held_y = 0;                  // wave-uniform: candidates staged in this wave's segments
-    T* const seg_d = stage_d + wave * SEG;
+    T* const seg_d = stage_d + wave * SEG_D;
+    const int trash_d = 4 * SEG_D + wave - wave * SEG_D;
     T* const seg_yd = sy_d + wave * SEG;
     T* const seg_ys = sy_st + wave * SEG;
     uint16_t* const seg_yb = sy_b + wave * SEG;
@@ -1146,7 +1151,7 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
 #pragma unroll
         for (int w = 0; w < 4; ++w) { n0[w] = __builtin_amdgcn_readfirstlane(s_cnt[0][w]); n1[w] = __builtin_amdgcn_readfirstlane(s_cnt[1][w]); }
         const int m0 = max(max(n0[0], n0[1]), max(n0[2], n0[3])), m1 = max(max(n1[0], n1[1]), max(n1[2], n1[3]));
-        const bool f0 = m0 > threshold, f1 = m1 > threshold;
+        const bool f0 = m0 > (threshold < SEG_D / 2 ? threshold : SEG_D / 2), f1 = m1 > threshold;
         if (f0 || f1) {   // (uniform)
             if (threadIdx.x == 0 && f0) s_base[0] = atomicAdd(&ctr[1], (unsigned long long)(n0[0] + n0[1] + n0[2] + n0[3]));
             if (threadIdx.x == 64 && f1) s_base[1] = atomicAdd(&ctr[5], (unsigned long long)(n1[0] + n1[1] + n1[2] + n1[3]));
@@ -1157,7 +1162,7 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                 for (int w = 0; w < 4; ++w) {
                     const int nw = __builtin_amdgcn_readfirstlane(s_cnt[0][w]);
                     for (int k = threadIdx.x; k < nw; k += blockDim.x) {
-                        if ((int64_t)(b0 + k) < cd_cap) cd_vals[b0 + k] = stage_d[w * SEG + k];
+                        if ((int64_t)(b0 + k) < cd_cap) cd_vals[b0 + k] = stage_d[w * SEG_D + k];
                         else ctr[2] = 1ull;
                     }
                     b0 += (unsigned long long)nw;
@@ -1242,11 +1247,15 @@ __global__ __launch_bounds__(256) void nk_fused_kernel(const T* __restrict__ ref
                 n_all += (uint32_t)__popcll(m_ok);
                 n_below += (uint32_t)__popcll(m_ok & m_lt);
                 if (mask) {   // (uniform)
-                    const int pos = held_d + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    seg_d[sel_mask(trash, pos, mask)] = out;
                     const int cn = __popcll(mask);
-                    held_d += cn;
                     n_in += (uint32_t)cn;
+                    if (held_d + cn <= SEG_D) {   // (uniform)
+                        const int pos = held_d + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        seg_d[sel_mask(trash_d, pos, mask)] = out;
+                        held_d += cn;
+                    } else if (lane == 0) {
+                        ctr[2] = 1ull;
+                    }
                 }
                 // ---- the bin side: y^ with its margin against the bracket of the pixel's aspect bin
                 const T rr = fz_rcp(stv);
@@ -1329,23 +1338,29 @@ __global__ void nk_fz_vshift_kernel(const uint64_t* cnt /* total, below, inside 
 }
 
 // candidates of the bin medians, now that vshift is known: y in the reference's arithmetic; below / inside the bin's bracket are
-// counted, the inside ones keep their y (NaN for the others: the digit passes skip NaN)
+// counted, the inside ones keep their y (NaN for the others: the digit passes skip NaN) -- and are entered into the FIRST digit's
+// histogram of the exact selection that follows (rebased keys, as hist_pass_kernel forms them), which saves that selection its
+// first pass over the candidates
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void nk_resolve_kernel(T* __restrict__ c_v /* dh in, y out */, const T* __restrict__ c_st,
                                                                   const uint16_t* __restrict__ c_b, int64_t cap, const unsigned long long* n_dev,
                                                                   const T* vshift_p, int nb, const typename KeyT<T>::type* __restrict__ klo,
-                                                                  const typename KeyT<T>::type* __restrict__ khi, uint64_t* res /* [2][nb] */) {
+                                                                  const typename KeyT<T>::type* __restrict__ khi, const uint32_t* rbs_p,
+                                                                  uint64_t* res /* [2][nb] */, uint64_t* hist /* [nb][256] */) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
     K* lo = reinterpret_cast<K*>(fz_smem);
     K* hi = lo + nb;
     uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);   // [2][nb]
+    uint32_t* h = c + 2 * nb;                              // [nb][256]
     for (int k = threadIdx.x; k < nb; k += blockDim.x) { lo[k] = klo[k]; hi[k] = khi[k]; }
-    for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x) c[k] = 0;
+    for (int k = threadIdx.x; k < 2 * nb + nb * SEL_RADIX; k += blockDim.x) c[k] = 0;
     __syncthreads();
     const unsigned long long m = *n_dev;
     const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
     const T vshift = *vshift_p;
+    const int rbs = (int)*rbs_p;
+    constexpr int TOP = 8 * (KeyT<T>::passes - 1);
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)c_b[p];
         const T y = t_div(t_sub(c_v[p], vshift), c_st[p]);
@@ -1353,13 +1368,26 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_resolve_kernel(T* __restrict_
         if (y == y && b < nb) {
             const K key = key_of(y);
             if (key < lo[b]) atomicAdd(&c[b], 1u);
-            else if (key <= hi[b]) { atomicAdd(&c[nb + b], 1u); keep = y; }
+            else if (key <= hi[b]) {
+                atomicAdd(&c[nb + b], 1u);
+                keep = y;
+                atomicAdd(&h[b * SEL_RADIX + (int)(((K)((K)(key - lo[b]) << rbs) >> TOP) & 0xFF)], 1u);
+            }
         }
         c_v[p] = keep;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x)
         if (c[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&res[k]), (unsigned long long)c[k]);
+    for (int k = threadIdx.x; k < nb * SEL_RADIX; k += blockDim.x)
+        if (h[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[k]), (unsigned long long)h[k]);
+}
+
+// every small result of a step gathered into one block (one device-to-host copy instead of ten)
+struct FzPack { const unsigned char* src[12]; uint32_t bytes[12]; uint32_t off[12]; int n; unsigned char* dst; };
+static __global__ __launch_bounds__(256) void nk_fz_pack_kernel(FzPack a) {
+    for (int k = 0; k < a.n; ++k)
+        for (uint32_t i = threadIdx.x; i < a.bytes[k]; i += blockDim.x) a.dst[a.off[k] + i] = a.src[k][i];
 }
 
 // per bin: total / below / inside in the layout bracket_given_kernel reads, from the classes of the pass and of the candidates
@@ -1400,6 +1428,9 @@ struct xdemhip_nk_plan {
     void* cd_vals = nullptr;      // ... candidates of the median of dh
     int64_t cd_cap = 0;
     void* c_st = nullptr;         // ... slope tangents of the bin candidates (next to ws.c_vals / ws.c_bins)
+    unsigned char* fz_pack = nullptr;   // ... the step's small results, gathered for one device-to-host copy
+    size_t fz_pack_bytes = 0;
+    std::vector<unsigned char> fz_host;
     int64_t n_onepass = 0, n_twopass = 0, n_plain = 0;   // steps answered by each route (xdemhip_nk_route_counts)
     void* scratch = nullptr;  // edges, stats, sums, selection states, successor keys, histograms
     size_t scratch_bytes = 0;
@@ -1800,7 +1831,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     {
         dim3 grid = grid2d(ctx, P->W, rows);
         if ((rows + grid.y - 1) / grid.y > NKZ_CHUNK_MAX) grid.y = (unsigned)((rows + NKZ_CHUNK_MAX - 1) / NKZ_CHUNK_MAX);
-        int copies = (6 * 1024) / (nb * 12);
+        int copies = (4608) / (nb * 12);   // (static 26 KB + this: five workgroups of 256 threads per CU)
         copies = copies < 1 ? 1 : (copies > 16 ? 16 : copies);
         const size_t lds = (size_t)nb * sizeof(FzPair<T>) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies + 64 * 4;
         T* cy_d = static_cast<T*>(ws->c_vals);
@@ -1821,20 +1852,23 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if (rc) return rc;
     hipLaunchKernelGGL((nk_fz_vshift_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, cnt_d, d_st, reinterpret_cast<const uint64_t*>(scratch + off_succ(1)),
                        klo_d, rbs_d, ctr, scratch + OFF_INFO);
-    // 6. the bin candidates with the exact vshift -> counts, exact medians among those inside the brackets
+    // 6. the bin candidates with the exact vshift -> counts + first digit's histogram, exact medians among those inside the brackets
     {
-        const size_t lds = (size_t)nb * 2 * sizeof(K) + (size_t)nb * 2 * 4;
+        uint64_t* d_hist = select_reset<K>(ctx, scratch, nb);   // (after the selection of step 5 has been read by the vshift kernel)
+        const size_t lds = (size_t)nb * 2 * sizeof(K) + (size_t)nb * 2 * 4 + (size_t)nb * SEL_RADIX * 4;
+        rc = set_big_lds(ctx, nk_resolve_kernel<T>, lds);
+        if (rc) return rc;
         hipLaunchKernelGGL((nk_resolve_kernel<T>), dim3(grid_for(ctx, n / 16 + 1, HIST_THREADS, 2)), dim3(HIST_THREADS), lds, ctx->stream,
                            static_cast<T*>(ws->c_vals), static_cast<const T*>(P->c_st), ws->c_bins, ws->c_cap, ctr + 5,
-                           reinterpret_cast<const T*>(scratch + OFF_INFO), nb, klo_y, khi_y, res_y);
+                           reinterpret_cast<const T*>(scratch + OFF_INFO), nb, klo_y, khi_y, rbs_y, res_y, d_hist);
     }
     hipLaunchKernelGGL(nk_fz_counts_kernel, dim3(nbb), dim3(64), 0, ctx->stream, cls_y, res_y, nb, cnt_y);
     hipLaunchKernelGGL(bracket_given_kernel, dim3(nbb), dim3(64), 0, ctx->stream, cnt_y, nb, given_y, ctr);
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, ws->c_cap, n / 16 + 1, ctr + 5, nb, scratch, SEL_GIVEN, given_y, 0, true,
-                           klo_y, rbs_y);
+                           klo_y, rbs_y, /*first_hist_done=*/true);
     if (rc) return rc;
-    // 7. everything the step hands back, behind one synchronisation
+    // 7. everything the step hands back: packed into one block on the device, one copy, one synchronisation
     std::vector<uint64_t> cnt(3 * (size_t)nb);
     std::vector<K> klo(nb);
     std::vector<T> edges(nb + 1);
@@ -1843,17 +1877,32 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     unsigned char info[32];
     double sums[5];
     T h_vhat = (T)0;
-    { const int rc_ = xd_d2h(ctx, cnt.data(), cnt_y, 8 * 3 * (size_t)nb); if (rc_) return rc_; }
-    { const int rc_ = xd_d2h(ctx, klo.data(), klo_y, sizeof(K) * nb); if (rc_) return rc_; }
-    { const int rc_ = xd_d2h(ctx, h_ctr, ctr, 64); if (rc_) return rc_; }
-    { const int rc_ = xd_d2h(ctx, &h_rbs, rbs_y, 8); if (rc_) return rc_; }
-    { const int rc_ = xd_d2h(ctx, info, scratch + OFF_INFO, 32); if (rc_) return rc_; }
-    { const int rc_ = xd_d2h(ctx, sums, d_sums, 40); if (rc_) return rc_; }
-    { const int rc_ = xd_d2h(ctx, &h_vhat, d_vhat, sizeof(T)); if (rc_) return rc_; }
-    { const int rc_ = xd_d2h(ctx, edges.data(), d_edges, sizeof(T) * (nb + 1)); if (rc_) return rc_; }
-    std::vector<SelResult<K>> hs;
-    rc = select_fetch<T>(ctx, scratch, nb, hs);  // (synchronises the stream)
-    if (rc) return rc;
+    std::vector<SelState<K>> h_st(nb);
+    std::vector<uint64_t> h_succ(nb);
+    {
+        FzPack pk;
+        void* dsts[10] = {cnt.data(), klo.data(), h_ctr, &h_rbs, info, sums, &h_vhat, edges.data(), h_st.data(), h_succ.data()};
+        const void* srcs[10] = {cnt_y, klo_y, ctr, rbs_y, scratch + OFF_INFO, d_sums, d_vhat, d_edges, scratch + OFF_STATE, scratch + off_succ(nb)};
+        const size_t sizes[10] = {8 * 3 * (size_t)nb, sizeof(K) * nb, 64, 8, 32, 40, sizeof(T), sizeof(T) * (nb + 1), sizeof(SelState<K>) * nb, 8 * (size_t)nb};
+        uint32_t off = 0;
+        pk.n = 10;
+        for (int k = 0; k < 10; ++k) {
+            pk.src[k] = static_cast<const unsigned char*>(srcs[k]);
+            pk.bytes[k] = (uint32_t)sizes[k];
+            pk.off[k] = off;
+            off += (uint32_t)((sizes[k] + 15) & ~(size_t)15);
+        }
+        if (off > P->fz_pack_bytes) return xd_fail(ctx, XDEMHIP_EINVAL, "one-pass step: result block too small");
+        pk.dst = P->fz_pack;
+        hipLaunchKernelGGL(nk_fz_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, pk);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+        P->fz_host.resize(off);
+        { const int rc_ = xd_d2h(ctx, P->fz_host.data(), P->fz_pack, off); if (rc_) return rc_; }
+        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+        for (int k = 0; k < 10; ++k) memcpy(dsts[k], P->fz_host.data() + pk.off[k], sizes[k]);
+    }
+    std::vector<SelResult<K>> hs(nb);
+    for (int k = 0; k < nb; ++k) { hs[k].st = h_st[k]; hs[k].succ = h_succ[k]; }
     if (h_ctr[2] != 0 || h_ctr[3] != 0) return XDEMHIP_OK;  // overflow / a bracket missed / no extreme-aspect survivor: the two-pass route
     uint64_t total;
     double vs;
@@ -2135,13 +2184,15 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
     if (P->ref_m && P->ws.d_small && ctx->nk_fused != 0) {
         P->fz_bytes = (size_t)(24 + 11 * P->ws.nb_max) * 8;
         P->cd_cap = (int64_t)n / 8 + 4096;
+        P->fz_pack_bytes = (size_t)P->ws.nb_max * (8 * 3 + 8 + 16 + 64 + 8) + 1024;
         if (hipMalloc(reinterpret_cast<void**>(&P->fz), P->fz_bytes) != hipSuccess || hipMalloc(&P->cd_vals, (size_t)P->cd_cap * es) != hipSuccess ||
-            hipMalloc(&P->c_st, (size_t)P->ws.c_cap * es) != hipSuccess) {
+            hipMalloc(&P->c_st, (size_t)P->ws.c_cap * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->fz_pack), P->fz_pack_bytes) != hipSuccess) {
             (void)hipGetLastError();
             if (P->fz) (void)hipFree(P->fz);
             if (P->cd_vals) (void)hipFree(P->cd_vals);
             if (P->c_st) (void)hipFree(P->c_st);
-            P->fz = nullptr; P->cd_vals = nullptr; P->c_st = nullptr;
+            if (P->fz_pack) (void)hipFree(P->fz_pack);
+            P->fz = nullptr; P->cd_vals = nullptr; P->c_st = nullptr; P->fz_pack = nullptr;
         }
     }
     const xdemhip_allreduce_fn hook = ctx->allreduce;
@@ -2163,7 +2214,7 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     (void)hipSetDevice(P->ctx->device);
     if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
     void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt,
-                    P->fz, P->cd_vals, P->c_st};
+                    P->fz, P->cd_vals, P->c_st, P->fz_pack};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     xd::sel_ws_free(P->ws);

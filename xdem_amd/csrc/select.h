@@ -89,13 +89,18 @@ template <typename K>
 __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
                                                             int mode = SEL_MEDIAN, const uint64_t* given = nullptr,
                                                             const uint32_t* rb_shift = nullptr, uint32_t wide_deff = PAIR_DEFF_WIDE,
-                                                            int dual_nb = 1 /* SEL_BRACKET_DUAL: states below this are low ends */) {
+                                                            int dual_nb = 1 /* SEL_BRACKET_DUAL: states below this are low ends */,
+                                                            uint64_t* succ = nullptr /* [nb]: successor keys from the last histogram */,
+                                                            uint32_t* need_succ = nullptr /* raised when some bin's successor needs the scan */) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
     // Rebased keys ((key - lo) << s, select_run.h) have s zero bits at the bottom: a digit that lies entirely inside them is 0
     // for every element, its pass is skipped (hist_pass_kernel leaves at once) and the state moves on without a histogram.
     if (!first && rb_shift && shift + 8 <= (int)*rb_shift) {
-        if (last && lane == 0 && st[b].count) st[b].n_le += st[b].group;
+        if (last && lane == 0 && st[b].count) {
+            st[b].n_le += st[b].group;
+            if (need_succ) *need_succ = 1u;   // (no histogram of the last digit: the successor pass has to look)
+        }
         return;
     }
     uint64_t* h = hist + (size_t)b * SEL_RADIX;
@@ -150,6 +155,22 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         s.rank -= cumsel;
         s.group = hsel;
         if (last) s.n_le += hsel;  // all digits fixed: group == the selected key's duplicates
+        if (last && succ) {
+            // Round 4: the smallest key above the selected one usually shares its leading digits -- then it is the next non-empty
+            // bucket of THIS histogram (the last digit completes the key) and the successor pass over the elements has nothing
+            // to do; only a selected key that is the largest of its group leaves the question to that pass (need_succ).
+            int cand = 0x7fffffff;
+#pragma unroll
+            for (int q = 3; q >= 0; --q)
+                if (c[q] > 0 && 4 * lane + q > dsel) cand = 4 * lane + q;
+            const unsigned long long have = __ballot(cand != 0x7fffffff);
+            if (have) {
+                const int nxt = __shfl(cand, (int)__ffsll((long long)have) - 1);   // buckets ascend with the lane: the first lane that has one holds the smallest
+                if (lane == 0) succ[b] = (uint64_t)(K)((s.prefix & ~((K)0xFF << shift)) | ((K)nxt << shift));
+            } else if (lane == 0 && need_succ) {
+                *need_succ = 1u;
+            }
+        }
     }
     if (lane == 0) st[b] = s;
 }

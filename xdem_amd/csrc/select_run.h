@@ -45,7 +45,7 @@ __device__ __forceinline__ uint64_t k_shfl_down(uint64_t v, int off) { return (u
 // low-entropy leading digit and serialise 64-way.  1024-thread workgroups so that even the 72 KB table of the
 // 72 aspect bins runs at full occupancy (2 workgroups = 32 waves per CU).
 constexpr int HIST_THREADS = 1024;
-constexpr int SEL_UNROLL = 4;
+constexpr int SEL_UNROLL = 8;   // elements per thread and step, all loads issued before the first use (4 in rounds 1-3)
 
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
@@ -132,8 +132,9 @@ __global__ __launch_bounds__(HIST_THREADS) void succ_pass_kernel(const T* __rest
                                                                  uint64_t* succ /* [nb], all-ones = none */,
                                                                  const unsigned long long* n_dev = nullptr,
                                                                  const typename KeyT<T>::type* rb_lo = nullptr,
-                                                                 const uint32_t* rb_shift = nullptr) {
+                                                                 const uint32_t* rb_shift = nullptr, const uint32_t* need = nullptr) {
     typedef typename KeyT<T>::type K;
+    if (need && *need == 0u) return;   // every bin's successor came out of the last histogram (select_advance_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K* m = reinterpret_cast<K*>(smem);
     if (n_dev) {
@@ -205,16 +206,17 @@ inline int grid_for(const xdemhip_ctx* ctx, int64_t n, int block, int per_cu) {
 
 
 // scratch layout (bytes): [0, 16384) bin edges | stats | sums | selection states | successor keys | histograms
-constexpr size_t OFF_STATS = 16384, OFF_SUMS = OFF_STATS + 64, OFF_STATE = OFF_STATS + 128;
+constexpr size_t OFF_STATS = 16384, OFF_SUMS = OFF_STATS + 64, OFF_NEED = OFF_STATS + 96 /* uint32: successor pass needed */, OFF_STATE = OFF_STATS + 128;
 inline int nb1(int nb) { return nb > 1 ? nb : 1; }
 inline size_t off_succ(int nb) { return OFF_STATE + (size_t)nb1(nb) * 64; }
 inline size_t off_hist(int nb) { return off_succ(nb) + (size_t)nb1(nb) * 8; }
 // (sized for 2 nb states: the dual bracket selection keeps a low-end and a high-end state per bin)
 inline size_t scratch_size(int nb) { return off_hist(2 * nb1(nb)) + (size_t)2 * nb1(nb) * SEL_RADIX * 8 + 256; }
 
-static __global__ void select_reset_kernel(uint64_t* base, int64_t w_state, int64_t w_succ, int64_t words) {
+static __global__ void select_reset_kernel(uint64_t* base, int64_t w_state, int64_t w_succ, int64_t words, uint32_t* need = nullptr) {
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x)
         base[w] = (w >= w_state && w < w_state + w_succ) ? ~(uint64_t)0 : (uint64_t)0;
+    if (need && blockIdx.x == 0 && threadIdx.x == 0) *need = 0u;
 }
 
 template <typename K> struct SelResult {
@@ -232,7 +234,8 @@ template <typename K> struct SelResult {
 template <typename T>
 int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int64_t n_grid, const unsigned long long* d_n, int nb,
                    unsigned char* scratch, int mode, const uint64_t* d_given, int n_passes = 0, bool want_succ = true,
-                   const typename KeyT<T>::type* rb_lo = nullptr, const uint32_t* rb_shift = nullptr) {
+                   const typename KeyT<T>::type* rb_lo = nullptr, const uint32_t* rb_shift = nullptr,
+                   bool first_hist_done = false /* the caller ran select_reset and filled the first digit's histogram itself */) {
     typedef typename KeyT<T>::type K;
     // SEL_BRACKET_DUAL: two selection states per data bin (low ends in states [0, nb), high ends in [nb, 2 nb)); `scratch` holds
     // 2 nb states (scratch_size provides for that)
@@ -243,13 +246,14 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
     uint64_t* d_hist = reinterpret_cast<uint64_t*>(scratch + off_hist(nb));
-    {
+    uint32_t* d_need = reinterpret_cast<uint32_t*>(scratch + OFF_NEED);
+    if (!first_hist_done) {
         // states | successor keys | histograms are contiguous in `scratch`: one launch resets all three (zeros, all-ones, zeros)
         static_assert(sizeof(SelState<K>) <= 64, "state records live in 64-byte slots");
         const int64_t w_state = (int64_t)nb1(nb) * 8, w_succ = (int64_t)nb1(nb), w_hist = (int64_t)nb * SEL_RADIX;
         const int64_t words = w_state + w_succ + w_hist;
         const int blocks = (int)((words + 1023) / 1024 < 256 ? (words + 1023) / 1024 : 256);
-        hipLaunchKernelGGL(select_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint64_t*>(st), w_state, w_succ, words);
+        hipLaunchKernelGGL(select_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint64_t*>(st), w_state, w_succ, words, d_need);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     const int passes = KeyT<T>::passes;
@@ -258,10 +262,10 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     // halves that fixed cost, which dominates their passes)
     // (measured on the Nuth-Kaab step, A/B in one session: 2 -> 1 workgroups per CU 3.00 / 3.13 -> 2.92 / 2.98 ms; half a
     // workgroup per CU 3.10: too few)
-    const int grid = grid_for(ctx, n_grid, HIST_THREADS * 4, n_grid < ((int64_t)1 << 24) ? 1 : 2);
+    const int grid = grid_for(ctx, n_grid, HIST_THREADS * SEL_UNROLL, n_grid < ((int64_t)1 << 24) ? 1 : 2);
     for (int p = 0; p < run; ++p) {
         const int shift = 8 * (passes - 1 - p);
-        if (n > 0) {
+        if (n > 0 && !(p == 0 && first_hist_done)) {
             const int per_sweep = dual ? MAX_ROWS_PER_SWEEP_DUAL / 2 : MAX_BINS_PER_SWEEP;
             for (int b0 = 0; b0 < nb_data; b0 += per_sweep) {
                 const int nbs = (nb_data - b0) < per_sweep ? (nb_data - b0) : per_sweep;
@@ -272,7 +276,13 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                 const size_t lds = ((size_t)rows * SEL_RADIX + 1) * sizeof(uint32_t) * copies + 8 + 2 * sizeof(K) * (size_t)rows;
                 int rc = set_big_lds(ctx, hist_pass_kernel<T>, lds);
                 if (rc) return rc;
-                hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
+                // every workgroup flushes a whole [rows][256] table with global atomics: with many rows and few elements (the 72-bin
+                // samples: 36 k counters against 24 k elements per workgroup) the flush IS the pass -- no more workgroups than give
+                // each of them two tables' worth of elements (at least 32)
+                int64_t g2 = n_grid / ((int64_t)2 * rows * SEL_RADIX);
+                g2 = g2 < 32 ? 32 : g2;
+                const int grid_p = (int)(g2 < grid ? g2 : grid);
+                hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_p), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
                                    st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift, dual ? nb_data : 0);
                 XD_HIP_CHECK(ctx, hipGetLastError());
             }
@@ -280,16 +290,30 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
-                           (int)(p == 0), (int)(p == passes - 1), mode, d_given, rb_shift, PAIR_DEFF_WIDE, nb_data);
+                           (int)(p == 0), (int)(p == passes - 1), mode, d_given, rb_shift, PAIR_DEFF_WIDE, nb_data,
+                           want_succ ? d_succ : nullptr, want_succ ? d_need : nullptr);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     if (!want_succ) return XDEMHIP_OK;
     if (n > 0) {
+        // (leaves at once unless some bin's selected key is the largest of its leading-digit group: see select_advance_kernel)
         hipLaunchKernelGGL((succ_pass_kernel<T>), dim3(grid), dim3(HIST_THREADS), 3 * sizeof(K) * nb, ctx->stream, vals, bins, n, nb, st,
-                           d_succ, d_n, rb_lo, rb_shift);
+                           d_succ, d_n, rb_lo, rb_shift, d_need);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     return xd_allreduce_device(ctx, d_succ, nb, XDEMHIP_RED_MIN_U64);
+}
+
+// The reset of select_enqueue on its own, for callers that fill the first digit's histogram themselves (first_hist_done): returns
+// the histogram table [nb][256] they add to.
+template <typename K> uint64_t* select_reset(xdemhip_ctx* ctx, unsigned char* scratch, int nb) {
+    SelState<K>* st = reinterpret_cast<SelState<K>*>(scratch + OFF_STATE);
+    const int64_t w_state = (int64_t)nb1(nb) * 8, w_succ = (int64_t)nb1(nb), w_hist = (int64_t)nb * SEL_RADIX;
+    const int64_t words = w_state + w_succ + w_hist;
+    const int blocks = (int)((words + 1023) / 1024 < 256 ? (words + 1023) / 1024 : 256);
+    hipLaunchKernelGGL(select_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint64_t*>(st), w_state, w_succ, words,
+                       reinterpret_cast<uint32_t*>(scratch + OFF_NEED));
+    return reinterpret_cast<uint64_t*>(scratch + off_hist(nb));
 }
 
 template <typename T>
