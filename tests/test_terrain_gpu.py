@@ -310,6 +310,9 @@ def test_library_allocated_planes(terrain, backing):
     n = 4608
     dem = fbm_torch(n, n, "cuda", seed=3)
     torch.cuda.synchronize()
+    gc.collect()
+    ctx.release_pool()
+    torch.cuda.empty_cache()   # (blocks cached by earlier tests would be handed back later and blur the accounting below)
     free0 = torch.cuda.mem_get_info()[0]
     planes = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx, backing=backing)
     assert planes.shape == (len(attrs), n, n) and planes.is_cuda and hasattr(planes, "xdem_contiguous")

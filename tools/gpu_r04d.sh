@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-4 session 4: Nuth-Kaab one-pass step after the mask rewrite (tests of the three routes, dispatch sequence, SQ counters of the
 # fused kernel), window / small-set terrain tests
-O=gpurun_out/r04d; mkdir -p $O
+O=gpurun_out/r04f; mkdir -p $O
 export PYTHONUNBUFFERED=1
 timeout 900 python -X faulthandler -m pytest tests/test_nuthkaab_gpu.py tests/test_terrain_gpu.py -q -m gpu --maxfail=8 -k "lean or route or C3 or ext or window or generic or options or fbm or randomised or halo or strips or one_rank" > $O/pytest.log 2>&1
 tail -12 $O/pytest.log | cut -c1-300

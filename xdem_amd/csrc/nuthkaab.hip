@@ -949,6 +949,21 @@ __device__ __forceinline__ uint32_t* sel_mask_ptr(uint32_t* a, uint32_t* b, unsi
     return (uint32_t*)(lp)(uintptr_t)r;
 }
 
+// Loads through buffer descriptors: address = descriptor base + per-lane byte offset (a loop-invariant register) + a scalar byte
+// offset -- the row of the chunk -- added by the load unit itself: no vector instruction forms an address inside the row loop
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fz_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float fz_bufload(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 2 /* nt */));
+}
+__device__ __forceinline__ double fz_bufload(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 2));
+}
+__device__ __forceinline__ uint16_t fz_bufload16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 2);
+}
+
 template <typename T> struct FzEps;   // relative slack that covers the roundings of y^ (fast reciprocal) and of y itself
 template <> struct FzEps<float> { static constexpr float rel = 4e-6f, grow = 1.00002f, tiny = 1e-37f; };
 template <> struct FzEps<double> { static constexpr double rel = 1e-14, grow = 1.0000000001, tiny = 1e-300; };
@@ -1125,13 +1140,11 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
     const uint32_t c0b = (cin ? (uint32_t)col.k0 : 0u) * (uint32_t)sizeof(T);
     const uint32_t c1b = c0b + (cin ? (uint32_t)col.d1 : 0u) * (uint32_t)sizeof(T);
     const uint32_t jl = jin ? (uint32_t)j : 0u;
-    const uint32_t wb = (uint32_t)g.W;
     const double fc = col.f;
     auto hlerp = [&](T a, T b) -> double {
         const double v0 = a, v1 = b;
         return t_add(v0, t_mul(fc, t_sub(v1, v0)));
     };
-    auto at = [](const void* base, uint32_t byte_off) { return reinterpret_cast<const char*>(base) + byte_off; };
     uint32_t n_all = 0, n_below = 0, n_in = 0;  // wave-uniform
     int held_d = 0, held_y = 0;                  // wave-uniform: candidates staged in this wave's segments
     T* const seg_d = stage_d + wave * SEG_D;
@@ -1140,7 +1153,11 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
     T* const seg_ys = sy_st + wave * SEG;
     uint16_t* const seg_yb = sy_b + wave * SEG;
     const int trash = NKZ_CAP + wave - wave * SEG;       // index of this wave's unread slot, relative to its segment
-    uint32_t* const dummy = c + cs * copies + lane;      // 64 words behind the counters: where "add 0" goes
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32p;
+    auto lds_addr = [](uint32_t* p) { return (uint32_t)(uintptr_t)(lds_u32p)p; };
+    auto lds_u32 = [](uint32_t a) { return (uint32_t*)(lds_u32p)(uintptr_t)a; };
+    const uint32_t dummy_a = lds_addr(c + cs * copies + lane);      // 64 words behind the counters: where "add 0" goes
+    const uint32_t cls_a = lds_addr(cc), cls_b = lds_addr(cc + nb), cls_c = lds_addr(cc + 2 * nb);
     // staging: [0] candidates of the median of dh (values), [1] candidates of the bin medians (dh, slope_tan, bin); a look at the
     // buffers every NKZ_ROWS rows (one barrier), a flush -- one global atomic per kind and workgroup -- when some wave's segment
     // could not take NKZ_ROWS more rows
@@ -1189,24 +1206,31 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
     double hl = 0.0;
     struct Pre { T b0, b1, rv, st; uint16_t bin; };
     Pre pre[NK_PF];
-    const int64_t rb0 = (i0 - g.roff) * g.W;
-    // uniform chunk bases of the three rasters indexed by the output pixel + one 32-bit per-lane element offset walking down the chunk
-    const T* const ref_c = ref + rb0;
-    const T* const st_c = slope_tan + rb0;
-    const uint16_t* const bin_c = bcache + rb0;
-    uint32_t o_el = jl;   // element offset of this lane's pixel in the row being issued
-    int issued = 0;       // rows issued so far (uniform)
-    auto issue = [&](int rr, Pre& q) {  // called with rr = 0, 1, 2, ... in order; rows past the chunk repeat its last row
+    // (wave-uniform, and said so: the descriptors below must sit in scalar registers -- a descriptor the compiler takes for
+    // lane-varying is read back lane by lane in a loop around every load)
+    const uint64_t rb0_u = (uint64_t)((i0 - g.roff) * g.W);
+    const int64_t rb0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rb0_u >> 32)) << 32) |
+                                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rb0_u));
+    // buffer descriptors: the three rasters indexed by the output pixel from the chunk's first row, tba from the chunk's first
+    // tap row (tap rows ascend with the output row; rows whose taps leave the raster are discarded anyway and read row k_base)
+    const int k_base = __builtin_amdgcn_readfirstlane((tab[0].flags & 1) ? tab[0].k0l : 0);
+    const __amdgpu_buffer_rsrc_t r_tba = fz_rsrc(tba + (int64_t)k_base * g.W);
+    const __amdgpu_buffer_rsrc_t r_ref = fz_rsrc(ref + rb0);
+    const __amdgpu_buffer_rsrc_t r_st = fz_rsrc(slope_tan + rb0);
+    const __amdgpu_buffer_rsrc_t r_bin = fz_rsrc(bcache + rb0);
+    const uint32_t wbytes = (uint32_t)g.W * (uint32_t)sizeof(T), wbytes2 = (uint32_t)g.W * 2u;
+    const uint32_t ob = jl * (uint32_t)sizeof(T), ob2 = jl * 2u;
+    auto tap_row = [&](int k) -> uint32_t { return (uint32_t)((k > k_base ? k : k_base) - k_base) * wbytes; };   // (scalar)
+    auto issue = [&](int rr, Pre& q) {  // rows past the chunk repeat its last row
         const int rc = rr < nrow ? rr : nrow - 1;
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
-        const T* rowp = tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W;
-        q.b0 = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(rowp, c0b)));
-        q.b1 = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(rowp, c1b)));
-        q.rv = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(ref_c, o_el * (uint32_t)sizeof(T))));
-        q.st = __builtin_nontemporal_load(reinterpret_cast<const T*>(at(st_c, o_el * (uint32_t)sizeof(T))));
-        q.bin = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(at(bin_c, o_el * 2u)));
-        if (issued + 1 < nrow) o_el += wb;   // (uniform condition)
-        ++issued;
+        const uint32_t so_t = tap_row(tk + ((tf >> 1) & 1));
+        q.b0 = fz_bufload(r_tba, c0b, so_t, T());
+        q.b1 = fz_bufload(r_tba, c1b, so_t, T());
+        const uint32_t so_r = (uint32_t)rc * wbytes;
+        q.rv = fz_bufload(r_ref, ob, so_r, T());
+        q.st = fz_bufload(r_st, ob, so_r, T());
+        q.bin = fz_bufload16(r_bin, ob2, (uint32_t)rc * wbytes2);
     };
     // sums of y^ and of the correction terms: float32 partial sums (y^, y^ y^ folded into float64 every NK_PF rows; the three
     // correction sums scale a term ~1e-3 of the total and stay float32 over the chunk)
@@ -1228,8 +1252,8 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
                 if (have == k0l) {
                     top = hl;
                 } else {  // chunk start, or a step of the tap row other than +1: fetch the upper row
-                    const T* up = tba + (int64_t)k0l * g.W;
-                    top = hlerp(*reinterpret_cast<const T*>(at(up, c0b)), *reinterpret_cast<const T*>(at(up, c1b)));
+                    const uint32_t so_u = tap_row(k0l);
+                    top = hlerp(fz_bufload(r_tba, c0b, so_u, T()), fz_bufload(r_tba, c1b, so_u, T()));
                 }
                 double bot = top;
                 if (fl & 2) bot = hlerp(b0v, b1v);
@@ -1260,14 +1284,15 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
                 // ---- the bin side: y^ with its margin against the bracket of the pixel's aspect bin
                 const T rr = fz_rcp(stv);
                 const T yh = (T)(out - vhat) * rr;
-                const T m = (T)(dgrow * rr) + (T)(fabs(yh) * FzEps<T>::rel) + FzEps<T>::tiny;
+                const T m = (T)(dgrow * rr) + (T)(fabs(yh) * FzEps<T>::rel);   // (m = 0 only for y^ = 0 under an exact v^: then y = 0 too)
                 const unsigned long long m_yb = m_ok & __builtin_amdgcn_ballot_w64(bin != (uint16_t)0xFFFF) & __builtin_amdgcn_ballot_w64(yh == yh);
                 const uint32_t binx = sel_mask(0u, (uint32_t)bin, m_yb);
                 const FzPair<T> lh = lohi[binx];
                 const unsigned long long m_nb = cm_nlt((T)(yh + m), lh.lo), m_na = cm_ngt((T)(yh - m), lh.hi);   // not certainly below / above
-                const uint32_t cls = sel_mask(1u, sel_mask(0u, 2u, m_na), m_nb);
+                // class row of this lane's counter copy: 0 above, 1 below, 2 candidate (the three row bases are loop-invariant)
+                const uint32_t rowa = sel_mask(cls_b, sel_mask(cls_a, cls_c, m_na), m_nb);
                 // (lanes without a bin add 0 to a word of their own: no exec mask, no same-address pile-up)
-                atomicAdd(sel_mask_ptr(dummy, &cc[__umul24(cls, (unsigned)nb) + binx], m_yb), sel_mask(0u, 1u, m_yb));
+                atomicAdd(lds_u32(sel_mask(dummy_a, rowa + (binx << 2), m_yb)), sel_mask(0u, 1u, m_yb));
                 const unsigned long long my = m_yb & m_nb & m_na;
                 if (my) {   // (uniform)
                     const int pos = sel_mask(trash, held_y + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(my >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)my, 0u)), my);

@@ -97,12 +97,11 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
     // Rebased keys ((key - lo) << s, select_run.h) have s zero bits at the bottom: a digit that lies entirely inside them is 0
     // for every element, its pass is skipped (hist_pass_kernel leaves at once) and the state moves on without a histogram.
     if (!first && rb_shift && shift + 8 <= (int)*rb_shift) {
-        if (last && lane == 0 && st[b].count) {
-            st[b].n_le += st[b].group;
-            if (need_succ) *need_succ = 1u;   // (no histogram of the last digit: the successor pass has to look)
-        }
+        if (last && lane == 0 && st[b].count) st[b].n_le += st[b].group;
         return;
     }
+    // the last digit that is not entirely inside the zero bits of rebased keys: every key's bits below it are zero
+    const bool eff_last = last || (rb_shift && shift <= (int)*rb_shift);
     uint64_t* h = hist + (size_t)b * SEL_RADIX;
     unsigned long long c[4], mine = 0;
 #pragma unroll
@@ -155,9 +154,9 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         s.rank -= cumsel;
         s.group = hsel;
         if (last) s.n_le += hsel;  // all digits fixed: group == the selected key's duplicates
-        if (last && succ) {
+        if (eff_last && succ) {
             // Round 4: the smallest key above the selected one usually shares its leading digits -- then it is the next non-empty
-            // bucket of THIS histogram (the last digit completes the key) and the successor pass over the elements has nothing
+            // bucket of THIS histogram (the last effective digit completes the key) and the successor pass over the elements has nothing
             // to do; only a selected key that is the largest of its group leaves the question to that pass (need_succ).
             int cand = 0x7fffffff;
 #pragma unroll

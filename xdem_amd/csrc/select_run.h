@@ -45,7 +45,7 @@ __device__ __forceinline__ uint64_t k_shfl_down(uint64_t v, int off) { return (u
 // low-entropy leading digit and serialise 64-way.  1024-thread workgroups so that even the 72 KB table of the
 // 72 aspect bins runs at full occupancy (2 workgroups = 32 waves per CU).
 constexpr int HIST_THREADS = 1024;
-constexpr int SEL_UNROLL = 8;   // elements per thread and step, all loads issued before the first use (4 in rounds 1-3)
+constexpr int SEL_UNROLL = 4;   // elements per thread and step, all loads issued before the first use (8 measured slower: r04e)
 
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
@@ -279,9 +279,12 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                 // every workgroup flushes a whole [rows][256] table with global atomics: with many rows and few elements (the 72-bin
                 // samples: 36 k counters against 24 k elements per workgroup) the flush IS the pass -- no more workgroups than give
                 // each of them two tables' worth of elements (at least 32)
+                // (the SECOND digit's pass: the first digit of float keys -- sign and exponent -- leaves most counters empty and from
+                // the third on few elements still match their prefix; measured on the 72-bin samples of the Nuth-Kaab step:
+                // 87 -> 55 us for that pass, the others lose when they get fewer workgroups)
                 int64_t g2 = n_grid / ((int64_t)2 * rows * SEL_RADIX);
                 g2 = g2 < 32 ? 32 : g2;
-                const int grid_p = (int)(g2 < grid ? g2 : grid);
+                const int grid_p = (p == 1 && g2 < grid) ? (int)g2 : grid;
                 hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_p), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
                                    st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift, dual ? nb_data : 0);
                 XD_HIP_CHECK(ctx, hipGetLastError());
