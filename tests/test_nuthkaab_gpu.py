@@ -892,3 +892,35 @@ def test_device_side_reductions_cost_little():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_onepass_step_hands_degenerate_rasters_to_the_two_pass_route(coreg):
+    """Round 4: the one-pass step stages the candidates of the median of dh in small per-wave segments (they are ~0.7 % of the
+    pixels on real pairs).  A pair whose dh is ONE value -- tba = ref + constant under a whole-pixel shift: every pixel lies
+    inside the bracket of the median -- overruns them by design: the step must notice (overflow flag), fall through to the
+    two-pass route and return exactly what the plain route returns."""
+    from xdem_amd.synth import fbm_numpy
+
+    ctx = coreg._lib.default_context()
+    H, W, res = 2304, 2200, 10.0
+    ref = fbm_numpy((H, W), seed=31, std=180.0)
+    tba = (ref + np.float32(1.25)).astype(np.float32)
+    tba[100:140, 300:900] = np.nan
+    got = {}
+    try:
+        for name, mode, fused in (("onepass", 3, 1), ("plain", 1, 0)):
+            ctx.set_option("selection", mode)
+            ctx.set_option("nk_fused", fused)
+            plan = coreg.NKPlan(ref, tba, None)
+            got[name] = [plan.step(sx, sy, (res, res), 8) for sx, sy in ((0.0, 0.0), (10.0, -20.0))]
+            rc = plan.route_counts()
+            plan.close()
+            if name == "onepass":
+                assert rc["onepass"] == 0 and rc["twopass"] + rc["plain"] == 2, rc
+    finally:
+        ctx.set_option("selection", 0)
+        ctx.set_option("nk_fused", 1)
+    for a, b in zip(got["onepass"], got["plain"]):
+        assert a["vshift"] == b["vshift"] and a["n_valid"] == b["n_valid"]
+        assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True)
+        assert np.array_equal(a["edges"], b["edges"])

@@ -14,6 +14,9 @@ import torch
 import bench
 from xdem_amd import _lib, coreg
 
+if os.environ.get("NK_LIB"):  # A/B of library builds across processes (measurement variants: xdem_amd/csrc/Makefile)
+    _lib.LIB_PATH = os.environ["NK_LIB"]
+
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda", 0)
@@ -26,5 +29,5 @@ for i in range(k):
     t0 = time.perf_counter()
     d = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
     dt = time.perf_counter() - t0
-    print(f"step {m}x{m}: {dt * 1e3:.3f} ms (n_valid {d['n_valid']}, vshift {d['vshift']:.6f})", flush=True)
+    print(f"[{os.path.basename(_lib.LIB_PATH)}] step {m}x{m}: {dt * 1e3:.3f} ms (n_valid {d['n_valid']}, vshift {d['vshift']:.6f})", flush=True)
 plan.close()

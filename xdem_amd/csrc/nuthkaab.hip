@@ -1067,14 +1067,30 @@ __global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, u
     }
 }
 
-constexpr int NKZ_ROWS = 2;      // rows between two looks at the staging buffers
+#ifndef XD_NKZ_ROWS      // (measurement builds override the two pipeline constants of the one-pass kernel)
+#define XD_NKZ_ROWS 8
+#endif
+#ifndef XD_NKZ_PF
+#define XD_NKZ_PF 4
+#endif
+#ifndef XD_NKZ_CAP      // staging slots of the bin candidates per workgroup (float32)
+#define XD_NKZ_CAP 1024
+#endif
+#ifndef XD_NKZ_LB       // workgroups per CU the register allocation aims at
+#define XD_NKZ_LB 7
+#endif
+#ifndef XD_NKZ_BUFFER   // 1: loads through buffer descriptors, 0: global loads from uniform row pointers + 32-bit offsets
+#define XD_NKZ_BUFFER 0
+#endif
+constexpr int NKZ_ROWS = XD_NKZ_ROWS;      // rows between two looks at the staging buffers
+constexpr int NKZ_PF = XD_NKZ_PF;          // rows of loads in flight per wave
 // staging slots per workgroup and kind (flushed once fewer than 2 x NKZ_ROWS rows would still fit; float64: static LDS stays < 48 KiB)
-template <typename T> struct NkzCap { static constexpr int v = sizeof(T) == 4 ? 2048 : 1024; };
+template <typename T> struct NkzCap { static constexpr int v = sizeof(T) == 4 ? XD_NKZ_CAP : 1024; };
 template <typename T> struct FzPair { T lo, hi; };
 
 constexpr int NKZ_CHUNK_MAX = 256;   // rows of a workgroup's chunk (row-tap table in LDS)
 template <typename T, int RULE>
-__global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
+__global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
                                                        const uint16_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
                                                        int nb, int copies, const typename KeyT<T>::type* __restrict__ klo_p,
                                                        const typename KeyT<T>::type* __restrict__ khi_p, const T* vhat_p, const T* delta_p,
@@ -1089,7 +1105,10 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
     constexpr int SEG = NKZ_CAP / 4;      // staging slots of ONE wave: waves reserve in their own segment with a scalar counter --
                                           // no LDS atomic with return and its round trip on the path of every row (bin candidates are
                                           // ~7 % of the pixels: practically every row of every wave holds some)
-    static_assert(SEG >= 2 * NKZ_ROWS * 64, "a flush check must leave room for NKZ_ROWS rows of candidates");
+    // (a look at the staging buffers every NKZ_ROWS rows, a flush when a segment is half full; a wave that would overrun its segment
+    // before the next look -- more than half of its pixels candidates over NKZ_ROWS rows: not a raster this route is for -- raises
+    // the overflow flag and the step falls through to the two-pass route)
+    static_assert(SEG >= 2 * 64, "a segment holds at least two rows of candidates");
     // candidates of the median of dh are ~0.7 % of the pixels (half a pixel per wave and row): their segments are small and a wave
     // that would overrun its segment between two looks -- more than half of its pixels inside the bracket of the median: a raster
     // of (nearly) one dh value -- raises the overflow flag, i.e. hands the step to the two-pass route, which is built for that
@@ -1205,7 +1224,7 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
     int have = -1;
     double hl = 0.0;
     struct Pre { T b0, b1, rv, st; uint16_t bin; };
-    Pre pre[NK_PF];
+    Pre pre[NKZ_PF];
     // (wave-uniform, and said so: the descriptors below must sit in scalar registers -- a descriptor the compiler takes for
     // lane-varying is read back lane by lane in a loop around every load)
     const uint64_t rb0_u = (uint64_t)((i0 - g.roff) * g.W);
@@ -1214,16 +1233,19 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
     // buffer descriptors: the three rasters indexed by the output pixel from the chunk's first row, tba from the chunk's first
     // tap row (tap rows ascend with the output row; rows whose taps leave the raster are discarded anyway and read row k_base)
     const int k_base = __builtin_amdgcn_readfirstlane((tab[0].flags & 1) ? tab[0].k0l : 0);
+#if XD_NKZ_BUFFER
     const __amdgpu_buffer_rsrc_t r_tba = fz_rsrc(tba + (int64_t)k_base * g.W);
     const __amdgpu_buffer_rsrc_t r_ref = fz_rsrc(ref + rb0);
     const __amdgpu_buffer_rsrc_t r_st = fz_rsrc(slope_tan + rb0);
     const __amdgpu_buffer_rsrc_t r_bin = fz_rsrc(bcache + rb0);
+#endif
     const uint32_t wbytes = (uint32_t)g.W * (uint32_t)sizeof(T), wbytes2 = (uint32_t)g.W * 2u;
     const uint32_t ob = jl * (uint32_t)sizeof(T), ob2 = jl * 2u;
     auto tap_row = [&](int k) -> uint32_t { return (uint32_t)((k > k_base ? k : k_base) - k_base) * wbytes; };   // (scalar)
     auto issue = [&](int rr, Pre& q) {  // rows past the chunk repeat its last row
         const int rc = rr < nrow ? rr : nrow - 1;
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
+#if XD_NKZ_BUFFER
         const uint32_t so_t = tap_row(tk + ((tf >> 1) & 1));
         q.b0 = fz_bufload(r_tba, c0b, so_t, T());
         q.b1 = fz_bufload(r_tba, c1b, so_t, T());
@@ -1231,29 +1253,43 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
         q.rv = fz_bufload(r_ref, ob, so_r, T());
         q.st = fz_bufload(r_st, ob, so_r, T());
         q.bin = fz_bufload16(r_bin, ob2, (uint32_t)rc * wbytes2);
+#else
+        const char* rowp = reinterpret_cast<const char*>(tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W);
+        q.b0 = __builtin_nontemporal_load(reinterpret_cast<const T*>(rowp + c0b));
+        q.b1 = __builtin_nontemporal_load(reinterpret_cast<const T*>(rowp + c1b));
+        const uint32_t o_b = (uint32_t)rc * wbytes + ob;
+        q.rv = __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(ref + rb0) + o_b));
+        q.st = __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(slope_tan + rb0) + o_b));
+        q.bin = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(bcache + rb0) + ((uint32_t)rc * wbytes2 + ob2)));
+#endif
     };
-    // sums of y^ and of the correction terms: float32 partial sums (y^, y^ y^ folded into float64 every NK_PF rows; the three
+    // sums of y^ and of the correction terms: float32 partial sums (y^, y^ y^ folded into float64 every NKZ_PF rows; the three
     // correction sums scale a term ~1e-3 of the total and stay float32 over the chunk)
     float p_y = 0.0f, p_yy = 0.0f, p_r = 0.0f, p_yr = 0.0f, p_rr = 0.0f;
     double a_y = 0.0, a_yy = 0.0;
 #pragma unroll
-    for (int u = 0; u < NK_PF; ++u) issue(u, pre[u]);
-    for (int r0 = 0; r0 < nrow; r0 += NK_PF) {
+    for (int u = 0; u < NKZ_PF; ++u) issue(u, pre[u]);
+    for (int r0 = 0; r0 < nrow; r0 += NKZ_PF) {
 #pragma unroll
-        for (int u = 0; u < NK_PF; ++u) {
+        for (int u = 0; u < NKZ_PF; ++u) {
             const int r = r0 + u;
             if (r < nrow) {   // (uniform)
                 const T b0v = pre[u].b0, b1v = pre[u].b1, rv = pre[u].rv, stv = pre[u].st;
                 const uint16_t bin = pre[u].bin;
-                issue(r + NK_PF, pre[u]);
+                issue(r + NKZ_PF, pre[u]);
                 const int k0l = __builtin_amdgcn_readfirstlane(tab[r].k0l), fl = __builtin_amdgcn_readfirstlane(tab[r].flags);
                 const double fr = tab[r].fr;
                 double top;
                 if (have == k0l) {
                     top = hl;
                 } else {  // chunk start, or a step of the tap row other than +1: fetch the upper row
+#if XD_NKZ_BUFFER
                     const uint32_t so_u = tap_row(k0l);
                     top = hlerp(fz_bufload(r_tba, c0b, so_u, T()), fz_bufload(r_tba, c1b, so_u, T()));
+#else
+                    const char* up = reinterpret_cast<const char*>(tba + (int64_t)k0l * g.W);
+                    top = hlerp(*reinterpret_cast<const T*>(up + c0b), *reinterpret_cast<const T*>(up + c1b));
+#endif
                 }
                 double bot = top;
                 if (fl & 2) bot = hlerp(b0v, b1v);
@@ -1295,16 +1331,21 @@ __global__ __launch_bounds__(256, 5) void nk_fused_kernel(const T* __restrict__ 
                 atomicAdd(lds_u32(sel_mask(dummy_a, rowa + (binx << 2), m_yb)), sel_mask(0u, 1u, m_yb));
                 const unsigned long long my = m_yb & m_nb & m_na;
                 if (my) {   // (uniform)
-                    const int pos = sel_mask(trash, held_y + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(my >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)my, 0u)), my);
-                    seg_yd[pos] = out; seg_ys[pos] = stv; seg_yb[pos] = bin;
-                    held_y += __popcll(my);
+                    const int cn = __popcll(my);
+                    if (held_y + cn <= SEG) {   // (uniform)
+                        const int pos = sel_mask(trash, held_y + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(my >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)my, 0u)), my);
+                        seg_yd[pos] = out; seg_ys[pos] = stv; seg_yb[pos] = bin;
+                        held_y += cn;
+                    } else if (lane == 0) {
+                        ctr[2] = 1ull;
+                    }
                 }
                 const float yf = sel_mask(0.0f, (float)yh, m_ok), rf = sel_mask(0.0f, (float)rr, m_ok);
                 p_y += yf; p_yy = fmaf(yf, yf, p_yy);
                 p_r += rf; p_yr = fmaf(yf, rf, p_yr); p_rr = fmaf(rf, rf, p_rr);
             }
             // (r is uniform over the workgroup: every wave walks the same rows) room for NKZ_ROWS more rows must remain
-            if (((r + 1) % NKZ_ROWS) == 0 && r + 1 < nrow) block_flush(SEG - 2 * NKZ_ROWS * 64);
+            if (((r + 1) % NKZ_ROWS) == 0 && r + 1 < nrow) block_flush(SEG / 2);
         }
         a_y += (double)p_y; a_yy += (double)p_yy;
         p_y = 0.0f; p_yy = 0.0f;
