@@ -30,7 +30,8 @@ import sys
 
 import numpy as np
 
-GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 
 def pin_interp() -> str | None:
@@ -137,7 +138,55 @@ def pin_subsample() -> str | None:
     return path
 
 
+def decide() -> str | None:
+    """From the recorded fixtures: WHICH of the switchable conventions reproduce the packages -- written to
+    xdem_amd/thirdparty_decision.json, which the product reads its defaults of "nk_nan_rule", "vario_edge", "vario_diff" from
+    when the file is present (xdem_amd/_lib.py: thirdparty_decision).  The lowest-numbered matching value wins; a convention
+    none of the values reproduces is left out (the built-in default stays, and tests/test_thirdparty_pins.py fails)."""
+    import json
+
+    sys.path.insert(0, HERE)
+    golden = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    out = {}
+    p_i = os.path.join(golden, "thirdparty_interp.npz")
+    if os.path.exists(p_i):
+        import nuthkaab_oracle as nko
+
+        z = np.load(p_i)
+        dem, res = z["dem"], float(z["res"])
+        for rule in (0, 1, 2, 3):
+            ok = True
+            for k in range(6):
+                sx, sy = z[f"shift{k}"]
+                got = nko.bilinear_shifted(dem, -sy / res, sx / res, nan_rule=rule)
+                ok &= bool(np.array_equal(np.isnan(got), np.isnan(z[f"vals{k}"])) and np.allclose(got, z[f"vals{k}"], rtol=1e-6, atol=0, equal_nan=True))
+            if ok:
+                out["nk_nan_rule"] = rule
+                break
+    p_s = os.path.join(golden, "thirdparty_skgstat.npz")
+    if os.path.exists(p_s):
+        import variogram_oracle as vo
+
+        z = np.load(p_s)
+        coords, values, edges = z["coords"], z["values"], [float(e) for e in z["edges"]]
+        for right_closed in (False, True):
+            for diff_f64 in (False, True):
+                ok = True
+                for est in ("matheron", "cressie", "dowd"):
+                    e, c = vo.empirical_variogram_blocks([(coords[:, 0], coords[:, 1], values)], edges, est, right_closed=right_closed, diff_f64=diff_f64)
+                    ok &= bool(np.array_equal(c, z[f"count_{est}_float32"]) and np.allclose(e, z[f"exp_{est}_float32"], rtol=1e-9, equal_nan=True))
+                if ok and "vario_edge" not in out:
+                    out["vario_edge"], out["vario_diff"] = int(right_closed), int(diff_f64)
+    if not out:
+        return None
+    out["_source"] = "oracle/pin_thirdparty.py: decided from tests/golden/thirdparty_*.npz"
+    path = os.path.join(os.path.dirname(HERE), "xdem_amd", "thirdparty_decision.json")
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    return path
+
+
 if __name__ == "__main__":
     made = [p for p in (pin_interp(), pin_skgstat(), pin_subsample()) if p]
     print("written:", made if made else "nothing (packages absent)")
+    print("decision file:", decide() or "none (no fixture to decide from: the built-in defaults stay)")
     sys.exit(0)

@@ -100,3 +100,23 @@ def test_geoutils_subsample_array_draw():
         want = np.zeros(arr.shape, dtype=bool)
         want[z[f"rows{k}"], z[f"cols{k}"]] = True
         assert np.array_equal(got, want), (name, subsample, seed)
+
+
+def test_defaults_follow_the_decision_file():
+    """Round 4: where oracle/pin_thirdparty.py could decide a convention from the packages' own outputs it writes
+    xdem_amd/thirdparty_decision.json and every context takes its defaults from there.  CPU check of the mechanism: the file, if
+    present, holds values in range for known options only, `_lib.thirdparty_decision()` returns exactly them, and the built-in
+    defaults are the documented ones (0 / 0 / 0: include/xdemhip.h)."""
+    import json
+
+    from xdem_amd import _lib
+
+    assert _lib.THIRDPARTY_DEFAULTS == {"nk_nan_rule": 0, "vario_edge": 0, "vario_diff": 0}
+    path = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "thirdparty_decision.json")
+    got = _lib.thirdparty_decision()
+    if not os.path.exists(path):
+        assert got == {}
+        return
+    raw = json.load(open(path))
+    assert set(k for k in raw if not k.startswith("_")) <= set(_lib.THIRDPARTY_DEFAULTS), raw
+    assert got == {k: int(v) for k, v in raw.items() if k in _lib.THIRDPARTY_DEFAULTS}

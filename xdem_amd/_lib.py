@@ -20,6 +20,31 @@ _lib = None
 _lock = threading.Lock()
 
 
+# Conventions of the two un-vendored third-party engines that nothing readable offline pins (DESIGN.md sections 2-3): built-in
+# defaults, overridden by xdem_amd/thirdparty_decision.json where oracle/pin_thirdparty.py could decide them from the packages' own
+# outputs.  What the best available evidence favours for each is stated in DESIGN.md; none of it is a measurement made here.
+THIRDPARTY_DEFAULTS = {"nk_nan_rule": 0, "vario_edge": 0, "vario_diff": 0}
+_THIRDPARTY_RANGE = {"nk_nan_rule": (0, 3), "vario_edge": (0, 1), "vario_diff": (0, 1)}
+
+
+def thirdparty_decision() -> dict:
+    """The decided conventions (subset of THIRDPARTY_DEFAULTS' keys) from thirdparty_decision.json next to this file; {} if absent."""
+    import json
+
+    path = os.path.join(HERE, "thirdparty_decision.json")
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    out = {}
+    for k, (lo, hi) in _THIRDPARTY_RANGE.items():
+        if k in d:
+            v = int(d[k])
+            if not lo <= v <= hi:
+                raise ValueError(f"{path}: {k} = {v} outside {lo}..{hi}")
+            out[k] = v
+    return out
+
+
 class XdemHipError(RuntimeError):
     """Raised for any non-zero status from libxdemhip.so."""
 
@@ -241,6 +266,9 @@ class Context:
         self._pool: list[tuple[int, int, int]] = []   # (nbytes, flags, ptr)
         self._pool_cap = int(float(os.environ.get("XDEM_PLANE_POOL_GB", "16")) * (1 << 30))
         self._pool_lock = threading.Lock()
+        for k, v in thirdparty_decision().items():   # conventions decided from the third-party packages' own outputs, where recorded
+            if v != THIRDPARTY_DEFAULTS[k]:
+                self.set_option(k, v)
         self.options: dict[str, int] = {}  # mirror of the xdemhip_set_option calls made through this object
 
     def check(self, rc: int) -> None:
