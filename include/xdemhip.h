@@ -299,6 +299,14 @@ int xdemhip_pairs_succ(xdemhip_pairs* pairs, const uint64_t* key, uint64_t* succ
  * with the plain 4 (float32) / 8 (float64) digit passes + successor pass as the fall-back and for small sets.  Histograms,
  * counters and successor keys go through the xdemhip_set_allreduce hook when the pair blocks are sharded over GPUs. */
 int xdemhip_pairs_medians(xdemhip_pairs* pairs, int64_t* counts, double* medians);
+/* Tell `pairs` that `sorted` holds THE SAME blocks (same sizes, value dtype, edges, context) with the points of every block
+ * in an order in which neighbouring slots are neighbouring points (Morton order): the one pass of xdemhip_pairs_medians that
+ * visits every pair -- counting against the brackets and compacting the candidates -- then reads `sorted`'s points and
+ * counts run-length (a lane touches its LDS counters once per run of equal lag class instead of once per pair).  Counts,
+ * candidates and medians do not depend on the slot order.  The sampled digit passes keep `pairs`' own order (their
+ * statistics assume unsorted tiles).  `sorted` is not owned and must outlive the calls; NULL (or `pairs` itself) unlinks.
+ * Context option "vario_runs" = 0 ignores the link. */
+int xdemhip_pairs_link_sorted(xdemhip_pairs* pairs, xdemhip_pairs* sorted);
 void xdemhip_pairs_destroy(xdemhip_pairs* pairs);
 
 /* ---- next row 8f-3: N-dimensional binned statistics ---------------------------------------------------------------

@@ -278,6 +278,14 @@ def test_C5_sampler_geometry_lattice_bracket_kernels(ss):
                     s_cap, c_cap = ps.sums(0)
                     ctx.set_option("pairs_launch_cap", 0)
                     assert np.array_equal(c_cap, c_m) and np.allclose(s_cap, s_m, rtol=1e-12, atol=0)
+                    # the counting pass per pair on the sorted copy (round 3's form) instead of run-length (round 4)
+                    ctx.set_option("vario_runs", 0)
+                    res["per-pair counters"] = ss.class_medians(ps)
+                    ctx.set_option("vario_runs", 1)
+                    # ... and on the caller's order (no sorted copy linked)
+                    ctx.check(ctx._L.xdemhip_pairs_link_sorted(ps.handle_sel, None))
+                    res["unlinked"] = ss.class_medians(ps)
+                    ctx.check(ctx._L.xdemhip_pairs_link_sorted(ps.handle_sel, ps.handle))
                 res[("sums", grid)] = (s_m, c_m)
             finally:
                 ps.close()
@@ -285,6 +293,7 @@ def test_C5_sampler_geometry_lattice_bracket_kernels(ss):
         ctx.set_option("vario_grid", 1)
         ctx.set_option("selection", 0)
         ctx.set_option("pairs_launch_cap", 0)
+        ctx.set_option("vario_runs", 1)
     med0, cnt0 = res[(1, 0)]
     for k, (med, cnt) in res.items():
         if k[0] == "sums":
@@ -549,6 +558,27 @@ def test_morton_ordered_copy_equals_callers_order(ss, estimator):
         assert np.array_equal(got[1][1], co)
         ok = np.isfinite(eo)
         assert np.allclose(got[1][0][ok], eo[ok], rtol=1e-12, atol=0)
+
+
+def test_link_sorted_refuses_a_different_pair_set(ss):
+    """xdemhip_pairs_link_sorted: the companion must hold the same blocks (sizes, dtype, edges); anything else is refused and
+    the set stays unlinked."""
+    from xdem_amd import _lib
+
+    rng = np.random.default_rng(5)
+    mk = lambda na, nbp: (rng.uniform(0, 100, na), rng.uniform(0, 100, na), rng.normal(size=na).astype(np.float32),
+                          rng.uniform(0, 100, nbp), rng.uniform(0, 100, nbp), rng.normal(size=nbp).astype(np.float32))
+    edges = np.linspace(10, 150, 8)
+    ctx = _lib.default_context()
+    a, b, c = ss.PairSet([mk(300, 500)], edges, ctx), ss.PairSet([mk(300, 501)], edges, ctx), ss.PairSet([mk(300, 500)], edges * 1.5, ctx)
+    try:
+        for other in (b, c):
+            assert ctx._L.xdemhip_pairs_link_sorted(a.handle_sel, other.handle_sel) == -1  # XDEMHIP_EINVAL
+        assert ctx._L.xdemhip_pairs_link_sorted(a.handle_sel, a.handle) == 0
+        med, cnt = ss.class_medians(a)
+        assert cnt.sum() > 0
+    finally:
+        a.close(); b.close(); c.close()
 
 
 def test_lattice_path_refuses_what_it_cannot_represent(ss):

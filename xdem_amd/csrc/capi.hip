@@ -280,6 +280,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->vario_sort = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "vario_runs") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "vario_runs: 0 or 1");
+        ctx->vario_runs = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "vario_deff") {  // 0 = built-in (select.h: PAIR_DEFF_*); brackets too narrow for the data fall back to wider ones
         if (value < 0 || value > (1 << 20)) return xd_fail(ctx, XDEMHIP_EINVAL, "vario_deff: 0 .. 2^20");
         ctx->vario_deff = value;

@@ -90,6 +90,7 @@ template <typename T> struct PairArgs {
     uint16_t* cand_b;              // and their class
     unsigned long long* cand_ctr;  // [0] count, [1] overflow flag
     long long cand_cap;
+    int runs;                      // OP_BRACKET on the lattice: the points come in Morton order (xdemhip_pairs_link_sorted) -- run-length counting
 };
 
 // Sampled digit passes (bracketed selection): EVERY (A tile x B tile) unit contributes exactly 1/64 of its pairs.  (Round 2
@@ -138,6 +139,14 @@ __device__ __forceinline__ double select_by_mask(double a, double b, unsigned lo
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// n + (mask bit of this lane): one v_addc with the lane mask as the carry-in
+__device__ __forceinline__ uint32_t add_mask_bit(uint32_t n, unsigned long long mask) {
+    uint32_t r;
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(n), "s"(mask));
+    return r;
+}
+
 // GRID (implies FAST): the points lie on an integer lattice (raster pixel centres -- the reference's cdist / pdist samplers
 // draw raster pixels, xdem/spatialstats.py:1413-1416): coordinates are packed int16 lattice indexes, the squared lattice
 // distance of a pair is ONE v_pk_sub_i16 + ONE v_dot2_i32_i16, exact in 32 bits, and the class follows from integer
@@ -179,8 +188,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     // interleaved {low, high} per class (one 8 / 16-byte read per pair; the spare class holds {all-ones, 0}: always "below",
     // never a candidate), then the staging buffer
     K* s_lh = reinterpret_cast<K*>(s_c3 + (a.nb + 1) * NCOPY);
+    // ... and the same ends as VALUES {low, high} per class for the run-length loop (float compares of |dv|; an end whose bits are
+    // no number compares false with everything, which is what an unreachable end means)
+    T* s_lhf = reinterpret_cast<T*>(s_lh + 2 * (a.nb + 1));
     if (OP == OP_BRACKET) {
-        stage.v = reinterpret_cast<T*>(s_lh + 2 * (a.nb + 1));
+        stage.v = s_lhf + 2 * (a.nb + 1);
         stage.b = reinterpret_cast<uint16_t*>(stage.v + SEL_STAGE_CAP);
         stage.base = reinterpret_cast<unsigned long long*>(stage.b + SEL_STAGE_CAP);
         stage.held = reinterpret_cast<int*>(stage.base + 1);
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     __shared__ uint2 s_lut2[GRID ? LUT_G : 1];
     // sums on the lattice (round 4): {class of the cell's lower bound c, threshold c, threshold c - 1 (0 for c = 0), threshold c + 1}: the
     // class of a d^2 AND the d^2 interval of that class from one 16-byte read (see the run-length loop)
-    __shared__ uint4 s_lut4[(GRID && (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)) ? LUT_G : 1];
+    __shared__ uint4 s_lut4[(GRID && (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT || OP == OP_BRACKET)) ? LUT_G : 1];
     const int tid = threadIdx.x;
     if (FAST)  // (NT may be smaller than the table: round 1 loaded only its first NT entries -- wrong classes beyond 32 binades of d^2)
         for (int k = tid; k < (GRID ? LUT_G : LUT_N); k += NT) s_lut[k] = GRID ? a.lut_i[k] : a.lut[k];
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         for (int k = tid; k < LUT_G; k += NT) {
             const uint32_t c = a.lut_i[k];
             s_lut2[k] = make_uint2(c, c < (uint32_t)a.nb ? a.thr_i[c] : 0xFFFFFFFFu);
-            if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT)
+            if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT || OP == OP_BRACKET)
                 s_lut4[k] = make_uint4(c, c < (uint32_t)a.nb ? a.thr_i[c] : 0xFFFFFFFFu, (c > 0 && c - 1 < (uint32_t)a.nb) ? a.thr_i[c - 1] : (c > 0 ? 0xFFFFFFFFu : 0u),
                                        c + 1 < (uint32_t)a.nb ? a.thr_i[c + 1] : 0xFFFFFFFFu);
         }
@@ -232,8 +244,17 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         // ceil(lo / 2), key <= hi <=> bits <= floor(hi / 2); the spare class gets an unreachable low end)
         for (int k = tid; k <= a.nb; k += NT) {
             const K lo = k < a.nb ? a.prefix[k] : ~(K)0, hi = k < a.nb ? a.khi[k] : (K)0;
-            s_lh[2 * k] = (K)((lo >> 1) + (lo & 1));
-            s_lh[2 * k + 1] = (K)(hi >> 1);
+            const K lo_h = (K)((lo >> 1) + (lo & 1)), hi_h = (K)(hi >> 1);
+            s_lh[2 * k] = lo_h;
+            s_lh[2 * k + 1] = hi_h;
+            // (lo_h can be 2^(bits - 1) -- the bit pattern of -0 -- when the low end is unreachable: NaN, never >= anything)
+            K lo_bits = lo_h, hi_bits = hi_h;
+            if (lo_h >> (8 * sizeof(K) - 1)) lo_bits = (K)~(K)0 >> 1;
+            T lo_f, hi_f;
+            __builtin_memcpy(&lo_f, &lo_bits, sizeof(T));
+            __builtin_memcpy(&hi_f, &hi_bits, sizeof(T));
+            s_lhf[2 * k] = lo_f;
+            s_lhf[2 * k + 1] = hi_f;
         }
         for (int k = tid; k < (a.nb + 1) * NCOPY; k += NT) s_c3[k] = 0ull;
         if (tid == 0) *stage.held = 0;
@@ -246,6 +267,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     uint32_t run_start = 0;    // position (count of plain-tile pairs so far, the same for every lane) at which the lane's run began
     uint32_t run_pos = 0;      // ... and the current position: a run's length is their difference, no per-pair counter
     uint32_t run_lo = 1u, run_w = 0u;   // GRID: d^2 interval of the run's class (empty: the first pair looks its class up)
+    uint32_t run_ge = 0u, run_gt = 0u;  // OP_BRACKET runs: pairs of the run at or above the bracket's low end / above its high end
+    T run_blo = (T)0, run_bhi = (T)0;   // ... and the bracket of the run's class
     // One workgroup = one (A tile x B chunk) unit, except in the SAMPLED digit passes: there a unit is 16 tile loads and 16 k pairs,
     // while zeroing and flushing the [classes][256] LDS tables costs ~25 k LDS writes and thousands of global atomics -- a
     // resident set of workgroups therefore walks over all units (grid-stride) and flushes once.
@@ -578,6 +601,63 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                         }
                         continue;
                     }
+                    if constexpr (OP == OP_BRACKET && GRID) {
+                        // Round 4: run-length counting.  With the points in Morton order a lane's pairs stay in one lag class for ~20
+                        // pairs at a stretch: the lane keeps the class's d^2 interval and bracket in registers and counts in registers
+                        // (two compares of |dv| against the bracket ends, two carry adds); the packed LDS counter gets ONE ds_add_u64
+                        // per run instead of one per pair, and the class lookup and the read of the bracket ends happen once per run
+                        // (19 -> 9 vector instructions and 4 -> 2 LDS operations per pair that stays in its class).
+                        if (a.runs && cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT) && (ta + 1) * (int64_t)NT <= na) {
+                            static_assert(NCOPY * 8 == 256, "counter records are 256 bytes");
+                            unsigned char* const c3_mine = reinterpret_cast<unsigned char*>(s_c3 + (tid & (NCOPY - 1)));
+                            for (int j = 0; j < PT; j += 4) {
+                                uint32_t d2[4];
+                                T dv[4];
+    #pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                                    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
+                                    dv[u] = pv - s_bv[j + u];
+                                }
+    #pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    if (!((uint32_t)(d2[u] - run_lo) < run_w)) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
+                                        const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
+                                        const uint4 e = s_lut4[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
+                                        const bool up = e.y <= d2[u];
+                                        const unsigned long long inc = (unsigned long long)(run_pos - run_start) | ((unsigned long long)run_ge << 21) |
+                                                                       ((unsigned long long)run_gt << 42);
+                                        atomicAdd(reinterpret_cast<unsigned long long*>(c3_mine + ((uint32_t)run_l << 8)), inc);
+                                        run_l = (int)e.x + (up ? 1 : 0);
+                                        run_ge = run_gt = 0u;
+                                        run_start = run_pos;
+                                        run_lo = up ? e.y : e.z;
+                                        run_w = (up ? e.w : e.y) - run_lo;
+                                        run_blo = s_lhf[2 * run_l];
+                                        run_bhi = s_lhf[2 * run_l + 1];
+                                    }
+                                    const T ad = sizeof(T) == 4 ? (T)__builtin_fabsf((float)dv[u]) : (T)__builtin_fabs((double)dv[u]);
+                                    const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ad >= run_blo);
+                                    const unsigned long long m_gt = __builtin_amdgcn_ballot_w64(ad > run_bhi) & m_ge;   // (an empty bracket, hi < lo: everything below or above)
+                                    run_ge = add_mask_bit(run_ge, m_ge);
+                                    run_gt = add_mask_bit(run_gt, m_gt);
+                                    const unsigned long long in = m_ge & ~m_gt;
+                                    if (in != 0) {   // (wave-uniform: a fifth of the wave-pairs hold a candidate)
+                                        if (__builtin_expect((in & pend_m) != 0, 0)) flush_pending();
+                                        const unsigned long long take = in & ~pend_m;
+                                        pend_v = select_by_mask(pend_v, ad, take);
+                                        pend_l = select_by_mask(pend_l, (uint32_t)run_l, take);
+                                        pend_m |= take;
+                                    }
+                                    run_pos += 1;
+                                }
+                                if ((j & 12) == 12) flush_pending();
+                                if ((j & 63) == 60 && j + 4 < PT)
+                                    stage.sync_and_flush_at(SEL_STAGE_CAP / 4, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+                            }
+                            continue;
+                        }
+                    }
                     auto run4 = [&](auto plain_tag) {
                         constexpr bool PLAIN = decltype(plain_tag)::value;  // every slot of the tile is a pair: no index / diagonal / NaN tests
                         const int jbeg = spread ? 0 : jslot;
@@ -700,6 +780,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
         atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_pos - run_start);
     }
+    if (OP == OP_BRACKET && run_pos != run_start) {   // (run-length counting: the open run of every lane)
+        const unsigned long long inc = (unsigned long long)(run_pos - run_start) | ((unsigned long long)run_ge << 21) | ((unsigned long long)run_gt << 42);
+        atomicAdd(s_c3 + (size_t)run_l * NCOPY + (tid & (NCOPY - 1)), inc);
+    }
     __syncthreads();
     if (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT) {
         for (int k = tid; k < nb; k += NT) {
@@ -772,6 +856,10 @@ struct xdemhip_pairs {
     void* cand_v = nullptr;
     uint16_t* cand_b = nullptr;
     long long cand_cap = 0;
+    // the same pair set with the points of every block in Morton order (xdemhip_pairs_link_sorted; not owned): the counting pass
+    // of the bracketed selection reads its points
+    xdemhip_pairs* sorted = nullptr;
+    std::vector<int64_t> h_a_off, h_b_off;   // host copies of the block offsets (link check)
 };
 
 namespace {
@@ -782,7 +870,7 @@ template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
     size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8 + 4 * (size_t)(PT + nb + 4);
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
     if (op == OP_BRACKET)
-        return base + (size_t)(nb + 1) * NCOPY * 8 + 2 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 8 +
+        return base + (size_t)(nb + 1) * NCOPY * 8 + 4 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 8 +
                (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
     return base + (size_t)(nb + 1) * NCOPY * 12;
@@ -808,6 +896,15 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     a.has_nan = P->has_nan;
     a.khi = static_cast<const typename KeyT<T>::type*>(P->khi);
     a.cnt3 = P->cnt3; a.cand_v = static_cast<T*>(P->cand_v); a.cand_b = P->cand_b; a.cand_ctr = P->cand_ctr; a.cand_cap = P->cand_cap;
+    a.runs = 0;
+    if (OP == OP_BRACKET && P->sorted && ctx->vario_runs != 0) {
+        // same blocks, same offsets, other slot order: counts and candidates are the same multiset
+        const xdemhip_pairs* S = P->sorted;
+        a.ax = S->ax; a.ay = S->ay; a.bx = S->bx; a.by = S->by;
+        a.av = static_cast<const T*>(S->av); a.bv = static_cast<const T*>(S->bv);
+        a.a_xy = S->a_xy; a.b_xy = S->b_xy;
+        a.runs = 1;
+    }
     const size_t lds = lds_bytes<T>(P->nb, OP, (OP == OP_HIST && P->dual) ? 2 * nbs : nbs);
     const int64_t n_wg = (NT == 1024) ? P->n_wg_big : P->n_wg;
     // HIP dispatches carry the TOTAL work-item count of a dimension in 32 bits (a larger grid x block product is silently
@@ -1015,6 +1112,8 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     P->n_wg = wg[n_blocks];
     P->n_wg_big = wgb[n_blocks];
     P->n_pairs = pairs;
+    P->h_a_off.assign(a_off, a_off + n_blocks + 1);
+    if (!pd) P->h_b_off.assign(b_off, b_off + n_blocks + 1);
     std::vector<double> thr(n_bins);
     // context option "vario_edge": 0 = classes [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]
     for (int k = 0; k < n_bins; ++k) thr[k] = ctx->vario_edge ? sq_threshold_strict(right_edges[k]) : sq_threshold(right_edges[k]);
@@ -1106,6 +1205,26 @@ int xdemhip_pairs_create(xdemhip_ctx* ctx, int n_blocks, const int64_t* a_off, c
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "upload failed");
     if (n_pairs) *n_pairs = pairs;
     *out = P;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_pairs_link_sorted(xdemhip_pairs* P, xdemhip_pairs* sorted) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (sorted == P) sorted = nullptr;
+    if (sorted) {
+        if (sorted->ctx != ctx || sorted->val_dtype != P->val_dtype || sorted->nblk != P->nblk || sorted->nb != P->nb ||
+            sorted->pdist != P->pdist || sorted->grid != P->grid || sorted->h_a_off != P->h_a_off || sorted->h_b_off != P->h_b_off ||
+            sorted->has_nan != P->has_nan)
+            return xd_fail(ctx, XDEMHIP_EINVAL, "pairs_link_sorted: the two sets must hold the same blocks (sizes, dtype, edges, context)");
+        std::vector<double> t0(P->nb), t1(P->nb);
+        XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        XD_HIP_CHECK(ctx, hipMemcpy(t0.data(), P->thr, 8 * (size_t)P->nb, hipMemcpyDeviceToHost));
+        XD_HIP_CHECK(ctx, hipMemcpy(t1.data(), sorted->thr, 8 * (size_t)P->nb, hipMemcpyDeviceToHost));
+        if (memcmp(t0.data(), t1.data(), 8 * (size_t)P->nb) != 0)
+            return xd_fail(ctx, XDEMHIP_EINVAL, "pairs_link_sorted: the two sets must hold the same lag edges");
+    }
+    P->sorted = sorted;
     return XDEMHIP_OK;
 }
 

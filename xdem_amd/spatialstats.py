@@ -77,9 +77,11 @@ class PairSet:
         #    (Matheron / Cressie): the pair kernels accumulate run-length, a lane keeps the sum of its current lag class in
         #    registers and touches the LDS accumulators only when the class changes, and consecutive B points of one
         #    neighbourhood mostly share the class (2.1 -> 2.7 Tpairs/s on SURVEY 8d's C5 input);
-        #  * `handle_sel` -- the caller's order for the exact-median selection (Dowd): its counting pass compacts the pairs
-        #    inside the brackets through a small staging buffer, and spatially sorted tiles of a correlated field fall into a
-        #    bracket wholesale (measured: 88 -> 590 ms).
+        #  * `handle_sel` -- the caller's order for the exact-median selection (Dowd): the SAMPLED digit passes that place the
+        #    brackets assume tiles that are no spatial clusters.  The one pass over all pairs (counting against the brackets,
+        #    compacting the candidates) reads the Morton copy through ``xdemhip_pairs_link_sorted`` and counts run-length
+        #    (round 4; round 2 measured 88 -> 590 ms for that pass on sorted tiles when the brackets held 5 % of the pairs and the
+        #    staging buffer had no spill path -- both changed since).
         # Counts and medians do not depend on the order; float64 sums agree to rounding.  Option "vario_sort" = 0: one copy.
         cat = lambda bl, i, dt: np.ascontiguousarray(np.concatenate([np.asarray(b[i], dtype=dt).ravel() for b in bl]))
         off = lambda i: np.ascontiguousarray(np.concatenate([[0], np.cumsum([np.asarray(b[i]).size for b in blocks])]), dtype=np.int64)
@@ -109,6 +111,8 @@ class PairSet:
                 self.close()
                 raise
             assert n2 == self.n_pairs
+            # the selection's one pass over all pairs reads the sorted copy (run-length counters, csrc/variogram.hip)
+            self.ctx.check(self.ctx._L.xdemhip_pairs_link_sorted(self.handle_sel, self.handle))
         else:
             self.handle = self.handle_sel
 
@@ -135,6 +139,8 @@ class PairSet:
 
     def close(self) -> None:
         h, hs = getattr(self, "handle", None), getattr(self, "handle_sel", None)
+        if hs and h and hs.value != h.value:
+            self.ctx._L.xdemhip_pairs_link_sorted(hs, None)
         if h:
             self.ctx._L.xdemhip_pairs_destroy(h)
         if hs and (not h or hs.value != h.value):
