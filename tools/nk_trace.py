@@ -22,6 +22,8 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda", 0)
 ref, tba = bench._c3_pair(dev, m)
 ctx = _lib.default_context(0)
+if os.environ.get("NK_NARROW"):   # sample brackets of the one-pass step: -1 adaptive (default), 0 / 1 / 2 fixed
+    ctx.set_option("nk_narrow", int(os.environ["NK_NARROW"]))
 plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
 plan.step(0.0, 0.0, (10.0, 10.0), 72)
 for i in range(k):
@@ -30,4 +32,5 @@ for i in range(k):
     d = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
     dt = time.perf_counter() - t0
     print(f"[{os.path.basename(_lib.LIB_PATH)}] step {m}x{m}: {dt * 1e3:.3f} ms (n_valid {d['n_valid']}, vshift {d['vshift']:.6f})", flush=True)
+print("routes", plan.route_counts(), flush=True)
 plan.close()

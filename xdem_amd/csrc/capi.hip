@@ -280,6 +280,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->vario_sort = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "nk_narrow") {
+        if (value < -1 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_narrow: -1 (adaptive), 0, 1 or 2");
+        ctx->nk_narrow = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "vario_runs") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "vario_runs: 0 or 1");
         ctx->vario_runs = value;

@@ -31,6 +31,7 @@ struct xdemhip_ctx {
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
     int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)
     int terrain_rows = 0;    // option "terrain_rows": tile height of the fused terrain kernel (0 automatic, 16, 24, 32)
+    int nk_narrow = -1;      // option "nk_narrow": sample brackets of the one-pass Nuth-Kaab step 2^-k as wide as the rule (-1 = adaptive: from the offsets measured in earlier steps)
     int vario_runs = 1;      // option "vario_runs": run-length counting pass of the bracketed Dowd selection when a Morton-ordered copy is linked (0 = per-pair counters)
     int vario_deff = 0;      // option "vario_deff": design effect assumed for the pair samples of the bracketed Dowd selection (0 = built-in rule)
     int vario_sort = 1;      // option "vario_sort": the Python side uploads the points of a pair block in Morton order (run-length accumulation of the pair kernels)

@@ -1498,6 +1498,12 @@ struct xdemhip_nk_plan {
     size_t fz_pack_bytes = 0;
     std::vector<unsigned char> fz_host;
     int64_t n_onepass = 0, n_twopass = 0, n_plain = 0;   // steps answered by each route (xdemhip_nk_route_counts)
+    // one-pass route: the sample brackets of the NEXT step are 2^-fz_narrow as wide as the rule for fully correlated sample lines
+    // asks (select.h: sel_bracket_halfwidth); set from how far off the bracket centres the wanted ranks lay in the steps so far
+    int fz_narrow = 0, fz_narrow_cap = 2;
+    double fz_worst = 0.0;   // largest |wanted rank - bracket centre| seen, in half widths of the FULL rule
+    double fz_off2 = 0.0;    // sum of squares of those offsets over all brackets of all steps so far
+    int64_t fz_offn = 0;
     void* scratch = nullptr;  // edges, stats, sums, selection states, successor keys, histograms
     size_t scratch_bytes = 0;
     int max_bins = 0;
@@ -1875,7 +1881,9 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     XD_HIP_CHECK(ctx, hipGetLastError());
     constexpr int BR_PASSES = 3;
     const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
-    int rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false);
+    const int narrow = P->fz_narrow;
+    int rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
+                               false, narrow);
     if (rc) return rc;
     hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, klo_d, khi_d);
     hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st + 1, 1, 1, 0, low_mask, klo_d, khi_d);
@@ -1886,7 +1894,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
                        P->bcache + q0, n, n_slots, d_vhat);
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = select_enqueue<T>(ctx, s_v, nb == 1 ? nullptr : ws->s_bins, n_slots, n_slots, nullptr, nb, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES,
-                           false);
+                           false, nullptr, nullptr, false, narrow);
     if (rc) return rc;
     const int nbb = (nb + 63) / 64;
     hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, klo_y, khi_y);
@@ -1938,7 +1946,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     std::vector<uint64_t> cnt(3 * (size_t)nb);
     std::vector<K> klo(nb);
     std::vector<T> edges(nb + 1);
-    unsigned long long h_ctr[8];
+    unsigned long long h_ctr[16];   // ctr[8] | rbs_d | rbs_y | cnt_d[3] (total, below, inside) | ...
     uint64_t h_rbs = 0;
     unsigned char info[32];
     double sums[5];
@@ -1949,7 +1957,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         FzPack pk;
         void* dsts[10] = {cnt.data(), klo.data(), h_ctr, &h_rbs, info, sums, &h_vhat, edges.data(), h_st.data(), h_succ.data()};
         const void* srcs[10] = {cnt_y, klo_y, ctr, rbs_y, scratch + OFF_INFO, d_sums, d_vhat, d_edges, scratch + OFF_STATE, scratch + off_succ(nb)};
-        const size_t sizes[10] = {8 * 3 * (size_t)nb, sizeof(K) * nb, 64, 8, 32, 40, sizeof(T), sizeof(T) * (nb + 1), sizeof(SelState<K>) * nb, 8 * (size_t)nb};
+        const size_t sizes[10] = {8 * 3 * (size_t)nb, sizeof(K) * nb, 128, 8, 32, 40, sizeof(T), sizeof(T) * (nb + 1), sizeof(SelState<K>) * nb, 8 * (size_t)nb};
         uint32_t off = 0;
         pk.n = 10;
         for (int k = 0; k < 10; ++k) {
@@ -1969,7 +1977,47 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     }
     std::vector<SelResult<K>> hs(nb);
     for (int k = 0; k < nb; ++k) { hs[k].st = h_st[k]; hs[k].succ = h_succ[k]; }
-    if (h_ctr[2] != 0 || h_ctr[3] != 0) return XDEMHIP_OK;  // overflow / a bracket missed / no extreme-aspect survivor: the two-pass route
+    if (h_ctr[2] != 0 || h_ctr[3] != 0) {   // overflow / a bracket missed / no extreme-aspect survivor: the two-pass route
+        if (narrow > 0) { P->fz_narrow_cap = narrow - 1; P->fz_narrow = 0; }   // (narrowed brackets may be what missed: not that narrow again)
+        return XDEMHIP_OK;
+    }
+    {
+        // How centred were the brackets?  |wanted rank - centre| in half widths, scaled to the full rule.  Lines of a sample that
+        // are not fully correlated (the rule's worst case) leave the ranks within a small fraction of it: the next step then takes
+        // brackets half or a quarter as wide -- fewer candidates staged, resolved and selected from (measured on C3: 1.88 -> 1.73
+        // -> 1.62 ms per step); a miss costs that step the two-pass route and caps the narrowing (exact either way).
+        auto off_of = [&](uint64_t tot, uint64_t lt, uint64_t in) {
+            return fabs(((double)(tot - 1) * 0.5 - (double)lt) - 0.5 * (double)in) / (0.5 * (double)in);
+        };
+        // (offsets are measured in half widths of the bracket that was used; all statistics are kept in units of the FULL rule)
+        const double unit = 1.0 / (double)(1 << narrow);
+        double worst = 0.0;
+        auto take = [&](uint64_t tot, uint64_t lt, uint64_t in) {
+            if (tot < 4096 || in < 64 || in >= tot) return;
+            const double o = off_of(tot, lt, in) * unit;
+            worst = o > worst ? o : worst;
+            P->fz_off2 += o * o;
+            P->fz_offn += 1;
+        };
+        take(h_ctr[10], h_ctr[11], h_ctr[12]);
+        for (int b = 0; b < nb; ++b) take(cnt[b], cnt[nb + b], cnt[2 * nb + b]);
+        P->fz_worst = worst > P->fz_worst ? worst : P->fz_worst;
+        // rms offset = one standard deviation of the sample ranks in units of the full half width (independent sample elements:
+        // 1 / 17, the rule being 6 sigma of 8-element lines that are fully correlated): the next brackets keep >= 7 sigma and
+        // >= 2.2 x the worst offset ever seen, in steps of halving
+        int next = 0;
+        if (P->fz_offn >= 24) {
+            const double sigma = sqrt(P->fz_off2 / (double)P->fz_offn);
+            for (int k = 2; k >= 1 && next == 0; --k)
+                if (7.0 * sigma <= 1.0 / (double)(1 << k) && 2.2 * P->fz_worst <= 1.0 / (double)(1 << k)) next = k;
+        }
+        next = next > P->fz_narrow_cap ? P->fz_narrow_cap : next;
+        if (ctx->nk_narrow >= 0) next = ctx->nk_narrow;   // option "nk_narrow": -1 = this rule, 0 / 1 / 2 fixed
+        if (getenv("XDEMHIP_DEBUG"))
+            fprintf(stderr, "[xdemhip] one-pass step: brackets 2^-%d, offsets rms %.3f worst %.3f of the full half width (%lld brackets) -> next 2^-%d\n", narrow,
+                    P->fz_offn ? sqrt(P->fz_off2 / (double)P->fz_offn) : 0.0, P->fz_worst, (long long)P->fz_offn, next);
+        P->fz_narrow = next;
+    }
     uint64_t total;
     double vs;
     memcpy(&total, info + 8, 8);

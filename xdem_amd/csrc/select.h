@@ -91,7 +91,9 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
                                                             const uint32_t* rb_shift = nullptr, uint32_t wide_deff = PAIR_DEFF_WIDE,
                                                             int dual_nb = 1 /* SEL_BRACKET_DUAL: states below this are low ends */,
                                                             uint64_t* succ = nullptr /* [nb]: successor keys from the last histogram */,
-                                                            uint32_t* need_succ = nullptr /* raised when some bin's successor needs the scan */) {
+                                                            uint32_t* need_succ = nullptr /* raised when some bin's successor needs the scan */,
+                                                            uint32_t narrow = 0 /* SEL_BRACKET_LO / _HI / _DUAL: half width >> narrow (callers that
+                                                                                   measured how centred their brackets are, nuthkaab.hip) */) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
     // Rebased keys ((key - lo) << s, select_run.h) have s zero bits at the bottom: a digit that lies entirely inside them is 0
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         uint64_t r = total ? (total - 1) / 2 : 0;  // lower median
         const bool lo_end = mode == SEL_BRACKET_LO || (mode == SEL_BRACKET_DUAL && b < dual_nb);
         const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && b >= dual_nb);
-        if (lo_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = r > h ? r - h : 0; }
-        if (hi_end && total) { const uint64_t h = sel_bracket_halfwidth(total); r = (r + h < total) ? r + h : total - 1; }
+        if (lo_end && total) { const uint64_t h = ((sel_bracket_halfwidth(total) - 32) >> narrow) + 32; r = r > h ? r - h : 0; }
+        if (hi_end && total) { const uint64_t h = ((sel_bracket_halfwidth(total) - 32) >> narrow) + 32; r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = r > h ? r - h : 0; }
         if (mode == SEL_BRACKET_HI_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_GIVEN) {

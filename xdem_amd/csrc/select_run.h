@@ -235,7 +235,8 @@ template <typename T>
 int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_t n, int64_t n_grid, const unsigned long long* d_n, int nb,
                    unsigned char* scratch, int mode, const uint64_t* d_given, int n_passes = 0, bool want_succ = true,
                    const typename KeyT<T>::type* rb_lo = nullptr, const uint32_t* rb_shift = nullptr,
-                   bool first_hist_done = false /* the caller ran select_reset and filled the first digit's histogram itself */) {
+                   bool first_hist_done = false /* the caller ran select_reset and filled the first digit's histogram itself */,
+                   int narrow = 0 /* bracket modes: half width >> narrow (select_advance_kernel) */) {
     typedef typename KeyT<T>::type K;
     // SEL_BRACKET_DUAL: two selection states per data bin (low ends in states [0, nb), high ends in [nb, 2 nb)); `scratch` holds
     // 2 nb states (scratch_size provides for that)
@@ -294,7 +295,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
         if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
                            (int)(p == 0), (int)(p == passes - 1), mode, d_given, rb_shift, PAIR_DEFF_WIDE, nb_data,
-                           want_succ ? d_succ : nullptr, want_succ ? d_need : nullptr);
+                           want_succ ? d_succ : nullptr, want_succ ? d_need : nullptr, (uint32_t)narrow);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     if (!want_succ) return XDEMHIP_OK;
