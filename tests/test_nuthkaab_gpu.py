@@ -861,7 +861,8 @@ def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
 def test_device_side_reductions_cost_little():
     """SURVEY 8e / round-2 review: the sharded step used to make ~25 host round trips (D2H + sync + hook + H2D + sync per digit
     pass).  With the device-side hook on a 1-rank RCCL group a 12000^2 step must stay within 25 % of the hook-less step
-    (the reductions are enqueued on the library's stream; what remains on the host are the two route agreements)."""
+    (the reductions are enqueued on the library's stream; what remains on the host are the two route agreements).  Both steps take the
+    two-pass route (option "nk_fused" = 0): the one-pass step of round 4 is a single-GPU route and would answer the hook-less plan."""
     import os
     import time
 
@@ -884,6 +885,7 @@ def test_device_side_reductions_cost_little():
         tba[torch.rand((m, m), device="cuda") < 0.1] = float("nan")
         torch.cuda.synchronize()
         ctx = _lib.default_context()
+        ctx.set_option("nk_fused", 0)
         times = {}
         res = {}
         for mode in ("plain", "hooked"):
@@ -903,6 +905,7 @@ def test_device_side_reductions_cost_little():
         print(f"step plain {times['plain'] * 1e3:.2f} ms, through the device-side hook {times['hooked'] * 1e3:.2f} ms")
         assert times["hooked"] < 1.25 * times["plain"] + 0.5e-3
     finally:
+        _lib.default_context().set_option("nk_fused", 1)
         if created:
             dist.destroy_process_group()
 

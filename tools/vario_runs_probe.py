@@ -26,8 +26,11 @@ ps.sums(0)
 s_m, c_m = ps.sums(0)
 print(f"pairs {total:.4e}; Matheron pass {ctx.last_kernel_ms():.2f} ms ({total / ctx.last_kernel_ms() / 1e6:.0f} Gpairs/s)", flush=True)
 ref = None
-for name, runs_opt, linked in (("run-length, sorted copy", 1, True), ("per pair, sorted copy", 0, True), ("per pair, caller's order", 1, False),
-                               ("run-length, sorted copy", 1, True)):
+cfgs = (("run-length, sorted copy", 1, True), ("per pair, sorted copy", 0, True), ("per pair, caller's order", 1, False),
+        ("run-length, sorted copy", 1, True))
+if os.environ.get("PROBE_CFG"):   # counter profiles: one form only
+    cfgs = tuple(cfgs[int(k)] for k in os.environ["PROBE_CFG"].split(","))
+for name, runs_opt, linked in cfgs:
     ctx.set_option("vario_runs", runs_opt)
     ctx.check(ctx._L.xdemhip_pairs_link_sorted(ps.handle_sel, ps.handle if linked else None))
     ss.class_medians(ps)

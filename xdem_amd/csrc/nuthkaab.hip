@@ -1656,9 +1656,7 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), nullptr, ws->s_cap, m_est, d_flags + 0, 1, scratch, SEL_BRACKET_DUAL, nullptr,
                            BR_PASSES, false);
     if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, d_klo, d_khi);
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st + 1, 1, 1, 0, low_mask, d_klo, d_khi);
-    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, 1, d_rbs);
+    hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, d_klo, d_khi, d_rbs);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // the one pass: dh for every own pixel (written), min / max aspect, counters, candidates
     bool ext_used = false;
@@ -1885,9 +1883,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     int rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
                                false, narrow);
     if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, 0, low_mask, klo_d, khi_d);
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st + 1, 1, 1, 0, low_mask, klo_d, khi_d);
-    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, klo_d, khi_d, 1, rbs_d);
+    hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
     hipLaunchKernelGGL((nk_vhat_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_st, klo_d, khi_d, d_vhat, d_delta, ctr);
     // 3. sample of y^ per aspect bin -> brackets of the bin medians
     hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
@@ -1897,9 +1893,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
                            false, nullptr, nullptr, false, narrow);
     if (rc) return rc;
     const int nbb = (nb + 63) / 64;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, klo_y, khi_y);
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st + nb, nb, 1, 0, low_mask, klo_y, khi_y);
-    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, klo_y, khi_y, nb, rbs_y);
+    hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, 0, low_mask, klo_y, khi_y, rbs_y);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 4. the one pass
     {

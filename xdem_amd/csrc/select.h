@@ -96,6 +96,10 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
                                                                                    measured how centred their brackets are, nuthkaab.hip) */) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= nb) return;
+    // SEL_BRACKET_DUAL, first digit: both ends of a bin's bracket start from the same histogram -- hist_pass_kernel fills only the
+    // low end's row and the low end's block sets up both states
+    const bool dual_first = first && mode == SEL_BRACKET_DUAL;
+    if (dual_first && b >= dual_nb) return;
     // Rebased keys ((key - lo) << s, select_run.h) have s zero bits at the bottom: a digit that lies entirely inside them is 0
     // for every element, its pass is skipped (hist_pass_kernel leaves at once) and the state moves on without a histogram.
     if (!first && rb_shift && shift + 8 <= (int)*rb_shift) {
@@ -116,18 +120,20 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
         if (lane >= off) incl += t;
     }
     const unsigned long long total = __shfl(incl, 63);
-    SelState<K> s = st[b];
+    for (int half = 0; half < (dual_first ? 2 : 1); ++half) {
+    const int bs = b + half * dual_nb;   // the state this trip advances
+    SelState<K> s = st[bs];
     if (first) {
         s.count = total;
         uint64_t r = total ? (total - 1) / 2 : 0;  // lower median
-        const bool lo_end = mode == SEL_BRACKET_LO || (mode == SEL_BRACKET_DUAL && b < dual_nb);
-        const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && b >= dual_nb);
+        const bool lo_end = mode == SEL_BRACKET_LO || (mode == SEL_BRACKET_DUAL && bs < dual_nb);
+        const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && bs >= dual_nb);
         if (lo_end && total) { const uint64_t h = ((sel_bracket_halfwidth(total) - 32) >> narrow) + 32; r = r > h ? r - h : 0; }
         if (hi_end && total) { const uint64_t h = ((sel_bracket_halfwidth(total) - 32) >> narrow) + 32; r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = r > h ? r - h : 0; }
         if (mode == SEL_BRACKET_HI_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_GIVEN) {
-            r = given[b];
+            r = given[bs];
             if (r == ~(uint64_t)0 || r >= total) { s.count = 0; r = 0; }
         }
         s.rank = r;
@@ -167,13 +173,14 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
             const unsigned long long have = __ballot(cand != 0x7fffffff);
             if (have) {
                 const int nxt = __shfl(cand, (int)__ffsll((long long)have) - 1);   // buckets ascend with the lane: the first lane that has one holds the smallest
-                if (lane == 0) succ[b] = (uint64_t)(K)((s.prefix & ~((K)0xFF << shift)) | ((K)nxt << shift));
+                if (lane == 0) succ[bs] = (uint64_t)(K)((s.prefix & ~((K)0xFF << shift)) | ((K)nxt << shift));
             } else if (lane == 0 && need_succ) {
                 *need_succ = 1u;
             }
         }
     }
-    if (lane == 0) st[b] = s;
+    if (lane == 0) st[bs] = s;
+    }
 }
 
 }  // namespace xd

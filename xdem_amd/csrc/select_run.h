@@ -106,8 +106,9 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
             if (dual_total) {
                 const K key = key_of(v[q]);
                 const int digit = (int)((key >> shift) & 0xFF);
+                // (first digit: one histogram serves both ends -- select_advance_kernel sets both states up from the low end's row)
                 if (first || (key & himask) == s_pref[b]) atomicAdd(&hc[b * SEL_RADIX + digit], 1u);
-                if (first || (key & himask) == s_pref[nb + b]) atomicAdd(&hc[(nb + b) * SEL_RADIX + digit], 1u);
+                if (!first && (key & himask) == s_pref[nb + b]) atomicAdd(&hc[(nb + b) * SEL_RADIX + digit], 1u);
                 continue;
             }
             K key = key_of(v[q]);
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < table; k += blockDim.x) {
+    for (int k = threadIdx.x; k < ((first && dual_total) ? nb * SEL_RADIX : table); k += blockDim.x) {
         unsigned long long c = 0;
         for (int q = 0; q < copies; ++q) c += h[q * cstride + k];
         // (dual: the high-end rows of this sweep belong to the states behind all the low-end ones)
@@ -552,6 +553,25 @@ __global__ __launch_bounds__(64) void rebase_shift_kernel(const K* klo, const K*
     if (threadIdx.x == 0) *shift = rebase_shift_of(r);
 }
 
+// bracket_keys_kernel (both ends) + rebase_shift_kernel in one launch: states [0, nb) hold the low ends, [nb, 2 nb) the high ends
+template <typename K>
+__global__ __launch_bounds__(64) void bracket_finish_kernel(const SelState<K>* st, int nb, int degenerate, K low_mask, K* klo, K* khi, uint32_t* shift) {
+    K r = 0;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        const K lo = st[b].count > 0 ? st[b].prefix : (K)0;
+        const K hi = st[nb + b].count > 0 ? (degenerate ? lo : (K)(st[nb + b].prefix | low_mask)) : (K)~(K)0;
+        klo[b] = lo;
+        khi[b] = hi;
+        const K d = hi >= lo ? (K)(hi - lo) : (K)0;
+        r = d > r ? d : r;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const K o = k_shfl_down(r, off);
+        r = o > r ? o : r;
+    }
+    if (threadIdx.x == 0) *shift = rebase_shift_of(r);
+}
+
 // Rank of the wanted order statistic among the candidates of every bin (all-ones: empty bin); raises flags[3] when a
 // bracket does not hold the lower (and, for an even count, the upper) median.
 static __global__ void bracket_given_kernel(const uint64_t* cnt /* [3][nb]: total, below, inside */, int nb, uint64_t* given,
@@ -752,10 +772,7 @@ int run_select_bracketed(xdemhip_ctx* ctx, const Src& src, int64_t n, int nb, un
     rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->s_vals), nb == 1 ? nullptr : ws->s_bins, ws->s_cap, m_est, d_flags + 0, nb, scratch,
                            SEL_BRACKET_DUAL, nullptr, BR_PASSES, false);
     if (rc) return rc;
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st, nb, 0, 0, low_mask, d_klo, d_khi);
-    hipLaunchKernelGGL((bracket_keys_kernel<K>), dim3(nbb), dim3(64), 0, ctx->stream, d_st + nb, nb, 1, (int)(ctx->selection_mode == 2), low_mask,
-                       d_klo, d_khi);
-    hipLaunchKernelGGL((rebase_shift_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_klo, d_khi, nb, d_rbs);
+    hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, (int)(ctx->selection_mode == 2), low_mask, d_klo, d_khi, d_rbs);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 3. the one pass over the data
     int copies = (32 * 1024) / (nb * 12);

@@ -139,6 +139,8 @@ __device__ __forceinline__ double select_by_mask(double a, double b, unsigned lo
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+template <typename T> struct alignas(8) FzEnds { T lo, hi; };   // a class's bracket as values: one 8 / 16-byte LDS read
+
 // n + (mask bit of this lane): one v_addc with the lane mask as the carry-in
 __device__ __forceinline__ uint32_t add_mask_bit(uint32_t n, unsigned long long mask) {
     uint32_t r;
@@ -191,8 +193,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     // ... and the same ends as VALUES {low, high} per class for the run-length loop (float compares of |dv|; an end whose bits are
     // no number compares false with everything, which is what an unreachable end means)
     T* s_lhf = reinterpret_cast<T*>(s_lh + 2 * (a.nb + 1));
+    // ... and per class the number of candidates the run-length loop staged (tallied when the wave hands its pending candidates to the
+    // staging buffer: the runs count only total and >= low end per pair)
+    uint32_t* s_in = reinterpret_cast<uint32_t*>(s_lhf + 2 * (a.nb + 1));
     if (OP == OP_BRACKET) {
-        stage.v = s_lhf + 2 * (a.nb + 1);
+        stage.v = reinterpret_cast<T*>(s_in + ((a.nb + 2) & ~1));
         stage.b = reinterpret_cast<uint16_t*>(stage.v + SEL_STAGE_CAP);
         stage.base = reinterpret_cast<unsigned long long*>(stage.b + SEL_STAGE_CAP);
         stage.held = reinterpret_cast<int*>(stage.base + 1);
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
             s_lhf[2 * k + 1] = hi_f;
         }
         for (int k = tid; k < (a.nb + 1) * NCOPY; k += NT) s_c3[k] = 0ull;
+        for (int k = tid; k < a.nb + 1; k += NT) s_in[k] = 0u;
         if (tid == 0) *stage.held = 0;
     }
 
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     uint32_t run_start = 0;    // position (count of plain-tile pairs so far, the same for every lane) at which the lane's run began
     uint32_t run_pos = 0;      // ... and the current position: a run's length is their difference, no per-pair counter
     uint32_t run_lo = 1u, run_w = 0u;   // GRID: d^2 interval of the run's class (empty: the first pair looks its class up)
-    uint32_t run_ge = 0u, run_gt = 0u;  // OP_BRACKET runs: pairs of the run at or above the bracket's low end / above its high end
+    uint32_t run_ge = 0u;               // OP_BRACKET runs: pairs of the run at or above the bracket's low end
     T run_blo = (T)0, run_bhi = (T)0;   // ... and the bracket of the run's class
     // One workgroup = one (A tile x B chunk) unit, except in the SAMPLED digit passes: there a unit is 16 tile loads and 16 k pairs,
     // while zeroing and flushing the [classes][256] LDS tables costs ~25 k LDS writes and thousands of global atomics -- a
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 else a.cand_ctr[1] = 1ull;
             }
         };
-        auto flush_pending = [&]() {
+        auto flush_pending = [&](bool tally = false) {
             const unsigned long long m = pend_m;
             if (m) {  // (wave-uniform)
                 const int lane = tid & 63;
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 const bool has = (m >> lane) & 1ull;
                 const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (has && pos < SEL_STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
+                if (tally && has) atomicAdd(&s_in[pend_l], 1u);
                 if (__builtin_expect(pos0 + __popcll(m) > SEL_STAGE_CAP, 0)) spill(has && pos >= SEL_STAGE_CAP, pend_v, pend_l);   // (wave-uniform test)
                 pend_m = 0;
             }
@@ -607,9 +614,21 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                         // (two compares of |dv| against the bracket ends, two carry adds); the packed LDS counter gets ONE ds_add_u64
                         // per run instead of one per pair, and the class lookup and the read of the bracket ends happen once per run
                         // (19 -> 9 vector instructions and 4 -> 2 LDS operations per pair that stays in its class).
-                        if (a.runs && cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT) && (ta + 1) * (int64_t)NT <= na) {
+                        // (a lane without an A point -- last A tile of a block -- sits in the spare class for good: an interval nothing leaves,
+                        // a low end nothing reaches)
+                        if (a.runs && cnt == PT && !a.has_nan && (!a.pdist || j0 >= (ta + 1) * (int64_t)NT)) {
+                            if (!have_a && run_w != 0xFFFFFFFFu) {
+                                const unsigned long long inc = (unsigned long long)(run_pos - run_start) | ((unsigned long long)run_ge << 21) | ((unsigned long long)run_ge << 42);
+                                atomicAdd(s_c3 + (size_t)run_l * NCOPY + (tid & (NCOPY - 1)), inc);
+                                run_l = nb; run_ge = 0u; run_start = run_pos; run_lo = 0u; run_w = 0xFFFFFFFFu;
+                                run_blo = s_lhf[2 * nb]; run_bhi = s_lhf[2 * nb + 1];
+                            }
                             static_assert(NCOPY * 8 == 256, "counter records are 256 bytes");
                             unsigned char* const c3_mine = reinterpret_cast<unsigned char*>(s_c3 + (tid & (NCOPY - 1)));
+                            // every fourth tile all lanes look their class up again: a run then holds at most 4 PT = 2^10 pairs and its
+                            // counts pack with two shifts (no 64-bit arithmetic)
+                            static_assert(4 * PT <= 1024, "a run's count of pairs >= the low end must fit 11 bits");
+                            if ((((j0 - jb0) / PT) & 3) == 0 && have_a) run_w = 0u;
                             for (int j = 0; j < PT; j += 4) {
                                 uint32_t d2[4];
                                 T dv[4];
@@ -625,25 +644,25 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                         const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
                                         const uint4 e = s_lut4[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
                                         const bool up = e.y <= d2[u];
-                                        const unsigned long long inc = (unsigned long long)(run_pos - run_start) | ((unsigned long long)run_ge << 21) |
-                                                                       ((unsigned long long)run_gt << 42);
-                                        atomicAdd(reinterpret_cast<unsigned long long*>(c3_mine + ((uint32_t)run_l << 8)), inc);
+                                        // packed counter: pairs | >= low end | "above" (here: >= low end as well -- the candidates among
+                                        // them are tallied in s_in and taken off at the end); a run holds <= 1024 pairs (see below)
+                                        const uint32_t inc_lo = (run_ge << 21) | (run_pos - run_start), inc_hi = run_ge << 10;
+                                        atomicAdd(reinterpret_cast<unsigned long long*>(c3_mine + ((uint32_t)run_l << 8)), ((unsigned long long)inc_hi << 32) | inc_lo);
                                         run_l = (int)e.x + (up ? 1 : 0);
-                                        run_ge = run_gt = 0u;
+                                        run_ge = 0u;
                                         run_start = run_pos;
                                         run_lo = up ? e.y : e.z;
                                         run_w = (up ? e.w : e.y) - run_lo;
-                                        run_blo = s_lhf[2 * run_l];
-                                        run_bhi = s_lhf[2 * run_l + 1];
+                                        const FzEnds<T> be = *reinterpret_cast<const FzEnds<T>*>(s_lhf + 2 * run_l);
+                                        run_blo = be.lo;
+                                        run_bhi = be.hi;
                                     }
                                     const T ad = sizeof(T) == 4 ? (T)__builtin_fabsf((float)dv[u]) : (T)__builtin_fabs((double)dv[u]);
                                     const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ad >= run_blo);
-                                    const unsigned long long m_gt = __builtin_amdgcn_ballot_w64(ad > run_bhi) & m_ge;   // (an empty bracket, hi < lo: everything below or above)
+                                    const unsigned long long in = m_ge & ~__builtin_amdgcn_ballot_w64(ad > run_bhi);   // (an empty bracket, hi < lo: nothing inside)
                                     run_ge = add_mask_bit(run_ge, m_ge);
-                                    run_gt = add_mask_bit(run_gt, m_gt);
-                                    const unsigned long long in = m_ge & ~m_gt;
                                     if (in != 0) {   // (wave-uniform: a fifth of the wave-pairs hold a candidate)
-                                        if (__builtin_expect((in & pend_m) != 0, 0)) flush_pending();
+                                        if (__builtin_expect((in & pend_m) != 0, 0)) flush_pending(true);
                                         const unsigned long long take = in & ~pend_m;
                                         pend_v = select_by_mask(pend_v, ad, take);
                                         pend_l = select_by_mask(pend_l, (uint32_t)run_l, take);
@@ -651,7 +670,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                     }
                                     run_pos += 1;
                                 }
-                                if ((j & 12) == 12) flush_pending();
+                                if ((j & 28) == 28) flush_pending(true);   // every 32 pairs (a second candidate of a lane before that flushes at once)
                                 if ((j & 63) == 60 && j + 4 < PT)
                                     stage.sync_and_flush_at(SEL_STAGE_CAP / 4, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
                             }
@@ -781,7 +800,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_pos - run_start);
     }
     if (OP == OP_BRACKET && run_pos != run_start) {   // (run-length counting: the open run of every lane)
-        const unsigned long long inc = (unsigned long long)(run_pos - run_start) | ((unsigned long long)run_ge << 21) | ((unsigned long long)run_gt << 42);
+        const unsigned long long inc = (unsigned long long)(run_pos - run_start) | ((unsigned long long)run_ge << 21) | ((unsigned long long)run_ge << 42);
         atomicAdd(s_c3 + (size_t)run_l * NCOPY + (tid & (NCOPY - 1)), inc);
     }
     __syncthreads();
@@ -815,6 +834,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 inside += ge - gt;
                 above += gt;
             }
+            // (run-length loop: its pairs at or above the low end sit in BOTH upper fields; the candidates among them were tallied)
+            inside += s_in[k];
+            above -= s_in[k];
             if (above + inside) atomicAdd(&a.cnt3[k], above + inside);  // [0]: at or above the bracket's low end
             if (below) atomicAdd(&a.cnt3[nb + k], below);
             if (inside) atomicAdd(&a.cnt3[2 * nb + k], inside);
@@ -870,7 +892,7 @@ template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
     size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8 + 4 * (size_t)(PT + nb + 4);
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
     if (op == OP_BRACKET)
-        return base + (size_t)(nb + 1) * NCOPY * 8 + 4 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 8 +
+        return base + (size_t)(nb + 1) * NCOPY * 8 + 4 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 4 * (size_t)(nb + 2) + 8 +
                (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
     return base + (size_t)(nb + 1) * NCOPY * 12;
