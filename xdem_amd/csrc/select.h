@@ -76,11 +76,13 @@ __host__ __device__ inline uint64_t sel_bracket_halfwidth(uint64_t m) {
 // `deff` = the design effect assumed for the sample (pairs per independent draw): 4096 for the samples that pair a few B points
 // with ALL A points of a tile (i < j blocks), PAIR_DEFF_SPREAD for the samples in which every point of a unit takes part in a
 // few pairs only (variogram.hip: unit_sample_slot).
-// PAIR_DEFF_SPREAD measured on SURVEY 8d's C5 input (tools/vario_c5_probe.py): with 16 the wanted rank lies 0.08 half widths off
-// the bracket centre at worst (rms 0.026 over the 50 classes) -- the spread sample behaves like independent draws (every unit is
-// represented: design effect < 1), 16 leaves a factor ~40 for fields and geometries that correlate more strongly, and a miss
-// costs one more counting pass with the wide brackets, not the plain route (variogram.hip: pairs_medians_typed).
-constexpr uint32_t PAIR_DEFF_WIDE = 4096, PAIR_DEFF_SPREAD = 16;
+// PAIR_DEFF_SPREAD measured on SURVEY 8d's C5 input (tools/vario_c5_probe.py): with 16 the wanted rank lay 0.08 half widths off
+// the bracket centre at worst (rms 0.026 over the 50 classes) -- the spread sample behaves like independent draws or better (every
+// unit is represented: design effect < 1).  Round 4 takes 4 (half the width of 16: half the candidates the counting pass stages and
+// the final selection reads, 0.44 -> 0.22 % of the pairs): a factor ~10 in variance remains for fields and geometries that correlate
+// more strongly, and a miss costs one more counting pass with 16 x the design effect, then the wide rule, not the plain route
+// (variogram.hip: pairs_medians_typed).
+constexpr uint32_t PAIR_DEFF_WIDE = 4096, PAIR_DEFF_SPREAD = 4;
 __host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m, uint32_t deff = PAIR_DEFF_WIDE) {
     return (uint64_t)(3.0 * sqrt((double)deff * (double)m)) + 64;
 }

@@ -881,6 +881,11 @@ struct xdemhip_pairs {
     // the same pair set with the points of every block in Morton order (xdemhip_pairs_link_sorted; not owned): the counting pass
     // of the bracketed selection reads its points
     xdemhip_pairs* sorted = nullptr;
+    // small device blocks of xdemhip_pairs_medians, kept between calls (their hipMalloc / hipFree cost ~1 ms per call)
+    unsigned char* sel_small = nullptr;
+    size_t sel_small_bytes = 0;
+    void* sel_scratch = nullptr;
+    size_t sel_scratch_bytes = 0;
     std::vector<int64_t> h_a_off, h_b_off;   // host copies of the block offsets (link check)
 };
 
@@ -1088,6 +1093,8 @@ void xdemhip_pairs_destroy(xdemhip_pairs* P) {
     for (void* p : b2) if (p) (void)hipFree(p);
     if (P->cand_v) (void)hipFree(P->cand_v);   // candidate buffers of the bracketed selection (kept between calls)
     if (P->cand_b) (void)hipFree(P->cand_b);
+    if (P->sel_small) (void)hipFree(P->sel_small);
+    if (P->sel_scratch) (void)hipFree(P->sel_scratch);
     delete P;
 }
 
@@ -1463,22 +1470,35 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     const size_t off_klo = 2 * (size_t)nb * sizeof(SelState<K>), off_khi = off_klo + 8 * (size_t)nb, off_given = off_khi + 8 * (size_t)nb,
                  off_cnt = off_given + 8 * (size_t)nb, off_ctr = off_cnt + 24 * (size_t)nb, off_rbs = off_ctr + 16, off_pref2 = off_rbs + 8,
                  small_bytes = off_pref2 + 8 * (size_t)nb;
-    if (hipMalloc(reinterpret_cast<void**>(&d_small), small_bytes) != hipSuccess) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+    if (P->sel_small_bytes < small_bytes) {
+        if (P->sel_small) (void)hipFree(P->sel_small);
+        P->sel_small = nullptr; P->sel_small_bytes = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&P->sel_small), small_bytes) != hipSuccess) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
+        P->sel_small_bytes = small_bytes;
+    }
+    d_small = P->sel_small;
     SelState<K>* d_st = reinterpret_cast<SelState<K>*>(d_small);
     void* scratch = nullptr;
     auto cleanup = [&]() {
-        // (the candidate buffers stay with the pair set -- tens of GB whose hipMalloc and first touch cost a second: a second
-        // selection on the same set, e.g. after a warm-up call, reuses them; xdemhip_pairs_destroy frees them)
+        // (the candidate buffers and the small blocks stay with the pair set -- tens of GB whose hipMalloc and first touch cost a
+        // second: a second selection on the same set, e.g. after a warm-up call, reuses them; xdemhip_pairs_destroy frees them)
         P->khi = nullptr; P->cnt3 = nullptr; P->cand_ctr = nullptr;
-        if (scratch) (void)hipFree(scratch);
-        (void)hipFree(d_small);
     };
     const bool dbg = getenv("XDEMHIP_DEBUG") != nullptr;
     auto now_ms = [&]() { (void)hipStreamSynchronize(ctx->stream); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t_phase = dbg ? now_ms() : 0.0;
     auto phase = [&](const char* what) { if (dbg) { const double t = now_ms(); fprintf(stderr, "[xdemhip] pair medians: %-28s %8.2f ms\n", what, t - t_phase); t_phase = t; } };
     bool bracket = ctx->selection_mode != 1 && nb <= HIST_BINS_PER_SWEEP && P->n_pairs >= PAIRS_BRACKET_MIN && P->n_wg_big >= 256;
-    if (bracket && hipMalloc(&scratch, scratch_size(nb)) != hipSuccess) bracket = false;
+    if (bracket) {
+        const size_t need = scratch_size(nb);
+        if (P->sel_scratch_bytes < need) {
+            if (P->sel_scratch) (void)hipFree(P->sel_scratch);
+            P->sel_scratch = nullptr; P->sel_scratch_bytes = 0;
+            if (hipMalloc(&P->sel_scratch, need) == hipSuccess) P->sel_scratch_bytes = need;
+            else { (void)hipGetLastError(); bracket = false; }
+        }
+        scratch = P->sel_scratch;
+    }
     if (ctx->allreduce) {  // sharded pair sets: every rank must take the same route
         uint64_t can = bracket ? 1 : 0;
         if (ctx->allreduce(&can, 1, XDEMHIP_RED_MIN_U64, ctx->allreduce_user) != 0) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed"); }
@@ -1493,11 +1513,11 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
     // bracket that misses its rank (the integer counts tell) costs one more attempt with the wide brackets before the plain
     // digit passes take over; with a reduction hook the counts are global, so every rank retries alike.
     uint32_t deff = ctx->vario_deff > 0 ? (uint32_t)ctx->vario_deff : (P->pdist ? PAIR_DEFF_WIDE : PAIR_DEFF_SPREAD);
-    for (int attempt = 0; attempt < 2 && bracket && !done; ++attempt) {
-        if (attempt == 1) {
+    for (int attempt = 0; attempt < 3 && bracket && !done; ++attempt) {
+        if (attempt >= 1) {   // a bracket missed its rank: 16 x the assumed design effect (4 x the width), then the wide rule
             if (deff >= PAIR_DEFF_WIDE) break;
-            deff = PAIR_DEFF_WIDE;
-            if (dbg) fprintf(stderr, "[xdemhip] pair medians: second attempt with the wide brackets\n");
+            deff = (attempt == 1 && deff * 16 < PAIR_DEFF_WIDE) ? deff * 16 : PAIR_DEFF_WIDE;
+            if (dbg) fprintf(stderr, "[xdemhip] pair medians: attempt %d with design effect %u\n", attempt + 1, deff);
         }
         if (bracket) {
             std::vector<SelState<K>> lo, hi;
