@@ -15,6 +15,8 @@ from xdem_amd import _lib
 from xdem_amd import spatialstats as ss
 from xdem_amd.synth import c5_variogram_blocks
 
+if os.environ.get("XD_LIB"):   # A/B of library builds across processes
+    _lib.LIB_PATH = os.environ["XD_LIB"]
 samples = int(sys.argv[1]) if len(sys.argv) > 1 else 9091
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = _lib.default_context(0)

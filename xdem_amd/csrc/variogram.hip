@@ -37,7 +37,10 @@ namespace xd {
 // spread pair sample (every-a-with-every-b blocks): B slots per lane and tile -> SPREAD_SLOTS / 256 of the pairs of every unit.
 // (4 = 1/64 was the first setting; the brackets scale with 1 / sqrt(sample), the three sampled passes with the sample: 2 slots
 // cost 0.1 % more candidates and save a third of the sampled passes' time on SURVEY 8d's C5)
-constexpr int SPREAD_SLOTS = 2;
+#ifndef XD_SPREAD_SLOTS
+#define XD_SPREAD_SLOTS 2
+#endif
+constexpr int SPREAD_SLOTS = XD_SPREAD_SLOTS;
 constexpr int PT = 256;      // B points per LDS tile; A points per workgroup = NT (256 for sums / succ, 1024 for histograms)
 // (a lane's SPREAD_SLOTS slots lie PT / SPREAD_SLOTS apart, so one wave covers SPREAD_SLOTS of the tile's four 64-slot groups:
 // consecutive waves start in different groups and the waves of a workgroup together cover every B point of the tile -- with one
