@@ -362,15 +362,16 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
     return out
 
 
-VARIO_LIMITER_NOTE = ("round 2 (profiles/r02_nk_vario_pmc.json): 14.7 vector + 4.0 LDS instructions per pair, the LDS array busy for the whole kernel "
-                      "with two accumulator atomics per pair.  Round 3: points uploaded in Morton order + run-length accumulation in registers "
-                      "(LDS atomics only when a lane's lag class changes): the pass is bound by vector-instruction issue (~17 per pair); "
-                      "the exact Dowd route = three sampled digit passes for both bracket ends (4 ms) + ONE counting / compaction pass over all pairs "
-                      "(46 ms, ~19 vector instructions per pair, one packed LDS counter update each) + the selection among the 0.4 % of the "
-                      "pairs inside the brackets (3 ms)")
+VARIO_LIMITER_NOTE = ("vector-instruction issue in both passes.  Matheron (round 4): a lane keeps the d^2 interval of its run's lag class, a pair that stays "
+                      "in the class costs a subtract and a compare instead of the class lookup; only class changes (5 % of the lane-pairs, a third of "
+                      "the wave-pairs on this geometry) look up, flush the run to LDS and reload.  Exact Dowd = three sampled digit passes for both "
+                      "bracket ends (3.7 ms) + ONE counting / compaction pass over all pairs (38 ms) + the selection among the 0.22 % of the pairs "
+                      "inside the brackets (1.6 ms); the counting pass reads the Morton-ordered copy and counts run-length as well (round 4, "
+                      "profiles/r04_vario_counting_pmc.json: 17.4 vector instructions per wave-pair against 20.8 per pair-wise form, VALU busy 0.82)")
 NK_ONEPASS_NOTE = ("the one pass touches 14 B/pixel: masked reference copy 4 + tba 4 + slope tangent 4 + cached aspect-bin id 2; no dh raster is "
                    "written or re-read (22 B/pixel in two passes in round 3); candidates of the medians (a few percent) leave as (dh, slope "
-                   "tangent, bin) triples")
+                   "tangent, bin) triples; from the second step of a plan on the sample brackets are half as wide as the rule for fully "
+                   "correlated sample lines when the rank offsets measured in the earlier steps allow it (exact either way)")
 NK_TOUCHED_BYTES = 22
 NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference copy 4 + tba 4 + dh out 4 -- min / max aspect come from the "
                    "plan's lists of extreme-aspect pixels, the inlier mask is folded into the reference copy as NaN; bin pass: dh 4 + "
