@@ -118,12 +118,37 @@ struct ChunkedAlloc { void* base = nullptr; size_t size = 0, piece = 0; std::vec
 std::mutex g_chunk_mu;
 std::vector<ChunkedAlloc> g_chunked;
 
+// Virtual ranges are NOT handed back for reuse when their pieces go: on this stack (ROCm 7.2, gfx950) a range that is freed, reserved
+// again at the same address and mapped onto other physical pieces can be read and written through translations of its previous
+// mapping -- planes of a 46400^2 raster came back with tens of MiB of other memory's contents in 6 of 14 repeats, and in none of 14 with
+// the addresses kept (tools/vmm_stale_probe.py, profiles/r04_vmm_stale_probe.txt).  Freed ranges stay reserved (address space only, no
+// memory) in a first-in first-out quarantine and are returned to the driver once more than XDEMHIP_VMM_QUARANTINE_TB (default 32 TiB
+// of the 128 TiB address space) wait there -- by then thousands of other ranges have been mapped and used since.
+struct QuarantinedRange { void* base; size_t size; };
+std::mutex g_quarantine_mu;
+std::vector<QuarantinedRange> g_quarantine;
+size_t g_quarantine_bytes = 0;
+
+void quarantine_range(void* base, size_t size) {
+    static const size_t limit = (size_t)(getenv("XDEMHIP_VMM_QUARANTINE_TB") ? atof(getenv("XDEMHIP_VMM_QUARANTINE_TB")) : 32.0) << 40;
+    std::lock_guard<std::mutex> lock(g_quarantine_mu);
+    g_quarantine.push_back({base, size});
+    g_quarantine_bytes += size;
+    size_t n_free = 0;
+    while (g_quarantine_bytes > limit && n_free < g_quarantine.size()) {
+        (void)hipMemAddressFree(g_quarantine[n_free].base, g_quarantine[n_free].size);
+        g_quarantine_bytes -= g_quarantine[n_free].size;
+        ++n_free;
+    }
+    if (n_free) g_quarantine.erase(g_quarantine.begin(), g_quarantine.begin() + (long)n_free);
+}
+
 void chunked_release(ChunkedAlloc& c, size_t mapped_pieces) {
     for (size_t i = 0; i < c.pieces.size(); ++i) {
         if (i < mapped_pieces) (void)hipMemUnmap(static_cast<char*>(c.base) + c.slot[i] * c.piece, c.piece);
         (void)hipMemRelease(c.pieces[i]);
     }
-    if (c.base) (void)hipMemAddressFree(c.base, c.size);
+    if (c.base) quarantine_range(c.base, c.size);
 }
 
 int device_alloc_chunked(xdemhip_ctx* ctx, size_t bytes, size_t piece, bool shuffle, void** ptr) {
@@ -142,7 +167,18 @@ int device_alloc_chunked(xdemhip_ctx* ctx, size_t bytes, size_t piece, bool shuf
     c.size = n * c.piece;
     if (hipMemAddressReserve(&c.base, c.size, 0, nullptr, 0) != hipSuccess || !c.base) {
         (void)hipGetLastError();
-        return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMemAddressReserve failed");
+        // out of address space with ranges waiting in the quarantine: hand them back and try once more
+        {
+            std::lock_guard<std::mutex> lock(g_quarantine_mu);
+            for (const QuarantinedRange& q : g_quarantine) (void)hipMemAddressFree(q.base, q.size);
+            g_quarantine.clear();
+            g_quarantine_bytes = 0;
+        }
+        c.base = nullptr;
+        if (hipMemAddressReserve(&c.base, c.size, 0, nullptr, 0) != hipSuccess || !c.base) {
+            (void)hipGetLastError();
+            return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMemAddressReserve failed");
+        }
     }
     c.slot.resize(n);
     for (size_t i = 0; i < n; ++i) c.slot[i] = i;
