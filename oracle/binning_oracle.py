@@ -22,11 +22,20 @@ def nmad(data, nfact: float = 1.4826):
     return nfact * np.nanmedian(np.abs(arr - np.nanmedian(arr)))
 
 
-def bin_edges(sample: np.ndarray, bins: list) -> tuple[list[np.ndarray], list[int]]:
-    """(edges per dimension, SciPy's rounding decimals) for a (N, D) sample matrix, range=None."""
+def bin_edges(sample: np.ndarray, bins: list, rng=None) -> tuple[list[np.ndarray], list[int]]:
+    """(edges per dimension, SciPy's rounding decimals) for a (N, D) sample matrix; ``rng`` = SciPy's ``range=`` after
+    binned_statistic's wrapping (one (start, stop) pair per dimension) or None."""
     edges_dtype = sample.dtype if np.issubdtype(sample.dtype, np.floating) else np.dtype(float)
-    smin = np.atleast_1d(np.array(sample.min(axis=0), float))
-    smax = np.atleast_1d(np.array(sample.max(axis=0), float))
+    if rng is None:
+        smin = np.atleast_1d(np.array(sample.min(axis=0), float))
+        smax = np.atleast_1d(np.array(sample.max(axis=0), float))
+    else:
+        if len(rng) != sample.shape[1]:
+            raise ValueError(f"range given for {len(rng)} dimensions; {sample.shape[1]} required")
+        smin = np.array([float(r[0]) for r in rng])
+        smax = np.array([float(r[1]) for r in rng])
+        if np.any(smax < smin):
+            raise ValueError("range: start must be <= stop")
     edges, decimals = [], []
     for i in range(sample.shape[1]):
         if smin[i] == smax[i]:
@@ -56,10 +65,10 @@ def bin_numbers(sample: np.ndarray, edges: list[np.ndarray], decimals: list[int]
     return flat
 
 
-def binned_stats(values: np.ndarray, cols: list[np.ndarray], bins: list):
+def binned_stats(values: np.ndarray, cols: list[np.ndarray], bins: list, rng=None):
     """count / nanmedian / nmad per bin (float64 arrays shaped like the bin grid) + edges, inputs already filtered."""
     sample = np.atleast_2d(cols).T
-    edges, decimals = bin_edges(sample, bins)
+    edges, decimals = bin_edges(sample, bins, rng)
     shape = tuple(len(e) - 1 for e in edges)
     ids = bin_numbers(sample, edges, decimals)
     nb = int(np.prod(shape))
@@ -79,10 +88,14 @@ def binned_stats(values: np.ndarray, cols: list[np.ndarray], bins: list):
     return count.reshape(shape), med.reshape(shape), nm.reshape(shape), edges
 
 
-def nd_binning_arrays(values, list_var, list_var_bins=None):
+def nd_binning_arrays(values, list_var, list_var_bins=None, list_ranges=None):
     """All binnings nd_binning performs, as a list of (var_ids, count, median, nmad, edges) in its order: every 1-D,
-    every 2-D combination, then the N-D one when there are more than two variables."""
+    every 2-D combination, then the N-D one when there are more than two variables.  ``list_ranges`` goes to every binning
+    as upstream hands it to SciPy (xdem/spatialstats.py:147, 176, 190; binned_statistic wraps a 2-element range into a list)."""
     nv = len(list_var)
+    r1 = list_ranges
+    if r1 is not None and len(r1) == 2:
+        r1 = [r1]
     if list_var_bins is None:
         list_var_bins = (10,) * nv
     elif isinstance(list_var_bins, (int, np.integer)):
@@ -94,12 +107,12 @@ def nd_binning_arrays(values, list_var, list_var_bins=None):
     list_var = [v[valid] for v in list_var]
     out = []
     for i in range(nv):
-        out.append(((i,),) + binned_stats(values, [list_var[i]], [list_var_bins[i]]))
+        out.append(((i,),) + binned_stats(values, [list_var[i]], [list_var_bins[i]], r1))
     if nv > 1:
         for i1, i2 in itertools.combinations(range(nv), 2):
-            out.append(((i1, i2),) + binned_stats(values, [list_var[i1], list_var[i2]], [list_var_bins[i1], list_var_bins[i2]]))
+            out.append(((i1, i2),) + binned_stats(values, [list_var[i1], list_var[i2]], [list_var_bins[i1], list_var_bins[i2]], list_ranges))
     if nv > 2:
-        out.append((tuple(range(nv)),) + binned_stats(values, list_var, list(list_var_bins)))
+        out.append((tuple(range(nv)),) + binned_stats(values, list_var, list(list_var_bins), list_ranges))
     return out
 
 

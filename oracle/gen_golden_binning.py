@@ -34,7 +34,59 @@ def cases():
     yield "constant_var", v, [np.full(x.size, 3.0, np.float32), x], (3, 5)
 
 
+def range_cases():
+    """``list_ranges`` (round 4): what upstream hands to SciPy's ``range=`` -- usable with ONE variable (a (start, stop) pair, or a
+    one-element list of pairs); samples outside the range fall into no bin, a sample ON the last edge into the last bin."""
+    rng = np.random.default_rng(91)
+    n = 5000
+    x = rng.uniform(0, 10, n).astype(np.float32)
+    x[:40] = np.float32(8.25)      # on the last edge of the first case
+    x[40:60] = np.float32(2.0)     # on its first edge
+    v = (rng.normal(0, 1, n) * (1 + 0.2 * x)).astype(np.float32)
+    v[::53] = np.nan
+    yield "range_pair_1var", v, [x], 6, (2.0, 8.25)
+    yield "range_list_1var", v.astype(np.float64), [x.astype(np.float64)], 5, [(1.5, 9.0)]
+    yield "range_equal_1var", v, [np.round(x)], 3, (3.0, 3.0)
+    yield "range_wider_than_data", v, [x], 4, (-5.0, 25.0)
+
+
+def range_errors():
+    x = np.linspace(0, 10, 200).astype(np.float32)
+    v = np.sin(x).astype(np.float32)
+    yield "two_vars_two_pairs", v, [x, x[::-1].copy()], (4, 3), [(0.0, 5.0), (0.0, 3.0)]
+    yield "start_after_stop", v, [x], 4, (5.0, 1.0)
+    yield "three_pairs_one_var", v, [x], 4, [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0)]
+
+
 def main(ref, out_dir: str) -> None:
+    import json
+
+    rrec, errs = {}, {}
+    for name, values, list_var, bins, ranges in range_cases():
+        names = [f"v{i}" for i in range(len(list_var))]
+        df = ref.spatialstats.nd_binning(values, list_var, names, list_var_bins=bins, statistics=["count", np.nanmedian, nmad], list_ranges=ranges)
+        rrec[f"{name}|values"] = values
+        for i, v in enumerate(list_var):
+            rrec[f"{name}|var{i}"] = v
+        rrec[f"{name}|bins"] = np.array(bins)
+        rrec[f"{name}|ranges"] = np.asarray(ranges, float)
+        rrec[f"{name}|ranges_is_list"] = np.array(isinstance(ranges, list))
+        rrec[f"{name}|nd"] = df["nd"].values.astype(np.int64)
+        for col in ("count", "nanmedian", "nmad"):
+            rrec[f"{name}|{col}"] = df[col].values.astype(np.float64)
+        for nm in names:
+            rrec[f"{name}|{nm}|left"] = np.array([iv.left for iv in df[nm].values], float)
+            rrec[f"{name}|{nm}|right"] = np.array([iv.right for iv in df[nm].values], float)
+    for name, values, list_var, bins, ranges in range_errors():
+        try:
+            ref.spatialstats.nd_binning(values, list_var, [f"v{i}" for i in range(len(list_var))], list_var_bins=bins,
+                                        statistics=["count", np.nanmedian], list_ranges=ranges)
+            errs[name] = None
+        except Exception as e:  # noqa: BLE001 -- whatever SciPy raises is the behaviour to reproduce
+            errs[name] = {"type": type(e).__name__, "message": str(e)}
+    np.savez_compressed(os.path.join(out_dir, "binning_ranges_golden.npz"), **rrec)
+    with open(os.path.join(out_dir, "binning_ranges_errors.json"), "w") as fh:
+        json.dump(errs, fh, indent=1, sort_keys=True)
     rec = {}
     for name, values, list_var, bins in cases():
         names = [f"v{i}" for i in range(len(list_var))]

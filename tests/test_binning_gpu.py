@@ -9,7 +9,7 @@ import pytest
 
 import binning_oracle as bo
 from conftest import GOLDEN
-from test_oracle_binning_golden import CASES, flatten_like_reference, load_case
+from test_oracle_binning_golden import CASES, RANGE_CASES, flatten_like_reference, load_case, load_range_case
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,43 @@ def test_nd_binning_equals_reference_dataframe(name):
     for key, arr in got.items():
         ref = np.asarray(z[f"{name}|{key}"], np.float64)
         assert arr.shape == ref.shape and np.array_equal(arr, ref, equal_nan=True), (name, key)
+
+
+@pytest.mark.parametrize("name", RANGE_CASES)
+def test_nd_binning_with_list_ranges_equals_reference_dataframe(name):
+    """``list_ranges`` (SciPy's ``range=``): the reference's DataFrame for one variable and a (start, stop) pair / a one-element
+    list of pairs -- edges from the range, samples outside in no bin, a sample on the last edge in the last bin."""
+    from xdem_amd import spatialstats as ss
+
+    z = np.load(os.path.join(GOLDEN, "binning_ranges_golden.npz"))
+    values, list_var, bins, ranges = load_range_case(z, name)
+    df = ss.nd_binning(values, list_var, ["v0"], list_var_bins=bins, statistics=["count", np.nanmedian, ss.nmad], list_ranges=ranges)
+    got = df_to_cols(df, 1)
+    for key, arr in got.items():
+        ref = np.asarray(z[f"{name}|{key}"], np.float64)
+        assert arr.shape == ref.shape and np.array_equal(arr, ref, equal_nan=True), (name, key)
+
+
+def test_nd_binning_list_ranges_errors_are_scipys():
+    """What upstream's ``range=list_ranges`` makes SciPy refuse (several variables, start after stop, wrong length) is refused
+    with the same exception and message (tests/golden/binning_ranges_errors.json, recorded from the reference)."""
+    import json
+
+    from xdem_amd import spatialstats as ss
+
+    errs = json.load(open(os.path.join(GOLDEN, "binning_ranges_errors.json")))
+    x = np.linspace(0, 10, 200).astype(np.float32)
+    v = np.sin(x).astype(np.float32)
+    calls = {"two_vars_two_pairs": ([x, x[::-1].copy()], (4, 3), [(0.0, 5.0), (0.0, 3.0)]),
+             "start_after_stop": ([x], 4, (5.0, 1.0)),
+             "three_pairs_one_var": ([x], 4, [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0)])}
+    assert set(calls) == set(errs)
+    for name, (lv, bins, ranges) in calls.items():
+        want = errs[name]
+        assert want is not None
+        with pytest.raises(Exception) as ei:
+            ss.nd_binning(v, lv, [f"v{i}" for i in range(len(lv))], list_var_bins=bins, statistics=["count", np.nanmedian], list_ranges=ranges)
+        assert type(ei.value).__name__ == want["type"] and str(ei.value) == want["message"], (name, repr(ei.value), want)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -71,8 +108,6 @@ def test_nd_binning_argument_rules():
     v = np.arange(100, dtype=np.float32)
     with pytest.raises(NotImplementedError, match="not available on the HIP engine"):
         ss.nd_binning(v, [v], ["a"], statistics=[np.nanmean])
-    with pytest.raises(NotImplementedError, match="list_ranges"):
-        ss.nd_binning(v, [v], ["a"], list_ranges=[0, 1])
     df = ss.nd_binning(v, [v], ["a"], list_var_bins=4, statistics=[np.nanmedian])  # count is added in front
     assert list(df.columns) == ["nd", "count", "nanmedian", "a"] and df["count"].tolist() == [25.0] * 4
     assert df["nanmedian"].tolist() == [12.0, 37.0, 62.0, 87.0]

@@ -75,6 +75,33 @@ def test_oracle_equals_reference_nd_binning(name):
         assert np.array_equal(np.asarray(arr, np.float64), np.asarray(ref, np.float64), equal_nan=True), (name, key)
 
 
+RANGE_CASES = ["range_pair_1var", "range_list_1var", "range_equal_1var", "range_wider_than_data"]
+
+
+def load_range_case(z, name):
+    values, list_var = z[f"{name}|values"], [z[f"{name}|var0"]]
+    r = z[f"{name}|ranges"]
+    ranges = [tuple(float(x) for x in row) for row in r] if bool(z[f"{name}|ranges_is_list"]) else tuple(float(x) for x in r)
+    return values, list_var, int(z[f"{name}|bins"]), ranges
+
+
+@pytest.mark.parametrize("name", RANGE_CASES)
+def test_oracle_equals_reference_nd_binning_with_ranges(name):
+    """``list_ranges`` as upstream hands it to SciPy's ``range=`` (xdem/spatialstats.py:147): edges from the range, samples outside
+    in no bin, a sample on the last edge in the last bin -- the reference's DataFrame, recorded by oracle/gen_golden_binning.py."""
+    import warnings
+
+    z = np.load(os.path.join(GOLDEN, "binning_ranges_golden.npz"))
+    values, list_var, bins, ranges = load_range_case(z, name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = flatten_like_reference(bo.nd_binning_arrays(values, list_var, bins, list_ranges=ranges), 1)
+    assert got["count"].sum() > 0
+    for key, arr in got.items():
+        ref = z[f"{name}|{key}"]
+        assert arr.shape == ref.shape and np.array_equal(np.asarray(arr, np.float64), np.asarray(ref, np.float64), equal_nan=True), (name, key)
+
+
 def test_oracle_heteroscedasticity_equals_reference():
     """Error map of the reference's _estimate_model_heteroscedasticity + fun(full grid) (spatialstats.py:576-631, 866-868)."""
     import warnings

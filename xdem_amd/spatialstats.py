@@ -698,10 +698,28 @@ def nmad(data, nfact: float = 1.4826):
 _GPU_STATS = {"count": "count", "nanmedian": "median", "median": "median", "nmad": "nmad"}
 
 
+def _scipy_range(rng, ndim: int, one_d: bool):
+    """``range=`` as scipy.stats.binned_statistic / _2d / _dd read it (scipy/stats/_binned_statistic.py: binned_statistic wraps a
+    2-element range into a list, ``_bin_edges`` checks the length and the order and unpacks a (start, stop) pair per dimension):
+    -> (smin, smax) arrays, raising what SciPy raises for what it refuses.  upstream hands ``list_ranges`` AS IS to every 1-D,
+    2-D and N-D call (xdem/spatialstats.py:147, 176, 190), so with more than one variable only SciPy's errors can come out --
+    reproduced, not repaired."""
+    if one_d and len(rng) == 2:
+        rng = [rng]
+    if len(rng) != ndim:
+        raise ValueError(f"range given for {len(rng)} dimensions; {ndim} required")
+    smin, smax = np.empty(ndim), np.empty(ndim)
+    for i in range(ndim):
+        if rng[i][1] < rng[i][0]:
+            raise ValueError(f"In {f'dimension {i + 1} of ' if ndim > 1 else ''}range, start must be <= stop")
+        smin[i], smax[i] = rng[i]
+    return smin, smax
+
+
 def _scipy_edges(sample_cols: list[np.ndarray], mins: list[float], maxs: list[float], bins: list) -> tuple[list[np.ndarray], list[int], Any]:
     """Bin edges, rounding decimals and sample dtype exactly as scipy.stats._binned_statistic._bin_edges /
-    _bin_numbers derive them (range=None): ``smin, smax`` of the kept rows as float, +-0.5 when equal, ``np.linspace`` in
-    the dtype of SciPy's sample matrix (the variables' common float dtype)."""
+    _bin_numbers derive them: ``smin, smax`` of the kept rows (range=None) or of the given range as float, +-0.5 when equal,
+    ``np.linspace`` in the dtype of SciPy's sample matrix (the variables' common float dtype)."""
     sdt = np.result_type(*[c.dtype for c in sample_cols])
     edges_dtype = sdt if np.issubdtype(sdt, np.floating) else np.dtype(float)
     edges, decimals = [], []
@@ -757,10 +775,12 @@ class BinStatsPlan:
         self.n_valid = int(nv.value)
         self.var_min, self.var_max = vmin, vmax
 
-    def run(self, var_ids: list[int], bins: list, want_nmad: bool = True, nfact: float = 1.4826):
-        """One binning over the given variables -> (count int64, median f64, nmad f64 | None, edges) in C order."""
+    def run(self, var_ids: list[int], bins: list, want_nmad: bool = True, nfact: float = 1.4826, ranges=None):
+        """One binning over the given variables -> (count int64, median f64, nmad f64 | None, edges) in C order.  ``ranges`` =
+        (smin, smax) per variable instead of the data's own extent (SciPy's ``range=``; samples outside fall into no bin)."""
         cols = [self.vars[i] for i in var_ids]
-        edges, decimals, sdt = _scipy_edges(cols, [self.var_min[i] for i in var_ids], [self.var_max[i] for i in var_ids], bins)
+        mins, maxs = ([self.var_min[i] for i in var_ids], [self.var_max[i] for i in var_ids]) if ranges is None else ranges
+        edges, decimals, sdt = _scipy_edges(cols, mins, maxs, bins)
         shape = tuple(len(e) - 1 for e in edges)
         nb = int(np.prod(shape))
         flat = np.concatenate([np.asarray(e, np.float64) for e in edges])
@@ -797,14 +817,14 @@ def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=
     1-D binnings per variable, all 2-D combinations, one N-D binning when there are more than two variables, and the
     same DataFrame layout (``nd``, statistic columns named after the callables, one ``pd.IntervalIndex`` column per
     variable).  Statistics evaluated on the device: ``"count"``, ``np.nanmedian`` / ``"median"`` and ``nmad``; any other
-    callable raises ``NotImplementedError`` (this package has no CPU engine).  ``list_ranges`` must be None.
+    callable raises ``NotImplementedError`` (this package has no CPU engine).  ``list_ranges`` goes to every binning exactly as
+    upstream hands it to SciPy's ``range=`` (a (start, stop) pair or a one-element list of pairs for ONE variable; with several
+    variables SciPy's own ValueError / TypeError comes out, as upstream).
     """
     import itertools
 
     import pandas as pd
 
-    if list_ranges is not None:
-        raise NotImplementedError("list_ranges is not supported by the HIP engine (bin ranges come from the data, as by default).")
     if list_var_bins is None:
         list_var_bins = (10,) * len(list_var_names)
     elif isinstance(list_var_bins, (int, np.integer)):
@@ -822,8 +842,9 @@ def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=
 
     plan = BinStatsPlan(np.asarray(values), [np.asarray(v) for v in list_var], ctx)
     try:
-        def stats_df(var_ids, bins):
-            c, m, s, edges = plan.run(var_ids, bins, want_nmad)
+        def stats_df(var_ids, bins, one_d=False):
+            rng = None if list_ranges is None else _scipy_range(list_ranges, len(var_ids), one_d)
+            c, m, s, edges = plan.run(var_ids, bins, want_nmad, ranges=rng)
             df = pd.DataFrame()
             for name, kind in zip(statistics_name, kinds):
                 col = {"count": c.astype(float), "median": m, "nmad": s}[kind]
@@ -832,7 +853,7 @@ def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=
 
         list_df_1d = []
         for i in range(len(list_var)):
-            df, (e,) = stats_df([i], [list_var_bins[i]])
+            df, (e,) = stats_df([i], [list_var_bins[i]], one_d=True)
             df[list_var_names[i]] = pd.IntervalIndex.from_breaks(e, closed="left")
             df.insert(0, "nd", 1)
             list_df_1d.append(df)
