@@ -1,9 +1,9 @@
 """Does the ORDER of the two big allocations decide which of the two speeds a process gets?  (measurement tool)
-  python tools/alloc_order_probe.py out_first|dem_first|dem_first_empty"""
+  python tools/probes/alloc_order_probe.py out_first|dem_first|dem_first_empty"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 import sys, os, time, faulthandler
 faulthandler.dump_traceback_later(45, repeat=True)
 print('start', flush=True)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from xdem_amd import _lib, terrain
 from xdem_amd.synth import fbm_numpy

@@ -1,9 +1,9 @@
-"""End-to-end rate of the host-buffer entry (numpy in, numpy out: H2D + kernel + D2H): python tools/host_path_probe.py [n]"""
+"""End-to-end rate of the host-buffer entry (numpy in, numpy out: H2D + kernel + D2H): python tools/probes/host_path_probe.py [n]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 from xdem_amd import terrain

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters + HBM bytes of the Nuth-Kaab lean kernels and of the variogram passes (<= 8 SQ counters per pass, every rocprofv3
-# under timeout); run through gpurun:  bash tools/gpu_nk_pmc.sh <tag>
+# under timeout); run through gpurun:  bash tools/sessions/gpu_nk_pmc.sh <tag>
 TAG=${1:-r02nk}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
