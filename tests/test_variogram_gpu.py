@@ -560,6 +560,58 @@ def test_morton_ordered_copy_equals_callers_order(ss, estimator):
         assert np.allclose(got[1][0][ok], eo[ok], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("kind,dtype", [("pdist", np.float32), ("cdist", np.float64)])
+def test_run_length_counting_pass_on_lattice_sets(ss, kind, dtype):
+    """The run-length counting pass of the exact Dowd selection (round 4) outside the bench's configuration: all i < j pairs of
+    one lattice point set (tiles at and below the diagonal keep the per-pair path) and float64 values, >= 4e9 pairs each.
+    Medians and counts identical with run-length counting, per-pair counting on the sorted copy, the caller's order, and the
+    plain digit passes; a spatially correlated field with ties."""
+    from xdem_amd import _lib
+
+    rng = np.random.default_rng(11)
+    L = 20000
+    f = lambda x, y: np.round(np.sin(x / 700.0) * np.cos(y / 900.0) + 0.05 * rng.normal(size=x.size), 3).astype(dtype)  # noqa: E731
+    if kind == "pdist":
+        n = 92000
+        x, y = rng.integers(0, L, n).astype(np.float64), rng.integers(0, L, n).astype(np.float64)
+        blocks = [(x, y, f(x, y))]
+        total = n * (n - 1) // 2
+    else:
+        blocks = []
+        for _ in range(3):
+            na, nbp = 20000, 70000
+            ax, ay = rng.integers(0, L, na).astype(np.float64), rng.integers(0, L, na).astype(np.float64)
+            bx, by = rng.integers(0, L, nbp).astype(np.float64), rng.integers(0, L, nbp).astype(np.float64)
+            blocks.append((ax, ay, f(ax, ay), bx, by, f(bx, by)))
+        total = 3 * 20000 * 70000
+    assert total >= 4_000_000_000
+    edges = np.geomspace(np.sqrt(2), np.hypot(L, L), 40)
+    ctx = _lib.default_context()
+    ps = ss.PairSet(blocks, edges, ctx)
+    res = {}
+    try:
+        assert ps.n_pairs == total
+        s_m, c_m = ps.sums(0)
+        res["run-length"] = ss.class_medians(ps)
+        ctx.set_option("vario_runs", 0)
+        res["per pair, sorted"] = ss.class_medians(ps)
+        ctx.set_option("vario_runs", 1)
+        ctx.check(ctx._L.xdemhip_pairs_link_sorted(ps.handle_sel, None))
+        res["per pair, caller's order"] = ss.class_medians(ps)
+        ctx.check(ctx._L.xdemhip_pairs_link_sorted(ps.handle_sel, ps.handle))
+        ctx.set_option("selection", 1)
+        res["plain"] = ss.class_medians(ps)
+    finally:
+        ctx.set_option("selection", 0)
+        ctx.set_option("vario_runs", 1)
+        ps.close()
+    med0, cnt0 = res["plain"]
+    assert np.array_equal(cnt0, c_m) and cnt0.sum() <= total
+    for k, (med, cnt) in res.items():
+        assert np.array_equal(cnt, cnt0), k
+        assert np.array_equal(med, med0, equal_nan=True), k
+
+
 def test_link_sorted_refuses_a_different_pair_set(ss):
     """xdemhip_pairs_link_sorted: the companion must hold the same blocks (sizes, dtype, edges); anything else is refused and
     the set stays unlinked."""
