@@ -3,7 +3,10 @@
 Same signature and DataFrame result (``exp``, ``lags``, ``count``, ``err_exp``; last lag dropped) as the reference
 (``xdem/spatialstats.py:1295-1546``).  The host preparation (grid coordinates, ``maxlag``, sqrt(2)-geometric right
 bin edges, child seeds, equidistant sampling parameters ``_choose_cdist_equidistant_sampling_parameters`` 1104-1183,
-multi-run aggregation) follows the reference line by line; the pairwise work that upstream delegates to scikit-gstat
+multi-run aggregation) follows the reference line by line -- deliberately: the integer parameter rule must reproduce ``runs /
+samples / ratio`` exactly, the reference's tests assert the messages, and the aggregation IS pandas' ``groupby().mean() / .std()``
+(its compensated summation is part of the recorded DataFrames), so those three blocks keep the reference's statements rather than
+an equivalent of their own; the pairwise work that upstream delegates to scikit-gstat
 (``skg.Variogram`` / ``skg.RasterEquidistantMetricSpace``) runs in ``csrc/variogram.hip`` through the
 ``xdemhip_pairs_*`` C-ABI: distances, lag classes, and per-class Matheron / Cressie-Hawkins sums or the exact
 median for Dowd (radix selection over integer histograms, all-reducible across GPUs).
