@@ -293,6 +293,49 @@ def test_halo_rows_equal_full_raster(terrain):
         assert np.array_equal(out[i].cpu().numpy(), f[r0:r1], equal_nan=True)
 
 
+def test_fresh_scattered_ranges_hold_what_the_kernel_wrote(terrain):
+    """Round 4: plane ranges that are allocated, freed (not pooled) and allocated again, with other ranges and torch blocks coming
+    and going in between.  A range that was re-reserved at the address of a freed one used to be read and written through
+    translations of the previous mapping (profiles/r04_vmm_stale_probe.txt: tens of MiB of other memory's contents in 6 of 14
+    repeats at 46400^2); the library keeps freed ranges reserved since.  Every pixel of every repeat against the same launch
+    into torch planes."""
+    import gc
+
+    import torch
+
+    from xdem_amd import _lib
+    from xdem_amd.synth import fbm_torch
+
+    ctx = _lib.default_context()
+    n = 23000
+    attrs, kw = ["roughness", "topographic_position_index"], {"window_size": 5}
+    dem = fbm_torch(n, n, "cuda", seed=9)
+    ref = torch.empty((2, n, n), device="cuda")
+    terrain.terrain_attributes_device(dem, attrs, resolution=10.0, out=ref, **kw)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(4)
+    seen = set()
+    for it in range(10):
+        junk = [terrain.alloc_planes(int(k), 6144, 6144, backing="scattered") for k in rng.integers(1, 10, 3)]
+        tj = [torch.empty(int(m) << 20, device="cuda") for m in rng.integers(64, 1024, 3)]
+        for j in junk:
+            j.fill_(float(it))
+        del junk, tj
+        gc.collect()
+        ctx.release_pool()          # (the ranges really go back: the next allocation maps new pieces)
+        if it % 3 == 2:
+            torch.cuda.empty_cache()
+        out = terrain.alloc_planes(2, n, n, backing="scattered")
+        terrain.terrain_attributes_device(dem, attrs, resolution=10.0, out=out, **kw)
+        torch.cuda.synchronize()
+        bad = int((out.view(torch.int32) != ref.view(torch.int32)).sum())
+        assert bad == 0, (it, bad, hex(out.data_ptr()), out.data_ptr() in seen)
+        seen.add(out.data_ptr())
+        del out
+        gc.collect()
+        ctx.release_pool()
+
+
 @pytest.mark.parametrize("backing", ["contiguous", "chunked", "scattered", "recycled"])
 def test_library_allocated_planes(terrain, backing):
     """xdemhip_device_alloc / terrain.alloc_planes(backing=...): resident planes on the library's own allocations (physically
