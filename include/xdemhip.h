@@ -94,7 +94,9 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
  * useful brackets; 1 plain 8-bit radix passes only; 2 degenerate brackets (exercises the fall-back); 3 bracketed even
  * where the per-bin sample is small (test switch).  Results are identical in every mode.
  * "host_chunk_mb": device-memory budget (MiB) of one row chunk of host-buffer xdemhip_terrain calls (0 = default 8192): host
- * rasters of any size stream through the GPU in row chunks with the overlap the attributes need.  "host_copy_threads":
+ * rasters of any size stream through the GPU in row chunks with the overlap the attributes need.  "host_chunk_rows": rows per
+ * chunk instead (0 = from the budget; at least 64 are taken) -- what the reference's tiled call takes from
+ * `mp_config.chunk_size` (xdem/terrain/terrain.py:412-466); chunked and one-pass results are bit-identical.  "host_copy_threads":
  * threads (one HIP stream each) that move host-buffer rasters over PCIe, rows split among them (0 = default 8, at most 16).
  * "nk_nan_rule": how nodata spreads through the bilinear taps of the Nuth-Kaab step / translation resample (the convention
  * of geoutils' _interp_points is not pinned by anything readable offline): 0 "4tap" (default; NaN if any of the four taps is
@@ -110,6 +112,10 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
  * integer-lattice pair kernels, 0 = always the float64-coordinate kernels; classes and results are identical.
  * "terrain_store" / "terrain_rows" / "terrain_math": measurement switches of the fused terrain kernel (0 = default each):
  * staged 1 KiB row stores, tile height, float64 attribute math for float32 rasters.
+ * "terrain_nonfinite": which of the reference's two rules decides what +-Inf pixels do to the surface-fit attributes -- 0
+ * (default) the SciPy engine's: an output is NaN iff its full window holds a non-finite value (surfit.py:1185-1192); 1 the
+ * Numba engine's (surfit.py:948-1088, 1270-1303): no mask, the float64 loop over every tap and the formulas decide (0 x Inf
+ * and Inf - Inf give NaN, other infinite windows give slope 90 deg etc.).  NaN pixels and raster edges behave alike under both.
  * "pairs_launch_cap": workgroups per launch of the variogram pair passes (0 = default 2^31 / workgroup size, the most a HIP
  * dispatch holds; a pass over more tiles goes out as several launches -- a small value is a test switch for that path). */
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value);

@@ -22,7 +22,7 @@ import numpy as np
 
 REFERENCE_ROOT = os.environ.get("XDEM_REFERENCE_ROOT", "/root/reference")
 
-_STUB_ROOTS = ("geoutils", "geopandas", "rasterio", "affine", "pyproj", "shapely", "pyogrio", "skgstat", "numba")
+_STUB_ROOTS = ("geoutils", "geopandas", "rasterio", "affine", "pyproj", "shapely", "pyogrio", "skgstat")
 
 
 class _Anything:
@@ -104,6 +104,35 @@ def _get_array_and_mask(array, check_shape=True, copy=True):
     return arr, invalid
 
 
+def _numba_shim() -> types.ModuleType:
+    """A `numba` that compiles nothing: the reference's @njit functions (surfit.py:948-1088, window.py:767-870,
+    spatialstats.py:2528-2555) are plain Python, so with `njit` = identity (both call forms: `@njit(...)` on a
+    function and `njit(...)(f)`), `prange` = `range` and `typed.List` = `list` the reference's own numba-engine code
+    runs in the interpreter -- same statements, same IEEE operations in the same order (Numba does not contract or
+    reassociate without fastmath), only slower.  That is what pins row a8: `engine="numba"` fixtures are outputs of the
+    reference's code, not of a restatement."""
+    m = types.ModuleType("numba")
+
+    def njit(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]  # bare @njit
+
+        def deco(f):
+            return f
+
+        return deco
+
+    m.njit = njit
+    m.jit = njit
+    m.prange = range
+    typed = types.ModuleType("numba.typed")
+    typed.List = list
+    m.typed = typed
+    m.__xdem_oracle_shim__ = True
+    sys.modules["numba.typed"] = typed
+    return m
+
+
 _installed = False
 
 
@@ -115,6 +144,8 @@ def install() -> None:
     if not os.path.isdir(os.path.join(REFERENCE_ROOT, "xdem")):
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT} (only exists in the build container)")
     sys.meta_path.insert(0, _StubFinder())
+    if "numba" not in sys.modules:
+        sys.modules["numba"] = _numba_shim()
     import geoutils  # noqa: F401  (stub)
     import geoutils.profiler
     import geoutils.raster
@@ -124,6 +155,9 @@ def install() -> None:
     geoutils.raster.Raster = _Raster
     geoutils.raster.RasterType = _Raster
     geoutils.raster.get_array_and_mask = _get_array_and_mask
+    import geoutils.raster.array
+
+    geoutils.raster.array.get_array_and_mask = _get_array_and_mask   # spatialstats.py:37 imports it from there
     import geopandas
 
     geopandas.GeoDataFrame = type("GeoDataFrame", (), {})  # isinstance() sentinel, never instantiated

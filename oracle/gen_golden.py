@@ -11,6 +11,9 @@ Fixture families:
   terrain_T4     int32 DEM -> float32 outputs
   terrain_T5     window sizes 3/5/7 for TPI/TRI
   terrain_T9     rugosity + fractal roughness (incl. the known answers of test_window.py:21-89)
+  terrain_T11    the reference's own NUMBA-engine code (surfit.py:948-1088, 1270-1303; window.py:767-870, 980-1000) run
+                 in the interpreter through the identity-njit shim of _refimport.py: T1 DEMs (f32 + f64, NaN and Inf
+                 holes), a terrain-like DEM, three fits, both curvature methods, windowed indexes
   nk_T5_*        Nuth-Kaab bin-fit cases (aspect binning, nanmedian per bin, curve_fit) + aux gradient (T8)
   nk_T6          _iterate_method stop-rule trace
   vario_T7       _choose_cdist_equidistant_sampling_parameters table + default bin edges
@@ -207,6 +210,65 @@ def terrain_T9() -> None:
     np.savez_compressed(os.path.join(OUT, "terrain_T9_rugosity_fractal.npz"), **rec)
 
 
+def terrain_T11_numba() -> None:
+    """Row a8 of SURVEY section 8: outputs of the reference's `engine="numba"` code path.  numba itself is absent; the
+    functions behind @njit are plain Python and run unchanged under _refimport's identity decorator (prange = range), i.e.
+    the same IEEE operations in the same order as the compiled loops (no fastmath in the decorators).  Surface fit: the
+    derivatives stay float64 (surfit.py:1044) -- and, unlike the SciPy engine, there is no dilation of the non-finite
+    mask: NaN comes from the arithmetic alone (0 x Inf, Inf - Inf), so pixels next to a +-Inf hole keep values such as
+    slope 90 deg.  Windowed indexes: the callbacks see the window in the DEM dtype (window.py:851), float32 sums
+    included (NumPy's pairwise `np.sum` here, a sequential loop under real numba -- recorded for float32 as the
+    reference's statements evaluated by NumPy, compared within the float32 rounding noise of that sum)."""
+    assert getattr(sys.modules["numba"], "__xdem_oracle_shim__", False) and ref.surfit._HAS_NUMBA
+    rng = np.random.default_rng(42)
+    base = rng.normal(size=(20, 20))
+    rec = {}
+    dems = {}
+    for dt in (np.float32, np.float64):
+        for hole in ("nan", "inf"):
+            dem = base.astype(dt)
+            dem[4, 4:6] = np.nan
+            dem[17, 16] = np.nan if hole == "nan" else np.inf
+            if hole == "inf":
+                dem[10, 2] = -np.inf
+            dems[f"T1_{np.dtype(dt).name}_{hole}"] = dem
+    rng2 = np.random.default_rng(7)
+    tl = (1000.0 + np.cumsum(np.cumsum(rng2.normal(scale=0.05, size=(28, 30)), axis=0), axis=1)).astype(np.float32)
+    tl[12:14, 20] = np.nan
+    dems["terrainlike_float32"] = tl
+    for name, dem in dems.items():
+        rec[f"dem|{name}"] = dem
+        for fit in ("Horn", "ZevenbergThorne", "Florinsky"):
+            for cm in ("geometric", "directional"):
+                if fit == "Horn" and cm == "directional":
+                    continue
+                for res in ((10.0,) if name.startswith("terrainlike") else (1.0, 2.0, 10.0)):
+                    attrs = SAH if fit == "Horn" else SURF
+                    outs = run_ref(dem, attrs, resolution=res, surface_fit=fit, curv_method=cm, engine="numba")
+                    for a, o in zip(attrs, outs):
+                        rec[f"{name}|{fit}|{cm}|{res}|{a}"] = o
+    # direct call of the engine boundary (SURVEY 8b row 1), radians, explicit out_dtype
+    d = dems["T1_float32_nan"]
+    for od in (np.float32, np.float64):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = ref.surfit._get_surface_attributes(dem=d, resolution=2.0, surface_attributes=SURF, out_dtype=od,
+                                                     surface_fit="Florinsky", curv_method="geometric", engine="numba")
+        rec[f"boundary|Florinsky|{np.dtype(od).name}"] = out
+    # windowed indexes through the numba path
+    win_all = WIN + ["roughness"]
+    for name in ("T1_float32_nan", "T1_float64_inf", "terrainlike_float32"):
+        dem = dems[name]
+        for w in (3, 5):
+            for tri in ("Riley", "Wilson"):
+                outs = run_ref(dem, win_all, window_size=w, tri_method=tri, engine="numba")
+                for a, o in zip(win_all, outs):
+                    rec[f"{name}|win|{w}|{tri}|{a}"] = o
+        rec[f"{name}|rugosity|2.0"] = run_ref(dem, ["rugosity"], resolution=2.0, engine="numba")[0]
+        rec[f"{name}|fractal_roughness|13"] = run_ref(dem, ["fractal_roughness"], engine="numba")[0]
+    np.savez_compressed(os.path.join(OUT, "terrain_T11_numba_engine.npz"), **rec)
+
+
 def terrain_T10() -> None:
     """Texture shading (freq.py:63-148), SURVEY 8f-4: reference outputs for float32 / float64 DEMs with holes, several alpha,
     FFT lengths below and above 1024 (power-of-two and 7-smooth padding), plus the data-free cases of test_freq.py."""
@@ -244,6 +306,7 @@ if __name__ == "__main__":
         terrain_T4_T5()
         terrain_T9()
         terrain_T10()
+        terrain_T11_numba()
         print("terrain fixtures written")
     if "nk" in which:
         import gen_golden_nk

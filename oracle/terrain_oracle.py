@@ -114,15 +114,39 @@ def _convolve_nan_const(dem: np.ndarray, kernel_f64: np.ndarray) -> np.ndarray:
     return acc.astype(dem.dtype)
 
 
-def surface_coefficients(dem: np.ndarray, resolution: float, surface_fit: str, names: list[str]) -> dict[str, np.ndarray]:
-    """Per-pixel derivative estimates (float64 arrays holding input-dtype-rounded values)."""
+def _convolve_numba_loop(dem: np.ndarray, kernel_f64: np.ndarray) -> np.ndarray:
+    """The per-pixel loop of the reference's Numba engine (surfit.py:948-971 on the NaN-padded DEM of 1275-1282),
+    vectorised over pixels: a float64 accumulator adds ``value * weight`` for EVERY tap of the flipped kernel in row-major
+    window order -- zero weights included, so 0 x Inf = NaN and Inf - Inf = NaN arise from the arithmetic itself -- and
+    the sum is NOT rounded to the DEM dtype (out_dtype=np.float64 at surfit.py:1044)."""
+    k = kernel_f64[::-1, ::-1]
+    m = k.shape[0]
+    h = m // 2
+    H, W = dem.shape
+    pad = np.full((H + 2 * h, W + 2 * h), np.nan, dtype=dem.dtype)
+    pad[h : h + H, h : h + W] = dem
+    acc = np.zeros((H, W), dtype=np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for a in range(m):
+            for b in range(m):
+                acc += pad[a : a + H, b : b + W] * k[a, b]
+    return acc
+
+
+def surface_coefficients(dem: np.ndarray, resolution: float, surface_fit: str, names: list[str],
+                         engine: str = "scipy") -> dict[str, np.ndarray]:
+    """Per-pixel derivative estimates: float64 arrays holding input-dtype-rounded values (SciPy engine) or the unrounded
+    float64 sums of the Numba engine's loop."""
     ks = conv_kernels(surface_fit)
     out = {}
     for n in names:
         tab, (const, power) = ks[n]
         kern = tab.astype(np.float64)
         kern /= const * resolution**power  # surfit.py:373-377: integer table / divider, in double
-        out[n] = _convolve_nan_const(dem, kern).astype(np.float64)
+        if engine == "numba":
+            out[n] = _convolve_numba_loop(dem, kern)
+        else:
+            out[n] = _convolve_nan_const(dem, kern).astype(np.float64)
     return out
 
 
@@ -149,8 +173,12 @@ def surface_attributes(
     hillshade_altitude: float = 45.0,
     hillshade_azimuth: float = 315.0,
     hillshade_z_factor: float = 1.0,
+    engine: str = "scipy",
 ) -> np.ndarray:
-    """Oracle of ``_get_surface_attributes(..., engine="scipy")`` (surfit.py:1197-1305). Output (n,H,W), radians."""
+    """Oracle of ``_get_surface_attributes`` (surfit.py:1197-1305). Output (n,H,W), radians.  ``engine="scipy"``: the
+    default recipe; ``engine="numba"``: surfit.py:948-1088, 1270-1303 -- float64 derivatives from the explicit loop, the
+    same formulas, and NO dilated non-finite mask (NaN only where the arithmetic produces it; pinned by
+    tests/golden/terrain_T11_numba_engine.npz, outputs of the reference's own numba-engine code)."""
     fit_id = FITS[surface_fit.lower()]
     directional = curv_method.lower() == "directional"
     want = set(surface_attributes)
@@ -162,7 +190,7 @@ def surface_attributes(
     names = (["zx", "zy"] if need_grad else []) + (["zxx", "zyy"] if need2 else [])
     if need2 and (want - {"slope", "aspect", "hillshade", "curvature"}):
         names.append("zxy")
-    C = surface_coefficients(dem, resolution, surface_fit, names)
+    C = surface_coefficients(dem, resolution, surface_fit, names, engine)
 
     H, W = dem.shape
     res = np.full((len(surface_attributes), H, W), np.nan, dtype=out_dtype)
@@ -233,7 +261,8 @@ def surface_attributes(
                     put("max_curvature", vmax * 100)
                     put("min_curvature", vmin * 100)
 
-    res[:, _window_invalid(dem, 5 if fit_id == 2 else 3)] = np.nan
+    if engine != "numba":
+        res[:, _window_invalid(dem, 5 if fit_id == 2 else 3)] = np.nan
     return res
 
 
@@ -429,8 +458,12 @@ def terrain_attributes(
     out_dtype=None,
     window_size_fractal: int = 13,
     texture_alpha: float = 0.8,
+    engine: str = "scipy",
 ) -> list[np.ndarray]:
-    """Oracle of ``_get_terrain_attribute`` for ndarray input (terrain.py:528-666): engines + unit/clip post-steps."""
+    """Oracle of ``_get_terrain_attribute`` for ndarray input (terrain.py:528-666): engines + unit/clip post-steps.
+    ``engine`` selects the surface-fit recipe only; windowed indexes are the SciPy engine's float64 callbacks either way
+    (the Numba engine hands them the window in the DEM dtype, window.py:851 -- its float32 sums are a noisier evaluation
+    of the same quantity, see tests/test_oracle_golden.py::test_T11_windowed)."""
     dem = np.asarray(dem)
     if out_dtype is None:
         out_dtype = np.float32 if np.issubdtype(dem.dtype, np.integer) else dem.dtype
@@ -441,7 +474,7 @@ def terrain_attributes(
     results: dict[str, np.ndarray] = {}
     if surf:
         s = surface_attributes(dem, resolution, surf, out_dtype, surface_fit, curv_method,
-                               hillshade_altitude, hillshade_azimuth, hillshade_z_factor)
+                               hillshade_altitude, hillshade_azimuth, hillshade_z_factor, engine)
         for i, name in enumerate(surf):
             v = s[i]
             if degrees and name in ("slope", "aspect"):

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../xdem_amd/csrc/terrain_math.h"
+#include "../../xdem_amd/csrc/terrain_nonfinite.h"
 
 using namespace xd;
 
@@ -95,4 +96,26 @@ extern "C" int hostsim_terrain(const void* dem, int dem_dtype, int64_t H, int64_
     if (dem_dtype == 1 && out_dtype == 1) return go<double, double>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
     if (dem_dtype == 0 && out_dtype == 1) return go<float, double>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
     return go<double, float>(dem, H, W, halo_top, halo_bottom, tile_rows, fit, P, planes12);
+}
+
+// The Numba engine's rule for +-Inf pixels (xdem_amd/csrc/terrain_nonfinite.h) applied on top of planes hostsim_terrain has
+// filled -- what terrain_nonfinite.hip's kernel does per pixel under option "terrain_nonfinite" = 1.
+template <typename TIN, typename TOUT>
+static void nf_go(const void* dem, int64_t H, int64_t W, int64_t ht, int64_t hb, const NfParams& P, void* const* planes) {
+    NfPlanes<TOUT> out;
+    for (int k = 0; k < 10; ++k) out.p[k] = static_cast<TOUT*>(planes[k]);
+    for (int64_t r = 0; r < H; ++r)
+        for (int64_t c = 0; c < W; ++c) nf_pixel<TIN, TOUT>(static_cast<const TIN*>(dem), r, c, H, W, W, ht, hb, P, out);
+}
+extern "C" int hostsim_nonfinite(const void* dem, int dem_dtype, int64_t H, int64_t W, int64_t halo_top, int64_t halo_bottom,
+                                 double resolution, int fit, int curv_dir, uint32_t mask, double hs_alt, double hs_az, double hs_z,
+                                 int degrees, int out_dtype, void* const* planes12) {
+    NfParams P;
+    nf_fill_params(P, fit, curv_dir, resolution, hs_alt, hs_az, hs_z, degrees, mask & 0x3ffu);
+    if (!P.mask) return 0;
+    if (dem_dtype == 0 && out_dtype == 0) nf_go<float, float>(dem, H, W, halo_top, halo_bottom, P, planes12);
+    else if (dem_dtype == 1 && out_dtype == 1) nf_go<double, double>(dem, H, W, halo_top, halo_bottom, P, planes12);
+    else if (dem_dtype == 0 && out_dtype == 1) nf_go<float, double>(dem, H, W, halo_top, halo_bottom, P, planes12);
+    else nf_go<double, float>(dem, H, W, halo_top, halo_bottom, P, planes12);
+    return 0;
 }

@@ -80,12 +80,15 @@ def compare_true(got: np.ndarray, ref: np.ndarray, floor: float = 0.0):
     # "excused" = share of the finite pixels that DIFFER from the reference and were not judged because the difference lies
     # inside the float64 noise floor (0 on outputs of real relief; up to all of them on fixtures whose exact answer is 0)
     out = {"nan_equal": nan_equal, "inf_equal": inf_equal, "max_rel": 0.0, "exact": 1.0, "hist": [1.0, 0, 0, 0, 0, 0],
-           "max_ulp": 0, "n": int(fin.sum()), "excused": 0.0}
+           "max_ulp": 0, "n": int(fin.sum()), "excused": 0.0, "n_signal": 0}
     if fin.any():
         r = ref[fin].astype(np.float64)
         g = got[fin].astype(np.float64)
         err = np.abs(g - r)
         judged = err > floor
+        # pixels whose REFERENCE value stands above the floor: a result of exactly 0 there has err = |ref| > floor and is judged
+        # (and fails) -- the floor can only excuse results on pixels whose reference value is itself noise
+        out["n_signal"] = int(np.sum(np.abs(r) > floor))
         out["excused"] = float(np.mean((err > 0) & ~judged))
         with np.errstate(divide="ignore", invalid="ignore"):
             rel = np.where(judged, err / np.abs(r), 0.0)

@@ -220,6 +220,20 @@ def test_variogram_host_preparation():
     assert (runs, samples) == (100, 23) and abs(ratio - 0.0037559253144038175) < 1e-18   # SURVEY probe value
     with pytest.raises(ValueError, match="needs to be at least 10"):
         ss._choose_cdist_equidistant_sampling_parameters(extent=(0, 9, 0, 9), shape=(10, 10), subsample=5)
+    # the whole T7 table recorded from the reference (integers exact, the ratio bit for bit), on the PRODUCT's function
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vario_golden.npz"))
+    n_ok = 0
+    for subsample, nx, ny, gsd, runs, samples, ratio in z["T7|params"]:
+        shape = (int(nx), int(ny))
+        kw = dict(extent=(0.0, (shape[0] - 1) * gsd, 0.0, (shape[1] - 1) * gsd), shape=shape, subsample=int(subsample))
+        if runs < 0:
+            with pytest.raises(ValueError, match="needs to be at least"):
+                ss._choose_cdist_equidistant_sampling_parameters(**kw)
+            continue
+        got = ss._choose_cdist_equidistant_sampling_parameters(**kw)
+        assert got[0] == int(runs) and got[1] == int(samples) and got[2] == ratio, (kw, got, runs, samples, ratio)
+        n_ok += 1
+    assert n_ok >= 30
     k = np.array([0x3F800000 << 1, 0x40000000 << 1], dtype=np.uint64)
     assert ss._key_to_value(k, 32).tolist() == [1.0, 2.0]
 
@@ -499,3 +513,17 @@ def test_dem_integer_nodata_becomes_nan():
     d = xdem_amd.DEM(z, nodata=-9999)
     assert d.dtype == np.float32 and np.isnan(d.data[2, 3]) and np.count_nonzero(np.isnan(d.data)) == 1
     assert xdem_amd.DEM(np.arange(30, dtype=np.int16).reshape(5, 6), nodata=-9999).dtype == np.int16  # nothing to mask: unchanged
+
+
+def test_mp_config_refusals_before_any_gpu_work():
+    """Upstream's tiled call needs a Raster (terrain.py:436-437: TypeError with this message); checked on CPU because it
+    fires before a context exists.  (What mp_config DOES is a GPU test: tests/test_terrain_gpu.py::test_mp_config...)"""
+    from types import SimpleNamespace
+
+    from xdem_amd import terrain as t
+
+    dem = np.arange(12 * 14, dtype=np.float32).reshape(12, 14)
+    with pytest.raises(TypeError, match="The DEM must be a Raster to use multiprocessing."):
+        t.get_terrain_attribute(dem, "slope", resolution=1.0, mp_config=SimpleNamespace(chunk_size=200, outfile=None, cluster=None))
+    with pytest.raises(TypeError, match="The DEM must be a Raster to use multiprocessing."):
+        t.slope(dem, resolution=1.0, mp_config=SimpleNamespace(chunk_size=200, outfile=None, cluster=None))

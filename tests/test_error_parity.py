@@ -35,3 +35,25 @@ def test_validation_matches_reference(case):
             fn(dem, **kw)
     assert type(ei.value).__name__ == case["raises"], (case, repr(ei.value))
     assert str(ei.value) == case["message"], (case["function"], case["kwargs"])
+
+
+SS_CASES = json.load(open(os.path.join(GOLDEN, "spatialstats_errors.json")))
+
+
+@pytest.mark.parametrize("case", SS_CASES, ids=[f"{c['function']}-{i}" for i, c in enumerate(SS_CASES)])
+def test_spatialstats_refusals_match_reference(case):
+    """Argument refusals of sample_empirical_variogram (spatialstats.py:1366-1400) and interp_nd_binning (292-352): exception
+    type and message as the reference itself produced them (recorded by oracle/gen_golden_errors.py; the named inputs are
+    rebuilt by its `build_input` recipe).  Every case is refused before any GPU work."""
+    from gen_golden_errors import build_input
+
+    from xdem_amd import spatialstats as ss
+
+    assert case["raises"] is not None
+    kw = {k: (build_input(v) if k in ("values", "coords", "df") else v) for k, v in case["kwargs"].items()}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(Exception) as ei:
+            getattr(ss, case["function"])(**kw)
+    assert type(ei.value).__name__ == case["raises"], (case, repr(ei.value))
+    assert str(ei.value) == case["message"], (case["function"], case["kwargs"])

@@ -116,6 +116,82 @@ def test_T9_rugosity_fractal_roughness():
         assert np.round(z[f"{name}|fractal_roughness|13"][6, 6], 3) == d
 
 
+def test_T11_numba_engine_surface_fit():
+    """Row a8 of SURVEY section 8: the oracle's numba recipe against outputs of the reference's OWN numba-engine code
+    (surfit.py:948-1088, 1270-1303, run in the interpreter through oracle/_refimport.py's identity-njit shim): float64
+    derivatives from the explicit loop, no dilated non-finite mask.  float32 outputs bit-exact (NaN and +-Inf positions
+    included: slope 90 deg next to an Inf pixel, `curvature` -Inf, ...); float64 outputs to 1e-14 (the per-pixel scalar code
+    path of NumPy uses pow() where the array path uses sqrt)."""
+    z = _load("terrain_T11_numba_engine.npz")
+    n = n_inf_windows = 0
+    for key in z.files:
+        parts = key.split("|")
+        if parts[0] in ("dem", "boundary") or len(parts) != 5 or parts[1] == "win":
+            continue
+        name, fit, cm, res, attr = parts
+        dem = z["dem|" + name]
+        got = to.terrain_attributes(dem, [attr], resolution=float(res), surface_fit=fit, curv_method=cm, engine="numba")[0]
+        ref = z[key]
+        assert got.dtype == ref.dtype and np.array_equal(np.isnan(got), np.isnan(ref)), key
+        if ref.dtype == np.float32:
+            assert _same(got, ref), key
+        else:
+            fin = np.isfinite(ref)
+            assert np.array_equal(got[~fin], ref[~fin], equal_nan=True), key
+            assert np.all(np.abs(got[fin] - ref[fin]) <= 1e-14 * np.abs(ref[fin])), key
+        if name.endswith("_inf"):
+            # the engines differ here: values (not NaN) inside the dilated non-finite mask of the SciPy engine
+            scipy_mask = to._window_invalid(dem, 5 if fit == "Florinsky" else 3)
+            n_inf_windows += int(np.sum(scipy_mask & ~np.isnan(ref)))
+        n += 1
+    assert n > 500 and n_inf_windows > 100
+    # the engine boundary called directly (SURVEY 8b row 1): radians, explicit out_dtype
+    d = z["dem|T1_float32_nan"]
+    for od in (np.float32, np.float64):
+        got = to.surface_attributes(d, 2.0, list(to.SURFACE_ATTRIBUTES), od, "Florinsky", "geometric", engine="numba")
+        ref = z[f"boundary|Florinsky|{np.dtype(od).name}"]
+        assert got.dtype == ref.dtype and got.shape == ref.shape
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.all(np.abs(got[fin] - ref[fin]) <= (0 if od == np.float32 else 1e-14) * np.abs(ref[fin]))
+
+
+def test_T11_numba_engine_windowed_indexes():
+    """The Numba engine hands the callbacks the window in the DEM dtype (window.py:851): for a float64 DEM that is the SciPy
+    engine's arithmetic up to the order of a float64 sum; for a float32 DEM the sums (TPI's mean, TRI's squares, rugosity's
+    areas) are formed in float32 -- a noisier evaluation of the same quantity.  The oracle (like the HIP path) keeps the
+    float64 window under every engine name; the recorded numba outputs must agree with it within the rounding noise of a
+    float32 sum over the window, w^2 * 2^-24 * max|z| (float64 DEM: 1e-12 relative), masks bit-exact."""
+    z = _load("terrain_T11_numba_engine.npz")
+    n = 0
+    for key in z.files:
+        parts = key.split("|")
+        if len(parts) == 5 and parts[1] == "win":
+            name, _, w, tri, attr = parts
+            kw = dict(window_size=int(w), tri_method=tri)
+        elif len(parts) == 3 and parts[1] in ("rugosity", "fractal_roughness"):
+            name, attr, par = parts
+            kw = dict(resolution=float(par)) if attr == "rugosity" else dict(window_size_fractal=int(par))
+            w = 3 if attr == "rugosity" else par
+        else:
+            continue
+        dem = z["dem|" + name]
+        got = to.terrain_attributes(dem, [attr], **kw)[0]
+        ref = z[key]
+        assert got.dtype == ref.dtype and np.array_equal(np.isnan(got), np.isnan(ref)), key
+        fin = np.isfinite(ref) & np.isfinite(got)
+        assert np.array_equal(got[~fin], ref[~fin], equal_nan=True), key
+        zmax = float(np.max(np.abs(dem[np.isfinite(dem)])))
+        if dem.dtype == np.float32:
+            tol = int(w) ** 2 * 2.0**-24 * zmax * (4.0 if attr in ("rugosity", "fractal_roughness") else 1.0)
+            tol = np.maximum(tol, 1e-5 * np.abs(ref[fin])) if attr in ("rugosity", "fractal_roughness") else tol
+        else:
+            tol = 1e-12 * np.maximum(np.abs(ref[fin]), zmax)
+        assert np.all(np.abs(got[fin].astype(np.float64) - ref[fin]) <= tol), (key, float(np.max(np.abs(got[fin].astype(np.float64) - ref[fin]))))
+        n += 1
+    assert n >= 40
+
+
 def test_T10_texture_shading():
     """f4 of SURVEY 8f: the oracle runs the same scipy.fft transforms as the reference -> bit-exact on this SciPy build
     (a different pocketfft build may differ in the last bits: 1e-5 of the output scale allowed)."""

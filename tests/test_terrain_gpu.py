@@ -78,8 +78,8 @@ def test_f64_in_out_and_mixed(terrain):
 
 def test_engine_names_select_the_precision_recipe(terrain):
     """'scipy' = the default recipe (derivatives rounded to the DEM dtype); 'numba' = float64 derivatives
-    (surfit.py:1044), i.e. what the float64-input path computes on the widened DEM.  The Numba engine itself cannot run
-    here (numba absent): its variant is checked against the oracle's float64 path, which the reference fixtures pin."""
+    (surfit.py:1044), i.e. what the float64-input path computes on the widened DEM.  Checked here against the oracle's
+    float64 path on a larger raster; the reference's own numba-engine outputs are test_T11_numba_engine_... below."""
     dem = _dem((150, 300), seed=13)
     attrs = FULL + ["roughness"]
     base = terrain.get_terrain_attribute(dem, attrs, resolution=10.0)
@@ -231,7 +231,7 @@ def test_T3_reference_known_answers_on_the_hip_path(terrain, record_property):
     reproduced by the kernel's reference-order recomputation of exactly cancelling derivative sums."""
     z = np.load(os.path.join(GOLDEN, "terrain_T3_known_answers.npz"))
     n = 0
-    exc = {}
+    exc, signal, fixtures_with_signal = {}, {}, {}
     for key in z.files:
         if key.startswith("dem|"):
             continue
@@ -243,14 +243,149 @@ def test_T3_reference_known_answers_on_the_hip_path(terrain, record_property):
         # float64 residues -- the noise floor's whole purpose -- can be every pixel of a fixture; the share is recorded)
         c = assert_parity_true(got, z[key], key, floor=noise_floor(attr, demf, float(res)))
         exc[attr] = max(exc.get(attr, 0.0), c["excused"])
+        signal[attr] = signal.get(attr, 0) + c["n_signal"]
+        fixtures_with_signal[attr] = fixtures_with_signal.get(attr, 0) + (c["n_signal"] > 0)
         n += 1
     assert n > 900
     for attr, e in exc.items():
         record_property(f"T3/{attr}/max_share_excused_by_noise_floor", f"{e:.5f}")
-        print(f"T3 {attr:28s} max share excused by the noise floor {e:.5f}")
+        record_property(f"T3/{attr}/pixels_judged_above_the_floor", f"{signal[attr]} in {fixtures_with_signal[attr]} fixtures")
+        print(f"T3 {attr:28s} max share excused by the noise floor {e:.5f}; {signal[attr]} pixels in "
+              f"{fixtures_with_signal[attr]} fixtures carry a reference value above the floor (judged at 1e-6)")
+        # the complement of the excusal: every attribute has fixtures (V shapes, saddle, ridge, trough, ramps for the first
+        # derivatives) whose reference values stand ABOVE the floor -- there a kernel that returned 0 would fail the 1e-6 bar
+        assert signal[attr] >= 40 and fixtures_with_signal[attr] >= 9, (attr, signal[attr], fixtures_with_signal[attr])
     flat = terrain.get_terrain_attribute(z["dem|flat"], ["slope", "aspect"], resolution=1.0, surface_fit="Florinsky")
     assert flat[1][2, 2] == z["flat|Florinsky|1.0|aspect"][2, 2] == np.float32(198.43494)
     assert flat[0][2, 2] == z["flat|Florinsky|1.0|slope"][2, 2] and 0 < flat[0][2, 2] < 1e-12
+
+
+def test_T11_numba_engine_reference_fixtures_on_the_hip_path(terrain, record_property):
+    """Row a8 of SURVEY section 8.  Outputs of the reference's OWN numba-engine code (surfit.py:948-1088, 1270-1303, run through
+    the identity-njit shim of oracle/_refimport.py; oracle/gen_golden.py: terrain_T11_numba) against `engine="numba"` on the HIP
+    path: float64 derivatives (the float64-input kernels on the widened DEM) and the Numba engine's rule for +-Inf pixels
+    (terrain_nonfinite.hip).  Masks bit-exact -- including the pixels next to an Inf value that the SciPy engine blanks and this
+    engine does not (slope 90 deg, hillshade 1.5 / 181.1, `curvature` -+Inf) --, TRUE relative error <= 1e-6 elsewhere."""
+    z = np.load(os.path.join(GOLDEN, "terrain_T11_numba_engine.npz"))
+    n = n_inf_window_values = 0
+    worst = {}
+    for key in z.files:
+        parts = key.split("|")
+        if parts[0] in ("dem", "boundary") or len(parts) != 5 or parts[1] == "win":
+            continue
+        name, fit, cm, res, attr = parts
+        dem = z["dem|" + name]
+        got = terrain.get_terrain_attribute(dem, attr, resolution=float(res), surface_fit=fit, curv_method=cm, engine="numba")
+        ref = z[key]
+        c = assert_parity_true(got, ref, key, floor=noise_floor(attr, dem, float(res)), max_excused=0.05)
+        if name.endswith("_inf"):
+            blanked_by_scipy = to._window_invalid(dem, 5 if fit == "Florinsky" else 3)
+            sel = blanked_by_scipy & ~np.isnan(ref)
+            n_inf_window_values += int(sel.sum())
+            if ref.dtype == np.float32:   # special values (90, 45 k, 1.5, 181.10512, 0, +-Inf): bit for bit
+                assert np.array_equal(got[sel], ref[sel]), (key, got[sel], ref[sel])
+        w = worst.setdefault(attr, c)
+        if c["max_rel"] >= w["max_rel"]:
+            worst[attr] = c
+        n += 1
+    assert n > 500 and n_inf_window_values > 100
+    for attr, c in worst.items():
+        record_property(f"T11/{attr}", _ulp_line(c))
+        print(f"T11 numba engine {attr:28s} {_ulp_line(c)}")
+    # ... and the option does not leak: the default engine after a numba call still blanks the Inf windows
+    dem = z["dem|T1_float32_inf"]
+    s = terrain.get_terrain_attribute(dem, "slope", resolution=1.0)
+    assert np.array_equal(np.isnan(s), to._window_invalid(dem, 5))
+    # windowed indexes under engine="numba": the float64-window evaluation, within the float32 rounding noise of the recorded one
+    for key in z.files:
+        parts = key.split("|")
+        if len(parts) == 5 and parts[1] == "win" and parts[0] == "terrainlike_float32":
+            name, _, w, tri, attr = parts
+            dem = z["dem|" + name]
+            got = terrain.get_terrain_attribute(dem, attr, window_size=int(w), tri_method=tri, engine="numba")
+            ref = z[key]
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), key
+            fin = np.isfinite(ref)
+            tol = int(w) ** 2 * 2.0**-24 * float(np.nanmax(np.abs(dem)))
+            assert np.all(np.abs(got[fin].astype(np.float64) - ref[fin]) <= tol), key
+
+
+def test_numba_engine_nonfinite_rule_at_scale_and_in_row_blocks(terrain):
+    """The +-Inf fix-up of engine="numba" against the oracle's numba recipe on a raster large enough for the streaming strips
+    and the chunked host path (several row chunks: Inf pixels next to chunk borders), float32 and float64 outputs."""
+    from xdem_amd import _lib
+
+    rng = np.random.default_rng(5)
+    dem = _dem((1500, 1100), seed=21)
+    rows = rng.integers(0, 1500, 40)
+    cols = rng.integers(0, 1100, 40)
+    dem[rows, cols] = np.where(rng.random(40) < 0.5, np.inf, -np.inf).astype(np.float32)
+    dem[0, 0] = np.inf
+    dem[-1, 5] = -np.inf
+    dem[700, 3:6] = np.inf   # two infinite taps of equal sign in one window
+    attrs = ["slope", "aspect", "hillshade", "curvature", "profile_curvature", "max_curvature", "min_curvature"]
+    ctx = _lib.default_context()
+    for chunk_mb in (0, 8):
+        ctx.set_option("host_chunk_mb", chunk_mb)
+        try:
+            for fit, cm in (("Florinsky", "geometric"), ("ZevenbergThorne", "directional")):
+                for od in (np.float32, np.float64):
+                    got = terrain.get_terrain_attribute(dem, attrs, resolution=10.0, surface_fit=fit, curv_method=cm,
+                                                        engine="numba", out_dtype=od)
+                    ref = to.terrain_attributes(dem, attrs, resolution=10.0, surface_fit=fit, curv_method=cm, engine="numba",
+                                                out_dtype=od)
+                    for a, g, r in zip(attrs, got, ref):
+                        assert_parity_true(g, r, f"{fit}/{cm}/{od.__name__}/{a}/chunk{chunk_mb}", floor=noise_floor(a, dem, 10.0))
+        finally:
+            ctx.set_option("host_chunk_mb", 0)
+
+
+class _FakeRaster:
+    """Duck-typed geoutils.Raster (the package is absent): what xdem_amd.terrain needs of one."""
+    saved = {}
+
+    def __init__(self, data, transform=(10.0, 0, 0, 0, -10.0, 0), crs=None, nodata=None):
+        self.data, self.transform, self.crs, self.nodata, self.res = data, transform, crs, nodata, (10.0, 10.0)
+
+    @classmethod
+    def from_array(cls, data, transform, crs, nodata=None):
+        return cls(data, transform, crs, nodata)
+
+    def save(self, filename):
+        _FakeRaster.saved[filename] = self.data.copy()
+
+
+def test_mp_config_is_the_row_chunked_host_path(terrain):
+    """`mp_config` (upstream: geoutils MultiprocConfig -> tiles with overlap, terrain.py:412-466) maps onto the library's
+    row-chunked host path: chunk_size rows per chunk, overlap derived from the attributes, planes bit-identical to the one-pass
+    call; `outfile` goes through the Raster's own save, one file per attribute named as upstream names them; a worker cluster is
+    ignored with a warning; the option does not outlive the call."""
+    from types import SimpleNamespace
+
+    from xdem_amd import _lib
+
+    dem = _dem((700, 800), seed=17)
+    ras = _FakeRaster(dem)
+    attrs = ["slope", "max_curvature", "topographic_position_index", "fractal_roughness"]
+    one = terrain.get_terrain_attribute(ras, attrs)
+    _FakeRaster.saved.clear()
+    cfg = SimpleNamespace(chunk_size=96, outfile="out/attr.tif", cluster=None)
+    tiled = terrain.get_terrain_attribute(ras, attrs, mp_config=cfg)
+    assert all(isinstance(t, _FakeRaster) and t.nodata == -99999 for t in tiled)
+    for a, o, t in zip(attrs, one, tiled):
+        assert np.array_equal(o.data, t.data, equal_nan=True), a
+        assert np.array_equal(_FakeRaster.saved[f"out/attr_{a}.tif"], t.data, equal_nan=True)
+    assert _lib.default_context().options.get("host_chunk_rows", 0) == 0
+    single = terrain.slope(ras, mp_config=SimpleNamespace(chunk_size=64, outfile="s.tif", cluster=None))
+    assert np.array_equal(single.data, one[0].data, equal_nan=True) and "s.tif" in _FakeRaster.saved
+
+    class MultiprocessingCluster:
+        pass
+
+    with pytest.warns(UserWarning, match="cluster is ignored"):
+        w = terrain.get_terrain_attribute(ras, "slope", mp_config=SimpleNamespace(chunk_size=128, outfile=None,
+                                                                                   cluster=MultiprocessingCluster()))
+    assert np.array_equal(w.data, one[0].data, equal_nan=True)
 
 
 def test_ulp_histogram_per_attribute(terrain, record_property):

@@ -98,3 +98,32 @@ def test_reference_noise_fixtures(fname):
         ref = z[key]
         got = hostsim_terrain(dem, [attr], resolution=float(res), surface_fit=fit, curv_method=cm, out_dtype=ref.dtype)[0]
         assert_parity_true(got, ref, key, floor=noise_floor(attr, dem, float(res)))
+
+
+def test_T11_numba_engine_reference_fixtures():
+    """Row a8: outputs of the reference's own numba-engine code (tests/golden/terrain_T11_numba_engine.npz) against the kernels'
+    math for engine="numba" -- float64-input marcher on the widened DEM + the +-Inf rule of terrain_nonfinite.h -- on the CPU.
+    Masks bit-exact (the values next to +-Inf pixels included), TRUE relative error <= 1e-6."""
+    import os
+
+    from conftest import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "terrain_T11_numba_engine.npz"))
+    n = n_inf = 0
+    for key in z.files:
+        parts = key.split("|")
+        if parts[0] in ("dem", "boundary") or len(parts) != 5 or parts[1] == "win":
+            continue
+        name, fit, cm, res, attr = parts
+        dem = z["dem|" + name]
+        ref = z[key]
+        got = hostsim_terrain(dem, [attr], resolution=float(res), surface_fit=fit, curv_method=cm, out_dtype=ref.dtype,
+                              engine="numba")[0]
+        assert_parity_true(got, ref, key, floor=noise_floor(attr, dem, float(res)))
+        if name.endswith("_inf"):
+            sel = to._window_invalid(dem, 5 if fit == "Florinsky" else 3) & ~np.isnan(ref)
+            n_inf += int(sel.sum())
+            if ref.dtype == np.float32:
+                assert np.array_equal(got[sel], ref[sel]), (key, got[sel], ref[sel])
+        n += 1
+    assert n > 500 and n_inf > 100

@@ -267,10 +267,10 @@ class Context:
         self._pool: list[tuple[int, int, int]] = []   # (nbytes, flags, ptr)
         self._pool_cap = int(float(os.environ.get("XDEM_PLANE_POOL_GB", "16")) * (1 << 30))
         self._pool_lock = threading.Lock()
+        self.options: dict[str, int] = {}  # mirror of the xdemhip_set_option calls made through this object
         for k, v in thirdparty_decision().items():   # conventions decided from the third-party packages' own outputs, where recorded
             if v != THIRDPARTY_DEFAULTS[k]:
                 self.set_option(k, v)
-        self.options: dict[str, int] = {}  # mirror of the xdemhip_set_option calls made through this object
 
     def check(self, rc: int) -> None:
         if rc != OK:
@@ -337,6 +337,11 @@ class Context:
         nbytes = count * np_dt.itemsize
         pooled = self._take_pooled(nbytes, flags)
         if pooled:
+            # The previous owner's tensor is gone, but work it queued on ANY stream (the overlap path's side streams, a caller's
+            # own streams, RCCL sends of its rows) may still be reading or writing the range: freeing it would have waited for the
+            # device (device_free_chunked synchronises before it unmaps), so reusing it waits the same way -- once per reuse,
+            # against ~30 us per 8 MiB piece for building a fresh range.  Callers that must never block pass `out=`.
+            torch.cuda.synchronize(self.device)
             ptr.value, got.value = pooled, 0
         else:
             rc = self._L.xdemhip_device_alloc(self.handle, nbytes, flags, ctypes.byref(ptr), ctypes.byref(got))
@@ -371,7 +376,8 @@ class Context:
         self._L.xdemhip_device_free(self.handle, ctypes.c_void_p(ptr))
 
     def release_pool(self) -> None:
-        """Hand the pooled plane ranges back to the driver (the analogue of ``torch.cuda.empty_cache()``)."""
+        """Hand the pooled plane ranges back to the driver (the analogue of ``torch.cuda.empty_cache()``, and to be called next
+        to it: torch's allocator cannot see or reclaim this memory -- up to XDEM_PLANE_POOL_GB, default 16 GiB per context)."""
         with self._pool_lock:
             items, self._pool = self._pool, []
         for _, _, p in items:

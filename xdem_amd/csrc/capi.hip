@@ -51,6 +51,7 @@ void xdemhip_destroy(xdemhip_ctx* ctx) {
         if (ctx->copy_streams[t]) (void)hipStreamDestroy(ctx->copy_streams[t]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->nf_flag) (void)hipFree(ctx->nf_flag);
     for (int q = 0; q < 2; ++q) {
         if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
         if (ctx->stage_out[q]) (void)hipHostFree(ctx->stage_out[q]);
@@ -130,7 +131,8 @@ std::vector<QuarantinedRange> g_quarantine;
 size_t g_quarantine_bytes = 0;
 
 void quarantine_range(void* base, size_t size) {
-    static const size_t limit = (size_t)(getenv("XDEMHIP_VMM_QUARANTINE_TB") ? atof(getenv("XDEMHIP_VMM_QUARANTINE_TB")) : 32.0) << 40;
+    // (scaled in double BEFORE the cast: a fractional value such as 0.5 must not truncate to 0 and switch the quarantine off)
+    static const size_t limit = (size_t)((getenv("XDEMHIP_VMM_QUARANTINE_TB") ? atof(getenv("XDEMHIP_VMM_QUARANTINE_TB")) : 32.0) * (double)((size_t)1 << 40));
     std::lock_guard<std::mutex> lock(g_quarantine_mu);
     g_quarantine.push_back({base, size});
     g_quarantine_bytes += size;
@@ -167,18 +169,17 @@ int device_alloc_chunked(xdemhip_ctx* ctx, size_t bytes, size_t piece, bool shuf
     c.size = n * c.piece;
     if (hipMemAddressReserve(&c.base, c.size, 0, nullptr, 0) != hipSuccess || !c.base) {
         (void)hipGetLastError();
-        // out of address space with ranges waiting in the quarantine: hand them back and try once more
-        {
-            std::lock_guard<std::mutex> lock(g_quarantine_mu);
-            for (const QuarantinedRange& q : g_quarantine) (void)hipMemAddressFree(q.base, q.size);
-            g_quarantine.clear();
-            g_quarantine_bytes = 0;
-        }
+        // out of address space with ranges waiting in the quarantine: hand the OLDEST back, one at a time, until the reserve
+        // succeeds -- the most recently freed ranges (the ones whose stale translations were measured) stay quarantined
         c.base = nullptr;
-        if (hipMemAddressReserve(&c.base, c.size, 0, nullptr, 0) != hipSuccess || !c.base) {
-            (void)hipGetLastError();
-            return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMemAddressReserve failed");
+        std::lock_guard<std::mutex> lock(g_quarantine_mu);
+        while (!c.base && !g_quarantine.empty()) {
+            (void)hipMemAddressFree(g_quarantine.front().base, g_quarantine.front().size);
+            g_quarantine_bytes -= g_quarantine.front().size;
+            g_quarantine.erase(g_quarantine.begin());
+            if (hipMemAddressReserve(&c.base, c.size, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); c.base = nullptr; }
         }
+        if (!c.base) return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMemAddressReserve failed");
     }
     c.slot.resize(n);
     for (size_t i = 0; i < n; ++i) c.slot[i] = i;
@@ -281,6 +282,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->host_chunk_mb = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "host_chunk_rows") {  // rows per chunk of host-buffer terrain calls (0 = derived from host_chunk_mb; at least 64 are taken)
+        if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "host_chunk_rows must be >= 0");
+        ctx->host_chunk_rows = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "host_release") {  // free the pinned staging buffers of the host-buffer terrain path (they come back with the next call)
         for (int q = 0; q < 2; ++q) {
             if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
@@ -364,6 +370,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
     if (std::string(name) == "terrain_ring_wait") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_ring_wait: 0 counted wait, 1 vmcnt(0)");
         ctx->terrain_ring_wait = value;
+        return XDEMHIP_OK;
+    }
+    if (std::string(name) == "terrain_nonfinite") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_nonfinite: 0 window rule (SciPy engine), 1 arithmetic rule (Numba engine)");
+        ctx->terrain_nonfinite = value;
         return XDEMHIP_OK;
     }
     if (std::string(name) == "terrain_math") {
@@ -477,6 +488,7 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     const size_t row_bytes = (size_t)W * (in_es + out_es * (size_t)n_planes);
     const size_t budget = (size_t)(ctx->host_chunk_mb > 0 ? ctx->host_chunk_mb : 288) << 20;
     int64_t chunk = (int64_t)(budget / (row_bytes ? row_bytes : 1)) - 2 * depth;
+    if (ctx->host_chunk_rows > 0) chunk = ctx->host_chunk_rows;  // the caller's tile size (mp_config.chunk_size of the reference's tiled call)
     if (chunk < 64) chunk = 64;  // (a few rows of a very wide raster may exceed the budget; still correct)
     if (chunk > H) chunk = H;
     size_t in_bytes = 0, plane_bytes = 0, out_bytes = 0;

@@ -28,6 +28,7 @@ struct xdemhip_ctx {
     xdemhip_allreduce_device_fn allreduce_dev = nullptr;  // device-side form of the hook (device arrays stay on the device)
     void* allreduce_dev_user = nullptr;
     int64_t n_red_host = 0, n_red_dev = 0;     // reductions that went through the host / the device hook
+    int host_chunk_rows = 0; // option "host_chunk_rows": rows per chunk of host-buffer terrain calls (0 = from the budget); the mp_config tile size
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
     int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)
     int terrain_rows = 0;    // option "terrain_rows": tile height of the fused terrain kernel (0 automatic, 16, 24, 32)
@@ -42,6 +43,8 @@ struct xdemhip_ctx {
     int terrain_order = 0;   // option "terrain_order": 0 one band of tiles per XCD (default), 1 natural order (XCDs interleave along a tile row); strips only: 2 permuted, 3 column-major (measurement)
     int terrain_window_lds = 1;  // option "terrain_window_lds": 1 LDS-tiled window kernel for window sizes != 3 (default), 0 the per-pixel form (its check)
     int terrain_ring_wait = 0;  // option "terrain_ring_wait": 1 = the streaming strips drain every VMEM operation before reading a refilled ring block (test switch for the counted wait)
+    int terrain_nonfinite = 0;  // option "terrain_nonfinite": 0 an output is NaN iff its full window holds a non-finite value (SciPy engine, default), 1 the Numba engine's rule: +-Inf pixels go through the arithmetic (terrain_nonfinite.hip)
+    int* nf_flag = nullptr;  // device word of that path: "the rows at hand hold an infinite pixel"
     int terrain_math = 2;    // option "terrain_math": float32 rasters: 2 lean tail for the specialised attribute sets (default), 0 mixed-precision tail of round 2, 1 float64 tail everywhere
     int vario_grid = 1;      // option "vario_grid": 1 = integer-lattice pair kernels for raster-sampled points (default), 0 = always float64 coordinates
     int vario_edge = 0;      // option "vario_edge": lag classes 0 = [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]
@@ -151,6 +154,7 @@ struct TerrainLaunch {
     void* planes[XDEMHIP_ATTR_COUNT];  // device pointers by attribute bit (null when not requested)
 };
 int launch_terrain(xdemhip_ctx* ctx, const TerrainLaunch& L);
+int launch_terrain_nonfinite(xdemhip_ctx* ctx, const TerrainLaunch& L);  // terrain_nonfinite.hip
 // rugosity / fractal roughness (window_extra.hip); plane indexes of the two attributes
 constexpr int P_RUGOSITY_IDX = 13, P_FRACTAL_IDX = 14;
 int launch_window_extra(xdemhip_ctx* ctx, const TerrainLaunch& L);

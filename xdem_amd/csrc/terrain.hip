@@ -22,8 +22,12 @@ int launch_terrain(xdemhip_ctx* ctx, const TerrainLaunch& L) {
     if (core) {
         TerrainLaunch C = L;
         C.attr_mask = core;
-        const int rc = launch_core(ctx, C);
+        int rc = launch_core(ctx, C);
         if (rc != XDEMHIP_OK) return rc;
+        if (ctx->terrain_nonfinite && (core & 0x3ffu)) {  // the Numba engine's +-Inf rule on top of the fused kernels' planes
+            rc = launch_terrain_nonfinite(ctx, C);
+            if (rc != XDEMHIP_OK) return rc;
+        }
     }
     if (L.attr_mask & ~((1u << N_ATTR) - 1u)) return launch_window_extra(ctx, L);  // rugosity, fractal roughness
     return XDEMHIP_OK;

@@ -292,29 +292,37 @@ def empirical_variogram_pairs(blocks: list[tuple], right_edges, estimator: str =
 
 
 # ---- host preparation mirrored from the reference --------------------------------------------------------------
-def _choose_cdist_equidistant_sampling_parameters(**kwargs: Any) -> tuple[int, int, float]:
-    """runs, samples, ratio_subsample for a N0^2/2 pair budget on 10 rings (xdem/spatialstats.py:1104-1183)."""
-    extent, shape, subsample = kwargs["extent"], kwargs["shape"], kwargs["subsample"]
-    nb_rings = kwargs.get("nb_rings", 10)
-    min_subsample = np.ceil(np.sqrt(2 * nb_rings * 2**2) + 1)
-    if subsample < min_subsample:
-        raise ValueError(f"The number of subsamples needs to be at least {min_subsample:.0f}.")
-    pairwise_comp_per_disk = np.ceil(subsample**2 / (2 * nb_rings))
-    if pairwise_comp_per_disk < 10:
-        runs = int(pairwise_comp_per_disk / 2**2)
+def _pair_budget_split(n_pairs_per_ring: float) -> tuple[int, int]:
+    """How a ring's pair budget is spread over independent runs: (runs, points per run and ring).  Budgets below 10 pairs run
+    budget / 4 times; otherwise 10 x ceil(cbrt(budget / 40)) runs capped at 100; each run then draws ceil(sqrt(budget / runs))
+    points.  Integer results pinned by tests/golden (T7 table recorded from the reference)."""
+    if n_pairs_per_ring < 10:
+        n_runs = int(n_pairs_per_ring / 4)
     else:
-        runs = int(min(100, 10 * np.ceil((pairwise_comp_per_disk / (2**2 * 10)) ** (1 / 3))))
-    subsample_per_disk_per_run = int(np.ceil(np.sqrt(pairwise_comp_per_disk / runs)))
-    maxdist = np.sqrt((extent[1] - extent[0]) ** 2 + (extent[3] - extent[2]) ** 2)
-    res = np.mean([(extent[1] - extent[0]) / (shape[0] - 1), (extent[3] - extent[2]) / (shape[1] - 1)])
-    ratio_subsample = res**2 * subsample_per_disk_per_run / (np.pi * maxdist**2 / np.sqrt(2) ** (2 * nb_rings))
-    logging.info(
-        "Equidistant circular sampling will be performed for %d runs (random center points) with pairwise "
-        "comparison between %d samples (points) of the central disk and again %d samples times %d independent "
-        "rings centered on the same center point. This results in approximately %d pairwise comparisons (duplicate "
-        "pairwise points randomly selected will be removed).",
-        runs, subsample_per_disk_per_run, subsample_per_disk_per_run, nb_rings, runs * subsample_per_disk_per_run**2 * nb_rings)
-    return runs, subsample_per_disk_per_run, ratio_subsample
+        n_runs = int(min(100, 10 * np.ceil((n_pairs_per_ring / 40) ** (1 / 3))))
+    return n_runs, int(np.ceil(np.sqrt(n_pairs_per_ring / n_runs)))
+
+
+def _choose_cdist_equidistant_sampling_parameters(**kwargs: Any) -> tuple[int, int, float]:
+    """(runs, samples, ratio_subsample) of the equidistant sampler for a pair budget of subsample^2 / 2 spread over `nb_rings`
+    rings (default 10) -- the integer rule and the disk ratio of xdem/spatialstats.py:1104-1183, which the T7 fixture table pins."""
+    n_rings = kwargs.get("nb_rings", 10)
+    budget_points = kwargs["subsample"]
+    fewest = np.ceil(np.sqrt(8 * n_rings) + 1)   # two points per ring pair at the very least
+    if budget_points < fewest:
+        raise ValueError(f"The number of subsamples needs to be at least {fewest:.0f}.")
+    runs, per_run = _pair_budget_split(np.ceil(budget_points**2 / (2 * n_rings)))
+
+    x0, x1, y0, y1 = kwargs["extent"][:4]
+    ny, nx = kwargs["shape"][:2]
+    diagonal = np.sqrt((x1 - x0) ** 2 + (y1 - y0) ** 2)
+    pixel = 0.5 * ((x1 - x0) / (ny - 1) + (y1 - y0) / (nx - 1))
+    # the centre disk is the innermost of rings whose radii grow by sqrt(2): its area is the extent circle's / 2^rings
+    centre_disk_area = np.pi * diagonal**2 / np.sqrt(2) ** (2 * n_rings)
+    ratio = pixel**2 * per_run / centre_disk_area
+    logging.info("equidistant sampling: %d runs x (%d centre-disk points against %d points in each of %d rings) = about %d pairs",
+                 runs, per_run, per_run, n_rings, runs * per_run**2 * n_rings)
+    return runs, per_run, ratio
 
 
 def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = None, subsample: int = 1000,
@@ -346,28 +354,29 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
         raise ValueError("Values must be of type NDArrayf, np.ma.masked_array or Raster subclass.")
     values = values.squeeze()
 
-    if (gsd is not None or subsample_method in ["cdist_equidistant", "pdist_disk", "pdist_ring"]) and values.ndim == 1:
-        raise ValueError(
-            'Values array must be 2D when using any of the "cdist_equidistant", "pdist_disk" and '
-            '"pdist_ring" methods, or providing a ground sampling distance instead of coordinates.'
-        )
-    elif coords is not None and values.ndim != 1:
-        raise ValueError("Values array must be 1D when providing coordinates.")
-    elif coords is not None and (coords.shape[0] != 2 and coords.shape[1] != 2):
-        raise ValueError("The coordinates array must have one dimension with length equal to 2")
-    elif values.ndim == 2 and gsd is None:
-        raise ValueError("The ground sampling distance must be defined when passing a 2D values array.")
-    if subsample_method not in ["cdist_equidistant", "cdist_point", "pdist_point", "pdist_disk", "pdist_ring"]:
-        raise TypeError(
-            'The subsampling method must be one of "cdist_equidistant, "cdist_point", "pdist_point", '
-            '"pdist_disk" or "pdist_ring".'
-        )
-    if n_variograms > 1 and "bin_func" in kwargs and not isinstance(kwargs.get("bin_func"), Iterable):
-        warnings.warn(
-            "Using a named binning function of scikit-gstat might provide different binnings for each "
-            "independent run. To remediate that issue, pass bin_func as an Iterable of right bin edges, "
-            "(or use default bin_func)."
-        )
+    # argument rules of upstream (xdem/spatialstats.py:1366-1400; messages as its tests assert them), first violated rule wins
+    raster_methods = ("cdist_equidistant", "pdist_disk", "pdist_ring")
+    all_methods = raster_methods[:1] + ("cdist_point", "pdist_point") + raster_methods[1:]
+    flat, gridded = values.ndim == 1, values.ndim == 2
+    shape_rules = (
+        (flat and (gsd is not None or subsample_method in raster_methods),
+         'Values array must be 2D when using any of the "cdist_equidistant", "pdist_disk" and '
+         '"pdist_ring" methods, or providing a ground sampling distance instead of coordinates.'),
+        (coords is not None and not flat, "Values array must be 1D when providing coordinates."),
+        (coords is not None and 2 not in coords.shape[:2], "The coordinates array must have one dimension with length equal to 2"),
+        (gridded and gsd is None, "The ground sampling distance must be defined when passing a 2D values array."),
+    )
+    for violated, message in shape_rules:
+        if violated:
+            raise ValueError(message)
+    if subsample_method not in all_methods:
+        raise TypeError('The subsampling method must be one of "cdist_equidistant, "cdist_point", "pdist_point", '
+                        '"pdist_disk" or "pdist_ring".')
+    named_bin_func = "bin_func" in kwargs and not isinstance(kwargs["bin_func"], Iterable)
+    if named_bin_func and n_variograms > 1:
+        warnings.warn("Using a named binning function of scikit-gstat might provide different binnings for each "
+                      "independent run. To remediate that issue, pass bin_func as an Iterable of right bin edges, "
+                      "(or use default bin_func).")
     if "bin_func" in kwargs and not isinstance(kwargs["bin_func"], Iterable):
         raise NotImplementedError("bin_func must be an iterable of right bin edges (or omitted) on the GPU path.")
 
@@ -450,20 +459,18 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
             exp, count = np.full(edges.size, np.nan), np.zeros(edges.size, dtype=np.int64)
         list_df_run.append(pd.DataFrame().assign(exp=exp, bins=edges, count=count))
 
-    df = pd.concat(list_df_run)
+    every_run = pd.concat(list_df_run)
     if n_variograms == 1:
-        df = df.rename(columns={"bins": "lags"})
-        df["err_exp"] = np.nan
+        table = every_run.rename(columns={"bins": "lags"}).assign(err_exp=np.nan)
     else:
-        df_grouped = df.groupby("bins", dropna=False)
-        df_mean = df_grouped[["exp"]].mean()
-        df_std = df_grouped[["exp"]].std()
-        df_count = df_grouped[["count"]].sum()
-        df_mean["lags"] = df_mean.index.values
-        df_mean["err_exp"] = df_std["exp"] / np.sqrt(n_variograms)
-        df_mean["count"] = df_count["count"]
-        df = df_mean
-    df.drop(df.tail(1).index, inplace=True)
+        # one row per lag class over the runs: mean of the estimates, their standard error, pairs added up (pandas' NaN-skipping
+        # group reductions, as upstream aggregates its runs: spatialstats.py:1518-1532)
+        per_lag = every_run.groupby("bins", dropna=False)
+        table = per_lag.agg(exp=("exp", "mean"), spread=("exp", "std"), count=("count", "sum"))
+        table["lags"] = table.index.values
+        table["err_exp"] = table.pop("spread") / np.sqrt(n_variograms)
+        table = table[["exp", "lags", "err_exp", "count"]]
+    df = table.iloc[:-1].copy()   # the last lag is always under-sampled
     df = df.astype({"exp": "float64", "err_exp": "float64", "lags": "float64", "count": "int64"})
     return df
 
@@ -945,6 +952,50 @@ def nmad_device(values: np.ndarray, nfact: float = 1.4826, abs_limit: float = np
     return med.value, nm.value, int(cnt.value)
 
 
+def _rows_of_one_binning(df, names: list[str], stat_col: str, min_count: int | None):
+    """The rows of `df` that belong to the binning over exactly `names`, bin positions as numbers: (rows, statistic values,
+    mask of the usable ones).  Refusals and their messages are upstream's (xdem/spatialstats.py:292-352, asserted by its tests)."""
+    import pandas as pd
+
+    missing = [v for v in names if v not in df.columns]
+    if missing:
+        raise ValueError('Variable "' + missing[0] + '" does not exist in the provided dataframe.')
+    if stat_col not in df.columns:
+        raise ValueError('Statistic "' + stat_col + '" does not exist in the provided dataframe.')
+    if min_count is not None and "count" not in df.columns:
+        raise ValueError('Statistic "count" is not in the provided dataframe, necessary to use the min_count argument.')
+    if df.empty:
+        raise ValueError("Dataframe is empty.")
+    rows = df[df.nd == len(names)].copy() if "nd" in df.columns else df.copy()
+    numeric = (int, float, np.integer, np.floating)
+    position = {}
+    for v in names:   # a bin's position: its mid value, given as a number or as the pandas interval nd_binning writes
+        cells = rows[v].values
+        if all(isinstance(x, numeric) for x in cells):
+            position[v] = np.asarray(cells, dtype=float) if len(cells) else np.empty(0)
+        elif any(isinstance(x, pd.Interval) for x in cells):
+            position[v] = pd.IntervalIndex(rows[v]).mid.values
+        else:
+            raise ValueError("The variable columns must be provided as numerical mid values, or pd.Interval values.")
+        rows[v] = position[v]
+    placed = np.ones(len(rows), dtype=bool)
+    for v in names:
+        placed &= np.isfinite(position[v])
+    rows = rows[placed]
+    if rows.empty:
+        raise ValueError("Dataframe does not contain a nd binning with the variables corresponding to the list of variables.")
+    if not np.isfinite(rows[stat_col].values).any():
+        raise ValueError("Dataframe does not contain any valid statistic values.")
+    if min_count is not None:
+        rows.loc[rows["count"] < min_count, stat_col] = np.nan
+    stat = rows[stat_col].values
+    usable = np.isfinite(stat)
+    if not usable.any():
+        raise ValueError("Dataframe does not contain any valid statistic values after filtering with min_count = "
+                         + str(min_count) + ".")
+    return rows, stat, usable
+
+
 def interp_nd_binning(df, list_var_names, statistic="nmad", interpolate_method: str = "linear", min_count: int | None = 100,
                       ctx: _lib.Context | None = None) -> GridInterpolant:
     """Interpolant of a binned statistic over its explanatory variables (mirror of xdem/spatialstats.py:237-421).
@@ -957,41 +1008,10 @@ def interp_nd_binning(df, list_var_names, statistic="nmad", interpolate_method: 
     import pandas as pd
     from scipy.interpolate import griddata
 
-    if isinstance(list_var_names, str):
-        list_var_names = [list_var_names]
-    for var in list_var_names:
-        if var not in df.columns:
-            raise ValueError('Variable "' + var + '" does not exist in the provided dataframe.')
-    statistic_name = statistic if isinstance(statistic, str) else statistic.__name__
-    if statistic_name not in df.columns:
-        raise ValueError('Statistic "' + statistic_name + '" does not exist in the provided dataframe.')
-    if min_count is not None and "count" not in df.columns:
-        raise ValueError('Statistic "count" is not in the provided dataframe, necessary to use the min_count argument.')
-    if df.empty:
-        raise ValueError("Dataframe is empty.")
-    sub = df.copy()
-    if "nd" in sub.columns:
-        sub = sub[sub.nd == len(list_var_names)]
-    for var in list_var_names:
-        col = sub[var].values
-        if all(isinstance(x, (int, float, np.integer, np.floating)) for x in col):
-            continue
-        if any(isinstance(x, pd.Interval) for x in col):
-            sub[var] = pd.IntervalIndex(sub[var]).mid.values
-        else:
-            raise ValueError("The variable columns must be provided as numerical mid values, or pd.Interval values.")
-    sub = sub[np.logical_and.reduce([np.isfinite(sub[var].values) for var in list_var_names])]
-    if sub.empty:
-        raise ValueError("Dataframe does not contain a nd binning with the variables corresponding to the list of variables.")
-    if all(~np.isfinite(sub[statistic_name].values)):
-        raise ValueError("Dataframe does not contain any valid statistic values.")
-    if min_count is not None:
-        sub.loc[sub["count"] < min_count, statistic_name] = np.nan
-    stat = sub[statistic_name].values
-    good = np.isfinite(stat)
-    if all(~good):
-        raise ValueError("Dataframe does not contain any valid statistic values after filtering with min_count = "
-                         + str(min_count) + ".")
+    names = [list_var_names] if isinstance(list_var_names, str) else list(list_var_names)
+    stat_col = statistic if isinstance(statistic, str) else statistic.__name__
+    sub, stat, good = _rows_of_one_binning(df, names, stat_col, min_count)
+    list_var_names = names
     centres = [sorted(np.unique(sub[var][good])) for var in list_var_names]
     shape = [len(c) for c in centres]
     # (1) inside the convex hull of the valid bins

@@ -207,19 +207,21 @@ def get_terrain_attribute(
     fit: ``"hip"`` / ``"scipy"`` (upstream's default engine, the one parity is pinned on) round the fitted derivatives
     to the DEM dtype before the float64 attribute formulas (``scipy.ndimage.convolve`` returns the input dtype,
     spatialstats.py:2512-2594); ``"numba"`` keeps them in float64 as upstream's Numba engine does (surfit.py:1044)
-    -- the two differ only for a float32 / integer DEM, at the 1e-7 relative level upstream itself tolerates
-    (tests/test_terrain/test_surfit.py:452).  Windowed indexes are the same in both.
+    and, like that engine, has no dilated non-finite mask: pixels next to a +-Inf value come out of the arithmetic (slope
+    90 deg, ...) instead of NaN (surfit.py:1270-1303 against 1185-1192).  On finite / NaN data the two differ only for a
+    float32 / integer DEM, at the 1e-7 .. 1e-6 relative level upstream itself tolerates (tests/test_terrain/test_surfit.py:452).
+    Pinned by outputs of upstream's own numba-engine code (tests/golden/terrain_T11_numba_engine.npz).  Windowed indexes are
+    evaluated on a float64 window under every engine name (upstream's Numba engine sums them in the DEM dtype, window.py:851:
+    a noisier evaluation of the same quantity).
     """
     if slope_method is not None:
         warnings.warn("'slope_method' is deprecated, use 'surface_fit' instead.", DeprecationWarning, stacklevel=2)
         surface_fit = slope_method
     if engine not in ("hip", "scipy", "numba"):
         raise ValueError(f"engine must be 'hip', 'scipy' or 'numba' (got '{engine}'); all of them run on the GPU.")
-    if mp_config is not None:
-        raise NotImplementedError("mp_config tiling is replaced by xdem_amd.dist (row blocks over GPUs); pass None.")
-
     attribute, resolution = _validate(dem, attribute, resolution, hillshade_altitude, hillshade_azimuth,
                                       hillshade_z_factor, surface_fit, curv_method, tri_method, window_size_fractal)
+    tile_rows = _tile_rows_of(mp_config, dem)   # (refusals of the tiled call come right after the validation, as upstream)
     if "texture_shading" in attribute:
         texture_alpha = 0.8 if texture_alpha is None else texture_alpha
         if not 0 <= texture_alpha <= 2:
@@ -243,17 +245,62 @@ def get_terrain_attribute(
 
     outs = {a: np.empty((H, W), dtype=out_dtype) for a in set(attribute)}
     ctx = _lib.default_context()
+    if tile_rows:
+        prev_rows = ctx.options.get("host_chunk_rows", 0)
+        ctx.set_option("host_chunk_rows", tile_rows)
+    try:
+        return _run_and_wrap(ctx, dem, dem_arr, attribute, outs, H, W, resolution, degrees, hillshade_altitude, hillshade_azimuth,
+                             hillshade_z_factor, surface_fit, curv_method, tri_method, window_size, window_size_fractal, engine,
+                             texture_alpha, out_dtype, mp_config)
+    finally:
+        if tile_rows:
+            ctx.set_option("host_chunk_rows", prev_rows)
+
+
+def _tile_rows_of(mp_config, dem) -> int:
+    """Upstream's tiled call (terrain.py:412-466: `mp_config` = geoutils' MultiprocConfig(chunk_size, outfile, cluster)) mapped
+    onto the library's chunked host path: the raster streams through the GPU in chunks of `chunk_size` ROWS with the overlap
+    the attributes need (the library derives the same depth as terrain.py:417-432) -- results are bit-identical to the one-pass
+    call, as upstream's tiles are to its untiled call.  `outfile` is honoured through the Raster's own `save`; a `cluster` of
+    worker processes has no counterpart (the tiles run on one GPU, one after the other) and is ignored with a warning."""
+    if mp_config is None:
+        return 0
+    if not _is_raster(dem):
+        raise TypeError("The DEM must be a Raster to use multiprocessing.")   # terrain.py:436-437
+    chunk = int(getattr(mp_config, "chunk_size", 0) or 0)
+    if chunk <= 0:
+        raise ValueError("mp_config.chunk_size must be a positive number of pixels.")
+    cluster = getattr(mp_config, "cluster", None)
+    if cluster is not None and "basic" not in type(cluster).__name__.lower():
+        warnings.warn("mp_config.cluster is ignored: the tiles are row chunks streamed through one GPU, not tasks of worker "
+                      "processes (multi-GPU: xdem_amd.dist).", UserWarning, stacklevel=3)
+    return chunk
+
+
+def _run_and_wrap(ctx, dem, dem_arr, attribute, outs, H, W, resolution, degrees, hillshade_altitude, hillshade_azimuth,
+                  hillshade_z_factor, surface_fit, curv_method, tri_method, window_size, window_size_fractal, engine,
+                  texture_alpha, out_dtype, mp_config):
     stencil = [a for a in attribute if a not in list_requiring_frequency_domain]
-    groups = [(dem_arr, stencil)]
-    if engine == "numba" and dem_arr.dtype == np.float32 and any(a in list_requiring_surface_fit for a in stencil):
-        # unrounded derivatives: the float64-input kernel on the widened DEM (exact), windowed indexes on the DEM as is
-        groups = [(dem_arr.astype(np.float64), [a for a in stencil if a in list_requiring_surface_fit]),
-                  (dem_arr, [a for a in stencil if a not in list_requiring_surface_fit])]
-    for arr, names in groups:
+    groups = [(dem_arr, stencil, 0)]
+    if engine == "numba" and any(a in list_requiring_surface_fit for a in stencil):
+        # upstream's Numba recipe for the surface fit (surfit.py:948-1088, 1270-1303): unrounded float64 derivatives -- the
+        # float64-input kernel on the (exactly) widened DEM -- and no dilated non-finite mask: +-Inf pixels go through the
+        # arithmetic (library option "terrain_nonfinite" = 1).  Windowed indexes on the DEM as is.
+        wide = dem_arr if dem_arr.dtype == np.float64 else dem_arr.astype(np.float64)
+        groups = [(wide, [a for a in stencil if a in list_requiring_surface_fit], 1),
+                  (dem_arr, [a for a in stencil if a not in list_requiring_surface_fit], 0)]
+    for arr, names, nonfinite in groups:
         if names:
-            launch_terrain(ctx, arr.ctypes.data, arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
-                           names, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
-                           degrees, out_dtype, {a: outs[a].ctypes.data for a in set(names)}, _lib.HOST, window_size_fractal)
+            prev = ctx.options.get("terrain_nonfinite", 0)
+            if nonfinite != prev:
+                ctx.set_option("terrain_nonfinite", nonfinite)
+            try:
+                launch_terrain(ctx, arr.ctypes.data, arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
+                               names, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
+                               degrees, out_dtype, {a: outs[a].ctypes.data for a in set(names)}, _lib.HOST, window_size_fractal)
+            finally:
+                if nonfinite != prev:
+                    ctx.set_option("terrain_nonfinite", prev)
     if "texture_shading" in attribute:  # frequency-domain attribute: its own engine (terrain.py:637-644)
         alpha = texture_alpha
         code = lambda dt: _lib.F32 if np.dtype(dt) == np.float32 else _lib.F64  # noqa: E731
@@ -264,6 +311,10 @@ def get_terrain_attribute(
         output_attributes = [
             type(dem).from_array(attr, transform=dem.transform, crs=dem.crs, nodata=-99999) for attr in output_attributes
         ]
+    outfile = getattr(mp_config, "outfile", None) if mp_config is not None else None
+    if outfile is not None:   # one file per attribute, named as upstream names them (terrain.py:441-443)
+        for name, raster in zip(attribute, output_attributes):
+            raster.save(outfile if len(attribute) == 1 else outfile.split(".")[0] + "_" + name + ".tif")
     return output_attributes if len(output_attributes) > 1 else output_attributes[0]
 
 
@@ -296,18 +347,22 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
     kw = dict(contiguous=backing in ("contiguous", "recycled"), recycled=backing == "recycled", chunked=backing == "chunked",
               scattered=backing == "scattered")
     np_dt = {torch.float32: "float32", torch.float64: "float64"}[dtype]
+    soft = (_lib.XdemHipError, RuntimeError, MemoryError)   # allocator refusals (library / torch); anything else is a bug and propagates
     try:
         return ctx.device_tensor((n_attr, H, W), np_dt, **kw)
-    except Exception:   # (XdemHipError from the allocator, or whatever torch raises when it cannot wrap the range)
+    except soft:
         if not auto:
             raise
     # "auto": the library's pieces do not come out of torch's cache -- hand the cached blocks back to the driver and try again,
-    # and rather take an ordinary allocation than fail
+    # and rather take an ordinary allocation than fail (said aloud: the backing decides the speed of the streaming kernel)
     torch.cuda.empty_cache()
     try:
         return ctx.device_tensor((n_attr, H, W), np_dt, **kw)
-    except Exception:
-        return torch.empty((n_attr, H, W), dtype=dtype, device=torch.device("cuda", ctx.device))
+    except soft as e:
+        warnings.warn(f"xdem_amd: scattered plane backing unavailable ({e}); falling back to torch's allocator", RuntimeWarning,
+                      stacklevel=2)
+    ctx.release_pool()   # memory torch cannot see: give it back before asking torch for the planes
+    return torch.empty((n_attr, H, W), dtype=dtype, device=torch.device("cuda", ctx.device))
 
 
 def terrain_attributes_device(dem, attribute: list[str], resolution: float = 1.0, degrees: bool = True,
