@@ -392,7 +392,9 @@ def terrain_sets(ctx, dev, dem, kw, steps: int) -> dict:
              ("slope+aspect Florinsky", ["slope", "aspect"], dict(surface_fit="Florinsky")),
              ("hillshade", ["hillshade"], dict(surface_fit="Florinsky")),
              ("slope+aspect+hillshade Florinsky", ["slope", "aspect", "hillshade"], dict(surface_fit="Florinsky")),
-             ("full 11, directional curvatures", FULL, dict(surface_fit="Florinsky", curv_method="directional"))]
+             ("full 11, directional curvatures", FULL, dict(surface_fit="Florinsky", curv_method="directional")),
+             ("full 11, ZevenbergThorne fit (3x3)", FULL, dict(surface_fit="ZevenbergThorne")),
+             ("full 11, ZevenbergThorne fit, directional curvatures", FULL, dict(surface_fit="ZevenbergThorne", curv_method="directional"))]
     out = {}
     for name, attrs, extra in cases:
         planes = terrain.alloc_planes(len(attrs), H, W, torch.float32, ctx, dev)

@@ -60,6 +60,16 @@ static int go(const void* dem, int64_t H, int64_t W, int64_t ht, int64_t hb, int
         }
         return 0;
     }
+    if (P.mask == MASK_FULL11 && P.curv_directional && P.degrees && !P.tri_wilson && fit != 0 && P.hs_zf2 == 1.0) {
+        if (g_tail == 2) {
+            if (fit == 2) run<2, true, true, Spec<MASK_FULL11, 1, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+            else run<1, true, true, Spec<MASK_FULL11, 1, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        } else {
+            if (fit == 2) run<2, true, true, Spec<MASK_FULL11, 1, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+            else run<1, true, true, Spec<MASK_FULL11, 1, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
+        }
+        return 0;
+    }
     if (P.mask == MASK_SAH_WIN && P.degrees && !P.tri_wilson && fit == 0 && P.hs_zf2 == 1.0) {
         if (g_tail == 2) run<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
         else run<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);

@@ -86,3 +86,38 @@ def test_two_contexts_two_threads_equal_serial():
     finally:
         ctx_a.close()
         ctx_b.close()
+
+
+def test_context_takes_decided_conventions_from_the_decision_file(tmp_path, monkeypatch):
+    """A decision file with NON-default conventions (what oracle/pin_thirdparty.py writes once the third-party packages can be
+    run) must configure every new context: options mirrored in `ctx.options`, and the behaviour really switched -- a pair
+    whose distance falls exactly on a class edge moves to the other lag class under vario_edge = 1."""
+    import json
+
+    from xdem_amd import _lib
+    from xdem_amd import spatialstats as ss
+
+    path = tmp_path / "thirdparty_decision.json"
+    path.write_text(json.dumps({"nk_nan_rule": 3, "vario_edge": 1, "_source": "test"}))
+    monkeypatch.setenv("XDEM_THIRDPARTY_DECISION", str(path))
+    assert _lib.thirdparty_decision() == {"nk_nan_rule": 3, "vario_edge": 1}
+    ctx = _lib.Context(0)
+    try:
+        assert ctx.options == {"nk_nan_rule": 3, "vario_edge": 1}
+        x = np.array([0.0, 2.0, 5.0])
+        y = np.zeros(3)
+        v = np.array([0.0, 1.0, 3.0], dtype=np.float32)
+        edges = [2.0, 4.0, 8.0]   # distances 2, 3, 5: the first lies on an edge
+        with _lib.use_context(ctx):
+            _, count_right_closed = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron")
+        monkeypatch.delenv("XDEM_THIRDPARTY_DECISION")
+        plain = _lib.Context(0)
+        try:
+            assert plain.options == {}
+            with _lib.use_context(plain):
+                _, count_default = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron")
+        finally:
+            plain.close()
+        assert count_right_closed.tolist() == [1, 1, 1] and count_default.tolist() == [0, 2, 1]
+    finally:
+        ctx.close()

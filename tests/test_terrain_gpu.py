@@ -376,8 +376,10 @@ def test_mp_config_is_the_row_chunked_host_path(terrain):
         assert np.array_equal(o.data, t.data, equal_nan=True), a
         assert np.array_equal(_FakeRaster.saved[f"out/attr_{a}.tif"], t.data, equal_nan=True)
     assert _lib.default_context().options.get("host_chunk_rows", 0) == 0
+    # (a single attribute takes the small-set kernel, whose lean tail may differ from the 4-attribute launch in the last ulp:
+    # the tiled call is held against the one-pass call of the SAME attribute set)
     single = terrain.slope(ras, mp_config=SimpleNamespace(chunk_size=64, outfile="s.tif", cluster=None))
-    assert np.array_equal(single.data, one[0].data, equal_nan=True) and "s.tif" in _FakeRaster.saved
+    assert np.array_equal(single.data, terrain.slope(ras).data, equal_nan=True) and "s.tif" in _FakeRaster.saved
 
     class MultiprocessingCluster:
         pass
@@ -385,7 +387,7 @@ def test_mp_config_is_the_row_chunked_host_path(terrain):
     with pytest.warns(UserWarning, match="cluster is ignored"):
         w = terrain.get_terrain_attribute(ras, "slope", mp_config=SimpleNamespace(chunk_size=128, outfile=None,
                                                                                    cluster=MultiprocessingCluster()))
-    assert np.array_equal(w.data, one[0].data, equal_nan=True)
+    assert np.array_equal(w.data, terrain.slope(ras).data, equal_nan=True)
 
 
 def test_ulp_histogram_per_attribute(terrain, record_property):

@@ -49,6 +49,28 @@ def test_specialised_kernel_math(fit, attrs):
         check_attribute(g, r, a, dem, 10.0, f"{fit}/{a}", exact_frac=0.9999)
 
 
+@pytest.mark.parametrize("fit", ["Florinsky", "ZevenbergThorne"])
+def test_specialised_directional_kernel_math(fit):
+    """Round 5: the eleven planes with curv_method="directional" have their own compile-time specialisation (lean tail)."""
+    dem = _dem(seed=9)
+    got = hostsim_terrain(dem, HOT11, resolution=10.0, surface_fit=fit, curv_method="directional")
+    ref = to.terrain_attributes(dem, HOT11, resolution=10.0, surface_fit=fit, curv_method="directional")
+    for a, g, r in zip(HOT11, got, ref):
+        check_attribute(g, r, a, dem, 10.0, f"{fit}/directional/{a}", exact_frac=0.9999)
+    for fname in ("terrain_T1_float32_nan.npz",):   # and the reference's own T1 outputs for that method, float32
+        import os
+
+        from conftest import GOLDEN
+
+        z = np.load(os.path.join(GOLDEN, fname))
+        for res in ("1.0", "2.0", "10.0"):
+            refs = [z[f"{fit}|directional|{res}|{a}"] for a in HOT11[:9]]
+            # the specialised kernel needs the full mask: TPI / TRI ride along
+            got = hostsim_terrain(z["dem"], HOT11, resolution=float(res), surface_fit=fit, curv_method="directional")
+            for a, g, r in zip(HOT11[:9], got, refs):
+                assert_parity_true(g, r, f"T1/{fit}/directional/{res}/{a}", floor=noise_floor(a, z["dem"], float(res)))
+
+
 def test_float64_and_tile_boundaries():
     dem = _dem((70, 530), seed=5, dtype=np.float64)  # three column tiles, three row tiles of 32
     got = hostsim_terrain(dem, HOT11, resolution=2.0)

@@ -31,7 +31,7 @@ def thirdparty_decision() -> dict:
     """The decided conventions (subset of THIRDPARTY_DEFAULTS' keys) from thirdparty_decision.json next to this file; {} if absent."""
     import json
 
-    path = os.path.join(HERE, "thirdparty_decision.json")
+    path = os.environ.get("XDEM_THIRDPARTY_DECISION") or os.path.join(HERE, "thirdparty_decision.json")   # (the variable: tests)
     if not os.path.exists(path):
         return {}
     d = json.load(open(path))

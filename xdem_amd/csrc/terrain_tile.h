@@ -634,8 +634,8 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
         const int fit = surf ? L.surface_fit : XDEMHIP_FIT_ZEVENBERGTHORNE;  // window-only: cheapest 3x3 march
         // Compile-time specialised kernels for the headline configurations (reference defaults: geometric
         // curvatures, degrees, Riley TRI, z_factor 1): all attribute branches fold away -> one schedulable basic block.
-        const bool defaults = L.curv_method == XDEMHIP_CURV_GEOMETRIC && L.degrees && L.tri_method == XDEMHIP_TRI_RILEY &&
-                              L.hs_z == 1.0;
+        const bool defaults_dir = L.degrees && L.tri_method == XDEMHIP_TRI_RILEY && L.hs_z == 1.0;  // ... with either curvature method
+        const bool defaults = L.curv_method == XDEMHIP_CURV_GEOMETRIC && defaults_dir;
         // option "terrain_math" = 1: float64 attribute math for float32 rasters too (other dtype pairs always use it);
         // 2 (default) / 0: lean / mixed tail of the specialised float32 kernels (the runtime-mask kernels keep the mixed tail)
         constexpr bool FF = SameT<TIN, float>::v && SameT<TOUT, float>::v;
@@ -651,16 +651,24 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
             const bool fl = defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_FLORINSKY;
             const bool zt = defaults && mask == MASK_FULL11 && fit == XDEMHIP_FIT_ZEVENBERGTHORNE;
             const bool hn = defaults && mask == MASK_SAH_WIN && fit == XDEMHIP_FIT_HORN;
+            // round 5: the same eleven planes with curv_method="directional" (the other value users pass: terrain.py:694-747) were
+            // the runtime-mask tile kernel's (0.60 of the roofline); they now have the full set's route
+            const bool dirc = defaults_dir && L.curv_method == XDEMHIP_CURV_DIRECTIONAL && mask == MASK_FULL11;
+            const bool fld = dirc && fit == XDEMHIP_FIT_FLORINSKY, ztd = dirc && fit == XDEMHIP_FIT_ZEVENBERGTHORNE;
 #define XD_SPECIALISED(LV)                                                                                                   \
     do {                                                                                                                     \
         int took = 0;                                                                                                        \
         if (fl) took = launch_stream<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>>(ctx, L, mask);                        \
         else if (zt) took = launch_stream<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>>(ctx, L, mask);                   \
         else if (hn) took = launch_stream<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1, LV>>(ctx, L, mask);                 \
+        else if (fld) took = launch_stream<2, true, true, Spec<MASK_FULL11, 1, 1, 0, 1, LV>>(ctx, L, mask);                  \
+        else if (ztd) took = launch_stream<1, true, true, Spec<MASK_FULL11, 1, 1, 0, 1, LV>>(ctx, L, mask);                  \
         if (took != 0) return took < 0 ? took : XDEMHIP_OK;                                                                  \
         if (fl) return launch_shaped<2, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>, TIN, TOUT, ALLSHAPES>(ctx, L, mask);  \
         if (zt) return launch_shaped<1, true, true, Spec<MASK_FULL11, 0, 1, 0, 1, LV>, TIN, TOUT>(ctx, L, mask);             \
         if (hn) return launch_shaped<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1, LV>, TIN, TOUT>(ctx, L, mask);           \
+        if (fld) return launch_shaped<2, true, true, Spec<MASK_FULL11, 1, 1, 0, 1, LV>, TIN, TOUT>(ctx, L, mask);            \
+        if (ztd) return launch_shaped<1, true, true, Spec<MASK_FULL11, 1, 1, 0, 1, LV>, TIN, TOUT>(ctx, L, mask);            \
     } while (0)
             if (ctx->terrain_math == 2) XD_SPECIALISED(2);
             else if (ctx->terrain_math == 0) XD_SPECIALISED(0);

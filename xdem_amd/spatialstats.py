@@ -470,7 +470,9 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
         table["lags"] = table.index.values
         table["err_exp"] = table.pop("spread") / np.sqrt(n_variograms)
         table = table[["exp", "lags", "err_exp", "count"]]
-    df = table.iloc[:-1].copy()   # the last lag is always under-sampled
+    # the last lag is always under-sampled.  Dropped BY INDEX LABEL, as upstream does (spatialstats.py:1540): the frames of a
+    # multi-range run (pdist_disk / pdist_ring) are concatenated with their own 0..n-1 labels, so the last lag of EVERY range goes
+    df = table.drop(table.tail(1).index)
     df = df.astype({"exp": "float64", "err_exp": "float64", "lags": "float64", "count": "int64"})
     return df
 
