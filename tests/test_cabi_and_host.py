@@ -191,7 +191,10 @@ def test_streaming_kernels_keep_plane_pointers_in_scalar_registers(tmp_path):
     """The streaming terrain kernels store through `global_store_dword v, v, s[base]` inline asm WITHOUT the scalar copy of the
     plane pointer the tile kernels carry (DirectSink<float, false>): that is only safe while no plane pointer is ever restored
     from a VGPR lane (v_readlane writes an SGPR on the vector unit; a VMEM instruction may not read it for 5 wait states and
-    inline asm gets no hazard handling).  Checked on the compiled code: no v_readlane / v_writelane in any streaming kernel."""
+    inline asm gets no hazard handling).  Checked on the compiled code: no v_readlane / v_writelane in a streaming kernel -- or, where
+    the compiler does park a scalar in a VGPR lane (round 5: the saved exec mask of a cold path in the Florinsky / directional
+    instantiation), every plane store takes its pointer through the `s_mov_b64` copy inside the asm text (a SALU read of a
+    VALU-written SGPR and a VMEM read of a SALU-written SGPR are both interlocked by the hardware)."""
     import re
     import shutil
     import subprocess
@@ -204,13 +207,19 @@ def test_streaming_kernels_keep_plane_pointers_in_scalar_registers(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
                            os.path.join(root, "xdem_amd", "csrc", "terrain_ff.hip"), "-o", out], stderr=subprocess.DEVNULL)
     src = open(out).read()
-    n = 0
+    n = n_copy = 0
     for m in re.finditer(r"\n(_Z\w*terrain_strip_kernel\w+):[^\n]*\n(.*?)\n\t\.amdhsa_kernel \1\n", src, re.S):
         body = m.group(2)
-        assert "v_readlane_b32" not in body and "v_writelane_b32" not in body, m.group(1)
         assert "global_load_lds_dwordx4" in body and "global_store_dword" in body
+        if "v_readlane_b32" in body or "v_writelane_b32" in body:
+            lines = [ln.strip() for ln in body.split("\n") if ln.startswith("\t") and not ln.strip().startswith((";", "."))]
+            stores = [i for i, ln in enumerate(lines) if ln.startswith("global_store_dword")]
+            assert stores and all(lines[i - 1].startswith("s_mov_b64") and lines[i - 1].split()[1].rstrip(",") == lines[i].split()[3]
+                                  for i in stores), m.group(1)
+            n_copy += 1
         n += 1
     assert n >= 6   # 3 attribute sets x 2 tails (x band heights)
+    assert n_copy <= 3, n_copy   # (the exception stays one instantiation x band heights: the hot kernels keep the direct form)
 
 
 def test_variogram_host_preparation():

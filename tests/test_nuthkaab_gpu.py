@@ -712,6 +712,59 @@ def test_lean_route_equals_plain_route_at_scale():
         ctx.close()
 
 
+@pytest.mark.parametrize("rule", [2, 3])
+def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
+    """Rules 2 / 3 of the bilinear taps (the forms with a dilated nodata mask -- rule 3 is what the only hint about geoutils'
+    convention favours) on a 7000^2 pair with noise, 20 % contiguous gaps and scattered single-pixel holes:
+    the one-pass step and the two-pass route (streaming kernels + the plan's bad-bit mask) against the plain route (generic
+    kernels, a 3 x 3 / cross neighbourhood read per pixel): every output of every step identical, fractional and integer
+    shifts, a repeated step; and the default rule gives a DIFFERENT valid count on the same pair (the rules do differ here)."""
+    import torch
+
+    from xdem_amd import _lib, coreg
+    from xdem_amd.synth import fbm_torch
+
+    m = 7000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    ref = fbm_torch(m, m, dev, seed=42)
+    tba = torch.roll(ref, shifts=(1, -2), dims=(0, 1)) + 2.0 + 0.5 * torch.randn((m, m), device=dev, generator=g)
+    hole = fbm_torch(m, m, dev, seed=44)
+    tba[hole < torch.quantile(hole[::16, ::16].flatten(), 0.2)] = float("nan")
+    tba[torch.rand((m, m), device=dev, generator=g) < 0.01] = float("nan")
+    del hole
+    torch.cuda.synchronize()
+    ctx = _lib.Context(0)
+    steps = ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (-10.0, 20.0), (4.999999999, -5.000000001), (3.0, -4.0))
+    try:
+        res = {}
+        ctx.set_option("nk_nan_rule", rule)
+        for name, mode, fused in (("onepass", 0, 1), ("twopass", 0, 0), ("plain", 1, 0)):
+            ctx.set_option("selection", mode)
+            ctx.set_option("nk_fused", fused)
+            plan = coreg.NKPlan(ref, tba, None, ctx)
+            res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in steps]
+            assert plan.route_counts()[name] == len(steps), (name, plan.route_counts())
+            plan.close()
+        for name in ("onepass", "twopass"):
+            for a, b in zip(res[name], res["plain"]):
+                assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], (rule, name)
+                assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), (rule, name)
+                assert np.array_equal(a["edges"], b["edges"]), (rule, name)
+                assert _moments_close(a, b, onepass=name == "onepass"), (rule, name)
+            assert np.array_equal(res[name][1]["medians"], res[name][5]["medians"], equal_nan=True)
+        ctx.set_option("nk_nan_rule", 0)
+        ctx.set_option("selection", 0)
+        ctx.set_option("nk_fused", 1)
+        plan = coreg.NKPlan(ref, tba, None, ctx)
+        d0 = plan.step(3.0, -4.0, (10.0, 10.0), 72)
+        plan.close()
+        assert d0["n_valid"] > res["plain"][1]["n_valid"]   # rule 0's mask is a subset of the dilating rules' at this shift
+    finally:
+        ctx.close()
+
+
 def test_bench_C3_pair_at_full_size_routes_agree():
     """The very input bench.py times (SURVEY 8d's C3: 20000^2 pair, tba = ref shifted bilinearly by (+1.7, -0.6) px + 2 m + noise,
     20 % gaps) at full size: the queued route the bench runs (EXT dh pass, lean kernels, dual bracket selections, aspect-bin cache)
@@ -753,7 +806,8 @@ def test_bench_C3_pair_at_full_size_routes_agree():
 
 
 @pytest.mark.parametrize("fused,n_bins", [(1, 8), (0, 72)])
-@pytest.mark.parametrize("dtype,rule", [(np.float32, 0), (np.float32, 1), (np.float64, 0)])
+@pytest.mark.parametrize("dtype,rule", [(np.float32, 0), (np.float32, 1), (np.float64, 0), (np.float32, 2), (np.float32, 3),
+                                        (np.float64, 3)])
 def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused, n_bins):
     """The queued route (lean dh / bin kernels, bracketed selections, aspect-bin cache) only runs from 2^22 pixels on: a
     2100 x 2050 pair, selection mode 3 (bracketed route for the 72 bins whatever their sample size), against the oracle for
@@ -762,7 +816,9 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused, n_bins):
     reused.  Vertical shift, valid count, edges, per-bin counts and medians bit-exact.
     Round 4: the one-pass step (option "nk_fused" = 1) on the same pair with 8 aspect bins -- at 4.3 M pixels a 1/64 sample gives
     72 bins ~900 values each, brackets that hold most of a bin, more candidates than the buffers take (the step then falls
-    through to the two passes, which is what the 72-bin case runs); 8 bins bracket tightly enough for the route to answer."""
+    through to the two passes, which is what the 72-bin case runs); 8 bins bracket tightly enough for the route to answer.
+    Round 5: rules 2 / 3 ("dilate3x3" / "dilate_cross") run the same streaming kernels through the plan's bad-bit mask
+    (nk_badbits_kernel: the neighbourhood test of the nearest pixel, evaluated once per plan) instead of the generic kernels."""
     from xdem_amd.synth import fbm_numpy
 
     ctx = coreg._lib.default_context()

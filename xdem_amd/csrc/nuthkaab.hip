@@ -405,7 +405,38 @@ __global__ __launch_bounds__(256) void nk_ext_eval_kernel(const T* __restrict__ 
 //     and one vertical lerp (same operations in the same order as bi_value: results are bit-identical);
 //   * addresses are a uniform row base plus constant 32-bit lane offsets; counters are wave-level popcounts of ballots;
 //   * the loads of row i + 1 are issued before row i is evaluated.
-struct NkRowTab { double fr; int k0l; int flags; };  // upper tap row (buffer-local, clamped), bit 0 = taps inside the raster, bit 1 = d1
+struct NkRowTab { double fr; int k0l; int flags; int rnl; int pad_; };  // upper tap row (buffer-local, clamped), bit 0 = taps inside the raster, bit 1 = d1; rnl: buffer row of the NEAREST pixel (rules 2 / 3), -1 = its neighbourhood leaves the raster
+
+// ---- rules 2 / 3 ("dilate3x3" / "dilate_cross") without a neighbourhood read per pixel (round 5) -------------------------------
+// Under these rules a sample is valid iff its four taps are finite AND the 3 x 3 / cross neighbourhood of the pixel NEAREST to the
+// tap position holds no non-finite value and stays inside the raster (bi_value above).  The second condition depends on tba alone:
+// it is evaluated ONCE per plan into a bit per pixel ("bad" = neighbourhood not clean; border pixels, the columns beyond W in a
+// row's last word and one all-ones pad word on either side of every row are bad too), and the streaming kernels then test the bit
+// of the nearest pixel -- the same floor(pos + 0.5) per row and per lane as bi_combine -- next to their rule-0 arithmetic: one 8-byte
+// word per lane and row, two distinct words per wave.  Results are those of the generic kernel bit for bit (GPU tests per rule).
+template <typename T>
+__global__ __launch_bounds__(256) void nk_badbits_kernel(const T* __restrict__ tba, int64_t H, int64_t W, int rule, int64_t wpr,
+                                                         uint64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // data word of the row (pad words: below)
+    const int64_t nwords = wpr - 2;
+    for (int64_t r = blockIdx.y; r < H; r += gridDim.y) {
+        if (word < nwords) {
+            const int64_t c = word * 64 + lane;
+            bool bad = !(r >= 1 && c >= 1 && r + 1 < H && c + 1 < W);
+            if (!bad) {
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx)
+                        if (rule == 2 || dy == 0 || dx == 0) bad = bad || !t_finite(tba[(r + dy) * W + (c + dx)]);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
+            if (lane == 0) out[r * wpr + 1 + word] = (uint64_t)m;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 2) out[r * wpr + (threadIdx.x ? wpr - 1 : 0)] = ~(uint64_t)0;
+    }
+}
+// nearest pixel of a row / column position as bi_combine computes it
+__device__ __forceinline__ int64_t nk_nearest(double pos) { return (int64_t)floor(pos + 0.5); }
 constexpr int NK_CHUNK_MAX = 512;
 constexpr int NK_PF = 4;
 constexpr int NKL_ROWS = 4;      // rows between two looks at the staging buffer
@@ -417,7 +448,7 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
                                                                int64_t nbuf, const typename KeyT<T>::type* __restrict__ klo_p,
                                                                const typename KeyT<T>::type* __restrict__ khi_p, uint64_t* counters /* [3] */,
                                                                T* out_v, unsigned long long* ctr /* [1] candidates, [2] overflow */,
-                                                               int64_t cap) {
+                                                               int64_t cap, const uint64_t* __restrict__ badbits = nullptr, int64_t bad_wpr = 0) {
     typedef typename KeyT<T>::type K;
     __shared__ NkRowTab tab[NK_CHUNK_MAX + 1];
     // candidates collect in a workgroup staging buffer and leave in bursts of more than NKL_FLUSH values: one global atomic per
@@ -438,6 +469,9 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
         kl = (a.in && kl >= 0 && kl + a.d1 < nbuf) ? kl : 0;
         NkRowTab e;
         e.fr = a.f; e.k0l = (int)kl; e.flags = (a.in ? 1 : 0) | (a.d1 ? 2 : 0);
+        const int64_t rn = nk_nearest(a.pos);
+        e.rnl = (rn >= 1 && rn + 1 < g.H && rn - g.roff >= 0 && rn - g.roff < nbuf) ? (int)(rn - g.roff) : -1;
+        e.pad_ = 0;
         tab[r] = e;
     }
     __syncthreads();
@@ -446,6 +480,13 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
     const bool jin = j < g.W;
     const BiAxis col = bi_axis(j, g.dc, g.W, RULE);
     const bool cin = col.in & jin;
+    // rules 2 / 3: word and bit of this lane's nearest column in a row of the bad-bit mask (columns left of the raster -> the left pad word)
+    int64_t cnc = nk_nearest(col.pos);
+    cnc = cnc < -1 ? -1 : (cnc > g.W ? g.W : cnc);
+    const uint32_t bad_ob = (uint32_t)(2 + (cnc >> 5)) * 4u;   // byte offset in the row (32-bit halves of the words: one register per row in flight)
+    const int bad_sh = (int)(cnc & 31);
+    const char* const bad_base = reinterpret_cast<const char*>(badbits);
+    const int64_t bad_rowb = bad_wpr * 8;
     const uint32_t c0 = cin ? (uint32_t)col.k0 : 0u, c1 = c0 + (cin ? (uint32_t)col.d1 : 0u);
     const uint32_t jl = jin ? (uint32_t)j : 0u;
     const double fc = col.f;
@@ -476,12 +517,18 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
     double hl = 0.0;
     // Software pipeline, NK_PF rows deep: the loads of row r + NK_PF are issued while row r is evaluated (one row in flight per
     // wave leaves the kernel latency-bound at about half of the HBM rate: 32 waves x 1 KiB per CU in flight against ~2 us).
-    struct Pre { T b0, b1, rv, av; uint8_t vd; };
+    struct Pre { T b0, b1, rv, av; uint8_t vd; uint32_t bw; };
     Pre pre[NK_PF];
     const int64_t rb0 = (i0 - g.roff) * g.W;
     auto issue = [&](int rr, Pre& q) {  // rr clamped: entry `nrow` of the table repeats the last row
         const int rc = rr < nrow ? rr : nrow - 1;
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
+        if (RULE == 2) {
+            const int rnl = __builtin_amdgcn_readfirstlane(tab[rc].rnl);
+            q.bw = rnl >= 0 ? *reinterpret_cast<const uint32_t*>(bad_base + (int64_t)rnl * bad_rowb + bad_ob) : ~0u;
+        } else {
+            q.bw = 0;
+        }
         const T* rowp = tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W;
         const int64_t rb = rb0 + (int64_t)rc * g.W;
         // (streaming hints: every input of this pass is read once per step)
@@ -499,6 +546,7 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
             if (r < nrow) {
                 const T b0v = pre[u].b0, b1v = pre[u].b1, rv = pre[u].rv, av = pre[u].av;
                 const uint8_t vd = pre[u].vd;
+                const bool nb_clean = RULE != 2 || ((pre[u].bw >> bad_sh) & 1u) == 0;   // rules 2 / 3: neighbourhood of the nearest pixel
                 issue(r + NK_PF, pre[u]);
                 const int k0l = __builtin_amdgcn_readfirstlane(tab[r].k0l), fl = __builtin_amdgcn_readfirstlane(tab[r].flags);
                 const double fr = tab[r].fr;
@@ -517,7 +565,7 @@ __global__ __launch_bounds__(256) void nk_dh_count_lean_kernel(const T* __restri
                 const T val = (T)t_add(top, t_mul(fr, t_sub(bot, top)));
                 T out = t_sub(rv, val);
                 // (a non-finite tap makes val, hence out, non-finite by itself -- also through a zero weight: 0 * NaN = 0 * inf = NaN)
-                const bool ok = ((fl & 1) != 0) & cin & (vd != 0) & t_finite(out);
+                const bool ok = ((fl & 1) != 0) & cin & (vd != 0) & t_finite(out) & nb_clean;
                 const K key = key_of(out);
                 const bool below = ok & (key < klo);
                 const bool cand = ok & (key >= klo) & (key <= khi);
@@ -1089,8 +1137,8 @@ template <typename T> struct NkzCap { static constexpr int v = sizeof(T) == 4 ? 
 template <typename T> struct FzPair { T lo, hi; };
 
 constexpr int NKZ_CHUNK_MAX = 256;   // rows of a workgroup's chunk (row-tap table in LDS)
-template <typename T, int RULE>
-__global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
+template <typename T, int RULE>   // (RULE 2 = rules 2 / 3 through the bad-bit mask: six more registers -> one workgroup per CU fewer instead of spills)
+__global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
                                                        const uint16_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
                                                        int nb, int copies, const typename KeyT<T>::type* __restrict__ klo_p,
                                                        const typename KeyT<T>::type* __restrict__ khi_p, const T* vhat_p, const T* delta_p,
@@ -1099,7 +1147,7 @@ __global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __res
                                                        uint64_t* cls_y /* [3][nb]: above, below, candidates */, T* cd_vals, int64_t cd_cap,
                                                        T* cy_d, T* cy_st, uint16_t* cy_b, int64_t cy_cap,
                                                        unsigned long long* ctr /* [1] dh candidates, [5] y candidates, [2] overflow */,
-                                                       double* sums /* [5] */) {
+                                                       double* sums /* [5] */, const uint64_t* __restrict__ badbits = nullptr, int64_t bad_wpr = 0) {
     typedef typename KeyT<T>::type K;
     constexpr int NKZ_CAP = NkzCap<T>::v;
     constexpr int SEG = NKZ_CAP / 4;      // staging slots of ONE wave: waves reserve in their own segment with a scalar counter --
@@ -1144,6 +1192,9 @@ __global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __res
         kl = (a.in && kl >= 0 && kl + a.d1 < nbuf) ? kl : 0;
         NkRowTab e;
         e.fr = a.f; e.k0l = (int)kl; e.flags = (a.in ? 1 : 0) | (a.d1 ? 2 : 0);
+        const int64_t rn = nk_nearest(a.pos);
+        e.rnl = (rn >= 1 && rn + 1 < g.H && rn - g.roff >= 0 && rn - g.roff < nbuf) ? (int)(rn - g.roff) : -1;
+        e.pad_ = 0;
         tab[r] = e;
     }
     __syncthreads();
@@ -1153,6 +1204,13 @@ __global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __res
     const bool jin = j < g.W;
     const BiAxis col = bi_axis(j, g.dc, g.W, RULE);
     const bool cin = col.in & jin;
+    // rules 2 / 3 (RULE == 2): word and bit of this lane's nearest column in a row of the bad-bit mask (nk_badbits_kernel)
+    int64_t cnc = nk_nearest(col.pos);
+    cnc = cnc < -1 ? -1 : (cnc > g.W ? g.W : cnc);
+    const uint32_t bad_ob = (uint32_t)(2 + (cnc >> 5)) * 4u;   // byte offset in the row (32-bit halves of the words: one register per row in flight)
+    const int bad_sh = (int)(cnc & 31);
+    const char* const bad_base = reinterpret_cast<const char*>(badbits);
+    const int64_t bad_rowb = bad_wpr * 8;
     const unsigned long long m_cin = __builtin_amdgcn_ballot_w64(cin);
     // byte offsets of this lane's columns: 32-bit, added to uniform row pointers by the load instruction itself (a chunk spans
     // at most NKZ_CHUNK_MAX rows: (NKZ_CHUNK_MAX + 1) * W * 4 < 2^32 is the launcher's condition for this route)
@@ -1223,7 +1281,7 @@ __global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __res
     };
     int have = -1;
     double hl = 0.0;
-    struct Pre { T b0, b1, rv, st; uint16_t bin; };
+    struct Pre { T b0, b1, rv, st; uint16_t bin; uint32_t bw; };
     Pre pre[NKZ_PF];
     // (wave-uniform, and said so: the descriptors below must sit in scalar registers -- a descriptor the compiler takes for
     // lane-varying is read back lane by lane in a loop around every load)
@@ -1245,6 +1303,12 @@ __global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __res
     auto issue = [&](int rr, Pre& q) {  // rows past the chunk repeat its last row
         const int rc = rr < nrow ? rr : nrow - 1;
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);
+        if (RULE == 2) {
+            const int rnl = __builtin_amdgcn_readfirstlane(tab[rc].rnl);
+            q.bw = rnl >= 0 ? *reinterpret_cast<const uint32_t*>(bad_base + (int64_t)rnl * bad_rowb + bad_ob) : ~0u;
+        } else {
+            q.bw = 0;
+        }
 #if XD_NKZ_BUFFER
         const uint32_t so_t = tap_row(tk + ((tf >> 1) & 1));
         q.b0 = fz_bufload(r_tba, c0b, so_t, T());
@@ -1276,6 +1340,7 @@ __global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __res
             if (r < nrow) {   // (uniform)
                 const T b0v = pre[u].b0, b1v = pre[u].b1, rv = pre[u].rv, stv = pre[u].st;
                 const uint16_t bin = pre[u].bin;
+                const unsigned long long m_clean = RULE != 2 ? ~0ull : __builtin_amdgcn_ballot_w64(((pre[u].bw >> bad_sh) & 1u) == 0);
                 issue(r + NKZ_PF, pre[u]);
                 const int k0l = __builtin_amdgcn_readfirstlane(tab[r].k0l), fl = __builtin_amdgcn_readfirstlane(tab[r].flags);
                 const double fr = tab[r].fr;
@@ -1299,7 +1364,7 @@ __global__ __launch_bounds__(256, XD_NKZ_LB) void nk_fused_kernel(const T* __res
                 const T out = t_sub(rv, val);
                 // lane masks as 64-bit scalars; per-lane choices are selects on those masks, stores and the counter update run
                 // unmasked (lanes that have nothing to say write to a slot / add 0 to a word nobody reads): one basic block per row
-                const unsigned long long m_row = (fl & 1) ? m_cin : 0ull;
+                const unsigned long long m_row = (fl & 1) ? (m_cin & m_clean) : 0ull;
                 const unsigned long long m_ok = __builtin_amdgcn_ballot_w64(t_finite(out)) & m_row;
                 const K key = key_of(out);
                 const unsigned long long m_lt = __builtin_amdgcn_ballot_w64(key < klo), m_le = __builtin_amdgcn_ballot_w64(key <= khi);
@@ -1509,6 +1574,8 @@ struct xdemhip_nk_plan {
     int max_bins = 0;
     long long n_valid0 = 0;
     xd::SelWorkspace ws;  // bracketed selection (select_run.h): sample + candidate buffers
+    uint64_t* badbits = nullptr;   // rules 2 / 3: one bit per buffer pixel, "the neighbourhood of this pixel of tba is not clean" (nk_badbits_kernel)
+    int64_t bad_wpr = 0;           // ... 64-bit words per row, one all-ones pad word on either side
     int bin_stat = XDEMHIP_BINSTAT_MEDIAN;
     int nan_rule = 0;
     int custom_decimal = 0;            // ... and the decimal of SciPy's rightmost-edge rule for them
@@ -1664,7 +1731,7 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         dim3 grid = grid2d(ctx, P->W, P->row1 - P->row0);
         const int64_t rows = P->row1 - P->row0;
         if ((rows + grid.y - 1) / grid.y > NK_CHUNK_MAX) grid.y = (unsigned)((rows + NK_CHUNK_MAX - 1) / NK_CHUNK_MAX);
-        const bool ext = P->ext_ok && !ctx->allreduce && g.rule <= 1;
+        const bool ext = P->ext_ok && !ctx->allreduce && (g.rule <= 1 || P->badbits);
         if (ext) {   // min / max aspect from the listed extreme-aspect pixels; the dh pass then reads neither mask nor aspect
             XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt + 2, 0, 16, ctx->stream));
             hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref_m),
@@ -1677,14 +1744,17 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         if (ext)                                                                                                                    \
             hipLaunchKernelGGL((nk_dh_count_lean_kernel<T, RULE, true>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref_m), \
                                static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh), d_stats, \
-                               P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap);   \
+                               P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap,    \
+                               P->badbits, P->bad_wpr);                                                                            \
         else                                                                                                                        \
             hipLaunchKernelGGL((nk_dh_count_lean_kernel<T, RULE>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),  \
                                static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh), d_stats, \
-                               P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap);   \
+                               P->row0, P->row1, P->nbuf, d_klo, d_khi, d_cnt, static_cast<T*>(ws->c_vals), d_flags, ws->c_cap,    \
+                               P->badbits, P->bad_wpr);                                                                            \
     } while (0)
         if (g.rule == 0) XD_NK_LEAN(0);
         else if (g.rule == 1) XD_NK_LEAN(1);
+        else if (P->badbits && !ctx->allreduce) XD_NK_LEAN(2);   // rules 2 / 3 through the bad-bit mask of the plan
         else
             hipLaunchKernelGGL((nk_dh_count_kernel<T>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),
                                static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh),
@@ -1819,7 +1889,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     SelWorkspace* ws = &P->ws;
     const int64_t rows = P->row1 - P->row0;
     const int64_t n_slots = ((((n + SEL_LINE - 1) >> SEL_LINE_LOG2) + 63) >> 6) << SEL_LINE_LOG2;
-    if (!ctx->nk_fused || ctx->allreduce || !P->fz || !P->cd_vals || !P->c_st || !P->bcache || !P->ext_ok || g.rule > 1 || rows <= 0 ||
+    if (!ctx->nk_fused || ctx->allreduce || !P->fz || !P->cd_vals || !P->c_st || !P->bcache || !P->ext_ok || (g.rule > 1 && !P->badbits) || rows <= 0 ||
         P->bin_stat != XDEMHIP_BINSTAT_MEDIAN || !(ctx->selection_mode == 0 || ctx->selection_mode == 3) || !ws->d_small ||
         ws->es != sizeof(T) || nb > ws->nb_max || nb > MAX_BINS_PER_SWEEP || n < SEL_BRACKET_MIN_N ||
         (ctx->selection_mode == 0 && n < SEL_BRACKET_MIN_PER_BIN * nb) || n_slots > ws->s_cap ||
@@ -1906,9 +1976,10 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
 #define XD_NK_FZ(RULE)                                                                                                               \
     hipLaunchKernelGGL((nk_fused_kernel<T, RULE>), grid, dim3(256), lds, ctx->stream, ref_m, tba, st_all, P->bcache, g, P->row0, P->row1,  \
                        P->nbuf, nb, copies, klo_d, khi_d, d_vhat, d_delta, klo_y, khi_y, cnt_d, cls_y, static_cast<T*>(P->cd_vals),   \
-                       P->cd_cap, cy_d, static_cast<T*>(P->c_st), ws->c_bins, ws->c_cap, ctr, d_sums)
+                       P->cd_cap, cy_d, static_cast<T*>(P->c_st), ws->c_bins, ws->c_cap, ctr, d_sums, P->badbits, P->bad_wpr)
         if (g.rule == 0) XD_NK_FZ(0);
-        else XD_NK_FZ(1);
+        else if (g.rule == 1) XD_NK_FZ(1);
+        else XD_NK_FZ(2);
 #undef XD_NK_FZ
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -2303,6 +2374,21 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
             P->fz = nullptr; P->cd_vals = nullptr; P->c_st = nullptr; P->fz_pack = nullptr;
         }
     }
+    // rules 2 / 3 on whole-raster plans large enough for the streaming kernels: the per-pixel neighbourhood flags of tba, once
+    if (P->nan_rule >= 2 && roff == 0 && nbuf == H && (int64_t)n >= SEL_BRACKET_MIN_N) {
+        P->bad_wpr = (W + 63) / 64 + 2;
+        if (hipMalloc(reinterpret_cast<void**>(&P->badbits), (size_t)P->bad_wpr * (size_t)H * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            P->badbits = nullptr;   // (the plan keeps the generic kernels)
+        } else {
+            const dim3 bgrid((unsigned)((P->bad_wpr - 2 + 3) / 4), (unsigned)(H < 4096 ? H : 4096));
+            if (dtype == XDEMHIP_F32)
+                hipLaunchKernelGGL((nk_badbits_kernel<float>), bgrid, dim3(256), 0, ctx->stream, static_cast<const float*>(P->tba), H, W, P->nan_rule, P->bad_wpr, P->badbits);
+            else
+                hipLaunchKernelGGL((nk_badbits_kernel<double>), bgrid, dim3(256), 0, ctx->stream, static_cast<const double*>(P->tba), H, W, P->nan_rule, P->bad_wpr, P->badbits);
+            if (hipGetLastError() != hipSuccess) return fail(XDEMHIP_EHIP, "nk_badbits_kernel launch failed");
+        }
+    }
     const xdemhip_allreduce_fn hook = ctx->allreduce;
     if (!global_count) ctx->allreduce = nullptr;  // whole-raster plan: local pass; xdemhip_nk_set_rows re-partitions with the hook
     int rc = dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
@@ -2322,7 +2408,7 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     (void)hipSetDevice(P->ctx->device);
     if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
     void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt,
-                    P->fz, P->cd_vals, P->c_st, P->fz_pack};
+                    P->fz, P->cd_vals, P->c_st, P->fz_pack, P->badbits};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     xd::sel_ws_free(P->ws);

@@ -740,11 +740,13 @@ XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, 
         if (m & (A_MAXC | A_MINC)) {
             float vmax, vmin;
             if (dir) {
-                const double half_tr = 50.0 * (zxx + zyy);
-                const double hd = 50.0 * (zxx - zyy), sxy = 100.0 * zxy;
-                const double rad = sqrt_nr_signed(fma(hd, hd, sxy * sxy));
-                vmax = (float)(rad - half_tr);
-                vmin = (float)(-half_tr - rad);
+                // (inline constants only -- 0.5 in float64, the 100.0f the other curvatures use: the streaming kernels have no
+                // scalar register to spare, and a spilled plane pointer is what their inline-asm stores must never meet)
+                const double half_tr = 0.5 * (zxx + zyy);
+                const double hd = 0.5 * (zxx - zyy);
+                const double rad = sqrt_nr_signed(fma(hd, hd, zxy * zxy));
+                vmax = (float)(rad - half_tr) * 100.0f;
+                vmin = (float)(-half_tr - rad) * 100.0f;
             } else {
                 // (h, the discriminant and +-root - h in float64 as in the mixed tail; only the common factor 100 / w^3 is float32)
                 const double h = 0.5 * ((zxx + zyy) + n_tan);

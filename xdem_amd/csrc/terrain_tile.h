@@ -312,8 +312,12 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
     const int64_t org_off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(org_u >> 32)) << 32) |
                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)org_u));
     // (plane pointers stay in scalar registers for the whole kernel -- none is spilled to VGPR lanes, which the CPU test suite
-    // checks on the compiled code -- so the stores read them directly: DirectSink<float, false>)
-    DirectSink<float, false> sk;
+    // checks on the compiled code -- so the stores read them directly: DirectSink<float, false>.  One instantiation does spill a
+    // scalar pair -- Florinsky with directional curvatures parks the saved exec mask of its cold path in a VGPR lane --: its stores
+    // take the plane pointer through the scalar copy, which is safe whatever was restored: the same ISA test checks that every
+    // kernel with a v_readlane has the copy in front of every store)
+    constexpr bool PTR_COPY = FIT == 2 && CURV && SP::DIR == 1;
+    DirectSink<float, PTR_COPY> sk;
 #pragma unroll
     for (int k = 0; k < N_ATTR; ++k) sk.org.p[k] = a.out.p[k] + org_off;
     sk.o0 = (uint32_t)(lane * sizeof(float));
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
 #if defined(XD_STRIP_SYNC)   // (measurement builds: workgroup barrier every XD_STRIP_SYNC output rows -- the four strips of a group then write
     sk.sync_n = XD_STRIP_SYNC;   // the same plane rows at about the same time; legal: the four waves march the same number of rows)
 #endif
-    march_rows<FIT, CURV, WIN, SP, float, DirectSink<float, false>, RowsRing<NPL>>(rows, n_out, a.P, sk);
+    march_rows<FIT, CURV, WIN, SP, float, DirectSink<float, PTR_COPY>, RowsRing<NPL>>(rows, n_out, a.P, sk);
 }
 
 // TPI / TRI / roughness for an arbitrary odd window (the reference default 3 is handled by the fused kernels above).
