@@ -70,7 +70,7 @@ def _usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(n: int = 6144) -> dict:
+def cpu_baseline(n: int = 6144, gpu_check: bool = True) -> dict:
     """Reference-recipe CPU port (oracle/terrain_oracle.py = NumPy restatement of the reference's SciPy engine) on bounded
     samples of the same workload, as SURVEY 8d asks: one thread, all host cores (one oracle process per core, one tile each),
     and the reference engine's own primitive -- scipy.ndimage.convolve with the five Florinsky kernels -- where SciPy is there."""
@@ -82,9 +82,28 @@ def cpu_baseline(n: int = 6144) -> dict:
 
     dem = fbm_numpy((n, n), seed=42)
     t0 = time.perf_counter()
-    terrain_oracle.terrain_attributes(dem, FULL, resolution=10.0)
+    ref = terrain_oracle.terrain_attributes(dem, FULL, resolution=10.0)
     dt = time.perf_counter() - t0
-    out = {"value": round(n * n / dt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+    # the oracle as the checker of this leg: the HIP path on the very sample the CPU was timed on (host buffers in and out), NaN
+    # masks bit for bit and every plane within 1e-6 of the oracle relative to max(|ref|, the plane's 99th percentile)
+    check = None
+    if gpu_check:
+        from xdem_amd import terrain
+
+        got = terrain.get_terrain_attribute(dem, FULL, resolution=10.0)
+        worst = 0.0
+        for a, g, r in zip(FULL, got, ref):
+            if not np.array_equal(np.isnan(g), np.isnan(r)):
+                raise RuntimeError(f"bench.py: NaN mask of {a} differs from the oracle on the CPU-baseline sample")
+            fin = np.isfinite(r)
+            scale = float(np.percentile(np.abs(r[fin]), 99)) or 1.0
+            err = float(np.max(np.abs(g[fin].astype(np.float64) - r[fin]) / np.maximum(np.abs(r[fin]), scale)))
+            worst = max(worst, err)
+            if err > 1e-6:
+                raise RuntimeError(f"bench.py: {a} differs from the oracle by {err:.3e} (scaled) on the CPU-baseline sample")
+        check = {"planes": len(FULL), "nan_masks_equal": True, "max_scaled_err": worst, "bar": 1e-6}
+    del ref
+    out = {"value": round(n * n / dt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port", "gpu_vs_oracle_on_this_sample": check,
            "sample": f"{n}x{n} fBm float32 DEM, full 11-attribute set, oracle/terrain_oracle.py (NumPy restatement of "
                      f"the reference SciPy engine), {dt:.1f} s, host has {os.cpu_count()} cores"}
     # all cores: one process per core (capped), each times the oracle on its own 1024 x 2048 tile; rate = pixels / slowest
@@ -560,6 +579,21 @@ def main() -> None:
     # allocation (torch.empty = hipMalloc), which on some boxes is one physically contiguous block -- after the library's
     # scattered backing above.  Every driver run is thereby a data point of "is >= 0.70 the kernel's or the allocator's"
     # (XDEM_BENCH_AB=0 skips it).
+    # Spot check of the TIMED output (not a parity claim -- that is the test suite's and the cpu_baseline leg's): 64 rows from the
+    # middle of this rank's planes against a second, small launch over just those rows + halo (the tile kernel instead of the
+    # streaming strips: another code path, the same arithmetic) -- bit for bit; and the planes hold no value the set cannot produce
+    lo = max(depth, (block.rows // 2) & ~31)
+    hi = min(lo + 64, block.rows - depth)
+    spot = None
+    if hi - lo >= 8:
+        crop = terrain.terrain_attributes_device(block.interior[lo - depth:hi + depth], FULL, halo_top=depth, halo_bottom=depth, **kw)
+        torch.cuda.synchronize(dev)
+        same = bool(torch.equal(torch.nan_to_num(crop, nan=-7.0e33), torch.nan_to_num(out[:, lo:hi], nan=-7.0e33)))
+        slope_ok = bool(((out[0, lo:hi] >= 0) & (out[0, lo:hi] <= 90)).all()) and bool(((out[2, lo:hi] >= 0) & (out[2, lo:hi] <= 255)).all())
+        spot = {"rows": [int(lo), int(hi)], "planes_equal_a_separate_launch_bit_for_bit": same, "slope_and_hillshade_in_range": slope_ok}
+        if not (same and slope_ok):
+            raise SystemExit(f"bench.py: spot check of the timed planes failed: {spot}")
+        del crop
     ab = None
     if world == 1 and os.environ.get("XDEM_BENCH_AB", "1") == "1" and os.environ.get("XDEM_BENCH_PLANES", "auto") == "auto":
         del out
@@ -627,7 +661,7 @@ def main() -> None:
                                    "terrain_tile_kernel (frame of edge tiles)",
                          "kernel_ms_source": "mean HIP-event time of the timed steps themselves (events on the launch stream)",
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(min(step_ms), 4),
-                         "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch},
+                         "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch, "output_spot_check": spot},
         }
         if ab is not None:
             res["roofline"]["frac_caller_planes"] = ab["frac"]

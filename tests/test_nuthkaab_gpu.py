@@ -715,7 +715,8 @@ def test_lean_route_equals_plain_route_at_scale():
 @pytest.mark.parametrize("rule", [2, 3])
 def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
     """Rules 2 / 3 of the bilinear taps (the forms with a dilated nodata mask -- rule 3 is what the only hint about geoutils'
-    convention favours) on a 7000^2 pair with noise, 20 % contiguous gaps and scattered single-pixel holes:
+    convention favours) on a 9000^2 pair with noise, 20 % contiguous gaps and scattered single-pixel holes,
+    36 aspect bins (about as many sampled values per bin as the 12000^2 / 72-bin case above: brackets the one-pass step can use):
     the one-pass step and the two-pass route (streaming kernels + the plan's bad-bit mask) against the plain route (generic
     kernels, a 3 x 3 / cross neighbourhood read per pixel): every output of every step identical, fractional and integer
     shifts, a repeated step; and the default rule gives a DIFFERENT valid count on the same pair (the rules do differ here)."""
@@ -724,7 +725,7 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
     from xdem_amd import _lib, coreg
     from xdem_amd.synth import fbm_torch
 
-    m = 7000
+    m, nbin = 9000, 36
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(11)
@@ -744,9 +745,11 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
             ctx.set_option("selection", mode)
             ctx.set_option("nk_fused", fused)
             plan = coreg.NKPlan(ref, tba, None, ctx)
-            res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in steps]
-            assert plan.route_counts()[name] == len(steps), (name, plan.route_counts())
-            plan.close()
+            try:
+                res[name] = [plan.step(sx, sy, (10.0, 10.0), nbin) for (sx, sy) in steps]
+                assert plan.route_counts()[name] == len(steps), (name, plan.route_counts())
+            finally:
+                plan.close()
         for name in ("onepass", "twopass"):
             for a, b in zip(res[name], res["plain"]):
                 assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], (rule, name)
@@ -758,7 +761,7 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
         ctx.set_option("selection", 0)
         ctx.set_option("nk_fused", 1)
         plan = coreg.NKPlan(ref, tba, None, ctx)
-        d0 = plan.step(3.0, -4.0, (10.0, 10.0), 72)
+        d0 = plan.step(3.0, -4.0, (10.0, 10.0), nbin)
         plan.close()
         assert d0["n_valid"] > res["plain"][1]["n_valid"]   # rule 0's mask is a subset of the dilating rules' at this shift
     finally:

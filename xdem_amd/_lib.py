@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
+import weakref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libxdemhip.so")
@@ -268,6 +269,9 @@ class Context:
         self._pool_cap = int(float(os.environ.get("XDEM_PLANE_POOL_GB", "16")) * (1 << 30))
         self._pool_lock = threading.Lock()
         self.options: dict[str, int] = {}  # mirror of the xdemhip_set_option calls made through this object
+        # objects that hold library handles created on this context (Nuth-Kaab plans, pair sets, binning plans): closed before the
+        # context goes -- a plan destroyed AFTER its context would hand the library a dangling context pointer
+        self._dependants: weakref.WeakSet = weakref.WeakSet()
         for k, v in thirdparty_decision().items():   # conventions decided from the third-party packages' own outputs, where recorded
             if v != THIRDPARTY_DEFAULTS[k]:
                 self.set_option(k, v)
@@ -393,8 +397,17 @@ class Context:
         self.check(self._L.xdemhip_last_kernel_ms(self.handle, ctypes.byref(ms)))
         return float(ms.value)
 
+    def adopt(self, obj) -> None:
+        """Register an object with a ``close()`` that owns handles created on this context (closed with it, if still alive)."""
+        self._dependants.add(obj)
+
     def close(self) -> None:
         if getattr(self, "handle", None):
+            for obj in list(getattr(self, "_dependants", ())):
+                try:
+                    obj.close()
+                except Exception:
+                    pass
             self.release_pool()
             self._L.xdemhip_destroy(self.handle)
             self.handle = None

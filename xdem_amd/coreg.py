@@ -59,6 +59,7 @@ class NKPlan:
         self.ctx = ctx or _lib.default_context()
         self.handle = None
         self.group = None
+        self.ctx.adopt(self)   # (closed with the context if the caller never closes it: the plan holds a pointer to the context)
         prev_group = getattr(self.ctx, "_group", None)   # hooks the caller had on the context before this plan
         try:
             self._create(ref, tba, inlier_mask, group, block)
@@ -216,10 +217,11 @@ class NKPlan:
 
     def close(self) -> None:
         if getattr(self, "handle", None):
-            self.ctx._L.xdemhip_nk_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):   # (a context that is already gone took its plans with it)
+                self.ctx._L.xdemhip_nk_destroy(self.handle)
+                if getattr(self, "group", None) is not None:
+                    self.ctx.set_allreduce(None)
             self.handle = None
-            if getattr(self, "group", None) is not None:
-                self.ctx.set_allreduce(None)
 
     def __del__(self):  # pragma: no cover
         try:

@@ -72,6 +72,7 @@ class PairSet:
         if any((len(b) == 3) != pd for b in blocks):
             raise ValueError("cannot mix pdist and cdist blocks")
         self.ctx = ctx or _lib.default_context()
+        self.ctx.adopt(self)
         vdt = np.float64 if any(np.asarray(b[2]).dtype == np.float64 for b in blocks) else np.float32
         if self.ctx.options.get("vario_diff"):
             vdt = np.float64  # option "vario_diff" = 1: |dv| in float64 whatever the value dtype (values are widened)
@@ -142,6 +143,9 @@ class PairSet:
 
     def close(self) -> None:
         h, hs = getattr(self, "handle", None), getattr(self, "handle_sel", None)
+        if not getattr(self.ctx, "handle", None):   # (the context is gone and took the sets with it)
+            self.handle = self.handle_sel = None
+            return
         if hs and h and hs.value != h.value:
             self.ctx._L.xdemhip_pairs_link_sorted(hs, None)
         if h:
@@ -757,6 +761,7 @@ class BinStatsPlan:
 
     def __init__(self, values: np.ndarray, list_var: list[np.ndarray], ctx: _lib.Context | None = None):
         self.ctx = ctx or _lib.default_context()
+        self.ctx.adopt(self)
         L = self.ctx._L
 
         def prep(a):
@@ -811,7 +816,8 @@ class BinStatsPlan:
 
     def close(self) -> None:
         if getattr(self, "handle", None):
-            self.ctx._L.xdemhip_binstats_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):
+                self.ctx._L.xdemhip_binstats_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
