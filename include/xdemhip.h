@@ -313,6 +313,13 @@ int xdemhip_pairs_medians(xdemhip_pairs* pairs, int64_t* counts, double* medians
  * statistics assume unsorted tiles).  `sorted` is not owned and must outlive the calls; NULL (or `pairs` itself) unlinks.
  * Context option "vario_runs" = 0 ignores the link. */
 int xdemhip_pairs_link_sorted(xdemhip_pairs* pairs, xdemhip_pairs* sorted);
+/* Round 5: float64 differences of float32 values (option "vario_diff" = 1 -- SciPy's pdist widens -- on float32 inputs) at the speed
+ * of the float32 kernels.  `shadow` is a float32 set of the same blocks and edges as the float64 set `pairs` (whose values are all
+ * exactly float32 numbers, widened): xdemhip_pairs_medians(pairs) then classifies every pair by its float32 difference on the
+ * shadow (rounding is monotone, so the integer counts hold for the exact differences too), stages the candidates as exact float64
+ * differences and selects among them in float64 -- the float64 medians bit for bit, the counting pass in 38 instead of 60 ms on
+ * BASELINE's C5.  NULL removes the link; the shadow must outlive it (not owned). */
+int xdemhip_pairs_link_shadow(xdemhip_pairs* pairs, xdemhip_pairs* shadow);
 void xdemhip_pairs_destroy(xdemhip_pairs* pairs);
 
 /* ---- next row 8f-3: N-dimensional binned statistics ---------------------------------------------------------------

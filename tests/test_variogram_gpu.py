@@ -612,6 +612,73 @@ def test_run_length_counting_pass_on_lattice_sets(ss, kind, dtype):
         assert np.array_equal(med, med0, equal_nan=True), k
 
 
+@pytest.mark.parametrize("kind", ["cdist lattice", "pdist lattice", "cdist float64 coordinates"])
+def test_float64_differences_of_float32_values_through_the_float32_shadow(ss, kind):
+    """Option "vario_diff" = 1 (|dv| in float64: what SciPy's pdist does to float32 values) on float32 inputs, >= 4e9 pairs: the
+    exact-median route runs its sampled passes and its counting pass on a float32 SHADOW of the set -- every pair classified by its
+    float32 difference, rounding being monotone -- and stages / selects the candidates as exact float64 differences
+    (xdemhip_pairs_link_shadow, WIDE kernels).  Medians and counts must be those of the float64 set's own route bit for bit (shadow
+    unlinked: float64 kernels; plain digit passes) -- and differ from the float32-difference medians in the last digits (the
+    conventions do differ).  Values with ties, a correlated field, differences that are no float32 numbers."""
+    from xdem_amd import _lib
+
+    rng = np.random.default_rng(23)
+    L = 20000
+    lattice = "lattice" in kind
+    coord = (lambda n: rng.integers(0, L, n).astype(np.float64)) if lattice else (lambda n: rng.uniform(0, L, n))
+    # (values around zero, all binades: float32 differences of such values round -- around 1000 m they would all be exact)
+    f = lambda x, y: (40.0 * np.sin(x / 700.0) * np.cos(y / 900.0) + rng.normal(scale=1.5, size=x.size)).astype(np.float32)  # noqa: E731
+    if kind.startswith("pdist"):
+        n = 92000
+        x, y = coord(n), coord(n)
+        blocks = [(x, y, f(x, y))]
+        total = n * (n - 1) // 2
+    else:
+        blocks = []
+        for _ in range(3):
+            na, nbp = 20000, 70000
+            ax, ay, bx, by = coord(na), coord(na), coord(nbp), coord(nbp)
+            blocks.append((ax, ay, f(ax, ay), bx, by, f(bx, by)))
+        total = 3 * 20000 * 70000
+    assert total >= 4_000_000_000
+    edges = np.geomspace(np.sqrt(2), np.hypot(L, L), 40)
+    ctx = _lib.default_context()
+    res = {}
+    try:
+        ps32 = ss.PairSet(blocks, edges, ctx)          # the default convention: float32 differences
+        res["float32 differences"] = ss.class_medians(ps32)
+        ps32.close()
+        ctx.set_option("vario_diff", 1)
+        ps = ss.PairSet(blocks, edges, ctx)
+        assert ps.shadow_sel is not None and ps.vdtype == np.float64
+        try:
+            res["shadow"] = ss.class_medians(ps)
+            ctx.set_option("vario_runs", 0)
+            res["shadow, per-pair counting"] = ss.class_medians(ps)
+            ctx.set_option("vario_runs", 1)
+            ctx.check(ctx._L.xdemhip_pairs_link_shadow(ps.handle_sel, None))
+            res["float64 kernels"] = ss.class_medians(ps)
+            ctx.set_option("selection", 1)
+            res["float64 plain passes"] = ss.class_medians(ps)
+            ctx.set_option("selection", 0)
+            ctx.check(ctx._L.xdemhip_pairs_link_shadow(ps.handle_sel, ps.shadow_sel))
+        finally:
+            ps.close()
+    finally:
+        ctx.set_option("vario_diff", 0)
+        ctx.set_option("vario_runs", 1)
+        ctx.set_option("selection", 0)
+    med0, cnt0 = res["float64 plain passes"]
+    for k in ("shadow", "shadow, per-pair counting", "float64 kernels"):
+        med, cnt = res[k]
+        assert np.array_equal(cnt, cnt0), k
+        assert np.array_equal(med, med0, equal_nan=True), (k, np.nanmax(np.abs(med - med0)))
+    m32, c32 = res["float32 differences"]
+    assert np.array_equal(c32, cnt0)
+    ok = np.isfinite(med0) & (cnt0 > 1000)
+    assert np.all(np.abs(m32[ok] - med0[ok]) <= 2e-7 * np.abs(med0[ok])) and np.any(m32[ok] != med0[ok])
+
+
 def test_link_sorted_refuses_a_different_pair_set(ss):
     """xdemhip_pairs_link_sorted: the companion must hold the same blocks (sizes, dtype, edges); anything else is refused and
     the set stays unlinked."""

@@ -125,6 +125,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_pairs_succ.argtypes = [ctypes.c_void_p, c_u64p, c_u64p]
         L.xdemhip_pairs_medians.argtypes = [ctypes.c_void_p, c_i64p, c_dp]
         L.xdemhip_pairs_link_sorted.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.xdemhip_pairs_link_shadow.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_pairs_destroy.argtypes = [ctypes.c_void_p]
         L.xdemhip_pairs_destroy.restype = None
         c_ip = ctypes.POINTER(ctypes.c_int)

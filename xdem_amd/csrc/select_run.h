@@ -398,7 +398,7 @@ __device__ __forceinline__ int64_t sel_sampled_line(int64_t group) {
 constexpr int SEL_TILE = 4;                        // elements per thread and step
 constexpr int SEL_STAGE_CAP = 8192;                // staging slots per workgroup
 constexpr int SEL_FLUSH_EVERY = 4;                 // bracket pass: steps (of SEL_TILE x 1024 elements) between two flushes
-template <typename T> struct BlockStage {
+template <typename T, int CAP = 8192 /* = SEL_STAGE_CAP: staging slots of the workgroup */> struct BlockStage {
     T* v;
     uint16_t* b;
     int* held;                   // LDS
@@ -428,21 +428,21 @@ template <typename T> struct BlockStage {
         pos0 = __shfl(pos0, leader);
         if (keep) {
             const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < SEL_STAGE_CAP) { v[pos] = val; b[pos] = bin; }
+            if (pos < CAP) { v[pos] = val; b[pos] = bin; }
             else *overflow = 1ull;
         }
     }
     // called by every thread of the workgroup after each step (and with force at the end)
     __device__ __forceinline__ void sync_and_flush(bool force, T* out_v, uint16_t* out_b, unsigned long long* counter, int64_t cap,
                                                    unsigned long long* overflow) {
-        sync_and_flush_at(force ? 0 : SEL_STAGE_CAP - SEL_TILE * (int)blockDim.x, out_v, out_b, counter, cap, overflow);
+        sync_and_flush_at(force ? 0 : CAP - SEL_TILE * (int)blockDim.x, out_v, out_b, counter, cap, overflow);
     }
     // barrier, then flush if more than `threshold` elements are staged
     __device__ __forceinline__ void sync_and_flush_at(int threshold, T* out_v, uint16_t* out_b, unsigned long long* counter, int64_t cap,
                                                       unsigned long long* overflow) {
         __syncthreads();
         int h = *held;
-        h = h > SEL_STAGE_CAP ? SEL_STAGE_CAP : h;  // (bounded appends may have counted past the end)
+        h = h > CAP ? CAP : h;  // (bounded appends may have counted past the end)
         if (h > threshold) {
             if (threadIdx.x == 0) *base = atomicAdd(counter, (unsigned long long)h);
             __syncthreads();

@@ -89,7 +89,7 @@ template <typename T> struct PairArgs {
     // OP_BRACKET (bracketed selection, select_run.h): keys in [prefix[k], khi[k]] are candidates
     const typename KeyT<T>::type* khi;
     unsigned long long* cnt3;      // [3][nb]: pairs per class at or above the bracket's low end, below it, inside the bracket
-    T* cand_v;                     // candidate |dv|
+    void* cand_v;                  // candidate |dv| (T; WIDE kernels: the EXACT float64 difference of two float32 values)
     uint16_t* cand_b;              // and their class
     unsigned long long* cand_ctr;  // [0] count, [1] overflow flag
     long long cand_cap;
@@ -157,11 +157,23 @@ __device__ __forceinline__ uint32_t add_mask_bit(uint32_t n, unsigned long long 
 // distance of a pair is ONE v_pk_sub_i16 + ONE v_dot2_i32_i16, exact in 32 bits, and the class follows from integer
 // thresholds that are the exact pre-images of the float64 thresholds (host: make_grid) -- identical classes, a third fewer
 // instructions per pair than the float64 coordinates (5 float64 operations + a 64-bit compare).
-template <typename T, int OP, bool FAST, int NT, bool GRID = false>
+// WIDE (float32 values only; context option "vario_diff" = 1 on float32 inputs, round 5): the pass classifies every pair by its
+// float32 difference fl(a - b) exactly as the default kernel does -- same instructions in the hot loop --, but a CANDIDATE leaves
+// as the exact float64 difference |double(a) - double(b)| (the B value is read again from the LDS tile when, rarely, a pair is a
+// candidate).  Rounding is monotone -- fl(d1) < fl(d2) implies d1 < d2 -- so the integer counts of the float32 classification
+// are exact counts below / inside / above the bracket for the exact differences too, and the order statistic selected among
+// the float64 candidates at rank (r - below) IS the exact float64 one: scikit-gstat's pdist-style float64 differences at the
+// speed of the float32 kernels (the float64 kernels spend 60 ms on this pass against 38).
+template <typename T, bool WIDE> struct CandT { typedef T type; };
+template <> struct CandT<float, true> { typedef double type; };
+template <typename T, int OP, bool FAST, int NT, bool GRID = false, bool WIDE = false>
 // (1024-thread workgroups: two of them per CU -- 8 waves per SIMD -- need at most 64 VGPRs: second launch-bound = waves per SIMD; float32 values only, the float64
 // kernels do not fit that budget without spilling)
 __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pairs_kernel(const PairArgs<T> a) {
     typedef typename KeyT<T>::type K;
+    typedef typename CandT<T, WIDE>::type TC;   // what a candidate is stored as
+    static_assert(!WIDE || (sizeof(T) == 4 && OP == OP_BRACKET), "WIDE: float32 values, counting pass only");
+    TC* const cand_out = static_cast<TC*>(a.cand_v);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_bx = reinterpret_cast<double*>(smem);
     double* s_by = s_bx + PT;
@@ -184,7 +196,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(acc);            // OP_HIST: nbs * 256
     K* s_min = reinterpret_cast<K*>(acc);                           // OP_SUCC: nb keys
     unsigned long long* s_c3 = reinterpret_cast<unsigned long long*>(acc);   // OP_BRACKET: [nb + 1][NCOPY] packed counters, then the staging buffer
-    BlockStage<T> stage;
+    // (WIDE: 8-byte candidates in half as many slots -- the staging buffer keeps its size, and with it two workgroups per CU)
+    constexpr int STAGE_CAP = WIDE ? SEL_STAGE_CAP / 2 : SEL_STAGE_CAP;
+    BlockStage<TC, STAGE_CAP> stage;
     // OP_BRACKET: one PACKED 64-bit counter per class and copy -- bits 0..20 pairs of the class, 21..41 those at or above the
     // bracket's low end, 42..62 those above its high end (a workgroup gives a copy at most 1024 x 4096 / 32 = 2^17 pairs): ONE
     // ds_add_u64 of (1 | ge << 21 | gt << 42) per pair, its value two selects on the compare masks, its address one shift-add
@@ -200,9 +214,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     // staging buffer: the runs count only total and >= low end per pair)
     uint32_t* s_in = reinterpret_cast<uint32_t*>(s_lhf + 2 * (a.nb + 1));
     if (OP == OP_BRACKET) {
-        stage.v = reinterpret_cast<T*>(s_in + ((a.nb + 2) & ~1));
-        stage.b = reinterpret_cast<uint16_t*>(stage.v + SEL_STAGE_CAP);
-        stage.base = reinterpret_cast<unsigned long long*>(stage.b + SEL_STAGE_CAP);
+        stage.v = reinterpret_cast<TC*>(s_in + ((a.nb + 2) & ~1));
+        stage.b = reinterpret_cast<uint16_t*>(stage.v + STAGE_CAP);
+        stage.base = reinterpret_cast<unsigned long long*>(stage.b + STAGE_CAP);
         stage.held = reinterpret_cast<int*>(stage.base + 1);
     }
 
@@ -321,14 +335,19 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
         // neighbouring points), so consecutive B points of a tile mostly fall into the same lag class of a lane's A point: the lane
         // keeps the running sum and count of its current class in registers and touches the LDS record -- two atomics -- only when
         // the class changes.  (Round 2 paid both atomics for every pair and the LDS array was busy for the whole kernel.)
-        T pend_v = (T)0;
+        TC pend_v = (TC)0;
         uint32_t pend_l = 0;
+        // the value a candidate is stored as: the pair's |dv| as classified, or (WIDE) the exact float64 difference with tile slot j
+        auto cand_value = [&](T abs_dv, int j) -> TC {
+            if constexpr (WIDE) return (TC)__builtin_fabs((double)pv - (double)s_bv[j]);
+            else return abs_dv;
+        };
         unsigned long long pend_m = 0;  // lanes with a pending candidate (wave-uniform scalar)
         // Candidates that find the staging buffer full go straight to the global candidate buffer, one global atomic per wave and
         // call.  (Values of a spatially correlated field cluster: all 262144 pairs of a tile -- 1024 neighbouring A points x 256 B
         // points -- can fall into a class's bracket at once, far more than the 8192 staging slots a tile may fill; round 2's "flag
         // an overflow and redo everything with plain passes" made the C5 input of SURVEY 8d five times slower than uniform noise.)
-        auto spill = [&](bool mine, T v, uint32_t l) {   // every lane of the wave calls this
+        auto spill = [&](bool mine, TC v, uint32_t l) {   // every lane of the wave calls this
             const unsigned long long ov = __builtin_amdgcn_ballot_w64(mine);
             if (!ov) return;
             const int lane = tid & 63;
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                    (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)base, leader);
             if (mine) {
                 const unsigned long long pos = base + (unsigned long long)__builtin_amdgcn_mbcnt_hi((uint32_t)(ov >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ov, 0u));
-                if ((long long)pos < a.cand_cap) { a.cand_v[pos] = v; a.cand_b[pos] = (uint16_t)l; }
+                if ((long long)pos < a.cand_cap) { cand_out[pos] = v; a.cand_b[pos] = (uint16_t)l; }
                 else a.cand_ctr[1] = 1ull;
             }
         };
@@ -353,9 +372,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 pos0 = __builtin_amdgcn_readlane(pos0, leader);
                 const bool has = (m >> lane) & 1ull;
                 const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (has && pos < SEL_STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
+                if (has && pos < STAGE_CAP) { stage.v[pos] = pend_v; stage.b[pos] = (uint16_t)pend_l; }
                 if (tally && has) atomicAdd(&s_in[pend_l], 1u);
-                if (__builtin_expect(pos0 + __popcll(m) > SEL_STAGE_CAP, 0)) spill(has && pos >= SEL_STAGE_CAP, pend_v, pend_l);   // (wave-uniform test)
+                if (__builtin_expect(pos0 + __popcll(m) > STAGE_CAP, 0)) spill(has && pos >= STAGE_CAP, pend_v, pend_l);   // (wave-uniform test)
                 pend_m = 0;
             }
         };
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 const bool sampled = OP == OP_HIST && a.sample;
                 const int jslot = sampled ? 4 * unit_sample_slot(wg, (int)((j0 - jb0) / PT)) : 0;
                 if (OP == OP_BRACKET)  // (starts with the barrier the tile reload needs); flush the staged candidates when half full
-                    stage.sync_and_flush_at(SEL_STAGE_CAP / 2, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+                    stage.sync_and_flush_at(STAGE_CAP / 2, cand_out, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
                 else
                     __syncthreads();
                 const int cnt = (int)((jb1 - j0) < PT ? (jb1 - j0) : PT);
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 __syncthreads();
                 if (!have_a && OP != OP_BRACKET) continue;   // (OP_BRACKET: every thread stays for the mid-tile flush barriers)
                 // OP_BRACKET, one pair: counters + staged candidate (every lane of the wave must reach the append)
-                auto bracket_pair = [&](bool ok, int l, T d) {
+                auto bracket_pair = [&](bool ok, int l, T d, int j) {
                     bool cand = false;
                     if (ok) {
                         const K key = key_abs(d);
@@ -446,8 +465,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             if (lane == leader) pos0 = atomicAdd(stage.held, __popcll(cm));
                             pos0 = __builtin_amdgcn_readlane(pos0, leader);
                             const int pos = pos0 + __popcll(cm & ((1ull << lane) - 1ull));
-                            if (cand && pos < SEL_STAGE_CAP) { stage.v[pos] = d; stage.b[pos] = (uint16_t)l; }
-                            if (pos0 + __popcll(cm) > SEL_STAGE_CAP) spill(cand && pos >= SEL_STAGE_CAP, d, (uint32_t)l);
+                            const TC dw = cand ? cand_value(d, j) : (TC)0;
+                            if (cand && pos < STAGE_CAP) { stage.v[pos] = dw; stage.b[pos] = (uint16_t)l; }
+                            if (pos0 + __popcll(cm) > STAGE_CAP) spill(cand && pos >= STAGE_CAP, dw, (uint32_t)l);
                         }
                     }
                 };
@@ -476,7 +496,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     T d = pv - s_bv[j];
                     d = d < 0 ? -d : d;
                     ok = ok && (l < nb) && (d == d);  // beyond the last edge (maxlag) / NaN values never form a pair
-                    if (OP == OP_BRACKET) { bracket_pair(ok, l, d); return; }
+                    if (OP == OP_BRACKET) { bracket_pair(ok, l, d, j); return; }
                     if (!ok) return;
                     if (OP == OP_SUMS_SQ) {
                         rec_add(l, (double)d * (double)d);
@@ -667,7 +687,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                     if (in != 0) {   // (wave-uniform: a fifth of the wave-pairs hold a candidate)
                                         if (__builtin_expect((in & pend_m) != 0, 0)) flush_pending(true);
                                         const unsigned long long take = in & ~pend_m;
-                                        pend_v = select_by_mask(pend_v, ad, take);
+                                        pend_v = select_by_mask(pend_v, cand_value(ad, j + u), take);
                                         pend_l = select_by_mask(pend_l, (uint32_t)run_l, take);
                                         pend_m |= take;
                                     }
@@ -675,7 +695,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 }
                                 if ((j & 28) == 28) flush_pending(true);   // every 32 pairs (a second candidate of a lane before that flushes at once)
                                 if ((j & 63) == 60 && j + 4 < PT)
-                                    stage.sync_and_flush_at(SEL_STAGE_CAP / 4, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+                                    stage.sync_and_flush_at(STAGE_CAP / 4, cand_out, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
                             }
                             continue;
                         }
@@ -737,7 +757,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                         // leave first, one LDS reservation for the wave, and the lane keeps the new one)
                                         if (__builtin_expect((in4[u] & pend_m) != 0, 0)) flush_pending();
                                         const unsigned long long take = in4[u] & ~pend_m;
-                                        pend_v = select_by_mask(pend_v, dv[u], take);
+                                        pend_v = select_by_mask(pend_v, cand_value(dv[u], js[u]), take);
                                         pend_l = select_by_mask(pend_l, (uint32_t)lc[u], take);
                                         pend_m |= take;
                                     }
@@ -747,7 +767,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 // the brackets of spatially correlated values hold a few per cent of the pairs, a whole tile's worth
                                 // would not fit (j and cnt are uniform over the workgroup: every thread meets this barrier)
                                 if ((j & 63) == 60 && j + 4 < jend)
-                                    stage.sync_and_flush_at(SEL_STAGE_CAP / 4, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+                                    stage.sync_and_flush_at(STAGE_CAP / 4, cand_out, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
                                 continue;
                             }
         #pragma unroll
@@ -757,7 +777,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                 const T d = dv[u];
                                 const bool ok = (PLAIN || (js[u] < cnt_m && js[u] > ia_rel && d == d)) && lu < nb && (!spread || u < SPREAD_SLOTS);   // (a trip = 4 pairs: the first SPREAD_SLOTS are the sampled ones)
                                 if (OP == OP_BRACKET) {
-                                    bracket_pair(ok, lu, d);
+                                    bracket_pair(ok, lu, d, js[u]);
                                 } else if (ok) {
                                     if (OP == OP_SUMS_SQ) {
                                         rec_add(lu, (double)d * (double)d);
@@ -827,7 +847,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                 if (c) atomicAdd(&a.hist2[(size_t)a.bin0 * SEL_RADIX + k], (unsigned long long)c);
             }
     } else if (OP == OP_BRACKET) {
-        stage.sync_and_flush_at(0, a.cand_v, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
+        stage.sync_and_flush_at(0, cand_out, a.cand_b, &a.cand_ctr[0], a.cand_cap, &a.cand_ctr[1]);
         for (int k = tid; k < nb; k += NT) {
             unsigned long long above = 0, below = 0, inside = 0;
             for (int q = 0; q < NCOPY; ++q) {
@@ -884,6 +904,9 @@ struct xdemhip_pairs {
     // the same pair set with the points of every block in Morton order (xdemhip_pairs_link_sorted; not owned): the counting pass
     // of the bracketed selection reads its points
     xdemhip_pairs* sorted = nullptr;
+    // a float32 copy of a float64 set whose values are all exactly float32 numbers (xdemhip_pairs_link_shadow; not owned): the
+    // bracketed exact-median route runs its passes there and takes float64 candidates (WIDE kernels)
+    xdemhip_pairs* shadow = nullptr;
     // small device blocks of xdemhip_pairs_medians, kept between calls (their hipMalloc / hipFree cost ~1 ms per call)
     unsigned char* sel_small = nullptr;
     size_t sel_small_bytes = 0;
@@ -896,17 +919,17 @@ namespace {
 
 constexpr int HIST_BINS_PER_SWEEP = 128;
 
-template <typename T> size_t lds_bytes(int nb, int op, int nbs) {
+template <typename T> size_t lds_bytes(int nb, int op, int nbs, bool wide = false) {
     size_t base = sizeof(double) * (2 * PT + nb + LUT_STEPS + 1) + 16 * (size_t)nb + sizeof(T) * PT + 8 + 4 * (size_t)(PT + nb + 4);
     if (op == OP_HIST) return base + (size_t)nbs * SEL_RADIX * 4;
     if (op == OP_BRACKET)
         return base + (size_t)(nb + 1) * NCOPY * 8 + 4 * (size_t)(nb + 1) * sizeof(typename KeyT<T>::type) + 4 * (size_t)(nb + 2) + 8 +
-               (size_t)SEL_STAGE_CAP * (sizeof(T) + 2) + 16;
+               (size_t)(wide ? SEL_STAGE_CAP / 2 : SEL_STAGE_CAP) * ((wide ? 8 : sizeof(T)) + 2) + 16;
     if (op == OP_SUCC) return base + (size_t)nb * sizeof(typename KeyT<T>::type);
     return base + (size_t)(nb + 1) * NCOPY * 12;
 }
 
-template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int first, int bin0, int nbs) {
+template <typename T, int OP, bool WIDE = false> int launch_pairs(xdemhip_pairs* P, int shift, int first, int bin0, int nbs) {
     xdemhip_ctx* ctx = P->ctx;
     constexpr int NT = (OP == OP_HIST || OP == OP_BRACKET) ? 1024 : 256;  // histograms: 16 waves share one 51 KB LDS table -> full occupancy
     PairArgs<T> a;
@@ -925,7 +948,7 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
     a.hist2 = P->hist2;
     a.has_nan = P->has_nan;
     a.khi = static_cast<const typename KeyT<T>::type*>(P->khi);
-    a.cnt3 = P->cnt3; a.cand_v = static_cast<T*>(P->cand_v); a.cand_b = P->cand_b; a.cand_ctr = P->cand_ctr; a.cand_cap = P->cand_cap;
+    a.cnt3 = P->cnt3; a.cand_v = P->cand_v; a.cand_b = P->cand_b; a.cand_ctr = P->cand_ctr; a.cand_cap = P->cand_cap;
     a.runs = 0;
     if (OP == OP_BRACKET && P->sorted && ctx->vario_runs != 0) {
         // same blocks, same offsets, other slot order: counts and candidates are the same multiset
@@ -935,15 +958,15 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
         a.a_xy = S->a_xy; a.b_xy = S->b_xy;
         a.runs = 1;
     }
-    const size_t lds = lds_bytes<T>(P->nb, OP, (OP == OP_HIST && P->dual) ? 2 * nbs : nbs);
+    const size_t lds = lds_bytes<T>(P->nb, OP, (OP == OP_HIST && P->dual) ? 2 * nbs : nbs, WIDE);
     const int64_t n_wg = (NT == 1024) ? P->n_wg_big : P->n_wg;
     // HIP dispatches carry the TOTAL work-item count of a dimension in 32 bits (a larger grid x block product is silently
     // truncated): a pass over more workgroups than 2^31 / NT goes out as several launches, each told where it starts.
     const int64_t per_launch = ctx->pairs_launch_cap > 0 ? (int64_t)ctx->pairs_launch_cap : ((int64_t)1 << 31) / NT;
     const bool grid = P->grid && ctx->vario_grid != 0;
-    if (grid) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT, true>, lds)) return rc; }
-    else if (P->lut) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT>, lds)) return rc; }
-    else { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, false, NT>, lds)) return rc; }
+    if (grid) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT, true, WIDE>, lds)) return rc; }
+    else if (P->lut) { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, true, NT, false, WIDE>, lds)) return rc; }
+    else { if (int rc = set_big_lds(ctx, pairs_kernel<T, OP, false, NT, false, WIDE>, lds)) return rc; }
     for (int64_t w0 = 0; w0 < n_wg; w0 += per_launch) {
         const int64_t nw = (n_wg - w0) < per_launch ? (n_wg - w0) : per_launch;
         a.wg_base = w0;
@@ -951,9 +974,9 @@ template <typename T, int OP> int launch_pairs(xdemhip_pairs* P, int shift, int 
         // sampled digit passes: resident workgroups walking over the units (see the kernel); everything else one unit each
         const int64_t resident = (int64_t)ctx->num_cu * (lds > 80 * 1024 ? 1 : 2);
         const unsigned nlaunch = (unsigned)((OP == OP_HIST && P->sample && nw > resident) ? resident : nw);
-        if (grid) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT, true>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
-        else if (P->lut) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
+        if (grid) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT, true, WIDE>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
+        else if (P->lut) hipLaunchKernelGGL((pairs_kernel<T, OP, true, NT, false, WIDE>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((pairs_kernel<T, OP, false, NT, false, WIDE>), dim3(nlaunch), dim3(NT), lds, ctx->stream, a);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     return XDEMHIP_OK;
@@ -1463,9 +1486,15 @@ int pairs_medians_plain(xdemhip_pairs* P, SelState<typename KeyT<T>::type>* d_st
 
 constexpr int64_t PAIRS_BRACKET_MIN = (int64_t)4000000000ll;  // pairs; below this the sample units are too few
 
-template <typename T>
-int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
+// WIDE (T = float): `P` is the float32 shadow of a float64 set (xdemhip_pairs_link_shadow) -- sampled passes and the counting pass
+// in float32, candidates and their selection in float64 (see pairs_kernel); returns with *answered = false instead of taking the
+// plain digit passes when the bracketed route does not apply or fails (the caller then runs the float64 set's own route).
+template <typename T, bool WIDE = false>
+int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians, bool* answered = nullptr) {
     typedef typename KeyT<T>::type K;
+    typedef typename CandT<T, WIDE>::type TC;      // candidate values ...
+    typedef typename KeyT<TC>::type KC;            // ... and their keys
+    if (answered) *answered = false;
     xdemhip_ctx* ctx = P->ctx;
     const int nb = P->nb;
     // small device block: selection states | klo | khi | given | counters[3 nb] | candidate counter, overflow
@@ -1550,7 +1579,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
                     if (P->cand_v) (void)hipFree(P->cand_v);
                     if (P->cand_b) (void)hipFree(P->cand_b);
                     P->cand_v = nullptr; P->cand_b = nullptr; P->cand_cap = 0;
-                    if (hipMalloc(&P->cand_v, (size_t)need * sizeof(T)) != hipSuccess ||
+                    if (hipMalloc(&P->cand_v, (size_t)need * sizeof(TC)) != hipSuccess ||
                         hipMalloc(reinterpret_cast<void**>(&P->cand_b), (size_t)need * 2) != hipSuccess) {
                         (void)hipGetLastError();
                         got = 0;
@@ -1572,7 +1601,7 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
         }
         phase("candidate buffers");
         if (bracket) {
-            K* d_klo = reinterpret_cast<K*>(d_small + off_klo);
+            KC* d_klo = reinterpret_cast<KC*>(d_small + off_klo);   // (8-byte slots: rebase origins of the CANDIDATE keys)
             K* d_khi = reinterpret_cast<K*>(d_small + off_khi);
             uint64_t* d_given = reinterpret_cast<uint64_t*>(d_small + off_given);
             P->cnt3 = reinterpret_cast<unsigned long long*>(d_small + off_cnt);
@@ -1583,22 +1612,39 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
             if (e == hipSuccess) e = hipMemsetAsync(d_small + off_cnt, 0, 24 * (size_t)nb + 16, ctx->stream);
             // candidate keys are rebased for their selection (select_run.h, hist_pass_kernel): low ends and the common shift
             // in key_of()'s key space (|dv| >= 0: key = bits | top bit; the pair passes use bits << 1)
-            const K top = (K)1 << (8 * sizeof(K) - 1);
-            std::vector<K> rb_lo(nb);
-            K widest = 0;
+            const KC top = (KC)1 << (8 * sizeof(KC) - 1);
+            std::vector<KC> rb_lo(nb);
+            KC widest = 0;
             for (int k = 0; k < nb; ++k) {
-                rb_lo[k] = (K)((klo[k] >> 1) | top);
-                const K r = khi[k] >= klo[k] ? (K)((khi[k] >> 1) - (klo[k] >> 1)) : (K)0;
-                widest = r > widest ? r : widest;
+                if constexpr (WIDE) {
+                    // candidates are the exact differences d with fl32(d) in [L, H] (L, H the float32 ends, raw bits klo >> 1 / khi >> 1):
+                    // every such d lies in (pred(L), succ(H)) -- the origin and the range of the rebased float64 keys
+                    const uint32_t lb = (uint32_t)(klo[k] >> 1), hb = (uint32_t)(khi[k] >> 1);
+                    const uint32_t lp = lb > 0 ? lb - 1 : 0u, hs = hb < 0x7f800000u ? hb + 1 : 0x7f800000u;
+                    float lf, hf;
+                    memcpy(&lf, &lp, 4);
+                    memcpy(&hf, &hs, 4);
+                    const double ld = (double)lf, hd = (double)hf;
+                    uint64_t lk, hk;
+                    memcpy(&lk, &ld, 8);
+                    memcpy(&hk, &hd, 8);
+                    rb_lo[k] = (KC)(lk | top);
+                    const KC r = (khi[k] >= klo[k] && hk >= lk) ? (KC)(hk - lk) : (KC)0;
+                    widest = r > widest ? r : widest;
+                } else {
+                    rb_lo[k] = (KC)((klo[k] >> 1) | top);
+                    const KC r = khi[k] >= klo[k] ? (KC)((khi[k] >> 1) - (klo[k] >> 1)) : (KC)0;
+                    widest = r > widest ? r : widest;
+                }
             }
             const uint32_t rbs = rebase_shift_of(widest);
             uint32_t* d_rbs = reinterpret_cast<uint32_t*>(d_small + off_rbs);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_klo, rb_lo.data(), sizeof(K) * nb, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_klo, rb_lo.data(), sizeof(KC) * nb, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(d_rbs, &rbs, 4, hipMemcpyHostToDevice, ctx->stream);
             if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket setup failed"); }
             if (P->n_wg_big > 0) {
                 XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-                rc = launch_pairs<T, OP_BRACKET>(P, 0, 0, 0, 0);
+                rc = launch_pairs<T, OP_BRACKET, WIDE>(P, 0, 0, 0, 0);
                 (void)hipEventRecord(ctx->ev_stop, ctx->stream);
                 ctx->timed = rc == XDEMHIP_OK;
             }
@@ -1649,10 +1695,10 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
             if (ok) {
                 e = hipMemcpyAsync(d_given, given.data(), 8 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream);
                 if (e != hipSuccess) { cleanup(); return xd_fail(ctx, XDEMHIP_EHIP, "bracket ranks upload failed"); }
-                std::vector<SelResult<K>> res;
-                rc = select_enqueue<T>(ctx, static_cast<const T*>(P->cand_v), P->cand_b, (int64_t)ctr[0], (int64_t)ctr[0], nullptr, nb,
-                                       static_cast<unsigned char*>(scratch), SEL_GIVEN, d_given, 0, true, d_klo, d_rbs);
-                if (rc == XDEMHIP_OK) rc = select_fetch<T>(ctx, static_cast<unsigned char*>(scratch), nb, res);
+                std::vector<SelResult<KC>> res;
+                rc = select_enqueue<TC>(ctx, static_cast<const TC*>(P->cand_v), P->cand_b, (int64_t)ctr[0], (int64_t)ctr[0], nullptr, nb,
+                                        static_cast<unsigned char*>(scratch), SEL_GIVEN, d_given, 0, true, d_klo, d_rbs);
+                if (rc == XDEMHIP_OK) rc = select_fetch<TC>(ctx, static_cast<unsigned char*>(scratch), nb, res);
                 if (rc) { cleanup(); return rc; }
                 phase("selection among candidates");
                 for (int k = 0; k < nb; ++k) {
@@ -1660,17 +1706,23 @@ int pairs_medians_typed(xdemhip_pairs* P, int64_t* counts, double* medians) {
                     if (cnt[k] == 0) { medians[k] = NAN; continue; }
                     res[k].st.count = cnt[k];
                     res[k].st.n_le += cnt[nb + k];
-                    res[k].st.prefix = (K)((K)(res[k].st.prefix >> rbs) + rb_lo[k]);  // back from the rebased keys
-                    if (res[k].succ != ~(uint64_t)0) res[k].succ = (uint64_t)(K)((K)((K)res[k].succ >> rbs) + rb_lo[k]);
-                    medians[k] = median_from<T>(res[k]);
+                    res[k].st.prefix = (KC)((KC)(res[k].st.prefix >> rbs) + rb_lo[k]);  // back from the rebased keys
+                    if (res[k].succ != ~(uint64_t)0) res[k].succ = (uint64_t)(KC)((KC)((KC)res[k].succ >> rbs) + rb_lo[k]);
+                    medians[k] = median_from<TC>(res[k]);
                 }
                 done = true;
             }
         }
     }
+    if (WIDE) {   // (the shadow answers through the bracketed route or not at all)
+        cleanup();
+        if (answered) *answered = done;
+        return rc;
+    }
     if (!done) { rc = pairs_medians_plain<T>(P, d_st, counts, medians); phase("plain digit passes"); }
     cleanup();
     phase("cleanup");
+    if (answered) *answered = true;
     return rc;
 }
 
@@ -1684,7 +1736,25 @@ int xdemhip_pairs_medians(xdemhip_pairs* P, int64_t* counts, double* medians) {
     xdemhip_ctx* ctx = P->ctx;
     if (!counts || !medians) return xd_fail(ctx, XDEMHIP_EINVAL, "bad argument");
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (P->val_dtype == XDEMHIP_F64 && P->shadow && P->shadow->val_dtype == XDEMHIP_F32 && !ctx->allreduce) {
+        // float64 differences of float32 values (option "vario_diff" = 1 on float32 inputs): the float32 shadow's passes, float64 candidates
+        bool answered = false;
+        const int rc = pairs_medians_typed<float, true>(P->shadow, counts, medians, &answered);
+        if (rc != XDEMHIP_OK || answered) return rc;
+    }
     return P->val_dtype == XDEMHIP_F32 ? pairs_medians_typed<float>(P, counts, medians) : pairs_medians_typed<double>(P, counts, medians);
+}
+
+int xdemhip_pairs_link_shadow(xdemhip_pairs* P, xdemhip_pairs* shadow) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (shadow) {
+        if (shadow->ctx != ctx || P->val_dtype != XDEMHIP_F64 || shadow->val_dtype != XDEMHIP_F32 || shadow->nblk != P->nblk || shadow->nb != P->nb ||
+            shadow->pdist != P->pdist || shadow->h_a_off != P->h_a_off || shadow->h_b_off != P->h_b_off)
+            return xd_fail(ctx, XDEMHIP_EINVAL, "pairs_link_shadow: a float64 set and a float32 set of the same blocks and edges are required");
+    }
+    P->shadow = shadow;
+    return XDEMHIP_OK;
 }
 
 }  // extern "C"

@@ -74,8 +74,11 @@ class PairSet:
         self.ctx = ctx or _lib.default_context()
         self.ctx.adopt(self)
         vdt = np.float64 if any(np.asarray(b[2]).dtype == np.float64 for b in blocks) else np.float32
+        # option "vario_diff" = 1: |dv| in float64 whatever the value dtype (values are widened).  Float32 inputs then also get a
+        # float32 SHADOW of the set for the exact-median route (below): same medians, the passes at float32 speed
+        widened = bool(self.ctx.options.get("vario_diff")) and vdt == np.float32
         if self.ctx.options.get("vario_diff"):
-            vdt = np.float64  # option "vario_diff" = 1: |dv| in float64 whatever the value dtype (values are widened)
+            vdt = np.float64
         # TWO device copies of the pair set (same pairs, different slot order):
         #  * `handle` -- points in MORTON ORDER within each block (neighbouring slots = neighbouring points) for the sum passes
         #    (Matheron / Cressie): the pair kernels accumulate run-length, a lane keeps the sum of its current lag class in
@@ -94,7 +97,7 @@ class PairSet:
         self.vdtype = np.dtype(vdt)
         self.key_bits = 32 if vdt == np.float32 else 64
 
-        def create(bl):
+        def create(bl, vdt=vdt):
             keep = [off(0), cat(bl, 0, np.float64), cat(bl, 1, np.float64), cat(bl, 2, vdt)]
             if not pd:
                 keep += [off(3), cat(bl, 3, np.float64), cat(bl, 4, np.float64), cat(bl, 5, vdt)]
@@ -107,6 +110,7 @@ class PairSet:
             return h, int(n_pairs.value)
 
         self.handle = self.handle_sel = None
+        self.shadow = self.shadow_sel = None
         self.handle_sel, self.n_pairs = create(blocks)
         if self.ctx.options.get("vario_sort", 1):
             try:
@@ -119,6 +123,22 @@ class PairSet:
             self.ctx.check(self.ctx._L.xdemhip_pairs_link_sorted(self.handle_sel, self.handle))
         else:
             self.handle = self.handle_sel
+        # float64 differences of float32 values, large sets (the bracketed route's domain, csrc/variogram.hip: PAIRS_BRACKET_MIN):
+        # float32 copies of both orders, linked as the shadow of the float64 selection set (xdemhip_pairs_link_shadow)
+        if widened and self.n_pairs >= 4_000_000_000:
+            try:
+                self.ctx.set_option("vario_diff", 0)   # (the library itself widens float32 values under the option: not the shadow's)
+                try:
+                    self.shadow_sel, _ = create(blocks, np.float32)
+                    if self.ctx.options.get("vario_sort", 1):
+                        self.shadow, _ = create([_morton_sorted_block(b) for b in blocks], np.float32)
+                        self.ctx.check(self.ctx._L.xdemhip_pairs_link_sorted(self.shadow_sel, self.shadow))
+                finally:
+                    self.ctx.set_option("vario_diff", 1)
+                self.ctx.check(self.ctx._L.xdemhip_pairs_link_shadow(self.handle_sel, self.shadow_sel))
+            except Exception:
+                self.close()
+                raise
 
     def sums(self, kind: int):
         s = np.zeros(self.nb, dtype=np.float64)
@@ -146,6 +166,15 @@ class PairSet:
         if not getattr(self.ctx, "handle", None):   # (the context is gone and took the sets with it)
             self.handle = self.handle_sel = None
             return
+        sh, shs = getattr(self, "shadow", None), getattr(self, "shadow_sel", None)
+        if shs:
+            if hs:
+                self.ctx._L.xdemhip_pairs_link_shadow(hs, None)
+            if sh:
+                self.ctx._L.xdemhip_pairs_link_sorted(shs, None)
+                self.ctx._L.xdemhip_pairs_destroy(sh)
+            self.ctx._L.xdemhip_pairs_destroy(shs)
+        self.shadow = self.shadow_sel = None
         if hs and h and hs.value != h.value:
             self.ctx._L.xdemhip_pairs_link_sorted(hs, None)
         if h:
