@@ -688,6 +688,16 @@ def test_lean_route_equals_plain_route_at_scale():
             res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
             assert plan.route_counts()[name] == 4, (name, plan.route_counts())   # every step answered by the route under test
             plan.close()
+        # round 5: the one-pass step selects among the bin candidates one workgroup per bin on per-bin segments (option "nk_binseg",
+        # default on); the digit passes over all candidate slots (round 4) stay behind the option
+        ctx.set_option("selection", 0)
+        ctx.set_option("nk_fused", 1)
+        ctx.set_option("nk_binseg", 0)
+        plan = coreg.NKPlan(ref, tba, None, ctx)
+        res["onepass, digit passes"] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
+        assert plan.route_counts()["onepass"] == 4, plan.route_counts()
+        plan.close()
+        ctx.set_option("nk_binseg", 1)
         # the one-pass step with its sample brackets at a fixed fraction of the rule (option "nk_narrow"; default: adaptive):
         # full width answers every step itself; a quarter may miss and hand a step to the two-pass route -- exact either way
         ctx.set_option("selection", 0)
@@ -701,7 +711,7 @@ def test_lean_route_equals_plain_route_at_scale():
             print(f"nk_narrow = {k}: routes {rc}")
             plan.close()
         ctx.set_option("nk_narrow", -1)
-        for name in ("onepass", "twopass", "narrow0", "narrow1", "narrow2"):
+        for name in ("onepass", "onepass, digit passes", "twopass", "narrow0", "narrow1", "narrow2"):
             for a, b in zip(res[name], res["plain"]):
                 assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], name
                 assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), name

@@ -24,6 +24,8 @@ ref, tba = bench._c3_pair(dev, m)
 ctx = _lib.default_context(0)
 if os.environ.get("NK_NARROW"):   # sample brackets of the one-pass step: -1 adaptive (default), 0 / 1 / 2 fixed
     ctx.set_option("nk_narrow", int(os.environ["NK_NARROW"]))
+if os.environ.get("XDEM_NK_BINSEG"):   # bin candidates: 1 per-bin segments + one workgroup per bin (default), 0 digit passes over all slots
+    ctx.set_option("nk_binseg", int(os.environ["XDEM_NK_BINSEG"]))
 plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
 plan.step(0.0, 0.0, (10.0, 10.0), 72)
 for i in range(k):

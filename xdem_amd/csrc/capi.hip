@@ -342,6 +342,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->nk_fused = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "nk_binseg") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_binseg: 0 or 1");
+        ctx->nk_binseg = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "nk_ext") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_ext: 0 or 1");
         ctx->nk_ext = value;

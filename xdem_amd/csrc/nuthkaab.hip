@@ -1514,6 +1514,294 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_resolve_kernel(T* __restrict_
         if (h[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[k]), (unsigned long long)h[k]);
 }
 
+
+// ---- round 5: the bin candidates partitioned by bin; ONE workgroup per bin selects its exact median ----------------------------
+// After nk_resolve_kernel the exact selection among the candidates of the 72 bins used to run as select_enqueue: three more digit
+// passes over ALL candidate slots (the resolved-away ones left as NaN) with the whole [72][256] LDS table zeroed and flushed by every
+// workgroup of every pass, an advance kernel behind each, the successor pass -- 10 launches, ~150 us of the step.  The fused kernel
+// already counts the candidates per bin (cls[2][b]), so the resolve kernel can write the kept y values INTO PER-BIN SEGMENTS
+// (exclusive scan of those counts; a workgroup reserves its places with one global atomic per bin and round) and histogram them on
+// the way into 256 VALUE buckets of the bin's bracket: bucket(y) = floor((y - lo_b) * 256 / (hi_b - lo_b)) in float64, a monotone
+// map.  (Digits of the float KEYS would not do: the bin medians of y lie around zero, a bracket that straddles zero spans every
+// binade of the key space, and most of a bin would sit in two or three leading-digit values.)  One workgroup per bin then reads its
+// segment ONCE: the histogram names the bucket that holds the wanted rank, the few hundred values in it go to LDS as keys, and the
+// exact order statistic and its successor are settled there by the usual digit passes.  Same integers and the same order of keys
+// as on the other routes: results are identical bit for bit.
+constexpr int BINSEG_U = 16;            // values per thread and round of the scatter (one reservation per bin, workgroup and round)
+constexpr int BINSEG_CTR_STRIDE = 16;   // the per-bin place counters sit one 128-byte line apart (same-line atomics serialise)
+struct BinsegMap { double lo, scale; };
+template <typename T, typename K> __device__ __forceinline__ BinsegMap binseg_map(K klo, K khi) {
+    BinsegMap m;
+    m.lo = (double)val_of(klo);
+    const double w = (double)val_of(khi) - m.lo;
+    m.scale = w > 0.0 ? 256.0 / w : 0.0;
+    return m;
+}
+template <typename T> __device__ __forceinline__ int binseg_bucket(T y, const BinsegMap& m) {   // y inside [lo, hi]
+    const double t = ((double)y - m.lo) * m.scale;   // (monotone in y; >= 0)
+    const int d = (int)t;
+    return d > 255 ? 255 : (d < 0 ? 0 : d);
+}
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_resolve_scatter_kernel(const T* __restrict__ c_v /* dh */, const T* __restrict__ c_st,
+                                                                          const uint16_t* __restrict__ c_b, int64_t cap, const unsigned long long* n_dev,
+                                                                          const T* vshift_p, int nb, const typename KeyT<T>::type* __restrict__ klo,
+                                                                          const typename KeyT<T>::type* __restrict__ khi, const uint64_t* __restrict__ cls /* [3][nb] */,
+                                                                          uint64_t* res /* [2][nb] */, unsigned long long* seg_ctr /* [nb], zeroed */,
+                                                                          T* __restrict__ seg_v, int64_t seg_cap, unsigned long long* ctr /* [2] overflow */) {
+    typedef typename KeyT<T>::type K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
+    unsigned long long* off = reinterpret_cast<unsigned long long*>(fz_smem);   // [nb] first slot of the bin's segment
+    unsigned long long* gbase = off + nb;                                       // [nb] this round's places inside the segment
+    unsigned long long* room = gbase + nb;                                      // [nb] slots of the segment
+    K* lo = reinterpret_cast<K*>(room + nb);
+    K* hi = lo + nb;
+    uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);   // [2][nb] below / inside (this workgroup)
+    uint32_t* lcnt = c + 2 * nb;                           // [nb] kept values of the round
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        lo[k] = klo[k]; hi[k] = khi[k]; lcnt[k] = 0u; room[k] = cls[2 * nb + k];
+    }
+    for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x) c[k] = 0u;
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        for (int k = 0; k < nb; ++k) { off[k] = acc; acc += cls[2 * nb + k]; }
+    }
+    __syncthreads();
+    const unsigned long long m = *n_dev;
+    const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
+    const T vshift = *vshift_p;
+    constexpr int U = BINSEG_U;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x * U;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x * U; base < n; base += step) {   // (uniform over the workgroup)
+        T dv[U], sv[U];
+        uint16_t bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {   // (all of a round's loads first)
+            const int64_t p = base + (int64_t)u * blockDim.x + threadIdx.x;
+            const bool have = p < n;
+            dv[u] = have ? c_v[p] : (T)NAN;
+            sv[u] = have ? c_st[p] : (T)1;
+            bv[u] = have ? c_b[p] : (uint16_t)0xFFFF;
+        }
+        T yk[U];
+        int bk[U];
+        uint32_t li[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bk[u] = -1;
+            li[u] = 0u;
+            const int b = (int)bv[u];
+            const T y = t_div(t_sub(dv[u], vshift), sv[u]);
+            yk[u] = y;
+            if (y == y && b < nb) {
+                const K key = key_of(y);
+                if (key < lo[b]) atomicAdd(&c[b], 1u);
+                else if (key <= hi[b]) {
+                    atomicAdd(&c[nb + b], 1u);
+                    li[u] = atomicAdd(&lcnt[b], 1u);
+                    bk[u] = b;
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+            const uint32_t cnt = lcnt[k];
+            gbase[k] = cnt ? atomicAdd(&seg_ctr[(size_t)k * BINSEG_CTR_STRIDE], (unsigned long long)cnt) : 0ull;   // (one cache line per bin's counter)
+            lcnt[k] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (bk[u] >= 0) {
+                const unsigned long long q = gbase[bk[u]] + li[u];
+                const unsigned long long pos = off[bk[u]] + q;
+                if (q < room[bk[u]] && (int64_t)pos < seg_cap) seg_v[pos] = yk[u];
+                else ctr[2] = 1ull;   // (cannot happen for consistent counters: the step then takes the two-pass route)
+            }
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x)
+        if (c[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&res[k]), (unsigned long long)c[k]);
+}
+
+constexpr int BINSEL_COPIES = 8;
+constexpr int BINSEL_KEY_BYTES = 96 * 1024;   // keys of the leading digit's group, held in LDS
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_bin_select_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls /* [3][nb] */,
+                                                                     const uint64_t* __restrict__ res /* [2][nb] */, const unsigned long long* seg_ctr, int nb,
+                                                                     const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
+                                                                     const uint32_t* rbs_p,
+                                                                     SelState<typename KeyT<T>::type>* st_out, uint64_t* succ_out, uint64_t* cnt_out /* [3][nb] */,
+                                                                     unsigned long long* ctr /* [2] overflow, [3] miss */) {
+    typedef typename KeyT<T>::type K;
+    constexpr int P = KeyT<T>::passes;
+    constexpr int CAPK = BINSEL_KEY_BYTES / (int)sizeof(K);
+    extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
+    K* keys = reinterpret_cast<K*>(fz_smem);                                      // [CAPK]
+    uint32_t* h = reinterpret_cast<uint32_t*>(keys + CAPK);                       // [BINSEL_COPIES][257]
+    unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(h + BINSEL_COPIES * (SEL_RADIX + 1) + ((BINSEL_COPIES * (SEL_RADIX + 1)) & 1));   // [256]
+    unsigned long long* s_pick = s_tot + SEL_RADIX;                               // digit, elements below it, elements in it
+    unsigned long long* s_off = s_pick + 4;
+    K* s_min = reinterpret_cast<K*>(s_off + 1);
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_off + 2);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const uint64_t total = cls[b] + cls[nb + b] + cls[2 * nb + b], lt = cls[nb + b] + res[b], in = res[nb + b];
+    if (tid == 0) {
+        cnt_out[b] = total; cnt_out[nb + b] = lt; cnt_out[2 * nb + b] = in;
+        unsigned long long acc = 0;
+        for (int k = 0; k < b; ++k) acc += cls[2 * nb + k];
+        *s_off = acc;
+        *s_min = ~(K)0;
+        *s_cnt = 0u;
+    }
+    SelState<K> s;
+    s.prefix = 0; s.rank = 0; s.count = 0; s.n_le = 0; s.group = 0;
+    bool run = total != 0;
+    if (run) {   // (the rule of bracket_given_kernel)
+        const uint64_t k = (total - 1) / 2, need = (total & 1) ? k : k + 1;
+        if (lt > k || need - lt >= in) { run = false; if (tid == 0) ctr[3] = 1ull; }
+        else { s.rank = k - lt; s.count = in; s.group = in; }
+        if (run && seg_ctr[(size_t)b * BINSEG_CTR_STRIDE] != in) { run = false; if (tid == 0) ctr[2] = 1ull; }   // (the segment does not hold what the counters say)
+    }
+    // the leading digit from the histogram the resolve kernel filled (one wave: lane l owns buckets 4 l .. 4 l + 3)
+    auto pick = [&](auto count_of) {   // every thread of the FIRST wave calls it; the result lands in s_pick
+        unsigned long long cq[4], mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { cq[q] = count_of(4 * lane + q); mine += cq[q]; }
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const unsigned long long excl = incl - mine;
+        if (s.rank >= excl && s.rank < incl) {   // (exactly one lane for a consistent histogram)
+            unsigned long long cum = excl;
+            int q = 0;
+            if (cum + cq[0] <= s.rank) { cum += cq[0]; q = 1;
+                if (cum + cq[1] <= s.rank) { cum += cq[1]; q = 2;
+                    if (cum + cq[2] <= s.rank) { cum += cq[2]; q = 3; } } }
+            s_pick[0] = (unsigned long long)(4 * lane + q);
+            s_pick[1] = cum;
+            s_pick[2] = q == 0 ? cq[0] : (q == 1 ? cq[1] : (q == 2 ? cq[2] : cq[3]));
+        }
+    };
+    __syncthreads();
+    if (!run) {   // (uniform over the workgroup)
+        if (tid == 0) { s.count = 0; st_out[b] = s; succ_out[b] = ~(uint64_t)0; }
+        return;
+    }
+    const T* v = seg_v + *s_off;
+    const int64_t n = (int64_t)in;
+    const K lo = klo[b];
+    const BinsegMap mp = binseg_map<T, K>(lo, khi[b]);   // 256 value buckets over the bin's bracket
+    const int rbs = (int)*rbs_p;                         // the rebase the host expects the state in
+    uint32_t* hc = h + (tid & (BINSEL_COPIES - 1)) * (SEL_RADIX + 1);
+    constexpr int U = 8;
+    // first read of the segment: how many values per bucket -> the bucket that holds the wanted rank
+    for (int k = tid; k < BINSEL_COPIES * (SEL_RADIX + 1); k += blockDim.x) h[k] = 0u;
+    __syncthreads();
+    for (int64_t i0 = tid; i0 < n; i0 += (int64_t)blockDim.x * U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * blockDim.x;
+            x[u] = i < n ? v[i] : (T)NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (x[u] == x[u]) atomicAdd(&hc[binseg_bucket<T>(x[u], mp)], 1u);
+    }
+    __syncthreads();
+    if (tid < SEL_RADIX) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int q = 0; q < BINSEL_COPIES; ++q) t += h[q * (SEL_RADIX + 1) + tid];
+        s_tot[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 64) pick([&](int d) { return s_tot[d]; });
+    __syncthreads();
+    if (s_pick[2] > (unsigned long long)CAPK) {   // (a bucket beyond the LDS buffer -- ties en masse: the two-pass route takes the step)
+        if (tid == 0) { ctr[2] = 1ull; s.count = 0; st_out[b] = s; succ_out[b] = ~(uint64_t)0; }
+        return;
+    }
+    const int d1 = (int)s_pick[0];
+    s.prefix = 0;
+    s.n_le = s_pick[1];
+    s.rank -= s_pick[1];
+    s.group = s_pick[2];
+    // second read (from the L2): keys of the chosen bucket's values into LDS, the smallest key of the buckets above on the way
+    K mn = ~(K)0;
+    __syncthreads();
+    for (int64_t i0 = tid; i0 < n; i0 += (int64_t)blockDim.x * U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * blockDim.x;
+            x[u] = i < n ? v[i] : (T)NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (x[u] != x[u]) continue;
+            const K key = key_of(x[u]);
+            const int d = binseg_bucket<T>(x[u], mp);
+            if (d == d1) {
+                const uint32_t pos = atomicAdd(s_cnt, 1u);
+                if (pos < (uint32_t)CAPK) keys[pos] = key;
+            } else if (d > d1 && key < mn) {
+                mn = key;
+            }
+        }
+    }
+    __syncthreads();
+    const int g = (int)(*s_cnt < (uint32_t)CAPK ? *s_cnt : (uint32_t)CAPK);   // (= s.group)
+    for (int p = 0; p < P; ++p) {   // exact selection among the bucket's keys (a few hundred, in LDS)
+        const int shift = 8 * (P - 1 - p);
+        for (int k = tid; k < BINSEL_COPIES * (SEL_RADIX + 1); k += blockDim.x) h[k] = 0u;
+        __syncthreads();
+        const K himask = p == 0 ? (K)0 : (K)(~(K)0 << (shift + 8));
+        for (int i = tid; i < g; i += blockDim.x) {
+            const K key = keys[i];
+            if ((key & himask) == s.prefix) atomicAdd(&hc[(int)((key >> shift) & 0xFF)], 1u);
+        }
+        __syncthreads();
+        if (tid < SEL_RADIX) {
+            unsigned long long t = 0;
+#pragma unroll
+            for (int q = 0; q < BINSEL_COPIES; ++q) t += h[q * (SEL_RADIX + 1) + tid];
+            s_tot[tid] = t;
+        }
+        __syncthreads();
+        if (tid < 64) pick([&](int d) { return s_tot[d]; });
+        __syncthreads();
+        s.prefix |= (K)s_pick[0] << shift;
+        s.n_le += s_pick[1];
+        s.rank -= s_pick[1];
+        s.group = s_pick[2];
+        __syncthreads();
+    }
+    s.n_le += s.group;   // every digit fixed: group = the selected key's duplicates
+    // successor: the smallest key above the selected one -- inside its bucket (LDS) or, failing that, the smallest key of the buckets
+    // above (collected while reading the segment)
+    for (int i = tid; i < g; i += blockDim.x) {
+        const K key = keys[i];
+        if (key > s.prefix && key < mn) mn = key;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const K t = k_shfl_down(mn, o);
+        mn = t < mn ? t : mn;
+    }
+    if (lane == 0 && mn != ~(K)0) k_atomic_min(s_min, mn);
+    __syncthreads();
+    if (tid == 0) {
+        // (handed back in the rebase of the other routes: offset from the bin's low end << rbs)
+        s.prefix = (K)((K)(s.prefix - lo) << rbs);
+        st_out[b] = s;
+        succ_out[b] = *s_min == ~(K)0 ? ~(uint64_t)0 : (uint64_t)(K)((K)(*s_min - lo) << rbs);
+    }
+}
+
 // every small result of a step gathered into one block (one device-to-host copy instead of ten)
 struct FzPack { const unsigned char* src[12]; uint32_t bytes[12]; uint32_t off[12]; int n; unsigned char* dst; };
 static __global__ __launch_bounds__(256) void nk_fz_pack_kernel(FzPack a) {
@@ -1991,7 +2279,24 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if (rc) return rc;
     hipLaunchKernelGGL((nk_fz_vshift_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, cnt_d, d_st, reinterpret_cast<const uint64_t*>(scratch + off_succ(1)),
                        klo_d, rbs_d, ctr, scratch + OFF_INFO);
-    // 6. the bin candidates with the exact vshift -> counts + first digit's histogram, exact medians among those inside the brackets
+    // 6. the bin candidates with the exact vshift -> counts, exact medians among those inside the brackets
+    const bool binseg = ctx->nk_binseg != 0 && (int64_t)P->nbuf * P->W >= ws->c_cap;
+    if (binseg) {
+        // round 5: kept values into per-bin segments (in the y raster, which this route does not use), one workgroup per bin selects
+        unsigned long long* seg_ctr = reinterpret_cast<unsigned long long*>(fz + 24 + 11 * nbm);   // [nb] x BINSEG_CTR_STRIDE words
+        const size_t lds = (size_t)nb * (3 * 8 + 2 * sizeof(K) + 3 * 4) + 16;
+        hipLaunchKernelGGL((nk_resolve_scatter_kernel<T>), dim3(grid_for(ctx, n / 16 + 1, HIST_THREADS * BINSEG_U, 2)), dim3(HIST_THREADS), lds, ctx->stream,
+                           static_cast<const T*>(ws->c_vals), static_cast<const T*>(P->c_st), ws->c_bins, ws->c_cap, ctr + 5,
+                           reinterpret_cast<const T*>(scratch + OFF_INFO), nb, klo_y, khi_y, cls_y, res_y, seg_ctr, static_cast<T*>(P->y),
+                           (int64_t)P->nbuf * P->W, ctr);
+        const size_t lds2 = (size_t)BINSEL_KEY_BYTES + (size_t)(BINSEL_COPIES * (SEL_RADIX + 1) + 1) * 4 + (size_t)(SEL_RADIX + 8) * 8;
+        rc = set_big_lds(ctx, nk_bin_select_kernel<T>, lds2);
+        if (rc) return rc;
+        hipLaunchKernelGGL((nk_bin_select_kernel<T>), dim3(nb), dim3(HIST_THREADS), lds2, ctx->stream, static_cast<const T*>(P->y), cls_y, res_y, seg_ctr, nb,
+                           klo_y, khi_y, rbs_y, reinterpret_cast<SelState<K>*>(scratch + OFF_STATE), reinterpret_cast<uint64_t*>(scratch + off_succ(nb)),
+                           cnt_y, ctr);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    } else {
     {
         uint64_t* d_hist = select_reset<K>(ctx, scratch, nb);   // (after the selection of step 5 has been read by the vshift kernel)
         const size_t lds = (size_t)nb * 2 * sizeof(K) + (size_t)nb * 2 * 4 + (size_t)nb * SEL_RADIX * 4;
@@ -2007,6 +2312,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, ws->c_cap, n / 16 + 1, ctr + 5, nb, scratch, SEL_GIVEN, given_y, 0, true,
                            klo_y, rbs_y, /*first_hist_done=*/true);
     if (rc) return rc;
+    }
     // 7. everything the step hands back: packed into one block on the device, one copy, one synchronisation
     std::vector<uint64_t> cnt(3 * (size_t)nb);
     std::vector<K> klo(nb);
@@ -2042,6 +2348,9 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     }
     std::vector<SelResult<K>> hs(nb);
     for (int k = 0; k < nb; ++k) { hs[k].st = h_st[k]; hs[k].succ = h_succ[k]; }
+    if ((h_ctr[2] != 0 || h_ctr[3] != 0) && getenv("XDEMHIP_DEBUG"))
+        fprintf(stderr, "[xdemhip] one-pass step falls through: overflow flag %llu, miss flag %llu, dh candidates %llu, bin candidates %llu\n", h_ctr[2], h_ctr[3],
+                h_ctr[1], h_ctr[5]);
     if (h_ctr[2] != 0 || h_ctr[3] != 0) {   // overflow / a bracket missed / no extreme-aspect survivor: the two-pass route
         if (narrow > 0) { P->fz_narrow_cap = narrow - 1; P->fz_narrow = 0; }   // (narrowed brackets may be what missed: not that narrow again)
         return XDEMHIP_OK;
@@ -2361,7 +2670,7 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
     // one-pass step (large single-GPU plans with the EXT buffers): its device block and candidate buffers; without the memory the
     // plan keeps the two-pass route
     if (P->ref_m && P->ws.d_small && ctx->nk_fused != 0) {
-        P->fz_bytes = (size_t)(24 + 11 * P->ws.nb_max) * 8;
+        P->fz_bytes = (size_t)(24 + (11 + BINSEG_CTR_STRIDE) * P->ws.nb_max) * 8;   // (... + places taken in the per-bin candidate segments: one line per bin)
         P->cd_cap = (int64_t)n / 8 + 4096;
         P->fz_pack_bytes = (size_t)P->ws.nb_max * (8 * 3 + 8 + 16 + 64 + 8) + 1024;
         if (hipMalloc(reinterpret_cast<void**>(&P->fz), P->fz_bytes) != hipSuccess || hipMalloc(&P->cd_vals, (size_t)P->cd_cap * es) != hipSuccess ||
