@@ -53,6 +53,7 @@ constexpr int LUT_G = 256;    // GRID: cells of float(d2) from LUT_G0 on (d2 = 1
 constexpr int LUT_G0 = 1016;
 constexpr int LUT_STEPS = 1;  // a cell holds at most ONE threshold (host-checked), flagged in the entry's low bit
 constexpr int NCOPY = 32;     // privatised accumulator copies (copy = lane % 32 -> one LDS bank per copy)
+constexpr int HIST_BINS_PER_SWEEP_K = 128;   // (= HIST_BINS_PER_SWEEP below: the most lag classes a bracketed selection takes)
 
 enum { OP_SUMS_SQ = 0, OP_SUMS_SQRT = 1, OP_HIST = 2, OP_SUCC = 3, OP_BRACKET = 4 };
 
@@ -227,6 +228,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     // sums on the lattice (round 4): {class of the cell's lower bound c, threshold c, threshold c - 1 (0 for c = 0), threshold c + 1}: the
     // class of a d^2 AND the d^2 interval of that class from one 16-byte read (see the run-length loop)
     __shared__ uint4 s_lut4[(GRID && (OP == OP_SUMS_SQ || OP == OP_SUMS_SQRT || OP == OP_BRACKET)) ? LUT_G : 1];
+    // run-length counting pass, float32 values (round 5): everything a lane loads when its run enters class l -- the class's d^2
+    // interval {low, width} and its bracket {low, high} as float bits -- in ONE 16-byte record (the interval used to be rebuilt from the
+    // cell's table entry with two selects and a subtract next to the 8-byte read of the bracket)
+#if defined(XD_NO_CLSREC)   // (measurement build: the round-4 form)
+    constexpr bool CLSREC = false;
+#else
+    constexpr bool CLSREC = GRID && OP == OP_BRACKET && sizeof(T) == 4;
+#endif
+    __shared__ uint4 s_clsrec[CLSREC ? HIST_BINS_PER_SWEEP_K + 2 : 1];
     const int tid = threadIdx.x;
     if (FAST)  // (NT may be smaller than the table: round 1 loaded only its first NT entries -- wrong classes beyond 32 binades of d^2)
         for (int k = tid; k < (GRID ? LUT_G : LUT_N); k += NT) s_lut[k] = GRID ? a.lut_i[k] : a.lut[k];
@@ -277,6 +287,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
             __builtin_memcpy(&hi_f, &hi_bits, sizeof(T));
             s_lhf[2 * k] = lo_f;
             s_lhf[2 * k + 1] = hi_f;
+            if constexpr (CLSREC) {
+                if (k <= HIST_BINS_PER_SWEEP_K) {
+                    const uint32_t lo_d2 = k > 0 ? a.thr_i[k - 1] : 0u, hi_d2 = k < a.nb ? a.thr_i[k] : 0xFFFFFFFFu;
+                    uint32_t lb, hb;
+                    __builtin_memcpy(&lb, &lo_f, 4);
+                    __builtin_memcpy(&hb, &hi_f, 4);
+                    s_clsrec[k] = make_uint4(lo_d2, hi_d2 - lo_d2, lb, hb);
+                }
+            }
         }
         for (int k = tid; k < (a.nb + 1) * NCOPY; k += NT) s_c3[k] = 0ull;
         for (int k = tid; k < a.nb + 1; k += NT) s_in[k] = 0u;
@@ -674,11 +693,19 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                         run_l = (int)e.x + (up ? 1 : 0);
                                         run_ge = 0u;
                                         run_start = run_pos;
-                                        run_lo = up ? e.y : e.z;
-                                        run_w = (up ? e.w : e.y) - run_lo;
-                                        const FzEnds<T> be = *reinterpret_cast<const FzEnds<T>*>(s_lhf + 2 * run_l);
-                                        run_blo = be.lo;
-                                        run_bhi = be.hi;
+                                        if constexpr (CLSREC) {
+                                            const uint4 cr = s_clsrec[run_l];
+                                            run_lo = cr.x;
+                                            run_w = cr.y;
+                                            __builtin_memcpy(&run_blo, &cr.z, 4);
+                                            __builtin_memcpy(&run_bhi, &cr.w, 4);
+                                        } else {
+                                            run_lo = up ? e.y : e.z;
+                                            run_w = (up ? e.w : e.y) - run_lo;
+                                            const FzEnds<T> be = *reinterpret_cast<const FzEnds<T>*>(s_lhf + 2 * run_l);
+                                            run_blo = be.lo;
+                                            run_bhi = be.hi;
+                                        }
                                     }
                                     const T ad = sizeof(T) == 4 ? (T)__builtin_fabsf((float)dv[u]) : (T)__builtin_fabs((double)dv[u]);
                                     const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(ad >= run_blo);
