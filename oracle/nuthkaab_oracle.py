@@ -29,6 +29,8 @@ from __future__ import annotations
 
 import numpy as np
 
+import _conventions
+
 
 def gradient_unit(dem: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     """np.gradient(dem) with unit spacing in the DEM dtype: central differences, one-sided at the borders."""
@@ -60,13 +62,15 @@ def aux_vars(ref: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     return slope_tan, aspect
 
 
-def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int = 0) -> np.ndarray:
+def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int | None = None) -> np.ndarray:
     """bilinear(img)(row + dr, col + dc) on the full grid, float64 weights, result in img's dtype.  ``nan_rule`` = the
     switchable nodata convention of the kernel (geoutils' own rule is unpinned, see header): 0 "4tap" -- NaN if any of the
     four taps is non-finite or outside, zero weights included (except a zero-weight tap beyond the last row / column: nodes on
     the upper edge keep their value); 1 "weighted" -- taps with zero weight are ignored; 2
     "dilate3x3" -- NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite pixel or leaves the raster; 3
     "dilate_cross" -- the same with the 4-connected cross."""
+    if nan_rule is None:   # the decided convention (oracle/_conventions.py: the product's default, 0 unless a decision file says otherwise)
+        nan_rule = _conventions.decided("nk_nan_rule")
     H, W = img.shape
     rr = np.arange(H, dtype=np.float64)[:, None] + dr
     cc = np.arange(W, dtype=np.float64)[None, :] + dc
@@ -114,7 +118,7 @@ def bilinear_shifted(img: np.ndarray, dr: float, dc: float, nan_rule: int = 0) -
 
 
 def shifted_dh(ref: np.ndarray, tba: np.ndarray, shift_x: float, shift_y: float, res: tuple[float, float],
-               nan_rule: int = 0) -> np.ndarray:
+               nan_rule: int | None = None) -> np.ndarray:
     """ref - bilinear(tba)(row - shift_y/res_y, col + shift_x/res_x) on the full grid (stated convention, see header)."""
     return ref - bilinear_shifted(tba, -shift_y / res[1], shift_x / res[0], nan_rule)
 

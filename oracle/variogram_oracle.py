@@ -30,6 +30,8 @@ from __future__ import annotations
 
 import numpy as np
 
+import _conventions
+
 ESTIMATORS = ("matheron", "cressie", "dowd")
 
 
@@ -86,22 +88,28 @@ def _estimate(diffs: np.ndarray, estimator: str) -> float:
     raise ValueError(estimator)
 
 
-def pair_groups(ax, ay, bx, by, edges, right_closed: bool = False):
+def pair_groups(ax, ay, bx, by, edges, right_closed: bool | None = None):
     """Lag class of every pair (rows = a, cols = b): k with e_{k-1} <= d < e_k (``right_closed``: e_{k-1} < d <= e_k), or -1.
     (Which of the two scikit-gstat uses is unpinned offline: the product switches with the option "vario_edge".)"""
+    if right_closed is None:   # the decided convention (oracle/_conventions.py)
+        right_closed = bool(_conventions.decided("vario_edge"))
     d = np.sqrt((ax[:, None] - bx[None, :]) ** 2 + (ay[:, None] - by[None, :]) ** 2)
     g = np.searchsorted(np.asarray(edges, dtype=np.float64), d, side="left" if right_closed else "right")
     g[g >= len(edges)] = -1
     return g
 
 
-def empirical_variogram_blocks(blocks, edges, estimator: str = "matheron", right_closed: bool = False, diff_f64: bool = False):
+def empirical_variogram_blocks(blocks, edges, estimator: str = "matheron", right_closed: bool | None = None, diff_f64: bool | None = None):
     """exp float64[n], count int64[n] over the union of pair blocks.
 
     ``blocks`` is a list of (ax, ay, av, bx, by, bv) -- every a paired with every b (cdist) -- or (ax, ay, av)
     -- all pairs i < j inside the set (pdist).  Values keep their dtype: |v_i - v_j| is formed in it, or in float64 with
     ``diff_f64`` (the product's option "vario_diff": SciPy's pdist / cdist widen first).
     """
+    if right_closed is None:
+        right_closed = bool(_conventions.decided("vario_edge"))
+    if diff_f64 is None:
+        diff_f64 = bool(_conventions.decided("vario_diff"))
     n = len(edges)
     per_bin: list[list[np.ndarray]] = [[] for _ in range(n)]
     for blk in blocks:

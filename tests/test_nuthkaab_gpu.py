@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import nuthkaab_oracle as nko
-from conftest import GOLDEN
+from conftest import GOLDEN, decided, default_conventions
 
 pytestmark = pytest.mark.gpu
 
@@ -187,6 +187,7 @@ def test_binned_median_edge_cases(coreg):
         assert np.array_equal(c, c0) and np.array_equal(m, m0, equal_nan=True)
 
 
+@pytest.mark.skipif(not default_conventions(), reason="T9 was recorded from the reference's loop with the rule-0 stand-in interpolator")
 def test_full_fit_vs_oracle_and_reference(coreg, z):
     ref, tba, inlier, res = z["T9|ref"], z["T9|tba"], z["T9|inlier"], float(z["T9|res"])
     for tol in ("0.0", "0.001"):
@@ -501,7 +502,9 @@ def test_unbinned_fit_mode_vs_oracle(coreg):
     p0 = (3 * np.nanstd(y) / (2**0.5), 0.0, np.nanmean(y))
     (a, b, c), _ = scipy.optimize.curve_fit(nko.fit_func, x, y, p0=p0, absolute_sigma=True)
     east, north, vert = coreg._fit_from_sums(det)
-    assert np.allclose([east, north, vert], [a * np.sin(b), a * np.cos(b), c], rtol=1e-6, atol=1e-8)
+    # to 1e-6 of the fitted amplitude (both sides stop a Levenberg-Marquardt iteration at ftol = xtol = 1e-8: the small third
+    # parameter is not known to 1e-6 of ITSELF -- under nodata rule 3 the two differed by 6e-6 of c = 3e-7 of a)
+    assert np.allclose([east, north, vert], [a * np.sin(b), a * np.cos(b), c], rtol=1e-6, atol=1e-6 * abs(a))
     # and the class recovers a synthetic shift in this mode, with an initial shift
     nk = coreg.NuthKaab(bin_before_fit=False, subsample=1, initial_shift=(5.0, -5.0))
     nk.fit(ref, tba, inlier, resolution=res)
@@ -559,7 +562,7 @@ def test_nan_rules_of_the_bilinear_taps(coreg, rule):
             out = coreg.apply_translation(tba, 0.0, 0.0, 0.0, (res, res))
             assert np.array_equal(out, tba, equal_nan=True)   # zero shift = identity, last row and column included
     finally:
-        ctx.set_option("nk_nan_rule", 0)
+        ctx.set_option("nk_nan_rule", decided("nk_nan_rule"))
 
 
 @pytest.mark.parametrize("rule", [0, 1, 2, 3])
@@ -600,7 +603,7 @@ def test_block_plan_halo_depth_per_nan_rule(coreg, rule):
                 for p in plans:
                     p.close()
     finally:
-        ctx.set_option("nk_nan_rule", 0)
+        ctx.set_option("nk_nan_rule", decided("nk_nan_rule"))
 
 
 def test_advice_round2_contracts(coreg):
@@ -751,16 +754,20 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
     try:
         res = {}
         ctx.set_option("nk_nan_rule", rule)
-        for name, mode, fused in (("onepass", 0, 1), ("twopass", 0, 0), ("plain", 1, 0)):
+        # ("twopass, aspect read": option "nk_ext" = 0, the counting kernel that reads mask and aspect itself -- what a plan with a
+        #  reduction hook runs)
+        for name, mode, fused, ext in (("onepass", 0, 1, 1), ("twopass", 0, 0, 1), ("twopass, aspect read", 0, 0, 0), ("plain", 1, 0, 1)):
             ctx.set_option("selection", mode)
             ctx.set_option("nk_fused", fused)
+            ctx.set_option("nk_ext", ext)
             plan = coreg.NKPlan(ref, tba, None, ctx)
             try:
                 res[name] = [plan.step(sx, sy, (10.0, 10.0), nbin) for (sx, sy) in steps]
-                assert plan.route_counts()[name] == len(steps), (name, plan.route_counts())
+                assert plan.route_counts()[name.split(",")[0]] == len(steps), (name, plan.route_counts())
             finally:
                 plan.close()
-        for name in ("onepass", "twopass"):
+        ctx.set_option("nk_ext", 1)
+        for name in ("onepass", "twopass", "twopass, aspect read"):
             for a, b in zip(res[name], res["plain"]):
                 assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], (rule, name)
                 assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), (rule, name)
@@ -871,7 +878,7 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused, n_bins):
         assert rc_["onepass" if fused else "twopass"] == 6 and rc_["plain"] == 0, rc_
         plan.close()
     finally:
-        ctx.set_option("nk_nan_rule", 0)
+        ctx.set_option("nk_nan_rule", decided("nk_nan_rule"))
         ctx.set_option("selection", 0)
         ctx.set_option("nk_fused", 1)
 

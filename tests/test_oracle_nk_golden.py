@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import nuthkaab_oracle as nko
-from conftest import GOLDEN
+from conftest import GOLDEN, default_conventions
 
 
 @pytest.fixture(scope="module")
@@ -60,6 +60,7 @@ def test_T6_stop_rule(z):
     assert int(z["T6|ncalls_loose"]) == 3  # never fewer than 3 iterations (affine.py:142)
 
 
+@pytest.mark.skipif(not default_conventions(), reason="T9 was recorded from the reference's loop with the rule-0 stand-in interpolator")
 @pytest.mark.parametrize("tol", ["0.0", "0.001"])
 def test_T9_full_loop(z, tol):
     ref, tba, inlier, res = z["T9|ref"], z["T9|tba"], z["T9|inlier"], float(z["T9|res"])

@@ -44,8 +44,10 @@ def test_estimators_known_values():
     assert vo._estimate(d, "dowd") == 2.198 * 2.5**2 / 2
     assert np.isnan(vo._estimate(np.array([]), "matheron"))
     # lag classes are [e_{k-1}, e_k): a distance equal to an edge opens the next class
-    g = vo.pair_groups(np.array([0.0]), np.array([0.0]), np.array([1.0, 2.0, 2.5, 5.0]), np.zeros(4), [1.0, 2.0, 5.0])
-    assert g.tolist() == [[1, 2, 2, -1]]
+    args = (np.array([0.0]), np.array([0.0]), np.array([1.0, 2.0, 2.5, 5.0]), np.zeros(4), [1.0, 2.0, 5.0])
+    assert vo.pair_groups(*args, right_closed=0).tolist() == [[1, 2, 2, -1]]
+    # ... and (e_{k-1}, e_k] under the other convention a decision file may select (option "vario_edge" = 1)
+    assert vo.pair_groups(*args, right_closed=1).tolist() == [[0, 1, 2, 2]]
 
 
 def test_T7_masks_and_multi_range_subsamples():

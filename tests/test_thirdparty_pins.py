@@ -112,7 +112,7 @@ def test_defaults_follow_the_decision_file():
     from xdem_amd import _lib
 
     assert _lib.THIRDPARTY_DEFAULTS == {"nk_nan_rule": 0, "vario_edge": 0, "vario_diff": 0}
-    path = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "thirdparty_decision.json")
+    path = os.environ.get("XDEM_THIRDPARTY_DECISION") or os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "thirdparty_decision.json")
     got = _lib.thirdparty_decision()
     if not os.path.exists(path):
         assert got == {}

@@ -4,6 +4,8 @@ Integer work (lag-class membership counts) bit-exact; Dowd (exact median) bit-ex
 import numpy as np
 import pytest
 
+from conftest import decided
+
 import variogram_oracle as vo
 
 pytestmark = pytest.mark.gpu
@@ -58,14 +60,18 @@ def test_edge_inclusivity_and_nan(ss):
     bv = np.array([2.0, 4.0, 8.0, 16.0, np.nan, 3.0], np.float32)
     edges = [1.0, 2.0, 5.0]
     exp, count = ss.empirical_variogram_pairs([(ax, ay, av, bx, by, bv)], edges, "matheron")
-    assert count.tolist() == [0, 1, 3] and np.isnan(exp[0])
+    # ([e_{k-1}, e_k) by default; (e_{k-1}, e_k] where a decision file says vario_edge = 1: d = 1 joins class 0, d = 5 class 2)
+    if decided("vario_edge") == 0:
+        assert count.tolist() == [0, 1, 3] and np.isnan(exp[0])
+    else:
+        assert count.tolist() == [1, 1, 3]
     # the oracle has no NaN filter of its own (the reference drops NaN values before pairing): compare on the finite points
     keep = np.isfinite(bv)
     exp_o, count_o = vo.empirical_variogram_blocks([(ax, ay, av, bx[keep], by[keep], bv[keep])], edges, "matheron")
     assert np.array_equal(count, count_o) and np.allclose(exp[1:], exp_o[1:], rtol=1e-14)
-    # 3-4-5 triangle: d == 5.0 exactly is outside [.., 5)
+    # 3-4-5 triangle: d == 5.0 exactly is outside [.., 5) -- and inside (.., 5]
     exp, count = ss.empirical_variogram_pairs([(np.array([0.0]), np.array([0.0]), av, np.array([3.0]), np.array([4.0]), av)], edges, "dowd")
-    assert count.sum() == 0 and np.isnan(exp).all()
+    assert count.sum() == (0 if decided("vario_edge") == 0 else 1) and np.isnan(exp[:2]).all()
 
 
 def test_dowd_even_odd_duplicates(ss):
@@ -645,7 +651,8 @@ def test_float64_differences_of_float32_values_through_the_float32_shadow(ss, ki
     ctx = _lib.default_context()
     res = {}
     try:
-        ps32 = ss.PairSet(blocks, edges, ctx)          # the default convention: float32 differences
+        ctx.set_option("vario_diff", 0)
+        ps32 = ss.PairSet(blocks, edges, ctx)          # float32 differences
         res["float32 differences"] = ss.class_medians(ps32)
         ps32.close()
         ctx.set_option("vario_diff", 1)
@@ -665,7 +672,7 @@ def test_float64_differences_of_float32_values_through_the_float32_shadow(ss, ki
         finally:
             ps.close()
     finally:
-        ctx.set_option("vario_diff", 0)
+        ctx.set_option("vario_diff", decided("vario_diff"))
         ctx.set_option("vario_runs", 1)
         ctx.set_option("selection", 0)
     med0, cnt0 = res["float64 plain passes"]
@@ -750,12 +757,13 @@ def test_switchable_scikit_gstat_conventions(ss):
                     assert np.array_equal(c, co), (edge, diff, est)
                     assert np.allclose(e, eo, rtol=1e-12, atol=0, equal_nan=True)
             finally:
-                ctx.set_option("vario_edge", 0)
-                ctx.set_option("vario_diff", 0)
+                ctx.set_option("vario_edge", decided("vario_edge"))
+                ctx.set_option("vario_diff", decided("vario_diff"))
+    ctx.set_option("vario_edge", 0)
     e0, c0 = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron", ctx)
     ctx.set_option("vario_edge", 1)
     try:
         e1, c1 = ss.empirical_variogram_pairs([(x, y, v)], edges, "matheron", ctx)
     finally:
-        ctx.set_option("vario_edge", 0)
+        ctx.set_option("vario_edge", decided("vario_edge"))
     assert not np.array_equal(c0, c1) and c0.sum() != 0   # the two conventions do differ on lattice data

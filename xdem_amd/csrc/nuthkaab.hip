@@ -2042,7 +2042,7 @@ int nk_global_fused(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     } while (0)
         if (g.rule == 0) XD_NK_LEAN(0);
         else if (g.rule == 1) XD_NK_LEAN(1);
-        else if (P->badbits && !ctx->allreduce) XD_NK_LEAN(2);   // rules 2 / 3 through the bad-bit mask of the plan
+        else if (P->badbits) XD_NK_LEAN(2);   // rules 2 / 3 through the bad-bit mask of the plan (whole-raster plans, with or without a reduction hook)
         else
             hipLaunchKernelGGL((nk_dh_count_kernel<T>), grid, dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),
                                static_cast<const T*>(P->tba), P->valid, static_cast<const T*>(P->aspect), g, static_cast<T*>(P->dh),
