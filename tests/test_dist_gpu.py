@@ -252,10 +252,32 @@ def _nk_pair():
     return ref, tba, inl
 
 
-def test_nuth_kaab_partitioned_row_blocks(tmp_path):
+@pytest.mark.parametrize("rule", [None, 3])
+def test_nuth_kaab_partitioned_row_blocks(tmp_path, monkeypatch, rule):
     """the pair is PARTITIONED -- every rank holds only its row block + halo rows (RowBlock exchange) --
     not replicated; steps and the whole fit are identical to the single-process results on the full rasters (exact
-    selections, integer histograms all-reduced through the hook)."""
+    selections, integer histograms all-reduced through the hook).
+    rule = 3: the same under the dilating nodata rule, handed to the ranks the way a decision would reach them (a decision file):
+    row blocks then run the streaming kernels through a bad-bit mask of their own buffer (round 5; the generic kernel before)."""
+    from conftest import decided
+    from xdem_amd import _lib
+
+    prev = decided("nk_nan_rule")
+    if rule is not None:
+        import json
+
+        path = os.path.join(str(tmp_path), "decision.json")
+        json.dump({"nk_nan_rule": rule}, open(path, "w"))
+        monkeypatch.setenv("XDEM_THIRDPARTY_DECISION", path)
+        _lib.default_context().set_option("nk_nan_rule", rule)
+    try:
+        _partitioned_row_blocks(tmp_path)
+    finally:
+        if rule is not None:
+            _lib.default_context().set_option("nk_nan_rule", prev)   # (monkeypatch puts the environment back)
+
+
+def _partitioned_row_blocks(tmp_path):
     world = 2
     ctx = mp.get_context("spawn")
     port = 29900 + (os.getpid() % 90)

@@ -199,6 +199,25 @@ def test_multiple_runs_aggregate(ss):
         ss.sample_empirical_variogram(vals, gsd=1.0, subsample_method="nope")
 
 
+def test_named_binning_even(ss):
+    """scikit-gstat's named binning 'even' (skgstat.binning.even_width_lags: n_lags classes of equal width up to maxlag; n_lags
+    defaults to 10) is the same call as the Iterable of those right edges; the binnings that depend on each run's sampled
+    distances are refused by name (reference: xdem/spatialstats.py:1396-1403 warns about exactly those)."""
+    from xdem_amd.synth import fbm_numpy
+
+    vals = fbm_numpy((64, 64), hurst=0.3, seed=2, mean=0.0, std=1.0)
+    maxlag = float(np.sqrt(63.0**2 + 63.0**2))
+    for kw, n in (({}, 10), ({"n_lags": 7}, 7)):
+        a = ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, random_state=3, bin_func="even", **kw)
+        b = ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, random_state=3, bin_func=np.linspace(0, maxlag, n + 1)[1:])
+        # (n - 1 rows: upstream drops the last lag class, xdem/spatialstats.py:1541)
+        assert len(a) == len(b) == n - 1 and np.array_equal(a["lags"].values, np.linspace(0, maxlag, n + 1)[1:-1])
+        # (Matheron sums are float64 atomics: equal to rounding between two calls, not bit for bit)
+        assert np.allclose(a["exp"].values, b["exp"].values, rtol=1e-12, atol=0, equal_nan=True) and np.array_equal(a["count"].values, b["count"].values)
+    with pytest.raises(NotImplementedError, match="only 'even'"):
+        ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, bin_func="uniform")
+
+
 def test_large_pair_count_properties(ss):
     """2e4-point pdist (2e8 pairs): counts sum to N(N-1)/2; a cdist block gives the same classes with A and B swapped."""
     x, y, v = _pts(20000, 9, np.float32, extent=4000.0, grid=False)

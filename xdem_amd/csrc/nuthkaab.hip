@@ -415,15 +415,18 @@ struct NkRowTab { double fr; int k0l; int flags; int rnl; int pad_; };  // upper
 // of the nearest pixel -- the same floor(pos + 0.5) per row and per lane as bi_combine -- next to their rule-0 arithmetic: one 8-byte
 // word per lane and row, two distinct words per wave.  Results are those of the generic kernel bit for bit (GPU tests per rule).
 template <typename T>
-__global__ __launch_bounds__(256) void nk_badbits_kernel(const T* __restrict__ tba, int64_t H, int64_t W, int rule, int64_t wpr,
-                                                         uint64_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void nk_badbits_kernel(const T* __restrict__ tba /* the plan's buffer: rows roff .. roff + nbuf of the raster */,
+                                                         int64_t H, int64_t W, int64_t roff, int64_t nbuf, int rule, int64_t wpr,
+                                                         uint64_t* __restrict__ out /* [nbuf][wpr] */) {
     const int lane = threadIdx.x & 63;
     const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // data word of the row (pad words: below)
     const int64_t nwords = wpr - 2;
-    for (int64_t r = blockIdx.y; r < H; r += gridDim.y) {
+    for (int64_t r = blockIdx.y; r < nbuf; r += gridDim.y) {
         if (word < nwords) {
             const int64_t c = word * 64 + lane;
-            bool bad = !(r >= 1 && c >= 1 && r + 1 < H && c + 1 < W);
+            // bad: on the raster's border -- or, in a row block, in the first / last row of the buffer where that is not the raster's:
+            // the halo rule of the step (HaloTooSmall) keeps every nearest pixel off those rows, so the bit is never consulted
+            bool bad = !(roff + r >= 1 && c >= 1 && roff + r + 1 < H && c + 1 < W) || r < 1 || r + 1 >= nbuf;
             if (!bad) {
                 for (int dy = -1; dy <= 1; ++dy)
                     for (int dx = -1; dx <= 1; ++dx)
@@ -1802,6 +1805,284 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bin_select_kernel(const T* __
     }
 }
 
+// ---- round 5: the median of dh among its candidates in THREE launches -------------------------------------------------------------
+// The candidates of the median of dh (every dh inside the sample bracket [lo, hi]: a few 1e5 values at 4e8 pixels) went through the
+// generic selection: a reset, four digit passes with an advance kernel each, the successor pass, the vshift kernel -- eleven
+// dependent launches for 2 MB of data.  Here, three: `nk_dhsel_hist_kernel` counts them into 4096 VALUE buckets of the bracket (the
+// monotone map of the per-bin segments above, 16 x finer); `nk_dhsel_gather_kernel` -- every workgroup -- scans that histogram for
+// the bucket that holds the wanted rank, appends the bucket's keys (a few hundred) to a small buffer and notes the smallest key of
+// the buckets above; `nk_dhsel_final_kernel` (one workgroup) settles the exact order statistic and its successor among those keys
+// in LDS and writes vshift the way nk_fz_vshift_kernel does.  (Gather and final in one launch -- the last workgroup to finish, by a
+// ticket, doing the final part -- needs the keys, plain stores of many workgroups, published by device-scope fences: on this
+// multi-XCD part a fence writes back the issuing XCD's whole L2, 38-55 us for 64 workgroups, measured; a kernel boundary is cheaper.)
+// Same integers, same keys: the result is the generic selection's bit for bit (GPU tests: every route agrees).
+constexpr int DSEL_BUCKETS = 4096;
+constexpr int DSEL_CAP = 8192;        // keys of the chosen bucket (more -- ties en masse -- send the step to the two-pass route)
+constexpr int DSEL_HDR_WORDS = 4;     // 64-bit words: [0] spare, [1] keys appended, [2] ~(smallest key above the bucket), [3] spare; then the histogram
+struct DselMap { double lo, scale; };
+template <typename T, typename K> __device__ __forceinline__ DselMap dsel_map(K klo, K khi) {
+    DselMap m;
+    m.lo = (double)val_of(klo);
+    const double w = (double)val_of(khi) - m.lo;
+    m.scale = w > 0.0 ? (double)DSEL_BUCKETS / w : 0.0;
+    return m;
+}
+template <typename T> __device__ __forceinline__ int dsel_bucket(T v, const DselMap& m) {   // v inside [lo, hi]; monotone in v
+    const double t = ((double)v - m.lo) * m.scale;
+    const int d = (int)t;
+    return d > DSEL_BUCKETS - 1 ? DSEL_BUCKETS - 1 : (d < 0 ? 0 : d);
+}
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_hist_kernel(const T* __restrict__ cd, int64_t cap, const unsigned long long* n_dev,
+                                                                     const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
+                                                                     uint32_t* hist /* [DSEL_BUCKETS], zeroed */) {
+    typedef typename KeyT<T>::type K;
+    __shared__ uint32_t h[DSEL_BUCKETS];
+    for (int k = threadIdx.x; k < DSEL_BUCKETS; k += blockDim.x) h[k] = 0u;
+    __syncthreads();
+    const unsigned long long m = *n_dev;
+    const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
+    const DselMap mp = dsel_map<T, K>(*klo, *khi);
+    constexpr int U = 8;
+    const int64_t step = (int64_t)blockDim.x * U;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * blockDim.x + threadIdx.x;
+            x[u] = i < n ? cd[i] : (T)NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (x[u] == x[u]) atomicAdd(&h[dsel_bucket<T>(x[u], mp)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < DSEL_BUCKETS; k += blockDim.x)
+        if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+
+// wanted rank among the candidates and the bucket that holds it: every workgroup of both kernels below comes to the same conclusions
+// from the same counters and the same (complete) histogram
+struct DselWhere { bool run; int bucket; unsigned long long rank, below, group; };
+template <typename T>
+__device__ __forceinline__ DselWhere dsel_locate(const uint64_t* cnt, int64_t n, const uint32_t* hist, unsigned long long* s_pick /* [3] */,
+                                                 unsigned long long* s_wsum /* [16] */, unsigned long long* ctr, bool report) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    DselWhere w;
+    w.run = false; w.bucket = 0; w.rank = 0; w.below = 0; w.group = 0;
+    const uint64_t total = cnt[0], lt = cnt[1], in = cnt[2];
+    if (total == 0) return w;
+    {   // (the rule of bracket_given_kernel)
+        const uint64_t k = (total - 1) / 2, need = (total & 1) ? k : k + 1;
+        if (lt > k || need - lt >= in) { if (report && tid == 0) ctr[3] = 1ull; return w; }
+        w.rank = k - lt;
+        if ((uint64_t)n != in) { if (report && tid == 0) ctr[2] = 1ull; return w; }   // (the buffer does not hold what the counters say)
+    }
+    // block scan of the 4096 counts (thread t owns buckets 4 t .. 4 t + 3)
+    unsigned long long cq[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cq[q] = hist[4 * tid + q]; mine += cq[q]; }
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    if (tid == 0) s_pick[2] = ~0ull;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int v = 0; v < wave; ++v) before += s_wsum[v];
+    incl += before;
+    {
+        const unsigned long long excl = incl - mine;
+        if (w.rank >= excl && w.rank < incl) {   // (exactly one thread for a consistent histogram)
+            unsigned long long cum = excl;
+            int q = 0;
+            if (cum + cq[0] <= w.rank) { cum += cq[0]; q = 1;
+                if (cum + cq[1] <= w.rank) { cum += cq[1]; q = 2;
+                    if (cum + cq[2] <= w.rank) { cum += cq[2]; q = 3; } } }
+            s_pick[0] = (unsigned long long)(4 * tid + q);
+            s_pick[1] = cum;
+            s_pick[2] = q == 0 ? cq[0] : (q == 1 ? cq[1] : (q == 2 ? cq[2] : cq[3]));
+        }
+    }
+    __syncthreads();
+    if (s_pick[2] > (unsigned long long)DSEL_CAP) {   // no bucket found (inconsistent histogram) or ties en masse: the two-pass route
+        if (report && tid == 0) ctr[2] = 1ull;
+        return w;
+    }
+    w.bucket = (int)s_pick[0];
+    w.below = s_pick[1];
+    w.group = s_pick[2];
+    w.run = true;
+    return w;
+}
+
+// keys of the chosen bucket -> small buffer; the smallest key of the buckets above
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* __restrict__ cd, int64_t cap, const unsigned long long* n_dev,
+                                                                       const uint64_t* __restrict__ cnt /* total, below, inside */,
+                                                                       const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
+                                                                       uint32_t* hdr /* DSEL_HDR_WORDS 64-bit words, then the histogram */,
+                                                                       typename KeyT<T>::type* gkeys /* [DSEL_CAP] */, unsigned long long* ctr) {
+    typedef typename KeyT<T>::type K;
+    __shared__ unsigned long long s_pick[4], s_wsum[16];
+    __shared__ K s_min;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long m = *n_dev;
+    const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
+    if (tid == 0) s_min = ~(K)0;
+    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, blockIdx.x == 0);
+    if (!w.run) return;   // (uniform over the grid; the final kernel hands back NaN)
+    const DselMap mp = dsel_map<T, K>(*klo, *khi);
+    K mn = ~(K)0;
+    constexpr int U = 8;
+    const int64_t step = (int64_t)blockDim.x * U;
+    for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * blockDim.x + tid;
+            x[u] = i < n ? cd[i] : (T)NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (x[u] != x[u]) continue;
+            const K key = key_of(x[u]);
+            const int d = dsel_bucket<T>(x[u], mp);
+            if (d == w.bucket) {
+                const uint32_t pos = atomicAdd(&hdr[2], 1u);
+                if (pos < (uint32_t)DSEL_CAP) gkeys[pos] = key;
+            } else if (d > w.bucket && key < mn) {
+                mn = key;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const K t = k_shfl_down(mn, o);
+        mn = t < mn ? t : mn;
+    }
+    if (lane == 0 && mn != ~(K)0) k_atomic_min(&s_min, mn);   // (one global atomic per workgroup: they all land on one address)
+    __syncthreads();
+    if (tid == 0 && s_min != ~(K)0) k_atomic_max(reinterpret_cast<K*>(reinterpret_cast<unsigned long long*>(hdr) + 2), (K)~s_min);
+}
+
+// one workgroup: the exact order statistic and its successor among the bucket's keys, vshift
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t cap, const unsigned long long* n_dev, const uint64_t* __restrict__ cnt,
+                                                                      const uint32_t* hdr, const typename KeyT<T>::type* gkeys, unsigned long long* ctr,
+                                                                      unsigned char* info) {
+    typedef typename KeyT<T>::type K;
+    constexpr int P = KeyT<T>::passes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
+    K* keys = reinterpret_cast<K*>(fz_smem);                                      // [DSEL_CAP]
+    uint32_t* h = reinterpret_cast<uint32_t*>(keys + DSEL_CAP);                   // [BINSEL_COPIES][257]
+    unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(h + BINSEL_COPIES * (SEL_RADIX + 1) + ((BINSEL_COPIES * (SEL_RADIX + 1)) & 1));   // [256]
+    unsigned long long* s_pick = s_tot + SEL_RADIX;                               // bucket / digit, elements below it, elements in it
+    unsigned long long* s_wsum = s_pick + 4;                                      // [16] wave totals of the bucket scan
+    K* s_min = reinterpret_cast<K*>(s_wsum + 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint64_t total = cnt[0], lt = cnt[1], in = cnt[2];
+    const unsigned long long m = *n_dev;
+    const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
+    auto hand_back = [&](T vs) {   // what nk_fz_vshift_kernel writes
+        *reinterpret_cast<T*>(info) = vs;
+        *reinterpret_cast<uint64_t*>(info + 8) = total;
+        *reinterpret_cast<uint64_t*>(info + 16) = (uint64_t)((ctr[2] != 0) | ((ctr[3] != 0) << 1));
+        *reinterpret_cast<double*>(info + 24) = (double)vs;
+    };
+    if (tid == 0) *s_min = ~(K)0;
+    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, true);
+    const uint32_t got = hdr[2];
+    if (!w.run || (unsigned long long)got != w.group) {   // (the second: cannot happen -- histogram and gather saw the same values)
+        __syncthreads();
+        if (tid == 0) {
+            if (w.run) ctr[2] = 1ull;
+            hand_back((T)NAN);
+        }
+        return;
+    }
+    const int g = (int)got;
+    for (int i = tid; i < g; i += blockDim.x) keys[i] = gkeys[i];
+    const K above = (K)~*reinterpret_cast<const K*>(reinterpret_cast<const unsigned long long*>(hdr) + 2);   // (zero-initialised: ~0 = none)
+    SelState<K> s;
+    s.prefix = 0; s.rank = w.rank - w.below; s.count = in; s.n_le = w.below; s.group = w.group;
+    uint32_t* hc = h + (tid & (BINSEL_COPIES - 1)) * (SEL_RADIX + 1);
+    auto pick = [&](auto count_of) {   // every thread of the FIRST wave calls it; the result lands in s_pick
+        unsigned long long c4[4], mine4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c4[q] = count_of(4 * lane + q); mine4 += c4[q]; }
+        unsigned long long inc = mine4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        const unsigned long long exc = inc - mine4;
+        if (s.rank >= exc && s.rank < inc) {
+            unsigned long long cum = exc;
+            int q = 0;
+            if (cum + c4[0] <= s.rank) { cum += c4[0]; q = 1;
+                if (cum + c4[1] <= s.rank) { cum += c4[1]; q = 2;
+                    if (cum + c4[2] <= s.rank) { cum += c4[2]; q = 3; } } }
+            s_pick[0] = (unsigned long long)(4 * lane + q);
+            s_pick[1] = cum;
+            s_pick[2] = q == 0 ? c4[0] : (q == 1 ? c4[1] : (q == 2 ? c4[2] : c4[3]));
+        }
+    };
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {   // exact selection among the bucket's keys
+        const int shift = 8 * (P - 1 - p);
+        for (int k = tid; k < BINSEL_COPIES * (SEL_RADIX + 1); k += blockDim.x) h[k] = 0u;
+        __syncthreads();
+        const K himask = p == 0 ? (K)0 : (K)(~(K)0 << (shift + 8));
+        for (int i = tid; i < g; i += blockDim.x) {
+            const K key = keys[i];
+            if ((key & himask) == s.prefix) atomicAdd(&hc[(int)((key >> shift) & 0xFF)], 1u);
+        }
+        __syncthreads();
+        if (tid < SEL_RADIX) {
+            unsigned long long t = 0;
+#pragma unroll
+            for (int q = 0; q < BINSEL_COPIES; ++q) t += h[q * (SEL_RADIX + 1) + tid];
+            s_tot[tid] = t;
+        }
+        __syncthreads();
+        if (tid < 64) pick([&](int d) { return s_tot[d]; });
+        __syncthreads();
+        s.prefix |= (K)s_pick[0] << shift;
+        s.n_le += s_pick[1];
+        s.rank -= s_pick[1];
+        s.group = s_pick[2];
+        __syncthreads();
+    }
+    s.n_le += s.group;   // every digit fixed: group = the selected key's duplicates
+    K mn2 = above;
+    for (int i = tid; i < g; i += blockDim.x) {
+        const K key = keys[i];
+        if (key > s.prefix && key < mn2) mn2 = key;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const K t = k_shfl_down(mn2, o);
+        mn2 = t < mn2 ? t : mn2;
+    }
+    if (lane == 0 && mn2 != ~(K)0) k_atomic_min(s_min, mn2);
+    __syncthreads();
+    if (tid == 0) {   // (the arithmetic of nk_fz_vshift_kernel)
+        const uint64_t n_le = s.n_le + lt;
+        const T lo = val_of(s.prefix);
+        T vs = lo;
+        if (!(total & 1)) {
+            const uint64_t k2 = total / 2;
+            T hi = lo;
+            if (!(n_le > k2)) hi = val_of(*s_min);
+            vs = (T)((T)(lo + hi) / (T)2);
+        }
+        hand_back(vs);
+    }
+}
+
 // every small result of a step gathered into one block (one device-to-host copy instead of ten)
 struct FzPack { const unsigned char* src[12]; uint32_t bytes[12]; uint32_t off[12]; int n; unsigned char* dst; };
 static __global__ __launch_bounds__(256) void nk_fz_pack_kernel(FzPack a) {
@@ -2238,20 +2519,23 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     constexpr int BR_PASSES = 3;
     const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
     const int narrow = P->fz_narrow;
+    // (round 5: the passes advance their own states and the last one writes the bracket ends -- hist_pass_kernel<T, true>; `fused`
+    //  tells whether that form ran)
+    bool fused = false;
     int rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
-                               false, narrow);
+                               false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused);
     if (rc) return rc;
-    hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
+    if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
     hipLaunchKernelGGL((nk_vhat_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_st, klo_d, khi_d, d_vhat, d_delta, ctr);
     // 3. sample of y^ per aspect bin -> brackets of the bin medians
     hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
                        P->bcache + q0, n, n_slots, d_vhat);
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = select_enqueue<T>(ctx, s_v, nb == 1 ? nullptr : ws->s_bins, n_slots, n_slots, nullptr, nb, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES,
-                           false, nullptr, nullptr, false, narrow);
+                           false, nullptr, nullptr, false, narrow, klo_y, khi_y, rbs_y, low_mask, &fused);
     if (rc) return rc;
     const int nbb = (nb + 63) / 64;
-    hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, 0, low_mask, klo_y, khi_y, rbs_y);
+    if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, 0, low_mask, klo_y, khi_y, rbs_y);
     XD_HIP_CHECK(ctx, hipGetLastError());
     // 4. the one pass
     {
@@ -2272,6 +2556,24 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     // 5. exact median of dh among its candidates -> vshift
+    if (ctx->nk_binseg != 0) {   // round 5: value buckets of the bracket, three launches (nk_dhsel_* above)
+        uint32_t* dsel = reinterpret_cast<uint32_t*>(fz + 24 + (11 + BINSEG_CTR_STRIDE) * nbm);
+        K* dsel_keys = reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(fz) + P->fz_bytes);
+        // (few workgroups: every one of them ends with an atomic on ONE word, which serialise -- 256 workgroups with an atomic per
+        //  wave spent 80 us there)
+        int grid = grid_for(ctx, n / 32 + 1, HIST_THREADS * 8, 1);
+        grid = grid > 64 ? 64 : grid;
+        hipLaunchKernelGGL((nk_dhsel_hist_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
+                           klo_d, khi_d, dsel + 2 * DSEL_HDR_WORDS);
+        hipLaunchKernelGGL((nk_dhsel_gather_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
+                           cnt_d, klo_d, khi_d, dsel, dsel_keys, ctr);
+        const size_t lds = (size_t)DSEL_CAP * sizeof(K) + (size_t)(BINSEL_COPIES * (SEL_RADIX + 1) + 1) * 4 + (size_t)(SEL_RADIX + 4 + 16 + 2) * 8;
+        rc = set_big_lds(ctx, nk_dhsel_final_kernel<T>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((nk_dhsel_final_kernel<T>), dim3(1), dim3(HIST_THREADS), lds, ctx->stream, P->cd_cap, ctr + 1, cnt_d, dsel, dsel_keys, ctr,
+                           scratch + OFF_INFO);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    } else {
     hipLaunchKernelGGL(bracket_given_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt_d, 1, given_d, ctr);
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = select_enqueue<T>(ctx, static_cast<const T*>(P->cd_vals), nullptr, P->cd_cap, n / 32 + 1, ctr + 1, 1, scratch, SEL_GIVEN, given_d, 0, true,
@@ -2279,6 +2581,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if (rc) return rc;
     hipLaunchKernelGGL((nk_fz_vshift_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, cnt_d, d_st, reinterpret_cast<const uint64_t*>(scratch + off_succ(1)),
                        klo_d, rbs_d, ctr, scratch + OFF_INFO);
+    }
     // 6. the bin candidates with the exact vshift -> counts, exact medians among those inside the brackets
     const bool binseg = ctx->nk_binseg != 0 && (int64_t)P->nbuf * P->W >= ws->c_cap;
     if (binseg) {
@@ -2670,10 +2973,12 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
     // one-pass step (large single-GPU plans with the EXT buffers): its device block and candidate buffers; without the memory the
     // plan keeps the two-pass route
     if (P->ref_m && P->ws.d_small && ctx->nk_fused != 0) {
-        P->fz_bytes = (size_t)(24 + (11 + BINSEG_CTR_STRIDE) * P->ws.nb_max) * 8;   // (... + places taken in the per-bin candidate segments: one line per bin)
+        // (... + places taken in the per-bin candidate segments: one line per bin; + header and histogram of the dh selection --
+        //  all zeroed at the start of a step; the keys of its chosen bucket sit behind, outside the zeroed part)
+        P->fz_bytes = (size_t)(24 + (11 + BINSEG_CTR_STRIDE) * P->ws.nb_max + DSEL_HDR_WORDS + DSEL_BUCKETS / 2) * 8;
         P->cd_cap = (int64_t)n / 8 + 4096;
         P->fz_pack_bytes = (size_t)P->ws.nb_max * (8 * 3 + 8 + 16 + 64 + 8) + 1024;
-        if (hipMalloc(reinterpret_cast<void**>(&P->fz), P->fz_bytes) != hipSuccess || hipMalloc(&P->cd_vals, (size_t)P->cd_cap * es) != hipSuccess ||
+        if (hipMalloc(reinterpret_cast<void**>(&P->fz), P->fz_bytes + (size_t)DSEL_CAP * 8) != hipSuccess || hipMalloc(&P->cd_vals, (size_t)P->cd_cap * es) != hipSuccess ||
             hipMalloc(&P->c_st, (size_t)P->ws.c_cap * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->fz_pack), P->fz_pack_bytes) != hipSuccess) {
             (void)hipGetLastError();
             if (P->fz) (void)hipFree(P->fz);
@@ -2683,18 +2988,19 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
             P->fz = nullptr; P->cd_vals = nullptr; P->c_st = nullptr; P->fz_pack = nullptr;
         }
     }
-    // rules 2 / 3 on whole-raster plans large enough for the streaming kernels: the per-pixel neighbourhood flags of tba, once
-    if (P->nan_rule >= 2 && roff == 0 && nbuf == H && (int64_t)n >= SEL_BRACKET_MIN_N) {
+    // rules 2 / 3 on plans large enough for the streaming kernels (whole rasters and row blocks alike): the per-pixel neighbourhood
+    // flags of the tba buffer, once
+    if (P->nan_rule >= 2 && (int64_t)n >= SEL_BRACKET_MIN_N) {
         P->bad_wpr = (W + 63) / 64 + 2;
-        if (hipMalloc(reinterpret_cast<void**>(&P->badbits), (size_t)P->bad_wpr * (size_t)H * 8) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void**>(&P->badbits), (size_t)P->bad_wpr * (size_t)nbuf * 8) != hipSuccess) {
             (void)hipGetLastError();
             P->badbits = nullptr;   // (the plan keeps the generic kernels)
         } else {
-            const dim3 bgrid((unsigned)((P->bad_wpr - 2 + 3) / 4), (unsigned)(H < 4096 ? H : 4096));
+            const dim3 bgrid((unsigned)((P->bad_wpr - 2 + 3) / 4), (unsigned)(nbuf < 4096 ? nbuf : 4096));
             if (dtype == XDEMHIP_F32)
-                hipLaunchKernelGGL((nk_badbits_kernel<float>), bgrid, dim3(256), 0, ctx->stream, static_cast<const float*>(P->tba), H, W, P->nan_rule, P->bad_wpr, P->badbits);
+                hipLaunchKernelGGL((nk_badbits_kernel<float>), bgrid, dim3(256), 0, ctx->stream, static_cast<const float*>(P->tba), H, W, roff, nbuf, P->nan_rule, P->bad_wpr, P->badbits);
             else
-                hipLaunchKernelGGL((nk_badbits_kernel<double>), bgrid, dim3(256), 0, ctx->stream, static_cast<const double*>(P->tba), H, W, P->nan_rule, P->bad_wpr, P->badbits);
+                hipLaunchKernelGGL((nk_badbits_kernel<double>), bgrid, dim3(256), 0, ctx->stream, static_cast<const double*>(P->tba), H, W, roff, nbuf, P->nan_rule, P->bad_wpr, P->badbits);
             if (hipGetLastError() != hipSuccess) return fail(XDEMHIP_EHIP, "nk_badbits_kernel launch failed");
         }
     }

@@ -87,16 +87,14 @@ __host__ __device__ inline uint64_t sel_bracket_halfwidth_wide(uint64_t m, uint3
     return (uint64_t)(3.0 * sqrt((double)deff * (double)m)) + 64;
 }
 
-template <typename K>
-__global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
-                                                            int mode = SEL_MEDIAN, const uint64_t* given = nullptr,
-                                                            const uint32_t* rb_shift = nullptr, uint32_t wide_deff = PAIR_DEFF_WIDE,
-                                                            int dual_nb = 1 /* SEL_BRACKET_DUAL: states below this are low ends */,
-                                                            uint64_t* succ = nullptr /* [nb]: successor keys from the last histogram */,
-                                                            uint32_t* need_succ = nullptr /* raised when some bin's successor needs the scan */,
-                                                            uint32_t narrow = 0 /* SEL_BRACKET_LO / _HI / _DUAL: half width >> narrow (callers that
-                                                                                   measured how centred their brackets are, nuthkaab.hip) */) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// One wave advances state `b` by one digit (the body of select_advance_kernel; also run by the last workgroup of a histogram pass
+// that advances its own states, select_run.h: hist_pass_kernel<T, true>).
+// DEV: the histogram was filled by device-scope atomics of THIS launch (other workgroups): it is read with device-scope loads, which
+// are performed where those atomics were; `lds_states` (optional) also receives the advanced state -- readers in the same workgroup.
+template <typename K, bool DEV = false>
+__device__ __forceinline__ void select_advance_body(const int b, const int lane, SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
+                                                    int mode, const uint64_t* given, const uint32_t* rb_shift, uint32_t wide_deff, int dual_nb,
+                                                    uint64_t* succ, uint32_t* need_succ, uint32_t narrow, SelState<K>* lds_states = nullptr) {
     if (b >= nb) return;
     // SEL_BRACKET_DUAL, first digit: both ends of a bin's bracket start from the same histogram -- hist_pass_kernel fills only the
     // low end's row and the low end's block sets up both states
@@ -113,7 +111,11 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
     uint64_t* h = hist + (size_t)b * SEL_RADIX;
     unsigned long long c[4], mine = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { c[q] = h[4 * lane + q]; mine += c[q]; h[4 * lane + q] = 0; }  // (zeroed for the next pass)
+    for (int q = 0; q < 4; ++q) {
+        c[q] = DEV ? (unsigned long long)__hip_atomic_load(&h[4 * lane + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)h[4 * lane + q];
+        mine += c[q];
+        h[4 * lane + q] = 0;   // (zeroed for the next pass)
+    }
     // inclusive scan of the per-lane totals
     unsigned long long incl = mine;
 #pragma unroll
@@ -181,8 +183,24 @@ __global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uin
             }
         }
     }
-    if (lane == 0) st[bs] = s;
+    if (lane == 0) {
+        st[bs] = s;
+        if (lds_states) lds_states[bs] = s;
     }
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(64) void select_advance_kernel(SelState<K>* st, uint64_t* hist, int nb, int shift, int first, int last,
+                                                            int mode = SEL_MEDIAN, const uint64_t* given = nullptr,
+                                                            const uint32_t* rb_shift = nullptr, uint32_t wide_deff = PAIR_DEFF_WIDE,
+                                                            int dual_nb = 1 /* SEL_BRACKET_DUAL: states below this are low ends */,
+                                                            uint64_t* succ = nullptr /* [nb]: successor keys from the last histogram */,
+                                                            uint32_t* need_succ = nullptr /* raised when some bin's successor needs the scan */,
+                                                            uint32_t narrow = 0 /* SEL_BRACKET_LO / _HI / _DUAL: half width >> narrow (callers that
+                                                                                   measured how centred their brackets are, nuthkaab.hip) */) {
+    select_advance_body<K>((int)blockIdx.x, (int)threadIdx.x, st, hist, nb, shift, first, last, mode, given, rb_shift, wide_deff, dual_nb, succ, need_succ,
+                           narrow);
 }
 
 }  // namespace xd

@@ -47,13 +47,54 @@ __device__ __forceinline__ uint64_t k_shfl_down(uint64_t v, int off) { return (u
 constexpr int HIST_THREADS = 1024;
 constexpr int SEL_UNROLL = 4;   // elements per thread and step, all loads issued before the first use (8 measured slower: r04e)
 
-template <typename T>
+__host__ __device__ inline uint32_t rebase_shift_of(uint32_t range) { return range ? (uint32_t)__builtin_clz(range) : 0u; }
+__host__ __device__ inline uint32_t rebase_shift_of(uint64_t range) { return range ? (uint32_t)__builtin_clzll((unsigned long long)range) : 0u; }
+// bracket ends of a dual selection (states [0, nb) the low ends, [nb, 2 nb) the high ends) + the rebase shift of the widest
+// bracket: one wave (the body of bracket_finish_kernel below)
+template <typename K>
+__device__ __forceinline__ void bracket_finish_body(const int lane, const SelState<K>* st, int nb, int degenerate, K low_mask, K* klo, K* khi, uint32_t* shift) {
+    K r = 0;
+    for (int b = lane; b < nb; b += 64) {
+        const K lo = st[b].count > 0 ? st[b].prefix : (K)0;
+        const K hi = st[nb + b].count > 0 ? (degenerate ? lo : (K)(st[nb + b].prefix | low_mask)) : (K)~(K)0;
+        klo[b] = lo;
+        khi[b] = hi;
+        const K d = hi >= lo ? (K)(hi - lo) : (K)0;
+        r = d > r ? d : r;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const K o = k_shfl_down(r, off);
+        r = o > r ? o : r;
+    }
+    if (lane == 0) *shift = rebase_shift_of(r);
+}
+
+// hist_pass_kernel<T, FUSE = true> (round 5): the LAST workgroup of the pass to flush its table -- a ticket counter behind a
+// device-scope fence -- advances the selection states itself (select_advance_body, one wave per state) and, after the last digit
+// of a bracket selection, writes the bracket ends (bracket_finish_body): the Nuth-Kaab step's two sample selections go from
+// 3 x (pass + advance) + finish = 7 dependent launches to 3.  Dual bracket selections without a reduction hook only.
+template <typename K> struct HistFuse {
+    uint32_t* ticket;      // zero before the pass; the last workgroup puts it back
+    SelState<K>* st;       // the states (writable view of `st`)
+    int n_states;          // 2 x data bins
+    int dual_nb;           // data bins
+    int last;              // this is the key's last digit
+    uint32_t narrow;
+    int finish;            // also write the bracket ends ...
+    K low_mask;
+    K* klo;
+    K* khi;
+    uint32_t* rb_shift_out;
+};
+
+template <typename T, bool FUSE = false>
 __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __restrict__ vals, const uint16_t* __restrict__ bins,
                                                                  int64_t n, int nb, int bin0, int copies,
                                                                  const SelState<typename KeyT<T>::type>* st, int shift, int first,
                                                                  uint64_t* hist, const unsigned long long* n_dev = nullptr,
                                                                  const typename KeyT<T>::type* rb_lo = nullptr,
-                                                                 const uint32_t* rb_shift = nullptr, int dual_total = 0) {
+                                                                 const uint32_t* rb_shift = nullptr, int dual_total = 0,
+                                                                 HistFuse<typename KeyT<T>::type> fa = HistFuse<typename KeyT<T>::type>()) {
     // dual (dual_total = number of data bins of the whole selection, 0 = off): TWO selection states per data bin -- states
     // [0, dual_total) the low ends, [dual_total, 2 dual_total) the high ends of the brackets -- advance in the same passes over
     // the sample; every element is offered to both states of its bin.  `nb` stays the number of DATA bins of this sweep, the
@@ -124,6 +165,31 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
         // (dual: the high-end rows of this sweep belong to the states behind all the low-end ones)
         const size_t row0 = (dual_total && k >= nb * SEL_RADIX) ? (size_t)(dual_total - nb) + (size_t)bin0 : (size_t)bin0;
         if (c) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[row0 * SEL_RADIX + k]), c);
+    }
+    if (FUSE) {
+        // Hand-over to the last workgroup WITHOUT a device-scope fence (a fence writes back and invalidates the XCD's whole L2: with
+        // 256 workgroups that cost 60 us per pass, measured).  Everything that crosses workgroups here is a device-scope atomic --
+        // the histogram adds above, the ticket, the last workgroup's loads of the histogram (select_advance_body<K, true>) -- performed
+        // at the device's coherence point: a workgroup only has to wait until its own adds have been acknowledged before it takes
+        // its ticket.  (Should a bracket ever come out of a stale count, the integer counts of the data pass tell: brackets from
+        // samples are proved afterwards, never trusted.)
+        __shared__ uint32_t s_last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = (atomicAdd(fa.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+        __syncthreads();
+        if (s_last == 0u) return;
+        if (threadIdx.x == 0) __hip_atomic_store(fa.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lane = threadIdx.x & 63;
+        SelState<K>* lds_st = reinterpret_cast<SelState<K>*>(smem);   // (the table has been flushed: every thread is past the barrier above)
+        for (int b = threadIdx.x >> 6; b < fa.n_states; b += HIST_THREADS / 64)
+            select_advance_body<K, true>(b, lane, fa.st, hist, fa.n_states, shift, first, fa.last, SEL_BRACKET_DUAL, nullptr, nullptr, PAIR_DEFF_WIDE,
+                                         fa.dual_nb, nullptr, nullptr, fa.narrow, fa.finish ? lds_st : nullptr);
+        if (fa.finish) {
+            __syncthreads();
+            if (threadIdx.x < 64) bracket_finish_body<K>(lane, lds_st, fa.dual_nb, 0, fa.low_mask, fa.klo, fa.khi, fa.rb_shift_out);
+        }
     }
 }
 
@@ -217,7 +283,7 @@ inline size_t scratch_size(int nb) { return off_hist(2 * nb1(nb)) + (size_t)2 * 
 static __global__ void select_reset_kernel(uint64_t* base, int64_t w_state, int64_t w_succ, int64_t words, uint32_t* need = nullptr) {
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x)
         base[w] = (w >= w_state && w < w_state + w_succ) ? ~(uint64_t)0 : (uint64_t)0;
-    if (need && blockIdx.x == 0 && threadIdx.x == 0) *need = 0u;
+    if (need && blockIdx.x == 0 && threadIdx.x == 0) { need[0] = 0u; need[2] = 0u; }   // ([2]: the ticket of hist_pass_kernel<T, true>)
 }
 
 template <typename K> struct SelResult {
@@ -237,8 +303,12 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                    unsigned char* scratch, int mode, const uint64_t* d_given, int n_passes = 0, bool want_succ = true,
                    const typename KeyT<T>::type* rb_lo = nullptr, const uint32_t* rb_shift = nullptr,
                    bool first_hist_done = false /* the caller ran select_reset and filled the first digit's histogram itself */,
-                   int narrow = 0 /* bracket modes: half width >> narrow (select_advance_kernel) */) {
+                   int narrow = 0 /* bracket modes: half width >> narrow (select_advance_kernel) */,
+                   typename KeyT<T>::type* fuse_klo = nullptr /* SEL_BRACKET_DUAL: the passes advance their own states and the last one writes the */,
+                   typename KeyT<T>::type* fuse_khi = nullptr /* bracket ends + rebase shift here (hist_pass_kernel<T, true>); *fused tells whether */,
+                   uint32_t* fuse_rbs = nullptr, typename KeyT<T>::type fuse_low_mask = 0, bool* fused = nullptr) {
     typedef typename KeyT<T>::type K;
+    if (fused) *fused = false;
     // SEL_BRACKET_DUAL: two selection states per data bin (low ends in states [0, nb), high ends in [nb, 2 nb)); `scratch` holds
     // 2 nb states (scratch_size provides for that)
     const int dual = mode == SEL_BRACKET_DUAL ? 1 : 0;
@@ -265,6 +335,11 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     // (measured on the Nuth-Kaab step, A/B in one session: 2 -> 1 workgroups per CU 3.00 / 3.13 -> 2.92 / 2.98 ms; half a
     // workgroup per CU 3.10: too few)
     const int grid = grid_for(ctx, n_grid, HIST_THREADS * SEL_UNROLL, n_grid < ((int64_t)1 << 24) ? 1 : 2);
+    const bool fuse = fuse_klo && fuse_khi && fuse_rbs && dual && !ctx->allreduce && n > 0 && !first_hist_done && !rb_lo && !rb_shift &&
+                      nb <= HIST_THREADS / 64 && ctx->nk_binseg != 0;   // (one state per wave of the last workgroup: with the 144 states of the 72
+                                                                         //  aspect bins that workgroup took 9 rounds of device-scope loads, 20-40 us
+                                                                         //  against the 5 us of a launch of 144 one-wave workgroups -- measured)
+    if (fused) *fused = fuse;
     for (int p = 0; p < run; ++p) {
         const int shift = 8 * (passes - 1 - p);
         if (n > 0 && !(p == 0 && first_hist_done)) {
@@ -287,11 +362,23 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                 int64_t g2 = n_grid / ((int64_t)2 * rows * SEL_RADIX);
                 g2 = g2 < 32 ? 32 : g2;
                 const int grid_p = (p == 1 && g2 < grid) ? (int)g2 : grid;
+                if (fuse) {
+                    HistFuse<K> fa;
+                    fa.ticket = d_need + 2; fa.st = st; fa.n_states = nb; fa.dual_nb = nb_data; fa.last = (int)(p == passes - 1); fa.narrow = (uint32_t)narrow;
+                    fa.finish = (int)(p == run - 1); fa.low_mask = fuse_low_mask; fa.klo = fuse_klo; fa.khi = fuse_khi; fa.rb_shift_out = fuse_rbs;
+                    rc = set_big_lds(ctx, hist_pass_kernel<T, true>, lds);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL((hist_pass_kernel<T, true>), dim3(grid_p), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
+                                       st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift, nb_data, fa);
+                    XD_HIP_CHECK(ctx, hipGetLastError());
+                    continue;
+                }
                 hipLaunchKernelGGL((hist_pass_kernel<T>), dim3(grid_p), dim3(HIST_THREADS), lds, ctx->stream, vals, bins, n, nbs, b0, copies,
                                    st, shift, (int)(p == 0), d_hist, d_n, rb_lo, rb_shift, dual ? nb_data : 0);
                 XD_HIP_CHECK(ctx, hipGetLastError());
             }
         }
+        if (fuse) continue;   // (states advanced by the pass itself)
         int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
@@ -537,8 +624,6 @@ __global__ void bracket_keys_kernel(const SelState<K>* st, int nb, int which, in
 }
 
 // Left shift that brings the widest bracket's (hi - lo) up to the top key bit (rebased candidate keys, hist_pass_kernel).
-__host__ __device__ inline uint32_t rebase_shift_of(uint32_t range) { return range ? (uint32_t)__builtin_clz(range) : 0u; }
-__host__ __device__ inline uint32_t rebase_shift_of(uint64_t range) { return range ? (uint32_t)__builtin_clzll((unsigned long long)range) : 0u; }
 template <typename K>
 __global__ __launch_bounds__(64) void rebase_shift_kernel(const K* klo, const K* khi, int nb, uint32_t* shift) {
     K r = 0;
@@ -556,20 +641,7 @@ __global__ __launch_bounds__(64) void rebase_shift_kernel(const K* klo, const K*
 // bracket_keys_kernel (both ends) + rebase_shift_kernel in one launch: states [0, nb) hold the low ends, [nb, 2 nb) the high ends
 template <typename K>
 __global__ __launch_bounds__(64) void bracket_finish_kernel(const SelState<K>* st, int nb, int degenerate, K low_mask, K* klo, K* khi, uint32_t* shift) {
-    K r = 0;
-    for (int b = threadIdx.x; b < nb; b += 64) {
-        const K lo = st[b].count > 0 ? st[b].prefix : (K)0;
-        const K hi = st[nb + b].count > 0 ? (degenerate ? lo : (K)(st[nb + b].prefix | low_mask)) : (K)~(K)0;
-        klo[b] = lo;
-        khi[b] = hi;
-        const K d = hi >= lo ? (K)(hi - lo) : (K)0;
-        r = d > r ? d : r;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const K o = k_shfl_down(r, off);
-        r = o > r ? o : r;
-    }
-    if (threadIdx.x == 0) *shift = rebase_shift_of(r);
+    bracket_finish_body<K>((int)threadIdx.x, st, nb, degenerate, low_mask, klo, khi, shift);
 }
 
 // Rank of the wanted order statistic among the candidates of every bin (all-ones: empty bin); raises flags[3] when a

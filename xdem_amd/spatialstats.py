@@ -411,7 +411,14 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
                       "independent run. To remediate that issue, pass bin_func as an Iterable of right bin edges, "
                       "(or use default bin_func).")
     if "bin_func" in kwargs and not isinstance(kwargs["bin_func"], Iterable):
-        raise NotImplementedError("bin_func must be an iterable of right bin edges (or omitted) on the GPU path.")
+        raise NotImplementedError("bin_func must be an iterable of right bin edges, 'even' (or omitted) on the GPU path.")
+    # scikit-gstat's named binnings (strings -- Iterables to the check above, as upstream): 'even' needs nothing but maxlag and
+    # n_lags (skgstat.binning.even_width_lags: linspace(0, maxlag, n_lags + 1)[1:]); the others ('uniform', 'fd', 'sturges',
+    # 'scott', 'doane', 'sqrt', 'kmeans', 'ward', 'stable_entropy') are functions of the sampled pair distances of each run --
+    # exactly the per-run binnings upstream warns about -- and are refused
+    if isinstance(kwargs.get("bin_func"), str) and kwargs["bin_func"] != "even":
+        raise NotImplementedError(f"bin_func='{kwargs['bin_func']}': of scikit-gstat's named binnings only 'even' is available on the "
+                                  "GPU path; pass bin_func as an Iterable of right bin edges (or use default bin_func).")
 
     shape2d = None
     if coords is not None:
@@ -441,6 +448,8 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
             right_bin_edge *= np.sqrt(2)
         bin_func.append(kwargs["maxlag"])
         kwargs["bin_func"] = bin_func
+    if isinstance(kwargs["bin_func"], str):   # 'even' (checked above); n_lags: scikit-gstat's default is 10
+        kwargs["bin_func"] = np.linspace(0, kwargs["maxlag"], int(kwargs.get("n_lags", 10)) + 1)[1:]
     edges = np.asarray(list(kwargs["bin_func"]), dtype=np.float64)
     estimator = kwargs.get("estimator", "matheron")
 
