@@ -104,6 +104,20 @@ inline int xd_d2h(xdemhip_ctx* ctx, void* dst, const void* dsrc, size_t bytes) {
     ctx->pin_used += need;
     return XDEMHIP_OK;
 }
+// The same for results a KERNEL writes itself: a region of the pinned staging buffer (device-writable: pinned host memory is mapped)
+// that the next xd_sync hands to `dst` -- saves the copy engine's launch behind the kernel.  nullptr: no room, use xd_d2h.
+inline unsigned char* xd_pin_claim(xdemhip_ctx* ctx, void* dst, size_t bytes) {
+    if (!ctx->pin) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pin), 256 * 1024, hipHostMallocDefault) == hipSuccess) ctx->pin_cap = 256 * 1024;
+        else { ctx->pin = nullptr; (void)hipGetLastError(); }
+    }
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    if (!ctx->pin || ctx->pin_used + need > ctx->pin_cap) return nullptr;
+    unsigned char* at = ctx->pin + ctx->pin_used;
+    ctx->pending.push_back({dst, ctx->pin_used, bytes});
+    ctx->pin_used += need;
+    return at;
+}
 inline int xd_sync(xdemhip_ctx* ctx) {
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {

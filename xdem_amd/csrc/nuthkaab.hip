@@ -156,6 +156,11 @@ struct DhStats {
 static __global__ void nk_stats_init_kernel(DhStats* s) {
     if (threadIdx.x == 0) { s->asp_min = ~(uint64_t)0; s->asp_max = 0; }
 }
+// ... and, for the one-pass step, the zeroing of its device block and of the EXT survivor counters in the same launch (two memsets less)
+static __global__ void nk_step_init_kernel(DhStats* s, uint64_t* fz, int64_t fz_words, unsigned long long* ext_survivors /* [2] */) {
+    for (int64_t w = threadIdx.x; w < fz_words; w += blockDim.x) fz[w] = 0;
+    if (threadIdx.x == 0) { s->asp_min = ~(uint64_t)0; s->asp_max = 0; ext_survivors[0] = 0; ext_survivors[1] = 0; }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void nk_dh_kernel(const T* __restrict__ ref, const T* __restrict__ tba,
@@ -1060,7 +1065,9 @@ __global__ __launch_bounds__(256) void nk_bin_fill_kernel(const T* __restrict__ 
 // pixel has no dh (the digit passes skip NaN), so no compaction and no counter
 template <typename T>
 __global__ __launch_bounds__(256) void nk_sample_dh_kernel(const T* __restrict__ ref_m, const T* __restrict__ tba, NkGeom g, int64_t q0, int64_t n,
-                                                           double invW, int64_t n_slots, T* __restrict__ s_d) {
+                                                           double invW, int64_t n_slots, T* __restrict__ s_d, SelReset reset) {
+    // (on the side: the reset of the selection that runs on this sample next -- a launch less)
+    if (reset.base) select_reset_slice(reset, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = (sel_sampled_line(i >> SEL_LINE_LOG2) << SEL_LINE_LOG2) + (i & (SEL_LINE - 1));
         T out = (T)NAN;
@@ -1081,28 +1088,55 @@ __global__ __launch_bounds__(256) void nk_sample_dh_kernel(const T* __restrict__
 
 // v^ and delta from the bracket keys of the dh sample (two selection states: low end, high end)
 template <typename T>
-__global__ void nk_vhat_kernel(const SelState<typename KeyT<T>::type>* st, const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
-                               T* vhat, T* delta, unsigned long long* ctr) {
+__device__ __forceinline__ bool nk_vhat_of(uint64_t sample_count, typename KeyT<T>::type lo, typename KeyT<T>::type hi, T& vhat, T& delta) {
     typedef typename KeyT<T>::type K;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st[0].count == 0) { ctr[3] = 1ull; *vhat = (T)0; *delta = (T)0; return; }
-    const K lo = klo[0], hi = khi[0];
+    if (sample_count == 0) { vhat = (T)0; delta = (T)0; return false; }
     const K mid = (K)(lo + (K)((K)(hi - lo) >> 1));
     const double vl = (double)val_of(lo), vh = (double)val_of(hi), vm = (double)val_of(mid);
     const double d = fmax(vm - vl, vh - vm);
-    *vhat = val_of(mid);
+    vhat = val_of(mid);
     // rounded up, with room for the roundings of (dh - v) in the value dtype
     T df = (T)(d * 1.000001 + 1e-300);
     if ((double)df < d * 1.0000005) df = (T)((double)df * 1.000001);
-    *delta = df;
-    if (!(vl <= vm && vm <= vh) || !t_finite((T)vl) || !t_finite((T)vh)) ctr[3] = 1ull;   // a bracket that reaches +-Inf: not this route
+    delta = df;
+    return (vl <= vm && vm <= vh) && t_finite((T)vl) && t_finite((T)vh);   // (a bracket that reaches +-Inf: not this route)
+}
+template <typename T>
+__global__ void nk_vhat_kernel(const SelState<typename KeyT<T>::type>* st, const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
+                               T* vhat, T* delta, unsigned long long* ctr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    T v, d;
+    if (!nk_vhat_of<T>(st[0].count, klo[0], khi[0], v, d)) ctr[3] = 1ull;
+    *vhat = v;
+    *delta = d;
 }
 
 // sample of y^ = (dh - v^) / slope_tan with its aspect bin, in place over the dh sample
 template <typename T>
 __global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, uint16_t* __restrict__ s_b, const T* __restrict__ slope_tan,
-                                                          const uint16_t* __restrict__ bcache, int64_t n, int64_t n_slots, const T* vhat_p) {
-    const T vhat = *vhat_p;
+                                                          const uint16_t* __restrict__ bcache, int64_t n, int64_t n_slots, const T* vhat_p,
+                                                          const typename KeyT<T>::type* klo_d = nullptr, const typename KeyT<T>::type* khi_d = nullptr,
+                                                          T* vhat_out = nullptr, T* delta_out = nullptr, unsigned long long* ctr = nullptr,
+                                                          SelReset reset = SelReset()) {
+    // round 5, on the side (two launches less): v^ and delta from the dh sample's bracket, which nk_vhat_kernel used to derive -- every
+    // thread forms them (a handful of scalar operations), the first one stores them for the data pass; and the reset of the selection
+    // that runs on this sample next.  (An empty sample is told from the bracket itself -- bracket_finish_body leaves {0, all-ones} --
+    // not from the selection's states, which that reset is clearing.)
+    T vhat;
+    if (klo_d) {
+        typedef typename KeyT<T>::type K;
+        T delta;
+        const K lo = klo_d[0], hi = khi_d[0];
+        const bool ok = nk_vhat_of<T>((lo == (K)0 && hi == (K)~(K)0) ? 0u : 1u, lo, hi, vhat, delta);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *vhat_out = vhat;
+            *delta_out = delta;
+            if (!ok) ctr[3] = 1ull;
+        }
+    } else {
+        vhat = *vhat_p;
+    }
+    if (reset.base) select_reset_slice(reset, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = (sel_sampled_line(i >> SEL_LINE_LOG2) << SEL_LINE_LOG2) + (i & (SEL_LINE - 1));
         const T d = s_v[i];
@@ -2487,7 +2521,8 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     uint64_t* cls_y = fz + 24 + 3 * nbm;
     uint64_t* res_y = fz + 24 + 6 * nbm;
     uint64_t* cnt_y = fz + 24 + 8 * nbm;
-    XD_HIP_CHECK(ctx, hipMemsetAsync(fz, 0, P->fz_bytes, ctx->stream));
+    const bool r5 = ctx->nk_binseg != 0;   // round 5's forms of the small steps (option "nk_binseg" = 0: round 4's, kept for A/B and tests)
+    if (!r5) XD_HIP_CHECK(ctx, hipMemsetAsync(fz, 0, P->fz_bytes, ctx->stream));
     const bool custom = !P->custom_edges.empty();
     const int last_decimal = custom ? P->custom_decimal : NK_AUTO_EDGES;
     if (custom) {  // explicit bin edges: SciPy casts them to the sample dtype (rare path: a blocking copy)
@@ -2500,8 +2535,12 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const T* tba = static_cast<const T*>(P->tba);
     const T* st_all = static_cast<const T*>(P->slope_tan);
     // 1. min / max aspect of this step from the EXT lists -> edges, freshness of the bin cache; (re)fill of the cache
-    hipLaunchKernelGGL(nk_stats_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats);
-    XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt + 2, 0, 16, ctx->stream));
+    if (r5) {
+        hipLaunchKernelGGL(nk_step_init_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_stats, fz, (int64_t)(P->fz_bytes / 8), P->ext_cnt + 2);
+    } else {
+        hipLaunchKernelGGL(nk_stats_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats);
+        XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt + 2, 0, 16, ctx->stream));
+    }
     hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, ref_m, tba, static_cast<const T*>(P->aspect), g,
                        P->ext_idx, P->ext_cnt, d_stats, P->ext_cnt + 2);
     hipLaunchKernelGGL((nk_fz_prep_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, nb, (int)custom, d_edges, d_rec,
@@ -2513,8 +2552,9 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     P->bcache_force = false;
     // 2. sample of dh -> bracket of its median, v^, delta
     T* s_v = static_cast<T*>(ws->s_vals);
+    // (round 5: the sample kernels also reset the selection that runs on their sample -- select_reset_slice)
     hipLaunchKernelGGL((nk_sample_dh_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
-                       1.0 / (double)P->W, n_slots, s_v);
+                       1.0 / (double)P->W, n_slots, s_v, r5 ? select_reset_plan<K>(scratch, 1, SEL_BRACKET_DUAL) : SelReset());
     XD_HIP_CHECK(ctx, hipGetLastError());
     constexpr int BR_PASSES = 3;
     const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
@@ -2523,16 +2563,21 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     //  tells whether that form ran)
     bool fused = false;
     int rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
-                               false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused);
+                               false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, r5);
     if (rc) return rc;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
-    hipLaunchKernelGGL((nk_vhat_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_st, klo_d, khi_d, d_vhat, d_delta, ctr);
-    // 3. sample of y^ per aspect bin -> brackets of the bin medians
-    hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
-                       P->bcache + q0, n, n_slots, d_vhat);
+    // 3. sample of y^ per aspect bin -> brackets of the bin medians (round 5: v^ and delta formed by the sample kernel itself)
+    if (r5) {
+        hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
+                           P->bcache + q0, n, n_slots, d_vhat, klo_d, khi_d, d_vhat, d_delta, ctr, select_reset_plan<K>(scratch, nb, SEL_BRACKET_DUAL));
+    } else {
+        hipLaunchKernelGGL((nk_vhat_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_st, klo_d, khi_d, d_vhat, d_delta, ctr);
+        hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
+                           P->bcache + q0, n, n_slots, d_vhat);
+    }
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = select_enqueue<T>(ctx, s_v, nb == 1 ? nullptr : ws->s_bins, n_slots, n_slots, nullptr, nb, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES,
-                           false, nullptr, nullptr, false, narrow, klo_y, khi_y, rbs_y, low_mask, &fused);
+                           false, nullptr, nullptr, false, narrow, klo_y, khi_y, rbs_y, low_mask, &fused, r5);
     if (rc) return rc;
     const int nbb = (nb + 63) / 64;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, 0, low_mask, klo_y, khi_y, rbs_y);
@@ -2641,11 +2686,13 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             off += (uint32_t)((sizes[k] + 15) & ~(size_t)15);
         }
         if (off > P->fz_pack_bytes) return xd_fail(ctx, XDEMHIP_EINVAL, "one-pass step: result block too small");
-        pk.dst = P->fz_pack;
+        P->fz_host.resize(off);
+        // (round 5: the block is written straight into the pinned staging buffer where there is room -- no copy behind the kernel)
+        unsigned char* pin = r5 ? xd_pin_claim(ctx, P->fz_host.data(), off) : nullptr;
+        pk.dst = pin ? pin : P->fz_pack;
         hipLaunchKernelGGL(nk_fz_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, pk);
         XD_HIP_CHECK(ctx, hipGetLastError());
-        P->fz_host.resize(off);
-        { const int rc_ = xd_d2h(ctx, P->fz_host.data(), P->fz_pack, off); if (rc_) return rc_; }
+        if (!pin) { const int rc_ = xd_d2h(ctx, P->fz_host.data(), P->fz_pack, off); if (rc_) return rc_; }
         { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
         for (int k = 0; k < 10; ++k) memcpy(dsts[k], P->fz_host.data() + pk.off[k], sizes[k]);
     }

@@ -280,10 +280,28 @@ inline size_t off_hist(int nb) { return off_succ(nb) + (size_t)nb1(nb) * 8; }
 // (sized for 2 nb states: the dual bracket selection keeps a low-end and a high-end state per bin)
 inline size_t scratch_size(int nb) { return off_hist(2 * nb1(nb)) + (size_t)2 * nb1(nb) * SEL_RADIX * 8 + 256; }
 
+// states | successor keys | histograms of a selection, contiguous in `scratch`: zeros, all-ones, zeros.  A device function so that a
+// kernel that runs before the selection anyway (the sample kernels of the Nuth-Kaab step) can do it on the side: SelReset says where.
+struct SelReset { uint64_t* base; int64_t w_state, w_succ, words; uint32_t* need; };
+__device__ __forceinline__ void select_reset_slice(const SelReset& r, int64_t gtid, int64_t gthreads) {
+    for (int64_t w = gtid; w < r.words; w += gthreads) r.base[w] = (w >= r.w_state && w < r.w_state + r.w_succ) ? ~(uint64_t)0 : (uint64_t)0;
+    if (r.need && gtid == 0) { r.need[0] = 0u; r.need[2] = 0u; }   // ([2]: the ticket of hist_pass_kernel<T, true>)
+}
 static __global__ void select_reset_kernel(uint64_t* base, int64_t w_state, int64_t w_succ, int64_t words, uint32_t* need = nullptr) {
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x)
-        base[w] = (w >= w_state && w < w_state + w_succ) ? ~(uint64_t)0 : (uint64_t)0;
-    if (need && blockIdx.x == 0 && threadIdx.x == 0) { need[0] = 0u; need[2] = 0u; }   // ([2]: the ticket of hist_pass_kernel<T, true>)
+    const SelReset r = {base, w_state, w_succ, words, need};
+    select_reset_slice(r, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+// what select_enqueue's own reset launch would do for a selection over `nb` data bins in `mode` (for callers that pass reset_done)
+template <typename K> inline SelReset select_reset_plan(unsigned char* scratch, int nb, int mode) {
+    static_assert(sizeof(SelState<K>) <= 64, "state records live in 64-byte slots");
+    if (mode == SEL_BRACKET_DUAL) nb *= 2;
+    SelReset r;
+    r.base = reinterpret_cast<uint64_t*>(scratch + OFF_STATE);
+    r.w_state = (int64_t)nb1(nb) * 8;
+    r.w_succ = (int64_t)nb1(nb);
+    r.words = r.w_state + r.w_succ + (int64_t)nb * SEL_RADIX;
+    r.need = reinterpret_cast<uint32_t*>(scratch + OFF_NEED);
+    return r;
 }
 
 template <typename K> struct SelResult {
@@ -306,7 +324,8 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                    int narrow = 0 /* bracket modes: half width >> narrow (select_advance_kernel) */,
                    typename KeyT<T>::type* fuse_klo = nullptr /* SEL_BRACKET_DUAL: the passes advance their own states and the last one writes the */,
                    typename KeyT<T>::type* fuse_khi = nullptr /* bracket ends + rebase shift here (hist_pass_kernel<T, true>); *fused tells whether */,
-                   uint32_t* fuse_rbs = nullptr, typename KeyT<T>::type fuse_low_mask = 0, bool* fused = nullptr) {
+                   uint32_t* fuse_rbs = nullptr, typename KeyT<T>::type fuse_low_mask = 0, bool* fused = nullptr,
+                   bool reset_done = false /* the caller's own kernel did select_reset_slice(select_reset_plan(...)) */) {
     typedef typename KeyT<T>::type K;
     if (fused) *fused = false;
     // SEL_BRACKET_DUAL: two selection states per data bin (low ends in states [0, nb), high ends in [nb, 2 nb)); `scratch` holds
@@ -319,13 +338,11 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     uint64_t* d_succ = reinterpret_cast<uint64_t*>(scratch + off_succ(nb));
     uint64_t* d_hist = reinterpret_cast<uint64_t*>(scratch + off_hist(nb));
     uint32_t* d_need = reinterpret_cast<uint32_t*>(scratch + OFF_NEED);
-    if (!first_hist_done) {
+    if (!first_hist_done && !reset_done) {
         // states | successor keys | histograms are contiguous in `scratch`: one launch resets all three (zeros, all-ones, zeros)
-        static_assert(sizeof(SelState<K>) <= 64, "state records live in 64-byte slots");
-        const int64_t w_state = (int64_t)nb1(nb) * 8, w_succ = (int64_t)nb1(nb), w_hist = (int64_t)nb * SEL_RADIX;
-        const int64_t words = w_state + w_succ + w_hist;
-        const int blocks = (int)((words + 1023) / 1024 < 256 ? (words + 1023) / 1024 : 256);
-        hipLaunchKernelGGL(select_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint64_t*>(st), w_state, w_succ, words, d_need);
+        const SelReset r = select_reset_plan<K>(scratch, nb_data, mode);
+        const int blocks = (int)((r.words + 1023) / 1024 < 256 ? (r.words + 1023) / 1024 : 256);
+        hipLaunchKernelGGL(select_reset_kernel, dim3(blocks), dim3(256), 0, ctx->stream, r.base, r.w_state, r.w_succ, r.words, r.need);
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     const int passes = KeyT<T>::passes;
