@@ -248,7 +248,9 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uin
  * the two queued passes of rounds 2-3, or by the plain digit passes (small rasters; the fall-back of both).  Results are
  * identical on every route (integer counts, exact selections); nanmean / nanstd of y -- the p0 of the curve fit -- agree to
  * 2e-6 of the spread on the one-pass route (float32 partial sums, the accuracy class of the reference's own float32
- * np.nanmean). */
+ * np.nanmean).  Context option "nk_binseg" (default 1) selects round 5's forms of the small steps around that one pass --
+ * per-bin candidate segments with one workgroup per bin, value-bucket selection of the median of dh, sample passes that
+ * advance their own selection states: 24 launches per step -- 0 round 4's generic selections (55); same integers either way. */
 int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* twopass, int64_t* plain);
 void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
