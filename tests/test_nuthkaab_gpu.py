@@ -785,6 +785,41 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
         ctx.close()
 
 
+def test_whole_fit_stays_on_the_one_pass_route():
+    """bench.py's whole-fit leg in small: the iteration converges, the pair ends aligned, dh collapses onto a few float32 values
+    (differences of ~1e3 m elevations are multiples of 1.2e-4 m) -- every step must still be answered by the one-pass route, in
+    round 5's form (value / key buckets: a bucket that is ONE key needs no gathered keys) and in round 4's (digit passes), with
+    identical offsets."""
+    import os
+    import sys
+
+    import scipy.optimize
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from xdem_amd import _lib, coreg
+
+    dev = torch.device("cuda", 0)
+    ref, tba = bench._c3_pair(dev, 9000)
+    got = {}
+    for form in (1, 0):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_option("nk_binseg", form)
+            plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
+            off = coreg._iterate(plan, (10.0, 10.0), 0.0, 8, 36, scipy.optimize.curve_fit, True)   # (36 bins: enough sample per bin at this size)
+            routes = plan.route_counts()
+            plan.close()
+            assert routes["twopass"] == 0 and routes["plain"] == 0 and routes["onepass"] >= 3, (form, routes)
+            got[form] = off
+        finally:
+            ctx.close()
+    # (not bit for bit: nanmean / nanstd of y -- the p0 of the curve fit -- are float32 partial sums combined by atomics in any order)
+    assert np.allclose(got[1], got[0], rtol=0, atol=1e-6), (got[1], got[0])
+    assert abs(got[1][0] + 17.0) < 0.05 and abs(got[1][1] + 6.0) < 0.05 and abs(got[1][2] + 2.0) < 0.01, got[1]
+
+
 def test_bench_C3_pair_at_full_size_routes_agree():
     """The very input bench.py times (SURVEY 8d's C3: 20000^2 pair, tba = ref shifted bilinearly by (+1.7, -0.6) px + 2 m + noise,
     20 % gaps) at full size: the queued route the bench runs (EXT dh pass, lean kernels, dual bracket selections, aspect-bin cache)
@@ -803,7 +838,10 @@ def test_bench_C3_pair_at_full_size_routes_agree():
     ref, tba = bench._c3_pair(dev, 20000)
     ctx = _lib.Context(0)
     try:
-        steps = ((0.0, 0.0), (1.7, 0.6), (1.2, 0.9), (1.7, 0.6))
+        # (-17, -6): the shift the fit converges to -- the pair ALIGNED: dh = offset + small noise, and a float32 difference of ~1e3 m
+        #  elevations is a multiple of their ulp: a dozen distinct values carry all the candidates of the median (ties en masse; the
+        #  value-bucket selection of round 5 first sent exactly these steps to the two-pass route -- bench.py's whole-fit leg found it)
+        steps = ((0.0, 0.0), (1.7, 0.6), (1.2, 0.9), (1.7, 0.6), (-17.0, -6.0), (-16.9998, -5.9996))
         res = {}
         for name, mode, fused in (("onepass", 0, 1), ("twopass", 0, 0), ("plain", 1, 0)):
             ctx.set_option("selection", mode)

@@ -1852,18 +1852,35 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bin_select_kernel(const T* __
 // Same integers, same keys: the result is the generic selection's bit for bit (GPU tests: every route agrees).
 constexpr int DSEL_BUCKETS = 4096;
 constexpr int DSEL_CAP = 8192;        // keys of the chosen bucket (more -- ties en masse -- send the step to the two-pass route)
-constexpr int DSEL_HDR_WORDS = 4;     // 64-bit words: [0] spare, [1] keys appended, [2] ~(smallest key above the bucket), [3] spare; then the histogram
-struct DselMap { double lo, scale; };
-template <typename T, typename K> __device__ __forceinline__ DselMap dsel_map(K klo, K khi) {
-    DselMap m;
+constexpr int DSEL_HDR_WORDS = 4;     // 64-bit words: [0] ~(smallest key IN the bucket), [1] keys appended, [2] ~(smallest key above the bucket), [3] largest key in the bucket; then the histogram
+// Two forms of the monotone bucket map.  VALUE buckets (floor((v - lo) * 4096 / (hi - lo)) in float64) for brackets that straddle
+// zero or span many binades -- there the float KEYS are spread exponentially and most values would sit in a few key buckets.
+// KEY buckets ((key - klo) >> s, s the smallest shift that brings the bracket under 4096 buckets) for brackets inside at most three
+// binades of one sign -- there keys are evenly dense, and this is where ties concentrate: a well-aligned pair (the state every fit
+// converges to) has dh = offset + small noise, a bracket a few hundred float32 values wide holding a million candidates.  With
+// s = 0 a bucket IS a key: the histogram alone gives the selected key, its duplicates and its successor -- nothing is gathered,
+// whatever the multiplicity (`exact`).  (Found by bench.py's whole-fit leg, whose later iterations fell to the two-pass route with
+// value buckets only: 2.4e6 candidates on ~300 distinct keys overflow any per-bucket key buffer.)
+template <typename K> struct DselMap { double lo, scale; K klo; int shift; int keyspace; };
+template <typename T, typename K> __device__ __forceinline__ DselMap<K> dsel_map(K klo, K khi) {
+    DselMap<K> m;
+    m.klo = klo;
     m.lo = (double)val_of(klo);
     const double w = (double)val_of(khi) - m.lo;
     m.scale = w > 0.0 ? (double)DSEL_BUCKETS / w : 0.0;
+    constexpr int MANT = sizeof(K) == 4 ? 23 : 52;
+    const K top = (K)1 << (sizeof(K) * 8 - 1);
+    const K span = khi >= klo ? (K)(khi - klo) : (K)0;
+    m.keyspace = (int)(((klo ^ khi) & top) == 0 && span < (K)3 << MANT);
+    int bits = 0;
+    for (K r = span; r; r >>= 1) ++bits;   // (bits needed for span)
+    m.shift = bits > 12 ? bits - 12 : 0;
     return m;
 }
-template <typename T> __device__ __forceinline__ int dsel_bucket(T v, const DselMap& m) {   // v inside [lo, hi]; monotone in v
-    const double t = ((double)v - m.lo) * m.scale;
-    const int d = (int)t;
+template <typename T, typename K> __device__ __forceinline__ int dsel_bucket(T v, const DselMap<K>& m) {   // v inside [lo, hi]; monotone in v
+    int d;
+    if (m.keyspace) d = (int)((K)(key_of(v) - m.klo) >> m.shift);
+    else d = (int)(((double)v - m.lo) * m.scale);
     return d > DSEL_BUCKETS - 1 ? DSEL_BUCKETS - 1 : (d < 0 ? 0 : d);
 }
 template <typename T>
@@ -1876,7 +1893,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_hist_kernel(const T* __
     __syncthreads();
     const unsigned long long m = *n_dev;
     const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
-    const DselMap mp = dsel_map<T, K>(*klo, *khi);
+    const DselMap<K> mp = dsel_map<T, K>(*klo, *khi);
     constexpr int U = 8;
     const int64_t step = (int64_t)blockDim.x * U;
     for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
@@ -1888,7 +1905,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_hist_kernel(const T* __
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (x[u] == x[u]) atomicAdd(&h[dsel_bucket<T>(x[u], mp)], 1u);
+            if (x[u] == x[u]) atomicAdd(&h[dsel_bucket<T, K>(x[u], mp)], 1u);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < DSEL_BUCKETS; k += blockDim.x)
@@ -1900,7 +1917,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_hist_kernel(const T* __
 struct DselWhere { bool run; int bucket; unsigned long long rank, below, group; };
 template <typename T>
 __device__ __forceinline__ DselWhere dsel_locate(const uint64_t* cnt, int64_t n, const uint32_t* hist, unsigned long long* s_pick /* [3] */,
-                                                 unsigned long long* s_wsum /* [16] */, unsigned long long* ctr, bool report) {
+                                                 unsigned long long* s_wsum /* [16] */, unsigned long long* ctr, bool report, bool exact) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     DselWhere w;
     w.run = false; w.bucket = 0; w.rank = 0; w.below = 0; w.group = 0;
@@ -1942,7 +1959,7 @@ __device__ __forceinline__ DselWhere dsel_locate(const uint64_t* cnt, int64_t n,
         }
     }
     __syncthreads();
-    if (s_pick[2] > (unsigned long long)DSEL_CAP) {   // no bucket found (inconsistent histogram) or ties en masse: the two-pass route
+    if (s_pick[2] == ~0ull) {   // no bucket found (inconsistent histogram): the two-pass route
         if (report && tid == 0) ctr[2] = 1ull;
         return w;
     }
@@ -1967,9 +1984,18 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
     const unsigned long long m = *n_dev;
     const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
     if (tid == 0) s_min = ~(K)0;
-    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, blockIdx.x == 0);
+    const DselMap<K> mp = dsel_map<T, K>(*klo, *khi);
+    const bool exact = mp.keyspace && mp.shift == 0;
+    if (exact) return;    // (a bucket is a key: the histogram says everything -- nk_dhsel_final_kernel)
+    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, blockIdx.x == 0, false);
     if (!w.run) return;   // (uniform over the grid; the final kernel hands back NaN)
-    const DselMap mp = dsel_map<T, K>(*klo, *khi);
+    // A bucket with more values than the key buffer takes: ties.  (dh of a well-aligned float32 pair is a difference of elevations of
+    // ~1e3 m: a multiple of their ulp, 1.2e-4 m -- a dozen distinct values carry millions of candidates.)  Its keys are not gathered;
+    // its smallest and largest key are: if they agree the bucket IS that key and the histogram says the rest (nk_dhsel_final_kernel).
+    const bool big = w.group > (unsigned long long)DSEL_CAP;
+    __shared__ K s_kmin, s_kmax;
+    if (tid == 0) { s_kmin = ~(K)0; s_kmax = (K)0; }
+    K bmin = ~(K)0, bmax = (K)0;
     K mn = ~(K)0;
     constexpr int U = 8;
     const int64_t step = (int64_t)blockDim.x * U;
@@ -1984,10 +2010,15 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
         for (int u = 0; u < U; ++u) {
             if (x[u] != x[u]) continue;
             const K key = key_of(x[u]);
-            const int d = dsel_bucket<T>(x[u], mp);
+            const int d = dsel_bucket<T, K>(x[u], mp);
             if (d == w.bucket) {
-                const uint32_t pos = atomicAdd(&hdr[2], 1u);
-                if (pos < (uint32_t)DSEL_CAP) gkeys[pos] = key;
+                if (big) {
+                    bmin = key < bmin ? key : bmin;
+                    bmax = key > bmax ? key : bmax;
+                } else {
+                    const uint32_t pos = atomicAdd(&hdr[2], 1u);
+                    if (pos < (uint32_t)DSEL_CAP) gkeys[pos] = key;
+                }
             } else if (d > w.bucket && key < mn) {
                 mn = key;
             }
@@ -1996,15 +2027,26 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
     for (int o = 32; o > 0; o >>= 1) {
         const K t = k_shfl_down(mn, o);
         mn = t < mn ? t : mn;
+        const K t1 = k_shfl_down(bmin, o), t2 = k_shfl_down(bmax, o);
+        bmin = t1 < bmin ? t1 : bmin;
+        bmax = t2 > bmax ? t2 : bmax;
     }
+    __syncthreads();   // (s_kmin / s_kmax set)
     if (lane == 0 && mn != ~(K)0) k_atomic_min(&s_min, mn);   // (one global atomic per workgroup: they all land on one address)
+    if (lane == 0 && big && bmin != ~(K)0) { k_atomic_min(&s_kmin, bmin); k_atomic_max(&s_kmax, bmax); }
     __syncthreads();
-    if (tid == 0 && s_min != ~(K)0) k_atomic_max(reinterpret_cast<K*>(reinterpret_cast<unsigned long long*>(hdr) + 2), (K)~s_min);
+    unsigned long long* hdr64 = reinterpret_cast<unsigned long long*>(hdr);
+    if (tid == 0 && s_min != ~(K)0) k_atomic_max(reinterpret_cast<K*>(hdr64 + 2), (K)~s_min);
+    if (tid == 0 && big && s_kmin != ~(K)0) {
+        k_atomic_max(reinterpret_cast<K*>(hdr64 + 0), (K)~s_kmin);
+        k_atomic_max(reinterpret_cast<K*>(hdr64 + 3), s_kmax);
+    }
 }
 
 // one workgroup: the exact order statistic and its successor among the bucket's keys, vshift
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t cap, const unsigned long long* n_dev, const uint64_t* __restrict__ cnt,
+                                                                      const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
                                                                       const uint32_t* hdr, const typename KeyT<T>::type* gkeys, unsigned long long* ctr,
                                                                       unsigned char* info) {
     typedef typename KeyT<T>::type K;
@@ -2027,7 +2069,56 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t ca
         *reinterpret_cast<double*>(info + 24) = (double)vs;
     };
     if (tid == 0) *s_min = ~(K)0;
-    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, true);
+    const DselMap<K> mp = dsel_map<T, K>(*klo, *khi);
+    const bool exact = mp.keyspace && mp.shift == 0;
+    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, true, exact);
+    const unsigned long long* hdr64 = reinterpret_cast<const unsigned long long*>(hdr);
+    const bool big = w.run && !exact && w.group > (unsigned long long)DSEL_CAP;
+    K one_key = (K)0;
+    if (big) {   // more values than the key buffer takes: one key many times over, or the two-pass route
+        const K kmin = (K)~*reinterpret_cast<const K*>(hdr64 + 0), kmax = *reinterpret_cast<const K*>(hdr64 + 3);
+        if (kmin != kmax) {
+            __syncthreads();
+            if (tid == 0) { ctr[2] = 1ull; hand_back((T)NAN); }
+            return;
+        }
+        one_key = kmin;
+    }
+    if (w.run && (exact || big)) {
+        // the bucket is ONE key (key buckets with shift 0: klo + bucket; or smallest = largest key of a bucket of ties): its duplicates = the
+        // bucket's count, its successor = the smallest key of the buckets above (the next bucket that holds anything / what the gather noted)
+        if (exact) {
+            const uint32_t* hist = hdr + 2 * DSEL_HDR_WORDS;
+            int nxt = DSEL_BUCKETS;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const int d = 4 * tid + q;
+                if (d > w.bucket && hist[d] != 0u) nxt = d;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int t = __shfl_down(nxt, o);
+                nxt = t < nxt ? t : nxt;
+            }
+            if (lane == 0 && nxt < DSEL_BUCKETS) k_atomic_min(s_min, (K)(mp.klo + (K)nxt));
+        } else if (tid == 0) {
+            *s_min = (K)~*reinterpret_cast<const K*>(hdr64 + 2);   // (zero-initialised: ~0 = none)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const K sel = exact ? (K)(mp.klo + (K)w.bucket) : one_key;
+            const uint64_t n_le = w.below + w.group + lt;
+            const T lo = val_of(sel);
+            T vs = lo;
+            if (!(total & 1)) {
+                const uint64_t k2 = total / 2;
+                T hi = lo;
+                if (!(n_le > k2)) hi = val_of(*s_min);
+                vs = (T)((T)(lo + hi) / (T)2);
+            }
+            hand_back(vs);
+        }
+        return;
+    }
     const uint32_t got = hdr[2];
     if (!w.run || (unsigned long long)got != w.group) {   // (the second: cannot happen -- histogram and gather saw the same values)
         __syncthreads();
@@ -2615,8 +2706,8 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         const size_t lds = (size_t)DSEL_CAP * sizeof(K) + (size_t)(BINSEL_COPIES * (SEL_RADIX + 1) + 1) * 4 + (size_t)(SEL_RADIX + 4 + 16 + 2) * 8;
         rc = set_big_lds(ctx, nk_dhsel_final_kernel<T>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((nk_dhsel_final_kernel<T>), dim3(1), dim3(HIST_THREADS), lds, ctx->stream, P->cd_cap, ctr + 1, cnt_d, dsel, dsel_keys, ctr,
-                           scratch + OFF_INFO);
+        hipLaunchKernelGGL((nk_dhsel_final_kernel<T>), dim3(1), dim3(HIST_THREADS), lds, ctx->stream, P->cd_cap, ctr + 1, cnt_d, klo_d, khi_d, dsel, dsel_keys,
+                           ctr, scratch + OFF_INFO);
         XD_HIP_CHECK(ctx, hipGetLastError());
     } else {
     hipLaunchKernelGGL(bracket_given_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt_d, 1, given_d, ctr);
