@@ -1994,7 +1994,13 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
     // its smallest and largest key are: if they agree the bucket IS that key and the histogram says the rest (nk_dhsel_final_kernel).
     const bool big = w.group > (unsigned long long)DSEL_CAP;
     __shared__ K s_kmin, s_kmax;
-    if (tid == 0) { s_kmin = ~(K)0; s_kmax = (K)0; }
+    // (the bucket's keys are collected per workgroup first and appended with ONE global atomic: a returning atomic per key on one
+    //  address cost ~15 us for the few hundred keys)
+    constexpr int LOCAL_KEYS = 512;
+    __shared__ K s_keys[LOCAL_KEYS];
+    __shared__ uint32_t s_nkeys, s_base;
+    if (tid == 0) { s_kmin = ~(K)0; s_kmax = (K)0; s_nkeys = 0u; }
+    __syncthreads();
     K bmin = ~(K)0, bmax = (K)0;
     K mn = ~(K)0;
     constexpr int U = 8;
@@ -2016,8 +2022,12 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
                     bmin = key < bmin ? key : bmin;
                     bmax = key > bmax ? key : bmax;
                 } else {
-                    const uint32_t pos = atomicAdd(&hdr[2], 1u);
-                    if (pos < (uint32_t)DSEL_CAP) gkeys[pos] = key;
+                    const uint32_t lp = atomicAdd(&s_nkeys, 1u);
+                    if (lp < (uint32_t)LOCAL_KEYS) s_keys[lp] = key;
+                    else {   // (more than the local buffer takes: straight to the global one)
+                        const uint32_t pos = atomicAdd(&hdr[2], 1u);
+                        if (pos < (uint32_t)DSEL_CAP) gkeys[pos] = key;
+                    }
                 }
             } else if (d > w.bucket && key < mn) {
                 mn = key;
@@ -2031,7 +2041,14 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
         bmin = t1 < bmin ? t1 : bmin;
         bmax = t2 > bmax ? t2 : bmax;
     }
-    __syncthreads();   // (s_kmin / s_kmax set)
+    __syncthreads();
+    {
+        const uint32_t nk = s_nkeys < (uint32_t)LOCAL_KEYS ? s_nkeys : (uint32_t)LOCAL_KEYS;
+        if (tid == 0 && nk) s_base = atomicAdd(&hdr[2], nk);
+        __syncthreads();
+        for (uint32_t i = tid; i < nk; i += blockDim.x)
+            if (s_base + i < (uint32_t)DSEL_CAP) gkeys[s_base + i] = s_keys[i];
+    }
     if (lane == 0 && mn != ~(K)0) k_atomic_min(&s_min, mn);   // (one global atomic per workgroup: they all land on one address)
     if (lane == 0 && big && bmin != ~(K)0) { k_atomic_min(&s_kmin, bmin); k_atomic_max(&s_kmax, bmax); }
     __syncthreads();
