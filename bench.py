@@ -347,11 +347,15 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         xdist.nuth_kaab_row_blocks(ref_rows, tba_rows, m, res, halo=8, ctx=ctx, tolerance=0.0, max_iterations=2)   # warm-up
         barrier()
         t0 = time.perf_counter()
-        offsets, n_valid = xdist.nuth_kaab_row_blocks(ref_rows, tba_rows, m, res, halo=8, ctx=ctx, tolerance=0.0, max_iterations=10)
+        nk_info = {}
+        offsets, n_valid = xdist.nuth_kaab_row_blocks(ref_rows, tba_rows, m, res, halo=8, ctx=ctx, tolerance=0.0, max_iterations=10, info=nk_info)
         barrier()
         dt_fit = (time.perf_counter() - t0) / 10
         dt = dt_fit
-        how = f"row blocks of {world} ranks + halo rows, every reduction of a step through the process group"
+        routes = nk_info.get("routes")
+        red = nk_info.get("reductions", (0, 0))
+        how = (f"row blocks of {world} ranks + halo rows, every reduction of a step through the process group "
+               f"({(red[0] + red[1]) / 10:.1f} all-reduces per iteration: {red[0]} staged through the host, {red[1]} enqueued on the device)")
     # full data passes per iteration: ONE on the one-pass step of round 4 (dh, the counting for its median and the aspect-bin
     # counting against sample brackets in the same pass), two on the queued route of rounds 2-3 (row-partitioned fits)
     onepass = bool(routes and routes["onepass"] > 0 and routes["twopass"] == 0 and routes["plain"] == 0)

@@ -139,6 +139,12 @@ int xdemhip_set_allreduce(xdemhip_ctx* ctx, xdemhip_allreduce_fn fn, void* user)
 typedef int (*xdemhip_allreduce_device_fn)(void* device_array, int64_t count, int kind, void* hip_stream, void* user);
 int xdemhip_set_allreduce_device(xdemhip_ctx* ctx, xdemhip_allreduce_device_fn fn, void* user);
 int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* device_calls);
+/* This process's place among the ranks the hooks reduce over (round 5).  The hooks only combine; a few exchanges of the one-pass
+ * Nuth-Kaab step on partitioned plans need every rank's contribution SEPARATELY (per-rank histogram rows, per-rank slices of a small
+ * key list): they travel as sum all-reduces in which every rank fills its own slot and adds zeros to the others', for which the
+ * library must know `rank` in [0, `world`).  world = 0 (default) = not told: partitioned plans keep the two-pass route.  Ranks
+ * must be numbered the same way on every process of the group (torch.distributed's group rank does). */
+int xdemhip_set_rank(xdemhip_ctx* ctx, int rank, int world);
 
 /* ---- path 1: terrain stencil engine --------------------------------------------------------------
  * Replaces  _get_surface_attributes(dem, resolution, surface_attributes, out_dtype, surface_fit,
@@ -210,8 +216,8 @@ int xdemhip_nk_step(xdemhip_nk_plan* plan, double shift_x, double shift_y, doubl
  * copied from the neighbours (xdem_amd.dist.RowBlock exchanges them over RCCL send / recv).  The gradient needs ONE halo
  * row; the bilinear taps of a step need floor(|shift_y / res_y|) + 1 more, so the halo bounds the vertical shift a fit may
  * reach: xdemhip_nk_step returns XDEMHIP_EINVAL ("halo too small ...") when a step would leave it, and the caller
- * re-creates the plan with a deeper halo.  Install the all-reduce hook BEFORE this call: n_valid is the global count, and
- * every reduction of a step (histograms, counters, min / max keys, successor keys) goes through the hook. */
+ * re-creates the plan with a deeper halo.  Install the all-reduce hook (and xdemhip_set_rank) BEFORE this call: n_valid is the
+ * global count, and every reduction of a step (histograms, counters, min / max keys, successor keys) goes through the hook. */
 int xdemhip_nk_create_block(xdemhip_ctx* ctx, const void* ref_block, const void* tba_block, const uint8_t* inlier_block_or_null,
                             int dtype, int64_t H, int64_t W, int64_t row_begin, int64_t row_end, int64_t halo_top,
                             int64_t halo_bottom, int memspace, xdemhip_nk_plan** out_plan, int64_t* n_valid);
@@ -250,7 +256,11 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uin
  * 2e-6 of the spread on the one-pass route (float32 partial sums, the accuracy class of the reference's own float32
  * np.nanmean).  Context option "nk_binseg" (default 1) selects round 5's forms of the small steps around that one pass --
  * per-bin candidate segments with one workgroup per bin, value-bucket selection of the median of dh, sample passes that
- * advance their own selection states: 24 launches per step -- 0 round 4's generic selections (55); same integers either way. */
+ * advance their own selection states: 24 launches per step -- 0 round 4's generic selections (55); same integers either way.
+ * PARTITIONED plans (reduction hook installed, xdemhip_set_rank told, context option "nk_fused_dist" = 1, the default) take the
+ * one-pass step as well: one data pass over the rank's own rows and TWELVE all-reduces per step (nuthkaab.hip: "the ONE-PASS step
+ * on PARTITIONED plans"), all of them enqueued through the device hook where it is installed; every rank returns the same integers
+ * as a single-GPU fit of the whole rasters (the two-pass route of such plans: two data passes, ~25 all-reduces). */
 int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* twopass, int64_t* plain);
 void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,

@@ -1054,3 +1054,72 @@ def test_onepass_step_hands_degenerate_rasters_to_the_two_pass_route(coreg):
         assert a["vshift"] == b["vshift"] and a["n_valid"] == b["n_valid"]
         assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True)
         assert np.array_equal(a["edges"], b["edges"])
+
+
+def test_onepass_step_on_a_hooked_plan():
+    """Round 5, second half: plans with a reduction hook (the partitioned layout's) take the ONE-PASS step as well -- one data pass over
+    the rank's rows and TWELVE all-reduces per step, all of them enqueued through the device-side hook -- instead of the two-pass route
+    (two data passes, ~25).  On a 1-rank RCCL group: every integer output identical to the hook-less plan's for fractional steps, the
+    aligned pair (ties en masse in dh) included; route and reduction counts asserted; the whole fit stays on the route."""
+    import os
+    import sys
+    import time
+
+    import scipy.optimize
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from xdem_amd import _lib, coreg
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29619")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    dev = torch.device("cuda", 0)
+    ctx = _lib.Context(0)
+    try:
+        ref, tba = bench._c3_pair(dev, 12000)
+        steps = ((0.0, 0.0), (1.7, 0.6), (1.2, 0.9), (-17.0, -6.0), (-16.9998, -5.9996))
+        res, times = {}, {}
+        for mode in ("plain", "hooked", "hooked_twopass"):
+            ctx.set_option("nk_fused_dist", 0 if mode == "hooked_twopass" else 1)
+            plan = coreg.NKPlan(ref, tba, None, ctx, group=None if mode == "plain" else "world")
+            plan.step(0.3, 0.1, (10.0, 10.0), 72)   # (route agreement, buffers, bin cache)
+            h0, d0 = ctx.reduction_calls()
+            r0 = plan.route_counts()
+            t0 = time.perf_counter()
+            res[mode] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in steps]
+            times[mode] = (time.perf_counter() - t0) / len(steps)
+            h1, d1 = ctx.reduction_calls()
+            r1 = plan.route_counts()
+            if mode == "hooked":
+                assert r1["onepass"] - r0["onepass"] == len(steps) and r1["twopass"] == r0["twopass"] and r1["plain"] == r0["plain"], (r0, r1)
+                assert h1 == h0 and d1 - d0 == 12 * len(steps), (h0, h1, d0, d1)
+                off = coreg._iterate(plan, (10.0, 10.0), 0.0, 8, 72, scipy.optimize.curve_fit, True)
+                r2 = plan.route_counts()
+                assert r2["twopass"] == r1["twopass"] and r2["plain"] == r1["plain"] and r2["onepass"] == r1["onepass"] + 8, (r1, r2)
+                assert abs(off[0] + 17.0) < 0.05 and abs(off[1] + 6.0) < 0.05 and abs(off[2] + 2.0) < 0.01, off
+            elif mode == "hooked_twopass":
+                assert r1["twopass"] - r0["twopass"] == len(steps), (r0, r1)
+                red_twopass = (d1 - d0) / len(steps)
+            else:
+                assert r1["onepass"] - r0["onepass"] == len(steps), (r0, r1)
+            plan.close()
+        for a, b, c in zip(res["hooked"], res["plain"], res["hooked_twopass"]):
+            for o in (b, c):
+                assert a["n_valid"] == o["n_valid"] and a["vshift"] == o["vshift"]
+                assert np.array_equal(a["counts"], o["counts"]) and np.array_equal(a["medians"], o["medians"], equal_nan=True)
+                assert np.array_equal(a["edges"], o["edges"])
+            assert _moments_close(a, b, onepass=True)
+        print(f"12000^2 step: hook-less {times['plain'] * 1e3:.2f} ms | hooked one-pass (12 reductions) {times['hooked'] * 1e3:.2f} ms | "
+              f"hooked two-pass ({red_twopass:.0f} reductions) {times['hooked_twopass'] * 1e3:.2f} ms")
+        assert times["hooked"] < times["hooked_twopass"]
+    finally:
+        ctx.set_allreduce(None)
+        ctx.close()
+        if created:
+            dist.destroy_process_group()

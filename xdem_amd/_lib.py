@@ -82,6 +82,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_set_allreduce_device.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_reduction_calls.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        L.xdemhip_set_rank.argtypes = [c_ctx, ctypes.c_int, ctypes.c_int]
         L.xdemhip_last_kernel_ms.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_float)]
         L.xdemhip_terrain.argtypes = [
             c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -300,7 +301,13 @@ class Context:
             self._dev_hook = None
             self.check(self._L.xdemhip_set_allreduce_device(self.handle, None, None))
             self.check(self._L.xdemhip_set_allreduce(self.handle, None, None))
+            self.check(self._L.xdemhip_set_rank(self.handle, 0, 0))
             return
+        import torch.distributed as dist
+
+        pg = None if group == "world" else group
+        # this process's place in the group: some exchanges carry one slot per rank (xdemhip_set_rank, include/xdemhip.h)
+        self.check(self._L.xdemhip_set_rank(self.handle, dist.get_rank(pg), dist.get_world_size(pg)))
         hook = make_reduce_hook(group, self.device)
         CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
         self._hook = CB(hook)  # keep alive

@@ -83,6 +83,14 @@ int xdemhip_set_allreduce_device(xdemhip_ctx* ctx, xdemhip_allreduce_device_fn f
     return XDEMHIP_OK;
 }
 
+int xdemhip_set_rank(xdemhip_ctx* ctx, int rank, int world) {
+    if (!ctx) return XDEMHIP_EINVAL;
+    if (world < 0 || (world > 0 && (rank < 0 || rank >= world))) return xd_fail(ctx, XDEMHIP_EINVAL, "rank must lie in [0, world)");
+    ctx->rank = world > 0 ? rank : 0;
+    ctx->world = world;
+    return XDEMHIP_OK;
+}
+
 int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* device_calls) {
     if (!ctx) return XDEMHIP_EINVAL;
     if (host_calls) *host_calls = ctx->n_red_host;
@@ -340,6 +348,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
     if (std::string(name) == "nk_fused") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_fused: 0 or 1");
         ctx->nk_fused = value;
+        return XDEMHIP_OK;
+    }
+    if (std::string(name) == "nk_fused_dist") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_fused_dist: 0 or 1");
+        ctx->nk_fused_dist = value;
         return XDEMHIP_OK;
     }
     if (std::string(name) == "nk_binseg") {

@@ -28,6 +28,8 @@ struct xdemhip_ctx {
     xdemhip_allreduce_device_fn allreduce_dev = nullptr;  // device-side form of the hook (device arrays stay on the device)
     void* allreduce_dev_user = nullptr;
     int64_t n_red_host = 0, n_red_dev = 0;     // reductions that went through the host / the device hook
+    int rank = 0, world = 0;                   // xdemhip_set_rank: this process's place among the ranks the hooks reduce over (world 0: not told)
+    int nk_fused_dist = 1;   // option "nk_fused_dist": 1 partitioned Nuth-Kaab plans (reduction hook + xdemhip_set_rank) take the one-pass step too: 12 all-reduces per step (default), 0 the two-pass route of round 3 (~25)
     int host_chunk_rows = 0; // option "host_chunk_rows": rows per chunk of host-buffer terrain calls (0 = from the budget); the mp_config tile size
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
     int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)
@@ -155,6 +157,14 @@ inline int xd_allreduce_device(xdemhip_ctx* ctx, void* dptr, int64_t count, int 
     e = hipMemcpyAsync(dptr, &buf[0], buf.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce staging (H2D) failed");
+    return XDEMHIP_OK;
+}
+
+// A small HOST array through the host hook: the route agreements, made once per plan (like the per-step agreements of the two-pass
+// route they are not counted by xdemhip_reduction_calls, which counts the data reductions of the steps).
+inline int xd_allreduce_host(xdemhip_ctx* ctx, void* hptr, int64_t count, int kind) {
+    if (!ctx->allreduce || count <= 0) return XDEMHIP_OK;
+    if (ctx->allreduce(hptr, count, kind, ctx->allreduce_user) != 0) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");
     return XDEMHIP_OK;
 }
 

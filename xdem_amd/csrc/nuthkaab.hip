@@ -1585,7 +1585,9 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_resolve_scatter_kernel(const 
                                                                           const T* vshift_p, int nb, const typename KeyT<T>::type* __restrict__ klo,
                                                                           const typename KeyT<T>::type* __restrict__ khi, const uint64_t* __restrict__ cls /* [3][nb] */,
                                                                           uint64_t* res /* [2][nb] */, unsigned long long* seg_ctr /* [nb], zeroed */,
-                                                                          T* __restrict__ seg_v, int64_t seg_cap, unsigned long long* ctr /* [2] overflow */) {
+                                                                          T* __restrict__ seg_v, int64_t seg_cap, unsigned long long* ctr /* [2] overflow */,
+                                                                          const uint64_t* __restrict__ cls_lay = nullptr /* partitioned plans: THIS rank's classes (the
+                                                                              segments hold this rank's candidates; `cls` is the sum over the ranks by then) */) {
     typedef typename KeyT<T>::type K;
     extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
     unsigned long long* off = reinterpret_cast<unsigned long long*>(fz_smem);   // [nb] first slot of the bin's segment
@@ -1595,13 +1597,14 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_resolve_scatter_kernel(const 
     K* hi = lo + nb;
     uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);   // [2][nb] below / inside (this workgroup)
     uint32_t* lcnt = c + 2 * nb;                           // [nb] kept values of the round
+    const uint64_t* lay = cls_lay ? cls_lay : cls;
     for (int k = threadIdx.x; k < nb; k += blockDim.x) {
-        lo[k] = klo[k]; hi[k] = khi[k]; lcnt[k] = 0u; room[k] = cls[2 * nb + k];
+        lo[k] = klo[k]; hi[k] = khi[k]; lcnt[k] = 0u; room[k] = lay[2 * nb + k];
     }
     for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x) c[k] = 0u;
     if (threadIdx.x == 0) {
         unsigned long long acc = 0;
-        for (int k = 0; k < nb; ++k) { off[k] = acc; acc += cls[2 * nb + k]; }
+        for (int k = 0; k < nb; ++k) { off[k] = acc; acc += lay[2 * nb + k]; }
     }
     __syncthreads();
     const unsigned long long m = *n_dev;
@@ -1669,7 +1672,8 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bin_select_kernel(const T* __
                                                                      const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
                                                                      const uint32_t* rbs_p,
                                                                      SelState<typename KeyT<T>::type>* st_out, uint64_t* succ_out, uint64_t* cnt_out /* [3][nb] */,
-                                                                     unsigned long long* ctr /* [2] overflow, [3] miss */) {
+                                                                     unsigned long long* ctr /* [2] overflow, [3] miss */,
+                                                                     int64_t seg_stride = 0 /* > 0: bin b's values start at b * seg_stride (partitioned plans) */) {
     typedef typename KeyT<T>::type K;
     constexpr int P = KeyT<T>::passes;
     constexpr int CAPK = BINSEL_KEY_BYTES / (int)sizeof(K);
@@ -1687,7 +1691,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bin_select_kernel(const T* __
         cnt_out[b] = total; cnt_out[nb + b] = lt; cnt_out[2 * nb + b] = in;
         unsigned long long acc = 0;
         for (int k = 0; k < b; ++k) acc += cls[2 * nb + k];
-        *s_off = acc;
+        *s_off = seg_stride > 0 ? (unsigned long long)b * (unsigned long long)seg_stride : acc;
         *s_min = ~(K)0;
         *s_cnt = 0u;
     }
@@ -1917,7 +1921,8 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_hist_kernel(const T* __
 struct DselWhere { bool run; int bucket; unsigned long long rank, below, group; };
 template <typename T>
 __device__ __forceinline__ DselWhere dsel_locate(const uint64_t* cnt, int64_t n, const uint32_t* hist, unsigned long long* s_pick /* [3] */,
-                                                 unsigned long long* s_wsum /* [16] */, unsigned long long* ctr, bool report, bool exact) {
+                                                 unsigned long long* s_wsum /* [16] */, unsigned long long* ctr, bool report, bool exact,
+                                                 bool check_n = true /* false on partitioned plans: `n` is this rank's share of the candidates */) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     DselWhere w;
     w.run = false; w.bucket = 0; w.rank = 0; w.below = 0; w.group = 0;
@@ -1927,7 +1932,7 @@ __device__ __forceinline__ DselWhere dsel_locate(const uint64_t* cnt, int64_t n,
         const uint64_t k = (total - 1) / 2, need = (total & 1) ? k : k + 1;
         if (lt > k || need - lt >= in) { if (report && tid == 0) ctr[3] = 1ull; return w; }
         w.rank = k - lt;
-        if ((uint64_t)n != in) { if (report && tid == 0) ctr[2] = 1ull; return w; }   // (the buffer does not hold what the counters say)
+        if (check_n && (uint64_t)n != in) { if (report && tid == 0) ctr[2] = 1ull; return w; }   // (the buffer does not hold what the counters say)
     }
     // block scan of the 4096 counts (thread t owns buckets 4 t .. 4 t + 3)
     unsigned long long cq[4], mine = 0;
@@ -1976,7 +1981,8 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
                                                                        const uint64_t* __restrict__ cnt /* total, below, inside */,
                                                                        const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
                                                                        uint32_t* hdr /* DSEL_HDR_WORDS 64-bit words, then the histogram */,
-                                                                       typename KeyT<T>::type* gkeys /* [DSEL_CAP] */, unsigned long long* ctr) {
+                                                                       typename KeyT<T>::type* gkeys /* [DSEL_CAP] */, unsigned long long* ctr,
+                                                                       int check_n = 1) {
     typedef typename KeyT<T>::type K;
     __shared__ unsigned long long s_pick[4], s_wsum[16];
     __shared__ K s_min;
@@ -1987,7 +1993,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_gather_kernel(const T* 
     const DselMap<K> mp = dsel_map<T, K>(*klo, *khi);
     const bool exact = mp.keyspace && mp.shift == 0;
     if (exact) return;    // (a bucket is a key: the histogram says everything -- nk_dhsel_final_kernel)
-    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, blockIdx.x == 0, false);
+    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, blockIdx.x == 0, false, check_n != 0);
     if (!w.run) return;   // (uniform over the grid; the final kernel hands back NaN)
     // A bucket with more values than the key buffer takes: ties.  (dh of a well-aligned float32 pair is a difference of elevations of
     // ~1e3 m: a multiple of their ulp, 1.2e-4 m -- a dozen distinct values carry millions of candidates.)  Its keys are not gathered;
@@ -2065,7 +2071,7 @@ template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t cap, const unsigned long long* n_dev, const uint64_t* __restrict__ cnt,
                                                                       const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
                                                                       const uint32_t* hdr, const typename KeyT<T>::type* gkeys, unsigned long long* ctr,
-                                                                      unsigned char* info) {
+                                                                      unsigned char* info, int check_n = 1) {
     typedef typename KeyT<T>::type K;
     constexpr int P = KeyT<T>::passes;
     extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
@@ -2088,7 +2094,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t ca
     if (tid == 0) *s_min = ~(K)0;
     const DselMap<K> mp = dsel_map<T, K>(*klo, *khi);
     const bool exact = mp.keyspace && mp.shift == 0;
-    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, true, exact);
+    const DselWhere w = dsel_locate<T>(cnt, n, hdr + 2 * DSEL_HDR_WORDS, s_pick, s_wsum, ctr, true, exact, check_n != 0);
     const unsigned long long* hdr64 = reinterpret_cast<const unsigned long long*>(hdr);
     const bool big = w.run && !exact && w.group > (unsigned long long)DSEL_CAP;
     K one_key = (K)0;
@@ -2225,6 +2231,283 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t ca
     }
 }
 
+// ---- round 5 (second half): the ONE-PASS step on PARTITIONED plans ---------------------------------------------------------------
+// With a reduction hook (row blocks over ranks, one process per GPU) the step used to take the two-pass route: ~25 small all-reduces and
+// two data passes.  The one-pass step needs, besides its data pass over THIS rank's rows, global counters and global order statistics
+// among candidates that are spread over the ranks.  Everything that crosses ranks is an all-reduce of 8-byte words through the hook
+// (sum / min), TWELVE per step:
+//   1     min / max aspect of the EXT lists + survivors                          (4 words, MIN: maxima travel complemented)
+//   2-4   the dh sample's dual bracket selection: one histogram per digit        (select_enqueue, as on the two-pass route)
+//   5-7   the y^ sample's dual bracket selection of the 72 bins
+//   8     the pass's counters (cnt_d[3], cls_y[3][nb]) + every rank's five float64 sums, each in ITS OWN slot (all other ranks add
+//         zeros there): a sum all-reduce used as an all-gather, so the float64 sums are added in rank order on every rank --
+//         the same bits everywhere, whatever the reduction tree
+//   9     the 4096-bucket histogram of the dh candidates, ONE ROW PER RANK (same trick): every rank then knows the global histogram
+//         -- hence the bucket that holds the wanted rank -- and how many of that bucket's keys each rank holds, i.e. where its own
+//         keys go in the bucket's global key list
+//   10    that key list (each rank writes its keys at its offset, zeros elsewhere) + the gather's header words per rank; then the
+//         single-GPU final kernel runs on it unchanged, on every rank: same vshift everywhere
+//   11    per bin: the 256-value-bucket histogram of this rank's segment of kept y, one row per rank, + the resolved counters
+//   12    per bin: the chosen bucket's values of all ranks + the smallest value above the bucket of every rank that has one, at
+//         offsets known from 11, in a fixed stride of MR_GSEG values per bin; the single-GPU `nk_bin_select_kernel` then runs on that
+//         small array with counters rewritten so that the wanted rank, the count below and the successor rule come out as on the
+//         whole set (elements below the bucket are counted into "below", nothing above the first value above the bucket matters)
+// All integers, the same keys, the same selection code: medians, counts, vshift are the single-GPU fit's bit for bit (GPU test:
+// 2 ranks == 1 process).  Failure flags that only one rank can see (a buffer overflow) travel with 11; flags raised later derive
+// from reduced data and are identical on every rank, so all ranks fall through to the two-pass route together or not at all.
+constexpr int MR_WORLD_MAX = 16;
+constexpr int MR_GSEG = 2048;   // values per bin in exchange 12 (the chosen bucket of a bin holds a few hundred)
+
+static __global__ void nk_mr_ext_pack_kernel(const DhStats* s, const unsigned long long* surv, uint64_t* red) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    red[0] = s->asp_min; red[1] = ~s->asp_max; red[2] = ~(uint64_t)surv[0]; red[3] = ~(uint64_t)surv[1];
+}
+static __global__ void nk_mr_ext_unpack_kernel(const uint64_t* red, DhStats* s, unsigned long long* surv) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    s->asp_min = red[0]; s->asp_max = ~red[1]; surv[0] = (unsigned long long)~red[2]; surv[1] = (unsigned long long)~red[3];   // (survivors: the largest count of a rank -- only "none" matters)
+}
+// exchange 8: [0, 3) cnt_d | [3, 3 + 3 nb) cls_y | [world][5] float64 sums, slot of this rank only
+static __global__ __launch_bounds__(256) void nk_mr_counts_pack_kernel(const uint64_t* cnt_d, const uint64_t* cls_y, const double* sums, int nb, int rank,
+                                                                        int world, uint64_t* red, uint64_t* cls_loc) {
+    const int nsum = 3 + 3 * nb, total = nsum + 5 * world;
+    for (int k = threadIdx.x; k < total; k += blockDim.x) {
+        uint64_t v = 0;
+        if (k < 3) v = cnt_d[k];
+        else if (k < nsum) { v = cls_y[k - 3]; cls_loc[k - 3] = v; }
+        else if ((k - nsum) / 5 == rank) v = (uint64_t)__double_as_longlong(sums[(k - nsum) % 5]);
+        red[k] = v;
+    }
+}
+static __global__ __launch_bounds__(256) void nk_mr_counts_unpack_kernel(const uint64_t* red, int nb, int world, uint64_t* cnt_d, uint64_t* cls_y, double* sums) {
+    const int nsum = 3 + 3 * nb;
+    for (int k = threadIdx.x; k < nsum; k += blockDim.x) {
+        if (k < 3) cnt_d[k] = red[k];
+        else cls_y[k - 3] = red[k];
+    }
+    if (threadIdx.x < 5) {
+        double a = 0.0;
+        for (int r = 0; r < world; ++r) a += __longlong_as_double((long long)red[nsum + 5 * r + threadIdx.x]);   // (rank order: the same bits on every rank)
+        sums[threadIdx.x] = a;
+    }
+}
+// after exchange 9: the global histogram (sum of the rows) into the selection's own place, the bucket of the wanted rank, and where
+// this rank's keys of that bucket go in the global key list: hdr[2] (the gather's append counter) starts there, hdr[3] remembers it
+template <typename T>
+__global__ __launch_bounds__(HIST_THREADS) void nk_mr_dh_base_kernel(const uint32_t* __restrict__ rows /* [world][DSEL_BUCKETS] */, int world, int rank,
+                                                                     const uint64_t* __restrict__ cnt, const typename KeyT<T>::type* klo,
+                                                                     const typename KeyT<T>::type* khi, uint32_t* hdr, unsigned long long* ctr) {
+    typedef typename KeyT<T>::type K;
+    __shared__ unsigned long long s_pick[4], s_wsum[16];
+    uint32_t* hist = hdr + 2 * DSEL_HDR_WORDS;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int d = 4 * tid + q;
+        uint32_t t = 0;
+        for (int r = 0; r < world; ++r) t += rows[(size_t)r * DSEL_BUCKETS + d];
+        hist[d] = t;   // (read back below by the thread that wrote it)
+    }
+    const DselMap<K> mp = dsel_map<T, K>(*klo, *khi);
+    if (mp.keyspace && mp.shift == 0) return;   // a bucket is a key: nothing is gathered
+    const DselWhere w = dsel_locate<T>(cnt, 0, hist, s_pick, s_wsum, ctr, false, false, false);
+    if (!w.run) return;
+    if (tid == 0) {
+        uint32_t base = 0;
+        for (int r = 0; r < rank; ++r) base += rows[(size_t)r * DSEL_BUCKETS + w.bucket];
+        hdr[2] = base;
+        hdr[3] = base;
+    }
+}
+// exchange 10, before: this rank's header words into its slot; after: the headers of all ranks folded (maxima; keys appended = sum of
+// what every rank appended behind its base)
+static __global__ void nk_mr_dh_hdr_pack_kernel(const uint32_t* hdr, int rank, uint64_t* slots /* [world][DSEL_HDR_WORDS] */) {
+    if (threadIdx.x < DSEL_HDR_WORDS && blockIdx.x == 0)
+        slots[(size_t)rank * DSEL_HDR_WORDS + threadIdx.x] = reinterpret_cast<const uint64_t*>(hdr)[threadIdx.x];
+}
+static __global__ void nk_mr_dh_hdr_merge_kernel(const uint64_t* slots, int world, uint32_t* hdr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t m0 = 0, m2 = 0, m3 = 0, got = 0;
+    for (int r = 0; r < world; ++r) {
+        const uint64_t* sl = slots + (size_t)r * DSEL_HDR_WORDS;
+        m0 = sl[0] > m0 ? sl[0] : m0;
+        m2 = sl[2] > m2 ? sl[2] : m2;
+        m3 = sl[3] > m3 ? sl[3] : m3;
+        got += (uint64_t)(uint32_t)sl[1] - (uint64_t)(uint32_t)(sl[1] >> 32);
+    }
+    uint64_t* h64 = reinterpret_cast<uint64_t*>(hdr);
+    h64[0] = m0; h64[1] = got; h64[2] = m2; h64[3] = m3;
+}
+// exchange 11, before: one workgroup per bin histograms THIS rank's segment of kept y into the 256 value buckets of the bin's bracket
+// (nk_bin_select_kernel's map), its row of red; the resolved counters of the rank; flags only this rank may know
+// red: [0] overflow, [1] miss | res [2][nb] | rows [world][nb][256] (uint32)
+template <typename T>
+__global__ __launch_bounds__(256) void nk_mr_bin_hist_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls_loc /* [3][nb] */,
+                                                             const uint64_t* __restrict__ res /* [2][nb], this rank */, const unsigned long long* seg_ctr,
+                                                             int nb, const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
+                                                             int rank, int world, uint64_t* red, const unsigned long long* ctr) {
+    typedef typename KeyT<T>::type K;
+    __shared__ uint32_t h[SEL_RADIX];
+    __shared__ unsigned long long s_off;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    h[tid] = 0u;
+    const unsigned long long n = seg_ctr[(size_t)b * BINSEG_CTR_STRIDE];
+    if (tid == 0) {
+        unsigned long long acc = 0;
+        for (int k = 0; k < b; ++k) acc += cls_loc[2 * nb + k];
+        s_off = acc;
+        red[2 + b] = res[b];
+        red[2 + nb + b] = res[nb + b];
+        if (n != res[nb + b]) atomicAdd(reinterpret_cast<unsigned long long*>(&red[0]), 1ull);   // (the segment does not hold what the counters say)
+        if (b == 0) {
+            if (ctr[2] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&red[0]), 1ull);
+            if (ctr[3] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&red[1]), 1ull);
+        }
+    }
+    __syncthreads();
+    const T* v = seg_v + s_off;
+    const BinsegMap mp = binseg_map<T, K>(klo[b], khi[b]);
+    for (unsigned long long i = tid; i < n; i += blockDim.x) {
+        const T x = v[i];
+        if (x == x) atomicAdd(&h[binseg_bucket<T>(x, mp)], 1u);
+    }
+    __syncthreads();
+    uint32_t* rows = reinterpret_cast<uint32_t*>(red + 2 + 2 * nb);
+    rows[((size_t)rank * nb + b) * SEL_RADIX + tid] = h[tid];
+}
+// exchange 12, before: per bin the bucket that holds the wanted rank (from the summed rows), this rank's values of that bucket and its
+// smallest value above it into the bin's stride of `gseg` at the offsets the rows give; the counters nk_bin_select_kernel will read,
+// rewritten for the small array (see the block comment); the true (total, below, inside) for the host's bracket statistics
+template <typename T>
+__global__ __launch_bounds__(256) void nk_mr_bin_gather_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls_loc, const uint64_t* __restrict__ cls /* summed */,
+                                                               const uint64_t* __restrict__ red /* exchange 11, summed */, const unsigned long long* seg_ctr, int nb,
+                                                               const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
+                                                               int rank, int world, T* __restrict__ gseg /* [nb][MR_GSEG], zeroed */, uint64_t* cls_f /* [3][nb] */,
+                                                               uint64_t* res_f /* [2][nb] */, unsigned long long* segf_ctr, uint64_t* cnt_true /* [3][nb] */,
+                                                               unsigned long long* ctr) {
+    typedef typename KeyT<T>::type K;
+    __shared__ unsigned long long s_g[SEL_RADIX];
+    __shared__ unsigned long long s_pick[3];
+    __shared__ uint32_t s_mloc[MR_WORLD_MAX], s_above[MR_WORLD_MAX];
+    __shared__ uint32_t s_cnt;
+    __shared__ K s_min;
+    __shared__ unsigned long long s_off;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const uint64_t* res_g = red + 2;
+    const uint32_t* rows = reinterpret_cast<const uint32_t*>(red + 2 + 2 * nb);
+    if (b == 0 && tid == 0) {   // what some rank flagged before the exchange holds for every rank
+        if (red[0] != 0) ctr[2] = 1ull;
+        if (red[1] != 0) ctr[3] = 1ull;
+    }
+    const uint64_t total = cls[b] + cls[nb + b] + cls[2 * nb + b], lt = cls[nb + b] + res_g[b], in = res_g[nb + b];
+    auto hand_over = [&](uint64_t below, uint64_t g) {   // (thread 0) the counters of the small array: total kept, `below` certainly below it
+        cls_f[b] = g ? total - below - g : 0; cls_f[nb + b] = g ? below : 0; cls_f[2 * nb + b] = g;
+        res_f[b] = 0; res_f[nb + b] = g;
+        segf_ctr[(size_t)b * BINSEG_CTR_STRIDE] = g;
+        cnt_true[b] = total; cnt_true[nb + b] = lt; cnt_true[2 * nb + b] = in;
+    };
+    bool run = total != 0;
+    uint64_t rk = 0;
+    if (run) {   // (the rule of bracket_given_kernel, as in nk_bin_select_kernel)
+        const uint64_t k = (total - 1) / 2, need = (total & 1) ? k : k + 1;
+        if (lt > k || need - lt >= in) { run = false; if (tid == 0) ctr[3] = 1ull; }
+        else rk = k - lt;
+    }
+    if (tid == 0) {
+        s_cnt = 0u; s_min = ~(K)0; s_pick[2] = ~0ull;
+        unsigned long long acc = 0;
+        for (int k = 0; k < b; ++k) acc += cls_loc[2 * nb + k];
+        s_off = acc;
+    }
+    if (!run) {   // (uniform) an empty bin, or a bracket that missed: the selection kernel sees an empty bin
+        if (tid == 0) hand_over(0, 0);
+        return;
+    }
+    {
+        unsigned long long t = 0;
+        for (int r = 0; r < world; ++r) t += rows[((size_t)r * nb + b) * SEL_RADIX + tid];
+        s_g[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 64) {   // one wave: lane l owns buckets 4 l .. 4 l + 3 (nk_bin_select_kernel's pick)
+        unsigned long long cq[4], mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { cq[q] = s_g[4 * lane + q]; mine += cq[q]; }
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const unsigned long long excl = incl - mine;
+        if (rk >= excl && rk < incl) {
+            unsigned long long cum = excl;
+            int q = 0;
+            if (cum + cq[0] <= rk) { cum += cq[0]; q = 1;
+                if (cum + cq[1] <= rk) { cum += cq[1]; q = 2;
+                    if (cum + cq[2] <= rk) { cum += cq[2]; q = 3; } } }
+            s_pick[0] = (unsigned long long)(4 * lane + q);
+            s_pick[1] = cum;
+            s_pick[2] = q == 0 ? cq[0] : (q == 1 ? cq[1] : (q == 2 ? cq[2] : cq[3]));
+        }
+    }
+    __syncthreads();
+    if (s_pick[2] == ~0ull) {   // (inconsistent rows: cannot happen -- the same on every rank, they are summed data)
+        if (tid == 0) { ctr[2] = 1ull; hand_over(0, 0); }
+        return;
+    }
+    const int d1 = (int)s_pick[0];
+    const unsigned long long below_d1 = s_pick[1], m = s_pick[2];
+    if (tid < world) {
+        const uint32_t* row = rows + ((size_t)tid * nb + b) * SEL_RADIX;
+        uint32_t above = 0;
+        for (int d = d1 + 1; d < SEL_RADIX; ++d) above |= row[d];
+        s_mloc[tid] = row[d1];
+        s_above[tid] = above ? 1u : 0u;
+    }
+    __syncthreads();
+    unsigned long long g = m, base = 0;
+    for (int r = 0; r < world; ++r) {
+        g += s_above[r];
+        if (r < rank) base += (unsigned long long)s_mloc[r] + s_above[r];
+    }
+    if (g > (unsigned long long)MR_GSEG) {   // (uniform, and the same on every rank)
+        if (tid == 0) { ctr[2] = 1ull; hand_over(0, 0); }
+        return;
+    }
+    const T* v = seg_v + s_off;
+    const unsigned long long n = seg_ctr[(size_t)b * BINSEG_CTR_STRIDE];
+    const BinsegMap mp = binseg_map<T, K>(klo[b], khi[b]);
+    T* out = gseg + (size_t)b * MR_GSEG + base;
+    const uint32_t mine = s_mloc[rank];
+    K mn = ~(K)0;
+    for (unsigned long long i = tid; i < n; i += blockDim.x) {
+        const T x = v[i];
+        if (x != x) continue;
+        const int d = binseg_bucket<T>(x, mp);
+        if (d == d1) {
+            const uint32_t pos = atomicAdd(&s_cnt, 1u);
+            if (pos < mine) out[pos] = x;
+        } else if (d > d1) {
+            const K key = key_of(x);
+            mn = key < mn ? key : mn;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const K t = k_shfl_down(mn, o);
+        mn = t < mn ? t : mn;
+    }
+    if (lane == 0 && mn != ~(K)0) k_atomic_min(&s_min, mn);
+    __syncthreads();
+    if (tid == 0) {
+        if (s_cnt != mine) ctr[2] = 1ull;   // (the segment changed between the two reads: cannot happen)
+        if (s_above[rank]) {
+            if (s_min != ~(K)0) out[mine] = val_of(s_min);
+            else ctr[2] = 1ull;
+        }
+        hand_over(lt + below_d1, g);
+    }
+}
+
 // every small result of a step gathered into one block (one device-to-host copy instead of ten)
 struct FzPack { const unsigned char* src[12]; uint32_t bytes[12]; uint32_t off[12]; int n; unsigned char* dst; };
 static __global__ __launch_bounds__(256) void nk_fz_pack_kernel(FzPack a) {
@@ -2280,6 +2563,14 @@ struct xdemhip_nk_plan {
     double fz_worst = 0.0;   // largest |wanted rank - bracket centre| seen, in half widths of the FULL rule
     double fz_off2 = 0.0;    // sum of squares of those offsets over all brackets of all steps so far
     int64_t fz_offn = 0;
+    // one-pass step on PARTITIONED plans (reduction hook + xdemhip_set_rank): the two exchange buffers, this rank's own classes and the
+    // counters rewritten for the gathered bucket values (nk_mr_* kernels); the ranks' agreement on the route, renewed when what it rests
+    // on changes
+    uint64_t *mr_a = nullptr, *mr_b = nullptr, *mr_small = nullptr;
+    size_t mr_a_words = 0, mr_b_words = 0;
+    int64_t mr_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    bool mr_can = false;
+    int64_t mr_nglob = 0;
     void* scratch = nullptr;  // edges, stats, sums, selection states, successor keys, histograms
     size_t scratch_bytes = 0;
     int max_bins = 0;
@@ -2337,20 +2628,36 @@ template <typename T> int nk_aux_typed(xdemhip_nk_plan* P) {
     P->n_valid0 = (long long)c;
     // EXT route (see nk_ext_build_kernel): single-GPU plans only -- with a reduction hook every rank would have to agree on
     // the route at every step; the sharded plans keep reading mask and aspect
+    // Partitioned plans (round 5, second half): every rank lists ITS extreme-aspect pixels against the same thresholds (the valid
+    // count is the global one), min / max aspect of a step are the min / max over the ranks' survivors, and the lists are usable if
+    // no rank's overflowed and each kind has a pixel on SOME rank -- agreed once, here.
     P->ext_ok = false;
-    if (P->ref_m && !ctx->allreduce && rows > 0 && P->n_valid0 >= 8 * (long long)EXT_TARGET) {
-        const double frac = (double)EXT_TARGET / (double)P->n_valid0;
-        const T thr_lo = (T)(6.283185307179586 * frac), thr_hi = (T)(6.283185307179586 * (1.0 - frac));
-        const int64_t q0 = (P->row0 - P->roff) * P->W, nown = rows * P->W;
-        XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt, 0, 32, ctx->stream));
-        hipLaunchKernelGGL((nk_ext_build_kernel<T>), dim3(grid_for(ctx, nown, 256, 16)), dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),
-                           P->valid, static_cast<const T*>(P->aspect), q0, nown, thr_lo, thr_hi, static_cast<T*>(P->ref_m), P->ext_idx, P->ext_cnt);
-        XD_HIP_CHECK(ctx, hipGetLastError());
+    const bool mr = ctx->allreduce != nullptr;
+    if (mr && !(ctx->nk_fused_dist != 0 && ctx->world >= 1 && ctx->world <= MR_WORLD_MAX)) return XDEMHIP_OK;
+    if (P->n_valid0 >= 8 * (long long)EXT_TARGET) {   // (the same decision on every rank)
+        const bool local_ok = P->ref_m != nullptr && rows > 0;
         unsigned long long ec[2] = {0, 0};
-        { const int rc_ = xd_d2h(ctx, ec, P->ext_cnt, 16); if (rc_) return rc_; }
-        { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+        if (local_ok) {
+            const double frac = (double)EXT_TARGET / (double)P->n_valid0;
+            const T thr_lo = (T)(6.283185307179586 * frac), thr_hi = (T)(6.283185307179586 * (1.0 - frac));
+            const int64_t q0 = (P->row0 - P->roff) * P->W, nown = rows * P->W;
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt, 0, 32, ctx->stream));
+            hipLaunchKernelGGL((nk_ext_build_kernel<T>), dim3(grid_for(ctx, nown, 256, 16)), dim3(256), 0, ctx->stream, static_cast<const T*>(P->ref),
+                               P->valid, static_cast<const T*>(P->aspect), q0, nown, thr_lo, thr_hi, static_cast<T*>(P->ref_m), P->ext_idx, P->ext_cnt);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+            { const int rc_ = xd_d2h(ctx, ec, P->ext_cnt, 16); if (rc_) return rc_; }
+            { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+        }
         // (aspects far from uniform -- a tilted plane, a raster of one slope direction -- leave a list empty or overfull)
-        P->ext_ok = ec[0] >= 1 && ec[0] <= (unsigned long long)EXT_CAP && ec[1] >= 1 && ec[1] <= (unsigned long long)EXT_CAP;
+        const bool over = ec[0] > (unsigned long long)EXT_CAP || ec[1] > (unsigned long long)EXT_CAP;
+        if (mr) {
+            uint64_t v[3] = {ec[0], ec[1], (uint64_t)((!local_ok || over) ? 1 : 0)};
+            const int rc_ = xd_allreduce_host(ctx, v, 3, XDEMHIP_RED_SUM_U64);
+            if (rc_) return rc_;
+            P->ext_ok = v[2] == 0 && v[0] >= 1 && v[1] >= 1;
+        } else {
+            P->ext_ok = local_ok && !over && ec[0] >= 1 && ec[1] >= 1;
+        }
     }
     return XDEMHIP_OK;
 }
@@ -2588,6 +2895,31 @@ int nk_stage_a(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int n
 }
 
 
+// exchange buffers of the one-pass step on partitioned plans, sized for `nb` bins and `world` ranks (see the nk_mr_* kernels)
+int nk_mr_alloc(xdemhip_nk_plan* P, int nb, int world, size_t es) {
+    auto mx = [](size_t a, size_t b) { return a > b ? a : b; };
+    const size_t wa = mx(mx(4, 3 + 3 * (size_t)nb + 5 * (size_t)world), mx((size_t)world * (DSEL_BUCKETS / 2), 2 + 2 * (size_t)nb + (size_t)world * nb * (SEL_RADIX / 2)));
+    const size_t wb = mx((size_t)world * DSEL_HDR_WORDS + (size_t)DSEL_CAP * es / 8, (size_t)nb * MR_GSEG * es / 8);
+    if (!P->mr_small && hipMalloc(reinterpret_cast<void**>(&P->mr_small), (size_t)(11 + BINSEG_CTR_STRIDE) * P->ws.nb_max * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        P->mr_small = nullptr;
+        return XDEMHIP_ENOMEM;
+    }
+    if (P->mr_a_words < wa) {
+        if (P->mr_a) (void)hipFree(P->mr_a);
+        P->mr_a = nullptr; P->mr_a_words = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&P->mr_a), wa * 8) != hipSuccess) { (void)hipGetLastError(); P->mr_a = nullptr; return XDEMHIP_ENOMEM; }
+        P->mr_a_words = wa;
+    }
+    if (P->mr_b_words < wb) {
+        if (P->mr_b) (void)hipFree(P->mr_b);
+        P->mr_b = nullptr; P->mr_b_words = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&P->mr_b), wb * 8) != hipSuccess) { (void)hipGetLastError(); P->mr_b = nullptr; return XDEMHIP_ENOMEM; }
+        P->mr_b_words = wb;
+    }
+    return XDEMHIP_OK;
+}
+
 // ---- host side of the one-pass step (device code: "Round 4: the ONE-PASS step" above) ------------------------------------------
 // *done = false (nothing returned) when the route does not apply or when a bracket missed / a buffer overflowed: the caller
 // then runs the two-pass route of round 3, which needs nothing from here.
@@ -2600,12 +2932,36 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     SelWorkspace* ws = &P->ws;
     const int64_t rows = P->row1 - P->row0;
     const int64_t n_slots = ((((n + SEL_LINE - 1) >> SEL_LINE_LOG2) + 63) >> 6) << SEL_LINE_LOG2;
-    if (!ctx->nk_fused || ctx->allreduce || !P->fz || !P->cd_vals || !P->c_st || !P->bcache || !P->ext_ok || (g.rule > 1 && !P->badbits) || rows <= 0 ||
-        P->bin_stat != XDEMHIP_BINSTAT_MEDIAN || !(ctx->selection_mode == 0 || ctx->selection_mode == 3) || !ws->d_small ||
-        ws->es != sizeof(T) || nb > ws->nb_max || nb > MAX_BINS_PER_SWEEP || n < SEL_BRACKET_MIN_N ||
-        (ctx->selection_mode == 0 && n < SEL_BRACKET_MIN_PER_BIN * nb) || n_slots > ws->s_cap ||
-        (int64_t)(NKZ_CHUNK_MAX + 2) * P->W * (int64_t)sizeof(T) >= ((int64_t)1 << 32))   // (32-bit byte offsets inside a chunk of rows)
+    const bool mr = ctx->allreduce != nullptr;   // a partitioned plan: this rank's rows, every count and order statistic over all ranks
+    const int world = ctx->world, rank = ctx->rank;
+    bool cannot = !ctx->nk_fused || !P->fz || !P->cd_vals || !P->c_st || !P->bcache || !P->ext_ok || (g.rule > 1 && !P->badbits) || rows <= 0 ||
+                  P->bin_stat != XDEMHIP_BINSTAT_MEDIAN || !(ctx->selection_mode == 0 || ctx->selection_mode == 3) || !ws->d_small ||
+                  ws->es != sizeof(T) || nb > ws->nb_max || nb > MAX_BINS_PER_SWEEP || n_slots > ws->s_cap ||
+                  (int64_t)(NKZ_CHUNK_MAX + 2) * P->W * (int64_t)sizeof(T) >= ((int64_t)1 << 32);   // (32-bit byte offsets inside a chunk of rows)
+    int64_t n_all = n;   // pixels of all ranks
+    if (mr) {
+        // Every rank must take the same route.  What the decision rests on is either fixed for the plan and its options or derives
+        // from reduced data (ext_ok), so the ranks agree ONCE -- a host all-reduce of (own pixels, "I cannot") -- and again whenever
+        // any of it changes, which it does on all ranks at the same step.
+        const int64_t key[8] = {nb, P->row0, P->row1, (int64_t)P->ext_ok, (int64_t)P->bin_stat, (int64_t)ctx->selection_mode,
+                                (int64_t)(ctx->nk_fused * 4 + ctx->nk_fused_dist * 2 + ctx->nk_binseg), (int64_t)world * 64 + rank};
+        if (memcmp(key, P->mr_key, sizeof key) != 0) {
+            cannot = cannot || !ctx->nk_fused_dist || ctx->nk_binseg == 0 || world < 1 || world > MR_WORLD_MAX || rank < 0 || rank >= world ||
+                     (int64_t)P->nbuf * P->W < ws->c_cap;
+            if (!cannot && nk_mr_alloc(P, nb, world, sizeof(T)) != XDEMHIP_OK) cannot = true;
+            uint64_t v[2] = {(uint64_t)n, (uint64_t)(cannot ? 1 : 0)};
+            const int rc_ = xd_allreduce_host(ctx, v, 2, XDEMHIP_RED_SUM_U64);
+            if (rc_) return rc_;
+            P->mr_nglob = (int64_t)v[0];
+            P->mr_can = v[1] == 0;
+            memcpy(P->mr_key, key, sizeof key);
+        }
+        if (!P->mr_can) return XDEMHIP_OK;
+        n_all = P->mr_nglob;
+    } else if (cannot) {
         return XDEMHIP_OK;
+    }
+    if (n_all < SEL_BRACKET_MIN_N || (ctx->selection_mode == 0 && n_all < SEL_BRACKET_MIN_PER_BIN * nb)) return XDEMHIP_OK;
     unsigned char* scratch = static_cast<unsigned char*>(P->scratch);
     T* d_edges = reinterpret_cast<T*>(scratch);
     DhStats* d_stats = reinterpret_cast<DhStats*>(scratch + OFF_STATS);
@@ -2651,6 +3007,14 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     }
     hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, ref_m, tba, static_cast<const T*>(P->aspect), g,
                        P->ext_idx, P->ext_cnt, d_stats, P->ext_cnt + 2);
+    int rc = XDEMHIP_OK;
+    if (mr) {   // exchange 1: min / max aspect and the survivors over all ranks
+        hipLaunchKernelGGL(nk_mr_ext_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, P->mr_a);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+        rc = xd_allreduce_device(ctx, P->mr_a, 4, XDEMHIP_RED_MIN_U64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nk_mr_ext_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, P->mr_a, d_stats, P->ext_cnt + 2);
+    }
     hipLaunchKernelGGL((nk_fz_prep_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, nb, (int)custom, d_edges, d_rec,
                        (int)P->bcache_force, ctr);
     hipLaunchKernelGGL((nk_bin_fill_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream,
@@ -2670,8 +3034,8 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     // (round 5: the passes advance their own states and the last one writes the bracket ends -- hist_pass_kernel<T, true>; `fused`
     //  tells whether that form ran)
     bool fused = false;
-    int rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
-                               false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, r5);
+    rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
+                           false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, r5);
     if (rc) return rc;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
     // 3. sample of y^ per aspect bin -> brackets of the bin medians (round 5: v^ and delta formed by the sample kernel itself)
@@ -2708,6 +3072,20 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
 #undef XD_NK_FZ
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
+    // (partitioned plans: this rank's classes, the counters rewritten for the gathered bucket values, the true counters of the bins)
+    uint64_t* cls_loc = mr ? P->mr_small : nullptr;
+    uint64_t* cls_f = mr ? cls_loc + 3 * nbm : nullptr;
+    uint64_t* res_f = mr ? cls_f + 3 * nbm : nullptr;
+    uint64_t* cnt_true = mr ? res_f + 2 * nbm : nullptr;
+    unsigned long long* segf_ctr = mr ? reinterpret_cast<unsigned long long*>(cnt_true + 3 * nbm) : nullptr;   // [nb] x BINSEG_CTR_STRIDE words
+    if (mr) {   // exchange 8: the pass's counters summed, the five float64 sums of every rank gathered and added in rank order
+        hipLaunchKernelGGL(nk_mr_counts_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt_d, cls_y, d_sums, nb, rank, world, P->mr_a, cls_loc);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+        rc = xd_allreduce_device(ctx, P->mr_a, 3 + 3 * (int64_t)nb + 5 * (int64_t)world, XDEMHIP_RED_SUM_U64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nk_mr_counts_unpack_kernel, dim3(1), dim3(256), 0, ctx->stream, P->mr_a, nb, world, cnt_d, cls_y, d_sums);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
     // 5. exact median of dh among its candidates -> vshift
     if (ctx->nk_binseg != 0) {   // round 5: value buckets of the bracket, three launches (nk_dhsel_* above)
         uint32_t* dsel = reinterpret_cast<uint32_t*>(fz + 24 + (11 + BINSEG_CTR_STRIDE) * nbm);
@@ -2716,15 +3094,41 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         //  wave spent 80 us there)
         int grid = grid_for(ctx, n / 32 + 1, HIST_THREADS * 8, 1);
         grid = grid > 64 ? 64 : grid;
+        const size_t lds = (size_t)DSEL_CAP * sizeof(K) + (size_t)(BINSEL_COPIES * (SEL_RADIX + 1) + 1) * 4 + (size_t)(SEL_RADIX + 4 + 16 + 2) * 8;
+        rc = set_big_lds(ctx, nk_dhsel_final_kernel<T>, lds);
+        if (rc) return rc;
+        if (mr) {
+            // exchange 9: the histogram of the candidates, one row per rank -> the global histogram, the bucket, this rank's offset
+            uint32_t* rows = reinterpret_cast<uint32_t*>(P->mr_a);
+            XD_HIP_CHECK(ctx, hipMemsetAsync(rows, 0, (size_t)world * DSEL_BUCKETS * 4, ctx->stream));
+            hipLaunchKernelGGL((nk_dhsel_hist_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
+                               klo_d, khi_d, rows + (size_t)rank * DSEL_BUCKETS);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+            rc = xd_allreduce_device(ctx, P->mr_a, (int64_t)world * (DSEL_BUCKETS / 2), XDEMHIP_RED_SUM_U64);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nk_mr_dh_base_kernel<T>), dim3(1), dim3(HIST_THREADS), 0, ctx->stream, rows, world, rank, cnt_d, klo_d, khi_d, dsel, ctr);
+            // exchange 10: the bucket's keys of all ranks, each at its offset, + every rank's header words
+            uint64_t* slots = P->mr_b;
+            K* gk = reinterpret_cast<K*>(P->mr_b + (size_t)world * DSEL_HDR_WORDS);
+            const int64_t words10 = (int64_t)world * DSEL_HDR_WORDS + (int64_t)DSEL_CAP * (int64_t)sizeof(K) / 8;
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_b, 0, (size_t)words10 * 8, ctx->stream));
+            hipLaunchKernelGGL((nk_dhsel_gather_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
+                               cnt_d, klo_d, khi_d, dsel, gk, ctr, 0);
+            hipLaunchKernelGGL(nk_mr_dh_hdr_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, dsel, rank, slots);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+            rc = xd_allreduce_device(ctx, P->mr_b, words10, XDEMHIP_RED_SUM_U64);
+            if (rc) return rc;
+            hipLaunchKernelGGL(nk_mr_dh_hdr_merge_kernel, dim3(1), dim3(64), 0, ctx->stream, slots, world, dsel);
+            hipLaunchKernelGGL((nk_dhsel_final_kernel<T>), dim3(1), dim3(HIST_THREADS), lds, ctx->stream, P->cd_cap, ctr + 1, cnt_d, klo_d, khi_d, dsel, gk,
+                               ctr, scratch + OFF_INFO, 0);
+        } else {
         hipLaunchKernelGGL((nk_dhsel_hist_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
                            klo_d, khi_d, dsel + 2 * DSEL_HDR_WORDS);
         hipLaunchKernelGGL((nk_dhsel_gather_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
                            cnt_d, klo_d, khi_d, dsel, dsel_keys, ctr);
-        const size_t lds = (size_t)DSEL_CAP * sizeof(K) + (size_t)(BINSEL_COPIES * (SEL_RADIX + 1) + 1) * 4 + (size_t)(SEL_RADIX + 4 + 16 + 2) * 8;
-        rc = set_big_lds(ctx, nk_dhsel_final_kernel<T>, lds);
-        if (rc) return rc;
         hipLaunchKernelGGL((nk_dhsel_final_kernel<T>), dim3(1), dim3(HIST_THREADS), lds, ctx->stream, P->cd_cap, ctr + 1, cnt_d, klo_d, khi_d, dsel, dsel_keys,
                            ctr, scratch + OFF_INFO);
+        }
         XD_HIP_CHECK(ctx, hipGetLastError());
     } else {
     hipLaunchKernelGGL(bracket_given_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt_d, 1, given_d, ctr);
@@ -2744,13 +3148,35 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         hipLaunchKernelGGL((nk_resolve_scatter_kernel<T>), dim3(grid_for(ctx, n / 16 + 1, HIST_THREADS * BINSEG_U, 2)), dim3(HIST_THREADS), lds, ctx->stream,
                            static_cast<const T*>(ws->c_vals), static_cast<const T*>(P->c_st), ws->c_bins, ws->c_cap, ctr + 5,
                            reinterpret_cast<const T*>(scratch + OFF_INFO), nb, klo_y, khi_y, cls_y, res_y, seg_ctr, static_cast<T*>(P->y),
-                           (int64_t)P->nbuf * P->W, ctr);
+                           (int64_t)P->nbuf * P->W, ctr, cls_loc);
         const size_t lds2 = (size_t)BINSEL_KEY_BYTES + (size_t)(BINSEL_COPIES * (SEL_RADIX + 1) + 1) * 4 + (size_t)(SEL_RADIX + 8) * 8;
         rc = set_big_lds(ctx, nk_bin_select_kernel<T>, lds2);
         if (rc) return rc;
+        if (mr) {
+            // exchange 11: per bin the value-bucket histogram of this rank's segment, one row per rank; the resolved counters; local flags
+            const int64_t words11 = 2 + 2 * (int64_t)nb + (int64_t)world * nb * (SEL_RADIX / 2);
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_a, 0, (size_t)words11 * 8, ctx->stream));
+            hipLaunchKernelGGL((nk_mr_bin_hist_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, res_y, seg_ctr, nb, klo_y,
+                               khi_y, rank, world, P->mr_a, ctr);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+            rc = xd_allreduce_device(ctx, P->mr_a, words11, XDEMHIP_RED_SUM_U64);
+            if (rc) return rc;
+            // exchange 12: per bin the chosen bucket's values of all ranks (+ each rank's smallest value above it)
+            const int64_t words12 = (int64_t)nb * MR_GSEG * (int64_t)sizeof(T) / 8;
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_b, 0, (size_t)words12 * 8, ctx->stream));
+            hipLaunchKernelGGL((nk_mr_bin_gather_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, cls_y, P->mr_a, seg_ctr, nb,
+                               klo_y, khi_y, rank, world, reinterpret_cast<T*>(P->mr_b), cls_f, res_f, segf_ctr, cnt_true, ctr);
+            XD_HIP_CHECK(ctx, hipGetLastError());
+            rc = xd_allreduce_device(ctx, P->mr_b, words12, XDEMHIP_RED_SUM_U64);
+            if (rc) return rc;
+            hipLaunchKernelGGL((nk_bin_select_kernel<T>), dim3(nb), dim3(HIST_THREADS), lds2, ctx->stream, reinterpret_cast<const T*>(P->mr_b), cls_f, res_f, segf_ctr,
+                               nb, klo_y, khi_y, rbs_y, reinterpret_cast<SelState<K>*>(scratch + OFF_STATE), reinterpret_cast<uint64_t*>(scratch + off_succ(nb)),
+                               cnt_y, ctr, (int64_t)MR_GSEG);
+        } else {
         hipLaunchKernelGGL((nk_bin_select_kernel<T>), dim3(nb), dim3(HIST_THREADS), lds2, ctx->stream, static_cast<const T*>(P->y), cls_y, res_y, seg_ctr, nb,
                            klo_y, khi_y, rbs_y, reinterpret_cast<SelState<K>*>(scratch + OFF_STATE), reinterpret_cast<uint64_t*>(scratch + off_succ(nb)),
                            cnt_y, ctr);
+        }
         XD_HIP_CHECK(ctx, hipGetLastError());
     } else {
     {
@@ -2780,14 +3206,17 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     T h_vhat = (T)0;
     std::vector<SelState<K>> h_st(nb);
     std::vector<uint64_t> h_succ(nb);
+    std::vector<uint64_t> cnt_t(mr ? 3 * (size_t)nb : 0);   // partitioned plans: (total, below, inside) of the bins' brackets (cnt holds the rewritten ones)
+    const int n_pk = mr ? 11 : 10;
     {
         FzPack pk;
-        void* dsts[10] = {cnt.data(), klo.data(), h_ctr, &h_rbs, info, sums, &h_vhat, edges.data(), h_st.data(), h_succ.data()};
-        const void* srcs[10] = {cnt_y, klo_y, ctr, rbs_y, scratch + OFF_INFO, d_sums, d_vhat, d_edges, scratch + OFF_STATE, scratch + off_succ(nb)};
-        const size_t sizes[10] = {8 * 3 * (size_t)nb, sizeof(K) * nb, 128, 8, 32, 40, sizeof(T), sizeof(T) * (nb + 1), sizeof(SelState<K>) * nb, 8 * (size_t)nb};
+        void* dsts[11] = {cnt.data(), klo.data(), h_ctr, &h_rbs, info, sums, &h_vhat, edges.data(), h_st.data(), h_succ.data(), cnt_t.data()};
+        const void* srcs[11] = {cnt_y, klo_y, ctr, rbs_y, scratch + OFF_INFO, d_sums, d_vhat, d_edges, scratch + OFF_STATE, scratch + off_succ(nb), cnt_true};
+        const size_t sizes[11] = {8 * 3 * (size_t)nb, sizeof(K) * nb, 128, 8, 32, 40, sizeof(T), sizeof(T) * (nb + 1), sizeof(SelState<K>) * nb, 8 * (size_t)nb,
+                                  8 * 3 * (size_t)nb};
         uint32_t off = 0;
-        pk.n = 10;
-        for (int k = 0; k < 10; ++k) {
+        pk.n = n_pk;
+        for (int k = 0; k < n_pk; ++k) {
             pk.src[k] = static_cast<const unsigned char*>(srcs[k]);
             pk.bytes[k] = (uint32_t)sizes[k];
             pk.off[k] = off;
@@ -2802,7 +3231,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         XD_HIP_CHECK(ctx, hipGetLastError());
         if (!pin) { const int rc_ = xd_d2h(ctx, P->fz_host.data(), P->fz_pack, off); if (rc_) return rc_; }
         { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
-        for (int k = 0; k < 10; ++k) memcpy(dsts[k], P->fz_host.data() + pk.off[k], sizes[k]);
+        for (int k = 0; k < n_pk; ++k) memcpy(dsts[k], P->fz_host.data() + pk.off[k], sizes[k]);
     }
     std::vector<SelResult<K>> hs(nb);
     for (int k = 0; k < nb; ++k) { hs[k].st = h_st[k]; hs[k].succ = h_succ[k]; }
@@ -2832,7 +3261,10 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             P->fz_offn += 1;
         };
         take(h_ctr[10], h_ctr[11], h_ctr[12]);
-        for (int b = 0; b < nb; ++b) take(cnt[b], cnt[nb + b], cnt[2 * nb + b]);
+        for (int b = 0; b < nb; ++b) {
+            if (mr) take(cnt_t[b], cnt_t[nb + b], cnt_t[2 * nb + b]);
+            else take(cnt[b], cnt[nb + b], cnt[2 * nb + b]);
+        }
         P->fz_worst = worst > P->fz_worst ? worst : P->fz_worst;
         // rms offset = one standard deviation of the sample ranks in units of the full half width (independent sample elements:
         // 1 / 17, the rule being 6 sigma of 8-element lines that are fully correlated): the next brackets keep >= 7 sigma and
@@ -3132,7 +3564,7 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
         //  all zeroed at the start of a step; the keys of its chosen bucket sit behind, outside the zeroed part)
         P->fz_bytes = (size_t)(24 + (11 + BINSEG_CTR_STRIDE) * P->ws.nb_max + DSEL_HDR_WORDS + DSEL_BUCKETS / 2) * 8;
         P->cd_cap = (int64_t)n / 8 + 4096;
-        P->fz_pack_bytes = (size_t)P->ws.nb_max * (8 * 3 + 8 + 16 + 64 + 8) + 1024;
+        P->fz_pack_bytes = (size_t)P->ws.nb_max * (8 * 3 + 8 + 16 + 64 + 8 + 8 * 3) + 1024;
         if (hipMalloc(reinterpret_cast<void**>(&P->fz), P->fz_bytes + (size_t)DSEL_CAP * 8) != hipSuccess || hipMalloc(&P->cd_vals, (size_t)P->cd_cap * es) != hipSuccess ||
             hipMalloc(&P->c_st, (size_t)P->ws.c_cap * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->fz_pack), P->fz_pack_bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -3178,7 +3610,7 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     (void)hipSetDevice(P->ctx->device);
     if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
     void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt,
-                    P->fz, P->cd_vals, P->c_st, P->fz_pack, P->badbits};
+                    P->fz, P->cd_vals, P->c_st, P->fz_pack, P->badbits, P->mr_a, P->mr_b, P->mr_small};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     xd::sel_ws_free(P->ws);

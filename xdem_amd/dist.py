@@ -163,7 +163,7 @@ def _rows(out: torch.Tensor, r0: int, n: int):
 def nuth_kaab_row_blocks(ref_rows: torch.Tensor, tba_rows: torch.Tensor, total_rows: int, res: tuple[float, float],
                          inlier_rows: torch.Tensor | None = None, group=None, halo: int = 8, ctx=None, tolerance: float = 0.001,
                          max_iterations: int = 10, bin_sizes=72, fit_optimizer=None, bin_statistic=None, bin_before_fit: bool = True,
-                         initial_offsets: tuple[float, float] = (0.0, 0.0)):
+                         initial_offsets: tuple[float, float] = (0.0, 0.0), info: dict | None = None):
     """Nuth & Kaab fit of a raster pair PARTITIONED by row block over the ranks of ``group``: every rank passes only ITS
     rows -- ``row_block(total_rows, world, rank)`` -- of the reference / to-be-aligned DEM (device tensors, same dtype) and
     of the optional inlier mask (uint8).  Layout and halo exchange as for the terrain path (structural
@@ -172,7 +172,11 @@ def nuth_kaab_row_blocks(ref_rows: torch.Tensor, tba_rows: torch.Tensor, total_r
     serves ``np.gradient``, the rest bounds the vertical shift the iteration may reach (``floor(|shift_y| / res_y) + 2``
     rows); if a step leaves it (``HaloTooSmall``, raised identically on every rank) the halo is doubled and the fit
     restarts.  Every reduction of a step -- integer histograms, counters, min / max keys -- is all-reduced through the
-    library hook, so all ranks obtain the same, exact result as a single-GPU fit of the whole rasters.
+    library hook, so all ranks obtain the same, exact result as a single-GPU fit of the whole rasters.  Large blocks take the
+    one-pass step (one data pass over the rank's rows, twelve all-reduces per step: include/xdemhip.h, xdemhip_nk_route_counts).
+
+    ``info`` (optional dict) receives ``routes`` -- how the steps of the fit were answered on this rank (one-pass / two-pass /
+    plain; identical on every rank) -- and ``reductions``, the (host-staged, device-side) reductions the fit made.
 
     Returns ((easting, northing, vertical) offsets, number of valid pixels of the whole pair)."""
     import numpy as np
@@ -213,7 +217,12 @@ def nuth_kaab_row_blocks(ref_rows: torch.Tensor, tba_rows: torch.Tensor, total_r
             plan.set_statistic(bin_statistic)
             if not isinstance(bin_sizes, (int, np.integer)):
                 plan.set_bin_edges(bin_sizes)
+            red0 = ctx.reduction_calls()
             offsets = coreg._iterate(plan, res, tolerance, max_iterations, bin_sizes, fit_optimizer, bin_before_fit, initial_offsets)
+            if info is not None:
+                red1 = ctx.reduction_calls()
+                info["routes"] = plan.route_counts()
+                info["reductions"] = (red1[0] - red0[0], red1[1] - red0[1])
             return offsets, plan.n_valid
         except coreg.HaloTooSmall:
             if world == 1 or depth >= total_rows // world:
