@@ -2939,6 +2939,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
                   ws->es != sizeof(T) || nb > ws->nb_max || nb > MAX_BINS_PER_SWEEP || n_slots > ws->s_cap ||
                   (int64_t)(NKZ_CHUNK_MAX + 2) * P->W * (int64_t)sizeof(T) >= ((int64_t)1 << 32);   // (32-bit byte offsets inside a chunk of rows)
     int64_t n_all = n;   // pixels of all ranks
+    if (mr && (world < 1 || !ctx->nk_fused_dist || !ctx->nk_fused)) return XDEMHIP_OK;   // (not told the ranks / switched off: context-level, the same on every rank)
     if (mr) {
         // Every rank must take the same route.  What the decision rests on is either fixed for the plan and its options or derives
         // from reduced data (ext_ok), so the ranks agree ONCE -- a host all-reduce of (own pixels, "I cannot") -- and again whenever
