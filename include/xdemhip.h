@@ -258,7 +258,7 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uin
  * per-bin candidate segments with one workgroup per bin, value-bucket selection of the median of dh, sample passes that
  * advance their own selection states: 24 launches per step -- 0 round 4's generic selections (55); same integers either way.
  * PARTITIONED plans (reduction hook installed, xdemhip_set_rank told, context option "nk_fused_dist" = 1, the default) take the
- * one-pass step as well: one data pass over the rank's own rows and TWELVE all-reduces per step (nuthkaab.hip: "the ONE-PASS step
+ * one-pass step as well: one data pass over the rank's own rows and TEN all-reduces per step (nuthkaab.hip: "the ONE-PASS step
  * on PARTITIONED plans"), all of them enqueued through the device hook where it is installed; every rank returns the same integers
  * as a single-GPU fit of the whole rasters (the two-pass route of such plans: two data passes, ~25 all-reduces). */
 int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* twopass, int64_t* plain);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-5, session u: the one-pass step on partitioned plans (12 all-reduces per step) -- the new tests first, the tests of the hooked
+# round-5, session u: the one-pass step on partitioned plans (10 all-reduces per step) -- the new tests first, the tests of the hooked
 # plans that now take the route, the shared-GPU probe of one-pass vs two-pass on 2 ranks
 TAG=${1:-r05u}
 O=gpurun_out/$TAG; mkdir -p $O

@@ -29,7 +29,7 @@ struct xdemhip_ctx {
     void* allreduce_dev_user = nullptr;
     int64_t n_red_host = 0, n_red_dev = 0;     // reductions that went through the host / the device hook
     int rank = 0, world = 0;                   // xdemhip_set_rank: this process's place among the ranks the hooks reduce over (world 0: not told)
-    int nk_fused_dist = 1;   // option "nk_fused_dist": 1 partitioned Nuth-Kaab plans (reduction hook + xdemhip_set_rank) take the one-pass step too: 12 all-reduces per step (default), 0 the two-pass route of round 3 (~25)
+    int nk_fused_dist = 1;   // option "nk_fused_dist": 1 partitioned Nuth-Kaab plans (reduction hook + xdemhip_set_rank) take the one-pass step too: 10 all-reduces per step (default), 0 the two-pass route of round 3 (~25)
     int host_chunk_rows = 0; // option "host_chunk_rows": rows per chunk of host-buffer terrain calls (0 = from the budget); the mp_config tile size
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
     int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)

@@ -2235,38 +2235,49 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t ca
 // With a reduction hook (row blocks over ranks, one process per GPU) the step used to take the two-pass route: ~25 small all-reduces and
 // two data passes.  The one-pass step needs, besides its data pass over THIS rank's rows, global counters and global order statistics
 // among candidates that are spread over the ranks.  Everything that crosses ranks is an all-reduce of 8-byte words through the hook
-// (sum / min), TWELVE per step:
-//   1     min / max aspect of the EXT lists + survivors                          (4 words, MIN: maxima travel complemented)
-//   2-4   the dh sample's dual bracket selection: one histogram per digit        (select_enqueue, as on the two-pass route)
-//   5-7   the y^ sample's dual bracket selection of the 72 bins
-//   8     the pass's counters (cnt_d[3], cls_y[3][nb]) + every rank's five float64 sums, each in ITS OWN slot (all other ranks add
-//         zeros there): a sum all-reduce used as an all-gather, so the float64 sums are added in rank order on every rank --
-//         the same bits everywhere, whatever the reduction tree
-//   9     the 4096-bucket histogram of the dh candidates, ONE ROW PER RANK (same trick): every rank then knows the global histogram
-//         -- hence the bucket that holds the wanted rank -- and how many of that bucket's keys each rank holds, i.e. where its own
-//         keys go in the bucket's global key list
-//   10    that key list (each rank writes its keys at its offset, zeros elsewhere) + the gather's header words per rank; then the
+// (sums), TEN per step:
+//   1-3   the dh sample's dual bracket selection: one histogram per digit        (select_enqueue, as on the two-pass route); the first
+//         of them also carries min / max aspect and the survivors of every rank's EXT lists, each rank in ITS OWN slot (all other
+//         ranks add zeros there): a sum all-reduce used as an all-gather, folded by every rank afterwards
+//   4-6   the y^ sample's dual bracket selection of the 72 bins
+//   7     the pass's counters (cnt_d[3], cls_y[3][nb]) + every rank's five float64 sums in per-rank slots (added in rank order on
+//         every rank: the same bits everywhere, whatever the reduction tree) + the 4096-bucket histogram of the dh candidates, ONE ROW PER
+//         RANK (same trick): every rank then knows the global histogram -- hence the bucket that holds the wanted rank -- and how
+//         many of that bucket's keys each rank holds, i.e. where its own keys go in the bucket's global key list
+//   8     that key list (each rank writes its keys at its offset, zeros elsewhere) + the gather's header words per rank; then the
 //         single-GPU final kernel runs on it unchanged, on every rank: same vshift everywhere
-//   11    per bin: the 256-value-bucket histogram of this rank's segment of kept y, one row per rank, + the resolved counters
-//   12    per bin: the chosen bucket's values of all ranks + the smallest value above the bucket of every rank that has one, at
-//         offsets known from 11, in a fixed stride of MR_GSEG values per bin; the single-GPU `nk_bin_select_kernel` then runs on that
+//   9     per bin: the 256-value-bucket histogram of this rank's segment of kept y, one row per rank, + the resolved counters
+//   10    per bin: the chosen bucket's values of all ranks + the smallest value above the bucket of every rank that has one, at
+//         offsets known from 9, in a fixed stride of MR_GSEG values per bin; the single-GPU `nk_bin_select_kernel` then runs on that
 //         small array with counters rewritten so that the wanted rank, the count below and the successor rule come out as on the
 //         whole set (elements below the bucket are counted into "below", nothing above the first value above the bucket matters)
 // All integers, the same keys, the same selection code: medians, counts, vshift are the single-GPU fit's bit for bit (GPU test:
-// 2 ranks == 1 process).  Failure flags that only one rank can see (a buffer overflow) travel with 11; flags raised later derive
+// 2 ranks == 1 process).  Failure flags that only one rank can see (a buffer overflow) travel with 9; flags raised later derive
 // from reduced data and are identical on every rank, so all ranks fall through to the two-pass route together or not at all.
 constexpr int MR_WORLD_MAX = 16;
-constexpr int MR_GSEG = 2048;   // values per bin in exchange 12 (the chosen bucket of a bin holds a few hundred)
+constexpr int MR_GSEG = 2048;   // values per bin in exchange 10 (the chosen bucket of a bin holds a few hundred)
 
-static __global__ void nk_mr_ext_pack_kernel(const DhStats* s, const unsigned long long* surv, uint64_t* red) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    red[0] = s->asp_min; red[1] = ~s->asp_max; red[2] = ~(uint64_t)surv[0]; red[3] = ~(uint64_t)surv[1];
+// exchange 1 (rides on the first histogram all-reduce of the dh sample's selection): min / max aspect key and survivors of this
+// rank's EXT lists in its slot of [world][4], zeros in the others'; afterwards the fold over the slots
+static __global__ void nk_mr_ext_pack_kernel(const DhStats* s, const unsigned long long* surv, int rank, int world, uint64_t* slots) {
+    const int k = threadIdx.x;
+    if (blockIdx.x != 0 || k >= 4 * world) return;
+    uint64_t v = 0;
+    if (k / 4 == rank) v = (k & 3) == 0 ? s->asp_min : ((k & 3) == 1 ? s->asp_max : (uint64_t)surv[(k & 3) - 2]);
+    slots[k] = v;
 }
-static __global__ void nk_mr_ext_unpack_kernel(const uint64_t* red, DhStats* s, unsigned long long* surv) {
+static __global__ void nk_mr_ext_unpack_kernel(const uint64_t* slots, int world, DhStats* s, unsigned long long* surv) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    s->asp_min = red[0]; s->asp_max = ~red[1]; surv[0] = (unsigned long long)~red[2]; surv[1] = (unsigned long long)~red[3];   // (survivors: the largest count of a rank -- only "none" matters)
+    uint64_t mn = ~(uint64_t)0, mx = 0, s0 = 0, s1 = 0;
+    for (int r = 0; r < world; ++r) {
+        mn = slots[4 * r] < mn ? slots[4 * r] : mn;
+        mx = slots[4 * r + 1] > mx ? slots[4 * r + 1] : mx;
+        s0 += slots[4 * r + 2];
+        s1 += slots[4 * r + 3];
+    }
+    s->asp_min = mn; s->asp_max = mx; surv[0] = s0; surv[1] = s1;
 }
-// exchange 8: [0, 3) cnt_d | [3, 3 + 3 nb) cls_y | [world][5] float64 sums, slot of this rank only
+// exchange 7: [0, 3) cnt_d | [3, 3 + 3 nb) cls_y | [world][5] float64 sums, slot of this rank only | (then the histogram rows)
 static __global__ __launch_bounds__(256) void nk_mr_counts_pack_kernel(const uint64_t* cnt_d, const uint64_t* cls_y, const double* sums, int nb, int rank,
                                                                         int world, uint64_t* red, uint64_t* cls_loc) {
     const int nsum = 3 + 3 * nb, total = nsum + 5 * world;
@@ -2290,7 +2301,7 @@ static __global__ __launch_bounds__(256) void nk_mr_counts_unpack_kernel(const u
         sums[threadIdx.x] = a;
     }
 }
-// after exchange 9: the global histogram (sum of the rows) into the selection's own place, the bucket of the wanted rank, and where
+// after exchange 7: the global histogram (sum of the rows) into the selection's own place, the bucket of the wanted rank, and where
 // this rank's keys of that bucket go in the global key list: hdr[2] (the gather's append counter) starts there, hdr[3] remembers it
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void nk_mr_dh_base_kernel(const uint32_t* __restrict__ rows /* [world][DSEL_BUCKETS] */, int world, int rank,
@@ -2318,7 +2329,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_mr_dh_base_kernel(const uint3
         hdr[3] = base;
     }
 }
-// exchange 10, before: this rank's header words into its slot; after: the headers of all ranks folded (maxima; keys appended = sum of
+// exchange 8, before: this rank's header words into its slot; after: the headers of all ranks folded (maxima; keys appended = sum of
 // what every rank appended behind its base)
 static __global__ void nk_mr_dh_hdr_pack_kernel(const uint32_t* hdr, int rank, uint64_t* slots /* [world][DSEL_HDR_WORDS] */) {
     if (threadIdx.x < DSEL_HDR_WORDS && blockIdx.x == 0)
@@ -2337,7 +2348,7 @@ static __global__ void nk_mr_dh_hdr_merge_kernel(const uint64_t* slots, int worl
     uint64_t* h64 = reinterpret_cast<uint64_t*>(hdr);
     h64[0] = m0; h64[1] = got; h64[2] = m2; h64[3] = m3;
 }
-// exchange 11, before: one workgroup per bin histograms THIS rank's segment of kept y into the 256 value buckets of the bin's bracket
+// exchange 9, before: one workgroup per bin histograms THIS rank's segment of kept y into the 256 value buckets of the bin's bracket
 // (nk_bin_select_kernel's map), its row of red; the resolved counters of the rank; flags only this rank may know
 // red: [0] overflow, [1] miss | res [2][nb] | rows [world][nb][256] (uint32)
 template <typename T>
@@ -2374,12 +2385,12 @@ __global__ __launch_bounds__(256) void nk_mr_bin_hist_kernel(const T* __restrict
     uint32_t* rows = reinterpret_cast<uint32_t*>(red + 2 + 2 * nb);
     rows[((size_t)rank * nb + b) * SEL_RADIX + tid] = h[tid];
 }
-// exchange 12, before: per bin the bucket that holds the wanted rank (from the summed rows), this rank's values of that bucket and its
+// exchange 10, before: per bin the bucket that holds the wanted rank (from the summed rows), this rank's values of that bucket and its
 // smallest value above it into the bin's stride of `gseg` at the offsets the rows give; the counters nk_bin_select_kernel will read,
 // rewritten for the small array (see the block comment); the true (total, below, inside) for the host's bracket statistics
 template <typename T>
 __global__ __launch_bounds__(256) void nk_mr_bin_gather_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls_loc, const uint64_t* __restrict__ cls /* summed */,
-                                                               const uint64_t* __restrict__ red /* exchange 11, summed */, const unsigned long long* seg_ctr, int nb,
+                                                               const uint64_t* __restrict__ red /* exchange 9, summed */, const unsigned long long* seg_ctr, int nb,
                                                                const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
                                                                int rank, int world, T* __restrict__ gseg /* [nb][MR_GSEG], zeroed */, uint64_t* cls_f /* [3][nb] */,
                                                                uint64_t* res_f /* [2][nb] */, unsigned long long* segf_ctr, uint64_t* cnt_true /* [3][nb] */,
@@ -2898,7 +2909,7 @@ int nk_stage_a(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int n
 // exchange buffers of the one-pass step on partitioned plans, sized for `nb` bins and `world` ranks (see the nk_mr_* kernels)
 int nk_mr_alloc(xdemhip_nk_plan* P, int nb, int world, size_t es) {
     auto mx = [](size_t a, size_t b) { return a > b ? a : b; };
-    const size_t wa = mx(mx(4, 3 + 3 * (size_t)nb + 5 * (size_t)world), mx((size_t)world * (DSEL_BUCKETS / 2), 2 + 2 * (size_t)nb + (size_t)world * nb * (SEL_RADIX / 2)));
+    const size_t wa = mx(mx(4, 3 + 3 * (size_t)nb + 5 * (size_t)world + (size_t)world * (DSEL_BUCKETS / 2)), 2 + 2 * (size_t)nb + (size_t)world * nb * (SEL_RADIX / 2));
     const size_t wb = mx((size_t)world * DSEL_HDR_WORDS + (size_t)DSEL_CAP * es / 8, (size_t)nb * MR_GSEG * es / 8);
     if (!P->mr_small && hipMalloc(reinterpret_cast<void**>(&P->mr_small), (size_t)(11 + BINSEG_CTR_STRIDE) * P->ws.nb_max * 8) != hipSuccess) {
         (void)hipGetLastError();
@@ -3009,20 +3020,22 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, ref_m, tba, static_cast<const T*>(P->aspect), g,
                        P->ext_idx, P->ext_cnt, d_stats, P->ext_cnt + 2);
     int rc = XDEMHIP_OK;
-    if (mr) {   // exchange 1: min / max aspect and the survivors over all ranks
-        hipLaunchKernelGGL(nk_mr_ext_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, P->mr_a);
+    // (partitioned plans: min / max aspect and the survivors of all ranks arrive with the first histogram all-reduce of the dh sample's
+    //  selection below -- per-rank slots behind its two histograms -- so the edges and the bin cache, which only the y^ sample and the
+    //  pass need, follow that selection)
+    uint64_t* ext_slots = reinterpret_cast<uint64_t*>(scratch + off_hist(2)) + 2 * SEL_RADIX;
+    if (mr) hipLaunchKernelGGL(nk_mr_ext_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, rank, world, ext_slots);
+    auto edges_and_bins = [&]() -> int {
+        hipLaunchKernelGGL((nk_fz_prep_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, nb, (int)custom, d_edges, d_rec,
+                           (int)P->bcache_force, ctr);
+        hipLaunchKernelGGL((nk_bin_fill_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream,
+                           static_cast<const T*>(P->aspect) + q0, n, d_edges, nb, last_decimal, d_rec, P->bcache + q0);
+        hipLaunchKernelGGL((nk_bin_cache_commit_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec);
         XD_HIP_CHECK(ctx, hipGetLastError());
-        rc = xd_allreduce_device(ctx, P->mr_a, 4, XDEMHIP_RED_MIN_U64);
-        if (rc) return rc;
-        hipLaunchKernelGGL(nk_mr_ext_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, P->mr_a, d_stats, P->ext_cnt + 2);
-    }
-    hipLaunchKernelGGL((nk_fz_prep_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_stats, P->ext_cnt + 2, nb, (int)custom, d_edges, d_rec,
-                       (int)P->bcache_force, ctr);
-    hipLaunchKernelGGL((nk_bin_fill_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream,
-                       static_cast<const T*>(P->aspect) + q0, n, d_edges, nb, last_decimal, d_rec, P->bcache + q0);
-    hipLaunchKernelGGL((nk_bin_cache_commit_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec);
-    XD_HIP_CHECK(ctx, hipGetLastError());
-    P->bcache_force = false;
+        P->bcache_force = false;
+        return XDEMHIP_OK;
+    };
+    if (!mr) { rc = edges_and_bins(); if (rc) return rc; }
     // 2. sample of dh -> bracket of its median, v^, delta
     T* s_v = static_cast<T*>(ws->s_vals);
     // (round 5: the sample kernels also reset the selection that runs on their sample -- select_reset_slice)
@@ -3036,9 +3049,14 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     //  tells whether that form ran)
     bool fused = false;
     rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
-                           false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, r5);
+                           false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, r5, mr ? 0 : -1, mr ? 4 * (int64_t)world : 0);
     if (rc) return rc;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
+    if (mr) {
+        hipLaunchKernelGGL(nk_mr_ext_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, ext_slots, world, d_stats, P->ext_cnt + 2);
+        rc = edges_and_bins();
+        if (rc) return rc;
+    }
     // 3. sample of y^ per aspect bin -> brackets of the bin medians (round 5: v^ and delta formed by the sample kernel itself)
     if (r5) {
         hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
@@ -3079,10 +3097,22 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     uint64_t* res_f = mr ? cls_f + 3 * nbm : nullptr;
     uint64_t* cnt_true = mr ? res_f + 2 * nbm : nullptr;
     unsigned long long* segf_ctr = mr ? reinterpret_cast<unsigned long long*>(cnt_true + 3 * nbm) : nullptr;   // [nb] x BINSEG_CTR_STRIDE words
-    if (mr) {   // exchange 8: the pass's counters summed, the five float64 sums of every rank gathered and added in rank order
+    // (few workgroups for the histogram / gather of the dh candidates: every one of them ends with an atomic on ONE word, which
+    //  serialise -- 256 workgroups with an atomic per wave spent 80 us there)
+    int dsel_grid = grid_for(ctx, n / 32 + 1, HIST_THREADS * 8, 1);
+    dsel_grid = dsel_grid > 64 ? 64 : dsel_grid;
+    const int64_t words7 = 3 + 3 * (int64_t)nb + 5 * (int64_t)world;
+    uint32_t* mr_rows = mr ? reinterpret_cast<uint32_t*>(P->mr_a + words7) : nullptr;   // [world][DSEL_BUCKETS]
+    if (mr) {
+        // exchange 7: the pass's counters summed, the five float64 sums of every rank gathered and added in rank order -- and, in the
+        // same all-reduce, the 4096-bucket histogram of this rank's dh candidates in its own row (the candidates and the bracket
+        // are there once the pass is through; only the choice of the bucket needs the summed counters)
+        XD_HIP_CHECK(ctx, hipMemsetAsync(mr_rows, 0, (size_t)world * DSEL_BUCKETS * 4, ctx->stream));
         hipLaunchKernelGGL(nk_mr_counts_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt_d, cls_y, d_sums, nb, rank, world, P->mr_a, cls_loc);
+        hipLaunchKernelGGL((nk_dhsel_hist_kernel<T>), dim3(dsel_grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
+                           klo_d, khi_d, mr_rows + (size_t)rank * DSEL_BUCKETS);
         XD_HIP_CHECK(ctx, hipGetLastError());
-        rc = xd_allreduce_device(ctx, P->mr_a, 3 + 3 * (int64_t)nb + 5 * (int64_t)world, XDEMHIP_RED_SUM_U64);
+        rc = xd_allreduce_device(ctx, P->mr_a, words7 + (int64_t)world * (DSEL_BUCKETS / 2), XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
         hipLaunchKernelGGL(nk_mr_counts_unpack_kernel, dim3(1), dim3(256), 0, ctx->stream, P->mr_a, nb, world, cnt_d, cls_y, d_sums);
         XD_HIP_CHECK(ctx, hipGetLastError());
@@ -3091,33 +3121,23 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if (ctx->nk_binseg != 0) {   // round 5: value buckets of the bracket, three launches (nk_dhsel_* above)
         uint32_t* dsel = reinterpret_cast<uint32_t*>(fz + 24 + (11 + BINSEG_CTR_STRIDE) * nbm);
         K* dsel_keys = reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(fz) + P->fz_bytes);
-        // (few workgroups: every one of them ends with an atomic on ONE word, which serialise -- 256 workgroups with an atomic per
-        //  wave spent 80 us there)
-        int grid = grid_for(ctx, n / 32 + 1, HIST_THREADS * 8, 1);
-        grid = grid > 64 ? 64 : grid;
+        const int grid = dsel_grid;
         const size_t lds = (size_t)DSEL_CAP * sizeof(K) + (size_t)(BINSEL_COPIES * (SEL_RADIX + 1) + 1) * 4 + (size_t)(SEL_RADIX + 4 + 16 + 2) * 8;
         rc = set_big_lds(ctx, nk_dhsel_final_kernel<T>, lds);
         if (rc) return rc;
         if (mr) {
-            // exchange 9: the histogram of the candidates, one row per rank -> the global histogram, the bucket, this rank's offset
-            uint32_t* rows = reinterpret_cast<uint32_t*>(P->mr_a);
-            XD_HIP_CHECK(ctx, hipMemsetAsync(rows, 0, (size_t)world * DSEL_BUCKETS * 4, ctx->stream));
-            hipLaunchKernelGGL((nk_dhsel_hist_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
-                               klo_d, khi_d, rows + (size_t)rank * DSEL_BUCKETS);
-            XD_HIP_CHECK(ctx, hipGetLastError());
-            rc = xd_allreduce_device(ctx, P->mr_a, (int64_t)world * (DSEL_BUCKETS / 2), XDEMHIP_RED_SUM_U64);
-            if (rc) return rc;
-            hipLaunchKernelGGL((nk_mr_dh_base_kernel<T>), dim3(1), dim3(HIST_THREADS), 0, ctx->stream, rows, world, rank, cnt_d, klo_d, khi_d, dsel, ctr);
-            // exchange 10: the bucket's keys of all ranks, each at its offset, + every rank's header words
+            // (the rows of exchange 7) -> the global histogram, the bucket, this rank's offset in the bucket's key list
+            hipLaunchKernelGGL((nk_mr_dh_base_kernel<T>), dim3(1), dim3(HIST_THREADS), 0, ctx->stream, mr_rows, world, rank, cnt_d, klo_d, khi_d, dsel, ctr);
+            // exchange 8: the bucket's keys of all ranks, each at its offset, + every rank's header words
             uint64_t* slots = P->mr_b;
             K* gk = reinterpret_cast<K*>(P->mr_b + (size_t)world * DSEL_HDR_WORDS);
-            const int64_t words10 = (int64_t)world * DSEL_HDR_WORDS + (int64_t)DSEL_CAP * (int64_t)sizeof(K) / 8;
-            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_b, 0, (size_t)words10 * 8, ctx->stream));
+            const int64_t words8 = (int64_t)world * DSEL_HDR_WORDS + (int64_t)DSEL_CAP * (int64_t)sizeof(K) / 8;
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_b, 0, (size_t)words8 * 8, ctx->stream));
             hipLaunchKernelGGL((nk_dhsel_gather_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
                                cnt_d, klo_d, khi_d, dsel, gk, ctr, 0);
             hipLaunchKernelGGL(nk_mr_dh_hdr_pack_kernel, dim3(1), dim3(64), 0, ctx->stream, dsel, rank, slots);
             XD_HIP_CHECK(ctx, hipGetLastError());
-            rc = xd_allreduce_device(ctx, P->mr_b, words10, XDEMHIP_RED_SUM_U64);
+            rc = xd_allreduce_device(ctx, P->mr_b, words8, XDEMHIP_RED_SUM_U64);
             if (rc) return rc;
             hipLaunchKernelGGL(nk_mr_dh_hdr_merge_kernel, dim3(1), dim3(64), 0, ctx->stream, slots, world, dsel);
             hipLaunchKernelGGL((nk_dhsel_final_kernel<T>), dim3(1), dim3(HIST_THREADS), lds, ctx->stream, P->cd_cap, ctr + 1, cnt_d, klo_d, khi_d, dsel, gk,
@@ -3154,21 +3174,21 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         rc = set_big_lds(ctx, nk_bin_select_kernel<T>, lds2);
         if (rc) return rc;
         if (mr) {
-            // exchange 11: per bin the value-bucket histogram of this rank's segment, one row per rank; the resolved counters; local flags
-            const int64_t words11 = 2 + 2 * (int64_t)nb + (int64_t)world * nb * (SEL_RADIX / 2);
-            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_a, 0, (size_t)words11 * 8, ctx->stream));
+            // exchange 9: per bin the value-bucket histogram of this rank's segment, one row per rank; the resolved counters; local flags
+            const int64_t words9 = 2 + 2 * (int64_t)nb + (int64_t)world * nb * (SEL_RADIX / 2);
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_a, 0, (size_t)words9 * 8, ctx->stream));
             hipLaunchKernelGGL((nk_mr_bin_hist_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, res_y, seg_ctr, nb, klo_y,
                                khi_y, rank, world, P->mr_a, ctr);
             XD_HIP_CHECK(ctx, hipGetLastError());
-            rc = xd_allreduce_device(ctx, P->mr_a, words11, XDEMHIP_RED_SUM_U64);
+            rc = xd_allreduce_device(ctx, P->mr_a, words9, XDEMHIP_RED_SUM_U64);
             if (rc) return rc;
-            // exchange 12: per bin the chosen bucket's values of all ranks (+ each rank's smallest value above it)
-            const int64_t words12 = (int64_t)nb * MR_GSEG * (int64_t)sizeof(T) / 8;
-            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_b, 0, (size_t)words12 * 8, ctx->stream));
+            // exchange 10: per bin the chosen bucket's values of all ranks (+ each rank's smallest value above it)
+            const int64_t words10 = (int64_t)nb * MR_GSEG * (int64_t)sizeof(T) / 8;
+            XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_b, 0, (size_t)words10 * 8, ctx->stream));
             hipLaunchKernelGGL((nk_mr_bin_gather_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, cls_y, P->mr_a, seg_ctr, nb,
                                klo_y, khi_y, rank, world, reinterpret_cast<T*>(P->mr_b), cls_f, res_f, segf_ctr, cnt_true, ctr);
             XD_HIP_CHECK(ctx, hipGetLastError());
-            rc = xd_allreduce_device(ctx, P->mr_b, words12, XDEMHIP_RED_SUM_U64);
+            rc = xd_allreduce_device(ctx, P->mr_b, words10, XDEMHIP_RED_SUM_U64);
             if (rc) return rc;
             hipLaunchKernelGGL((nk_bin_select_kernel<T>), dim3(nb), dim3(HIST_THREADS), lds2, ctx->stream, reinterpret_cast<const T*>(P->mr_b), cls_f, res_f, segf_ctr,
                                nb, klo_y, khi_y, rbs_y, reinterpret_cast<SelState<K>*>(scratch + OFF_STATE), reinterpret_cast<uint64_t*>(scratch + off_succ(nb)),

@@ -325,7 +325,10 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
                    typename KeyT<T>::type* fuse_klo = nullptr /* SEL_BRACKET_DUAL: the passes advance their own states and the last one writes the */,
                    typename KeyT<T>::type* fuse_khi = nullptr /* bracket ends + rebase shift here (hist_pass_kernel<T, true>); *fused tells whether */,
                    uint32_t* fuse_rbs = nullptr, typename KeyT<T>::type fuse_low_mask = 0, bool* fused = nullptr,
-                   bool reset_done = false /* the caller's own kernel did select_reset_slice(select_reset_plan(...)) */) {
+                   bool reset_done = false /* the caller's own kernel did select_reset_slice(select_reset_plan(...)) */,
+                   int extra_pass = -1, int64_t extra_words = 0 /* with a reduction hook: the all-reduce of pass `extra_pass` also carries the
+                                                                    `extra_words` 8-byte words that follow the histograms in `scratch`
+                                                                    (per-rank slots of the caller: a sum all-reduce used as an all-gather) */) {
     typedef typename KeyT<T>::type K;
     if (fused) *fused = false;
     // SEL_BRACKET_DUAL: two selection states per data bin (low ends in states [0, nb), high ends in [nb, 2 nb)); `scratch` holds
@@ -396,7 +399,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
             }
         }
         if (fuse) continue;   // (states advanced by the pass itself)
-        int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX, XDEMHIP_RED_SUM_U64);
+        int rc = xd_allreduce_device(ctx, d_hist, (int64_t)nb * SEL_RADIX + (p == extra_pass ? extra_words : 0), XDEMHIP_RED_SUM_U64);
         if (rc) return rc;
         hipLaunchKernelGGL((select_advance_kernel<K>), dim3(nb), dim3(64), 0, ctx->stream, st, d_hist, nb, shift,
                            (int)(p == 0), (int)(p == passes - 1), mode, d_given, rb_shift, PAIR_DEFF_WIDE, nb_data,
