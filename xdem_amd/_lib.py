@@ -229,10 +229,21 @@ def make_device_reduce_hook(group="world", device: int | None = None):
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
     top = -(2**63)
 
+    # (a step of a partitioned Nuth-Kaab plan makes ten of these calls on the same few library buffers: the tensor views and the stream
+    #  wrapper are kept -- building them costs more host time than enqueueing the collective; a view holds an address, not the memory)
+    views, streams = {}, {}
+
     def hook(ptr, count, kind, stream, user):
         try:
-            t = torch.as_tensor(_DeviceArray(ptr, count, "<f8" if kind == 1 else "<i8"), device=dev)
-            s = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+            key = (ptr, count, kind == 1)
+            t = views.get(key)
+            if t is None:
+                if len(views) > 256:
+                    views.clear()
+                t = views[key] = torch.as_tensor(_DeviceArray(ptr, count, "<f8" if kind == 1 else "<i8"), device=dev)
+            s = streams.get(stream)
+            if s is None:
+                s = streams[stream] = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
             with torch.cuda.stream(s):
                 if kind in (2, 3):
                     t.bitwise_xor_(top)
