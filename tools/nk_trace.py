@@ -26,13 +26,28 @@ if os.environ.get("NK_NARROW"):   # sample brackets of the one-pass step: -1 ada
     ctx.set_option("nk_narrow", int(os.environ["NK_NARROW"]))
 if os.environ.get("XDEM_NK_BINSEG"):   # bin candidates: 1 per-bin segments + one workgroup per bin (default), 0 digit passes over all slots
     ctx.set_option("nk_binseg", int(os.environ["XDEM_NK_BINSEG"]))
-plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
+group = None
+if os.environ.get("NK_HOOKED"):   # the partitioned plan's route on one GPU: a 1-rank RCCL group, reductions through the device-side hook
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29633")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    group = "world"
+    if os.environ.get("NK_FUSED_DIST"):
+        ctx.set_option("nk_fused_dist", int(os.environ["NK_FUSED_DIST"]))
+plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx, group)
 plan.step(0.0, 0.0, (10.0, 10.0), 72)
+plan.step(1.0, 0.0, (10.0, 10.0), 72)
 for i in range(k):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     d = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
     dt = time.perf_counter() - t0
     print(f"[{os.path.basename(_lib.LIB_PATH)}] step {m}x{m}: {dt * 1e3:.3f} ms (n_valid {d['n_valid']}, vshift {d['vshift']:.6f})", flush=True)
-print("routes", plan.route_counts(), flush=True)
+print("routes", plan.route_counts(), "reductions (host, device)", ctx.reduction_calls(), flush=True)
 plan.close()
+if group is not None:
+    import torch.distributed as dist
+
+    dist.destroy_process_group()
