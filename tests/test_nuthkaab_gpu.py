@@ -1123,3 +1123,51 @@ def test_onepass_step_on_a_hooked_plan():
         ctx.close()
         if created:
             dist.destroy_process_group()
+
+
+def test_onepass_step_on_a_hooked_plan_float64():
+    """The same route for float64 rasters (64-bit keys in the exchanged key lists, 8-byte values in the per-bin exchange): 6000^2 pair,
+    18 bins, 1-rank RCCL group -- identical to the hook-less plan, ten reductions per step."""
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from xdem_amd import _lib, coreg
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29621")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    ctx = _lib.Context(0)
+    try:
+        ref, tba = bench._c3_pair(torch.device("cuda", 0), 6000)
+        ref, tba = ref.double().contiguous(), tba.double().contiguous()
+        steps = ((0.0, 0.0), (1.7, 0.6), (-17.0, -6.0))
+        res = {}
+        for mode in ("plain", "hooked"):
+            plan = coreg.NKPlan(ref, tba, None, ctx, group=None if mode == "plain" else "world")
+            plan.step(0.3, 0.1, (10.0, 10.0), 18)
+            h0, d0 = ctx.reduction_calls()
+            r0 = plan.route_counts()
+            res[mode] = [plan.step(sx, sy, (10.0, 10.0), 18) for (sx, sy) in steps]
+            h1, d1 = ctx.reduction_calls()
+            r1 = plan.route_counts()
+            assert r1["onepass"] - r0["onepass"] == len(steps) and r1["twopass"] == r0["twopass"] and r1["plain"] == r0["plain"], (mode, r0, r1)
+            if mode == "hooked":
+                assert h1 == h0 and d1 - d0 == 10 * len(steps), (h0, h1, d0, d1)
+            plan.close()
+        for a, b in zip(res["hooked"], res["plain"]):
+            assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"]
+            assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True)
+            assert np.array_equal(a["edges"], b["edges"])
+    finally:
+        ctx.set_allreduce(None)
+        ctx.close()
+        if created:
+            dist.destroy_process_group()
