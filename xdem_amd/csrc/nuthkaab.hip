@@ -2352,15 +2352,17 @@ static __global__ void nk_mr_dh_hdr_merge_kernel(const uint64_t* slots, int worl
 // (nk_bin_select_kernel's map), its row of red; the resolved counters of the rank; flags only this rank may know
 // red: [0] overflow, [1] miss | res [2][nb] | rows [world][nb][256] (uint32)
 template <typename T>
-__global__ __launch_bounds__(256) void nk_mr_bin_hist_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls_loc /* [3][nb] */,
-                                                             const uint64_t* __restrict__ res /* [2][nb], this rank */, const unsigned long long* seg_ctr,
-                                                             int nb, const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
-                                                             int rank, int world, uint64_t* red, const unsigned long long* ctr) {
+__global__ __launch_bounds__(HIST_THREADS) void nk_mr_bin_hist_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls_loc /* [3][nb] */,
+                                                                      const uint64_t* __restrict__ res /* [2][nb], this rank */, const unsigned long long* seg_ctr,
+                                                                      int nb, const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
+                                                                      int rank, int world, uint64_t* red, const unsigned long long* ctr) {
+    // (one workgroup per bin, like nk_bin_select_kernel's first read: 1024 threads, eight values per thread and trip with all loads
+    //  issued first, eight copies of the table -- 256 threads with one value in flight took 190 us for the 72 segments of C3)
     typedef typename KeyT<T>::type K;
-    __shared__ uint32_t h[SEL_RADIX];
+    __shared__ uint32_t h[BINSEL_COPIES * (SEL_RADIX + 1)];
     __shared__ unsigned long long s_off;
     const int b = blockIdx.x, tid = threadIdx.x;
-    h[tid] = 0u;
+    for (int k = tid; k < BINSEL_COPIES * (SEL_RADIX + 1); k += blockDim.x) h[k] = 0u;
     const unsigned long long n = seg_ctr[(size_t)b * BINSEG_CTR_STRIDE];
     if (tid == 0) {
         unsigned long long acc = 0;
@@ -2377,19 +2379,33 @@ __global__ __launch_bounds__(256) void nk_mr_bin_hist_kernel(const T* __restrict
     __syncthreads();
     const T* v = seg_v + s_off;
     const BinsegMap mp = binseg_map<T, K>(klo[b], khi[b]);
-    for (unsigned long long i = tid; i < n; i += blockDim.x) {
-        const T x = v[i];
-        if (x == x) atomicAdd(&h[binseg_bucket<T>(x, mp)], 1u);
+    uint32_t* hc = h + (tid & (BINSEL_COPIES - 1)) * (SEL_RADIX + 1);
+    constexpr int U = 8;
+    for (unsigned long long i0 = tid; i0 < n; i0 += (unsigned long long)blockDim.x * U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long i = i0 + (unsigned long long)u * blockDim.x;
+            x[u] = i < n ? v[i] : (T)NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (x[u] == x[u]) atomicAdd(&hc[binseg_bucket<T>(x[u], mp)], 1u);
     }
     __syncthreads();
-    uint32_t* rows = reinterpret_cast<uint32_t*>(red + 2 + 2 * nb);
-    rows[((size_t)rank * nb + b) * SEL_RADIX + tid] = h[tid];
+    if (tid < SEL_RADIX) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int q = 0; q < BINSEL_COPIES; ++q) t += h[q * (SEL_RADIX + 1) + tid];
+        uint32_t* rows = reinterpret_cast<uint32_t*>(red + 2 + 2 * nb);
+        rows[((size_t)rank * nb + b) * SEL_RADIX + tid] = t;
+    }
 }
 // exchange 10, before: per bin the bucket that holds the wanted rank (from the summed rows), this rank's values of that bucket and its
 // smallest value above it into the bin's stride of `gseg` at the offsets the rows give; the counters nk_bin_select_kernel will read,
 // rewritten for the small array (see the block comment); the true (total, below, inside) for the host's bracket statistics
 template <typename T>
-__global__ __launch_bounds__(256) void nk_mr_bin_gather_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls_loc, const uint64_t* __restrict__ cls /* summed */,
+__global__ __launch_bounds__(HIST_THREADS) void nk_mr_bin_gather_kernel(const T* __restrict__ seg_v, const uint64_t* __restrict__ cls_loc, const uint64_t* __restrict__ cls /* summed */,
                                                                const uint64_t* __restrict__ red /* exchange 9, summed */, const unsigned long long* seg_ctr, int nb,
                                                                const typename KeyT<T>::type* __restrict__ klo, const typename KeyT<T>::type* __restrict__ khi,
                                                                int rank, int world, T* __restrict__ gseg /* [nb][MR_GSEG], zeroed */, uint64_t* cls_f /* [3][nb] */,
@@ -2433,7 +2449,7 @@ __global__ __launch_bounds__(256) void nk_mr_bin_gather_kernel(const T* __restri
         if (tid == 0) hand_over(0, 0);
         return;
     }
-    {
+    if (tid < SEL_RADIX) {
         unsigned long long t = 0;
         for (int r = 0; r < world; ++r) t += rows[((size_t)r * nb + b) * SEL_RADIX + tid];
         s_g[tid] = t;
@@ -2491,16 +2507,25 @@ __global__ __launch_bounds__(256) void nk_mr_bin_gather_kernel(const T* __restri
     T* out = gseg + (size_t)b * MR_GSEG + base;
     const uint32_t mine = s_mloc[rank];
     K mn = ~(K)0;
-    for (unsigned long long i = tid; i < n; i += blockDim.x) {
-        const T x = v[i];
-        if (x != x) continue;
-        const int d = binseg_bucket<T>(x, mp);
-        if (d == d1) {
-            const uint32_t pos = atomicAdd(&s_cnt, 1u);
-            if (pos < mine) out[pos] = x;
-        } else if (d > d1) {
-            const K key = key_of(x);
-            mn = key < mn ? key : mn;
+    constexpr int U = 8;   // (1024 threads, eight values per thread and trip, all loads first: nk_bin_select_kernel's second read)
+    for (unsigned long long i0 = tid; i0 < n; i0 += (unsigned long long)blockDim.x * U) {
+        T x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long i = i0 + (unsigned long long)u * blockDim.x;
+            x[u] = i < n ? v[i] : (T)NAN;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (x[u] != x[u]) continue;
+            const int d = binseg_bucket<T>(x[u], mp);
+            if (d == d1) {
+                const uint32_t pos = atomicAdd(&s_cnt, 1u);
+                if (pos < mine) out[pos] = x[u];
+            } else if (d > d1) {
+                const K key = key_of(x[u]);
+                mn = key < mn ? key : mn;
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -3177,7 +3202,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             // exchange 9: per bin the value-bucket histogram of this rank's segment, one row per rank; the resolved counters; local flags
             const int64_t words9 = 2 + 2 * (int64_t)nb + (int64_t)world * nb * (SEL_RADIX / 2);
             XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_a, 0, (size_t)words9 * 8, ctx->stream));
-            hipLaunchKernelGGL((nk_mr_bin_hist_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, res_y, seg_ctr, nb, klo_y,
+            hipLaunchKernelGGL((nk_mr_bin_hist_kernel<T>), dim3(nb), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, res_y, seg_ctr, nb, klo_y,
                                khi_y, rank, world, P->mr_a, ctr);
             XD_HIP_CHECK(ctx, hipGetLastError());
             rc = xd_allreduce_device(ctx, P->mr_a, words9, XDEMHIP_RED_SUM_U64);
@@ -3185,7 +3210,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             // exchange 10: per bin the chosen bucket's values of all ranks (+ each rank's smallest value above it)
             const int64_t words10 = (int64_t)nb * MR_GSEG * (int64_t)sizeof(T) / 8;
             XD_HIP_CHECK(ctx, hipMemsetAsync(P->mr_b, 0, (size_t)words10 * 8, ctx->stream));
-            hipLaunchKernelGGL((nk_mr_bin_gather_kernel<T>), dim3(nb), dim3(256), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, cls_y, P->mr_a, seg_ctr, nb,
+            hipLaunchKernelGGL((nk_mr_bin_gather_kernel<T>), dim3(nb), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->y), cls_loc, cls_y, P->mr_a, seg_ctr, nb,
                                klo_y, khi_y, rank, world, reinterpret_cast<T*>(P->mr_b), cls_f, res_f, segf_ctr, cnt_true, ctr);
             XD_HIP_CHECK(ctx, hipGetLastError());
             rc = xd_allreduce_device(ctx, P->mr_b, words10, XDEMHIP_RED_SUM_U64);
