@@ -75,6 +75,21 @@ static int go(const void* dem, int64_t H, int64_t W, int64_t ht, int64_t hb, int
         else run<0, false, true, Spec<MASK_SAH_WIN, 0, 1, 0, 1>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);
         return 0;
     }
+    // the small first-derivative sets of terrain_tile.h's XD_SMALL (lean tail, compile-time masks), every fit
+    if (g_tail == 2 && !win && !curv && P.degrees && P.hs_zf2 == 1.0 && sizeof(TIN) == 4 && sizeof(TOUT) == 4) {
+#define SMALL(M)                                                                                                   \
+    do {                                                                                                           \
+        if (fit == 0) run<0, false, false, Spec<M, 0, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);        \
+        else if (fit == 1) run<1, false, false, Spec<M, 0, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);   \
+        else run<2, false, false, Spec<M, 0, 1, 0, 1, 2>, TIN, TOUT>(d, H, W, ht, hb, TH, P, out);                 \
+        return 0;                                                                                                  \
+    } while (0)
+        if (P.mask == A_SLOPE) SMALL(A_SLOPE);
+        if (P.mask == (A_SLOPE | A_ASPECT)) SMALL(A_SLOPE | A_ASPECT);
+        if (P.mask == A_HILLSHADE) SMALL(A_HILLSHADE);
+        if (P.mask == (A_SLOPE | A_ASPECT | A_HILLSHADE)) SMALL(A_SLOPE | A_ASPECT | A_HILLSHADE);
+#undef SMALL
+    }
 #define GO(F, C, Wn) run<F, C, Wn, SpecRuntime, TIN, TOUT>(d, H, W, ht, hb, TH, P, out)
     if (fit == 0) { if (win) GO(0, false, true); else GO(0, false, false); }
     else if (fit == 1) { if (curv) { if (win) GO(1, true, true); else GO(1, true, false); } else { if (win) GO(1, false, true); else GO(1, false, false); } }

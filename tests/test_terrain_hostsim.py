@@ -149,3 +149,35 @@ def test_T11_numba_engine_reference_fixtures():
                 assert np.array_equal(got[sel], ref[sel]), (key, got[sel], ref[sel])
         n += 1
     assert n > 500 and n_inf > 100
+
+
+@pytest.mark.parametrize("fit", ["Florinsky", "Horn", "ZevenbergThorne"])
+@pytest.mark.parametrize("attrs", [["slope"], ["slope", "aspect"], ["hillshade"], ["slope", "aspect", "hillshade"]])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_first_derivative_sets_nonfinite_windows(fit, attrs, dtype):
+    """The small attribute sets (no curvature, no windowed index) have no sum over the whole window to take their NaN rule from; for the
+    Florinsky fit the two derivative sums and the centre row's partial stand in for it (terrain_math.h, `poison`).  NaN, +Inf, -Inf,
+    runs of them, pixels next to the raster's edge, a hole of exactly one pixel in the window's centre / corner: the NaN mask must be the
+    oracle's exactly -- an output is NaN iff its window holds a non-finite pixel or leaves the raster -- and the values agree."""
+    from xdem_amd.synth import fbm_numpy
+
+    dem = fbm_numpy((90, 200), seed=21, dtype=dtype)
+    dem[5, 7] = np.nan
+    dem[20, 100] = np.inf
+    dem[21, 101] = -np.inf            # +Inf and -Inf in one window: sums that cancel to NaN
+    dem[40, 50:62] = np.inf           # a run: every column of some windows
+    dem[41, 50:62] = -np.inf
+    dem[60:66, 150] = np.nan          # a column run: every row of some windows
+    dem[70, 30] = -np.inf
+    dem[2, 2] = np.inf                # within the halo of the raster's corner
+    dem[-1, -1] = np.nan
+    dem[80, 120] = 3.0e38             # huge but finite: must NOT poison anything (float32 max ~3.4e38)
+    kw = dict(resolution=10.0, surface_fit=fit)
+    got = hostsim_terrain(dem, attrs, **kw)
+    ref = to.terrain_attributes(dem, attrs, **kw)
+    for a, g, r in zip(attrs, got, ref):
+        assert np.array_equal(np.isnan(g), np.isnan(r)), f"{fit}/{a}: NaN mask differs at {np.argwhere(np.isnan(g) != np.isnan(r))[:5]}"
+        far = np.ones(dem.shape, dtype=bool)
+        far[74:87, 114:127] = False    # (windows that hold the 3e38 pixel: slopes of 90 deg minus rounding, not a parity case)
+        ok = np.isfinite(r) & far
+        check_attribute(np.where(ok, g, np.nan), np.where(ok, r, np.nan), a, dem, 10.0, f"{fit}/{a}")

@@ -1017,7 +1017,7 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                     A[k] = zr - zl;
                     B[k] = z4 - z0;
                     if (CURV) D2[k] = fma_2(B[k], A[k]);
-                    R[k] = (p + q) + zc;
+                    if (CURV) R[k] = (p + q) + zc;   // (the plain row sum serves zyy only; without curvatures nothing needs it -- see `poison` below)
                     if (CURV) Wr[k] = fma(2.0, p - zc, -q);
                     Ua[k] = fma(68.0, zc, fma(62.0, q, 44.0 * p));
                     Ub[k] = fma(17.0, zc, fma(5.0, q, -31.0 * p));
@@ -1044,10 +1044,23 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                         const double sx = fma(17.0, B[c0], fma(68.0, A[c0],
                                           fma(5.0, B[m1] + B[p1], fma(62.0, A[m1] + A[p1],
                                           fma(-31.0, B[m2] + B[p2], 44.0 * (A[m2] + A[p2]))))));
-                        det = CURV ? ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2] : ((R[m2] + R[m1]) + (R[c0] + R[p1])) + R[p2];
-                        poison = det - det;
+                        const double sy = (Ua[p1] - Ua[m1]) + (Ub[p2] - Ub[m2]);
+                        if (CURV) {
+                            det = ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2];
+                            poison = det - det;
+                        } else {
+                            // Without second derivatives there is no sum over the whole window to borrow, and one of its own cost seven
+                            // float64 operations per pixel (row sums, their sum, det - det) in launches that are bound by instruction issue.
+                            // The two first-derivative sums already see every pixel but the centre one with a NONZERO weight -- sx all
+                            // rows of the four outer columns, sy all columns of the four outer rows -- and Ua of the centre row holds the
+                            // centre pixel (weight 68): their sum is non-finite exactly when some pixel of the window is (a finite raster
+                            // cannot overflow float64 here), so v - v is the same 0 / NaN as det - det, in three operations.
+                            det = 0.0;
+                            const double v = (sx + sy) + Ua[c0];
+                            poison = v - v;
+                        }
                         zx = (TIN)fma(-sx, P.s1, poison);
-                        zy = (TIN)(((Ua[p1] - Ua[m1]) + (Ub[p2] - Ub[m2])) * P.s1);
+                        zy = (TIN)(sy * P.s1);
                         if (CURV) {
                             zxx = (TIN)fma(det, P.sxx, poison);
                             zyy = (TIN)(fma(2.0, (R[m2] + R[p2]) - R[c0], -(R[m1] + R[p1])) * P.sxx);
