@@ -666,7 +666,10 @@ XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, 
     const float g2f = (float)g2;
     const float opgf = 1.0f + g2f;
     float rwf, rgf;                              // cos(slope), 1 / |grad|
-    rsq32_pair(opgf, g2f, rwf, rgf);
+    // (a launch that asks for the hillshade alone never uses 1 / |grad|: one seed and one plain Newton step instead of the pair --
+    //  the same operations on the half it keeps, so the plane is bit-identical)
+    if (m & (A_SLOPE | A_ASPECT | (A_ANY_CURV & ~A_CURVATURE))) rsq32_pair(opgf, g2f, rwf, rgf);
+    else { rwf = rsq32(opgf); rgf = 0.0f; }
     bool want_f64 = false;
     const float ax = fabsf(zxf), ay = fabsf(zyf);
     const float amin = fminf(ax, ay);
