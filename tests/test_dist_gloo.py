@@ -68,6 +68,18 @@ def _worker(rank, world, port, q):
         ok_hook &= red([big + 10 - rank, 7 + rank, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF if rank else big + 1], 2) == \
             [big + 10 - (world - 1), 7, 0xFFFFFFFFFFFFFFFF, big + 1]
         ok_hook &= red([big + rank, 3 + rank, (3 if rank else big + 2)], 3) == [big + world - 1, 3 + world - 1, big + 2]
+        # a SUM all-reduce used as an ALL-GATHER (the one-pass Nuth-Kaab step on partitioned plans, xdemhip_set_rank): every rank fills
+        # its own slot with arbitrary 8-byte patterns -- packed uint32 pairs, float64 bits (-0.0, NaN payloads, denormals, -Inf),
+        # all-ones words -- and zeros elsewhere; what comes back must be every rank's slot, bit for bit
+        def slot_words(r):
+            f = np.array([-0.0, np.nan, 5e-324, -np.inf, 1.0 + r, -1.75e300 * (r + 1)], dtype=np.float64).view(np.uint64)
+            u = np.array([0xFFFFFFFFFFFFFFFF, (0xFFFFFFFF << 32) | r, (r + 1) << 32, 0x80000000_80000000, 0x7FF8_0000_DEAD_0000 + r], dtype=np.uint64)
+            return np.concatenate([f, u])
+        width_s = len(slot_words(0))
+        mine = np.zeros(world * width_s, dtype=np.uint64)
+        mine[rank * width_s:(rank + 1) * width_s] = slot_words(rank)
+        got = np.array(red(mine.tolist(), 0), dtype=np.uint64)
+        ok_hook &= bool(np.array_equal(got, np.concatenate([slot_words(r) for r in range(world)])))
         ok_red = ok_red and ok_hook
         t = torch.tensor([float(rank)])
         xd.allreduce_sum_(t)
