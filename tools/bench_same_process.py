@@ -6,7 +6,7 @@
   python tools/bench_same_process.py <dir> profiles/<tag>_bench_same_process.json
 
 bench.py launches, in this order: W warm-up + K timed steps on the library's scattered planes, then (XDEM_BENCH_AB, default on)
-W + K on torch.empty planes.  A step = one `terrain_strip_kernel` dispatch (raster interior) + one `terrain_tile_kernel`
+W + K on torch.empty planes (a one-launch spot check of the timed planes in between).  A step = one `terrain_strip_kernel` dispatch (raster interior) + one `terrain_tile_kernel`
 dispatch (frame of edge tiles).  This tool takes the kernel trace, keeps the dispatches of those two kernels in start order,
 cuts them into the four groups and compares the mean duration of the TIMED dispatches with the `kernel_ms` /
 `kernel_ms_caller_planes` of the JSON line the very same process printed (HIP events on the launch stream).  Every dispatch
@@ -37,7 +37,9 @@ strips = [(s, e) for s, e, k, _ in rows if k == "strip"]
 tiles = [(s, e) for s, e, k, _ in rows if k == "tile"]
 names = sorted({n[:140] for _, _, _, n in rows})
 ab = "caller_planes" in line["roofline"]
-groups = [("scattered_warmup", W), ("scattered_timed", K)] + ([("torch_warmup", W), ("torch_timed", K)] if ab else [])
+# (bench.py checks a 64-row crop of the timed planes with one more small launch right behind the scattered group: one strip + one tile dispatch)
+spot = [("spot_check", 1)] if line["roofline"].get("output_spot_check") else []
+groups = [("scattered_warmup", W), ("scattered_timed", K)] + spot + ([("torch_warmup", W), ("torch_timed", K)] if ab else [])
 assert len(strips) == len(tiles) == sum(n for _, n in groups), (len(strips), len(tiles), groups)
 out = {"bench_line": {"steps": K, "warmup": W, "ms_per_step": line["ms_per_step"], "kernel_ms": line["roofline"]["kernel_ms"],
                       "kernel_ms_min": line["roofline"]["kernel_ms_min"], "kernel_ms_max": line["roofline"]["kernel_ms_max"],
