@@ -1,9 +1,12 @@
 #!/bin/bash
-# round-5, session u: the one-pass step on partitioned plans (10 all-reduces per step) -- the new tests first, the tests of the hooked
-# plans that now take the route, the shared-GPU probe of one-pass vs two-pass on 2 ranks
+# round-5, session u: per-workgroup aggregation of the gathered keys -- NK tests, step time, dispatch sequence
 TAG=${1:-r05u}
 O=gpurun_out/$TAG; mkdir -p $O
-export PYTHONUNBUFFERED=1 XDEMHIP_DEBUG=1
-timeout 300 python -m pytest tests/test_nuthkaab_gpu.py -q -m gpu -p no:cacheprovider -x -s -k "hooked_plan or sharded_reduction_path" > $O/pytest_a.log 2>&1; echo "a rc=$?"; tail -25 $O/pytest_a.log | cut -c1-400
-timeout 500 python -m pytest tests/test_dist_gpu.py -q -m gpu -p no:cacheprovider -x -s -k "one_pass_step or partitioned_row_blocks" > $O/pytest_b.log 2>&1; echo "b rc=$?"; tail -25 $O/pytest_b.log | cut -c1-400
-timeout 300 python -u tools/nk_dist_probe.py 20000 2 5 > $O/nk_dist_probe.log 2>&1; echo "probe rc=$?"; grep -v "^\[xdemhip\]" $O/nk_dist_probe.log | tail -8 | cut -c1-400
+export PYTHONUNBUFFERED=1
+timeout 900 python -m pytest tests/test_nuthkaab_gpu.py -q -m gpu -p no:cacheprovider > $O/pytest.log 2>&1; tail -3 $O/pytest.log | cut -c1-300
+timeout 300 python -u tools/nk_trace.py 20000 6 > $O/nk_default.log 2>&1; grep -E "step|routes" $O/nk_default.log | tail -7
+XDEM_NK_BINSEG=0 timeout 300 python -u tools/nk_trace.py 20000 6 > $O/nk_old.log 2>&1; grep -E "step|routes" $O/nk_old.log | tail -7
+R=$GRAFT_REPO_ROOT
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/nktrace -o nk -- python $R/tools/nk_trace.py 20000 3 > $R/$O/nktrace.log 2>&1 )
+python tools/trace_sequence.py $O/nktrace 24 > $O/nk_sequence.txt 2>&1; tail -26 $O/nk_sequence.txt | cut -c1-120
+find $O -name '*.csv' -size +2M -delete
