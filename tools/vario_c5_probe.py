@@ -15,6 +15,8 @@ from xdem_amd import _lib
 from xdem_amd import spatialstats as ss
 from xdem_amd.synth import c5_variogram_blocks
 
+if os.environ.get("XD_LIB"):   # A/B of library builds across processes
+    _lib.LIB_PATH = os.environ["XD_LIB"]
 deffs = [int(a) for a in sys.argv[1:]] or [4096, 0]
 runs = int(os.environ.get("C5_RUNS", "100"))
 ctx = _lib.default_context(0)
