@@ -293,7 +293,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                     uint32_t lb, hb;
                     __builtin_memcpy(&lb, &lo_f, 4);
                     __builtin_memcpy(&hb, &hi_f, 4);
-                    s_clsrec[k] = make_uint4(0u - lo_d2, hi_d2 - lo_d2, lb, hb);   // (-lo: what the pair's v_dot2 accumulates onto)
+                    s_clsrec[k] = make_uint4(lo_d2, hi_d2 - lo_d2, lb, hb);
                 }
             }
         }
@@ -308,9 +308,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
     double run_s = 0.0;
     uint32_t run_start = 0;    // position (count of plain-tile pairs so far, the same for every lane) at which the lane's run began
     uint32_t run_pos = 0;      // ... and the current position: a run's length is their difference, no per-pair counter
-    // GRID: d^2 interval [lo, lo + run_w) of the run's class, kept as -lo: the accumulator of the pair's v_dot2, which then yields d^2 - lo
-    // at once (see the run loops); empty at first: the first pair looks its class up
-    uint32_t run_nlo = 0u - 1u, run_w = 0u;
+    uint32_t run_lo = 1u, run_w = 0u;   // GRID: d^2 interval of the run's class (empty: the first pair looks its class up)
     uint32_t run_ge = 0u;               // OP_BRACKET runs: pairs of the run at or above the bracket's low end
     T run_blo = (T)0, run_bhi = (T)0;   // ... and the bracket of the run's class
     // One workgroup = one (A tile x B chunk) unit, except in the SAMPLED digit passes: there a unit is 16 tile loads and 16 k pairs,
@@ -599,37 +597,29 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             // -- 5 % of the pairs of a lane, a third of the wave-pairs on SURVEY 8d's C5 geometry -- looks its
                             // class up, flushes the run (the run's length is the distance of its positions: no counter per pair)
                             // and loads the new bounds.
-                            // (second half of round 5: the subtract rides on the dot product -- v_dot2_i32_i16 takes an accumulator, and with
-                            //  -lo there it returns d^2 - lo directly: the pair that stays in its class costs ONE compare for its class.  The
-                            //  dot product is formed pair by pair, against the lane's class of that moment -- formed for the whole trip up
-                            //  front, a class change had to rebase the rest of the trip, and on this geometry, where a third of the
-                            //  wave-pairs see some lane change, that cost more than the subtract saved: 31.0 -> 31.9 ms, measured)
                             for (int j = 0; j < PT; j += 4) {
-                                v2s16 dd4[4];
+                                uint32_t d2[4];
                                 T dv[4];
     #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    dd4[u] = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                                    const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                                    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
                                     dv[u] = pv - s_bv[j + u];
                                 }
     #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    uint32_t d2r;   // d^2 - lo of the lane's class
-                                    asm("v_dot2_i32_i16 %0, %1, %1, %2" : "=v"(d2r) : "v"(dd4[u]), "v"(run_nlo));
-                                    if (!(d2r < run_w)) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
-                                        const uint32_t d2t = d2r - run_nlo;   // the pair's d^2 itself
-                                        const uint32_t cell = __float_as_uint((float)d2t) >> 20;
+                                    if (!((uint32_t)(d2[u] - run_lo) < run_w)) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
+                                        const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
                                         const uint4 e = s_lut4[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
-                                        const bool up = e.y <= d2t;   // the cell's one threshold lies at or below d^2: the class above it
+                                        const bool up = e.y <= d2[u];   // the cell's one threshold lies at or below d^2: the class above it
                                         const int off = (int)__umul24((unsigned)run_l, (unsigned)REC);
                                         atomicAdd(reinterpret_cast<double*>(s_sum_cp + off), run_s);
                                         atomicAdd(reinterpret_cast<uint32_t*>(s_cnt_cp + off), run_pos - run_start);
                                         run_l = (int)e.x + (up ? 1 : 0);
                                         run_s = 0.0;
                                         run_start = run_pos;
-                                        const uint32_t lo = up ? e.y : e.z;
-                                        run_w = (up ? e.w : e.y) - lo;   // (beyond the last edge: thresholds padded with all ones)
-                                        run_nlo = 0u - lo;
+                                        run_lo = up ? e.y : e.z;
+                                        run_w = (up ? e.w : e.y) - run_lo;   // (beyond the last edge: thresholds padded with all ones)
                                     }
                                     const double dd = (double)dv[u];
                                     run_s = OP == OP_SUMS_SQ ? __builtin_fma(dd, dd, run_s) : run_s + sqrt(fabs(dd));
@@ -672,7 +662,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             if (!have_a && run_w != 0xFFFFFFFFu) {
                                 const unsigned long long inc = (unsigned long long)(run_pos - run_start) | ((unsigned long long)run_ge << 21) | ((unsigned long long)run_ge << 42);
                                 atomicAdd(s_c3 + (size_t)run_l * NCOPY + (tid & (NCOPY - 1)), inc);
-                                run_l = nb; run_ge = 0u; run_start = run_pos; run_nlo = 0u; run_w = 0xFFFFFFFFu;
+                                run_l = nb; run_ge = 0u; run_start = run_pos; run_lo = 0u; run_w = 0xFFFFFFFFu;
                                 run_blo = s_lhf[2 * nb]; run_bhi = s_lhf[2 * nb + 1];
                             }
                             static_assert(NCOPY * 8 == 256, "counter records are 256 bytes");
@@ -682,22 +672,20 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                             static_assert(4 * PT <= 1024, "a run's count of pairs >= the low end must fit 11 bits");
                             if ((((j0 - jb0) / PT) & 3) == 0 && have_a) run_w = 0u;
                             for (int j = 0; j < PT; j += 4) {
-                                v2s16 dd4[4];
+                                uint32_t d2[4];
                                 T dv[4];
     #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    dd4[u] = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                                    const v2s16 d = __builtin_bit_cast(v2s16, pxy) - __builtin_bit_cast(v2s16, s_bxy[j + u]);
+                                    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(d2[u]) : "v"(d));
                                     dv[u] = pv - s_bv[j + u];
                                 }
     #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    uint32_t d2r;   // d^2 - lo of the lane's class (the subtract rides on the dot product: see the sums loop)
-                                    asm("v_dot2_i32_i16 %0, %1, %1, %2" : "=v"(d2r) : "v"(dd4[u]), "v"(run_nlo));
-                                    if (!(d2r < run_w)) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
-                                        const uint32_t d2t = d2r - run_nlo;   // the pair's d^2 itself
-                                        const uint32_t cell = __float_as_uint((float)d2t) >> 20;
+                                    if (!((uint32_t)(d2[u] - run_lo) < run_w)) {   // (exec-masked; skipped by the whole wave while every lane stays in its class)
+                                        const uint32_t cell = __float_as_uint((float)d2[u]) >> 20;
                                         const uint4 e = s_lut4[(cell > LUT_G0 ? cell : (uint32_t)LUT_G0) - LUT_G0];
-                                        const bool up = e.y <= d2t;
+                                        const bool up = e.y <= d2[u];
                                         // packed counter: pairs | >= low end | "above" (here: >= low end as well -- the candidates among
                                         // them are tallied in s_in and taken off at the end); a run holds <= 1024 pairs (see below)
                                         const uint32_t inc_lo = (run_ge << 21) | (run_pos - run_start), inc_hi = run_ge << 10;
@@ -706,15 +694,14 @@ __global__ __launch_bounds__(NT, (NT == 1024 && sizeof(T) == 4) ? 8 : 1) void pa
                                         run_ge = 0u;
                                         run_start = run_pos;
                                         if constexpr (CLSREC) {
-                                            const uint4 cr = s_clsrec[run_l];   // (-lo, width, bracket ends)
-                                            run_nlo = cr.x;
+                                            const uint4 cr = s_clsrec[run_l];
+                                            run_lo = cr.x;
                                             run_w = cr.y;
                                             __builtin_memcpy(&run_blo, &cr.z, 4);
                                             __builtin_memcpy(&run_bhi, &cr.w, 4);
                                         } else {
-                                            const uint32_t lo = up ? e.y : e.z;
-                                            run_w = (up ? e.w : e.y) - lo;
-                                            run_nlo = 0u - lo;
+                                            run_lo = up ? e.y : e.z;
+                                            run_w = (up ? e.w : e.y) - run_lo;
                                             const FzEnds<T> be = *reinterpret_cast<const FzEnds<T>*>(s_lhf + 2 * run_l);
                                             run_blo = be.lo;
                                             run_bhi = be.hi;
