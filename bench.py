@@ -19,6 +19,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -469,6 +470,110 @@ def device_state() -> list:
         return []
 
 
+class GpuSampler:
+    """Shader clock / memory clock / socket power / temperatures of the GPU DURING a timed loop, so that a slow line can be read
+    against the state of the box it came from (the same binary runs the headline launch at 13.1 ms on most boxes and 13.9 ms on
+    some; an idle rocm-smi snapshot cannot tell a power-managed clock from a slow placement of the planes).  A thread reads the
+    amdgpu sysfs files of the device every `period` seconds -- `pp_dpm_sclk` / `pp_dpm_mclk` (the starred level = the current
+    clock), hwmon `freq1_input`, `power1_average` / `power1_input`, `temp*_input` -- no subprocess, no SMI library, nothing the
+    GPU executes.  Best effort: whatever is unreadable is left out, and an empty result says so."""
+
+    def __init__(self, local_rank: int = 0, period: float = 0.01):
+        import glob
+        import threading
+
+        self.period = period
+        self.samples = []          # (t, {name: value})
+        self._stop = threading.Event()
+        self._thread = None
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() == "0x1002" and glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                    cards.append(d)
+            except Exception:
+                pass
+        self.dev = cards[local_rank] if local_rank < len(cards) else (cards[0] if cards else None)
+        self.files = {}
+        if self.dev:
+            hw = (glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")) or [None])[0]
+            cand = {"sclk_dpm": os.path.join(self.dev, "pp_dpm_sclk"), "mclk_dpm": os.path.join(self.dev, "pp_dpm_mclk"),
+                    "busy_pct": os.path.join(self.dev, "gpu_busy_percent")}
+            if hw:
+                cand.update({"sclk_hz": os.path.join(hw, "freq1_input"), "mclk_hz": os.path.join(hw, "freq2_input"),
+                             "power_avg_uW": os.path.join(hw, "power1_average"), "power_in_uW": os.path.join(hw, "power1_input"),
+                             "power_cap_uW": os.path.join(hw, "power1_cap"),
+                             "temp1_mC": os.path.join(hw, "temp1_input"), "temp2_mC": os.path.join(hw, "temp2_input"),
+                             "temp3_mC": os.path.join(hw, "temp3_input")})
+            for k, f in cand.items():
+                try:
+                    open(f).read()
+                    self.files[k] = f
+                except Exception:
+                    pass
+
+    @staticmethod
+    def _parse(name, txt):
+        txt = txt.strip()
+        if name.endswith("_dpm"):   # "0: 132Mhz\n1: 2400Mhz *": the starred level is the current clock
+            for line in txt.splitlines():
+                if line.rstrip().endswith("*"):
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                    return float(m.group(1)) if m else None
+            return None
+        try:
+            return float(txt)
+        except ValueError:
+            return None
+
+    def _read(self):
+        out = {}
+        for k, f in self.files.items():
+            try:
+                v = self._parse(k, open(f).read())
+                if v is not None:
+                    out[k] = v
+            except Exception:
+                pass
+        return out
+
+    def _loop(self):
+        while not self._stop.is_set():
+            self.samples.append((time.perf_counter(), self._read()))
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+
+        if self.files:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+
+    def summary(self, t0: float, t1: float) -> dict:
+        """Statistics of the samples taken inside [t0, t1] (perf_counter times of the timed region)."""
+        if not self.files:
+            return {"available": False, "why": "no readable amdgpu sysfs files (/sys/class/drm/card*/device)"}
+        inside = [s for t, s in self.samples if t0 <= t <= t1] or [s for _, s in self.samples]
+
+        def stat(key, scale):
+            v = sorted(s[key] * scale for s in inside if key in s)
+            return None if not v else {"mean": round(sum(v) / len(v), 1), "min": round(v[0], 1), "max": round(v[-1], 1)}
+
+        out = {"available": True, "samples_in_timed_region": len([1 for t, _ in self.samples if t0 <= t <= t1]),
+               "period_ms": self.period * 1e3, "source": "amdgpu sysfs (" + self.dev + ")",
+               "sclk_MHz": stat("sclk_hz", 1e-6) or stat("sclk_dpm", 1.0), "mclk_MHz": stat("mclk_hz", 1e-6) or stat("mclk_dpm", 1.0),
+               "power_W": stat("power_avg_uW", 1e-6) or stat("power_in_uW", 1e-6), "power_cap_W": stat("power_cap_uW", 1e-6),
+               "temp_C": {k: stat(k, 1e-3) for k in ("temp1_mC", "temp2_mC", "temp3_mC") if stat(k, 1e-3)},
+               "gpu_busy_pct": stat("busy_pct", 1.0)}
+        return out
+
+
 def end_to_end_host_path(ctx, n: int = 16384) -> dict:
     """SURVEY 8d "separate end-to-end number including H2D/D2H": BASELINE C2 (16384^2 float32, 11 attributes) through the call
     users make -- get_terrain_attribute(ndarray) -> list of ndarrays -- host buffers in and out, PCIe both ways."""
@@ -563,26 +668,50 @@ def main() -> None:
         if world > 1:  # communicator set-up (RCCL creates its point-to-point channels lazily) is not a step: do it up front
             xdist.RowBlock.wait_all(block.exchange())
             barrier()
+        sampler = GpuSampler(local_rank).start()   # clock / power / temperature while the warm-up and the timed steps run
         for _ in range(warmup):
             step()
         barrier()
         # HIP events around every step ON THE LAUNCH STREAM (the library launches on torch's current stream here), recorded
         # inside the timed region and read after it: the same launches under both clocks
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # the shader clock UNDER the launch: one sleeping wave per timed step on a side stream (xdemhip_clock_probe: ticks of the
+        # shader-clock counter against the constant 100 MHz one; ~7 ms each, inside its step) -- nothing the timed stream waits for
+        side = torch.cuda.Stream(device=dev)
+        ticks = torch.zeros((steps, 2), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for a_, b_ in ev:
+        for i, (a_, b_) in enumerate(ev):
             a_.record()
             step()
             b_.record()
+            try:
+                ctx.clock_probe(side, ticks[i], sleeps=1600)
+            except Exception:
+                pass
         barrier()
-        t = torch.tensor([time.perf_counter() - t0], device="cpu" if share else dev, dtype=torch.float64)
+        t1 = time.perf_counter()
+        sampler.stop()
+        tk = ticks.cpu().numpy().astype("float64")
+        mhz = [100.0 * c / w for c, w in tk if w > 0]
+        clock = None if not mhz else {"mean_GHz": round(sum(mhz) / len(mhz) / 1e3, 4), "min_GHz": round(min(mhz) / 1e3, 4),
+                                      "max_GHz": round(max(mhz) / 1e3, 4), "probes": len(mhz),
+                                      "source": "xdemhip_clock_probe: one sleeping wave per timed step next to the launch, s_memtime "
+                                                "(shader clock) / s_memrealtime (100 MHz)"}
+        t = torch.tensor([t1 - t0], device="cpu" if share else dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         step_ms = [a_.elapsed_time(b_) for a_, b_ in ev]
-        return float(t.item()), block, out, step_ms
+        state = sampler.summary(t0, t1)
+        state["shader_clock_under_load"] = clock
+        busy = (state.get("gpu_busy_pct") or {}).get("mean")
+        if busy is not None and busy < 50.0:
+            state["sysfs_note"] = (f"gpu_busy_percent read {busy} % while this GPU ran back-to-back launches: on this box the sysfs sensors do "
+                                   "not follow this GPU's load (stale or another device's) -- power / sclk from sysfs are not evidence here")
+        return float(t.item()), block, out, step_ms, state
 
     n = args.size
-    elapsed, block, out, step_ms = partitioned_run(n, args.steps, args.warmup)
+    elapsed, block, out, step_ms, gpu_state = partitioned_run(n, args.steps, args.warmup)
     kernel_ms = sum(step_ms) / len(step_ms)
     # A/B of the plane backing inside the same process (one GPU): the same launches on planes a CALLER would bring -- an ordinary
     # allocation (torch.empty = hipMalloc), which on some boxes is one physically contiguous block -- after the library's
@@ -608,17 +737,19 @@ def main() -> None:
             raise SystemExit(f"bench.py: spot check of the timed planes failed: {spot}")
         del crop
     ab = None
+    gpu_state2 = None
     if world == 1 and os.environ.get("XDEM_BENCH_AB", "1") == "1" and os.environ.get("XDEM_BENCH_PLANES", "auto") == "auto":
         del out
         import gc
 
         gc.collect()
-        _, _, out, ms2 = partitioned_run(n, args.steps, args.warmup, backing="torch", block=block)
+        _, _, out, ms2, gpu_state2 = partitioned_run(n, args.steps, args.warmup, backing="torch", block=block)
         k2 = sum(ms2) / len(ms2)
         ab = {"planes": "torch.empty (ordinary hipMalloc: what a caller of the C-ABI brings)", "kernel_ms": round(k2, 4),
               "kernel_ms_min": round(min(ms2), 4), "kernel_ms_max": round(max(ms2), 4),
               "achieved": round(BYTES_PER_PIXEL * block.rows * n / (k2 * 1e-3) / 1e9, 1),
-              "frac": round(BYTES_PER_PIXEL * block.rows * n / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+              "frac": round(BYTES_PER_PIXEL * block.rows * n / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+              "gpu_state_during_timed_steps": gpu_state2}
 
     # Kernel duration for the roofline: the mean of the HIP-event times of the K timed steps themselves (events recorded on the
     # launch stream around each step; one step = the streaming kernel over the raster interior + the tile kernel over its frame
@@ -633,7 +764,7 @@ def main() -> None:
         del out, block
         torch.cuda.empty_cache()
         c4_steps = max(2, min(args.steps, 5))
-        c4_elapsed, block, out, _ = partitioned_run(C4_SIZE, c4_steps, max(1, min(args.warmup, 2)))
+        c4_elapsed, block, out, _, _ = partitioned_run(C4_SIZE, c4_steps, max(1, min(args.warmup, 2)))
         c4 = {"workload": f"C4: {C4_SIZE}x{C4_SIZE} float32 fBm DEM, 11 attributes, {world} row blocks, halo depth {depth}, "
                           + ("shared-GPU gloo test mode" if share else "RCCL send/recv over xGMI"),
               "value": round(float(C4_SIZE) ** 2 * c4_steps / c4_elapsed / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
@@ -674,7 +805,12 @@ def main() -> None:
                                    "terrain_tile_kernel (frame of edge tiles)",
                          "kernel_ms_source": "mean HIP-event time of the timed steps themselves (events on the launch stream)",
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(min(step_ms), 4),
-                         "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch, "output_spot_check": spot},
+                         "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch, "output_spot_check": spot,
+                         # what the GPU was doing WHILE the timed steps ran (sysfs samples: see GpuSampler)
+                         "clock_GHz": (lambda c: None if not c else c["mean_GHz"])((gpu_state or {}).get("shader_clock_under_load")),
+                         "clock_GHz_caller_planes": (lambda c: None if not c else c["mean_GHz"])((gpu_state2 or {}).get("shader_clock_under_load")),
+                         "power_W": (lambda c: None if not c else c["mean"])(None if (gpu_state or {}).get("sysfs_note") else (gpu_state or {}).get("power_W")),
+                         "gpu_state_during_timed_steps": gpu_state},
         }
         if ab is not None:
             res["roofline"]["frac_caller_planes"] = ab["frac"]

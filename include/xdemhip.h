@@ -88,6 +88,13 @@ int xdemhip_device_free(xdemhip_ctx* ctx, void* ptr);
 /* Timing of the work enqueued by the last call on the context stream, measured with hipEvents recorded on
  * that stream around the kernel launch(es); returns milliseconds in *ms (synchronises the stop event). */
 int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
+/* Diagnostics: the shader clock WHILE other work runs.  Enqueues on `hip_stream` (a stream of the caller's, not the context's: the
+ * point is to run next to the context's kernels) one wave that sleeps `sleeps` x 8128 shader clocks (about 3.4 us each at 2.4 GHz)
+ * and writes to out_device[0..1] (device memory, 16 bytes) the ticks of the shader-clock counter and of the constant 100 MHz
+ * counter it saw go by: clock in MHz = 100 x out[0] / out[1].  No profiler, no SMI, nothing synchronises.  (bench.py launches one
+ * per timed step: the same binary runs the terrain launch at 12.7 ms on one box and 13.9 ms on the next, and only the clock under
+ * load tells a power-managed part from a slow placement of the planes.) */
+int xdemhip_clock_probe(xdemhip_ctx* ctx, void* hip_stream, int sleeps, uint64_t* out_device);
 /* Tuning / test switches.  "selection": how the exact medians (nanmedian of dh, aspect-bin and nd_binning medians, NMAD) are
  * selected -- 0 (default) bracketed for large inputs: brackets from a ~1/64 line sample, one counting + compaction pass,
  * exact selection among the candidates, plain radix passes if a bracket misses or if the input is too small per bin for

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--mask", type=int, default=FULL_MASK, help="attribute mask (1 slope, 2 aspect, 4 hillshade, ...; default the 11 of the headline)")
     ap.add_argument("--fit", type=int, default=2, help="0 Horn, 1 Zevenbergen-Thorne, 2 Florinsky")
+    ap.add_argument("--curv", type=int, default=0, help="0 geometric, 1 directional curvatures")
+    ap.add_argument("--planes", default="torch", help="torch (torch.empty = ordinary hipMalloc) | scattered (the product library's 8 MiB-piece backing) | both")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     import numpy as np
@@ -31,7 +33,9 @@ def main():
 
     n = a.size
     dem = fbm_torch(n, n, "cuda", seed=42)
-    out = torch.empty((11, n, n), dtype=torch.float32, device="cuda")
+    outs = {}
+    if a.planes in ("torch", "both"):
+        outs["torch"] = torch.empty((11, n, n), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     built = []
     for spec in a.libs:
@@ -48,11 +52,27 @@ def main():
             ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
             ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
         built.append((name, L, ctx))
-    planes = (ctypes.c_void_p * 11)(*[out[i].data_ptr() for i in range(11)])
+    if a.planes in ("scattered", "both"):
+        # the scattered backing through the C-ABI of the LAST library given (never through xdem_amd._lib: that loader opens the product
+        # library RTLD_GLOBAL, after which every build loaded here would resolve its internal symbols to the product's -- an A/B of a
+        # library against itself, as session r06c found out)
+        _, L, ctx = built[-1]
+        L.xdemhip_device_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]
+        ptr, gotc = ctypes.c_void_p(), ctypes.c_int()
+        rc = L.xdemhip_device_alloc(ctx, 11 * n * n * 4, 8, ctypes.byref(ptr), ctypes.byref(gotc))
+        assert rc == 0, rc
+
+        class _Arr:   # torch view of the library's allocation (kept alive for the process: a measurement tool)
+            __cuda_array_interface__ = {"shape": (11, n, n), "typestr": "<f4", "data": (ptr.value, False), "version": 2}
+
+        outs["scattered"] = torch.as_tensor(_Arr(), device="cuda")
+    out = next(iter(outs.values()))
+    assert getattr(sys.modules.get("xdem_amd._lib"), "_lib", None) is None, "the product library is loaded RTLD_GLOBAL: this A/B would compare it with itself"
     npl = bin(a.mask).count("1")
+    planes = (ctypes.c_void_p * 11)(*[out[i].data_ptr() for i in range(11)])
 
     def launch(L, ctx):
-        rc = L.xdemhip_terrain(ctx, ctypes.c_void_p(dem.data_ptr()), 0, n, n, n, 0, 0, 10.0, a.fit, 0, a.mask, 0, 3, 45.0, 315.0,
+        rc = L.xdemhip_terrain(ctx, ctypes.c_void_p(dem.data_ptr()), 0, n, n, n, 0, 0, 10.0, a.fit, a.curv, a.mask, 0, 3, 45.0, 315.0,
                                1.0, 1, 0, planes, 1)
         assert rc == 0, rc
         L.xdemhip_synchronize(ctx)
@@ -60,23 +80,28 @@ def main():
         L.xdemhip_last_kernel_ms(ctx, ctypes.byref(ms))
         return float(ms.value)
 
-    times = {name: [] for name, _, _ in built}
-    for name, L, ctx in built:
-        launch(L, ctx)
-    for _ in range(a.rounds):
+    for pname, pl in outs.items():
+        out = pl
+        planes = (ctypes.c_void_p * 11)(*[out[i].data_ptr() for i in range(11)])
+        times = {name: [] for name, _, _ in built}
         for name, L, ctx in built:
-            for _ in range(a.reps):
-                times[name].append(launch(L, ctx))
-    for name, t in times.items():
-        t = sorted(t)
-        print(f"{name:12s} min {t[0]:7.3f}  median {t[len(t) // 2]:7.3f}  max {t[-1]:7.3f} ms", flush=True)
+            launch(L, ctx)
+        for _ in range(a.rounds):
+            for name, L, ctx in built:
+                for _ in range(a.reps):
+                    times[name].append(launch(L, ctx))
+        for name, t in times.items():
+            t = sorted(t)
+            print(f"[{pname:9s} planes] {name:12s} min {t[0]:7.3f}  median {t[len(t) // 2]:7.3f}  max {t[-1]:7.3f} ms", flush=True)
     # agreement on a crop (bit patterns; NaN == NaN)
     crop = slice(0, min(n, 4096))
     ref = None
     for name, L, ctx in built:
         launch(L, ctx)
-        got = out[:npl, crop, crop].cpu().numpy().view(np.int32).astype(np.int64)
+        gf = out[:npl, crop, crop].cpu().numpy()
+        got = gf.view(np.int32).astype(np.int64)
         got = np.where(got < 0, -(got & 0x7FFFFFFF), got)
+        got[np.isnan(gf)] = 1 << 40   # every NaN is the same NaN (the sign of a NaN is not an output)
         if ref is None:
             ref = got
             continue

@@ -84,6 +84,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_reduction_calls.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.xdemhip_set_rank.argtypes = [c_ctx, ctypes.c_int, ctypes.c_int]
         L.xdemhip_last_kernel_ms.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_float)]
+        L.xdemhip_clock_probe.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.xdemhip_terrain.argtypes = [
             c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
             ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
@@ -410,6 +411,11 @@ class Context:
         """Tuning / test switch of the library (``xdemhip_set_option``), e.g. ``("selection", 1)``."""
         self.check(self._L.xdemhip_set_option(self.handle, name.encode(), int(value)))
         self.options[name] = int(value)
+
+    def clock_probe(self, stream, out, sleeps: int = 2000) -> None:
+        """Enqueue the shader-clock probe (``xdemhip_clock_probe``) on `stream` (a ``torch.cuda.Stream`` other than the one the
+        context launches on); `out` = a device tensor of two int64 / uint64 words: shader-clock ticks, 100 MHz ticks."""
+        self.check(self._L.xdemhip_clock_probe(self.handle, ctypes.c_void_p(int(stream.cuda_stream)), int(sleeps), ctypes.c_void_p(int(out.data_ptr()))))
 
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_float()

@@ -249,7 +249,12 @@ int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, 
         *ptr = nullptr;
         if (got_contiguous) *got_contiguous = 0;
         const bool scattered = (flags & XDEMHIP_ALLOC_SCATTERED) != 0;
-        return device_alloc_chunked(ctx, bytes, scattered ? (size_t)8 << 20 : (size_t)64 << 20, scattered, ptr);
+        size_t piece_mb = scattered ? 8 : 64;
+        if (const char* e = getenv("XDEMHIP_SCATTER_PIECE_MB")) {   // (measurements: tools/piece_probe.py)
+            const long v = atol(e);
+            if (scattered && v >= 1 && v <= 4096) piece_mb = (size_t)v;
+        }
+        return device_alloc_chunked(ctx, bytes, piece_mb << 20, scattered, ptr);
     }
     const bool contiguous = (flags & XDEMHIP_ALLOC_CONTIGUOUS) != 0;
     if (flags & XDEMHIP_ALLOC_RECYCLED) {
@@ -423,6 +428,24 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms) {
     if (!ctx->timed) return xd_fail(ctx, XDEMHIP_EINVAL, "no timed launch on this context yet");
     XD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_stop));
     XD_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return XDEMHIP_OK;
+}
+
+// One wave that sleeps `sleeps` x 64 x 127 shader clocks and reads both device counters around it: s_memtime (clock64: counts at the
+// SHADER clock on gfx950 -- 24.0 ticks per tick of the other one on an idle 2.4 GHz part, tools/clock_probe.hip) and s_memrealtime
+// (wall_clock64: constant 100 MHz).  Launched on a side stream next to a heavy kernel it tells that kernel's effective clock.
+static __global__ void xd_clock_probe_kernel(uint64_t* out, int sleeps) {
+    const uint64_t t0 = wall_clock64(), c0 = clock64();
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    const uint64_t t1 = wall_clock64(), c1 = clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = t1 - t0; }
+}
+
+int xdemhip_clock_probe(xdemhip_ctx* ctx, void* hip_stream, int sleeps, uint64_t* out_device) {
+    if (!ctx || !out_device || sleeps < 1) return XDEMHIP_EINVAL;
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(xd_clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(hip_stream), out_device, sleeps);
+    XD_HIP_CHECK(ctx, hipGetLastError());
     return XDEMHIP_OK;
 }
 

@@ -264,6 +264,28 @@ XD_HD float select_gt(double x, double y, float a, float b) {
     return (x > y) ? a : b;
 #endif
 }
+// x > y ? a : b, all float32: compare into a scalar mask + VOP3 select (see select_gt)
+XD_HD float select_gt32(float x, float y, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    uint64_t mk;
+    asm("v_cmp_gt_f32_e64 %1, %2, %3\n\tv_cndmask_b32_e64 %0, %5, %4, %1" : "=v"(r), "=&s"(mk) : "v"(x), "v"(y), "v"(a), "v"(b));
+    return r;
+#else
+    return (x > y) ? a : b;
+#endif
+}
+// |x| > |y| ? a : b (the absolute values are operand modifiers of the compare)
+XD_HD float select_absgt32(float x, float y, float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    uint64_t mk;
+    asm("v_cmp_gt_f32_e64 %1, |%2|, |%3|\n\tv_cndmask_b32_e64 %0, %5, %4, %1" : "=v"(r), "=&s"(mk) : "v"(x), "v"(y), "v"(a), "v"(b));
+    return r;
+#else
+    return (fabsf(x) > fabsf(y)) ? a : b;
+#endif
+}
 // clamp to [lo, hi] that keeps NaN (v_med3_f32 alone would return the smaller bound for a NaN input)
 XD_HD float clamp_keep_nan(float v, float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -654,9 +676,11 @@ XD_HD void surface_pixel_mixed(float zxf, float zyf, float zxxf, float zyyf, flo
 // Returns flag bits: TAIL_WANT_F64 (hillshade plane wants float64), TAIL_COLD (the pixel belongs to the cold path: a first
 // derivative cancelled exactly or the squared gradient is outside the range above -- decided here from values the tail has
 // anyway: min(|zx|, |zy|) and the rounded g2), TAIL_COLD_KNOWN (always set: the caller need not test again).
-enum : unsigned { TAIL_WANT_F64 = 1u, TAIL_COLD = 2u, TAIL_COLD_KNOWN = 4u };
+// (round 6: the two decisions leave as two booleans -- compare results the compiler keeps as scalar lane masks -- instead of flag
+// bits in a vector register that had to be materialised with a select and tested again with a compare)
 template <bool CURV, class SP, class SINK>
-XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, float zxyf, const TerrainParams& P, SINK& sk) {
+XD_HD void surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, float zxyf, const TerrainParams& P, SINK& sk,
+                              bool& cold_out, bool& want_f64_out, uint64_t& cold_any) {
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
     const bool deg = SP::DEG < 0 ? (P.degrees != 0) : (SP::DEG != 0);
     const bool zf_not_1 = SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0);
@@ -675,7 +699,21 @@ XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, 
     const float amin = fminf(ax, ay);
     // (NaN: the range tests are false and NaN propagates by itself; fminf(0, NaN) = 0 sends a zero derivative next to a
     // NaN one to the cold path, which returns NaN for it as well)
-    const unsigned cold_bits = TAIL_COLD_KNOWN | (((amin == 0.0f) | (g2f < 1e-13f) | (g2f > 1e16f)) ? TAIL_COLD : 0u);
+    cold_out = (amin == 0.0f) | (g2f < 1e-13f) | (g2f > 1e16f);
+    // "does any lane of the wave go to the cold path" = the three compares OR-ed on the scalar unit.  (Asked as
+    // ballot(cold_out) != 0 hipcc selects 0 / 1 into a vector register and compares that again: two vector instructions per row
+    // for a value that already sits in a scalar register pair.  `cold_out` itself is only read inside the cold branch.)
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        uint64_t k0, k1, k2;
+        asm("v_cmp_eq_f32_e64 %0, 0, %1" : "=s"(k0) : "v"(amin));
+        asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(k1) : "s"(1e-13f), "v"(g2f));
+        asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(k2) : "s"(1e16f), "v"(g2f));
+        cold_any = k0 | k1 | k2;
+    }
+#else
+    cold_any = cold_out ? 1u : 0u;
+#endif
     float as_slope = 0.0f, as_aspect = 0.0f;
     {
         const float xs = fminf((g2f * rgf) * rwf, rwf), xa = amin * rgf;   // min(sin, cos) of the slope; aspect octant
@@ -683,21 +721,28 @@ XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, 
         else if (m & A_SLOPE) as_slope = asin32(xs);
         else if (m & A_ASPECT) as_aspect = asin32(xa);
     }
-    if (m & A_SLOPE) {
+    if ((m & A_SLOPE) && SP::DEG == 1) {
+        // degrees at compile time (round 6): the angle is scaled FIRST and the quarter turn is the exact constant 90 -- one
+        // subtraction instead of the two-piece pi/2 and the scaling after it
+        const float d = as_slope * DegScale<float>::v();
+        sk.template put<P_SLOPE>(select_gt32(g2f, 1.0f, 90.0f - d, d));
+    } else if (m & A_SLOPE) {
         const float a0 = as_slope;
-#if defined(__HIP_DEVICE_COMPILE__)
-        float a;
-        {
-            uint64_t mk;
-            asm("v_cmp_gt_f32_e64 %1, %2, 1.0\n\tv_cndmask_b32_e64 %0, %4, %3, %1" : "=v"(a), "=&s"(mk) : "v"(g2f), "v"((1.57079637f - a0) + -4.37113883e-08f), "v"(a0));
-        }
-#else
-        float a = (g2f > 1.0f) ? ((1.57079637f - a0) + -4.37113883e-08f) : a0;
-#endif
+        float a = select_gt32(g2f, 1.0f, (1.57079637f - a0) + -4.37113883e-08f, a0);
         if (deg) a = a * DegScale<float>::v();
         sk.template put<P_SLOPE>(a);
     }
-    if (m & A_ASPECT) {
+    if ((m & A_ASPECT) && SP::DEG == 1) {
+        // aspect = atan2(zx, zy) mod 360 from the octant angle d in [0, 45]: three reflections about exact constants (90, 180,
+        // 360 degrees), each a subtraction and a select on a scalar mask -- 10 instructions where the sign-bit assembly of the
+        // radian form below takes 16.  (-0 counts as not negative, like the reference's `< 0`; a zero derivative never reaches
+        // this tail: such pixels are the cold path's.)
+        const float d = as_aspect * DegScale<float>::v();
+        float a = select_absgt32(zxf, zyf, 90.0f - d, d);
+        a = select_gt32(0.0f, zyf, 180.0f - a, a);
+        a = select_gt32(0.0f, zxf, 360.0f - a, a);
+        sk.template put<P_ASPECT>(a);
+    } else if (m & A_ASPECT) {
         // (the octant assembly of surface_pixel_mixed)
         const float a0 = as_aspect;
         const uint32_t sx = f32_bits(zxf + 0.0f) >> 31, sy = f32_bits(zyf + 0.0f) >> 31;
@@ -720,7 +765,8 @@ XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, 
         want_f64 = fabsf(v - 0.15f) < 0.15001f;   // -1e-5 < v < 0.30001: the float64 cold path decides (exact zero / tiny values)
         sk.template put<P_HILLSHADE>(clamp_keep_nan(v, 0.0f, 255.0f));
     }
-    if (!CURV) return cold_bits | (want_f64 ? TAIL_WANT_F64 : 0u);
+    want_f64_out = want_f64;
+    if (!CURV) return;
     const double zxx = (double)zxxf, zyy = (double)zyyf, zxy = (double)zxyf;
     if (m & A_CURVATURE) sk.template put<P_CURVATURE>((float)(-2.0 * (zxx + zyy) * 100.0));
     if (m & (A_ANY_CURV & ~A_CURVATURE)) {
@@ -763,7 +809,6 @@ XD_HD unsigned surface_pixel_lean(float zxf, float zyf, float zxxf, float zyyf, 
             if (m & A_MINC) sk.template put<P_MINC>(vmin);
         }
     }
-    return cold_bits | (want_f64 ? TAIL_WANT_F64 : 0u);
 }
 
 // TPI / TRI of a 3x3 window given as raw values (row-major n0..n8, n4 = centre).  Plain IEEE propagation.
@@ -900,18 +945,23 @@ template <int FIT> struct Halo { static constexpr int v = (FIT == 2) ? 2 : 1; };
 template <typename A, typename B> struct SameT { static constexpr bool v = false; };
 template <typename A> struct SameT<A, A> { static constexpr bool v = true; };
 
-// hot-path tail; returns the TAIL_* flag bits (lean tail only: nearly black hillshade wants float64; cold-path decision)
+// hot-path tail; returns true if it has decided the cold path itself (lean tail only: `cold` = the pixel belongs to the cold
+// path, `want_f64` = its nearly black hillshade wants the float64 factors)
 template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct SurfaceTail {
-    static XD_HD unsigned go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk) {
+    static XD_HD bool go(TIN zx, TIN zy, TIN zxx, TIN zyy, TIN zxy, const TerrainParams& P, SINK& sk, bool&, bool&, uint64_t&) {
         surface_pixel<CURV, SP, SINK>((double)zx, (double)zy, (double)zxx, (double)zyy, (double)zxy, P, sk);
-        return 0u;
+        return false;
     }
 };
 template <bool CURV, class SP, class SINK> struct SurfaceTail<true, CURV, SP, float, SINK> {
-    static XD_HD unsigned go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk) {
-        if (SP::F64TAIL == 2) return surface_pixel_lean<CURV, SP, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
+    static XD_HD bool go(float zx, float zy, float zxx, float zyy, float zxy, const TerrainParams& P, SINK& sk, bool& cold, bool& want_f64,
+                         uint64_t& cold_any) {
+        if (SP::F64TAIL == 2) {
+            surface_pixel_lean<CURV, SP, SINK>(zx, zy, zxx, zyy, zxy, P, sk, cold, want_f64, cold_any);
+            return true;
+        }
         surface_pixel_mixed<CURV, SP, false, SINK>(zx, zy, zxx, zyy, zxy, P, sk);
-        return 0u;
+        return false;
     }
 };
 template <bool MIXED, bool CURV, class SP, typename TIN, class SINK> struct ColdTail {
@@ -980,14 +1030,30 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
     const int nrows = n_out + 2 * HALO;
     const uint32_t m = SP::CMASK ? SP::CMASK : P.mask;
 
-    // per-row partials (float64) -- Florinsky
-    double A[NS], B[NS], R[NS], Wr[NS], Ua[NS], Ub[NS], D2[NS];  // D2 = A + 2 B (mixed derivative rows)
+    // Florinsky (round 6): FORWARD accumulation.  Output row i needs tile rows i .. i + 4; instead of keeping seven per-row
+    // partials for five rows (35 float64 values) and combining them when the window is complete, every new row is pushed at
+    // once into the five sums of each of the five outputs it belongs to -- slot (i mod 5) holds the running sum of output i, a
+    // row of age a = r - i in that output's window adds its weight-a share.  Same operation count, 20 live float64 values
+    // instead of 33 between two rows: the streaming kernel drops from 164 to <= 128 VGPRs (a fourth wave per SIMD).
+    double Zx[NS], Zy[NS], Zxx[NS], Zyy[NS], Zxy[NS], Pz[NS];
+    // ... and the raw pixels of the 3 x 3 window of TPI / TRI are READ AGAIN from the tile (LDS: an idle pipe in this kernel) when
+    // their output row is emitted, through the row addresses kept from the prefetches (four live 32-bit values instead of the
+    // twelve pixels of four rows)
+    typedef decltype(rows.ptr(0)) rowptr_t;
+    constexpr bool REREAD = (FIT == 2) && WIN;
+    rowptr_t Pn[NS];
     // per-row partials -- 3x3 fits
     double Dr[NS], S[NS], Zc[NS];
     // 3-wide row sums and the raw pixels of the three centre columns for TPI / TRI (and the 3x3 detector)
     double R3[NS];
     TIN Nl[NS], Nc[NS], Nr[NS];
 
+    if (FIT == 2) {   // (the sums of the "outputs" above the band's first one are formed and never emitted: give them a value)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) Zx[k] = Zy[k] = Zxx[k] = Zyy[k] = Zxy[k] = Pz[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Pn[k] = rows.ptr(0) - 2;
     // the tile row of the NEXT step is fetched from LDS one step ahead, so its latency hides behind a whole row of math
     TIN nx0 = (TIN)0, nx1, nx2, nx3, nx4 = (TIN)0;
     {
@@ -1009,21 +1075,63 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                 const double z0 = FIT == 2 ? (double)t0 : 0.0, z4 = FIT == 2 ? (double)t4 : 0.0;
                 XD_SCHED_FENCE();
                 rows.step(r);
+                TIN w9[9] = {};
                 {
                     const auto row = rows.ptr((r + 1 < nrows) ? r + 1 : r);
                     nx1 = row[-1]; nx2 = row[0]; nx3 = row[1];
                     if (FIT == 2) { nx0 = row[-2]; nx4 = row[2]; }
+                    if (REREAD) {
+                        // (addresses are kept two columns to the left: an LDS instruction adds an UNSIGNED offset to its address register)
+                        // rows r - 3 .. r - 1 = the 3 x 3 window of the output this step emits (centre row r - 2); their addresses are
+                        // the ones of the prefetches of steps r - 4 .. r - 2.  (Both tile forms keep those rows readable: the streaming
+                        // ring refills a half only once its newest row is more than four steps old.)
+                        const rowptr_t a1 = Pn[(k + 2) % NS], a2 = Pn[(k + 3) % NS], a3 = Pn[(k + 4) % NS];
+                        w9[0] = a1[1]; w9[1] = a1[2]; w9[2] = a1[3];
+                        w9[3] = a2[1]; w9[4] = a2[2]; w9[5] = a2[3];
+                        w9[6] = a3[1]; w9[7] = a3[2]; w9[8] = a3[3];
+                        Pn[(k + 1) % NS] = row - 2;
+                    }
                 }
                 XD_SCHED_FENCE();
                 if (FIT == 2) {
+                    // Row partials.  With p = z0 + z4, q = zl + zr, A = zr - zl, B = z4 - z0 (columns -2 .. +2 of this row):
+                    //   D  = A + 2 B                      the row's share of zxy (weights -2 -1 0 1 2)
+                    //   R  = p + q + zc                   ... of zyy (plain row sum)
+                    //   Wr = 2 p - q - 2 zc               ... of zxx (weights 2 -1 -2 -1 2)
+                    //   Ua = 44 p + 62 q + 68 zc = 56 R - 6 Wr,   Ub = -31 p + 5 q + 17 zc = -7 R - 12 Wr      (zy: rows +-1 / +-2)
+                    //   X1 = 44 A - 31 B,   X2 = 62 A + 5 B = X1 + 18 D,   X3 = 68 A + 17 B = X2 + 6 D        (zx: rows +-2 / +-1 / 0)
+                    // -- the second forms are identities of Florinsky's least-squares weights (surfit.py:204-252): 4 + 4 operations
+                    // where the weighted sums taken literally cost 6 + 6.  Integer weights on float32 pixels: every sum is exact.
                     const double p = z0 + z4, q = zl + zr;
-                    A[k] = zr - zl;
-                    B[k] = z4 - z0;
-                    if (CURV) D2[k] = fma_2(B[k], A[k]);
-                    if (CURV) R[k] = (p + q) + zc;   // (the plain row sum serves zyy only; without curvatures nothing needs it -- see `poison` below)
-                    if (CURV) Wr[k] = fma(2.0, p - zc, -q);
-                    Ua[k] = fma(68.0, zc, fma(62.0, q, 44.0 * p));
-                    Ub[k] = fma(17.0, zc, fma(5.0, q, -31.0 * p));
+                    const double Ar = zr - zl, Br = z4 - z0;
+                    const double Dr2 = fma_2(Br, Ar);
+                    double Rr = 0.0, Wrr = 0.0, Uar, Ubr;
+                    if (CURV) {
+                        Rr = (p + q) + zc;
+                        Wrr = fma(2.0, p - zc, -q);
+                        Uar = fma(56.0, Rr, -6.0 * Wrr);
+                        Ubr = fma(-7.0, Rr, -12.0 * Wrr);
+                    } else {   // (without second derivatives nothing else needs R and Wr: the literal forms are the cheaper ones)
+                        Uar = fma(68.0, zc, fma(62.0, q, 44.0 * p));
+                        Ubr = fma(17.0, zc, fma(5.0, q, -31.0 * p));
+                    }
+                    const double X1 = fma(44.0, Ar, -31.0 * Br);
+                    const double X2 = fma(18.0, Dr2, X1);
+                    const double X3 = fma(6.0, Dr2, X2);
+                    // this row has age a in the window of output r - a, whose sums live in slot (k - a) mod 5
+                    const int s0 = k % NS, s1 = (k + 4) % NS, s2 = (k + 3) % NS, s3 = (k + 2) % NS, s4 = (k + 1) % NS;
+                    Zx[s4] += X1; Zx[s3] += X2; Zx[s2] += X3; Zx[s1] += X2; Zx[s0] = X1;
+                    // zy = (Ua[+1] - Ua[-1]) + (Ub[+2] - Ub[-2]): the slot holds +Ub[-2] after age 0, the signs are settled at age 1
+                    Zy[s4] += Ubr; Zy[s3] += Uar; Zy[s1] = -Zy[s1] - Uar; Zy[s0] = Ubr;
+                    if (CURV) {
+                        Zxx[s4] += Wrr; Zxx[s3] += Wrr; Zxx[s2] += Wrr; Zxx[s1] += Wrr; Zxx[s0] = Wrr;
+                        // zyy: 2 R[-2] - R[-1] - 2 R[0] - R[+1] + 2 R[+2]
+                        Zyy[s4] = fma(2.0, Rr, Zyy[s4]); Zyy[s3] -= Rr; Zyy[s2] = fma(-2.0, Rr, Zyy[s2]); Zyy[s1] = fma(2.0, Zyy[s1], -Rr); Zyy[s0] = Rr;
+                        // zxy: 2 D[-2] + D[-1] - D[+1] - 2 D[+2]
+                        Zxy[s4] = fma(-2.0, Dr2, Zxy[s4]); Zxy[s3] -= Dr2; Zxy[s1] = fma_2(Zxy[s1], Dr2); Zxy[s0] = Dr2;
+                    } else {
+                        Pz[s2] = Uar;   // the centre row's partial holds the centre pixel (see `poison` below)
+                    }
                     if (WIN) R3[k] = q + zc;
                 } else {
                     Dr[k] = zr - zl;
@@ -1031,7 +1139,7 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                     Zc[k] = zc;
                     R3[k] = (zl + zr) + zc;
                 }
-                if (WIN) { Nl[k] = tl; Nc[k] = tc; Nr[k] = tr; }
+                if (WIN && !REREAD) { Nl[k] = tl; Nc[k] = tc; Nr[k] = tr; }
 
                 const int i = r - 2 * HALO;  // output row whose window is now complete
                 if (i >= 0) {
@@ -1043,13 +1151,10 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                     // det - det (0 or NaN) rides on the scaling fma of zx (and zxx): invalid windows come out NaN at no cost
                     double det, poison;
                     if (FIT == 2) {
-                        const int m2 = XD_SLOT(-2), m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1), p2 = XD_SLOT(2);
-                        const double sx = fma(17.0, B[c0], fma(68.0, A[c0],
-                                          fma(5.0, B[m1] + B[p1], fma(62.0, A[m1] + A[p1],
-                                          fma(-31.0, B[m2] + B[p2], 44.0 * (A[m2] + A[p2]))))));
-                        const double sy = (Ua[p1] - Ua[m1]) + (Ub[p2] - Ub[m2]);
+                        const int se = (k + 1) % NS;   // the output whose fifth row this was
+                        const double sx = Zx[se], sy = Zy[se];
                         if (CURV) {
-                            det = ((Wr[m2] + Wr[m1]) + (Wr[c0] + Wr[p1])) + Wr[p2];
+                            det = Zxx[se];
                             poison = det - det;
                         } else {
                             // Without second derivatives there is no sum over the whole window to borrow, and one of its own cost seven
@@ -1059,15 +1164,16 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                             // centre pixel (weight 68): their sum is non-finite exactly when some pixel of the window is (a finite raster
                             // cannot overflow float64 here), so v - v is the same 0 / NaN as det - det, in three operations.
                             det = 0.0;
-                            const double v = (sx + sy) + Ua[c0];
+                            const double v = (sx + sy) + Pz[se];
                             poison = v - v;
                         }
                         zx = (TIN)fma(-sx, P.s1, poison);
                         zy = (TIN)(sy * P.s1);
                         if (CURV) {
-                            zxx = (TIN)fma(det, P.sxx, poison);
-                            zyy = (TIN)(fma(2.0, (R[m2] + R[p2]) - R[c0], -(R[m1] + R[p1])) * P.sxx);
-                            zxy = (TIN)(fma(2.0, D2[m2] - D2[p2], D2[m1] - D2[p1]) * P.sxy);
+                            // (every curvature but the deprecated `curvature` = -2 (zxx + zyy) depends on zx, which carries the poison)
+                            zxx = (m & A_CURVATURE) ? (TIN)fma(det, P.sxx, poison) : (TIN)(det * P.sxx);
+                            zyy = (TIN)(Zyy[se] * P.sxx);
+                            zxy = (TIN)(Zxy[se] * P.sxy);
                         }
                     } else {
                         const int m1 = XD_SLOT(-1), c0 = XD_SLOT(0), p1 = XD_SLOT(1);
@@ -1086,13 +1192,19 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                             }
                         }
                     }
-                    unsigned tail_bits = 0u;
+                    if (REREAD) {
+                        // TPI / TRI first: their nine pixels are dead before the surface tail's temporaries come alive
+                        const int w1 = XD_SLOT(-1), w0 = XD_SLOT(0), w2 = XD_SLOT(1);
+                        WindowTail<MIXED, SP, TIN, SINK>::go(w9, (R3[w1] + R3[w0]) + R3[w2], P, sk);
+                        XD_SCHED_FENCE();
+                    }
+                    bool tail_decided = false, tail_is_cold = false, tail_cold = false;
+                    uint64_t tail_cold_any = 0;
                     if (m & ~A_ANY_WIN) {
                         // hot path: every lane, straight-line (one basic block per output row)
-                        tail_bits = SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk);
+                        tail_decided = SurfaceTail<MIXED, CURV, SP, TIN, SINK>::go(zx, zy, zxx, zyy, zxy, P, sk, tail_is_cold, tail_cold, tail_cold_any);
                     }
-                    const bool tail_cold = (tail_bits & TAIL_WANT_F64) != 0u;
-                    if (WIN) {
+                    if (WIN && !REREAD) {
                         const int w1 = XD_SLOT(-1), w0 = XD_SLOT(0), w2 = XD_SLOT(1);
                         const TIN n[9] = {Nl[w1], Nc[w1], Nr[w1], Nl[w0], Nc[w0], Nr[w0], Nl[w2], Nc[w2], Nr[w2]};
                         WindowTail<MIXED, SP, TIN, SINK>::go(n, (R3[w1] + R3[w0]) + R3[w2], P, sk);
@@ -1106,8 +1218,8 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
                         // (An exactly cancelling SECOND derivative alone does not send a pixel here: its residue only adds ~1e-15 of
                         // the other curvature terms -- float64 rounding noise the reference's own result carries as well.)
                         bool cold;
-                        if (tail_bits & TAIL_COLD_KNOWN) {
-                            cold = (tail_bits & TAIL_COLD) != 0u;
+                        if (tail_decided) {
+                            cold = tail_is_cold;
                         } else {
                             cold = first_derivative_zero<TIN>(zx, zy);
                             if (MIXED) cold |= mixed_tail_out_of_range((float)zx, (float)zy);
@@ -1126,7 +1238,9 @@ XD_HD void march_rows(ROWS& rows, int n_out, const TerrainParams& P, SINK& sk) {
 #if defined(XD_NO_COLD)  // (instruction-count analysis builds only: tools/isa_stats.py)
                         cold = false;
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(XD_NO_COLD)
+                        if (__builtin_expect(tail_decided ? (tail_cold_any != 0) : (__builtin_amdgcn_ballot_w64(cold) != 0), 0))
+#elif defined(__HIP_DEVICE_COMPILE__)
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(cold) != 0, 0))
 #endif
                         {

@@ -275,8 +275,8 @@ template <int NPL> struct RowsRing {
     }
 };
 
-template <int FIT, bool CURV, bool WIN, class SP, int BH>
-__global__ __launch_bounds__(256) void terrain_strip_kernel(const StripArgs a) {
+template <int FIT, bool CURV, bool WIN, class SP, int BH, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void terrain_strip_kernel(const StripArgs a) {
     constexpr int HALO = Halo<FIT>::v;
     constexpr int NPL = __builtin_popcount(SP::CMASK);
     static_assert(SP::CMASK != 0 && BH % 32 == 0, "specialised attribute sets only");
@@ -616,10 +616,14 @@ static int launch_stream(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
         a.perm_mul = m;
     }
     const dim3 grid(a.grid8 * 8), block(256);
+    // four waves per SIMD for every streaming kernel (four workgroups of 36 KB LDS per CU): the Florinsky sets with curvatures get
+    // there since round 6 (forward-accumulated stencil sums + the TPI / TRI window re-read from LDS: 164 -> 127 VGPRs, no scratch:
+    // the CPU suite checks the compiled kernels); the register allocator is told so -- left alone it takes 129
+    constexpr int MINW = (FIT == 2 && CURV && SP::F64TAIL != 2) ? 1 : 4;   // (the mixed tail of option terrain_math = 0 would spill two registers)
     if (dbg_no_strips) {}
-    else if (bh == 128) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 128>), grid, block, 0, ctx->stream, a);
-    else if (bh == 256) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 256>), grid, block, 0, ctx->stream, a);
-    else if (bh == 512) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 512>), grid, block, 0, ctx->stream, a);
+    else if (bh == 128) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 128, MINW>), grid, block, 0, ctx->stream, a);
+    else if (bh == 256) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 256, MINW>), grid, block, 0, ctx->stream, a);
+    else if (bh == 512) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 512, MINW>), grid, block, 0, ctx->stream, a);
     else return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_stream: 0, 1, 128, 256 or 512");
     XD_HIP_CHECK(ctx, hipGetLastError());
     const int rc = dbg_no_frame ? XDEMHIP_OK : launch_tiles<FIT, CURV, WIN, SP, float, float, TH, 0>(ctx, L, mask, 0, fr);
