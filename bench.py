@@ -336,6 +336,13 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         t0 = time.perf_counter()
         offsets = coreg._iterate(plan, res, 0.0, 10, 72, scipy.optimize.curve_fit, True)
         dt_fit = (time.perf_counter() - t0) / 10
+        # SETTLED steps (round 6): what the later iterations of a fit look like -- the offsets move by ~1e-4 px per step -- timed at the
+        # fit's end point; such steps take their brackets from the previous step's exact medians (xdemhip_nk_predict_counts)
+        k = 5
+        t0 = time.perf_counter()
+        for i in range(k):
+            plan.step(offsets[0] + 2e-3 * ((i * 7) % 5 - 2), offsets[1] + 1.5e-3 * ((i * 3) % 5 - 2), res, 72)
+        dt_settled = (time.perf_counter() - t0) / k
         n_valid = r["n_valid"]
         routes = plan.route_counts()
         plan.close()
@@ -353,6 +360,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         barrier()
         dt_fit = (time.perf_counter() - t0) / 10
         dt = dt_fit
+        dt_settled = None
         routes = nk_info.get("routes")
         red = nk_info.get("reductions", (0, 0))
         how = (f"row blocks of {world} ranks + halo rows, every reduction of a step through the process group "
@@ -374,6 +382,8 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
     out["nuthkaab"] = {"grid": f"{m}x{m}", "n_gpus": world, "partition": how, "valid_fraction": round(n_valid / (m * m), 3),
                        "Mpixel_iterations_s": round(px / dt / 1e6, 1), "ms_per_iteration": round(dt * 1e3, 2),
                        "ms_per_iteration_whole_fit": round(dt_fit * 1e3, 2),
+                       "ms_per_iteration_settled": None if dt_settled is None else round(dt_settled * 1e3, 3),
+                       "settled_roofline_frac": None if dt_settled is None else round(roof_bpp * px / dt_settled / 1e9 / (HBM_PEAK_GBPS * world), 4),
                        "fitted_shift_px": [round(sx, 3), round(sy, 3), round(sz, 3)],
                        "validated": "the 10-iteration fit recovers the (+1.7, +0.6) px, -2.0 m shift the pair was built with",
                        "routes": routes, "nk_nan_rule": int(ctx.options.get("nk_nan_rule", 0)),
@@ -391,7 +401,10 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
                                     "touched_bytes_per_pixel": touched,
                                     "touched_GBps": round(touched * px / dt / 1e9, 1),
                                     "note": NK_ONEPASS_NOTE if onepass else NK_TOUCHED_NOTE},
-                       "note": "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32); "
+                       "note": "ms_per_iteration = steps whose shift moves by 0.1 px (the early iterations of a fit: sampled brackets); ms_per_iteration_settled = "
+                               "steps at the fit's end point, shift changes of ~2e-4 px (the later iterations: brackets predicted from the previous step's exact "
+                               "medians, routes.predicted counts them; results identical either way).  "
+                               "C3: one iteration = shifted dh, exact nanmedian, 72-bin exact medians of dh/slope_tan (float32); "
                                "ms_per_iteration = grid work of a step (host 72-point fit excluded; with more than one rank: the whole fit "
                                "per iteration), ms_per_iteration_whole_fit = NuthKaab's 10-iteration loop incl. scipy curve_fit, per iteration"}
     return out
@@ -413,6 +426,35 @@ NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference c
                    "slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not recomputed; 27 B/pixel in round 2")
 
 
+def isa_cycles() -> dict:
+    """Vector-issue cycles per output row of the streaming kernels of the launches timed here (newest profiles/*_isa_cycles.json,
+    written by tools/isa_ledger.py --json from the compiled kernels at the per-instruction costs of tools/ubench.hip).  The cost
+    table is in cycles at the nominal 2.4 GHz, i.e. seconds x 2.4e9: issue time of a launch = cycles_per_row x (pixels / 64) /
+    (1024 SIMDs) / 2.4e9.  (Check of the model: the headline kernel with its stores compiled out -- pure vector work -- runs in
+    8.09-8.12 ms, the model says 8.09: profiles/r06_terrain_bound_variants.txt.)"""
+    import glob
+
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_isa_cycles.json")))
+    if not f:
+        return {}
+    try:
+        return {"file": os.path.basename(f[-1]), **json.load(open(f[-1]))}
+    except Exception:
+        return {}
+
+
+def issue_bound(name: str, pixels: float, kernel_ms: float, hbm_frac: float, cyc: dict) -> dict | None:
+    """Fraction of the launch's time its vector instructions need to issue (the roofline that binds the small attribute sets: they are
+    float64-issue-bound, not HBM-bound) next to the HBM fraction, and which of the two is nearer."""
+    e = (cyc.get("sets") or {}).get(name)
+    if not e:
+        return None
+    ms = e["cycles_per_row"] * (pixels / 64.0) / 1024.0 / 2.4e9 * 1e3
+    return {"issue_ms": round(ms, 3), "issue_frac": round(ms / kernel_ms, 4), "vector_instructions_per_row": e["vector_instructions_per_row"],
+            "float64_class_per_row": e["float64_class_per_row"], "nearer_bound": "vector issue" if ms / kernel_ms > hbm_frac else "hbm",
+            "source": "profiles/" + cyc.get("file", "?")}
+
+
 def terrain_sets(ctx, dev, dem, kw, steps: int) -> dict:
     """The SMALL attribute sets users ask for far more often than all eleven planes -- DEM.slope(), slope + aspect, a hillshade
     -- and the full set with directional curvatures, on the headline raster: rate, bytes per pixel (4 read + 4 per plane
@@ -431,6 +473,7 @@ def terrain_sets(ctx, dev, dem, kw, steps: int) -> dict:
              ("full 11, ZevenbergThorne fit (3x3)", FULL, dict(surface_fit="ZevenbergThorne")),
              ("full 11, ZevenbergThorne fit, directional curvatures", FULL, dict(surface_fit="ZevenbergThorne", curv_method="directional"))]
     out = {}
+    cyc = isa_cycles()
     for name, attrs, extra in cases:
         planes = terrain.alloc_planes(len(attrs), H, W, torch.float32, ctx, dev)
         k = dict(kw)
@@ -449,10 +492,13 @@ def terrain_sets(ctx, dev, dem, kw, steps: int) -> dict:
         gbps = bpp * float(H) * W / (med * 1e-3) / 1e9
         out[name] = {"planes": len(attrs), "bytes_per_pixel": bpp, "kernel_ms_median": round(med, 4), "kernel_ms_min": round(ms[0], 4),
                      "Mpixels_s": round(float(H) * W / (med * 1e-3) / 1e6, 1), "achieved_GBps": round(gbps, 1),
-                     "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
+                     "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
+                     "issue": issue_bound(name, float(H) * W, med, gbps / HBM_PEAK_GBPS, cyc)}
         del planes
     return {"raster": f"{H}x{W} float32 (the headline DEM)", "steps": steps, "sets": out,
-            "note": "one launch per step, device-resident; fractions against the 8 TB/s HBM peak at 4 + 4 K bytes per pixel"}
+            "note": "one launch per step, device-resident; fractions against the 8 TB/s HBM peak at 4 + 4 K bytes per pixel; `issue` = the share of "
+                    "the launch's time its vector instructions need to issue (static count of the compiled kernel x measured cost per instruction): "
+                    "the one-to-three-plane sets sit at 0.73-0.83 of THAT bound and 0.44-0.60 of the HBM one"}
 
 
 def device_state() -> list:
@@ -807,6 +853,7 @@ def main() -> None:
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(min(step_ms), 4),
                          "kernel_ms_max": round(max(step_ms), 4), "pixels_per_launch": px_launch, "output_spot_check": spot,
                          # what the GPU was doing WHILE the timed steps ran (sysfs samples: see GpuSampler)
+                         "issue": issue_bound("headline: full 11, Florinsky, geometric curvatures", float(px_launch), kernel_ms, achieved / HBM_PEAK_GBPS, isa_cycles()),
                          "clock_GHz": (lambda c: None if not c else c["mean_GHz"])((gpu_state or {}).get("shader_clock_under_load")),
                          "clock_GHz_caller_planes": (lambda c: None if not c else c["mean_GHz"])((gpu_state2 or {}).get("shader_clock_under_load")),
                          "power_W": (lambda c: None if not c else c["mean"])(None if (gpu_state or {}).get("sysfs_note") else (gpu_state or {}).get("power_W")),

@@ -100,9 +100,9 @@ int xdemhip_clock_probe(xdemhip_ctx* ctx, void* hip_stream, int sleeps, uint64_t
  * exact selection among the candidates, plain radix passes if a bracket misses or if the input is too small per bin for
  * useful brackets; 1 plain 8-bit radix passes only; 2 degenerate brackets (exercises the fall-back); 3 bracketed even
  * where the per-bin sample is small (test switch).  Results are identical in every mode.
- * "host_chunk_mb": device-memory budget (MiB) of one row chunk of host-buffer xdemhip_terrain calls (0 = default 8192): host
+ * "host_chunk_mb": device-memory budget (MiB) of one row chunk of host-buffer xdemhip_terrain calls (0 = default 288): host
  * rasters of any size stream through the GPU in row chunks with the overlap the attributes need.  "host_chunk_rows": rows per
- * chunk instead (0 = from the budget; at least 64 are taken) -- what the reference's tiled call takes from
+ * chunk where that is FEWER than the budget gives (0 = from the budget; at least 64 are taken) -- what the reference's tiled call takes from
  * `mp_config.chunk_size` (xdem/terrain/terrain.py:412-466); chunked and one-pass results are bit-identical.  "host_copy_threads":
  * threads (one HIP stream each) that move host-buffer rasters over PCIe, rows split among them (0 = default 8, at most 16).
  * "nk_nan_rule": how nodata spreads through the bilinear taps of the Nuth-Kaab step / translation resample (the convention
@@ -269,6 +269,11 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uin
  * on PARTITIONED plans"), all of them enqueued through the device hook where it is installed; every rank returns the same integers
  * as a single-GPU fit of the whole rasters (the two-pass route of such plans: two data passes, ~25 all-reduces). */
 int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* twopass, int64_t* plain);
+/* Round 6: how many of the one-pass steps took PREDICTED brackets -- the previous step's exact medians moved by the Nuth-Kaab
+ * model for the change of the shift, instead of brackets from a fresh 1/64 sample: no sample kernels and no digit passes over
+ * samples on a settled fit (context option "nk_predict", default 1; 0 = every step samples) -- and how many of those missed (such
+ * a step is run again with sampled brackets: the integers returned are the same either way). */
+int xdemhip_nk_predict_counts(xdemhip_nk_plan* plan, int64_t* predicted, int64_t* missed);
 void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
                           int64_t* counts, double* medians);
@@ -339,6 +344,10 @@ int xdemhip_pairs_link_sorted(xdemhip_pairs* pairs, xdemhip_pairs* sorted);
  * differences and selects among them in float64 -- the float64 medians bit for bit, the counting pass in 38 instead of 60 ms on
  * BASELINE's C5.  NULL removes the link; the shadow must outlive it (not owned). */
 int xdemhip_pairs_link_shadow(xdemhip_pairs* pairs, xdemhip_pairs* shadow);
+/* Whether exact medians on this pair set take the bracketed route (one counting pass against sample brackets: large sets, few
+ * enough lag classes, the selection mode that allows it, no reduction hook) -- the only route that reads a float32 shadow, so a
+ * caller builds one (two more uploads and their device memory) exactly when this says 1. */
+int xdemhip_pairs_takes_brackets(xdemhip_pairs* pairs, int* yes);
 void xdemhip_pairs_destroy(xdemhip_pairs* pairs);
 
 /* ---- next row 8f-3: N-dimensional binned statistics ---------------------------------------------------------------

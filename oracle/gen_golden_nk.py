@@ -95,6 +95,8 @@ def main(ref, out_dir: str) -> None:
     def _res(transform):
         return (transform.a, -transform.e)
 
+    t9_rule = [0]   # nodata convention of the stand-in interpolator (the four values of the product's "nk_nan_rule": see nuthkaab_oracle.bilinear_shifted)
+
     def _reproject(raster_arr, src_transform, dst_transform=None, return_interpolator=False, resampling="linear"):
         assert return_interpolator
         res = (src_transform.a, -src_transform.e)
@@ -103,24 +105,50 @@ def main(ref, out_dir: str) -> None:
             yy, xx = yx
             colf = (xx - src_transform.c) / res[0] - 0.5
             rowf = (src_transform.f - yy) / res[1] - 0.5
-            return _bilinear_points(raster_arr, rowf, colf)
+            return _bilinear_points(raster_arr, rowf, colf, t9_rule[0])
 
         return interp
 
-    def _bilinear_points(arr, rowf, colf):
+    def _bilinear_points(arr, rowf, colf, rule=0):
+        # the point form of nuthkaab_oracle.bilinear_shifted: rule 0 "4tap" NaN if any of the four taps is non-finite or outside
+        # (rule 0 as T9 was first recorded: a tap row / column beyond the last one is outside even at zero weight); 1 "weighted"
+        # zero-weight taps ignored; 2 "dilate3x3" / 3 "dilate_cross": NaN also where the 3 x 3 / cross neighbourhood of the pixel
+        # nearest to the tap position holds a non-finite pixel or leaves the raster
         H, W = arr.shape
         r0 = np.floor(rowf).astype(np.int64)
         c0 = np.floor(colf).astype(np.int64)
         fr, fc = rowf - r0, colf - c0
-        ok = (r0 >= 0) & (r0 + 1 < H) & (c0 >= 0) & (c0 + 1 < W)
-        r0c, c0c = np.clip(r0, 0, H - 2), np.clip(c0, 0, W - 2)
+        if rule == 0:
+            need_r1 = np.ones(r0.shape, dtype=bool)
+            need_c1 = np.ones(c0.shape, dtype=bool)
+        elif rule == 1:
+            need_r1, need_c1 = fr != 0, fc != 0
+        else:
+            need_r1, need_c1 = (fr != 0) | (r0 + 1 < H), (fc != 0) | (c0 + 1 < W)
+        r1 = np.where(need_r1, r0 + 1, r0)
+        c1 = np.where(need_c1, c0 + 1, c0)
+        ok = (r0 >= 0) & (r1 < H) & (c0 >= 0) & (c1 < W)
+        r0c, r1c, c0c, c1c = np.clip(r0, 0, H - 1), np.clip(r1, 0, H - 1), np.clip(c0, 0, W - 1), np.clip(c1, 0, W - 1)
         t = arr.astype(np.float64)
-        v00, v01, v10, v11 = t[r0c, c0c], t[r0c, c0c + 1], t[r0c + 1, c0c], t[r0c + 1, c0c + 1]
-        top = v00 + fc * (v01 - v00)
-        bot = v10 + fc * (v11 - v10)
-        val = top + fr * (bot - top)
-        fin = np.isfinite(v00) & np.isfinite(v01) & np.isfinite(v10) & np.isfinite(v11)
-        return np.where(ok & fin, val, np.nan).astype(arr.dtype)
+        with np.errstate(invalid="ignore"):
+            v00, v01, v10, v11 = t[r0c, c0c], t[r0c, c1c], t[r1c, c0c], t[r1c, c1c]
+            top = v00 + fc * (v01 - v00)
+            bot = v10 + fc * (v11 - v10)
+            val = top + fr * (bot - top)
+        good = ok & np.isfinite(v00) & np.isfinite(v01) & np.isfinite(v10) & np.isfinite(v11)
+        if rule >= 2:
+            pad = np.ones((H + 2, W + 2), dtype=bool)
+            pad[1:-1, 1:-1] = ~np.isfinite(arr)
+            dil = np.zeros((H, W), dtype=bool)
+            for a in range(3):
+                for b in range(3):
+                    if rule == 2 or a == 1 or b == 1:
+                        dil |= pad[a:a + H, b:b + W]
+            rn = np.floor(rowf + 0.5).astype(np.int64)
+            cn = np.floor(colf + 0.5).astype(np.int64)
+            inside = (rn >= 0) & (rn < H) & (cn >= 0) & (cn < W)
+            good &= ~np.where(inside, dil[np.clip(rn, 0, H - 1), np.clip(cn, 0, W - 1)], True)
+        return np.where(good, val, np.nan).astype(arr.dtype)
 
     aff._coords, aff._res, aff._reproject_horizontal_shift_samecrs = _coords, _res, _reproject
     crs = types.SimpleNamespace(is_projected=True)
@@ -141,6 +169,16 @@ def main(ref, out_dir: str) -> None:
                                           {"subsample": 1, "random_state": None}, "z")
         rec[f"T9|{tol}|offsets"] = np.array([e, n_, v], dtype=np.float64)
         rec[f"T9|{tol}|subsample_final"] = np.int64(nsub)
+    # ... and the same loop around the stand-ins of the other three nodata conventions (round 6): whichever rule a decision file
+    # settles on, the full-loop pin is there (tests select "T9|rule{r}|..." by the decided rule; rule 0 = the keys above)
+    for rule in (1, 2, 3):
+        t9_rule[0] = rule
+        for it, tol in ((10, 0.0), (10, 0.001)):
+            (e, n_, v), nsub = aff.nuth_kaab(refdem, tba, inlier, _T(res), crs, "Area", tol, it, _params(),
+                                              {"subsample": 1, "random_state": None}, "z")
+            rec[f"T9|rule{rule}|{tol}|offsets"] = np.array([e, n_, v], dtype=np.float64)
+            rec[f"T9|rule{rule}|{tol}|subsample_final"] = np.int64(nsub)
+    t9_rule[0] = 0
     rec["T9|ref"], rec["T9|tba"], rec["T9|inlier"], rec["T9|res"] = refdem, tba, inlier, np.float64(res)
 
     np.savez_compressed(os.path.join(out_dir, "nk_golden.npz"), **rec)

@@ -198,9 +198,9 @@ def bin_fit(dh: np.ndarray, slope_tan: np.ndarray, aspect: np.ndarray, n_bins: i
                                                 "p0": np.array(p0, dtype=np.float64), "popt": popt}
 
 
-def iteration_step(offsets, ref, tba, valid, slope_tan, aspect, res, n_bins: int = 72):
+def iteration_step(offsets, ref, tba, valid, slope_tan, aspect, res, n_bins: int = 72, nan_rule: int | None = None):
     """_nuth_kaab_iteration_step (affine.py:477-536) on the full grid restricted to `valid`."""
-    dh = shifted_dh(ref, tba, offsets[0], offsets[1], res)[valid]
+    dh = shifted_dh(ref, tba, offsets[0], offsets[1], res, nan_rule)[valid]
     vshift = np.nanmedian(dh)
     dh = dh - vshift
     ok = np.isfinite(dh)
@@ -214,8 +214,9 @@ def iteration_step(offsets, ref, tba, valid, slope_tan, aspect, res, n_bins: int
 
 
 def nuth_kaab(ref: np.ndarray, tba: np.ndarray, inlier_mask: np.ndarray | None, res: tuple[float, float],
-              tolerance: float = 0.001, max_iterations: int = 10, n_bins: int = 72):
-    """nuth_kaab (affine.py:539-609) with subsample == 1: returns ((east, north, vertical), n_valid0, trace)."""
+              tolerance: float = 0.001, max_iterations: int = 10, n_bins: int = 72, nan_rule: int | None = None):
+    """nuth_kaab (affine.py:539-609) with subsample == 1: returns ((east, north, vertical), n_valid0, trace).  `nan_rule`: the nodata
+    convention of the interpolator (None = the decided one)."""
     slope_tan, aspect = aux_vars(ref)
     if inlier_mask is None:
         inlier_mask = np.ones(ref.shape, dtype=bool)
@@ -225,7 +226,7 @@ def nuth_kaab(ref: np.ndarray, tba: np.ndarray, inlier_mask: np.ndarray | None, 
     offsets = (0.0, 0.0, 0.0)
     trace = []
     for i in range(max_iterations):
-        offsets, stat, det = iteration_step(offsets, ref, tba, valid, slope_tan, aspect, res, n_bins)
+        offsets, stat, det = iteration_step(offsets, ref, tba, valid, slope_tan, aspect, res, n_bins, nan_rule)
         trace.append((offsets, stat, det))
         if i > 1 and stat < tolerance:
             break

@@ -232,6 +232,38 @@ def test_streaming_kernels_keep_plane_pointers_in_scalar_registers(tmp_path):
     assert n >= 6 and n_four >= 6   # 3 attribute sets x 2 tails (x band heights)
 
 
+def test_largest_pair_distance_from_hulls():
+    """`bin_func='even'` needs np.nanmax of the sampled pair distances (skgstat.binning.even_width_lags clips maxlag to it); the
+    product takes it from the convex hulls of the point sets.  Against brute force: every-a-with-every-b and i < j blocks, lattice
+    and real coordinates, several blocks, a collinear set, tiny sets."""
+    from xdem_amd import spatialstats as ss
+
+    rng = np.random.default_rng(5)
+
+    def brute(blocks):
+        best = 0.0
+        for blk in blocks:
+            xa, ya = np.asarray(blk[0], float), np.asarray(blk[1], float)
+            xb, yb = (xa, ya) if len(blk) == 3 else (np.asarray(blk[3], float), np.asarray(blk[4], float))
+            d = np.sqrt((xa[:, None] - xb[None, :]) ** 2 + (ya[:, None] - yb[None, :]) ** 2)
+            best = max(best, float(d.max())) if d.size else best
+        return best
+
+    for trial in range(6):
+        n, m = int(rng.integers(70, 900)), int(rng.integers(70, 900))
+        lat = trial % 2 == 0
+        mk = (lambda k: rng.integers(0, 500, k).astype(float)) if lat else (lambda k: rng.uniform(-3e5, 7e5, k))
+        blocks = [(mk(n), mk(n), np.zeros(n)), (mk(n), mk(n), np.zeros(n), mk(m) + 100.0, mk(m), np.zeros(m))]
+        assert ss._max_pair_distance(blocks) == brute(blocks)
+        assert ss._max_pair_distance(blocks[1:]) == brute(blocks[1:])
+    t = np.arange(200.0)
+    line = [(3.0 * t, 7.0 - 2.0 * t, np.zeros(200))]
+    assert ss._max_pair_distance(line) == brute(line)
+    assert ss._max_pair_distance([(np.array([1.0]), np.array([2.0]), np.zeros(1))]) == 0.0
+    assert ss._max_pair_distance([(np.array([0.0, 3.0]), np.array([0.0, 4.0]), np.zeros(2))]) == 5.0
+    assert ss._max_pair_distance([]) == 0.0
+
+
 def test_variogram_host_preparation():
     from xdem_amd import spatialstats as ss
 

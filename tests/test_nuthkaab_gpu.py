@@ -187,19 +187,24 @@ def test_binned_median_edge_cases(coreg):
         assert np.array_equal(c, c0) and np.array_equal(m, m0, equal_nan=True)
 
 
-@pytest.mark.skipif(not default_conventions(), reason="T9 was recorded from the reference's loop with the rule-0 stand-in interpolator")
 def test_full_fit_vs_oracle_and_reference(coreg, z):
+    """T9: the reference's own `nuth_kaab` loop around a stand-in interpolator, recorded for each of the four nodata conventions
+    (round 6: oracle/gen_golden_nk.py) -- the fixture of the DECIDED rule is the one compared (rule 0 keeps the first round's keys)."""
+    from conftest import decided
+
+    rule = decided("nk_nan_rule")
+    pre = "T9|" if rule == 0 else f"T9|rule{rule}|"
     ref, tba, inlier, res = z["T9|ref"], z["T9|tba"], z["T9|inlier"], float(z["T9|res"])
     for tol in ("0.0", "0.001"):
         offsets, n_final = coreg.nuth_kaab(ref, tba, inlier, (res, res), tolerance=float(tol), max_iterations=10)
         o_off, o_n, _ = nko.nuth_kaab(ref, tba, inlier, (res, res), tolerance=float(tol), max_iterations=10)
-        assert n_final == o_n == int(z[f"T9|{tol}|subsample_final"])
+        assert n_final == o_n == int(z[f"{pre}{tol}|subsample_final"])
         # Every grid quantity of a step is bit-exact (test_step_matches_oracle).  The final offsets additionally go
         # through scipy's Levenberg-Marquardt on 72 points, which near convergence (amplitude a -> 0, phase b
         # undetermined) is sensitive to the last bits of its start value p0 -- accumulated in float64 on the GPU,
         # float32 by NumPy.  Agreement is therefore asserted at the method's own convergence threshold (1e-3 px).
         assert np.allclose(offsets, o_off, rtol=0, atol=1e-3 * res)
-        assert np.allclose(offsets, z[f"T9|{tol}|offsets"], rtol=0, atol=1e-3 * res)  # the reference's own loop
+        assert np.allclose(offsets, z[f"{pre}{tol}|offsets"], rtol=0, atol=1e-3 * res)  # the reference's own loop
         assert abs(offsets[2] - o_off[2]) < 1e-3  # (medians are exact per step; the offsets they are taken at differ as above)
 
 
@@ -823,6 +828,56 @@ def test_whole_fit_stays_on_the_one_pass_route():
     assert abs(got[1][0] + 17.0) < 0.05 and abs(got[1][1] + 6.0) < 0.05 and abs(got[1][2] + 2.0) < 0.01, got[1]
 
 
+def test_predicted_brackets_return_the_sampled_steps_integers():
+    """Round 6: a settled one-pass step takes its 73 brackets from the previous step's exact medians moved by the Nuth-Kaab model for
+    the change of the shift (no sample kernels, no digit passes over samples: option "nk_predict", default on).  A sequence of
+    steps shaped like a converging fit -- large corrections first, then changes of a thousandth of a pixel -- with the option on and
+    off: every integer and every median of every step identical; the settled steps really are predicted; a jump back to the start
+    is sampled again; and a whole fit ends where the sampled fit ends."""
+    import os
+    import sys
+
+    import scipy.optimize
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from xdem_amd import _lib, coreg
+
+    dev = torch.device("cuda", 0)
+    ref, tba = bench._c3_pair(dev, 9000)
+    steps = ((0.0, 0.0), (-15.0, -5.0), (-16.8, -5.9), (-16.98, -5.99), (-17.0, -6.0), (-17.004, -6.002), (-17.0045, -6.0016),
+             (-17.0046, -6.0017), (-17.0046, -6.0017), (-17.0041, -6.0020), (0.0, 0.0), (-17.0, -6.0))
+    res, routes, fits = {}, {}, {}
+    for on in (1, 0):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_option("nk_predict", on)
+            plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
+            res[on] = [plan.step(sx, sy, (10.0, 10.0), 36) for (sx, sy) in steps]
+            routes[on] = plan.route_counts()
+            plan.close()
+            plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
+            fits[on] = (coreg._iterate(plan, (10.0, 10.0), 0.0, 9, 36, scipy.optimize.curve_fit, True), plan.route_counts())
+            plan.close()
+        finally:
+            ctx.close()
+    print("routes with / without prediction:", routes[1], routes[0], "whole fit:", fits[1][1], fits[0][1])
+    for on in (1, 0):
+        assert routes[on]["onepass"] == len(steps) and routes[on]["twopass"] == 0 and routes[on]["plain"] == 0, routes[on]
+    assert routes[0]["predicted"] == 0 and routes[1]["predicted"] >= 3, routes
+    assert routes[1]["predict_missed"] <= 1, routes[1]
+    for k, (a, b) in enumerate(zip(res[1], res[0])):
+        assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], k
+        assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), k
+        assert np.array_equal(a["edges"], b["edges"]), k
+        assert _moments_close(a, b, onepass=True), k
+    # the whole fit: predicted steps in it, the same end point as the sampled fit to what two runs of one form agree to (see
+    # test_whole_fit_stays_on_the_one_pass_route)
+    assert fits[1][1]["predicted"] >= 2 and fits[1][1]["twopass"] == 0 and fits[1][1]["plain"] == 0, fits[1][1]
+    assert np.allclose(fits[1][0], fits[0][0], rtol=0, atol=1e-4), (fits[1][0], fits[0][0])
+
+
 def test_bench_C3_pair_at_full_size_routes_agree():
     """The very input bench.py times (SURVEY 8d's C3: 20000^2 pair, tba = ref shifted bilinearly by (+1.7, -0.6) px + 2 m + noise,
     20 % gaps) at full size: the queued route the bench runs (EXT dh pass, lean kernels, dual bracket selections, aspect-bin cache)
@@ -1101,7 +1156,11 @@ def test_onepass_step_on_a_hooked_plan():
             r1 = plan.route_counts()
             if mode == "hooked":
                 assert r1["onepass"] - r0["onepass"] == len(steps) and r1["twopass"] == r0["twopass"] and r1["plain"] == r0["plain"], (r0, r1)
-                assert h1 == h0 and d1 - d0 == 10 * len(steps), (h0, h1, d0, d1)
+                # ten all-reduces per step with sampled brackets, FIVE with predicted ones (round 6: the last step moves the aligned
+                # pair by 4e-5 px -- its brackets come from the step before it: no sample selections, no histogram exchanges)
+                n_pred = r1["predicted"] - r0["predicted"]
+                assert n_pred >= 1 and r1["predict_missed"] == r0["predict_missed"], (r0, r1)
+                assert h1 == h0 and d1 - d0 == 10 * (len(steps) - n_pred) + 5 * n_pred, (h0, h1, d0, d1, n_pred)
                 off = coreg._iterate(plan, (10.0, 10.0), 0.0, 8, 72, scipy.optimize.curve_fit, True)
                 r2 = plan.route_counts()
                 assert r2["twopass"] == r1["twopass"] and r2["plain"] == r1["plain"] and r2["onepass"] == r1["onepass"] + 8, (r1, r2)
@@ -1151,7 +1210,7 @@ def test_onepass_step_on_a_hooked_plan_float64():
     try:
         ref, tba = bench._c3_pair(torch.device("cuda", 0), 6000)
         ref, tba = ref.double().contiguous(), tba.double().contiguous()
-        steps = ((0.0, 0.0), (1.7, 0.6), (-17.0, -6.0))
+        steps = ((0.0, 0.0), (1.7, 0.6), (-17.0, -6.0), (-16.9998, -5.9996))   # (the last one: a settled step, predicted brackets)
         res = {}
         for mode in ("plain", "hooked"):
             plan = coreg.NKPlan(ref, tba, None, ctx, group=None if mode == "plain" else "world")
@@ -1163,7 +1222,11 @@ def test_onepass_step_on_a_hooked_plan_float64():
             r1 = plan.route_counts()
             assert r1["onepass"] - r0["onepass"] == len(steps) and r1["twopass"] == r0["twopass"] and r1["plain"] == r0["plain"], (mode, r0, r1)
             if mode == "hooked":
-                assert h1 == h0 and d1 - d0 == 10 * len(steps), (h0, h1, d0, d1)
+                # ten all-reduces per step with sampled brackets, FIVE with predicted ones (round 6: the last step moves the aligned
+                # pair by 4e-5 px -- its brackets come from the step before it: no sample selections, no histogram exchanges)
+                n_pred = r1["predicted"] - r0["predicted"]
+                assert n_pred >= 1 and r1["predict_missed"] == r0["predict_missed"], (r0, r1)
+                assert h1 == h0 and d1 - d0 == 10 * (len(steps) - n_pred) + 5 * n_pred, (h0, h1, d0, d1, n_pred)
             plan.close()
         for a, b in zip(res["hooked"], res["plain"]):
             assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"]

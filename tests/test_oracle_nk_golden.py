@@ -60,13 +60,19 @@ def test_T6_stop_rule(z):
     assert int(z["T6|ncalls_loose"]) == 3  # never fewer than 3 iterations (affine.py:142)
 
 
-@pytest.mark.skipif(not default_conventions(), reason="T9 was recorded from the reference's loop with the rule-0 stand-in interpolator")
+@pytest.mark.parametrize("rule", [None, 0, 1, 2, 3])
 @pytest.mark.parametrize("tol", ["0.0", "0.001"])
-def test_T9_full_loop(z, tol):
+def test_T9_full_loop(z, tol, rule):
+    """The reference's `nuth_kaab` loop was recorded around a stand-in interpolator for each of the four nodata conventions (round 6):
+    the oracle under each rule against its fixture, and under the DECIDED rule (None: what the product runs) against that rule's."""
+    from conftest import decided
+
+    r = decided("nk_nan_rule") if rule is None else rule
+    pre = "T9|" if r == 0 else f"T9|rule{r}|"
     ref, tba, inlier, res = z["T9|ref"], z["T9|tba"], z["T9|inlier"], float(z["T9|res"])
-    offsets, nvalid, trace = nko.nuth_kaab(ref, tba, inlier, (res, res), tolerance=float(tol), max_iterations=10)
-    want = z[f"T9|{tol}|offsets"]
-    assert nvalid == int(z[f"T9|{tol}|subsample_final"])
+    offsets, nvalid, trace = nko.nuth_kaab(ref, tba, inlier, (res, res), tolerance=float(tol), max_iterations=10, **({} if rule is None else {"nan_rule": rule}))
+    want = z[f"{pre}{tol}|offsets"]
+    assert nvalid == int(z[f"{pre}{tol}|subsample_final"])
     # aspect differs from the reference's libm atan2f by <= 1 ulp on a few pixels -> a handful of points change bin;
     # the fitted shifts agree far below the 1e-3 px convergence threshold
     assert np.allclose(offsets, want, rtol=1e-5, atol=1e-5 * res), (offsets, want)

@@ -200,20 +200,26 @@ def test_multiple_runs_aggregate(ss):
 
 
 def test_named_binning_even(ss):
-    """scikit-gstat's named binning 'even' (skgstat.binning.even_width_lags: n_lags classes of equal width up to maxlag; n_lags
-    defaults to 10) is the same call as the Iterable of those right edges; the binnings that depend on each run's sampled
-    distances are refused by name (reference: xdem/spatialstats.py:1396-1403 warns about exactly those)."""
+    """scikit-gstat's named binning 'even' (skgstat.binning.even_width_lags: n_lags classes of equal width up to maxlag CLIPPED to the
+    largest sampled pair distance; n_lags defaults to 10): equally wide classes whose top is a distance between two sampled points
+    -- below the extent diagonal upstream passes as maxlag -- and the same call as the Iterable of those right edges; an explicit
+    maxlag below every sampled distance is kept; the binnings that depend on the sampled distances in other ways are refused by
+    name (reference: xdem/spatialstats.py:1396-1403 warns about exactly those).  (`_max_pair_distance` against brute force: CPU suite.)"""
     from xdem_amd.synth import fbm_numpy
 
     vals = fbm_numpy((64, 64), hurst=0.3, seed=2, mean=0.0, std=1.0)
     maxlag = float(np.sqrt(63.0**2 + 63.0**2))
     for kw, n in (({}, 10), ({"n_lags": 7}, 7)):
         a = ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, random_state=3, bin_func="even", **kw)
-        b = ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, random_state=3, bin_func=np.linspace(0, maxlag, n + 1)[1:])
+        top = float(a["lags"].values[0]) * n
+        assert 0.5 * maxlag < top < maxlag and abs(top * top - round(top * top)) < 1e-6   # a distance between two lattice points
+        b = ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, random_state=3, bin_func=np.linspace(0, top, n + 1)[1:])
         # (n - 1 rows: upstream drops the last lag class, xdem/spatialstats.py:1541)
-        assert len(a) == len(b) == n - 1 and np.array_equal(a["lags"].values, np.linspace(0, maxlag, n + 1)[1:-1])
+        assert len(a) == len(b) == n - 1 and np.allclose(a["lags"].values, np.linspace(0, top, n + 1)[1:-1], rtol=1e-15, atol=0)
         # (Matheron sums are float64 atomics: equal to rounding between two calls, not bit for bit)
         assert np.allclose(a["exp"].values, b["exp"].values, rtol=1e-12, atol=0, equal_nan=True) and np.array_equal(a["count"].values, b["count"].values)
+    c = ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, random_state=3, bin_func="even", maxlag=20.0)
+    assert np.array_equal(c["lags"].values, np.linspace(0, 20.0, 11)[1:-1])
     with pytest.raises(NotImplementedError, match="only 'even'"):
         ss.sample_empirical_variogram(vals, gsd=1.0, subsample=80, bin_func="uniform")
 

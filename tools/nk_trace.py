@@ -37,12 +37,18 @@ if os.environ.get("NK_HOOKED"):   # the partitioned plan's route on one GPU: a 1
     if os.environ.get("NK_FUSED_DIST"):
         ctx.set_option("nk_fused_dist", int(os.environ["NK_FUSED_DIST"]))
 plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx, group)
+if os.environ.get("NK_PREDICT"):   # round 6: 1 settled steps take predicted brackets (default), 0 every step samples
+    ctx.set_option("nk_predict", int(os.environ["NK_PREDICT"]))
+settled = os.environ.get("NK_SETTLED") == "1"   # the timed steps are those of a fit that has converged: shift changes of ~1e-4 px
 plan.step(0.0, 0.0, (10.0, 10.0), 72)
 plan.step(1.0, 0.0, (10.0, 10.0), 72)
+if settled:
+    for sx, sy in ((-15.0, -5.0), (-16.8, -5.9), (-16.98, -5.99), (-17.0, -6.0), (-17.003, -6.002)):
+        plan.step(sx, sy, (10.0, 10.0), 72)
 for i in range(k):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    d = plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
+    d = plan.step(-17.003 + 0.0007 * ((i * 7) % 5 - 2), -6.002 + 0.0005 * ((i * 3) % 5 - 2), (10.0, 10.0), 72) if settled else plan.step(3.0 + i, -4.0, (10.0, 10.0), 72)
     dt = time.perf_counter() - t0
     print(f"[{os.path.basename(_lib.LIB_PATH)}] step {m}x{m}: {dt * 1e3:.3f} ms (n_valid {d['n_valid']}, vshift {d['vshift']:.6f})", flush=True)
 print("routes", plan.route_counts(), "reductions (host, device)", ctx.reduction_calls(), flush=True)

@@ -5,6 +5,7 @@ created, the package raises -- a silent CPU path would void every parity claim.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import threading
@@ -118,6 +119,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_nk_set_rows.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_i64p]
         L.xdemhip_nk_set_statistic.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_nk_route_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p, c_i64p]
+        L.xdemhip_nk_predict_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p]
         c_u64p = ctypes.POINTER(ctypes.c_uint64)
         L.xdemhip_pairs_create.argtypes = [c_ctx, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -128,6 +130,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_pairs_medians.argtypes = [ctypes.c_void_p, c_i64p, c_dp]
         L.xdemhip_pairs_link_sorted.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_pairs_link_shadow.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.xdemhip_pairs_takes_brackets.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         L.xdemhip_pairs_destroy.argtypes = [ctypes.c_void_p]
         L.xdemhip_pairs_destroy.restype = None
         c_ip = ctypes.POINTER(ctypes.c_int)
@@ -282,6 +285,11 @@ class Context:
         self._pool: list[tuple[int, int, int]] = []   # (nbytes, flags, ptr)
         self._pool_cap = int(float(os.environ.get("XDEM_PLANE_POOL_GB", "16")) * (1 << 30))
         self._pool_lock = threading.Lock()
+        # Options belong to the context, not to a call: engine="numba", mp_config and the float32 shadow of a pair set change one for
+        # the duration of their launches and put it back.  Those sequences -- and every terrain launch -- hold this lock, so two
+        # threads sharing a context (the process-wide default one, typically) cannot see each other's setting; a context still
+        # does one thing at a time (its one stream, its scratch state: include/xdemhip.h).
+        self.call_lock = threading.RLock()
         self.options: dict[str, int] = {}  # mirror of the xdemhip_set_option calls made through this object
         # objects that hold library handles created on this context (Nuth-Kaab plans, pair sets, binning plans): closed before the
         # context goes -- a plan destroyed AFTER its context would hand the library a dangling context pointer
@@ -411,6 +419,20 @@ class Context:
         """Tuning / test switch of the library (``xdemhip_set_option``), e.g. ``("selection", 1)``."""
         self.check(self._L.xdemhip_set_option(self.handle, name.encode(), int(value)))
         self.options[name] = int(value)
+
+    @contextlib.contextmanager
+    def option_scope(self, name: str, value: int):
+        """``with ctx.option_scope("terrain_nonfinite", 1): ...`` -- the option set for the body and restored after it, the whole
+        sequence under the context's call lock (see ``call_lock``)."""
+        with self.call_lock:
+            prev = self.options.get(name, 0)
+            if int(value) != prev:
+                self.set_option(name, value)
+            try:
+                yield
+            finally:
+                if int(value) != prev:
+                    self.set_option(name, prev)
 
     def clock_probe(self, stream, out, sleeps: int = 2000) -> None:
         """Enqueue the shader-clock probe (``xdemhip_clock_probe``) on `stream` (a ``torch.cuda.Stream`` other than the one the

@@ -355,6 +355,11 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->nk_fused = value;
         return XDEMHIP_OK;
     }
+    if (std::string(name) == "nk_predict") {
+        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_predict: 0 or 1");
+        ctx->nk_predict = value;
+        return XDEMHIP_OK;
+    }
     if (std::string(name) == "nk_fused_dist") {
         if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_fused_dist: 0 or 1");
         ctx->nk_fused_dist = value;
@@ -529,7 +534,10 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     const size_t row_bytes = (size_t)W * (in_es + out_es * (size_t)n_planes);
     const size_t budget = (size_t)(ctx->host_chunk_mb > 0 ? ctx->host_chunk_mb : 288) << 20;
     int64_t chunk = (int64_t)(budget / (row_bytes ? row_bytes : 1)) - 2 * depth;
-    if (ctx->host_chunk_rows > 0) chunk = ctx->host_chunk_rows;  // the caller's tile size (mp_config.chunk_size of the reference's tiled call)
+    // the caller's tile size (mp_config.chunk_size of the reference's tiled call) can only SHRINK the chunks: a tile of the whole raster's
+    // height -- or a moderate one on a very wide raster -- would otherwise put input + all planes of the raster on the device and
+    // fail with ENOMEM where the untiled call streams
+    if (ctx->host_chunk_rows > 0 && ctx->host_chunk_rows < chunk) chunk = ctx->host_chunk_rows;
     if (chunk < 64) chunk = 64;  // (a few rows of a very wide raster may exceed the budget; still correct)
     if (chunk > H) chunk = H;
     size_t in_bytes = 0, plane_bytes = 0, out_bytes = 0;

@@ -42,6 +42,7 @@ struct xdemhip_ctx {
     int nk_binseg = 1;       // option "nk_binseg": 1 round 5's forms of the small steps of the one-pass Nuth-Kaab step (per-bin candidate segments + one workgroup per bin,
                              // value-bucket selection of the median of dh, sample passes that advance their own states, resets / v^ folded into the sample kernels; default),
                              // 0 round 4's generic selections -- same integers either way (A/B, tests)
+    int nk_predict = 1;      // option "nk_predict": 1 a settled one-pass Nuth-Kaab step takes its brackets from the previous step's exact medians moved by the model (no sample kernels, no digit passes over samples; default), 0 every step samples
     int nk_fused = 1;        // option "nk_fused": 1 the Nuth-Kaab step of large single-GPU plans is ONE data pass (14 B/pixel: dh, its median's counting and the aspect-bin counting against sample brackets with per-pixel margins; default), 0 the two passes of round 3
     int terrain_stream = 1;  // option "terrain_stream": 1 streaming strips for the raster interior where they apply (default), 0 tiles only; 128 / 256 / 512 = band height
     int terrain_sync = 0;    // option "terrain_sync": workgroup barrier every N output rows of the direct-store march (0 none; N a power of two)

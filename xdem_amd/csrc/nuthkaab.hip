@@ -1152,6 +1152,43 @@ __global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, u
     }
 }
 
+// Round 6: the brackets of a step from the host's PREDICTION instead of from samples (nk_step_onepass).  Values in, what the sample
+// selections would have left out: bracket keys of the median of dh and of the bins' medians, the rebase shifts of the candidate
+// selections, v^ and delta.  An empty bin (lo > hi) gets the bracket {0, all-ones} of a bin without sample elements.
+constexpr int NK_PREDICT_MAX_BINS = 128;
+template <typename T> struct NkPredicted { T dlo, dhi; T lo[NK_PREDICT_MAX_BINS], hi[NK_PREDICT_MAX_BINS]; };
+template <typename T>
+__global__ __launch_bounds__(64) void nk_predict_kernel(const NkPredicted<T> pr, int nb, typename KeyT<T>::type* klo_d, typename KeyT<T>::type* khi_d,
+                                                        uint32_t* rbs_d, T* vhat, T* delta, typename KeyT<T>::type* klo_y,
+                                                        typename KeyT<T>::type* khi_y, uint32_t* rbs_y, unsigned long long* ctr) {
+    typedef typename KeyT<T>::type K;
+    const int lane = threadIdx.x;
+    K r = 0;
+    for (int b = lane; b < nb; b += 64) {
+        K lo = (K)0, hi = (K)~(K)0;
+        if (pr.lo[b] <= pr.hi[b]) { lo = key_of(pr.lo[b]); hi = key_of(pr.hi[b]); }
+        klo_y[b] = lo;
+        khi_y[b] = hi;
+        const K d = hi >= lo ? (K)(hi - lo) : (K)0;
+        r = d > r ? d : r;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const K o = k_shfl_down(r, off);
+        r = o > r ? o : r;
+    }
+    if (lane == 0) {
+        *rbs_y = rebase_shift_of(r);
+        const K lo = key_of(pr.dlo), hi = key_of(pr.dhi);
+        *klo_d = lo;
+        *khi_d = hi;
+        *rbs_d = rebase_shift_of(hi >= lo ? (K)(hi - lo) : (K)0);
+        T v, d;
+        if (!(pr.dlo <= pr.dhi) || !nk_vhat_of<T>(1u, lo, hi, v, d)) ctr[3] = 1ull;
+        *vhat = v;
+        *delta = d;
+    }
+}
+
 #ifndef XD_NKZ_ROWS      // (measurement builds override the two pipeline constants of the one-pass kernel)
 #define XD_NKZ_ROWS 8
 #endif
@@ -2545,7 +2582,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_mr_bin_gather_kernel(const T*
 }
 
 // every small result of a step gathered into one block (one device-to-host copy instead of ten)
-struct FzPack { const unsigned char* src[12]; uint32_t bytes[12]; uint32_t off[12]; int n; unsigned char* dst; };
+struct FzPack { const unsigned char* src[16]; uint32_t bytes[16]; uint32_t off[16]; int n; unsigned char* dst; };
 static __global__ __launch_bounds__(256) void nk_fz_pack_kernel(FzPack a) {
     for (int k = 0; k < a.n; ++k)
         for (uint32_t i = threadIdx.x; i < a.bytes[k]; i += blockDim.x) a.dst[a.off[k] + i] = a.src[k][i];
@@ -2599,6 +2636,21 @@ struct xdemhip_nk_plan {
     double fz_worst = 0.0;   // largest |wanted rank - bracket centre| seen, in half widths of the FULL rule
     double fz_off2 = 0.0;    // sum of squares of those offsets over all brackets of all steps so far
     int64_t fz_offn = 0;
+    // one-pass route, round 6: PREDICTED brackets.  Once a fit has settled its offsets move by a few thousandths of a pixel per
+    // step and the 73 exact medians of the previous step, moved by what the Nuth-Kaab model says the shift does to them, bracket
+    // this step's medians better than a fresh 1/64 sample does -- the two sample kernels and their six digit passes (~0.26 ms of
+    // a 1.66 ms step at C3) are skipped.  What the previous step left (host side; identical on every rank of a partitioned plan):
+    bool pr_have = false;             // ... it answered on the one-pass route and everything below is its record
+    int pr_nb = 0;
+    double pr_sx = 0, pr_sy = 0, pr_rx = 0, pr_ry = 0;   // its shifts and resolutions (georeferenced units)
+    double pr_v = 0, pr_wd = 0;       // its vshift; half width (value) of the last SAMPLED bracket of the median of dh
+    double pr_st = 0;                 // n / sum(1 / slope_tan): the scale that turns a shift in pixels into a change of dh
+    std::vector<double> pr_med, pr_w, pr_mid;   // per bin: exact median of y, half width of the last sampled bracket, centre aspect
+    std::vector<unsigned char> pr_ok; // ... the bin had a median
+    double pr_err = 1e30, pr_err_d = 1e30;   // how far the prediction of the LAST step would have been off (or was), in sampled half widths: bins / median of dh
+    double pr_dpx = 1e30;             // the shift change of the last step, pixels
+    int pr_cooldown = 0;              // sampled steps still to run after a predicted bracket missed
+    int64_t n_predicted = 0, n_predict_miss = 0;
     // one-pass step on PARTITIONED plans (reduction hook + xdemhip_set_rank): the two exchange buffers, this rank's own classes and the
     // counters rewritten for the gathered bucket values (nk_mr_* kernels); the ranks' agreement on the route, renewed when what it rests
     // on changes
@@ -2961,7 +3013,7 @@ int nk_mr_alloc(xdemhip_nk_plan* P, int nb, int world, size_t es) {
 // then runs the two-pass route of round 3, which needs nothing from here.
 template <typename T>
 int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, int nb, bool* done, double* vshift, int64_t* n_valid,
-                    double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians) {
+                    double* y_mean, double* y_std, double* edges_out, int64_t* counts, double* medians, bool allow_predict = true) {
     typedef typename KeyT<T>::type K;
     *done = false;
     xdemhip_ctx* ctx = P->ctx;
@@ -3061,18 +3113,63 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         return XDEMHIP_OK;
     };
     if (!mr) { rc = edges_and_bins(); if (rc) return rc; }
-    // 2. sample of dh -> bracket of its median, v^, delta
+    // Round 6: brackets PREDICTED from the previous step instead of sampled.  A bin median of y = (dh - vshift) / slope_tan moves by
+    // -(dE sin(aspect) + dN cos(aspect)) when the tap position moves by (dE, dN) pixels -- the Nuth-Kaab model itself -- and the
+    // median of dh stays to first order; how well that held is MEASURED at every step (pr_err: the worst miss of the centres in
+    // half widths of the sampled brackets, for the step just finished), and a step is predicted only when the last one would have
+    // been hit with room to spare and the shift change has not grown.  The brackets are then 0.25 ... 1 sampled widths around the
+    // predicted centres; the integer counts of the pass prove them like any sampled bracket, a miss reruns THIS step sampled
+    // (and the next one): exact either way.  Identical decisions on every rank of a partitioned plan (everything is derived from
+    // reduced results and the call's arguments).
+    const double dE = g.dc - P->pr_sx, dN = -(g.dr - P->pr_sy);   // (pr_sx / pr_sy hold the previous tap offsets in pixels)
+    const double dpx = sqrt(dE * dE + dN * dN);
+    // (the measured miss of the centres is proportional to the shift change -- 0.90 / 0.11 / 0.012 half widths at 0.2 / 0.02 / 0.002 px
+    //  on C3: the model's error is its second-order term -- so the miss to EXPECT at this step is the last one scaled by the ratio of
+    //  the shift changes, with a floor for the jitter of the medians themselves)
+    const bool pr_scaled = P->pr_dpx > 0 && P->pr_dpx < 1e29;
+    const double pr_expect = pr_scaled ? fmax(0.02, P->pr_err * (dpx / P->pr_dpx)) : 1e30;      // bin medians
+    const double pr_expect_d = pr_scaled ? fmax(0.02, P->pr_err_d * (dpx / P->pr_dpx)) : 1e30;  // median of dh (assumed not to move)
+    bool predict = allow_predict && ctx->nk_predict != 0 && P->pr_have && P->pr_nb == nb && nb <= NK_PREDICT_MAX_BINS && P->pr_cooldown == 0 &&
+                   pr_expect <= 0.20 && pr_expect_d <= 0.20 && dpx <= 0.05 && P->pr_wd > 0 && r5;
+    if (P->pr_cooldown > 0 && allow_predict) --P->pr_cooldown;
+    double pr_h = 1.0;   // bracket half widths of this step in sampled half widths
     T* s_v = static_cast<T*>(ws->s_vals);
+    bool fused = false;
+    constexpr int BR_PASSES = 3;
+    const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
+    const int narrow = P->fz_narrow;
+    if (predict) {
+        pr_h = fmin(1.0, fmax(0.25, 2.0 * pr_expect + 0.15));
+        NkPredicted<T> pr;
+        // (the bracket of the median of dh may not be padded: its half width is the margin delta / slope_tan of EVERY pixel's y, and on
+        //  flat ground a centimetre of it turns whole waves into bin candidates -- session r06h: overflow flag at 0.04 px)
+        const double hd = fmin(1.0, fmax(0.25, 2.0 * pr_expect_d + 0.15)) * P->pr_wd;
+        pr.dlo = (T)(P->pr_v - hd);
+        pr.dhi = (T)(P->pr_v + hd);
+        for (int b = 0; b < nb; ++b) {
+            if (!P->pr_ok[b]) { pr.lo[b] = (T)1; pr.hi[b] = (T)0; continue; }   // (an empty bin stays empty: the aspects do not move)
+            const double c = P->pr_med[b] - (dE * sin(P->pr_mid[b]) + dN * cos(P->pr_mid[b]));
+            const double h = pr_h * P->pr_w[b] + 0.05 * dpx;
+            pr.lo[b] = (T)(c - h);
+            pr.hi[b] = (T)(c + h);
+        }
+        if (mr) {   // min / max aspect and the EXT survivors of all ranks: their own small exchange (they ride on the dh sample's first histogram otherwise)
+            rc = xd_allreduce_device(ctx, ext_slots, 4 * (int64_t)world, XDEMHIP_RED_SUM_U64);
+            if (rc) return rc;
+            hipLaunchKernelGGL(nk_mr_ext_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, ext_slots, world, d_stats, P->ext_cnt + 2);
+            rc = edges_and_bins();
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL((nk_predict_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, pr, nb, klo_d, khi_d, rbs_d, d_vhat, d_delta, klo_y, khi_y, rbs_y, ctr);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    } else {
+    // 2. sample of dh -> bracket of its median, v^, delta
     // (round 5: the sample kernels also reset the selection that runs on their sample -- select_reset_slice)
     hipLaunchKernelGGL((nk_sample_dh_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
                        1.0 / (double)P->W, n_slots, s_v, r5 ? select_reset_plan<K>(scratch, 1, SEL_BRACKET_DUAL) : SelReset());
     XD_HIP_CHECK(ctx, hipGetLastError());
-    constexpr int BR_PASSES = 3;
-    const K low_mask = (K)(((K)1 << (8 * (KeyT<T>::passes - BR_PASSES))) - 1);
-    const int narrow = P->fz_narrow;
     // (round 5: the passes advance their own states and the last one writes the bracket ends -- hist_pass_kernel<T, true>; `fused`
     //  tells whether that form ran)
-    bool fused = false;
     rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
                            false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, r5, mr ? 0 : -1, mr ? 4 * (int64_t)world : 0);
     if (rc) return rc;
@@ -3095,9 +3192,10 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     rc = select_enqueue<T>(ctx, s_v, nb == 1 ? nullptr : ws->s_bins, n_slots, n_slots, nullptr, nb, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES,
                            false, nullptr, nullptr, false, narrow, klo_y, khi_y, rbs_y, low_mask, &fused, r5);
     if (rc) return rc;
-    const int nbb = (nb + 63) / 64;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, 0, low_mask, klo_y, khi_y, rbs_y);
     XD_HIP_CHECK(ctx, hipGetLastError());
+    }   // (sampled brackets)
+    const int nbb = (nb + 63) / 64;
     // 4. the one pass
     {
         dim3 grid = grid2d(ctx, P->W, rows);
@@ -3253,13 +3351,17 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     std::vector<SelState<K>> h_st(nb);
     std::vector<uint64_t> h_succ(nb);
     std::vector<uint64_t> cnt_t(mr ? 3 * (size_t)nb : 0);   // partitioned plans: (total, below, inside) of the bins' brackets (cnt holds the rewritten ones)
-    const int n_pk = mr ? 11 : 10;
+    std::vector<K> khi(nb);
+    K h_kd[2] = {0, 0};   // bracket of the median of dh (the next step's prediction keeps the widths of the last sampled brackets)
+    const int n_pk = mr ? 14 : 13;
     {
         FzPack pk;
-        void* dsts[11] = {cnt.data(), klo.data(), h_ctr, &h_rbs, info, sums, &h_vhat, edges.data(), h_st.data(), h_succ.data(), cnt_t.data()};
-        const void* srcs[11] = {cnt_y, klo_y, ctr, rbs_y, scratch + OFF_INFO, d_sums, d_vhat, d_edges, scratch + OFF_STATE, scratch + off_succ(nb), cnt_true};
-        const size_t sizes[11] = {8 * 3 * (size_t)nb, sizeof(K) * nb, 128, 8, 32, 40, sizeof(T), sizeof(T) * (nb + 1), sizeof(SelState<K>) * nb, 8 * (size_t)nb,
-                                  8 * 3 * (size_t)nb};
+        void* dsts[14] = {cnt.data(), klo.data(), h_ctr, &h_rbs, info, sums, &h_vhat, edges.data(), h_st.data(), h_succ.data(), khi.data(), &h_kd[0], &h_kd[1],
+                          cnt_t.data()};
+        const void* srcs[14] = {cnt_y, klo_y, ctr, rbs_y, scratch + OFF_INFO, d_sums, d_vhat, d_edges, scratch + OFF_STATE, scratch + off_succ(nb), khi_y, klo_d,
+                                khi_d, cnt_true};
+        const size_t sizes[14] = {8 * 3 * (size_t)nb, sizeof(K) * nb, 128, 8, 32, 40, sizeof(T), sizeof(T) * (nb + 1), sizeof(SelState<K>) * nb, 8 * (size_t)nb,
+                                  sizeof(K) * nb, sizeof(K), sizeof(K), 8 * 3 * (size_t)nb};
         uint32_t off = 0;
         pk.n = n_pk;
         for (int k = 0; k < n_pk; ++k) {
@@ -3284,11 +3386,20 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if ((h_ctr[2] != 0 || h_ctr[3] != 0) && getenv("XDEMHIP_DEBUG"))
         fprintf(stderr, "[xdemhip] one-pass step falls through: overflow flag %llu, miss flag %llu, dh candidates %llu, bin candidates %llu\n", h_ctr[2], h_ctr[3],
                 h_ctr[1], h_ctr[5]);
+    if ((h_ctr[2] != 0 || h_ctr[3] != 0) && predict) {
+        // a PREDICTED bracket missed (or overflowed): this step once more with sampled brackets, and the next one sampled too; the
+        // prediction has to earn its way back through a measured error
+        ++P->n_predict_miss;
+        P->pr_cooldown = 1;
+        P->pr_err = P->pr_err_d = 1e30;
+        return nk_step_onepass<T>(P, g, q0, n, nb, done, vshift, n_valid, y_mean, y_std, edges_out, counts, medians, false);
+    }
     if (h_ctr[2] != 0 || h_ctr[3] != 0) {   // overflow / a bracket missed / no extreme-aspect survivor: the two-pass route
         if (narrow > 0) { P->fz_narrow_cap = narrow - 1; P->fz_narrow = 0; }   // (narrowed brackets may be what missed: not that narrow again)
+        P->pr_have = false;
         return XDEMHIP_OK;
     }
-    {
+    if (!predict) {
         // How centred were the brackets?  |wanted rank - centre| in half widths, scaled to the full rule.  Lines of a sample that
         // are not fully correlated (the rule's worst case) leave the ranks within a small fraction of it: the next step then takes
         // brackets half or a quarter as wide -- fewer candidates staged, resolved and selected from (measured on C3: 1.88 -> 1.73
@@ -3354,6 +3465,48 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const double mean = s1 / cntd, var = s2 / cntd - mean * mean;
     *y_mean = mean;
     *y_std = var > 0 ? sqrt(var) : 0.0;
+    {
+        // Round 6: what the NEXT step's prediction rests on, and how well THIS step was (or would have been) predicted by the model
+        // "a bin median moves by -(dE sin(aspect) + dN cos(aspect))" (dE = change of the column offset of the taps, dN = minus the
+        // change of their row offset, pixels) and "the median of dh stays".  (Were the signs wrong for some layout, the measured
+        // misses would be large and no step would ever be predicted.)
+        std::vector<double> mid(nb);
+        for (int b = 0; b < nb; ++b) mid[b] = 0.5 * ((double)edges[b] + (double)edges[b + 1]);
+        if (P->pr_have && P->pr_nb == nb) {
+            double worst = 0.0;
+            for (int b = 0; b < nb; ++b) {
+                if (!P->pr_ok[b] || counts[b] == 0 || !(P->pr_w[b] > 0)) continue;
+                const double e = fabs(medians[b] - (P->pr_med[b] - (dE * sin(P->pr_mid[b]) + dN * cos(P->pr_mid[b])))) / P->pr_w[b];
+                worst = e > worst ? e : worst;
+            }
+            P->pr_err = worst;
+            P->pr_err_d = P->pr_wd > 0 ? fabs(vs - P->pr_v) / P->pr_wd : 1e30;
+            P->pr_dpx = fmax(dpx, 1e-5);   // (a repeated step measures the jitter floor: the ratio rule then stays conservative)
+            if (getenv("XDEMHIP_DEBUG"))
+                fprintf(stderr, "[xdemhip] one-pass step (%s, half widths x %.2f): shift change %.2e px, centres off by %.3f (bins) / %.3f (dh) sampled half widths\n",
+                        predict ? "PREDICTED brackets" : "sampled brackets", pr_h, dpx, P->pr_err, P->pr_err_d);
+        } else {
+            P->pr_err = P->pr_err_d = 1e30;
+            P->pr_dpx = 1e30;
+        }
+        if (!predict || (int)P->pr_w.size() != nb) {   // the widths of SAMPLED brackets only (predicted ones are fractions of them)
+            P->pr_w.assign(nb, 0.0);
+            for (int b = 0; b < nb; ++b)
+                if (counts[b] > 0 && khi[b] >= klo[b]) P->pr_w[b] = 0.5 * ((double)val_of(khi[b]) - (double)val_of(klo[b]));
+            P->pr_wd = h_kd[1] >= h_kd[0] ? 0.5 * ((double)val_of(h_kd[1]) - (double)val_of(h_kd[0])) : 0.0;
+        }
+        P->pr_med.assign(medians, medians + nb);
+        P->pr_mid = mid;
+        P->pr_ok.assign(nb, 0);
+        for (int b = 0; b < nb; ++b) P->pr_ok[b] = (counts[b] > 0 && P->pr_w[b] > 0 && std::isfinite(P->pr_w[b]) && std::isfinite(medians[b])) ? 1 : 0;
+        P->pr_v = vs;
+        P->pr_st = sums[2] > 0 ? cntd / sums[2] : 0.0;
+        P->pr_sx = g.dc;
+        P->pr_sy = g.dr;
+        P->pr_nb = nb;
+        P->pr_have = true;
+        if (predict) ++P->n_predicted;
+    }
     *done = true;
     return XDEMHIP_OK;
 }
@@ -3610,7 +3763,7 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
         //  all zeroed at the start of a step; the keys of its chosen bucket sit behind, outside the zeroed part)
         P->fz_bytes = (size_t)(24 + (11 + BINSEG_CTR_STRIDE) * P->ws.nb_max + DSEL_HDR_WORDS + DSEL_BUCKETS / 2) * 8;
         P->cd_cap = (int64_t)n / 8 + 4096;
-        P->fz_pack_bytes = (size_t)P->ws.nb_max * (8 * 3 + 8 + 16 + 64 + 8 + 8 * 3) + 1024;
+        P->fz_pack_bytes = (size_t)P->ws.nb_max * (8 * 3 + 8 + 16 + 64 + 8 + 8 * 3 + 16) + 1024;
         if (hipMalloc(reinterpret_cast<void**>(&P->fz), P->fz_bytes + (size_t)DSEL_CAP * 8) != hipSuccess || hipMalloc(&P->cd_vals, (size_t)P->cd_cap * es) != hipSuccess ||
             hipMalloc(&P->c_st, (size_t)P->ws.c_cap * es) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->fz_pack), P->fz_pack_bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -3694,10 +3847,18 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, 
     P->row0 = row_begin;
     P->row1 = row_end;
     P->bcache_force = true;  // other own rows: their bins were never cached
+    P->pr_have = false;      // ... and their medians are not the previous step's
     // valid mask / aux rasters outside the range are never read by this rank; recount the global number of valid pixels
     int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
     if (rc) return rc;
     if (n_valid) *n_valid = P->n_valid0;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_nk_predict_counts(xdemhip_nk_plan* P, int64_t* predicted, int64_t* missed) {
+    if (!P) return XDEMHIP_EINVAL;
+    if (predicted) *predicted = P->n_predicted;
+    if (missed) *missed = P->n_predict_miss;
     return XDEMHIP_OK;
 }
 
@@ -3769,6 +3930,7 @@ int xdemhip_nk_step_fit(xdemhip_nk_plan* P, double shift_x, double shift_y, doub
 int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* P, const double* edges, int n_edges, int decimal) {
     if (!P) return XDEMHIP_EINVAL;
     P->bcache_force = true;
+    P->pr_have = false;
     if (n_edges == 0) { P->custom_edges.clear(); return XDEMHIP_OK; }
     if (!edges || n_edges < 2 || n_edges - 1 > MAX_BINS_PER_SWEEP) return xd_fail(P->ctx, XDEMHIP_EINVAL, "bin edges: 2 .. 129 increasing values");
     for (int k = 1; k < n_edges; ++k)

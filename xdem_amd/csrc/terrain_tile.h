@@ -270,7 +270,9 @@ template <int NPL> struct RowsRing {
         // tile rows below 16 (r >> 4) are dead from here on (the oldest row any path still reads is r - 4): refill their half
         if ((r & (RING_BLOCK - 1)) == REFILL_AT && r >= RING_BLOCK + REFILL_AT) {
             const int k = (r >> 4) + 1;
+#if !defined(XD_STRIP_NOREFILL)   // (measurement builds: no input traffic after the first two blocks -- what do the refills and their waits cost?)
             if (RING_BLOCK * k < n_rows()) issue(k);
+#endif
         }
     }
 };

@@ -1772,6 +1772,14 @@ int xdemhip_pairs_medians(xdemhip_pairs* P, int64_t* counts, double* medians) {
     return P->val_dtype == XDEMHIP_F32 ? pairs_medians_typed<float>(P, counts, medians) : pairs_medians_typed<double>(P, counts, medians);
 }
 
+int xdemhip_pairs_takes_brackets(xdemhip_pairs* P, int* yes) {
+    if (!P || !yes) return XDEMHIP_EINVAL;
+    const xdemhip_ctx* ctx = P->ctx;
+    // (the conditions of the bracketed route in pairs_medians_typed, plus: a float32 shadow is only read on hook-less contexts)
+    *yes = (ctx->selection_mode != 1 && P->nb <= HIST_BINS_PER_SWEEP && P->n_pairs >= PAIRS_BRACKET_MIN && P->n_wg_big >= 256 && !ctx->allreduce) ? 1 : 0;
+    return XDEMHIP_OK;
+}
+
 int xdemhip_pairs_link_shadow(xdemhip_pairs* P, xdemhip_pairs* shadow) {
     if (!P) return XDEMHIP_EINVAL;
     xdemhip_ctx* ctx = P->ctx;

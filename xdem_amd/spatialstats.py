@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes
 import logging
+import os
 import warnings
 from collections.abc import Iterable
 from typing import Any, Callable
@@ -52,10 +53,33 @@ def _morton_order(x: np.ndarray, y: np.ndarray) -> np.ndarray | None:
     return np.argsort(spread(qx) | (spread(qy) << np.uint64(1)), kind="stable")
 
 
+def _polar_morton_order(x: np.ndarray, y: np.ndarray, cx: float, cy: float):
+    """Morton order of (log distance from (cx, cy), angle around it): consecutive points are neighbours in the ring they lie in -- for
+    the B points of a centre-disk x rings block the order with the fewest lag-class changes per wave of the orders simulated
+    (profiles/r06_vario_class_change_sim.txt: 0.316 of the wave-pairs against 0.350 in Cartesian Morton order)."""
+    r = np.hypot(x - cx, y - cy)
+    lr = np.log(np.maximum(r, 1e-300))
+    big = np.isfinite(lr) & (r > 0)
+    if not big.any():
+        return None
+    lo = float(lr[big].min())
+    lr = np.where(big, lr, lo)
+    th = np.arctan2(y - cy, x - cx)
+    return _morton_order(lr, th)
+
+
 def _morton_sorted_block(b: tuple) -> tuple:
     out = list(np.asarray(c) for c in b)
+    polar = len(out) == 6 and os.environ.get("XDEM_VARIO_B_ORDER", "morton") == "polar"
     for k in range(0, len(out), 3):
-        o = _morton_order(np.asarray(out[k], dtype=np.float64).ravel(), np.asarray(out[k + 1], dtype=np.float64).ravel())
+        xs, ys = np.asarray(out[k], dtype=np.float64).ravel(), np.asarray(out[k + 1], dtype=np.float64).ravel()
+        if polar and k == 3 and xs.size:
+            ax, ay = np.asarray(out[0], dtype=np.float64).ravel(), np.asarray(out[1], dtype=np.float64).ravel()
+            o = _polar_morton_order(xs, ys, float(ax.mean()), float(ay.mean())) if ax.size else None
+            if o is None:
+                o = _morton_order(xs, ys)
+        else:
+            o = _morton_order(xs, ys)
         if o is not None:
             out[k], out[k + 1], out[k + 2] = (np.asarray(out[k]).ravel()[o], np.asarray(out[k + 1]).ravel()[o], np.asarray(out[k + 2]).ravel()[o])
     return tuple(out)
@@ -125,16 +149,16 @@ class PairSet:
             self.handle = self.handle_sel
         # float64 differences of float32 values, large sets (the bracketed route's domain, csrc/variogram.hip: PAIRS_BRACKET_MIN):
         # float32 copies of both orders, linked as the shadow of the float64 selection set (xdemhip_pairs_link_shadow)
-        if widened and self.n_pairs >= 4_000_000_000:
+        takes = ctypes.c_int(0)
+        if widened:   # (the library knows its own route: size threshold, classes per sweep, selection mode, reduction hook)
+            self.ctx.check(self.ctx._L.xdemhip_pairs_takes_brackets(self.handle_sel, ctypes.byref(takes)))
+        if widened and takes.value:
             try:
-                self.ctx.set_option("vario_diff", 0)   # (the library itself widens float32 values under the option: not the shadow's)
-                try:
+                with self.ctx.option_scope("vario_diff", 0):   # (the library itself widens float32 values under the option: not the shadow's)
                     self.shadow_sel, _ = create(blocks, np.float32)
                     if self.ctx.options.get("vario_sort", 1):
                         self.shadow, _ = create([_morton_sorted_block(b) for b in blocks], np.float32)
                         self.ctx.check(self.ctx._L.xdemhip_pairs_link_sorted(self.shadow_sel, self.shadow))
-                finally:
-                    self.ctx.set_option("vario_diff", 1)
                 self.ctx.check(self.ctx._L.xdemhip_pairs_link_shadow(self.handle_sel, self.shadow_sel))
             except Exception:
                 self.close()
@@ -448,10 +472,20 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
             right_bin_edge *= np.sqrt(2)
         bin_func.append(kwargs["maxlag"])
         kwargs["bin_func"] = bin_func
-    if isinstance(kwargs["bin_func"], str):   # 'even' (checked above); n_lags: scikit-gstat's default is 10
-        kwargs["bin_func"] = np.linspace(0, kwargs["maxlag"], int(kwargs.get("n_lags", 10)) + 1)[1:]
-    edges = np.asarray(list(kwargs["bin_func"]), dtype=np.float64)
+    # 'even' (checked above; n_lags: scikit-gstat's default is 10): skgstat.binning.even_width_lags(distances, n, maxlag) first CLIPS
+    # maxlag to nanmax(distances) of the sampled pairs -- and upstream's default maxlag, the extent diagonal, is practically always
+    # larger -- so the edges are linspace(0, min(maxlag, largest sampled pair distance), n_lags + 1)[1:], per Variogram object:
+    # formed below for every pair set (`edges_for`), with the largest distance taken from the hulls of the point sets
+    even_lags = int(kwargs.get("n_lags", 10)) if isinstance(kwargs["bin_func"], str) else None
+    edges = None if even_lags is not None else np.asarray(list(kwargs["bin_func"]), dtype=np.float64)
     estimator = kwargs.get("estimator", "matheron")
+
+    def edges_for(blocks):
+        if even_lags is None:
+            return edges
+        dmax = _max_pair_distance(blocks)
+        top = kwargs["maxlag"] if not (dmax < kwargs["maxlag"]) else dmax
+        return np.linspace(0, top, even_lags + 1)[1:]
 
     if random_state is not None:
         rng = np.random.default_rng(random_state)
@@ -492,14 +526,17 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
         else:  # pdist_disk / pdist_ring: one pdist variogram per range, all rows kept (1007-1060)
             for sel in _pdist_multi_range_subsamples(valid, shape2d, int(subsample), subsample_method, gsd, kwargs["maxlag"],
                                                      kwargs.get("pdist_multi_ranges"), list_random_state[i]):
-                exp, count = empirical_variogram_pairs([xy_of(sel) + (values[sel],)], edges, estimator)
-                list_df_run.append(pd.DataFrame().assign(exp=exp, bins=edges, count=count))
+                blk = [xy_of(sel) + (values[sel],)]
+                e_run = edges_for(blk)
+                exp, count = empirical_variogram_pairs(blk, e_run, estimator)
+                list_df_run.append(pd.DataFrame().assign(exp=exp, bins=e_run, count=count))
             continue
+        e_run = edges_for(blocks) if blocks else (edges if edges is not None else np.linspace(0, kwargs["maxlag"], even_lags + 1)[1:])
         if blocks:
-            exp, count = empirical_variogram_pairs(blocks, edges, estimator)
+            exp, count = empirical_variogram_pairs(blocks, e_run, estimator)
         else:
-            exp, count = np.full(edges.size, np.nan), np.zeros(edges.size, dtype=np.int64)
-        list_df_run.append(pd.DataFrame().assign(exp=exp, bins=edges, count=count))
+            exp, count = np.full(e_run.size, np.nan), np.zeros(e_run.size, dtype=np.int64)
+        list_df_run.append(pd.DataFrame().assign(exp=exp, bins=e_run, count=count))
 
     every_run = pd.concat(list_df_run)
     if n_variograms == 1:
@@ -517,6 +554,40 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
     df = table.drop(table.tail(1).index)
     df = df.astype({"exp": "float64", "err_exp": "float64", "lags": "float64", "count": "int64"})
     return df
+
+
+def _hull_points(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """Vertices of the convex hull of a point set as an (m, 2) array (all points when the set is tiny or degenerate: collinear
+    points have no 2-D hull -- their two extremes along the longer axis of the bounding box, plus the box's corner-most points, do)."""
+    pts = np.column_stack([np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)])
+    pts = pts[np.isfinite(pts).all(axis=1)]
+    if pts.shape[0] <= 64:
+        return pts
+    try:
+        from scipy.spatial import ConvexHull
+
+        return pts[ConvexHull(pts).vertices]
+    except Exception:   # degenerate (collinear / duplicate) sets: the extremes of x, y, x + y and x - y hold the farthest pair of a line
+        k = [f(v) for v in (pts[:, 0], pts[:, 1], pts[:, 0] + pts[:, 1], pts[:, 0] - pts[:, 1]) for f in (np.argmin, np.argmax)]
+        return pts[np.unique(k)]
+
+
+def _max_pair_distance(blocks) -> float:
+    """``np.nanmax`` of the pair distances of a pair set -- what ``skgstat.binning.even_width_lags`` clips ``maxlag`` to -- without
+    forming the pairs: the farthest pair of two point sets (or of one) joins two vertices of their convex hulls, and its distance
+    is evaluated like SciPy's ``pdist`` / ``cdist`` evaluate it (``sqrt(dx*dx + dy*dy)`` in float64).  `blocks`: (x, y, v) = every
+    i < j pair of one set, (xa, ya, va, xb, yb, vb) = every a with every b.  Empty pair sets give 0."""
+    best = 0.0
+    for blk in blocks:
+        a = _hull_points(blk[0], blk[1])
+        b = a if len(blk) == 3 else _hull_points(blk[3], blk[4])
+        if a.shape[0] == 0 or b.shape[0] == 0 or (len(blk) == 3 and a.shape[0] < 2):
+            continue
+        for i0 in range(0, a.shape[0], 4096):   # (hulls of lattice points are small; chunked all the same)
+            dx = a[i0:i0 + 4096, 0][:, None] - b[None, :, 0]
+            dy = a[i0:i0 + 4096, 1][:, None] - b[None, :, 1]
+            best = max(best, float(np.sqrt(np.max(dx * dx + dy * dy))))
+    return best
 
 
 def _create_circular_mask(shape: tuple[int, int], center=None, radius=None) -> np.ndarray:

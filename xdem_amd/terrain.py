@@ -169,12 +169,14 @@ def launch_terrain(ctx: _lib.Context, dem_ptr: int, dem_dtype, H: int, W: int, r
         mask |= 1 << ATTR_BIT[a]
     ordered = sorted(set(attribute), key=lambda a: ATTR_BIT[a])
     planes = (ctypes.c_void_p * len(ordered))(*[plane_ptrs[a] for a in ordered])
-    ctx.check(ctx._L.xdemhip_terrain(
-        ctx.handle, ctypes.c_void_p(dem_ptr), _lib.F32 if np.dtype(dem_dtype) == np.float32 else _lib.F64, H, W,
-        row_stride, halo_top, halo_bottom, float(resolution), _FIT_ID[surface_fit.lower()],
-        _CURV_ID[curv_method.lower()], mask, _TRI_ID[tri_method.lower()], int(window_size), float(hillshade_altitude),
-        float(hillshade_azimuth), float(hillshade_z_factor), int(bool(degrees)),
-        _lib.F32 if np.dtype(out_dtype) == np.float32 else _lib.F64, planes, memspace))
+    args = (ctx.handle, ctypes.c_void_p(dem_ptr), _lib.F32 if np.dtype(dem_dtype) == np.float32 else _lib.F64, H, W,
+            row_stride, halo_top, halo_bottom, float(resolution), _FIT_ID[surface_fit.lower()],
+            _CURV_ID[curv_method.lower()], mask, _TRI_ID[tri_method.lower()], int(window_size), float(hillshade_altitude),
+            float(hillshade_azimuth), float(hillshade_z_factor), int(bool(degrees)),
+            _lib.F32 if np.dtype(out_dtype) == np.float32 else _lib.F64, planes, memspace)
+    with ctx.call_lock:   # (a launch reads the context's options: not while another thread has one changed for its own call)
+        rc = ctx._L.xdemhip_terrain(*args)
+    ctx.check(rc)
 
 
 def get_terrain_attribute(
@@ -245,16 +247,10 @@ def get_terrain_attribute(
 
     outs = {a: np.empty((H, W), dtype=out_dtype) for a in set(attribute)}
     ctx = _lib.default_context()
-    if tile_rows:
-        prev_rows = ctx.options.get("host_chunk_rows", 0)
-        ctx.set_option("host_chunk_rows", tile_rows)
-    try:
+    with (ctx.option_scope("host_chunk_rows", tile_rows) if tile_rows else ctx.call_lock):
         return _run_and_wrap(ctx, dem, dem_arr, attribute, outs, H, W, resolution, degrees, hillshade_altitude, hillshade_azimuth,
                              hillshade_z_factor, surface_fit, curv_method, tri_method, window_size, window_size_fractal, engine,
                              texture_alpha, out_dtype, mp_config)
-    finally:
-        if tile_rows:
-            ctx.set_option("host_chunk_rows", prev_rows)
 
 
 def _tile_rows_of(mp_config, dem) -> int:
@@ -291,16 +287,10 @@ def _run_and_wrap(ctx, dem, dem_arr, attribute, outs, H, W, resolution, degrees,
                   (dem_arr, [a for a in stencil if a not in list_requiring_surface_fit], 0)]
     for arr, names, nonfinite in groups:
         if names:
-            prev = ctx.options.get("terrain_nonfinite", 0)
-            if nonfinite != prev:
-                ctx.set_option("terrain_nonfinite", nonfinite)
-            try:
+            with ctx.option_scope("terrain_nonfinite", nonfinite):
                 launch_terrain(ctx, arr.ctypes.data, arr.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method,
                                names, tri_method, window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor,
                                degrees, out_dtype, {a: outs[a].ctypes.data for a in set(names)}, _lib.HOST, window_size_fractal)
-            finally:
-                if nonfinite != prev:
-                    ctx.set_option("terrain_nonfinite", prev)
     if "texture_shading" in attribute:  # frequency-domain attribute: its own engine (terrain.py:637-644)
         alpha = texture_alpha
         code = lambda dt: _lib.F32 if np.dtype(dt) == np.float32 else _lib.F64  # noqa: E731
