@@ -52,6 +52,44 @@ def _cpu_terrain_tile(args):
     return time.perf_counter() - t0
 
 
+def _cpu_nk_step(args):
+    """Worker of the all-cores Nuth-Kaab leg: one iteration step of the oracle on its own m x m pair."""
+    seed, m = args
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import nuthkaab_oracle as nko
+
+    rng = np.random.default_rng(seed)
+    ref = (1000.0 + np.cumsum(np.cumsum(rng.normal(scale=0.2, size=(m, m)), 0), 1)).astype(np.float32)
+    tba = (np.roll(ref, (1, -2), (0, 1)) + 2.0).astype(np.float32)
+    tba[rng.uniform(size=(m, m)) < 0.2] = np.nan
+    st, asp = nko.aux_vars(ref)
+    valid = np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+    t0 = time.perf_counter()
+    nko.iteration_step((0.0, 0.0, 0.0), ref, tba, valid, st, asp, (10.0, 10.0), 72)
+    return time.perf_counter() - t0
+
+
+def _cpu_vario_pdist(args):
+    """Worker of the all-cores variogram leg: exact-Dowd pdist of its own n points (oracle)."""
+    seed, n = args
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import variogram_oracle as vo
+
+    rng = np.random.default_rng(seed)
+    x, y = rng.uniform(0, 20000, n), rng.uniform(0, 20000, n)
+    v = (np.sin(x / 900) + 0.2 * rng.normal(size=n)).astype(np.float32)
+    edges = np.geomspace(np.sqrt(2), np.hypot(20000, 20000), 50)
+    t0 = time.perf_counter()
+    vo.empirical_variogram_blocks([(x, y, v)], edges, "dowd")
+    return time.perf_counter() - t0
+
+
 def _usable_cores() -> int:
     """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container that sees 256 CPUs
     but is granted a handful would only time-share 256 workers)."""
@@ -194,6 +232,27 @@ def secondary_cpu_baselines() -> dict:
     dt = time.perf_counter() - t0
     out["variogram"] = {"value": round(float(c.sum()) / dt / 1e9, 5), "unit": "Gpairs_s", "cores": 1, "kind": "port",
                         "sample": f"pdist of {n} points ({int(c.sum())} pairs), 50 classes, Dowd, oracle/variogram_oracle.py, {dt:.1f} s"}
+    # all host cores: one oracle process per usable core, each on its own sample; rate = work of all / slowest wall
+    try:
+        import multiprocessing as mp
+
+        cores = min(_usable_cores(), 256)
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_cpu_nk_step, [(i, 64) for i in range(cores)])   # spin the workers up (imports) outside the clock
+            mm = 1000
+            t0 = time.perf_counter()
+            pool.map(_cpu_nk_step, [(100 + i, mm) for i in range(2 * cores)], chunksize=2)
+            wall = time.perf_counter() - t0
+            out["nuthkaab"]["all_cores"] = {"value": round(2 * cores * mm * mm / wall / 1e6, 2), "unit": "Mpixel_iterations_s", "cores": cores, "kind": "port",
+                                            "sample": f"{cores} processes x two {mm}x{mm} pairs each, one iteration step, {wall:.1f} s wall"}
+            nn = 3000
+            t0 = time.perf_counter()
+            pool.map(_cpu_vario_pdist, [(200 + i, nn) for i in range(2 * cores)], chunksize=2)
+            wall = time.perf_counter() - t0
+            out["variogram"]["all_cores"] = {"value": round(2 * cores * (nn * (nn - 1) // 2) / wall / 1e9, 4), "unit": "Gpairs_s", "cores": cores, "kind": "port",
+                                             "sample": f"{cores} processes x two pdist of {nn} points each, 50 classes, Dowd, {wall:.1f} s wall"}
+    except Exception as e:  # pragma: no cover - the single-thread figures stand on their own
+        out["all_cores_error"] = repr(e)
     return out
 
 
@@ -256,6 +315,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         mine = blocks[rank::world]
         ps = ss.PairSet(mine, edges, ctx)
         del blocks
+        red0 = ctx.reduction_calls()
         try:
             if warm:
                 ps.sums(0)                   # warm-up (kernel load, clocks)
@@ -289,7 +349,11 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
             raise RuntimeError("variogram: non-finite class estimate")
         mat_rate = total / (ms_kernel * 1e-3 if ms_kernel else dt_m) / 1e9     # Gpairs/s (kernel time on one GPU, wall over ranks)
         dowd_rate = total / dt_d / 1e9
+        red1 = ctx.reduction_calls()
         return {"pairs": total, "lag_classes": int(len(edges)), "n_gpus": world,
+                "reductions": {"through_the_host": red1[0] - red0[0], "device": red1[1] - red0[1],
+                               "note": "library-hook all-reduces of the exact-Dowd selection over all timed and warm-up calls of this leg (integer histograms, counters, "
+                                       "successor keys); the Matheron sums are two torch.distributed all-reduces per call on top"},
                 "matheron_pass_Gpairs_s": round(mat_rate, 1), "dowd_exact_median_Gpairs_s": round(dowd_rate, 2),
                 "dowd_first_call_Gpairs_s": round(total / dt_d_cold / 1e9, 2), "runs": runs, "points_per_sample": samples,
                 "validated": "class counts of the Matheron and exact-Dowd routes identical, their sum = pairs formed",
@@ -343,6 +407,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         for i in range(k):
             plan.step(offsets[0] + 2e-3 * ((i * 7) % 5 - 2), offsets[1] + 1.5e-3 * ((i * 3) % 5 - 2), res, 72)
         dt_settled = (time.perf_counter() - t0) / k
+        nk_red = None
         n_valid = r["n_valid"]
         routes = plan.route_counts()
         plan.close()
@@ -363,6 +428,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
         dt_settled = None
         routes = nk_info.get("routes")
         red = nk_info.get("reductions", (0, 0))
+        nk_red = {"through_the_host": int(red[0]), "device": int(red[1]), "per_iteration": round((red[0] + red[1]) / 10, 1)}
         how = (f"row blocks of {world} ranks + halo rows, every reduction of a step through the process group "
                f"({(red[0] + red[1]) / 10:.1f} all-reduces per iteration: {red[0]} staged through the host, {red[1]} enqueued on the device)")
     # full data passes per iteration: ONE on the one-pass step of round 4 (dh, the counting for its median and the aspect-bin
@@ -387,6 +453,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
                        "fitted_shift_px": [round(sx, 3), round(sy, 3), round(sz, 3)],
                        "validated": "the 10-iteration fit recovers the (+1.7, +0.6) px, -2.0 m shift the pair was built with",
                        "routes": routes, "nk_nan_rule": int(ctx.options.get("nk_nan_rule", 0)),
+                       "reductions": nk_red,
                        "roofline": {"bound": "hbm", "model": ("SURVEY 8d: 16 B/pixel per data pass with stored aux arrays (ref 4 + tba 4 + slope tangent + aspect bin) "
                                                               "x P passes; P = 1: the one-pass step counts for the median of dh and for the 72 bin medians in the "
                                                               "same pass, against brackets from a 1/64 sample (8 B/pixel/pass x 2 passes in rounds 2-3: the same 16)"
@@ -699,7 +766,7 @@ def main() -> None:
         fresh = block is None
         if fresh:
             block = xdist.RowBlock(n, n, depth, rank, world, dev)
-        # resident planes from the library's allocator: one virtual range over 8 MiB physical pieces in pseudo-random order, so that
+        # resident planes from the library's allocator: one virtual range over 32 MiB physical pieces in pseudo-random order, so that
         # the ~55 row streams of the kernel spread over the memory channels whatever the driver's free list looks like (DESIGN.md
         # section 1; XDEM_BENCH_PLANES = torch | contiguous | chunked selects another backing for measurements)
         out = terrain.alloc_planes(len(FULL), block.rows, n, torch.float32, ctx, dev,
@@ -833,7 +900,9 @@ def main() -> None:
             "dtype": "f32 in/out, mixed f64/f32 arithmetic (f64 where cancellation demands: stencil sums, curvature numerators, discriminants)",
             "data": "synthetic",
             "config": {"workload": f"{n}x{n} float32 fBm DEM (H=0.7, 1000+-300 m, res 10 m), Florinsky fit, geometric "
-                                   f"curvatures, 11 attributes, device-resident in/out (planes: the library's scattered 8 MiB-piece backing)",
+                                   f"curvatures, 11 attributes, device-resident in/out (planes: the library's scattered 32 MiB-piece backing)",
+                       # what a step exchanges: `depth` rows of 4-byte pixels with each neighbour, sent and received (interior ranks: 2 neighbours)
+                       "halo_bytes_per_step_and_rank": 0 if world == 1 else int(2 * min(2, world - 1) * depth * n * 4),
                        "partition": f"{world} row block(s), halo depth {depth}" +
                                     (", shared-GPU gloo test mode" if share else (", RCCL send/recv" if world > 1 else "")),
                        "bytes_per_pixel": BYTES_PER_PIXEL},

@@ -77,7 +77,7 @@ int xdemhip_synchronize(xdemhip_ctx* ctx);
 /* Device memory with a chosen PHYSICAL backing, for resident planes.  The streaming terrain kernel keeps
  * ~55 row streams going at once; in physically contiguous memory -- XDEMHIP_ALLOC_CONTIGUOUS, or an ordinary allocation on a box
  * whose free memory is one block -- they collide in the memory channels (14.4-15.6 ms for the 40000^2 set), in memory whose
- * pieces are scattered they do not (12.7-13.3 ms).  XDEMHIP_ALLOC_SCATTERED is the form to use: one virtual range over 8 MiB
+ * pieces are scattered they do not (12.7-13.3 ms).  XDEMHIP_ALLOC_SCATTERED is the form to use: one virtual range over 32 MiB
  * physical pieces mapped in a fixed pseudo-random order (HIP virtual memory management).  `flags` = 0: hipMalloc.
  * XDEMHIP_ALLOC_CONTIGUOUS (hipExtMallocWithFlags / hipDeviceMallocContiguous; *got_contiguous -- optional -- tells whether the
  * driver had one piece), XDEMHIP_ALLOC_RECYCLED (allocate, touch, free, allocate again), XDEMHIP_ALLOC_CHUNKED (64 MiB pieces in
@@ -95,36 +95,49 @@ int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms);
  * per timed step: the same binary runs the terrain launch at 12.7 ms on one box and 13.9 ms on the next, and only the clock under
  * load tells a power-managed part from a slow placement of the planes.) */
 int xdemhip_clock_probe(xdemhip_ctx* ctx, void* hip_stream, int sleeps, uint64_t* out_device);
-/* Tuning / test switches.  "selection": how the exact medians (nanmedian of dh, aspect-bin and nd_binning medians, NMAD) are
- * selected -- 0 (default) bracketed for large inputs: brackets from a ~1/64 line sample, one counting + compaction pass,
- * exact selection among the candidates, plain radix passes if a bracket misses or if the input is too small per bin for
- * useful brackets; 1 plain 8-bit radix passes only; 2 degenerate brackets (exercises the fall-back); 3 bracketed even
- * where the per-bin sample is small (test switch).  Results are identical in every mode.
- * "host_chunk_mb": device-memory budget (MiB) of one row chunk of host-buffer xdemhip_terrain calls (0 = default 288): host
- * rasters of any size stream through the GPU in row chunks with the overlap the attributes need.  "host_chunk_rows": rows per
- * chunk where that is FEWER than the budget gives (0 = from the budget; at least 64 are taken) -- what the reference's tiled call takes from
- * `mp_config.chunk_size` (xdem/terrain/terrain.py:412-466); chunked and one-pass results are bit-identical.  "host_copy_threads":
- * threads (one HIP stream each) that move host-buffer rasters over PCIe, rows split among them (0 = default 8, at most 16).
- * "nk_nan_rule": how nodata spreads through the bilinear taps of the Nuth-Kaab step / translation resample (the convention
- * of geoutils' _interp_points is not pinned by anything readable offline): 0 "4tap" (default; NaN if any of the four taps is
- * non-finite or outside, zero weights included -- except a zero-weight tap beyond the last row / column, so a node exactly
- * on the upper edge keeps its value), 1 "weighted" (zero-weight taps ignored everywhere: a NaN neighbour with weight 0
- * does not spread), 2 "dilate3x3" (NaN if the 3 x 3 neighbourhood of the nearest pixel holds a non-finite value), 3 "dilate_cross" (the same
- * with the 4-connected cross: SciPy's default binary-dilation structure).  Read when a
- * plan is created / a resample is launched.
- * "vario_edge": lag classes of the pair kernels, 0 = [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k]; "vario_diff": |dv| formed
- * 0 = in the value dtype (default), 1 = in float64 (float32 values widened at xdemhip_pairs_create) -- the two scikit-gstat
- * conventions that nothing readable offline pins (oracle/pin_thirdparty.py regenerates fixtures for them where the package
- * is importable).  "vario_grid": 1 (default) = raster-sampled points (coordinates on an integer lattice) run the
- * integer-lattice pair kernels, 0 = always the float64-coordinate kernels; classes and results are identical.
- * "terrain_store" / "terrain_rows" / "terrain_math": measurement switches of the fused terrain kernel (0 = default each):
- * staged 1 KiB row stores, tile height, float64 attribute math for float32 rasters.
- * "terrain_nonfinite": which of the reference's two rules decides what +-Inf pixels do to the surface-fit attributes -- 0
- * (default) the SciPy engine's: an output is NaN iff its full window holds a non-finite value (surfit.py:1185-1192); 1 the
- * Numba engine's (surfit.py:948-1088, 1270-1303): no mask, the float64 loop over every tap and the formulas decide (0 x Inf
- * and Inf - Inf give NaN, other infinite windows give slope 90 deg etc.).  NaN pixels and raster edges behave alike under both.
- * "pairs_launch_cap": workgroups per launch of the variogram pair passes (0 = default 2^31 / workgroup size, the most a HIP
- * dispatch holds; a pass over more tiles goes out as several launches -- a small value is a test switch for that path). */
+/* OPTIONS of a context (fourteen names; every one of them has a GPU test).  Switches that only choose between internal routes
+ * which must agree -- for the route-agreement tests and for measurements -- are not options: include/xdemhip_test.h.
+ *  Host-buffer terrain calls
+ *   "host_chunk_mb"     device-memory budget (MiB) of one row chunk (0 = default 288): host rasters of any size stream through the
+ *                       GPU in row chunks with the overlap the attributes need.
+ *   "host_chunk_rows"   rows per chunk where that is FEWER than the budget gives (0 = from the budget; at least 64 are taken) -- what
+ *                       the reference's tiled call takes from `mp_config.chunk_size` (xdem/terrain/terrain.py:412-466); chunked and
+ *                       one-pass results are bit-identical.
+ *   "host_copy_threads" threads (one HIP stream each) that move host-buffer rasters over PCIe, rows split among them (0 = default 8,
+ *                       at most 16).
+ *   "host_release"      (any value) frees the pinned staging buffers the context keeps between such calls.
+ *  Terrain
+ *   "terrain_math"      precision recipe of float32 -> float32 launches: 2 (default) lean tail -- float64 where terms cancel, float32
+ *                       scale factors; 0 mixed tail -- float64 everywhere but the arcsines; 1 float64 attribute math (what every other
+ *                       dtype pair always runs).  All three meet the 1e-6 bar of the reference fixtures.
+ *   "terrain_nonfinite" which of the reference's two rules decides what +-Inf pixels do to the surface-fit attributes -- 0 (default) the
+ *                       SciPy engine's: an output is NaN iff its full window holds a non-finite value (surfit.py:1185-1192); 1 the
+ *                       Numba engine's (surfit.py:948-1088, 1270-1303): no mask, the float64 loop over every tap and the formulas decide
+ *                       (0 x Inf and Inf - Inf give NaN, other infinite windows give slope 90 deg etc.).  NaN pixels and raster edges
+ *                       behave alike under both.
+ *  Conventions of the third-party packages that nothing readable offline pins (oracle/pin_thirdparty.py decides them where the
+ *  packages are importable; xdem_amd/thirdparty_decision.json then sets every context's defaults)
+ *   "nk_nan_rule"       how nodata spreads through the bilinear taps of the Nuth-Kaab step / translation resample (geoutils'
+ *                       _interp_points): 0 "4tap" (default; NaN if any of the four taps is non-finite or outside, zero weights included --
+ *                       except a zero-weight tap beyond the last row / column, so a node exactly on the upper edge keeps its value), 1
+ *                       "weighted" (zero-weight taps ignored everywhere), 2 "dilate3x3" (NaN if the 3 x 3 neighbourhood of the nearest
+ *                       pixel holds a non-finite value), 3 "dilate_cross" (the same with the 4-connected cross: SciPy's default
+ *                       binary-dilation structure).  Read when a plan is created / a resample is launched.
+ *   "vario_edge"        lag classes of the pair kernels, 0 = [e_{k-1}, e_k) (default), 1 = (e_{k-1}, e_k].
+ *   "vario_diff"        |dv| formed 0 = in the value dtype (default), 1 = in float64 (float32 values widened at xdemhip_pairs_create).
+ *  Exact order statistics and the Nuth-Kaab step (results are identical under every value; tests hold the routes against each other)
+ *   "selection"         how the exact medians (nanmedian of dh, aspect-bin and nd_binning medians, NMAD, Dowd) are selected -- 0 (default)
+ *                       bracketed for large inputs: brackets from a ~1/64 sample, one counting + compaction pass, exact selection among
+ *                       the candidates, plain radix passes if a bracket misses or the input is too small per bin; 1 plain 8-bit radix
+ *                       passes only (the fall-back, and the check of the other); 2 degenerate brackets (exercises the fall-back); 3
+ *                       bracketed even where the per-bin sample is small.
+ *   "nk_fused"          1 (default) the Nuth-Kaab step of large plans is ONE data pass (14 B/pixel), 0 the two queued passes (the route a
+ *                       one-pass step hands over to when a bracket misses or a buffer overflows).
+ *   "nk_fused_dist"     1 (default) partitioned plans (reduction hook + xdemhip_set_rank) take the one-pass step too, 0 the two-pass route.
+ *   "nk_predict"        1 (default) a settled one-pass step takes its brackets from the previous step's exact medians (see
+ *                       xdemhip_nk_predict_counts), 0 every step samples.
+ *   "pairs_launch_cap"  workgroups per launch of the variogram pair passes (0 = default 2^31 / workgroup size, the most a HIP dispatch
+ *                       holds; a pass over more tiles goes out as several launches -- a small value exercises that path). */
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value);
 
 /* Multi-GPU hook for the accumulator-style paths (Nuth-Kaab reductions): one process per GPU, every rank works on its
@@ -261,9 +274,9 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uin
  * the two queued passes of rounds 2-3, or by the plain digit passes (small rasters; the fall-back of both).  Results are
  * identical on every route (integer counts, exact selections); nanmean / nanstd of y -- the p0 of the curve fit -- agree to
  * 2e-6 of the spread on the one-pass route (float32 partial sums, the accuracy class of the reference's own float32
- * np.nanmean).  Context option "nk_binseg" (default 1) selects round 5's forms of the small steps around that one pass --
- * per-bin candidate segments with one workgroup per bin, value-bucket selection of the median of dh, sample passes that
- * advance their own selection states: 24 launches per step -- 0 round 4's generic selections (55); same integers either way.
+ * np.nanmean).  Around that one pass: per-bin candidate segments with one workgroup per bin, value-bucket selection of the
+ * median of dh, sample passes that advance their own selection states -- 24 launches per step with sampled brackets, 14 with
+ * predicted ones (option "nk_predict").
  * PARTITIONED plans (reduction hook installed, xdemhip_set_rank told, context option "nk_fused_dist" = 1, the default) take the
  * one-pass step as well: one data pass over the rank's own rows and TEN all-reduces per step (nuthkaab.hip: "the ONE-PASS step
  * on PARTITIONED plans"), all of them enqueued through the device hook where it is installed; every rank returns the same integers

@@ -22,12 +22,36 @@ def lib():
 
 
 def test_every_declared_symbol_is_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "xdemhip.h")).read()
-    names = sorted(set(re.findall(r"\b(xdemhip_[a-z_0-9]+)\s*\(", hdr)))
-    assert len(names) >= 18, names
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/xdemhip.h but not exported by libxdemhip.so"
+    import glob
+
+    total = 0
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        hdr = open(h).read()
+        names = sorted(set(re.findall(r"\b(xdemhip_[a-z_0-9]+)\s*\(", hdr)))
+        total += len(names)
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in include/{os.path.basename(h)} but not exported by libxdemhip.so"
+    assert total >= 19, total
     assert lib.xdemhip_version() >= 100
+
+
+def test_option_names_of_the_header_and_the_library_agree():
+    """include/xdemhip.h documents the OPTIONS of a context (at most fourteen names since round 6), include/xdemhip_test.h the test
+    switches between internal routes; the tables of csrc/capi.hip hold exactly those names, and the Python binding routes a name to
+    the right entry point.  (That every option changes what it says it changes is the GPU suite's business.)"""
+    from xdem_amd import _lib
+
+    def doc_names(path):
+        txt = open(os.path.join(ROOT, "include", path)).read()
+        return set(re.findall(r'^ \*   "([a-z_0-9]+)"', txt, flags=re.M))   # (the list entries: three spaces of indent; continuation lines have more)
+
+    src = open(os.path.join(ROOT, "xdem_amd", "csrc", "capi.hip")).read()
+    tab = lambda name: set(re.findall(r'\{"([a-z_0-9]+)",', src[src.index(name):src.index("};", src.index(name))]))
+    opts = tab("kOptions[]") | {"host_release", "host_copy_threads"}
+    switches = tab("kTestSwitches[]")
+    assert doc_names("xdemhip.h") == opts and len(opts) <= 14, (sorted(doc_names("xdemhip.h")), sorted(opts))
+    assert doc_names("xdemhip_test.h") | {"terrain_store", "terrain_rows", "terrain_sync", "vario_deff"} == switches, sorted(switches)
+    assert switches == set(_lib.Context.TEST_SWITCHES) and not (opts & switches)
 
 
 def test_header_constants_match_the_binding():

@@ -338,6 +338,42 @@ def test_bench_two_ranks_reports_c4(tmp_path):
     assert nk["n_gpus"] == 2 and "row blocks of 2 ranks" in nk["partition"] and abs(nk["fitted_shift_px"][0] - 1.7) < 0.05
 
 
+def test_bench_two_ranks_over_rccl_one_gpu_each(tmp_path):
+    """The run the driver makes on its 8-GPU node, in small: `bench.py --gpus 2` under torch.distributed.run with ONE RANK PER GPU --
+    `init_process_group("nccl")`, `batch_isend_irecv` halo rows between two devices, the device-side reduction hook with a real peer,
+    the partitioned Nuth-Kaab fit and the sharded variogram -- so that the first multi-GPU run is not also the first execution of
+    those code paths.  Needs two GPUs: on the one-GPU test boxes of this pool it is an expected failure (the reason says so)."""
+    import json
+    import socket
+    import subprocess
+
+    if torch.cuda.device_count() < 2:
+        pytest.xfail(f"needs >= 2 GPUs for one RCCL rank per GPU; this box shows {torch.cuda.device_count()} "
+                     "(the shared-GPU gloo form of the same run is test_bench_two_ranks_reports_c4)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XDEM_BENCH_C4_SIZE="8192", XDEM_BENCH_C3_SIZE="6000", XDEM_BENCH_C5_RUNS="6", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("XDEM_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "8192"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["rccl_ranks"] == 2 and "RCCL send/recv" in res["config"]["partition"]
+    assert res["config"]["halo_bytes_per_step_and_rank"] > 0 and res["value"] > 0
+    sec = res["secondary"]
+    assert "error" not in sec, sec
+    nk = sec["nuthkaab"]
+    assert nk["n_gpus"] == 2 and abs(nk["fitted_shift_px"][0] - 1.7) < 0.05 and nk["reductions"]["through_the_host"] == 0, nk
+    assert sec["variogram"]["n_gpus"] == 2 and sec["variogram"]["reductions"]["device"] > 0
+    assert sec["c4_terrain_row_blocks"]["n_gpus"] == 2
+
+
 def test_rccl_branch_of_the_halo_exchange_on_a_one_rank_group():
     """The branch of ``RowBlock.exchange`` the 8-GPU run takes -- ``batch_isend_irecv`` of DEVICE row slices under the nccl (=
     RCCL) backend, grouped ncclSend / ncclRecv on the communicator's stream -- driven on the one GPU of the test box: a block

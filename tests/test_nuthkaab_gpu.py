@@ -696,16 +696,6 @@ def test_lean_route_equals_plain_route_at_scale():
             res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
             assert plan.route_counts()[name] == 4, (name, plan.route_counts())   # every step answered by the route under test
             plan.close()
-        # round 5: the one-pass step selects among the bin candidates one workgroup per bin on per-bin segments (option "nk_binseg",
-        # default on); the digit passes over all candidate slots (round 4) stay behind the option
-        ctx.set_option("selection", 0)
-        ctx.set_option("nk_fused", 1)
-        ctx.set_option("nk_binseg", 0)
-        plan = coreg.NKPlan(ref, tba, None, ctx)
-        res["onepass, digit passes"] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
-        assert plan.route_counts()["onepass"] == 4, plan.route_counts()
-        plan.close()
-        ctx.set_option("nk_binseg", 1)
         # the one-pass step with its sample brackets at a fixed fraction of the rule (option "nk_narrow"; default: adaptive):
         # full width answers every step itself; a quarter may miss and hand a step to the two-pass route -- exact either way
         ctx.set_option("selection", 0)
@@ -719,7 +709,7 @@ def test_lean_route_equals_plain_route_at_scale():
             print(f"nk_narrow = {k}: routes {rc}")
             plan.close()
         ctx.set_option("nk_narrow", -1)
-        for name in ("onepass", "onepass, digit passes", "twopass", "narrow0", "narrow1", "narrow2"):
+        for name in ("onepass", "twopass", "narrow0", "narrow1", "narrow2"):
             for a, b in zip(res[name], res["plain"]):
                 assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], name
                 assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), name
@@ -792,9 +782,8 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
 
 def test_whole_fit_stays_on_the_one_pass_route():
     """bench.py's whole-fit leg in small: the iteration converges, the pair ends aligned, dh collapses onto a few float32 values
-    (differences of ~1e3 m elevations are multiples of 1.2e-4 m) -- every step must still be answered by the one-pass route, in
-    round 5's form (value / key buckets: a bucket that is ONE key needs no gathered keys) and in round 4's (digit passes), with
-    identical offsets."""
+    (differences of ~1e3 m elevations are multiples of 1.2e-4 m) -- every step must still be answered by the one-pass route (value /
+    key buckets: a bucket that is ONE key needs no gathered keys), and two runs end at the same offsets."""
     import os
     import sys
 
@@ -808,10 +797,9 @@ def test_whole_fit_stays_on_the_one_pass_route():
     dev = torch.device("cuda", 0)
     ref, tba = bench._c3_pair(dev, 9000)
     got = {}
-    for form in (1, 0):
+    for form in (1, 0):   # (two runs of the one form: round 4's digit-pass selections, the other form of rounds 4-5, went in round 6)
         ctx = _lib.Context(0)
         try:
-            ctx.set_option("nk_binseg", form)
             plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx)
             off = coreg._iterate(plan, (10.0, 10.0), 0.0, 8, 36, scipy.optimize.curve_fit, True)   # (36 bins: enough sample per bin at this size)
             routes = plan.route_counts()

@@ -24,8 +24,6 @@ ref, tba = bench._c3_pair(dev, m)
 ctx = _lib.default_context(0)
 if os.environ.get("NK_NARROW"):   # sample brackets of the one-pass step: -1 adaptive (default), 0 / 1 / 2 fixed
     ctx.set_option("nk_narrow", int(os.environ["NK_NARROW"]))
-if os.environ.get("XDEM_NK_BINSEG"):   # bin candidates: 1 per-bin segments + one workgroup per bin (default), 0 digit passes over all slots
-    ctx.set_option("nk_binseg", int(os.environ["XDEM_NK_BINSEG"]))
 group = None
 if os.environ.get("NK_HOOKED"):   # the partitioned plan's route on one GPU: a 1-rank RCCL group, reductions through the device-side hook
     import torch.distributed as dist

@@ -80,6 +80,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_device_alloc.argtypes = [c_ctx, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]
         L.xdemhip_device_free.argtypes = [c_ctx, ctypes.c_void_p]
         L.xdemhip_set_option.argtypes = [c_ctx, ctypes.c_char_p, ctypes.c_int]
+        L.xdemhip_set_test_switch.argtypes = [c_ctx, ctypes.c_char_p, ctypes.c_int]
         L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_set_allreduce_device.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_reduction_calls.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
@@ -415,9 +416,14 @@ class Context:
         for _, _, p in items:
             self._L.xdemhip_device_free(self.handle, ctypes.c_void_p(p))
 
+    TEST_SWITCHES = frozenset(("terrain_stream", "terrain_order", "terrain_ring_wait", "terrain_window_lds", "nk_ext", "nk_narrow",
+                               "vario_grid", "vario_runs", "vario_sort", "terrain_store", "terrain_rows", "terrain_sync", "vario_deff"))
+
     def set_option(self, name: str, value: int) -> None:
-        """Tuning / test switch of the library (``xdemhip_set_option``), e.g. ``("selection", 1)``."""
-        self.check(self._L.xdemhip_set_option(self.handle, name.encode(), int(value)))
+        """Option of the library (``xdemhip_set_option``: the fourteen names of include/xdemhip.h), e.g. ``("selection", 1)`` -- or,
+        for the names of include/xdemhip_test.h, a test switch between internal routes (``xdemhip_set_test_switch``)."""
+        fn = self._L.xdemhip_set_test_switch if name in self.TEST_SWITCHES else self._L.xdemhip_set_option
+        self.check(fn(self.handle, name.encode(), int(value)))
         self.options[name] = int(value)
 
     @contextlib.contextmanager

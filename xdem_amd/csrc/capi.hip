@@ -249,7 +249,10 @@ int xdemhip_device_alloc(xdemhip_ctx* ctx, size_t bytes, int flags, void** ptr, 
         *ptr = nullptr;
         if (got_contiguous) *got_contiguous = 0;
         const bool scattered = (flags & XDEMHIP_ALLOC_SCATTERED) != 0;
-        size_t piece_mb = scattered ? 8 : 64;
+        // (round 6: 32 MiB pieces.  On boxes whose ordinary allocations are FAST placements larger pieces are faster -- fewer TLB misses:
+        //  13.05 / 12.93 / 12.80 ms for 8 / 32 / 128 MiB against 12.87 on torch.empty planes --, on a box whose ordinary allocations are
+        //  slow ones (14.7 ms) 8 / 32 / 128 MiB ran 13.0 / 12.8-13.0 / 12.8-13.2: profiles/r06_piece_probe.txt)
+        size_t piece_mb = scattered ? 32 : 64;
         if (const char* e = getenv("XDEMHIP_SCATTER_PIECE_MB")) {   // (measurements: tools/piece_probe.py)
             const long v = atol(e);
             if (scattered && v >= 1 && v <= 4096) piece_mb = (size_t)v;
@@ -288,19 +291,58 @@ int xdemhip_synchronize(xdemhip_ctx* ctx) {
     return XDEMHIP_OK;
 }
 
+// Options of the PRODUCT (include/xdemhip.h): what a caller of the C-ABI may want to set.  Everything that only selects between
+// internal routes that must agree -- for the route-agreement tests and for measurements -- is a TEST SWITCH
+// (xdemhip_set_test_switch, include/xdemhip_test.h); switches of measurement builds exist under -DXD_EXPERIMENT only.
+namespace {
+struct XdOpt { const char* name; int lo, hi; int xdemhip_ctx::*field; const char* what; };
+const XdOpt kOptions[] = {
+    {"host_chunk_mb", 0, 1 << 30, &xdemhip_ctx::host_chunk_mb, "host_chunk_mb must be >= 0"},
+    {"host_chunk_rows", 0, 1 << 30, &xdemhip_ctx::host_chunk_rows, "host_chunk_rows must be >= 0"},
+    {"pairs_launch_cap", 0, 1 << 30, &xdemhip_ctx::pairs_launch_cap, "pairs_launch_cap must be >= 0"},
+    {"terrain_nonfinite", 0, 1, &xdemhip_ctx::terrain_nonfinite, "terrain_nonfinite: 0 window rule (SciPy engine), 1 arithmetic rule (Numba engine)"},
+    {"terrain_math", 0, 2, &xdemhip_ctx::terrain_math, "terrain_math: 0 mixed precision, 1 float64, 2 lean"},
+    {"vario_edge", 0, 1, &xdemhip_ctx::vario_edge, "vario_edge: 0 or 1"},
+    {"vario_diff", 0, 1, &xdemhip_ctx::vario_diff, "vario_diff: 0 or 1"},
+    {"nk_nan_rule", 0, 3, &xdemhip_ctx::nk_nan_rule, "nk_nan_rule: 0 4tap, 1 weighted, 2 dilate3x3, 3 dilate_cross"},
+    {"selection", 0, 3, &xdemhip_ctx::selection_mode, "selection: 0 auto, 1 plain, 2 degenerate brackets, 3 bracketed"},
+    {"nk_fused", 0, 1, &xdemhip_ctx::nk_fused, "nk_fused: 0 or 1"},
+    {"nk_fused_dist", 0, 1, &xdemhip_ctx::nk_fused_dist, "nk_fused_dist: 0 or 1"},
+    {"nk_predict", 0, 1, &xdemhip_ctx::nk_predict, "nk_predict: 0 or 1"},
+};
+const XdOpt kTestSwitches[] = {
+    {"terrain_stream", 0, 512, &xdemhip_ctx::terrain_stream, "terrain_stream: 0, 1, 2, 3, 128, 256 or 512"},
+    {"terrain_order", 0, 3, &xdemhip_ctx::terrain_order, "terrain_order: 0 XCD bands, 1 natural order, 2 permuted strips, 3 column-major strips"},
+    {"terrain_ring_wait", 0, 1, &xdemhip_ctx::terrain_ring_wait, "terrain_ring_wait: 0 counted wait, 1 vmcnt(0)"},
+    {"terrain_window_lds", 0, 1, &xdemhip_ctx::terrain_window_lds, "terrain_window_lds: 0 or 1"},
+    {"nk_ext", 0, 1, &xdemhip_ctx::nk_ext, "nk_ext: 0 or 1"},
+    {"nk_narrow", -1, 2, &xdemhip_ctx::nk_narrow, "nk_narrow: -1 (adaptive), 0, 1 or 2"},
+    {"vario_grid", 0, 1, &xdemhip_ctx::vario_grid, "vario_grid: 0 or 1"},
+    {"vario_runs", 0, 1, &xdemhip_ctx::vario_runs, "vario_runs: 0 or 1"},
+    {"vario_sort", 0, 1, &xdemhip_ctx::vario_sort, "vario_sort: 0 or 1"},
+#ifdef XD_EXPERIMENT   // measurement builds (csrc/Makefile: libxdemhip_exp*.so) only
+    {"terrain_store", 0, 1, &xdemhip_ctx::terrain_store, "terrain_store: 0 direct, 1 staged row stores"},
+    {"terrain_rows", 0, 1000, &xdemhip_ctx::terrain_rows, "terrain_rows: 0, 16, 24, 32 or an occupancy experiment >= 100"},
+    {"terrain_sync", 0, 32, &xdemhip_ctx::terrain_sync, "terrain_sync: 0 or a power of two <= 32"},
+    {"vario_deff", 0, 1 << 20, &xdemhip_ctx::vario_deff, "vario_deff: 0 .. 2^20"},
+#endif
+};
+int xd_set_from(xdemhip_ctx* ctx, const XdOpt* tab, size_t n, const char* name, int value, bool* found) {
+    *found = false;
+    for (size_t k = 0; k < n; ++k)
+        if (const XdOpt& o = tab[k]; strcmp(o.name, name) == 0) {
+            *found = true;
+            if (value < o.lo || value > o.hi) return xd_fail(ctx, XDEMHIP_EINVAL, o.what);
+            ctx->*(o.field) = value;
+            return XDEMHIP_OK;
+        }
+    return XDEMHIP_OK;
+}
+}  // namespace
+
 int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return XDEMHIP_EINVAL;
-    if (std::string(name) == "host_chunk_mb") {  // device / pinned budget of one row chunk of host-buffer terrain calls (0 = default 288 MiB)
-        if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "host_chunk_mb must be >= 0");
-        ctx->host_chunk_mb = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "host_chunk_rows") {  // rows per chunk of host-buffer terrain calls (0 = derived from host_chunk_mb; at least 64 are taken)
-        if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "host_chunk_rows must be >= 0");
-        ctx->host_chunk_rows = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "host_release") {  // free the pinned staging buffers of the host-buffer terrain path (they come back with the next call)
+    if (strcmp(name, "host_release") == 0) {  // free the pinned staging buffers of the host-buffer terrain path (they come back with the next call)
         for (int q = 0; q < 2; ++q) {
             if (ctx->stage_in[q]) (void)hipHostFree(ctx->stage_in[q]);
             if (ctx->stage_out[q]) (void)hipHostFree(ctx->stage_out[q]);
@@ -309,123 +351,28 @@ int xdemhip_set_option(xdemhip_ctx* ctx, const char* name, int value) {
         ctx->stage_in_bytes = ctx->stage_out_bytes = 0;
         return XDEMHIP_OK;
     }
-    if (std::string(name) == "host_copy_threads") {  // threads (one stream each) moving host-buffer rasters over PCIe (0 = default 8)
+    if (strcmp(name, "host_copy_threads") == 0) {  // threads (one stream each) moving host-buffer rasters over PCIe (0 = default 8)
         if (value < 0 || value > xdemhip_ctx::MAX_COPY_THREADS) return xd_fail(ctx, XDEMHIP_EINVAL, "host_copy_threads must be 0..16");
         ctx->host_copy_threads = value ? value : 8;
         return XDEMHIP_OK;
     }
-    if (std::string(name) == "pairs_launch_cap") {  // test switch: split the pair passes into launches of at most this many workgroups
-        if (value < 0) return xd_fail(ctx, XDEMHIP_EINVAL, "pairs_launch_cap must be >= 0");
-        ctx->pairs_launch_cap = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_store") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_store: 0 direct, 1 staged row stores");
-        ctx->terrain_store = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_rows") {
-                // (values >= 100 select occupancy experiments of measurement builds and are ignored by the shipped library)
-        if (value != 0 && value != 16 && value != 24 && value != 32 && value < 100) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_rows: 0, 16, 24 or 32");
-        ctx->terrain_rows = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "vario_sort") {  // host side (PairSet): Morton order of the uploaded points; recorded here so that the option travels with the context
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "vario_sort: 0 or 1");
-        ctx->vario_sort = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "nk_narrow") {
-        if (value < -1 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_narrow: -1 (adaptive), 0, 1 or 2");
-        ctx->nk_narrow = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "vario_runs") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "vario_runs: 0 or 1");
-        ctx->vario_runs = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "vario_deff") {  // 0 = built-in (select.h: PAIR_DEFF_*); brackets too narrow for the data fall back to wider ones
-        if (value < 0 || value > (1 << 20)) return xd_fail(ctx, XDEMHIP_EINVAL, "vario_deff: 0 .. 2^20");
-        ctx->vario_deff = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "nk_fused") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_fused: 0 or 1");
-        ctx->nk_fused = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "nk_predict") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_predict: 0 or 1");
-        ctx->nk_predict = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "nk_fused_dist") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_fused_dist: 0 or 1");
-        ctx->nk_fused_dist = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "nk_binseg") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_binseg: 0 or 1");
-        ctx->nk_binseg = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "nk_ext") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_ext: 0 or 1");
-        ctx->nk_ext = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_stream") {
-        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 128 && value != 256 && value != 512) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_stream: 0, 1, 128, 256 or 512");
-        ctx->terrain_stream = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_sync") {
-        if (value < 0 || value > 32 || (value & (value - 1))) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_sync: 0 or a power of two <= 32");
-        ctx->terrain_sync = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_order") {
-        if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_order: 0 XCD bands, 1 natural order, 2 permuted strips, 3 column-major strips");
-        ctx->terrain_order = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_window_lds") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_window_lds: 0 or 1");
-        ctx->terrain_window_lds = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_ring_wait") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_ring_wait: 0 counted wait, 1 vmcnt(0)");
-        ctx->terrain_ring_wait = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_nonfinite") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_nonfinite: 0 window rule (SciPy engine), 1 arithmetic rule (Numba engine)");
-        ctx->terrain_nonfinite = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "terrain_math") {
-        if (value < 0 || value > 2) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_math: 0 mixed precision, 1 float64, 2 lean");
-        ctx->terrain_math = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "vario_grid" || std::string(name) == "vario_edge" || std::string(name) == "vario_diff") {
-        if (value < 0 || value > 1) return xd_fail(ctx, XDEMHIP_EINVAL, std::string(name) + ": 0 or 1");
-        (std::string(name) == "vario_grid" ? ctx->vario_grid : std::string(name) == "vario_edge" ? ctx->vario_edge : ctx->vario_diff) = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "nk_nan_rule") {
-        if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "nk_nan_rule: 0 4tap, 1 weighted, 2 dilate3x3, 3 dilate_cross");
-        ctx->nk_nan_rule = value;
-        return XDEMHIP_OK;
-    }
-    if (std::string(name) == "selection") {
-        if (value < 0 || value > 3) return xd_fail(ctx, XDEMHIP_EINVAL, "selection: 0 auto, 1 plain, 2 degenerate brackets, 3 bracketed");
-        ctx->selection_mode = value;
-        return XDEMHIP_OK;
-    }
+    bool found = false;
+    const int rc = xd_set_from(ctx, kOptions, sizeof kOptions / sizeof kOptions[0], name, value, &found);
+    if (found) return rc;
+    for (const XdOpt& o : kTestSwitches)
+        if (strcmp(o.name, name) == 0) return xd_fail(ctx, XDEMHIP_EINVAL, std::string(name) + " is a test switch, not an option: xdemhip_set_test_switch (include/xdemhip_test.h)");
     return xd_fail(ctx, XDEMHIP_EINVAL, std::string("unknown option: ") + name);
+}
+
+int xdemhip_set_test_switch(xdemhip_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return XDEMHIP_EINVAL;
+    if (strcmp(name, "terrain_stream") == 0 && !(value == 0 || value == 1 || value == 2 || value == 3 || value == 128 || value == 256 || value == 512))
+        return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_stream: 0, 1, 2, 3, 128, 256 or 512");
+    if (strcmp(name, "terrain_sync") == 0 && (value & (value - 1))) return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_sync: 0 or a power of two <= 32");
+    bool found = false;
+    const int rc = xd_set_from(ctx, kTestSwitches, sizeof kTestSwitches / sizeof kTestSwitches[0], name, value, &found);
+    if (found) return rc;
+    return xd_fail(ctx, XDEMHIP_EINVAL, std::string("unknown test switch: ") + name);
 }
 
 int xdemhip_last_kernel_ms(xdemhip_ctx* ctx, float* ms) {

@@ -39,9 +39,6 @@ struct xdemhip_ctx {
     int vario_deff = 0;      // option "vario_deff": design effect assumed for the pair samples of the bracketed Dowd selection (0 = built-in rule)
     int vario_sort = 1;      // option "vario_sort": the Python side uploads the points of a pair block in Morton order (run-length accumulation of the pair kernels)
     int nk_ext = 1;          // option "nk_ext": 1 the Nuth-Kaab dh pass takes min / max aspect from lists of extreme-aspect pixels and reads a masked reference DEM (default), 0 it reads mask and aspect of every pixel
-    int nk_binseg = 1;       // option "nk_binseg": 1 round 5's forms of the small steps of the one-pass Nuth-Kaab step (per-bin candidate segments + one workgroup per bin,
-                             // value-bucket selection of the median of dh, sample passes that advance their own states, resets / v^ folded into the sample kernels; default),
-                             // 0 round 4's generic selections -- same integers either way (A/B, tests)
     int nk_predict = 1;      // option "nk_predict": 1 a settled one-pass Nuth-Kaab step takes its brackets from the previous step's exact medians moved by the model (no sample kernels, no digit passes over samples; default), 0 every step samples
     int nk_fused = 1;        // option "nk_fused": 1 the Nuth-Kaab step of large single-GPU plans is ONE data pass (14 B/pixel: dh, its median's counting and the aspect-bin counting against sample brackets with per-pixel margins; default), 0 the two passes of round 3
     int terrain_stream = 1;  // option "terrain_stream": 1 streaming strips for the raster interior where they apply (default), 0 tiles only; 128 / 256 / 512 = band height

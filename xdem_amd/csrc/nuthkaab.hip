@@ -1101,15 +1101,6 @@ __device__ __forceinline__ bool nk_vhat_of(uint64_t sample_count, typename KeyT<
     delta = df;
     return (vl <= vm && vm <= vh) && t_finite((T)vl) && t_finite((T)vh);   // (a bracket that reaches +-Inf: not this route)
 }
-template <typename T>
-__global__ void nk_vhat_kernel(const SelState<typename KeyT<T>::type>* st, const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
-                               T* vhat, T* delta, unsigned long long* ctr) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    T v, d;
-    if (!nk_vhat_of<T>(st[0].count, klo[0], khi[0], v, d)) ctr[3] = 1ull;
-    *vhat = v;
-    *delta = d;
-}
 
 // sample of y^ = (dh - v^) / slope_tan with its aspect bin, in place over the dh sample
 template <typename T>
@@ -1515,78 +1506,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
     }
 }
 
-// vertical shift from the counters and the selection among the dh candidates (the arithmetic of nk_vshift_edges_kernel)
-template <typename T>
-__global__ void nk_fz_vshift_kernel(const uint64_t* cnt /* total, below, inside */, const SelState<typename KeyT<T>::type>* st, const uint64_t* succ,
-                                    const typename KeyT<T>::type* klo, const uint32_t* rbs_p, const unsigned long long* ctr, unsigned char* info) {
-    typedef typename KeyT<T>::type K;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint64_t total = cnt[0], lt = cnt[1];
-    const int rbs = (int)*rbs_p;
-    T vs = (T)NAN;
-    if (total) {
-        const K prefix = (K)((K)(st[0].prefix >> rbs) + klo[0]);
-        const uint64_t n_le = st[0].n_le + lt;
-        const T lo = val_of(prefix);
-        if (total & 1) vs = lo;
-        else {
-            const uint64_t k2 = total / 2;
-            T hi = lo;
-            if (!(n_le > k2)) hi = val_of((K)((K)((K)succ[0] >> rbs) + klo[0]));
-            vs = (T)((T)(lo + hi) / (T)2);
-        }
-    }
-    *reinterpret_cast<T*>(info) = vs;
-    *reinterpret_cast<uint64_t*>(info + 8) = total;
-    *reinterpret_cast<uint64_t*>(info + 16) = (uint64_t)((ctr[2] != 0) | ((ctr[3] != 0) << 1));
-    *reinterpret_cast<double*>(info + 24) = (double)vs;
-}
 
-// candidates of the bin medians, now that vshift is known: y in the reference's arithmetic; below / inside the bin's bracket are
-// counted, the inside ones keep their y (NaN for the others: the digit passes skip NaN) -- and are entered into the FIRST digit's
-// histogram of the exact selection that follows (rebased keys, as hist_pass_kernel forms them), which saves that selection its
-// first pass over the candidates
-template <typename T>
-__global__ __launch_bounds__(HIST_THREADS) void nk_resolve_kernel(T* __restrict__ c_v /* dh in, y out */, const T* __restrict__ c_st,
-                                                                  const uint16_t* __restrict__ c_b, int64_t cap, const unsigned long long* n_dev,
-                                                                  const T* vshift_p, int nb, const typename KeyT<T>::type* __restrict__ klo,
-                                                                  const typename KeyT<T>::type* __restrict__ khi, const uint32_t* rbs_p,
-                                                                  uint64_t* res /* [2][nb] */, uint64_t* hist /* [nb][256] */) {
-    typedef typename KeyT<T>::type K;
-    extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
-    K* lo = reinterpret_cast<K*>(fz_smem);
-    K* hi = lo + nb;
-    uint32_t* c = reinterpret_cast<uint32_t*>(hi + nb);   // [2][nb]
-    uint32_t* h = c + 2 * nb;                              // [nb][256]
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) { lo[k] = klo[k]; hi[k] = khi[k]; }
-    for (int k = threadIdx.x; k < 2 * nb + nb * SEL_RADIX; k += blockDim.x) c[k] = 0;
-    __syncthreads();
-    const unsigned long long m = *n_dev;
-    const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
-    const T vshift = *vshift_p;
-    const int rbs = (int)*rbs_p;
-    constexpr int TOP = 8 * (KeyT<T>::passes - 1);
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)c_b[p];
-        const T y = t_div(t_sub(c_v[p], vshift), c_st[p]);
-        T keep = (T)NAN;
-        if (y == y && b < nb) {
-            const K key = key_of(y);
-            if (key < lo[b]) atomicAdd(&c[b], 1u);
-            else if (key <= hi[b]) {
-                atomicAdd(&c[nb + b], 1u);
-                keep = y;
-                atomicAdd(&h[b * SEL_RADIX + (int)(((K)((K)(key - lo[b]) << rbs) >> TOP) & 0xFF)], 1u);
-            }
-        }
-        c_v[p] = keep;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < 2 * nb; k += blockDim.x)
-        if (c[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&res[k]), (unsigned long long)c[k]);
-    for (int k = threadIdx.x; k < nb * SEL_RADIX; k += blockDim.x)
-        if (h[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[k]), (unsigned long long)h[k]);
-}
 
 
 // ---- round 5: the bin candidates partitioned by bin; ONE workgroup per bin selects its exact median ----------------------------
@@ -2589,14 +2509,6 @@ static __global__ __launch_bounds__(256) void nk_fz_pack_kernel(FzPack a) {
 }
 
 // per bin: total / below / inside in the layout bracket_given_kernel reads, from the classes of the pass and of the candidates
-static __global__ void nk_fz_counts_kernel(const uint64_t* cls /* [3][nb]: above, below, candidates */, const uint64_t* res /* [2][nb] */, int nb,
-                                           uint64_t* cnt /* [3][nb] */) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    cnt[b] = cls[b] + cls[nb + b] + cls[2 * nb + b];
-    cnt[nb + b] = cls[nb + b] + res[b];
-    cnt[2 * nb + b] = res[nb + b];
-}
 
 }  // namespace xd
 
@@ -3024,6 +2936,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const int world = ctx->world, rank = ctx->rank;
     bool cannot = !ctx->nk_fused || !P->fz || !P->cd_vals || !P->c_st || !P->bcache || !P->ext_ok || (g.rule > 1 && !P->badbits) || rows <= 0 ||
                   P->bin_stat != XDEMHIP_BINSTAT_MEDIAN || !(ctx->selection_mode == 0 || ctx->selection_mode == 3) || !ws->d_small ||
+                  (int64_t)P->nbuf * P->W < ws->c_cap ||   // (the kept bin candidates go into per-bin segments of the y raster)
                   ws->es != sizeof(T) || nb > ws->nb_max || nb > MAX_BINS_PER_SWEEP || n_slots > ws->s_cap ||
                   (int64_t)(NKZ_CHUNK_MAX + 2) * P->W * (int64_t)sizeof(T) >= ((int64_t)1 << 32);   // (32-bit byte offsets inside a chunk of rows)
     int64_t n_all = n;   // pixels of all ranks
@@ -3033,9 +2946,9 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         // from reduced data (ext_ok), so the ranks agree ONCE -- a host all-reduce of (own pixels, "I cannot") -- and again whenever
         // any of it changes, which it does on all ranks at the same step.
         const int64_t key[8] = {nb, P->row0, P->row1, (int64_t)P->ext_ok, (int64_t)P->bin_stat, (int64_t)ctx->selection_mode,
-                                (int64_t)(ctx->nk_fused * 4 + ctx->nk_fused_dist * 2 + ctx->nk_binseg), (int64_t)world * 64 + rank};
+                                (int64_t)(ctx->nk_fused * 4 + ctx->nk_fused_dist * 2), (int64_t)world * 64 + rank};
         if (memcmp(key, P->mr_key, sizeof key) != 0) {
-            cannot = cannot || !ctx->nk_fused_dist || ctx->nk_binseg == 0 || world < 1 || world > MR_WORLD_MAX || rank < 0 || rank >= world ||
+            cannot = cannot || !ctx->nk_fused_dist || world < 1 || world > MR_WORLD_MAX || rank < 0 || rank >= world ||
                      (int64_t)P->nbuf * P->W < ws->c_cap;
             if (!cannot && nk_mr_alloc(P, nb, world, sizeof(T)) != XDEMHIP_OK) cannot = true;
             uint64_t v[2] = {(uint64_t)n, (uint64_t)(cannot ? 1 : 0)};
@@ -3074,8 +2987,6 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     uint64_t* cls_y = fz + 24 + 3 * nbm;
     uint64_t* res_y = fz + 24 + 6 * nbm;
     uint64_t* cnt_y = fz + 24 + 8 * nbm;
-    const bool r5 = ctx->nk_binseg != 0;   // round 5's forms of the small steps (option "nk_binseg" = 0: round 4's, kept for A/B and tests)
-    if (!r5) XD_HIP_CHECK(ctx, hipMemsetAsync(fz, 0, P->fz_bytes, ctx->stream));
     const bool custom = !P->custom_edges.empty();
     const int last_decimal = custom ? P->custom_decimal : NK_AUTO_EDGES;
     if (custom) {  // explicit bin edges: SciPy casts them to the sample dtype (rare path: a blocking copy)
@@ -3088,12 +2999,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const T* tba = static_cast<const T*>(P->tba);
     const T* st_all = static_cast<const T*>(P->slope_tan);
     // 1. min / max aspect of this step from the EXT lists -> edges, freshness of the bin cache; (re)fill of the cache
-    if (r5) {
-        hipLaunchKernelGGL(nk_step_init_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_stats, fz, (int64_t)(P->fz_bytes / 8), P->ext_cnt + 2);
-    } else {
-        hipLaunchKernelGGL(nk_stats_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d_stats);
-        XD_HIP_CHECK(ctx, hipMemsetAsync(P->ext_cnt + 2, 0, 16, ctx->stream));
-    }
+    hipLaunchKernelGGL(nk_step_init_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_stats, fz, (int64_t)(P->fz_bytes / 8), P->ext_cnt + 2);
     hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, ref_m, tba, static_cast<const T*>(P->aspect), g,
                        P->ext_idx, P->ext_cnt, d_stats, P->ext_cnt + 2);
     int rc = XDEMHIP_OK;
@@ -3130,7 +3036,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const double pr_expect = pr_scaled ? fmax(0.02, P->pr_err * (dpx / P->pr_dpx)) : 1e30;      // bin medians
     const double pr_expect_d = pr_scaled ? fmax(0.02, P->pr_err_d * (dpx / P->pr_dpx)) : 1e30;  // median of dh (assumed not to move)
     bool predict = allow_predict && ctx->nk_predict != 0 && P->pr_have && P->pr_nb == nb && nb <= NK_PREDICT_MAX_BINS && P->pr_cooldown == 0 &&
-                   pr_expect <= 0.20 && pr_expect_d <= 0.20 && dpx <= 0.05 && P->pr_wd > 0 && r5;
+                   pr_expect <= 0.20 && pr_expect_d <= 0.20 && dpx <= 0.05 && P->pr_wd > 0;
     if (P->pr_cooldown > 0 && allow_predict) --P->pr_cooldown;
     double pr_h = 1.0;   // bracket half widths of this step in sampled half widths
     T* s_v = static_cast<T*>(ws->s_vals);
@@ -3166,12 +3072,12 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     // 2. sample of dh -> bracket of its median, v^, delta
     // (round 5: the sample kernels also reset the selection that runs on their sample -- select_reset_slice)
     hipLaunchKernelGGL((nk_sample_dh_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
-                       1.0 / (double)P->W, n_slots, s_v, r5 ? select_reset_plan<K>(scratch, 1, SEL_BRACKET_DUAL) : SelReset());
+                       1.0 / (double)P->W, n_slots, s_v, select_reset_plan<K>(scratch, 1, SEL_BRACKET_DUAL));
     XD_HIP_CHECK(ctx, hipGetLastError());
     // (round 5: the passes advance their own states and the last one writes the bracket ends -- hist_pass_kernel<T, true>; `fused`
     //  tells whether that form ran)
     rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
-                           false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, r5, mr ? 0 : -1, mr ? 4 * (int64_t)world : 0);
+                           false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, true, mr ? 0 : -1, mr ? 4 * (int64_t)world : 0);
     if (rc) return rc;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
     if (mr) {
@@ -3180,17 +3086,11 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         if (rc) return rc;
     }
     // 3. sample of y^ per aspect bin -> brackets of the bin medians (round 5: v^ and delta formed by the sample kernel itself)
-    if (r5) {
-        hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
-                           P->bcache + q0, n, n_slots, d_vhat, klo_d, khi_d, d_vhat, d_delta, ctr, select_reset_plan<K>(scratch, nb, SEL_BRACKET_DUAL));
-    } else {
-        hipLaunchKernelGGL((nk_vhat_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_st, klo_d, khi_d, d_vhat, d_delta, ctr);
-        hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
-                           P->bcache + q0, n, n_slots, d_vhat);
-    }
+    hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
+                       P->bcache + q0, n, n_slots, d_vhat, klo_d, khi_d, d_vhat, d_delta, ctr, select_reset_plan<K>(scratch, nb, SEL_BRACKET_DUAL));
     XD_HIP_CHECK(ctx, hipGetLastError());
     rc = select_enqueue<T>(ctx, s_v, nb == 1 ? nullptr : ws->s_bins, n_slots, n_slots, nullptr, nb, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES,
-                           false, nullptr, nullptr, false, narrow, klo_y, khi_y, rbs_y, low_mask, &fused, r5);
+                           false, nullptr, nullptr, false, narrow, klo_y, khi_y, rbs_y, low_mask, &fused, true);
     if (rc) return rc;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, 0, low_mask, klo_y, khi_y, rbs_y);
     XD_HIP_CHECK(ctx, hipGetLastError());
@@ -3241,7 +3141,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         XD_HIP_CHECK(ctx, hipGetLastError());
     }
     // 5. exact median of dh among its candidates -> vshift
-    if (ctx->nk_binseg != 0) {   // round 5: value buckets of the bracket, three launches (nk_dhsel_* above)
+    {   // value buckets of the bracket, three launches (nk_dhsel_* above)
         uint32_t* dsel = reinterpret_cast<uint32_t*>(fz + 24 + (11 + BINSEG_CTR_STRIDE) * nbm);
         K* dsel_keys = reinterpret_cast<K*>(reinterpret_cast<unsigned char*>(fz) + P->fz_bytes);
         const int grid = dsel_grid;
@@ -3274,18 +3174,9 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
                            ctr, scratch + OFF_INFO);
         }
         XD_HIP_CHECK(ctx, hipGetLastError());
-    } else {
-    hipLaunchKernelGGL(bracket_given_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt_d, 1, given_d, ctr);
-    XD_HIP_CHECK(ctx, hipGetLastError());
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(P->cd_vals), nullptr, P->cd_cap, n / 32 + 1, ctr + 1, 1, scratch, SEL_GIVEN, given_d, 0, true,
-                           klo_d, rbs_d);
-    if (rc) return rc;
-    hipLaunchKernelGGL((nk_fz_vshift_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, cnt_d, d_st, reinterpret_cast<const uint64_t*>(scratch + off_succ(1)),
-                       klo_d, rbs_d, ctr, scratch + OFF_INFO);
     }
     // 6. the bin candidates with the exact vshift -> counts, exact medians among those inside the brackets
-    const bool binseg = ctx->nk_binseg != 0 && (int64_t)P->nbuf * P->W >= ws->c_cap;
-    if (binseg) {
+    {
         // round 5: kept values into per-bin segments (in the y raster, which this route does not use), one workgroup per bin selects
         unsigned long long* seg_ctr = reinterpret_cast<unsigned long long*>(fz + 24 + 11 * nbm);   // [nb] x BINSEG_CTR_STRIDE words
         const size_t lds = (size_t)nb * (3 * 8 + 2 * sizeof(K) + 3 * 4) + 16;
@@ -3322,22 +3213,6 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
                            cnt_y, ctr);
         }
         XD_HIP_CHECK(ctx, hipGetLastError());
-    } else {
-    {
-        uint64_t* d_hist = select_reset<K>(ctx, scratch, nb);   // (after the selection of step 5 has been read by the vshift kernel)
-        const size_t lds = (size_t)nb * 2 * sizeof(K) + (size_t)nb * 2 * 4 + (size_t)nb * SEL_RADIX * 4;
-        rc = set_big_lds(ctx, nk_resolve_kernel<T>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((nk_resolve_kernel<T>), dim3(grid_for(ctx, n / 16 + 1, HIST_THREADS, 2)), dim3(HIST_THREADS), lds, ctx->stream,
-                           static_cast<T*>(ws->c_vals), static_cast<const T*>(P->c_st), ws->c_bins, ws->c_cap, ctr + 5,
-                           reinterpret_cast<const T*>(scratch + OFF_INFO), nb, klo_y, khi_y, rbs_y, res_y, d_hist);
-    }
-    hipLaunchKernelGGL(nk_fz_counts_kernel, dim3(nbb), dim3(64), 0, ctx->stream, cls_y, res_y, nb, cnt_y);
-    hipLaunchKernelGGL(bracket_given_kernel, dim3(nbb), dim3(64), 0, ctx->stream, cnt_y, nb, given_y, ctr);
-    XD_HIP_CHECK(ctx, hipGetLastError());
-    rc = select_enqueue<T>(ctx, static_cast<const T*>(ws->c_vals), ws->c_bins, ws->c_cap, n / 16 + 1, ctr + 5, nb, scratch, SEL_GIVEN, given_y, 0, true,
-                           klo_y, rbs_y, /*first_hist_done=*/true);
-    if (rc) return rc;
     }
     // 7. everything the step hands back: packed into one block on the device, one copy, one synchronisation
     std::vector<uint64_t> cnt(3 * (size_t)nb);
@@ -3373,7 +3248,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         if (off > P->fz_pack_bytes) return xd_fail(ctx, XDEMHIP_EINVAL, "one-pass step: result block too small");
         P->fz_host.resize(off);
         // (round 5: the block is written straight into the pinned staging buffer where there is room -- no copy behind the kernel)
-        unsigned char* pin = r5 ? xd_pin_claim(ctx, P->fz_host.data(), off) : nullptr;
+        unsigned char* pin = xd_pin_claim(ctx, P->fz_host.data(), off);
         pk.dst = pin ? pin : P->fz_pack;
         hipLaunchKernelGGL(nk_fz_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, pk);
         XD_HIP_CHECK(ctx, hipGetLastError());

@@ -73,6 +73,11 @@ __device__ __forceinline__ void bracket_finish_body(const int lane, const SelSta
 // device-scope fence -- advances the selection states itself (select_advance_body, one wave per state) and, after the last digit
 // of a bracket selection, writes the bracket ends (bracket_finish_body): the Nuth-Kaab step's two sample selections go from
 // 3 x (pass + advance) + finish = 7 dependent launches to 3.  Dual bracket selections without a reduction hook only.
+// LEGAL ONLY FOR BRACKETS THAT A COUNTING PASS VERIFIES: the hand-over to the last workgroup goes through relaxed device-scope atomics,
+// counted waits and a workgroup-scope fence -- no agent-scope release / acquire pair (a device-scope fence writes back and invalidates the
+// XCD's whole L2: 38-60 us per pass, measured) -- which the HIP memory model does not order formally; the states it produces are SAMPLE
+// brackets whose every rank claim the following exact counting pass checks (a wrong bracket costs a fall-back, never a wrong order
+// statistic).  select_enqueue asserts the use: `fuse` requires the dual bracket mode with caller-supplied bracket outputs.
 template <typename K> struct HistFuse {
     uint32_t* ticket;      // zero before the pass; the last workgroup puts it back
     SelState<K>* st;       // the states (writable view of `st`)
@@ -356,7 +361,7 @@ int select_enqueue(xdemhip_ctx* ctx, const T* vals, const uint16_t* bins, int64_
     // workgroup per CU 3.10: too few)
     const int grid = grid_for(ctx, n_grid, HIST_THREADS * SEL_UNROLL, n_grid < ((int64_t)1 << 24) ? 1 : 2);
     const bool fuse = fuse_klo && fuse_khi && fuse_rbs && dual && !ctx->allreduce && n > 0 && !first_hist_done && !rb_lo && !rb_shift &&
-                      nb <= HIST_THREADS / 64 && ctx->nk_binseg != 0;   // (one state per wave of the last workgroup: with the 144 states of the 72
+                      nb <= HIST_THREADS / 64;                          // (one state per wave of the last workgroup: with the 144 states of the 72
                                                                          //  aspect bins that workgroup took 9 rounds of device-scope loads, 20-40 us
                                                                          //  against the 5 us of a launch of 144 one-wave workgroups -- measured)
     if (fused) *fused = fuse;

@@ -553,6 +553,7 @@ template <typename TOUT> static bool staged_ok(const TerrainLaunch& L, uint32_t 
 template <int FIT, bool CURV, bool WIN, class SP, typename TIN, typename TOUT, bool ALLSHAPES = false>
 static int launch_shaped(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask) {
     constexpr int TH_DIRECT = (sizeof(TIN) == 4) ? 32 : 16;
+#ifdef XD_EXPERIMENT   // (the staged store form measured 5-8 % slower: measurement builds only -- the product does not carry its kernels)
     if constexpr (sizeof(TOUT) == 4) {
         if ((ctx->terrain_store == 1) && staged_ok<TOUT>(L, mask)) {
             if constexpr (ALLSHAPES) {  // measurement builds: option "terrain_rows"
@@ -562,6 +563,7 @@ static int launch_shaped(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
             return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 16, 1>(ctx, L, mask);
         }
     }
+#endif
     if constexpr (ALLSHAPES && sizeof(TIN) == 4) {
         if (ctx->terrain_rows == 16) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 16, 0>(ctx, L, mask);
         if (ctx->terrain_rows == 24) return launch_tiles<FIT, CURV, WIN, SP, TIN, TOUT, 24, 0>(ctx, L, mask);

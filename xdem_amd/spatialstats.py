@@ -53,33 +53,13 @@ def _morton_order(x: np.ndarray, y: np.ndarray) -> np.ndarray | None:
     return np.argsort(spread(qx) | (spread(qy) << np.uint64(1)), kind="stable")
 
 
-def _polar_morton_order(x: np.ndarray, y: np.ndarray, cx: float, cy: float):
-    """Morton order of (log distance from (cx, cy), angle around it): consecutive points are neighbours in the ring they lie in -- for
-    the B points of a centre-disk x rings block the order with the fewest lag-class changes per wave of the orders simulated
-    (profiles/r06_vario_class_change_sim.txt: 0.316 of the wave-pairs against 0.350 in Cartesian Morton order)."""
-    r = np.hypot(x - cx, y - cy)
-    lr = np.log(np.maximum(r, 1e-300))
-    big = np.isfinite(lr) & (r > 0)
-    if not big.any():
-        return None
-    lo = float(lr[big].min())
-    lr = np.where(big, lr, lo)
-    th = np.arctan2(y - cy, x - cx)
-    return _morton_order(lr, th)
-
-
 def _morton_sorted_block(b: tuple) -> tuple:
+    # (round 6: a Morton order of (log distance from the centre sample, angle) for the B points -- the order with the fewest lag-class
+    #  changes per wave in simulation, 0.316 against 0.350 of the wave-pairs -- measured no faster on the GPU: exact Dowd 41.3 -> 41.6 ms on
+    #  C5, Matheron pass 31.1 -> 31.7: profiles/r06_vario_class_change_sim.txt)
     out = list(np.asarray(c) for c in b)
-    polar = len(out) == 6 and os.environ.get("XDEM_VARIO_B_ORDER", "morton") == "polar"
     for k in range(0, len(out), 3):
-        xs, ys = np.asarray(out[k], dtype=np.float64).ravel(), np.asarray(out[k + 1], dtype=np.float64).ravel()
-        if polar and k == 3 and xs.size:
-            ax, ay = np.asarray(out[0], dtype=np.float64).ravel(), np.asarray(out[1], dtype=np.float64).ravel()
-            o = _polar_morton_order(xs, ys, float(ax.mean()), float(ay.mean())) if ax.size else None
-            if o is None:
-                o = _morton_order(xs, ys)
-        else:
-            o = _morton_order(xs, ys)
+        o = _morton_order(np.asarray(out[k], dtype=np.float64).ravel(), np.asarray(out[k + 1], dtype=np.float64).ravel())
         if o is not None:
             out[k], out[k + 1], out[k + 2] = (np.asarray(out[k]).ravel()[o], np.asarray(out[k + 1]).ravel()[o], np.asarray(out[k + 2]).ravel()[o])
     return tuple(out)

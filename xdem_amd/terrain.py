@@ -317,7 +317,7 @@ def alloc_planes(n_attr: int, H: int, W: int, dtype=None, ctx: _lib.Context | No
     channels: 14.4-15.6 ms for the 40000^2 set instead of 12.7-13.3 ms.  ``backing``:
     "auto" (default) = "scattered" for sets of 256 MiB and more (an ordinary allocation if the driver cannot provide the pieces),
     torch's allocator below; "scattered" = one virtual range over
-    8 MiB physical pieces mapped in a fixed pseudo-random order (``xdemhip_device_alloc``, HIP virtual memory management): 13.3 ms
+    32 MiB physical pieces (8 MiB until round 6) mapped in a fixed pseudo-random order (``xdemhip_device_alloc``, HIP virtual memory management): 13.3 ms
     on a box where ordinary and contiguous planes ran at 15.0-15.6 / 14.8 ms in the same process; "torch" = torch's allocator
     (ordinary hipMalloc); "contiguous", "chunked" (64 MiB pieces in order), "recycled" = the other forms, kept for measurements.
     The memory of the library's forms is released when the tensor (and every view of it) is gone.  The scattered pieces are mapped
