@@ -436,10 +436,10 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
     onepass = bool(routes and routes["onepass"] > 0 and routes["twopass"] == 0 and routes["plain"] == 0)
     passes = 1 if onepass else 2
     alg_bpp = 16 if onepass else 8 * passes   # 8 B/pixel/pass recomputing the aux rasters, 16 B/pixel/pass with stored aux arrays
-    touched = 14 if onepass else NK_TOUCHED_BYTES
+    touched = 13 if onepass else NK_TOUCHED_BYTES
     # the roofline fraction is priced at what the kernels can at most be credited with: the SMALLER of SURVEY's algorithmic figure
-    # and the bytes the step really touches (one-pass: 14 < 16 -- pricing it at 16 would credit bytes that never move, and could
-    # exceed the physical peak; two passes: 16 < 22).  The 16 B figure stays next to it, labelled, for comparison across rounds.
+    # and the bytes the step really touches (one-pass: 13 < 16 -- pricing it at 16 would credit bytes that never move, and could
+    # exceed the physical peak; two passes: 16 < 21).  The 16 B figure stays next to it, labelled, for comparison across rounds.
     roof_bpp = min(alg_bpp, touched)
     # validation inside the run: the fit must find the shift the pair was built with
     sx, sy, sz = -offsets[0] / res[0], -offsets[1] / res[1], offsets[2]
@@ -483,14 +483,14 @@ VARIO_LIMITER_NOTE = ("vector-instruction issue in both passes.  Matheron (round
                       "bracket ends (3.7 ms) + ONE counting / compaction pass over all pairs (38 ms) + the selection among the 0.22 % of the pairs "
                       "inside the brackets (1.6 ms); the counting pass reads the Morton-ordered copy and counts run-length as well (round 4, "
                       "profiles/r04_vario_counting_pmc.json: 17.4 vector instructions per wave-pair against 20.8 per pair-wise form, VALU busy 0.82)")
-NK_ONEPASS_NOTE = ("the one pass touches 14 B/pixel: masked reference copy 4 + tba 4 + slope tangent 4 + cached aspect-bin id 2; no dh raster is "
+NK_ONEPASS_NOTE = ("the one pass touches 13 B/pixel: masked reference copy 4 + tba 4 + slope tangent 4 + cached aspect-bin id 1 (2 until round 6); no dh raster is "
                    "written or re-read (22 B/pixel in two passes in round 3); candidates of the medians (a few percent) leave as (dh, slope "
                    "tangent, bin) triples; from the second step of a plan on the sample brackets are half as wide as the rule for fully "
                    "correlated sample lines when the rank offsets measured in the earlier steps allow it (exact either way)")
-NK_TOUCHED_BYTES = 22
-NK_TOUCHED_NOTE = ("the two passes touch 22 B/pixel (dh pass: masked reference copy 4 + tba 4 + dh out 4 -- min / max aspect come from the "
+NK_TOUCHED_BYTES = 21
+NK_TOUCHED_NOTE = ("the two passes touch 21 B/pixel (dh pass: masked reference copy 4 + tba 4 + dh out 4 -- min / max aspect come from the "
                    "plan's lists of extreme-aspect pixels, the inlier mask is folded into the reference copy as NaN; bin pass: dh 4 + "
-                   "slope_tan 4 + cached aspect-bin id 2): the aux rasters are stored, not recomputed; 27 B/pixel in round 2")
+                   "slope_tan 4 + cached aspect-bin id 1): the aux rasters are stored, not recomputed; 27 B/pixel in round 2")
 
 
 def isa_cycles() -> dict:

@@ -131,7 +131,7 @@ int xdemhip_clock_probe(xdemhip_ctx* ctx, void* hip_stream, int sleeps, uint64_t
  *                       the candidates, plain radix passes if a bracket misses or the input is too small per bin; 1 plain 8-bit radix
  *                       passes only (the fall-back, and the check of the other); 2 degenerate brackets (exercises the fall-back); 3
  *                       bracketed even where the per-bin sample is small.
- *   "nk_fused"          1 (default) the Nuth-Kaab step of large plans is ONE data pass (14 B/pixel), 0 the two queued passes (the route a
+ *   "nk_fused"          1 (default) the Nuth-Kaab step of large plans is ONE data pass (13 B/pixel), 0 the two queued passes (the route a
  *                       one-pass step hands over to when a bracket misses or a buffer overflows).
  *   "nk_fused_dist"     1 (default) partitioned plans (reduction hook + xdemhip_set_rank) take the one-pass step too, 0 the two-pass route.
  *   "nk_predict"        1 (default) a settled one-pass step takes its brackets from the previous step's exact medians (see
@@ -269,7 +269,7 @@ int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* plan, const double* edges, int n_e
 int xdemhip_nk_set_statistic(xdemhip_nk_plan* plan, int bin_stat);
 int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uint8_t* valid);
 /* How the steps of this plan were answered so far (any pointer may be NULL): by the ONE-PASS step of round 4 (one data pass of
- * 14 B/pixel: the shifted elevation difference, the counting for its exact median and the aspect-bin counting against sample
+ * 13 B/pixel since round 6 -- the aspect-bin cache is one byte per pixel; 14 before --: the shifted elevation difference, the counting for its exact median and the aspect-bin counting against sample
  * brackets with per-pixel margins; large single-GPU plans, median statistic, context option "nk_fused" = 1, the default), by
  * the two queued passes of rounds 2-3, or by the plain digit passes (small rasters; the fall-back of both).  Results are
  * identical on every route (integer counts, exact selections); nanmean / nanstd of y -- the p0 of the curve fit -- agree to
@@ -284,9 +284,11 @@ int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uin
 int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* twopass, int64_t* plain);
 /* Round 6: how many of the one-pass steps took PREDICTED brackets -- the previous step's exact medians moved by the Nuth-Kaab
  * model for the change of the shift, instead of brackets from a fresh 1/64 sample: no sample kernels and no digit passes over
- * samples on a settled fit (context option "nk_predict", default 1; 0 = every step samples) -- and how many of those missed (such
- * a step is run again with sampled brackets: the integers returned are the same either way). */
-int xdemhip_nk_predict_counts(xdemhip_nk_plan* plan, int64_t* predicted, int64_t* missed);
+ * samples on a settled fit (context option "nk_predict", default 1; 0 = every step samples) --, how many predicted only the bracket
+ * of the median of dh (steps that still move too far for the bins: the dh sample's three digit passes are skipped, the bins'
+ * brackets are sampled), and how many predictions missed (such a step is run again with sampled brackets: the integers returned
+ * are the same either way). */
+int xdemhip_nk_predict_counts(xdemhip_nk_plan* plan, int64_t* predicted, int64_t* predicted_dh_only, int64_t* missed);
 void xdemhip_nk_destroy(xdemhip_nk_plan* plan);
 int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dtype, int64_t n, int n_bins, double* edges,
                           int64_t* counts, double* medians);
@@ -348,7 +350,7 @@ int xdemhip_pairs_medians(xdemhip_pairs* pairs, int64_t* counts, double* medians
  * counts run-length (a lane touches its LDS counters once per run of equal lag class instead of once per pair).  Counts,
  * candidates and medians do not depend on the slot order.  The sampled digit passes keep `pairs`' own order (their
  * statistics assume unsorted tiles).  `sorted` is not owned and must outlive the calls; NULL (or `pairs` itself) unlinks.
- * Context option "vario_runs" = 0 ignores the link. */
+ * (Test switch "vario_runs" = 0 ignores the link: include/xdemhip_test.h.) */
 int xdemhip_pairs_link_sorted(xdemhip_pairs* pairs, xdemhip_pairs* sorted);
 /* Round 5: float64 differences of float32 values (option "vario_diff" = 1 -- SciPy's pdist widens -- on float32 inputs) at the speed
  * of the float32 kernels.  `shadow` is a float32 set of the same blocks and edges as the float64 set `pairs` (whose values are all

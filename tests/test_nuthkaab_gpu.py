@@ -1146,9 +1146,11 @@ def test_onepass_step_on_a_hooked_plan():
                 assert r1["onepass"] - r0["onepass"] == len(steps) and r1["twopass"] == r0["twopass"] and r1["plain"] == r0["plain"], (r0, r1)
                 # ten all-reduces per step with sampled brackets, FIVE with predicted ones (round 6: the last step moves the aligned
                 # pair by 4e-5 px -- its brackets come from the step before it: no sample selections, no histogram exchanges)
-                n_pred = r1["predicted"] - r0["predicted"]
+                # (... and EIGHT where only the bracket of the median of dh is predicted: its three histogram exchanges go, the EXT slots
+                #  get an exchange of their own)
+                n_pred, n_pd = r1["predicted"] - r0["predicted"], r1["predicted_dh_only"] - r0["predicted_dh_only"]
                 assert n_pred >= 1 and r1["predict_missed"] == r0["predict_missed"], (r0, r1)
-                assert h1 == h0 and d1 - d0 == 10 * (len(steps) - n_pred) + 5 * n_pred, (h0, h1, d0, d1, n_pred)
+                assert h1 == h0 and d1 - d0 == 10 * (len(steps) - n_pred - n_pd) + 8 * n_pd + 5 * n_pred, (h0, h1, d0, d1, n_pred, n_pd)
                 off = coreg._iterate(plan, (10.0, 10.0), 0.0, 8, 72, scipy.optimize.curve_fit, True)
                 r2 = plan.route_counts()
                 assert r2["twopass"] == r1["twopass"] and r2["plain"] == r1["plain"] and r2["onepass"] == r1["onepass"] + 8, (r1, r2)
@@ -1212,9 +1214,11 @@ def test_onepass_step_on_a_hooked_plan_float64():
             if mode == "hooked":
                 # ten all-reduces per step with sampled brackets, FIVE with predicted ones (round 6: the last step moves the aligned
                 # pair by 4e-5 px -- its brackets come from the step before it: no sample selections, no histogram exchanges)
-                n_pred = r1["predicted"] - r0["predicted"]
+                # (... and EIGHT where only the bracket of the median of dh is predicted: its three histogram exchanges go, the EXT slots
+                #  get an exchange of their own)
+                n_pred, n_pd = r1["predicted"] - r0["predicted"], r1["predicted_dh_only"] - r0["predicted_dh_only"]
                 assert n_pred >= 1 and r1["predict_missed"] == r0["predict_missed"], (r0, r1)
-                assert h1 == h0 and d1 - d0 == 10 * (len(steps) - n_pred) + 5 * n_pred, (h0, h1, d0, d1, n_pred)
+                assert h1 == h0 and d1 - d0 == 10 * (len(steps) - n_pred - n_pd) + 8 * n_pd + 5 * n_pred, (h0, h1, d0, d1, n_pred, n_pd)
             plan.close()
         for a, b in zip(res["hooked"], res["plain"]):
             assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"]

@@ -187,9 +187,10 @@ class NKPlan:
         """Steps answered so far by the one-pass step, by the two queued passes, by the plain digit passes (``xdemhip_nk_route_counts``)."""
         a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         self.ctx.check(self.ctx._L.xdemhip_nk_route_counts(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        p, m = ctypes.c_int64(), ctypes.c_int64()
-        self.ctx.check(self.ctx._L.xdemhip_nk_predict_counts(self.handle, ctypes.byref(p), ctypes.byref(m)))
-        return {"onepass": int(a.value), "twopass": int(b.value), "plain": int(c.value), "predicted": int(p.value), "predict_missed": int(m.value)}
+        p, d, m = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self.ctx.check(self.ctx._L.xdemhip_nk_predict_counts(self.handle, ctypes.byref(p), ctypes.byref(d), ctypes.byref(m)))
+        return {"onepass": int(a.value), "twopass": int(b.value), "plain": int(c.value), "predicted": int(p.value),
+                "predicted_dh_only": int(d.value), "predict_missed": int(m.value)}
 
     def set_bin_edges(self, edges) -> None:
         """Explicit aspect-bin edges (``bin_sizes={"aspect": edges}`` upstream); ``None`` restores SciPy's automatic edges."""

@@ -767,6 +767,14 @@ __global__ __launch_bounds__(256) void nk_y_kernel(const T* __restrict__ dh, con
 // min and max aspect of the valid pixels, or the caller's explicit edges) hardly ever change between the steps of a fit.  The
 // first pass under a given set of edges stores every pixel's bin id (uint16, 0xFFFF = outside) and later passes read 2 bytes
 // instead of digitizing a 4-byte aspect again; a one-thread kernel compares the edges with the record of what the cache holds.
+// The aspect-bin cache holds ONE BYTE per pixel (round 6; two until then): every route that reads it takes at most MAX_BINS_PER_SWEEP
+// = 128 bins, 0xFF = "no bin" -- the one-pass step touches 13 instead of 14 bytes per pixel, the bin pass of the two-pass route 9
+// instead of 10.  Candidates and samples keep 16-bit bin ids (the selection code is shared with nd_binning).
+typedef uint8_t nk_bin_t;
+constexpr nk_bin_t NK_NOBIN = 0xFF;
+constexpr int NK_BINCACHE_MAX_BINS = 254;
+__host__ __device__ inline uint16_t nk_bin16(nk_bin_t b) { return b == NK_NOBIN ? (uint16_t)0xFFFF : (uint16_t)b; }
+__host__ __device__ inline nk_bin_t nk_bin8(uint16_t b) { return b == (uint16_t)0xFFFF ? NK_NOBIN : (nk_bin_t)b; }
 struct BinCacheRec { double e0, eN; int nb; int fresh; };
 template <typename T> __global__ void nk_bin_cache_check_kernel(const T* edges, int nb, BinCacheRec* rec, int force) {
     if (threadIdx.x == 0) {
@@ -794,7 +802,7 @@ template <typename T> struct NkYSource {
     double inv_width;
     T vshift;
     int last_decimal;  // rounding precision of SciPy's rightmost-edge rule (NK_AUTO_EDGES for the automatic edges)
-    uint16_t* bcache = nullptr;          // per-pixel bin ids (null: no cache)
+    nk_bin_t* bcache = nullptr;          // per-pixel bin ids (null: no cache)
     const BinCacheRec* rec = nullptr;
     int fresh = -1;                      // 1: read the cache, 0: digitize and fill it, -1: digitize only
     struct Raw { T d, st, x; int64_t p; uint16_t b; };
@@ -809,7 +817,7 @@ template <typename T> struct NkYSource {
     }
     __device__ __forceinline__ void fetch(int64_t p, Raw& r) const {
         r.d = dh[p]; r.st = slope_tan[p]; r.p = p;
-        if (fresh == 1) { r.b = bcache[p]; r.x = (T)0; }
+        if (fresh == 1) { r.b = nk_bin16(bcache[p]); r.x = (T)0; }
         else { r.x = aspect[p]; r.b = 0xFFFF; }
     }
     __device__ __forceinline__ void blank(Raw& r) const { r.d = (T)NAN; r.st = (T)1; r.x = (T)0; r.p = -1; r.b = 0xFFFF; }
@@ -828,7 +836,7 @@ template <typename T> struct NkYSource {
         uint16_t bin = r.b;
         if (fresh != 1) {
             if (fresh == 0) {  // filling pass: every pixel, whatever its dh is this step
-                if (r.p >= 0) { bin = digitize(r.x, nb); bcache[r.p] = bin; }
+                if (r.p >= 0) { bin = digitize(r.x, nb); bcache[r.p] = nk_bin8(bin); }
             } else if (r.d == r.d) {
                 bin = digitize(r.x, nb);
             }
@@ -861,7 +869,7 @@ template <typename T> struct NkYSource {
 constexpr int NKB_TILE = 8;
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __restrict__ dh, const T* __restrict__ slope_tan,
-                                                                    const uint16_t* __restrict__ bcache, const BinCacheRec* rec,
+                                                                    const nk_bin_t* __restrict__ bcache, const BinCacheRec* rec,
                                                                     const T* vshift_p, int64_t n, int nb, int copies,
                                                                     const typename KeyT<T>::type* __restrict__ klo,
                                                                     const typename KeyT<T>::type* __restrict__ khi,
@@ -897,7 +905,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __r
             for (int q = 0; q < NKB_TILE; ++q) {
                 const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
                 d[q] = __builtin_nontemporal_load(dh + p); sl[q] = __builtin_nontemporal_load(slope_tan + p);
-                b[q] = __builtin_nontemporal_load(bcache + p);
+                b[q] = nk_bin16(__builtin_nontemporal_load(bcache + p));
             }
         } else {
 #pragma unroll
@@ -905,7 +913,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bins_lean_kernel(const T* __r
                 const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
                 const bool in = p < n;
                 const int64_t pc = in ? p : n - 1;
-                d[q] = dh[pc]; sl[q] = slope_tan[pc]; b[q] = bcache[pc];
+                d[q] = dh[pc]; sl[q] = slope_tan[pc]; b[q] = nk_bin16(bcache[pc]);
                 if (!in) d[q] = (T)NAN;
             }
         }
@@ -1050,7 +1058,7 @@ template <typename T> __device__ __forceinline__ uint16_t fz_digitize(const T* e
 // (re)fill of the aspect-bin cache; leaves at once while the cache is fresh
 template <typename T>
 __global__ __launch_bounds__(256) void nk_bin_fill_kernel(const T* __restrict__ aspect, int64_t n, const T* __restrict__ edges, int nb,
-                                                          int last_decimal, const BinCacheRec* rec, uint16_t* __restrict__ bcache) {
+                                                          int last_decimal, const BinCacheRec* rec, nk_bin_t* __restrict__ bcache) {
     if (rec->fresh == 1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
     T* e = reinterpret_cast<T*>(fz_smem);
@@ -1058,7 +1066,7 @@ __global__ __launch_bounds__(256) void nk_bin_fill_kernel(const T* __restrict__ 
     __syncthreads();
     const double inv_width = (double)nb / ((double)e[nb] - (double)e[0]);
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
-        bcache[p] = fz_digitize<T>(e, inv_width, nb, aspect[p], last_decimal);
+        bcache[p] = nk_bin8(fz_digitize<T>(e, inv_width, nb, aspect[p], last_decimal));
 }
 
 // positional 1/64 line sample of dh at this step's shift: slot i <-> element (i mod 8) of sampled line (i / 8); NaN where the
@@ -1105,7 +1113,7 @@ __device__ __forceinline__ bool nk_vhat_of(uint64_t sample_count, typename KeyT<
 // sample of y^ = (dh - v^) / slope_tan with its aspect bin, in place over the dh sample
 template <typename T>
 __global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, uint16_t* __restrict__ s_b, const T* __restrict__ slope_tan,
-                                                          const uint16_t* __restrict__ bcache, int64_t n, int64_t n_slots, const T* vhat_p,
+                                                          const nk_bin_t* __restrict__ bcache, int64_t n, int64_t n_slots, const T* vhat_p,
                                                           const typename KeyT<T>::type* klo_d = nullptr, const typename KeyT<T>::type* khi_d = nullptr,
                                                           T* vhat_out = nullptr, T* delta_out = nullptr, unsigned long long* ctr = nullptr,
                                                           SelReset reset = SelReset()) {
@@ -1134,7 +1142,7 @@ __global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, u
         T y = (T)NAN;
         uint16_t b = 0xFFFF;
         if (p < n && d == d) {
-            b = bcache[p];
+            b = nk_bin16(bcache[p]);
             y = t_div(t_sub(d, vhat), slope_tan[p]);
             if (b == 0xFFFF || !(y == y)) y = (T)NAN;
         }
@@ -1204,7 +1212,7 @@ template <typename T> struct FzPair { T lo, hi; };
 constexpr int NKZ_CHUNK_MAX = 256;   // rows of a workgroup's chunk (row-tap table in LDS)
 template <typename T, int RULE>   // (RULE 2 = rules 2 / 3 through the bad-bit mask: six more registers -> one workgroup per CU fewer instead of spills)
 __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
-                                                       const uint16_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
+                                                       const nk_bin_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
                                                        int nb, int copies, const typename KeyT<T>::type* __restrict__ klo_p,
                                                        const typename KeyT<T>::type* __restrict__ khi_p, const T* vhat_p, const T* delta_p,
                                                        const typename KeyT<T>::type* __restrict__ klo_y,
@@ -1346,7 +1354,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
     };
     int have = -1;
     double hl = 0.0;
-    struct Pre { T b0, b1, rv, st; uint16_t bin; uint32_t bw; };
+    struct Pre { T b0, b1, rv, st; nk_bin_t bin; uint32_t bw; };
     Pre pre[NKZ_PF];
     // (wave-uniform, and said so: the descriptors below must sit in scalar registers -- a descriptor the compiler takes for
     // lane-varying is read back lane by lane in a loop around every load)
@@ -1362,8 +1370,8 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
     const __amdgpu_buffer_rsrc_t r_st = fz_rsrc(slope_tan + rb0);
     const __amdgpu_buffer_rsrc_t r_bin = fz_rsrc(bcache + rb0);
 #endif
-    const uint32_t wbytes = (uint32_t)g.W * (uint32_t)sizeof(T), wbytes2 = (uint32_t)g.W * 2u;
-    const uint32_t ob = jl * (uint32_t)sizeof(T), ob2 = jl * 2u;
+    const uint32_t wbytes = (uint32_t)g.W * (uint32_t)sizeof(T), wbytes2 = (uint32_t)g.W * (uint32_t)sizeof(nk_bin_t);
+    const uint32_t ob = jl * (uint32_t)sizeof(T), ob2 = jl * (uint32_t)sizeof(nk_bin_t);
     auto tap_row = [&](int k) -> uint32_t { return (uint32_t)((k > k_base ? k : k_base) - k_base) * wbytes; };   // (scalar)
     auto issue = [&](int rr, Pre& q) {  // rows past the chunk repeat its last row
         const int rc = rr < nrow ? rr : nrow - 1;
@@ -1381,7 +1389,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
         const uint32_t so_r = (uint32_t)rc * wbytes;
         q.rv = fz_bufload(r_ref, ob, so_r, T());
         q.st = fz_bufload(r_st, ob, so_r, T());
-        q.bin = fz_bufload16(r_bin, ob2, (uint32_t)rc * wbytes2);
+        q.bin = (nk_bin_t)__builtin_amdgcn_raw_buffer_load_b8(r_bin, (int)ob2, (int)((uint32_t)rc * wbytes2), 2);
 #else
         const char* rowp = reinterpret_cast<const char*>(tba + (int64_t)(tk + ((tf >> 1) & 1)) * g.W);
         q.b0 = __builtin_nontemporal_load(reinterpret_cast<const T*>(rowp + c0b));
@@ -1389,7 +1397,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
         const uint32_t o_b = (uint32_t)rc * wbytes + ob;
         q.rv = __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(ref + rb0) + o_b));
         q.st = __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(slope_tan + rb0) + o_b));
-        q.bin = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(bcache + rb0) + ((uint32_t)rc * wbytes2 + ob2)));
+        q.bin = __builtin_nontemporal_load(reinterpret_cast<const nk_bin_t*>(reinterpret_cast<const char*>(bcache + rb0) + ((uint32_t)rc * wbytes2 + ob2)));
 #endif
     };
     // sums of y^ and of the correction terms: float32 partial sums (y^, y^ y^ folded into float64 every NKZ_PF rows; the three
@@ -1404,7 +1412,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
             const int r = r0 + u;
             if (r < nrow) {   // (uniform)
                 const T b0v = pre[u].b0, b1v = pre[u].b1, rv = pre[u].rv, stv = pre[u].st;
-                const uint16_t bin = pre[u].bin;
+                const nk_bin_t bin = pre[u].bin;
                 const unsigned long long m_clean = RULE != 2 ? ~0ull : __builtin_amdgcn_ballot_w64(((pre[u].bw >> bad_sh) & 1u) == 0);
                 issue(r + NKZ_PF, pre[u]);
                 const int k0l = __builtin_amdgcn_readfirstlane(tab[r].k0l), fl = __builtin_amdgcn_readfirstlane(tab[r].flags);
@@ -1451,7 +1459,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
                 const T rr = fz_rcp(stv);
                 const T yh = (T)(out - vhat) * rr;
                 const T m = (T)(dgrow * rr) + (T)(fabs(yh) * FzEps<T>::rel);   // (m = 0 only for y^ = 0 under an exact v^: then y = 0 too)
-                const unsigned long long m_yb = m_ok & __builtin_amdgcn_ballot_w64(bin != (uint16_t)0xFFFF) & __builtin_amdgcn_ballot_w64(yh == yh);
+                const unsigned long long m_yb = m_ok & __builtin_amdgcn_ballot_w64(bin != NK_NOBIN) & __builtin_amdgcn_ballot_w64(yh == yh);
                 const uint32_t binx = sel_mask(0u, (uint32_t)bin, m_yb);
                 const FzPair<T> lh = lohi[binx];
                 const unsigned long long m_nb = cm_nlt((T)(yh + m), lh.lo), m_na = cm_ngt((T)(yh - m), lh.hi);   // not certainly below / above
@@ -1464,7 +1472,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
                     const int cn = __popcll(my);
                     if (held_y + cn <= SEG) {   // (uniform)
                         const int pos = sel_mask(trash, held_y + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(my >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)my, 0u)), my);
-                        seg_yd[pos] = out; seg_ys[pos] = stv; seg_yb[pos] = bin;
+                        seg_yd[pos] = out; seg_ys[pos] = stv; seg_yb[pos] = (uint16_t)bin;
                         held_y += cn;
                     } else if (lane == 0) {
                         ctr[2] = 1ull;
@@ -2527,7 +2535,7 @@ struct xdemhip_nk_plan {
     void *slope_tan = nullptr, *aspect = nullptr, *dh = nullptr, *y = nullptr;
     uint8_t* valid = nullptr;
     uint16_t* bins = nullptr;
-    uint16_t* bcache = nullptr;   // aspect-bin cache (NkYSource), one id per buffer pixel
+    nk_bin_t* bcache = nullptr;   // aspect-bin cache (NkYSource), one BYTE per buffer pixel
     bool bcache_force = true;     // the cache does not hold the bins of the current own rows / edges: refill at the next step
     void* ref_m = nullptr;        // reference DEM with NaN where a pixel is not valid (EXT route of the dh pass)
     int64_t* ext_idx = nullptr;   // [2][EXT_CAP] pixels with the lowest / highest aspects
@@ -2562,7 +2570,7 @@ struct xdemhip_nk_plan {
     double pr_err = 1e30, pr_err_d = 1e30;   // how far the prediction of the LAST step would have been off (or was), in sampled half widths: bins / median of dh
     double pr_dpx = 1e30;             // the shift change of the last step, pixels
     int pr_cooldown = 0;              // sampled steps still to run after a predicted bracket missed
-    int64_t n_predicted = 0, n_predict_miss = 0;
+    int64_t n_predicted = 0, n_predicted_d = 0, n_predict_miss = 0;   // steps with every bracket predicted / with the bracket of the median of dh predicted / reruns after a miss
     // one-pass step on PARTITIONED plans (reduction hook + xdemhip_set_rank): the two exchange buffers, this rank's own classes and the
     // counters rewritten for the gathered bucket values (nk_mr_* kernels); the ranks' agreement on the route, renewed when what it rests
     // on changes
@@ -2998,6 +3006,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const T* ref_m = static_cast<const T*>(P->ref_m);
     const T* tba = static_cast<const T*>(P->tba);
     const T* st_all = static_cast<const T*>(P->slope_tan);
+    static_assert(MAX_BINS_PER_SWEEP <= NK_BINCACHE_MAX_BINS, "the one-pass step's bins fit the byte-wide cache");
     // 1. min / max aspect of this step from the EXT lists -> edges, freshness of the bin cache; (re)fill of the cache
     hipLaunchKernelGGL(nk_step_init_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_stats, fz, (int64_t)(P->fz_bytes / 8), P->ext_cnt + 2);
     hipLaunchKernelGGL((nk_ext_eval_kernel<T>), dim3(EXT_CAP / 256, 2), dim3(256), 0, ctx->stream, ref_m, tba, static_cast<const T*>(P->aspect), g,
@@ -3037,6 +3046,11 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     const double pr_expect_d = pr_scaled ? fmax(0.02, P->pr_err_d * (dpx / P->pr_dpx)) : 1e30;  // median of dh (assumed not to move)
     bool predict = allow_predict && ctx->nk_predict != 0 && P->pr_have && P->pr_nb == nb && nb <= NK_PREDICT_MAX_BINS && P->pr_cooldown == 0 &&
                    pr_expect <= 0.20 && pr_expect_d <= 0.20 && dpx <= 0.05 && P->pr_wd > 0;
+    // ... and on steps that still move too far for the bins, the bracket of the MEDIAN OF DH alone may be predicted: that median
+    // hardly follows the shift (0.19 / 0.29 sampled half widths off at 0.1 / 0.5 px on C3), and without its three digit passes the y^
+    // sample can be taken straight away (the bins' brackets are sampled as ever)
+    const bool predict_d = !predict && allow_predict && ctx->nk_predict != 0 && P->pr_have && P->pr_nb == nb && P->pr_cooldown == 0 &&
+                           pr_expect_d <= 0.35 && dpx <= 0.6 && P->pr_wd > 0;
     if (P->pr_cooldown > 0 && allow_predict) --P->pr_cooldown;
     double pr_h = 1.0;   // bracket half widths of this step in sampled half widths
     T* s_v = static_cast<T*>(ws->s_vals);
@@ -3074,12 +3088,26 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     hipLaunchKernelGGL((nk_sample_dh_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
                        1.0 / (double)P->W, n_slots, s_v, select_reset_plan<K>(scratch, 1, SEL_BRACKET_DUAL));
     XD_HIP_CHECK(ctx, hipGetLastError());
+    if (predict_d) {
+        // the dh sample is still taken (the y^ sample is formed from it), its selection is not: bracket from the previous median
+        NkPredicted<T> pr;
+        const double hd = fmin(1.0, fmax(0.25, 2.0 * pr_expect_d + 0.15)) * P->pr_wd;
+        pr.dlo = (T)(P->pr_v - hd);
+        pr.dhi = (T)(P->pr_v + hd);
+        if (mr) {
+            rc = xd_allreduce_device(ctx, ext_slots, 4 * (int64_t)world, XDEMHIP_RED_SUM_U64);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL((nk_predict_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, pr, 0, klo_d, khi_d, rbs_d, d_vhat, d_delta, klo_y, khi_y, rbs_y, ctr);
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    } else {
     // (round 5: the passes advance their own states and the last one writes the bracket ends -- hist_pass_kernel<T, true>; `fused`
     //  tells whether that form ran)
     rc = select_enqueue<T>(ctx, s_v, nullptr, n_slots, n_slots, nullptr, 1, scratch, SEL_BRACKET_DUAL, nullptr, BR_PASSES, false, nullptr, nullptr,
                            false, narrow, klo_d, khi_d, rbs_d, low_mask, &fused, true, mr ? 0 : -1, mr ? 4 * (int64_t)world : 0);
     if (rc) return rc;
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, 1, 0, low_mask, klo_d, khi_d, rbs_d);
+    }
     if (mr) {
         hipLaunchKernelGGL(nk_mr_ext_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, ext_slots, world, d_stats, P->ext_cnt + 2);
         rc = edges_and_bins();
@@ -3261,7 +3289,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if ((h_ctr[2] != 0 || h_ctr[3] != 0) && getenv("XDEMHIP_DEBUG"))
         fprintf(stderr, "[xdemhip] one-pass step falls through: overflow flag %llu, miss flag %llu, dh candidates %llu, bin candidates %llu\n", h_ctr[2], h_ctr[3],
                 h_ctr[1], h_ctr[5]);
-    if ((h_ctr[2] != 0 || h_ctr[3] != 0) && predict) {
+    if ((h_ctr[2] != 0 || h_ctr[3] != 0) && (predict || predict_d)) {
         // a PREDICTED bracket missed (or overflowed): this step once more with sampled brackets, and the next one sampled too; the
         // prediction has to earn its way back through a measured error
         ++P->n_predict_miss;
@@ -3292,7 +3320,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             P->fz_off2 += o * o;
             P->fz_offn += 1;
         };
-        take(h_ctr[10], h_ctr[11], h_ctr[12]);
+        if (!predict_d) take(h_ctr[10], h_ctr[11], h_ctr[12]);   // (a predicted bracket says nothing about the centring of sample brackets)
         for (int b = 0; b < nb; ++b) {
             if (mr) take(cnt_t[b], cnt_t[nb + b], cnt_t[2 * nb + b]);
             else take(cnt[b], cnt[nb + b], cnt[2 * nb + b]);
@@ -3359,7 +3387,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             P->pr_dpx = fmax(dpx, 1e-5);   // (a repeated step measures the jitter floor: the ratio rule then stays conservative)
             if (getenv("XDEMHIP_DEBUG"))
                 fprintf(stderr, "[xdemhip] one-pass step (%s, half widths x %.2f): shift change %.2e px, centres off by %.3f (bins) / %.3f (dh) sampled half widths\n",
-                        predict ? "PREDICTED brackets" : "sampled brackets", pr_h, dpx, P->pr_err, P->pr_err_d);
+                        predict ? "PREDICTED brackets" : (predict_d ? "sampled brackets, PREDICTED bracket of the median of dh" : "sampled brackets"), pr_h, dpx, P->pr_err, P->pr_err_d);
         } else {
             P->pr_err = P->pr_err_d = 1e30;
             P->pr_dpx = 1e30;
@@ -3368,7 +3396,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             P->pr_w.assign(nb, 0.0);
             for (int b = 0; b < nb; ++b)
                 if (counts[b] > 0 && khi[b] >= klo[b]) P->pr_w[b] = 0.5 * ((double)val_of(khi[b]) - (double)val_of(klo[b]));
-            P->pr_wd = h_kd[1] >= h_kd[0] ? 0.5 * ((double)val_of(h_kd[1]) - (double)val_of(h_kd[0])) : 0.0;
+            if (!predict_d) P->pr_wd = h_kd[1] >= h_kd[0] ? 0.5 * ((double)val_of(h_kd[1]) - (double)val_of(h_kd[0])) : 0.0;
         }
         P->pr_med.assign(medians, medians + nb);
         P->pr_mid = mid;
@@ -3381,6 +3409,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         P->pr_nb = nb;
         P->pr_have = true;
         if (predict) ++P->n_predicted;
+        if (predict_d) ++P->n_predicted_d;
     }
     *done = true;
     return XDEMHIP_OK;
@@ -3442,7 +3471,7 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
         NkYSource<T> src{dh, st, asp, d_vshift, d_edges, d_sums, nullptr, 0.0, (T)0,
                          P->custom_edges.empty() ? NK_AUTO_EDGES : P->custom_decimal};
         BinCacheRec* d_rec = reinterpret_cast<BinCacheRec*>(base + OFF_INFO + 64);
-        if (!fit_sums && P->bcache) {
+        if (!fit_sums && P->bcache && nb <= NK_BINCACHE_MAX_BINS) {   // (one byte per cached bin id)
             src.bcache = P->bcache + q0;
             src.rec = d_rec;
             hipLaunchKernelGGL((nk_bin_cache_check_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, d_edges, nb, d_rec, (int)P->bcache_force);
@@ -3615,7 +3644,7 @@ int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uin
     if (hipMalloc(&P->slope_tan, n * es) != hipSuccess || hipMalloc(&P->aspect, n * es) != hipSuccess ||
         hipMalloc(&P->dh, n * es) != hipSuccess || hipMalloc(&P->y, n * es) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&P->valid), n) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&P->bins), n * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->bcache), n * 2) != hipSuccess || hipMalloc(&P->scratch, P->scratch_bytes) != hipSuccess)
+        hipMalloc(reinterpret_cast<void**>(&P->bins), n * 2) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P->bcache), n * sizeof(nk_bin_t)) != hipSuccess || hipMalloc(&P->scratch, P->scratch_bytes) != hipSuccess)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
     if ((int64_t)n >= SEL_BRACKET_MIN_N && sel_ws_create(ctx, (int64_t)n, es, MAX_BINS_PER_SWEEP, P->ws) != XDEMHIP_OK)
         return fail(XDEMHIP_ENOMEM, "hipMalloc failed");
@@ -3730,9 +3759,10 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, 
     return XDEMHIP_OK;
 }
 
-int xdemhip_nk_predict_counts(xdemhip_nk_plan* P, int64_t* predicted, int64_t* missed) {
+int xdemhip_nk_predict_counts(xdemhip_nk_plan* P, int64_t* predicted, int64_t* predicted_dh_only, int64_t* missed) {
     if (!P) return XDEMHIP_EINVAL;
     if (predicted) *predicted = P->n_predicted;
+    if (predicted_dh_only) *predicted_dh_only = P->n_predicted_d;
     if (missed) *missed = P->n_predict_miss;
     return XDEMHIP_OK;
 }
