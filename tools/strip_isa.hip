@@ -15,4 +15,4 @@
 #define XD_MASK 4087u
 #endif
 template __global__ void xd::terrain_strip_kernel<XD_FIT, ((XD_MASK) & xd::A_ANY_CURV) != 0, ((XD_MASK) & xd::A_ANY_WIN) != 0,
-                                                  xd::Spec<(XD_MASK), XD_DIR, 1, 0, 1, 2>, 128, XD_MINW>(const xd::StripArgs);
+                                                  xd::Spec<(XD_MASK), XD_DIR, 1, 0, 1, 2>, 128, XD_MINW, XD_RING_BLOCK(__builtin_popcount(XD_MASK))>(const xd::StripArgs);

@@ -216,68 +216,97 @@ struct StripArgs {
     Planes<float> out;
 };
 
-constexpr int RING_ROWS = 32, RING_PITCH = 72, RING_BLOCK = 16;
-constexpr int RING_QUADS = RING_BLOCK * RING_PITCH / 4;   // 288 float4 per block = 4.5 wave instructions
+constexpr int RING_ROWS = 32, RING_PITCH = 72;
+#ifndef XD_RING_BLOCK   // (measurement builds: -DXD_RING_BLOCK(n)=8 or 16 for every set)
+#define XD_RING_BLOCK(nplanes) ((nplanes) <= 5 ? 8 : 16)
+#endif
 
 typedef const __attribute__((address_space(3))) float* lds_cfloat_ptr;   // 32-bit LDS address (a generic pointer costs 64-bit adds)
-template <int NPL> struct RowsRing {
+// The ring holds RING_ROWS tile rows in RING_ROWS / BLK blocks of BLK rows; a block is refilled as soon as no path reads its rows
+// any more (the oldest row a step r reads is r - 4: the Florinsky window, the cold path's reference-order sums, the TPI / TRI
+// re-read) with the rows RING_ROWS further down.  BLK = 16 (rounds 3-5: two halves) issues a refill 11 rows ahead of its first
+// use; BLK = 8 (round 6: four quarters) 19 rows ahead -- the 1-3-plane sets march a row in ~300 issue cycles, 11 rows are 1.7 us
+// at 1.9 GHz and their loads were NOT back in time (measurement build without refills: slope alone 3.58 -> 3.11 ms, the issue
+// bound; profiles/r06_small_sets_bound.txt); the eleven-plane sets take ~800 cycles per row and never waited.
+template <int NPL, int BLK> struct RowsRing {
+    static constexpr int NBLK = RING_ROWS / BLK;
+    static constexpr int QUADS = BLK * RING_PITCH / 4;     // float4 per block: 288 (4.5 wave instructions) / 144 (2.25)
+    static constexpr int LOADS = (QUADS + 63) / 64;        // wave instructions per block
     lds_cfloat_ptr mine;    // LDS: this lane's column in ring row 0
     const float* gsrc;      // global: first pixel (column x0 - 4) of tile row 0
     float* ring;            // LDS: this wave's ring
     int64_t stride;
-    int nrows, lane;        // nrows: bit 30 = option "terrain_ring_wait" (drain every VMEM operation instead of counting: the check of the
+    int nrows, lane;        // nrows: bit 30 = test switch "terrain_ring_wait" (drain every VMEM operation instead of counting: the check of the
                             // counted form) -- packed into a value that is live anyway: the headline kernel has no scalar register to spare
                             // (a spilled plane pointer would come back through v_readlane, which the inline-asm stores must not follow)
     static constexpr int SAFE_BIT = 1 << 30;
     __device__ __forceinline__ int n_rows() const { return nrows & (SAFE_BIT - 1); }
     __device__ __forceinline__ lds_cfloat_ptr ptr(int t) const { return mine + (t & (RING_ROWS - 1)) * RING_PITCH; }
-    __device__ __forceinline__ void issue(int k) const {   // block k = tile rows [16 k, 16 k + 16) -> ring half k & 1
-        float* dst = ring + (k & 1) * (RING_BLOCK * RING_PITCH);
+    __device__ __forceinline__ void issue(int k) const {   // block k = tile rows [BLK k, BLK k + BLK) -> ring block k mod NBLK
+        float* dst = ring + (k & (NBLK - 1)) * (BLK * RING_PITCH);
         // block base on the scalar unit, per-lane element offsets in 24-bit multiplies (stride < 2^24: launch_stream checks)
-        const float* base = gsrc + (int64_t)(RING_BLOCK * k) * stride;
-        const int last = n_rows() - 1 - RING_BLOCK * k;   // (rows past the band's last: duplicates of it, never read)
+        const float* base = gsrc + (int64_t)(BLK * k) * stride;
+        const int last = n_rows() - 1 - BLK * k;   // (rows past the band's last: duplicates of it, never read)
 #pragma unroll
-        for (int i = 0; i < (RING_QUADS + 63) / 64; ++i) {
+        for (int i = 0; i < LOADS; ++i) {
             const int t = 64 * i + lane;
             int r = t / (RING_PITCH / 4);
             const int q = t - r * (RING_PITCH / 4);
             r = r < last ? r : last;
-            if (t < RING_QUADS)
+            if (t < QUADS)
                 __builtin_amdgcn_global_load_lds(base + (__umul24((uint32_t)r, (uint32_t)stride) + 4u * (uint32_t)q),
                                                  (__attribute__((address_space(3))) void*)(dst + 64 * i * 4), 16, 0, 0);
         }
     }
-    // The counted wait below is only as good as the schedule it counts on.  A block is issued at march step r with
-    // (r mod RING_BLOCK) == REFILL_AT and first read at the step with (r + 1) mod RING_BLOCK == 0, i.e. ROWS_BETWEEN steps later;
-    // every one of those steps emits one output row (r >= RING_BLOCK + REFILL_AT > 2 HALO: past the band's lead-in) and an
-    // output row is NPL unpredicated plane stores -- the cold paths only ADD stores -- so at least ROWS_BETWEEN * NPL VMEM
-    // operations are younger than the block's loads, and gfx9 retires a wave's VMEM operations in order: "at most N
-    // outstanding" with N <= ROWS_BETWEEN * NPL means the loads have landed.  The constants are tied together here so that an
-    // edit of the schedule fails to compile instead of reading stale ring rows; option "terrain_ring_wait" = 1 replaces the
-    // counted wait by vmcnt(0) (GPU test: identical planes).
+    // The counted waits below are only as good as the schedule they count on.  Block b >= NBLK is issued at the march step r with
+    // r mod BLK == REFILL_AT in which block b - NBLK died, and first read at step BLK b - 1 (the prefetch of tile row BLK b):
+    // ROWS_BETWEEN steps later, every one of which emits one output row (r >= BLK + REFILL_AT > 2 HALO: past the band's lead-in) and
+    // an output row is NPL unpredicated plane stores -- the cold paths only ADD stores -- so at least ROWS_BETWEEN * NPL VMEM
+    // operations are younger than the block's loads, and gfx9 retires a wave's VMEM operations in order: "at most N outstanding" with
+    // N <= ROWS_BETWEEN * NPL means the loads have landed.  (Loads of blocks issued in between are younger as well, but not every band
+    // issues them -- its last blocks have no successors --, so they are not counted on.)  The blocks of the kernel's prologue (0 ..
+    // NBLK - 1, all issued: a band holds at least 68 tile rows) are waited for with what is certainly younger than them: the later
+    // prologue blocks' loads and the rows stored since step 4.  The constants are tied together here so that an edit of the schedule
+    // fails to compile instead of reading stale ring rows; test switch "terrain_ring_wait" = 1 replaces every counted wait by
+    // vmcnt(0) (GPU test: identical planes).
     static constexpr int REFILL_AT = 4;                                  // oldest row still read at step r is r - 4 (Florinsky window)
-    static constexpr int ROWS_BETWEEN = RING_BLOCK - 1 - REFILL_AT;      // 11 output rows between a block's issue and its first read
+    static constexpr int ROWS_BETWEEN = BLK * (NBLK - 1) - 1 - REFILL_AT;   // 11 (BLK 16) / 19 (BLK 8) output rows between a block's issue and its first read
     static constexpr int N_WAIT = ROWS_BETWEEN * NPL < 63 ? ROWS_BETWEEN * NPL : 63;
-    static_assert(RING_ROWS == 2 * RING_BLOCK, "two ring halves: the block being marched and the one in flight");
-    static_assert(REFILL_AT >= 4 && REFILL_AT < RING_BLOCK - 1, "a half is refilled only once no path reads its rows any more");
+    static constexpr int n_prologue(int b) { return (LOADS * (NBLK - 1 - b) + NPL * (BLK * b - 1 - REFILL_AT)) < 63 ? (LOADS * (NBLK - 1 - b) + NPL * (BLK * b - 1 - REFILL_AT)) : 63; }
+    static_assert(BLK == 8 || BLK == 16, "two halves or four quarters");
+    static_assert(RING_ROWS % BLK == 0 && NBLK >= 2 && NBLK <= 4, "ring blocks");
+    static_assert(REFILL_AT >= 4 && REFILL_AT < BLK - 1, "a block is refilled only once no path reads its rows any more");
     static_assert(N_WAIT >= 1 && N_WAIT <= ROWS_BETWEEN * NPL, "the counted wait may not exceed the stores issued since the refill");
-    __device__ __forceinline__ void step(int r) const {
-        // about to read tile row r + 1, the first of its block: that block was issued ROWS_BETWEEN output rows ago
-        if (((r + 1) & (RING_BLOCK - 1)) == 0) {
-            if (nrows & SAFE_BIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_WAIT) : "memory");
+    static_assert(BLK - 1 - REFILL_AT >= 1, "prologue block 1 is read after at least one stored row");
+    __device__ __forceinline__ void prologue() const {   // every block of the ring in flight, block 0 landed
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) {
+            if (BLK * k < n_rows()) issue(k);
+            else all = false;
         }
-        // tile rows below 16 (r >> 4) are dead from here on (the oldest row any path still reads is r - 4): refill their half
-        if ((r & (RING_BLOCK - 1)) == REFILL_AT && r >= RING_BLOCK + REFILL_AT) {
-            const int k = (r >> 4) + 1;
-#if !defined(XD_STRIP_NOREFILL)   // (measurement builds: no input traffic after the first two blocks -- what do the refills and their waits cost?)
-            if (RING_BLOCK * k < n_rows()) issue(k);
-#endif
+        if (all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NBLK - 1)) : "memory");   // block 0 landed, the others in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __device__ __forceinline__ void step(int r) const {
+        // about to read tile row r + 1, the first of its block b
+        if (((r + 1) & (BLK - 1)) == 0) {
+            const int b = (r + 1) / BLK;
+            if (nrows & SAFE_BIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (b >= NBLK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_WAIT) : "memory");
+            else if (b == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_prologue(1)) : "memory");
+            else if (b == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_prologue(NBLK > 2 ? 2 : 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_prologue(NBLK > 3 ? 3 : 1)) : "memory");
+        }
+        // the block that held tile rows below BLK (r / BLK) is dead from here on: refill it with the rows RING_ROWS further down
+        if ((r & (BLK - 1)) == REFILL_AT && r >= BLK + REFILL_AT) {
+            const int k = r / BLK - 1 + NBLK;
+            if (BLK * k < n_rows()) issue(k);
         }
     }
 };
 
-template <int FIT, bool CURV, bool WIN, class SP, int BH, int MINW = 1>
+template <int FIT, bool CURV, bool WIN, class SP, int BH, int MINW = 1, int RBLK = 16>
 __global__ __launch_bounds__(256, MINW) void terrain_strip_kernel(const StripArgs a) {
     constexpr int HALO = Halo<FIT>::v;
     constexpr int NPL = __builtin_popcount(SP::CMASK);
@@ -296,20 +325,15 @@ __global__ __launch_bounds__(256, MINW) void terrain_strip_kernel(const StripArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t x0 = a.xi0 + ((int64_t)gx * 4 + wave) * 64, y0 = a.yi0 + (int64_t)band * BH;
     const int n_out = (int)((a.yi1 - y0) < BH ? (a.yi1 - y0) : BH);
-    RowsRing<NPL> rows;
+    typedef RowsRing<NPL, RBLK> ring_t;
+    ring_t rows;
     rows.ring = ring + wave * (RING_ROWS * RING_PITCH);
     rows.mine = (lds_cfloat_ptr)(rows.ring + 4 + lane);
     rows.gsrc = a.dem + (y0 - HALO + a.halo_top) * a.stride + (x0 - 4);
     rows.stride = a.stride;
-    rows.nrows = (n_out + 2 * HALO) | (a.safe_wait ? RowsRing<NPL>::SAFE_BIT : 0);
+    rows.nrows = (n_out + 2 * HALO) | (a.safe_wait ? ring_t::SAFE_BIT : 0);
     rows.lane = lane;
-    rows.issue(0);
-    if (RING_BLOCK < rows.n_rows()) {
-        rows.issue(1);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // block 0 landed, the 5 loads of block 1 in flight
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    rows.prologue();
     const uint64_t org_u = (uint64_t)(y0 * a.W + x0);
     const int64_t org_off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(org_u >> 32)) << 32) |
                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)org_u));
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(256, MINW) void terrain_strip_kernel(const StripArg
 #if defined(XD_STRIP_SYNC)   // (measurement builds: workgroup barrier every XD_STRIP_SYNC output rows -- the four strips of a group then write
     sk.sync_n = XD_STRIP_SYNC;   // the same plane rows at about the same time; legal: the four waves march the same number of rows)
 #endif
-    march_rows<FIT, CURV, WIN, SP, float, DirectSink<float, PTR_COPY>, RowsRing<NPL>>(rows, n_out, a.P, sk);
+    march_rows<FIT, CURV, WIN, SP, float, DirectSink<float, PTR_COPY>, ring_t>(rows, n_out, a.P, sk);
 }
 
 // TPI / TRI / roughness for an arbitrary odd window (the reference default 3 is handled by the fused kernels above).
@@ -624,10 +648,12 @@ static int launch_stream(xdemhip_ctx* ctx, const TerrainLaunch& L, uint32_t mask
     // there since round 6 (forward-accumulated stencil sums + the TPI / TRI window re-read from LDS: 164 -> 127 VGPRs, no scratch:
     // the CPU suite checks the compiled kernels); the register allocator is told so -- left alone it takes 129
     constexpr int MINW = (FIT == 2 && CURV && SP::F64TAIL != 2) ? 1 : 4;   // (the mixed tail of option terrain_math = 0 would spill two registers)
+    // ring blocks: the sets of up to five planes march a row in a few hundred cycles and need their refills further ahead (RowsRing)
+    constexpr int RBLK = XD_RING_BLOCK(__builtin_popcount(SP::CMASK));
     if (dbg_no_strips) {}
-    else if (bh == 128) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 128, MINW>), grid, block, 0, ctx->stream, a);
-    else if (bh == 256) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 256, MINW>), grid, block, 0, ctx->stream, a);
-    else if (bh == 512) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 512, MINW>), grid, block, 0, ctx->stream, a);
+    else if (bh == 128) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 128, MINW, RBLK>), grid, block, 0, ctx->stream, a);
+    else if (bh == 256) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 256, MINW, RBLK>), grid, block, 0, ctx->stream, a);
+    else if (bh == 512) hipLaunchKernelGGL((terrain_strip_kernel<FIT, CURV, WIN, SP, 512, MINW, RBLK>), grid, block, 0, ctx->stream, a);
     else return xd_fail(ctx, XDEMHIP_EINVAL, "terrain_stream: 0, 1, 128, 256 or 512");
     XD_HIP_CHECK(ctx, hipGetLastError());
     const int rc = dbg_no_frame ? XDEMHIP_OK : launch_tiles<FIT, CURV, WIN, SP, float, float, TH, 0>(ctx, L, mask, 0, fr);
