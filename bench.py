@@ -433,7 +433,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
                f"({(red[0] + red[1]) / 10:.1f} all-reduces per iteration: {red[0]} staged through the host, {red[1]} enqueued on the device)")
     # full data passes per iteration: ONE on the one-pass step of round 4 (dh, the counting for its median and the aspect-bin
     # counting against sample brackets in the same pass), two on the queued route of rounds 2-3 (row-partitioned fits)
-    onepass = bool(routes and routes["onepass"] > 0 and routes["twopass"] == 0 and routes["plain"] == 0)
+    onepass = bool(routes and routes["onepass"] > 0 and routes["plain"] == 0)
     passes = 1 if onepass else 2
     alg_bpp = 16 if onepass else 8 * passes   # 8 B/pixel/pass recomputing the aux rasters, 16 B/pixel/pass with stored aux arrays
     touched = 13 if onepass else NK_TOUCHED_BYTES

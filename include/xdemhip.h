@@ -131,9 +131,9 @@ int xdemhip_clock_probe(xdemhip_ctx* ctx, void* hip_stream, int sleeps, uint64_t
  *                       the candidates, plain radix passes if a bracket misses or the input is too small per bin; 1 plain 8-bit radix
  *                       passes only (the fall-back, and the check of the other); 2 degenerate brackets (exercises the fall-back); 3
  *                       bracketed even where the per-bin sample is small.
- *   "nk_fused"          1 (default) the Nuth-Kaab step of large plans is ONE data pass (13 B/pixel), 0 the two queued passes (the route a
- *                       one-pass step hands over to when a bracket misses or a buffer overflows).
- *   "nk_fused_dist"     1 (default) partitioned plans (reduction hook + xdemhip_set_rank) take the one-pass step too, 0 the two-pass route.
+ *   "nk_fused"          1 (default) the Nuth-Kaab step of large plans is ONE data pass (13 B/pixel), 0 the plain route (stored dh and selections
+ *                       over it: what a one-pass step hands over to when a bracket misses or a buffer overflows).
+ *   "nk_fused_dist"     1 (default) partitioned plans (reduction hook + xdemhip_set_rank) take the one-pass step too, 0 the plain route.
  *   "nk_predict"        1 (default) a settled one-pass step takes its brackets from the previous step's exact medians (see
  *                       xdemhip_nk_predict_counts), 0 every step samples.
  *   "pairs_launch_cap"  workgroups per launch of the variogram pair passes (0 = default 2^31 / workgroup size, the most a HIP dispatch
@@ -162,7 +162,7 @@ int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* devi
 /* This process's place among the ranks the hooks reduce over (round 5).  The hooks only combine; a few exchanges of the one-pass
  * Nuth-Kaab step on partitioned plans need every rank's contribution SEPARATELY (per-rank histogram rows, per-rank slices of a small
  * key list): they travel as sum all-reduces in which every rank fills its own slot and adds zeros to the others', for which the
- * library must know `rank` in [0, `world`).  world = 0 (default) = not told: partitioned plans keep the two-pass route.  Ranks
+ * library must know `rank` in [0, `world`).  world = 0 (default) = not told: partitioned plans keep the plain route.  Ranks
  * must be numbered the same way on every process of the group (torch.distributed's group rank does). */
 int xdemhip_set_rank(xdemhip_ctx* ctx, int rank, int world);
 
@@ -268,20 +268,23 @@ int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* plan, const double* edges, int n_e
 #define XDEMHIP_BINSTAT_MEAN 1
 int xdemhip_nk_set_statistic(xdemhip_nk_plan* plan, int bin_stat);
 int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uint8_t* valid);
-/* How the steps of this plan were answered so far (any pointer may be NULL): by the ONE-PASS step of round 4 (one data pass of
- * 13 B/pixel since round 6 -- the aspect-bin cache is one byte per pixel; 14 before --: the shifted elevation difference, the counting for its exact median and the aspect-bin counting against sample
- * brackets with per-pixel margins; large single-GPU plans, median statistic, context option "nk_fused" = 1, the default), by
- * the two queued passes of rounds 2-3, or by the plain digit passes (small rasters; the fall-back of both).  Results are
- * identical on every route (integer counts, exact selections); nanmean / nanstd of y -- the p0 of the curve fit -- agree to
- * 2e-6 of the spread on the one-pass route (float32 partial sums, the accuracy class of the reference's own float32
- * np.nanmean).  Around that one pass: per-bin candidate segments with one workgroup per bin, value-bucket selection of the
- * median of dh, sample passes that advance their own selection states -- 24 launches per step with sampled brackets, 14 with
- * predicted ones (option "nk_predict").
+/* How the steps of this plan were answered so far (either pointer may be NULL).  Two routes since round 6:
+ *   ONE-PASS  one data pass of 13 B/pixel -- the shifted elevation difference, the counting for its exact median and the
+ *             aspect-bin counting against brackets with per-pixel margins (large plans, median statistic, context option
+ *             "nk_fused" = 1, the default); around it per-bin candidate segments with one workgroup per bin, a value-bucket
+ *             selection of the median of dh, sample passes that advance their own selection states: 24 launches per step with
+ *             sampled brackets, 14 with predicted ones (option "nk_predict");
+ *   PLAIN     dh written by a generic kernel that reads mask and aspect, then the selections of select_run.h over the stored
+ *             arrays (bracketed where the size pays, plain digit passes otherwise): small rasters, the mean statistic, the
+ *             un-binned fit, "nk_fused" = 0, and the fall-back of a one-pass step whose brackets missed or overflowed.
+ * (The queued two-pass route of rounds 2-5 is retired: no plan needed it.)  Results are identical on both routes (integer
+ * counts, exact selections); nanmean / nanstd of y -- the p0 of the curve fit -- agree to 2e-6 of the spread on the one-pass
+ * route (float32 partial sums, the accuracy class of the reference's own float32 np.nanmean).
  * PARTITIONED plans (reduction hook installed, xdemhip_set_rank told, context option "nk_fused_dist" = 1, the default) take the
- * one-pass step as well: one data pass over the rank's own rows and TEN all-reduces per step (nuthkaab.hip: "the ONE-PASS step
- * on PARTITIONED plans"), all of them enqueued through the device hook where it is installed; every rank returns the same integers
- * as a single-GPU fit of the whole rasters (the two-pass route of such plans: two data passes, ~25 all-reduces). */
-int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* twopass, int64_t* plain);
+ * one-pass step as well: one data pass over the rank's own rows and ten all-reduces per sampled step, five per predicted one
+ * (nuthkaab.hip: "the ONE-PASS step on PARTITIONED plans"), all of them enqueued through the device hook where it is installed;
+ * every rank returns the same integers as a single-GPU fit of the whole rasters. */
+int xdemhip_nk_route_counts(xdemhip_nk_plan* plan, int64_t* onepass, int64_t* plain);
 /* Round 6: how many of the one-pass steps took PREDICTED brackets -- the previous step's exact medians moved by the Nuth-Kaab
  * model for the change of the shift, instead of brackets from a fresh 1/64 sample: no sample kernels and no digit passes over
  * samples on a settled fit (context option "nk_predict", default 1; 0 = every step samples) --, how many predicted only the bracket

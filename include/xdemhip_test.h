@@ -7,8 +7,6 @@
  *   "terrain_order"      0 (default) one band of strip groups per XCD, 1 natural order, 2 permuted, 3 column-major (measurement forms).
  *   "terrain_ring_wait"  0 (default) counted s_waitcnt for the LDS-DMA ring of the streaming kernels, 1 vmcnt(0): the check of the count.
  *   "terrain_window_lds" 1 (default) LDS-tiled kernel for windowed indexes of window sizes other than 3, 0 the per-pixel kernel.
- *   "nk_ext"             1 (default) min / max aspect of a Nuth-Kaab step from the lists of extreme-aspect pixels + masked reference
- *                        copy, 0 the pass reads mask and aspect of every pixel.
  *   "nk_narrow"          -1 (default) sample brackets of the one-pass step narrowed by the measured rank offsets, 0 / 1 / 2 fixed.
  *   "vario_grid"         1 (default) raster-sampled points run the integer-lattice pair kernels, 0 always the float64-coordinate ones.
  *   "vario_runs"         1 (default) run-length counting pass of the exact-Dowd route on the Morton-ordered copy, 0 per-pair counters.

@@ -500,9 +500,9 @@ def _worker_nk_onepass(rank, world, port, outdir, rule):
         off, n_final = xd.nuth_kaab_row_blocks(to(ref), to(tba), H, (10.0, 10.0), halo=6, ctx=ctx, tolerance=0.0, max_iterations=6, bin_sizes=NB1P, info=info)
         np.savez(os.path.join(outdir, f"nk1p{rank}.npz"),
                  steps=np.array([np.concatenate([[d["vshift"], d["n_valid"], d["y_mean"], d["y_std"]], d["counts"], d["medians"], d["edges"]]) for d in out]),
-                 routes=np.array([c1[k] - c0[k] for k in ("onepass", "twopass", "plain")]), reductions=np.array([h1 - h0, d1 - d0]),
+                 routes=np.array([c1[k] - c0[k] for k in ("onepass", "plain")]), reductions=np.array([h1 - h0, d1 - d0]),
                  predicted=np.array([c1["predicted"] - c0["predicted"], c1["predict_missed"] - c0["predict_missed"], c1["predicted_dh_only"] - c0["predicted_dh_only"]]),
-                 fit=np.array([*off, n_final], dtype=np.float64), fit_routes=np.array([info["routes"][k] for k in ("onepass", "twopass", "plain")]))
+                 fit=np.array([*off, n_final], dtype=np.float64), fit_routes=np.array([info["routes"][k] for k in ("onepass", "plain")]))
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -558,13 +558,13 @@ def test_nuth_kaab_partitioned_one_pass_step(tmp_path, rule):
     assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), f"nk1p{r}.npz"))
-        assert tuple(g["routes"]) == (len(steps), 0, 0), (r, g["routes"])
+        assert tuple(g["routes"]) == (len(steps), 0), (r, g["routes"])
         # (gloo group: every reduction staged through the host hook.)  Ten per step with sampled brackets, five with predicted ones -- round 6:
         # the last step moves the aligned pair by 4e-5 px and takes its brackets from the step before it, on every rank alike
         n_pred, n_miss, n_pd = (int(v) for v in g["predicted"])
         assert n_pred >= 1 and n_miss == 0, (r, g["predicted"])
         assert tuple(g["reductions"]) == (10 * (len(steps) - n_pred - n_pd) + 8 * n_pd + 5 * n_pred, 0), (r, g["reductions"], n_pred, n_pd)
-        assert g["fit_routes"][1] == 0 and g["fit_routes"][2] == 0 and g["fit_routes"][0] == 6, (r, g["fit_routes"])
+        assert g["fit_routes"][1] == 0 and g["fit_routes"][0] == 6, (r, g["fit_routes"])
         for row, d in zip(g["steps"], want):
             exact = np.concatenate([[d["vshift"], d["n_valid"]], d["counts"], d["medians"], d["edges"]])
             assert np.array_equal(np.concatenate([row[:2], row[4:]]), exact, equal_nan=True), r

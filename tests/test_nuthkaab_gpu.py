@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def _moments_close(a, b, onepass=True):
     """nanmean / nanstd of y.  They only seed the 72-point curve fit (p0, xdem/coreg/affine.py:386) and the reference itself
-    forms them in float32 (np.nanmean / np.nanstd of a float32 array: pairwise float32 sums, ~1e-7 of the spread).  The two-pass
-    routes accumulate float64 atomics (last bits depend on the order of the additions); the one-pass step of round 4 (option
+    forms them in float32 (np.nanmean / np.nanstd of a float32 array: pairwise float32 sums, ~1e-7 of the spread).  The plain
+    route accumulates float64 atomics (last bits depend on the order of the additions); the one-pass step of round 4 (option
     "nk_fused") sums y^ = (dh - v^) / slope_tan in float32 pieces with a first-order correction in (v^ - vshift): 2e-6 of
     the spread, the reference's own accuracy class."""
     tol = 2e-6 * abs(b["y_std"]) if onepass else 1e-10 * abs(b["y_std"]) + 1e-11 * abs(b["y_mean"]) + 1e-13
@@ -688,16 +688,17 @@ def test_lean_route_equals_plain_route_at_scale():
     ctx = _lib.Context(0)
     try:
         res = {}
-        # round 4: three implementations -- the one-pass step (default), the two-pass queued route (option "nk_fused" = 0) and plain
-        for name, mode, fused in (("onepass", 0, 1), ("twopass", 0, 0), ("plain", 1, 0)):
+        # three implementations: the one-pass step (default); the plain route (option "nk_fused" = 0: stored dh, generic kernels) with
+        # bracketed selections over the stored arrays; the same with plain digit passes only (option "selection" = 1)
+        for name, mode, fused, route in (("onepass", 0, 1, "onepass"), ("plain, bracketed", 0, 0, "plain"), ("plain", 1, 0, "plain")):
             ctx.set_option("selection", mode)
             ctx.set_option("nk_fused", fused)
             plan = coreg.NKPlan(ref, tba, None, ctx)
             res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
-            assert plan.route_counts()[name] == 4, (name, plan.route_counts())   # every step answered by the route under test
+            assert plan.route_counts()[route] == 4, (name, plan.route_counts())   # every step answered by the route under test
             plan.close()
         # the one-pass step with its sample brackets at a fixed fraction of the rule (option "nk_narrow"; default: adaptive):
-        # full width answers every step itself; a quarter may miss and hand a step to the two-pass route -- exact either way
+        # full width answers every step itself; a quarter may miss and hand a step to the plain route -- exact either way
         ctx.set_option("selection", 0)
         ctx.set_option("nk_fused", 1)
         for k in (0, 1, 2):
@@ -705,16 +706,16 @@ def test_lean_route_equals_plain_route_at_scale():
             plan = coreg.NKPlan(ref, tba, None, ctx)
             res[f"narrow{k}"] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in ((0.0, 0.0), (3.0, -4.0), (13.7, 21.3), (3.0, -4.0))]
             rc = plan.route_counts()
-            assert rc["onepass"] + rc["twopass"] == 4 and rc["plain"] == 0 and (k > 0 or rc["onepass"] == 4), (k, rc)
+            assert rc["onepass"] + rc["plain"] == 4 and (k > 0 or rc["onepass"] == 4), (k, rc)
             print(f"nk_narrow = {k}: routes {rc}")
             plan.close()
         ctx.set_option("nk_narrow", -1)
-        for name in ("onepass", "twopass", "narrow0", "narrow1", "narrow2"):
+        for name in ("onepass", "plain, bracketed", "narrow0", "narrow1", "narrow2"):
             for a, b in zip(res[name], res["plain"]):
                 assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], name
                 assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), name
                 assert np.array_equal(a["edges"], b["edges"]), name
-                assert _moments_close(a, b, onepass=name != "twopass"), (name, a["y_mean"], b["y_mean"], a["y_std"], b["y_std"])
+                assert _moments_close(a, b, onepass=name != "plain, bracketed"), (name, a["y_mean"], b["y_mean"], a["y_std"], b["y_std"])
             assert res[name][1]["n_valid"] == res[name][3]["n_valid"] and np.array_equal(res[name][1]["medians"], res[name][3]["medians"], equal_nan=True)
     finally:
         ctx.close()
@@ -725,8 +726,8 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
     """Rules 2 / 3 of the bilinear taps (the forms with a dilated nodata mask -- rule 3 is what the only hint about geoutils'
     convention favours) on a 9000^2 pair with noise, 20 % contiguous gaps and scattered single-pixel holes,
     36 aspect bins (about as many sampled values per bin as the 12000^2 / 72-bin case above: brackets the one-pass step can use):
-    the one-pass step and the two-pass route (streaming kernels + the plan's bad-bit mask) against the plain route (generic
-    kernels, a 3 x 3 / cross neighbourhood read per pixel): every output of every step identical, fractional and integer
+    the one-pass step (streaming kernel + the plan's bad-bit mask) against the plain route (generic kernel, a 3 x 3 / cross
+    neighbourhood read per pixel; with bracketed selections and with plain digit passes): every output of every step identical, fractional and integer
     shifts, a repeated step; and the default rule gives a DIFFERENT valid count on the same pair (the rules do differ here)."""
     import torch
 
@@ -749,20 +750,16 @@ def test_dilating_nan_rules_all_routes_agree_at_scale(rule):
     try:
         res = {}
         ctx.set_option("nk_nan_rule", rule)
-        # ("twopass, aspect read": option "nk_ext" = 0, the counting kernel that reads mask and aspect itself -- what a plan with a
-        #  reduction hook runs)
-        for name, mode, fused, ext in (("onepass", 0, 1, 1), ("twopass", 0, 0, 1), ("twopass, aspect read", 0, 0, 0), ("plain", 1, 0, 1)):
+        for name, mode, fused in (("onepass", 0, 1), ("plain, bracketed", 0, 0), ("plain", 1, 0)):
             ctx.set_option("selection", mode)
             ctx.set_option("nk_fused", fused)
-            ctx.set_option("nk_ext", ext)
             plan = coreg.NKPlan(ref, tba, None, ctx)
             try:
                 res[name] = [plan.step(sx, sy, (10.0, 10.0), nbin) for (sx, sy) in steps]
                 assert plan.route_counts()[name.split(",")[0]] == len(steps), (name, plan.route_counts())
             finally:
                 plan.close()
-        ctx.set_option("nk_ext", 1)
-        for name in ("onepass", "twopass", "twopass, aspect read"):
+        for name in ("onepass", "plain, bracketed"):
             for a, b in zip(res[name], res["plain"]):
                 assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], (rule, name)
                 assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), (rule, name)
@@ -804,7 +801,7 @@ def test_whole_fit_stays_on_the_one_pass_route():
             off = coreg._iterate(plan, (10.0, 10.0), 0.0, 8, 36, scipy.optimize.curve_fit, True)   # (36 bins: enough sample per bin at this size)
             routes = plan.route_counts()
             plan.close()
-            assert routes["twopass"] == 0 and routes["plain"] == 0 and routes["onepass"] >= 3, (form, routes)
+            assert routes["plain"] == 0 and routes["onepass"] >= 3, (form, routes)
             got[form] = off
         finally:
             ctx.close()
@@ -852,7 +849,7 @@ def test_predicted_brackets_return_the_sampled_steps_integers():
             ctx.close()
     print("routes with / without prediction:", routes[1], routes[0], "whole fit:", fits[1][1], fits[0][1])
     for on in (1, 0):
-        assert routes[on]["onepass"] == len(steps) and routes[on]["twopass"] == 0 and routes[on]["plain"] == 0, routes[on]
+        assert routes[on]["onepass"] == len(steps) and routes[on]["plain"] == 0, routes[on]
     assert routes[0]["predicted"] == 0 and routes[1]["predicted"] >= 3, routes
     assert routes[1]["predict_missed"] <= 1, routes[1]
     for k, (a, b) in enumerate(zip(res[1], res[0])):
@@ -862,7 +859,7 @@ def test_predicted_brackets_return_the_sampled_steps_integers():
         assert _moments_close(a, b, onepass=True), k
     # the whole fit: predicted steps in it, the same end point as the sampled fit to what two runs of one form agree to (see
     # test_whole_fit_stays_on_the_one_pass_route)
-    assert fits[1][1]["predicted"] >= 2 and fits[1][1]["twopass"] == 0 and fits[1][1]["plain"] == 0, fits[1][1]
+    assert fits[1][1]["predicted"] >= 2 and fits[1][1]["plain"] == 0, fits[1][1]
     assert np.allclose(fits[1][0], fits[0][0], rtol=0, atol=1e-4), (fits[1][0], fits[0][0])
 
 
@@ -886,18 +883,18 @@ def test_bench_C3_pair_at_full_size_routes_agree():
     try:
         # (-17, -6): the shift the fit converges to -- the pair ALIGNED: dh = offset + small noise, and a float32 difference of ~1e3 m
         #  elevations is a multiple of their ulp: a dozen distinct values carry all the candidates of the median (ties en masse; the
-        #  value-bucket selection of round 5 first sent exactly these steps to the two-pass route -- bench.py's whole-fit leg found it)
+        #  value-bucket selection of round 5 first sent exactly these steps to the fall-back route -- bench.py's whole-fit leg found it)
         steps = ((0.0, 0.0), (1.7, 0.6), (1.2, 0.9), (1.7, 0.6), (-17.0, -6.0), (-16.9998, -5.9996))
         res = {}
-        for name, mode, fused in (("onepass", 0, 1), ("twopass", 0, 0), ("plain", 1, 0)):
+        for name, mode, fused in (("onepass", 0, 1), ("plain, bracketed", 0, 0), ("plain", 1, 0)):
             ctx.set_option("selection", mode)
             ctx.set_option("nk_fused", fused)
             plan = coreg.NKPlan(ref, tba, None, ctx)
             res[name] = [plan.step(sx, sy, (10.0, 10.0), 72) for (sx, sy) in steps]
-            assert plan.route_counts()[name] == len(steps), (name, plan.route_counts())
+            assert plan.route_counts()[name.split(",")[0]] == len(steps), (name, plan.route_counts())
             plan.close()
         ctx.set_option("selection", 0)
-        for name in ("onepass", "twopass"):
+        for name in ("onepass", "plain, bracketed"):
             for a, b in zip(res[name], res["plain"]):
                 assert a["n_valid"] == b["n_valid"] and a["vshift"] == b["vshift"], name
                 assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["medians"], b["medians"], equal_nan=True), name
@@ -939,7 +936,7 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused, n_bins):
     try:
         ctx.set_option("nk_nan_rule", rule)
         ctx.set_option("selection", 3)
-        ctx.set_option("nk_fused", fused)   # round 4: the one-pass step (1, default) / the two passes of round 3 (0)
+        ctx.set_option("nk_fused", fused)   # the one-pass step (1, default) / the plain route with bracketed selections (0)
         plan = coreg.NKPlan(ref, tba, inlier)
         if dtype == np.float64:
             asp = plan.aux()[1]
@@ -959,7 +956,7 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused, n_bins):
             y64 = y.astype(np.float64)
             assert _moments_close(det, {"y_mean": float(y64.mean()), "y_std": float(y64.std())}, onepass=bool(fused)), (sx, sy)
         rc_ = plan.route_counts()
-        assert rc_["onepass" if fused else "twopass"] == 6 and rc_["plain"] == 0, rc_
+        assert rc_["onepass" if fused else "plain"] == 6 and rc_["plain" if fused else "onepass"] == 0, rc_
         plan.close()
     finally:
         ctx.set_option("nk_nan_rule", decided("nk_nan_rule"))
@@ -967,62 +964,70 @@ def test_lean_kernels_vs_oracle(coreg, dtype, rule, fused, n_bins):
         ctx.set_option("nk_fused", 1)
 
 
-def test_ext_route_equals_aspect_reading_route_and_falls_back(coreg):
-    """Round 3: the dh pass of large single-GPU plans takes min / max aspect from lists of extreme-aspect pixels and reads a
-    masked copy of the reference DEM instead of mask + aspect (option "nk_ext", default on).  (i) Steps of both routes are
-    identical field by field; (ii) when every listed pixel loses its dh -- here: the only rows whose aspects reach the ends of
-    [0, 2 pi) have no tba -- the step notices, repeats on the route that reads the aspect, and stays identical."""
+def test_ext_lists_equal_the_aspect_reading_route_and_fall_back(coreg, capfd, monkeypatch):
+    """The one-pass step takes min / max aspect from the plan's lists of extreme-aspect pixels and reads a masked copy of the
+    reference DEM instead of mask + aspect; the plain route (option "nk_fused" = 0) reads both for every pixel.  (i) Steps of
+    both routes are identical field by field; (ii) when every listed pixel loses its dh -- here: the only rows whose aspects
+    reach the ends of [0, 2 pi) are VALID (tba is finite at every other row of the top half) but lose their dh at every shift
+    (the lower tap row is missing) -- the first step notices (counter [6] of its device block; one "falls through" line under
+    XDEMHIP_DEBUG), the plain route answers it, the plan gives its lists up (no second attempt), and the results stay
+    identical: bin edges from the aspects of the pixels that do keep a dh."""
     from xdem_amd.synth import fbm_numpy
 
     ctx = coreg._lib.default_context()
-    H, W, res = 2200, 2048, 10.0
+    H, W, res, nb = 2200, 2048, 10.0, 8    # (8 bins: the one-pass step wants ~460 k pixels per bin)
     rng = np.random.default_rng(23)
     base = fbm_numpy((H, W), seed=9, std=120.0)
-    # bottom half tilted steeply towards one side: its aspects stay away from 0 / 2 pi, the extremes all come from the top half
+    # bottom half tilted towards one side: its aspects stay within [1.29, 1.87], the extremes all come from the top half
     tilt = np.zeros((H, W), dtype=np.float32)
-    tilt[H // 2:] = (np.arange(W, dtype=np.float32) * 80.0)[None, :]
+    tilt[H // 2:] = (np.arange(W, dtype=np.float32) * 20.0)[None, :]
     ref = (base + tilt).astype(np.float32)
-    tba_full = (np.roll(ref, (1, -1), (0, 1)) + rng.normal(0, 0.2, (H, W)).astype(np.float32) + 0.7).astype(np.float32)
+    tba_full = (np.roll(ref, (1, 0), (0, 1)) + rng.normal(0, 0.2, (H, W)).astype(np.float32) + 0.7).astype(np.float32)
     tba_full[rng.uniform(size=(H, W)) < 0.02] = np.nan
-    tba_bottom = tba_full.copy()
-    tba_bottom[: H // 2 + 8] = np.nan      # no dh in the top half: every listed extreme-aspect pixel dies
+    tba_comb = tba_full.copy()
+    tba_comb[1: H // 2 + 8: 2] = np.nan      # top half: every other row of tba missing -> valid pixels without a dh at any shift
     keys = ("vshift", "n_valid")
-    for name, tba in (("full", tba_full), ("bottom only", tba_bottom)):
-        got = {}
-        # (ext, fused): the one-pass step of round 4 builds on the EXT buffers and, like the EXT dh pass, must notice when no
-        # listed extreme-aspect pixel keeps a dh and hand the step to the route that reads the aspect
-        for ext, fused in ((1, 1), (1, 0), (0, 0)):
-            ctx.set_option("nk_ext", ext)
+    steps = ((0.0, 0.0), (0.0, -12.1), (0.0, -12.1))   # (shifts along the rows: the tilt does not enter dh)
+    monkeypatch.setenv("XDEMHIP_DEBUG", "1")
+    for name, tba in (("full", tba_full), ("comb", tba_comb)):
+        got, routes, fell = {}, {}, {}
+        for fused in (1, 0):
             ctx.set_option("nk_fused", fused)
             try:
+                capfd.readouterr()
                 plan = coreg.NKPlan(ref, tba, None)
-                got[(ext, fused)] = [plan.step(sx, sy, (res, res), 72) for sx, sy in ((0.0, 0.0), (7.3, -12.1), (7.3, -12.1))]
+                got[fused] = [plan.step(sx, sy, (res, res), nb) for sx, sy in steps]
+                routes[fused] = plan.route_counts()
+                valid, asp = plan.aux()[2].astype(bool), plan.aux()[1]
                 plan.close()
+                fell[fused] = capfd.readouterr().err.count("one-pass step falls through")
             finally:
-                ctx.set_option("nk_ext", 1)
                 ctx.set_option("nk_fused", 1)
-        for cfg in ((1, 1), (1, 0)):
-            for a, b in zip(got[cfg], got[(0, 0)]):
-                assert all(a[k] == b[k] for k in keys), (name, cfg)
-                # (the two moments are float64 atomics: their last bits depend on the order of the additions even within one route)
-                assert _moments_close(a, b, onepass=cfg == (1, 1) and name == "full"), (name, cfg)
-                assert np.array_equal(a["edges"], b["edges"]) and np.array_equal(a["counts"], b["counts"]), (name, cfg)
-                assert np.array_equal(a["medians"], b["medians"], equal_nan=True), (name, cfg)
-        got[1], got[0] = got[(1, 0)], got[(0, 0)]
-        if name == "bottom only":
-            asp = coreg.NKPlan(ref, tba, None)
-            a_ = asp.aux()[1]
-            asp.close()
-            # the premise of (ii): the surviving half does not reach the aspect extremes the full raster has
-            assert np.nanmin(a_[H // 2 + 10:]) > np.nanmin(a_[: H // 2]) and np.nanmax(a_[H // 2 + 10:]) < np.nanmax(a_[: H // 2])
-            assert got[1][0]["edges"][0] > float(np.nanmin(a_[: H // 2]))
+        assert routes[0]["plain"] == 3 and routes[0]["onepass"] == 0 and fell[0] == 0, (name, routes, fell)
+        if name == "full":   # (i) the lists answer every step
+            assert routes[1]["onepass"] == 3 and routes[1]["plain"] == 0 and fell[1] == 0, (routes, fell)
+        else:                # (ii) the first step notices, hands over, and the plan does not try its lists again
+            assert routes[1]["onepass"] == 0 and routes[1]["plain"] == 3 and fell[1] == 1, (routes, fell)
+        for a, b in zip(got[1], got[0]):
+            assert all(a[k] == b[k] for k in keys), name
+            # (the two moments are float64 atomics on the plain route: their last bits depend on the order of the additions)
+            assert _moments_close(a, b, onepass=name == "full"), name
+            assert np.array_equal(a["edges"], b["edges"]) and np.array_equal(a["counts"], b["counts"]), name
+            assert np.array_equal(a["medians"], b["medians"], equal_nan=True), name
+        if name == "comb":
+            # the premise of (ii): valid pixels of the top half reach aspect extremes the surviving half does not -- and the edges
+            # are the survivors'
+            top = np.where(valid[: H // 2], asp[: H // 2], np.nan)
+            bot = np.where(valid[H // 2 + 10:], asp[H // 2 + 10:], np.nan)
+            assert np.nanmin(top) < np.nanmin(bot) and np.nanmax(top) > np.nanmax(bot)
+            assert got[1][0]["edges"][0] > float(np.nanmin(top)) and got[1][0]["edges"][-1] < float(np.nanmax(top))
 
 
 def test_device_side_reductions_cost_little():
     """SURVEY 8e / round-2 review: the sharded step used to make ~25 host round trips (D2H + sync + hook + H2D + sync per digit
     pass).  With the device-side hook on a 1-rank RCCL group a 12000^2 step must stay within 25 % of the hook-less step
-    (the reductions are enqueued on the library's stream; what remains on the host are the two route agreements).  Both steps take the
-    two-pass route (option "nk_fused" = 0): the one-pass step of round 4 is a single-GPU route and would answer the hook-less plan."""
+    (the reductions are enqueued on the library's stream; what remains on the host are the route agreements).  Both steps take the
+    plain route (option "nk_fused" = 0), the one with a reduction per key digit."""
     import os
     import time
 
@@ -1070,11 +1075,11 @@ def test_device_side_reductions_cost_little():
             dist.destroy_process_group()
 
 
-def test_onepass_step_hands_degenerate_rasters_to_the_two_pass_route(coreg):
+def test_onepass_step_hands_degenerate_rasters_to_the_plain_route(coreg):
     """Round 4: the one-pass step stages the candidates of the median of dh in small per-wave segments (they are ~0.7 % of the
     pixels on real pairs).  A pair whose dh is ONE value -- tba = ref + constant at shift 0: every pixel lies inside the bracket
-    of the median -- overruns them by design: the step must notice (overflow flag), fall through to the two-pass route and return
-    exactly what the plain route returns (steps 1 and 3; step 2 shifts tba by whole pixels: dh varies, any route may answer)."""
+    of the median -- overruns them by design: the step must notice (overflow flag), fall through to the plain route and return
+    exactly what plain digit passes return (steps 1 and 3; step 2 shifts tba by whole pixels: dh varies, any route may answer)."""
     from xdem_amd.synth import fbm_numpy
 
     ctx = coreg._lib.default_context()
@@ -1092,7 +1097,7 @@ def test_onepass_step_hands_degenerate_rasters_to_the_two_pass_route(coreg):
             rc = plan.route_counts()
             plan.close()
             if name == "onepass":
-                assert rc["onepass"] <= 1 and rc["twopass"] + rc["plain"] >= 2, rc
+                assert rc["onepass"] <= 1 and rc["plain"] >= 2, rc
     finally:
         ctx.set_option("selection", 0)
         ctx.set_option("nk_fused", 1)
@@ -1104,8 +1109,8 @@ def test_onepass_step_hands_degenerate_rasters_to_the_two_pass_route(coreg):
 
 def test_onepass_step_on_a_hooked_plan():
     """Round 5, second half: plans with a reduction hook (the partitioned layout's) take the ONE-PASS step as well -- one data pass over
-    the rank's rows and TEN all-reduces per step, all of them enqueued through the device-side hook -- instead of the two-pass route
-    (two data passes, ~25).  On a 1-rank RCCL group: every integer output identical to the hook-less plan's for fractional steps, the
+    the rank's rows and TEN all-reduces per step, all of them enqueued through the device-side hook -- instead of the plain route
+    (stored dh, a reduction per key digit).  On a 1-rank RCCL group: every integer output identical to the hook-less plan's for fractional steps, the
     aligned pair (ties en masse in dh) included; route and reduction counts asserted; the whole fit stays on the route."""
     import os
     import sys
@@ -1131,8 +1136,8 @@ def test_onepass_step_on_a_hooked_plan():
         ref, tba = bench._c3_pair(dev, 12000)
         steps = ((0.0, 0.0), (1.7, 0.6), (1.2, 0.9), (-17.0, -6.0), (-16.9998, -5.9996))
         res, times = {}, {}
-        for mode in ("plain", "hooked", "hooked_twopass"):
-            ctx.set_option("nk_fused_dist", 0 if mode == "hooked_twopass" else 1)
+        for mode in ("plain", "hooked", "hooked_plain"):   # ("plain" here: the hook-less plan; "hooked_plain": the plain ROUTE under the hook)
+            ctx.set_option("nk_fused_dist", 0 if mode == "hooked_plain" else 1)
             plan = coreg.NKPlan(ref, tba, None, ctx, group=None if mode == "plain" else "world")
             plan.step(0.3, 0.1, (10.0, 10.0), 72)   # (route agreement, buffers, bin cache)
             h0, d0 = ctx.reduction_calls()
@@ -1143,7 +1148,7 @@ def test_onepass_step_on_a_hooked_plan():
             h1, d1 = ctx.reduction_calls()
             r1 = plan.route_counts()
             if mode == "hooked":
-                assert r1["onepass"] - r0["onepass"] == len(steps) and r1["twopass"] == r0["twopass"] and r1["plain"] == r0["plain"], (r0, r1)
+                assert r1["onepass"] - r0["onepass"] == len(steps) and r1["plain"] == r0["plain"], (r0, r1)
                 # ten all-reduces per step with sampled brackets, FIVE with predicted ones (round 6: the last step moves the aligned
                 # pair by 4e-5 px -- its brackets come from the step before it: no sample selections, no histogram exchanges)
                 # (... and EIGHT where only the bracket of the median of dh is predicted: its three histogram exchanges go, the EXT slots
@@ -1153,23 +1158,23 @@ def test_onepass_step_on_a_hooked_plan():
                 assert h1 == h0 and d1 - d0 == 10 * (len(steps) - n_pred - n_pd) + 8 * n_pd + 5 * n_pred, (h0, h1, d0, d1, n_pred, n_pd)
                 off = coreg._iterate(plan, (10.0, 10.0), 0.0, 8, 72, scipy.optimize.curve_fit, True)
                 r2 = plan.route_counts()
-                assert r2["twopass"] == r1["twopass"] and r2["plain"] == r1["plain"] and r2["onepass"] == r1["onepass"] + 8, (r1, r2)
+                assert r2["plain"] == r1["plain"] and r2["onepass"] == r1["onepass"] + 8, (r1, r2)
                 assert abs(off[0] + 17.0) < 0.05 and abs(off[1] + 6.0) < 0.05 and abs(off[2] + 2.0) < 0.01, off
-            elif mode == "hooked_twopass":
-                assert r1["twopass"] - r0["twopass"] == len(steps), (r0, r1)
-                red_twopass = (d1 - d0) / len(steps)
+            elif mode == "hooked_plain":
+                assert r1["plain"] - r0["plain"] == len(steps) and r1["onepass"] == r0["onepass"], (r0, r1)
+                red_plain = (d1 - d0) / len(steps)
             else:
                 assert r1["onepass"] - r0["onepass"] == len(steps), (r0, r1)
             plan.close()
-        for a, b, c in zip(res["hooked"], res["plain"], res["hooked_twopass"]):
+        for a, b, c in zip(res["hooked"], res["plain"], res["hooked_plain"]):
             for o in (b, c):
                 assert a["n_valid"] == o["n_valid"] and a["vshift"] == o["vshift"]
                 assert np.array_equal(a["counts"], o["counts"]) and np.array_equal(a["medians"], o["medians"], equal_nan=True)
                 assert np.array_equal(a["edges"], o["edges"])
             assert _moments_close(a, b, onepass=True)
         print(f"12000^2 step: hook-less {times['plain'] * 1e3:.2f} ms | hooked one-pass (10 reductions) {times['hooked'] * 1e3:.2f} ms | "
-              f"hooked two-pass ({red_twopass:.0f} reductions) {times['hooked_twopass'] * 1e3:.2f} ms")
-        assert times["hooked"] < times["hooked_twopass"]
+              f"hooked plain route ({red_plain:.0f} reductions) {times['hooked_plain'] * 1e3:.2f} ms")
+        assert times["hooked"] < times["hooked_plain"]
     finally:
         ctx.set_allreduce(None)
         ctx.close()
@@ -1210,7 +1215,7 @@ def test_onepass_step_on_a_hooked_plan_float64():
             res[mode] = [plan.step(sx, sy, (10.0, 10.0), 18) for (sx, sy) in steps]
             h1, d1 = ctx.reduction_calls()
             r1 = plan.route_counts()
-            assert r1["onepass"] - r0["onepass"] == len(steps) and r1["twopass"] == r0["twopass"] and r1["plain"] == r0["plain"], (mode, r0, r1)
+            assert r1["onepass"] - r0["onepass"] == len(steps) and r1["plain"] == r0["plain"], (mode, r0, r1)
             if mode == "hooked":
                 # ten all-reduces per step with sampled brackets, FIVE with predicted ones (round 6: the last step moves the aligned
                 # pair by 4e-5 px -- its brackets come from the step before it: no sample selections, no histogram exchanges)

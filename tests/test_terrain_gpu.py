@@ -960,6 +960,25 @@ def test_host_path_row_chunks_equal_single_pass():
             ctx.set_option("host_chunk_mb", 0)
         for a, g, w in zip(attrs, got, want):
             assert np.array_equal(g.view(np.int32), w.view(np.int32)), (a, kw)
+    # options "host_copy_threads" (copy threads / streams of the PCIe legs: 1, 3, the default 8) and "host_release" (the pinned
+    # staging buffers are freed and come back with the next call): neither may change a bit of the result
+    attrs, kw = configs[0]
+    want = t.get_terrain_attribute(dem, attrs, **kw)
+    try:
+        for nthreads in (1, 3, 0):
+            ctx.set_option("host_copy_threads", nthreads)
+            ctx.set_option("host_chunk_mb", 1 if nthreads == 3 else 0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = t.get_terrain_attribute(dem, attrs, **kw)
+            for a, g, w in zip(attrs, got, want):
+                assert np.array_equal(g.view(np.int32), w.view(np.int32)), (a, nthreads)
+            ctx.set_option("host_release", 1)
+        with pytest.raises(_lib.XdemHipError):
+            ctx.set_option("host_copy_threads", 17)
+    finally:
+        ctx.set_option("host_copy_threads", 0)
+        ctx.set_option("host_chunk_mb", 0)
 
 
 def test_c4_size_on_one_gpu_crops_equal_full():

@@ -1,7 +1,7 @@
-"""Partitioned Nuth-Kaab step, one-pass vs two-pass route, on ranks that SHARE one GPU (gloo group, reductions staged through the
+"""Partitioned Nuth-Kaab step, one-pass step vs plain route, on ranks that SHARE one GPU (gloo group, reductions staged through the
 host hook -- an upper bound of what RCCL ranks on their own GPUs pay per reduction).  Every rank builds bench.py's C3 pair, keeps its
-row block + halo, and times steps of a partitioned plan under option "nk_fused_dist" = 1 (one data pass, 10 all-reduces) and 0 (two
-passes, ~25); rank 0 also times the hook-less plan on the whole pair while the others wait.
+row block + halo, and times steps of a partitioned plan under option "nk_fused_dist" = 1 (one data pass, 5-10 all-reduces) and 0 (the plain
+route: stored dh, a reduction per key digit); rank 0 also times the hook-less plan on the whole pair while the others wait.
 
     python tools/nk_dist_probe.py [size=20000] [world=2] [steps=5]
 """

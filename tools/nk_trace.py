@@ -24,6 +24,8 @@ ref, tba = bench._c3_pair(dev, m)
 ctx = _lib.default_context(0)
 if os.environ.get("NK_NARROW"):   # sample brackets of the one-pass step: -1 adaptive (default), 0 / 1 / 2 fixed
     ctx.set_option("nk_narrow", int(os.environ["NK_NARROW"]))
+if os.environ.get("NK_FUSED"):    # 1 the one-pass step (default), 0 the plain route (stored dh, selections over the stored arrays)
+    ctx.set_option("nk_fused", int(os.environ["NK_FUSED"]))
 group = None
 if os.environ.get("NK_HOOKED"):   # the partitioned plan's route on one GPU: a 1-rank RCCL group, reductions through the device-side hook
     import torch.distributed as dist
@@ -35,6 +37,8 @@ if os.environ.get("NK_HOOKED"):   # the partitioned plan's route on one GPU: a 1
     if os.environ.get("NK_FUSED_DIST"):
         ctx.set_option("nk_fused_dist", int(os.environ["NK_FUSED_DIST"]))
 plan = coreg.NKPlan(ref.contiguous(), tba.contiguous(), None, ctx, group)
+if os.environ.get("NK_STAT") == "mean":   # bin_statistic = np.nanmean (plain route: one pass of per-bin sums)
+    plan.set_statistic("mean")
 if os.environ.get("NK_PREDICT"):   # round 6: 1 settled steps take predicted brackets (default), 0 every step samples
     ctx.set_option("nk_predict", int(os.environ["NK_PREDICT"]))
 settled = os.environ.get("NK_SETTLED") == "1"   # the timed steps are those of a fit that has converged: shift changes of ~1e-4 px

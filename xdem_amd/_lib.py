@@ -119,7 +119,7 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_nk_set_rows.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_i64p]
         L.xdemhip_nk_set_statistic.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        L.xdemhip_nk_route_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p, c_i64p]
+        L.xdemhip_nk_route_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p]
         L.xdemhip_nk_predict_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p, c_i64p]
         c_u64p = ctypes.POINTER(ctypes.c_uint64)
         L.xdemhip_pairs_create.argtypes = [c_ctx, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -416,7 +416,7 @@ class Context:
         for _, _, p in items:
             self._L.xdemhip_device_free(self.handle, ctypes.c_void_p(p))
 
-    TEST_SWITCHES = frozenset(("terrain_stream", "terrain_order", "terrain_ring_wait", "terrain_window_lds", "nk_ext", "nk_narrow",
+    TEST_SWITCHES = frozenset(("terrain_stream", "terrain_order", "terrain_ring_wait", "terrain_window_lds", "nk_narrow",
                                "vario_grid", "vario_runs", "vario_sort", "terrain_store", "terrain_rows", "terrain_sync", "vario_deff"))
 
     def set_option(self, name: str, value: int) -> None:

@@ -184,12 +184,13 @@ class NKPlan:
         return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value, "sums": sums}
 
     def route_counts(self) -> dict[str, int]:
-        """Steps answered so far by the one-pass step, by the two queued passes, by the plain digit passes (``xdemhip_nk_route_counts``)."""
-        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-        self.ctx.check(self.ctx._L.xdemhip_nk_route_counts(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        """Steps answered so far by the one-pass step and by the plain route (``xdemhip_nk_route_counts``); how many one-pass steps took
+        predicted brackets (``xdemhip_nk_predict_counts``)."""
+        a, c = ctypes.c_int64(), ctypes.c_int64()
+        self.ctx.check(self.ctx._L.xdemhip_nk_route_counts(self.handle, ctypes.byref(a), ctypes.byref(c)))
         p, d, m = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         self.ctx.check(self.ctx._L.xdemhip_nk_predict_counts(self.handle, ctypes.byref(p), ctypes.byref(d), ctypes.byref(m)))
-        return {"onepass": int(a.value), "twopass": int(b.value), "plain": int(c.value), "predicted": int(p.value),
+        return {"onepass": int(a.value), "plain": int(c.value), "predicted": int(p.value),
                 "predicted_dh_only": int(d.value), "predict_missed": int(m.value)}
 
     def set_bin_edges(self, edges) -> None:

@@ -315,7 +315,6 @@ const XdOpt kTestSwitches[] = {
     {"terrain_order", 0, 3, &xdemhip_ctx::terrain_order, "terrain_order: 0 XCD bands, 1 natural order, 2 permuted strips, 3 column-major strips"},
     {"terrain_ring_wait", 0, 1, &xdemhip_ctx::terrain_ring_wait, "terrain_ring_wait: 0 counted wait, 1 vmcnt(0)"},
     {"terrain_window_lds", 0, 1, &xdemhip_ctx::terrain_window_lds, "terrain_window_lds: 0 or 1"},
-    {"nk_ext", 0, 1, &xdemhip_ctx::nk_ext, "nk_ext: 0 or 1"},
     {"nk_narrow", -1, 2, &xdemhip_ctx::nk_narrow, "nk_narrow: -1 (adaptive), 0, 1 or 2"},
     {"vario_grid", 0, 1, &xdemhip_ctx::vario_grid, "vario_grid: 0 or 1"},
     {"vario_runs", 0, 1, &xdemhip_ctx::vario_runs, "vario_runs: 0 or 1"},

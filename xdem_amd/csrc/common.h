@@ -29,7 +29,7 @@ struct xdemhip_ctx {
     void* allreduce_dev_user = nullptr;
     int64_t n_red_host = 0, n_red_dev = 0;     // reductions that went through the host / the device hook
     int rank = 0, world = 0;                   // xdemhip_set_rank: this process's place among the ranks the hooks reduce over (world 0: not told)
-    int nk_fused_dist = 1;   // option "nk_fused_dist": 1 partitioned Nuth-Kaab plans (reduction hook + xdemhip_set_rank) take the one-pass step too: 10 all-reduces per step (default), 0 the two-pass route of round 3 (~25)
+    int nk_fused_dist = 1;   // option "nk_fused_dist": 1 partitioned Nuth-Kaab plans (reduction hook + xdemhip_set_rank) take the one-pass step too: 5-10 all-reduces per step (default), 0 the plain route
     int host_chunk_rows = 0; // option "host_chunk_rows": rows per chunk of host-buffer terrain calls (0 = from the budget); the mp_config tile size
     int host_chunk_mb = 0;   // device budget (MiB) of one row chunk of host-buffer terrain calls; 0 = default
     int terrain_store = 0;   // option "terrain_store": 0 direct stores (default), 1 staged 1 KiB row stores where possible (measured slower)
@@ -38,7 +38,6 @@ struct xdemhip_ctx {
     int vario_runs = 1;      // option "vario_runs": run-length counting pass of the bracketed Dowd selection when a Morton-ordered copy is linked (0 = per-pair counters)
     int vario_deff = 0;      // option "vario_deff": design effect assumed for the pair samples of the bracketed Dowd selection (0 = built-in rule)
     int vario_sort = 1;      // option "vario_sort": the Python side uploads the points of a pair block in Morton order (run-length accumulation of the pair kernels)
-    int nk_ext = 1;          // option "nk_ext": 1 the Nuth-Kaab dh pass takes min / max aspect from lists of extreme-aspect pixels and reads a masked reference DEM (default), 0 it reads mask and aspect of every pixel
     int nk_predict = 1;      // option "nk_predict": 1 a settled one-pass Nuth-Kaab step takes its brackets from the previous step's exact medians moved by the model (no sample kernels, no digit passes over samples; default), 0 every step samples
     int nk_fused = 1;        // option "nk_fused": 1 the Nuth-Kaab step of large single-GPU plans is ONE data pass (14 B/pixel: dh, its median's counting and the aspect-bin counting against sample brackets with per-pixel margins; default), 0 the two passes of round 3
     int terrain_stream = 1;  // option "terrain_stream": 1 streaming strips for the raster interior where they apply (default), 0 tiles only; 128 / 256 / 512 = band height
@@ -158,8 +157,8 @@ inline int xd_allreduce_device(xdemhip_ctx* ctx, void* dptr, int64_t count, int 
     return XDEMHIP_OK;
 }
 
-// A small HOST array through the host hook: the route agreements, made once per plan (like the per-step agreements of the two-pass
-// route they are not counted by xdemhip_reduction_calls, which counts the data reductions of the steps).
+// A small HOST array through the host hook: the route agreements, made once per plan (like the per-step agreements of the selection
+// routes they are not counted by xdemhip_reduction_calls, which counts the data reductions of the steps).
 inline int xd_allreduce_host(xdemhip_ctx* ctx, void* hptr, int64_t count, int kind) {
     if (!ctx->allreduce || count <= 0) return XDEMHIP_OK;
     if (ctx->allreduce(hptr, count, kind, ctx->allreduce_user) != 0) return xd_fail(ctx, XDEMHIP_EHIP, "all-reduce hook failed");

@@ -173,9 +173,9 @@ def nuth_kaab_row_blocks(ref_rows: torch.Tensor, tba_rows: torch.Tensor, total_r
     rows); if a step leaves it (``HaloTooSmall``, raised identically on every rank) the halo is doubled and the fit
     restarts.  Every reduction of a step -- integer histograms, counters, min / max keys -- is all-reduced through the
     library hook, so all ranks obtain the same, exact result as a single-GPU fit of the whole rasters.  Large blocks take the
-    one-pass step (one data pass over the rank's rows, ten all-reduces per step: include/xdemhip.h, xdemhip_nk_route_counts).
+    one-pass step (one data pass over the rank's rows, ten all-reduces per sampled step, five per predicted one: include/xdemhip.h, xdemhip_nk_route_counts).
 
-    ``info`` (optional dict) receives ``routes`` -- how the steps of the fit were answered on this rank (one-pass / two-pass /
+    ``info`` (optional dict) receives ``routes`` -- how the steps of the fit were answered on this rank (one-pass /
     plain; identical on every rank) -- and ``reductions``, the (host-staged, device-side) reductions the fit made.
 
     Returns ((easting, northing, vertical) offsets, number of valid pixels of the whole pair)."""
