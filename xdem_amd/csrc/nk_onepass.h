@@ -17,7 +17,7 @@ namespace xd {
 // bracket [lo_b, hi_b] of its aspect bin (from the same sample, evaluated with v^) a pixel is
 //     certainly below   if y^ + m < lo_b,        certainly above   if y^ - m > hi_b,        a candidate otherwise;
 // the certain ones are counted, the candidates (a few percent) staged as (dh, slope_tan, bin) triples.  Once vshift is
-// known exactly (selection among the dh candidates, as before), nk_resolve_kernel evaluates the candidates' y in the
+// known exactly (selection among the dh candidates), the resolve step (nk_resolve_scatter_kernel) evaluates the candidates' y in the
 // reference's arithmetic, counts those below / inside [lo_b, hi_b] and hands the inside ones to the same exact selection as
 // before: rank (k - certainly below - candidates below) among them.  All counting is integer; every rank claim is checked by
 // the counts (bracket_given_kernel); a miss or an overflow anywhere sends the step to the plain route.
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, u
                                                           const typename KeyT<T>::type* klo_d = nullptr, const typename KeyT<T>::type* khi_d = nullptr,
                                                           T* vhat_out = nullptr, T* delta_out = nullptr, unsigned long long* ctr = nullptr,
                                                           SelReset reset = SelReset()) {
-    // round 5, on the side (two launches less): v^ and delta from the dh sample's bracket, which nk_vhat_kernel used to derive -- every
+    // round 5, on the side (two launches less): v^ and delta from the dh sample's bracket, which a kernel of their own used to derive -- every
     // thread forms them (a handful of scalar operations), the first one stores them for the data pass; and the reset of the selection
     // that runs on this sample next.  (An empty sample is told from the bracket itself -- bracket_finish_body leaves {0, all-ones} --
     // not from the selection's states, which that reset is clearing.)
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
 
 
 // ---- round 5: the bin candidates partitioned by bin; ONE workgroup per bin selects its exact median ----------------------------
-// After nk_resolve_kernel the exact selection among the candidates of the 72 bins used to run as select_enqueue: three more digit
+// After round 4's resolve kernel (nk_resolve_kernel, gone since round 6) the exact selection among the candidates of the 72 bins used to run as select_enqueue: three more digit
 // passes over ALL candidate slots (the resolved-away ones left as NaN) with the whole [72][256] LDS table zeroed and flushed by every
 // workgroup of every pass, an advance kernel behind each, the successor pass -- 10 launches, ~150 us of the step.  The fused kernel
 // already counts the candidates per bin (cls[2][b]), so the resolve kernel can write the kept y values INTO PER-BIN SEGMENTS
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_bin_select_kernel(const T* __
 // monotone map of the per-bin segments above, 16 x finer); `nk_dhsel_gather_kernel` -- every workgroup -- scans that histogram for
 // the bucket that holds the wanted rank, appends the bucket's keys (a few hundred) to a small buffer and notes the smallest key of
 // the buckets above; `nk_dhsel_final_kernel` (one workgroup) settles the exact order statistic and its successor among those keys
-// in LDS and writes vshift the way nk_fz_vshift_kernel does.  (Gather and final in one launch -- the last workgroup to finish, by a
+// in LDS and writes vshift (value, count, flags: the step's info block).  (Gather and final in one launch -- the last workgroup to finish, by a
 // ticket, doing the final part -- needs the keys, plain stores of many workgroups, published by device-scope fences: on this
 // multi-XCD part a fence writes back the issuing XCD's whole L2, 38-55 us for 64 workgroups, measured; a kernel boundary is cheaper.)
 // Same integers, same keys: the result is the generic selection's bit for bit (GPU tests: every route agrees).
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t ca
     const uint64_t total = cnt[0], lt = cnt[1], in = cnt[2];
     const unsigned long long m = *n_dev;
     const int64_t n = m < (unsigned long long)cap ? (int64_t)m : cap;
-    auto hand_back = [&](T vs) {   // what nk_fz_vshift_kernel writes
+    auto hand_back = [&](T vs) {   // the step's info block: vshift in the DEM dtype and in float64, the valid count, the flags
         *reinterpret_cast<T*>(info) = vs;
         *reinterpret_cast<uint64_t*>(info + 8) = total;
         *reinterpret_cast<uint64_t*>(info + 16) = (uint64_t)((ctr[2] != 0) | ((ctr[3] != 0) << 1));
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_final_kernel(int64_t ca
     }
     if (lane == 0 && mn2 != ~(K)0) k_atomic_min(s_min, mn2);
     __syncthreads();
-    if (tid == 0) {   // (the arithmetic of nk_fz_vshift_kernel)
+    if (tid == 0) {   // (np.nanmedian's arithmetic: the middle value, or the mean of the two middle values formed in the DEM dtype)
         const uint64_t n_le = s.n_le + lt;
         const T lo = val_of(s.prefix);
         T vs = lo;

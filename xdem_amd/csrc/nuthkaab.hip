@@ -336,7 +336,7 @@ template <typename T> struct NkYSource {
     const T* dh;
     const T* slope_tan;
     const T* aspect;
-    const T* vshift_p;  // device scalar (written by nk_vshift_edges_kernel, or uploaded by the host on the plain route)
+    const T* vshift_p;  // device scalar (uploaded by the host on the plain route)
     const T* edges;  // [nb + 1], device
     double* sums;    // [sum, sumsq], device
     T* e;            // LDS copy of the edges (setup)
