@@ -201,6 +201,31 @@ def measured_traffic_bytes(pixels_per_launch: int):
     return best
 
 
+def nk_pass_profile(pixels_per_launch: int):
+    """The one data pass of the Nuth-Kaab step (nk_fused_kernel) in the newest committed PMC profile of this launch size
+    (profiles/*_nk_fused_pmc.json, tools/profile_nk.sh): HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, KiB units, the gfx950
+    correction of MI355X_MICROARCH.md), the share of the launch's cycles its vector instructions were issuing, or None."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_nk_fused_pmc.json"))):
+        try:
+            d = json.load(open(f))
+            if int(d.get("_pixels_per_launch", 0)) != int(pixels_per_launch):
+                continue
+            med = lambda c: d[c]["per_kernel"]["nk_fused_kernel"]["median"]
+            traffic = (2.0 * med("FETCH_SIZE") + med("WRITE_SIZE")) * 1024.0
+            cycles = med("GRBM_GUI_ACTIVE") / 8.0                 # (the counter sums the 8 XCDs)
+            busy = med("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0      # (per-SIMD issue cycles: 256 CUs x 4 SIMDs)
+            best = {"traffic_bytes_per_launch": round(traffic), "traffic_over_touched_bytes": round(traffic / (13.0 * pixels_per_launch), 3),
+                    "vector_instructions_per_64_pixel_row": round(med("SQ_INSTS_VALU") / (pixels_per_launch / 64.0), 1),
+                    "vector_issue_share_of_cycles": round(busy / cycles, 3),
+                    "source": os.path.basename(f) + ": rocprofv3 --pmc passes of tools/nk_trace.py (a committed profile, not re-measured in this run)"}
+        except Exception:
+            pass
+    return best
+
+
 def secondary_cpu_baselines() -> dict:
     """The CPU ports (oracles) of the two other paths on bounded samples (reported as rates, never extrapolated)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -467,6 +492,7 @@ def secondary_metrics(ctx, dev, rank: int = 0, world: int = 1, barrier=None, c5a
                                     "frac_at_survey_bytes": round(alg_bpp * px / dt / 1e9 / (HBM_PEAK_GBPS * world), 4),
                                     "touched_bytes_per_pixel": touched,
                                     "touched_GBps": round(touched * px / dt / 1e9, 1),
+                                    "data_pass": nk_pass_profile(m * m) if (onepass and world == 1) else None,
                                     "note": NK_ONEPASS_NOTE if onepass else NK_TOUCHED_NOTE},
                        "note": "ms_per_iteration = steps whose shift moves by 0.1 px (the early iterations of a fit: sampled brackets); ms_per_iteration_settled = "
                                "steps at the fit's end point, shift changes of ~2e-4 px (the later iterations: brackets predicted from the previous step's exact "
