@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--opts", default="terrain_sync=0,2,4,8;terrain_order=0,1")
     ap.add_argument("--combos", default="")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--planes", default="torch", choices=("torch", "scattered"), help="torch.empty planes or the library's scattered backing")
     a = ap.parse_args()
     import torch
 
@@ -35,8 +36,13 @@ def main():
 
     n = a.size
     dem = fbm_torch(n, n, "cuda", seed=42)
-    out = torch.empty((len(FULL), n, n), dtype=torch.float32, device="cuda")
     ctx = _lib.default_context(0)
+    if a.planes == "scattered":
+        from xdem_amd.terrain import alloc_planes
+
+        out = alloc_planes(len(FULL), n, n, torch.float32, ctx, torch.device("cuda", 0), backing="auto")
+    else:
+        out = torch.empty((len(FULL), n, n), dtype=torch.float32, device="cuda")
     # --opts "a=0,1;b=2" times every listed value of a and of b alone (the other options at 0);
     # --combos "a=1+b=2;a=0+b=2" times the named combinations.  Options not named in a setting are set to 0.
     settings = []
@@ -65,7 +71,7 @@ def main():
     for label, _ in settings:
         t = sorted(res[label])
         summary[label] = {"min": round(t[0], 3), "median": round(t[len(t) // 2], 3)}
-        print(f"{label:28s} min {t[0]:8.3f} ms   median {t[len(t) // 2]:8.3f} ms   ({48 * n * n / t[len(t) // 2] / 1e9:6.1f} GB/s, frac {48 * n * n / t[len(t) // 2] / 1e9 / 8000:.3f})", flush=True)
+        print(f"{label:28s} min {t[0]:8.3f} ms   median {t[len(t) // 2]:8.3f} ms   ({48 * n * n / t[len(t) // 2] / 1e6:6.1f} GB/s, frac {48 * n * n / t[len(t) // 2] / 1e6 / 8000:.3f})", flush=True)
     if a.json:
         json.dump(summary, open(a.json, "w"), indent=1)
 
