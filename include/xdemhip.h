@@ -258,6 +258,15 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* plan, int64_t row_begin, int64_t row_en
  * n_valid and the p0 ingredients (np.nanmean / np.nanstd of y). */
 int xdemhip_nk_step_fit(xdemhip_nk_plan* plan, double shift_x, double shift_y, double res_x, double res_y, double* vshift,
                         int64_t* n_valid, double* y_mean, double* y_std, double* sums /* [10] */);
+/* NuthKaab(bin_statistic=<a callable other than np.nanmedian / np.nanmean>) (xdem/coreg/affine.py:2404; nd_binning hands the callable to
+ * scipy.stats.binned_statistic, xdem/spatialstats.py:143-157): host code cannot run on the GPU, so this entry returns what the callable is
+ * applied to -- y = (dh - vshift) / slope_tan in the DEM dtype and the aspect-bin id (uint16; 0xFFFF = no bin) of every pixel of the raster
+ * in raster order, NaN / 0xFFFF where the pixel has no dh at this shift -- next to vshift, the valid count, np.nanmean / np.nanstd of y and
+ * the n_bins + 1 bin edges.  `y_out` holds H x W values of the plan's dtype, `bins_out` H x W uint16, both in `memspace`.  Whole-raster
+ * plans without a reduction hook only (a partitioned plan holds a part of every bin: XDEMHIP_EINVAL); the step takes the plain route. */
+int xdemhip_nk_step_values(xdemhip_nk_plan* plan, double shift_x, double shift_y, double res_x, double res_y, int n_bins, double* vshift,
+                           int64_t* n_valid, double* y_mean, double* y_std, double* edges /* [n_bins + 1] */, void* y_out,
+                           uint16_t* bins_out, int memspace);
 /* Explicit aspect-bin edges (NuthKaab(bin_sizes={"aspect": edges}), the array form of scipy.stats.binned_statistic's `bins`):
  * n_edges increasing values (2 .. 129: at most 128 bins, one histogram sweep); xdemhip_nk_step must then be called with
  * n_bins = n_edges - 1 (its output arrays are sized by n_bins; any other value is XDEMHIP_EINVAL).  `decimal` = SciPy's

@@ -602,3 +602,18 @@ def test_mp_config_refusals_before_any_gpu_work():
         t.get_terrain_attribute(dem, "slope", resolution=1.0, mp_config=SimpleNamespace(chunk_size=200, outfile=None, cluster=None))
     with pytest.raises(TypeError, match="The DEM must be a Raster to use multiprocessing."):
         t.slope(dem, resolution=1.0, mp_config=SimpleNamespace(chunk_size=200, outfile=None, cluster=None))
+
+
+def test_bin_statistic_dispatch():
+    """NuthKaab(bin_statistic=...): the median and the mean run on the GPU, any other callable over the GPU's y values on the host
+    (xdem_amd/coreg.py: _bin_statistic_id); anything that is not callable is a TypeError at construction, before any GPU work."""
+    from xdem_amd import coreg
+
+    assert coreg._bin_statistic_id(np.nanmedian) == 0 and coreg._bin_statistic_id(np.median) == 0 and coreg._bin_statistic_id("median") == 0
+    assert coreg._bin_statistic_id(np.nanmean) == 1 and coreg._bin_statistic_id(np.mean) == 1
+    assert coreg._bin_statistic_id(np.nanmax) == 2 and coreg._bin_statistic_id(lambda v: 0.0) == 2 and coreg._bin_statistic_id(np.sum) == 2
+    with pytest.raises(TypeError):
+        coreg._bin_statistic_id(0.5)
+    with pytest.raises(TypeError):
+        coreg.NuthKaab(bin_statistic="percentile")
+    assert coreg.NuthKaab(bin_statistic=np.nanstd).meta["inputs"]["fitorbin"]["bin_statistic"] is np.nanstd

@@ -136,8 +136,82 @@ def test_step_mean_statistic_matches_oracle(coreg, dtype):
     det2 = plan.step(17.3, -5.1, (res, res), 72)
     assert np.array_equal(det2["medians"], nko.bin_medians(a, y, 72)[2], equal_nan=True)
     plan.close()
-    with pytest.raises(NotImplementedError):
-        coreg.NuthKaab(bin_statistic=np.nanmax)
+    with pytest.raises(TypeError):
+        coreg.NuthKaab(bin_statistic=0.5)   # (not a callable)
+
+
+def _p75(v):
+    return np.percentile(v, 75) if len(v) else np.nan
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_step_callable_statistic_equals_scipy_binned_statistic(coreg, dtype):
+    """NuthKaab(bin_statistic=<any callable>) (affine.py:2404; nd_binning hands it to scipy.stats.binned_statistic,
+    spatialstats.py:143-157): the GPU returns y and the bin id of every pixel (xdemhip_nk_step_values), the callable runs on the host
+    over each bin's values in raster order.  Against SciPy's own binned_statistic on the oracle's y: bit for bit, empty bins included
+    (SciPy fills them with statistic([]), or NaN if that raises), for an order statistic, a sum, a spread and a lambda -- and the
+    median / mean through the same door equal the GPU's own exact medians / the NumPy means."""
+    import scipy.stats
+
+    ref, tba, inlier, res = _pair(dtype=dtype)
+    plan = coreg.NKPlan(ref, tba, inlier)
+    aspect_dev = plan.aux()[1]
+    st, asp = nko.aux_vars(ref)
+    valid = inlier & np.isfinite(ref) & np.isfinite(tba) & np.isfinite(st) & np.isfinite(asp)
+    dh = nko.shifted_dh(ref, tba, 17.3, -5.1, (res, res))[valid]
+    vshift = np.nanmedian(dh)
+    dh = dh - vshift
+    ok = np.isfinite(dh)
+    with np.errstate(all="ignore"):
+        y = dh[ok] / st[valid][ok]
+    a = asp[valid][ok] if dtype == np.float32 else aspect_dev[valid][ok]
+    plan.set_statistic(np.nanmedian)
+    exact = plan.step(17.3, -5.1, (res, res), 72)
+    for nb in (72, 500):
+        edges = nko.bin_medians(a, y, nb)[0]
+        for f in (np.nanmax, np.sum, np.std, np.min, np.max, np.nanstd, np.nansum, _p75, lambda v: float(np.median(v)) if len(v) else np.nan, lambda v: float(np.mean(v, dtype=np.float64)) if len(v) else np.nan):
+            plan.set_statistic(f)
+            det = plan.step(17.3, -5.1, (res, res), nb)
+            want = scipy.stats.binned_statistic(a, y, statistic=f, bins=edges).statistic
+            cnt = scipy.stats.binned_statistic(a, y, statistic="count", bins=edges).statistic
+            assert det["vshift"] == float(vshift) and det["n_valid"] == int(ok.sum())
+            assert np.array_equal(det["edges"], edges.astype(np.float64)) and np.array_equal(det["counts"], cnt.astype(np.int64))
+            assert np.array_equal(det["medians"], np.asarray(want, dtype=np.float64), equal_nan=True), (nb, f)
+            if nb == 72 and f.__name__ == "<lambda>" and "median" in f.__code__.co_names:
+                assert np.array_equal(det["medians"], exact["medians"], equal_nan=True)
+    assert plan.route_counts()["plain"] >= 18
+    # explicit edges that reach beyond [0, 2 pi): the outer bins stay empty -> statistic([]) where it exists (np.sum: 0), NaN otherwise
+    if dtype == np.float32:
+        edges = np.linspace(-1.5, 7.5, 19)
+        plan.set_bin_edges(edges)
+        for f in (np.sum, np.nanmax, _p75):
+            plan.set_statistic(f)
+            det = plan.step(17.3, -5.1, (res, res))
+            want = scipy.stats.binned_statistic(a, y, statistic=f, bins=edges.astype(np.float32)).statistic
+            cnt = scipy.stats.binned_statistic(a, y, statistic="count", bins=edges.astype(np.float32)).statistic
+            assert (cnt == 0).any() and np.array_equal(det["counts"], cnt.astype(np.int64))
+            assert np.array_equal(det["medians"], np.asarray(want, dtype=np.float64), equal_nan=True), f
+        assert plan.step(17.3, -5.1, (res, res))["medians"][0] != plan.step(17.3, -5.1, (res, res))["medians"][0]   # (NaN: _p75 of an empty bin)
+    plan.close()
+
+
+def test_class_api_callable_statistic(coreg):
+    """The class with a callable statistic: a trimmed mean recovers the construction like the median does."""
+    from xdem_amd.synth import fbm_numpy
+
+    def trimmed(v):
+        lo, hi = np.percentile(v, [10, 90])
+        return float(np.mean(v[(v >= lo) & (v <= hi)]))
+
+    n, res = 600, 10.0
+    ref = fbm_numpy((n, n), seed=8, std=150.0)
+    tba = (np.roll(ref, (2, -1), (0, 1)) + 1.25).astype(np.float32)
+    nk = coreg.NuthKaab(bin_statistic=trimmed, subsample=1, offset_threshold=0.0, max_iterations=8)
+    nk.fit(ref, tba, None, resolution=res)
+    a = nk.meta["outputs"]["affine"]
+    med = coreg.NuthKaab(subsample=1, offset_threshold=0.0, max_iterations=8).fit(ref, tba, None, resolution=res).meta["outputs"]["affine"]
+    for k in ("shift_x", "shift_y", "shift_z"):
+        assert abs(a[k] - med[k]) < 0.05 * res, (k, a[k], med[k])
 
 
 def test_class_api_mean_statistic_recovers_shift(coreg):

@@ -7,15 +7,18 @@ over the grids (gradient, shifted elevation difference, exact ``nanmedian`` vert
 with exact per-bin ``nanmedian``) runs in ``csrc/nuthkaab.hip`` through ``xdemhip_nk_create`` / ``xdemhip_nk_step``.
 The 72-point ``scipy.optimize.curve_fit`` stays on the host exactly as upstream (``xdem/coreg/base.py:1038-1045``).
 
-Scope: two rasters on the same grid given as arrays (+ resolution); the default ``bin_before_fit=True`` with
-``bin_statistic=np.nanmedian``.  ``subsample=1`` uses all valid pixels (the BASELINE configuration); any other value a
-random subset drawn once by the restated rule of geoutils' ``subsample_array`` (``subsample_valid_mask``).  Point-cloud
-inputs and other statistics are outside the hot path and raise ``NotImplementedError``.
+Scope: two rasters on the same grid given as arrays (+ resolution); ``bin_before_fit=True`` (default) or ``False``;
+``bin_statistic`` = ``np.nanmedian`` (default: exact medians on the GPU), ``np.nanmean`` (per-bin sums on the GPU) or any other
+callable (the GPU hands y and the bin ids of every pixel back and the callable runs on the host per bin, exactly as
+``scipy.stats.binned_statistic`` calls it upstream -- single-process fits only).  ``subsample=1`` uses all valid pixels (the
+BASELINE configuration); any other value a random subset drawn once by the restated rule of geoutils' ``subsample_array``
+(``subsample_valid_mask``).  Point-cloud inputs are outside the hot path and raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
 import ctypes
 import logging
+import warnings
 from typing import Any, Callable
 
 import numpy as np
@@ -29,13 +32,17 @@ def _nuth_kaab_fit_func(xx, *params):
 
 
 def _bin_statistic_id(bin_statistic) -> int:
-    """0 = median, 1 = mean for the callables the GPU bins with (``NuthKaab(bin_statistic=...)``, affine.py:2404)."""
-    if bin_statistic in (np.nanmedian, np.median, "median", "nanmedian"):
+    """How ``NuthKaab(bin_statistic=...)`` (affine.py:2404) is evaluated: 0 = exact medians on the GPU (np.nanmedian, the reference
+    default), 1 = per-bin sums on the GPU (np.nanmean), 2 = any other callable -- the GPU produces y and the bin ids of every pixel, the
+    callable runs on the host over each bin's values in raster order, as ``scipy.stats.binned_statistic`` calls it upstream
+    (``NKPlan._step_callable``; whole-raster plans only)."""
+    if any(bin_statistic is f for f in (np.nanmedian, np.median)) or bin_statistic in ("median", "nanmedian"):
         return 0
-    if bin_statistic in (np.nanmean, np.mean, "mean", "nanmean"):
+    if any(bin_statistic is f for f in (np.nanmean, np.mean)) or bin_statistic in ("mean", "nanmean"):
         return 1
-    raise NotImplementedError("xdem_amd.NuthKaab bins with np.nanmedian (reference default, exact) or np.nanmean; other "
-                              "callables would need the binned values on the host.")
+    if callable(bin_statistic):
+        return 2
+    raise TypeError("bin_statistic must be a callable (np.nanmedian, np.nanmean, or any function of a 1-D array)")
 
 
 class HaloTooSmall(_lib.XdemHipError):
@@ -143,6 +150,8 @@ class NKPlan:
 
     def step(self, shift_x: float, shift_y: float, res: tuple[float, float], n_bins: int = 72) -> dict[str, Any]:
         n_bins = getattr(self, "_n_custom_bins", None) or int(n_bins)
+        if getattr(self, "_bin_callable", None) is not None:
+            return self._step_callable(shift_x, shift_y, res, n_bins)
         edges = np.empty(n_bins + 1, dtype=np.float64)
         counts = np.empty(n_bins, dtype=np.int64)
         med = np.empty(n_bins, dtype=np.float64)
@@ -156,6 +165,64 @@ class NKPlan:
             self._raise_step_error(rc)
         return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
                 "edges": edges, "counts": counts, "medians": med}
+
+    def _step_callable(self, shift_x: float, shift_y: float, res: tuple[float, float], n_bins: int) -> dict[str, Any]:
+        """The step under a ``bin_statistic`` that is neither the median nor the mean: ``xdemhip_nk_step_values`` returns y =
+        (dh - vshift) / slope_tan and the aspect-bin id of every pixel (raster order); the callable is applied per bin exactly as
+        ``scipy.stats.binned_statistic`` does it upstream (xdem/spatialstats.py:143-157 after the finite-value filter of
+        ``nd_binning``, spatialstats.py:122-131): empty bins receive ``statistic([])``, or NaN if that raises."""
+        if self.group is not None:
+            raise NotImplementedError("a bin_statistic other than np.nanmedian / np.nanmean needs all values of a bin in one process: "
+                                      "not available for partitioned (group=...) fits")
+        if getattr(self, "_vals", None) is None:
+            self._vals = (np.empty(self.shape, dtype=self.dtype), np.empty(self.shape, dtype=np.uint16))
+        y, bins = self._vals
+        edges = np.empty(n_bins + 1, dtype=np.float64)
+        vshift, ymean, ystd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        nv = ctypes.c_int64()
+        dp = ctypes.POINTER(ctypes.c_double)
+        rc = self.ctx._L.xdemhip_nk_step_values(self.handle, float(shift_x), float(shift_y), float(res[0]), float(res[1]), int(n_bins),
+                                                ctypes.byref(vshift), ctypes.byref(nv), ctypes.byref(ymean), ctypes.byref(ystd),
+                                                edges.ctypes.data_as(dp), y.ctypes.data, bins.ctypes.data, _lib.HOST)
+        if rc != _lib.OK:
+            self._raise_step_error(rc)
+        ok = (bins != 0xFFFF) & np.isfinite(y)
+        b, v = bins[ok], y[ok]
+        counts = np.bincount(b, minlength=n_bins).astype(np.int64)
+        order = np.argsort(b, kind="stable")   # (stable: every bin keeps its values in raster order, as upstream's per-bin lists do)
+        starts = np.concatenate(([0], np.cumsum(counts)))
+        f = self._bin_callable
+        # SciPy answers the NumPy function OBJECTS np.sum / np.std / np.min / np.max itself (vectorised branches of
+        # binned_statistic_dd, float64 accumulation in element order) instead of calling them per bin: the same arithmetic here
+        # (np.mean / np.median never arrive: the GPU statistics answer them)
+        if any(f is g for g in (np.sum, np.std, np.min, np.max)):
+            stat = np.full(n_bins, 0.0 if f is np.sum else np.nan, dtype=np.float64)
+            nz = counts > 0
+            if f is np.sum:
+                stat[:] = np.bincount(b, weights=v, minlength=n_bins)
+            elif f is np.std:
+                flatsum = np.bincount(b, weights=v, minlength=n_bins)
+                delta = v - flatsum[b] / counts[b]
+                stat[nz] = np.sqrt(np.bincount(b, weights=delta * np.conj(delta), minlength=n_bins)[nz] / counts[nz])
+            else:
+                red = np.minimum if f is np.min else np.maximum
+                stat[nz] = red.reduceat(v[order], starts[:-1][nz])
+            return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
+                    "edges": edges, "counts": counts, "medians": stat}
+        v = v[order]
+        with np.errstate(invalid="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            try:
+                null = f([])
+            except Exception:
+                null = np.nan
+        stat = np.full(n_bins, null, dtype=np.float64)
+        for k in np.flatnonzero(counts):
+            # (a fresh array per bin, as upstream builds one: NumPy's vectorised reductions peel to the buffer's alignment, so a slice
+            #  at an odd offset can sum in another order than the same values at the start of an allocation)
+            stat[k] = f(v[starts[k]:starts[k + 1]].copy())
+        return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
+                "edges": edges, "counts": counts, "medians": stat}
 
     def _raise_step_error(self, rc: int) -> None:
         msg = self.ctx._L.xdemhip_last_error(self.ctx.handle).decode()
@@ -209,7 +276,9 @@ class NKPlan:
     def set_statistic(self, bin_statistic) -> None:
         """Statistic of the aspect bins: ``np.nanmedian`` / ``np.median`` (exact selection, the default) or ``np.nanmean`` /
         ``np.mean`` (per-bin sums and counts); ``step`` then returns the bin means under ``"medians"``."""
-        self.ctx.check(self.ctx._L.xdemhip_nk_set_statistic(self.handle, _bin_statistic_id(bin_statistic)))
+        sid = _bin_statistic_id(bin_statistic)
+        self._bin_callable = bin_statistic if sid == 2 else None
+        self.ctx.check(self.ctx._L.xdemhip_nk_set_statistic(self.handle, 0 if sid == 2 else sid))
 
     def aux(self):
         """(slope_tan, aspect, valid) copied back to the host (tests / debugging)."""
@@ -424,7 +493,7 @@ class NuthKaab:
                  vertical_shift: bool = True, initial_shift=None) -> None:
         import scipy.optimize
 
-        _bin_statistic_id(bin_statistic)  # np.nanmedian (default) or np.nanmean; raises for anything else
+        _bin_statistic_id(bin_statistic)  # (np.nanmedian / np.nanmean on the GPU, any other callable over the GPU's y values; not a callable: TypeError)
         _check_unbinned_optimizer(fit_optimizer, bin_before_fit)
         if isinstance(bin_sizes, dict):  # upstream's {"aspect": n | edges} form (base.py:957-966)
             if list(bin_sizes) != ["aspect"]:

@@ -1456,6 +1456,56 @@ int nk_step_typed(xdemhip_nk_plan* P, double shift_x, double shift_y, double res
     return XDEMHIP_OK;
 }
 
+// NuthKaab(bin_statistic=<any callable>) (xdem/coreg/affine.py:2404 -> nd_binning -> scipy.stats.binned_statistic with the callable):
+// a Python callable cannot run here, so the step hands back what it would be called on -- y = (dh - vshift) / slope_tan and the aspect-bin
+// id of every pixel of the plan's rows, in raster order (NaN / 0xFFFF where the pixel has no dh) -- next to vshift, the valid count, the
+// moments of y and the bin edges.  Plain route (stored dh); whole-raster plans only: a callable needs all of a bin's values in one place.
+template <typename T>
+int nk_step_values(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int nb, double* vshift, int64_t* n_valid,
+                   double* y_mean, double* y_std, double* edges_out, void* y_out, uint16_t* bins_out, int memspace) {
+    xdemhip_ctx* ctx = P->ctx;
+    if (ctx->allreduce) return xd_fail(ctx, XDEMHIP_EINVAL, "per-pixel values of a step: whole-raster plans only (a partitioned plan holds a part of every bin)");
+    if (P->row0 != 0 || P->row1 != P->H || P->roff != 0) return xd_fail(ctx, XDEMHIP_EINVAL, "per-pixel values of a step: the plan must cover the whole raster");
+    const int64_t n = P->H * P->W;
+    unsigned char* base = static_cast<unsigned char*>(P->scratch);
+    double* d_sums = reinterpret_cast<double*>(base + OFF_SUMS);
+    T* d_edges = reinterpret_cast<T*>(base);
+    if (!P->custom_edges.empty()) nb = (int)P->custom_edges.size() - 1;
+    const NkGeom g = geom_of(P, -shift_y / res_y, shift_x / res_x);
+    int rc = nk_stage_a<T>(P, g, 0, n, nb);
+    if (rc) return rc;
+    unsigned char info[32];
+    { const int rc_ = xd_d2h(ctx, info, base + OFF_INFO, 32); if (rc_) return rc_; }
+    { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+    uint64_t total;
+    double vs;
+    memcpy(&total, info + 8, 8);
+    memcpy(&vs, info + 24, 8);
+    ++P->n_plain;
+    *n_valid = (int64_t)total;
+    if (total == 0) return xd_fail(ctx, XDEMHIP_EINVAL, "The subsample contains no more valid values.");
+    *vshift = vs;
+    XD_HIP_CHECK(ctx, hipMemsetAsync(d_sums, 0, 16, ctx->stream));
+    hipLaunchKernelGGL((nk_y_kernel<T>), dim3(grid_for(ctx, n, 256, 16)), dim3(256), sizeof(T) * (nb + 1), ctx->stream, static_cast<const T*>(P->dh),
+                       static_cast<const T*>(P->slope_tan), static_cast<const T*>(P->aspect), n, (T)vs, d_edges, nb, static_cast<T*>(P->y), P->bins,
+                       d_sums, P->custom_edges.empty() ? NK_AUTO_EDGES : P->custom_decimal);
+    XD_HIP_CHECK(ctx, hipGetLastError());
+    P->bcache_force = true;   // (nothing here maintains the bin cache of the other routes)
+    std::vector<T> edges(nb + 1);
+    double sums[2];
+    { const int rc_ = xd_d2h(ctx, edges.data(), d_edges, sizeof(T) * (nb + 1)); if (rc_) return rc_; }
+    { const int rc_ = xd_d2h(ctx, sums, d_sums, 16); if (rc_) return rc_; }
+    const hipMemcpyKind kind = memspace == XDEMHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(y_out, P->y, (size_t)n * sizeof(T), kind, ctx->stream));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(bins_out, P->bins, (size_t)n * 2, kind, ctx->stream));
+    { const int rc_ = xd_sync(ctx); if (rc_) return rc_; }
+    const double cnt = (double)total, mean = sums[0] / cnt, var = sums[1] / cnt - mean * mean;
+    *y_mean = mean;
+    *y_std = var > 0 ? sqrt(var) : 0.0;
+    for (int k = 0; k <= nb; ++k) edges_out[k] = (double)edges[k];
+    return XDEMHIP_OK;
+}
+
 // Shared by the two creation entry points.  Buffers hold raster rows [roff, roff + nbuf); own rows [row0, row1).
 int nk_create_impl(xdemhip_ctx* ctx, const void* ref, const void* tba, const uint8_t* inlier, int dtype, int64_t H, int64_t W,
                    int64_t roff, int64_t nbuf, int64_t row0, int64_t row1, int memspace, bool global_count,
@@ -1672,6 +1722,27 @@ int xdemhip_nk_step_fit(xdemhip_nk_plan* P, double shift_x, double shift_y, doub
     int rc = P->dtype == XDEMHIP_F32
                  ? nk_step_typed<float>(P, shift_x, shift_y, res_x, res_y, 72, vshift, n_valid, y_mean, y_std, nullptr, nullptr, nullptr, sums)
                  : nk_step_typed<double>(P, shift_x, shift_y, res_x, res_y, 72, vshift, n_valid, y_mean, y_std, nullptr, nullptr, nullptr, sums);
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+    ctx->timed = (rc == XDEMHIP_OK);
+    return rc;
+}
+
+int xdemhip_nk_step_values(xdemhip_nk_plan* P, double shift_x, double shift_y, double res_x, double res_y, int n_bins, double* vshift,
+                           int64_t* n_valid, double* y_mean, double* y_std, double* edges, void* y_out, uint16_t* bins_out, int memspace) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (!vshift || !n_valid || !y_mean || !y_std || !edges || !y_out || !bins_out) return xd_fail(ctx, XDEMHIP_EINVAL, "null output");
+    if (!(res_x > 0) || !(res_y > 0)) return xd_fail(ctx, XDEMHIP_EINVAL, "resolution must be > 0");
+    if (memspace != XDEMHIP_HOST && memspace != XDEMHIP_DEVICE) return xd_fail(ctx, XDEMHIP_EINVAL, "memspace must be XDEMHIP_HOST or XDEMHIP_DEVICE");
+    if (n_bins < 1 || n_bins > P->max_bins) return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins out of range (1..1024)");
+    if (!P->custom_edges.empty() && n_bins != (int)P->custom_edges.size() - 1)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "n_bins must equal the number of explicit bin edges - 1 (xdemhip_nk_set_bin_edges)");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    const int rc = P->dtype == XDEMHIP_F32
+                       ? nk_step_values<float>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, y_out, bins_out, memspace)
+                       : nk_step_values<double>(P, shift_x, shift_y, res_x, res_y, n_bins, vshift, n_valid, y_mean, y_std, edges, y_out, bins_out, memspace);
     (void)hipEventRecord(ctx->ev_stop, ctx->stream);
     ctx->timed = (rc == XDEMHIP_OK);
     return rc;
