@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void nk_predict_kernel(const NkPredicted<T> pr,
         *klo_d = lo;
         *khi_d = hi;
         *rbs_d = rebase_shift_of(hi >= lo ? (K)(hi - lo) : (K)0);
-        T v, d;
+        T v = (T)0, d = (T)0;   // (an empty / reversed bracket raises the miss flag: the values are then never used)
         if (!(pr.dlo <= pr.dhi) || !nk_vhat_of<T>(1u, lo, hi, v, d)) ctr[3] = 1ull;
         *vhat = v;
         *delta = d;
@@ -248,8 +248,8 @@ template <typename T> struct NkzCap { static constexpr int v = sizeof(T) == 4 ? 
 template <typename T> struct FzPair { T lo, hi; };
 
 constexpr int NKZ_CHUNK_MAX = 256;   // rows of a workgroup's chunk (row-tap table in LDS)
-template <typename T, int RULE>   // (RULE 2 = rules 2 / 3 through the bad-bit mask: six more registers -> one workgroup per CU fewer instead of spills)
-__global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
+template <typename T, int RULE>   // (RULE 2 = rules 2 / 3 through the bad-bit mask: six more registers -> one workgroup per CU fewer instead of spills; float64 rasters: 5 / 4 -- what the allocator reaches)
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? (RULE == 2 ? 4 : 5) : (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB))) void nk_fused_kernel(const T* __restrict__ ref, const T* __restrict__ tba, const T* __restrict__ slope_tan,
                                                        const nk_bin_t* __restrict__ bcache, NkGeom g, int64_t row0, int64_t row1, int64_t nbuf,
                                                        int nb, int copies, const typename KeyT<T>::type* __restrict__ klo_p,
                                                        const typename KeyT<T>::type* __restrict__ khi_p, const T* vhat_p, const T* delta_p,
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, (RULE == 2 ? XD_NKZ_LB - 1 : XD_NKZ_LB)) void 
 #endif
     const uint32_t wbytes = (uint32_t)g.W * (uint32_t)sizeof(T), wbytes2 = (uint32_t)g.W * (uint32_t)sizeof(nk_bin_t);
     const uint32_t ob = jl * (uint32_t)sizeof(T), ob2 = jl * (uint32_t)sizeof(nk_bin_t);
-    auto tap_row = [&](int k) -> uint32_t { return (uint32_t)((k > k_base ? k : k_base) - k_base) * wbytes; };   // (scalar)
+    [[maybe_unused]] auto tap_row = [&](int k) -> uint32_t { return (uint32_t)((k > k_base ? k : k_base) - k_base) * wbytes; };   // (scalar)
     auto issue = [&](int rr, Pre& q) {  // rows past the chunk repeat its last row
         const int rc = rr < nrow ? rr : nrow - 1;
         const int tk = __builtin_amdgcn_readfirstlane(tab[rc].k0l), tf = __builtin_amdgcn_readfirstlane(tab[rc].flags);

@@ -833,7 +833,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     uint32_t* rbs_d = reinterpret_cast<uint32_t*>(fz + 8);
     uint32_t* rbs_y = reinterpret_cast<uint32_t*>(fz + 9);
     uint64_t* cnt_d = fz + 10;
-    uint64_t* given_d = fz + 13;
+    // (fz + 13: ranks of the dh selection, written and read on the device only)
     K* klo_d = reinterpret_cast<K*>(fz + 14);
     K* khi_d = reinterpret_cast<K*>(fz + 15);
     T* d_vhat = reinterpret_cast<T*>(fz + 16);
@@ -841,7 +841,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     double* d_sums = reinterpret_cast<double*>(fz + 18);
     K* klo_y = reinterpret_cast<K*>(fz + 24);
     K* khi_y = reinterpret_cast<K*>(fz + 24 + nbm);
-    uint64_t* given_y = fz + 24 + 2 * nbm;
+    // (fz + 24 + 2 * nbm: ranks of the bin selections, device only)
     uint64_t* cls_y = fz + 24 + 3 * nbm;
     uint64_t* res_y = fz + 24 + 6 * nbm;
     uint64_t* cnt_y = fz + 24 + 8 * nbm;
@@ -973,7 +973,6 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     if (!fused) hipLaunchKernelGGL((bracket_finish_kernel<K>), dim3(1), dim3(64), 0, ctx->stream, d_st, nb, 0, low_mask, klo_y, khi_y, rbs_y);
     XD_HIP_CHECK(ctx, hipGetLastError());
     }   // (sampled brackets)
-    const int nbb = (nb + 63) / 64;
     // 4. the one pass
     {
         dim3 grid = grid2d(ctx, P->W, rows);
