@@ -180,6 +180,36 @@ def test_step_callable_statistic_equals_scipy_binned_statistic(coreg, dtype):
             if nb == 72 and f.__name__ == "<lambda>" and "median" in f.__code__.co_names:
                 assert np.array_equal(det["medians"], exact["medians"], equal_nan=True)
     assert plan.route_counts()["plain"] >= 18
+    # the C-ABI entry with DEVICE buffers (what a caller holding torch tensors passes) returns the same arrays as with host buffers
+    import ctypes
+
+    import torch
+
+    L, dp = plan.ctx._L, ctypes.POINTER(ctypes.c_double)
+    outs = {}
+    for space in ("host", "device"):
+        if space == "host":
+            yb, bb = np.empty(ref.shape, dtype=dtype), np.empty(ref.shape, dtype=np.uint16)
+            yp, bp = yb.ctypes.data, bb.ctypes.data
+        else:
+            yb = torch.empty(ref.shape, dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
+            bb = torch.empty(ref.shape, dtype=torch.int16, device="cuda")
+            yp, bp = yb.data_ptr(), bb.data_ptr()
+        e = np.empty(73)
+        v = [ctypes.c_double() for _ in range(3)]
+        nv = ctypes.c_int64()
+        rc = L.xdemhip_nk_step_values(plan.handle, 17.3, -5.1, res, res, 72, ctypes.byref(v[0]), ctypes.byref(nv), ctypes.byref(v[1]), ctypes.byref(v[2]),
+                                      e.ctypes.data_as(dp), yp, bp, coreg._lib.HOST if space == "host" else coreg._lib.DEVICE)
+        assert rc == 0
+        if space == "device":
+            torch.cuda.synchronize()
+            yb, bb = yb.cpu().numpy(), bb.cpu().numpy().view(np.uint16)
+        outs[space] = (yb, bb, e.copy(), v[0].value, nv.value)
+    assert np.array_equal(outs["host"][0], outs["device"][0], equal_nan=True) and np.array_equal(outs["host"][1], outs["device"][1])
+    assert np.array_equal(outs["host"][2], outs["device"][2]) and outs["host"][3:] == outs["device"][3:] and outs["host"][3] == float(vshift)
+    # (NaN / 0xFFFF exactly where the pixel has no dh; every other pixel carries the oracle's y)
+    has = np.isfinite(outs["host"][0])
+    assert int(has.sum()) == int(ok.sum()) and np.array_equal(outs["host"][0][has], y) and np.all(outs["host"][1][~has] == 0xFFFF)
     # explicit edges that reach beyond [0, 2 pi): the outer bins stay empty -> statistic([]) where it exists (np.sum: 0), NaN otherwise
     if dtype == np.float32:
         edges = np.linspace(-1.5, 7.5, 19)
