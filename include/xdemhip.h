@@ -159,6 +159,24 @@ int xdemhip_set_allreduce(xdemhip_ctx* ctx, xdemhip_allreduce_fn fn, void* user)
 typedef int (*xdemhip_allreduce_device_fn)(void* device_array, int64_t count, int kind, void* hip_stream, void* user);
 int xdemhip_set_allreduce_device(xdemhip_ctx* ctx, xdemhip_allreduce_device_fn fn, void* user);
 int xdemhip_reduction_calls(xdemhip_ctx* ctx, int64_t* host_calls, int64_t* device_calls);
+/* ---- host-side preparation of the variogram path in native code (no context, no GPU: plain C++ on `threads` host threads) ----------
+ * xdem's default sampler of raster variograms is scikit-gstat's RasterEquidistantMetricSpace (xdem/spatialstats.py:1185-1260; un-vendored):
+ * per run a random centre, a centre disk and rings whose radii grow by sqrt(2), up to `samples` pixels of each, every centre-disk pixel
+ * paired with every ring pixel.  xdemhip_host_ring_sample draws, for `runs` centres (cx, cy: pixel column / row) and `n_rings` rings
+ * ring_lo[k] <= d < ring_hi[k] (distances in units of gsd x pixels, float64 arithmetic as NumPy forms them), up to `samples` distinct
+ * pixels of every ring uniformly without replacement -- valid[iy * nx + ix] != 0 only, if `valid` is given -- as flat indexes iy * nx + ix
+ * into out_idx[run][ring][0 .. out_count[run][ring]) (padded with -1; a ring that holds no more than `samples` pixels is returned whole,
+ * in raster order, any other in random order).  Every (run, ring) has its own random stream derived from `seed`: the result does not
+ * depend on `threads`.  Returns XDEMHIP_OK / XDEMHIP_EINVAL. */
+int xdemhip_host_ring_sample(const uint8_t* valid, int64_t ny, int64_t nx, double gsd, int64_t runs, const int64_t* cx, const int64_t* cy,
+                             int n_rings, const double* ring_lo, const double* ring_hi, int64_t samples, uint64_t seed, int threads,
+                             int64_t* out_idx, int64_t* out_count);
+/* Coordinates (x = ix gsd, y = iy gsd, float64) and values (`dtype` XDEMHIP_F32 / XDEMHIP_F64, gathered from the row-major raster
+ * `values` with `nx` columns) of `n_blocks` point sets given as flat pixel indexes idx[off[b] .. off[b + 1]), in the order given (x_out,
+ * y_out, v_out) and -- if sx_out is not NULL -- once more with every set permuted into Z-order over its own bounding box (sx_out, sy_out,
+ * sv_out: the slot order the pair kernels' run-length accumulation wants). */
+int xdemhip_host_gather_points(const void* values, int dtype, int64_t nx, double gsd, int n_blocks, const int64_t* off, const int64_t* idx,
+                               int threads, double* x_out, double* y_out, void* v_out, double* sx_out, double* sy_out, void* sv_out);
 /* This process's place among the ranks the hooks reduce over (round 5).  The hooks only combine; a few exchanges of the one-pass
  * Nuth-Kaab step on partitioned plans need every rank's contribution SEPARATELY (per-rank histogram rows, per-rank slices of a small
  * key list): they travel as sum all-reduces in which every rank fills its own slot and adds zeros to the others', for which the

@@ -617,3 +617,109 @@ def test_bin_statistic_dispatch():
     with pytest.raises(TypeError):
         coreg.NuthKaab(bin_statistic="percentile")
     assert coreg.NuthKaab(bin_statistic=np.nanstd).meta["inputs"]["fitorbin"]["bin_statistic"] is np.nanstd
+
+
+def test_native_ring_sampler_and_gather():
+    """csrc/hostprep.hip (host-only native code of the variogram path; no GPU): xdemhip_host_ring_sample draws what the NumPy form
+    `_draw_ring_pixels` specifies -- distinct valid members of each ring, as many as asked or the whole ring (then in raster order,
+    identical to the enumeration), uniformly over the ring, the same for any number of threads -- and xdemhip_host_gather_points
+    returns coordinates and values in the order given and in Morton order (a permutation of the same points that sorts their Z-order
+    keys).  `equidistant_blocks_from_raster` on the native path: the block structure of the NumPy path."""
+    import ctypes
+
+    from xdem_amd import _lib
+    from xdem_amd import spatialstats as ss
+
+    L = _lib.host_library()
+    i64p, dp = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
+    rng = np.random.default_rng(1)
+    ny, nx, gsd = 300, 420, 2.0
+    v = rng.normal(size=(ny, nx)).astype(np.float32)
+    v[50:80, 100:200] = np.nan
+    valid = np.isfinite(v)
+    iy, ix = np.mgrid[0:ny, 0:nx]
+    cases = [(10, 10, 0.0, 30.0, 50), (200, 150, 100.0, 160.0, 20000), (419, 299, 37.5, 400.0, 300), (5, 290, 250.0, 1000.0, 10**5),
+             (100, 100, 0.0, 3.0, 100), (0, 0, 2000.0, 3000.0, 10), (210, 150, 100.0, 160.0, 200)]
+
+    def sample(cxs, cys, los, his, n, seed, threads, mask=valid):
+        cx, cy = np.ascontiguousarray(cxs, dtype=np.int64), np.ascontiguousarray(cys, dtype=np.int64)
+        lo, hi = np.ascontiguousarray(los, dtype=np.float64), np.ascontiguousarray(his, dtype=np.float64)
+        out = np.empty((cx.size, lo.size, n), dtype=np.int64)
+        cnt = np.empty((cx.size, lo.size), dtype=np.int64)
+        m8 = None if mask is None else np.ascontiguousarray(mask).view(np.uint8)
+        rc = L.xdemhip_host_ring_sample(None if m8 is None else m8.ctypes.data, ny, nx, gsd, cx.size, cx.ctypes.data_as(i64p), cy.ctypes.data_as(i64p),
+                                        lo.size, lo.ctypes.data_as(dp), hi.ctypes.data_as(dp), n, ctypes.c_uint64(seed), threads,
+                                        out.ctypes.data_as(i64p), cnt.ctypes.data_as(i64p))
+        assert rc == 0
+        return out, cnt
+
+    for cx, cy, lo, hi, n in cases:
+        out, cnt = sample([cx], [cy], [lo], [hi], n, 3, 1)
+        got = out[0, 0, :cnt[0, 0]]
+        assert np.all(out[0, 0, cnt[0, 0]:] == -1)
+        d = np.sqrt(((ix - cx) * gsd) ** 2 + ((iy - cy) * gsd) ** 2)
+        full = np.flatnonzero((valid & (d >= lo) & (d < hi)).ravel())
+        assert np.unique(got).size == got.size and np.isin(got, full).all() and got.size == min(n, full.size), (cx, cy, lo, hi, n)
+        if n >= full.size:
+            assert np.array_equal(got, full)   # the whole ring, in raster order
+    # many (run, ring) jobs: independent of the number of threads; different seeds differ
+    cxs, cys = rng.integers(0, nx, 9), rng.integers(0, ny, 9)
+    los, his = [0.0, 0.0, 40.0, 80.0, 160.0], [40.0, 40.0, 80.0, 160.0, 320.0]
+    o1, c1 = sample(cxs, cys, los, his, 150, 77, 1)
+    o4, c4 = sample(cxs, cys, los, his, 150, 77, 4)
+    assert np.array_equal(o1, o4) and np.array_equal(c1, c4)
+    assert not np.array_equal(o1, sample(cxs, cys, los, his, 150, 78, 4)[0])
+    assert not np.array_equal(o1[:, 0], o1[:, 1])   # (the centre disk and the first ring: same bounds, streams of their own)
+    # uniformity: 400 seeds x 200 of a ring of ~12000 pixels hit every octant of the ring about equally
+    cx, cy, lo, hi = 210, 150, 100.0, 160.0
+    hits = np.zeros(8)
+    for seed in range(400):
+        g = sample([cx], [cy], [lo], [hi], 200, seed, 1, mask=None)[0][0, 0]
+        ang = np.arctan2((g // nx) - cy, (g % nx) - cx)
+        hits += np.bincount(((ang + np.pi) / (2 * np.pi) * 8).astype(int) % 8, minlength=8)
+    assert hits.sum() == 400 * 200 and np.all(np.abs(hits / hits.mean() - 1) < 0.05)
+    # bad arguments
+    assert L.xdemhip_host_ring_sample(None, ny, nx, gsd, 1, np.array([nx], dtype=np.int64).ctypes.data_as(i64p), np.array([0], dtype=np.int64).ctypes.data_as(i64p),
+                                      1, np.array([0.0]).ctypes.data_as(dp), np.array([5.0]).ctypes.data_as(dp), 5, ctypes.c_uint64(1), 1,
+                                      np.empty(5, dtype=np.int64).ctypes.data_as(i64p), np.empty(1, dtype=np.int64).ctypes.data_as(i64p)) == -1
+    # gather: order given and Morton order
+    for dtype in (np.float32, np.float64):
+        vals = rng.normal(size=(ny, nx)).astype(dtype)
+        off = np.array([0, 5, 5, 2005, 2007], dtype=np.int64)
+        flat = rng.choice(ny * nx, 2007, replace=False).astype(np.int64)
+        o = [np.empty(2007), np.empty(2007), np.empty(2007, dtype=dtype), np.empty(2007), np.empty(2007), np.empty(2007, dtype=dtype)]
+        rc = L.xdemhip_host_gather_points(vals.ctypes.data, _lib.F32 if dtype == np.float32 else _lib.F64, nx, gsd, 4, off.ctypes.data_as(i64p),
+                                          flat.ctypes.data_as(i64p), 3, o[0].ctypes.data_as(dp), o[1].ctypes.data_as(dp), o[2].ctypes.data,
+                                          o[3].ctypes.data_as(dp), o[4].ctypes.data_as(dp), o[5].ctypes.data)
+        assert rc == 0
+        assert np.array_equal(o[0], (flat % nx) * gsd) and np.array_equal(o[1], (flat // nx) * gsd) and np.array_equal(o[2], vals.reshape(-1)[flat])
+        for b in range(4):
+            sl = slice(off[b], off[b + 1])
+            key = lambda x, y, val: sorted(zip(x.tolist(), y.tolist(), val.tolist()))
+            assert key(o[0][sl], o[1][sl], o[2][sl]) == key(o[3][sl], o[4][sl], o[5][sl])   # a permutation of the same points
+            if sl.stop - sl.start >= 3:
+                order = ss._morton_order(o[3][sl], o[4][sl])
+                x, y = o[3][sl], o[4][sl]
+                qx = ((x - x.min()) * (65535.0 / (x.max() - x.min()))).astype(np.uint32)
+                qy = ((y - y.min()) * (65535.0 / (y.max() - y.min()))).astype(np.uint32)
+                code = sum(((qx >> k) & 1).astype(np.uint64) << np.uint64(2 * k) | ((qy >> k) & 1).astype(np.uint64) << np.uint64(2 * k + 1) for k in range(16))
+                assert np.all(np.diff(code.astype(np.int64)) >= 0) and order is not None
+    # the product's sampler on the native path: block structure of the NumPy path (centre disk x rings, inner to outer, values of the pixels)
+    centres, centres_np = [], []
+    blocks = ss.equidistant_blocks_from_raster(v, gsd, 3, 30, 0.002, np.random.default_rng(9), centres_out=centres)
+    blocks_np = ss.equidistant_blocks_from_raster(v, gsd, 3, 30, 0.002, np.random.default_rng(9), centres_out=centres_np, native=False)
+    assert type(blocks).__name__ == "_Blocks" and blocks.packed is not None and blocks.packed_sorted is not None and centres == centres_np
+    maxlag = float(np.hypot((nx - 1) * gsd, (ny - 1) * gsd))
+    r0, radii = ss._equidistant_radii(30, 0.002, gsd, maxlag)
+    assert len(blocks) == len(blocks_np) == 3
+    for (ax, ay, av, bx, by, bv), (cxi, cyi), other in zip(blocks, centres, blocks_np):
+        assert ax.size == other[0].size and bx.size == other[3].size
+        assert np.array_equal(av, v[(ay / gsd).astype(int), (ax / gsd).astype(int)]) and np.isfinite(av).all() and np.isfinite(bv).all()
+        assert np.all(np.hypot(ax - cxi * gsd, ay - cyi * gsd) < r0)
+        k = np.digitize(np.hypot(bx - cxi * gsd, by - cyi * gsd), radii) - 1
+        assert np.all(np.diff(k) >= 0)
+        assert np.array_equal(np.bincount(k, minlength=len(radii) - 1), np.bincount(np.digitize(np.hypot(other[3] - cxi * gsd, other[4] - cyi * gsd), radii) - 1, minlength=len(radii) - 1))
+    # packed arrays = the blocks, concatenated
+    a_off, pax, pay, pav, b_off, pbx, pby, pbv = blocks.packed
+    assert np.array_equal(pax, np.concatenate([b[0] for b in blocks])) and np.array_equal(pbv, np.concatenate([b[5] for b in blocks]))
+    assert a_off[-1] == pax.size and b_off[-1] == pbx.size

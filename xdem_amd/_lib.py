@@ -51,6 +51,16 @@ class XdemHipError(RuntimeError):
     """Raised for any non-zero status from libxdemhip.so."""
 
 
+def host_library(required: bool = True):
+    """The library for its HOST-side entry points (csrc/hostprep.hip: no context, no GPU needed); None if it is missing and not required."""
+    try:
+        return lib()
+    except XdemHipError:
+        if required:
+            raise
+        return None
+
+
 def lib() -> ctypes.CDLL:
     """Load (once) and return the shared library with argtypes declared."""
     global _lib
@@ -120,6 +130,10 @@ def lib() -> ctypes.CDLL:
         L.xdemhip_nk_set_rows.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_i64p]
         L.xdemhip_nk_set_statistic.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_nk_route_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p]
+        L.xdemhip_host_ring_sample.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_int64, c_i64p, c_i64p,
+                                               ctypes.c_int, c_dp, c_dp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int, c_i64p, c_i64p]
+        L.xdemhip_host_gather_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_int, c_i64p, c_i64p,
+                                                 ctypes.c_int, c_dp, c_dp, ctypes.c_void_p, c_dp, c_dp, ctypes.c_void_p]
         L.xdemhip_nk_step_values.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                              c_dp, c_i64p, c_dp, c_dp, c_dp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_nk_predict_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p, c_i64p]

@@ -21,6 +21,10 @@
 #include <string.h>
 
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <algorithm>
+#include <sched.h>
 
 #include <stdio.h>
 #include <time.h>
@@ -1050,40 +1054,99 @@ struct GridInfo {
     std::vector<uint8_t> lut;
     int emin = 0;
 };
+// (host threads of the scans below: the cores this process may use, at most 16; XDEM_HOST_THREADS overrides -- the same rule as
+//  xdem_amd/spatialstats.py: _host_threads)
+static int host_threads() {
+    if (const char* e = getenv("XDEM_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return v; }
+    cpu_set_t set;
+    int n = 1;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+// f(first, last, thread) over [0, n) cut into one contiguous piece per thread
+template <class F> static void host_chunks(int64_t n, int threads, F f) {
+    threads = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (n + (1 << 16) - 1) >> 16));   // (pieces of at least 64 K elements)
+    if (threads == 1) { f((int64_t)0, n, 0); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back([=]() { f(n * t / threads, n * (t + 1) / threads, t); });
+    for (auto& th : pool) th.join();
+}
+
 bool make_grid(const double* ax, const double* ay, int64_t na, const double* bx, const double* by, int64_t nbt, const std::vector<double>& thr,
                GridInfo& out) {
-    auto scan = [&](auto&& f) {
-        for (int64_t i = 0; i < na; ++i) { if (!f(ax[i], 0) || !f(ay[i], 1)) return false; }
-        for (int64_t i = 0; i < nbt; ++i) { if (!f(bx[i], 0) || !f(by[i], 1)) return false; }
-        return true;
-    };
+    // The scans run over every coordinate of the set (6e8 values for SURVEY 8d's C5 reading A): each is a reduction -- all-of, min, gcd,
+    // max -- done in pieces on the host's threads and combined.
+    const int T = host_threads();
+    const double* arr[4] = {ax, ay, bx, by};
+    const int64_t len[4] = {na, na, bx ? nbt : 0, by ? nbt : 0};
     if (na + nbt == 0) return false;
     // 1. a power-of-two scale that makes every coordinate an integer below 2^52
     int k = -1;
     for (int kk = 0; kk <= 20 && k < 0; ++kk) {
         const double sc = ldexp(1.0, kk);
-        if (scan([&](double v, int) { const double w = v * sc; return std::isfinite(v) && fabs(w) < 4.5e15 && w == floor(w); })) k = kk;
+        std::atomic<int> bad(0);
+        for (int q = 0; q < 4; ++q)
+            host_chunks(len[q], T, [&, q](int64_t i0, int64_t i1, int) {
+                const double* v = arr[q];
+                bool ok = true;
+                for (int64_t i = i0; i < i1 && ok; ++i) { const double w = v[i] * sc; ok = std::isfinite(v[i]) && fabs(w) < 4.5e15 && w == floor(w); }
+                if (!ok) bad.store(1);
+            });
+        if (!bad.load()) k = kk;
     }
     if (k < 0) return false;
     const double sc = ldexp(1.0, k);
     double mn[2] = {INFINITY, INFINITY};
-    scan([&](double v, int ax_) { const double w = v * sc; mn[ax_] = w < mn[ax_] ? w : mn[ax_]; return true; });
-    // 2. lattice constant: gcd of all offsets from the minima
-    unsigned long long G = 0;
+    for (int q = 0; q < 4; ++q) {
+        std::vector<double> part((size_t)T, INFINITY);
+        host_chunks(len[q], T, [&, q](int64_t i0, int64_t i1, int t) {
+            const double* v = arr[q];
+            double m = INFINITY;
+            for (int64_t i = i0; i < i1; ++i) { const double w = v[i] * sc; m = w < m ? w : m; }
+            part[(size_t)t] = m;
+        });
+        for (double m : part) mn[q & 1] = m < mn[q & 1] ? m : mn[q & 1];
+    }
+    // 2. lattice constant: gcd of all offsets from the minima; 3. index range
     auto gcd = [](unsigned long long a_, unsigned long long b_) { while (b_) { const unsigned long long t = a_ % b_; a_ = b_; b_ = t; } return a_; };
-    scan([&](double v, int ax_) { G = gcd(G, (unsigned long long)(v * sc - mn[ax_])); return true; });
+    unsigned long long G = 0;
+    for (int q = 0; q < 4; ++q) {
+        std::vector<unsigned long long> part((size_t)T, 0ull);
+        host_chunks(len[q], T, [&, q](int64_t i0, int64_t i1, int t) {
+            const double* v = arr[q];
+            const double m0 = mn[q & 1];
+            unsigned long long g = 0;
+            for (int64_t i = i0; i < i1; ++i) {
+                const unsigned long long u = (unsigned long long)(v[i] * sc - m0);
+                if (g != 1 && (g == 0 || u % g != 0)) g = gcd(g, u);   // (most offsets are multiples of the running gcd: one modulo each)
+            }
+            part[(size_t)t] = g;
+        });
+        for (unsigned long long g : part) G = gcd(G, g);
+    }
     if (G == 0) G = 1;
-    // 3. index range and exactness of the float64 arithmetic on these points
     unsigned long long imax = 0;
-    scan([&](double v, int ax_) { const unsigned long long i = (unsigned long long)(v * sc - mn[ax_]) / G; imax = i > imax ? i : imax; return true; });
+    for (int q = 0; q < 4; ++q) {
+        std::vector<unsigned long long> part((size_t)T, 0ull);
+        host_chunks(len[q], T, [&, q](int64_t i0, int64_t i1, int t) {
+            const double* v = arr[q];
+            const double m0 = mn[q & 1];
+            unsigned long long m = 0;
+            for (int64_t i = i0; i < i1; ++i) { const unsigned long long u = (unsigned long long)(v[i] * sc - m0) / G; m = u > m ? u : m; }
+            part[(size_t)t] = m;
+        });
+        for (unsigned long long m : part) imax = m > imax ? m : imax;
+    }
     if (imax > 32767ull) return false;
     if ((long double)G * (long double)imax >= 67108864.0L) return false;  // (G dx)^2 + (G dy)^2 < 2^53
     auto pack = [&](const double* x, const double* y, int64_t n, std::vector<uint32_t>& o) {
         o.resize((size_t)n);
-        for (int64_t i = 0; i < n; ++i) {
-            const uint32_t ix = (uint32_t)((unsigned long long)(x[i] * sc - mn[0]) / G), iy = (uint32_t)((unsigned long long)(y[i] * sc - mn[1]) / G);
-            o[(size_t)i] = ix | (iy << 16);
-        }
+        host_chunks(n, T, [&](int64_t i0, int64_t i1, int) {
+            for (int64_t i = i0; i < i1; ++i) {
+                const uint32_t ix = (uint32_t)((unsigned long long)(x[i] * sc - mn[0]) / G), iy = (uint32_t)((unsigned long long)(y[i] * sc - mn[1]) / G);
+                o[(size_t)i] = ix | (iy << 16);
+            }
+        });
     };
     pack(ax, ay, na, out.a_xy);
     if (bx) pack(bx, by, nbt, out.b_xy);

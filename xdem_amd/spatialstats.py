@@ -31,6 +31,32 @@ from . import _lib
 _ESTIMATORS = ("matheron", "cressie", "dowd")
 
 
+def _host_threads() -> int:
+    """Threads of the host-side preparation (sampling runs, Morton orders of the pair blocks): the cores this process may use,
+    at most 16; XDEM_HOST_THREADS overrides (1 = serial)."""
+    import os
+
+    env = os.environ.get("XDEM_HOST_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def _host_map(fn, jobs: list) -> list:
+    """`[fn(j) for j in jobs]` on a pool of host threads, results in job order (the jobs are NumPy-bound and independent)."""
+    n = min(_host_threads(), len(jobs))
+    if n <= 1:
+        return [fn(j) for j in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=n) as pool:
+        return list(pool.map(fn, jobs))
+
+
 def _morton_order(x: np.ndarray, y: np.ndarray) -> np.ndarray | None:
     """Permutation that sorts the points along a Z-order curve over their bounding box (16 bits per axis)."""
     if x.size < 3:
@@ -39,18 +65,21 @@ def _morton_order(x: np.ndarray, y: np.ndarray) -> np.ndarray | None:
         fin = np.isfinite(x) & np.isfinite(y)
     if not fin.all():
         return None
-    spanx, spany = float(x.max() - x.min()), float(y.max() - y.min())
-    qx = ((x - x.min()) * (65535.0 / spanx if spanx > 0 else 0.0)).astype(np.uint64)
-    qy = ((y - y.min()) * (65535.0 / spany if spany > 0 else 0.0)).astype(np.uint64)
+    x0, y0 = x.min(), y.min()
+    spanx, spany = float(x.max() - x0), float(y.max() - y0)
+    qx = ((x - x0) * (65535.0 / spanx if spanx > 0 else 0.0)).astype(np.uint32)
+    qy = ((y - y0) * (65535.0 / spany if spany > 0 else 0.0)).astype(np.uint32)
 
     def spread(v):
-        v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF)
-        v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F)
-        v = (v | (v << np.uint64(2))) & np.uint64(0x33333333)
-        v = (v | (v << np.uint64(1))) & np.uint64(0x55555555)
+        v = (v | (v << np.uint32(8))) & np.uint32(0x00FF00FF)
+        v = (v | (v << np.uint32(4))) & np.uint32(0x0F0F0F0F)
+        v = (v | (v << np.uint32(2))) & np.uint32(0x33333333)
+        v = (v | (v << np.uint32(1))) & np.uint32(0x55555555)
         return v
 
-    return np.argsort(spread(qx) | (spread(qy) << np.uint64(1)), kind="stable")
+    # (32-bit keys and NumPy's default sort -- the vectorised quicksort, 5x the stable merge sort on 3e5 keys; points that share a
+    #  cell of the 65536^2 grid may come out in either order, which the pair sums and medians do not depend on)
+    return np.argsort(spread(qx) | (spread(qy) << np.uint32(1)))
 
 
 def _morton_sorted_block(b: tuple) -> tuple:
@@ -63,6 +92,66 @@ def _morton_sorted_block(b: tuple) -> tuple:
         if o is not None:
             out[k], out[k + 1], out[k + 2] = (np.asarray(out[k]).ravel()[o], np.asarray(out[k + 1]).ravel()[o], np.asarray(out[k + 2]).ravel()[o])
     return tuple(out)
+
+
+class _Blocks(list):
+    """A list of pair blocks that also carries them PACKED -- the concatenated arrays and offsets `xdemhip_pairs_create` takes --
+    in the caller's order (`packed`) and in Morton order (`packed_sorted`): what the native sampler produces in one go, so that
+    PairSet neither concatenates nor sorts again."""
+    packed = None
+    packed_sorted = None
+
+
+def _native_equidistant_blocks(values2d: np.ndarray, valid2d, gsd: float, centres: list, rings: list, samples: int, seed: int) -> "_Blocks":
+    """The draws of `equidistant_blocks_from_raster` by the library's host-side sampler (csrc/hostprep.hip: xdemhip_host_ring_sample, one
+    random stream per (run, ring), std::threads over them) + the gather of coordinates and values, once in the order drawn and once
+    in Morton order (xdemhip_host_gather_points).  rings[0] is the centre disk, rings[1:] the B rings, inner to outer."""
+    L = _lib.host_library()
+    ny, nx = values2d.shape
+    runs, nr, thr = len(centres), len(rings), _host_threads()
+    cx = np.ascontiguousarray([c[0] for c in centres], dtype=np.int64)
+    cy = np.ascontiguousarray([c[1] for c in centres], dtype=np.int64)
+    lo = np.ascontiguousarray([r[0] for r in rings], dtype=np.float64)
+    hi = np.ascontiguousarray([r[1] for r in rings], dtype=np.float64)
+    idx = np.empty((runs, nr, samples), dtype=np.int64)
+    cnt = np.empty((runs, nr), dtype=np.int64)
+    vmask = None if valid2d is None else np.ascontiguousarray(valid2d, dtype=np.bool_).view(np.uint8)
+    i64p, dp = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)
+    rc = L.xdemhip_host_ring_sample(None if vmask is None else vmask.ctypes.data, ny, nx, float(gsd), runs, cx.ctypes.data_as(i64p),
+                                    cy.ctypes.data_as(i64p), nr, lo.ctypes.data_as(dp), hi.ctypes.data_as(dp), int(samples),
+                                    ctypes.c_uint64(seed & (2**64 - 1)), thr, idx.ctypes.data_as(i64p), cnt.ctypes.data_as(i64p))
+    if rc != 0:
+        raise _lib.XdemHipError(f"xdemhip_host_ring_sample: status {rc}")
+    # runs whose centre disk or rings came out empty are dropped (as the NumPy form drops them)
+    na, nb = cnt[:, 0], cnt[:, 1:].sum(axis=1)
+    keep = np.flatnonzero((na > 0) & (nb > 0))
+    a_idx = np.concatenate([idx[r, 0, :na[r]] for r in keep]) if keep.size else np.empty(0, dtype=np.int64)
+    b_idx = (np.concatenate([idx[r, k, :cnt[r, k]] for r in keep for k in range(1, nr)]) if keep.size else np.empty(0, dtype=np.int64))
+    a_off = np.concatenate(([0], np.cumsum(na[keep]))).astype(np.int64)
+    b_off = np.concatenate(([0], np.cumsum(nb[keep]))).astype(np.int64)
+    vals = np.ascontiguousarray(values2d)
+    dt = _lib.F32 if vals.dtype == np.float32 else _lib.F64
+
+    def gather(off, flat):   # -> (x, y, v) in the order drawn, (x, y, v) in Morton order
+        outs = [np.empty(flat.size, dtype=np.float64), np.empty(flat.size, dtype=np.float64), np.empty(flat.size, dtype=vals.dtype),
+                np.empty(flat.size, dtype=np.float64), np.empty(flat.size, dtype=np.float64), np.empty(flat.size, dtype=vals.dtype)]
+        rc_ = L.xdemhip_host_gather_points(vals.ctypes.data, dt, nx, float(gsd), int(off.size - 1), off.ctypes.data_as(i64p),
+                                           flat.ctypes.data_as(i64p), thr, outs[0].ctypes.data_as(dp), outs[1].ctypes.data_as(dp),
+                                           outs[2].ctypes.data, outs[3].ctypes.data_as(dp), outs[4].ctypes.data_as(dp), outs[5].ctypes.data)
+        if rc_ != 0:
+            raise _lib.XdemHipError(f"xdemhip_host_gather_points: status {rc_}")
+        return outs
+
+    out = _Blocks()
+    ax, ay, av, sax, say, sav = gather(a_off, a_idx)
+    bx, by, bv, sbx, sby, sbv = gather(b_off, b_idx)
+    out.packed = (a_off, ax, ay, av, b_off, bx, by, bv)
+    out.packed_sorted = (a_off, sax, say, sav, b_off, sbx, sby, sbv)
+    for k in range(keep.size):
+        sa, sb = slice(a_off[k], a_off[k + 1]), slice(b_off[k], b_off[k + 1])
+        out.append((ax[sa], ay[sa], av[sa], bx[sb], by[sb], bv[sb]))
+    out.kept_runs = keep
+    return out
 
 
 class PairSet:
@@ -101,10 +190,13 @@ class PairSet:
         self.vdtype = np.dtype(vdt)
         self.key_bits = 32 if vdt == np.float32 else 64
 
-        def create(bl, vdt=vdt):
-            keep = [off(0), cat(bl, 0, np.float64), cat(bl, 1, np.float64), cat(bl, 2, vdt)]
-            if not pd:
-                keep += [off(3), cat(bl, 3, np.float64), cat(bl, 4, np.float64), cat(bl, 5, vdt)]
+        def create(bl, vdt=vdt, packed=None):
+            if packed is not None and not pd and packed[3].dtype == np.dtype(vdt):
+                keep = [np.ascontiguousarray(a) for a in packed]
+            else:
+                keep = [off(0), cat(bl, 0, np.float64), cat(bl, 1, np.float64), cat(bl, 2, vdt)]
+                if not pd:
+                    keep += [off(3), cat(bl, 3, np.float64), cat(bl, 4, np.float64), cat(bl, 5, vdt)]
             p = [a.ctypes.data for a in keep] + ([None] * 4 if pd else [])
             h, n_pairs = ctypes.c_void_p(), ctypes.c_int64()
             self.ctx.check(self.ctx._L.xdemhip_pairs_create(
@@ -115,10 +207,13 @@ class PairSet:
 
         self.handle = self.handle_sel = None
         self.shadow = self.shadow_sel = None
-        self.handle_sel, self.n_pairs = create(blocks)
+        self.handle_sel, self.n_pairs = create(blocks, packed=getattr(blocks, "packed", None))
         if self.ctx.options.get("vario_sort", 1):
             try:
-                self.handle, n2 = create([_morton_sorted_block(b) for b in blocks])
+                if getattr(blocks, "packed_sorted", None) is not None and not pd:
+                    self.handle, n2 = create(blocks, packed=blocks.packed_sorted)
+                else:
+                    self.handle, n2 = create(_host_map(_morton_sorted_block, list(blocks)))
             except Exception:
                 self.close()
                 raise
@@ -474,6 +569,7 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
         list_random_state = [None for _ in range(n_variograms)]
 
     valid = np.isfinite(values)
+    all_valid = bool(valid.all())
     list_df_run = []
     for i in range(n_variograms):
         run_rng = np.random.default_rng(list_random_state[i])
@@ -492,7 +588,8 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
                 blocks = equidistant_blocks_from_coords(coords, values, valid, gsd, runs, samples, ratio, run_rng)
             else:  # full raster, indexed (values.shape[0] along x) like upstream's meshgrid call
                 blocks = equidistant_blocks_from_raster(values.reshape(shape2d[1], shape2d[0]), gsd, runs, samples, ratio, run_rng,
-                                                        valid2d=None if valid.all() else valid.reshape(shape2d[1], shape2d[0]))
+                                                        valid2d=None if all_valid else valid.reshape(shape2d[1], shape2d[0]),
+                                                        assume_valid=all_valid)
         elif subsample_method == "cdist_point":
             idx = np.flatnonzero(valid)
             n = min(int(subsample), idx.size)
@@ -688,9 +785,12 @@ def _draw_ring_pixels(valid2d, ny: int, nx: int, cxi: int, cyi: int, lo: float, 
                       rng: np.random.Generator) -> np.ndarray:
     """Up to `samples` distinct valid pixels (flat indexes iy * nx + ix) with lo <= distance to pixel (cxi, cyi) < hi, drawn
     uniformly without replacement, without forming the distance of every raster pixel (4e8 of them at 20000^2).  Per raster row
-    the ring is two column spans known in closed form (taken one pixel generous); a uniform draw over the concatenated spans,
-    filtered by the exact distance test and the validity mask, is a uniform draw over the ring; the first occurrences of
-    independent draws are a uniform sample without replacement.  Small rings are enumerated instead."""
+    the ring is two column spans known in closed form (taken one pixel generous); independent uniform draws over the
+    concatenated spans, filtered by the exact distance test and the validity mask, are independent uniform draws over the ring;
+    the SET of distinct pixels among them is exchangeable over the ring's pixels, so a uniformly random subset of it of the wanted
+    size is a uniform sample without replacement (returned in random order).  The draws are sorted before they are mapped to
+    pixels (sorted look-ups into the span table run 4x faster than random ones, and duplicates fall out by comparing neighbours).
+    Small rings are enumerated instead."""
     reach = int(np.floor(hi / gsd)) + 1
     y0, y1 = max(0, cyi - reach), min(ny - 1, cyi + reach)
     if y1 < y0:
@@ -733,19 +833,21 @@ def _draw_ring_pixels(valid2d, ny: int, nx: int, cxi: int, cyi: int, lo: float, 
 
     if total <= max(1 << 16, 4 * samples):
         return enumerate_all()
-    kept = np.empty(0, dtype=np.int64)
+    kept = np.empty(0, dtype=np.int64)    # distinct ring pixels met so far, ascending
     batch = int(1.3 * samples) + 64
     drawn = accepted = 0
     for _ in range(16):
-        ix, iy = pixels(rng.integers(0, total, batch))
+        k = rng.integers(0, total, batch)
+        k.sort()
+        k = k[np.concatenate(([True], k[1:] != k[:-1]))]
+        ix, iy = pixels(k)
         ok = exact(ix, iy)
         drawn += batch
         accepted += int(ok.sum())
-        cand = np.concatenate([kept, iy[ok] * nx + ix[ok]])
-        _, first = np.unique(cand, return_index=True)
-        kept = cand[np.sort(first)]
+        new = iy[ok] * nx + ix[ok]          # (ascending: rows ascend with k, within a row the left span lies left of the right one)
+        kept = new if kept.size == 0 else np.union1d(kept, new)
         if kept.size >= samples:
-            return kept[:samples]
+            return rng.choice(kept, samples, replace=False)
         if accepted * (total / drawn) < 1.5 * samples:   # about as many (valid) ring pixels as wanted, or fewer: take them all
             return enumerate_all()
         batch = int(min(4e7, 1.5 * (samples - kept.size) * drawn / max(accepted, 1))) + 64
@@ -755,35 +857,62 @@ def _draw_ring_pixels(valid2d, ny: int, nx: int, cxi: int, cyi: int, lo: float, 
 def equidistant_blocks_from_raster(values2d: np.ndarray, gsd: float, runs: int, samples: int, ratio_subsample: float,
                                    rng: np.random.Generator, valid2d: np.ndarray | None = None,
                                    exp_increase_fac: float = np.sqrt(2), values_of=None, shape=None,
-                                   centres_out: list | None = None) -> list[tuple]:
+                                   centres_out: list | None = None, native: bool | None = None, assume_valid: bool = False) -> list[tuple]:
     """The centre-disk x equidistant-ring scheme of `equidistant_blocks_from_coords` for a full raster (pixel (iy, ix) at
     x = ix gsd, y = iy gsd), drawn ring by ring without forming the distance of every pixel to the centre: same disk and ring
     definitions (centre sample = valid pixels with d < r0; rings [0, r0), [r0, r0 f), ... the last one ending at the extent
     diagonal; up to `samples` pixels of each), uniform without replacement.  RNG protocol: centre by rejection among the
     valid pixels, then `_draw_ring_pixels` for the centre sample and for each ring, inner to outer.  `values_of(flat_idx)`
     may supply the values (e.g. a gather from a device-resident raster; then `values2d` may be None and `shape` = (ny, nx)
-    names the raster)."""
+    names the raster).  With a host raster the draws, the gather and the Morton-ordered copies the pair kernels want are made by the
+    library's native host code on all cores (csrc/hostprep.hip; `native=False` keeps the NumPy form below, which is its
+    specification: same rings, same uniform-without-replacement law, other random streams)."""
     ny, nx = values2d.shape if values2d is not None else (valid2d.shape if valid2d is not None else shape)
     maxdist = np.sqrt(((nx - 1) * gsd) ** 2 + ((ny - 1) * gsd) ** 2)
     r0, radii = _equidistant_radii(samples, ratio_subsample, gsd, maxdist, exp_increase_fac)
-    if valid2d is None and values2d is not None:
+    if valid2d is None and values2d is not None and not assume_valid:   # (assume_valid: the caller has looked already)
         valid2d = np.isfinite(values2d)
         if valid2d.all():
             valid2d = None
     get = values_of if values_of is not None else (lambda idx: values2d.reshape(-1)[idx])
-    blocks = []
+    # RNG protocol (round 6): the centres of all runs first, from `rng`; then one child generator per run (`rng.spawn`), so that
+    # the runs -- independent of each other -- are drawn by a pool of host threads (NumPy releases the GIL in the sorts, look-ups
+    # and gathers that make up a draw) and still come out the same for the same seed whatever the number of threads
+    centres = []
     for _ in range(runs):
         for _try in range(10000):
             cyi, cxi = int(rng.integers(0, ny)), int(rng.integers(0, nx))
             if valid2d is None or valid2d[cyi, cxi]:
                 break
         else:
-            return blocks  # (practically) no valid pixel
-        a = _draw_ring_pixels(valid2d, ny, nx, cxi, cyi, 0.0, r0, gsd, samples, rng)
-        sets = [_draw_ring_pixels(valid2d, ny, nx, cxi, cyi, lo, hi, gsd, samples, rng) for lo, hi in zip(radii[:-1], radii[1:])]
+            break  # (practically) no valid pixel
+        centres.append((cxi, cyi))
+    if (native is not False and values_of is None and values2d is not None and values2d.dtype in (np.dtype(np.float32), np.dtype(np.float64))
+            and centres and _lib.host_library(required=False) is not None):
+        # the library's host-side sampler: same rings, same distribution, its own random streams seeded from `rng`
+        rings = [(0.0, r0)] + list(zip(radii[:-1], radii[1:]))
+        blocks = _native_equidistant_blocks(values2d, valid2d, gsd, centres, rings, samples, int(rng.integers(0, 2**63)))
+        if centres_out is not None:
+            centres_out.extend(centres[k] for k in blocks.kept_runs)
+        return blocks
+    try:
+        children = rng.spawn(len(centres))
+    except (AttributeError, TypeError):   # (a Generator over a bit generator without a seed sequence)
+        children = [np.random.default_rng(int(s_)) for s_ in rng.integers(0, 2**63, len(centres))]
+
+    def one_run(job):
+        (cxi, cyi), run_rng = job
+        a = _draw_ring_pixels(valid2d, ny, nx, cxi, cyi, 0.0, r0, gsd, samples, run_rng)
+        sets = [_draw_ring_pixels(valid2d, ny, nx, cxi, cyi, lo, hi, gsd, samples, run_rng) for lo, hi in zip(radii[:-1], radii[1:])]
         b = np.concatenate(sets) if sets else np.empty(0, dtype=np.int64)
-        if a.size and b.size:
-            blocks.append(((a % nx) * float(gsd), (a // nx) * float(gsd), get(a), (b % nx) * float(gsd), (b // nx) * float(gsd), get(b)))
+        if not (a.size and b.size):
+            return None
+        return ((a % nx) * float(gsd), (a // nx) * float(gsd), get(a), (b % nx) * float(gsd), (b // nx) * float(gsd), get(b))
+
+    blocks = []
+    for (cxi, cyi), blk in zip(centres, _host_map(one_run, list(zip(centres, children)))):
+        if blk is not None:
+            blocks.append(blk)
             if centres_out is not None:
                 centres_out.append((cxi, cyi))
     return blocks
