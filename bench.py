@@ -734,6 +734,41 @@ def end_to_end_host_path(ctx, n: int = 16384) -> dict:
             "note": "never the reported `value` (that is device-resident); PCIe Gen5 x16 = 63 GB/s per direction"}
 
 
+def end_to_end_calls(ctx, dev) -> dict:
+    """The other two paths through the calls users make, HOST arrays in (never the reported rates): sample_empirical_variogram on a
+    20000^2 NumPy raster (subsample 1e6, one variogram = 100 runs, exact Dowd: sampling of the equidistant metric space, gather,
+    Morton-ordered copies and lattice packing in the library's native host code, upload, pair passes, exact medians) and
+    NuthKaab(subsample=1).fit on the C3 pair as NumPy arrays (uploads, plan creation, ten iterations, ten host curve fits)."""
+    import torch
+
+    from xdem_amd import coreg, spatialstats
+    from xdem_amd.synth import fbm_torch
+
+    out = {}
+    dh = fbm_torch(20000, 20000, dev, seed=3, hurst=0.3).cpu().numpy()
+    kw = dict(gsd=10.0, estimator="dowd", random_state=42)
+    spatialstats.sample_empirical_variogram(dh[:2000, :2000], subsample=1000, **kw)   # (first launches)
+    t0 = time.perf_counter()
+    df = spatialstats.sample_empirical_variogram(dh, subsample=1000000, **kw)
+    dt = time.perf_counter() - t0
+    pairs = float(df["count"].sum())
+    out["variogram"] = {"workload": "sample_empirical_variogram(20000x20000 float32 NumPy raster, subsample=1e6, estimator='dowd'): host raster in, DataFrame out",
+                        "seconds": round(dt, 3), "pairs_in_kept_classes": int(pairs), "Gpairs_s": round(pairs / dt / 1e9, 1),
+                        "note": "profiles/r06_vario_end_to_end.txt has the C5 size (subsample 1e7: 22 s, 2.4 Tpairs/s end to end) and the breakdown"}
+    del dh
+    ref, tba = _c3_pair(dev, 20000)
+    ref, tba = ref.cpu().numpy(), tba.cpu().numpy()
+    torch.cuda.empty_cache()
+    coreg.NuthKaab(subsample=1, max_iterations=2).fit(ref[:2000, :2000].copy(), tba[:2000, :2000].copy(), None, resolution=10.0)
+    t0 = time.perf_counter()
+    nk = coreg.NuthKaab(subsample=1, max_iterations=10, offset_threshold=0.0).fit(ref, tba, None, resolution=10.0)
+    dt = time.perf_counter() - t0
+    a = nk.meta["outputs"]["affine"]
+    out["nuthkaab"] = {"workload": "NuthKaab(subsample=1, max_iterations=10).fit on the C3 pair as NumPy arrays (20000x20000 float32 each)",
+                       "seconds": round(dt, 3), "shift": [round(float(a["shift_x"]), 3), round(float(a["shift_y"]), 3), round(float(a["shift_z"]), 3)]}
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1005,6 +1040,11 @@ def main() -> None:
             except Exception as e:
                 res["end_to_end"] = {"error": repr(e)}
                 failed.append("end_to_end")
+            try:
+                res["end_to_end_calls"] = end_to_end_calls(ctx, dev)
+            except Exception as e:
+                res["end_to_end_calls"] = {"error": repr(e)}
+                failed.append("end_to_end_calls")
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
