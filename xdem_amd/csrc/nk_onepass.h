@@ -189,6 +189,49 @@ __global__ __launch_bounds__(256) void nk_sample_y_kernel(T* __restrict__ s_v, u
     }
 }
 
+// Both samples in one kernel, for steps whose bracket of the median of dh is PREDICTED (nk_step_onepass: predict_d): v^ is known
+// before any sample is taken, so the dh sample never has to exist in memory -- one launch, and 50 MB of sample traffic, less.
+// Slot for slot what nk_sample_dh_kernel followed by nk_sample_y_kernel leave in s_v / s_b.
+template <typename T>
+__global__ __launch_bounds__(256) void nk_sample_dy_kernel(const T* __restrict__ ref_m, const T* __restrict__ tba, NkGeom g, int64_t q0, int64_t n,
+                                                           double invW, int64_t n_slots, T* __restrict__ s_v, uint16_t* __restrict__ s_b,
+                                                           const T* __restrict__ slope_tan /* + q0 */, const nk_bin_t* __restrict__ bcache /* + q0 */,
+                                                           const typename KeyT<T>::type* klo_d, const typename KeyT<T>::type* khi_d, T* vhat_out,
+                                                           T* delta_out, unsigned long long* ctr, SelReset reset) {
+    typedef typename KeyT<T>::type K;
+    T vhat, delta;
+    const K lo = klo_d[0], hi = khi_d[0];
+    const bool ok = nk_vhat_of<T>((lo == (K)0 && hi == (K)~(K)0) ? 0u : 1u, lo, hi, vhat, delta);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *vhat_out = vhat;
+        *delta_out = delta;
+        if (!ok) ctr[3] = 1ull;
+    }
+    if (reset.base) select_reset_slice(reset, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = (sel_sampled_line(i >> SEL_LINE_LOG2) << SEL_LINE_LOG2) + (i & (SEL_LINE - 1));
+        T y = (T)NAN;
+        uint16_t b = 0xFFFF;
+        if (p < n) {
+            const int64_t q = q0 + p;
+            int64_t li, j;
+            row_col(q, g.W, invW, li, j);
+            const BiTap t = bi_locate(g, li + g.roff, j);
+            const BiVals<T> tv = bi_load<T>(tba, t);
+            T val;
+            const bool in = bi_value<T>(g, tba, t, tv.a00, tv.a01, tv.a10, tv.a11, val);
+            const T d = t_sub(ref_m[q], val);
+            if (in && t_finite(d)) {
+                b = nk_bin16(bcache[p]);
+                y = t_div(t_sub(d, vhat), slope_tan[p]);
+                if (b == 0xFFFF || !(y == y)) y = (T)NAN;
+            }
+        }
+        s_v[i] = y;
+        s_b[i] = b;
+    }
+}
+
 // Round 6: the brackets of a step from the host's PREDICTION instead of from samples (nk_step_onepass).  Values in, what the sample
 // selections would have left out: bracket keys of the median of dh and of the bins' medians, the rebase shifts of the candidate
 // selections, v^ and delta.  An empty bin (lo > hi) gets the bracket {0, all-ones} of a bin without sample elements.
@@ -226,6 +269,29 @@ __global__ __launch_bounds__(64) void nk_predict_kernel(const NkPredicted<T> pr,
     }
 }
 
+// The five float64 sums of the pass from its workgroups' slots, in a FIXED order (the same bits in every run): the first 256 threads of
+// the calling workgroup each add every 256th slot, then a tree over the 256 partial sums.  `s_part`: 256 x 5 doubles of LDS.
+constexpr int NK_SUMS_THREADS = 256;
+__device__ __forceinline__ void nk_sums_reduce(const double* __restrict__ wg_sums, int n_wg, double (*s_part)[5], double* out5) {
+    const int t = threadIdx.x;
+    if (t < NK_SUMS_THREADS) {
+        double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int w = t; w < n_wg; w += NK_SUMS_THREADS)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] += wg_sums[(size_t)w * 5 + k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_part[t][k] = a[k];
+    }
+    __syncthreads();
+    for (int half = NK_SUMS_THREADS / 2; half > 0; half >>= 1) {
+        if (t < half)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s_part[t][k] += s_part[t + half][k];
+        __syncthreads();
+    }
+    if (t < 5) out5[t] = s_part[0][t];
+}
+
 #ifndef XD_NKZ_ROWS      // (measurement builds override the two pipeline constants of the one-pass kernel)
 #define XD_NKZ_ROWS 8
 #endif
@@ -258,7 +324,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? (RULE == 2 ? 4 : 5) : (RULE 
                                                        uint64_t* cls_y /* [3][nb]: above, below, candidates */, T* cd_vals, int64_t cd_cap,
                                                        T* cy_d, T* cy_st, uint16_t* cy_b, int64_t cy_cap,
                                                        unsigned long long* ctr /* [1] dh candidates, [5] y candidates, [2] overflow */,
-                                                       double* sums /* [5] */, const uint64_t* __restrict__ badbits = nullptr, int64_t bad_wpr = 0) {
+                                                       double* wg_sums /* [workgroups][5]: nk_sums_reduce adds them up in a fixed order */,
+                                                       const uint64_t* __restrict__ badbits = nullptr, int64_t bad_wpr = 0) {
     typedef typename KeyT<T>::type K;
     constexpr int NKZ_CAP = NkzCap<T>::v;
     constexpr int SEG = NKZ_CAP / 4;      // staging slots of ONE wave: waves reserve in their own segment with a scalar counter --
@@ -309,7 +376,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? (RULE == 2 ? 4 : 5) : (RULE 
         tab[r] = e;
     }
     __syncthreads();
-    if (nrow <= 0) return;  // (uniform over the workgroup)
+    if (nrow <= 0) {  // (uniform over the workgroup)
+        if (threadIdx.x < 5) wg_sums[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = 0.0;
+        return;
+    }
     uint32_t* cc = c + (threadIdx.x % (unsigned)copies) * cs;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool jin = j < g.W;
@@ -544,7 +614,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? (RULE == 2 ? 4 : 5) : (RULE 
         if (q1) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt_d[1]), q1);
         if (q2) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt_d[2]), q2);
     }
-    if (threadIdx.x < 5) atomicAdd(&sums[threadIdx.x], s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]);
+    // (a slot per workgroup, not an atomic: float64 adds in the order the workgroups happen to finish gave every run of the same step its
+    //  own last bits of nanmean / nanstd of y -- the p0 of the curve fit -- and a whole fit its own last digits of the shift)
+    if (threadIdx.x < 5)
+        wg_sums[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x];
     for (int k = threadIdx.x; k < 3 * nb; k += blockDim.x) {
         unsigned long long t = 0;
         for (int q = 0; q < copies; ++q) t += c[q * cs + k];
@@ -893,9 +966,13 @@ template <typename T, typename K> __device__ __forceinline__ int dsel_bucket(T v
 template <typename T>
 __global__ __launch_bounds__(HIST_THREADS) void nk_dhsel_hist_kernel(const T* __restrict__ cd, int64_t cap, const unsigned long long* n_dev,
                                                                      const typename KeyT<T>::type* klo, const typename KeyT<T>::type* khi,
-                                                                     uint32_t* hist /* [DSEL_BUCKETS], zeroed */) {
+                                                                     uint32_t* hist /* [DSEL_BUCKETS], zeroed */,
+                                                                     const double* __restrict__ wg_sums = nullptr, int n_wg = 0, double* sums_out = nullptr) {
     typedef typename KeyT<T>::type K;
     __shared__ uint32_t h[DSEL_BUCKETS];
+    __shared__ double s_part[NK_SUMS_THREADS][5];
+    // (on the side, first launch behind the pass: its float64 sums in a fixed order -- one workgroup's job, the last one's)
+    if (wg_sums && blockIdx.x == gridDim.x - 1) nk_sums_reduce(wg_sums, n_wg, s_part, sums_out);
     for (int k = threadIdx.x; k < DSEL_BUCKETS; k += blockDim.x) h[k] = 0u;
     __syncthreads();
     const unsigned long long m = *n_dev;
@@ -1281,8 +1358,13 @@ static __global__ void nk_mr_ext_unpack_kernel(const uint64_t* slots, int world,
     s->asp_min = mn; s->asp_max = mx; surv[0] = s0; surv[1] = s1;
 }
 // exchange 7: [0, 3) cnt_d | [3, 3 + 3 nb) cls_y | [world][5] float64 sums, slot of this rank only | (then the histogram rows)
-static __global__ __launch_bounds__(256) void nk_mr_counts_pack_kernel(const uint64_t* cnt_d, const uint64_t* cls_y, const double* sums, int nb, int rank,
+static __global__ __launch_bounds__(256) void nk_mr_counts_pack_kernel(const uint64_t* cnt_d, const uint64_t* cls_y, const double* wg_sums, int n_wg, int nb, int rank,
                                                                         int world, uint64_t* red, uint64_t* cls_loc) {
+    static_assert(NK_SUMS_THREADS == 256, "this kernel's block is the reduction's");
+    __shared__ double s_part[NK_SUMS_THREADS][5];
+    __shared__ double sums[5];
+    nk_sums_reduce(wg_sums, n_wg, s_part, sums);   // (this rank's sums of the pass, fixed order)
+    __syncthreads();
     const int nsum = 3 + 3 * nb, total = nsum + 5 * world;
     for (int k = threadIdx.x; k < total; k += blockDim.x) {
         uint64_t v = 0;

@@ -540,13 +540,17 @@ struct xdemhip_nk_plan {
     void* cd_vals = nullptr;      // ... candidates of the median of dh
     int64_t cd_cap = 0;
     void* c_st = nullptr;         // ... slope tangents of the bin candidates (next to ws.c_vals / ws.c_bins)
+    double* wg_sums = nullptr;    // ... the pass's five float64 sums per workgroup (added up in a fixed order: nk_sums_reduce)
+    size_t wg_sums_cap = 0;
     unsigned char* fz_pack = nullptr;   // ... the step's small results, gathered for one device-to-host copy
     size_t fz_pack_bytes = 0;
     std::vector<unsigned char> fz_host;
     int64_t n_onepass = 0, n_plain = 0;   // steps answered by each route (xdemhip_nk_route_counts)
-    // one-pass route: the sample brackets of the NEXT step are 2^-fz_narrow as wide as the rule for fully correlated sample lines
-    // asks (select.h: sel_bracket_halfwidth); set from how far off the bracket centres the wanted ranks lay in the steps so far
-    int fz_narrow = 0, fz_narrow_cap = 2;
+    // one-pass route: the sample brackets of the NEXT step are a fraction (code fz_narrow, select.h: sel_narrowed / sel_narrow_unit)
+    // of what the rule for fully correlated sample lines asks (select.h: sel_bracket_halfwidth); set from how far off the bracket
+    // centres the wanted ranks lay in the steps so far, never below fz_unit_min (raised by a miss)
+    int fz_narrow = 0;
+    double fz_unit_min = 0.25;
     double fz_worst = 0.0;   // largest |wanted rank - bracket centre| seen, in half widths of the FULL rule
     double fz_off2 = 0.0;    // sum of squares of those offsets over all brackets of all steps so far
     int64_t fz_offn = 0;
@@ -935,11 +939,14 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     } else {
     // 2. sample of dh -> bracket of its median, v^, delta
     // (round 5: the sample kernels also reset the selection that runs on their sample -- select_reset_slice)
-    hipLaunchKernelGGL((nk_sample_dh_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
-                       1.0 / (double)P->W, n_slots, s_v, select_reset_plan<K>(scratch, 1, SEL_BRACKET_DUAL));
-    XD_HIP_CHECK(ctx, hipGetLastError());
+    if (!predict_d) {
+        hipLaunchKernelGGL((nk_sample_dh_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
+                           1.0 / (double)P->W, n_slots, s_v, select_reset_plan<K>(scratch, 1, SEL_BRACKET_DUAL));
+        XD_HIP_CHECK(ctx, hipGetLastError());
+    }
     if (predict_d) {
-        // the dh sample is still taken (the y^ sample is formed from it), its selection is not: bracket from the previous median
+        // no dh sample in memory and no selection on it: the bracket comes from the previous median, and the y^ sample is formed
+        // straight from the rasters (nk_sample_dy_kernel below)
         NkPredicted<T> pr;
         const double hd = fmin(1.0, fmax(0.25, 2.0 * pr_expect_d + 0.15)) * P->pr_wd;
         pr.dlo = (T)(P->pr_v - hd);
@@ -964,6 +971,11 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         if (rc) return rc;
     }
     // 3. sample of y^ per aspect bin -> brackets of the bin medians (round 5: v^ and delta formed by the sample kernel itself)
+    if (predict_d)
+        hipLaunchKernelGGL((nk_sample_dy_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, ref_m, tba, g, q0, n,
+                           1.0 / (double)P->W, n_slots, s_v, ws->s_bins, st_all + q0, P->bcache + q0, klo_d, khi_d, d_vhat, d_delta, ctr,
+                           select_reset_plan<K>(scratch, nb, SEL_BRACKET_DUAL));
+    else
     hipLaunchKernelGGL((nk_sample_y_kernel<T>), dim3(grid_for(ctx, n_slots, 256, 8)), dim3(256), 0, ctx->stream, s_v, ws->s_bins, st_all + q0,
                        P->bcache + q0, n, n_slots, d_vhat, klo_d, khi_d, d_vhat, d_delta, ctr, select_reset_plan<K>(scratch, nb, SEL_BRACKET_DUAL));
     XD_HIP_CHECK(ctx, hipGetLastError());
@@ -974,9 +986,20 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     XD_HIP_CHECK(ctx, hipGetLastError());
     }   // (sampled brackets)
     // 4. the one pass
+    int n_wg = 0;
     {
         dim3 grid = grid2d(ctx, P->W, rows);
         if ((rows + grid.y - 1) / grid.y > NKZ_CHUNK_MAX) grid.y = (unsigned)((rows + NKZ_CHUNK_MAX - 1) / NKZ_CHUNK_MAX);
+        n_wg = (int)(grid.x * grid.y);
+        if ((size_t)n_wg > P->wg_sums_cap) {   // (per-workgroup slots of the pass's five float64 sums: nk_sums_reduce)
+            if (P->wg_sums) (void)hipFree(P->wg_sums);
+            P->wg_sums = nullptr; P->wg_sums_cap = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&P->wg_sums), (size_t)n_wg * 5 * sizeof(double)) != hipSuccess) {
+                (void)hipGetLastError();
+                return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc(per-workgroup sums of the one-pass step) failed");
+            }
+            P->wg_sums_cap = (size_t)n_wg;
+        }
         int copies = (4608) / (nb * 12);   // (static 26 KB + this: five workgroups of 256 threads per CU)
         copies = copies < 1 ? 1 : (copies > 16 ? 16 : copies);
         const size_t lds = (size_t)nb * sizeof(FzPair<T>) + (size_t)((3 * nb) | 1) * 4 * (size_t)copies + 64 * 4;
@@ -984,7 +1007,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
 #define XD_NK_FZ(RULE)                                                                                                               \
     hipLaunchKernelGGL((nk_fused_kernel<T, RULE>), grid, dim3(256), lds, ctx->stream, ref_m, tba, st_all, P->bcache, g, P->row0, P->row1,  \
                        P->nbuf, nb, copies, klo_d, khi_d, d_vhat, d_delta, klo_y, khi_y, cnt_d, cls_y, static_cast<T*>(P->cd_vals),   \
-                       P->cd_cap, cy_d, static_cast<T*>(P->c_st), ws->c_bins, ws->c_cap, ctr, d_sums, P->badbits, P->bad_wpr)
+                       P->cd_cap, cy_d, static_cast<T*>(P->c_st), ws->c_bins, ws->c_cap, ctr, P->wg_sums, P->badbits, P->bad_wpr)
         if (g.rule == 0) XD_NK_FZ(0);
         else if (g.rule == 1) XD_NK_FZ(1);
         else XD_NK_FZ(2);
@@ -1008,7 +1031,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         // same all-reduce, the 4096-bucket histogram of this rank's dh candidates in its own row (the candidates and the bracket
         // are there once the pass is through; only the choice of the bucket needs the summed counters)
         XD_HIP_CHECK(ctx, hipMemsetAsync(mr_rows, 0, (size_t)world * DSEL_BUCKETS * 4, ctx->stream));
-        hipLaunchKernelGGL(nk_mr_counts_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt_d, cls_y, d_sums, nb, rank, world, P->mr_a, cls_loc);
+        hipLaunchKernelGGL(nk_mr_counts_pack_kernel, dim3(1), dim3(256), 0, ctx->stream, cnt_d, cls_y, P->wg_sums, n_wg, nb, rank, world, P->mr_a, cls_loc);
         hipLaunchKernelGGL((nk_dhsel_hist_kernel<T>), dim3(dsel_grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
                            klo_d, khi_d, mr_rows + (size_t)rank * DSEL_BUCKETS);
         XD_HIP_CHECK(ctx, hipGetLastError());
@@ -1044,7 +1067,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
                                ctr, scratch + OFF_INFO, 0);
         } else {
         hipLaunchKernelGGL((nk_dhsel_hist_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
-                           klo_d, khi_d, dsel + 2 * DSEL_HDR_WORDS);
+                           klo_d, khi_d, dsel + 2 * DSEL_HDR_WORDS, P->wg_sums, n_wg, d_sums);
         hipLaunchKernelGGL((nk_dhsel_gather_kernel<T>), dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, static_cast<const T*>(P->cd_vals), P->cd_cap, ctr + 1,
                            cnt_d, klo_d, khi_d, dsel, dsel_keys, ctr);
         hipLaunchKernelGGL((nk_dhsel_final_kernel<T>), dim3(1), dim3(HIST_THREADS), lds, ctx->stream, P->cd_cap, ctr + 1, cnt_d, klo_d, khi_d, dsel, dsel_keys,
@@ -1148,7 +1171,10 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
     }
     if (h_ctr[2] != 0 || h_ctr[3] != 0) {   // overflow / a bracket missed / no extreme-aspect survivor: the plain route takes the step
         if (h_ctr[6] != 0) P->ext_ok = false;   // (no listed extreme-aspect pixel kept a finite dh: this plan reads the aspect from now on -- identical on every rank, the flag derives from reduced counts)
-        if (narrow > 0) { P->fz_narrow_cap = narrow - 1; P->fz_narrow = 0; }   // (narrowed brackets may be what missed: not that narrow again)
+        if (narrow > 0) {   // (narrowed brackets may be what missed: not that narrow again)
+            P->fz_unit_min = fmin(1.0, 1.5 * sel_narrow_unit((uint32_t)narrow));
+            P->fz_narrow = 0;
+        }
         P->pr_have = false;
         return XDEMHIP_OK;
     }
@@ -1161,7 +1187,7 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             return fabs(((double)(tot - 1) * 0.5 - (double)lt) - 0.5 * (double)in) / (0.5 * (double)in);
         };
         // (offsets are measured in half widths of the bracket that was used; all statistics are kept in units of the FULL rule)
-        const double unit = 1.0 / (double)(1 << narrow);
+        const double unit = sel_narrow_unit((uint32_t)narrow);
         double worst = 0.0;
         auto take = [&](uint64_t tot, uint64_t lt, uint64_t in) {
             if (tot < 4096 || in < 64 || in >= tot) return;
@@ -1177,19 +1203,23 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
         }
         P->fz_worst = worst > P->fz_worst ? worst : P->fz_worst;
         // rms offset = one standard deviation of the sample ranks in units of the full half width (independent sample elements:
-        // 1 / 17, the rule being 6 sigma of 8-element lines that are fully correlated): the next brackets keep >= 7 sigma and
-        // >= 2.2 x the worst offset ever seen, in steps of halving
+        // 1 / 17, the rule being 6 sigma of 8-element lines that are fully correlated; 0.062-0.068 measured on C3): the next brackets
+        // keep >= 4.8 sigma (a miss in 1e-4 of the steps with 73 brackets each -- it costs that step the plain route, nothing else) and
+        // >= 1.5 x the worst offset ever seen, in sixteenths of the rule.  (Rounds 4-5 halved or quartered only, at 7 sigma and 2.2 x:
+        // C3 sat at one half with 7.7 sigma of room; five sixteenths stage 38 % fewer candidates.)
         int next = 0;
         if (P->fz_offn >= 24) {
             const double sigma = sqrt(P->fz_off2 / (double)P->fz_offn);
-            for (int k = 2; k >= 1 && next == 0; --k)
-                if (7.0 * sigma <= 1.0 / (double)(1 << k) && 2.2 * P->fz_worst <= 1.0 / (double)(1 << k)) next = k;
+            static const int qs[] = {4, 5, 6, 7, 8, 10, 12};
+            for (int q : qs) {
+                const double u = (double)q / 16.0;
+                if (4.8 * sigma <= u && 1.5 * P->fz_worst <= u && u >= P->fz_unit_min) { next = q == 8 ? 1 : (q == 4 ? 2 : (int)SEL_NARROW_16THS + q); break; }
+            }
         }
-        next = next > P->fz_narrow_cap ? P->fz_narrow_cap : next;
         if (ctx->nk_narrow >= 0) next = ctx->nk_narrow;   // option "nk_narrow": -1 = this rule, 0 / 1 / 2 fixed
         if (getenv("XDEMHIP_DEBUG"))
-            fprintf(stderr, "[xdemhip] one-pass step: brackets 2^-%d, offsets rms %.3f worst %.3f of the full half width (%lld brackets) -> next 2^-%d\n", narrow,
-                    P->fz_offn ? sqrt(P->fz_off2 / (double)P->fz_offn) : 0.0, P->fz_worst, (long long)P->fz_offn, next);
+            fprintf(stderr, "[xdemhip] one-pass step: brackets x %.4f, offsets rms %.3f worst %.3f of the full half width (%lld brackets) -> next x %.4f\n", unit,
+                    P->fz_offn ? sqrt(P->fz_off2 / (double)P->fz_offn) : 0.0, P->fz_worst, (long long)P->fz_offn, sel_narrow_unit((uint32_t)next));
         P->fz_narrow = next;
     }
     uint64_t total;
@@ -1243,10 +1273,13 @@ int nk_step_onepass(xdemhip_nk_plan* P, const NkGeom& g, int64_t q0, int64_t n, 
             P->pr_dpx = 1e30;
         }
         if (!predict || (int)P->pr_w.size() != nb) {   // the widths of SAMPLED brackets only (predicted ones are fractions of them)
+            // (kept in units of HALF the rule, the brackets the prediction's thresholds were tuned on: narrower sample brackets -- the
+            //  sixteenths above -- must not make the prediction shyer or its brackets thinner)
+            const double norm = narrow >= (int)SEL_NARROW_16THS ? 0.5 / sel_narrow_unit((uint32_t)narrow) : 1.0;
             P->pr_w.assign(nb, 0.0);
             for (int b = 0; b < nb; ++b)
-                if (counts[b] > 0 && khi[b] >= klo[b]) P->pr_w[b] = 0.5 * ((double)val_of(khi[b]) - (double)val_of(klo[b]));
-            if (!predict_d) P->pr_wd = h_kd[1] >= h_kd[0] ? 0.5 * ((double)val_of(h_kd[1]) - (double)val_of(h_kd[0])) : 0.0;
+                if (counts[b] > 0 && khi[b] >= klo[b]) P->pr_w[b] = norm * 0.5 * ((double)val_of(khi[b]) - (double)val_of(klo[b]));
+            if (!predict_d) P->pr_wd = h_kd[1] >= h_kd[0] ? norm * 0.5 * ((double)val_of(h_kd[1]) - (double)val_of(h_kd[0])) : 0.0;
         }
         P->pr_med.assign(medians, medians + nb);
         P->pr_mid = mid;
@@ -1608,7 +1641,7 @@ void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     (void)hipSetDevice(P->ctx->device);
     if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
     void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt,
-                    P->fz, P->cd_vals, P->c_st, P->fz_pack, P->badbits, P->mr_a, P->mr_b, P->mr_small};
+                    P->fz, P->cd_vals, P->c_st, P->fz_pack, P->badbits, P->mr_a, P->mr_b, P->mr_small, P->wg_sums};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     xd::sel_ws_free(P->ws);

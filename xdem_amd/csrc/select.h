@@ -68,6 +68,16 @@ enum { SEL_MEDIAN = 0, SEL_BRACKET_LO = 1, SEL_BRACKET_HI = 2, SEL_GIVEN = 3, SE
 __host__ __device__ inline uint64_t sel_bracket_halfwidth(uint64_t m) {
     return (uint64_t)(3.0 * sqrt(8.0 * (double)m)) + 32;
 }
+// Narrowed half widths (callers that MEASURE how well their samples centre: the one-pass Nuth-Kaab step).  `narrow` is a code: below
+// 16 a right shift of the rule's width (0 = the full rule, 1 = half, 2 = a quarter), 16 + q = q sixteenths of it (q = 1 .. 16).
+constexpr uint32_t SEL_NARROW_16THS = 16;
+__host__ __device__ inline uint64_t sel_narrowed(uint64_t h_full, uint32_t narrow) {
+    const uint64_t w = h_full - 32;
+    return (narrow < SEL_NARROW_16THS ? (w >> narrow) : ((w * (uint64_t)(narrow - SEL_NARROW_16THS)) >> 4)) + 32;
+}
+__host__ __device__ inline double sel_narrow_unit(uint32_t narrow) {   // the fraction of the full rule a code stands for
+    return narrow < SEL_NARROW_16THS ? 1.0 / (double)(1u << narrow) : (double)(narrow - SEL_NARROW_16THS) / 16.0;
+}
 // Same for samples of point PAIRS (variogram.hip).  The sample is a 1/64 subsample of the B points against ALL A points of a block
 // (variogram.hip: unit_sample_slot): pairs that share a point are strongly dependent (values of a spatially correlated field:
 // |v_a - v_b| moves with v_b for all ~9000 A points at once), so the effective sample size is about the number of distinct
@@ -132,8 +142,8 @@ __device__ __forceinline__ void select_advance_body(const int b, const int lane,
         uint64_t r = total ? (total - 1) / 2 : 0;  // lower median
         const bool lo_end = mode == SEL_BRACKET_LO || (mode == SEL_BRACKET_DUAL && bs < dual_nb);
         const bool hi_end = mode == SEL_BRACKET_HI || (mode == SEL_BRACKET_DUAL && bs >= dual_nb);
-        if (lo_end && total) { const uint64_t h = ((sel_bracket_halfwidth(total) - 32) >> narrow) + 32; r = r > h ? r - h : 0; }
-        if (hi_end && total) { const uint64_t h = ((sel_bracket_halfwidth(total) - 32) >> narrow) + 32; r = (r + h < total) ? r + h : total - 1; }
+        if (lo_end && total) { const uint64_t h = sel_narrowed(sel_bracket_halfwidth(total), narrow); r = r > h ? r - h : 0; }
+        if (hi_end && total) { const uint64_t h = sel_narrowed(sel_bracket_halfwidth(total), narrow); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_BRACKET_LO_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = r > h ? r - h : 0; }
         if (mode == SEL_BRACKET_HI_WIDE && total) { const uint64_t h = sel_bracket_halfwidth_wide(total, wide_deff); r = (r + h < total) ? r + h : total - 1; }
         if (mode == SEL_GIVEN) {

@@ -135,15 +135,25 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
     const int rbs = rb_shift ? (int)*rb_shift : 0;
     // four elements per thread and step, all loads issued before the first use (memory-level parallelism)
     const int64_t step = (int64_t)blockDim.x * SEL_UNROLL;
+    // (the loads of the NEXT step are issued before this step's elements are counted: with one workgroup per CU, or fewer, a thread
+    //  walks 6-18 steps and used to sit out a full memory latency in each)
+    T vn[SEL_UNROLL];
+    uint16_t bn[SEL_UNROLL];
+    auto fetch = [&](int64_t base) {
+#pragma unroll
+        for (int q = 0; q < SEL_UNROLL; ++q) {
+            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
+            vn[q] = (p < n) ? vals[p] : (T)NAN;
+            bn[q] = (p < n && bins) ? bins[p] : (uint16_t)0;
+        }
+    };
+    fetch((int64_t)blockIdx.x * step);
     for (int64_t base = (int64_t)blockIdx.x * step; base < n; base += (int64_t)gridDim.x * step) {
         T v[SEL_UNROLL];
         uint16_t bb[SEL_UNROLL];
 #pragma unroll
-        for (int q = 0; q < SEL_UNROLL; ++q) {
-            const int64_t p = base + (int64_t)q * blockDim.x + threadIdx.x;
-            v[q] = (p < n) ? vals[p] : (T)NAN;
-            bb[q] = (p < n && bins) ? bins[p] : (uint16_t)0;
-        }
+        for (int q = 0; q < SEL_UNROLL; ++q) { v[q] = vn[q]; bb[q] = bn[q]; }
+        fetch(base + (int64_t)gridDim.x * step);
 #pragma unroll
         for (int q = 0; q < SEL_UNROLL; ++q) {
             if (v[q] != v[q]) continue;
@@ -164,7 +174,12 @@ __global__ __launch_bounds__(HIST_THREADS) void hist_pass_kernel(const T* __rest
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < ((first && dual_total) ? nb * SEL_RADIX : table); k += blockDim.x) {
+    // (every workgroup finishes its share at about the same time and would walk the table in the same order -- the same few cache
+    //  lines of `hist` under all of them at once: each starts at its own row)
+    const int flush_n = (first && dual_total) ? nb * SEL_RADIX : table;
+    const int flush_0 = (int)(((unsigned)blockIdx.x * 37u) % (unsigned)(flush_n / SEL_RADIX)) * SEL_RADIX;
+    for (int kk = threadIdx.x; kk < flush_n; kk += blockDim.x) {
+        const int k = kk + flush_0 < flush_n ? kk + flush_0 : kk + flush_0 - flush_n;
         unsigned long long c = 0;
         for (int q = 0; q < copies; ++q) c += h[q * cstride + k];
         // (dual: the high-end rows of this sweep belong to the states behind all the low-end ones)
