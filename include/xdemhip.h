@@ -295,6 +295,13 @@ int xdemhip_nk_set_bin_edges(xdemhip_nk_plan* plan, const double* edges, int n_e
 #define XDEMHIP_BINSTAT_MEAN 1
 int xdemhip_nk_set_statistic(xdemhip_nk_plan* plan, int bin_stat);
 int xdemhip_nk_get_aux(xdemhip_nk_plan* plan, void* slope_tan, void* aspect, uint8_t* valid);
+/* The random subsample of the valid pixels (replaces the host round trip of _get_subsample_on_valid_mask, xdem/coreg/base.py:577-617,
+ * whose draw is `rng.choice(np.flatnonzero(valid), k, replace=False)` = flatnonzero(valid)[rng.choice(n_valid, k, replace=False)]): the
+ * caller draws `k` distinct RANKS in [0, n_valid) -- positions among the plan's valid pixels in raster order -- and the plan keeps
+ * exactly those pixels as inliers (the valid mask never travels to the host; rasters and aux variables stay where they are; a second
+ * call draws again among the pixels still valid).  `ranks`: int64, host or device (`memspace`).  Whole-raster plans of one process
+ * only (XDEMHIP_EINVAL otherwise: partitioned plans pass the drawn mask as their inlier mask).  n_valid returns the new count (= k). */
+int xdemhip_nk_subsample(xdemhip_nk_plan* plan, const int64_t* ranks, int64_t k, int memspace, int64_t* n_valid);
 /* How the steps of this plan were answered so far (either pointer may be NULL).  Two routes since round 6:
  *   ONE-PASS  one data pass of 13 B/pixel -- the shifted elevation difference, the counting for its exact median and the
  *             aspect-bin counting against brackets with per-pixel margins (large plans, median statistic, context option

@@ -386,6 +386,33 @@ def test_nuthkaab_class_contract():
     assert np.allclose(coreg._nuth_kaab_fit_func(x, 2.0, 0.5, 1.0), 2.0 * np.cos(0.5 - x) + 1.0)
 
 
+def test_subsample_ranks_are_the_host_draw():
+    """``rng.choice(valids, n, replace=False)`` == ``valids[rng.choice(len(valids), n, replace=False)]`` -- what lets nuth_kaab draw
+    RANKS from the count of valid pixels and leave the mask on the device (coreg.subsample_ranks, xdemhip_nk_subsample): both of
+    NumPy's algorithms for a draw without replacement (tail shuffle, Floyd's set for n < size / 50 above 10 000 elements)."""
+    from xdem_amd import coreg
+
+    rng0 = np.random.default_rng(0)
+    for size, frac_valid in ((977, 0.7), (200_000, 0.8)):
+        valid = rng0.random(size) < frac_valid
+        valids = np.flatnonzero(valid)
+        for sub, seed in ((0.5, 1), (25, 2), (3000, 3), (1.0 - 1e-9, 4), (10**9, 5), (0.001, None)):
+            if seed is None:
+                assert coreg.subsample_ranks(len(valids), sub, None).size == int(sub * len(valids))
+                continue
+            ranks = coreg.subsample_ranks(len(valids), sub, seed)
+            n = min(int(sub * len(valids)) if sub <= 1 else int(sub), len(valids))
+            assert ranks.size == n and np.unique(ranks).size == n
+            want = np.random.default_rng(seed).choice(valids, n, replace=False)
+            assert np.array_equal(valids[ranks], want)
+            m = coreg.subsample_valid_mask(valid.reshape(1, -1), sub, seed)
+            assert m.sum() == n and np.array_equal(np.flatnonzero(m.ravel()), np.sort(want))
+    with pytest.raises(ValueError, match="no valid points"):
+        coreg.subsample_ranks(0, 0.5, 1)
+    with pytest.raises(ValueError, match="must be > 0"):
+        coreg.subsample_ranks(10, 0, 1)
+
+
 def test_unbinned_fit_from_sums_equals_curve_fit():
     """bin_before_fit=False: the normal-equation solution from the ten sums xdemhip_nk_step_fit returns is the optimum that
     the reference's curve_fit call (xdem/coreg/base.py:975-989) converges to from its p0 (affine.py:384)."""

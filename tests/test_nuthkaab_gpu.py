@@ -336,6 +336,67 @@ def test_class_api_recovers_shift(coreg):
         coreg.NuthKaab(subsample=1).fit(ref, np.full_like(tba, np.nan), None, resolution=res)
 
 
+def test_device_side_subsample_equals_the_host_draw(coreg):
+    """``nuth_kaab(subsample != 1)`` draws RANKS among the valid pixels on the host and lets the plan turn them into pixels
+    (``xdemhip_nk_subsample``): the valid mask, the steps and the fit must be those of the host form -- the mask copied back,
+    ``rng.choice(np.flatnonzero(valid), n, replace=False)``, a second plan with that mask (``coreg._HOST_DRAW``)."""
+    from xdem_amd import _lib
+
+    ref, tba, inlier, res = _pair(shape=(517, 333))   # (neither a multiple of 16 nor of the kernels' 4096-pixel tiles)
+    plan = coreg.NKPlan(ref, tba, inlier)
+    try:
+        valid0 = plan.aux()[2]
+        n0 = plan.n_valid
+        assert n0 == int(valid0.sum())
+        # all of them: nothing changes
+        assert plan.subsample(np.random.default_rng(5).permutation(n0)) == n0
+        assert np.array_equal(plan.aux()[2], valid0)
+        ranks = coreg.subsample_ranks(n0, 0.3, 7)
+        assert plan.subsample(ranks) == ranks.size == int(0.3 * n0)
+        valid1 = plan.aux()[2]
+        assert np.array_equal(valid1, coreg.subsample_valid_mask(valid0, 0.3, 7))
+        # a second draw is among the pixels still valid
+        ranks2 = coreg.subsample_ranks(plan.n_valid, 1000, 11)
+        assert plan.subsample(ranks2) == 1000
+        want = np.zeros(valid1.size, dtype=bool)
+        want[np.flatnonzero(valid1.ravel())[ranks2]] = True
+        assert np.array_equal(plan.aux()[2].ravel(), want)
+        with pytest.raises(_lib.XdemHipError, match="outside"):
+            plan.subsample(np.array([0, 1000], dtype=np.int64))
+        with pytest.raises(_lib.XdemHipError, match="1 <= k"):
+            plan.subsample(np.arange(1001, dtype=np.int64))
+    finally:
+        plan.close()
+    # the steps of a subsampled plan: device form against a plan created with the host-drawn mask (one-pass route at this size)
+    ref, tba, inlier, res = _pair(shape=(2304, 2304), seed=3)
+    a = coreg.NKPlan(ref, tba, inlier)
+    try:
+        valid0 = a.aux()[2]
+        a.subsample(coreg.subsample_ranks(a.n_valid, 0.5, 21))
+        b = coreg.NKPlan(ref, tba, coreg.subsample_valid_mask(valid0, 0.5, 21))
+        try:
+            assert a.n_valid == b.n_valid
+            for sx, sy in ((0.0, 0.0), (7.0, -3.0), (16.5, -6.2)):
+                da, db = a.step(sx, sy, (res, res), 72), b.step(sx, sy, (res, res), 72)
+                assert da["n_valid"] == db["n_valid"] and da["vshift"] == db["vshift"]
+                assert np.array_equal(da["counts"], db["counts"]) and np.array_equal(da["medians"], db["medians"], equal_nan=True)
+                assert np.array_equal(da["edges"], db["edges"])
+        finally:
+            b.close()
+    finally:
+        a.close()
+    # ... and the whole call
+    got = {}
+    for host in (False, True):
+        coreg._HOST_DRAW = host
+        try:
+            got[host] = coreg.nuth_kaab(ref, tba, inlier, (res, res), subsample=0.25, random_state=99, max_iterations=5)
+        finally:
+            coreg._HOST_DRAW = False
+    assert got[False][1] == got[True][1] > 0
+    assert np.allclose(got[False][0], got[True][0], rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("shape", [(128, 200), (2304, 2304)])
 def test_sharded_reduction_path_single_rank(coreg, shape):
     """The multi-GPU path (row range + all-reduce hook through torch.distributed) on a 1-rank NCCL group: must give

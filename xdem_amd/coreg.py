@@ -288,6 +288,16 @@ class NKPlan:
         self.ctx.check(self.ctx._L.xdemhip_nk_get_aux(self.handle, st.ctypes.data, asp.ctypes.data, valid.ctypes.data))
         return st, asp, valid.astype(bool)
 
+    def subsample(self, ranks: np.ndarray) -> int:
+        """Keep as inliers exactly the valid pixels whose rank -- position among the plan's valid pixels in raster order -- is in
+        ``ranks`` (distinct, in [0, n_valid)): what ``flatnonzero(valid)[ranks]`` selects, formed on the device
+        (``xdemhip_nk_subsample``).  Whole-raster plans of one process only.  Returns the new number of valid pixels."""
+        ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+        nv = ctypes.c_int64()
+        self.ctx.check(self.ctx._L.xdemhip_nk_subsample(self.handle, ranks.ctypes.data, int(ranks.size), _lib.HOST, ctypes.byref(nv)))
+        self.n_valid = int(nv.value)
+        return self.n_valid
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             if getattr(self.ctx, "handle", None):   # (a context that is already gone took its plans with it)
@@ -367,22 +377,31 @@ def subsample_valid_mask(valid_mask: np.ndarray, subsample: float | int, random_
     ``rng = default_rng(random_state)``, ``n = int(subsample * n_valid)`` for 0 < subsample <= 1 else ``int(subsample)``,
     capped at n_valid, ``rng.choice(flat valid indices, n, replace=False)`` -- **parity unpinned**."""
     n_valid = int(np.count_nonzero(valid_mask))
+    if subsample == 1 and n_valid > 0:
+        return valid_mask
+    ranks = subsample_ranks(n_valid, subsample, random_state)
+    valids = np.flatnonzero(valid_mask.ravel())
+    out = np.zeros(valid_mask.size, dtype=bool)
+    out[valids[ranks]] = True
+    return out.reshape(valid_mask.shape)
+
+
+def subsample_ranks(n_valid: int, subsample: float | int, random_state=None) -> np.ndarray:
+    """The draw of ``subsample_valid_mask`` as RANKS among the valid pixels: ``rng.choice(valids, n, replace=False)`` is
+    ``valids[rng.choice(len(valids), n, replace=False)]`` -- NumPy draws the positions from the population SIZE and indexes the array
+    with them (same generator stream, same order; CPU test) -- so the ranks need only the count of valid pixels, not the mask:
+    the device turns them into pixels (``NKPlan.subsample``) and the mask stays where it is."""
     if n_valid == 0:
         raise ValueError(
             "There is no valid points common to the input and auxiliary data (bias variables, or "
             "derivatives required for this method, for example slope, aspect, etc)."
         )
-    if subsample == 1:
-        return valid_mask
     if subsample <= 0:
         raise ValueError("`subsample` must be > 0")
     npoints = int(subsample * n_valid) if subsample <= 1 else int(subsample)
     npoints = min(npoints, n_valid)
     rng = np.random.default_rng(random_state)
-    valids = np.flatnonzero(valid_mask.ravel())
-    out = np.zeros(valid_mask.size, dtype=bool)
-    out[rng.choice(valids, npoints, replace=False)] = True
-    return out.reshape(valid_mask.shape)
+    return rng.choice(n_valid, npoints, replace=False)
 
 
 def _iterate(plan: "NKPlan", res, tolerance, max_iterations, bin_sizes, fit_optimizer, bin_before_fit: bool, initial_offsets=(0.0, 0.0)):
@@ -403,6 +422,9 @@ def _iterate(plan: "NKPlan", res, tolerance, max_iterations, bin_sizes, fit_opti
             logging.info("   Last offset was below the residual offset threshold of %s -> stopping", tolerance)
             break
     return offsets
+
+
+_HOST_DRAW = False   # tests: True sends nuth_kaab's random subsample through the host-mask form (the only form before round 6's end)
 
 
 def _shared_seed(random_state, group):
@@ -433,8 +455,13 @@ def nuth_kaab(ref_elev: np.ndarray, tba_elev: np.ndarray, inlier_mask: np.ndarra
     fit_optimizer = fit_optimizer or scipy.optimize.curve_fit
     logging.info("Running Nuth and Kääb (2011) coregistration")
     plan = NKPlan(ref_elev, tba_elev, inlier_mask, ctx, group)
-    if subsample != 1 and plan.n_valid > 0:
-        # valid = inlier & finite ref / tba / slope / aspect (base.py:650-661), as the aux pass just established it
+    if subsample != 1 and plan.n_valid > 0 and group is None and not _HOST_DRAW:
+        # valid = inlier & finite ref / tba / slope / aspect (base.py:650-661), as the aux pass just established it; the draw needs its
+        # COUNT only (subsample_ranks), the plan turns the drawn ranks into pixels on the device: no mask back to the host, no second
+        # plan (20000^2 host arrays, default subsample: 0.95 s -> profiles/r06_nk_end_to_end.txt)
+        plan.subsample(subsample_ranks(plan.n_valid, subsample, random_state))
+    elif subsample != 1 and plan.n_valid > 0:
+        # partitioned fits (and the test switch _HOST_DRAW): the mask travels, the draw indexes it on the host, a second plan takes it
         valid = plan.aux()[2]
         plan.close()
         if group is not None:

@@ -525,6 +525,9 @@ struct xdemhip_nk_plan {
     int64_t row0 = 0, row1 = 0;           // this rank's own rows [row0, row1) (whole raster unless sharded)
     void *ref = nullptr, *tba = nullptr;  // device (owned when own_inputs)
     uint8_t* inlier = nullptr;            // device copy kept for re-partitioning (owned when own_inputs)
+    uint8_t* sub_inlier = nullptr;        // xdemhip_nk_subsample: the inlier mask in force after it (owned; `inlier` then points here and
+    uint8_t* inlier_user = nullptr;       //  the mask the plan was created with is remembered for its release)
+    bool subsampled = false;
     bool own_inputs = false;
     void *slope_tan = nullptr, *aspect = nullptr, *dh = nullptr, *y = nullptr;
     uint8_t* valid = nullptr;
@@ -606,6 +609,95 @@ dim3 grid2d(const xdemhip_ctx* ctx, int64_t W, int64_t rows) {
 template <typename T> void make_edges(double smin, double smax, int nb, std::vector<T>& e) {
     e.resize(nb + 1);
     make_edges_into<T>(smin, smax, nb, e.data());
+}
+
+// ---- xdemhip_nk_subsample: the valid pixels whose RANK (position among the valid pixels in raster order) is listed stay inliers ----------
+// What the caller's `rng.choice(np.flatnonzero(valid), k, replace=False)` selects, without the mask travelling to the host and back:
+// the host draws ranks, the device turns them into pixels.  Tiles of 4096 pixels: counts, an exclusive scan over the tiles, then every
+// tile ranks its own valid pixels and looks its ranks up in the byte array of marked ranks.
+constexpr int SUBS_TILE = 4096;
+static __global__ __launch_bounds__(256) void nk_subs_count_kernel(const uint8_t* __restrict__ valid, int64_t n, unsigned long long* __restrict__ tile_cnt) {
+    const int64_t t0 = (int64_t)blockIdx.x * SUBS_TILE + (int64_t)threadIdx.x * 16;
+    int c = 0;
+    if (t0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(valid + t0);   // (tiles start at multiples of 4096: aligned)
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) c += ((w[k] >> (8 * b)) & 0xFFu) ? 1 : 0;
+    } else {
+        for (int64_t p = t0; p < n && p < t0 + 16; ++p) c += valid[p] ? 1 : 0;
+    }
+    __shared__ int s[256];
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int half = 128; half > 0; half >>= 1) {
+        if ((int)threadIdx.x < half) s[threadIdx.x] += s[threadIdx.x + half];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = (unsigned long long)s[0];
+}
+// exclusive scan over the tile counts, in place (one workgroup walks them in pieces of 1024 with a carry)
+static __global__ __launch_bounds__(1024) void nk_subs_scan_kernel(unsigned long long* tile_cnt, int64_t n_tiles, unsigned long long* total) {
+    __shared__ unsigned long long s[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < n_tiles; b0 += 1024) {
+        const int64_t k = b0 + threadIdx.x;
+        const unsigned long long v = k < n_tiles ? tile_cnt[k] : 0ull;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned long long a = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            s[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (k < n_tiles) tile_cnt[k] = carry + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+static __global__ __launch_bounds__(256) void nk_subs_mark_kernel(const int64_t* __restrict__ ranks, int64_t k, int64_t n_ranks, uint8_t* __restrict__ mark,
+                                                                  unsigned long long* bad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = ranks[i];
+        if (r < 0 || r >= n_ranks) atomicAdd(bad, 1ull);
+        else mark[r] = 1;
+    }
+}
+static __global__ __launch_bounds__(256) void nk_subs_apply_kernel(const uint8_t* __restrict__ valid, int64_t n, const unsigned long long* __restrict__ tile_off,
+                                                                   const uint8_t* __restrict__ mark, uint8_t* __restrict__ inl_out) {
+    const int64_t t0 = (int64_t)blockIdx.x * SUBS_TILE + (int64_t)threadIdx.x * 16;
+    uint8_t v[16];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = (t0 + k < n) ? valid[t0 + k] : (uint8_t)0;
+        c += v[k] ? 1 : 0;
+    }
+    __shared__ int s[256];
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int a = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += a;
+        __syncthreads();
+    }
+    unsigned long long r = tile_off[blockIdx.x] + (unsigned long long)(s[threadIdx.x] - c);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (t0 + k < n) {
+            uint8_t o = 0;
+            if (v[k]) { o = mark[r]; ++r; }
+            inl_out[t0 + k] = o;
+        }
+    }
 }
 
 NkGeom geom_of(const xdemhip_nk_plan* P, double dr, double dc) {
@@ -1639,7 +1731,9 @@ extern "C" {
 void xdemhip_nk_destroy(xdemhip_nk_plan* P) {
     if (!P) return;
     (void)hipSetDevice(P->ctx->device);
-    if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (P->inlier) (void)hipFree(P->inlier); }
+    uint8_t* inl_created = P->subsampled ? P->inlier_user : P->inlier;
+    if (P->own_inputs) { (void)hipFree(P->ref); (void)hipFree(P->tba); if (inl_created) (void)hipFree(inl_created); }
+    if (P->sub_inlier) (void)hipFree(P->sub_inlier);
     void* bufs[] = {P->slope_tan, P->aspect, P->dh, P->y, P->valid, P->bins, P->bcache, P->scratch, P->ref_m, P->ext_idx, P->ext_cnt,
                     P->fz, P->cd_vals, P->c_st, P->fz_pack, P->badbits, P->mr_a, P->mr_b, P->mr_small, P->wg_sums};
     for (void* b : bufs)
@@ -1682,6 +1776,62 @@ int xdemhip_nk_set_rows(xdemhip_nk_plan* P, int64_t row_begin, int64_t row_end, 
     P->pr_have = false;      // ... and their medians are not the previous step's
     // valid mask / aux rasters outside the range are never read by this rank; recount the global number of valid pixels
     int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
+    if (rc) return rc;
+    if (n_valid) *n_valid = P->n_valid0;
+    return XDEMHIP_OK;
+}
+
+int xdemhip_nk_subsample(xdemhip_nk_plan* P, const int64_t* ranks, int64_t k, int memspace, int64_t* n_valid) {
+    XdFetchScope fetch_scope_(P ? P->ctx : nullptr);
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (ctx->allreduce || P->row0 != 0 || P->row1 != P->H || P->roff != 0 || P->nbuf != P->H)
+        return xd_fail(ctx, XDEMHIP_EINVAL, "xdemhip_nk_subsample: whole-raster plans of one process only (partitioned plans: pass the drawn mask as inlier mask)");
+    if (!ranks || k < 1 || k > P->n_valid0) return xd_fail(ctx, XDEMHIP_EINVAL, "xdemhip_nk_subsample: 1 <= k <= the plan's valid pixels");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int64_t n = P->H * P->W, n_tiles = (n + SUBS_TILE - 1) / SUBS_TILE, n_ranks = P->n_valid0;
+    if (n_tiles > 0x7FFFFFFF) return xd_fail(ctx, XDEMHIP_EINVAL, "xdemhip_nk_subsample: raster too large");
+    uint8_t* mark = nullptr;
+    unsigned long long* tiles = nullptr;   // [n_tiles] counts -> offsets, [n_tiles] total, [n_tiles + 1] ranks out of range
+    int64_t* d_ranks = nullptr;
+    auto release = [&]() {
+        if (mark) (void)hipFree(mark);
+        if (tiles) (void)hipFree(tiles);
+        if (d_ranks) (void)hipFree(d_ranks);
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&mark), (size_t)n_ranks) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&tiles), (size_t)(n_tiles + 2) * 8) != hipSuccess ||
+        (memspace == XDEMHIP_HOST && hipMalloc(reinterpret_cast<void**>(&d_ranks), (size_t)k * 8) != hipSuccess) ||
+        (!P->sub_inlier && hipMalloc(reinterpret_cast<void**>(&P->sub_inlier), (size_t)n) != hipSuccess)) {
+        (void)hipGetLastError();
+        release();
+        return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed (xdemhip_nk_subsample)");
+    }
+    auto fail = [&](int code, const char* msg) { release(); return xd_fail(ctx, code, msg); };
+    const int64_t* rk = ranks;
+    if (memspace == XDEMHIP_HOST) {
+        if (hipMemcpyAsync(d_ranks, ranks, (size_t)k * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(XDEMHIP_EHIP, "copy of the ranks failed");
+        rk = d_ranks;
+    }
+    if (hipMemsetAsync(mark, 0, (size_t)n_ranks, ctx->stream) != hipSuccess || hipMemsetAsync(tiles + n_tiles, 0, 16, ctx->stream) != hipSuccess)
+        return fail(XDEMHIP_EHIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(nk_subs_mark_kernel, dim3(grid_for(ctx, k, 256, 8)), dim3(256), 0, ctx->stream, rk, k, n_ranks, mark, tiles + n_tiles + 1);
+    hipLaunchKernelGGL(nk_subs_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, ctx->stream, P->valid, n, tiles);
+    hipLaunchKernelGGL(nk_subs_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tiles, n_tiles, tiles + n_tiles);
+    hipLaunchKernelGGL(nk_subs_apply_kernel, dim3((unsigned)n_tiles), dim3(256), 0, ctx->stream, P->valid, n, tiles, mark, P->sub_inlier);
+    if (hipGetLastError() != hipSuccess) return fail(XDEMHIP_EHIP, "xdemhip_nk_subsample: kernel launch failed");
+    unsigned long long chk[2] = {0, 0};
+    { const int rc_ = xd_d2h(ctx, chk, tiles + n_tiles, 16); if (rc_) { release(); return rc_; } }
+    { const int rc_ = xd_sync(ctx); if (rc_) { release(); return rc_; } }
+    release();
+    if ((long long)chk[0] != P->n_valid0) return xd_fail(ctx, XDEMHIP_EINVAL, "xdemhip_nk_subsample: the valid mask changed under the call");
+    if (chk[1] != 0) return xd_fail(ctx, XDEMHIP_EINVAL, "xdemhip_nk_subsample: a rank is outside [0, n_valid)");
+    if (!P->subsampled) { P->inlier_user = P->inlier; P->subsampled = true; }
+    P->inlier = P->sub_inlier;
+    // (as after xdemhip_nk_set_rows: other valid pixels -- no cached bins, no previous medians, no measured sample offsets)
+    P->bcache_force = true;
+    P->pr_have = false;
+    P->fz_narrow = 0; P->fz_unit_min = 0.25; P->fz_worst = 0.0; P->fz_off2 = 0.0; P->fz_offn = 0;
+    const int rc = P->dtype == XDEMHIP_F32 ? nk_aux_typed<float>(P) : nk_aux_typed<double>(P);
     if (rc) return rc;
     if (n_valid) *n_valid = P->n_valid0;
     return XDEMHIP_OK;
