@@ -571,49 +571,78 @@ def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = N
     valid = np.isfinite(values)
     all_valid = bool(valid.all())
     list_df_run = []
-    for i in range(n_variograms):
+
+    def equidistant_blocks(i):
+        """The point sets of variogram `i` under ``cdist_equidistant`` (its own generator: nothing it draws depends on the other variograms)."""
         run_rng = np.random.default_rng(list_random_state[i])
-        if subsample_method == "cdist_equidistant":
-            if "runs" in kwargs or "samples" in kwargs:
-                # user-defined: upstream only auto-chooses when NEITHER is given (spatialstats.py:1203) and otherwise leaves
-                # the missing one to RasterEquidistantMetricSpace's defaults (samples=100, ratio_subsample=0.01,
-                # runs = 1 % of the coordinates / samples)
-                samples = int(kwargs.get("samples", 100))
-                ratio = kwargs.get("ratio_subsample", 0.01)
-                runs = int(kwargs["runs"]) if kwargs.get("runs") is not None else int(np.count_nonzero(valid) * 0.01 / samples)
-            else:
-                runs, samples, ratio = _choose_cdist_equidistant_sampling_parameters(
-                    extent=extent, shape=shape2d, subsample=subsample, **({"nb_rings": kwargs["nb_rings"]} if "nb_rings" in kwargs else {}))
-            if coords is not None:
-                blocks = equidistant_blocks_from_coords(coords, values, valid, gsd, runs, samples, ratio, run_rng)
-            else:  # full raster, indexed (values.shape[0] along x) like upstream's meshgrid call
-                blocks = equidistant_blocks_from_raster(values.reshape(shape2d[1], shape2d[0]), gsd, runs, samples, ratio, run_rng,
-                                                        valid2d=None if all_valid else valid.reshape(shape2d[1], shape2d[0]),
-                                                        assume_valid=all_valid)
-        elif subsample_method == "cdist_point":
-            idx = np.flatnonzero(valid)
-            n = min(int(subsample), idx.size)
-            a = run_rng.choice(idx, n, replace=False)
-            b = run_rng.choice(idx, n, replace=False)
-            blocks = [xy_of(a) + (values[a],) + xy_of(b) + (values[b],)]
-        elif subsample_method == "pdist_point":
-            idx = np.flatnonzero(valid)
-            a = run_rng.choice(idx, min(int(subsample), idx.size), replace=False)
-            blocks = [xy_of(a) + (values[a],)]
-        else:  # pdist_disk / pdist_ring: one pdist variogram per range, all rows kept (1007-1060)
-            for sel in _pdist_multi_range_subsamples(valid, shape2d, int(subsample), subsample_method, gsd, kwargs["maxlag"],
-                                                     kwargs.get("pdist_multi_ranges"), list_random_state[i]):
-                blk = [xy_of(sel) + (values[sel],)]
-                e_run = edges_for(blk)
-                exp, count = empirical_variogram_pairs(blk, e_run, estimator)
-                list_df_run.append(pd.DataFrame().assign(exp=exp, bins=e_run, count=count))
-            continue
-        e_run = edges_for(blocks) if blocks else (edges if edges is not None else np.linspace(0, kwargs["maxlag"], even_lags + 1)[1:])
-        if blocks:
-            exp, count = empirical_variogram_pairs(blocks, e_run, estimator)
+        if "runs" in kwargs or "samples" in kwargs:
+            # user-defined: upstream only auto-chooses when NEITHER is given (spatialstats.py:1203) and otherwise leaves
+            # the missing one to RasterEquidistantMetricSpace's defaults (samples=100, ratio_subsample=0.01,
+            # runs = 1 % of the coordinates / samples)
+            samples = int(kwargs.get("samples", 100))
+            ratio = kwargs.get("ratio_subsample", 0.01)
+            runs = int(kwargs["runs"]) if kwargs.get("runs") is not None else int(np.count_nonzero(valid) * 0.01 / samples)
         else:
-            exp, count = np.full(e_run.size, np.nan), np.zeros(e_run.size, dtype=np.int64)
-        list_df_run.append(pd.DataFrame().assign(exp=exp, bins=e_run, count=count))
+            runs, samples, ratio = _choose_cdist_equidistant_sampling_parameters(
+                extent=extent, shape=shape2d, subsample=subsample, **({"nb_rings": kwargs["nb_rings"]} if "nb_rings" in kwargs else {}))
+        if coords is not None:
+            return equidistant_blocks_from_coords(coords, values, valid, gsd, runs, samples, ratio, run_rng)
+        # full raster, indexed (values.shape[0] along x) like upstream's meshgrid call
+        return equidistant_blocks_from_raster(values.reshape(shape2d[1], shape2d[0]), gsd, runs, samples, ratio, run_rng,
+                                              valid2d=None if all_valid else valid.reshape(shape2d[1], shape2d[0]),
+                                              assume_valid=all_valid)
+
+    # Several variograms (the error bars of upstream's n_variograms): the host preparation of the NEXT one -- sampling of the metric
+    # space, gathers, Morton-ordered copies: native threaded code that releases the GIL -- runs while the GPU works through the
+    # pair passes of the current one (a helper thread, one variogram ahead; every variogram has its own generator, so the numbers
+    # drawn do not depend on when)
+    ahead = None
+    pool = None
+    # (not for the largest samples: a prepared variogram of subsample 1e7 is ~12 GB of host arrays, and its passes take 15-20 s
+    #  against 3.5 s of preparation -- nothing worth a second copy in memory)
+    if subsample_method == "cdist_equidistant" and n_variograms > 1 and subsample <= 2_000_000:
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = ThreadPoolExecutor(max_workers=1)
+        ahead = pool.submit(equidistant_blocks, 0)
+    try:
+        for i in range(n_variograms):
+            run_rng = np.random.default_rng(list_random_state[i])
+            if subsample_method == "cdist_equidistant" and ahead is not None:
+                blocks = ahead.result()
+                ahead = pool.submit(equidistant_blocks, i + 1) if i + 1 < n_variograms else None
+                if ahead is None:
+                    pool.shutdown(wait=False)
+                    pool = None
+            elif subsample_method == "cdist_equidistant":
+                blocks = equidistant_blocks(i)
+            elif subsample_method == "cdist_point":
+                idx = np.flatnonzero(valid)
+                n = min(int(subsample), idx.size)
+                a = run_rng.choice(idx, n, replace=False)
+                b = run_rng.choice(idx, n, replace=False)
+                blocks = [xy_of(a) + (values[a],) + xy_of(b) + (values[b],)]
+            elif subsample_method == "pdist_point":
+                idx = np.flatnonzero(valid)
+                a = run_rng.choice(idx, min(int(subsample), idx.size), replace=False)
+                blocks = [xy_of(a) + (values[a],)]
+            else:  # pdist_disk / pdist_ring: one pdist variogram per range, all rows kept (1007-1060)
+                for sel in _pdist_multi_range_subsamples(valid, shape2d, int(subsample), subsample_method, gsd, kwargs["maxlag"],
+                                                         kwargs.get("pdist_multi_ranges"), list_random_state[i]):
+                    blk = [xy_of(sel) + (values[sel],)]
+                    e_run = edges_for(blk)
+                    exp, count = empirical_variogram_pairs(blk, e_run, estimator)
+                    list_df_run.append(pd.DataFrame().assign(exp=exp, bins=e_run, count=count))
+                continue
+            e_run = edges_for(blocks) if blocks else (edges if edges is not None else np.linspace(0, kwargs["maxlag"], even_lags + 1)[1:])
+            if blocks:
+                exp, count = empirical_variogram_pairs(blocks, e_run, estimator)
+            else:
+                exp, count = np.full(e_run.size, np.nan), np.zeros(e_run.size, dtype=np.int64)
+            list_df_run.append(pd.DataFrame().assign(exp=exp, bins=e_run, count=count))
+    finally:
+        if pool is not None:   # (an exception on the way: the helper thread is not left waiting on the executor)
+            pool.shutdown(wait=False, cancel_futures=True)
 
     every_run = pd.concat(list_df_run)
     if n_variograms == 1:
