@@ -177,6 +177,10 @@ int xdemhip_host_ring_sample(const uint8_t* valid, int64_t ny, int64_t nx, doubl
  * sv_out: the slot order the pair kernels' run-length accumulation wants). */
 int xdemhip_host_gather_points(const void* values, int dtype, int64_t nx, double gsd, int n_blocks, const int64_t* off, const int64_t* idx,
                                int threads, double* x_out, double* y_out, void* v_out, double* sx_out, double* sy_out, void* sv_out);
+/* np.isfinite(values) over a host array of gigabytes on `threads` threads (the first thing sample_empirical_variogram does with its
+ * raster, xdem/spatialstats.py:1404-1410: the NaN filter of its values): the number of finite elements, and -- if valid_out is not
+ * NULL -- the 0 / 1 mask itself (a caller whose raster turns out to be all finite never needs one). */
+int xdemhip_host_count_finite(const void* values, int dtype, int64_t n, int threads, int64_t* n_finite, uint8_t* valid_out);
 /* This process's place among the ranks the hooks reduce over (round 5).  The hooks only combine; a few exchanges of the one-pass
  * Nuth-Kaab step on partitioned plans need every rank's contribution SEPARATELY (per-rank histogram rows, per-rank slices of a small
  * key list): they travel as sum all-reduces in which every rank fills its own slot and adds zeros to the others', for which the

@@ -750,3 +750,29 @@ def test_native_ring_sampler_and_gather():
     a_off, pax, pay, pav, b_off, pbx, pby, pbv = blocks.packed
     assert np.array_equal(pax, np.concatenate([b[0] for b in blocks])) and np.array_equal(pbv, np.concatenate([b[5] for b in blocks]))
     assert a_off[-1] == pax.size and b_off[-1] == pbx.size
+
+
+def test_native_count_finite_equals_numpy():
+    """xdemhip_host_count_finite (the NaN filter of sample_empirical_variogram on the library's host threads) against np.isfinite:
+    NaN payloads, both infinities, zeros of both signs, subnormals, the largest finite values; float32 / float64; more elements than
+    one piece of the thread loop; the NumPy fall-back for arrays the native code does not take."""
+    from xdem_amd import spatialstats
+
+    rng = np.random.default_rng(0)
+    for dt, bits in ((np.float32, np.uint32), (np.float64, np.uint64)):
+        v = rng.standard_normal(5_000_003).astype(dt)
+        v[rng.integers(0, v.size, 1000)] = np.nan
+        v[rng.integers(0, v.size, 500)] = np.inf
+        v[rng.integers(0, v.size, 500)] = -np.inf
+        special = np.array([0.0, -0.0, np.finfo(dt).max, -np.finfo(dt).max, np.finfo(dt).tiny / 4, np.nan, -np.nan], dtype=dt)
+        v[:special.size] = special
+        v[special.size:special.size + 2] = np.array([np.iinfo(bits).max, np.iinfo(bits).max >> 1], dtype=bits).view(dt)   # NaNs with full payloads
+        want = np.isfinite(v)
+        n, mask = spatialstats._count_finite(v)
+        assert n == int(want.sum()) and mask is None
+        n, mask = spatialstats._count_finite(v, want_mask=True)
+        assert n == int(want.sum()) and mask.dtype == np.bool_ and np.array_equal(mask, want)
+        n, mask = spatialstats._count_finite(v[::2], want_mask=True)   # (not contiguous: NumPy)
+        assert n == int(want[::2].sum()) and np.array_equal(mask, want[::2])
+    assert spatialstats._count_finite(np.empty(0, dtype=np.float32)) == (0, None)
+    assert spatialstats._count_finite(np.arange(10, dtype=np.float16))[0] == 10

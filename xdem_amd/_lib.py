@@ -138,6 +138,7 @@ def lib() -> ctypes.CDLL:
                                              c_dp, c_i64p, c_dp, c_dp, c_dp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_nk_predict_counts.argtypes = [ctypes.c_void_p, c_i64p, c_i64p, c_i64p]
         L.xdemhip_nk_subsample.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_i64p]
+        L.xdemhip_host_count_finite.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_i64p, ctypes.c_void_p]
         c_u64p = ctypes.POINTER(ctypes.c_uint64)
         L.xdemhip_pairs_create.argtypes = [c_ctx, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,

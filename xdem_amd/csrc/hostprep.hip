@@ -168,6 +168,8 @@ template <class W, class F> void parallel_for(int64_t n, int threads, F f) {
     for (auto& th : pool) th.join();
 }
 
+struct NoScratch {};
+
 inline uint32_t spread16(uint32_t v) {
     v = (v | (v << 8)) & 0x00FF00FFu;
     v = (v | (v << 4)) & 0x0F0F0F0Fu;
@@ -252,6 +254,31 @@ int xdemhip_host_gather_points(const void* values, int dtype, int64_t nx, double
             else static_cast<double*>(sv_out)[o + i] = static_cast<const double*>(v_out)[j];
         }
     });
+    return XDEMHIP_OK;
+}
+
+// (declared in include/xdemhip.h)
+int xdemhip_host_count_finite(const void* values, int dtype, int64_t n, int threads, int64_t* n_finite, uint8_t* valid_out) {
+    if ((!values && n > 0) || (dtype != XDEMHIP_F32 && dtype != XDEMHIP_F64) || n < 0 || !n_finite) return XDEMHIP_EINVAL;
+    constexpr int64_t PIECE = (int64_t)1 << 22;
+    const int64_t pieces = (n + PIECE - 1) / PIECE;
+    std::atomic<int64_t> total(0);
+    parallel_for<NoScratch>(pieces, threads, [&](int64_t k, NoScratch&) {
+        const int64_t a = k * PIECE, b = std::min(n, a + PIECE);
+        int64_t c = 0;
+        // (finite <=> the exponent bits are not all ones: integer tests, which the compiler vectorises)
+        if (dtype == XDEMHIP_F32) {
+            const uint32_t* v = static_cast<const uint32_t*>(values);
+            if (valid_out) for (int64_t i = a; i < b; ++i) { const int f = (v[i] & 0x7F800000u) != 0x7F800000u; valid_out[i] = (uint8_t)f; c += f; }
+            else for (int64_t i = a; i < b; ++i) c += (v[i] & 0x7F800000u) != 0x7F800000u;
+        } else {
+            const uint64_t* v = static_cast<const uint64_t*>(values);
+            if (valid_out) for (int64_t i = a; i < b; ++i) { const int f = (v[i] & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; valid_out[i] = (uint8_t)f; c += f; }
+            else for (int64_t i = a; i < b; ++i) c += (v[i] & 0x7FF0000000000000ull) != 0x7FF0000000000000ull;
+        }
+        total.fetch_add(c);
+    });
+    *n_finite = total.load();
     return XDEMHIP_OK;
 }
 
