@@ -174,7 +174,9 @@ class PairSet:
     """Device-resident pair blocks + lag edges (``xdemhip_pairs``).  ``blocks`` is a list of (ax, ay, av, bx, by, bv)
     (every a with every b) or (ax, ay, av) (all i < j)."""
 
-    def __init__(self, blocks: list[tuple], right_edges, ctx: _lib.Context | None = None):
+    def __init__(self, blocks: list[tuple], right_edges, ctx: _lib.Context | None = None, selection: bool = True):
+        """``selection=False``: the caller will only ask for sums (Matheron / Cressie) -- the copy in the caller's order, which only the
+        exact-median selection reads, is not made (half the uploads and lattice scans of the construction)."""
         if not blocks:
             raise ValueError("at least one pair block is required")
         pd = len(blocks[0]) == 3
@@ -223,25 +225,32 @@ class PairSet:
 
         self.handle = self.handle_sel = None
         self.shadow = self.shadow_sel = None
-        self.handle_sel, self.n_pairs = create(blocks, packed=getattr(blocks, "packed", None))
-        if self.ctx.options.get("vario_sort", 1):
-            try:
-                if getattr(blocks, "packed_sorted", None) is not None and not pd:
-                    self.handle, n2 = create(blocks, packed=blocks.packed_sorted)
-                else:
-                    self.handle, n2 = create(_host_map(_morton_sorted_block, list(blocks)))
-            except Exception:
-                self.close()
-                raise
-            assert n2 == self.n_pairs
-            # the selection's one pass over all pairs reads the sorted copy (run-length counters, csrc/variogram.hip)
-            self.ctx.check(self.ctx._L.xdemhip_pairs_link_sorted(self.handle_sel, self.handle))
+        def create_sorted():
+            if getattr(blocks, "packed_sorted", None) is not None and not pd:
+                return create(blocks, packed=blocks.packed_sorted)
+            return create(_host_map(_morton_sorted_block, list(blocks)))
+
+        if not selection and self.ctx.options.get("vario_sort", 1):
+            # sums only: the Morton-ordered copy alone (it also answers a selection, should one be asked for after all)
+            self.handle, self.n_pairs = create_sorted()
+            self.handle_sel = self.handle
         else:
-            self.handle = self.handle_sel
+            self.handle_sel, self.n_pairs = create(blocks, packed=getattr(blocks, "packed", None))
+            if self.ctx.options.get("vario_sort", 1):
+                try:
+                    self.handle, n2 = create_sorted()
+                except Exception:
+                    self.close()
+                    raise
+                assert n2 == self.n_pairs
+                # the selection's one pass over all pairs reads the sorted copy (run-length counters, csrc/variogram.hip)
+                self.ctx.check(self.ctx._L.xdemhip_pairs_link_sorted(self.handle_sel, self.handle))
+            else:
+                self.handle = self.handle_sel
         # float64 differences of float32 values, large sets (the bracketed route's domain, csrc/variogram.hip: PAIRS_BRACKET_MIN):
         # float32 copies of both orders, linked as the shadow of the float64 selection set (xdemhip_pairs_link_shadow)
         takes = ctypes.c_int(0)
-        if widened:   # (the library knows its own route: size threshold, classes per sweep, selection mode, reduction hook)
+        if widened and selection:   # (the library knows its own route: size threshold, classes per sweep, selection mode, reduction hook)
             self.ctx.check(self.ctx._L.xdemhip_pairs_takes_brackets(self.handle_sel, ctypes.byref(takes)))
         if widened and takes.value:
             try:
@@ -417,7 +426,7 @@ def empirical_variogram_pairs(blocks: list[tuple], right_edges, estimator: str =
     estimator = estimator.lower()
     if estimator not in _ESTIMATORS:
         raise ValueError(f"estimator must be one of {_ESTIMATORS}")
-    pairs = PairSet(blocks, right_edges, ctx)
+    pairs = PairSet(blocks, right_edges, ctx, selection=estimator == "dowd")
     try:
         if estimator == "dowd":
             med, count = class_medians(pairs, group)
