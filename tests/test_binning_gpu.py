@@ -189,6 +189,25 @@ def test_nmad_device_matches_numpy():
         assert cnt == np.isfinite(w).sum() and med == np.nanmedian(w) and nm == float(bo.nmad(w))
 
 
+def test_nmad_of_a_large_array_takes_the_device_route_and_returns_numpys_scalar():
+    """``spatialstats.nmad`` on raster-sized float arrays goes through ``nmad_device`` (exact selection): the value and the scalar type
+    NumPy's expression returns, for float32 / float64, NaNs, a masked array and a non-default ``nfact``; small arrays stay on the host."""
+    from xdem_amd import spatialstats as ss
+
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64):
+        v = rng.standard_t(3, (2100, 2000)).astype(dt)
+        v[::7, ::13] = np.nan
+        for nfact in (1.4826, 1.0):
+            want = nfact * np.nanmedian(np.abs(v - np.nanmedian(v)))
+            got = ss.nmad(v, nfact)
+            assert type(got) is type(want) and got == want, (dt, nfact, got, want)
+        m = np.ma.masked_array(v, mask=np.isnan(v))
+        assert ss.nmad(m) == 1.4826 * np.nanmedian(np.abs(v - np.nanmedian(v)))
+    small = rng.normal(size=1000).astype(np.float32)
+    assert ss.nmad(small) == 1.4826 * np.nanmedian(np.abs(small - np.nanmedian(small)))
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_selection_modes_agree_on_large_inputs(mode):
     """Bracketed selection (sample -> brackets -> one counting/compaction pass -> candidates; mode 3 forces it for the
