@@ -766,6 +766,18 @@ def end_to_end_calls(ctx, dev) -> dict:
     a = nk.meta["outputs"]["affine"]
     out["nuthkaab"] = {"workload": "NuthKaab(subsample=1, max_iterations=10).fit on the C3 pair as NumPy arrays (20000x20000 float32 each)",
                        "seconds": round(dt, 3), "shift": [round(float(a["shift_x"]), 3), round(float(a["shift_y"]), 3), round(float(a["shift_z"]), 3)]}
+    # ... and with the reference's DEFAULT subsample (5e5 of the valid pixels, drawn once: ranks on the host, pixels on the device)
+    t0 = time.perf_counter()
+    nk = coreg.NuthKaab(max_iterations=10, offset_threshold=0.0).fit(ref, tba, None, resolution=10.0, random_state=42)
+    dt = time.perf_counter() - t0
+    a = nk.meta["outputs"]["affine"]
+    out["nuthkaab_default_subsample"] = {"workload": "NuthKaab(max_iterations=10).fit (subsample=5e5, the reference's default) on the same NumPy arrays",
+                                         "seconds": round(dt, 3), "subsample_final": int(nk.meta["outputs"]["random"]["subsample_final"]),
+                                         "shift": [round(float(a["shift_x"]), 3), round(float(a["shift_y"]), 3), round(float(a["shift_z"]), 3)]}
+    t0 = time.perf_counter()
+    moved = coreg.apply_translation(tba, 17.0, 6.0, 2.0, 10.0)
+    out["apply_translation"] = {"workload": "apply_translation of the 20000x20000 float32 NumPy raster (upload, bilinear resample, download)",
+                                "seconds": round(time.perf_counter() - t0, 3), "shape_ok": bool(moved.shape == tba.shape)}
     return out
 
 
