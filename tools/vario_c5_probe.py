@@ -17,7 +17,7 @@ from xdem_amd.synth import c5_variogram_blocks
 
 if os.environ.get("XD_LIB"):   # A/B of library builds across processes
     _lib.LIB_PATH = os.environ["XD_LIB"]
-deffs = [int(a) for a in sys.argv[1:]] or [4096, 0]
+deffs = [int(a) for a in sys.argv[1:]] or [4096, 0]   # (non-zero values need an -DXD_EXPERIMENT build: "vario_deff" is a measurement switch)
 runs = int(os.environ.get("C5_RUNS", "100"))
 ctx = _lib.default_context(0)
 blocks, edges = c5_variogram_blocks(torch.device("cuda:0"), runs=runs, samples=9091)
@@ -29,7 +29,8 @@ s_m, c_m = ps.sums(0)
 print(f"pairs {total:.4e}; Matheron pass {ctx.last_kernel_ms():.2f} ms", flush=True)
 ref = None
 for d in deffs:
-    ctx.set_option("vario_deff", d)
+    if d != 0:
+        ctx.set_option("vario_deff", d)
     ss.class_medians(ps)                      # first call under this setting (candidate buffers may grow)
     sys.stderr.write(f"---- vario_deff = {d}: timed call\n")
     sys.stderr.flush()
@@ -41,5 +42,6 @@ for d in deffs:
         ref = (med, cnt)
     assert np.array_equal(cnt, c_m), "class counts differ from the Matheron pass"
     print(f"vario_deff {d:5d}: exact Dowd {dt * 1e3:7.1f} ms = {total / dt / 1e9:7.1f} Gpairs/s   medians {same}", flush=True)
-ctx.set_option("vario_deff", 0)
+if any(deffs):
+    ctx.set_option("vario_deff", 0)
 ps.close()
