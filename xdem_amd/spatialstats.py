@@ -1382,10 +1382,15 @@ def infer_heteroscedasticity_from_stable(dvalues, list_var, stable_mask=None, un
     for m in (stable_mask, unstable_mask):
         if m is not None and not isinstance(m, np.ndarray):
             raise ValueError("xdem_amd takes stable / unstable masks as boolean arrays (vector rasterisation is outside the hot path).")
-    include = np.ones(np.shape(arrs[0]), dtype=bool) if stable_mask is None else np.asarray(stable_mask, dtype=bool)
-    exclude = np.zeros(np.shape(arrs[0]), dtype=bool) if unstable_mask is None else np.asarray(unstable_mask, dtype=bool)
-    include = np.logical_and(include, ~exclude).squeeze()
-    stable = [a[include] for a in arrs]
+    if stable_mask is None and unstable_mask is None:
+        # (everything is stable terrain: upstream's all-True mask selects every element in C order -- the flat views, without three
+        #  raster-sized boolean-index copies; nothing below writes to them)
+        stable = [np.asarray(a).squeeze().reshape(-1) for a in arrs]
+    else:
+        include = np.ones(np.shape(arrs[0]), dtype=bool) if stable_mask is None else np.asarray(stable_mask, dtype=bool)
+        exclude = np.zeros(np.shape(arrs[0]), dtype=bool) if unstable_mask is None else np.asarray(unstable_mask, dtype=bool)
+        include = np.logical_and(include, ~exclude).squeeze()
+        stable = [a[include] for a in arrs]
     df, fun = _estimate_model_heteroscedasticity(stable[0], stable[1:], list_var_names, spread_statistic, list_var_bins, min_count,
                                                  fac_spread_outliers, ctx)
     error = fun(tuple(arrs[1:]))
