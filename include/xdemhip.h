@@ -344,6 +344,32 @@ int xdemhip_binned_median(xdemhip_ctx* ctx, const void* x, const void* y, int dt
 int xdemhip_mean_filter_nan(xdemhip_ctx* ctx, const void* img, int dtype, int64_t H, int64_t W, int kernel_size, int kernel_shape,
                             double* mean_out, double* nvalid_out, int* n_kernel_px, int memspace);
 
+/* Row a5 as the PUBLIC function: xdem.spatialstats.convolution(imgs, filters, method)
+ * (xdem/spatialstats.py:2558-2594; called by the reference's surface fit, surfit.py:1107, and by its tests,
+ * tests/test_terrain/test_surfit.py:542-563, 612): `n_img` images (H x W, `dtype` float32 / float64, contiguous) against
+ * `n_f` filters (M1 x M2, float64, HOST memory whatever `memspace` says) -> out float64 (n_img, n_f, H, W).
+ * method 0 = "scipy": scipy.ndimage.convolve(img, filter, mode="constant", cval=nan) per pair (_scipy_convolution,
+ * spatialstats.py:2512-2525) -- true convolution, weights with |w| <= DBL_EPSILON skipped, NaN beyond the border, double
+ * accumulation in SciPy's tap order, rounded to the image dtype; method 1 = "numba": the loop of _numba_convolution
+ * (spatialstats.py:2528-2555) on the NaN-padded images of 2582-2585 -- correlation over every tap, unrounded float64, last
+ * row / column left 0 for an even filter size.  Bit for bit in both (tests/test_convolution_gpu.py). */
+int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype, int64_t n_img, int64_t H, int64_t W, const double* filters,
+                        int n_f, int M1, int M2, int method, double* out, int memspace);
+
+/* "Next" row f3, consumer side: xdem.spatialstats.get_perbin_nd_binning(df, list_var, list_var_names,
+ * statistic, min_count) (xdem/spatialstats.py:425-527; used by the bias corrections, xdem/coreg/biascorr.py:302) as ONE
+ * lookup per pixel instead of a mask per bin.  `vars[k]` = variable k (n values, `var_dtypes[k]` float32 / float64, in
+ * `memspace`); host tables: variable k's `n_intervals[k]` sorted unique intervals [left, right) concatenated in `left` /
+ * `right` (float64, already rounded to the dtype NumPy compares in), `table` / `pass` over the Cartesian product of the
+ * intervals in itertools.product order (last variable fastest): the bin's statistic and 1 = write it (count > min_count),
+ * 0 = leave NaN, 2 = the DataFrame has no such row.  `disjoint` != 0: the intervals of every variable are pairwise disjoint
+ * (nd_binning's output) -- one containing interval per variable; 0: overlapping intervals, the product is walked per pixel in
+ * upstream's order and the last bin that writes wins.  out float64 (n); *n_missing = pixels lying in a bin of kind 2 (upstream
+ * raises IndexError there, and so does the Python side). */
+int xdemhip_perbin_lookup(xdemhip_ctx* ctx, const void* const* vars, const int* var_dtypes, int n_var, int64_t n,
+                          const int* n_intervals, const double* left, const double* right, const double* table,
+                          const unsigned char* pass, int disjoint, double* out, int64_t* n_missing, int memspace);
+
 /* "Next" row f1: the step right after a Nuth-Kaab fit -- resampling the translated DEM back onto
  * its own grid, i.e. _reproject_horizontal_shift_samecrs(raster_arr, src_transform, dst_transform)
  * (xdem/coreg/base.py:1615-1655) as used by Coreg.apply for pure translations:

@@ -297,7 +297,7 @@ def terrain_T10() -> None:
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["terrain", "nk", "vario", "binning", "patches"]
+    which = sys.argv[1:] or ["terrain", "nk", "vario", "binning", "patches", "conv"]
     if "terrain" in which:
         _check_tables()
         terrain_T1()
@@ -324,3 +324,7 @@ if __name__ == "__main__":
         import gen_golden_patches
 
         gen_golden_patches.main(ref, OUT)
+    if "conv" in which:
+        import gen_golden_conv
+
+        gen_golden_conv.main(ref, OUT)

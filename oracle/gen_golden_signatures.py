@@ -21,7 +21,8 @@ SPATIALSTATS = ["nd_binning", "interp_nd_binning", "two_step_standardization", "
                 "sample_empirical_variogram", "get_variogram_model_func", "covariance_from_variogram", "correlation_from_variogram",
                 "fit_sum_model_variogram", "infer_spatial_correlation_from_stable", "neff_circular_approx_theoretical",
                 "neff_circular_approx_numerical", "neff_exact", "neff_hugonnet_approx", "number_effective_samples",
-                "spatial_error_propagation", "mean_filter_nan", "patches_method", "_patches_convolution", "_patches_loop_quadrants"]
+                "spatial_error_propagation", "mean_filter_nan", "patches_method", "_patches_convolution", "_patches_loop_quadrants",
+                "convolution", "get_perbin_nd_binning", "_pandas_str_to_interval", "nmad"]
 
 
 def _literal(v):

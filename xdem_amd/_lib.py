@@ -124,6 +124,11 @@ def lib() -> ctypes.CDLL:
                                             c_dp, c_i64p, c_dp]
         L.xdemhip_mean_filter_nan.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        L.xdemhip_convolution.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_dp, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.xdemhip_perbin_lookup.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int64,
+                                            ctypes.POINTER(ctypes.c_int), c_dp, c_dp, c_dp, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
+                                            c_i64p, ctypes.c_int]
         L.xdemhip_shift_bilinear.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                              ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_set_allreduce.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_void_p]

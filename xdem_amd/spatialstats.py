@@ -1249,6 +1249,132 @@ def nmad_device(values: np.ndarray, nfact: float = 1.4826, abs_limit: float = np
     return med.value, nm.value, int(cnt.value)
 
 
+def _pandas_str_to_interval(istr):
+    """A ``pd.Interval`` written to text (a DataFrame saved to CSV without its MultiIndex) read back: ``"[0.0, 2.5)"`` ->
+    ``Interval(0.0, 2.5, closed="left")``; a float cell (NaN of another binning's rows) or an interval pandas refuses -> NaN.
+    Mirror of xdem/spatialstats.py:221-234."""
+    import pandas as pd
+
+    if isinstance(istr, float):
+        return np.nan
+    closed = {("[", ")"): "left", ("(", "]"): "right", ("[", "]"): "both"}.get((istr[0] if istr[0] == "[" else "(", istr[-1] if istr[-1] == "]" else ")"), "neither")
+    left, right = (float(t) for t in istr[1:-1].split(","))
+    try:
+        return pd.Interval(left, right, closed)
+    except Exception:
+        return np.nan
+
+
+def _edge_as_numpy_compares(dtype: np.dtype, edge) -> float:
+    """The value ``arr >= edge`` really tests against for an array of `dtype`: NumPy converts a Python number (a weak scalar: the
+    ends of an interval parsed from text) to the array's dtype before comparing, while a ``np.float64`` end -- what nd_binning's
+    ``pd.IntervalIndex.from_breaks`` stores -- widens a float32 array instead.  ``np.result_type`` answers for whichever
+    promotion rules the installed NumPy applies."""
+    return float(np.asarray(edge).astype(np.result_type(dtype, edge)))
+
+
+def get_perbin_nd_binning(df, list_var, list_var_names, statistic=np.nanmedian, min_count: int | None = 0,
+                          ctx: _lib.Context | None = None) -> np.ndarray:
+    """Per-pixel value of a binned statistic: every element of the explanatory variables receives the statistic of the bin of
+    `df` (an ``nd_binning`` output, or a DataFrame of ``pd.Interval`` columns) it falls into -- NaN outside every bin and in
+    bins whose count does not exceed `min_count`.  Drop-in for ``xdem.spatialstats.get_perbin_nd_binning``
+    (xdem/spatialstats.py:425-527; `statistic` a column name or a callable whose ``__name__`` is one, upstream's default is
+    ``np.nanmedian``), used by the bias corrections (xdem/coreg/biascorr.py:302).
+
+    Upstream builds one boolean mask per interval and variable and walks the product of the intervals, writing bin after bin;
+    here the small tables are prepared on the host -- sorted unique intervals per variable (``np.unique``, as upstream), the
+    statistic and the "count > min_count" decision per bin of the product -- and ``xdemhip_perbin_lookup`` does the per-pixel
+    search on the GPU.  Same results bit for bit, including overlapping intervals (the last bin of upstream's walk that writes
+    wins) and NaN variables.  Where upstream fails, this fails the same way: a pixel in a bin the DataFrame has no row for ->
+    ``IndexError`` (upstream's ``.values[0]`` on an empty selection); ``min_count=None`` with a pixel in any bin -> the
+    ``TypeError`` of ``count > None``.  One deviation: cells that are neither ``pd.Interval`` nor their text form raise the
+    ``ValueError`` upstream constructs at spatialstats.py:479 but forgets to raise (it dies with an ``AttributeError`` a few
+    lines later)."""
+    import itertools
+
+    import pandas as pd
+
+    shape = np.shape(list_var[0])
+    if isinstance(list_var_names, str):
+        list_var_names = [list_var_names]
+    if len(list_var) != len(list_var_names):
+        raise ValueError("The lists of variables and variable names should be the same length.")
+    for var in list_var_names:
+        if var not in df.columns:
+            raise ValueError('Variable "' + var + '" does not exist in the provided dataframe.')
+    statistic_name = statistic if isinstance(statistic, str) else statistic.__name__
+    if statistic_name not in df.columns:
+        raise ValueError('Statistic "' + statistic_name + '" does not exist in the provided dataframe.')
+    if min_count is not None and "count" not in df.columns:
+        raise ValueError('Statistic "count" is not in the provided dataframe, necessary to use the min_count argument.')
+    if df.empty:
+        raise ValueError("Dataframe is empty.")
+    rows = df.copy()
+    if "nd" in rows.columns:
+        rows = rows[rows.nd == len(list_var_names)]
+    for name in list_var_names:
+        cells = rows[name].values
+        if any(isinstance(x, pd.Interval) for x in cells):
+            continue
+        parsed = [_pandas_str_to_interval(x) for x in cells]
+        if not any(isinstance(x, pd.Interval) for x in parsed):
+            raise ValueError("The bin intervals of the dataframe should be pandas.Interval.")
+        rows[name] = parsed
+    n_var = len(list_var)
+    if n_var > 8:
+        raise NotImplementedError("get_perbin_nd_binning: at most 8 explanatory variables")
+    arrays, uniques = [], []
+    for k, name in enumerate(list_var_names):
+        a = np.ascontiguousarray(list_var[k])
+        if a.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            a = a.astype(np.float64)   # (integers and half floats compare as float64 against float ends: exact below 2^53)
+        if a.shape != shape:
+            raise ValueError(f"variable {name!r} has shape {a.shape}, the first variable {shape}")   # (upstream: a boolean-index error)
+        arrays.append(a.reshape(-1))
+        uniques.append(np.unique(rows[name].values))
+    counts = [len(u) for u in uniques]
+    n_bins = int(np.prod(counts, dtype=np.int64)) if all(counts) else 0
+    out = np.full(int(np.prod(shape, dtype=np.int64)), np.nan, dtype=np.float64)
+    if n_bins == 0 or out.size == 0:
+        return out.reshape(shape)
+    left = np.array([_edge_as_numpy_compares(arrays[k].dtype, iv.left) for k in range(n_var) for iv in uniques[k]], dtype=np.float64)
+    right = np.array([_edge_as_numpy_compares(arrays[k].dtype, iv.right) for k in range(n_var) for iv in uniques[k]], dtype=np.float64)
+    # the bin table over the product of the intervals (itertools.product order); the FIRST row of a bin counts (`.values[0]`)
+    table = np.full(n_bins, np.nan, dtype=np.float64)
+    decided = np.full(n_bins, 2, dtype=np.uint8)   # 2 = the DataFrame has no row for this bin
+    place = [{iv: j for j, iv in enumerate(u)} for u in uniques]
+    stat_col = rows[statistic_name].values
+    count_col = rows["count"].values if "count" in rows.columns else None
+    cols = [rows[name].values for name in list_var_names]
+    for r in range(len(rows)):
+        flat = 0
+        for k in range(n_var):
+            flat = flat * counts[k] + place[k][cols[k][r]]
+        if decided[flat] != 2:
+            continue
+        table[flat] = stat_col[r]
+        if min_count is None:
+            continue   # stays "undecidable": upstream's `count > None` raises as soon as a pixel lies in a bin (below)
+        decided[flat] = 1 if count_col[r] > min_count else 0
+    disjoint = all(all(uniques[k][j].right <= uniques[k][j + 1].left for j in range(counts[k] - 1)) for k in range(n_var))
+    ctx = ctx or _lib.default_context()
+    ptrs = (ctypes.c_void_p * n_var)(*[a.ctypes.data for a in arrays])
+    dts = (ctypes.c_int * n_var)(*[_lib.F32 if a.dtype == np.float32 else _lib.F64 for a in arrays])
+    nint = (ctypes.c_int * n_var)(*counts)
+    missing = ctypes.c_int64()
+    dp = ctypes.POINTER(ctypes.c_double)
+    with ctx.call_lock:
+        rc = ctx._L.xdemhip_perbin_lookup(ctx.handle, ptrs, dts, n_var, out.size, nint, left.ctypes.data_as(dp), right.ctypes.data_as(dp),
+                                          table.ctypes.data_as(dp), decided.ctypes.data_as(ctypes.c_char_p), 1 if disjoint else 0,
+                                          out.ctypes.data, ctypes.byref(missing), _lib.HOST)
+    ctx.check(rc)
+    if missing.value:
+        if min_count is None and count_col is not None:
+            count_col[0] > min_count   # noqa: B015 -- raises upstream's TypeError ('>' between a float and None)
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")   # upstream's `.values[0]` of a bin without a row
+    return out.reshape(shape)
+
+
 def _rows_of_one_binning(df, names: list[str], stat_col: str, min_count: int | None):
     """The rows of `df` that belong to the binning over exactly `names`, bin positions as numbers: (rows, statistic values,
     mask of the usable ones).  Refusals and their messages are upstream's (xdem/spatialstats.py:292-352, asserted by its tests)."""
@@ -1736,6 +1862,57 @@ def spatial_error_propagation(areas, errors, params_variogram_model, **kwargs: A
 # ======================================================================================================================
 # Patches method: mirror of xdem/spatialstats.py:2597-3048 over csrc/meanfilter.hip
 # ======================================================================================================================
+def convolution(imgs: np.ndarray, filters: np.ndarray, method: str = "scipy", ctx: _lib.Context | None = None) -> np.ndarray:
+    """Convolution of `n_N` images (N1 x N2) with `n_M` filters (M1 x M2): float64 array (n_N, n_M, N1, N2).  Drop-in for
+    ``xdem.spatialstats.convolution`` (xdem/spatialstats.py:2558-2594), the engine under the reference's surface fit
+    (surfit.py:1107) and mean filter, as ONE HIP kernel that reads an image once for all filters (``xdemhip_convolution``,
+    csrc/convolve.hip).  `method` selects WHICH of upstream's two engines is reproduced bit for bit, not where it runs:
+    "scipy" = ``scipy.ndimage.convolve(img, filter, mode="constant", cval=nan)`` (true convolution, zero weights skipped, NaN
+    beyond the border, the float64 sum rounded to the image dtype), any name containing "numba" = upstream's Numba loop on the
+    NaN-padded images (correlation over every tap, unrounded; an even filter size leaves the last row / column 0).
+    Images must be float32 or float64 (SciPy's result for integer images under ``cval=nan`` is a C cast of NaN: refused);
+    filters are taken as float64, as SciPy takes its weights.  torch device tensors are accepted for `imgs` and return a
+    device tensor."""
+    m = method.lower()
+    if m != "scipy" and "numba" not in m:
+        raise ValueError('Method must be "scipy" or "numba".')
+    code = 0 if m == "scipy" else 1
+    filt = np.ascontiguousarray(np.asarray(filters, dtype=np.float64))
+    if filt.ndim != 3:
+        raise ValueError(f"filters must have three dimensions (n_M, M1, M2), got shape {filt.shape}")
+    n_f, m1, m2 = filt.shape
+    ctx = ctx or _lib.default_context()
+    dp = ctypes.POINTER(ctypes.c_double)
+    is_tensor = type(imgs).__module__.startswith("torch")
+    if is_tensor:
+        import torch
+
+        t = imgs.contiguous()
+        if t.dim() != 3 or t.dtype not in (torch.float32, torch.float64) or not t.is_cuda:
+            raise TypeError("convolution: a device tensor must be a float32 / float64 CUDA tensor of shape (n_N, N1, N2)")
+        out = torch.empty((t.shape[0], n_f, t.shape[1], t.shape[2]), dtype=torch.float64, device=t.device)
+        with ctx.call_lock:
+            ctx.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+            rc = ctx._L.xdemhip_convolution(ctx.handle, t.data_ptr(), _lib.F32 if t.dtype == torch.float32 else _lib.F64, t.shape[0],
+                                            t.shape[1], t.shape[2], filt.ctypes.data_as(dp), n_f, m1, m2, code, out.data_ptr(), _lib.DEVICE)
+        ctx.check(rc)
+        return out
+    arr = np.ascontiguousarray(imgs)
+    if arr.ndim != 3:
+        raise ValueError(f"imgs must have three dimensions (n_N, N1, N2), got shape {arr.shape}")
+    if arr.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise TypeError(f"convolution: images must be float32 or float64, got {arr.dtype} (with cval=nan SciPy's result for other "
+                        "dtypes is a C cast of NaN; convert the images first)")
+    out = np.empty((arr.shape[0], n_f, arr.shape[1], arr.shape[2]), dtype=np.float64)
+    if out.size == 0:
+        return out
+    with ctx.call_lock:
+        rc = ctx._L.xdemhip_convolution(ctx.handle, arr.ctypes.data, _lib.F32 if arr.dtype == np.float32 else _lib.F64, arr.shape[0],
+                                        arr.shape[1], arr.shape[2], filt.ctypes.data_as(dp), n_f, m1, m2, code, out.ctypes.data, _lib.HOST)
+    ctx.check(rc)
+    return out
+
+
 def mean_filter_nan(img: np.ndarray, kernel_size: int, kernel_shape: str = "circular", method: str = "scipy",
                     ctx: _lib.Context | None = None) -> tuple[np.ndarray, np.ndarray, int]:
     """Mean filter with a square or circular kernel that ignores NaNs; drop-in for ``xdem.spatialstats.mean_filter_nan``
