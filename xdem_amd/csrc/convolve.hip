@@ -17,6 +17,10 @@
 // (outside the image: NaN) and every thread walks the taps of its 4 pixels, filter after filter -- the image is read once
 // for all filters.  HBM traffic: sizeof(T) read + 8 * n_M written per pixel.  Filters whose LDS patch would exceed 64 KiB
 // take the same loop on global memory (bounds tested per tap).
+// The sizes the reference itself uses (3 x 3 and 5 x 5 stencil tables, surfit.py:1107; 7 x 7) take convolve_window_kernel: a
+// thread owns 4 CONSECUTIVE rows of one column, reads the (4 + M1 - 1) x M2 window they share from LDS once -- 40 reads for
+// 5 x 5 instead of 100 per filter -- and keeps it in registers as float64 for all filters; the tap loops are unrolled, weights
+// and the per-filter bit mask of the taps that count (SciPy's footprint) are wave-uniform scalars.  Same sums in the same order.
 #include "common.h"
 
 #include <float.h>
@@ -31,16 +35,17 @@ constexpr size_t CV_LDS_MAX = 64 * 1024;
 
 struct CvArgs {
     int64_t H, W;
-    const int2* tap_yx;     // (dy, dx): image offset of a tap relative to the output pixel
-    const double* tap_w;
-    const int* f_start;     // taps of filter f: [f_start[f], f_start[f + 1])
     int n_f, dy_min, dx_min, M1, M2, round_to_t;
     int64_t vr, vc;         // rows / columns that receive a sum (the rest stays 0: the Numba engine with even filter sizes)
-    double* out;            // (n_f, H, W) of this image
 };
 
+// (the tap lists and the output are top-level __restrict__ parameters: only then are the wave-uniform tap reads scalar loads that
+// the compiler may issue ahead of the stores -- as members of the argument block they came out as one vector load + full wait per tap)
+// tap_yx: (dy, dx) image offset of a tap relative to the output pixel; taps of filter f: [f_start[f], f_start[f + 1]); out: (n_f, H, W)
 template <typename T, bool LDS>
-__global__ __launch_bounds__(256) void convolve_kernel(const T* __restrict__ img, CvArgs a) {
+__global__ __launch_bounds__(256) void convolve_kernel(const T* __restrict__ img, const int2* __restrict__ tap_yx,
+                                                       const double* __restrict__ tap_w, const int* __restrict__ f_start,
+                                                       double* __restrict__ out, CvArgs a) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     T* s = reinterpret_cast<T*>(s_raw);
     const int64_t x0 = (int64_t)blockIdx.x * CV_TX, y0 = (int64_t)blockIdx.y * CV_TY;
@@ -59,10 +64,10 @@ __global__ __launch_bounds__(256) void convolve_kernel(const T* __restrict__ img
     const int64_t plane = a.H * a.W;
     for (int f = 0; f < a.n_f; ++f) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const int k0 = a.f_start[f], k1 = a.f_start[f + 1];
+        const int k0 = f_start[f], k1 = f_start[f + 1];
         for (int k = k0; k < k1; ++k) {
-            const int2 yx = a.tap_yx[k];
-            const double w = a.tap_w[k];
+            const int2 yx = tap_yx[k];
+            const double w = tap_w[k];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ty = ty0 + 4 * q;
@@ -82,10 +87,73 @@ __global__ __launch_bounds__(256) void convolve_kernel(const T* __restrict__ img
                 const int64_t gy = y0 + ty0 + 4 * q;
                 if (gy >= a.H) continue;
                 const double r = a.round_to_t ? (double)(T)acc[q] : acc[q];
-                a.out[(int64_t)f * plane + gy * a.W + gx] = (gy < a.vr && gx < a.vc) ? r : 0.0;
+                out[(int64_t)f * plane + gy * a.W + gx] = (gy < a.vr && gx < a.vc) ? r : 0.0;
             }
         }
     }
+}
+
+// Small filters of compile-time size: the window of a thread's 4 consecutive rows lives in registers.
+// w: (n_f, M1, M2) weights in TAP order (SciPy: the flipped kernel), zeros included; mask: per filter, bit a * M2 + b set = the tap
+// takes part in the sum
+template <typename T, int M1, int M2>
+__global__ __launch_bounds__(256) void convolve_window_kernel(const T* __restrict__ img, const double* __restrict__ w_all,
+                                                              const unsigned long long* __restrict__ mask,
+                                                              double* __restrict__ out, CvArgs a) {
+    constexpr int PW = CV_TX + M2 - 1, PH = CV_TY + M1 - 1, RP = 4;
+    __shared__ T s[PH * PW];
+    const int64_t x0 = (int64_t)blockIdx.x * CV_TX, y0 = (int64_t)blockIdx.y * CV_TY;
+    const T nan_t = (T)NAN;
+    for (int k = threadIdx.x; k < PW * PH; k += 256) {
+        const int r = k / PW, c = k - r * PW;
+        const int64_t gy = y0 + a.dy_min + r, gx = x0 + a.dx_min + c;
+        s[k] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? img[gy * a.W + gx] : nan_t;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * RP;
+    double win[RP + M1 - 1][M2];
+#pragma unroll
+    for (int r = 0; r < RP + M1 - 1; ++r)
+#pragma unroll
+        for (int b = 0; b < M2; ++b) win[r][b] = (double)s[(r0 + r) * PW + tx + b];
+    const int64_t gx = x0 + tx, plane = a.H * a.W;
+    for (int f = 0; f < a.n_f; ++f) {
+        const unsigned long long m = mask[f];
+        const double* __restrict__ wf = w_all + (size_t)f * (M1 * M2);
+        double acc[RP] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < M1; ++r) {
+            double wr[M2];   // one tap row of weights at a time: a single scalar load of M2 doubles, one wait
+#pragma unroll
+            for (int b = 0; b < M2; ++b) wr[b] = wf[r * M2 + b];
+#pragma unroll
+            for (int b = 0; b < M2; ++b) {
+                if ((m >> (r * M2 + b)) & 1ull) {   // (wave-uniform)
+#pragma unroll
+                    for (int q = 0; q < RP; ++q) acc[q] = acc[q] + win[q + r][b] * wr[b];
+                }
+            }
+        }
+        if (gx < a.W) {
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+                const int64_t gy = y0 + r0 + q;
+                if (gy >= a.H) continue;
+                const double r = a.round_to_t ? (double)(T)acc[q] : acc[q];
+                out[(int64_t)f * plane + gy * a.W + gx] = (gy < a.vr && gx < a.vc) ? r : 0.0;
+            }
+        }
+    }
+}
+
+template <typename T>
+static bool launch_window(int M1, int M2, dim3 grid, hipStream_t st, const T* src, const double* w, const unsigned long long* mask,
+                          double* out, const CvArgs& a) {
+    if (M1 == 3 && M2 == 3) hipLaunchKernelGGL((convolve_window_kernel<T, 3, 3>), grid, dim3(256), 0, st, src, w, mask, out, a);
+    else if (M1 == 5 && M2 == 5) hipLaunchKernelGGL((convolve_window_kernel<T, 5, 5>), grid, dim3(256), 0, st, src, w, mask, out, a);
+    else if (M1 == 7 && M2 == 7) hipLaunchKernelGGL((convolve_window_kernel<T, 7, 7>), grid, dim3(256), 0, st, src, w, mask, out, a);
+    else return false;
+    return true;
 }
 
 }  // namespace xd
@@ -103,6 +171,9 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
     std::vector<int2> yx;
     std::vector<double> wt;
     std::vector<int> start(1, 0);
+    std::vector<double> dense((size_t)n_f * M1 * M2);        // weights in tap order, zeros included (the window kernels)
+    std::vector<unsigned long long> mask((size_t)n_f, 0ull);
+    const bool windowed = (M1 == M2) && (M1 == 3 || M1 == 5 || M1 == 7);
     const int dy_min = method == 0 ? -(M1 - 1 - M1 / 2) : -((M1 - 1) / 2);
     const int dx_min = method == 0 ? -(M2 - 1 - M2 / 2) : -((M2 - 1) / 2);
     for (int f = 0; f < n_f; ++f) {
@@ -111,7 +182,9 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
             for (int b = 0; b < M2; ++b) {
                 // scipy: the flipped kernel in row-major order; numba: the kernel as it stands
                 const double w = method == 0 ? k[(size_t)(M1 - 1 - a) * M2 + (M2 - 1 - b)] : k[(size_t)a * M2 + b];
+                dense[((size_t)f * M1 + a) * M2 + b] = w;
                 if (method == 0 && !(fabs(w) > DBL_EPSILON)) continue;   // (a NaN weight fails the test too, as in SciPy's footprint)
+                if (windowed) mask[f] |= 1ull << (a * M2 + b);
                 yx.push_back(make_int2(dy_min + a, dx_min + b));
                 wt.push_back(w);
             }
@@ -121,7 +194,8 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
     const size_t es = dtype == XDEMHIP_F32 ? 4 : 8, n = (size_t)H * (size_t)W;
     const size_t ntap = yx.size() ? yx.size() : 1;
     int2* d_yx = nullptr;
-    double* d_w = nullptr;
+    double *d_w = nullptr, *d_dense = nullptr;
+    unsigned long long* d_mask = nullptr;
     int* d_start = nullptr;
     void* d_img = nullptr;
     double* d_out = nullptr;
@@ -129,6 +203,8 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
         if (d_yx) (void)hipFree(d_yx);
         if (d_w) (void)hipFree(d_w);
         if (d_start) (void)hipFree(d_start);
+        if (d_dense) (void)hipFree(d_dense);
+        if (d_mask) (void)hipFree(d_mask);
         if (memspace == XDEMHIP_HOST) {
             if (d_img) (void)hipFree(d_img);
             if (d_out) (void)hipFree(d_out);
@@ -136,13 +212,17 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
     };
     if (hipMalloc(reinterpret_cast<void**>(&d_yx), ntap * sizeof(int2)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&d_w), ntap * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_start), start.size() * sizeof(int)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&d_start), start.size() * sizeof(int)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_dense), dense.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_mask), mask.size() * sizeof(unsigned long long)) != hipSuccess) {
         release();
         return xd_fail(ctx, XDEMHIP_ENOMEM, "hipMalloc failed");
     }
     if ((yx.size() && (hipMemcpy(d_yx, yx.data(), yx.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess ||
                        hipMemcpy(d_w, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) ||
-        hipMemcpy(d_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(d_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_dense, dense.data(), dense.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_mask, mask.data(), mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) {
         release();
         return xd_fail(ctx, XDEMHIP_EHIP, "upload of the filter taps failed");
     }
@@ -153,7 +233,7 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
         }
     }
     CvArgs a;
-    a.H = H; a.W = W; a.tap_yx = d_yx; a.tap_w = d_w; a.f_start = d_start; a.n_f = n_f;
+    a.H = H; a.W = W; a.n_f = n_f;
     a.dy_min = dy_min; a.dx_min = dx_min; a.M1 = M1; a.M2 = M2; a.round_to_t = method == 0 ? 1 : 0;
     a.vr = (method == 1 && !(M1 & 1)) ? H - 1 : H;
     a.vc = (method == 1 && !(M2 & 1)) ? W - 1 : W;
@@ -171,16 +251,17 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
                 break;
             }
             src = d_img;
-            a.out = d_out;
-        } else {
-            a.out = dst;
         }
-        if (dtype == XDEMHIP_F32) {
-            if (use_lds) hipLaunchKernelGGL((convolve_kernel<float, true>), grid, dim3(256), lds, ctx->stream, static_cast<const float*>(src), a);
-            else hipLaunchKernelGGL((convolve_kernel<float, false>), grid, dim3(256), 0, ctx->stream, static_cast<const float*>(src), a);
+        double* o = memspace == XDEMHIP_HOST ? d_out : dst;
+        if (windowed) {
+            if (dtype == XDEMHIP_F32) launch_window<float>(M1, M2, grid, ctx->stream, static_cast<const float*>(src), d_dense, d_mask, o, a);
+            else launch_window<double>(M1, M2, grid, ctx->stream, static_cast<const double*>(src), d_dense, d_mask, o, a);
+        } else if (dtype == XDEMHIP_F32) {
+            if (use_lds) hipLaunchKernelGGL((convolve_kernel<float, true>), grid, dim3(256), lds, ctx->stream, static_cast<const float*>(src), d_yx, d_w, d_start, o, a);
+            else hipLaunchKernelGGL((convolve_kernel<float, false>), grid, dim3(256), 0, ctx->stream, static_cast<const float*>(src), d_yx, d_w, d_start, o, a);
         } else {
-            if (use_lds) hipLaunchKernelGGL((convolve_kernel<double, true>), grid, dim3(256), lds, ctx->stream, static_cast<const double*>(src), a);
-            else hipLaunchKernelGGL((convolve_kernel<double, false>), grid, dim3(256), 0, ctx->stream, static_cast<const double*>(src), a);
+            if (use_lds) hipLaunchKernelGGL((convolve_kernel<double, true>), grid, dim3(256), lds, ctx->stream, static_cast<const double*>(src), d_yx, d_w, d_start, o, a);
+            else hipLaunchKernelGGL((convolve_kernel<double, false>), grid, dim3(256), 0, ctx->stream, static_cast<const double*>(src), d_yx, d_w, d_start, o, a);
         }
         if (hipGetLastError() != hipSuccess) {
             rc = xd_fail(ctx, XDEMHIP_EHIP, "convolution kernel launch failed");

@@ -20,7 +20,7 @@ constexpr int PB_MAXVAR = 8;
 struct PbArgs {
     const void* var[PB_MAXVAR];
     int dt[PB_MAXVAR], n_int[PB_MAXVAR], off[PB_MAXVAR];
-    int n_var;
+    int n_var, vec;
     int64_t n, n_bins;
     const double *left, *right, *table;
     const unsigned char* pass;
@@ -32,46 +32,142 @@ __device__ __forceinline__ double pb_load(const void* p, int dt, int64_t i) {
     return dt == XDEMHIP_F32 ? (double)static_cast<const float*>(p)[i] : static_cast<const double*>(p)[i];
 }
 
-template <bool DISJOINT>
+constexpr int PB_LDS_EDGES = 2048, PB_LDS_BINS = 2048;   // tables staged in LDS up to these sizes (beyond: read from global memory)
+constexpr int PB_U = 4;                                    // pixels per thread and trip: four independent search chains in flight
+
+// Every loop over the variables is unrolled over PB_MAXVAR with a guard, so that the per-variable fields of the argument block
+// are indexed statically (scalar registers) instead of living in scratch memory.  LDS: interval ends, statistics and decision
+// bytes of the bins are staged in (dynamic) shared memory -- [left | right | table | pass].
+template <bool DISJOINT, bool LDS>
 __global__ __launch_bounds__(256) void perbin_kernel(PbArgs a) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    int n_edges = 0;
+#pragma unroll
+    for (int k = 0; k < PB_MAXVAR; ++k)
+        if (k < a.n_var) n_edges += a.n_int[k];
+    double* s_left = reinterpret_cast<double*>(s_raw);
+    double* s_right = s_left + n_edges;
+    double* s_table = s_right + n_edges;
+    unsigned char* s_pass = reinterpret_cast<unsigned char*>(s_table + a.n_bins);
+    if (LDS) {
+        for (int e = threadIdx.x; e < n_edges; e += 256) {
+            s_left[e] = a.left[e];
+            s_right[e] = a.right[e];
+        }
+        for (int e = threadIdx.x; e < (int)a.n_bins; e += 256) {
+            s_table[e] = a.table[e];
+            s_pass[e] = a.pass[e];
+        }
+        __syncthreads();
+    }
+    const double* __restrict__ g_left = a.left;
+    const double* __restrict__ g_right = a.right;
+    auto lo_of = [&](int e) { return LDS ? s_left[e] : g_left[e]; };
+    auto hi_of = [&](int e) { return LDS ? s_right[e] : g_right[e]; };
+    auto pass_of = [&](int64_t b) { return LDS ? s_pass[b] : a.pass[b]; };
+    auto table_of = [&](int64_t b) { return LDS ? s_table[b] : a.table[b]; };
+    // a thread owns PB_U CONSECUTIVE pixels per trip: one 16-byte load per float32 variable (two for float64), two 16-byte
+    // stores -- when every array is 16-byte aligned (a.vec; the library's and NumPy's / torch's allocations are), else element-wise
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * PB_U;
     unsigned long long miss = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        double v[PB_MAXVAR];
-        for (int k = 0; k < a.n_var; ++k) v[k] = pb_load(a.var[k], a.dt[k], i);
-        double res = (double)NAN;
-        if (DISJOINT) {
-            int64_t idx = 0;
-            bool in = true;
-            for (int k = 0; k < a.n_var; ++k) {
-                int j = -1;
-                for (int jj = 0; jj < a.n_int[k]; ++jj)
-                    if (v[k] >= a.left[a.off[k] + jj] && v[k] < a.right[a.off[k] + jj]) j = jj;
-                in = in && j >= 0;
-                idx = idx * a.n_int[k] + (j < 0 ? 0 : j);
-            }
-            if (in) {
-                const unsigned char p = a.pass[idx];
-                if (p == 1) res = a.table[idx];
-                miss += p == 2;
-            }
-        } else {
-            for (int64_t b = 0; b < a.n_bins; ++b) {   // itertools.product order: the last variable runs fastest
-                int64_t r = b;
-                bool in = true;
-                for (int k = a.n_var - 1; k >= 0; --k) {
-                    const int j = (int)(r % a.n_int[k]);
-                    r /= a.n_int[k];
-                    in = in && v[k] >= a.left[a.off[k] + j] && v[k] < a.right[a.off[k] + j];
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * PB_U; i0 < a.n; i0 += stride) {
+        double v[PB_U][PB_MAXVAR];
+        const bool whole = a.vec && i0 + PB_U <= a.n;
+#pragma unroll
+        for (int k = 0; k < PB_MAXVAR; ++k) {
+            if (k < a.n_var && whole) {
+                if (a.dt[k] == XDEMHIP_F32) {
+                    const float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.var[k]) + i0);
+                    v[0][k] = (double)t.x; v[1][k] = (double)t.y; v[2][k] = (double)t.z; v[3][k] = (double)t.w;
+                } else {
+                    const double2 t0 = *reinterpret_cast<const double2*>(static_cast<const double*>(a.var[k]) + i0);
+                    const double2 t1 = *reinterpret_cast<const double2*>(static_cast<const double*>(a.var[k]) + i0 + 2);
+                    v[0][k] = t0.x; v[1][k] = t0.y; v[2][k] = t1.x; v[3][k] = t1.y;
                 }
-                if (in) {
-                    const unsigned char p = a.pass[b];
-                    if (p == 1) res = a.table[b];
+            } else {
+#pragma unroll
+                for (int u = 0; u < PB_U; ++u) v[u][k] = (k < a.n_var && i0 + u < a.n) ? pb_load(a.var[k], a.dt[k], i0 + u) : (double)NAN;
+            }
+        }
+        double res[PB_U];
+        if (DISJOINT) {
+            // sorted disjoint intervals: the only candidate is the last one whose left end is <= v.  Branch-free binary search
+            // with a wave-uniform trip count (a NaN compares false everywhere and finds none).
+            int64_t idx[PB_U];
+            bool in[PB_U];
+#pragma unroll
+            for (int u = 0; u < PB_U; ++u) { idx[u] = 0; in[u] = true; }
+#pragma unroll
+            for (int k = 0; k < PB_MAXVAR; ++k) {
+                if (k < a.n_var) {
+                    const int base = a.off[k], n = a.n_int[k];
+                    int top = 1;
+                    while (top <= n) top <<= 1;   // (uniform)
+                    int pos[PB_U];
+#pragma unroll
+                    for (int u = 0; u < PB_U; ++u) pos[u] = 0;
+                    for (int len = top >> 1; len > 0; len >>= 1) {
+#pragma unroll
+                        for (int u = 0; u < PB_U; ++u) {
+                            const int cand = pos[u] + len;
+                            const int at = cand <= n ? cand : n;   // (stay inside the table; the result is discarded when cand > n)
+                            pos[u] = (cand <= n && lo_of(base + at - 1) <= v[u][k]) ? cand : pos[u];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < PB_U; ++u) {
+                        const int j = pos[u] - 1;
+                        in[u] = in[u] && j >= 0 && v[u][k] < hi_of(base + (j < 0 ? 0 : j));
+                        idx[u] = idx[u] * n + (j < 0 ? 0 : j);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PB_U; ++u) {
+                res[u] = (double)NAN;
+                if (in[u]) {
+                    const unsigned char p = pass_of(idx[u]);
+                    if (p == 1) res[u] = table_of(idx[u]);
                     miss += p == 2;
                 }
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PB_U; ++u) res[u] = (double)NAN;
+            for (int64_t b = 0; b < a.n_bins; ++b) {   // itertools.product order: the last variable runs fastest
+                int jk[PB_MAXVAR];
+                int64_t r = b;
+#pragma unroll
+                for (int k = PB_MAXVAR - 1; k >= 0; --k) {
+                    jk[k] = 0;
+                    if (k < a.n_var) {
+                        jk[k] = (int)(r % a.n_int[k]);
+                        r /= a.n_int[k];
+                    }
+                }
+                const unsigned char p = pass_of(b);
+                const double t = table_of(b);
+#pragma unroll
+                for (int u = 0; u < PB_U; ++u) {
+                    bool in = true;
+#pragma unroll
+                    for (int k = 0; k < PB_MAXVAR; ++k)
+                        if (k < a.n_var) in = in && v[u][k] >= lo_of(a.off[k] + jk[k]) && v[u][k] < hi_of(a.off[k] + jk[k]);
+                    if (in) {
+                        if (p == 1) res[u] = t;
+                        miss += p == 2;
+                    }
+                }
+            }
         }
-        a.out[i] = res;
+        if (whole) {
+            *reinterpret_cast<double2*>(a.out + i0) = make_double2(res[0], res[1]);
+            *reinterpret_cast<double2*>(a.out + i0 + 2) = make_double2(res[2], res[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PB_U; ++u)
+                if (i0 + u < a.n) a.out[i0 + u] = res[u];
+        }
     }
     if (miss) atomicAdd(a.missing, miss);
 }
@@ -150,14 +246,20 @@ extern "C" int xdemhip_perbin_lookup(xdemhip_ctx* ctx, const void* const* vars, 
         return xd_fail(ctx, XDEMHIP_EHIP, "upload failed");
     }
     a.n_var = n_var; a.n = n; a.n_bins = n_bins;
+    a.vec = ((uintptr_t)(memspace == XDEMHIP_HOST ? (void*)d_out : (void*)out) & 15) == 0;
+    for (int k = 0; k < n_var; ++k) a.vec = a.vec && ((uintptr_t)a.var[k] & 15) == 0;
     a.left = d_left; a.right = d_right; a.table = d_table; a.pass = d_pass;
     a.out = memspace == XDEMHIP_HOST ? d_out : out;
     a.missing = d_miss;
-    const int64_t want = (n + 255) / 256;
+    const int64_t want = (n + 256 * PB_U - 1) / (256 * PB_U);
     const unsigned blocks = (unsigned)(want < (int64_t)ctx->num_cu * 16 ? want : (int64_t)ctx->num_cu * 16);
     (void)hipEventRecord(ctx->ev_start, ctx->stream);
-    if (disjoint) hipLaunchKernelGGL((perbin_kernel<true>), dim3(blocks), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((perbin_kernel<false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+    const bool lds = n_edges <= PB_LDS_EDGES && n_bins <= PB_LDS_BINS;
+    const size_t smem = lds ? (size_t)n_edges * 16 + (size_t)n_bins * 9 + 16 : 0;
+    if (disjoint && lds) hipLaunchKernelGGL((perbin_kernel<true, true>), dim3(blocks), dim3(256), smem, ctx->stream, a);
+    else if (disjoint) hipLaunchKernelGGL((perbin_kernel<true, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+    else if (lds) hipLaunchKernelGGL((perbin_kernel<false, true>), dim3(blocks), dim3(256), smem, ctx->stream, a);
+    else hipLaunchKernelGGL((perbin_kernel<false, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
     (void)hipEventRecord(ctx->ev_stop, ctx->stream);
     ctx->timed = true;
     int rc = XDEMHIP_OK;
