@@ -519,6 +519,66 @@ NK_TOUCHED_NOTE = ("the two passes touch 21 B/pixel (dh pass: masked reference c
                    "slope_tan 4 + cached aspect-bin id 1): the aux rasters are stored, not recomputed; 27 B/pixel in round 2")
 
 
+def public_functions_leg(ctx, dev, n: int = 16384) -> dict:
+    """Two public functions next to the paths (last paragraph), device-resident, never part of `value`:
+    `spatialstats.convolution` (SURVEY 8a row a5 as upstream exposes it) with five dense 5 x 5 filters and with three 3 x 3 filters in one
+    call each, and the per-bin lookup behind `get_perbin_nd_binning` (8f row f3) on two float32 variables; kernel times from the
+    context's events, a crop of the convolution checked against torch's float64 conv2d (plumbing check, not the parity claim)."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from xdem_amd import _lib
+    from xdem_amd import spatialstats as ss
+    from xdem_amd.synth import fbm_torch
+
+    out = {"grid": f"{n}x{n} float32"}
+    dem = fbm_torch(n, n, dev, seed=9)[None].contiguous()
+    rng = np.random.default_rng(17)
+    for label, filt in (("five_5x5_filters", rng.normal(size=(5, 5, 5))), ("three_3x3_filters", rng.normal(size=(3, 3, 3)))):
+        res = ss.convolution(dem, filt, method="scipy", ctx=ctx)
+        torch.cuda.synchronize(dev)
+        ms = []
+        for _ in range(3):
+            res = ss.convolution(dem, filt, method="scipy", ctx=ctx)
+            torch.cuda.synchronize(dev)
+            ms.append(ctx.last_kernel_ms())
+        m = filt.shape[1]
+        crop = dem[:, 1000:1100, 2000:2100].double()[:, None]
+        want = torch.nn.functional.conv2d(crop, torch.from_numpy(filt[:, None, ::-1, ::-1].copy()).to(dev))   # (conv2d correlates: flip for a convolution)
+        got = res[0, :, 1000 + m // 2:1100 - m // 2, 2000 + m // 2:2100 - m // 2]
+        err = float((got - want[0]).abs().max() / want.abs().max())
+        if not err < 1e-6:   # (float32-rounded sums against unrounded float64 ones)
+            raise RuntimeError(f"convolution leg: crop differs from conv2d by {err:.3e}")
+        bpp = 4 + 8 * filt.shape[0]
+        out[label] = {"ms": round(min(ms), 4), "bytes_per_pixel": bpp, "GBps": round(bpp * n * n / min(ms) / 1e6, 1),
+                      "frac_of_hbm_peak": round(bpp * n * n / min(ms) / 1e6 / HBM_PEAK_GBPS, 4), "crop_vs_conv2d_rel": err}
+        del res, got, want
+    a = torch.rand((n, n), device=dev) * 40
+    b = torch.rand((n, n), device=dev) * 5
+    res = torch.empty((n, n), dtype=torch.float64, device=dev)
+    na = nb = 10
+    left = np.concatenate([np.arange(na) * 4.0, np.arange(nb) * 0.5])
+    right = np.concatenate([(np.arange(na) + 1) * 4.0, (np.arange(nb) + 1) * 0.5])
+    table = rng.normal(size=na * nb)
+    kind = np.ones(na * nb, dtype=np.uint8)
+    dp = ctypes.POINTER(ctypes.c_double)
+    miss = ctypes.c_int64()
+    ms = []
+    for _ in range(3):
+        ctx.check(ctx._L.xdemhip_perbin_lookup(ctx.handle, (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr()), (ctypes.c_int * 2)(_lib.F32, _lib.F32), 2, n * n,
+                                               (ctypes.c_int * 2)(na, nb), left.ctypes.data_as(dp), right.ctypes.data_as(dp), table.ctypes.data_as(dp),
+                                               kind.ctypes.data_as(ctypes.c_char_p), 1, res.data_ptr(), ctypes.byref(miss), _lib.DEVICE))
+        ms.append(ctx.last_kernel_ms())
+    ia, ib = (a[5, :7] / 4.0).long().cpu().numpy(), (b[5, :7] / 0.5).long().cpu().numpy()
+    if not np.array_equal(res[5, :7].cpu().numpy(), table[ia * nb + ib]):
+        raise RuntimeError("per-bin lookup leg: wrong bin values")
+    out["perbin_lookup_two_variables"] = {"ms": round(min(ms), 4), "bytes_per_pixel": 16, "GBps": round(16 * n * n / min(ms) / 1e6, 1),
+                                          "frac_of_hbm_peak": round(16 * n * n / min(ms) / 1e6 / HBM_PEAK_GBPS, 4), "bins": na * nb}
+    return out
+
+
 def isa_cycles() -> dict:
     """Vector-issue cycles per output row of the streaming kernels of the launches timed here (newest profiles/*_isa_cycles.json,
     written by tools/isa_ledger.py --json from the compiled kernels at the per-instruction costs of tools/ubench.hip).  The cost
@@ -1041,6 +1101,15 @@ def main() -> None:
             failed.append("secondary")
         if sets is not None:
             sec["terrain_sets"] = sets
+        if world == 1 and "error" not in sec:
+            try:
+                sec["public_functions"] = public_functions_leg(ctx, dev)
+            except Exception as e:
+                import traceback
+
+                traceback.print_exc()
+                sec["public_functions"] = {"error": repr(e)}
+                failed.append("public_functions")
     if rank == 0:
         if sec is not None:
             res.setdefault("secondary", {}).update(sec)

@@ -22,7 +22,7 @@ import logging
 import os
 import warnings
 from collections.abc import Iterable
-from typing import Any, Callable
+from typing import Any, Callable, TypedDict
 
 import numpy as np
 
@@ -480,6 +480,11 @@ def _choose_cdist_equidistant_sampling_parameters(**kwargs: Any) -> tuple[int, i
     logging.info("equidistant sampling: %d runs x (%d centre-disk points against %d points in each of %d rings) = about %d pairs",
                  runs, per_run, per_run, n_rings, runs * per_run**2 * n_rings)
     return runs, per_run, ratio
+
+
+# The keyword arguments `sample_empirical_variogram` forwards (upstream's typing aid of the same name, xdem/spatialstats.py:1284-1292)
+EmpiricalVariogramKArgs = TypedDict("EmpiricalVariogramKArgs", {"runs": int, "pdist_multi_ranges": list, "ratio_subsample": float, "samples": int,
+                                                                "nb_rings": int, "maxlag": float, "bin_func": Any, "estimator": str}, total=False)
 
 
 def sample_empirical_variogram(values, gsd: float = None, coords: np.ndarray = None, subsample: int = 1000,
