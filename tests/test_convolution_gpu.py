@@ -52,7 +52,7 @@ def test_convolution_larger_images_and_filters_vs_oracle(ss, dtype):
     imgs = (800.0 + np.cumsum(np.cumsum(rng.normal(scale=0.2, size=(2, 203, 331)), axis=1), axis=2)).astype(dtype)
     imgs[0, 50:53, 100] = np.nan
     imgs[1, 7, 7] = np.inf
-    for shape in ((3, 3), (5, 5), (2, 2), (9, 4), (21, 35)):
+    for shape in ((3, 3), (5, 5), (7, 7), (2, 2), (9, 4), (21, 35)):   # (3, 5, 7: the register-window kernels; the rest: runtime tap lists)
         filters = rng.normal(size=(3,) + shape)
         filters[1][rng.uniform(size=shape) < 0.5] = 0.0
         for method in ("scipy", "numba"):
