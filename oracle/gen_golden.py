@@ -14,6 +14,7 @@ Fixture families:
   terrain_T11    the reference's own NUMBA-engine code (surfit.py:948-1088, 1270-1303; window.py:767-870, 980-1000) run
                  in the interpreter through the identity-njit shim of _refimport.py: T1 DEMs (f32 + f64, NaN and Inf
                  holes), a terrain-like DEM, three fits, both curvature methods, windowed indexes
+  terrain_T12    the engine boundary called directly (surfit._get_surface_attributes, window._get_windowed_indexes), both engines
   nk_T5_*        Nuth-Kaab bin-fit cases (aspect binning, nanmedian per bin, curve_fit) + aux gradient (T8)
   nk_T6          _iterate_method stop-rule trace
   vario_T7       _choose_cdist_equidistant_sampling_parameters table + default bin edges
@@ -269,6 +270,51 @@ def terrain_T11_numba() -> None:
     np.savez_compressed(os.path.join(OUT, "terrain_T11_numba_engine.npz"), **rec)
 
 
+def terrain_T12_engine_boundary() -> None:
+    """SURVEY 8b rows 1-2 called DIRECTLY: the reference's `surfit._get_surface_attributes` and `window._get_windowed_indexes`
+    (the functions the HIP engine replaces), both of their engines -- the Numba one through the identity-njit shim --, explicit
+    `out_dtype`, radians, UNCLIPPED hillshade (the caller's post-steps, terrain.py:586-596, are not part of the engine)."""
+    rng = np.random.default_rng(12)
+    base = 1000.0 + np.cumsum(np.cumsum(rng.normal(scale=0.08, size=(30, 34)), axis=0), axis=1)
+    rec = {}
+    for dt in (np.float32, np.float64):
+        dem = base.astype(dt)
+        dem[9:11, 30] = np.nan
+        dem[25, 5] = np.nan
+        name = np.dtype(dt).name
+        rec[f"dem|{name}"] = dem
+        for engine in ("scipy", "numba"):
+            for fit in ("Horn", "ZevenbergThorne", "Florinsky"):
+                for cm in ("geometric", "directional"):
+                    if fit == "Horn" and cm == "directional":
+                        continue
+                    attrs = SAH if fit == "Horn" else [a for a in SURF if a != "curvature"]
+                    main = fit == "Florinsky" and cm == "geometric"   # (the full product only for the default fit: the file stays small)
+                    for od in ((np.float32, np.float64) if main else (dt,)):
+                        for hs in (((315.0, 45.0, 1.0), (120.0, 5.0, 4.0)) if main else ((315.0, 45.0, 1.0),)):   # the second one drives hillshade below 0 (unclipped here)
+                            with warnings.catch_warnings():
+                                warnings.simplefilter("ignore")
+                                out = ref.surfit._get_surface_attributes(dem=dem, resolution=5.0, surface_attributes=attrs, out_dtype=od, surface_fit=fit,
+                                                                         curv_method=cm, engine=engine, hillshade_azimuth=hs[0],
+                                                                         hillshade_altitude=hs[1], hillshade_z_factor=hs[2])
+                            assert out.dtype == np.dtype(od)
+                            rec[f"surf|{name}|{engine}|{fit}|{cm}|{np.dtype(od).name}|{hs[0]}"] = out
+            for w in (3, 5):
+                for tri in ("Riley", "Wilson"):
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        out = ref.window._get_windowed_indexes(dem=dem, window_size=w, windowed_indexes=WIN + ["roughness"], resolution=5.0,
+                                                               out_dtype=dt, tri_method=tri, engine=engine)
+                    rec[f"win|{name}|{engine}|{w}|{tri}"] = out
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                rec[f"rug|{name}|{engine}"] = ref.window._get_windowed_indexes(dem=dem, window_size=3, windowed_indexes=["rugosity"], resolution=5.0,
+                                                                               out_dtype=dt, engine=engine)
+                rec[f"frac|{name}|{engine}"] = ref.window._get_windowed_indexes(dem=dem, window_size=13, windowed_indexes=["fractal_roughness"],
+                                                                                resolution=5.0, out_dtype=dt, engine=engine)
+    np.savez_compressed(os.path.join(OUT, "terrain_T12_engine_boundary.npz"), **rec)
+
+
 def terrain_T10() -> None:
     """Texture shading (freq.py:63-148), SURVEY 8f-4: reference outputs for float32 / float64 DEMs with holes, several alpha,
     FFT lengths below and above 1024 (power-of-two and 7-smooth padding), plus the data-free cases of test_freq.py."""
@@ -307,6 +353,7 @@ if __name__ == "__main__":
         terrain_T9()
         terrain_T10()
         terrain_T11_numba()
+        terrain_T12_engine_boundary()
         print("terrain fixtures written")
     if "nk" in which:
         import gen_golden_nk

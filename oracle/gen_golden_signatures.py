@@ -93,6 +93,12 @@ def main() -> None:
         rec["terrain"][n] = record(getattr(ref.terrain, n))
     for n in SPATIALSTATS:
         rec["spatialstats"][n] = record(getattr(ref.spatialstats, n))
+    # the engine-boundary functions of SURVEY 8b rows 1-2 and the texture helper, under their own modules
+    import importlib
+
+    rec["surfit"] = {"_get_surface_attributes": record(ref.surfit._get_surface_attributes)}
+    rec["window"] = {"_get_windowed_indexes": record(ref.window._get_windowed_indexes)}
+    rec["freq"] = {"_nextprod_fft": record(importlib.import_module("xdem.terrain.freq")._nextprod_fft)}
     rec["coreg"]["NuthKaab.__init__"] = record(ref.affine.NuthKaab.__init__)
     rec["coreg"]["NuthKaab.fit"] = record(ref.affine.NuthKaab.fit)
     rec["coreg"]["NuthKaab.fit_and_apply"] = record(ref.affine.NuthKaab.fit_and_apply)

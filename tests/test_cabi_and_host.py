@@ -776,3 +776,22 @@ def test_native_count_finite_equals_numpy():
         assert n == int(want[::2].sum()) and np.array_equal(mask, want[::2])
     assert spatialstats._count_finite(np.empty(0, dtype=np.float32)) == (0, None)
     assert spatialstats._count_finite(np.arange(10, dtype=np.float16))[0] == 10
+
+
+def test_nextprod_fft_rule_of_the_texture_path():
+    """xdem_amd.terrain.freq._nextprod_fft (the reference's helper of the same name, xdem/terrain/freq.py:33-61): the known answers
+    of the reference's own test (tests/test_terrain/test_freq.py:198-215) and the oracle's restatement over a range."""
+    import terrain_oracle as to
+    import xdem_amd
+
+    f = xdem_amd.terrain.freq._nextprod_fft
+    assert [f(n) for n in (0, 1, 2, 3, 10, 20, 100, 1000, 1024)] == [1, 1, 2, 4, 16, 32, 128, 1024, 1024]
+    for n in list(range(1, 1300)) + [1025, 2047, 2049, 4801, 10007, 16385, 40000, 65537]:
+        m = f(n)
+        assert m == to._next_fft_len(n) and m >= n
+        if n > 1024:
+            r = m
+            for p in (2, 3, 5, 7):
+                while r % p == 0:
+                    r //= p
+            assert r == 1

@@ -224,3 +224,40 @@ def test_oracle_convolution_equals_scipy():
             want = scipy_ndimage.convolve(dem, k, mode="constant", cval=np.nan)
             got = to._convolve_nan_const(dem, k)
             assert _same(got, want), (fit, name)
+
+
+def test_T12_engine_boundary_called_directly():
+    """The oracle's engine-level functions against the reference's `surfit._get_surface_attributes` / `window._get_windowed_indexes`
+    called directly: radians, explicit out_dtype, hillshade BEFORE the caller's clip -- bit for bit for the SciPy
+    engine's surface fit and windowed indexes and for the Numba recipe's float32 outputs, 2e-14 relative for its float64 outputs."""
+    z = _load("terrain_T12_engine_boundary.npz")
+    surf = ["slope", "aspect", "hillshade", "profile_curvature", "tangential_curvature", "planform_curvature", "flowline_curvature",
+            "max_curvature", "min_curvature"]
+    n = 0
+    for key in z.files:
+        parts = key.split("|")
+        if parts[0] == "surf":
+            _, dname, engine, fit, cm, od, az = parts
+            alt, zf = (45.0, 1.0) if az == "315.0" else (5.0, 4.0)
+            attrs = surf[:3] if fit == "Horn" else surf
+            got = np.asarray(to.surface_attributes(z[f"dem|{dname}"], 5.0, attrs, np.dtype(od), fit, cm, alt, float(az), zf, engine))
+            if engine == "scipy" or od == "float32":
+                assert _same(got, z[key]), key
+            else:   # the Numba loop evaluates the formulas pixel by pixel with scalar `**` / sqrt: last-digit differences from NumPy's array
+                # routines in float64 outputs (as in test_T11_numba_engine_surface_fit)
+                w = z[key]
+                assert got.dtype == w.dtype and np.array_equal(np.isnan(got), np.isnan(w)), key
+                ok = ~np.isnan(w)
+                assert np.all(np.abs(got[ok] - w[ok]) <= 2e-14 * np.maximum(np.abs(w[ok]), 1e-300)), key
+            n += 1
+        elif parts[0] in ("win", "rug", "frac") and parts[2] == "scipy":
+            dem = z[f"dem|{parts[1]}"]
+            if parts[0] == "win":
+                got = to.windowed_indexes(dem, int(parts[3]), ["topographic_position_index", "terrain_ruggedness_index", "roughness"], dem.dtype, parts[4], 5.0)
+            elif parts[0] == "rug":
+                got = to.windowed_indexes(dem, 3, ["rugosity"], dem.dtype, "Riley", 5.0)
+            else:
+                got = to.windowed_indexes(dem, 13, ["fractal_roughness"], dem.dtype, "Riley", 5.0)
+            assert _same(np.asarray(got), z[key]), key
+            n += 1
+    assert n >= 40

@@ -22,6 +22,10 @@ def _mirror(module: str, name: str):
         from xdem_amd import terrain as m
     elif module == "spatialstats":
         from xdem_amd import spatialstats as m
+    elif module in ("surfit", "window", "freq"):   # the reference's xdem.terrain.<module>, reachable here as xdem_amd.terrain.<module>
+        import xdem_amd
+
+        return getattr(getattr(xdem_amd.terrain, module), name)
     elif module == "dem":
         from xdem_amd import dem as m
 
