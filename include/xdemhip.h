@@ -202,7 +202,10 @@ int xdemhip_set_rank(xdemhip_ctx* ctx, int rank, int world);
  *               do columns outside [0, W).  Single raster: halo_top = halo_bottom = 0.
  *  attr_mask    OR of XDEMHIP_ATTR_*; out_planes[k] receives the k-th SET bit in ascending bit order,
  *               each an (H, W) plane with row stride W in out_dtype.
- *  degrees      non-zero: slope / aspect in degrees (terrain.py:586-591), else radians.
+ *  degrees      bit 0: slope / aspect in degrees (terrain.py:586-591), else radians.  Bit 1 (value 2, or 3 with degrees): the
+ *               hillshade plane as the reference's ENGINE returns it (surfit.py:609-622), WITHOUT the caller's clip to [0, 255]
+ *               (terrain.py:594-596) that every other call fuses -- for bindings at the engine boundary
+ *               (_get_surface_attributes); such a launch takes the float64 attribute tail.
  *  window_size  odd window of TPI / TRI / roughness (reference default 3) and of fractal roughness (reference default
  *               13 through its own window_size_fractal: request that attribute in a call of its own); rugosity is 3x3.
  * NaN / +-Inf in the DEM are nodata: an output pixel is NaN iff its full window (3x3 Horn/ZT, 5x5

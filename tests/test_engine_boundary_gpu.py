@@ -1,8 +1,8 @@
 """The engine boundary of SURVEY 8b rows 1-2 under the reference's own names: xdem_amd.terrain.surfit._get_surface_attributes and
 xdem_amd.terrain.window._get_windowed_indexes against outputs of the reference's functions of the same name called directly
 (tests/golden/terrain_T12_engine_boundary.npz: both upstream engines, float32 / float64 DEMs and out_dtypes, radians, hillshade
-NOT yet clipped).  Bar as for the terrain path: NaN masks identical, values within 1e-6 true relative of the reference (the SciPy
-engine's planes; the Numba engine's float32 window sums within their rounding noise), hillshade equal to np.clip of upstream's."""
+NOT clipped -- on either side).  Bar as for the terrain path: NaN masks identical, values within 1e-6 true relative of the reference
+(the SciPy engine's planes; the Numba engine's float32 window sums within their rounding noise)."""
 import os
 
 import numpy as np
@@ -38,10 +38,9 @@ def test_surface_engine_equals_the_reference_engine(key):
     attrs = SAH if fit == "Horn" else SURF
     got = xdem_amd.terrain.surfit._get_surface_attributes(Z[f"dem|{dname}"], 5.0, attrs, out_dtype=np.dtype(od), surface_fit=fit, curv_method=cm,
                                                           engine=engine, hillshade_azimuth=hs[0], hillshade_altitude=hs[1], hillshade_z_factor=hs[2])
-    want = Z[key].copy()
+    want = Z[key]
     i_hs = attrs.index("hillshade")
-    assert az == "315.0" or np.nanmin(want[i_hs]) < 0          # the second setting leaves [0, 255] before the clip
-    want[i_hs] = np.clip(want[i_hs], 0, 255)                   # the caller's post-step (terrain.py:594-596) is fused into the kernel
+    assert az == "315.0" or np.nanmin(want[i_hs]) < 0          # the second setting leaves [0, 255]: the engine does not clip, nor does the mirror
     assert got.shape == want.shape and got.dtype == np.dtype(od)
     for i, a in enumerate(attrs):
         if a == "aspect":    # flat or near-flat pixels may sit on either side of the 0 / 2 pi seam
@@ -86,18 +85,23 @@ def test_window_engine_equals_the_reference_engine(key):
         close(got[i], want[i], rel, (key, a))
 
 
-def test_engine_stack_equals_the_public_call_bit_for_bit():
-    """The boundary mirror and get_terrain_attribute(degrees=False) are the same launch: same bits, any order, duplicates."""
+def test_engine_stack_against_the_public_call():
+    """The boundary mirror against get_terrain_attribute(degrees=False): the same planes up to the clip of the hillshade, any order, duplicates."""
     import xdem_amd
 
     dem = Z["dem|float32"]
     names = ["min_curvature", "slope", "hillshade", "slope", "aspect"]
-    stack = xdem_amd.terrain.surfit._get_surface_attributes(dem, 5.0, names, out_dtype=np.float32, surface_fit="ZevenbergThorne")
     planes = xdem_amd.terrain.get_terrain_attribute(dem, ["min_curvature", "slope", "hillshade", "aspect"], resolution=5.0, degrees=False,
-                                                    surface_fit="ZevenbergThorne")
+                                                    surface_fit="ZevenbergThorne", hillshade_altitude=5.0, hillshade_z_factor=4.0)
+    stack = xdem_amd.terrain.surfit._get_surface_attributes(dem, 5.0, names, out_dtype=np.float32, surface_fit="ZevenbergThorne",
+                                                            hillshade_altitude=5.0, hillshade_z_factor=4.0)
     by_name = dict(zip(["min_curvature", "slope", "hillshade", "aspect"], planes))
+    assert np.nanmin(stack[2]) < 0 and np.nanmin(by_name["hillshade"]) == 0          # the engine does not clip, the public call does
     for i, a in enumerate(names):
-        assert np.array_equal(stack[i], by_name[a], equal_nan=True), a
+        want = np.clip(stack[i], 0, 255) if a == "hillshade" else stack[i]
+        # (the public call runs the mixed float32 tail, the engine call the float64 one: same planes within the float32 rounding)
+        assert np.array_equal(np.isnan(want), np.isnan(by_name[a])) and np.allclose(want, by_name[a], rtol=2e-6, atol=1e-6, equal_nan=True), a
+    assert np.array_equal(stack[1], stack[3], equal_nan=True)
     with pytest.raises(ValueError, match="not surface-fit attributes"):
         xdem_amd.terrain.surfit._get_surface_attributes(dem, 5.0, ["roughness"])
     with pytest.raises(ValueError, match="not windowed indexes"):

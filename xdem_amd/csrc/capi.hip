@@ -447,7 +447,7 @@ int xdemhip_terrain(xdemhip_ctx* ctx, const void* dem, int dem_dtype, int64_t H,
     L.H = H; L.W = W; L.row_stride = row_stride; L.halo_top = halo_top; L.halo_bottom = halo_bottom;
     L.resolution = (attr_mask & needs_res) ? resolution : 1.0;
     L.surface_fit = surface_fit; L.curv_method = curv_method; L.tri_method = tri_method;
-    L.window_size = window_size; L.degrees = degrees; L.attr_mask = attr_mask;
+    L.window_size = window_size; L.degrees = degrees & 1; L.hs_unclipped = (degrees >> 1) & 1; L.attr_mask = attr_mask;
     L.hs_alt = hs_alt; L.hs_az = hs_az; L.hs_z = hs_z;
 
     const size_t in_es = dem_dtype == XDEMHIP_F32 ? 4 : 8, out_es = out_dtype == XDEMHIP_F32 ? 4 : 8;

@@ -194,6 +194,7 @@ struct TerrainLaunch {
     int64_t H, W, row_stride, halo_top, halo_bottom;
     double resolution;
     int surface_fit, curv_method, tri_method, window_size, degrees;
+    int hs_unclipped;    // bit 1 of xdemhip_terrain's `degrees`: hillshade as the reference's ENGINE returns it (no clip to [0, 255])
     uint32_t attr_mask;
     double hs_alt, hs_az, hs_z;
     void* planes[XDEMHIP_ATTR_COUNT];  // device pointers by attribute bit (null when not requested)

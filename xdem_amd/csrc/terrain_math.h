@@ -61,6 +61,7 @@ struct TerrainParams {
     int curv_directional;
     int tri_wilson;
     int degrees;
+    int hs_clip = 1;   // 1: hillshade clipped to [0, 255] (the caller's post-step, terrain.py:594-596, fused; default), 0: as the ENGINE returns it
     // The reference's own convolution weights (integer table / divider in double, flipped to correlation order, row-major
     // over the window; |w| <= DBL_EPSILON -> 0 = skipped, as scipy.ndimage does) for zx, zy, zxx, zyy, zxy: used by the
     // rare exact-cancellation path of march_column (see ref_order_sum).
@@ -497,7 +498,7 @@ XD_HD void surface_pixel(double zx, double zy, double zxx, double zyy, double zx
         if (SP::ZF1 < 0 ? (P.hs_zf2 != 1.0) : (SP::ZF1 == 0)) rwz = rsqrt_pos(fma(P.hs_zf2, g2, 1.0));
         // 1.5 + 254 * shade; the factor 254 is folded into the three sun coefficients on the host (fill_params)
         TOUT v = (TOUT)fma_c(rwz, P.hs_sin_alt + fma(P.hs_ky, zy, P.hs_kx * zx), 1.5);
-        v = v < (TOUT)0 ? (TOUT)0 : (v > (TOUT)255 ? (TOUT)255 : v);
+        if (P.hs_clip) v = v < (TOUT)0 ? (TOUT)0 : (v > (TOUT)255 ? (TOUT)255 : v);   // (only this float64-tail form knows the unclipped mode)
         sk.template put<P_HILLSHADE>((TOUT)(v));
     }
     if (!CURV) return;

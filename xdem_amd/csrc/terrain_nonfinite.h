@@ -10,13 +10,13 @@ namespace xd {
 struct NfParams {
     double w[5][25];  // zx, zy, zxx, zyy, zxy: table / divider in double, flipped to correlation order, zeros kept
     double sin_alt, cos_alt, az, zf;
-    int M, fit, directional, degrees;
+    int M, fit, directional, degrees, hs_clip;
     uint32_t mask;
 };
 template <typename TOUT> struct NfPlanes { TOUT* p[10]; };
 
 inline void nf_fill_params(NfParams& P, int surface_fit, int curv_directional, double resolution, double hs_alt, double hs_az,
-                           double hs_z, int degrees, uint32_t surface_mask) {
+                           double hs_z, int degrees, uint32_t surface_mask, int hs_clip = 1) {
     memset(&P, 0, sizeof P);
     fill_ref_weights(surface_fit, resolution, P.w);
     const double deg = 0.017453292519943295;  // np.deg2rad's factor
@@ -28,6 +28,7 @@ inline void nf_fill_params(NfParams& P, int surface_fit, int curv_directional, d
     P.fit = surface_fit;
     P.directional = curv_directional;
     P.degrees = degrees;
+    P.hs_clip = hs_clip;
     P.mask = surface_mask;
 }
 
@@ -80,7 +81,7 @@ XD_HD void nf_pixel(const TIN* dem, int64_t r, int64_t c, int64_t H, int64_t W, 
     auto put = [&](int plane, double v, int post) {  // post: 0 none, 1 rad2deg (if degrees), 2 clip to [0, 255]
         TOUT t = (TOUT)v;
         if (post == 1 && P.degrees) t = t * DegScale<TOUT>::v();
-        if (post == 2) t = isnan((double)t) ? t : (t < (TOUT)0 ? (TOUT)0 : (t > (TOUT)255 ? (TOUT)255 : t));
+        if (post == 2 && P.hs_clip) t = isnan((double)t) ? t : (t < (TOUT)0 ? (TOUT)0 : (t > (TOUT)255 ? (TOUT)255 : t));
         out.p[plane][o] = t;
     };
     double slope = 0.0, aspect = 0.0;

@@ -63,7 +63,7 @@ int launch_terrain_nonfinite(xdemhip_ctx* ctx, const TerrainLaunch& L) {
     if (!surf) return XDEMHIP_OK;
     if (!ctx->nf_flag) XD_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->nf_flag), sizeof(int)));
     NfParams P;
-    nf_fill_params(P, L.surface_fit, L.curv_method == XDEMHIP_CURV_DIRECTIONAL, L.resolution, L.hs_alt, L.hs_az, L.hs_z, L.degrees, surf);
+    nf_fill_params(P, L.surface_fit, L.curv_method == XDEMHIP_CURV_DIRECTIONAL, L.resolution, L.hs_alt, L.hs_az, L.hs_z, L.degrees, surf, L.hs_unclipped ? 0 : 1);
     if (L.dem_dtype == XDEMHIP_F32 && L.out_dtype == XDEMHIP_F32) return nf_launch<float, float>(ctx, L, P);
     if (L.dem_dtype == XDEMHIP_F64 && L.out_dtype == XDEMHIP_F64) return nf_launch<double, double>(ctx, L, P);
     if (L.dem_dtype == XDEMHIP_F32 && L.out_dtype == XDEMHIP_F64) return nf_launch<float, double>(ctx, L, P);

@@ -520,6 +520,7 @@ static void fill_params(const TerrainLaunch& L, TerrainParams& P) {
     P.curv_directional = L.curv_method == XDEMHIP_CURV_DIRECTIONAL;
     P.tri_wilson = L.tri_method == XDEMHIP_TRI_WILSON;
     P.degrees = L.degrees;
+    P.hs_clip = L.hs_unclipped ? 0 : 1;
 }
 
 struct FrameRect { int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0; };  // interior tile rectangle left out in frame mode (empty: all tiles)
@@ -672,12 +673,13 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
         const int fit = surf ? L.surface_fit : XDEMHIP_FIT_ZEVENBERGTHORNE;  // window-only: cheapest 3x3 march
         // Compile-time specialised kernels for the headline configurations (reference defaults: geometric
         // curvatures, degrees, Riley TRI, z_factor 1): all attribute branches fold away -> one schedulable basic block.
-        const bool defaults_dir = L.degrees && L.tri_method == XDEMHIP_TRI_RILEY && L.hs_z == 1.0;  // ... with either curvature method
+        // (an unclipped hillshade -- the engine-boundary call -- is known to the float64 tail of the runtime-mask kernels only)
+        const bool defaults_dir = L.degrees && L.tri_method == XDEMHIP_TRI_RILEY && L.hs_z == 1.0 && !L.hs_unclipped;  // ... with either curvature method
         const bool defaults = L.curv_method == XDEMHIP_CURV_GEOMETRIC && defaults_dir;
         // option "terrain_math" = 1: float64 attribute math for float32 rasters too (other dtype pairs always use it);
         // 2 (default) / 0: lean / mixed tail of the specialised float32 kernels (the runtime-mask kernels keep the mixed tail)
         constexpr bool FF = SameT<TIN, float>::v && SameT<TOUT, float>::v;
-        const bool f64tail = FF && ctx->terrain_math == 1;
+        const bool f64tail = FF && (ctx->terrain_math == 1 || L.hs_unclipped);
 #ifdef XD_EXPERIMENT
         constexpr bool ALLSHAPES = FF;
 #else
@@ -716,7 +718,7 @@ static int launch_typed(xdemhip_ctx* ctx, const TerrainLaunch& L) {
             // With 8-16 bytes per pixel instead of 48 these launches are bound by instruction issue, so the folded attribute
             // branches and the float32 scale factors matter more here than for the eleven planes.
             // (win == 0: a windowed index of another window size still has its own launch below -- these macros return)
-            if (win == 0 && ctx->terrain_math == 2 && L.degrees && L.hs_z == 1.0 && (mask & ~(A_SLOPE | A_ASPECT | A_HILLSHADE)) == 0) {
+            if (win == 0 && ctx->terrain_math == 2 && L.degrees && !L.hs_unclipped && L.hs_z == 1.0 && (mask & ~(A_SLOPE | A_ASPECT | A_HILLSHADE)) == 0) {
 #define XD_SMALL(F, M)                                                                                                       \
     do {                                                                                                                     \
         const int took = launch_stream<F, false, false, Spec<M, 0, 1, 0, 1, 2>>(ctx, L, mask);                              \

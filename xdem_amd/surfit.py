@@ -8,9 +8,10 @@
 (n_attributes, H, W) in `out_dtype`, attributes in the order asked for, slope and aspect in RADIANS as the engine returns them
 (the conversion to degrees is the caller's post-step, terrain.py:586-591).
 
-One documented difference: HILLSHADE comes out clipped to [0, 255].  Upstream clips in the caller (terrain.py:594-596); the
-kernel fuses that post-step, so the stack equals ``np.clip`` of upstream's engine output for that plane and is identical to
-upstream's for every other one (tests/test_engine_boundary_gpu.py, fixtures recorded from the reference's engine functions).
+Hillshade comes out as the engine returns it, NOT clipped to [0, 255]: the clip is the caller's post-step (terrain.py:594-596),
+which every other entry of the library fuses into the kernel; here the launch asks for the unclipped plane (bit 1 of
+``xdemhip_terrain``'s `degrees` argument; float64 attribute tail).  Pinned by fixtures recorded from the reference's engine
+functions called directly (tests/golden/terrain_T12_engine_boundary.npz, tests/test_engine_boundary_gpu.py).
 """
 from __future__ import annotations
 
@@ -24,8 +25,8 @@ from . import _lib, terrain
 def _engine_stack(dem, names: list[str], out_dtype, engine: str, resolution: float, surface_fit: str = "Florinsky",
                   curv_method: str = "geometric", tri_method: str = "Riley", window_size: int = 3, hillshade_altitude: float = 45.0,
                   hillshade_azimuth: float = 315.0, hillshade_z_factor: float = 1.0, ctx: _lib.Context | None = None) -> np.ndarray:
-    """(len(names), H, W) stack of the fused kernel's planes for a 2-D float array, radians, no Raster handling: what both
-    engine-boundary mirrors (this module and ``xdem_amd.window``) return."""
+    """(len(names), H, W) stack of the fused kernel's planes for a 2-D float array, radians, hillshade unclipped, no Raster
+    handling: what both engine-boundary mirrors (this module and ``xdem_amd.window``) return."""
     if engine not in ("scipy", "numba", "hip"):
         raise ValueError(f"engine must be 'scipy', 'numba' or 'hip' (got '{engine}'); all of them run on the GPU.")
     out_dtype = np.dtype(out_dtype)
@@ -54,7 +55,7 @@ def _engine_stack(dem, names: list[str], out_dtype, engine: str, resolution: flo
             continue
         with ctx.option_scope("terrain_nonfinite", nonfinite):
             terrain.launch_terrain(ctx, src.ctypes.data, src.dtype, H, W, W, 0, 0, resolution, surface_fit, curv_method, group, tri_method,
-                                   window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor, False, out_dtype,
+                                   window_size, hillshade_altitude, hillshade_azimuth, hillshade_z_factor, 2, out_dtype,
                                    {a: stack[planes[a]].ctypes.data for a in group}, _lib.HOST, window_size)
     for i, a in enumerate(names):   # (a name asked for twice: the same plane twice, as upstream's index lists give)
         if planes[a] != i:

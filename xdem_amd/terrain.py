@@ -154,7 +154,8 @@ def launch_terrain(ctx: _lib.Context, dem_ptr: int, dem_dtype, H: int, W: int, r
                    hillshade_z_factor: float, degrees: bool, out_dtype, plane_ptrs: dict[str, int], memspace: int,
                    window_size_fractal: int = 13) -> None:
     """Thin marshalling of ``xdemhip_terrain`` (planes are passed in ascending attribute-bit order).  Fractal
-    roughness has its own window size and, like upstream (terrain.py:619-630), its own engine call."""
+    roughness has its own window size and, like upstream (terrain.py:619-630), its own engine call.  ``degrees`` is a bool, or the
+    library's integer form: bit 0 degrees, bit 1 hillshade without the clip (the engine-boundary call of ``xdem_amd.surfit``)."""
     frac = [a for a in attribute if a in list_requiring_windowed_fractal_index]
     if frac and len(frac) < len(set(attribute)):
         rest = [a for a in attribute if a not in list_requiring_windowed_fractal_index]
@@ -172,7 +173,7 @@ def launch_terrain(ctx: _lib.Context, dem_ptr: int, dem_dtype, H: int, W: int, r
     args = (ctx.handle, ctypes.c_void_p(dem_ptr), _lib.F32 if np.dtype(dem_dtype) == np.float32 else _lib.F64, H, W,
             row_stride, halo_top, halo_bottom, float(resolution), _FIT_ID[surface_fit.lower()],
             _CURV_ID[curv_method.lower()], mask, _TRI_ID[tri_method.lower()], int(window_size), float(hillshade_altitude),
-            float(hillshade_azimuth), float(hillshade_z_factor), int(bool(degrees)),
+            float(hillshade_azimuth), float(hillshade_z_factor), (int(degrees) & 3) if isinstance(degrees, int) and not isinstance(degrees, bool) else int(bool(degrees)),
             _lib.F32 if np.dtype(out_dtype) == np.float32 else _lib.F64, planes, memspace)
     with ctx.call_lock:   # (a launch reads the context's options: not while another thread has one changed for its own call)
         rc = ctx._L.xdemhip_terrain(*args)
