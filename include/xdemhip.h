@@ -458,6 +458,11 @@ int xdemhip_binstats_finalize(xdemhip_binstats* plan, int64_t* n_valid, double* 
 int xdemhip_binstats_run(xdemhip_binstats* plan, int n_dims, const int* var_ids, const double* edges, const int* n_edges,
                          const int* decimals, int sample_dtype, int want_nmad, double nfact, int64_t* counts,
                          double* medians, double* nmads);
+/* The flat bin number (C order over the dimensions of the LAST xdemhip_binstats_run) of each of the n samples, 0xFFFF for a sample
+ * the joint finiteness filter dropped or that lies in no bin: what a binding needs to evaluate a statistic the device does not know
+ * -- any Python callable nd_binning is given (xdem/spatialstats.py:143-157 hands it to scipy.stats.binned_statistic, which applies
+ * it to the values of every bin in sample order) -- on the host.  bins_out: host array of n uint16. */
+int xdemhip_binstats_bin_numbers(xdemhip_binstats* plan, uint16_t* bins_out);
 void xdemhip_binstats_destroy(xdemhip_binstats* plan);
 
 /* Global NMAD of an array, NaN-skipping: median = np.nanmedian(v), nmad = nfact * np.nanmedian(|v - median|) in the value

@@ -58,8 +58,50 @@ def range_errors():
     yield "three_pairs_one_var", v, [x], 4, [(0.0, 1.0), (0.0, 1.0), (0.0, 1.0)]
 
 
+def p90(a):
+    """A statistic SciPy has never heard of (and that fails on an empty bin: SciPy then fills NaN)."""
+    return np.percentile(a, 90)
+
+
+def spread(a):
+    return float(np.max(a) - np.min(a)) if len(a) else -1.0   # (answers the empty bin itself: SciPy fills -1)
+
+
+STAT_LIST = ["count", np.nanmedian, nmad, np.nanmean, np.nanstd, "mean", "std", np.sum, "min", np.max, "median", p90, spread]
+
+
+def stat_cases():
+    """`statistics` beyond the three the device evaluates: SciPy's names, NumPy function objects, plain callables."""
+    rng = np.random.default_rng(314)
+    n = 3000
+    a = rng.gamma(2.0, 8.0, n).astype(np.float32)
+    b = np.abs(rng.normal(0, 1.5, n))
+    c = rng.uniform(-3, 3, n).astype(np.float32)
+    v = (rng.normal(0, 1, n) * (0.5 + 0.05 * a)).astype(np.float32)
+    v[::89] = np.nan
+    a[3::101] = np.nan
+    yield "stats_f32_1var", v, [a], 7
+    yield "stats_f64_2var", v.astype(np.float64), [a, b], (5, 3)
+    yield "stats_f32_3var", v, [a, b, c], (4, 3, 2)
+
+
 def main(ref, out_dir: str) -> None:
     import json
+
+    srec = {}
+    for name, values, list_var, bins in stat_cases():
+        names = [f"v{i}" for i in range(len(list_var))]
+        df = ref.spatialstats.nd_binning(values, list_var, names, list_var_bins=bins, statistics=STAT_LIST)
+        srec[f"{name}|values"] = values
+        for i, v in enumerate(list_var):
+            srec[f"{name}|var{i}"] = v
+        srec[f"{name}|bins"] = np.array(bins)
+        srec[f"{name}|nd"] = df["nd"].values.astype(np.int64)
+        srec[f"{name}|columns"] = np.array(list(df.columns))
+        for f in STAT_LIST:
+            col = f if isinstance(f, str) else f.__name__
+            srec[f"{name}|{col}"] = df[col].values.astype(np.float64)
+    np.savez_compressed(os.path.join(out_dir, "binning_stats_golden.npz"), **srec)
 
     rrec, errs = {}, {}
     for name, values, list_var, bins, ranges in range_cases():

@@ -106,8 +106,8 @@ def test_nd_binning_argument_rules():
     from xdem_amd import spatialstats as ss
 
     v = np.arange(100, dtype=np.float32)
-    with pytest.raises(NotImplementedError, match="not available on the HIP engine"):
-        ss.nd_binning(v, [v], ["a"], statistics=[np.nanmean])
+    df = ss.nd_binning(v, [v], ["a"], list_var_bins=4, statistics=[np.nanmean])   # (a statistic of the host half: refused until round 6)
+    assert list(df.columns) == ["nd", "count", "nanmean", "a"] and df["nanmean"].tolist() == [12.0, 37.0, 62.0, 87.0]
     df = ss.nd_binning(v, [v], ["a"], list_var_bins=4, statistics=[np.nanmedian])  # count is added in front
     assert list(df.columns) == ["nd", "count", "nanmedian", "a"] and df["count"].tolist() == [25.0] * 4
     assert df["nanmedian"].tolist() == [12.0, 37.0, 62.0, 87.0]
@@ -342,3 +342,35 @@ def test_randomised_binnings_vs_oracle():
         got = df_to_cols(df, nv)
         for key, arr in got.items():
             assert np.array_equal(arr, np.asarray(ref[key], np.float64), equal_nan=True), (trial, key, n, nv, bins)
+
+
+@pytest.mark.parametrize("name", ["stats_f32_1var", "stats_f64_2var", "stats_f32_3var"])
+def test_nd_binning_with_any_statistic_equals_reference_dataframe(name):
+    """`statistics` beyond count / nanmedian / nmad (tests/golden/binning_stats_golden.npz: the reference's DataFrames for SciPy's
+    names, NumPy function objects and plain callables): the device produces the bin numbers, the host applies the statistic per
+    bin as scipy.stats.binned_statistic_dd does -- every column bit for bit, columns in upstream's order."""
+    def p90(a):
+        return np.percentile(a, 90)
+
+    def spread(a):
+        return float(np.max(a) - np.min(a)) if len(a) else -1.0
+
+    from xdem_amd import spatialstats as ss
+
+    z = np.load(os.path.join(GOLDEN, "binning_stats_golden.npz"))
+    values = z[f"{name}|values"]
+    list_var = [z[f"{name}|var{i}"] for i in range(int(name[-4]))]
+    bins = z[f"{name}|bins"]
+    bins = int(bins) if bins.ndim == 0 else tuple(int(b) for b in bins)
+    STAT_LIST = ["count", np.nanmedian, ss.nmad, np.nanmean, np.nanstd, "mean", "std", np.sum, "min", np.max, "median", p90, spread]   # (oracle/gen_golden_binning.py)
+    stats = STAT_LIST
+    names = [f"v{i}" for i in range(len(list_var))]
+    df = ss.nd_binning(values, list_var, names, list_var_bins=bins, statistics=stats)
+    assert list(df.columns) == [str(c) for c in z[f"{name}|columns"]]
+    assert np.array_equal(df["nd"].values.astype(np.int64), z[f"{name}|nd"])
+    for f in STAT_LIST:
+        col = f if isinstance(f, str) else f.__name__
+        got, ref = df[col].values.astype(np.float64), z[f"{name}|{col}"]
+        assert got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True), (name, col, np.flatnonzero(~np.isclose(got, ref, rtol=0, atol=0, equal_nan=True))[:5])
+    with pytest.raises(ValueError, match="invalid statistic 'mode'"):
+        ss.nd_binning(values, list_var, names, list_var_bins=bins, statistics=["count", "mode"])

@@ -795,3 +795,36 @@ def test_nextprod_fft_rule_of_the_texture_path():
                 while r % p == 0:
                     r //= p
             assert r == 1
+
+
+def test_host_half_of_binned_statistics_equals_scipy():
+    """xdem_amd/_binstat_host.binned_statistic_host -- what nd_binning / NuthKaab apply to bin numbers from the GPU for statistics the
+    device does not evaluate -- against scipy.stats.binned_statistic / _2d themselves: SciPy's names, the NumPy function objects it
+    answers itself, callables (one that fails on an empty bin, one that answers it), float32 and float64 values, bit for bit."""
+    import scipy.stats
+
+    from xdem_amd._binstat_host import binned_statistic_host as host
+
+    def p90(a):
+        return np.percentile(a, 90)
+
+    def spread(a):
+        return float(np.max(a) - np.min(a)) if len(a) else -1.0
+
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(0, 10, 6000).astype(np.float32), rng.uniform(-1, 1, 6000)
+    x[:300] = 9.99   # (a crowded bin; bins 3 and 4 of the 2-D grid stay empty below)
+    stats = ["count", "mean", "std", "sum", "min", "max", "median", np.mean, np.std, np.sum, np.min, np.max, np.median, np.nanmean, np.nanstd,
+             np.nanmedian, p90, spread, np.ptp]
+    for dt in (np.float32, np.float64):
+        v = rng.normal(size=x.size).astype(dt)
+        for st in stats:
+            r = scipy.stats.binned_statistic(x, v, statistic=st, bins=12)
+            b = np.minimum(r.binnumber - 1, 11)
+            assert np.array_equal(host(st, b, v, 12), r.statistic, equal_nan=True), (dt, st)
+            keep = (y < 0.2) | (x > 5)      # leaves bins of the 5 x 4 grid empty
+            r2 = scipy.stats.binned_statistic_2d(x[keep], y[keep], v[keep], statistic=st, bins=(5, 4), range=[(0, 10), (-1, 1)], expand_binnumbers=True)
+            b2 = (np.minimum(r2.binnumber[0] - 1, 4)) * 4 + np.minimum(r2.binnumber[1] - 1, 3)
+            assert np.array_equal(host(st, b2, v[keep], 20), r2.statistic.ravel(), equal_nan=True), (dt, st, "2d")
+    with pytest.raises(ValueError, match="invalid statistic 'mode'"):
+        host("mode", np.zeros(3, np.intp), np.ones(3), 2)

@@ -124,6 +124,7 @@ def lib() -> ctypes.CDLL:
                                             c_dp, c_i64p, c_dp]
         L.xdemhip_mean_filter_nan.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        L.xdemhip_binstats_bin_numbers.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.xdemhip_convolution.argtypes = [c_ctx, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_dp, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.xdemhip_perbin_lookup.argtypes = [c_ctx, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int64,

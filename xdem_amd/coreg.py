@@ -189,38 +189,11 @@ class NKPlan:
         ok = (bins != 0xFFFF) & np.isfinite(y)
         b, v = bins[ok], y[ok]
         counts = np.bincount(b, minlength=n_bins).astype(np.int64)
-        order = np.argsort(b, kind="stable")   # (stable: every bin keeps its values in raster order, as upstream's per-bin lists do)
-        starts = np.concatenate(([0], np.cumsum(counts)))
-        f = self._bin_callable
-        # SciPy answers the NumPy function OBJECTS np.sum / np.std / np.min / np.max itself (vectorised branches of
-        # binned_statistic_dd, float64 accumulation in element order) instead of calling them per bin: the same arithmetic here
-        # (np.mean / np.median never arrive: the GPU statistics answer them)
-        if any(f is g for g in (np.sum, np.std, np.min, np.max)):
-            stat = np.full(n_bins, 0.0 if f is np.sum else np.nan, dtype=np.float64)
-            nz = counts > 0
-            if f is np.sum:
-                stat[:] = np.bincount(b, weights=v, minlength=n_bins)
-            elif f is np.std:
-                flatsum = np.bincount(b, weights=v, minlength=n_bins)
-                delta = v - flatsum[b] / counts[b]
-                stat[nz] = np.sqrt(np.bincount(b, weights=delta * np.conj(delta), minlength=n_bins)[nz] / counts[nz])
-            else:
-                red = np.minimum if f is np.min else np.maximum
-                stat[nz] = red.reduceat(v[order], starts[:-1][nz])
-            return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
-                    "edges": edges, "counts": counts, "medians": stat}
-        v = v[order]
-        with np.errstate(invalid="ignore"), warnings.catch_warnings():
-            warnings.simplefilter("ignore", RuntimeWarning)
-            try:
-                null = f([])
-            except Exception:
-                null = np.nan
-        stat = np.full(n_bins, null, dtype=np.float64)
-        for k in np.flatnonzero(counts):
-            # (a fresh array per bin, as upstream builds one: NumPy's vectorised reductions peel to the buffer's alignment, so a slice
-            #  at an odd offset can sum in another order than the same values at the start of an allocation)
-            stat[k] = f(v[starts[k]:starts[k + 1]].copy())
+        # the callable per bin, SciPy's way (shared with nd_binning: xdem_amd/_binstat_host.py -- sample order within a bin, a fresh
+        # array per bin, statistic([]) for empty bins, SciPy's own vectorised answers for np.sum / np.std / np.min / np.max)
+        from ._binstat_host import binned_statistic_host
+
+        stat = binned_statistic_host(self._bin_callable, b, v, n_bins)
         return {"vshift": vshift.value, "n_valid": int(nv.value), "y_mean": ymean.value, "y_std": ystd.value,
                 "edges": edges, "counts": counts, "medians": stat}
 

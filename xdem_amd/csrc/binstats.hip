@@ -429,6 +429,16 @@ int xdemhip_binstats_run(xdemhip_binstats* P, int n_dims, const int* var_ids, co
     return rc;
 }
 
+int xdemhip_binstats_bin_numbers(xdemhip_binstats* P, uint16_t* bins_out) {
+    if (!P) return XDEMHIP_EINVAL;
+    xdemhip_ctx* ctx = P->ctx;
+    if (!P->finalized || !P->bins || !bins_out) return xd_fail(ctx, XDEMHIP_EINVAL, "xdemhip_binstats_bin_numbers: after xdemhip_binstats_run, with an output array");
+    XD_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    XD_HIP_CHECK(ctx, hipMemcpyAsync(bins_out, P->bins, (size_t)P->n * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+    XD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return XDEMHIP_OK;
+}
+
 }  // extern "C"
 
 template <typename T>

@@ -1108,6 +1108,16 @@ class BinStatsPlan:
                 int(want_nmad), float(nfact), counts.ctypes.data_as(lp), med.ctypes.data_as(dp), nm.ctypes.data_as(dp)))
         return counts.reshape(shape), med.reshape(shape), (nm.reshape(shape) if want_nmad else None), edges
 
+    def bin_numbers(self) -> np.ndarray:
+        """uint16 flat bin number (C order over the dimensions of the last ``run``) of every sample, 0xFFFF = dropped by the joint
+        finiteness filter or in no bin: for statistics evaluated on the host (``xdemhip_binstats_bin_numbers``)."""
+        out = np.empty(self.values.size, dtype=np.uint16)
+        if self.n_valid > 0:
+            self.ctx.check(self.ctx._L.xdemhip_binstats_bin_numbers(self.handle, out.ctypes.data))
+        else:
+            out[:] = 0xFFFF
+        return out
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             if getattr(self.ctx, "handle", None):
@@ -1128,8 +1138,11 @@ def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=
     Drop-in for ``xdem.spatialstats.nd_binning`` (xdem/spatialstats.py:91-216): same flattening, joint finite filter,
     1-D binnings per variable, all 2-D combinations, one N-D binning when there are more than two variables, and the
     same DataFrame layout (``nd``, statistic columns named after the callables, one ``pd.IntervalIndex`` column per
-    variable).  Statistics evaluated on the device: ``"count"``, ``np.nanmedian`` / ``"median"`` and ``nmad``; any other
-    callable raises ``NotImplementedError`` (this package has no CPU engine).  ``list_ranges`` goes to every binning exactly as
+    variable).  Statistics evaluated on the device: ``"count"``, ``np.nanmedian`` / ``"median"`` and ``nmad``.  Every other
+    statistic upstream would pass on to SciPy -- ``"mean"`` / ``"std"`` / ``"sum"`` / ``"min"`` / ``"max"``, the NumPy function
+    objects of those names, any callable of a 1-D array (``np.nanmean``, ``np.nanstd``, a lambda ...) -- is applied on the HOST to
+    the values of each bin, from the bin numbers the device computed (``xdemhip_binstats_bin_numbers``), exactly as
+    ``scipy.stats.binned_statistic_dd`` does (``xdem_amd/_binstat_host.py``): a Python callable cannot run anywhere else.  ``list_ranges`` goes to every binning exactly as
     upstream hands it to SciPy's ``range=`` (a (start, stop) pair or a one-element list of pairs for ONE variable; with several
     variables SciPy's own ValueError / TypeError comes out, as upstream).
     """
@@ -1145,11 +1158,17 @@ def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=
     if "count" not in statistics:
         statistics.insert(0, "count")
     statistics_name = [f if isinstance(f, str) else f.__name__ for f in statistics]
+    # "count", the exact median and the NMAD are evaluated on the device; anything else upstream would hand to SciPy -- its other
+    # names ("mean", "std", "sum", "min", "max"), the NumPy function objects it answers itself, any callable of a 1-D array -- is
+    # evaluated on the host from the bin numbers the device produced, the way scipy.stats.binned_statistic_dd does it
+    from ._binstat_host import KNOWN_NAMES, binned_statistic_host
+
     kinds = []
-    for name in statistics_name:
-        if name not in _GPU_STATS:
-            raise NotImplementedError(f"Statistic '{name}' is not available on the HIP engine (count, nanmedian, nmad are).")
-        kinds.append(_GPU_STATS[name])
+    for f, name in zip(statistics, statistics_name):
+        on_device = name in _GPU_STATS and (isinstance(f, str) or f is np.nanmedian or f is np.median or name == "nmad")
+        if not on_device and not callable(f) and f not in KNOWN_NAMES:
+            raise ValueError(f"invalid statistic {f!r}")   # (SciPy's refusal of an unknown name)
+        kinds.append(_GPU_STATS[name] if on_device else None)
     want_nmad = "nmad" in kinds
 
     plan = BinStatsPlan(np.asarray(values), [np.asarray(v) for v in list_var], ctx)
@@ -1158,9 +1177,16 @@ def nd_binning(values, list_var, list_var_names, list_var_bins=None, statistics=
             rng = None if list_ranges is None else _scipy_range(list_ranges, len(var_ids), one_d)
             c, m, s, edges = plan.run(var_ids, bins, want_nmad, ranges=rng)
             df = pd.DataFrame()
-            for name, kind in zip(statistics_name, kinds):
-                col = {"count": c.astype(float), "median": m, "nmad": s}[kind]
-                df[name] = col.flatten()
+            sample_bins = None
+            for f, name, kind in zip(statistics, statistics_name, kinds):
+                if kind is None:
+                    if sample_bins is None:
+                        sample_bins = plan.bin_numbers()
+                        kept = sample_bins != 0xFFFF
+                        sample_bins, sample_vals = sample_bins[kept], plan.values[kept]
+                    df[name] = binned_statistic_host(f, sample_bins, sample_vals, c.size)
+                else:
+                    df[name] = {"count": c.astype(float), "median": m, "nmad": s}[kind].flatten()
             return df, edges
 
         list_df_1d = []
