@@ -101,6 +101,23 @@ def main(ref, out_dir: str) -> None:
         for f in STAT_LIST:
             col = f if isinstance(f, str) else f.__name__
             srec[f"{name}|{col}"] = df[col].values.astype(np.float64)
+    # the heteroscedasticity pipeline under a spread statistic other than the NMAD (spatialstats.py:576-631 with spread_statistic=np.nanstd):
+    # binned table, interpolant, two-step standardization -- the error function on probe points and on the rasters
+    rng = np.random.default_rng(321)
+    shape = (90, 100)
+    slope = rng.gamma(2.0, 8.0, shape).astype(np.float32)
+    maxc = np.abs(rng.normal(0, 1.5, shape)).astype(np.float32)
+    dh = (rng.normal(0, 1, shape) * (0.5 + 0.05 * slope + 0.3 * maxc)).astype(np.float32)
+    dh[::11, ::7] = np.nan
+    df, fun = ref.spatialstats._estimate_model_heteroscedasticity(dvalues=dh.ravel(), list_var=[slope.ravel(), maxc.ravel()], list_var_names=["slope", "maxc"],
+                                                                  spread_statistic=np.nanstd, list_var_bins=(6, 5), min_count=20)
+    probe = (np.array([-5.0, 0.0, 3.3, 20.0, 55.5, 500.0, np.nan, 10.0]), np.array([0.1, -2.0, 1.7, 9.0, 0.5, 3.0, 1.0, np.nan]))
+    srec["hetstd|dh"], srec["hetstd|slope"], srec["hetstd|maxc"] = dh, slope, maxc
+    srec["hetstd|df_nanstd"] = df["nanstd"].values.astype(np.float64)
+    srec["hetstd|df_count"] = df["count"].values.astype(np.float64)
+    srec["hetstd|probe_x"], srec["hetstd|probe_y"] = probe
+    srec["hetstd|probe_out"] = np.asarray(fun(probe), np.float64)
+    srec["hetstd|error"] = np.asarray(fun((slope, maxc)), np.float64)
     np.savez_compressed(os.path.join(out_dir, "binning_stats_golden.npz"), **srec)
 
     rrec, errs = {}, {}

@@ -374,3 +374,20 @@ def test_nd_binning_with_any_statistic_equals_reference_dataframe(name):
         assert got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True), (name, col, np.flatnonzero(~np.isclose(got, ref, rtol=0, atol=0, equal_nan=True))[:5])
     with pytest.raises(ValueError, match="invalid statistic 'mode'"):
         ss.nd_binning(values, list_var, names, list_var_bins=bins, statistics=["count", "mode"])
+
+
+def test_heteroscedasticity_under_another_spread_statistic():
+    """`spread_statistic=np.nanstd` through the whole pipeline (xdem/spatialstats.py:576-631): binned table (host half on the device's
+    bin numbers) bit for bit, error function within 1e-12 relative of the reference's -- refused until the end of round 6."""
+    from xdem_amd import spatialstats as ss
+
+    z = np.load(os.path.join(GOLDEN, "binning_stats_golden.npz"))
+    dh, slope, maxc = z["hetstd|dh"], z["hetstd|slope"], z["hetstd|maxc"]
+    df, fun = ss._estimate_model_heteroscedasticity(dh.ravel(), [slope.ravel(), maxc.ravel()], ["slope", "maxc"], spread_statistic=np.nanstd,
+                                                    list_var_bins=(6, 5), min_count=20)
+    assert np.array_equal(df["count"].values, z["hetstd|df_count"])
+    assert np.array_equal(df["nanstd"].values, z["hetstd|df_nanstd"], equal_nan=True)
+    probe = (z["hetstd|probe_x"], z["hetstd|probe_y"])
+    assert np.allclose(fun(probe), z["hetstd|probe_out"], rtol=1e-12, atol=0, equal_nan=True)
+    err = fun((slope, maxc))
+    assert np.array_equal(np.isnan(err), np.isnan(z["hetstd|error"])) and np.allclose(err, z["hetstd|error"], rtol=1e-12, atol=0, equal_nan=True)

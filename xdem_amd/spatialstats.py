@@ -1486,18 +1486,17 @@ def interp_nd_binning(df, list_var_names, statistic="nmad", interpolate_method: 
 def two_step_standardization(dvalues, list_var, unscaled_error_fun, spread_statistic=nmad, fac_spread_outliers: float | None = 7,
                              ctx: _lib.Context | None = None):
     """Standardize ``dvalues`` by the modelled spread, filter outliers, re-scale to unit spread
-    (mirror of xdem/spatialstats.py:530-573).  Returns (z-scores, final error function).  The spread statistic must be
-    ``nmad`` (evaluated by exact selection on the GPU)."""
-    name = spread_statistic if isinstance(spread_statistic, str) else spread_statistic.__name__
-    if name != "nmad":
-        raise NotImplementedError("two_step_standardization on the HIP engine supports spread_statistic=nmad only.")
+    (mirror of xdem/spatialstats.py:530-573).  Returns (z-scores, final error function).  ``nmad`` -- the default -- is evaluated by
+    exact selection on the GPU; any other `spread_statistic` is called on the z-scores on the host, as upstream calls it."""
+    name = spread_statistic if isinstance(spread_statistic, str) else getattr(spread_statistic, "__name__", "")
+    on_device = name == "nmad"
     with np.errstate(all="ignore"):
         zscores = np.asarray(dvalues) / unscaled_error_fun(tuple(list_var))
-    limit = np.inf
+    spread = (lambda z: nmad_device(z, ctx=ctx)[1]) if on_device else spread_statistic
     if fac_spread_outliers is not None:
-        limit = fac_spread_outliers * nmad_device(zscores, ctx=ctx)[1]
-        zscores[np.abs(zscores) > limit] = np.nan
-    zscore_nmad = nmad_device(zscores, ctx=ctx)[1]
+        with np.errstate(invalid="ignore"):
+            zscores[np.abs(zscores) > fac_spread_outliers * spread(zscores)] = np.nan
+    zscore_nmad = spread(zscores)
     zscores /= zscore_nmad
     if isinstance(unscaled_error_fun, GridInterpolant):
         error_fun = unscaled_error_fun.scaled(zscore_nmad)
