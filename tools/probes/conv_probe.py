@@ -11,19 +11,22 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-import terrain_oracle as to
 from xdem_amd import _lib, spatialstats
 from xdem_amd.synth import fbm_torch
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ctx = _lib.default_context()
 dem = fbm_torch(n, n, "cuda", seed=1)[None].contiguous()
-ks = to.conv_kernels("florinsky")
-fl = np.stack([ks[k][0].astype(np.float64) / (ks[k][1][0] * 10.0 ** ks[k][1][1]) for k in ("zx", "zy", "zxx", "zyy", "zxy")])
+# the five Florinsky stencil tables over their dividers at res = 10 (the structure of fill_ref_weights, csrc/terrain_math.h)
+u5, c5 = np.array([-2, -1, 0, 1, 2]), np.array([2, -1, -2, -1, 2])
+al, be = np.array([44, 62, 68, 62, 44]), np.array([-31, 5, 17, 5, -31])
+a5, b5 = np.array([0, -1, 0, 1, 0]), np.array([-1, 0, 0, 0, 1])
+zx = np.outer(al, a5) + np.outer(be, b5)
+fl = np.stack([zx / 4200.0, -zx.T / 4200.0, np.tile(c5, (5, 1)) / 3500.0, np.tile(c5[:, None], (1, 5)) / 3500.0, -np.outer(u5, u5) / 10000.0]).astype(np.float64)
 rng = np.random.default_rng(0)
 for label, filt in (("5 Florinsky tables 5x5", fl), ("3 filters 3x3", rng.normal(size=(3, 3, 3))), ("1 filter 9x9", rng.normal(size=(1, 9, 9)))):
     for method in ("scipy", "numba"):
