@@ -38,12 +38,14 @@ constexpr int PB_U = 4;                                    // pixels per thread 
 // Every loop over the variables is unrolled over PB_MAXVAR with a guard, so that the per-variable fields of the argument block
 // are indexed statically (scalar registers) instead of living in scratch memory.  LDS: interval ends, statistics and decision
 // bytes of the bins are staged in (dynamic) shared memory -- [left | right | table | pass].
-template <bool DISJOINT, bool LDS>
+// NV: compile-time bound of the variable loops (1, 2, 3, 4 or 8 >= n_var): two variables keep 8 instead of 32 values per thread in
+// registers, i.e. more waves per SIMD to hide the dependent LDS reads of the searches behind
+template <bool DISJOINT, bool LDS, int NV>
 __global__ __launch_bounds__(256) void perbin_kernel(PbArgs a) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     int n_edges = 0;
 #pragma unroll
-    for (int k = 0; k < PB_MAXVAR; ++k)
+    for (int k = 0; k < NV; ++k)
         if (k < a.n_var) n_edges += a.n_int[k];
     double* s_left = reinterpret_cast<double*>(s_raw);
     double* s_right = s_left + n_edges;
@@ -71,10 +73,10 @@ __global__ __launch_bounds__(256) void perbin_kernel(PbArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * PB_U;
     unsigned long long miss = 0;
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * PB_U; i0 < a.n; i0 += stride) {
-        double v[PB_U][PB_MAXVAR];
+        double v[PB_U][NV];
         const bool whole = a.vec && i0 + PB_U <= a.n;
 #pragma unroll
-        for (int k = 0; k < PB_MAXVAR; ++k) {
+        for (int k = 0; k < NV; ++k) {
             if (k < a.n_var && whole) {
                 if (a.dt[k] == XDEMHIP_F32) {
                     const float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.var[k]) + i0);
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void perbin_kernel(PbArgs a) {
 #pragma unroll
             for (int u = 0; u < PB_U; ++u) { idx[u] = 0; in[u] = true; }
 #pragma unroll
-            for (int k = 0; k < PB_MAXVAR; ++k) {
+            for (int k = 0; k < NV; ++k) {
                 if (k < a.n_var) {
                     const int base = a.off[k], n = a.n_int[k];
                     int top = 1;
@@ -135,10 +137,10 @@ __global__ __launch_bounds__(256) void perbin_kernel(PbArgs a) {
 #pragma unroll
             for (int u = 0; u < PB_U; ++u) res[u] = (double)NAN;
             for (int64_t b = 0; b < a.n_bins; ++b) {   // itertools.product order: the last variable runs fastest
-                int jk[PB_MAXVAR];
+                int jk[NV];
                 int64_t r = b;
 #pragma unroll
-                for (int k = PB_MAXVAR - 1; k >= 0; --k) {
+                for (int k = NV - 1; k >= 0; --k) {
                     jk[k] = 0;
                     if (k < a.n_var) {
                         jk[k] = (int)(r % a.n_int[k]);
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void perbin_kernel(PbArgs a) {
                 for (int u = 0; u < PB_U; ++u) {
                     bool in = true;
 #pragma unroll
-                    for (int k = 0; k < PB_MAXVAR; ++k)
+                    for (int k = 0; k < NV; ++k)
                         if (k < a.n_var) in = in && v[u][k] >= lo_of(a.off[k] + jk[k]) && v[u][k] < hi_of(a.off[k] + jk[k]);
                     if (in) {
                         if (p == 1) res[u] = t;
@@ -256,10 +258,19 @@ extern "C" int xdemhip_perbin_lookup(xdemhip_ctx* ctx, const void* const* vars, 
     (void)hipEventRecord(ctx->ev_start, ctx->stream);
     const bool lds = n_edges <= PB_LDS_EDGES && n_bins <= PB_LDS_BINS;
     const size_t smem = lds ? (size_t)n_edges * 16 + (size_t)n_bins * 9 + 16 : 0;
-    if (disjoint && lds) hipLaunchKernelGGL((perbin_kernel<true, true>), dim3(blocks), dim3(256), smem, ctx->stream, a);
-    else if (disjoint) hipLaunchKernelGGL((perbin_kernel<true, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
-    else if (lds) hipLaunchKernelGGL((perbin_kernel<false, true>), dim3(blocks), dim3(256), smem, ctx->stream, a);
-    else hipLaunchKernelGGL((perbin_kernel<false, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);
+#define XD_PB_GO(NV)                                                                                                      \
+    do {                                                                                                                  \
+        if (disjoint && lds) hipLaunchKernelGGL((perbin_kernel<true, true, NV>), dim3(blocks), dim3(256), smem, ctx->stream, a);   \
+        else if (disjoint) hipLaunchKernelGGL((perbin_kernel<true, false, NV>), dim3(blocks), dim3(256), 0, ctx->stream, a);       \
+        else if (lds) hipLaunchKernelGGL((perbin_kernel<false, true, NV>), dim3(blocks), dim3(256), smem, ctx->stream, a);         \
+        else hipLaunchKernelGGL((perbin_kernel<false, false, NV>), dim3(blocks), dim3(256), 0, ctx->stream, a);                    \
+    } while (0)
+    if (n_var == 1) XD_PB_GO(1);
+    else if (n_var == 2) XD_PB_GO(2);
+    else if (n_var == 3) XD_PB_GO(3);
+    else if (n_var == 4) XD_PB_GO(4);
+    else XD_PB_GO(8);
+#undef XD_PB_GO
     (void)hipEventRecord(ctx->ev_stop, ctx->stream);
     ctx->timed = true;
     int rc = XDEMHIP_OK;
