@@ -18,7 +18,7 @@
 // for all filters.  HBM traffic: sizeof(T) read + 8 * n_M written per pixel.  Filters whose LDS patch would exceed 64 KiB
 // take the same loop on global memory (bounds tested per tap).
 // The sizes the reference itself uses (3 x 3 and 5 x 5 stencil tables, surfit.py:1107; 7 x 7) take convolve_window_kernel: a
-// thread owns 4 CONSECUTIVE rows of one column, reads the (4 + M1 - 1) x M2 window they share from LDS once -- 40 reads for
+// thread owns RP = 4 CONSECUTIVE rows of one column, reads the (RP + M1 - 1) x M2 window they share from LDS once -- 40 reads for
 // 5 x 5 instead of 100 per filter -- and keeps it in registers as float64 for all filters; the tap loops are unrolled, weights
 // and the per-filter bit mask of the taps that count (SciPy's footprint) are wave-uniform scalars.  Same sums in the same order.
 #include "common.h"
@@ -96,13 +96,13 @@ __global__ __launch_bounds__(256) void convolve_kernel(const T* __restrict__ img
 // Small filters of compile-time size: the window of a thread's 4 consecutive rows lives in registers.
 // w: (n_f, M1, M2) weights in TAP order (SciPy: the flipped kernel), zeros included; mask: per filter, bit a * M2 + b set = the tap
 // takes part in the sum
-template <typename T, int M1, int M2>
+template <typename T, int M1, int M2, int RP>
 __global__ __launch_bounds__(256) void convolve_window_kernel(const T* __restrict__ img, const double* __restrict__ w_all,
                                                               const unsigned long long* __restrict__ mask,
                                                               double* __restrict__ out, CvArgs a) {
-    constexpr int PW = CV_TX + M2 - 1, PH = CV_TY + M1 - 1, RP = 4;
+    constexpr int TY = 4 * RP, PW = CV_TX + M2 - 1, PH = TY + M1 - 1;   // RP consecutive rows per thread, 4 row groups per workgroup
     __shared__ T s[PH * PW];
-    const int64_t x0 = (int64_t)blockIdx.x * CV_TX, y0 = (int64_t)blockIdx.y * CV_TY;
+    const int64_t x0 = (int64_t)blockIdx.x * CV_TX, y0 = (int64_t)blockIdx.y * TY;
     const T nan_t = (T)NAN;
     for (int k = threadIdx.x; k < PW * PH; k += 256) {
         const int r = k / PW, c = k - r * PW;
@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void convolve_window_kernel(const T* __restric
     for (int f = 0; f < a.n_f; ++f) {
         const unsigned long long m = mask[f];
         const double* __restrict__ wf = w_all + (size_t)f * (M1 * M2);
-        double acc[RP] = {0.0, 0.0, 0.0, 0.0};
+        double acc[RP];
+#pragma unroll
+        for (int q = 0; q < RP; ++q) acc[q] = 0.0;
 #pragma unroll
         for (int r = 0; r < M1; ++r) {
             double wr[M2];   // one tap row of weights at a time: a single scalar load of M2 doubles, one wait
@@ -146,12 +148,19 @@ __global__ __launch_bounds__(256) void convolve_window_kernel(const T* __restric
     }
 }
 
+// rows per thread: 4 for all three sizes.  Two rows for 5 x 5 (78 instead of 104 registers: six waves per SIMD instead of four) were
+// measured SLOWER, 4.6 against 3.5 ms for the five Florinsky tables at 16384^2 -- the shared window shrinks from 8 to 6 rows but serves
+// half the pixels (15 instead of 10 LDS reads per pixel), and tile margin, weight loads and tap branches are paid per 8 rows instead of 16
+// (profiles/r06ao_conv_probe.txt)
+constexpr int cv_rows_per_thread(int) { return 4; }
+
 template <typename T>
-static bool launch_window(int M1, int M2, dim3 grid, hipStream_t st, const T* src, const double* w, const unsigned long long* mask,
+static bool launch_window(int M1, int M2, int64_t H, int64_t W, hipStream_t st, const T* src, const double* w, const unsigned long long* mask,
                           double* out, const CvArgs& a) {
-    if (M1 == 3 && M2 == 3) hipLaunchKernelGGL((convolve_window_kernel<T, 3, 3>), grid, dim3(256), 0, st, src, w, mask, out, a);
-    else if (M1 == 5 && M2 == 5) hipLaunchKernelGGL((convolve_window_kernel<T, 5, 5>), grid, dim3(256), 0, st, src, w, mask, out, a);
-    else if (M1 == 7 && M2 == 7) hipLaunchKernelGGL((convolve_window_kernel<T, 7, 7>), grid, dim3(256), 0, st, src, w, mask, out, a);
+    auto grid = [&](int rp) { return dim3((unsigned)((W + CV_TX - 1) / CV_TX), (unsigned)((H + 4 * rp - 1) / (4 * rp))); };
+    if (M1 == 3 && M2 == 3) hipLaunchKernelGGL((convolve_window_kernel<T, 3, 3, cv_rows_per_thread(3)>), grid(cv_rows_per_thread(3)), dim3(256), 0, st, src, w, mask, out, a);
+    else if (M1 == 5 && M2 == 5) hipLaunchKernelGGL((convolve_window_kernel<T, 5, 5, cv_rows_per_thread(5)>), grid(cv_rows_per_thread(5)), dim3(256), 0, st, src, w, mask, out, a);
+    else if (M1 == 7 && M2 == 7) hipLaunchKernelGGL((convolve_window_kernel<T, 7, 7, cv_rows_per_thread(7)>), grid(cv_rows_per_thread(7)), dim3(256), 0, st, src, w, mask, out, a);
     else return false;
     return true;
 }
@@ -254,8 +263,8 @@ extern "C" int xdemhip_convolution(xdemhip_ctx* ctx, const void* imgs, int dtype
         }
         double* o = memspace == XDEMHIP_HOST ? d_out : dst;
         if (windowed) {
-            if (dtype == XDEMHIP_F32) launch_window<float>(M1, M2, grid, ctx->stream, static_cast<const float*>(src), d_dense, d_mask, o, a);
-            else launch_window<double>(M1, M2, grid, ctx->stream, static_cast<const double*>(src), d_dense, d_mask, o, a);
+            if (dtype == XDEMHIP_F32) launch_window<float>(M1, M2, H, W, ctx->stream, static_cast<const float*>(src), d_dense, d_mask, o, a);
+            else launch_window<double>(M1, M2, H, W, ctx->stream, static_cast<const double*>(src), d_dense, d_mask, o, a);
         } else if (dtype == XDEMHIP_F32) {
             if (use_lds) hipLaunchKernelGGL((convolve_kernel<float, true>), grid, dim3(256), lds, ctx->stream, static_cast<const float*>(src), d_yx, d_w, d_start, o, a);
             else hipLaunchKernelGGL((convolve_kernel<float, false>), grid, dim3(256), 0, ctx->stream, static_cast<const float*>(src), d_yx, d_w, d_start, o, a);
