@@ -123,16 +123,20 @@ __global__ __launch_bounds__(256) void convolve_window_kernel(const T* __restric
         double acc[RP];
 #pragma unroll
         for (int q = 0; q < RP; ++q) acc[q] = 0.0;
+        // weights as wave-uniform scalars: a whole filter up front where it fits the scalar registers (<= 25 taps: one wait per filter),
+        // else one tap row at a time (one wait per row)
+        constexpr int WB = (M1 * M2 <= 25) ? M1 : 1;   // tap rows per batch of weights
 #pragma unroll
-        for (int r = 0; r < M1; ++r) {
-            double wr[M2];   // one tap row of weights at a time: a single scalar load of M2 doubles, one wait
+        for (int r0w = 0; r0w < M1; r0w += WB) {
+            double wr[WB * M2];
 #pragma unroll
-            for (int b = 0; b < M2; ++b) wr[b] = wf[r * M2 + b];
+            for (int t = 0; t < WB * M2; ++t) wr[t] = wf[r0w * M2 + t];
 #pragma unroll
-            for (int b = 0; b < M2; ++b) {
+            for (int t = 0; t < WB * M2; ++t) {
+                const int r = r0w + t / M2, b = t % M2;
                 if ((m >> (r * M2 + b)) & 1ull) {   // (wave-uniform)
 #pragma unroll
-                    for (int q = 0; q < RP; ++q) acc[q] = acc[q] + win[q + r][b] * wr[b];
+                    for (int q = 0; q < RP; ++q) acc[q] = acc[q] + win[q + r][b] * wr[t];
                 }
             }
         }
