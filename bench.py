@@ -899,14 +899,21 @@ def main() -> None:
         fresh = block is None
         if fresh:
             block = xdist.RowBlock(n, n, depth, rank, world, dev)
-        # resident planes from the library's allocator: one virtual range over 32 MiB physical pieces in pseudo-random order, so that
-        # the ~55 row streams of the kernel spread over the memory channels whatever the driver's free list looks like (DESIGN.md
-        # section 1; XDEM_BENCH_PLANES = torch | contiguous | chunked selects another backing for measurements)
-        out = terrain.alloc_planes(len(FULL), block.rows, n, torch.float32, ctx, dev,
-                                   backing=backing or os.environ.get("XDEM_BENCH_PLANES", "auto"))
         # each rank synthesises exactly its rows of the global raster (halo rows come from the neighbours)
         if fresh:
             block.interior.copy_(fbm_torch(block.rows, n, dev, seed=42, row0=block.r0, total_rows=n))
+        # resident planes from the library's allocator (XDEM_BENCH_PLANES = torch | scattered | contiguous | chunked
+        # forces one backing for measurements).  The default, "auto" WITH A PROBE: four candidate placements are tried in turn -- one
+        # virtual range over 32 MiB physical pieces in pseudo-random order, an ordinary allocation, and each once more --, this rank's
+        # own launch is timed on each (two untimed + three timed launches, no halo exchange: every rank decides alone, no rank waits
+        # for another) and the fastest is kept: which placement the memory controller likes better depends on the state of the
+        # box's free device memory and differs from allocation to allocation (terrain.alloc_planes).  All of it before the warm-up.
+        which = backing or os.environ.get("XDEM_BENCH_PLANES", "auto")
+        out = terrain.alloc_planes(len(FULL), block.rows, n, torch.float32, ctx, dev, backing=which,
+                                   probe=(lambda planes: terrain.terrain_attributes_device(block.buf, FULL, out=planes, halo_top=block.halo_top,
+                                                                                           halo_bottom=block.halo_bottom, **kw)) if which == "auto" else None)
+        chosen = {"backing": getattr(out, "_xdem_backing", which), "calibration_ms": getattr(out, "_xdem_calibration_ms", None),
+                  "calibration_s": getattr(out, "_xdem_calibration_s", None), "calibration_launches_per_candidate": getattr(out, "_xdem_calibration_launches", None)}
 
         def step():
             xdist.terrain_row_block(block, FULL, out=out, overlap=not args.no_overlap, **kw)
@@ -956,6 +963,7 @@ def main() -> None:
         if busy is not None and busy < 50.0:
             state["sysfs_note"] = (f"gpu_busy_percent read {busy} % while this GPU ran back-to-back launches: on this box the sysfs sensors do "
                                    "not follow this GPU's load (stale or another device's) -- power / sclk from sysfs are not evidence here")
+        state["planes"] = chosen
         return float(t.item()), block, out, step_ms, state
 
     n = args.size
@@ -991,9 +999,14 @@ def main() -> None:
         import gc
 
         gc.collect()
-        _, _, out, ms2, gpu_state2 = partitioned_run(n, args.steps, args.warmup, backing="torch", block=block)
+        # (the OTHER placement: the ordinary allocation when the calibration kept the scattered pieces, the scattered pieces when it kept
+        # the ordinary allocation -- every line shows both)
+        other = "scattered" if (gpu_state.get("planes") or {}).get("backing") == "torch" else "torch"
+        _, _, out, ms2, gpu_state2 = partitioned_run(n, args.steps, args.warmup, backing=other, block=block)
         k2 = sum(ms2) / len(ms2)
-        ab = {"planes": "torch.empty (ordinary hipMalloc: what a caller of the C-ABI brings)", "kernel_ms": round(k2, 4),
+        ab = {"planes": "torch.empty (ordinary hipMalloc: what a caller of the C-ABI brings)" if other == "torch" else
+                        "the library's scattered 32 MiB-piece backing (the calibration of this run kept the ordinary allocation)",
+              "backing": other, "kernel_ms": round(k2, 4),
               "kernel_ms_min": round(min(ms2), 4), "kernel_ms_max": round(max(ms2), 4),
               "achieved": round(BYTES_PER_PIXEL * block.rows * n / (k2 * 1e-3) / 1e9, 1),
               "frac": round(BYTES_PER_PIXEL * block.rows * n / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -1035,7 +1048,7 @@ def main() -> None:
             "dtype": "f32 in/out, mixed f64/f32 arithmetic (f64 where cancellation demands: stencil sums, curvature numerators, discriminants)",
             "data": "synthetic",
             "config": {"workload": f"{n}x{n} float32 fBm DEM (H=0.7, 1000+-300 m, res 10 m), Florinsky fit, geometric "
-                                   f"curvatures, 11 attributes, device-resident in/out (planes: the library's scattered 32 MiB-piece backing)",
+                                   f"curvatures, 11 attributes, device-resident in/out (planes: " + ({"scattered": "the library's scattered 32 MiB-piece backing", "torch": "an ordinary allocation"}.get((gpu_state.get("planes") or {}).get("backing"), str((gpu_state.get("planes") or {}).get("backing"))) + (", kept by the allocator's calibration of both placements before the warm-up" if (gpu_state.get("planes") or {}).get("calibration_ms") else "")) + ")",
                        # what a step exchanges: `depth` rows of 4-byte pixels with each neighbour, sent and received (interior ranks: 2 neighbours)
                        "halo_bytes_per_step_and_rank": 0 if world == 1 else int(2 * min(2, world - 1) * depth * n * 4),
                        "partition": f"{world} row block(s), halo depth {depth}" +
@@ -1064,10 +1077,16 @@ def main() -> None:
                          "power_W": (lambda c: None if not c else c["mean"])(None if (gpu_state or {}).get("sysfs_note") else (gpu_state or {}).get("power_W")),
                          "gpu_state_during_timed_steps": gpu_state},
         }
+        res["roofline"]["planes"] = gpu_state.get("planes")   # which placement the timed planes have, and the calibration that chose it
         if ab is not None:
-            res["roofline"]["frac_caller_planes"] = ab["frac"]
-            res["roofline"]["kernel_ms_caller_planes"] = ab["kernel_ms"]
-            res["roofline"]["caller_planes"] = ab
+            # frac_caller_planes = the ORDINARY allocation (what a caller of the C-ABI brings), frac_scattered_planes = the library's pieces:
+            # one of the two is the headline's own `frac`, the other the A/B leg's
+            main_is_torch = (gpu_state.get("planes") or {}).get("backing") == "torch"
+            res["roofline"]["frac_caller_planes"] = round(achieved / HBM_PEAK_GBPS, 4) if main_is_torch else ab["frac"]
+            res["roofline"]["kernel_ms_caller_planes"] = round(kernel_ms, 4) if main_is_torch else ab["kernel_ms"]
+            res["roofline"]["frac_scattered_planes"] = ab["frac"] if main_is_torch else round(achieved / HBM_PEAK_GBPS, 4)
+            res["roofline"]["kernel_ms_scattered_planes"] = ab["kernel_ms"] if main_is_torch else round(kernel_ms, 4)
+            res["roofline"]["other_planes"] = ab
         res["config"]["rccl_ranks"] = world if world == 1 else dist.get_world_size()
         res["config"]["visible_gpus"] = torch.cuda.device_count()
         res["device_state"] = device_state()

@@ -1019,3 +1019,35 @@ def test_c4_size_on_one_gpu_crops_equal_full():
     assert bool(torch.isnan(out[0, 50001, 60005])) and bool(torch.isfinite(out[0, 40000, 61000]))
     del out, dem
     torch.cuda.empty_cache()
+
+
+def test_alloc_planes_with_a_probe_keeps_one_of_the_candidates(terrain):
+    """terrain.alloc_planes(backing="auto", probe=...): the candidates (scattered, ordinary, each twice) are probed with the caller's own
+    launch and the fastest is returned -- whichever it is, the planes it holds after a launch are the ordinary call's bit for bit, the
+    calibration log names every candidate, and without a probe nothing is calibrated."""
+    import torch
+
+    from xdem_amd import _lib
+
+    ctx = _lib.default_context()
+    n = 4608
+    attrs = ["slope", "aspect", "hillshade", "max_curvature"]
+    dem = torch.from_numpy((1000 + np.cumsum(np.cumsum(np.random.default_rng(3).normal(scale=0.2, size=(n, n)), 0), 1)).astype(np.float32)).cuda()
+    calls = []
+
+    def probe(planes):
+        calls.append(planes.data_ptr())
+        terrain.terrain_attributes_device(dem, attrs, out=planes, resolution=10.0)
+
+    planes = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx, backing="auto", probe=probe)
+    log = planes._xdem_calibration_ms
+    assert planes._xdem_backing in ("scattered", "torch") and [k for k, _ in log] == ["scattered", "torch", "scattered", "torch"]
+    assert len(calls) == 5 * len(log) and planes.data_ptr() in calls and all(ms > 0 for _, ms in log)
+    kept = [ms for k, ms in log if k == planes._xdem_backing]
+    assert min(kept) <= 1.0101 * min(ms for _, ms in log)          # the fastest candidate, up to the 1 % that favours the incumbent
+    terrain.terrain_attributes_device(dem, attrs, out=planes, resolution=10.0)
+    want = terrain.terrain_attributes_device(dem, attrs, resolution=10.0)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(planes, nan=-1e30), torch.nan_to_num(want, nan=-1e30))
+    plain = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx, backing="auto")
+    assert not hasattr(plain, "_xdem_calibration_ms")

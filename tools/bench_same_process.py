@@ -36,15 +36,27 @@ rows.sort()
 strips = [(s, e) for s, e, k, _ in rows if k == "strip"]
 tiles = [(s, e) for s, e, k, _ in rows if k == "tile"]
 names = sorted({n[:140] for _, _, _, n in rows})
-ab = "caller_planes" in line["roofline"]
-# (bench.py checks a 64-row crop of the timed planes with one more small launch right behind the scattered group: one strip + one tile dispatch)
-spot = [("spot_check", 1)] if line["roofline"].get("output_spot_check") else []
-groups = [("scattered_warmup", W), ("scattered_timed", K)] + spot + ([("torch_warmup", W), ("torch_timed", K)] if ab else [])
+roof = line["roofline"]
+ab = "caller_planes" in roof or "other_planes" in roof
+# lines since the allocator's calibration (round 6, last session): 3 probe launches on each placement come first, and the timed planes are
+# whichever placement the calibration kept -- the group names say which
+planes = roof.get("planes") or {}
+main = planes.get("backing") or "scattered"
+other = "scattered" if main == "torch" else "torch"
+cal = planes.get("calibration_ms")
+per = int(planes.get("calibration_launches_per_candidate") or 3)
+calib = ([(f"calibration_{i}_{k}", per) for i, (k, _) in enumerate(cal)] if isinstance(cal, list) else
+         [("calibration_scattered", 3), ("calibration_torch", 3)]) if cal else []
+# (bench.py checks a 64-row crop of the timed planes with one more small launch right behind the first timed group: one strip + one tile dispatch)
+spot = [("spot_check", 1)] if roof.get("output_spot_check") else []
+groups = calib + [(main + "_warmup", W), (main + "_timed", K)] + spot + ([(other + "_warmup", W), (other + "_timed", K)] if ab else [])
 assert len(strips) == len(tiles) == sum(n for _, n in groups), (len(strips), len(tiles), groups)
 out = {"bench_line": {"steps": K, "warmup": W, "ms_per_step": line["ms_per_step"], "kernel_ms": line["roofline"]["kernel_ms"],
                       "kernel_ms_min": line["roofline"]["kernel_ms_min"], "kernel_ms_max": line["roofline"]["kernel_ms_max"],
-                      "frac": line["roofline"]["frac"], "kernel_ms_caller_planes": line["roofline"].get("kernel_ms_caller_planes"),
-                      "frac_caller_planes": line["roofline"].get("frac_caller_planes")},
+                      "frac": line["roofline"]["frac"], "planes": planes or {"backing": "scattered"},
+                      "kernel_ms_other_planes": (roof.get("other_planes") or roof.get("caller_planes") or {}).get("kernel_ms"),
+                      "kernel_ms_caller_planes": line["roofline"].get("kernel_ms_caller_planes"),
+                      "frac_caller_planes": line["roofline"].get("frac_caller_planes"), "frac_scattered_planes": roof.get("frac_scattered_planes")},
        "kernels": names, "groups": {}}
 i = 0
 for gname, n in groups:
@@ -59,7 +71,7 @@ for gname, n in groups:
     i += n
 px = line["roofline"]["pixels_per_launch"]
 cmp_ = {}
-for gname, key in (("scattered_timed", "kernel_ms"), ("torch_timed", "kernel_ms_caller_planes")):
+for gname, key in ((main + "_timed", "kernel_ms"), (other + "_timed", "kernel_ms_other_planes")):
     if gname in out["groups"] and out["bench_line"].get(key):
         g = out["groups"][gname]
         ksum = g["strip_mean_ms"] + g["tile_mean_ms"]
