@@ -903,8 +903,9 @@ def main() -> None:
         if fresh:
             block.interior.copy_(fbm_torch(block.rows, n, dev, seed=42, row0=block.r0, total_rows=n))
         # resident planes from the library's allocator (XDEM_BENCH_PLANES = torch | scattered | contiguous | chunked
-        # forces one backing for measurements).  The default, "auto" WITH A PROBE: four candidate placements are tried in turn -- one
-        # virtual range over 32 MiB physical pieces in pseudo-random order, an ordinary allocation, and each once more --, this rank's
+        # forces one backing for measurements).  The default, "auto" WITH A PROBE: three to eight candidate placements are tried in turn --
+        # one virtual range over 32 MiB physical pieces in pseudo-random order, an ordinary allocation, and again, until a second
+        # candidate has come within 3 % of the fastest --, this rank's
         # own launch is timed on each (two untimed + three timed launches, no halo exchange: every rank decides alone, no rank waits
         # for another) and the fastest is kept: which placement the memory controller likes better depends on the state of the
         # box's free device memory and differs from allocation to allocation (terrain.alloc_planes).  All of it before the warm-up.

@@ -1022,7 +1022,7 @@ def test_c4_size_on_one_gpu_crops_equal_full():
 
 
 def test_alloc_planes_with_a_probe_keeps_one_of_the_candidates(terrain):
-    """terrain.alloc_planes(backing="auto", probe=...): the candidates (scattered, ordinary, each twice) are probed with the caller's own
+    """terrain.alloc_planes(backing="auto", probe=...): the candidates (scattered, ordinary, in turn: three to eight) are probed with the caller's own
     launch and the fastest is returned -- whichever it is, the planes it holds after a launch are the ordinary call's bit for bit, the
     calibration log names every candidate, and without a probe nothing is calibrated."""
     import torch
@@ -1041,8 +1041,10 @@ def test_alloc_planes_with_a_probe_keeps_one_of_the_candidates(terrain):
 
     planes = terrain.alloc_planes(len(attrs), n, n, torch.float32, ctx, backing="auto", probe=probe)
     log = planes._xdem_calibration_ms
-    assert planes._xdem_backing in ("scattered", "torch") and [k for k, _ in log] == ["scattered", "torch", "scattered", "torch"]
+    assert planes._xdem_backing in ("scattered", "torch") and 3 <= len(log) <= 8 and [k for k, _ in log] == (["scattered", "torch"] * 4)[:len(log)]
     assert len(calls) == 5 * len(log) and planes.data_ptr() in calls and all(ms > 0 for _, ms in log)
+    ordered = sorted(ms for _, ms in log)
+    assert len(log) == 8 or ordered[1] <= 1.03 * ordered[0]          # stopped because a second candidate confirmed the fastest, or ran out
     kept = [ms for k, ms in log if k == planes._xdem_backing]
     assert min(kept) <= 1.0101 * min(ms for _, ms in log)          # the fastest candidate, up to the 1 % that favours the incumbent
     terrain.terrain_attributes_device(dem, attrs, out=planes, resolution=10.0)
